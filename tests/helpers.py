@@ -1,0 +1,43 @@
+"""Shared helpers for the parity tests (test infrastructure; may import oracle/)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle.dsact_oracle import DsactOracle, default_config
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+STEP_CASES = ["tiny_l3", "tiny_l2", "pendulum", "fixed_alpha"]
+
+
+def load_step_case(name):
+    z = np.load(os.path.join(GOLDEN, "step_%s.npz" % name))
+    O, A = int(z["cfg_obs_dim"]), int(z["cfg_act_dim"])
+    cfg = default_config(
+        O, A, hidden=[int(h) for h in z["cfg_hidden"]], act_limit=float(z["cfg_act_limit"]),
+        auto_alpha=bool(int(z["cfg_auto_alpha"])), alpha=float(z["cfg_alpha"]),
+        delay_update=int(z["cfg_delay_update"]))
+    init = {k[len("init/"):]: torch.as_tensor(z[k]) for k in z.files if k.startswith("init/")}
+    return z, cfg, init
+
+
+def step_inputs(z, it):
+    data = {k: torch.as_tensor(z["s%d/%s" % (it, k)]) for k in ("obs", "obs2", "act", "rew", "done", "logp")}
+    noise = {k: torch.as_tensor(z["s%d/%s" % (it, k)]) for k in ("eps_new", "eps_2", "z5", "z6")}
+    return data, noise
+
+
+def synth_batch(rng, B, O, A, lim=0.4, p_done=0.01):
+    return {
+        "obs": torch.as_tensor(rng.standard_normal((B, O), dtype=np.float32)),
+        "obs2": torch.as_tensor(rng.standard_normal((B, O), dtype=np.float32)),
+        "act": torch.as_tensor(rng.uniform(-lim, lim, (B, A)).astype(np.float32)),
+        "rew": torch.as_tensor(rng.standard_normal(B, dtype=np.float32)),
+        "done": torch.as_tensor((rng.random(B) < p_done).astype(np.float32)),
+        "logp": torch.zeros(B),
+    }
+
+
+def make_oracle(cfg, init=None, seed=0):
+    torch.manual_seed(seed)
+    return DsactOracle(cfg, state_dict=init)

@@ -1,0 +1,72 @@
+"""The oracle restatement vs the golden vectors generated from the unmodified reference
+(oracle/make_golden.py). Runs anywhere (no GPU, no /root/reference needed)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.dsact_oracle import TB_KEYS, DsactOracle, MT19937, ReplayOracle, randint_legacy
+from helpers import GOLDEN, STEP_CASES, load_step_case, step_inputs
+
+
+@pytest.mark.parametrize("name", STEP_CASES)
+def test_step_matches_reference_golden(name):
+    torch.set_num_threads(1)
+    z, cfg, init = load_step_case(name)
+    orc = DsactOracle(cfg, state_dict=init)
+    for it in range(int(z["cfg_steps"])):
+        data, noise = step_inputs(z, it)
+        tb = orc.local_update(data, noise, it)
+        got = np.array([float(tb[k]) for k in TB_KEYS[:-1]])
+        # same torch build => bit-exact; a different torch build may differ in the last ulp
+        np.testing.assert_allclose(got, z["s%d/tb" % it], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(orc.flat_grads().numpy(), z["s%d/grad" % it], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(orc.flat_params().numpy(), z["s%d/params" % it], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(orc.flat_targets().numpy(), z["s%d/targets" % it], rtol=0, atol=2e-6)
+
+
+def test_state_dict_layout_matches_reference():
+    lay = json.load(open(os.path.join(GOLDEN, "checkpoint_layout.json")))
+    from oracle.dsact_oracle import default_config
+    orc = DsactOracle(default_config(376, 17, (256, 256, 256)))
+    got = [[k, list(v.shape)] for k, v in orc.state_dict().items()]
+    assert got == lay["humanoid_l3"]
+    orc = DsactOracle(default_config(3, 1, (256, 256, 256), act_limit=2.0))
+    got = [[k, list(v.shape)] for k, v in orc.state_dict().items()]
+    assert got == lay["pendulum_shipped"]
+    # the shipped apprfunc_0.pkl was saved after the iteration-0 update: log_alpha = 1 - lr_alpha
+    assert abs(lay["pendulum_shipped_log_alpha_it0"] - (1.0 - 3e-4)) < 1e-6
+
+
+def test_replay_ring_and_gather_match_reference_golden():
+    z = np.load(os.path.join(GOLDEN, "replay.npz"))
+    O, A, N = [int(v) for v in z["cfg"]]
+    buf = ReplayOracle(O, A, N)
+    samples = []
+    for i in range(73):
+        r, d, l = z["in/rdl%d" % i]
+        samples.append((z["in/obs%d" % i], {}, z["in/act%d" % i], float(r), z["in/obs2_%d" % i], bool(d),
+                        np.float32(l), {}))
+    buf.add_batch(samples[:30])
+    assert (buf.size, buf.ptr) == (int(z["size_30"]), int(z["ptr_30"]))
+    np.random.seed(11)
+    b = buf.sample_batch(16)
+    for k, v in b.items():
+        np.testing.assert_array_equal(v.numpy(), z["b30/" + k])
+    buf.add_batch(samples[30:])
+    assert (buf.size, buf.ptr) == (int(z["size_73"]), int(z["ptr_73"]))
+    b = buf.sample_batch(16)
+    for k, v in b.items():
+        np.testing.assert_array_equal(v.numpy(), z["b73/" + k])
+
+
+@pytest.mark.parametrize("n", [1, 2, 10000, 12345, 2 ** 20, 2 ** 20 + 1, 10 ** 6, 10 ** 7])
+def test_index_draw_restatement_bit_exact(n):
+    z = np.load(os.path.join(GOLDEN, "replay.npz"))
+    want = z["idx/%d" % n]
+    got = randint_legacy(MT19937(1), n, 700)
+    np.testing.assert_array_equal(got, want)
+    np.random.seed(1)
+    np.testing.assert_array_equal(np.random.randint(0, n, size=700), want)

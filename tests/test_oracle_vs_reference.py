@@ -1,0 +1,43 @@
+"""Pins oracle/dsact_oracle.py against the LIVE unmodified reference (only where /root/reference
+is mounted, i.e. in the build container; skipped on the GPU box)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_loader
+from oracle.dsact_oracle import TB_KEYS, DsactOracle, default_config, draw_noise
+from helpers import synth_batch
+
+pytestmark = pytest.mark.skipif(not ref_loader.reference_available(), reason="reference not mounted")
+
+
+@pytest.mark.parametrize("O,A,hid,B", [(376, 17, (256, 256, 256), 256), (376, 17, (256, 256), 128), (3, 1, (64, 64, 64), 64)])
+def test_bit_exact_vs_live_reference(O, A, hid, B):
+    torch.set_num_threads(2)
+    ref = ref_loader.import_reference()
+    kw = ref_loader.reference_kwargs(O, A, hid)
+    torch.manual_seed(0)
+    alg = ref.DSAC_V2(**kw)
+    cfg = default_config(O, A, hid)
+    torch.manual_seed(0)
+    same_seed = DsactOracle(cfg)  # same construction order => same init from the same seed
+    sd = alg.networks.state_dict()
+    osd = same_seed.state_dict()
+    assert list(sd.keys()) == list(osd.keys())
+    assert all(torch.equal(sd[k], osd[k]) for k in sd)
+    orc = DsactOracle(cfg, state_dict=sd)
+    rng = np.random.default_rng(0)
+    for it in range(4):
+        d = synth_batch(rng, B, O, A)
+        torch.manual_seed(1000 + it)
+        tb_ref = alg.local_update({k: v.clone() for k, v in d.items()}, it)
+        torch.manual_seed(1000 + it)
+        tb = orc.local_update(d, draw_noise(B, A), it)
+        for k in TB_KEYS[:-1]:
+            assert float(tb_ref[k]) == float(tb[k]), k
+        nets = alg.networks
+        gref = torch.cat([p.grad.reshape(-1) for n in ("q1", "q2", "policy") for p in getattr(nets, n).parameters()]
+                         + [nets.log_alpha.grad.reshape(1)])
+        assert torch.equal(gref, orc.flat_grads())
+        sd, osd = nets.state_dict(), orc.state_dict()
+        assert all(torch.equal(sd[k], osd[k]) for k in sd)
