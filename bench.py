@@ -1,0 +1,273 @@
+#!/usr/bin/env python
+"""bench.py -- DSAC-T gradient steps/sec on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one DSAC_V2.local_update (reference dsac_v2.py:102-105) INCLUDING the replay gather
+(training/replay_buffer.py:85-90): k_gather -> forward/backward of the six nets -> fused Adam/Polyak,
+on synthetic Humanoid-shaped data (obs 376 / act 17, batch 256 per GPU, 1M-row replay ring resident in
+HBM, random-init nets of the reference architecture). Nothing is skipped inside the timed region:
+every step gathers a fresh minibatch, draws fresh noise (device Philox), computes all three losses and
+their gradients, runs Adam for q1/q2 (policy/alpha/Polyak every `delay_update`-th step as the
+reference does).
+
+Prints ONE JSON line (rank 0). Extra objects: `roofline` (FP32-compute bound of the whole step, the
+binding roofline per SURVEY.md section 8d), `roofline_hbm` (the HBM view north_star asks for),
+`kernels` (per-launch hipEvent times of one eager step), `cpu_baseline` (the oracle port on the host
+cores, bounded sample), `alt` (the other hidden-layer setting of SURVEY.md D1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "dsac-v2_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+FP32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md (vector == f32 MFMA)
+HBM_PEAK_GBS = 8000.0     # spec; 6290 measured float4 copy
+
+O, A, B = 376, 17, 256
+N_REPLAY = 1_000_000
+IDX_ROWS = 2048
+
+
+def env_int(k, d):
+    return int(os.environ.get(k, d))
+
+
+def make_alg(hidden, device, seed=0, batch=B):
+    import numpy as np
+    import torch
+    from dsac_v2_hip import DSAC_V2_HIP
+
+    torch.manual_seed(seed)
+    kw = dict(
+        algorithm="DSAC_V2_HIP", obsv_dim=O, action_dim=A, action_type="continu",
+        value_func_type="MLP", policy_func_type="MLP", value_hidden_sizes=list(hidden),
+        policy_hidden_sizes=list(hidden), value_hidden_activation="gelu", policy_hidden_activation="gelu",
+        value_output_activation="linear", policy_output_activation="linear",
+        policy_act_distribution="TanhGaussDistribution", policy_min_log_std=-20, policy_max_log_std=0.5,
+        value_learning_rate=1e-4, policy_learning_rate=1e-4, alpha_learning_rate=3e-4,
+        gamma=0.99, tau=0.005, auto_alpha=True, alpha=0.2, delay_update=2, cnn_shared=False,
+        replay_batch_size=batch, seed=seed + 1, hip_device=device,
+        action_high_limit=np.full((A,), 0.4, np.float32), action_low_limit=np.full((A,), -0.4, np.float32),
+    )
+    return DSAC_V2_HIP(**kw)
+
+
+def fill_replay(engine, n_rows, seed):
+    """synthetic ring per SURVEY.md 8(d): obs,obs2 ~ N(0,1); act ~ U(-.4,.4); rew ~ N(0,1); done ~ Bern(.01);
+    generated on the device in chunks (3.09 GB at 1M rows never crosses PCIe)."""
+    import torch
+
+    engine.buffer_create(n_rows)
+    g = torch.Generator(device=engine.device).manual_seed(seed)
+    chunk = 131072
+    for r0 in range(0, n_rows, chunk):
+        n = min(chunk, n_rows - r0)
+        obs = torch.randn(n, O, device=engine.device, generator=g)
+        obs2 = torch.randn(n, O, device=engine.device, generator=g)
+        act = torch.rand(n, A, device=engine.device, generator=g) * 0.8 - 0.4
+        rew = torch.randn(n, device=engine.device, generator=g)
+        done = (torch.rand(n, device=engine.device, generator=g) < 0.01).float()
+        engine.buffer_fill_device(r0, obs, act, rew, obs2, done)
+
+
+def upload_indices(engine, n_rows, rows, seed):
+    import numpy as np
+
+    np.random.seed(seed)  # legacy global RandomState, as the reference buffer uses (replay_buffer.py:86)
+    engine.upload_index_table(np.random.randint(0, n_rows, size=(rows, engine.batch)))
+
+
+def cpu_baseline(hidden, budget_s=12.0):
+    """The oracle port (oracle/dsact_oracle.py == reference arithmetic, pinned bit-exact against the live
+    reference in tests/test_oracle_vs_reference.py) timed on the host cores: sample_batch + local_update,
+    4 torch threads like the reference (utils/init_args.py:14)."""
+    import numpy as np
+    import torch
+    from oracle.dsact_oracle import DsactOracle, ReplayOracle, default_config, draw_noise
+
+    threads = 4
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    orc = DsactOracle(default_config(O, A, hidden))
+    n = 100_000
+    buf = ReplayOracle(O, A, n)
+    rng = np.random.default_rng(0)
+    buf.buf["obs"][:] = rng.standard_normal((n, O), dtype=np.float32)
+    buf.buf["obs2"][:] = rng.standard_normal((n, O), dtype=np.float32)
+    buf.buf["act"][:] = rng.uniform(-0.4, 0.4, (n, A)).astype(np.float32)
+    buf.buf["rew"][:] = rng.standard_normal(n, dtype=np.float32)
+    buf.buf["done"][:] = (rng.random(n) < 0.01).astype(np.float32)
+    buf.size = n
+    np.random.seed(1)
+    it = 0
+    for _ in range(10):
+        orc.local_update(buf.sample_batch(B), draw_noise(B, A), it)
+        it += 1
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < budget_s:
+        orc.local_update(buf.sample_batch(B), draw_noise(B, A), it)
+        it += 1
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": "%d updates (batch 256, hidden %s, 100k-row host ring) in %.1f s, torch %s CPU, %d of %d host cores"
+                      % (steps, "x".join(map(str, hidden)), dt, torch.__version__, threads, os.cpu_count())}
+
+
+def measure(alg, steps, warmup, world=1, dp=None):
+    """returns (wall seconds for `steps` steps, hipEvent ms for the same region or None)"""
+    import torch
+
+    e = alg.engine
+    if dp is None:
+        e.graph_build(2)
+        e.graph_run(0, warmup)
+        e.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ms = e.time_steps(warmup, steps, use_graph=True)  # hipEvents on the engine's stream + host sync
+        wall = time.perf_counter() - t0
+        return wall, ms
+    import torch.distributed as dist
+
+    e.dp_begin(0)
+    for _ in range(warmup):
+        dp.step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        dp.step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    wall = time.perf_counter() - t0
+    return wall, None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--hidden", type=str, default="256,256,256",
+                    help="reference default (example_train/*.py); BASELINE.json words it as 256,256 -> reported in `alt`")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true")
+    ap.add_argument("--replay-rows", type=int, default=N_REPLAY)
+    args = ap.parse_args()
+    steps = args.steps + (args.steps & 1)
+    warmup = args.warmup + (args.warmup & 1)
+
+    import __graft_entry__ as entry
+    rank, world, local = env_int("RANK", 0), env_int("WORLD_SIZE", 1), env_int("LOCAL_RANK", 0)
+    if rank == 0:
+        entry.build()
+    import torch
+
+    dp = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.barrier()
+        if rank != 0:
+            entry.build()
+    hidden = [int(x) for x in args.hidden.split(",")]
+    alg = make_alg(hidden, local, seed=0)
+    e = alg.engine
+    fill_replay(e, args.replay_rows, seed=100 + rank)  # every rank owns its own replay shard
+    upload_indices(e, args.replay_rows, IDX_ROWS, seed=1 + rank)
+    if world > 1:
+        from dsact.dp import DataParallelUpdater
+
+        e.use_torch_stream()
+        dp = DataParallelUpdater(e, broadcast_tensors=(e.online, e.target, e.adam_m, e.adam_v))
+    wall, ev_ms = measure(alg, steps, warmup, world, dp)
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([wall], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    stats = e.read_stats()
+    finite = all(v == v and abs(v) < 1e30 for v in stats.values())
+    updates_per_s = steps / wall
+    value = updates_per_s * world  # batch-256 gradient-step equivalents per second over the whole job
+    lay = e.layout
+    flop = lay.flop_per_step(B)
+    byts = lay.bytes_per_step(B, 2)
+    out = {
+        "metric": "DSAC-T gradient steps/sec, batch=256 Humanoid (obs376/act17)",
+        "value": value, "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": 1000.0 * wall / steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "gym_humanoid-shaped DSAC_V2 update: obs 376, act 17, MLP %s GELU, batch 256 per GPU, "
+                        "%d-row replay ring in HBM per GPU, gather+forward+backward+Adam+Polyak every step"
+                        % ("x".join(map(str, hidden)), args.replay_rows),
+            "global_batch": B * world, "parallelism": "dp%d" % world, "hidden": hidden,
+            "noise": "device Philox4x32-10", "launch": "hipGraph (2 steps/graph)" if world == 1 else "eager + RCCL all-reduce",
+            "unit_note": "value = synchronized updates/s x n_gpus (each rank contributes one batch-256 gradient per update)",
+        },
+        "finite_stats": finite,
+    }
+    if rank == 0:
+        per_gpu_steps = updates_per_s
+        out["roofline"] = {
+            "bound": "mfma", "achieved": flop * per_gpu_steps / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": flop * per_gpu_steps / 1e12 / FP32_PEAK_TFLOPS, "traffic": None,
+            "note": "whole update step = one launch chain (one hipGraph replay = 2 steps); algorithmic FLOP/step "
+                    "= %.4g (SURVEY.md 8d), fp32 MFMA/VALU peak" % flop,
+        }
+        out["roofline_hbm"] = {
+            "bound": "hbm", "achieved": byts * per_gpu_steps / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": byts * per_gpu_steps / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "note": "algorithmic bytes/step = %.4g (SURVEY.md 8d)" % byts,
+        }
+        if ev_ms is not None:
+            out["hip_event_ms_per_step"] = ev_ms / steps
+        try:
+            prof = e.profile_step(warmup + steps)
+            e.sync()
+            out["kernels"] = [{"name": n, "us": round(ms * 1000, 2), "blocks": b} for n, ms, b in prof]
+            dom = max(prof, key=lambda r: r[1])
+            out["dominant_kernel"] = {"name": dom[0], "us": round(dom[1] * 1000, 2)}
+        except Exception as ex:  # profiling is informational
+            out["kernels_error"] = str(ex)
+    if world == 1 and not args.no_alt:
+        alt_hidden = [256, 256] if hidden != [256, 256] else [256, 256, 256]
+        del alg
+        alg2 = make_alg(alt_hidden, local, seed=0)
+        fill_replay(alg2.engine, min(args.replay_rows, 200_000), seed=100)
+        upload_indices(alg2.engine, min(args.replay_rows, 200_000), IDX_ROWS, seed=1)
+        w2, _ = measure(alg2, steps, warmup)
+        l2 = alg2.engine.layout
+        out["alt"] = {"hidden": alt_hidden, "value": steps / w2, "unit": "steps/s",
+                      "frac_fp32": l2.flop_per_step(B) * steps / w2 / 1e12 / FP32_PEAK_TFLOPS,
+                      "frac_hbm": l2.bytes_per_step(B, 2) * steps / w2 / 1e9 / HBM_PEAK_GBS}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(hidden)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,1109 @@
+// dsact_api.hip -- host side of libdsact.so: handle, HBM layout, task tables, launch sequence,
+// hipGraph capture and the extern "C" entry points declared in include/dsact.h.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/dsact.h"
+#include "dsact_kernels.h"
+
+using namespace dsact;
+
+namespace {
+
+enum Chain { C_PI = 0, C_PIT, C_Q1C, C_Q2C, C_Q1T, C_Q2T, C_Q1P, C_Q2P, N_CHAIN };
+static const char* kChainName[N_CHAIN] = {"pi", "pit", "q1c", "q2c", "q1t", "q2t", "q1p", "q2p"};
+enum Net { N_Q1 = 0, N_Q2, N_POL, N_Q1T, N_Q2T, N_POLT, N_NET };
+static const int kChainNet[N_CHAIN] = {N_POL, N_POLT, N_Q1, N_Q2, N_Q1T, N_Q2T, N_Q1, N_Q2};
+// chains that are differentiated and their slot in the dZ storage
+static const int kDzSlot[N_CHAIN] = {0, -1, 1, 2, -1, -1, 3, 4};
+
+constexpr int kMaxLin = DSACT_MAX_HIDDEN_LAYERS + 1;
+constexpr int kActRows = 64;  // rows of the stand-alone policy forward (sampler feed)
+
+struct NetDesc {
+  int n_lin = 0;
+  int in[kMaxLin], out[kMaxLin];
+  size_t w_off[kMaxLin], b_off[kMaxLin];
+  size_t count = 0;
+};
+
+struct Stage {
+  std::string name;
+  int task_off = 0, n_tasks = 0;
+};
+
+struct ProfRec {
+  std::string name;
+  hipEvent_t e0, e1;
+  int blocks;
+};
+
+}  // namespace
+
+struct dsact_handle {
+  dsact_config cfg;
+  int device = 0;
+  char err[512] = {0};
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // nets
+  NetDesc qd, pd;
+  size_t n_q = 0, n_pi = 0, n_online = 0, n_target = 0;
+  float *online = nullptr, *target = nullptr, *adam_m = nullptr, *adam_v = nullptr, *grads = nullptr;
+  // dims
+  int O = 0, A = 0, L = 0, B = 0, ldx = 0;
+  int w[DSACT_MAX_HIDDEN_LAYERS];
+  // workspace
+  char* ws = nullptr;
+  size_t ws_bytes = 0;
+  float *X0, *XP, *X2, *rew, *done;
+  float *eps_new, *eps_2, *z5, *z6;
+  float* Hb[N_CHAIN][DSACT_MAX_HIDDEN_LAYERS];
+  float* Gb[N_CHAIN][DSACT_MAX_HIDDEN_LAYERS];
+  float* dZ[5][DSACT_MAX_HIDDEN_LAYERS];
+  float *logits_pi, *logits_pit, *logp_new, *logp2;
+  float *qout_c[2], *qout_t[2], *qout_p[2];
+  float* dout[4];
+  float *dout_pi, *d_new_act;
+  float *part_loss, *part_heads, *stats, *ones, *std_sums;
+  float *act_scale, *act_center;
+  DevState* st = nullptr;
+  int* idx_eager = nullptr;
+  int* idx_table = nullptr;
+  int idx_rows = 0;
+  int n_loss_wg = 0, loss_rows = 0, n_heads_wg = 0;
+  // stand-alone policy forward
+  float *Xact, *Hact[DSACT_MAX_HIDDEN_LAYERS], *Gact, *act_out;
+  // tasks
+  TileTask* d_tasks = nullptr;
+  std::vector<Stage> fwd1, fwd2, bwdq, bwdpi, actf;
+  Stage dw;
+  // replay ring
+  long long cap = 0, ptr = 0, size = 0;
+  float *rb_obs = nullptr, *rb_obs2 = nullptr, *rb_act = nullptr, *rb_rew = nullptr, *rb_done = nullptr, *rb_logp = nullptr;
+  float* stage_dev = nullptr;  // staging for ring writes
+  size_t stage_rows = 0;
+  // pinned host staging
+  int* h_idx[8];
+  hipEvent_t h_idx_ev[8];
+  int h_idx_slot = 0;
+  // rng
+  uint64_t rng_seed = 0;
+  bool have_batch = false;
+  bool limits_set = false;
+  // graph
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  int graph_steps = 0;
+  uint32_t graph_flags = 0;
+  // profiling
+  bool profiling = false;
+  std::vector<ProfRec> prof;
+  // strict DP
+  bool use_std_sums = false;
+};
+
+namespace {
+
+int fail(dsact_handle* h, int code, const char* fmt, ...) {
+  if (h) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(h->err, sizeof(h->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define HIPCHK(h, call)                                                                          \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) return fail(h, DSACT_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+void build_net(NetDesc& d, int in0, const int* hidden, int L, int n_out) {
+  d.n_lin = L + 1;
+  size_t off = 0;
+  int in = in0;
+  for (int l = 0; l <= L; ++l) {
+    const int out = l < L ? hidden[l] : n_out;
+    d.in[l] = in; d.out[l] = out;
+    d.w_off[l] = off; off += (size_t)in * out;
+    d.b_off[l] = off; off += out;
+    in = out;
+  }
+  d.count = off;
+}
+
+const NetDesc& net_desc(const dsact_handle* h, int net) { return (net == N_POL || net == N_POLT) ? h->pd : h->qd; }
+
+// base pointer of a net's parameters inside its arena (online or target)
+float* net_base(const dsact_handle* h, int net, float* online, float* target) {
+  switch (net) {
+    case N_Q1: return online;
+    case N_Q2: return online + h->n_q;
+    case N_POL: return online + 2 * h->n_q;
+    case N_Q1T: return target;
+    case N_Q2T: return target + h->n_q;
+    default: return target + 2 * h->n_q;
+  }
+}
+float* net_params(const dsact_handle* h, int net) { return net_base(h, net, h->online, h->target); }
+float* net_grads(const dsact_handle* h, int net) { return net_base(h, net, h->grads, nullptr); }
+
+template <typename... KArgs, typename... Args>
+int launch(dsact_handle* h, const char* name, void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, Args... args) {
+  if (h->profiling) {
+    ProfRec r;
+    r.name = name;
+    r.blocks = (int)(grid.x * grid.y * grid.z);
+    HIPCHK(h, hipEventCreate(&r.e0));
+    HIPCHK(h, hipEventCreate(&r.e1));
+    HIPCHK(h, hipEventRecord(r.e0, h->stream));
+    hipLaunchKernelGGL(kernel, grid, block, shmem, h->stream, args...);
+    HIPCHK(h, hipEventRecord(r.e1, h->stream));
+    h->prof.push_back(r);
+  } else {
+    hipLaunchKernelGGL(kernel, grid, block, shmem, h->stream, args...);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(h, DSACT_E_HIP, "launch %s failed: %s", name, hipGetErrorString(e));
+  return DSACT_OK;
+}
+
+#define TRY(x)            \
+  do {                    \
+    int rc_ = (x);        \
+    if (rc_ != DSACT_OK) return rc_; \
+  } while (0)
+
+// ---- workspace carving ------------------------------------------------------------------------
+struct Carver {
+  size_t off = 0;
+  char* base = nullptr;
+  template <typename T>
+  T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+void carve(dsact_handle* h, Carver& c) {
+  const size_t B = h->B;
+  const int A = h->A, L = h->L;
+  h->st = c.take<DevState>(1);
+  h->X0 = c.take<float>(B * h->ldx);
+  h->XP = c.take<float>(B * h->ldx);
+  h->X2 = c.take<float>(B * h->ldx);
+  h->rew = c.take<float>(B);
+  h->done = c.take<float>(B);
+  h->eps_new = c.take<float>(B * A);
+  h->eps_2 = c.take<float>(B * A);
+  h->z5 = c.take<float>(B);
+  h->z6 = c.take<float>(B);
+  for (int ch = 0; ch < N_CHAIN; ++ch)
+    for (int l = 0; l < L; ++l) {
+      h->Hb[ch][l] = c.take<float>(B * h->w[l]);
+      h->Gb[ch][l] = c.take<float>(B * h->w[l]);
+    }
+  for (int s = 0; s < 5; ++s)
+    for (int l = 0; l < L; ++l) h->dZ[s][l] = c.take<float>(B * h->w[l]);
+  h->logits_pi = c.take<float>(B * 2 * A);
+  h->logits_pit = c.take<float>(B * 2 * A);
+  h->logp_new = c.take<float>(B);
+  h->logp2 = c.take<float>(B);
+  for (int i = 0; i < 2; ++i) {
+    h->qout_c[i] = c.take<float>(B * 2);
+    h->qout_t[i] = c.take<float>(B * 2);
+    h->qout_p[i] = c.take<float>(B * 2);
+  }
+  for (int i = 0; i < 4; ++i) h->dout[i] = c.take<float>(B * 2);
+  h->dout_pi = c.take<float>(B * 2 * A);
+  h->d_new_act = c.take<float>(B * A);
+  h->part_loss = c.take<float>((size_t)h->n_loss_wg * kLossPart);
+  h->part_heads = c.take<float>((size_t)h->n_heads_wg * 2);
+  h->stats = c.take<float>(16);
+  h->ones = c.take<float>(B);
+  h->std_sums = c.take<float>(2);
+  h->act_scale = c.take<float>(A);
+  h->act_center = c.take<float>(A);
+  h->idx_eager = c.take<int>(B);
+  h->Xact = c.take<float>((size_t)kActRows * h->ldx);
+  for (int l = 0; l < L; ++l) h->Hact[l] = c.take<float>((size_t)kActRows * h->w[l]);
+  int wmax = 0;
+  for (int l = 0; l < L; ++l) wmax = h->w[l] > wmax ? h->w[l] : wmax;
+  h->Gact = c.take<float>((size_t)kActRows * wmax);
+  h->act_out = c.take<float>((size_t)kActRows * 2 * A);
+}
+
+// ---- task tables --------------------------------------------------------------------------------
+void add_tiles(std::vector<TileTask>& v, TileTask proto) {
+  for (int m0 = 0; m0 < proto.M; m0 += TM)
+    for (int n0 = 0; n0 < proto.N; n0 += TN) {
+      TileTask t = proto;
+      t.m0 = m0; t.n0 = n0;
+      v.push_back(t);
+    }
+}
+
+const float* chain_input(const dsact_handle* h, int ch) {
+  switch (ch) {
+    case C_PI: case C_Q1C: case C_Q2C: return h->X0;
+    case C_PIT: case C_Q1T: case C_Q2T: return h->X2;
+    default: return h->XP;
+  }
+}
+
+TileTask fwd_task(const dsact_handle* h, int ch, int l, const float* x0, int ldx0, int M, float* const* Hrow, float* Grow) {
+  const int net = kChainNet[ch];
+  const NetDesc& d = net_desc(h, net);
+  const float* base = net_params(h, net);
+  TileTask t;
+  memset(&t, 0, sizeof(t));
+  t.P = l == 0 ? x0 : Hrow[l - 1];
+  t.ldp = l == 0 ? ldx0 : d.out[l - 1];
+  t.Q = base + d.w_off[l];
+  t.ldq = d.in[l];
+  t.aux = base + d.b_off[l];
+  t.C0 = Hrow[l];
+  t.C1 = Grow;
+  t.ldc = d.out[l];
+  t.M = M; t.N = d.out[l]; t.K = d.in[l];
+  t.layout = LAY_KC_KC; t.epi = EPI_GELU;
+  return t;
+}
+
+int build_tasks(dsact_handle* h) {
+  std::vector<TileTask> all;
+  const int L = h->L, B = h->B;
+  auto begin = [&](Stage& s, const std::string& name) { s.name = name; s.task_off = (int)all.size(); };
+  auto end = [&](Stage& s) { s.n_tasks = (int)all.size() - s.task_off; };
+  // forward group 1: policy(obs), policy_target(obs2), q1/q2(obs,act); group 2: q1_t/q2_t(obs2,act2), q1/q2(obs,new_act)
+  const int g1[4] = {C_PI, C_PIT, C_Q1C, C_Q2C}, g2[4] = {C_Q1T, C_Q2T, C_Q1P, C_Q2P};
+  h->fwd1.assign(L, Stage()); h->fwd2.assign(L, Stage());
+  for (int grp = 0; grp < 2; ++grp)
+    for (int l = 0; l < L; ++l) {
+      Stage& s = grp == 0 ? h->fwd1[l] : h->fwd2[l];
+      begin(s, std::string(grp == 0 ? "fwdA_l" : "fwdB_l") + std::to_string(l));
+      for (int i = 0; i < 4; ++i) {
+        const int ch = grp == 0 ? g1[i] : g2[i];
+        add_tiles(all, fwd_task(h, ch, l, chain_input(h, ch), h->ldx, B, h->Hb[ch], h->Gb[ch][l]));
+      }
+      end(s);
+    }
+  // backward through hidden layers: dZ[l-1] = (dZ[l] W_l) * G[l-1]
+  auto bwd_task = [&](int ch, int l) {
+    const int net = kChainNet[ch];
+    const NetDesc& d = net_desc(h, net);
+    const float* base = net_params(h, net);
+    const int slot = kDzSlot[ch];
+    TileTask t;
+    memset(&t, 0, sizeof(t));
+    t.P = h->dZ[slot][l]; t.ldp = d.out[l];
+    t.Q = base + d.w_off[l]; t.ldq = d.in[l];
+    t.aux = h->Gb[ch][l - 1]; t.ldaux = d.in[l];
+    t.C0 = h->dZ[slot][l - 1]; t.ldc = d.in[l];
+    t.M = B; t.N = d.in[l]; t.K = d.out[l];
+    t.layout = LAY_KC_MC; t.epi = EPI_MULG;
+    return t;
+  };
+  h->bwdq.assign(L > 1 ? L - 1 : 0, Stage()); h->bwdpi.assign(L > 1 ? L - 1 : 0, Stage());
+  for (int l = L - 1; l >= 1; --l) {
+    Stage& s = h->bwdq[L - 1 - l];
+    begin(s, "bwdQ_l" + std::to_string(l));
+    for (int ch : {C_Q1C, C_Q2C, C_Q1P, C_Q2P}) add_tiles(all, bwd_task(ch, l));
+    end(s);
+  }
+  for (int l = L - 1; l >= 1; --l) {
+    Stage& s = h->bwdpi[L - 1 - l];
+    begin(s, "bwdPi_l" + std::to_string(l));
+    add_tiles(all, bwd_task(C_PI, l));
+    end(s);
+  }
+  // weight / bias gradients of q1, q2, policy
+  begin(h->dw, "dW");
+  for (int ch : {C_Q1C, C_Q2C, C_PI}) {
+    const int net = kChainNet[ch];
+    const NetDesc& d = net_desc(h, net);
+    float* g = net_grads(h, net);
+    const int slot = kDzSlot[ch];
+    for (int l = 0; l <= L; ++l) {
+      TileTask t;
+      memset(&t, 0, sizeof(t));
+      if (l < L) { t.P = h->dZ[slot][l]; t.ldp = d.out[l]; }
+      else if (ch == C_PI) { t.P = h->dout_pi; t.ldp = 2 * h->A; }
+      else { t.P = h->dout[ch == C_Q1C ? 0 : 1]; t.ldp = 2; }
+      t.M = d.out[l]; t.K = B;
+      t.layout = LAY_MC_MC; t.epi = EPI_STORE;
+      // weights
+      t.Q = l == 0 ? h->X0 : h->Hb[ch][l - 1];
+      t.ldq = l == 0 ? h->ldx : d.out[l - 1];
+      t.N = d.in[l];
+      t.C0 = g + d.w_off[l]; t.ldc = d.in[l];
+      add_tiles(all, t);
+      // bias: Q = ones
+      t.Q = h->ones; t.ldq = 1; t.N = 1;
+      t.C0 = g + d.b_off[l]; t.ldc = 1;
+      add_tiles(all, t);
+    }
+  }
+  end(h->dw);
+  // stand-alone policy forward (kActRows rows)
+  h->actf.assign(L, Stage());
+  for (int l = 0; l < L; ++l) {
+    begin(h->actf[l], "act_l" + std::to_string(l));
+    add_tiles(all, fwd_task(h, C_PI, l, h->Xact, h->ldx, kActRows, h->Hact, h->Gact));
+    end(h->actf[l]);
+  }
+  if (h->d_tasks) { hipFree(h->d_tasks); h->d_tasks = nullptr; }
+  HIPCHK(h, hipMalloc(&h->d_tasks, all.size() * sizeof(TileTask)));
+  HIPCHK(h, hipMemcpy(h->d_tasks, all.data(), all.size() * sizeof(TileTask), hipMemcpyHostToDevice));
+  return DSACT_OK;
+}
+
+int run_stage(dsact_handle* h, const Stage& s) {
+  if (s.n_tasks == 0) return DSACT_OK;
+  return launch(h, s.name.c_str(), k_tiles, dim3(s.n_tasks), dim3(kThreads), 0, (const TileTask*)(h->d_tasks + s.task_off));
+}
+
+StepHyper step_hyper(const dsact_handle* h) {
+  StepHyper hp;
+  hp.delay_update = h->cfg.delay_update;
+  hp.lr_q = h->cfg.lr_q; hp.lr_pi = h->cfg.lr_pi; hp.lr_alpha = h->cfg.lr_alpha;
+  hp.beta1 = h->cfg.adam_beta1; hp.beta2 = h->cfg.adam_beta2;
+  return hp;
+}
+NoiseArgs noise_args(const dsact_handle* h) {
+  NoiseArgs nz;
+  nz.seed = h->rng_seed;
+  nz.eps_new = h->eps_new; nz.eps_2 = h->eps_2; nz.z5 = h->z5; nz.z6 = h->z6;
+  return nz;
+}
+
+int enqueue_gather(dsact_handle* h, const int* table, int rows, int use_dev, long long it, int advance) {
+  GatherArgs a;
+  a.rb_obs = h->rb_obs; a.rb_obs2 = h->rb_obs2; a.rb_act = h->rb_act; a.rb_rew = h->rb_rew; a.rb_done = h->rb_done;
+  a.idx_table = table; a.idx_rows = rows; a.use_dev = use_dev; a.host_it = it; a.host_row = 0;
+  a.X0 = h->X0; a.XP = h->XP; a.X2 = h->X2; a.rew = h->rew; a.done = h->done;
+  a.B = h->B; a.O = h->O; a.A = h->A; a.ldx = h->ldx;
+  a.st = h->st; a.bookkeeping = 1; a.advance_counters = advance; a.hp = step_hyper(h); a.nz = noise_args(h);
+  return launch(h, "gather", k_gather, dim3((h->B + 3) / 4), dim3(kThreads), 0, a);
+}
+
+int enqueue_prologue(dsact_handle* h, int use_dev, long long it, int advance, int fill_noise) {
+  PrologueArgs a;
+  a.st = h->st; a.use_dev = use_dev; a.host_it = it; a.advance_counters = advance; a.fill_noise = fill_noise;
+  a.hp = step_hyper(h); a.nz = noise_args(h); a.B = h->B; a.A = h->A;
+  return launch(h, "prologue", k_prologue, dim3(1), dim3(kThreads), 0, a);
+}
+
+// everything of __compute_gradient after the minibatch is staged (dsac_v2.py:150-206)
+int enqueue_grads(dsact_handle* h, bool actor_backward) {
+  const int L = h->L, B = h->B, A = h->A;
+  for (int l = 0; l < L; ++l) TRY(run_stage(h, h->fwd1[l]));
+  {
+    HeadsArgs a;
+    const int chs[4] = {C_PI, C_PIT, C_Q1C, C_Q2C};
+    for (int i = 0; i < 4; ++i) {
+      const int net = kChainNet[chs[i]];
+      const NetDesc& d = net_desc(h, net);
+      a.H[i] = h->Hb[chs[i]][L - 1];
+      a.Wout[i] = net_params(h, net) + d.w_off[L];
+      a.bout[i] = net_params(h, net) + d.b_off[L];
+    }
+    a.W = h->w[L - 1]; a.B = B; a.O = h->O; a.A = A; a.ldx = h->ldx;
+    a.eps_new = h->eps_new; a.eps_2 = h->eps_2; a.XP = h->XP; a.X2 = h->X2;
+    a.logits_pi = h->logits_pi; a.logits_pit = h->logits_pit; a.logp_new = h->logp_new; a.logp2 = h->logp2;
+    a.qout[0] = h->qout_c[0]; a.qout[1] = h->qout_c[1];
+    a.part_heads = h->part_heads; a.act_scale = h->act_scale; a.act_center = h->act_center;
+    a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
+    TRY(launch(h, "heads", k_heads, dim3(h->n_heads_wg, 4), dim3(kThreads), 0, a));
+  }
+  for (int l = 0; l < L; ++l) TRY(run_stage(h, h->fwd2[l]));
+  if (h->use_std_sums) {
+    // strict data-parallel mode: the caller all-reduces std_sums between compute phases; on one
+    // GPU the local sums are used directly.
+    StdSumArgs s;
+    s.qout_c[0] = h->qout_c[0]; s.qout_c[1] = h->qout_c[1]; s.B = B; s.out = h->std_sums;
+    TRY(launch(h, "std_sums", k_std_sums, dim3(1), dim3(kThreads), 0, s));
+  }
+  {
+    LossArgs a;
+    const int chs[4] = {C_Q1T, C_Q2T, C_Q1P, C_Q2P};
+    for (int i = 0; i < 4; ++i) {
+      const int net = kChainNet[chs[i]];
+      a.Hl[i] = h->Hb[chs[i]][L - 1];
+      a.Wout[i] = net_params(h, net) + h->qd.w_off[L];
+      a.bout[i] = net_params(h, net) + h->qd.b_off[L];
+    }
+    const int dch[4] = {C_Q1C, C_Q2C, C_Q1P, C_Q2P};
+    for (int i = 0; i < 4; ++i) {
+      a.Gl[i] = h->Gb[dch[i]][L - 1];
+      a.dZl[i] = h->dZ[kDzSlot[dch[i]]][L - 1];
+      a.dout[i] = h->dout[i];
+    }
+    a.Wq[0] = net_params(h, N_Q1) + h->qd.w_off[L];
+    a.Wq[1] = net_params(h, N_Q2) + h->qd.w_off[L];
+    for (int i = 0; i < 2; ++i) { a.qout_c[i] = h->qout_c[i]; a.qout_t[i] = h->qout_t[i]; a.qout_p[i] = h->qout_p[i]; }
+    a.rew = h->rew; a.done = h->done; a.logp2 = h->logp2; a.logp_new = h->logp_new; a.z5 = h->z5; a.z6 = h->z6;
+    a.log_alpha = h->online + h->n_online - 1;
+    a.part_loss = h->part_loss; a.grads_tail = h->grads + h->n_online; a.st = h->st;
+    a.W = h->w[L - 1]; a.B = B; a.rows_per_wg = h->loss_rows;
+    a.inv_B = 1.0f / (float)B;
+    a.inv_Bg = h->use_std_sums ? 1.0f / (float)h->cfg.global_batch : 1.0f / (float)B;
+    a.std_sums = h->use_std_sums ? h->std_sums : nullptr;
+    a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.gamma = h->cfg.gamma; a.tau_b = h->cfg.tau_b;
+    TRY(launch(h, "loss", k_loss, dim3(h->n_loss_wg), dim3(kThreads), (size_t)h->loss_rows * 16 * sizeof(float), a));
+  }
+  for (size_t i = 0; i < h->bwdq.size(); ++i) TRY(run_stage(h, h->bwdq[i]));
+  {
+    HeadsBwdArgs a;
+    a.dZ1[0] = h->dZ[kDzSlot[C_Q1P]][0]; a.dZ1[1] = h->dZ[kDzSlot[C_Q2P]][0];
+    a.W1[0] = net_params(h, N_Q1) + h->qd.w_off[0]; a.W1[1] = net_params(h, N_Q2) + h->qd.w_off[0];
+    a.W0 = h->w[0]; a.ld1 = h->O + A;
+    a.logits_pi = h->logits_pi; a.eps_new = h->eps_new; a.log_alpha = h->online + h->n_online - 1;
+    a.Wout_pi = net_params(h, N_POL) + h->pd.w_off[L];
+    a.G_pi = h->Gb[C_PI][L - 1]; a.dZ_pi = h->dZ[kDzSlot[C_PI]][L - 1];
+    a.dout_pi = h->dout_pi; a.d_new_act = h->d_new_act;
+    a.WL = h->w[L - 1]; a.B = B; a.O = h->O; a.A = A;
+    a.inv_B = 1.0f / (float)B; a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed;
+    a.act_scale = h->act_scale; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
+    TRY(launch(h, "heads_bwd", k_heads_bwd, dim3((B + 3) / 4), dim3(kThreads), 0, a));
+  }
+  for (size_t i = 0; i < h->bwdpi.size(); ++i) TRY(run_stage(h, h->bwdpi[i]));
+  TRY(run_stage(h, h->dw));
+  {
+    FinalizeArgs a;
+    a.part_loss = h->part_loss; a.n_part = h->n_loss_wg; a.inv_B = 1.0f / (float)B;
+    a.target_entropy = -(float)A; a.grad_log_alpha = h->grads + h->n_online - 1; a.auto_alpha = h->cfg.auto_alpha;
+    TRY(launch(h, "finalize", k_finalize_grads, dim3(1), dim3(64), 0, a));
+  }
+  (void)actor_backward;
+  return DSACT_OK;
+}
+
+int enqueue_adam(dsact_handle* h) {
+  AdamArgs a;
+  a.p = h->online; a.tgt = h->target; a.m = h->adam_m; a.v = h->adam_v; a.g = h->grads;
+  a.n_q2 = (long long)(2 * h->n_q); a.n_online3 = (long long)(2 * h->n_q + h->n_pi); a.n_total = (long long)h->n_online;
+  a.st = h->st;
+  a.b1w = (float)(1.0 - (double)h->cfg.adam_beta1);
+  a.beta2 = h->cfg.adam_beta2;
+  a.b2w = (float)(1.0 - (double)h->cfg.adam_beta2);
+  a.eps = h->cfg.adam_eps;
+  const double polyak = 1.0 - (double)h->cfg.tau;  // dsac_v2.py:331
+  a.polyak = (float)polyak;
+  a.one_minus_polyak = (float)(1.0 - polyak);
+  a.auto_alpha = h->cfg.auto_alpha;
+  a.commit_ms = 1;
+  const int blocks = (int)((h->n_online + kThreads * 4 - 1) / (kThreads * 4));
+  return launch(h, "adam_polyak", k_adam, dim3(blocks), dim3(kThreads), 0, a);
+}
+
+int check_ready(dsact_handle* h, bool need_batch) {
+  if (!h) return DSACT_E_INVALID;
+  if (!h->online || !h->grads) return fail(h, DSACT_E_STATE, "arenas not bound (dsact_bind_arenas)");
+  if (!h->limits_set) return fail(h, DSACT_E_STATE, "action limits not set (dsact_set_action_limits)");
+  if (need_batch && !h->have_batch) return fail(h, DSACT_E_STATE, "no minibatch staged (dsact_gather / dsact_load_batch)");
+  return DSACT_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int dsact_version(void) { return 1; }
+
+int dsact_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* dsact_last_error(const dsact_handle* h) { return h ? h->err : "null handle"; }
+
+int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
+  if (!cfg || !out) return DSACT_E_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return DSACT_E_NODEVICE;
+  if (device < 0 || device >= ndev) return DSACT_E_INVALID;
+  dsact_handle* h = new dsact_handle();
+  h->cfg = *cfg;
+  h->device = device;
+  *out = h;  // returned even on failure so that the caller can read the message, then destroy
+  if (cfg->obs_dim < 1 || cfg->act_dim < 1 || cfg->act_dim > 32) return fail(h, DSACT_E_INVALID, "act_dim must be in 1..32 (got %d), obs_dim >= 1", cfg->act_dim);
+  if (cfg->n_hidden < 1 || cfg->n_hidden > DSACT_MAX_HIDDEN_LAYERS) return fail(h, DSACT_E_INVALID, "n_hidden must be 1..%d", DSACT_MAX_HIDDEN_LAYERS);
+  for (int l = 0; l < cfg->n_hidden; ++l)
+    if (cfg->hidden[l] < 1 || cfg->hidden[l] > kMaxWidth) return fail(h, DSACT_E_INVALID, "hidden width must be 1..%d", kMaxWidth);
+  if (cfg->batch < 1) return fail(h, DSACT_E_INVALID, "batch must be >= 1");
+  if (cfg->delay_update < 1) return fail(h, DSACT_E_INVALID, "delay_update must be >= 1");
+  if (h->cfg.global_batch < h->cfg.batch) h->cfg.global_batch = h->cfg.batch;
+  HIPCHK(h, hipSetDevice(device));
+  h->O = cfg->obs_dim; h->A = cfg->act_dim; h->L = cfg->n_hidden; h->B = cfg->batch;
+  for (int l = 0; l < h->L; ++l) h->w[l] = cfg->hidden[l];
+  h->ldx = (h->O + h->A + 3) & ~3;
+  build_net(h->qd, h->O + h->A, h->w, h->L, 2);
+  build_net(h->pd, h->O, h->w, h->L, 2 * h->A);
+  h->n_q = h->qd.count; h->n_pi = h->pd.count;
+  h->n_online = 2 * h->n_q + h->n_pi + 1;
+  h->n_target = 2 * h->n_q + h->n_pi;
+  h->n_heads_wg = (h->B + 3) / 4;
+  h->n_loss_wg = h->B >= 1024 ? 256 : (h->B + 3) / 4;
+  h->loss_rows = (h->B + h->n_loss_wg - 1) / h->n_loss_wg;
+  h->n_loss_wg = (h->B + h->loss_rows - 1) / h->loss_rows;
+  Carver c0;
+  carve(h, c0);
+  h->ws_bytes = c0.off + 256;
+  HIPCHK(h, hipMalloc(&h->ws, h->ws_bytes));
+  HIPCHK(h, hipMemset(h->ws, 0, h->ws_bytes));
+  Carver c1;
+  c1.base = h->ws;
+  carve(h, c1);
+  {
+    std::vector<float> ones(h->B, 1.0f);
+    HIPCHK(h, hipMemcpy(h->ones, ones.data(), h->B * sizeof(float), hipMemcpyHostToDevice));
+  }
+  HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  h->own_stream = true;
+  for (int i = 0; i < 8; ++i) {
+    HIPCHK(h, hipHostMalloc((void**)&h->h_idx[i], (size_t)h->B * sizeof(int), hipHostMallocDefault));
+    HIPCHK(h, hipEventCreateWithFlags(&h->h_idx_ev[i], hipEventDisableTiming));
+  }
+  return DSACT_OK;
+}
+
+int dsact_destroy(dsact_handle* h) {
+  if (!h) return DSACT_E_INVALID;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+  if (h->graph) hipGraphDestroy(h->graph);
+  for (auto& r : h->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  for (int i = 0; i < 8; ++i) {
+    if (h->h_idx[i]) hipHostFree(h->h_idx[i]);
+    if (h->h_idx_ev[i]) hipEventDestroy(h->h_idx_ev[i]);
+  }
+  if (h->d_tasks) hipFree(h->d_tasks);
+  if (h->idx_table) hipFree(h->idx_table);
+  if (h->stage_dev) hipFree(h->stage_dev);
+  for (float* p : {h->rb_obs, h->rb_obs2, h->rb_act, h->rb_rew, h->rb_done, h->rb_logp})
+    if (p) hipFree(p);
+  if (h->ws) hipFree(h->ws);
+  if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return DSACT_OK;
+}
+
+int dsact_set_stream(dsact_handle* h, void* s) {
+  if (!h) return DSACT_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->graph_exec) return fail(h, DSACT_E_STATE, "cannot change stream after dsact_graph_build");
+  if (h->stream) HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->own_stream && h->stream) { hipStreamDestroy(h->stream); h->stream = nullptr; }
+  if (s) { h->stream = (hipStream_t)s; h->own_stream = false; }
+  else { HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+  return DSACT_OK;
+}
+
+int dsact_sync(dsact_handle* h) {
+  if (!h) return DSACT_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return DSACT_OK;
+}
+
+size_t dsact_online_count(const dsact_handle* h) { return h ? h->n_online : 0; }
+size_t dsact_target_count(const dsact_handle* h) { return h ? h->n_target : 0; }
+size_t dsact_q_count(const dsact_handle* h) { return h ? h->n_q : 0; }
+size_t dsact_pi_count(const dsact_handle* h) { return h ? h->n_pi : 0; }
+
+int dsact_bind_arenas(dsact_handle* h, float* online, float* target, float* adam_m, float* adam_v, float* grads) {
+  if (!h) return DSACT_E_INVALID;
+  if (!online || !target || !adam_m || !adam_v || !grads) return fail(h, DSACT_E_INVALID, "null arena pointer");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->graph_exec) return fail(h, DSACT_E_STATE, "cannot rebind arenas after dsact_graph_build");
+  h->online = online; h->target = target; h->adam_m = adam_m; h->adam_v = adam_v; h->grads = grads;
+  return build_tasks(h);
+}
+
+int dsact_set_action_limits(dsact_handle* h, const float* high, const float* low) {
+  if (!h || !high || !low) return DSACT_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<float> s(h->A), c(h->A);
+  for (int j = 0; j < h->A; ++j) {
+    if (!(high[j] > low[j])) return fail(h, DSACT_E_INVALID, "action_high_limit must exceed action_low_limit");
+    s[j] = (high[j] - low[j]) / 2;  // fp32 like the reference's tensor arithmetic
+    c[j] = (high[j] + low[j]) / 2;
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(h->act_scale, s.data(), h->A * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->act_center, c.data(), h->A * sizeof(float), hipMemcpyHostToDevice));
+  h->limits_set = true;
+  return DSACT_OK;
+}
+
+int dsact_get_state(dsact_handle* h, int32_t adam_steps[3], float mean_std[2]) {
+  if (!h) return DSACT_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  DevState st;
+  HIPCHK(h, hipMemcpy(&st, h->st, sizeof(st), hipMemcpyDeviceToHost));
+  if (adam_steps) { adam_steps[0] = st.t_q; adam_steps[1] = st.t_pi; adam_steps[2] = st.t_alpha; }
+  if (mean_std) { mean_std[0] = st.ms_init ? st.ms1 : -1.0f; mean_std[1] = st.ms_init ? st.ms2 : -1.0f; }
+  return DSACT_OK;
+}
+
+int dsact_set_state(dsact_handle* h, const int32_t adam_steps[3], const float mean_std[2]) {
+  if (!h) return DSACT_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  DevState st;
+  HIPCHK(h, hipMemcpy(&st, h->st, sizeof(st), hipMemcpyDeviceToHost));
+  if (adam_steps) { st.t_q = adam_steps[0]; st.t_pi = adam_steps[1]; st.t_alpha = adam_steps[2]; }
+  if (mean_std) {
+    st.ms_init = (mean_std[0] >= 0.0f && mean_std[1] >= 0.0f) ? 1 : 0;
+    st.ms1 = mean_std[0]; st.ms2 = mean_std[1];
+  }
+  HIPCHK(h, hipMemcpy(h->st, &st, sizeof(st), hipMemcpyHostToDevice));
+  return DSACT_OK;
+}
+
+// ---- replay ring ---------------------------------------------------------------------------------
+int dsact_buffer_create(dsact_handle* h, int64_t capacity) {
+  if (!h || capacity < 1) return DSACT_E_INVALID;
+  if (capacity > 2147483647LL) return fail(h, DSACT_E_INVALID, "capacity must fit int32 (device indices)");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->rb_obs) return fail(h, DSACT_E_STATE, "buffer already created");
+  const size_t N = (size_t)capacity;
+  HIPCHK(h, hipMalloc(&h->rb_obs, N * h->O * sizeof(float)));
+  HIPCHK(h, hipMalloc(&h->rb_obs2, N * h->O * sizeof(float)));
+  HIPCHK(h, hipMalloc(&h->rb_act, N * h->A * sizeof(float)));
+  HIPCHK(h, hipMalloc(&h->rb_rew, N * sizeof(float)));
+  HIPCHK(h, hipMalloc(&h->rb_done, N * sizeof(float)));
+  HIPCHK(h, hipMalloc(&h->rb_logp, N * sizeof(float)));
+  // replay_buffer.py:25-38: zero-initialised
+  HIPCHK(h, hipMemsetAsync(h->rb_obs, 0, N * h->O * sizeof(float), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->rb_obs2, 0, N * h->O * sizeof(float), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->rb_act, 0, N * h->A * sizeof(float), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->rb_rew, 0, N * sizeof(float), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->rb_done, 0, N * sizeof(float), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->rb_logp, 0, N * sizeof(float), h->stream));
+  h->cap = capacity; h->ptr = 0; h->size = 0;
+  return DSACT_OK;
+}
+
+int64_t dsact_buffer_size(const dsact_handle* h) { return h ? h->size : -1; }
+int64_t dsact_buffer_ptr(const dsact_handle* h) { return h ? h->ptr : -1; }
+
+int dsact_buffer_add(dsact_handle* h, int64_t n, const float* obs, const float* act, const float* rew,
+                     const float* obs2, const float* done, const float* logp) {
+  if (!h || n < 0 || !obs || !act || !rew || !obs2 || !done) return DSACT_E_INVALID;
+  if (!h->rb_obs) return fail(h, DSACT_E_STATE, "buffer not created");
+  if (n == 0) return DSACT_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t O = h->O, A = h->A;
+  const size_t row_f = 2 * O + A + 3;
+  if ((size_t)n > h->stage_rows) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->stage_dev) hipFree(h->stage_dev);
+    h->stage_rows = (size_t)n < 64 ? 64 : (size_t)n;
+    HIPCHK(h, hipMalloc(&h->stage_dev, h->stage_rows * row_f * sizeof(float)));
+  }
+  const size_t R = h->stage_rows;
+  float* s_obs = h->stage_dev;
+  float* s_obs2 = s_obs + R * O;
+  float* s_act = s_obs2 + R * O;
+  float* s_rew = s_act + R * A;
+  float* s_done = s_rew + R;
+  float* s_logp = s_done + R;
+  HIPCHK(h, hipMemcpyAsync(s_obs, obs, n * O * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(s_obs2, obs2, n * O * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(s_act, act, n * A * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(s_rew, rew, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(s_done, done, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  if (logp) HIPCHK(h, hipMemcpyAsync(s_logp, logp, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  // if n exceeds the capacity only the last `cap` rows survive (same as sequential store())
+  long long first = 0, cnt = n;
+  if (n > h->cap) { first = n - h->cap; cnt = h->cap; }
+  ScatterArgs a;
+  a.s_obs = s_obs + first * O; a.s_obs2 = s_obs2 + first * O; a.s_act = s_act + first * A;
+  a.s_rew = s_rew + first; a.s_done = s_done + first; a.s_logp = logp ? s_logp + first : nullptr;
+  a.rb_obs = h->rb_obs; a.rb_obs2 = h->rb_obs2; a.rb_act = h->rb_act; a.rb_rew = h->rb_rew; a.rb_done = h->rb_done; a.rb_logp = h->rb_logp;
+  a.ptr = (h->ptr + first) % h->cap; a.cap = h->cap; a.n = (int)cnt; a.O = h->O; a.A = h->A;
+  TRY(launch(h, "ring_write", k_ring_write, dim3((unsigned)((cnt + 3) / 4)), dim3(kThreads), 0, a));
+  // host pointers may be reused by the caller right away
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->ptr = (h->ptr + n) % h->cap;
+  h->size = h->size + n > h->cap ? h->cap : h->size + n;
+  return DSACT_OK;
+}
+
+int dsact_buffer_fill_device(dsact_handle* h, int64_t row0, int64_t n, const float* obs, const float* act,
+                             const float* rew, const float* obs2, const float* done) {
+  if (!h || row0 < 0 || n < 0) return DSACT_E_INVALID;
+  if (!h->rb_obs) return fail(h, DSACT_E_STATE, "buffer not created");
+  if (row0 + n > h->cap) return fail(h, DSACT_E_INVALID, "fill exceeds capacity");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t O = h->O, A = h->A;
+  HIPCHK(h, hipMemcpyAsync(h->rb_obs + row0 * O, obs, n * O * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->rb_obs2 + row0 * O, obs2, n * O * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->rb_act + row0 * A, act, n * A * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->rb_rew + row0, rew, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->rb_done + row0, done, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (row0 + n > h->size) h->size = row0 + n;
+  h->ptr = (row0 + n) % h->cap;
+  return DSACT_OK;
+}
+
+int dsact_gather(dsact_handle* h, const int64_t* idx_host, int32_t batch) {
+  if (!h || !idx_host) return DSACT_E_INVALID;
+  if (!h->rb_obs) return fail(h, DSACT_E_STATE, "buffer not created");
+  if (batch != h->B) return fail(h, DSACT_E_INVALID, "batch %d != configured batch %d", batch, h->B);
+  if (h->size == 0) return fail(h, DSACT_E_STATE, "buffer empty");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int slot = h->h_idx_slot;
+  h->h_idx_slot = (slot + 1) & 7;
+  HIPCHK(h, hipEventSynchronize(h->h_idx_ev[slot]));
+  for (int i = 0; i < batch; ++i) {
+    if (idx_host[i] < 0 || idx_host[i] >= h->size) return fail(h, DSACT_E_INVALID, "index %lld out of range [0,%lld)", (long long)idx_host[i], h->size);
+    h->h_idx[slot][i] = (int)idx_host[i];
+  }
+  HIPCHK(h, hipMemcpyAsync(h->idx_eager, h->h_idx[slot], batch * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipEventRecord(h->h_idx_ev[slot], h->stream));
+  // bookkeeping (iteration, counters) is done by the step call; this gather only stages rows
+  GatherArgs a;
+  memset(&a, 0, sizeof(a));
+  a.rb_obs = h->rb_obs; a.rb_obs2 = h->rb_obs2; a.rb_act = h->rb_act; a.rb_rew = h->rb_rew; a.rb_done = h->rb_done;
+  a.idx_table = h->idx_eager; a.idx_rows = 1; a.use_dev = 0; a.host_it = 0; a.host_row = 0;
+  a.X0 = h->X0; a.XP = h->XP; a.X2 = h->X2; a.rew = h->rew; a.done = h->done;
+  a.B = h->B; a.O = h->O; a.A = h->A; a.ldx = h->ldx; a.st = h->st; a.bookkeeping = 0; a.advance_counters = 0;
+  a.hp = step_hyper(h); a.nz = noise_args(h); a.nz.seed = 0;
+  TRY(launch(h, "gather", k_gather, dim3((h->B + 3) / 4), dim3(kThreads), 0, a));
+  h->have_batch = true;
+  return DSACT_OK;
+}
+
+int dsact_read_batch(dsact_handle* h, float* obs, float* act, float* rew, float* obs2, float* done, float* logp) {
+  if (!h) return DSACT_E_INVALID;
+  if (!h->have_batch) return fail(h, DSACT_E_STATE, "no minibatch staged");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const size_t B = h->B, O = h->O, A = h->A, ld = h->ldx;
+  if (obs) HIPCHK(h, hipMemcpy2D(obs, O * 4, h->X0, ld * 4, O * 4, B, hipMemcpyDeviceToHost));
+  if (obs2) HIPCHK(h, hipMemcpy2D(obs2, O * 4, h->X2, ld * 4, O * 4, B, hipMemcpyDeviceToHost));
+  if (act) HIPCHK(h, hipMemcpy2D(act, A * 4, h->X0 + O, ld * 4, A * 4, B, hipMemcpyDeviceToHost));
+  if (rew) HIPCHK(h, hipMemcpy(rew, h->rew, B * 4, hipMemcpyDeviceToHost));
+  if (done) HIPCHK(h, hipMemcpy(done, h->done, B * 4, hipMemcpyDeviceToHost));
+  if (logp) {
+    if (!h->rb_logp) return fail(h, DSACT_E_STATE, "buffer not created");
+    std::vector<int> idx(B);
+    HIPCHK(h, hipMemcpy(idx.data(), h->idx_eager, B * sizeof(int), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < B; ++i) HIPCHK(h, hipMemcpy(logp + i, h->rb_logp + idx[i], 4, hipMemcpyDeviceToHost));
+  }
+  return DSACT_OK;
+}
+
+int dsact_load_batch(dsact_handle* h, const float* obs, const float* act, const float* rew, const float* obs2, const float* done) {
+  if (!h || !obs || !act || !rew || !obs2 || !done) return DSACT_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t B = h->B, O = h->O, A = h->A, ld = h->ldx;
+  hipStream_t s = h->stream;
+  HIPCHK(h, hipMemcpy2DAsync(h->X0, ld * 4, obs, O * 4, O * 4, B, hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpy2DAsync(h->XP, ld * 4, obs, O * 4, O * 4, B, hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpy2DAsync(h->X2, ld * 4, obs2, O * 4, O * 4, B, hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpy2DAsync(h->X0 + O, ld * 4, act, A * 4, A * 4, B, hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(h->rew, rew, B * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(h->done, done, B * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipStreamSynchronize(s));  // host buffers are the caller's
+  h->have_batch = true;
+  return DSACT_OK;
+}
+
+int dsact_upload_index_table(dsact_handle* h, const int64_t* idx_host, int32_t rows) {
+  if (!h || !idx_host || rows < 1) return DSACT_E_INVALID;
+  if (!h->rb_obs) return fail(h, DSACT_E_STATE, "buffer not created");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const size_t n = (size_t)rows * h->B;
+  std::vector<int> tmp(n);
+  for (size_t i = 0; i < n; ++i) {
+    if (idx_host[i] < 0 || idx_host[i] >= h->size) return fail(h, DSACT_E_INVALID, "index out of range");
+    tmp[i] = (int)idx_host[i];
+  }
+  if (h->graph_exec && rows != h->idx_rows) return fail(h, DSACT_E_STATE, "index table shape is baked into the captured graph");
+  if (!h->idx_table || rows != h->idx_rows) {
+    if (h->idx_table) hipFree(h->idx_table);
+    HIPCHK(h, hipMalloc(&h->idx_table, n * sizeof(int)));
+    h->idx_rows = rows;
+  }
+  HIPCHK(h, hipMemcpy(h->idx_table, tmp.data(), n * sizeof(int), hipMemcpyHostToDevice));
+  return DSACT_OK;
+}
+
+// ---- noise ---------------------------------------------------------------------------------------
+int dsact_set_noise(dsact_handle* h, const float* eps_new, const float* eps_2, const float* z5, const float* z6) {
+  if (!h || !eps_new || !eps_2 || !z5 || !z6) return DSACT_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t B = h->B, A = h->A;
+  HIPCHK(h, hipMemcpyAsync(h->eps_new, eps_new, B * A * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->eps_2, eps_2, B * A * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->z5, z5, B * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->z6, z6, B * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->rng_seed = 0;
+  return DSACT_OK;
+}
+
+int dsact_set_device_rng(dsact_handle* h, uint64_t seed) {
+  if (!h) return DSACT_E_INVALID;
+  if (h->graph_exec) return fail(h, DSACT_E_STATE, "rng mode is baked into the captured graph");
+  h->rng_seed = seed;
+  return DSACT_OK;
+}
+
+// ---- update --------------------------------------------------------------------------------------
+int dsact_compute_grads(dsact_handle* h, int64_t iteration, uint32_t flags) {
+  TRY(check_ready(h, true));
+  HIPCHK(h, hipSetDevice(h->device));
+  TRY(enqueue_prologue(h, 0, iteration, 0, 1));
+  return enqueue_grads(h, !(flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) || (iteration % h->cfg.delay_update) == 0);
+}
+
+int dsact_apply_update(dsact_handle* h, int64_t iteration) {
+  TRY(check_ready(h, false));
+  HIPCHK(h, hipSetDevice(h->device));
+  TRY(enqueue_prologue(h, 0, iteration, 1, 0));
+  return enqueue_adam(h);
+}
+
+int dsact_step(dsact_handle* h, int64_t iteration, uint32_t flags) {
+  TRY(check_ready(h, true));
+  HIPCHK(h, hipSetDevice(h->device));
+  TRY(enqueue_prologue(h, 0, iteration, 1, 1));
+  TRY(enqueue_grads(h, !(flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) || (iteration % h->cfg.delay_update) == 0));
+  return enqueue_adam(h);
+}
+
+static int enqueue_graph_step(dsact_handle* h) {
+  TRY(enqueue_gather(h, h->idx_table, h->idx_rows, 1, 0, 1));
+  TRY(enqueue_grads(h, true));
+  return enqueue_adam(h);
+}
+
+int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) {
+  TRY(check_ready(h, false));
+  if (steps_per_graph < 1) return fail(h, DSACT_E_INVALID, "steps_per_graph must be >= 1");
+  if (!h->idx_table) return fail(h, DSACT_E_STATE, "upload an index table first (dsact_upload_index_table)");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+  if (h->graph) { hipGraphDestroy(h->graph); h->graph = nullptr; }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const bool was_prof = h->profiling;
+  h->profiling = false;
+  HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  int rc = DSACT_OK;
+  for (int s = 0; s < steps_per_graph && rc == DSACT_OK; ++s) rc = enqueue_graph_step(h);
+  hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
+  h->profiling = was_prof;
+  if (rc != DSACT_OK) return rc;
+  if (e != hipSuccess) return fail(h, DSACT_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  HIPCHK(h, hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+  h->graph_steps = steps_per_graph;
+  h->graph_flags = flags;
+  h->have_batch = true;
+  return DSACT_OK;
+}
+
+static int set_device_iteration(dsact_handle* h, long long it) {
+  // it_next lives at offset 0 of DevState
+  HIPCHK(h, hipMemcpyAsync(&h->st->it_next, &it, sizeof(long long), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return DSACT_OK;
+}
+
+int dsact_graph_run(dsact_handle* h, int64_t first_iteration, int64_t n_steps) {
+  if (!h) return DSACT_E_INVALID;
+  if (!h->graph_exec) return fail(h, DSACT_E_STATE, "dsact_graph_build first");
+  if (n_steps % h->graph_steps) return fail(h, DSACT_E_INVALID, "n_steps must be a multiple of steps_per_graph");
+  HIPCHK(h, hipSetDevice(h->device));
+  TRY(set_device_iteration(h, first_iteration));
+  for (int64_t i = 0; i < n_steps / h->graph_steps; ++i) HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
+  return DSACT_OK;
+}
+
+int dsact_dp_begin(dsact_handle* h, int64_t first_iteration) {
+  if (!h) return DSACT_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  return set_device_iteration(h, first_iteration);
+}
+
+int dsact_dp_enqueue_grads(dsact_handle* h, uint32_t flags) {
+  TRY(check_ready(h, false));
+  if (!h->idx_table) return fail(h, DSACT_E_STATE, "upload an index table first");
+  HIPCHK(h, hipSetDevice(h->device));
+  (void)flags;
+  TRY(enqueue_gather(h, h->idx_table, h->idx_rows, 1, 0, 0));
+  h->have_batch = true;
+  return enqueue_grads(h, true);
+}
+
+int dsact_dp_enqueue_apply(dsact_handle* h) {
+  TRY(check_ready(h, false));
+  HIPCHK(h, hipSetDevice(h->device));
+  TRY(enqueue_prologue(h, 1, 0, 1, 0));
+  return enqueue_adam(h);
+}
+
+int dsact_read_stats(dsact_handle* h, float out[16]) {
+  if (!h || !out) return DSACT_E_INVALID;
+  TRY(check_ready(h, false));
+  HIPCHK(h, hipSetDevice(h->device));
+  StatsArgs a;
+  a.part_loss = h->part_loss; a.n_loss = h->n_loss_wg; a.part_heads = h->part_heads; a.n_heads = h->n_heads_wg;
+  a.log_alpha = h->online + h->n_online - 1; a.st = h->st;
+  a.inv_B = 1.0f / (float)h->B; a.inv_BA = 1.0f / ((float)h->B * (float)h->A);
+  a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.out = h->stats;
+  const bool was_prof = h->profiling;
+  h->profiling = false;
+  int rc = launch(h, "stats", k_stats, dim3(1), dim3(64), 0, a);
+  h->profiling = was_prof;
+  TRY(rc);
+  HIPCHK(h, hipMemcpyAsync(out, h->stats, 16 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return DSACT_OK;
+}
+
+// ---- measurement -----------------------------------------------------------------------------------
+int dsact_time_steps(dsact_handle* h, int64_t first_iteration, int64_t n_steps, uint32_t flags, int32_t use_graph, float* ms_total) {
+  if (!h || !ms_total || n_steps < 1) return DSACT_E_INVALID;
+  TRY(check_ready(h, false));
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->idx_table) return fail(h, DSACT_E_STATE, "upload an index table first");
+  hipEvent_t e0, e1;
+  HIPCHK(h, hipEventCreate(&e0));
+  HIPCHK(h, hipEventCreate(&e1));
+  TRY(set_device_iteration(h, first_iteration));
+  HIPCHK(h, hipEventRecord(e0, h->stream));
+  if (use_graph) {
+    if (!h->graph_exec) return fail(h, DSACT_E_STATE, "dsact_graph_build first");
+    if (n_steps % h->graph_steps) return fail(h, DSACT_E_INVALID, "n_steps must be a multiple of steps_per_graph");
+    for (int64_t i = 0; i < n_steps / h->graph_steps; ++i) HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
+  } else {
+    for (int64_t i = 0; i < n_steps; ++i) TRY(enqueue_graph_step(h));
+  }
+  (void)flags;
+  HIPCHK(h, hipEventRecord(e1, h->stream));
+  HIPCHK(h, hipEventSynchronize(e1));
+  HIPCHK(h, hipEventElapsedTime(ms_total, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return DSACT_OK;
+}
+
+int dsact_profile_step(dsact_handle* h, int64_t iteration, uint32_t flags, dsact_kernel_time* out, int32_t cap, int32_t* n) {
+  if (!h || !out || !n) return DSACT_E_INVALID;
+  TRY(check_ready(h, false));
+  if (!h->idx_table) return fail(h, DSACT_E_STATE, "upload an index table first");
+  HIPCHK(h, hipSetDevice(h->device));
+  TRY(set_device_iteration(h, iteration));
+  for (auto& r : h->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  h->prof.clear();
+  h->profiling = true;
+  int rc = enqueue_graph_step(h);
+  h->profiling = false;
+  (void)flags;
+  TRY(rc);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  int cnt = 0;
+  for (auto& r : h->prof) {
+    if (cnt >= cap) break;
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, r.e0, r.e1));
+    memset(&out[cnt], 0, sizeof(out[cnt]));
+    strncpy(out[cnt].name, r.name.c_str(), sizeof(out[cnt].name) - 1);
+    out[cnt].ms = ms;
+    out[cnt].blocks = r.blocks;
+    ++cnt;
+  }
+  *n = cnt;
+  return DSACT_OK;
+}
+
+const char* dsact_debug_names(void) {
+  return "X0,XP,X2,rew,done,eps_new,eps_2,z5,z6,logits_pi,logits_pit,logp_new,logp2,"
+         "qout_c0,qout_c1,qout_t0,qout_t1,qout_p0,qout_p1,dout0,dout1,dout2,dout3,dout_pi,d_new_act,"
+         "part_loss,part_heads,H.<chain>.<l>,G.<chain>.<l>,dZ.<chain>.<l> (chains: pi,pit,q1c,q2c,q1t,q2t,q1p,q2p)";
+}
+
+int dsact_debug_read(dsact_handle* h, const char* name, float* out, size_t cap, size_t* n) {
+  if (!h || !name || !out || !n) return DSACT_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t B = h->B, A = h->A;
+  const float* src = nullptr;
+  size_t cnt = 0;
+  std::string s(name);
+  struct E { const char* k; const float* p; size_t c; };
+  const E tab[] = {
+      {"X0", h->X0, B * h->ldx}, {"XP", h->XP, B * h->ldx}, {"X2", h->X2, B * h->ldx}, {"rew", h->rew, B}, {"done", h->done, B},
+      {"eps_new", h->eps_new, B * A}, {"eps_2", h->eps_2, B * A}, {"z5", h->z5, B}, {"z6", h->z6, B},
+      {"logits_pi", h->logits_pi, B * 2 * A}, {"logits_pit", h->logits_pit, B * 2 * A}, {"logp_new", h->logp_new, B}, {"logp2", h->logp2, B},
+      {"qout_c0", h->qout_c[0], 2 * B}, {"qout_c1", h->qout_c[1], 2 * B}, {"qout_t0", h->qout_t[0], 2 * B}, {"qout_t1", h->qout_t[1], 2 * B},
+      {"qout_p0", h->qout_p[0], 2 * B}, {"qout_p1", h->qout_p[1], 2 * B},
+      {"dout0", h->dout[0], 2 * B}, {"dout1", h->dout[1], 2 * B}, {"dout2", h->dout[2], 2 * B}, {"dout3", h->dout[3], 2 * B},
+      {"dout_pi", h->dout_pi, B * 2 * A}, {"d_new_act", h->d_new_act, B * A},
+      {"part_loss", h->part_loss, (size_t)h->n_loss_wg * kLossPart}, {"part_heads", h->part_heads, (size_t)h->n_heads_wg * 2},
+  };
+  for (const E& e : tab) if (s == e.k) { src = e.p; cnt = e.c; }
+  if (!src && s.size() > 4 && (s[0] == 'H' || s[0] == 'G' || s.compare(0, 2, "dZ") == 0)) {
+    const size_t d1 = s.find('.'), d2 = s.rfind('.');
+    if (d1 != std::string::npos && d2 != d1) {
+      const std::string kind = s.substr(0, d1), chn = s.substr(d1 + 1, d2 - d1 - 1);
+      const int l = atoi(s.c_str() + d2 + 1);
+      int ch = -1;
+      for (int c = 0; c < N_CHAIN; ++c) if (chn == kChainName[c]) ch = c;
+      if (ch >= 0 && l >= 0 && l < h->L) {
+        cnt = B * h->w[l];
+        if (kind == "H") src = h->Hb[ch][l];
+        else if (kind == "G") src = h->Gb[ch][l];
+        else if (kind == "dZ" && kDzSlot[ch] >= 0) src = h->dZ[kDzSlot[ch]][l];
+      }
+    }
+  }
+  if (!src) return fail(h, DSACT_E_INVALID, "unknown debug buffer '%s'", name);
+  if (cnt > cap) return fail(h, DSACT_E_INVALID, "debug buffer '%s' needs %zu floats, cap %zu", name, cnt, cap);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(out, src, cnt * sizeof(float), hipMemcpyDeviceToHost));
+  *n = cnt;
+  return DSACT_OK;
+}
+
+int dsact_policy_forward(dsact_handle* h, const float* obs_host, int32_t n, float* logits_host) {
+  if (!h || !obs_host || !logits_host) return DSACT_E_INVALID;
+  if (n < 1 || n > kActRows) return fail(h, DSACT_E_INVALID, "n must be 1..%d", kActRows);
+  if (!h->online) return fail(h, DSACT_E_STATE, "arenas not bound");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t O = h->O, ld = h->ldx;
+  HIPCHK(h, hipMemcpy2DAsync(h->Xact, ld * 4, obs_host, O * 4, O * 4, n, hipMemcpyHostToDevice, h->stream));
+  for (int l = 0; l < h->L; ++l) TRY(run_stage(h, h->actf[l]));
+  PolicyOutArgs a;
+  a.H = h->Hact[h->L - 1];
+  a.Wout = net_params(h, N_POL) + h->pd.w_off[h->L];
+  a.bout = net_params(h, N_POL) + h->pd.b_off[h->L];
+  a.W = h->w[h->L - 1]; a.n = n; a.A = h->A; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std; a.out = h->act_out;
+  TRY(launch(h, "policy_out", k_policy_out, dim3((n + 3) / 4), dim3(kThreads), 0, a));
+  HIPCHK(h, hipMemcpyAsync(logits_host, h->act_out, (size_t)n * 2 * h->A * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return DSACT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,860 @@
+// dsact_kernels.h -- gfx950 (MI355X / CDNA4) kernels of the DSAC-T update. HIP only, wave64.
+//
+// One update (= DSAC_V2.local_update, dsac_v2.py:102-105) is a short chain of launches:
+//   k_gather   replay rows -> minibatch staging (+ per-step bookkeeping, device RNG)
+//   k_tiles    task-table driven 32x32 output tiles on the fp32 matrix cores
+//              (v_mfma_f32_16x16x4_f32: bit-exact fmaf chain, same peak as the fp32 VALU),
+//              LDS-staged operands, fused bias+GELU / GELU' / weight-gradient epilogues
+//   k_heads    output layers + tanh-Gaussian rsample (wave per row, shuffle reductions)
+//   k_loss     twin distributional-Q target with the three DSAC-T refinements, actor/alpha loss,
+//              output-layer gradients, last-hidden-layer dZ
+//   k_heads_bwd  dQ/da -> rsample backward -> policy output-layer gradient
+//   k_adam     fused Adam (q1,q2 every step; policy, log_alpha delayed) + Polyak target sync
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dsact_math.h"
+
+namespace dsact {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// 4-byte aligned 16-byte vector: gfx950 global memory runs in unaligned-access mode, so a
+// dword-aligned dwordx4 is legal (weight rows of the Q nets have odd leading dimension O+A).
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+constexpr int kWave = 64;
+constexpr int kThreads = 256;  // 4 waves, one per SIMD
+constexpr int kMaxWidth = 1024;
+
+// ---------------------------------------------------------------------------------------------
+// device-resident step state (nothing here is read back by the host on the hot path)
+// ---------------------------------------------------------------------------------------------
+struct DevState {
+  long long it_next;   // iteration the next graph-replayed step will use (written by k_adam)
+  long long it_cur;    // iteration of the step in flight (written by the prologue)
+  long long seq_next;  // replayed-step sequence number -> row of the index table
+  int t_q, t_pi, t_alpha;  // Adam step counters (torch: state["step"])
+  int ms_init;             // 0 <=> reference sentinel mean_std == -1.0
+  float ms1, ms2;          // mean_std1/2 EMA (dsac_v2.py:233-241)
+  float ss_q, bc2_q;       // Adam scalars of the step in flight: lr/(1-b1^t), sqrt(1-b2^t)
+  float ss_pi, bc2_pi;
+  float ss_alpha, bc2_alpha;
+  int do_delayed;          // it % delay_update == 0
+  int pad;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller (production-mode noise; parity mode injects torch.randn draws)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                           uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// 4 standard normals for (stream, index/4) of iteration `it`
+__device__ __forceinline__ void normal4(uint64_t seed, long long it, uint32_t stream, uint32_t idx4, float z[4]) {
+  uint32_t r[4];
+  philox4x32(idx4, (uint32_t)it, (uint32_t)((uint64_t)it >> 32), stream, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  const float u0 = ((float)(r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u1 = ((float)(r[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = ((float)(r[2] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u3 = ((float)(r[3] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+  float s, c;
+  sincosf(6.28318530717958647692f * u1, &s, &c);
+  z[0] = ra * c; z[1] = ra * s;
+  sincosf(6.28318530717958647692f * u3, &s, &c);
+  z[2] = rb * c; z[3] = rb * s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gather: replay rows -> staging (training/replay_buffer.py:85-90 + trainer.py:72-74)
+//   X0 = [obs | act | 0pad], XP = [obs | (new_act later) ], X2 = [obs2 | (act2 later)], rew, done
+//   one wave per row; rows are 4*O bytes contiguous in the ring (coalesced dwordx4 when O%4==0)
+// block 0 additionally performs the per-step bookkeeping (see prologue_duties).
+// ---------------------------------------------------------------------------------------------
+struct StepHyper {
+  int delay_update;
+  float lr_q, lr_pi, lr_alpha, beta1, beta2;
+};
+
+__device__ void prologue_duties(DevState* st, long long it, int advance_counters, StepHyper hp) {
+  st->it_cur = it;
+  const int delayed = (it % hp.delay_update) == 0;
+  st->do_delayed = delayed;
+  if (advance_counters) {
+    const int tq = st->t_q + 1;
+    st->t_q = tq;
+    int tp = st->t_pi, ta = st->t_alpha;
+    if (delayed) { tp += 1; ta += 1; st->t_pi = tp; st->t_alpha = ta; }
+    // torch Adam: bias_correction1 = 1 - beta1**step ; step_size = lr/bias_correction1 ;
+    //             bias_correction2_sqrt = (1 - beta2**step)**0.5      (Python doubles)
+    const double b1 = (double)hp.beta1, b2 = (double)hp.beta2;
+    st->ss_q = (float)((double)hp.lr_q / (1.0 - pow(b1, (double)tq)));
+    st->bc2_q = (float)sqrt(1.0 - pow(b2, (double)tq));
+    const int tpe = tp > 0 ? tp : 1, tae = ta > 0 ? ta : 1;
+    st->ss_pi = (float)((double)hp.lr_pi / (1.0 - pow(b1, (double)tpe)));
+    st->bc2_pi = (float)sqrt(1.0 - pow(b2, (double)tpe));
+    st->ss_alpha = (float)((double)hp.lr_alpha / (1.0 - pow(b1, (double)tae)));
+    st->bc2_alpha = (float)sqrt(1.0 - pow(b2, (double)tae));
+  }
+}
+
+struct NoiseArgs {
+  uint64_t seed;  // 0: noise buffers were filled by the host (parity mode)
+  float* eps_new; float* eps_2; float* z5; float* z6;
+};
+
+// fills the noise of rows [r0, r1)
+__device__ void fill_noise_rows(const NoiseArgs& nz, long long it, int r0, int r1, int A, int tid, int nthreads) {
+  const int per_row4 = (A + 3) >> 2;
+  const int n4 = (r1 - r0) * per_row4;
+  for (int q = tid; q < n4; q += nthreads) {
+    const int r = r0 + q / per_row4, j4 = (q % per_row4) * 4;
+    float z[4];
+    normal4(nz.seed, it, 1u, (uint32_t)(r * per_row4 + j4 / 4), z);
+    for (int e = 0; e < 4; ++e) if (j4 + e < A) nz.eps_new[(size_t)r * A + j4 + e] = z[e];
+    normal4(nz.seed, it, 2u, (uint32_t)(r * per_row4 + j4 / 4), z);
+    for (int e = 0; e < 4; ++e) if (j4 + e < A) nz.eps_2[(size_t)r * A + j4 + e] = z[e];
+  }
+  for (int r = r0 + tid; r < r1; r += nthreads) {
+    float z[4];
+    normal4(nz.seed, it, 3u, (uint32_t)r, z);
+    nz.z5[r] = z[0];
+    nz.z6[r] = z[1];
+  }
+}
+
+struct GatherArgs {
+  const float* rb_obs; const float* rb_obs2; const float* rb_act; const float* rb_rew; const float* rb_done;
+  const int* idx_table;   // [rows][B]
+  int idx_rows;           // rows in the table (>=1)
+  int use_dev;            // 1: iteration / table row from DevState (graph replay); 0: host values
+  long long host_it; int host_row;
+  float* X0; float* XP; float* X2; float* rew; float* done;
+  int B, O, A, ldx;
+  DevState* st;
+  int bookkeeping;        // 1: block 0 performs prologue_duties (fused gather+step flows)
+  int advance_counters;
+  StepHyper hp;
+  NoiseArgs nz;
+};
+
+__global__ void __launch_bounds__(kThreads) k_gather(GatherArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long it = a.use_dev ? a.st->it_next : a.host_it;
+  const int trow = a.use_dev ? (int)(a.st->seq_next % a.idx_rows) : a.host_row;
+  const int r0 = blockIdx.x * 4;
+  const int r = r0 + wave;
+  if (r < a.B) {
+    const long long src = a.idx_table[(size_t)trow * a.B + r];
+    const float* so = a.rb_obs + (size_t)src * a.O;
+    const float* so2 = a.rb_obs2 + (size_t)src * a.O;
+    float* d0 = a.X0 + (size_t)r * a.ldx;
+    float* dp = a.XP + (size_t)r * a.ldx;
+    float* d2 = a.X2 + (size_t)r * a.ldx;
+    if ((a.O & 3) == 0) {
+      for (int k = lane * 4; k < a.O; k += 256) {
+        const f32x4 v = *(const f32x4*)(so + k);
+        const f32x4 w = *(const f32x4*)(so2 + k);
+        *(f32x4*)(d0 + k) = v;
+        *(f32x4*)(dp + k) = v;
+        *(f32x4*)(d2 + k) = w;
+      }
+    } else {
+      for (int k = lane; k < a.O; k += 64) {
+        const float v = so[k], w = so2[k];
+        d0[k] = v; dp[k] = v; d2[k] = w;
+      }
+    }
+    // action columns + zero padding up to ldx
+    for (int k = a.O + lane; k < a.ldx; k += 64) {
+      const int j = k - a.O;
+      const float v = j < a.A ? a.rb_act[(size_t)src * a.A + j] : 0.0f;
+      d0[k] = v;
+      if (j >= a.A) { dp[k] = 0.0f; d2[k] = 0.0f; }
+    }
+    if (lane == 0) { a.rew[r] = a.rb_rew[src]; a.done[r] = a.rb_done[src]; }
+  }
+  if (a.nz.seed != 0) {
+    const int r1 = r0 + 4 < a.B ? r0 + 4 : a.B;
+    if (r0 < a.B) fill_noise_rows(a.nz, it, r0, r1, a.A, tid, kThreads);
+  }
+  if (a.bookkeeping && blockIdx.x == 0 && tid == 0) prologue_duties(a.st, it, a.advance_counters, a.hp);
+}
+
+// stand-alone bookkeeping for the flows that do not gather (host-staged minibatch, apply-only)
+struct PrologueArgs {
+  DevState* st; int use_dev; long long host_it; int advance_counters; int fill_noise; StepHyper hp;
+  NoiseArgs nz; int B, A;
+};
+__global__ void __launch_bounds__(kThreads) k_prologue(PrologueArgs a) {
+  const long long it = a.use_dev ? a.st->it_next : a.host_it;
+  if (a.nz.seed != 0 && a.fill_noise) fill_noise_rows(a.nz, it, 0, a.B, a.A, threadIdx.x, kThreads);
+  if (threadIdx.x == 0) prologue_duties(a.st, it, a.advance_counters, a.hp);
+}
+
+// replay ring scatter (training/replay_buffer.py:58-83): n staged rows -> ring rows (ptr+i) % cap
+struct ScatterArgs {
+  const float* s_obs; const float* s_obs2; const float* s_act; const float* s_rew; const float* s_done; const float* s_logp;
+  float* rb_obs; float* rb_obs2; float* rb_act; float* rb_rew; float* rb_done; float* rb_logp;
+  long long ptr, cap; int n, O, A;
+};
+__global__ void __launch_bounds__(kThreads) k_ring_write(ScatterArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= a.n) return;
+  const long long dst = (a.ptr + i) % a.cap;
+  for (int k = lane; k < a.O; k += 64) {
+    a.rb_obs[(size_t)dst * a.O + k] = a.s_obs[(size_t)i * a.O + k];
+    a.rb_obs2[(size_t)dst * a.O + k] = a.s_obs2[(size_t)i * a.O + k];
+  }
+  for (int k = lane; k < a.A; k += 64) a.rb_act[(size_t)dst * a.A + k] = a.s_act[(size_t)i * a.A + k];
+  if (lane == 0) {
+    a.rb_rew[dst] = a.s_rew[i];
+    a.rb_done[dst] = a.s_done[i];
+    a.rb_logp[dst] = a.s_logp ? a.s_logp[i] : 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tiles: C[m][n] (+epilogue) = sum_k P(m,k) * Q(n,k) on 32x32 tiles, BK = 64
+//   operand storage: KC  element (row,k) at base[row*ld + k]   (k contiguous)
+//                    MC  element (row,k) at base[k*ld + row]   (row contiguous)
+//   forward  Z = X W^T      : P = X (KC),  Q = W (KC)          epilogue bias + GELU -> H, GELU'
+//   backward dH = dZ W      : P = dZ (KC), Q = W (MC)          epilogue * GELU'(z_prev) -> dZ_prev
+//   weights  dW = dZ^T X    : P = dZ (MC), Q = X (MC)          epilogue store (bias grads: Q = ones)
+// 4 waves: wave (wr,wc) owns a 16x16 quadrant; each lane feeds one P and one Q element per MFMA.
+// k-slot mapping: MFMA step s of a 16-wide k group contracts k = 4*(lane>>4) + s, identically for
+// both operands, so a KC fragment is ONE ds_read_b128.
+// ---------------------------------------------------------------------------------------------
+constexpr int TM = 32, TN = 32, BK = 64;
+constexpr int KC_LD = BK + 4;   // 68 floats: 16B-aligned rows, spreads ds_read_b128 over banks
+constexpr int MC_LD = TM + 4;   // 36 floats
+constexpr int TILE_LDS = BK * MC_LD;  // 2304 floats >= 32*KC_LD (2176)
+
+enum : int { EPI_GELU = 0, EPI_MULG = 1, EPI_STORE = 2 };
+enum : int { LAY_KC_KC = 0, LAY_KC_MC = 1, LAY_MC_MC = 2 };
+
+struct TileTask {
+  const float* P; const float* Q;
+  float* C0; float* C1;
+  const float* aux;     // EPI_GELU: bias[N]; EPI_MULG: G[M x ldaux]
+  int ldp, ldq, ldc, ldaux;
+  int M, N, K;
+  int m0, n0;
+  int layout, epi;
+  int pad0;
+};
+
+template <bool MC>
+__device__ __forceinline__ void tile_load(const float* __restrict__ base, int ld, int row0, int rows, int k0,
+                                          int K, int tid, f32x4 (&r)[2]) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!MC) {
+      const int row = row0 + (tid >> 4) + 16 * j;
+      const int k = k0 + (tid & 15) * 4;
+      if (row < rows && k < K) {
+        const float* p = base + (size_t)row * ld + k;
+        if (k + 3 < K) v = *(const f32x4u*)p;
+        else { v.x = p[0]; if (k + 1 < K) v.y = p[1]; if (k + 2 < K) v.z = p[2]; }
+      }
+    } else {
+      const int k = k0 + (tid >> 3) + 32 * j;
+      const int row = row0 + (tid & 7) * 4;
+      if (k < K && row < rows) {
+        const float* p = base + (size_t)k * ld + row;
+        if (row + 3 < rows) v = *(const f32x4u*)p;
+        else { v.x = p[0]; if (row + 1 < rows) v.y = p[1]; if (row + 2 < rows) v.z = p[2]; }
+      }
+    }
+    r[j] = v;
+  }
+}
+
+template <bool MC>
+__device__ __forceinline__ void tile_store_lds(float* lds, int tid, const f32x4 (&r)[2]) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (!MC) *(f32x4*)(lds + ((tid >> 4) + 16 * j) * KC_LD + (tid & 15) * 4) = r[j];
+    else *(f32x4*)(lds + ((tid >> 3) + 32 * j) * MC_LD + (tid & 7) * 4) = r[j];
+  }
+}
+
+template <bool MC>
+__device__ __forceinline__ f32x4 frag_read(const float* lds, int row, int kk, int g) {
+  if (!MC) return *(const f32x4*)(lds + row * KC_LD + kk * 16 + 4 * g);
+  f32x4 v;
+  const float* p = lds + (kk * 16 + 4 * g) * MC_LD + row;
+  v.x = p[0]; v.y = p[MC_LD]; v.z = p[2 * MC_LD]; v.w = p[3 * MC_LD];
+  return v;
+}
+
+template <bool P_MC, bool Q_MC>
+__device__ __forceinline__ void run_tile(const TileTask& t, float* lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int i = lane & 15, g = lane >> 4;
+  float* Ps[2] = {lds, lds + 2 * TILE_LDS};
+  float* Qs[2] = {lds + TILE_LDS, lds + 3 * TILE_LDS};
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 pr[2], qr[2];
+  const int T = (t.K + BK - 1) / BK;
+  tile_load<P_MC>(t.P, t.ldp, t.m0, t.M, 0, t.K, tid, pr);
+  tile_load<Q_MC>(t.Q, t.ldq, t.n0, t.N, 0, t.K, tid, qr);
+  for (int it = 0; it < T; ++it) {
+    const int b = it & 1;
+    tile_store_lds<P_MC>(Ps[b], tid, pr);
+    tile_store_lds<Q_MC>(Qs[b], tid, qr);
+    __syncthreads();
+    if (it + 1 < T) {
+      tile_load<P_MC>(t.P, t.ldp, t.m0, t.M, (it + 1) * BK, t.K, tid, pr);
+      tile_load<Q_MC>(t.Q, t.ldq, t.n0, t.N, (it + 1) * BK, t.K, tid, qr);
+    }
+    const float* ps = Ps[b];
+    const float* qs = Qs[b];
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const f32x4 p = frag_read<P_MC>(ps, wr * 16 + i, kk, g);
+      const f32x4 q = frag_read<Q_MC>(qs, wc * 16 + i, kk, g);
+      // D[row = n][col = m]: lane holds n = 4*g + reg, m = i
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.x, p.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.y, p.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.z, p.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.w, p.w, acc1, 0, 0, 0);
+    }
+  }
+  const f32x4 acc = acc0 + acc1;
+  const int m = t.m0 + wr * 16 + i;
+  const int n = t.n0 + wc * 16 + 4 * g;
+  if (m >= t.M || n >= t.N) return;
+  const bool full = (n + 3 < t.N);
+  if (t.epi == EPI_GELU) {
+    f32x4 h, gd;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float z = acc[e] + (n + e < t.N ? t.aux[n + e] : 0.0f);
+      float hh, gg;
+      gelu_fwd_grad(z, hh, gg);
+      h[e] = hh; gd[e] = gg;
+    }
+    float* c0 = t.C0 + (size_t)m * t.ldc + n;
+    float* c1 = t.C1 + (size_t)m * t.ldc + n;
+    if (full) { *(f32x4u*)c0 = h; *(f32x4u*)c1 = gd; }
+    else for (int e = 0; e < 4 && n + e < t.N; ++e) { c0[e] = h[e]; c1[e] = gd[e]; }
+  } else if (t.epi == EPI_MULG) {
+    const float* gp = t.aux + (size_t)m * t.ldaux + n;
+    float* c0 = t.C0 + (size_t)m * t.ldc + n;
+    if (full) {
+      const f32x4 gv = *(const f32x4u*)gp;
+      *(f32x4u*)c0 = acc * gv;
+    } else for (int e = 0; e < 4 && n + e < t.N; ++e) c0[e] = acc[e] * gp[e];
+  } else {
+    float* c0 = t.C0 + (size_t)m * t.ldc + n;
+    if (full) *(f32x4u*)c0 = acc;
+    else for (int e = 0; e < 4 && n + e < t.N; ++e) c0[e] = acc[e];
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) k_tiles(const TileTask* __restrict__ tasks) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * TILE_LDS];
+  const TileTask t = tasks[blockIdx.x];
+  if (t.layout == LAY_KC_KC) run_tile<false, false>(t, lds);
+  else if (t.layout == LAY_KC_MC) run_tile<false, true>(t, lds);
+  else run_tile<true, true>(t, lds);
+}
+
+// ---------------------------------------------------------------------------------------------
+// row-vector helpers for the narrow output layers (N_out = 2 or 2A): one wave per row, the row
+// lives in registers (float4 per lane per 256-chunk), each output is one shuffle reduction.
+// ---------------------------------------------------------------------------------------------
+struct RowRegs { f32x4 v[kMaxWidth / 256]; };
+
+__device__ __forceinline__ void row_load(const float* x, int W, int lane, RowRegs& r) {
+#pragma unroll
+  for (int c = 0; c < kMaxWidth / 256; ++c) {
+    const int k = c * 256 + lane * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (k + 3 < W) v = *(const f32x4u*)(x + k);
+    else if (k < W) { v.x = x[k]; if (k + 1 < W) v.y = x[k + 1]; if (k + 2 < W) v.z = x[k + 2]; }
+    r.v[c] = v;
+  }
+}
+__device__ __forceinline__ float row_dot(const RowRegs& r, const float* w, int W, int lane) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < kMaxWidth / 256; ++c) {
+    const int k = c * 256 + lane * 4;
+    if (k + 3 < W) {
+      const f32x4 wv = *(const f32x4u*)(w + k);
+      s += r.v[c].x * wv.x; s += r.v[c].y * wv.y; s += r.v[c].z * wv.z; s += r.v[c].w * wv.w;
+    } else if (k < W) {
+      s += r.v[c].x * w[k];
+      if (k + 1 < W) s += r.v[c].y * w[k + 1];
+      if (k + 2 < W) s += r.v[c].z * w[k + 2];
+    }
+  }
+  return wave_sum(s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_heads: output layers of policy(obs), policy_target(obs2), q1(obs,act), q2(obs,act)
+//   policy chains: logits -> (mu, raw) -> rsample (act_distribution_cls.py:44-54) -> action into
+//   the action columns of XP (policy) / X2 (policy_target), log-prob.
+//   grid (ceil(B/4), 4): y = 0 policy, 1 policy_target, 2 q1, 3 q2.
+// ---------------------------------------------------------------------------------------------
+struct HeadsArgs {
+  const float* H[4];      // last hidden activations [B x W]
+  const float* Wout[4];   // [n_out x W]
+  const float* bout[4];
+  int W, B, O, A, ldx;
+  const float* eps_new; const float* eps_2;
+  float* XP; float* X2;
+  float* logits_pi;   // [B x 2A] (mu | raw log-std) of policy(obs), kept for the backward
+  float* logits_pit;  // [B x 2A] same for policy_target(obs2) (debug / parity only)
+  float* logp_new; float* logp2;
+  float* qout[2];     // raw (mean, pre-softplus std) of q1/q2(obs,act)  [B x 2]
+  float* part_heads;  // [gridDim.x][2]: sum tanh(mu), sum sigma  (policy chain)
+  const float* act_scale; const float* act_center;  // (hi-lo)/2, (hi+lo)/2
+  float lo_ls, hi_ls;
+};
+
+__global__ void __launch_bounds__(kThreads) k_heads(HeadsArgs a) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chain = blockIdx.y;
+  const int r = blockIdx.x * 4 + wave;
+  const bool active = r < a.B;
+  float s_tanh = 0.f, s_sig = 0.f;
+  if (active) {
+    RowRegs h;
+    row_load(a.H[chain] + (size_t)r * a.W, a.W, lane, h);
+    if (chain >= 2) {
+      const float o0 = row_dot(h, a.Wout[chain], a.W, lane) + a.bout[chain][0];
+      const float o1 = row_dot(h, a.Wout[chain] + a.W, a.W, lane) + a.bout[chain][1];
+      if (lane == 0) { a.qout[chain - 2][2 * r] = o0; a.qout[chain - 2][2 * r + 1] = o1; }
+    } else {
+      const int A = a.A;
+      float mine = 0.f;  // lane n keeps logits[n]
+      for (int n = 0; n < 2 * A; ++n) {
+        const float o = row_dot(h, a.Wout[chain] + (size_t)n * a.W, a.W, lane) + a.bout[chain][n];
+        if (lane == n) mine = o;
+      }
+      const float raw = __shfl(mine, lane + A, 64);  // lane j < A: raw log-std of dim j
+      float lp = 0.f;
+      if (lane < A) {
+        const float eps = (chain == 0 ? a.eps_new : a.eps_2)[(size_t)r * A + lane];
+        const TanhGaussFwd f = tanh_gauss_fwd(mine, raw, eps, a.act_scale[lane], a.act_center[lane], a.lo_ls, a.hi_ls);
+        lp = f.lp;
+        float* X = chain == 0 ? a.XP : a.X2;
+        X[(size_t)r * a.ldx + a.O + lane] = f.a;
+        if (chain == 0) { s_tanh = tanhf(mine); s_sig = f.sigma; }
+      }
+      float* lg = chain == 0 ? a.logits_pi : a.logits_pit;
+      if (lane < 2 * A) lg[(size_t)r * 2 * A + lane] = mine;
+      lp = wave_sum(lp);
+      if (lane == 0) (chain == 0 ? a.logp_new : a.logp2)[r] = lp;
+    }
+  }
+  if (chain == 0) {
+    s_tanh = wave_sum(s_tanh);
+    s_sig = wave_sum(s_sig);
+    if (lane == 0) { red[wave] = s_tanh; red[4 + wave] = s_sig; }
+    __syncthreads();
+    if (tid == 0) {
+      a.part_heads[2 * blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+      a.part_heads[2 * blockIdx.x + 1] = red[4] + red[5] + red[6] + red[7];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_loss: dsac_v2.py:218-318 for the rows of this workgroup.
+//   phase 1  batch means of std1/std2 (every workgroup, redundantly: 2B floats) -> mean_std EMA
+//   phase 2  output layers of q1_t,q2_t(obs2,act2) and q1,q2(obs,new_act)   (wave per row)
+//   phase 3  per-sample targets / ratio / losses -> dL/d(out) of the 4 differentiated chains
+//   phase 4  dZ of the last hidden layer of those chains: (dOut . Wout) * GELU'(z)
+// part_loss[wg][12]: loss_q1, loss_q2, sum q1, q2, std1, std2, actor, logp_new, then [10],[11] =
+// min std1, min std2 (reduced with min).
+// ---------------------------------------------------------------------------------------------
+constexpr int kLossPart = 12;
+struct LossArgs {
+  const float* Hl[4];    // last hidden activations of q1_t, q2_t, q1(obs,new_act), q2(obs,new_act)
+  const float* Wout[4];  // out weights: q1_target, q2_target, q1, q2   [2 x W]
+  const float* bout[4];
+  const float* Gl[4];    // GELU' of the last hidden layer of q1c, q2c, q1p, q2p
+  float* dZl[4];         // dZ (last hidden) of q1c, q2c, q1p, q2p
+  const float* Wq[2];    // out weights of q1, q2 (online)  [2 x W]
+  const float* qout_c[2];  // raw outs q1(obs,act), q2(obs,act)  [B x 2]
+  float* qout_t[2];        // raw outs of the targets (debug)      [B x 2]
+  float* qout_p[2];        // raw outs q(obs,new_act)   (debug)     [B x 2]
+  float* dout[4];          // dL/d(out) [B x 2]: q1c, q2c, q1p, q2p
+  const float* rew; const float* done; const float* logp2; const float* logp_new;
+  const float* z5; const float* z6;
+  const float* log_alpha;
+  float* part_loss;
+  float* grads_tail;       // [2] updated mean_std1/2 (re-synchronised by the gradient all-reduce)
+  const DevState* st;
+  int W, B, rows_per_wg;
+  float inv_B;             // 1 / local batch
+  float inv_Bg;            // 1 / global batch   (mean of std for the EMA; == inv_B on one GPU)
+  const float* std_sums;   // strict data-parallel mode: all-reduced {sum std1, sum std2}; NULL otherwise
+  int auto_alpha; float alpha_fixed, gamma, tau_b;
+};
+
+__global__ void __launch_bounds__(kThreads) k_loss(LossArgs a) {
+  __shared__ float red[4 * kLossPart];
+  __shared__ float sh_ms[2];
+  extern __shared__ float dyn[];  // [rows_per_wg][16]: raw outs (8) and dL/d(out) (8) of the 4 chains, my rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r_begin = blockIdx.x * a.rows_per_wg;
+  const int r_end = min(r_begin + a.rows_per_wg, a.B);
+  // ---- phase 1 ----
+  float s1 = 0.f, s2 = 0.f;
+  if (a.std_sums == nullptr) {
+    for (int r = tid; r < a.B; r += kThreads) {
+      s1 += softplus(a.qout_c[0][2 * r + 1]);
+      s2 += softplus(a.qout_c[1][2 * r + 1]);
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) { red[wave] = s1; red[4 + wave] = s2; }
+    __syncthreads();
+    s1 = red[0] + red[1] + red[2] + red[3];
+    s2 = red[4] + red[5] + red[6] + red[7];
+  } else { s1 = a.std_sums[0]; s2 = a.std_sums[1]; }
+  if (tid == 0) {
+    const float m1 = s1 * a.inv_Bg, m2 = s2 * a.inv_Bg;
+    float ms1, ms2;
+    if (!a.st->ms_init) { ms1 = m1; ms2 = m2; }
+    else {
+      const float c1 = 1.0f - a.tau_b;  // (1 - tau_b) as fp32 scalar
+      ms1 = c1 * a.st->ms1 + a.tau_b * m1;
+      ms2 = c1 * a.st->ms2 + a.tau_b * m2;
+    }
+    sh_ms[0] = ms1; sh_ms[1] = ms2;
+    if (blockIdx.x == 0) { a.grads_tail[0] = ms1; a.grads_tail[1] = ms2; }
+  }
+  __syncthreads();
+  const float ms1 = sh_ms[0], ms2 = sh_ms[1];
+  const float alpha = a.auto_alpha ? expf(a.log_alpha[0]) : a.alpha_fixed;
+  // ---- phase 2 ----
+  for (int r = r_begin + wave; r < r_end; r += 4) {
+    for (int c = 0; c < 4; ++c) {
+      RowRegs h;
+      row_load(a.Hl[c] + (size_t)r * a.W, a.W, lane, h);
+      const float o0 = row_dot(h, a.Wout[c], a.W, lane) + a.bout[c][0];
+      const float o1 = row_dot(h, a.Wout[c] + a.W, a.W, lane) + a.bout[c][1];
+      if (lane == 0) {
+        dyn[(r - r_begin) * 16 + 2 * c] = o0;
+        dyn[(r - r_begin) * 16 + 2 * c + 1] = o1;
+        float* dbg = c < 2 ? a.qout_t[c] : a.qout_p[c - 2];
+        dbg[2 * r] = o0; dbg[2 * r + 1] = o1;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 3 ----
+  float acc[kLossPart];
+#pragma unroll
+  for (int k = 0; k < kLossPart; ++k) acc[k] = 0.f;
+  acc[10] = INFINITY; acc[11] = INFINITY;
+  for (int r = r_begin + tid; r < r_end; r += kThreads) {
+    float* o = dyn + (r - r_begin) * 16;
+    const float q1 = a.qout_c[0][2 * r], raw1 = a.qout_c[0][2 * r + 1];
+    const float q2 = a.qout_c[1][2 * r], raw2 = a.qout_c[1][2 * r + 1];
+    const float std1 = softplus(raw1), std2 = softplus(raw2);
+    const float q1n = o[0], std1n = softplus(o[1]);
+    const float q2n = o[2], std2n = softplus(o[3]);
+    const float qn = fminf(q1n, q2n);
+    const float z5 = clampf(a.z5[r], -3.f, 3.f), z6 = clampf(a.z6[r], -3.f, 3.f);
+    const float qs = (q1n < q2n) ? (q1n + z5 * std1n) : (q2n + z6 * std2n);
+    const float rew = a.rew[r], nd = 1.0f - a.done[r];
+    const float lp2 = a.logp2[r];
+    const float tq = rew + nd * a.gamma * (qn - alpha * lp2);
+    const float tqs = rew + nd * a.gamma * (qs - alpha * lp2);
+    const CriticTerm c1 = critic_term(q1, std1, ms1, tq, tqs);
+    const CriticTerm c2 = critic_term(q2, std2, ms2, tq, tqs);
+    float dv[8];
+    dv[0] = c1.dq * a.inv_B;
+    dv[1] = c1.dstd * a.inv_B * softplus_grad(raw1);
+    dv[2] = c2.dq * a.inv_B;
+    dv[3] = c2.dstd * a.inv_B * softplus_grad(raw2);
+    // actor: mean(alpha*logp_new - min(q1p, q2p)); torch.min ties split the gradient evenly
+    const float q1p = o[4], q2p = o[6];
+    const float lpn = a.logp_new[r];
+    const float w1 = q1p < q2p ? 1.0f : (q1p > q2p ? 0.0f : 0.5f);
+    dv[4] = -w1 * a.inv_B; dv[5] = 0.0f;
+    dv[6] = -(1.0f - w1) * a.inv_B; dv[7] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      a.dout[c][2 * r] = dv[2 * c]; a.dout[c][2 * r + 1] = dv[2 * c + 1];
+      o[8 + 2 * c] = dv[2 * c]; o[8 + 2 * c + 1] = dv[2 * c + 1];
+    }
+    acc[0] += c1.loss; acc[1] += c2.loss;
+    acc[2] += q1; acc[3] += q2; acc[4] += std1; acc[5] += std2;
+    acc[6] += alpha * lpn - fminf(q1p, q2p);
+    acc[7] += lpn;
+    acc[10] = fminf(acc[10], std1); acc[11] = fminf(acc[11], std2);
+  }
+#pragma unroll
+  for (int k = 0; k < kLossPart; ++k) {
+    const float v = k < 10 ? wave_sum(acc[k]) : wave_min(acc[k]);
+    if (lane == 0) red[wave * kLossPart + k] = v;
+  }
+  __syncthreads();
+  if (tid < kLossPart) {
+    const float v0 = red[tid], v1 = red[kLossPart + tid], v2 = red[2 * kLossPart + tid], v3 = red[3 * kLossPart + tid];
+    a.part_loss[blockIdx.x * kLossPart + tid] = tid < 10 ? (v0 + v1) + (v2 + v3) : fminf(fminf(v0, v1), fminf(v2, v3));
+  }
+  // ---- phase 4 ---- (dL/d(out) of my rows is staged in LDS)
+  __syncthreads();
+  const int W4 = (a.W + 3) >> 2;
+  const int total = 4 * (r_end - r_begin) * W4;
+  for (int e = tid; e < total; e += kThreads) {
+    const int c = e / ((r_end - r_begin) * W4);
+    const int rem = e - c * (r_end - r_begin) * W4;
+    const int r = r_begin + rem / W4, k = (rem % W4) * 4;
+    const float d0 = dyn[(r - r_begin) * 16 + 8 + 2 * c], d1 = dyn[(r - r_begin) * 16 + 9 + 2 * c];
+    const float* w0 = a.Wq[c & 1] + k;
+    const float* w1 = a.Wq[c & 1] + a.W + k;
+    const float* gp = a.Gl[c] + (size_t)r * a.W + k;
+    float* dz = a.dZl[c] + (size_t)r * a.W + k;
+    if (k + 3 < a.W) {
+      const f32x4 wv0 = *(const f32x4u*)w0, wv1 = *(const f32x4u*)w1, gv = *(const f32x4u*)gp;
+      f32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = (d0 * wv0[q] + d1 * wv1[q]) * gv[q];
+      *(f32x4u*)dz = o;
+    } else {
+      for (int q = 0; q < 4 && k + q < a.W; ++q) dz[q] = (d0 * w0[q] + d1 * w1[q]) * gp[q];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_heads_bwd: actor path between the Q nets' first layer and the policy's last hidden layer.
+//   dA[r][j]   = sum_k dZ1_q1p[r][k] W1_q1[k][O+j] + sum_k dZ1_q2p[r][k] W1_q2[k][O+j]
+//   (dmu,draw) = tanh-Gaussian rsample backward with dL/dlogp = alpha/B     (App. A.3)
+//   dZ_pi_last = ((dmu|draw) . Wout_pi) * GELU'(z_last)
+// one wave per row.
+// ---------------------------------------------------------------------------------------------
+struct HeadsBwdArgs {
+  const float* dZ1[2];     // [B x W0] first-hidden dZ of q1(obs,new_act), q2(obs,new_act)
+  const float* W1[2];      // q1/q2 first-layer weights [W0 x (O+A)]
+  int W0, ld1;             // ld1 = O + A
+  const float* logits_pi;  // [B x 2A]
+  const float* eps_new;
+  const float* log_alpha;
+  const float* Wout_pi;    // [2A x WL]
+  const float* G_pi;       // GELU' of the policy's last hidden layer [B x WL]
+  float* dZ_pi;            // [B x WL]
+  float* dout_pi;          // [B x 2A]
+  float* d_new_act;        // [B x A] (debug / parity)
+  int WL, B, O, A;
+  float inv_B; int auto_alpha; float alpha_fixed;
+  const float* act_scale; float lo_ls, hi_ls;
+};
+
+__global__ void __launch_bounds__(kThreads) k_heads_bwd(HeadsBwdArgs a) {
+  __shared__ float sh_dout[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= a.B) return;  // whole wave exits together; no block-level barrier below
+  const int A = a.A;
+  float dA = 0.f;  // lane j < A keeps dL/d new_act[j]
+  for (int net = 0; net < 2; ++net) {
+    float accj[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) accj[j] = 0.f;
+    const float* dz = a.dZ1[net] + (size_t)r * a.W0;
+    for (int k = lane; k < a.W0; k += 64) {
+      const float d = dz[k];
+      const float* w = a.W1[net] + (size_t)k * a.ld1 + a.O;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) if (j < A) accj[j] += d * w[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      if (j < A) {
+        const float s = wave_sum(accj[j]);
+        if (lane == j) dA += s;
+      }
+    }
+  }
+  const float alpha = a.auto_alpha ? expf(a.log_alpha[0]) : a.alpha_fixed;
+  float dmu = 0.f, draw = 0.f;
+  if (lane < A) {
+    const float mu = a.logits_pi[(size_t)r * 2 * A + lane];
+    const float raw = a.logits_pi[(size_t)r * 2 * A + A + lane];
+    const float eps = a.eps_new[(size_t)r * A + lane];
+    tanh_gauss_bwd(mu, raw, eps, a.act_scale[lane], a.lo_ls, a.hi_ls, dA, alpha * a.inv_B, dmu, draw);
+    a.dout_pi[(size_t)r * 2 * A + lane] = dmu;
+    a.dout_pi[(size_t)r * 2 * A + A + lane] = draw;
+    a.d_new_act[(size_t)r * A + lane] = dA;
+    sh_dout[wave][lane] = dmu;
+    sh_dout[wave][A + lane] = draw;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  // dZ of the policy's last hidden layer
+  for (int k = lane * 4; k < a.WL; k += 256) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const bool full = k + 3 < a.WL;
+    for (int n = 0; n < 2 * A; ++n) {
+      const float d = sh_dout[wave][n];
+      const float* w = a.Wout_pi + (size_t)n * a.WL + k;
+      if (full) { const f32x4 wv = *(const f32x4u*)w; s += d * wv; }
+      else for (int q = 0; q < 4 && k + q < a.WL; ++q) s[q] += d * w[q];
+    }
+    const float* gp = a.G_pi + (size_t)r * a.WL + k;
+    float* dz = a.dZ_pi + (size_t)r * a.WL + k;
+    if (full) { const f32x4 gv = *(const f32x4u*)gp; *(f32x4u*)dz = s * gv; }
+    else for (int q = 0; q < 4 && k + q < a.WL; ++q) dz[q] = s[q] * gp[q];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_finalize_grads: alpha gradient (dsac_v2.py:312-318) from the per-workgroup partial sums.
+//   d loss_alpha / d log_alpha = -mean(logp_new + target_entropy)
+// ---------------------------------------------------------------------------------------------
+struct FinalizeArgs {
+  const float* part_loss; int n_part; float inv_B; float target_entropy; float* grad_log_alpha; int auto_alpha;
+};
+__global__ void k_finalize_grads(FinalizeArgs a) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < a.n_part; i += 64) s += a.part_loss[i * kLossPart + 7];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) a.grad_log_alpha[0] = a.auto_alpha ? -(s * a.inv_B + a.target_entropy) : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_adam: DSAC_V2.__update (dsac_v2.py:320-347) as one streaming pass over the flat arenas.
+// ---------------------------------------------------------------------------------------------
+struct AdamArgs {
+  float* p; float* tgt; float* m; float* v; const float* g;
+  long long n_q2;      // floats in q1|q2
+  long long n_online3; // floats in q1|q2|policy
+  long long n_total;   // + log_alpha
+  DevState* st;
+  float b1w, beta2, b2w, eps;
+  float polyak, one_minus_polyak;
+  int auto_alpha;
+  int commit_ms;       // 1: take mean_std from g[n_total..n_total+1]
+};
+
+__global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
+  const DevState st = *a.st;
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < a.n_total; i += stride) {
+    bool upd; float ss, bc2;
+    if (i < a.n_q2) { upd = true; ss = st.ss_q; bc2 = st.bc2_q; }
+    else if (i < a.n_online3) { upd = st.do_delayed != 0; ss = st.ss_pi; bc2 = st.bc2_pi; }
+    else { upd = st.do_delayed != 0 && a.auto_alpha; ss = st.ss_alpha; bc2 = st.bc2_alpha; }
+    float p = a.p[i];
+    if (upd) {
+      float m = a.m[i], v = a.v[i];
+      adam_update(p, m, v, a.g[i], a.b1w, a.beta2, a.b2w, ss, bc2, a.eps);
+      a.p[i] = p; a.m[i] = m; a.v[i] = v;
+    }
+    if (st.do_delayed && i < a.n_online3) a.tgt[i] = polyak_update(a.tgt[i], p, a.polyak, a.one_minus_polyak);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (a.commit_ms) { a.st->ms1 = a.g[a.n_total]; a.st->ms2 = a.g[a.n_total + 1]; a.st->ms_init = 1; }
+    a.st->it_next = st.it_cur + 1;
+    a.st->seq_next = st.seq_next + 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_stats: the 14 numeric tb_info entries (dsac_v2.py:188-202) from the partial sums; launched
+// only when the host asks (trainer logs every log_save_interval iterations).
+// ---------------------------------------------------------------------------------------------
+struct StatsArgs {
+  const float* part_loss; int n_loss; const float* part_heads; int n_heads;
+  const float* log_alpha; const DevState* st; float inv_B; float inv_BA; int auto_alpha; float alpha_fixed;
+  float* out;  // [16]
+};
+__global__ void k_stats(StatsArgs a) {
+  const int lane = threadIdx.x;
+  float s[kLossPart];
+  for (int k = 0; k < kLossPart; ++k) s[k] = k < 10 ? 0.f : INFINITY;
+  for (int i = lane; i < a.n_loss; i += 64)
+    for (int k = 0; k < kLossPart; ++k) {
+      const float v = a.part_loss[i * kLossPart + k];
+      s[k] = k < 10 ? s[k] + v : fminf(s[k], v);
+    }
+  for (int k = 0; k < kLossPart; ++k) s[k] = k < 10 ? wave_sum(s[k]) : wave_min(s[k]);
+  float h0 = 0.f, h1 = 0.f;
+  for (int i = lane; i < a.n_heads; i += 64) { h0 += a.part_heads[2 * i]; h1 += a.part_heads[2 * i + 1]; }
+  h0 = wave_sum(h0); h1 = wave_sum(h1);
+  if (lane == 0) {
+    float* o = a.out;
+    o[0] = s[2] * a.inv_B; o[1] = s[3] * a.inv_B; o[2] = s[4] * a.inv_B; o[3] = s[5] * a.inv_B;
+    o[4] = s[10]; o[5] = s[11];
+    o[6] = s[6] * a.inv_B;
+    o[7] = s[0] * a.inv_B + s[1] * a.inv_B;
+    o[8] = h0 * a.inv_BA; o[9] = h1 * a.inv_BA;
+    o[10] = -(s[7] * a.inv_B);
+    o[11] = a.auto_alpha ? expf(a.log_alpha[0]) : a.alpha_fixed;
+    o[12] = a.st->ms1; o[13] = a.st->ms2;
+    o[14] = (float)a.st->it_cur; o[15] = 0.f;
+  }
+}
+
+// strict data-parallel mode: local {sum std1, sum std2} for the pre-loss all-reduce
+struct StdSumArgs { const float* qout_c[2]; int B; float* out; };
+__global__ void __launch_bounds__(kThreads) k_std_sums(StdSumArgs a) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float s1 = 0.f, s2 = 0.f;
+  for (int r = tid; r < a.B; r += kThreads) {
+    s1 += softplus(a.qout_c[0][2 * r + 1]);
+    s2 += softplus(a.qout_c[1][2 * r + 1]);
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (lane == 0) { red[wave] = s1; red[4 + wave] = s2; }
+  __syncthreads();
+  if (tid == 0) { a.out[0] = red[0] + red[1] + red[2] + red[3]; a.out[1] = red[4] + red[5] + red[6] + red[7]; }
+}
+
+// policy head only (sampler / evaluator feed): logits (mean | std) as StochaPolicy.forward returns
+struct PolicyOutArgs { const float* H; const float* Wout; const float* bout; int W, n, A; float lo_ls, hi_ls; float* out; };
+__global__ void __launch_bounds__(kThreads) k_policy_out(PolicyOutArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= a.n) return;
+  RowRegs h;
+  row_load(a.H + (size_t)r * a.W, a.W, lane, h);
+  for (int n = 0; n < 2 * a.A; ++n) {
+    float o = row_dot(h, a.Wout + (size_t)n * a.W, a.W, lane) + a.bout[n];
+    if (n >= a.A) o = expf(clampf(o, a.lo_ls, a.hi_ls));
+    if (lane == 0) a.out[(size_t)r * 2 * a.A + n] = o;
+  }
+}
+
+}  // namespace dsact

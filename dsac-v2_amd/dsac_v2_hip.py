@@ -1,0 +1,454 @@
+"""DSAC_V2_HIP -- drop-in algorithm plugin for the DSAC-T update on MI355X.
+
+Discovered exactly like the reference's algorithms: `create_alg(algorithm="DSAC_V2_HIP", **kwargs)`
+imports module `dsac_v2_hip` and instantiates class `DSAC_V2_HIP`; samplers / evaluators / the
+PolicyRunner re-import `ApproxContainer` from the same module (reference
+utils/initialization.py:48-63, training/off_sampler.py:19-23, training/evaluator.py:16-20,
+utils/sys_run.py:574-578). The surface mirrors reference dsac_v2.py:19-138:
+
+    .networks            ApproxContainer (nn.Module; state_dict keys/order == reference App. C)
+    .local_update(data, iteration) -> dict with the 15 tb_info keys (dsac_v2.py:188-204)
+    .get_remote_update_info(data, iteration) -> (tb_info, update_info)
+    .remote_update(update_info)
+    .adjustable_parameters
+
+All arithmetic of the update runs in libdsact.so (hand-written gfx950 kernels, C-ABI in
+include/dsact.h). torch owns the parameter/optimizer arenas and the checkpoint I/O only. There is no
+CPU fallback for the update: constructing DSAC_V2_HIP without the library or without a GPU raises.
+"""
+__all__ = ["ApproxContainer", "DSAC_V2_HIP", "TanhGaussDistribution"]
+
+import copy
+import math
+import os
+import sys
+import time
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+if _PKG not in sys.path:
+    sys.path.insert(0, _PKG)
+
+from dsact.engine import STAT_KEYS, DsactEngine, register_engine  # noqa: E402
+from dsact.layout import ArenaLayout  # noqa: E402
+
+ALG_TIME_KEY = "Time/Algorithm time [ms]-RL iter"  # reference utils/tensorboard_setup.py:149
+_LOG_EPS = 1e-6  # reference utils/act_distribution_cls.py:3
+
+
+# --------------------------------------------------------------------------------------------------
+# action distribution (host side, tiny tensors: acting / evaluation only)
+# --------------------------------------------------------------------------------------------------
+class TanhGaussDistribution:
+    """tanh-squashed diagonal Gaussian with the interface the reference's samplers use
+    (utils/act_distribution_cls.py:21-79): sample / rsample / log_prob / mode / entropy."""
+
+    def __init__(self, logits: torch.Tensor):
+        self.logits = logits
+        self.mean, self.std = torch.chunk(logits, chunks=2, dim=-1)
+        self.act_high_lim = torch.tensor([1.0])
+        self.act_low_lim = torch.tensor([-1.0])
+
+    def _half_range(self):
+        return (self.act_high_lim - self.act_low_lim) / 2
+
+    def _center(self):
+        return (self.act_high_lim + self.act_low_lim) / 2
+
+    def _base_log_prob(self, x):
+        var = self.std ** 2
+        return (-((x - self.mean) ** 2) / (2 * var) - self.std.log() - math.log(math.sqrt(2 * math.pi))).sum(-1)
+
+    def _squash(self, x):
+        t = torch.tanh(x)
+        act = self._half_range() * t + self._center()
+        logp = (self._base_log_prob(x) - torch.log(1 + _LOG_EPS - t.pow(2)).sum(-1)
+                - torch.log(self._half_range()).sum(-1))
+        return act, logp
+
+    def sample(self):
+        with torch.no_grad():
+            x = torch.normal(self.mean, self.std)  # same generator consumption as Normal.sample
+        return self._squash(x)
+
+    def rsample(self):
+        eps = torch.randn(self.mean.shape, dtype=self.mean.dtype, device=self.mean.device)
+        return self._squash(self.mean + eps * self.std)
+
+    def log_prob(self, action_limited):
+        x = torch.atanh((1 - _LOG_EPS) * (2 * action_limited - (self.act_high_lim + self.act_low_lim))
+                        / (self.act_high_lim - self.act_low_lim))
+        return self._base_log_prob(x) - torch.log(
+            (self.act_high_lim - self.act_low_lim) * (1 + _LOG_EPS - torch.tanh(x).pow(2))).sum(-1)
+
+    def entropy(self):
+        return (0.5 + 0.5 * math.log(2 * math.pi) + torch.log(self.std)).sum(-1)
+
+    def mode(self):
+        return self._half_range() * torch.tanh(self.mean) + self._center()
+
+
+# --------------------------------------------------------------------------------------------------
+# networks: torch modules whose parameters become views of the HIP arenas once attached
+# --------------------------------------------------------------------------------------------------
+def _mlp(sizes):
+    layers = []
+    for j in range(len(sizes) - 1):
+        layers.append(nn.Linear(sizes[j], sizes[j + 1]))
+        layers.append(nn.GELU() if j < len(sizes) - 2 else nn.Identity())
+    return nn.Sequential(*layers)
+
+
+class HipActionValueDistri(nn.Module):
+    """Distributional Q(s,a) -> (mean, std); parameter names as reference networks/mlp.py:109-127."""
+
+    def __init__(self, obs_dim, act_dim, hidden):
+        super().__init__()
+        self.q = _mlp([obs_dim + act_dim] + list(hidden) + [2])
+
+    def forward(self, obs, act):
+        out = self.q(torch.cat([obs, act], dim=-1))
+        return torch.cat((out[..., :1], nn.functional.softplus(out[..., 1:])), dim=-1)
+
+
+class HipStochaPolicy(nn.Module):
+    """Stochastic policy obs -> (mean | std); parameter names as reference networks/mlp.py:28-100."""
+
+    def __init__(self, obs_dim, act_dim, hidden, act_high, act_low, min_log_std, max_log_std):
+        super().__init__()
+        self.policy = _mlp([obs_dim] + list(hidden) + [2 * act_dim])
+        self.min_log_std, self.max_log_std = float(min_log_std), float(max_log_std)
+        self.register_buffer("act_high_lim", torch.from_numpy(np.asarray(act_high, dtype=np.float32).copy()))
+        self.register_buffer("act_low_lim", torch.from_numpy(np.asarray(act_low, dtype=np.float32).copy()))
+        self._engine = None  # set by ApproxContainer.attach for the ONLINE policy only
+
+    def forward(self, obs):
+        if self._engine is not None:
+            # parameters live in the HIP arena: the fused-MLP kernels serve the forward
+            lg = self._engine.policy_forward(obs.detach().cpu().numpy())
+            return torch.from_numpy(lg).reshape(*obs.shape[:-1], lg.shape[-1]).to(obs.device)
+        out = self.policy(obs)
+        mean, log_std = torch.chunk(out, chunks=2, dim=-1)
+        return torch.cat((mean, torch.clamp(log_std, self.min_log_std, self.max_log_std).exp()), dim=-1)
+
+    def get_act_dist(self, logits):
+        dist = TanhGaussDistribution(logits)
+        dist.act_high_lim = self.act_high_lim.to(logits.device)
+        dist.act_low_lim = self.act_low_lim.to(logits.device)
+        return dist
+
+
+def _hidden_sizes(kwargs):
+    hv, hp = list(kwargs["value_hidden_sizes"]), list(kwargs["policy_hidden_sizes"])
+    if hv != hp:
+        raise NotImplementedError("DSAC_V2_HIP needs value_hidden_sizes == policy_hidden_sizes (got %s / %s)" % (hv, hp))
+    return hv
+
+
+def _check_supported(kwargs):
+    for key, want in (("value_func_type", "MLP"), ("policy_func_type", "MLP"),
+                      ("value_hidden_activation", "gelu"), ("policy_hidden_activation", "gelu"),
+                      ("value_output_activation", "linear"), ("policy_output_activation", "linear"),
+                      ("policy_act_distribution", "TanhGaussDistribution")):
+        got = kwargs.get(key, want)
+        if got != want:
+            raise NotImplementedError("DSAC_V2_HIP supports %s=%r only (got %r)" % (key, want, got))
+    if kwargs.get("cnn_shared", False):
+        raise NotImplementedError("cnn_shared is not supported by the HIP path")
+    if kwargs.get("policy_std_type", "mlp_shared") != "mlp_shared":
+        raise NotImplementedError("policy_std_type must be mlp_shared")
+
+
+class ApproxContainer(nn.Module):
+    """Same members, registration order and state_dict keys as reference dsac_v2.py:19-62.
+
+    Stand-alone it is a plain CPU torch module (samplers / evaluators / PolicyRunner build their own
+    copies and load checkpoints into them). `attach(engine)` (done by DSAC_V2_HIP) re-homes every
+    parameter as a VIEW into the engine's flat HBM arenas, after which the HIP kernels update the
+    storage in place and `state_dict()/load_state_dict()/torch.save` keep working unchanged.
+    """
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        _check_supported(kwargs)
+        hidden = _hidden_sizes(kwargs)
+        O, A = int(kwargs["obsv_dim"]), int(kwargs["action_dim"])
+        hi = np.asarray(kwargs["action_high_limit"], dtype=np.float32)
+        lo = np.asarray(kwargs["action_low_limit"], dtype=np.float32)
+        # construction order == reference, so the same torch seed gives the same initial weights
+        self.q1 = HipActionValueDistri(O, A, hidden)
+        self.q2 = HipActionValueDistri(O, A, hidden)
+        self.q1_target = copy.deepcopy(self.q1)  # no RNG consumed, like the reference's deepcopy
+        self.q2_target = copy.deepcopy(self.q2)
+        mn = kwargs.get("policy_min_log_std", -20.0)
+        mx = kwargs.get("policy_max_log_std", 2.0)
+        self.policy = HipStochaPolicy(O, A, hidden, hi, lo, mn, mx)
+        self.policy_target = copy.deepcopy(self.policy)
+        for net in (self.policy_target, self.q1_target, self.q2_target):
+            for p in net.parameters():
+                p.requires_grad = False
+        self.log_alpha = nn.Parameter(torch.tensor(1, dtype=torch.float32))
+        # nn.Module.__setattr__ would register these as sub-state; keep them out of state_dict
+        object.__setattr__(self, "_engine", None)
+        object.__setattr__(self, "_layout", ArenaLayout(O, A, hidden))
+
+    # reference dsac_v2.py:61-62
+    def create_action_distributions(self, logits):
+        return self.policy.get_act_dist(logits)
+
+    def _named_param_slots(self):
+        """[(parameter, arena_name, offset, shape)] for every parameter incl. log_alpha."""
+        lay = self._layout
+        out = []
+        for net in ("q1", "q2", "policy", "q1_target", "q2_target", "policy_target"):
+            mod = getattr(self, net)
+            params = dict(mod.named_parameters())
+            for suffix, arena, off, shape in lay.param_slices(net):
+                out.append((params[suffix], arena, off, shape))
+        out.append((self.log_alpha, "online", lay.log_alpha_offset, ()))
+        return out
+
+    def attach(self, engine: DsactEngine):
+        """Move the current parameter values into the engine's arenas and alias them."""
+        arenas = {"online": engine.online, "target": engine.target}
+        with torch.no_grad():
+            for p, arena, off, shape in self._named_param_slots():
+                n = int(np.prod(shape)) if len(shape) else 1
+                view = arenas[arena][off:off + n].view(shape)
+                view.copy_(p.data.to(view.device))
+                p.data = view
+            for pol in (self.policy, self.policy_target):
+                pol.act_high_lim = pol.act_high_lim.to(engine.device)
+                pol.act_low_lim = pol.act_low_lim.to(engine.device)
+        object.__setattr__(self, "_engine", engine)
+        self.policy._engine = engine
+        engine.set_action_limits(self.policy.act_high_lim.cpu().numpy(), self.policy.act_low_lim.cpu().numpy())
+
+    def _apply(self, fn, *a, **k):
+        # Attached parameters are views of HIP-owned arenas: `.to()/.cpu()/.cuda()` (e.g. the
+        # reference trainer's ModuleOnDevice ping-pong, utils/common_utils.py:164-177) must not
+        # re-home them. Acting with CPU observations is served by HipStochaPolicy.forward.
+        if self._engine is not None:
+            return self
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        if self._engine is not None:
+            self._engine.sync()
+            state_dict = {k: v.to(self._engine.device) for k, v in state_dict.items()}
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        if self._engine is not None:
+            self._engine.set_action_limits(self.policy.act_high_lim.cpu().numpy(),
+                                           self.policy.act_low_lim.cpu().numpy())
+        return out
+
+    def state_dict(self, *a, **k):
+        if self._engine is not None:
+            self._engine.sync()
+        return super().state_dict(*a, **k)
+
+
+# --------------------------------------------------------------------------------------------------
+# lazily materialised tb_info: the only host sync of an update, paid only when somebody reads it
+# --------------------------------------------------------------------------------------------------
+class LazyTbInfo(dict):
+    def __init__(self, alg, serial, alg_time_ms):
+        super().__init__()
+        self._alg, self._serial, self._done = alg, serial, False
+        dict.__setitem__(self, ALG_TIME_KEY, alg_time_ms)
+
+    def _materialize(self):
+        if self._done:
+            return
+        if self._alg._serial != self._serial:
+            raise RuntimeError("tb_info of an earlier update was read after a newer update was issued; "
+                               "device statistics are kept for the last update only")
+        stats = self._alg.engine.read_stats()
+        for k in STAT_KEYS:
+            v = stats[k]
+            if k in ("DSAC2/mean_std1", "DSAC2/mean_std2"):
+                v = torch.tensor(v)  # 0-dim tensors in the reference (dsac_v2.py:201-202)
+            dict.__setitem__(self, k, v)
+        t = dict.pop(self, ALG_TIME_KEY)
+        dict.__setitem__(self, ALG_TIME_KEY, t)  # keep the reference's key order (time last)
+        self._done = True
+
+    def __getitem__(self, k):
+        if k != ALG_TIME_KEY:
+            self._materialize()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        self._materialize()
+        return dict.get(self, k, default)
+
+    def __contains__(self, k):
+        return k == ALG_TIME_KEY or k in STAT_KEYS
+
+    def keys(self):
+        self._materialize()
+        return dict.keys(self)
+
+    def values(self):
+        self._materialize()
+        return dict.values(self)
+
+    def items(self):
+        self._materialize()
+        return dict.items(self)
+
+    def __iter__(self):
+        self._materialize()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        return len(STAT_KEYS) + 1
+
+
+class HipBatch(dict):
+    """Token returned by HipReplayBuffer.sample_batch: the minibatch is already staged inside the
+    engine (`engine_id`), so local_update skips the host round trip. Behaves like the reference's
+    dict of tensors when somebody else indexes it (materialised on demand)."""
+
+    def __init__(self, engine, serial):
+        super().__init__()
+        self.engine, self.serial = engine, serial
+
+    def _fill(self):
+        if not dict.__len__(self):
+            b = self.engine.read_batch(with_logp=True)
+            for k in ("obs", "obs2", "act", "rew", "done", "logp"):
+                dict.__setitem__(self, k, torch.from_numpy(b[k]))
+
+    def __getitem__(self, k):
+        self._fill()
+        return dict.__getitem__(self, k)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
+    def __iter__(self):
+        self._fill()
+        return dict.__iter__(self)
+
+
+class DSAC_V2_HIP:
+    """DSAC-T on MI355X. kwargs are the reference's flat dict (dsac_v2.py:27-59,81-90) plus additive
+    keys: `replay_batch_size` (minibatch rows), `hip_device` (default 0), `strict_rng` (default
+    False: device Philox noise; True: draw the 8 torch.randn tensors of App. A.1 on the host in the
+    reference's order and inject them -- bit-identical noise to the reference after the same seed),
+    `hip_flags` (DSACT_F_*), `global_batch` (data parallel)."""
+
+    def __init__(self, **kwargs):
+        _check_supported(kwargs)
+        self.networks = ApproxContainer(**kwargs)
+        self.gamma = kwargs["gamma"]
+        self.tau = kwargs["tau"]
+        self.target_entropy = -kwargs["action_dim"]
+        self.auto_alpha = kwargs["auto_alpha"]
+        self.alpha = kwargs.get("alpha", 0.2)
+        self.delay_update = kwargs["delay_update"]
+        self.tau_b = kwargs.get("tau_b", self.tau)
+        self.strict_rng = bool(kwargs.get("strict_rng", False))
+        self.flags = int(kwargs.get("hip_flags", 0))
+        B = int(kwargs["replay_batch_size"])
+        self.engine = DsactEngine(
+            int(kwargs["obsv_dim"]), int(kwargs["action_dim"]), _hidden_sizes(kwargs), B,
+            gamma=self.gamma, tau=self.tau, tau_b=self.tau_b, auto_alpha=bool(self.auto_alpha),
+            alpha=float(self.alpha), delay_update=int(self.delay_update),
+            lr_q=kwargs["value_learning_rate"], lr_pi=kwargs["policy_learning_rate"],
+            lr_alpha=kwargs["alpha_learning_rate"],
+            min_log_std=kwargs.get("policy_min_log_std", -20.0), max_log_std=kwargs.get("policy_max_log_std", 2.0),
+            global_batch=kwargs.get("global_batch"), device=int(kwargs.get("hip_device", 0)))
+        self.networks.attach(self.engine)
+        register_engine(self.engine)
+        if not self.strict_rng:
+            seed = kwargs.get("seed") or 0
+            self.engine.set_device_rng((int(seed) * 0x9E3779B97F4A7C15 + 0x1234567) % (1 << 63) or 1)
+        self._serial = 0
+
+    @property
+    def adjustable_parameters(self):
+        return ("gamma", "tau", "auto_alpha", "alpha", "delay_update")
+
+    @property
+    def mean_std1(self):
+        return self.engine.get_state()["mean_std"][0]
+
+    @property
+    def mean_std2(self):
+        return self.engine.get_state()["mean_std"][1]
+
+    # ---- staging -------------------------------------------------------------------------------
+    def _stage(self, data):
+        if isinstance(data, HipBatch) and data.engine is self.engine:
+            return  # already in HBM (HipReplayBuffer fast path)
+        g = lambda k: data[k].detach().cpu().numpy()
+        self.engine.load_batch(g("obs"), g("act"), g("rew"), g("obs2"), g("done"))
+
+    def _noise(self):
+        if not self.strict_rng:
+            return
+        B, A = self.engine.batch, self.engine.act_dim
+        # the reference's 8 draws, in order; 4 of them are discarded there too
+        eps_new, eps_2 = torch.randn(B, A), torch.randn(B, A)
+        z = [torch.randn(B) for _ in range(6)]
+        self.engine.set_noise(eps_new.numpy(), eps_2.numpy(), z[2].numpy(), z[3].numpy())
+
+    # ---- reference surface ------------------------------------------------------------------------
+    def local_update(self, data: Dict, iteration: int) -> dict:
+        t0 = time.time()
+        self._stage(data)
+        self._noise()
+        self.engine.step(int(iteration), self.flags)
+        self._serial += 1
+        return LazyTbInfo(self, self._serial, (time.time() - t0) * 1000)
+
+    def _grad_views(self):
+        lay, g = self.engine.layout, self.engine.grads
+        out = {}
+        for net in ("q1", "q2", "policy"):
+            views = []
+            for _, _, off, shape in lay.param_slices(net):
+                n = int(np.prod(shape))
+                views.append(g[off:off + n].view(shape))
+            out[net] = views
+        out["log_alpha"] = g[lay.log_alpha_offset:lay.log_alpha_offset + 1].view(())
+        return out
+
+    def get_remote_update_info(self, data: Dict, iteration: int) -> Tuple[dict, dict]:
+        t0 = time.time()
+        self._stage(data)
+        self._noise()
+        self.engine.compute_grads(int(iteration), self.flags)
+        self._serial += 1
+        tb = LazyTbInfo(self, self._serial, (time.time() - t0) * 1000)
+        v = self._grad_views()
+        info = {"q1_grad": v["q1"], "q2_grad": v["q2"], "policy_grad": v["policy"], "iteration": iteration}
+        if self.auto_alpha:
+            info["log_alpha_grad"] = v["log_alpha"]
+        return tb, info
+
+    def remote_update(self, update_info: dict):
+        v = self._grad_views()
+        self.engine.sync()
+        with torch.no_grad():
+            for key, name in (("q1_grad", "q1"), ("q2_grad", "q2"), ("policy_grad", "policy")):
+                for dst, src in zip(v[name], update_info[key]):
+                    if src.data_ptr() != dst.data_ptr():
+                        dst.copy_(src.to(dst.device))
+            if self.auto_alpha:
+                src = update_info["log_alpha_grad"]
+                if src.data_ptr() != v["log_alpha"].data_ptr():
+                    v["log_alpha"].copy_(src.to(v["log_alpha"].device))
+        torch.cuda.current_stream(self.engine.device).synchronize()
+        self.engine.apply_update(int(update_info["iteration"]))

@@ -1,0 +1,49 @@
+"""Data-parallel DSAC-T update: one process + one engine per GPU, ONE collective per step.
+
+The reference has no multi-worker learner; its only seam is `get_remote_update_info` /
+`remote_update` (dsac_v2.py:107-138): gradient lists out, gradient lists in. This module slots one
+all-reduce (RCCL over xGMI when the backend is "nccl") of the flat gradient arena
+`[q1 | q2 | policy | log_alpha | mean_std1 | mean_std2]` between those two halves:
+
+    every rank:  grads  = compute_grads(local minibatch of its own replay shard)     (local mean)
+                 grads <- all_reduce(grads) / world                                  (one message)
+                 apply_update()                                                      (identical on all ranks)
+
+Local losses are local means, so the average over ranks is the gradient of the global-batch mean.
+The two trailing floats carry the updated `mean_std` EMA so that the replicated state stays bitwise
+identical across ranks without a second collective ("fast" mode).
+
+`engine` is anything exposing `.grads` (flat torch tensor), `.dp_grads()`, `.dp_apply()` -- the
+DsactEngine in production; the CPU tests drive the same coordinator with an oracle-backed stand-in
+over the gloo backend.
+"""
+import torch
+import torch.distributed as dist
+
+
+class DataParallelUpdater:
+    def __init__(self, engine, group=None, broadcast_tensors=()):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.engine, self.group = engine, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self._avg = dist.get_backend(group) == "nccl"  # RCCL supports ReduceOp.AVG; gloo does not
+        # replicas must start identical: rank 0's parameters / optimiser state win
+        for t in broadcast_tensors:
+            dist.broadcast(t, src=0, group=group)
+
+    def allreduce_grads(self):
+        g = self.engine.grads
+        if self.world == 1:
+            return
+        if self._avg:
+            dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            g.div_(self.world)
+
+    def step(self):
+        self.engine.dp_grads()
+        self.allreduce_grads()
+        self.engine.dp_apply()

@@ -1,0 +1,269 @@
+"""DsactEngine -- thin Python owner of one libdsact handle (one per GPU / process).
+
+PyTorch-ROCm is used for exactly two things here: it OWNS the flat parameter / Adam / gradient
+arenas (so `state_dict()`, `torch.save`, `torch.distributed.all_reduce` work on them unchanged), and
+it provides the stream. All arithmetic of the update runs in the HIP kernels behind the C-ABI.
+"""
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import DsactError
+from .layout import ArenaLayout
+
+STAT_KEYS = [  # order of dsact_read_stats == dsac_v2.py:188-202
+    "DSAC2/critic_avg_q1-RL iter", "DSAC2/critic_avg_q2-RL iter",
+    "DSAC2/critic_avg_std1-RL iter", "DSAC2/critic_avg_std2-RL iter",
+    "DSAC2/critic_avg_min_std1-RL iter", "DSAC2/critic_avg_min_std2-RL iter",
+    "Loss/Actor loss-RL iter", "Loss/Critic loss-RL iter",
+    "DSAC2/policy_mean-RL iter", "DSAC2/policy_std-RL iter", "DSAC2/entropy-RL iter",
+    "DSAC2/alpha-RL iter", "DSAC2/mean_std1", "DSAC2/mean_std2",
+]
+
+
+def _f32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+class DsactEngine:
+    def __init__(self, obs_dim: int, act_dim: int, hidden: Sequence[int], batch: int, *,
+                 gamma=0.99, tau=0.005, tau_b=None, auto_alpha=True, alpha=0.2, delay_update=2,
+                 lr_q=1e-4, lr_pi=1e-4, lr_alpha=3e-4, min_log_std=-20.0, max_log_std=0.5,
+                 global_batch: Optional[int] = None, device: int = 0):
+        import torch
+
+        self._lib = _ffi.load()
+        if not torch.cuda.is_available():
+            raise DsactError("DsactEngine needs an MI355X (torch.cuda.is_available() is False); "
+                             "the DSAC-T update has no CPU fallback")
+        self.torch = torch
+        self.layout = ArenaLayout(obs_dim, act_dim, list(hidden))
+        self.obs_dim, self.act_dim, self.batch = int(obs_dim), int(act_dim), int(batch)
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        cfg = _ffi.Config()
+        cfg.obs_dim, cfg.act_dim, cfg.n_hidden = obs_dim, act_dim, len(hidden)
+        if len(hidden) > _ffi.MAX_HIDDEN:
+            raise DsactError("at most %d hidden layers" % _ffi.MAX_HIDDEN)
+        for i, w in enumerate(hidden):
+            cfg.hidden[i] = int(w)
+        cfg.batch = batch
+        cfg.global_batch = int(global_batch or batch)
+        cfg.auto_alpha = 1 if auto_alpha else 0
+        cfg.delay_update = int(delay_update)
+        cfg.gamma, cfg.tau = gamma, tau
+        cfg.tau_b = tau if tau_b is None else tau_b
+        cfg.lr_q, cfg.lr_pi, cfg.lr_alpha = lr_q, lr_pi, lr_alpha
+        cfg.alpha_fixed = alpha
+        cfg.min_log_std, cfg.max_log_std = min_log_std, max_log_std
+        cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps = 0.9, 0.999, 1e-8
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        rc = self._lib.dsact_create(C.byref(cfg), self.device_index, C.byref(self._h))
+        if rc != 0:
+            msg = self._lib.dsact_last_error(self._h).decode() if self._h else ""
+            if self._h:
+                self._lib.dsact_destroy(self._h)
+                self._h = C.c_void_p()
+            raise DsactError("dsact_create failed (%s): %s" % (_ffi.E_NAMES.get(rc, rc), msg))
+        lay = self.layout
+        assert self._lib.dsact_online_count(self._h) == lay.n_online
+        assert self._lib.dsact_target_count(self._h) == lay.n_target
+        # arenas: torch tensors, device pointers handed to the library
+        dev = self.device
+        self.online = torch.zeros(lay.n_online, dtype=torch.float32, device=dev)
+        self.target = torch.zeros(lay.n_target, dtype=torch.float32, device=dev)
+        self.adam_m = torch.zeros(lay.n_online, dtype=torch.float32, device=dev)
+        self.adam_v = torch.zeros(lay.n_online, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(lay.n_online + 2, dtype=torch.float32, device=dev)
+        self._chk(self._lib.dsact_bind_arenas(
+            self._h, self.online.data_ptr(), self.target.data_ptr(), self.adam_m.data_ptr(),
+            self.adam_v.data_ptr(), self.grads.data_ptr()))
+        self._graph_steps = 0
+
+    # ---- plumbing -----------------------------------------------------------------------------
+    def _chk(self, rc):
+        if rc != 0:
+            raise DsactError("%s: %s" % (_ffi.E_NAMES.get(rc, rc), self._lib.dsact_last_error(self._h).decode()))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dsact_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def use_torch_stream(self):
+        """Run on torch's current stream (orders the kernels with torch ops such as all_reduce)."""
+        s = self.torch.cuda.current_stream(self.device).cuda_stream
+        self._chk(self._lib.dsact_set_stream(self._h, C.c_void_p(s)))
+
+    def sync(self):
+        self._chk(self._lib.dsact_sync(self._h))
+
+    def set_action_limits(self, high, low):
+        hi, lo = _f32(high), _f32(low)
+        self._chk(self._lib.dsact_set_action_limits(self._h, _ffi.fptr(hi), _ffi.fptr(lo)))
+
+    # ---- state ------------------------------------------------------------------------------------
+    def get_state(self):
+        steps = (C.c_int32 * 3)()
+        ms = (C.c_float * 2)()
+        self._chk(self._lib.dsact_get_state(self._h, steps, ms))
+        return {"adam_steps": [int(s) for s in steps], "mean_std": [float(ms[0]), float(ms[1])]}
+
+    def set_state(self, adam_steps=None, mean_std=None):
+        st = (C.c_int32 * 3)(*adam_steps) if adam_steps is not None else None
+        ms = (C.c_float * 2)(*mean_std) if mean_std is not None else None
+        self._chk(self._lib.dsact_set_state(self._h, st, ms))
+
+    # ---- replay ring -------------------------------------------------------------------------------
+    def buffer_create(self, capacity: int):
+        self._chk(self._lib.dsact_buffer_create(self._h, int(capacity)))
+
+    def buffer_add(self, obs, act, rew, obs2, done, logp=None):
+        obs, act, rew, obs2, done = _f32(obs), _f32(act), _f32(rew), _f32(obs2), _f32(done)
+        n = int(rew.shape[0])
+        lp = _f32(logp) if logp is not None else None
+        self._chk(self._lib.dsact_buffer_add(self._h, n, _ffi.fptr(obs), _ffi.fptr(act), _ffi.fptr(rew),
+                                             _ffi.fptr(obs2), _ffi.fptr(done), _ffi.fptr(lp)))
+
+    def buffer_fill_device(self, row0, obs, act, rew, obs2, done):
+        """rows from torch CUDA tensors (synthetic benchmark buffers stay on the device)."""
+        n = int(rew.shape[0])
+        for t in (obs, act, rew, obs2, done):
+            assert t.is_cuda and t.dtype == self.torch.float32 and t.is_contiguous()
+        self.torch.cuda.current_stream(self.device).synchronize()
+        self._chk(self._lib.dsact_buffer_fill_device(self._h, int(row0), n, obs.data_ptr(), act.data_ptr(),
+                                                     rew.data_ptr(), obs2.data_ptr(), done.data_ptr()))
+
+    @property
+    def buffer_size(self):
+        return int(self._lib.dsact_buffer_size(self._h))
+
+    @property
+    def buffer_ptr(self):
+        return int(self._lib.dsact_buffer_ptr(self._h))
+
+    def gather(self, idx):
+        idx = np.ascontiguousarray(np.asarray(idx, dtype=np.int64))
+        self._chk(self._lib.dsact_gather(self._h, idx.ctypes.data_as(C.POINTER(C.c_int64)), int(idx.shape[0])))
+
+    def read_batch(self, with_logp=True) -> Dict[str, np.ndarray]:
+        B, O, A = self.batch, self.obs_dim, self.act_dim
+        out = {"obs": np.empty((B, O), np.float32), "act": np.empty((B, A), np.float32),
+               "rew": np.empty(B, np.float32), "obs2": np.empty((B, O), np.float32),
+               "done": np.empty(B, np.float32)}
+        lp = np.empty(B, np.float32) if with_logp else None
+        self._chk(self._lib.dsact_read_batch(self._h, _ffi.fptr(out["obs"]), _ffi.fptr(out["act"]),
+                                             _ffi.fptr(out["rew"]), _ffi.fptr(out["obs2"]),
+                                             _ffi.fptr(out["done"]), _ffi.fptr(lp)))
+        if with_logp:
+            out["logp"] = lp
+        return out
+
+    def load_batch(self, obs, act, rew, obs2, done):
+        obs, act, rew, obs2, done = _f32(obs), _f32(act), _f32(rew), _f32(obs2), _f32(done)
+        assert obs.shape == (self.batch, self.obs_dim), obs.shape
+        self._chk(self._lib.dsact_load_batch(self._h, _ffi.fptr(obs), _ffi.fptr(act), _ffi.fptr(rew),
+                                             _ffi.fptr(obs2), _ffi.fptr(done)))
+
+    def upload_index_table(self, idx):
+        idx = np.ascontiguousarray(np.asarray(idx, dtype=np.int64))
+        assert idx.ndim == 2 and idx.shape[1] == self.batch
+        self._chk(self._lib.dsact_upload_index_table(self._h, idx.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                     int(idx.shape[0])))
+
+    # ---- noise ---------------------------------------------------------------------------------------
+    def set_noise(self, eps_new, eps_2, z5, z6):
+        a, b, c, d = _f32(eps_new), _f32(eps_2), _f32(z5), _f32(z6)
+        assert a.shape == (self.batch, self.act_dim) and c.shape == (self.batch,)
+        self._chk(self._lib.dsact_set_noise(self._h, _ffi.fptr(a), _ffi.fptr(b), _ffi.fptr(c), _ffi.fptr(d)))
+
+    def set_device_rng(self, seed: int):
+        self._chk(self._lib.dsact_set_device_rng(self._h, int(seed)))
+
+    # ---- update ---------------------------------------------------------------------------------------
+    def compute_grads(self, iteration: int, flags: int = 0):
+        self._chk(self._lib.dsact_compute_grads(self._h, int(iteration), int(flags)))
+
+    def apply_update(self, iteration: int):
+        self._chk(self._lib.dsact_apply_update(self._h, int(iteration)))
+
+    def step(self, iteration: int, flags: int = 0):
+        self._chk(self._lib.dsact_step(self._h, int(iteration), int(flags)))
+
+    def graph_build(self, steps_per_graph: int = 2, flags: int = 0):
+        self._chk(self._lib.dsact_graph_build(self._h, int(steps_per_graph), int(flags)))
+        self._graph_steps = int(steps_per_graph)
+
+    def graph_run(self, first_iteration: int, n_steps: int):
+        self._chk(self._lib.dsact_graph_run(self._h, int(first_iteration), int(n_steps)))
+
+    # data-parallel halves (iteration and index-table row come from device state)
+    def dp_begin(self, first_iteration: int):
+        self._chk(self._lib.dsact_dp_begin(self._h, int(first_iteration)))
+
+    def dp_grads(self, flags: int = 0):
+        self._chk(self._lib.dsact_dp_enqueue_grads(self._h, int(flags)))
+
+    def dp_apply(self):
+        self._chk(self._lib.dsact_dp_enqueue_apply(self._h))
+
+    def read_stats(self) -> Dict[str, float]:
+        out = (C.c_float * 16)()
+        self._chk(self._lib.dsact_read_stats(self._h, out))
+        d = {k: float(out[i]) for i, k in enumerate(STAT_KEYS)}
+        d["_iteration"] = float(out[14])
+        return d
+
+    # ---- measurement ------------------------------------------------------------------------------------
+    def time_steps(self, first_iteration: int, n_steps: int, use_graph: bool = True, flags: int = 0) -> float:
+        ms = C.c_float()
+        self._chk(self._lib.dsact_time_steps(self._h, int(first_iteration), int(n_steps), int(flags),
+                                             1 if use_graph else 0, C.byref(ms)))
+        return float(ms.value)
+
+    def profile_step(self, iteration: int, flags: int = 0):
+        arr = (_ffi.KernelTime * 64)()
+        n = C.c_int32()
+        self._chk(self._lib.dsact_profile_step(self._h, int(iteration), int(flags), arr, 64, C.byref(n)))
+        return [(arr[i].name.decode(), float(arr[i].ms), int(arr[i].blocks)) for i in range(n.value)]
+
+    def debug_read(self, name: str, cap: int = 1 << 24) -> np.ndarray:
+        buf = np.empty(cap, np.float32)
+        n = C.c_size_t()
+        self._chk(self._lib.dsact_debug_read(self._h, name.encode(), _ffi.fptr(buf), cap, C.byref(n)))
+        return buf[: n.value].copy()
+
+    def policy_forward(self, obs) -> np.ndarray:
+        obs = _f32(obs).reshape(-1, self.obs_dim)
+        n = obs.shape[0]
+        out = np.empty((n, 2 * self.act_dim), np.float32)
+        for s in range(0, n, 64):
+            e = min(n, s + 64)
+            chunk = np.ascontiguousarray(obs[s:e])
+            o = np.empty((e - s, 2 * self.act_dim), np.float32)
+            self._chk(self._lib.dsact_policy_forward(self._h, _ffi.fptr(chunk), e - s, _ffi.fptr(o)))
+            out[s:e] = o
+        return out
+
+
+# process-wide registry: the replay buffer plugin shares the algorithm's handle so that a gathered
+# minibatch never leaves HBM (mix-and-match case iii)
+_CURRENT = None
+
+
+def register_engine(engine: "DsactEngine"):
+    global _CURRENT
+    _CURRENT = engine
+
+
+def current_engine() -> Optional["DsactEngine"]:
+    return _CURRENT

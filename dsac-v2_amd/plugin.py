@@ -1,0 +1,42 @@
+"""importlib-by-name factories with the reference's discovery rules (utils/initialization.py:48-117,
+training/trainer.py:155-158): the drop-in surface of this repository.
+
+    create_alg(algorithm="DSAC_V2_HIP", **kw)          -> module dsac_v2_hip, class DSAC_V2_HIP
+    create_buffer(buffer_name="hip_replay_buffer", **kw) -> module training.hip_replay_buffer,
+                                                            class HipReplayBuffer
+    create_trainer(alg, sampler, buffer, evaluator, **kw) -> training.hip_trainer.HipOffSerialTrainer
+"""
+import importlib
+import os
+import sys
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+if _PKG not in sys.path:
+    sys.path.insert(0, _PKG)
+
+
+def camel(name: str) -> str:
+    return "".join(part[:1].upper() + part[1:] for part in name.split("_"))
+
+
+def create_alg(**kwargs):
+    name = kwargs["algorithm"]
+    module = importlib.import_module(name.lower())
+    if not hasattr(module, name):
+        raise NotImplementedError("algorithm %s is not defined in module %s" % (name, name.lower()))
+    return getattr(module, name)(**kwargs)
+
+
+def create_buffer(**kwargs):
+    file_name = kwargs["buffer_name"].lower()
+    module = importlib.import_module("training." + file_name)
+    cls = camel(file_name)
+    if not hasattr(module, cls):
+        raise NotImplementedError("buffer %s is not defined in training.%s" % (cls, file_name))
+    return getattr(module, cls)(**kwargs)
+
+
+def create_trainer(alg, sampler, buffer, evaluator, **kwargs):
+    from training.hip_trainer import HipOffSerialTrainer
+
+    return HipOffSerialTrainer(alg, sampler, buffer, evaluator, **kwargs)

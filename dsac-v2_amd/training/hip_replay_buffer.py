@@ -1,0 +1,75 @@
+"""HipReplayBuffer -- device-resident replay ring; drop-in for reference training/replay_buffer.py.
+
+Discovered by the reference's rule `create_buffer(buffer_name="hip_replay_buffer")` -> module
+`training.hip_replay_buffer`, class `HipReplayBuffer` (reference utils/initialization.py:90-117).
+
+Same observable behaviour as the reference ReplayBuffer (replay_buffer.py:20-90): SoA fp32 ring with
+`ptr=(ptr+1)%N`, `size=min(size+1,N)`, uniform index draw with replacement from the GLOBAL legacy
+NumPy RandomState (`np.random.randint(0, size, batch)`, bit-exact by construction because the very
+same call is made here on the host), `sample_batch` returns a dict with keys
+obs/obs2/act/rew/done/logp. The rows live in HBM; the gather is a HIP kernel (k_gather) that writes
+straight into the update's staging area, and the returned `HipBatch` is a token for it.
+"""
+import numpy as np
+
+from dsact.engine import DsactEngine, current_engine
+
+__all__ = ["HipReplayBuffer"]
+
+
+class HipReplayBuffer:
+    def __init__(self, index=0, **kwargs):
+        self.obsv_dim = kwargs["obsv_dim"]
+        self.act_dim = kwargs["action_dim"]
+        self.max_size = int(kwargs["buffer_max_size"])
+        if kwargs.get("additional_info"):
+            raise NotImplementedError("additional_info is not supported by HipReplayBuffer")
+        eng = kwargs.get("hip_engine") or current_engine()
+        B = int(kwargs["replay_batch_size"])
+        if eng is None or eng.obs_dim != self.obsv_dim or eng.act_dim != self.act_dim or eng.batch != B:
+            hidden = list(kwargs.get("value_hidden_sizes", [32]))
+            eng = DsactEngine(self.obsv_dim, self.act_dim, hidden, B, device=int(kwargs.get("hip_device", 0)))
+        self.engine = eng
+        self.engine.buffer_create(self.max_size)
+        self._serial = 0
+
+    @property
+    def size(self):
+        return self.engine.buffer_size
+
+    @property
+    def ptr(self):
+        return self.engine.buffer_ptr
+
+    def __len__(self):
+        return self.size
+
+    def __get_RAM__(self):
+        row_bytes = 4 * (2 * self.obsv_dim + self.act_dim + 3)
+        return row_bytes * self.size / 1e6  # MB resident in HBM
+
+    def store(self, obs, info, act, rew, next_obs, done, logp, next_info):
+        self.add_batch([(obs, info, act, rew, next_obs, done, logp, next_info)])
+
+    def add_batch(self, samples: list):
+        n = len(samples)
+        if n == 0:
+            return
+        O, A = self.obsv_dim, self.act_dim
+        obs = np.empty((n, O), np.float32)
+        obs2 = np.empty((n, O), np.float32)
+        act = np.empty((n, A), np.float32)
+        rew = np.empty(n, np.float32)
+        done = np.empty(n, np.float32)
+        logp = np.empty(n, np.float32)
+        for i, s in enumerate(samples):
+            obs[i], act[i], rew[i], obs2[i], done[i], logp[i] = s[0], s[2], s[3], s[4], s[5], s[6]
+        self.engine.buffer_add(obs, act, rew, obs2, done, logp)
+
+    def sample_batch(self, batch_size: int):
+        from dsac_v2_hip import HipBatch
+
+        idxs = np.random.randint(0, self.size, size=batch_size)  # reference replay_buffer.py:86
+        self.engine.gather(idxs)
+        self._serial += 1
+        return HipBatch(self.engine, self._serial)

@@ -1,0 +1,181 @@
+/*
+ * dsact.h -- C-ABI of libdsact.so: the MI355X-native (gfx950) DSAC-T off-policy update path.
+ *
+ * This is the drop-in boundary for ONE path of Jingliang-Duan/DSAC-v2 (all file:line below are
+ * relative to the reference repository):
+ *
+ *   dsac_v2.py:150-206   DSAC_V2.__compute_gradient      -> dsact_compute_grads
+ *   dsac_v2.py:320-347   DSAC_V2.__update                -> dsact_apply_update
+ *   dsac_v2.py:102-105   DSAC_V2.local_update            -> dsact_step
+ *   dsac_v2.py:107-138   get_remote_update_info / remote_update (data-parallel seam)
+ *                                                        -> dsact_compute_grads / [all-reduce of the
+ *                                                           bound gradient arena] / dsact_apply_update
+ *   training/replay_buffer.py:20-50   ReplayBuffer.__init__   -> dsact_buffer_create
+ *   training/replay_buffer.py:58-83   store / add_batch       -> dsact_buffer_add
+ *   training/replay_buffer.py:85-90   sample_batch            -> dsact_gather (index draw stays on the
+ *                                                                host: np.random.randint, bit-exact)
+ *   training/trainer.py:72-74         per-key .cuda() of a CPU minibatch -> dsact_load_batch
+ *   dsac_v2.py:188-204                the 14 numeric tb_info entries     -> dsact_read_stats
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 on success, a negative DSACT_E_* on
+ *     failure; the message of the last failure on a handle is dsact_last_error(h).
+ *   - all device work is enqueued on ONE stream per handle (dsact_set_stream; default: a stream the
+ *     handle owns). Calls are asynchronous unless stated; one handle is used from one host thread.
+ *   - parameter / optimiser memory is OWNED BY THE CALLER (torch-ROCm tensors on the Python side):
+ *     dsact_bind_arenas only records device pointers. Flat fp32 arena order:
+ *         online  : q1 | q2 | policy | log_alpha        (dsact_online_count floats)
+ *         target  : q1_target | q2_target | policy_target
+ *         adam_m, adam_v, grads : same order and size as `online`; `grads` has 2 extra floats at the
+ *                   tail (the updated mean_std1/2 EMA, so that ONE all-reduce re-synchronises them)
+ *     inside a net: [W0 (out x in, row-major, == nn.Linear.weight) | b0 | W1 | b1 | ...], i.e. the
+ *     parameter order of torch's state_dict.
+ *   - all tensors fp32; replay indices int64 on the host API (int32 on device).
+ */
+#ifndef DSACT_H
+#define DSACT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSACT_MAX_HIDDEN_LAYERS 6
+
+#define DSACT_OK 0
+#define DSACT_E_INVALID (-1)   /* bad argument / unsupported configuration */
+#define DSACT_E_HIP (-2)       /* a HIP runtime call failed */
+#define DSACT_E_STATE (-3)     /* call order violated (arenas not bound, buffer empty, ...) */
+#define DSACT_E_NODEVICE (-4)  /* no MI355X visible */
+
+typedef struct dsact_handle dsact_handle;
+
+/* Hyper-parameters consumed by DSAC_V2.__init__ / ApproxContainer.__init__
+ * (dsac_v2.py:27-59,81-90; utils/common_utils.py:48-89). */
+typedef struct dsact_config {
+  int32_t obs_dim;                              /* obsv_dim */
+  int32_t act_dim;                              /* action_dim (<= 32) */
+  int32_t n_hidden;                             /* len(hidden_sizes), 1..DSACT_MAX_HIDDEN_LAYERS */
+  int32_t hidden[DSACT_MAX_HIDDEN_LAYERS];      /* value/policy_hidden_sizes (same for both) */
+  int32_t batch;                                /* replay_batch_size (local batch of this rank) */
+  int32_t global_batch;                         /* batch summed over data-parallel ranks (>= batch) */
+  int32_t auto_alpha;                           /* auto_alpha */
+  int32_t delay_update;                         /* delay_update */
+  float gamma, tau, tau_b;                      /* gamma, tau, tau_b (= tau when absent) */
+  float lr_q, lr_pi, lr_alpha;                  /* value/policy/alpha_learning_rate */
+  float alpha_fixed;                            /* alpha when !auto_alpha */
+  float min_log_std, max_log_std;               /* policy_min/max_log_std */
+  float adam_beta1, adam_beta2, adam_eps;       /* torch.optim.Adam defaults 0.9, 0.999, 1e-8 */
+} dsact_config;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+int dsact_version(void);
+int dsact_device_count(void);
+int dsact_create(const dsact_config* cfg, int device, dsact_handle** out);
+int dsact_destroy(dsact_handle* h);
+const char* dsact_last_error(const dsact_handle* h);
+/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL -> handle-owned stream */
+int dsact_set_stream(dsact_handle* h, void* hip_stream);
+int dsact_sync(dsact_handle* h); /* blocks until the handle's stream is idle */
+
+/* ---- parameters (ApproxContainer, dsac_v2.py:19-62) ------------------------------------------- */
+size_t dsact_online_count(const dsact_handle* h); /* floats in q1|q2|policy|log_alpha */
+size_t dsact_target_count(const dsact_handle* h); /* floats in q1_t|q2_t|policy_t */
+size_t dsact_q_count(const dsact_handle* h);      /* floats in one Q net */
+size_t dsact_pi_count(const dsact_handle* h);     /* floats in the policy net */
+int dsact_bind_arenas(dsact_handle* h, float* online, float* target, float* adam_m, float* adam_v,
+                      float* grads /* online_count + 2 floats */);
+/* act_high_lim / act_low_lim buffers of StochaPolicy (networks/mlp.py:75-76); host pointers */
+int dsact_set_action_limits(dsact_handle* h, const float* high, const float* low);
+/* Adam step counters (q, policy, alpha) and the mean_std EMA state (dsac_v2.py:88-89,233-241);
+ * mean_std < 0 encodes the reference's -1.0 "not yet initialised" sentinel. Synchronous. */
+int dsact_get_state(dsact_handle* h, int32_t adam_steps[3], float mean_std[2]);
+int dsact_set_state(dsact_handle* h, const int32_t adam_steps[3], const float mean_std[2]);
+
+/* ---- replay buffer (training/replay_buffer.py) -------------------------------------------------- */
+int dsact_buffer_create(dsact_handle* h, int64_t capacity);
+/* n transitions, SoA host arrays (obs[n*O], act[n*A], rew[n], obs2[n*O], done[n], logp[n]); ring
+ * write at ptr with the reference's ptr/size semantics (replay_buffer.py:58-79). */
+int dsact_buffer_add(dsact_handle* h, int64_t n, const float* obs, const float* act, const float* rew,
+                     const float* obs2, const float* done, const float* logp);
+int64_t dsact_buffer_size(const dsact_handle* h);
+int64_t dsact_buffer_ptr(const dsact_handle* h);
+/* bulk fill of rows [row0,row0+n) directly from DEVICE arrays (synthetic benchmark buffers);
+ * sets size=max(size,row0+n), ptr=(row0+n)%capacity */
+int dsact_buffer_fill_device(dsact_handle* h, int64_t row0, int64_t n, const float* obs, const float* act,
+                             const float* rew, const float* obs2, const float* done);
+/* gather rows idx[0..batch) into the handle's minibatch staging area (== sample_batch + .cuda()) */
+int dsact_gather(dsact_handle* h, const int64_t* idx_host, int32_t batch);
+/* copy the staged minibatch back to host arrays (any may be NULL); synchronous. `logp` comes from
+ * the ring (it is not part of the staging area the update reads). */
+int dsact_read_batch(dsact_handle* h, float* obs, float* act, float* rew, float* obs2, float* done,
+                     float* logp);
+/* stage a host minibatch produced elsewhere (reference ReplayBuffer + new algorithm mix) */
+int dsact_load_batch(dsact_handle* h, const float* obs, const float* act, const float* rew,
+                     const float* obs2, const float* done);
+/* index table for graph replay: rows x batch indices, row r is consumed by the r-th replayed step */
+int dsact_upload_index_table(dsact_handle* h, const int64_t* idx_host, int32_t rows);
+
+/* ---- noise (the torch.randn draws of one __compute_gradient) ------------- */
+/* parity mode: inject eps_new[B*A], eps_2[B*A], z5[B], z6[B] (host pointers) for the next step */
+int dsact_set_noise(dsact_handle* h, const float* eps_new, const float* eps_2, const float* z5,
+                    const float* z6);
+/* production mode: device Philox4x32-10 + Box-Muller keyed by (seed, iteration); 0 disables */
+int dsact_set_device_rng(dsact_handle* h, uint64_t seed);
+
+/* ---- the update ----------------------------------------------------------------------------------- */
+#define DSACT_F_SKIP_ACTOR_ON_OFF_ITERS 1u /* "fast": skip actor/alpha backward when it % delay != 0
+                                              (their gradients are discarded by the reference,
+                                              dsac_v2.py:174-186 vs :324); parameter trajectory is
+                                              unchanged */
+int dsact_compute_grads(dsact_handle* h, int64_t iteration, uint32_t flags);
+int dsact_apply_update(dsact_handle* h, int64_t iteration);
+int dsact_step(dsact_handle* h, int64_t iteration, uint32_t flags); /* compute_grads + apply_update */
+/* hipGraph path: captures `steps_per_graph` consecutive updates (gather from the index table +
+ * step, iteration read from device state) and replays them; dsact_graph_run enqueues n_steps
+ * updates starting at `first_iteration` (n_steps % steps_per_graph == 0). */
+int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags);
+int dsact_graph_run(dsact_handle* h, int64_t first_iteration, int64_t n_steps);
+
+/* data-parallel replay (one process per GPU): the same two halves with iteration / index-table row
+ * taken from device state, so the host never touches the step. Between them the caller all-reduces
+ * the bound gradient arena (online_count + 2 floats, average over ranks) on the same stream:
+ *   dsact_dp_enqueue_grads  = gather(table row) + __compute_gradient   (get_remote_update_info)
+ *   dsact_dp_enqueue_apply  = __update                                   (remote_update)
+ * dsact_dp_begin sets the first iteration (synchronous). */
+int dsact_dp_begin(dsact_handle* h, int64_t first_iteration);
+int dsact_dp_enqueue_grads(dsact_handle* h, uint32_t flags);
+int dsact_dp_enqueue_apply(dsact_handle* h);
+
+/* 14 numeric tb_info entries of the last update in the order of dsac_v2.py:188-202
+ * (avg_q1, avg_q2, avg_std1, avg_std2, min_std1, min_std2, loss_actor, loss_critic, policy_mean,
+ *  policy_std, entropy, alpha, mean_std1, mean_std2) + out[14] = iteration, out[15] = reserved.
+ * Synchronous (this is the only per-step host sync, and only when the trainer logs). */
+int dsact_read_stats(dsact_handle* h, float out[16]);
+
+/* ---- measurement / debugging -------------------------------------------------------------------- */
+/* time n replays of the step on the handle's stream with hipEvents: total milliseconds */
+int dsact_time_steps(dsact_handle* h, int64_t first_iteration, int64_t n_steps, uint32_t flags,
+                     int32_t use_graph, float* ms_total);
+/* per-kernel hipEvent timing of ONE eager step: fills up to `cap` entries; returns count in *n */
+typedef struct dsact_kernel_time {
+  char name[32];
+  float ms;
+  int32_t blocks;
+} dsact_kernel_time;
+int dsact_profile_step(dsact_handle* h, int64_t iteration, uint32_t flags, dsact_kernel_time* out,
+                       int32_t cap, int32_t* n);
+/* copy an internal device buffer to host by name (parity tests); returns element count in *n.
+ * names: see dsact_debug_names(). */
+int dsact_debug_read(dsact_handle* h, const char* name, float* out, size_t cap, size_t* n);
+const char* dsact_debug_names(void);
+/* stand-alone fused-MLP forward of the policy net on a host batch (sampler / evaluator feed):
+ * logits[n*2A] = (mean | std) exactly as StochaPolicy.forward returns (networks/mlp.py:79-100) */
+int dsact_policy_forward(dsact_handle* h, const float* obs_host, int32_t n, float* logits_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSACT_H */

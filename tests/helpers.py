@@ -41,3 +41,25 @@ def synth_batch(rng, B, O, A, lim=0.4, p_done=0.01):
 def make_oracle(cfg, init=None, seed=0):
     torch.manual_seed(seed)
     return DsactOracle(cfg, state_dict=init)
+
+
+def hip_kwargs(O, A, hidden, B, act_limit=0.4, **over):
+    """The reference's flat kwargs dict (example_train/dsacv2_mlp_mujoco_offserial.py defaults +
+    utils/init_args.py) for synthetic shapes, with the additive HIP keys."""
+    kw = dict(
+        algorithm="DSAC_V2_HIP", env_id="synthetic", seed=0, action_type="continu",
+        value_func_name="ActionValueDistri", value_func_type="MLP",
+        value_hidden_sizes=list(hidden), value_hidden_activation="gelu", value_output_activation="linear",
+        policy_func_name="StochaPolicy", policy_func_type="MLP", policy_act_distribution="TanhGaussDistribution",
+        policy_hidden_sizes=list(hidden), policy_hidden_activation="gelu", policy_output_activation="linear",
+        policy_min_log_std=-20, policy_max_log_std=0.5,
+        value_learning_rate=1e-4, policy_learning_rate=1e-4, alpha_learning_rate=3e-4,
+        gamma=0.99, tau=0.005, auto_alpha=True, alpha=0.2, delay_update=2,
+        buffer_name="hip_replay_buffer", buffer_warm_size=1000, buffer_max_size=10000,
+        replay_batch_size=B, obsv_dim=O, action_dim=A,
+        action_high_limit=np.full((A,), act_limit, dtype=np.float32),
+        action_low_limit=np.full((A,), -act_limit, dtype=np.float32),
+        additional_info={}, cnn_shared=False, trainer="off_serial_trainer", use_gpu=True,
+    )
+    kw.update(over)
+    return kw

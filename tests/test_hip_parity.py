@@ -1,0 +1,358 @@
+"""Parity of the HIP path (through the C-ABI) against the oracle and the reference golden vectors.
+
+Tolerances (BASELINE.json north_star): losses / stats within 1e-4 of the reference CPU path; replay
+index draws and gathered rows bit-exact. Gradients are compared relative to their own scale
+(fp32 summation order differs between the MFMA k-ordering and the CPU BLAS); parameters after an
+update within 1e-4 absolute (Adam's first steps move every weight by ~lr regardless of |g|, so a
+sign flip of a ~1e-9 gradient element is the worst case: 2*lr = 2e-4).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import STEP_CASES, hip_kwargs, load_step_case, step_inputs, synth_batch
+from oracle.dsact_oracle import TB_KEYS, DsactOracle, ReplayOracle, default_config, draw_noise
+
+pytestmark = pytest.mark.gpu
+
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.txt")
+
+
+class Report:
+    def __init__(self, title):
+        self.title, self.rows, self.bad = title, [], []
+
+    def cmp(self, name, got, want, atol, rtol=0.0):
+        got = np.asarray(got, dtype=np.float64).reshape(-1)
+        want = np.asarray(want.detach().cpu().numpy() if torch.is_tensor(want) else want, dtype=np.float64).reshape(-1)
+        assert got.shape == want.shape, (name, got.shape, want.shape)
+        err = float(np.max(np.abs(got - want))) if got.size else 0.0
+        scale = float(np.max(np.abs(want))) if want.size else 0.0
+        tol = atol + rtol * scale
+        ok = bool(np.isfinite(got).all() and err <= tol)
+        self.rows.append((name, err, scale, tol, ok))
+        if not ok:
+            self.bad.append(name)
+        return ok
+
+    def finish(self):
+        lines = ["== %s ==" % self.title]
+        for name, err, scale, tol, ok in self.rows:
+            lines.append("%-28s err %.3e  scale %.3e  tol %.3e  %s" % (name, err, scale, tol, "ok" if ok else "FAIL"))
+        txt = "\n".join(lines)
+        print(txt)
+        try:
+            os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+            with open(REPORT, "a") as f:
+                f.write(txt + "\n")
+        except OSError:
+            pass
+        assert not self.bad, "parity failures in %s: %s" % (self.title, self.bad)
+
+
+def make_pair(O, A, hid, B, act_limit=0.4, seed=0, init=None, **over):
+    from dsac_v2_hip import DSAC_V2_HIP
+
+    torch.manual_seed(seed)
+    alg = DSAC_V2_HIP(**hip_kwargs(O, A, hid, B, act_limit=act_limit, strict_rng=True, **over))
+    if init is not None:
+        alg.networks.load_state_dict(init)
+    cfg = default_config(O, A, hid, act_limit=act_limit,
+                         **{k: over[k] for k in ("auto_alpha", "alpha", "delay_update") if k in over})
+    orc = DsactOracle(cfg, state_dict={k: v.cpu() for k, v in alg.networks.state_dict().items()})
+    return alg, orc
+
+
+def gelu_np(z):
+    return torch.nn.functional.gelu(z).numpy()
+
+
+def compare_intermediates(rep, alg, orc, L, B, A):
+    e, I = alg.engine, orc.inter
+    d = lambda n: e.debug_read(n)
+    ld = e.debug_read("X0").size // B
+    O = e.obs_dim
+    rep.cmp("new_act", d("XP").reshape(B, ld)[:, O:O + A], I["new_act"], 2e-6)
+    rep.cmp("act2", d("X2").reshape(B, ld)[:, O:O + A], I["act2"], 2e-6)
+    rep.cmp("logp_new", d("logp_new"), I["new_log_prob"], 2e-4)
+    rep.cmp("logp2", d("logp2"), I["log_prob_act2"], 2e-4)
+    mu = d("logits_pi").reshape(B, 2 * A)[:, :A]
+    rep.cmp("policy_mean", mu, I["logits"][:, :A], 2e-5)
+    for i, (q, s) in enumerate((("q1", "q1_std"), ("q2", "q2_std"))):
+        o = d("qout_c%d" % i).reshape(B, 2)
+        rep.cmp(q, o[:, 0], I[q], 2e-5)
+        rep.cmp(s, torch.nn.functional.softplus(torch.as_tensor(o[:, 1])).numpy(), I[s], 2e-5)
+    for i, q in enumerate(("q1_next", "q2_next")):
+        rep.cmp(q, d("qout_t%d" % i).reshape(B, 2)[:, 0], I[q], 2e-5)
+    for i, q in enumerate(("q1_pi", "q2_pi")):
+        rep.cmp(q, d("qout_p%d" % i).reshape(B, 2)[:, 0], I[q], 2e-5)
+    for ch, key in (("pi", "z_pi"), ("q1c", "z_q1"), ("q2c", "z_q2"), ("q1p", "z_q1p"), ("q2p", "z_q2p")):
+        for l in range(L):
+            rep.cmp("H.%s.%d" % (ch, l), d("H.%s.%d" % (ch, l)), gelu_np(I[key][l]), 2e-6, 2e-5)
+    rep.cmp("d_new_act", d("d_new_act"), I["d_new_act"], 1e-9, 2e-4)
+    for ch, key in (("q1c", "dz_q1"), ("q2c", "dz_q2"), ("q1p", "dz_q1p"), ("q2p", "dz_q2p"), ("pi", "dz_pi")):
+        for l in range(L):
+            rep.cmp("dZ.%s.%d" % (ch, l), d("dZ.%s.%d" % (ch, l)), I[key][l], 1e-10, 2e-4)
+
+
+def run_case(title, O, A, hid, B, steps, act_limit=0.4, init=None, golden=None, **over):
+    rep = Report(title)
+    alg, orc = make_pair(O, A, hid, B, act_limit=act_limit, init=init, **over)
+    e = alg.engine
+    L = len(hid)
+    rng = np.random.default_rng(5)
+    lay = e.layout
+    for it in range(steps):
+        if golden is not None:
+            data, noise = step_inputs(golden, it)
+        else:
+            data = synth_batch(rng, B, O, A, lim=act_limit, p_done=0.05)
+            torch.manual_seed(1000 + it)
+            noise = draw_noise(B, A)
+        keep = it in (0, steps - 1)
+        tb_ref = orc.compute_gradient(data, noise, keep=keep)
+        e.load_batch(*(data[k].numpy() for k in ("obs", "act", "rew", "obs2", "done")))
+        e.set_noise(noise["eps_new"].numpy(), noise["eps_2"].numpy(), noise["z5"].numpy(), noise["z6"].numpy())
+        e.compute_grads(it)
+        if keep:
+            compare_intermediates(rep, alg, orc, L, B, A)
+        g = e.grads.cpu().numpy()
+        g_ref = orc.flat_grads().numpy()
+        off = 0
+        for net, n in (("q1", lay.n_q), ("q2", lay.n_q), ("policy", lay.n_pi), ("log_alpha", 1)):
+            rep.cmp("it%d grad.%s" % (it, net), g[off:off + n], g_ref[off:off + n], 1e-9, 3e-4)
+            off += n
+        e.apply_update(it)
+        orc.update(it)
+        st = e.read_stats()
+        for k in TB_KEYS[:-1]:
+            want = float(tb_ref[k])
+            rep.cmp("it%d %s" % (it, k.split("/")[-1][:18]), [st[k]], [want], 1e-4, 1e-4)
+        if golden is not None:
+            # the same numbers straight from the unmodified reference
+            rep.cmp("it%d tb vs reference" % it, [st[k] for k in TB_KEYS[:-1]], golden["s%d/tb" % it], 1e-4, 1e-4)
+            rep.cmp("it%d params vs reference" % it, e.online.cpu().numpy(), golden["s%d/params" % it], 1e-4)
+            rep.cmp("it%d targets vs reference" % it, e.target.cpu().numpy(), golden["s%d/targets" % it], 1e-5)
+        rep.cmp("it%d params" % it, e.online.cpu().numpy(), orc.flat_params(), 1e-4)
+        rep.cmp("it%d targets" % it, e.target.cpu().numpy(), orc.flat_targets(), 1e-5)
+        state = e.get_state()
+        rep.cmp("it%d mean_std" % it, state["mean_std"], [float(orc.mean_std1), float(orc.mean_std2)], 1e-5, 1e-5)
+    # Adam moments of q1 (first parameter tensor) against torch.optim.Adam's state
+    st0 = orc.opt["q1"].state[orc.p["q1"][0]]
+    n0 = orc.p["q1"][0].numel()
+    rep.cmp("adam_m q1.W0", e.adam_m.cpu().numpy()[:n0], st0["exp_avg"].reshape(-1), 1e-10, 1e-3)
+    rep.cmp("adam_v q1.W0", e.adam_v.cpu().numpy()[:n0], st0["exp_avg_sq"].reshape(-1), 1e-14, 1e-3)
+    assert e.get_state()["adam_steps"][0] == steps
+    rep.finish()
+
+
+def test_humanoid_l3_b256():
+    run_case("humanoid 3x256 B=256", 376, 17, (256, 256, 256), 256, steps=4)
+
+
+def test_humanoid_l2_b256():
+    run_case("humanoid 2x256 B=256", 376, 17, (256, 256), 256, steps=3)
+
+
+def test_ragged_shapes():
+    # widths not multiples of the 32x32 tile, batch not a multiple of 4, one action dim
+    run_case("ragged O=11 A=3 (96,40) B=50", 11, 3, (96, 40), 50, steps=3)
+    run_case("ragged O=5 A=1 (33,) B=7", 5, 1, (33,), 7, steps=3, act_limit=2.0)
+
+
+def test_large_batch_and_width():
+    run_case("B=1024 hidden 512x2", 24, 6, (512, 512), 1024, steps=2)
+
+
+@pytest.mark.parametrize("name", STEP_CASES)
+def test_against_reference_golden(name):
+    z, cfg, init = load_step_case(name)
+    over = dict(auto_alpha=cfg["auto_alpha"], alpha=cfg["alpha"], delay_update=cfg["delay_update"])
+    run_case("golden " + name, cfg["obs_dim"], cfg["act_dim"], tuple(cfg["hidden"]), int(z["cfg_batch"]),
+             steps=int(z["cfg_steps"]), act_limit=float(z["cfg_act_limit"]), init=init, golden=z, **over)
+
+
+def test_local_update_surface_and_lazy_stats():
+    alg, orc = make_pair(11, 3, (64, 64), 64)
+    rng = np.random.default_rng(0)
+    for it in range(4):
+        data = synth_batch(rng, 64, 11, 3)
+        torch.manual_seed(7 + it)
+        noise = draw_noise(64, 3)
+        torch.manual_seed(7 + it)
+        tb = alg.local_update(data, it)  # strict_rng: draws the same 8 tensors from the global RNG
+        ref = orc.local_update(data, noise, it)
+        assert list(tb.keys()) == TB_KEYS
+        for k in TB_KEYS[:-1]:
+            assert abs(float(tb[k]) - float(ref[k])) <= 1e-4 * max(1.0, abs(float(ref[k]))), (it, k)
+        assert torch.is_tensor(tb["DSAC2/mean_std1"])
+    stale = alg.local_update(data, 4)
+    alg.local_update(data, 5)
+    with pytest.raises(RuntimeError):
+        stale["Loss/Critic loss-RL iter"]
+
+
+def test_remote_update_seam_equals_local_update():
+    a1, _ = make_pair(11, 3, (64, 64), 64, seed=3)
+    a2, _ = make_pair(11, 3, (64, 64), 64, seed=3)
+    rng = np.random.default_rng(1)
+    for it in range(3):
+        data = synth_batch(rng, 64, 11, 3)
+        torch.manual_seed(50 + it)
+        a1.local_update(data, it)
+        torch.manual_seed(50 + it)
+        _, info = a2.get_remote_update_info(data, it)
+        assert len(info["q1_grad"]) == 6 and info["q1_grad"][0].shape == (64, 14)
+        a2.remote_update(info)
+    a1.engine.sync(); a2.engine.sync()
+    assert torch.equal(a1.engine.online, a2.engine.online)
+    assert torch.equal(a1.engine.target, a2.engine.target)
+
+
+def test_replay_ring_and_gather_bit_exact():
+    from plugin import create_buffer
+
+    O, A, N, B = 13, 2, 50, 16
+    alg, _ = make_pair(O, A, (32,), B)
+    buf = create_buffer(**hip_kwargs(O, A, (32,), B, buffer_max_size=N))
+    assert buf.engine is alg.engine
+    orc = ReplayOracle(O, A, N)
+    rng = np.random.default_rng(3)
+    samples = [(rng.standard_normal(O).astype(np.float32), {}, rng.uniform(-1, 1, A).astype(np.float32),
+                float(rng.standard_normal()), rng.standard_normal(O).astype(np.float32), bool(rng.random() < 0.2),
+                np.float32(rng.standard_normal()), {}) for _ in range(123)]
+    for lo, hi in ((0, 30), (30, 31), (31, 73), (73, 123)):  # wraps the ring twice
+        buf.add_batch(samples[lo:hi])
+        orc.add_batch(samples[lo:hi])
+        assert (buf.size, buf.ptr) == (orc.size, orc.ptr)
+        np.random.seed(11 + lo)
+        got = buf.sample_batch(B)
+        np.random.seed(11 + lo)
+        want = orc.sample_batch(B)
+        for k in ("obs", "obs2", "act", "rew", "done", "logp"):
+            assert torch.equal(got[k], want[k]), k
+    # golden vectors produced by the reference ReplayBuffer itself
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "replay.npz"))
+    O, A, N = [int(v) for v in z["cfg"]]
+    alg2, _ = make_pair(O, A, (32,), 16)
+    buf2 = create_buffer(**hip_kwargs(O, A, (32,), 16, buffer_max_size=N))
+    s = []
+    for i in range(73):
+        r, d, l = z["in/rdl%d" % i]
+        s.append((z["in/obs%d" % i], {}, z["in/act%d" % i], float(r), z["in/obs2_%d" % i], bool(d), np.float32(l), {}))
+    buf2.add_batch(s[:30])
+    np.random.seed(11)
+    b = buf2.sample_batch(16)
+    for k in ("obs", "obs2", "act", "rew", "done", "logp"):
+        np.testing.assert_array_equal(b[k].numpy(), z["b30/" + k])
+    buf2.add_batch(s[30:])
+    assert (buf2.size, buf2.ptr) == (int(z["size_73"]), int(z["ptr_73"]))
+    b = buf2.sample_batch(16)
+    for k in ("obs", "obs2", "act", "rew", "done", "logp"):
+        np.testing.assert_array_equal(b[k].numpy(), z["b73/" + k])
+
+
+def test_buffer_fast_path_equals_host_path():
+    """HipReplayBuffer token (minibatch stays in HBM) == reference-style dict of CPU tensors."""
+    from plugin import create_buffer
+
+    O, A, B = 11, 3, 64
+    a1, _ = make_pair(O, A, (64, 64), B, seed=2)
+    buf = create_buffer(**hip_kwargs(O, A, (64, 64), B, buffer_max_size=500))
+    rng = np.random.default_rng(9)
+    n = 300
+    buf.engine.buffer_add(rng.standard_normal((n, O), dtype=np.float32), rng.uniform(-.4, .4, (n, A)).astype(np.float32),
+                          rng.standard_normal(n, dtype=np.float32), rng.standard_normal((n, O), dtype=np.float32),
+                          (rng.random(n) < 0.1).astype(np.float32))
+    a2, _ = make_pair(O, A, (64, 64), B, seed=2)
+    for it in range(3):
+        np.random.seed(it)
+        tok = buf.sample_batch(B)
+        host = {k: v.clone() for k, v in tok.items()}
+        torch.manual_seed(it)
+        a1.local_update(tok, it)
+        torch.manual_seed(it)
+        a2.local_update(host, it)
+    a1.engine.sync(); a2.engine.sync()
+    assert torch.equal(a1.engine.online, a2.engine.online)
+
+
+def test_graph_replay_equals_eager_steps():
+    O, A, B, N = 17, 4, 64, 4096
+    algs = []
+    for mode in ("eager", "graph"):
+        alg, _ = make_pair(O, A, (64, 64), B, seed=4)
+        e = alg.engine
+        e.set_device_rng(12345)
+        e.buffer_create(N)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        e.buffer_fill_device(0, torch.randn(N, O, device="cuda", generator=g), torch.rand(N, A, device="cuda", generator=g) - .5,
+                             torch.randn(N, device="cuda", generator=g), torch.randn(N, O, device="cuda", generator=g),
+                             (torch.rand(N, device="cuda", generator=g) < .05).float())
+        np.random.seed(1)
+        idx = np.random.randint(0, N, size=(8, B))
+        e.upload_index_table(idx)
+        if mode == "graph":
+            e.graph_build(2)
+            e.graph_run(0, 8)
+        else:
+            ms = e.time_steps(0, 8, use_graph=False)
+            assert ms > 0
+        e.sync()
+        algs.append(alg)
+    assert torch.equal(algs[0].engine.online, algs[1].engine.online)
+    assert torch.equal(algs[0].engine.target, algs[1].engine.target)
+    st = algs[1].engine.get_state()
+    assert st["adam_steps"] == [8, 4, 4]
+    assert torch.isfinite(algs[1].engine.online).all()
+
+
+def test_device_rng_is_standard_normal():
+    alg, _ = make_pair(8, 8, (32,), 1024)
+    e = alg.engine
+    e.set_device_rng(99)
+    data = synth_batch(np.random.default_rng(0), 1024, 8, 8)
+    e.load_batch(*(data[k].numpy() for k in ("obs", "act", "rew", "obs2", "done")))
+    e.step(0)
+    a = np.concatenate([e.debug_read("eps_new"), e.debug_read("eps_2"), e.debug_read("z5"), e.debug_read("z6")])
+    assert abs(a.mean()) < 0.03 and abs(a.std() - 1.0) < 0.03
+    e.step(1)
+    b = e.debug_read("eps_new")
+    assert not np.array_equal(a[: b.size], b)
+
+
+def test_policy_forward_and_checkpoint_roundtrip(tmp_path):
+    from dsac_v2_hip import ApproxContainer
+
+    O, A, hid, B = 376, 17, (256, 256, 256), 256
+    alg, orc = make_pair(O, A, hid, B)
+    obs = torch.randn(5, O)
+    lg = alg.networks.policy(obs)
+    from oracle.dsact_oracle import policy_forward
+    want = policy_forward(obs, [p.detach() for p in orc.p["policy"]], orc.cfg)
+    assert torch.allclose(lg, want, atol=2e-5, rtol=1e-5)
+    dist = alg.networks.create_action_distributions(lg)
+    act, logp = dist.sample()
+    assert act.shape == (5, A) and logp.shape == (5,) and act.abs().max() <= 0.4 + 1e-6
+    # state_dict format == reference checkpoints
+    import json
+    lay = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "checkpoint_layout.json")))
+    sd = {k: v.clone() for k, v in alg.networks.state_dict().items()}  # state_dict() aliases the arenas
+    assert [[k, list(v.shape)] for k, v in sd.items()] == lay["humanoid_l3"]
+    p = str(tmp_path / "apprfunc_0.pkl")
+    torch.save(sd, p)
+    data = synth_batch(np.random.default_rng(0), B, O, A)
+    torch.manual_seed(0)
+    alg.local_update(data, 0)
+    changed = alg.networks.state_dict()
+    assert not torch.equal(changed["q1.q.0.weight"], sd["q1.q.0.weight"])
+    alg.networks.load_state_dict(torch.load(p))
+    back = alg.networks.state_dict()
+    for k in sd:
+        assert torch.equal(back[k].cpu(), sd[k].cpu()), k
+    # a stand-alone CPU container (sampler / evaluator / PolicyRunner) loads the same file
+    cpu = ApproxContainer(**hip_kwargs(O, A, hid, B))
+    cpu.load_state_dict(torch.load(p, map_location="cpu"))
+    assert torch.allclose(cpu.policy(obs), lg, atol=2e-5, rtol=1e-5)

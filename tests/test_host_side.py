@@ -1,0 +1,109 @@
+"""CPU-side checks (no GPU): C-ABI exports, arena layout / cost model, plugin surface on CPU."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, hip_kwargs
+from oracle.dsact_oracle import DsactOracle, default_config, policy_forward
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    return g
+
+
+def test_library_exports_every_declared_symbol(built):
+    from dsact import _ffi
+    lib = _ffi.load()
+    hdr = open(os.path.join(ROOT, "include", "dsact.h")).read()
+    declared = sorted(set(re.findall(r"\b(dsact_[a-z_0-9]+)\s*\(", hdr)))
+    bound = sorted(n for n, _, _ in _ffi.SYMBOLS)
+    assert declared == bound, set(declared) ^ set(bound)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.dsact_version() >= 1
+    # no GPU here: the library must say so instead of computing anything
+    if lib.dsact_device_count() == 0:
+        cfg = _ffi.Config()
+        h = ctypes.c_void_p()
+        assert lib.dsact_create(ctypes.byref(cfg), 0, ctypes.byref(h)) == -4  # DSACT_E_NODEVICE
+
+
+def test_update_path_fails_loudly_without_gpu(built):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from dsac_v2_hip import DSAC_V2_HIP
+    from dsact._ffi import DsactError
+    with pytest.raises(DsactError):
+        DSAC_V2_HIP(**hip_kwargs(11, 3, (32, 32), 32))
+
+
+def test_layout_counts_and_cost_model_match_survey():
+    from dsact.layout import ArenaLayout
+    l3 = ArenaLayout(376, 17, [256, 256, 256])
+    assert (l3.n_q, l3.n_pi, l3.n_online - 1 + l3.n_target) == (232962, 236834, 1405516)
+    f, b = l3.mac_per_sample()
+    assert (f, b) == (1865216, 1375232)
+    assert abs(l3.flop_per_step(256) / 1e9 - 1.659) < 1e-3
+    assert abs(l3.bytes_per_step(256) / 1e6 - 23.25) < 0.02
+    l2 = ArenaLayout(376, 17, [256, 256])
+    f, b = l2.mac_per_sample()
+    assert (f, b) == (1340928, 850944)
+    assert abs(l2.bytes_per_step(256) / 1e6 - 16.93) < 0.02
+    lay = json.load(open(os.path.join(GOLDEN, "checkpoint_layout.json")))
+    assert [[k, list(v)] for k, v in l3.state_dict_keys().items()] == lay["humanoid_l3"]
+
+
+def test_cpu_container_matches_reference_init_and_format():
+    from dsac_v2_hip import ApproxContainer
+    O, A, hid = 376, 17, (256, 256, 256)
+    torch.manual_seed(0)
+    net = ApproxContainer(**hip_kwargs(O, A, hid, 256))
+    torch.manual_seed(0)
+    orc = DsactOracle(default_config(O, A, hid))  # same init as the reference (tests/test_oracle_vs_reference.py)
+    sd, osd = net.state_dict(), orc.state_dict()
+    assert list(sd.keys()) == list(osd.keys())
+    for k in sd:
+        assert torch.equal(sd[k], osd[k]), k
+    obs = torch.randn(3, O)
+    assert torch.equal(net.policy(obs), policy_forward(obs, [p.detach() for p in orc.p["policy"]], orc.cfg))
+    dist = net.create_action_distributions(net.policy(obs))
+    torch.manual_seed(5)
+    a, lp = dist.sample()
+    torch.manual_seed(5)
+    x = torch.distributions.Normal(dist.mean, dist.std).sample()
+    assert torch.equal(a, 0.4 * torch.tanh(x))
+    assert a.shape == (3, A) and lp.shape == (3,)
+    assert torch.allclose(dist.mode(), 0.4 * torch.tanh(dist.mean))
+    lim = json.load(open(os.path.join(GOLDEN, "checkpoint_layout.json")))["pendulum_shipped"]
+    pend = ApproxContainer(**hip_kwargs(3, 1, (256, 256, 256), 256, act_limit=2.0))
+    assert [[k, list(v.shape)] for k, v in pend.state_dict().items()] == lim
+
+
+def test_unsupported_configs_raise():
+    from dsac_v2_hip import ApproxContainer
+    with pytest.raises(NotImplementedError):
+        ApproxContainer(**hip_kwargs(4, 2, (32,), 8, value_func_type="CNN"))
+    with pytest.raises(NotImplementedError):
+        ApproxContainer(**hip_kwargs(4, 2, (32,), 8, policy_hidden_activation="relu"))
+    with pytest.raises(NotImplementedError):
+        ApproxContainer(**hip_kwargs(4, 2, (32,), 8, value_hidden_sizes=[16]))
+
+
+def test_plugin_discovery_rules():
+    import plugin
+    assert plugin.camel("hip_replay_buffer") == "HipReplayBuffer"
+    import importlib
+    m = importlib.import_module("training.hip_replay_buffer")
+    assert hasattr(m, "HipReplayBuffer")
+    m = importlib.import_module("dsac_v2_hip")
+    assert hasattr(m, "DSAC_V2_HIP") and hasattr(m, "ApproxContainer")
