@@ -499,8 +499,8 @@ __global__ void __launch_bounds__(kThreads) k_heads(HeadsArgs a) {
 //   phase 2  output layers of q1_t,q2_t(obs2,act2) and q1,q2(obs,new_act)   (wave per row)
 //   phase 3  per-sample targets / ratio / losses -> dL/d(out) of the 4 differentiated chains
 //   phase 4  dZ of the last hidden layer of those chains: (dOut . Wout) * GELU'(z)
-// part_loss[wg][12]: loss_q1, loss_q2, sum q1, q2, std1, std2, actor, logp_new, then [10],[11] =
-// min std1, min std2 (reduced with min).
+// part_loss[wg][12]: loss_q1, loss_q2, sum q1, q2, std1, std2, actor, logp_new, [8] = alpha used by
+// this update (workgroup 0 only), then [10],[11] = min std1, min std2 (reduced with min).
 // ---------------------------------------------------------------------------------------------
 constexpr int kLossPart = 12;
 struct LossArgs {
@@ -629,7 +629,9 @@ __global__ void __launch_bounds__(kThreads) k_loss(LossArgs a) {
   __syncthreads();
   if (tid < kLossPart) {
     const float v0 = red[tid], v1 = red[kLossPart + tid], v2 = red[2 * kLossPart + tid], v3 = red[3 * kLossPart + tid];
-    a.part_loss[blockIdx.x * kLossPart + tid] = tid < 10 ? (v0 + v1) + (v2 + v3) : fminf(fminf(v0, v1), fminf(v2, v3));
+    float pv = tid < 10 ? (v0 + v1) + (v2 + v3) : fminf(fminf(v0, v1), fminf(v2, v3));
+    if (tid == 8) pv = blockIdx.x == 0 ? alpha : 0.0f;  // tb_info reports the alpha the losses used
+    a.part_loss[blockIdx.x * kLossPart + tid] = pv;
   }
   // ---- phase 4 ---- (dL/d(out) of my rows is staged in LDS)
   __syncthreads();
@@ -820,7 +822,7 @@ __global__ void k_stats(StatsArgs a) {
     o[7] = s[0] * a.inv_B + s[1] * a.inv_B;
     o[8] = h0 * a.inv_BA; o[9] = h1 * a.inv_BA;
     o[10] = -(s[7] * a.inv_B);
-    o[11] = a.auto_alpha ? expf(a.log_alpha[0]) : a.alpha_fixed;
+    o[11] = s[8];
     o[12] = a.st->ms1; o[13] = a.st->ms2;
     o[14] = (float)a.st->it_cur; o[15] = 0.f;
   }

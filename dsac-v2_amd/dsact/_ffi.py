@@ -99,6 +99,10 @@ def load():
         raise DsactError(
             "libdsact.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950). The DSAC-T HIP path has no CPU fallback." % LIB_PATH)
+    # torch-ROCm bundles its own libamdhip64; it must be in the process BEFORE libdsact.so so that both
+    # resolve to the SAME HIP runtime (device pointers and streams are shared across the boundary).
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the header and the library drifted apart

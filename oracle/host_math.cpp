@@ -1,0 +1,38 @@
+// TEST INFRASTRUCTURE ONLY: the scalar closed forms of dsac-v2_amd/csrc/dsact_math.h compiled for
+// the host so that tests/test_host_math.py can check them against torch autograd on a CPU box.
+// Never loaded by the product.
+#include "dsact_math.h"
+
+extern "C" {
+void hm_gelu(const float* z, int n, float* h, float* g) {
+  for (int i = 0; i < n; ++i) dsact::gelu_fwd_grad(z[i], h[i], g[i]);
+}
+void hm_softplus(const float* x, int n, float* y, float* dy) {
+  for (int i = 0; i < n; ++i) { y[i] = dsact::softplus(x[i]); dy[i] = dsact::softplus_grad(x[i]); }
+}
+void hm_tanh_gauss_fwd(const float* mu, const float* raw, const float* eps, int n, float s, float c, float lo,
+                       float hi, float* a, float* lp) {
+  for (int i = 0; i < n; ++i) {
+    dsact::TanhGaussFwd f = dsact::tanh_gauss_fwd(mu[i], raw[i], eps[i], s, c, lo, hi);
+    a[i] = f.a; lp[i] = f.lp;
+  }
+}
+void hm_tanh_gauss_bwd(const float* mu, const float* raw, const float* eps, const float* gA, int n, float s,
+                       float lo, float hi, float gLp, float* dmu, float* draw) {
+  for (int i = 0; i < n; ++i) dsact::tanh_gauss_bwd(mu[i], raw[i], eps[i], s, lo, hi, gA[i], gLp, dmu[i], draw[i]);
+}
+void hm_critic(const float* q, const float* stdv, const float* tq, const float* tqs, int n, float ms, float* loss,
+               float* dq, float* dstd) {
+  for (int i = 0; i < n; ++i) {
+    dsact::CriticTerm t = dsact::critic_term(q[i], stdv[i], ms, tq[i], tqs[i]);
+    loss[i] = t.loss; dq[i] = t.dq; dstd[i] = t.dstd;
+  }
+}
+void hm_adam(float* p, float* m, float* v, const float* g, int n, float b1w, float beta2, float b2w, float ss,
+             float bc2, float eps) {
+  for (int i = 0; i < n; ++i) dsact::adam_update(p[i], m[i], v[i], g[i], b1w, beta2, b2w, ss, bc2, eps);
+}
+void hm_polyak(float* pt, const float* p, int n, float polyak, float one_minus) {
+  for (int i = 0; i < n; ++i) pt[i] = dsact::polyak_update(pt[i], p[i], polyak, one_minus);
+}
+}

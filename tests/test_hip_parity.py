@@ -116,6 +116,7 @@ def run_case(title, O, A, hid, B, steps, act_limit=0.4, init=None, golden=None, 
         e.load_batch(*(data[k].numpy() for k in ("obs", "act", "rew", "obs2", "done")))
         e.set_noise(noise["eps_new"].numpy(), noise["eps_2"].numpy(), noise["z5"].numpy(), noise["z6"].numpy())
         e.compute_grads(it)
+        e.sync()  # the engine runs on its own stream; torch reads below are on torch's
         if keep:
             compare_intermediates(rep, alg, orc, L, B, A)
         g = e.grads.cpu().numpy()
@@ -126,7 +127,7 @@ def run_case(title, O, A, hid, B, steps, act_limit=0.4, init=None, golden=None, 
             off += n
         e.apply_update(it)
         orc.update(it)
-        st = e.read_stats()
+        st = e.read_stats()  # synchronous
         for k in TB_KEYS[:-1]:
             want = float(tb_ref[k])
             rep.cmp("it%d %s" % (it, k.split("/")[-1][:18]), [st[k]], [want], 1e-4, 1e-4)

@@ -1,0 +1,121 @@
+"""The scalar closed forms every HIP kernel uses (dsac-v2_amd/csrc/dsact_math.h), compiled for the
+host, against torch ops / autograd -- the same ops the reference calls. CPU only."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FP = C.POINTER(C.c_float)
+
+
+@pytest.fixture(scope="module")
+def hm():
+    import __graft_entry__ as g
+    g.build()
+    return C.CDLL(os.path.join(ROOT, "oracle", "_build", "libdsact_hostmath.so"))
+
+
+def p(a):
+    return a.ctypes.data_as(FP)
+
+
+def f32(t):
+    return np.ascontiguousarray(t.detach().numpy().astype(np.float32))
+
+
+def test_gelu_and_softplus(hm):
+    z = torch.cat([torch.randn(5000) * 3, torch.tensor([0.0, -10.0, 10.0, 25.0, -25.0])]).requires_grad_(True)
+    h = F.gelu(z)
+    h.sum().backward()
+    zn = f32(z)
+    ho, go = np.empty_like(zn), np.empty_like(zn)
+    hm.hm_gelu(p(zn), zn.size, p(ho), p(go))
+    np.testing.assert_allclose(ho, f32(h), atol=1e-6, rtol=1e-6)
+    np.testing.assert_allclose(go, f32(z.grad), atol=2e-6, rtol=1e-6)
+    x = torch.cat([torch.randn(3000) * 8, torch.tensor([20.0, 20.0001, 19.9999, -30.0])]).requires_grad_(True)
+    y = F.softplus(x)
+    y.sum().backward()
+    xn = f32(x)
+    yo, dyo = np.empty_like(xn), np.empty_like(xn)
+    hm.hm_softplus(p(xn), xn.size, p(yo), p(dyo))
+    np.testing.assert_allclose(yo, f32(y), atol=1e-6, rtol=1e-6)
+    np.testing.assert_allclose(dyo, f32(x.grad), atol=1e-6, rtol=1e-6)
+
+
+def test_tanh_gauss_forward_backward(hm):
+    from oracle.dsact_oracle import tanh_gauss_rsample
+    n = 4000
+    torch.manual_seed(0)
+    mu = (torch.randn(n) * 1.5).requires_grad_(True)
+    raw = torch.cat([torch.randn(n - 4) * 2 - 1, torch.tensor([0.5, 0.6, -20.0, -21.0])]).requires_grad_(True)
+    eps = torch.randn(n)
+    std = torch.clamp(raw, -20.0, 0.5).exp()
+    hi, lo = torch.tensor([0.4]), torch.tensor([-0.4])
+    # one action dimension per row: Independent(...).sum(-1) over a single column
+    act, lp = tanh_gauss_rsample(torch.stack([mu, std], -1).unsqueeze(1).reshape(n, 2), eps.unsqueeze(-1), hi, lo)
+    gA = torch.randn(n)
+    gLp = 0.0123
+    ((act.squeeze(-1) * gA).sum() + gLp * lp.sum()).backward()
+    a_o, lp_o = np.empty(n, np.float32), np.empty(n, np.float32)
+    hm.hm_tanh_gauss_fwd.argtypes = [FP, FP, FP, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, FP, FP]
+    hm.hm_tanh_gauss_fwd(p(f32(mu)), p(f32(raw)), p(f32(eps)), n, 0.4, 0.0, -20.0, 0.5, p(a_o), p(lp_o))
+    np.testing.assert_allclose(a_o, f32(act.squeeze(-1)), atol=1e-6)
+    np.testing.assert_allclose(lp_o, f32(lp), atol=3e-5, rtol=1e-5)
+    dmu, draw = np.empty(n, np.float32), np.empty(n, np.float32)
+    hm.hm_tanh_gauss_bwd.argtypes = [FP, FP, FP, FP, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, FP, FP]
+    hm.hm_tanh_gauss_bwd(p(f32(mu)), p(f32(raw)), p(f32(eps)), p(f32(gA)), n, 0.4, -20.0, 0.5, gLp, p(dmu), p(draw))
+    np.testing.assert_allclose(dmu, f32(mu.grad), atol=2e-6, rtol=2e-5)
+    np.testing.assert_allclose(draw, f32(raw.grad), atol=2e-6, rtol=2e-4)
+
+
+def test_critic_term_matches_reference_loss_autograd(hm):
+    n = 5000
+    torch.manual_seed(1)
+    q = (torch.randn(n) * 40).requires_grad_(True)      # many |q - tq| > 50 (Huber saturated)
+    std = (torch.rand(n) * 3 + 1e-3).requires_grad_(True)
+    tq, tqs = torch.randn(n) * 40, torch.randn(n) * 60
+    ms = torch.tensor(0.8)
+    sd = torch.clamp(std, min=0.0).detach()
+    ratio = (ms.pow(2) / (sd.pow(2) + 0.1)).clamp(min=0.1, max=10)
+    tqb = (q.detach() + torch.clamp(tqs - q.detach(), -3 * ms, 3 * ms))
+    hub = lambda a, b: F.huber_loss(a, b, delta=50, reduction="none")
+    per = ratio * (hub(q, tq) + std * (sd.pow(2) - hub(q.detach(), tqb)) / (sd + 0.1))
+    per.sum().backward()
+    lo, dq, ds = (np.empty(n, np.float32) for _ in range(3))
+    hm.hm_critic.argtypes = [FP, FP, FP, FP, C.c_int, C.c_float, FP, FP, FP]
+    hm.hm_critic(p(f32(q)), p(f32(std)), p(f32(tq)), p(f32(tqs)), n, 0.8, p(lo), p(dq), p(ds))
+    np.testing.assert_allclose(lo, f32(per), rtol=2e-6, atol=1e-5)
+    np.testing.assert_allclose(dq, f32(q.grad), rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(ds, f32(std.grad), rtol=2e-6, atol=1e-5)
+
+
+def test_adam_and_polyak_track_torch(hm):
+    n = 4096
+    torch.manual_seed(2)
+    prm = torch.randn(n).requires_grad_(True)
+    opt = torch.optim.Adam([prm], lr=1e-4)
+    pn, m, v = f32(prm).copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    hm.hm_adam.argtypes = [FP, FP, FP, FP, C.c_int] + [C.c_float] * 6
+    tgt = torch.randn(n)
+    tn = f32(tgt).copy()
+    hm.hm_polyak.argtypes = [FP, FP, C.c_int, C.c_float, C.c_float]
+    for t in range(1, 8):
+        g = torch.randn(n) * (10.0 ** float(np.random.default_rng(t).integers(-6, 2)))
+        prm.grad = g.clone()
+        opt.step()
+        ss = np.float32(1e-4 / (1 - 0.9 ** t))
+        bc2 = np.float32((1 - 0.999 ** t) ** 0.5)
+        hm.hm_adam(p(pn), p(m), p(v), p(f32(g)), n, np.float32(1 - 0.9), np.float32(0.999), np.float32(1 - 0.999), ss, bc2, np.float32(1e-8))
+        np.testing.assert_allclose(pn, f32(prm), atol=2e-9, rtol=3e-7)
+        polyak = 1 - 0.005
+        tgt.mul_(polyak)
+        tgt.add_((1 - polyak) * prm.data)
+        hm.hm_polyak(p(tn), p(pn), n, np.float32(polyak), np.float32(1 - polyak))
+        np.testing.assert_allclose(tn, f32(tgt), atol=1e-9, rtol=3e-7)
+    st = opt.state[prm]
+    np.testing.assert_allclose(m, f32(st["exp_avg"]), rtol=1e-6, atol=1e-7 * float(np.abs(m).max()))
+    np.testing.assert_allclose(v, f32(st["exp_avg_sq"]), rtol=1e-6, atol=1e-7 * float(np.abs(v).max()))
