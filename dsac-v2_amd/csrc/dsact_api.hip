@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -32,9 +34,12 @@ struct NetDesc {
   size_t count = 0;
 };
 
-struct Stage {
+struct Stage {            // one k_stage launch: <= kMaxProb GEMM problems in the kernel arguments
   std::string name;
-  int task_off = 0, n_tasks = 0;
+  StageArgs args;
+  int n_blocks = 0;
+  int max_k = 0;          // longest contraction of the stage -> dynamic LDS
+  int kind = 0;           // 0 forward (KC x KC, bias+GELU), 1 backward (KC x MC, * GELU'), 2 KC x MC plain store
 };
 
 struct ProfRec {
@@ -70,7 +75,9 @@ struct dsact_handle {
   float *qout_c[2], *qout_t[2], *qout_p[2];
   float* dout[4];
   float *dout_pi, *d_new_act;
+  float* dA[2];  // dL/d new_act through q1 / q2  [B x A]
   float *part_loss, *part_heads, *stats, *ones, *std_sums;
+  long long* timeline;  // [512][8] stamps of the stage named by DSACT_TIMELINE_STAGE (instrumented builds)
   float *act_scale, *act_center;
   DevState* st = nullptr;
   int* idx_eager = nullptr;
@@ -80,9 +87,10 @@ struct dsact_handle {
   // stand-alone policy forward
   float *Xact, *Hact[DSACT_MAX_HIDDEN_LAYERS], *Gact, *act_out;
   // tasks
-  TileTask* d_tasks = nullptr;
+  GemmProb* d_tiles = nullptr;   // per-tile table of the weight/bias-gradient stage
+  int n_dw_tiles = 0;
   std::vector<Stage> fwd1, fwd2, bwdq, bwdpi, actf;
-  Stage dw;
+  Stage bwda;  // dA = dZ1(q_i(obs,new_act)) . W1_i[:, O:O+A]
   // replay ring
   long long cap = 0, ptr = 0, size = 0;
   float *rb_obs = nullptr, *rb_obs2 = nullptr, *rb_act = nullptr, *rb_rew = nullptr, *rb_done = nullptr, *rb_logp = nullptr;
@@ -227,11 +235,14 @@ void carve(dsact_handle* h, Carver& c) {
   for (int i = 0; i < 4; ++i) h->dout[i] = c.take<float>(B * 2);
   h->dout_pi = c.take<float>(B * 2 * A);
   h->d_new_act = c.take<float>(B * A);
+  h->dA[0] = c.take<float>(B * A);
+  h->dA[1] = c.take<float>(B * A);
   h->part_loss = c.take<float>((size_t)h->n_loss_wg * kLossPart);
   h->part_heads = c.take<float>((size_t)h->n_heads_wg * 2);
   h->stats = c.take<float>(16);
   h->ones = c.take<float>(B);
   h->std_sums = c.take<float>(2);
+  h->timeline = c.take<long long>(512 * 8);
   h->act_scale = c.take<float>(A);
   h->act_center = c.take<float>(A);
   h->idx_eager = c.take<int>(B);
@@ -243,16 +254,7 @@ void carve(dsact_handle* h, Carver& c) {
   h->act_out = c.take<float>((size_t)kActRows * 2 * A);
 }
 
-// ---- task tables --------------------------------------------------------------------------------
-void add_tiles(std::vector<TileTask>& v, TileTask proto) {
-  for (int m0 = 0; m0 < proto.M; m0 += TM)
-    for (int n0 = 0; n0 < proto.N; n0 += TN) {
-      TileTask t = proto;
-      t.m0 = m0; t.n0 = n0;
-      v.push_back(t);
-    }
-}
-
+// ---- stage descriptions ---------------------------------------------------------------------------
 const float* chain_input(const dsact_handle* h, int ch) {
   switch (ch) {
     case C_PI: case C_Q1C: case C_Q2C: return h->X0;
@@ -261,11 +263,22 @@ const float* chain_input(const dsact_handle* h, int ch) {
   }
 }
 
-TileTask fwd_task(const dsact_handle* h, int ch, int l, const float* x0, int ldx0, int M, float* const* Hrow, float* Grow) {
+int tiles_of(int n, int t) { return (n + t - 1) / t; }
+
+void stage_add(Stage& s, GemmProb g) {
+  g.tiles_n = tiles_of(g.N, TN);
+  const int nt = tiles_of(g.M, TM) * g.tiles_n;
+  s.n_blocks += nt;
+  g.tile_end = s.n_blocks;
+  if (g.K > s.max_k) s.max_k = g.K;
+  s.args.p[s.args.n_prob++] = g;
+}
+
+GemmProb fwd_prob(const dsact_handle* h, int ch, int l, const float* x0, int ldx0, int M, float* const* Hrow, float* Grow) {
   const int net = kChainNet[ch];
   const NetDesc& d = net_desc(h, net);
   const float* base = net_params(h, net);
-  TileTask t;
+  GemmProb t;
   memset(&t, 0, sizeof(t));
   t.P = l == 0 ? x0 : Hrow[l - 1];
   t.ldp = l == 0 ? ldx0 : d.out[l - 1];
@@ -276,108 +289,160 @@ TileTask fwd_task(const dsact_handle* h, int ch, int l, const float* x0, int ldx
   t.C1 = Grow;
   t.ldc = d.out[l];
   t.M = M; t.N = d.out[l]; t.K = d.in[l];
-  t.layout = LAY_KC_KC; t.epi = EPI_GELU;
   return t;
 }
 
 int build_tasks(dsact_handle* h) {
-  std::vector<TileTask> all;
   const int L = h->L, B = h->B;
-  auto begin = [&](Stage& s, const std::string& name) { s.name = name; s.task_off = (int)all.size(); };
-  auto end = [&](Stage& s) { s.n_tasks = (int)all.size() - s.task_off; };
-  // forward group 1: policy(obs), policy_target(obs2), q1/q2(obs,act); group 2: q1_t/q2_t(obs2,act2), q1/q2(obs,new_act)
+  auto fresh = [](const std::string& name, int kind) {
+    Stage s;
+    s.name = name; s.kind = kind; s.n_blocks = 0;
+    memset(&s.args, 0, sizeof(s.args));
+    return s;
+  };
+  // forward group A: policy(obs), policy_target(obs2), q1/q2(obs,act); group B: q1_t/q2_t(obs2,act2), q1/q2(obs,new_act)
   const int g1[4] = {C_PI, C_PIT, C_Q1C, C_Q2C}, g2[4] = {C_Q1T, C_Q2T, C_Q1P, C_Q2P};
-  h->fwd1.assign(L, Stage()); h->fwd2.assign(L, Stage());
+  h->fwd1.clear(); h->fwd2.clear();
   for (int grp = 0; grp < 2; ++grp)
     for (int l = 0; l < L; ++l) {
-      Stage& s = grp == 0 ? h->fwd1[l] : h->fwd2[l];
-      begin(s, std::string(grp == 0 ? "fwdA_l" : "fwdB_l") + std::to_string(l));
+      Stage s = fresh(std::string(grp == 0 ? "fwdA_l" : "fwdB_l") + std::to_string(l), 0);
       for (int i = 0; i < 4; ++i) {
         const int ch = grp == 0 ? g1[i] : g2[i];
-        add_tiles(all, fwd_task(h, ch, l, chain_input(h, ch), h->ldx, B, h->Hb[ch], h->Gb[ch][l]));
+        stage_add(s, fwd_prob(h, ch, l, chain_input(h, ch), h->ldx, B, h->Hb[ch], h->Gb[ch][l]));
       }
-      end(s);
+      (grp == 0 ? h->fwd1 : h->fwd2).push_back(s);
     }
   // backward through hidden layers: dZ[l-1] = (dZ[l] W_l) * G[l-1]
-  auto bwd_task = [&](int ch, int l) {
+  auto bwd_prob = [&](int ch, int l) {
     const int net = kChainNet[ch];
     const NetDesc& d = net_desc(h, net);
     const float* base = net_params(h, net);
     const int slot = kDzSlot[ch];
-    TileTask t;
+    GemmProb t;
     memset(&t, 0, sizeof(t));
     t.P = h->dZ[slot][l]; t.ldp = d.out[l];
     t.Q = base + d.w_off[l]; t.ldq = d.in[l];
     t.aux = h->Gb[ch][l - 1]; t.ldaux = d.in[l];
     t.C0 = h->dZ[slot][l - 1]; t.ldc = d.in[l];
     t.M = B; t.N = d.in[l]; t.K = d.out[l];
-    t.layout = LAY_KC_MC; t.epi = EPI_MULG;
     return t;
   };
-  h->bwdq.assign(L > 1 ? L - 1 : 0, Stage()); h->bwdpi.assign(L > 1 ? L - 1 : 0, Stage());
+  h->bwdq.clear(); h->bwdpi.clear();
   for (int l = L - 1; l >= 1; --l) {
-    Stage& s = h->bwdq[L - 1 - l];
-    begin(s, "bwdQ_l" + std::to_string(l));
-    for (int ch : {C_Q1C, C_Q2C, C_Q1P, C_Q2P}) add_tiles(all, bwd_task(ch, l));
-    end(s);
+    Stage s = fresh("bwdQ_l" + std::to_string(l), 1);
+    for (int ch : {C_Q1C, C_Q2C, C_Q1P, C_Q2P}) stage_add(s, bwd_prob(ch, l));
+    h->bwdq.push_back(s);
   }
   for (int l = L - 1; l >= 1; --l) {
-    Stage& s = h->bwdpi[L - 1 - l];
-    begin(s, "bwdPi_l" + std::to_string(l));
-    add_tiles(all, bwd_task(C_PI, l));
-    end(s);
+    Stage s = fresh("bwdPi_l" + std::to_string(l), 1);
+    stage_add(s, bwd_prob(C_PI, l));
+    h->bwdpi.push_back(s);
   }
-  // weight / bias gradients of q1, q2, policy
-  begin(h->dw, "dW");
+  // action gradient through the first layer of q1 / q2: dA_i = dZ1_i . W1_i[:, O:O+A]
+  h->bwda = fresh("bwdA", 2);
+  for (int qi = 0; qi < 2; ++qi) {
+    const int ch = qi == 0 ? C_Q1P : C_Q2P;
+    GemmProb t;
+    memset(&t, 0, sizeof(t));
+    t.P = h->dZ[kDzSlot[ch]][0]; t.ldp = h->w[0];
+    t.Q = net_params(h, kChainNet[ch]) + h->qd.w_off[0] + h->O; t.ldq = h->O + h->A;
+    t.C0 = h->dA[qi]; t.ldc = h->A;
+    t.M = B; t.N = h->A; t.K = h->w[0];
+    stage_add(h->bwda, t);
+  }
+  // stand-alone policy forward (kActRows rows)
+  h->actf.clear();
+  for (int l = 0; l < L; ++l) {
+    Stage s = fresh("act_l" + std::to_string(l), 0);
+    stage_add(s, fwd_prob(h, C_PI, l, h->Xact, h->ldx, kActRows, h->Hact, h->Gact));
+    h->actf.push_back(s);
+  }
+  // weight / bias gradients of q1, q2, policy: one table entry per 32x32 tile
+  std::vector<GemmProb> tiles;
+  auto add_tiles = [&](GemmProb t) {
+    for (int m0 = 0; m0 < t.M; m0 += TM)
+      for (int n0 = 0; n0 < t.N; n0 += TN) {
+        GemmProb q = t;
+        q.tiles_n = m0; q.tile_end = n0;  // table form: tile origin
+        tiles.push_back(q);
+      }
+  };
   for (int ch : {C_Q1C, C_Q2C, C_PI}) {
     const int net = kChainNet[ch];
     const NetDesc& d = net_desc(h, net);
     float* g = net_grads(h, net);
     const int slot = kDzSlot[ch];
     for (int l = 0; l <= L; ++l) {
-      TileTask t;
+      GemmProb t;
       memset(&t, 0, sizeof(t));
       if (l < L) { t.P = h->dZ[slot][l]; t.ldp = d.out[l]; }
       else if (ch == C_PI) { t.P = h->dout_pi; t.ldp = 2 * h->A; }
       else { t.P = h->dout[ch == C_Q1C ? 0 : 1]; t.ldp = 2; }
       t.M = d.out[l]; t.K = B;
-      t.layout = LAY_MC_MC; t.epi = EPI_STORE;
       // weights
       t.Q = l == 0 ? h->X0 : h->Hb[ch][l - 1];
       t.ldq = l == 0 ? h->ldx : d.out[l - 1];
       t.N = d.in[l];
       t.C0 = g + d.w_off[l]; t.ldc = d.in[l];
-      add_tiles(all, t);
+      add_tiles(t);
       // bias: Q = ones
       t.Q = h->ones; t.ldq = 1; t.N = 1;
       t.C0 = g + d.b_off[l]; t.ldc = 1;
-      add_tiles(all, t);
+      add_tiles(t);
     }
   }
-  end(h->dw);
-  // stand-alone policy forward (kActRows rows)
-  h->actf.assign(L, Stage());
-  for (int l = 0; l < L; ++l) {
-    begin(h->actf[l], "act_l" + std::to_string(l));
-    add_tiles(all, fwd_task(h, C_PI, l, h->Xact, h->ldx, kActRows, h->Hact, h->Gact));
-    end(h->actf[l]);
-  }
-  if (h->d_tasks) { hipFree(h->d_tasks); h->d_tasks = nullptr; }
-  HIPCHK(h, hipMalloc(&h->d_tasks, all.size() * sizeof(TileTask)));
-  HIPCHK(h, hipMemcpy(h->d_tasks, all.data(), all.size() * sizeof(TileTask), hipMemcpyHostToDevice));
+  if (h->d_tiles) { hipFree(h->d_tiles); h->d_tiles = nullptr; }
+  h->n_dw_tiles = (int)tiles.size();
+  HIPCHK(h, hipMalloc(&h->d_tiles, tiles.size() * sizeof(GemmProb)));
+  HIPCHK(h, hipMemcpy(h->d_tiles, tiles.data(), tiles.size() * sizeof(GemmProb), hipMemcpyHostToDevice));
   return DSACT_OK;
 }
 
-int run_stage(dsact_handle* h, const Stage& s) {
-  if (s.n_tasks == 0) return DSACT_OK;
-  return launch(h, s.name.c_str(), k_tiles, dim3(s.n_tasks), dim3(kThreads), 0, (const TileTask*)(h->d_tasks + s.task_off));
+long long* tl_for(dsact_handle* h, const char* name) {
+  const char* want = getenv("DSACT_TIMELINE_STAGE");
+  return (want && !strcmp(want, name)) ? h->timeline : nullptr;
+}
+
+int run_stage(dsact_handle* h, const Stage& s0) {
+  if (s0.n_blocks == 0) return DSACT_OK;
+  Stage s = s0;
+  const char* want = getenv("DSACT_TIMELINE_STAGE");
+  s.args.timeline = (want && s.name == want) ? h->timeline : nullptr;
+  const size_t lds = tile_lds_bytes(s.max_k);
+  if (s.kind == 0)
+    return launch(h, s.name.c_str(), k_stage<false, false, EPI_GELU>, dim3(s.n_blocks), dim3(kThreads), lds, s.args);
+  if (s.kind == 2)
+    return launch(h, s.name.c_str(), k_stage<false, true, EPI_STORE>, dim3(s.n_blocks), dim3(kThreads), lds, s.args);
+  return launch(h, s.name.c_str(), k_stage<false, true, EPI_MULG>, dim3(s.n_blocks), dim3(kThreads), lds, s.args);
+}
+
+int run_dw(dsact_handle* h) {
+  return launch(h, "dW", k_stage_table, dim3(h->n_dw_tiles), dim3(kThreads), tile_lds_bytes(h->B), (const GemmProb*)h->d_tiles);
+}
+
+// dispatch on the number of 256-wide chunks of a hidden row (register arrays are statically indexed)
+#define NCH_DISPATCH(W, CALL)                  \
+  do {                                         \
+    const int nch_ = ((W) + 255) / 256;        \
+    if (nch_ <= 1) { CALL(1); }                \
+    else if (nch_ == 2) { CALL(2); }           \
+    else if (nch_ == 3) { CALL(3); }           \
+    else { CALL(4); }                          \
+  } while (0)
+
+// exact decimal value a float config field was written as (0.9f -> 0.9, 1e-4f -> 1e-4): the
+// reference computes Adam's bias corrections from Python doubles
+double dec7(float f) {
+  char buf[32];
+  snprintf(buf, sizeof(buf), "%.7g", (double)f);
+  return strtod(buf, nullptr);
 }
 
 StepHyper step_hyper(const dsact_handle* h) {
   StepHyper hp;
   hp.delay_update = h->cfg.delay_update;
-  hp.lr_q = h->cfg.lr_q; hp.lr_pi = h->cfg.lr_pi; hp.lr_alpha = h->cfg.lr_alpha;
-  hp.beta1 = h->cfg.adam_beta1; hp.beta2 = h->cfg.adam_beta2;
+  hp.lr_q = dec7(h->cfg.lr_q); hp.lr_pi = dec7(h->cfg.lr_pi); hp.lr_alpha = dec7(h->cfg.lr_alpha);
+  hp.beta1 = dec7(h->cfg.adam_beta1); hp.beta2 = dec7(h->cfg.adam_beta2);
   return hp;
 }
 NoiseArgs noise_args(const dsact_handle* h) {
@@ -424,7 +489,9 @@ int enqueue_grads(dsact_handle* h, bool actor_backward) {
     a.qout[0] = h->qout_c[0]; a.qout[1] = h->qout_c[1];
     a.part_heads = h->part_heads; a.act_scale = h->act_scale; a.act_center = h->act_center;
     a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
-    TRY(launch(h, "heads", k_heads, dim3(h->n_heads_wg, 4), dim3(kThreads), 0, a));
+    a.timeline = tl_for(h, "heads");
+#define CALL_HEADS(N) TRY(launch(h, "heads", k_heads<N>, dim3(h->n_heads_wg, 4), dim3(kThreads), 0, a))
+    NCH_DISPATCH(a.W, CALL_HEADS);
   }
   for (int l = 0; l < L; ++l) TRY(run_stage(h, h->fwd2[l]));
   if (h->use_std_sums) {
@@ -459,15 +526,16 @@ int enqueue_grads(dsact_handle* h, bool actor_backward) {
     a.inv_B = 1.0f / (float)B;
     a.inv_Bg = h->use_std_sums ? 1.0f / (float)h->cfg.global_batch : 1.0f / (float)B;
     a.std_sums = h->use_std_sums ? h->std_sums : nullptr;
-    a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.gamma = h->cfg.gamma; a.tau_b = h->cfg.tau_b;
-    TRY(launch(h, "loss", k_loss, dim3(h->n_loss_wg), dim3(kThreads), (size_t)h->loss_rows * 16 * sizeof(float), a));
+    a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.gamma = h->cfg.gamma; a.tau_b = h->cfg.tau_b; a.one_minus_tau_b = (float)(1.0 - dec7(h->cfg.tau_b));
+    a.timeline = tl_for(h, "loss");
+#define CALL_LOSS(N) TRY(launch(h, "loss", k_loss<N>, dim3(h->n_loss_wg), dim3(kThreads), (size_t)h->loss_rows * 16 * sizeof(float), a))
+    NCH_DISPATCH(a.W, CALL_LOSS);
   }
   for (size_t i = 0; i < h->bwdq.size(); ++i) TRY(run_stage(h, h->bwdq[i]));
   {
+    TRY(run_stage(h, h->bwda));
     HeadsBwdArgs a;
-    a.dZ1[0] = h->dZ[kDzSlot[C_Q1P]][0]; a.dZ1[1] = h->dZ[kDzSlot[C_Q2P]][0];
-    a.W1[0] = net_params(h, N_Q1) + h->qd.w_off[0]; a.W1[1] = net_params(h, N_Q2) + h->qd.w_off[0];
-    a.W0 = h->w[0]; a.ld1 = h->O + A;
+    a.dA[0] = h->dA[0]; a.dA[1] = h->dA[1];
     a.logits_pi = h->logits_pi; a.eps_new = h->eps_new; a.log_alpha = h->online + h->n_online - 1;
     a.Wout_pi = net_params(h, N_POL) + h->pd.w_off[L];
     a.G_pi = h->Gb[C_PI][L - 1]; a.dZ_pi = h->dZ[kDzSlot[C_PI]][L - 1];
@@ -475,16 +543,14 @@ int enqueue_grads(dsact_handle* h, bool actor_backward) {
     a.WL = h->w[L - 1]; a.B = B; a.O = h->O; a.A = A;
     a.inv_B = 1.0f / (float)B; a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed;
     a.act_scale = h->act_scale; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
-    TRY(launch(h, "heads_bwd", k_heads_bwd, dim3((B + 3) / 4), dim3(kThreads), 0, a));
+    a.part_loss = h->part_loss; a.n_part = h->n_loss_wg; a.target_entropy = -(float)A;
+    a.grad_log_alpha = h->grads + h->n_online - 1;
+    a.timeline = tl_for(h, "heads_bwd");
+#define CALL_HBWD(N) TRY(launch(h, "heads_bwd", k_heads_bwd<N>, dim3((B + 3) / 4), dim3(kThreads), 0, a))
+    NCH_DISPATCH(a.WL, CALL_HBWD);
   }
   for (size_t i = 0; i < h->bwdpi.size(); ++i) TRY(run_stage(h, h->bwdpi[i]));
-  TRY(run_stage(h, h->dw));
-  {
-    FinalizeArgs a;
-    a.part_loss = h->part_loss; a.n_part = h->n_loss_wg; a.inv_B = 1.0f / (float)B;
-    a.target_entropy = -(float)A; a.grad_log_alpha = h->grads + h->n_online - 1; a.auto_alpha = h->cfg.auto_alpha;
-    TRY(launch(h, "finalize", k_finalize_grads, dim3(1), dim3(64), 0, a));
-  }
+  TRY(run_dw(h));
   (void)actor_backward;
   return DSACT_OK;
 }
@@ -494,16 +560,16 @@ int enqueue_adam(dsact_handle* h) {
   a.p = h->online; a.tgt = h->target; a.m = h->adam_m; a.v = h->adam_v; a.g = h->grads;
   a.n_q2 = (long long)(2 * h->n_q); a.n_online3 = (long long)(2 * h->n_q + h->n_pi); a.n_total = (long long)h->n_online;
   a.st = h->st;
-  a.b1w = (float)(1.0 - (double)h->cfg.adam_beta1);
-  a.beta2 = h->cfg.adam_beta2;
-  a.b2w = (float)(1.0 - (double)h->cfg.adam_beta2);
+  a.b1w = (float)(1.0 - dec7(h->cfg.adam_beta1));
+  a.beta2 = (float)dec7(h->cfg.adam_beta2);
+  a.b2w = (float)(1.0 - dec7(h->cfg.adam_beta2));
   a.eps = h->cfg.adam_eps;
-  const double polyak = 1.0 - (double)h->cfg.tau;  // dsac_v2.py:331
+  const double polyak = 1.0 - dec7(h->cfg.tau);  // dsac_v2.py:331
   a.polyak = (float)polyak;
   a.one_minus_polyak = (float)(1.0 - polyak);
   a.auto_alpha = h->cfg.auto_alpha;
   a.commit_ms = 1;
-  const int blocks = (int)((h->n_online + kThreads * 4 - 1) / (kThreads * 4));
+  const int blocks = (int)((h->n_online + kThreads * 8 - 1) / (kThreads * 8));  // 2 float4 groups per thread
   return launch(h, "adam_polyak", k_adam, dim3(blocks), dim3(kThreads), 0, a);
 }
 
@@ -569,11 +635,24 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   c1.base = h->ws;
   carve(h, c1);
   {
+    DevState st0;
+    memset(&st0, 0, sizeof(st0));
+    st0.b1p_q = st0.b2p_q = st0.b1p_pi = st0.b2p_pi = st0.b1p_alpha = st0.b2p_alpha = 1.0;
+    HIPCHK(h, hipMemcpy(h->st, &st0, sizeof(st0), hipMemcpyHostToDevice));
+  }
+  {
     std::vector<float> ones(h->B, 1.0f);
     HIPCHK(h, hipMemcpy(h->ones, ones.data(), h->B * sizeof(float), hipMemcpyHostToDevice));
   }
   HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   h->own_stream = true;
+  {
+    const int max_lds = (int)tile_lds_bytes(BK * kMaxPrefetchTiles);  // 129 KB of the CU's 160 KB
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, false, EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, true, EPI_MULG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_stage_table, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, true, EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+  }
   for (int i = 0; i < 8; ++i) {
     HIPCHK(h, hipHostMalloc((void**)&h->h_idx[i], (size_t)h->B * sizeof(int), hipHostMallocDefault));
     HIPCHK(h, hipEventCreateWithFlags(&h->h_idx_ev[i], hipEventDisableTiming));
@@ -592,7 +671,7 @@ int dsact_destroy(dsact_handle* h) {
     if (h->h_idx[i]) hipHostFree(h->h_idx[i]);
     if (h->h_idx_ev[i]) hipEventDestroy(h->h_idx_ev[i]);
   }
-  if (h->d_tasks) hipFree(h->d_tasks);
+  if (h->d_tiles) hipFree(h->d_tiles);
   if (h->idx_table) hipFree(h->idx_table);
   if (h->stage_dev) hipFree(h->stage_dev);
   for (float* p : {h->rb_obs, h->rb_obs2, h->rb_act, h->rb_rew, h->rb_done, h->rb_logp})
@@ -668,7 +747,13 @@ int dsact_set_state(dsact_handle* h, const int32_t adam_steps[3], const float me
   HIPCHK(h, hipStreamSynchronize(h->stream));
   DevState st;
   HIPCHK(h, hipMemcpy(&st, h->st, sizeof(st), hipMemcpyDeviceToHost));
-  if (adam_steps) { st.t_q = adam_steps[0]; st.t_pi = adam_steps[1]; st.t_alpha = adam_steps[2]; }
+  if (adam_steps) {
+    st.t_q = adam_steps[0]; st.t_pi = adam_steps[1]; st.t_alpha = adam_steps[2];
+    const double b1 = dec7(h->cfg.adam_beta1), b2 = dec7(h->cfg.adam_beta2);
+    st.b1p_q = pow(b1, st.t_q); st.b2p_q = pow(b2, st.t_q);
+    st.b1p_pi = pow(b1, st.t_pi); st.b2p_pi = pow(b2, st.t_pi);
+    st.b1p_alpha = pow(b1, st.t_alpha); st.b2p_alpha = pow(b2, st.t_alpha);
+  }
   if (mean_std) {
     st.ms_init = (mean_std[0] >= 0.0f && mean_std[1] >= 0.0f) ? 1 : 0;
     st.ms1 = mean_std[0]; st.ms2 = mean_std[1];
@@ -1062,6 +1147,7 @@ int dsact_debug_read(dsact_handle* h, const char* name, float* out, size_t cap, 
       {"dout0", h->dout[0], 2 * B}, {"dout1", h->dout[1], 2 * B}, {"dout2", h->dout[2], 2 * B}, {"dout3", h->dout[3], 2 * B},
       {"dout_pi", h->dout_pi, B * 2 * A}, {"d_new_act", h->d_new_act, B * A},
       {"part_loss", h->part_loss, (size_t)h->n_loss_wg * kLossPart}, {"part_heads", h->part_heads, (size_t)h->n_heads_wg * 2},
+      {"timeline", (const float*)h->timeline, (size_t)512 * 8 * 2},
   };
   for (const E& e : tab) if (s == e.k) { src = e.p; cnt = e.c; }
   if (!src && s.size() > 4 && (s[0] == 'H' || s[0] == 'G' || s.compare(0, 2, "dZ") == 0)) {
@@ -1100,7 +1186,8 @@ int dsact_policy_forward(dsact_handle* h, const float* obs_host, int32_t n, floa
   a.Wout = net_params(h, N_POL) + h->pd.w_off[h->L];
   a.bout = net_params(h, N_POL) + h->pd.b_off[h->L];
   a.W = h->w[h->L - 1]; a.n = n; a.A = h->A; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std; a.out = h->act_out;
-  TRY(launch(h, "policy_out", k_policy_out, dim3((n + 3) / 4), dim3(kThreads), 0, a));
+#define CALL_POUT(N) TRY(launch(h, "policy_out", k_policy_out<N>, dim3((n + 3) / 4), dim3(kThreads), 0, a))
+  NCH_DISPATCH(a.W, CALL_POUT);
   HIPCHK(h, hipMemcpyAsync(logits_host, h->act_out, (size_t)n * 2 * h->A * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return DSACT_OK;

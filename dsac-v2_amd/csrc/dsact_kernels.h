@@ -42,16 +42,61 @@ struct DevState {
   float ss_alpha, bc2_alpha;
   int do_delayed;          // it % delay_update == 0
   int pad;
+  // beta1^t, beta2^t per optimiser as running products (double): device pow() is ~1 us per call
+  double b1p_q, b2p_q, b1p_pi, b2p_pi, b1p_alpha, b2p_alpha;
 };
 
+// opt-in phase timeline (build with -DDSACT_TIMELINE): shader-clock stamps of selected blocks
+#ifdef DSACT_TIMELINE
+#define TL_DECL long long tl_t[8]; int tl_n = 0;
+#define TL_STAMP() do { if (tl_n < 8) tl_t[tl_n++] = (long long)__builtin_readcyclecounter(); } while (0)
+#define TL_FLUSH(buf, slot) do { if ((buf) && threadIdx.x == 0 && (slot) < 512) { \
+    for (int q_ = 0; q_ < 8; ++q_) (buf)[(slot) * 8 + q_] = q_ < tl_n ? tl_t[q_] : 0; } } while (0)
+#else
+#define TL_DECL
+#define TL_STAMP() do {} while (0)
+#define TL_FLUSH(buf, slot) do {} while (0)
+#endif
+
+// Wave64 all-reduce in pure VALU: 4 DPP steps give every lane its 16-lane row total, then
+// v_permlane16_swap / v_permlane32_swap (gfx950) exchange rows and halves. A dependent chain of
+// __shfl_xor (ds_bpermute, an LDS-crossbar round trip per step) costs ~100+ cycles per step; this costs
+// a handful. NOTE the empty asm on the swap results: with identical operands hipcc (ROCm 7.2)
+// copy-propagates the two outputs into one register (emits v_add v1,v1,v1) without it.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void swap16(float v, float& a, float& b) {
+  auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  unsigned r0 = r[0], r1 = r[1];
+  asm volatile("" : "+v"(r0), "+v"(r1));
+  a = __builtin_bit_cast(float, r0); b = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ void swap32(float v, float& a, float& b) {
+  auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  unsigned r0 = r[0], r1 = r[1];
+  asm volatile("" : "+v"(r0), "+v"(r1));
+  a = __builtin_bit_cast(float, r0); b = __builtin_bit_cast(float, r1);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  float a, b;
+  swap16(v, a, b); v = a + b;
+  swap32(v, a, b); v = a + b;
   return v;
 }
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+  v = fminf(v, dpp_mov<0xB1>(v));
+  v = fminf(v, dpp_mov<0x4E>(v));
+  v = fminf(v, dpp_mov<0x141>(v));
+  v = fminf(v, dpp_mov<0x140>(v));
+  float a, b;
+  swap16(v, a, b); v = fminf(a, b);
+  swap32(v, a, b); v = fminf(a, b);
   return v;
 }
 
@@ -98,7 +143,7 @@ __device__ __forceinline__ void normal4(uint64_t seed, long long it, uint32_t st
 // ---------------------------------------------------------------------------------------------
 struct StepHyper {
   int delay_update;
-  float lr_q, lr_pi, lr_alpha, beta1, beta2;
+  double lr_q, lr_pi, lr_alpha, beta1, beta2;  // the decimal values of the config (Python doubles)
 };
 
 __device__ void prologue_duties(DevState* st, long long it, int advance_counters, StepHyper hp) {
@@ -106,20 +151,22 @@ __device__ void prologue_duties(DevState* st, long long it, int advance_counters
   const int delayed = (it % hp.delay_update) == 0;
   st->do_delayed = delayed;
   if (advance_counters) {
-    const int tq = st->t_q + 1;
-    st->t_q = tq;
-    int tp = st->t_pi, ta = st->t_alpha;
-    if (delayed) { tp += 1; ta += 1; st->t_pi = tp; st->t_alpha = ta; }
     // torch Adam: bias_correction1 = 1 - beta1**step ; step_size = lr/bias_correction1 ;
     //             bias_correction2_sqrt = (1 - beta2**step)**0.5      (Python doubles)
-    const double b1 = (double)hp.beta1, b2 = (double)hp.beta2;
-    st->ss_q = (float)((double)hp.lr_q / (1.0 - pow(b1, (double)tq)));
-    st->bc2_q = (float)sqrt(1.0 - pow(b2, (double)tq));
-    const int tpe = tp > 0 ? tp : 1, tae = ta > 0 ? ta : 1;
-    st->ss_pi = (float)((double)hp.lr_pi / (1.0 - pow(b1, (double)tpe)));
-    st->bc2_pi = (float)sqrt(1.0 - pow(b2, (double)tpe));
-    st->ss_alpha = (float)((double)hp.lr_alpha / (1.0 - pow(b1, (double)tae)));
-    st->bc2_alpha = (float)sqrt(1.0 - pow(b2, (double)tae));
+    const double b1 = hp.beta1, b2 = hp.beta2;
+    st->t_q += 1;
+    st->b1p_q *= b1; st->b2p_q *= b2;
+    st->ss_q = (float)(hp.lr_q / (1.0 - st->b1p_q));
+    st->bc2_q = (float)sqrt(1.0 - st->b2p_q);
+    if (delayed) {
+      st->t_pi += 1; st->t_alpha += 1;
+      st->b1p_pi *= b1; st->b2p_pi *= b2;
+      st->b1p_alpha *= b1; st->b2p_alpha *= b2;
+      st->ss_pi = (float)(hp.lr_pi / (1.0 - st->b1p_pi));
+      st->bc2_pi = (float)sqrt(1.0 - st->b2p_pi);
+      st->ss_alpha = (float)(hp.lr_alpha / (1.0 - st->b1p_alpha));
+      st->bc2_alpha = (float)sqrt(1.0 - st->b2p_alpha);
+    }
   }
 }
 
@@ -171,33 +218,41 @@ __global__ void __launch_bounds__(kThreads) k_gather(GatherArgs a) {
   const int r = r0 + wave;
   if (r < a.B) {
     const long long src = a.idx_table[(size_t)trow * a.B + r];
-    const float* so = a.rb_obs + (size_t)src * a.O;
-    const float* so2 = a.rb_obs2 + (size_t)src * a.O;
-    float* d0 = a.X0 + (size_t)r * a.ldx;
-    float* dp = a.XP + (size_t)r * a.ldx;
-    float* d2 = a.X2 + (size_t)r * a.ldx;
+    const float* __restrict__ so = a.rb_obs + (size_t)src * a.O;
+    const float* __restrict__ so2 = a.rb_obs2 + (size_t)src * a.O;
+    float* __restrict__ d0 = a.X0 + (size_t)r * a.ldx;
+    float* __restrict__ dp = a.XP + (size_t)r * a.ldx;
+    float* __restrict__ d2 = a.X2 + (size_t)r * a.ldx;
+    // all loads of the row first (HBM latency paid once), then the stores
+    const int ja = lane < a.A ? lane : 0;
+    const float av = a.rb_act[(size_t)src * a.A + ja];
+    const float rw = a.rb_rew[src], dn = a.rb_done[src];
     if ((a.O & 3) == 0) {
-      for (int k = lane * 4; k < a.O; k += 256) {
-        const f32x4 v = *(const f32x4*)(so + k);
-        const f32x4 w = *(const f32x4*)(so2 + k);
-        *(f32x4*)(d0 + k) = v;
-        *(f32x4*)(dp + k) = v;
-        *(f32x4*)(d2 + k) = w;
+      for (int k0 = 0; k0 < a.O; k0 += 512) {
+        const int ka = k0 + lane * 4, kb = ka + 256;
+        f32x4 va = {0.f, 0.f, 0.f, 0.f}, wa = va, vb = va, wb = va;
+        if (ka < a.O) { va = *(const f32x4*)(so + ka); wa = *(const f32x4*)(so2 + ka); }
+        if (kb < a.O) { vb = *(const f32x4*)(so + kb); wb = *(const f32x4*)(so2 + kb); }
+        if (ka < a.O) { *(f32x4*)(d0 + ka) = va; *(f32x4*)(dp + ka) = va; *(f32x4*)(d2 + ka) = wa; }
+        if (kb < a.O) { *(f32x4*)(d0 + kb) = vb; *(f32x4*)(dp + kb) = vb; *(f32x4*)(d2 + kb) = wb; }
       }
     } else {
-      for (int k = lane; k < a.O; k += 64) {
-        const float v = so[k], w = so2[k];
-        d0[k] = v; dp[k] = v; d2[k] = w;
+      for (int k0 = 0; k0 < a.O; k0 += 128) {
+        const int ka = k0 + lane, kb = ka + 64;
+        float va = 0.f, wa = 0.f, vb = 0.f, wb = 0.f;
+        if (ka < a.O) { va = so[ka]; wa = so2[ka]; }
+        if (kb < a.O) { vb = so[kb]; wb = so2[kb]; }
+        if (ka < a.O) { d0[ka] = va; dp[ka] = va; d2[ka] = wa; }
+        if (kb < a.O) { d0[kb] = vb; dp[kb] = vb; d2[kb] = wb; }
       }
     }
-    // action columns + zero padding up to ldx
+    // action columns + zero padding up to ldx (A <= 32 < 64 lanes)
     for (int k = a.O + lane; k < a.ldx; k += 64) {
       const int j = k - a.O;
-      const float v = j < a.A ? a.rb_act[(size_t)src * a.A + j] : 0.0f;
-      d0[k] = v;
+      d0[k] = j < a.A ? av : 0.0f;
       if (j >= a.A) { dp[k] = 0.0f; d2[k] = 0.0f; }
     }
-    if (lane == 0) { a.rew[r] = a.rb_rew[src]; a.done[r] = a.rb_done[src]; }
+    if (lane == 0) { a.rew[r] = rw; a.done[r] = dn; }
   }
   if (a.nz.seed != 0) {
     const int r1 = r0 + 4 < a.B ? r0 + 4 : a.B;
@@ -257,52 +312,52 @@ constexpr int MC_LD = TM + 4;   // 36 floats
 constexpr int TILE_LDS = BK * MC_LD;  // 2304 floats >= 32*KC_LD (2176)
 
 enum : int { EPI_GELU = 0, EPI_MULG = 1, EPI_STORE = 2 };
-enum : int { LAY_KC_KC = 0, LAY_KC_MC = 1, LAY_MC_MC = 2 };
 
-struct TileTask {
-  const float* P; const float* Q;
-  float* C0; float* C1;
-  const float* aux;     // EPI_GELU: bias[N]; EPI_MULG: G[M x ldaux]
-  int ldp, ldq, ldc, ldaux;
-  int M, N, K;
-  int m0, n0;
-  int layout, epi;
-  int pad0;
-};
 
+// Operand fetch: ONE unconditional dwordx4 per lane and slot (addresses clamped into the matrix,
+// out-of-range elements zeroed by selects) so that every load of a tile -- and of ALL k-tiles, see
+// run_tile -- is in flight at once; a divergent bounds branch around each load would serialise them
+// (each dependent L2/MALL round trip is ~0.7 us, the whole tile's MFMA work ~0.2 us).
+// The clamped vector may over-read <= 12 bytes past a row end; all operands sit inside larger
+// allocations (parameter arenas / 256-byte spaced workspace buffers), never at an allocation end.
 template <bool MC>
-__device__ __forceinline__ void tile_load(const float* __restrict__ base, int ld, int row0, int rows, int k0,
-                                          int K, int tid, f32x4 (&r)[2]) {
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (!MC) {
-      const int row = row0 + (tid >> 4) + 16 * j;
-      const int k = k0 + (tid & 15) * 4;
-      if (row < rows && k < K) {
-        const float* p = base + (size_t)row * ld + k;
-        if (k + 3 < K) v = *(const f32x4u*)p;
-        else { v.x = p[0]; if (k + 1 < K) v.y = p[1]; if (k + 2 < K) v.z = p[2]; }
-      }
-    } else {
-      const int k = k0 + (tid >> 3) + 32 * j;
-      const int row = row0 + (tid & 7) * 4;
-      if (k < K && row < rows) {
-        const float* p = base + (size_t)k * ld + row;
-        if (row + 3 < rows) v = *(const f32x4u*)p;
-        else { v.x = p[0]; if (row + 1 < rows) v.y = p[1]; if (row + 2 < rows) v.z = p[2]; }
-      }
-    }
-    r[j] = v;
+__device__ __forceinline__ f32x4 tile_load1(const float* __restrict__ base, int ld, int row0, int rows, int k0,
+                                            int K, int tid, int j) {
+  if (!MC) {
+    const int row = row0 + (tid >> 4) + 16 * j;
+    const int k = k0 + (tid & 15) * 4;
+    const int rc = row < rows ? row : rows - 1;
+    const int kc = k < K ? k : 0;
+    f32x4 v = *(const f32x4u*)(base + (size_t)rc * ld + kc);
+    const bool rv = row < rows;
+    v.x = (rv && k < K) ? v.x : 0.f;
+    v.y = (rv && k + 1 < K) ? v.y : 0.f;
+    v.z = (rv && k + 2 < K) ? v.z : 0.f;
+    v.w = (rv && k + 3 < K) ? v.w : 0.f;
+    return v;
+  } else {
+    const int k = k0 + (tid >> 3) + 32 * j;
+    const int row = row0 + (tid & 7) * 4;
+    const int kc = k < K ? k : 0;
+    const int rc = row < rows ? row : 0;
+    f32x4 v = *(const f32x4u*)(base + (size_t)kc * ld + rc);
+    const bool kv = k < K;
+    v.x = (kv && row < rows) ? v.x : 0.f;
+    v.y = (kv && row + 1 < rows) ? v.y : 0.f;
+    v.z = (kv && row + 2 < rows) ? v.z : 0.f;
+    v.w = (kv && row + 3 < rows) ? v.w : 0.f;
+    return v;
   }
 }
 
 template <bool MC>
-__device__ __forceinline__ void tile_store_lds(float* lds, int tid, const f32x4 (&r)[2]) {
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    if (!MC) *(f32x4*)(lds + ((tid >> 4) + 16 * j) * KC_LD + (tid & 15) * 4) = r[j];
-    else *(f32x4*)(lds + ((tid >> 3) + 32 * j) * MC_LD + (tid & 7) * 4) = r[j];
+__device__ __forceinline__ void tile_store_lds(float* lds, int tid, const f32x4& r0, const f32x4& r1) {
+  if (!MC) {
+    *(f32x4*)(lds + (tid >> 4) * KC_LD + (tid & 15) * 4) = r0;
+    *(f32x4*)(lds + ((tid >> 4) + 16) * KC_LD + (tid & 15) * 4) = r1;
+  } else {
+    *(f32x4*)(lds + (tid >> 3) * MC_LD + (tid & 7) * 4) = r0;
+    *(f32x4*)(lds + ((tid >> 3) + 32) * MC_LD + (tid & 7) * 4) = r1;
   }
 }
 
@@ -316,49 +371,156 @@ __device__ __forceinline__ f32x4 frag_read(const float* lds, int row, int kk, in
 }
 
 template <bool P_MC, bool Q_MC>
-__device__ __forceinline__ void run_tile(const TileTask& t, float* lds) {
+__device__ __forceinline__ void tile_mma(const float* ps, const float* qs, int prow, int qrow, int g, f32x4& acc0,
+                                         f32x4& acc1) {
+#pragma unroll
+  for (int kk = 0; kk < BK / 16; ++kk) {
+    const f32x4 p = frag_read<P_MC>(ps, prow, kk, g);
+    const f32x4 q = frag_read<Q_MC>(qs, qrow, kk, g);
+    // D[row = n][col = m]: lane holds n = 4*g + reg, m = lane & 15
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.x, p.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.y, p.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.z, p.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.w, p.w, acc1, 0, 0, 0);
+  }
+}
+
+// one GEMM problem (all tiles of one matrix product)
+struct GemmProb {
+  const float* P; const float* Q;
+  float* C0; float* C1;
+  const float* aux;     // EPI_GELU: bias[N]; EPI_MULG: G[M x ldaux]
+  int ldp, ldq, ldc, ldaux;
+  int M, N, K;
+  int tiles_n;          // n-tiles per m-tile row
+  int tile_end;         // exclusive end of this problem's block range inside its stage
+};
+
+constexpr int kMaxPrefetchTiles = 7;  // K <= 448 is fetched completely up front (112 VGPRs)
+// dynamic LDS a tile kernel needs for contraction length K
+inline size_t tile_lds_bytes(int K) {
+  const int T = (K + BK - 1) / BK;
+  return (size_t)(T <= kMaxPrefetchTiles ? T : 2) * 2 * TILE_LDS * sizeof(float);
+}
+
+// per-thread operand cursor: the two (clamped) element pointers of k-tile 0 and what the fast path
+// needs to know. Full tiles (uniform test) are plain dwordx4 loads at pointer + tile offset.
+template <bool MC>
+struct OpCursor {
+  const float* p0; const float* p1;  // slot 0 / slot 1 of k-tile 0
+  size_t step;                       // floats between consecutive k-tiles
+  bool v0, v1;                       // slot row valid (KC) -- always true when the tile is row-full
+};
+
+template <bool MC>
+__device__ __forceinline__ OpCursor<MC> make_cursor(const float* base, int ld, int row0, int rows, int tid) {
+  OpCursor<MC> c;
+  if (!MC) {
+    const int r_0 = row0 + (tid >> 4), r_1 = r_0 + 16;
+    c.v0 = r_0 < rows; c.v1 = r_1 < rows;
+    c.p0 = base + (size_t)(c.v0 ? r_0 : rows - 1) * ld + (tid & 15) * 4;
+    c.p1 = base + (size_t)(c.v1 ? r_1 : rows - 1) * ld + (tid & 15) * 4;
+    c.step = BK;
+  } else {
+    const int col = row0 + (tid & 7) * 4;
+    c.v0 = c.v1 = true;
+    c.p0 = base + (size_t)(tid >> 3) * ld + col;
+    c.p1 = c.p0 + (size_t)32 * ld;
+    c.step = (size_t)BK * ld;
+  }
+  return c;
+}
+
+template <bool P_MC, bool Q_MC, int EPI>
+__device__ __forceinline__ void run_tile(const GemmProb& t, int m0, int n0, float* lds, long long* tl_buf = nullptr,
+                                         int tl_slot = 0) {
+  TL_DECL
+  TL_STAMP();  // 0: tile start (problem decoded)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int i = lane & 15, g = lane >> 4;
-  float* Ps[2] = {lds, lds + 2 * TILE_LDS};
-  float* Qs[2] = {lds + TILE_LDS, lds + 3 * TILE_LDS};
+  // LDS image: k-tile t occupies [t*2*TILE_LDS, (t+1)*2*TILE_LDS): P tile then Q tile. When the whole
+  // K range is prefetched (T <= kMaxPrefetchTiles) every tile has its own slot and ONE barrier
+  // separates staging from the MFMA run; otherwise two slots are used as a double buffer.
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 pr[2], qr[2];
   const int T = (t.K + BK - 1) / BK;
-  tile_load<P_MC>(t.P, t.ldp, t.m0, t.M, 0, t.K, tid, pr);
-  tile_load<Q_MC>(t.Q, t.ldq, t.n0, t.N, 0, t.K, tid, qr);
-  for (int it = 0; it < T; ++it) {
-    const int b = it & 1;
-    tile_store_lds<P_MC>(Ps[b], tid, pr);
-    tile_store_lds<Q_MC>(Qs[b], tid, qr);
-    __syncthreads();
-    if (it + 1 < T) {
-      tile_load<P_MC>(t.P, t.ldp, t.m0, t.M, (it + 1) * BK, t.K, tid, pr);
-      tile_load<Q_MC>(t.Q, t.ldq, t.n0, t.N, (it + 1) * BK, t.K, tid, qr);
-    }
-    const float* ps = Ps[b];
-    const float* qs = Qs[b];
+  const int Tfull = t.K / BK;                      // k-tiles that need no k mask
+  // a row-full tile needs no row mask; MC operands additionally need it for the vector not to straddle
+  const bool p_rows_full = m0 + TM <= t.M, q_rows_full = n0 + TN <= t.N;
+  const OpCursor<P_MC> pc = make_cursor<P_MC>(t.P, t.ldp, m0, t.M, tid);
+  const OpCursor<Q_MC> qc = make_cursor<Q_MC>(t.Q, t.ldq, n0, t.N, tid);
+  const bool p_fast = P_MC ? p_rows_full : true, q_fast = Q_MC ? q_rows_full : true;
+  // output coordinates + epilogue operands (bias / GELU') are fetched now, not after the MFMA loop
+  const int m = m0 + wr * 16 + i;
+  const int n = n0 + wc * 16 + 4 * g;
+  const bool in_range = m < t.M && n < t.N;
+  const bool full = n + 3 < t.N;
+  f32x4 epv = {0.f, 0.f, 0.f, 0.f};
+  if (EPI == EPI_GELU) { if (in_range && full) epv = *(const f32x4u*)(t.aux + n); }
+  else if (EPI == EPI_MULG) { if (in_range && full) epv = *(const f32x4u*)(t.aux + (size_t)m * t.ldaux + n); }
+#define DSACT_LOAD_TILE(IT, P0, P1, Q0, Q1)                                                         \
+  do {                                                                                              \
+    if ((IT) < Tfull && p_fast) {                                                                   \
+      P0 = *(const f32x4u*)(pc.p0 + (size_t)(IT) * pc.step);                                        \
+      P1 = *(const f32x4u*)(pc.p1 + (size_t)(IT) * pc.step);                                        \
+      if (!P_MC && !p_rows_full) { if (!pc.v0) P0 = f32x4{0.f, 0.f, 0.f, 0.f}; if (!pc.v1) P1 = f32x4{0.f, 0.f, 0.f, 0.f}; } \
+    } else {                                                                                        \
+      P0 = tile_load1<P_MC>(t.P, t.ldp, m0, t.M, (IT) * BK, t.K, tid, 0);                           \
+      P1 = tile_load1<P_MC>(t.P, t.ldp, m0, t.M, (IT) * BK, t.K, tid, 1);                           \
+    }                                                                                               \
+    if ((IT) < Tfull && q_fast) {                                                                   \
+      Q0 = *(const f32x4u*)(qc.p0 + (size_t)(IT) * qc.step);                                        \
+      Q1 = *(const f32x4u*)(qc.p1 + (size_t)(IT) * qc.step);                                        \
+      if (!Q_MC && !q_rows_full) { if (!qc.v0) Q0 = f32x4{0.f, 0.f, 0.f, 0.f}; if (!qc.v1) Q1 = f32x4{0.f, 0.f, 0.f, 0.f}; } \
+    } else {                                                                                        \
+      Q0 = tile_load1<Q_MC>(t.Q, t.ldq, n0, t.N, (IT) * BK, t.K, tid, 0);                           \
+      Q1 = tile_load1<Q_MC>(t.Q, t.ldq, n0, t.N, (IT) * BK, t.K, tid, 1);                           \
+    }                                                                                               \
+  } while (0)
+  if (T <= kMaxPrefetchTiles) {
+    f32x4 pr[kMaxPrefetchTiles][2], qr[kMaxPrefetchTiles][2];
 #pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      const f32x4 p = frag_read<P_MC>(ps, wr * 16 + i, kk, g);
-      const f32x4 q = frag_read<Q_MC>(qs, wc * 16 + i, kk, g);
-      // D[row = n][col = m]: lane holds n = 4*g + reg, m = i
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.x, p.x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.y, p.y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.z, p.z, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.w, p.w, acc1, 0, 0, 0);
+    for (int it = 0; it < kMaxPrefetchTiles; ++it) {
+      if (it < T) DSACT_LOAD_TILE(it, pr[it][0], pr[it][1], qr[it][0], qr[it][1]);
+    }
+    TL_STAMP();  // 1: all loads issued
+#pragma unroll
+    for (int it = 0; it < kMaxPrefetchTiles; ++it) {
+      if (it < T) {
+        tile_store_lds<P_MC>(lds + it * 2 * TILE_LDS, tid, pr[it][0], pr[it][1]);
+        tile_store_lds<Q_MC>(lds + it * 2 * TILE_LDS + TILE_LDS, tid, qr[it][0], qr[it][1]);
+      }
+    }
+    __syncthreads();
+    TL_STAMP();  // 2: every k-tile landed and staged
+#pragma unroll
+    for (int it = 0; it < kMaxPrefetchTiles; ++it) {
+      if (it < T)
+        tile_mma<P_MC, Q_MC>(lds + it * 2 * TILE_LDS, lds + it * 2 * TILE_LDS + TILE_LDS, wr * 16 + i, wc * 16 + i, g, acc0, acc1);
+    }
+  } else {
+    float* Ps[2] = {lds, lds + 2 * TILE_LDS};
+    float* Qs[2] = {lds + TILE_LDS, lds + 3 * TILE_LDS};
+    f32x4 p0, p1, q0, q1;
+    DSACT_LOAD_TILE(0, p0, p1, q0, q1);
+    for (int it = 0; it < T; ++it) {
+      const int b = it & 1;
+      tile_store_lds<P_MC>(Ps[b], tid, p0, p1);
+      tile_store_lds<Q_MC>(Qs[b], tid, q0, q1);
+      __syncthreads();
+      if (it + 1 < T) DSACT_LOAD_TILE(it + 1, p0, p1, q0, q1);
+      tile_mma<P_MC, Q_MC>(Ps[b], Qs[b], wr * 16 + i, wc * 16 + i, g, acc0, acc1);
     }
   }
+#undef DSACT_LOAD_TILE
   const f32x4 acc = acc0 + acc1;
-  const int m = t.m0 + wr * 16 + i;
-  const int n = t.n0 + wc * 16 + 4 * g;
-  if (m >= t.M || n >= t.N) return;
-  const bool full = (n + 3 < t.N);
-  if (t.epi == EPI_GELU) {
+  TL_STAMP();  // 3: MFMA loop done
+  if (!in_range) { TL_FLUSH(tl_buf, tl_slot); return; }
+  if (EPI == EPI_GELU) {
     f32x4 h, gd;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float z = acc[e] + (n + e < t.N ? t.aux[n + e] : 0.0f);
+      const float z = acc[e] + (full ? epv[e] : (n + e < t.N ? t.aux[n + e] : 0.0f));
       float hh, gg;
       gelu_fwd_grad(z, hh, gg);
       h[e] = hh; gd[e] = gg;
@@ -367,59 +529,110 @@ __device__ __forceinline__ void run_tile(const TileTask& t, float* lds) {
     float* c1 = t.C1 + (size_t)m * t.ldc + n;
     if (full) { *(f32x4u*)c0 = h; *(f32x4u*)c1 = gd; }
     else for (int e = 0; e < 4 && n + e < t.N; ++e) { c0[e] = h[e]; c1[e] = gd[e]; }
-  } else if (t.epi == EPI_MULG) {
-    const float* gp = t.aux + (size_t)m * t.ldaux + n;
+  } else if (EPI == EPI_MULG) {
     float* c0 = t.C0 + (size_t)m * t.ldc + n;
-    if (full) {
-      const f32x4 gv = *(const f32x4u*)gp;
-      *(f32x4u*)c0 = acc * gv;
-    } else for (int e = 0; e < 4 && n + e < t.N; ++e) c0[e] = acc[e] * gp[e];
+    if (full) *(f32x4u*)c0 = acc * epv;
+    else {
+      const float* gp = t.aux + (size_t)m * t.ldaux + n;
+      for (int e = 0; e < 4 && n + e < t.N; ++e) c0[e] = acc[e] * gp[e];
+    }
   } else {
     float* c0 = t.C0 + (size_t)m * t.ldc + n;
     if (full) *(f32x4u*)c0 = acc;
     else for (int e = 0; e < 4 && n + e < t.N; ++e) c0[e] = acc[e];
   }
+  TL_STAMP();  // 4: epilogue stores issued
+  TL_FLUSH(tl_buf, tl_slot);
 }
 
-__global__ void __launch_bounds__(kThreads) k_tiles(const TileTask* __restrict__ tasks) {
-  __shared__ __attribute__((aligned(16))) float lds[4 * TILE_LDS];
-  const TileTask t = tasks[blockIdx.x];
-  if (t.layout == LAY_KC_KC) run_tile<false, false>(t, lds);
-  else if (t.layout == LAY_KC_MC) run_tile<false, true>(t, lds);
-  else run_tile<true, true>(t, lds);
+// XCD-aware block -> logical tile map. The dispatcher places block b on XCD b % 8 and each XCD has a
+// private, non-coherent L2. Tiles are listed (problem, m-tile, n-tile), so giving every XCD one
+// CONTIGUOUS chunk of that list confines a problem's weight / activation slabs to 1-2 XCDs instead
+// of having all 8 L2s fetch all of them through the fabric. Bijective for any grid size; placement
+// only affects speed, never results.
+__device__ __forceinline__ int xcd_logical_block(int b, int nb) {
+  const int xcd = b & 7, slot = b >> 3;
+  const int q = nb >> 3, r = nb & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
-// ---------------------------------------------------------------------------------------------
-// row-vector helpers for the narrow output layers (N_out = 2 or 2A): one wave per row, the row
-// lives in registers (float4 per lane per 256-chunk), each output is one shuffle reduction.
-// ---------------------------------------------------------------------------------------------
-struct RowRegs { f32x4 v[kMaxWidth / 256]; };
+// ---- stage launch form 1: <= kMaxProb problems described in the kernel arguments ----------------
+constexpr int kMaxProb = 6;
+struct StageArgs {
+  GemmProb p[kMaxProb];
+  int n_prob;
+  long long* timeline;  // DSACT_TIMELINE builds only (else unused)
+};
 
-__device__ __forceinline__ void row_load(const float* x, int W, int lane, RowRegs& r) {
+template <bool P_MC, bool Q_MC, int EPI>
+__global__ void __launch_bounds__(kThreads) k_stage(StageArgs s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // tile_lds_bytes(max K of the stage)
+  const int b = xcd_logical_block(blockIdx.x, gridDim.x);
+  int pi = 0;
 #pragma unroll
-  for (int c = 0; c < kMaxWidth / 256; ++c) {
+  for (int q = 0; q + 1 < kMaxProb; ++q)
+    if (q + 1 < s.n_prob && b >= s.p[q].tile_end) pi = q + 1;
+  const GemmProb& g = s.p[pi];
+  const int local = b - (pi ? s.p[pi - 1].tile_end : 0);
+  const int mt = local / g.tiles_n, nt = local - mt * g.tiles_n;
+  run_tile<P_MC, Q_MC, EPI>(g, mt * TM, nt * TN, lds, s.timeline, (int)blockIdx.x);
+}
+
+// ---- stage launch form 2: many small problems (weight / bias gradients) from a device table ------
+// one GemmProb PER TILE (tiles_n / tile_end are reused as the tile origin m0 / n0): a single
+// dependent load per block. Every problem is an MC x MC product with a plain store.
+__global__ void __launch_bounds__(kThreads) k_stage_table(const GemmProb* __restrict__ tiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const GemmProb g = tiles[xcd_logical_block(blockIdx.x, gridDim.x)];
+  run_tile<true, true, EPI_STORE>(g, g.tiles_n, g.tile_end, lds);
+}
+
+// ---------------------------------------------------------------------------------------------
+// row-vector helpers for the narrow layers (N_out = 2 or 2A, K = 2A): one wave per row, the row lives
+// in registers (float4 per lane per 256-chunk; NCH = ceil(W/256) chunks, template parameter so that
+// register arrays are statically indexed). Weight rows are fetched in GROUPS of independent
+// dwordx4 loads -- a dependent L2/MALL round trip costs ~0.7 us, so N_out sequential dot products
+// would cost N_out round trips; a group costs one.
+// ---------------------------------------------------------------------------------------------
+template <int NCH>
+__device__ __forceinline__ void row_load(const float* x, int W, int lane, f32x4 (&r)[NCH]) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
     const int k = c * 256 + lane * 4;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (k + 3 < W) v = *(const f32x4u*)(x + k);
-    else if (k < W) { v.x = x[k]; if (k + 1 < W) v.y = x[k + 1]; if (k + 2 < W) v.z = x[k + 2]; }
-    r.v[c] = v;
+    const int kc = k < W ? k : 0;
+    f32x4 v = *(const f32x4u*)(x + kc);   // may over-read <= 12 B inside the workspace
+    v.x = k < W ? v.x : 0.f;
+    v.y = k + 1 < W ? v.y : 0.f;
+    v.z = k + 2 < W ? v.z : 0.f;
+    v.w = k + 3 < W ? v.w : 0.f;
+    r[c] = v;
   }
 }
-__device__ __forceinline__ float row_dot(const RowRegs& r, const float* w, int W, int lane) {
-  float s = 0.f;
+
+// out[q] = <h, w[(n0+q)*W .. ]> for q < G (rows clamped to n_out-1; the caller ignores the extras).
+// h is zero beyond W, so clamped / over-read weight elements (finite parameters) contribute 0.
+template <int NCH, int G>
+__device__ __forceinline__ void row_dots(const f32x4 (&h)[NCH], const float* w, int W, int n0, int n_out,
+                                         int lane, float (&out)[G]) {
+  f32x4 wv[G][NCH];
 #pragma unroll
-  for (int c = 0; c < kMaxWidth / 256; ++c) {
-    const int k = c * 256 + lane * 4;
-    if (k + 3 < W) {
-      const f32x4 wv = *(const f32x4u*)(w + k);
-      s += r.v[c].x * wv.x; s += r.v[c].y * wv.y; s += r.v[c].z * wv.z; s += r.v[c].w * wv.w;
-    } else if (k < W) {
-      s += r.v[c].x * w[k];
-      if (k + 1 < W) s += r.v[c].y * w[k + 1];
-      if (k + 2 < W) s += r.v[c].z * w[k + 2];
+  for (int q = 0; q < G; ++q) {
+    const int n = n0 + q < n_out ? n0 + q : n_out - 1;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int k = c * 256 + lane * 4;
+      wv[q][c] = *(const f32x4u*)(w + (size_t)n * W + (k < W ? k : 0));
     }
   }
-  return wave_sum(s);
+#pragma unroll
+  for (int q = 0; q < G; ++q) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      s += h[c].x * wv[q][c].x; s += h[c].y * wv[q][c].y; s += h[c].z * wv[q][c].z; s += h[c].w * wv[q][c].w;
+    }
+    out[q] = wave_sum(s);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -442,29 +655,41 @@ struct HeadsArgs {
   float* part_heads;  // [gridDim.x][2]: sum tanh(mu), sum sigma  (policy chain)
   const float* act_scale; const float* act_center;  // (hi-lo)/2, (hi+lo)/2
   float lo_ls, hi_ls;
+  long long* timeline;
 };
 
+template <int NCH>
 __global__ void __launch_bounds__(kThreads) k_heads(HeadsArgs a) {
   __shared__ float red[8];
+  constexpr int G = NCH == 1 ? 12 : (NCH == 2 ? 8 : 4);
+  TL_DECL
+  TL_STAMP();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int chain = blockIdx.y;
   const int r = blockIdx.x * 4 + wave;
   const bool active = r < a.B;
   float s_tanh = 0.f, s_sig = 0.f;
   if (active) {
-    RowRegs h;
-    row_load(a.H[chain] + (size_t)r * a.W, a.W, lane, h);
+    f32x4 h[NCH];
+    row_load<NCH>(a.H[chain] + (size_t)r * a.W, a.W, lane, h);
     if (chain >= 2) {
-      const float o0 = row_dot(h, a.Wout[chain], a.W, lane) + a.bout[chain][0];
-      const float o1 = row_dot(h, a.Wout[chain] + a.W, a.W, lane) + a.bout[chain][1];
-      if (lane == 0) { a.qout[chain - 2][2 * r] = o0; a.qout[chain - 2][2 * r + 1] = o1; }
+      float o[2];
+      row_dots<NCH, 2>(h, a.Wout[chain], a.W, 0, 2, lane, o);
+      if (lane == 0) {
+        a.qout[chain - 2][2 * r] = o[0] + a.bout[chain][0];
+        a.qout[chain - 2][2 * r + 1] = o[1] + a.bout[chain][1];
+      }
     } else {
       const int A = a.A;
       float mine = 0.f;  // lane n keeps logits[n]
-      for (int n = 0; n < 2 * A; ++n) {
-        const float o = row_dot(h, a.Wout[chain] + (size_t)n * a.W, a.W, lane) + a.bout[chain][n];
-        if (lane == n) mine = o;
+      for (int n0 = 0; n0 < 2 * A; n0 += G) {
+        float o[G];
+        row_dots<NCH, G>(h, a.Wout[chain], a.W, n0, 2 * A, lane, o);
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+          if (lane == n0 + q) mine = o[q];
       }
+      if (lane < 2 * A) mine += a.bout[chain][lane];
       const float raw = __shfl(mine, lane + A, 64);  // lane j < A: raw log-std of dim j
       float lp = 0.f;
       if (lane < A) {
@@ -491,6 +716,8 @@ __global__ void __launch_bounds__(kThreads) k_heads(HeadsArgs a) {
       a.part_heads[2 * blockIdx.x + 1] = red[4] + red[5] + red[6] + red[7];
     }
   }
+  TL_STAMP();
+  TL_FLUSH(a.timeline, (int)(blockIdx.y * gridDim.x + blockIdx.x));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -524,23 +751,59 @@ struct LossArgs {
   float inv_B;             // 1 / local batch
   float inv_Bg;            // 1 / global batch   (mean of std for the EMA; == inv_B on one GPU)
   const float* std_sums;   // strict data-parallel mode: all-reduced {sum std1, sum std2}; NULL otherwise
-  int auto_alpha; float alpha_fixed, gamma, tau_b;
+  int auto_alpha; float alpha_fixed, gamma, tau_b, one_minus_tau_b;
+  long long* timeline;
 };
 
+template <int NCH>
 __global__ void __launch_bounds__(kThreads) k_loss(LossArgs a) {
   __shared__ float red[4 * kLossPart];
   __shared__ float sh_ms[2];
   extern __shared__ float dyn[];  // [rows_per_wg][16]: raw outs (8) and dL/d(out) (8) of the 4 chains, my rows
+  TL_DECL
+  TL_STAMP();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r_begin = blockIdx.x * a.rows_per_wg;
   const int r_end = min(r_begin + a.rows_per_wg, a.B);
-  // ---- phase 1 ----
+  // all independent global loads are issued up front: phase-1 column of std, then the per-sample
+  // inputs of phase 3, then the rows / weights of phase 2 -- one exposed round trip instead of three
   float s1 = 0.f, s2 = 0.f;
   if (a.std_sums == nullptr) {
     for (int r = tid; r < a.B; r += kThreads) {
       s1 += softplus(a.qout_c[0][2 * r + 1]);
       s2 += softplus(a.qout_c[1][2 * r + 1]);
     }
+  }
+  const int my_r = r_begin + tid;  // phase 3 handles one row per thread (rows_per_wg <= 256)
+  const bool mine = my_r < r_end;
+  const int rr = mine ? my_r : r_begin;
+  const float in_q1 = a.qout_c[0][2 * rr], in_raw1 = a.qout_c[0][2 * rr + 1];
+  const float in_q2 = a.qout_c[1][2 * rr], in_raw2 = a.qout_c[1][2 * rr + 1];
+  const float in_z5 = a.z5[rr], in_z6 = a.z6[rr], in_rew = a.rew[rr], in_done = a.done[rr];
+  const float in_lp2 = a.logp2[rr], in_lpn = a.logp_new[rr];
+  const float la = a.auto_alpha ? a.log_alpha[0] : 0.f;
+  // ---- phase 2 ----
+  for (int r = r_begin + wave; r < r_end; r += 4) {
+    f32x4 h[4][NCH];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) row_load<NCH>(a.Hl[c] + (size_t)r * a.W, a.W, lane, h[c]);
+    float o[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) row_dots<NCH, 2>(h[c], a.Wout[c], a.W, 0, 2, lane, o[c]);
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float o0 = o[c][0] + a.bout[c][0], o1 = o[c][1] + a.bout[c][1];
+        dyn[(r - r_begin) * 16 + 2 * c] = o0;
+        dyn[(r - r_begin) * 16 + 2 * c + 1] = o1;
+        float* dbg = c < 2 ? a.qout_t[c] : a.qout_p[c - 2];
+        dbg[2 * r] = o0; dbg[2 * r + 1] = o1;
+      }
+    }
+  }
+  TL_STAMP();  // 1: phase 2 (out layers) done
+  // ---- phase 1 ----
+  if (a.std_sums == nullptr) {
     s1 = wave_sum(s1); s2 = wave_sum(s2);
     if (lane == 0) { red[wave] = s1; red[4 + wave] = s2; }
     __syncthreads();
@@ -552,49 +815,34 @@ __global__ void __launch_bounds__(kThreads) k_loss(LossArgs a) {
     float ms1, ms2;
     if (!a.st->ms_init) { ms1 = m1; ms2 = m2; }
     else {
-      const float c1 = 1.0f - a.tau_b;  // (1 - tau_b) as fp32 scalar
+      const float c1 = a.one_minus_tau_b;  // Python double (1 - tau_b) cast to fp32 by the tensor multiply
       ms1 = c1 * a.st->ms1 + a.tau_b * m1;
       ms2 = c1 * a.st->ms2 + a.tau_b * m2;
     }
     sh_ms[0] = ms1; sh_ms[1] = ms2;
     if (blockIdx.x == 0) { a.grads_tail[0] = ms1; a.grads_tail[1] = ms2; }
   }
-  __syncthreads();
+  __syncthreads();  // also publishes dyn[] of phase 2
   const float ms1 = sh_ms[0], ms2 = sh_ms[1];
-  const float alpha = a.auto_alpha ? expf(a.log_alpha[0]) : a.alpha_fixed;
-  // ---- phase 2 ----
-  for (int r = r_begin + wave; r < r_end; r += 4) {
-    for (int c = 0; c < 4; ++c) {
-      RowRegs h;
-      row_load(a.Hl[c] + (size_t)r * a.W, a.W, lane, h);
-      const float o0 = row_dot(h, a.Wout[c], a.W, lane) + a.bout[c][0];
-      const float o1 = row_dot(h, a.Wout[c] + a.W, a.W, lane) + a.bout[c][1];
-      if (lane == 0) {
-        dyn[(r - r_begin) * 16 + 2 * c] = o0;
-        dyn[(r - r_begin) * 16 + 2 * c + 1] = o1;
-        float* dbg = c < 2 ? a.qout_t[c] : a.qout_p[c - 2];
-        dbg[2 * r] = o0; dbg[2 * r + 1] = o1;
-      }
-    }
-  }
-  __syncthreads();
+  const float alpha = a.auto_alpha ? expf(la) : a.alpha_fixed;
+  TL_STAMP();  // 2: mean_std done
   // ---- phase 3 ----
   float acc[kLossPart];
 #pragma unroll
   for (int k = 0; k < kLossPart; ++k) acc[k] = 0.f;
   acc[10] = INFINITY; acc[11] = INFINITY;
-  for (int r = r_begin + tid; r < r_end; r += kThreads) {
+  if (mine) {
+    const int r = my_r;
     float* o = dyn + (r - r_begin) * 16;
-    const float q1 = a.qout_c[0][2 * r], raw1 = a.qout_c[0][2 * r + 1];
-    const float q2 = a.qout_c[1][2 * r], raw2 = a.qout_c[1][2 * r + 1];
+    const float q1 = in_q1, raw1 = in_raw1, q2 = in_q2, raw2 = in_raw2;
     const float std1 = softplus(raw1), std2 = softplus(raw2);
     const float q1n = o[0], std1n = softplus(o[1]);
     const float q2n = o[2], std2n = softplus(o[3]);
     const float qn = fminf(q1n, q2n);
-    const float z5 = clampf(a.z5[r], -3.f, 3.f), z6 = clampf(a.z6[r], -3.f, 3.f);
+    const float z5 = clampf(in_z5, -3.f, 3.f), z6 = clampf(in_z6, -3.f, 3.f);
     const float qs = (q1n < q2n) ? (q1n + z5 * std1n) : (q2n + z6 * std2n);
-    const float rew = a.rew[r], nd = 1.0f - a.done[r];
-    const float lp2 = a.logp2[r];
+    const float rew = in_rew, nd = 1.0f - in_done;
+    const float lp2 = in_lp2;
     const float tq = rew + nd * a.gamma * (qn - alpha * lp2);
     const float tqs = rew + nd * a.gamma * (qs - alpha * lp2);
     const CriticTerm c1 = critic_term(q1, std1, ms1, tq, tqs);
@@ -606,7 +854,7 @@ __global__ void __launch_bounds__(kThreads) k_loss(LossArgs a) {
     dv[3] = c2.dstd * a.inv_B * softplus_grad(raw2);
     // actor: mean(alpha*logp_new - min(q1p, q2p)); torch.min ties split the gradient evenly
     const float q1p = o[4], q2p = o[6];
-    const float lpn = a.logp_new[r];
+    const float lpn = in_lpn;
     const float w1 = q1p < q2p ? 1.0f : (q1p > q2p ? 0.0f : 0.5f);
     dv[4] = -w1 * a.inv_B; dv[5] = 0.0f;
     dv[6] = -(1.0f - w1) * a.inv_B; dv[7] = 0.0f;
@@ -633,42 +881,42 @@ __global__ void __launch_bounds__(kThreads) k_loss(LossArgs a) {
     if (tid == 8) pv = blockIdx.x == 0 ? alpha : 0.0f;  // tb_info reports the alpha the losses used
     a.part_loss[blockIdx.x * kLossPart + tid] = pv;
   }
+  TL_STAMP();  // 3: per-sample math + partial sums done
   // ---- phase 4 ---- (dL/d(out) of my rows is staged in LDS)
-  __syncthreads();
   const int W4 = (a.W + 3) >> 2;
-  const int total = 4 * (r_end - r_begin) * W4;
-  for (int e = tid; e < total; e += kThreads) {
-    const int c = e / ((r_end - r_begin) * W4);
-    const int rem = e - c * (r_end - r_begin) * W4;
+  const int per_chain = (r_end - r_begin) * W4;
+#pragma unroll 4
+  for (int e = tid; e < 4 * per_chain; e += kThreads) {
+    const int c = e / per_chain;
+    const int rem = e - c * per_chain;
     const int r = r_begin + rem / W4, k = (rem % W4) * 4;
     const float d0 = dyn[(r - r_begin) * 16 + 8 + 2 * c], d1 = dyn[(r - r_begin) * 16 + 9 + 2 * c];
     const float* w0 = a.Wq[c & 1] + k;
     const float* w1 = a.Wq[c & 1] + a.W + k;
     const float* gp = a.Gl[c] + (size_t)r * a.W + k;
     float* dz = a.dZl[c] + (size_t)r * a.W + k;
-    if (k + 3 < a.W) {
-      const f32x4 wv0 = *(const f32x4u*)w0, wv1 = *(const f32x4u*)w1, gv = *(const f32x4u*)gp;
-      f32x4 o;
+    const f32x4 wv0 = *(const f32x4u*)w0, wv1 = *(const f32x4u*)w1, gv = *(const f32x4u*)gp;  // <= 12 B over-read
+    f32x4 o;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) o[q] = (d0 * wv0[q] + d1 * wv1[q]) * gv[q];
-      *(f32x4u*)dz = o;
-    } else {
-      for (int q = 0; q < 4 && k + q < a.W; ++q) dz[q] = (d0 * w0[q] + d1 * w1[q]) * gp[q];
-    }
+    for (int q = 0; q < 4; ++q) o[q] = (d0 * wv0[q] + d1 * wv1[q]) * gv[q];
+    if (k + 3 < a.W) *(f32x4u*)dz = o;
+    else for (int q = 0; q < 4 && k + q < a.W; ++q) dz[q] = o[q];
   }
+  TL_STAMP();  // 4: dZ written
+  TL_FLUSH(a.timeline, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_heads_bwd: actor path between the Q nets' first layer and the policy's last hidden layer.
 //   dA[r][j]   = sum_k dZ1_q1p[r][k] W1_q1[k][O+j] + sum_k dZ1_q2p[r][k] W1_q2[k][O+j]
+//                (the two sums are tile-stage products "bwdA": P = dZ1, Q = W1[:, O:O+A], K = W0)
 //   (dmu,draw) = tanh-Gaussian rsample backward with dL/dlogp = alpha/B     (App. A.3)
 //   dZ_pi_last = ((dmu|draw) . Wout_pi) * GELU'(z_last)
-// one wave per row.
+// one wave per row. Block 0 / wave 0 also finalises the alpha gradient (dsac_v2.py:312-318):
+//   d loss_alpha / d log_alpha = -mean(logp_new + target_entropy)
 // ---------------------------------------------------------------------------------------------
 struct HeadsBwdArgs {
-  const float* dZ1[2];     // [B x W0] first-hidden dZ of q1(obs,new_act), q2(obs,new_act)
-  const float* W1[2];      // q1/q2 first-layer weights [W0 x (O+A)]
-  int W0, ld1;             // ld1 = O + A
+  const float* dA[2];      // [B x A] dL/d new_act through q1 / q2 (tile stage bwdA: dZ1 . W1[:, O:O+A])
   const float* logits_pi;  // [B x 2A]
   const float* eps_new;
   const float* log_alpha;
@@ -680,41 +928,45 @@ struct HeadsBwdArgs {
   int WL, B, O, A;
   float inv_B; int auto_alpha; float alpha_fixed;
   const float* act_scale; float lo_ls, hi_ls;
+  const float* part_loss; int n_part; float target_entropy; float* grad_log_alpha;
+  long long* timeline;
 };
 
+template <int NCH>
 __global__ void __launch_bounds__(kThreads) k_heads_bwd(HeadsBwdArgs a) {
   __shared__ float sh_dout[4][64];
+  TL_DECL
+  TL_STAMP();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (blockIdx.x == 0 && wave == 0) {
+    float s = 0.f;
+    for (int i = lane; i < a.n_part; i += 64) s += a.part_loss[i * kLossPart + 7];
+    s = wave_sum(s);
+    if (lane == 0) a.grad_log_alpha[0] = a.auto_alpha ? -(s * a.inv_B + a.target_entropy) : 0.0f;
+  }
   const int r = blockIdx.x * 4 + wave;
   if (r >= a.B) return;  // whole wave exits together; no block-level barrier below
   const int A = a.A;
-  float dA = 0.f;  // lane j < A keeps dL/d new_act[j]
-  for (int net = 0; net < 2; ++net) {
-    float accj[32];
+  float mu = 0.f, raw = 0.f, eps = 0.f, scale = 1.f, dA = 0.f;
+  if (lane < A) {
+    mu = a.logits_pi[(size_t)r * 2 * A + lane];
+    raw = a.logits_pi[(size_t)r * 2 * A + A + lane];
+    eps = a.eps_new[(size_t)r * A + lane];
+    scale = a.act_scale[lane];
+    dA = a.dA[0][(size_t)r * A + lane] + a.dA[1][(size_t)r * A + lane];
+  }
+  // prefetch this lane's GELU' values of the row (used at the very end)
+  f32x4 gv[NCH];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) accj[j] = 0.f;
-    const float* dz = a.dZ1[net] + (size_t)r * a.W0;
-    for (int k = lane; k < a.W0; k += 64) {
-      const float d = dz[k];
-      const float* w = a.W1[net] + (size_t)k * a.ld1 + a.O;
-#pragma unroll
-      for (int j = 0; j < 32; ++j) if (j < A) accj[j] += d * w[j];
-    }
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      if (j < A) {
-        const float s = wave_sum(accj[j]);
-        if (lane == j) dA += s;
-      }
-    }
+  for (int c = 0; c < NCH; ++c) {
+    const int k = c * 256 + lane * 4;
+    gv[c] = *(const f32x4u*)(a.G_pi + (size_t)r * a.WL + (k < a.WL ? k : 0));
   }
   const float alpha = a.auto_alpha ? expf(a.log_alpha[0]) : a.alpha_fixed;
+  TL_STAMP();  // 1: inputs loaded
   float dmu = 0.f, draw = 0.f;
   if (lane < A) {
-    const float mu = a.logits_pi[(size_t)r * 2 * A + lane];
-    const float raw = a.logits_pi[(size_t)r * 2 * A + A + lane];
-    const float eps = a.eps_new[(size_t)r * A + lane];
-    tanh_gauss_bwd(mu, raw, eps, a.act_scale[lane], a.lo_ls, a.hi_ls, dA, alpha * a.inv_B, dmu, draw);
+    tanh_gauss_bwd(mu, raw, eps, scale, a.lo_ls, a.hi_ls, dA, alpha * a.inv_B, dmu, draw);
     a.dout_pi[(size_t)r * 2 * A + lane] = dmu;
     a.dout_pi[(size_t)r * 2 * A + A + lane] = draw;
     a.d_new_act[(size_t)r * A + lane] = dA;
@@ -723,35 +975,33 @@ __global__ void __launch_bounds__(kThreads) k_heads_bwd(HeadsBwdArgs a) {
   }
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
-  // dZ of the policy's last hidden layer
-  for (int k = lane * 4; k < a.WL; k += 256) {
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    const bool full = k + 3 < a.WL;
-    for (int n = 0; n < 2 * A; ++n) {
-      const float d = sh_dout[wave][n];
-      const float* w = a.Wout_pi + (size_t)n * a.WL + k;
-      if (full) { const f32x4 wv = *(const f32x4u*)w; s += d * wv; }
-      else for (int q = 0; q < 4 && k + q < a.WL; ++q) s[q] += d * w[q];
+  TL_STAMP();  // 2: rsample backward done
+  // dZ of the policy's last hidden layer: lane owns 4 consecutive hidden units per 256-chunk
+  f32x4 s[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) s[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int n = 0; n < 2 * A; ++n) {
+    const float d = sh_dout[wave][n];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int k = c * 256 + lane * 4;
+      const f32x4 wv = *(const f32x4u*)(a.Wout_pi + (size_t)n * a.WL + (k < a.WL ? k : 0));
+      s[c] += d * wv;
     }
-    const float* gp = a.G_pi + (size_t)r * a.WL + k;
-    float* dz = a.dZ_pi + (size_t)r * a.WL + k;
-    if (full) { const f32x4 gv = *(const f32x4u*)gp; *(f32x4u*)dz = s * gv; }
-    else for (int q = 0; q < 4 && k + q < a.WL; ++q) dz[q] = s[q] * gp[q];
   }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_finalize_grads: alpha gradient (dsac_v2.py:312-318) from the per-workgroup partial sums.
-//   d loss_alpha / d log_alpha = -mean(logp_new + target_entropy)
-// ---------------------------------------------------------------------------------------------
-struct FinalizeArgs {
-  const float* part_loss; int n_part; float inv_B; float target_entropy; float* grad_log_alpha; int auto_alpha;
-};
-__global__ void k_finalize_grads(FinalizeArgs a) {
-  float s = 0.f;
-  for (int i = threadIdx.x; i < a.n_part; i += 64) s += a.part_loss[i * kLossPart + 7];
-  s = wave_sum(s);
-  if (threadIdx.x == 0) a.grad_log_alpha[0] = a.auto_alpha ? -(s * a.inv_B + a.target_entropy) : 0.0f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int k = c * 256 + lane * 4;
+    if (k < a.WL) {
+      float* dz = a.dZ_pi + (size_t)r * a.WL + k;
+      const f32x4 o = s[c] * gv[c];
+      if (k + 3 < a.WL) *(f32x4u*)dz = o;
+      else for (int q = 0; q < 4 && k + q < a.WL; ++q) dz[q] = o[q];
+    }
+  }
+  TL_STAMP();  // 3: dZ_pi written
+  TL_FLUSH(a.timeline, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -772,18 +1022,52 @@ struct AdamArgs {
 __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
   const DevState st = *a.st;
   const long long stride = (long long)gridDim.x * kThreads;
-  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < a.n_total; i += stride) {
-    bool upd; float ss, bc2;
-    if (i < a.n_q2) { upd = true; ss = st.ss_q; bc2 = st.bc2_q; }
-    else if (i < a.n_online3) { upd = st.do_delayed != 0; ss = st.ss_pi; bc2 = st.bc2_pi; }
-    else { upd = st.do_delayed != 0 && a.auto_alpha; ss = st.ss_alpha; bc2 = st.bc2_alpha; }
-    float p = a.p[i];
-    if (upd) {
-      float m = a.m[i], v = a.v[i];
-      adam_update(p, m, v, a.g[i], a.b1w, a.beta2, a.b2w, ss, bc2, a.eps);
-      a.p[i] = p; a.m[i] = m; a.v[i] = v;
+  const long long n4 = (a.n_total + 3) >> 2;
+  const bool delayed = st.do_delayed != 0;
+  for (long long i4 = (long long)blockIdx.x * kThreads + threadIdx.x; i4 < n4; i4 += stride) {
+    const long long base = i4 << 2;
+    // elements [base, base+4) may straddle the q | policy | log_alpha boundaries: classify each
+    bool upd[4]; float ss[4], bc2[4];
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long long i = base + e;
+      if (i < a.n_q2) { upd[e] = true; ss[e] = st.ss_q; bc2[e] = st.bc2_q; }
+      else if (i < a.n_online3) { upd[e] = delayed; ss[e] = st.ss_pi; bc2[e] = st.bc2_pi; }
+      else { upd[e] = delayed && a.auto_alpha && i < a.n_total; ss[e] = st.ss_alpha; bc2[e] = st.bc2_alpha; }
+      any = any || upd[e];
     }
-    if (st.do_delayed && i < a.n_online3) a.tgt[i] = polyak_update(a.tgt[i], p, a.polyak, a.one_minus_polyak);
+    if (!any) continue;  // policy / alpha segments on the off iterations of the delayed update
+    if (base + 3 < a.n_total) {
+      f32x4 p = *(const f32x4*)(a.p + base), m = *(const f32x4*)(a.m + base), v = *(const f32x4*)(a.v + base);
+      const f32x4 g = *(const f32x4*)(a.g + base);
+      const bool tvec = delayed && base + 3 < a.n_online3;
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      if (tvec) t = *(const f32x4*)(a.tgt + base);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (upd[e]) {
+          float pe = p[e], me = m[e], ve = v[e];
+          adam_update(pe, me, ve, g[e], a.b1w, a.beta2, a.b2w, ss[e], bc2[e], a.eps);
+          p[e] = pe; m[e] = me; v[e] = ve;
+        }
+        if (tvec) t[e] = polyak_update(t[e], p[e], a.polyak, a.one_minus_polyak);
+        else if (delayed && base + e < a.n_online3) a.tgt[base + e] = polyak_update(a.tgt[base + e], p[e], a.polyak, a.one_minus_polyak);
+      }
+      *(f32x4*)(a.p + base) = p; *(f32x4*)(a.m + base) = m; *(f32x4*)(a.v + base) = v;
+      if (tvec) *(f32x4*)(a.tgt + base) = t;
+    } else {
+      for (int e = 0; e < 4 && base + e < a.n_total; ++e) {
+        const long long i = base + e;
+        float p = a.p[i];
+        if (upd[e]) {
+          float m = a.m[i], v = a.v[i];
+          adam_update(p, m, v, a.g[i], a.b1w, a.beta2, a.b2w, ss[e], bc2[e], a.eps);
+          a.p[i] = p; a.m[i] = m; a.v[i] = v;
+        }
+        if (delayed && i < a.n_online3) a.tgt[i] = polyak_update(a.tgt[i], p, a.polyak, a.one_minus_polyak);
+      }
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (a.commit_ms) { a.st->ms1 = a.g[a.n_total]; a.st->ms2 = a.g[a.n_total + 1]; a.st->ms_init = 1; }
@@ -846,16 +1130,26 @@ __global__ void __launch_bounds__(kThreads) k_std_sums(StdSumArgs a) {
 
 // policy head only (sampler / evaluator feed): logits (mean | std) as StochaPolicy.forward returns
 struct PolicyOutArgs { const float* H; const float* Wout; const float* bout; int W, n, A; float lo_ls, hi_ls; float* out; };
+template <int NCH>
 __global__ void __launch_bounds__(kThreads) k_policy_out(PolicyOutArgs a) {
+  constexpr int G = NCH == 1 ? 12 : (NCH == 2 ? 8 : 4);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = blockIdx.x * 4 + wave;
   if (r >= a.n) return;
-  RowRegs h;
-  row_load(a.H + (size_t)r * a.W, a.W, lane, h);
-  for (int n = 0; n < 2 * a.A; ++n) {
-    float o = row_dot(h, a.Wout + (size_t)n * a.W, a.W, lane) + a.bout[n];
-    if (n >= a.A) o = expf(clampf(o, a.lo_ls, a.hi_ls));
-    if (lane == 0) a.out[(size_t)r * 2 * a.A + n] = o;
+  f32x4 h[NCH];
+  row_load<NCH>(a.H + (size_t)r * a.W, a.W, lane, h);
+  for (int n0 = 0; n0 < 2 * a.A; n0 += G) {
+    float o[G];
+    row_dots<NCH, G>(h, a.Wout, a.W, n0, 2 * a.A, lane, o);
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      const int n = n0 + q;
+      if (lane == 0 && n < 2 * a.A) {
+        float v = o[q] + a.bout[n];
+        if (n >= a.A) v = expf(clampf(v, a.lo_ls, a.hi_ls));
+        a.out[(size_t)r * 2 * a.A + n] = v;
+      }
+    }
   }
 }
 

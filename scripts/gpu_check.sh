@@ -21,6 +21,6 @@ echo "== bench" | tee -a $OUT/steps.log
 timeout 600 python bench.py --steps 4000 --warmup 400 > $OUT/bench.log 2>&1; echo "bench rc=$?" | tee -a $OUT/steps.log
 tail -2 $OUT/bench.log
 echo "== rocprof" | tee -a $OUT/steps.log
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-alt > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?" | tee -a $OUT/steps.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-alt > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?" | tee -a $OUT/steps.log
 ls -R $OUT/prof | head -20
 fi
