@@ -72,10 +72,12 @@ struct dsact_handle {
   float* Gb[N_CHAIN][DSACT_MAX_HIDDEN_LAYERS];
   float* dZ[5][DSACT_MAX_HIDDEN_LAYERS];
   float *logits_pi, *logits_pit, *logp_new, *logp2;
-  float *qout_c[2], *qout_t[2], *qout_p[2];
+  float *qout_c[2], *qout_t[2], *qout_p[2], *qstd_c[2];
+  float* W1p[4];  // zero-padded first-layer weights of q1, q2, q1_target, q2_target  [w0 x ldx]
   float* dout[4];
   float *dout_pi, *d_new_act;
-  float* dA[2];  // dL/d new_act through q1 / q2  [B x A]
+  float* dA[2];   // dL/d new_act through q1 / q2  [B x 32] (zero padded)
+  float* W1a[2];  // action columns of q1 / q2's first layer  [w0 x 32] (zero padded)
   float *part_loss, *part_heads, *stats, *ones, *std_sums;
   long long* timeline;  // [512][8] stamps of the stage named by DSACT_TIMELINE_STAGE (instrumented builds)
   float *act_scale, *act_center;
@@ -87,8 +89,9 @@ struct dsact_handle {
   // stand-alone policy forward
   float *Xact, *Hact[DSACT_MAX_HIDDEN_LAYERS], *Gact, *act_out;
   // tasks
-  GemmProb* d_tiles = nullptr;   // per-tile table of the weight/bias-gradient stage
+  GemmProb* d_tiles = nullptr;   // per-tile table of the weight/bias-gradient tiles: [q1 | q2 | policy]
   int n_dw_tiles = 0;
+  int dw_off[4] = {0, 0, 0, 0};  // start of q1, q2, policy tiles, end
   std::vector<Stage> fwd1, fwd2, bwdq, bwdpi, actf;
   Stage bwda;  // dA = dZ1(q_i(obs,new_act)) . W1_i[:, O:O+A]
   // replay ring
@@ -114,6 +117,7 @@ struct dsact_handle {
   std::vector<ProfRec> prof;
   // strict DP
   bool use_std_sums = false;
+  bool auto_std_sums = false;
 };
 
 namespace {
@@ -231,13 +235,17 @@ void carve(dsact_handle* h, Carver& c) {
     h->qout_c[i] = c.take<float>(B * 2);
     h->qout_t[i] = c.take<float>(B * 2);
     h->qout_p[i] = c.take<float>(B * 2);
+    h->qstd_c[i] = c.take<float>(B * 2);
   }
   for (int i = 0; i < 4; ++i) h->dout[i] = c.take<float>(B * 2);
   h->dout_pi = c.take<float>(B * 2 * A);
   h->d_new_act = c.take<float>(B * A);
-  h->dA[0] = c.take<float>(B * A);
-  h->dA[1] = c.take<float>(B * A);
-  h->part_loss = c.take<float>((size_t)h->n_loss_wg * kLossPart);
+  h->dA[0] = c.take<float>(B * 32);
+  h->dA[1] = c.take<float>(B * 32);
+  h->W1a[0] = c.take<float>((size_t)h->w[0] * 32);
+  h->W1a[1] = c.take<float>((size_t)h->w[0] * 32);
+  h->part_loss = c.take<float>(B * kLossPart);
+  for (int i = 0; i < 4; ++i) h->W1p[i] = c.take<float>((size_t)h->w[0] * h->ldx);
   h->part_heads = c.take<float>((size_t)h->n_heads_wg * 2);
   h->stats = c.take<float>(16);
   h->ones = c.take<float>(B);
@@ -284,6 +292,12 @@ GemmProb fwd_prob(const dsact_handle* h, int ch, int l, const float* x0, int ldx
   t.ldp = l == 0 ? ldx0 : d.out[l - 1];
   t.Q = base + d.w_off[l];
   t.ldq = d.in[l];
+  if (l == 0 && net != N_POL && net != N_POLT) {
+    // Q nets: rows of O+A floats are not 16-byte aligned -> use the zero-padded copy (k_gather repack)
+    const int slot = net == N_Q1 ? 0 : net == N_Q2 ? 1 : net == N_Q1T ? 2 : 3;
+    t.Q = h->W1p[slot];
+    t.ldq = h->ldx;
+  }
   t.aux = base + d.b_off[l];
   t.C0 = Hrow[l];
   t.C1 = Grow;
@@ -345,9 +359,9 @@ int build_tasks(dsact_handle* h) {
     GemmProb t;
     memset(&t, 0, sizeof(t));
     t.P = h->dZ[kDzSlot[ch]][0]; t.ldp = h->w[0];
-    t.Q = net_params(h, kChainNet[ch]) + h->qd.w_off[0] + h->O; t.ldq = h->O + h->A;
-    t.C0 = h->dA[qi]; t.ldc = h->A;
-    t.M = B; t.N = h->A; t.K = h->w[0];
+    t.Q = h->W1a[qi]; t.ldq = 32;   // zero-padded action columns (k_gather repack): a full 32-wide tile
+    t.C0 = h->dA[qi]; t.ldc = 32;
+    t.M = B; t.N = 32; t.K = h->w[0];
     stage_add(h->bwda, t);
   }
   // stand-alone policy forward (kActRows rows)
@@ -367,7 +381,9 @@ int build_tasks(dsact_handle* h) {
         tiles.push_back(q);
       }
   };
+  int which = 0;
   for (int ch : {C_Q1C, C_Q2C, C_PI}) {
+    h->dw_off[which++] = (int)tiles.size();
     const int net = kChainNet[ch];
     const NetDesc& d = net_desc(h, net);
     float* g = net_grads(h, net);
@@ -393,6 +409,7 @@ int build_tasks(dsact_handle* h) {
   }
   if (h->d_tiles) { hipFree(h->d_tiles); h->d_tiles = nullptr; }
   h->n_dw_tiles = (int)tiles.size();
+  h->dw_off[3] = h->n_dw_tiles;
   HIPCHK(h, hipMalloc(&h->d_tiles, tiles.size() * sizeof(GemmProb)));
   HIPCHK(h, hipMemcpy(h->d_tiles, tiles.data(), tiles.size() * sizeof(GemmProb), hipMemcpyHostToDevice));
   return DSACT_OK;
@@ -403,21 +420,28 @@ long long* tl_for(dsact_handle* h, const char* name) {
   return (want && !strcmp(want, name)) ? h->timeline : nullptr;
 }
 
-int run_stage(dsact_handle* h, const Stage& s0) {
-  if (s0.n_blocks == 0) return DSACT_OK;
+// runs a stage; tiles [x0, x1) of the weight-gradient table ride along in the same launch
+int run_stage(dsact_handle* h, const Stage& s0, int x0 = 0, int x1 = 0) {
+  if (s0.n_blocks == 0 && x1 <= x0) return DSACT_OK;
   Stage s = s0;
   const char* want = getenv("DSACT_TIMELINE_STAGE");
   s.args.timeline = (want && s.name == want) ? h->timeline : nullptr;
-  const size_t lds = tile_lds_bytes(s.max_k);
+  s.args.n_stage_blocks = s.n_blocks;
+  s.args.extra = h->d_tiles + x0;
+  s.args.n_extra = x1 > x0 ? x1 - x0 : 0;
+  const int grid = s.n_blocks + s.args.n_extra;
+  size_t lds = tile_lds_bytes(s.max_k);
+  if (s.args.n_extra && tile_lds_bytes(h->B) > lds) lds = tile_lds_bytes(h->B);
   if (s.kind == 0)
-    return launch(h, s.name.c_str(), k_stage<false, false, EPI_GELU>, dim3(s.n_blocks), dim3(kThreads), lds, s.args);
+    return launch(h, s.name.c_str(), k_stage<false, false, EPI_GELU>, dim3(grid), dim3(kThreads), lds, s.args);
   if (s.kind == 2)
-    return launch(h, s.name.c_str(), k_stage<false, true, EPI_STORE>, dim3(s.n_blocks), dim3(kThreads), lds, s.args);
-  return launch(h, s.name.c_str(), k_stage<false, true, EPI_MULG>, dim3(s.n_blocks), dim3(kThreads), lds, s.args);
+    return launch(h, s.name.c_str(), k_stage<false, true, EPI_STORE>, dim3(grid), dim3(kThreads), lds, s.args);
+  return launch(h, s.name.c_str(), k_stage<false, true, EPI_MULG>, dim3(grid), dim3(kThreads), lds, s.args);
 }
 
-int run_dw(dsact_handle* h) {
-  return launch(h, "dW", k_stage_table, dim3(h->n_dw_tiles), dim3(kThreads), tile_lds_bytes(h->B), (const GemmProb*)h->d_tiles);
+int run_dw(dsact_handle* h, int x0, int x1) {
+  if (x1 <= x0) return DSACT_OK;
+  return launch(h, "dW", k_stage_table, dim3(x1 - x0), dim3(kThreads), tile_lds_bytes(h->B), (const GemmProb*)(h->d_tiles + x0));
 }
 
 // dispatch on the number of 256-wide chunks of a hidden row (register arrays are statically indexed)
@@ -452,6 +476,21 @@ NoiseArgs noise_args(const dsact_handle* h) {
   return nz;
 }
 
+RepackArgs repack_args(const dsact_handle* h, int n_blocks) {
+  RepackArgs rp;
+  const int nets[4] = {N_Q1, N_Q2, N_Q1T, N_Q2T};
+  for (int i = 0; i < 4; ++i) { rp.src[i] = net_params(h, nets[i]) + h->qd.w_off[0]; rp.dst[i] = h->W1p[i]; }
+  rp.rows = h->w[0]; rp.K = h->O + h->A; rp.ldp = h->ldx;
+  rp.n_blocks = n_blocks;
+  rp.w1a[0] = h->W1a[0]; rp.w1a[1] = h->W1a[1]; rp.O = h->O; rp.A = h->A;
+  return rp;
+}
+int repack_blocks(const dsact_handle* h) {
+  const int total4 = 4 * h->w[0] * h->ldx;
+  int nb = (total4 + kThreads * 8 - 1) / (kThreads * 8);
+  return nb < 1 ? 1 : (nb > 256 ? 256 : nb);
+}
+
 int enqueue_gather(dsact_handle* h, const int* table, int rows, int use_dev, long long it, int advance) {
   GatherArgs a;
   a.rb_obs = h->rb_obs; a.rb_obs2 = h->rb_obs2; a.rb_act = h->rb_act; a.rb_rew = h->rb_rew; a.rb_done = h->rb_done;
@@ -459,14 +498,21 @@ int enqueue_gather(dsact_handle* h, const int* table, int rows, int use_dev, lon
   a.X0 = h->X0; a.XP = h->XP; a.X2 = h->X2; a.rew = h->rew; a.done = h->done;
   a.B = h->B; a.O = h->O; a.A = h->A; a.ldx = h->ldx;
   a.st = h->st; a.bookkeeping = 1; a.advance_counters = advance; a.hp = step_hyper(h); a.nz = noise_args(h);
-  return launch(h, "gather", k_gather, dim3((h->B + 3) / 4), dim3(kThreads), 0, a);
+  a.n_gather_blocks = (h->B + 3) / 4;
+  a.rp = repack_args(h, repack_blocks(h));
+  return launch(h, "gather", k_gather, dim3(a.n_gather_blocks + a.rp.n_blocks), dim3(kThreads), 0, a);
 }
 
 int enqueue_prologue(dsact_handle* h, int use_dev, long long it, int advance, int fill_noise) {
   PrologueArgs a;
   a.st = h->st; a.use_dev = use_dev; a.host_it = it; a.advance_counters = advance; a.fill_noise = fill_noise;
   a.hp = step_hyper(h); a.nz = noise_args(h); a.B = h->B; a.A = h->A;
-  return launch(h, "prologue", k_prologue, dim3(1), dim3(kThreads), 0, a);
+  TRY(launch(h, "prologue", k_prologue, dim3(1), dim3(kThreads), 0, a));
+  if (fill_noise || !advance) {  // a forward pass follows: refresh the padded first-layer weights
+    const int nb = repack_blocks(h);
+    if (nb) TRY(launch(h, "repack", k_repack, dim3(nb), dim3(kThreads), 0, repack_args(h, nb)));
+  }
+  return DSACT_OK;
 }
 
 // everything of __compute_gradient after the minibatch is staged (dsac_v2.py:150-206)
@@ -487,6 +533,7 @@ int enqueue_grads(dsact_handle* h, bool actor_backward) {
     a.eps_new = h->eps_new; a.eps_2 = h->eps_2; a.XP = h->XP; a.X2 = h->X2;
     a.logits_pi = h->logits_pi; a.logits_pit = h->logits_pit; a.logp_new = h->logp_new; a.logp2 = h->logp2;
     a.qout[0] = h->qout_c[0]; a.qout[1] = h->qout_c[1];
+    a.qstd[0] = h->qstd_c[0]; a.qstd[1] = h->qstd_c[1];
     a.part_heads = h->part_heads; a.act_scale = h->act_scale; a.act_center = h->act_center;
     a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
     a.timeline = tl_for(h, "heads");
@@ -494,11 +541,11 @@ int enqueue_grads(dsact_handle* h, bool actor_backward) {
     NCH_DISPATCH(a.W, CALL_HEADS);
   }
   for (int l = 0; l < L; ++l) TRY(run_stage(h, h->fwd2[l]));
-  if (h->use_std_sums) {
-    // strict data-parallel mode: the caller all-reduces std_sums between compute phases; on one
-    // GPU the local sums are used directly.
+  if (h->use_std_sums || h->auto_std_sums) {
+    // large batches (and the strict data-parallel mode, where the caller all-reduces std_sums
+    // between the phases): the std column is summed by one workgroup instead of by every wave
     StdSumArgs s;
-    s.qout_c[0] = h->qout_c[0]; s.qout_c[1] = h->qout_c[1]; s.B = B; s.out = h->std_sums;
+    s.qstd_c[0] = h->qstd_c[0]; s.qstd_c[1] = h->qstd_c[1]; s.B = B; s.out = h->std_sums;
     TRY(launch(h, "std_sums", k_std_sums, dim3(1), dim3(kThreads), 0, s));
   }
   {
@@ -516,26 +563,27 @@ int enqueue_grads(dsact_handle* h, bool actor_backward) {
       a.dZl[i] = h->dZ[kDzSlot[dch[i]]][L - 1];
       a.dout[i] = h->dout[i];
     }
-    a.Wq[0] = net_params(h, N_Q1) + h->qd.w_off[L];
-    a.Wq[1] = net_params(h, N_Q2) + h->qd.w_off[L];
-    for (int i = 0; i < 2; ++i) { a.qout_c[i] = h->qout_c[i]; a.qout_t[i] = h->qout_t[i]; a.qout_p[i] = h->qout_p[i]; }
+    for (int i = 0; i < 2; ++i) { a.qout_c[i] = h->qout_c[i]; a.qstd_c[i] = h->qstd_c[i]; a.qout_t[i] = h->qout_t[i]; a.qout_p[i] = h->qout_p[i]; }
     a.rew = h->rew; a.done = h->done; a.logp2 = h->logp2; a.logp_new = h->logp_new; a.z5 = h->z5; a.z6 = h->z6;
     a.log_alpha = h->online + h->n_online - 1;
     a.part_loss = h->part_loss; a.grads_tail = h->grads + h->n_online; a.st = h->st;
-    a.W = h->w[L - 1]; a.B = B; a.rows_per_wg = h->loss_rows;
+    a.W = h->w[L - 1]; a.B = B;
     a.inv_B = 1.0f / (float)B;
     a.inv_Bg = h->use_std_sums ? 1.0f / (float)h->cfg.global_batch : 1.0f / (float)B;
-    a.std_sums = h->use_std_sums ? h->std_sums : nullptr;
+    a.std_sums = (h->use_std_sums || h->auto_std_sums) ? h->std_sums : nullptr;
     a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.gamma = h->cfg.gamma; a.tau_b = h->cfg.tau_b; a.one_minus_tau_b = (float)(1.0 - dec7(h->cfg.tau_b));
     a.timeline = tl_for(h, "loss");
-#define CALL_LOSS(N) TRY(launch(h, "loss", k_loss<N>, dim3(h->n_loss_wg), dim3(kThreads), (size_t)h->loss_rows * 16 * sizeof(float), a))
+#define CALL_LOSS(N) TRY(launch(h, "loss", k_loss<N>, dim3(h->n_loss_wg), dim3(kThreads), 0, a))
     NCH_DISPATCH(a.W, CALL_LOSS);
   }
   for (size_t i = 0; i < h->bwdq.size(); ++i) TRY(run_stage(h, h->bwdq[i]));
   {
-    TRY(run_stage(h, h->bwda));
+    // the critics' weight-gradient tiles are independent of the actor path: they ride along in its
+    // under-filled launches (q1's with bwdA, q2's with the first policy-backward stage)
+    const bool q2_rides_pi = !h->bwdpi.empty();
+    TRY(run_stage(h, h->bwda, h->dw_off[0], q2_rides_pi ? h->dw_off[1] : h->dw_off[2]));
     HeadsBwdArgs a;
-    a.dA[0] = h->dA[0]; a.dA[1] = h->dA[1];
+    a.dA[0] = h->dA[0]; a.dA[1] = h->dA[1]; a.ldA = 32;
     a.logits_pi = h->logits_pi; a.eps_new = h->eps_new; a.log_alpha = h->online + h->n_online - 1;
     a.Wout_pi = net_params(h, N_POL) + h->pd.w_off[L];
     a.G_pi = h->Gb[C_PI][L - 1]; a.dZ_pi = h->dZ[kDzSlot[C_PI]][L - 1];
@@ -543,14 +591,15 @@ int enqueue_grads(dsact_handle* h, bool actor_backward) {
     a.WL = h->w[L - 1]; a.B = B; a.O = h->O; a.A = A;
     a.inv_B = 1.0f / (float)B; a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed;
     a.act_scale = h->act_scale; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
-    a.part_loss = h->part_loss; a.n_part = h->n_loss_wg; a.target_entropy = -(float)A;
+    a.part_loss = h->part_loss; a.n_part = B; a.target_entropy = -(float)A;
     a.grad_log_alpha = h->grads + h->n_online - 1;
     a.timeline = tl_for(h, "heads_bwd");
 #define CALL_HBWD(N) TRY(launch(h, "heads_bwd", k_heads_bwd<N>, dim3((B + 3) / 4), dim3(kThreads), 0, a))
     NCH_DISPATCH(a.WL, CALL_HBWD);
   }
-  for (size_t i = 0; i < h->bwdpi.size(); ++i) TRY(run_stage(h, h->bwdpi[i]));
-  TRY(run_dw(h));
+  for (size_t i = 0; i < h->bwdpi.size(); ++i)
+    TRY(run_stage(h, h->bwdpi[i], i == 0 ? h->dw_off[1] : 0, i == 0 ? h->dw_off[2] : 0));
+  TRY(run_dw(h, h->dw_off[2], h->dw_off[3]));  // policy weight gradients
   (void)actor_backward;
   return DSACT_OK;
 }
@@ -623,9 +672,9 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->n_online = 2 * h->n_q + h->n_pi + 1;
   h->n_target = 2 * h->n_q + h->n_pi;
   h->n_heads_wg = (h->B + 3) / 4;
-  h->n_loss_wg = h->B >= 1024 ? 256 : (h->B + 3) / 4;
-  h->loss_rows = (h->B + h->n_loss_wg - 1) / h->n_loss_wg;
-  h->n_loss_wg = (h->B + h->loss_rows - 1) / h->loss_rows;
+  h->n_loss_wg = (h->B + 3) / 4;  // one wave per sample
+  h->loss_rows = 4;
+  h->auto_std_sums = h->B > 1024;   // large batches: the std column is summed once, not by every wave
   Carver c0;
   carve(h, c0);
   h->ws_bytes = c0.off + 256;
@@ -873,6 +922,8 @@ int dsact_gather(dsact_handle* h, const int64_t* idx_host, int32_t batch) {
   a.X0 = h->X0; a.XP = h->XP; a.X2 = h->X2; a.rew = h->rew; a.done = h->done;
   a.B = h->B; a.O = h->O; a.A = h->A; a.ldx = h->ldx; a.st = h->st; a.bookkeeping = 0; a.advance_counters = 0;
   a.hp = step_hyper(h); a.nz = noise_args(h); a.nz.seed = 0;
+  a.n_gather_blocks = (h->B + 3) / 4;
+  a.rp = repack_args(h, 0);
   TRY(launch(h, "gather", k_gather, dim3((h->B + 3) / 4), dim3(kThreads), 0, a));
   h->have_batch = true;
   return DSACT_OK;
@@ -1054,7 +1105,7 @@ int dsact_read_stats(dsact_handle* h, float out[16]) {
   TRY(check_ready(h, false));
   HIPCHK(h, hipSetDevice(h->device));
   StatsArgs a;
-  a.part_loss = h->part_loss; a.n_loss = h->n_loss_wg; a.part_heads = h->part_heads; a.n_heads = h->n_heads_wg;
+  a.part_loss = h->part_loss; a.n_loss = h->B; a.part_heads = h->part_heads; a.n_heads = h->n_heads_wg;
   a.log_alpha = h->online + h->n_online - 1; a.st = h->st;
   a.inv_B = 1.0f / (float)h->B; a.inv_BA = 1.0f / ((float)h->B * (float)h->A);
   a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.out = h->stats;
@@ -1146,7 +1197,7 @@ int dsact_debug_read(dsact_handle* h, const char* name, float* out, size_t cap, 
       {"qout_p0", h->qout_p[0], 2 * B}, {"qout_p1", h->qout_p[1], 2 * B},
       {"dout0", h->dout[0], 2 * B}, {"dout1", h->dout[1], 2 * B}, {"dout2", h->dout[2], 2 * B}, {"dout3", h->dout[3], 2 * B},
       {"dout_pi", h->dout_pi, B * 2 * A}, {"d_new_act", h->d_new_act, B * A},
-      {"part_loss", h->part_loss, (size_t)h->n_loss_wg * kLossPart}, {"part_heads", h->part_heads, (size_t)h->n_heads_wg * 2},
+      {"part_loss", h->part_loss, (size_t)h->B * kLossPart}, {"part_heads", h->part_heads, (size_t)h->n_heads_wg * 2},
       {"timeline", (const float*)h->timeline, (size_t)512 * 8 * 2},
   };
   for (const E& e : tab) if (s == e.k) { src = e.p; cnt = e.c; }

@@ -48,10 +48,11 @@ struct DevState {
 
 // opt-in phase timeline (build with -DDSACT_TIMELINE): shader-clock stamps of selected blocks
 #ifdef DSACT_TIMELINE
-#define TL_DECL long long tl_t[8]; int tl_n = 0;
+#define TL_DECL long long tl_t[8]; int tl_n = 0; const long long tl_w0 = (long long)wall_clock64();
 #define TL_STAMP() do { if (tl_n < 8) tl_t[tl_n++] = (long long)__builtin_readcyclecounter(); } while (0)
 #define TL_FLUSH(buf, slot) do { if ((buf) && threadIdx.x == 0 && (slot) < 512) { \
-    for (int q_ = 0; q_ < 8; ++q_) (buf)[(slot) * 8 + q_] = q_ < tl_n ? tl_t[q_] : 0; } } while (0)
+    for (int q_ = 0; q_ < 8; ++q_) (buf)[(slot) * 8 + q_] = q_ < tl_n ? tl_t[q_] : 0; \
+    (buf)[(slot) * 8 + 6] = tl_w0; (buf)[(slot) * 8 + 7] = (long long)wall_clock64(); } } while (0)
 #else
 #define TL_DECL
 #define TL_STAMP() do {} while (0)
@@ -195,6 +196,34 @@ __device__ void fill_noise_rows(const NoiseArgs& nz, long long it, int r0, int r
   }
 }
 
+// zero-padded copies of the Q nets' first-layer weights: rows of O+A floats (odd leading dimension)
+// become rows of `ldp` floats (multiple of 4) so that the K=O+A tile stages issue aligned dwordx4.
+// Rebuilt at the start of every step (after Adam / Polyak / any external state_dict load) by spare
+// blocks of the gather launch; 4 nets x W0 x ldp floats.
+struct RepackArgs {
+  const float* src[4]; float* dst[4];
+  int rows, K, ldp;
+  int n_blocks;        // blocks assigned to the repack (0 = none)
+  float* w1a[2];       // action columns of q1 / q2's first layer, [rows][32] zero padded (bwdA stage)
+  int O, A;
+};
+__device__ void repack_rows(const RepackArgs& rp, int blk, int tid) {
+  const int per_net = rp.rows * rp.ldp;
+  const int total = 4 * per_net;
+  for (int e = blk * kThreads + tid; e < total; e += rp.n_blocks * kThreads) {
+    const int net = e / per_net, rem = e - net * per_net;
+    const int row = rem / rp.ldp, col = rem - row * rp.ldp;
+    rp.dst[net][rem] = col < rp.K ? rp.src[net][(size_t)row * rp.K + col] : 0.0f;
+  }
+  const int nact = 2 * rp.rows * 32;
+  for (int e = blk * kThreads + tid; e < nact; e += rp.n_blocks * kThreads) {
+    const int net = e / (rp.rows * 32), rem = e - net * rp.rows * 32;
+    const int row = rem >> 5, j = rem & 31;
+    rp.w1a[net][rem] = j < rp.A ? rp.src[net][(size_t)row * rp.K + rp.O + j] : 0.0f;
+  }
+}
+__global__ void __launch_bounds__(kThreads) k_repack(RepackArgs rp) { repack_rows(rp, blockIdx.x, threadIdx.x); }
+
 struct GatherArgs {
   const float* rb_obs; const float* rb_obs2; const float* rb_act; const float* rb_rew; const float* rb_done;
   const int* idx_table;   // [rows][B]
@@ -208,10 +237,16 @@ struct GatherArgs {
   int advance_counters;
   StepHyper hp;
   NoiseArgs nz;
+  RepackArgs rp;
+  int n_gather_blocks;
 };
 
 __global__ void __launch_bounds__(kThreads) k_gather(GatherArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x >= a.n_gather_blocks) {  // spare blocks: weight repack (independent of the gather)
+    repack_rows(a.rp, (int)blockIdx.x - a.n_gather_blocks, tid);
+    return;
+  }
   const long long it = a.use_dev ? a.st->it_next : a.host_it;
   const int trow = a.use_dev ? (int)(a.st->seq_next % a.idx_rows) : a.host_row;
   const int r0 = blockIdx.x * 4;
@@ -561,13 +596,21 @@ constexpr int kMaxProb = 6;
 struct StageArgs {
   GemmProb p[kMaxProb];
   int n_prob;
-  long long* timeline;  // DSACT_TIMELINE builds only (else unused)
+  int n_stage_blocks;      // blocks [0, n_stage_blocks) run the problems above ...
+  const GemmProb* extra;   // ... the remaining blocks run per-tile table entries (weight gradients that
+  int n_extra;             //     are independent of this stage and would otherwise idle-wait for it)
+  long long* timeline;     // DSACT_TIMELINE builds only (else unused)
 };
 
 template <bool P_MC, bool Q_MC, int EPI>
 __global__ void __launch_bounds__(kThreads) k_stage(StageArgs s) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // tile_lds_bytes(max K of the stage)
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // tile_lds_bytes(max K of the launch)
   const int b = xcd_logical_block(blockIdx.x, gridDim.x);
+  if (b >= s.n_stage_blocks) {  // ride-along weight-gradient tile (MC x MC, plain store)
+    const GemmProb g = s.extra[b - s.n_stage_blocks];
+    run_tile<true, true, EPI_STORE>(g, g.tiles_n, g.tile_end, lds);
+    return;
+  }
   int pi = 0;
 #pragma unroll
   for (int q = 0; q + 1 < kMaxProb; ++q)
@@ -652,6 +695,7 @@ struct HeadsArgs {
   float* logits_pit;  // [B x 2A] same for policy_target(obs2) (debug / parity only)
   float* logp_new; float* logp2;
   float* qout[2];     // raw (mean, pre-softplus std) of q1/q2(obs,act)  [B x 2]
+  float* qstd[2];     // (softplus(raw std), d softplus / d raw) of the same          [B x 2]
   float* part_heads;  // [gridDim.x][2]: sum tanh(mu), sum sigma  (policy chain)
   const float* act_scale; const float* act_center;  // (hi-lo)/2, (hi+lo)/2
   float lo_ls, hi_ls;
@@ -676,8 +720,11 @@ __global__ void __launch_bounds__(kThreads) k_heads(HeadsArgs a) {
       float o[2];
       row_dots<NCH, 2>(h, a.Wout[chain], a.W, 0, 2, lane, o);
       if (lane == 0) {
-        a.qout[chain - 2][2 * r] = o[0] + a.bout[chain][0];
-        a.qout[chain - 2][2 * r + 1] = o[1] + a.bout[chain][1];
+        const float mean = o[0] + a.bout[chain][0], raw = o[1] + a.bout[chain][1];
+        a.qout[chain - 2][2 * r] = mean;
+        a.qout[chain - 2][2 * r + 1] = raw;
+        a.qstd[chain - 2][2 * r] = softplus(raw);
+        a.qstd[chain - 2][2 * r + 1] = softplus_grad(raw);
       }
     } else {
       const int A = a.A;
@@ -721,13 +768,16 @@ __global__ void __launch_bounds__(kThreads) k_heads(HeadsArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_loss: dsac_v2.py:218-318 for the rows of this workgroup.
-//   phase 1  batch means of std1/std2 (every workgroup, redundantly: 2B floats) -> mean_std EMA
-//   phase 2  output layers of q1_t,q2_t(obs2,act2) and q1,q2(obs,new_act)   (wave per row)
-//   phase 3  per-sample targets / ratio / losses -> dL/d(out) of the 4 differentiated chains
-//   phase 4  dZ of the last hidden layer of those chains: (dOut . Wout) * GELU'(z)
-// part_loss[wg][12]: loss_q1, loss_q2, sum q1, q2, std1, std2, actor, logp_new, [8] = alpha used by
-// this update (workgroup 0 only), then [10],[11] = min std1, min std2 (reduced with min).
+// k_loss: dsac_v2.py:218-318, ONE WAVE PER SAMPLE, no block-level barriers.
+//   Every global load of the wave (batch std column, the sample's scalars, the four last-hidden rows,
+//   the output-layer weights, the GELU' rows) is issued at kernel entry, so the wave pays one
+//   memory round trip; the per-sample scalar math is done redundantly by all lanes.
+//     1  batch means of std1/std2 (each wave sums the whole column: 2B floats) -> mean_std EMA
+//     2  output layers of q1_t,q2_t(obs2,act2) and q1,q2(obs,new_act)
+//     3  targets / ratio / losses -> dL/d(out) of the 4 differentiated chains
+//     4  dZ of the last hidden layer of those chains: (dOut . Wout) * GELU'(z)
+// part_loss[row][12]: loss_q1, loss_q2, q1, q2, std1, std2, actor term, logp_new, [8] = alpha used by
+// this update (row 0 only), [10],[11] = std1, std2 (consumers reduce these two with min).
 // ---------------------------------------------------------------------------------------------
 constexpr int kLossPart = 12;
 struct LossArgs {
@@ -736,171 +786,142 @@ struct LossArgs {
   const float* bout[4];
   const float* Gl[4];    // GELU' of the last hidden layer of q1c, q2c, q1p, q2p
   float* dZl[4];         // dZ (last hidden) of q1c, q2c, q1p, q2p
-  const float* Wq[2];    // out weights of q1, q2 (online)  [2 x W]
-  const float* qout_c[2];  // raw outs q1(obs,act), q2(obs,act)  [B x 2]
-  float* qout_t[2];        // raw outs of the targets (debug)      [B x 2]
-  float* qout_p[2];        // raw outs q(obs,new_act)   (debug)     [B x 2]
+  const float* qout_c[2];  // raw outs q1(obs,act), q2(obs,act)          [B x 2]
+  const float* qstd_c[2];  // (std, d std / d raw) of the same             [B x 2]
+  float* qout_t[2];        // raw outs of the targets (debug)              [B x 2]
+  float* qout_p[2];        // raw outs q(obs,new_act)   (debug)             [B x 2]
   float* dout[4];          // dL/d(out) [B x 2]: q1c, q2c, q1p, q2p
   const float* rew; const float* done; const float* logp2; const float* logp_new;
   const float* z5; const float* z6;
   const float* log_alpha;
-  float* part_loss;
+  float* part_loss;        // [B][kLossPart]
   float* grads_tail;       // [2] updated mean_std1/2 (re-synchronised by the gradient all-reduce)
   const DevState* st;
-  int W, B, rows_per_wg;
+  int W, B;
   float inv_B;             // 1 / local batch
   float inv_Bg;            // 1 / global batch   (mean of std for the EMA; == inv_B on one GPU)
-  const float* std_sums;   // strict data-parallel mode: all-reduced {sum std1, sum std2}; NULL otherwise
+  const float* std_sums;   // {sum std1, sum std2} computed elsewhere (large B / strict data-parallel); else NULL
   int auto_alpha; float alpha_fixed, gamma, tau_b, one_minus_tau_b;
   long long* timeline;
 };
 
 template <int NCH>
 __global__ void __launch_bounds__(kThreads) k_loss(LossArgs a) {
-  __shared__ float red[4 * kLossPart];
-  __shared__ float sh_ms[2];
-  extern __shared__ float dyn[];  // [rows_per_wg][16]: raw outs (8) and dL/d(out) (8) of the 4 chains, my rows
   TL_DECL
   TL_STAMP();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r_begin = blockIdx.x * a.rows_per_wg;
-  const int r_end = min(r_begin + a.rows_per_wg, a.B);
-  // all independent global loads are issued up front: phase-1 column of std, then the per-sample
-  // inputs of phase 3, then the rows / weights of phase 2 -- one exposed round trip instead of three
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= a.B) return;  // waves are independent: no barrier anywhere in this kernel
+  // ---------------- all loads ----------------
   float s1 = 0.f, s2 = 0.f;
   if (a.std_sums == nullptr) {
-    for (int r = tid; r < a.B; r += kThreads) {
-      s1 += softplus(a.qout_c[0][2 * r + 1]);
-      s2 += softplus(a.qout_c[1][2 * r + 1]);
-    }
-  }
-  const int my_r = r_begin + tid;  // phase 3 handles one row per thread (rows_per_wg <= 256)
-  const bool mine = my_r < r_end;
-  const int rr = mine ? my_r : r_begin;
-  const float in_q1 = a.qout_c[0][2 * rr], in_raw1 = a.qout_c[0][2 * rr + 1];
-  const float in_q2 = a.qout_c[1][2 * rr], in_raw2 = a.qout_c[1][2 * rr + 1];
-  const float in_z5 = a.z5[rr], in_z6 = a.z6[rr], in_rew = a.rew[rr], in_done = a.done[rr];
-  const float in_lp2 = a.logp2[rr], in_lpn = a.logp_new[rr];
+    for (int rr = lane; rr < a.B; rr += 64) { s1 += a.qstd_c[0][2 * rr]; s2 += a.qstd_c[1][2 * rr]; }
+  } else if (lane == 0) { s1 = a.std_sums[0]; s2 = a.std_sums[1]; }
+  const float q1 = a.qout_c[0][2 * r], q2 = a.qout_c[1][2 * r];
+  const float std1 = a.qstd_c[0][2 * r], sg1 = a.qstd_c[0][2 * r + 1];
+  const float std2 = a.qstd_c[1][2 * r], sg2 = a.qstd_c[1][2 * r + 1];
+  const float in_z5 = a.z5[r], in_z6 = a.z6[r], rew = a.rew[r], in_done = a.done[r];
+  const float lp2 = a.logp2[r], lpn = a.logp_new[r];
   const float la = a.auto_alpha ? a.log_alpha[0] : 0.f;
-  // ---- phase 2 ----
-  for (int r = r_begin + wave; r < r_end; r += 4) {
-    f32x4 h[4][NCH];
+  const float ms1_old = a.st->ms1, ms2_old = a.st->ms2;
+  const int ms_init = a.st->ms_init;
+  float bo[4][2];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) row_load<NCH>(a.Hl[c] + (size_t)r * a.W, a.W, lane, h[c]);
-    float o[4][2];
+  for (int c = 0; c < 4; ++c) { bo[c][0] = a.bout[c][0]; bo[c][1] = a.bout[c][1]; }
+  f32x4 h[4][NCH], wv[4][2][NCH], gv[4][NCH];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) row_dots<NCH, 2>(h[c], a.Wout[c], a.W, 0, 2, lane, o[c]);
-    if (lane == 0) {
+  for (int c = 0; c < 4; ++c) {
+    row_load<NCH>(a.Hl[c] + (size_t)r * a.W, a.W, lane, h[c]);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float o0 = o[c][0] + a.bout[c][0], o1 = o[c][1] + a.bout[c][1];
-        dyn[(r - r_begin) * 16 + 2 * c] = o0;
-        dyn[(r - r_begin) * 16 + 2 * c + 1] = o1;
-        float* dbg = c < 2 ? a.qout_t[c] : a.qout_p[c - 2];
-        dbg[2 * r] = o0; dbg[2 * r + 1] = o1;
+    for (int q = 0; q < NCH; ++q) {
+      const int k = q * 256 + lane * 4;
+      const int kc = k < a.W ? k : 0;
+      wv[c][0][q] = *(const f32x4u*)(a.Wout[c] + kc);
+      wv[c][1][q] = *(const f32x4u*)(a.Wout[c] + a.W + kc);
+      gv[c][q] = *(const f32x4u*)(a.Gl[c] + (size_t)r * a.W + kc);
+    }
+  }
+  TL_STAMP();  // 1: loads issued
+  // ---------------- 2: output layers ----------------
+  float o[4][2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < NCH; ++q) {
+        s += h[c][q].x * wv[c][j][q].x; s += h[c][q].y * wv[c][j][q].y;
+        s += h[c][q].z * wv[c][j][q].z; s += h[c][q].w * wv[c][j][q].w;
       }
+      o[c][j] = wave_sum(s) + bo[c][j];
     }
+  // ---------------- 1: mean_std EMA ----------------
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  const float m1 = s1 * a.inv_Bg, m2 = s2 * a.inv_Bg;
+  float ms1, ms2;
+  if (!ms_init) { ms1 = m1; ms2 = m2; }
+  else {
+    ms1 = a.one_minus_tau_b * ms1_old + a.tau_b * m1;  // Python double (1 - tau_b) cast to fp32 by the tensor multiply
+    ms2 = a.one_minus_tau_b * ms2_old + a.tau_b * m2;
   }
-  TL_STAMP();  // 1: phase 2 (out layers) done
-  // ---- phase 1 ----
-  if (a.std_sums == nullptr) {
-    s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if (lane == 0) { red[wave] = s1; red[4 + wave] = s2; }
-    __syncthreads();
-    s1 = red[0] + red[1] + red[2] + red[3];
-    s2 = red[4] + red[5] + red[6] + red[7];
-  } else { s1 = a.std_sums[0]; s2 = a.std_sums[1]; }
-  if (tid == 0) {
-    const float m1 = s1 * a.inv_Bg, m2 = s2 * a.inv_Bg;
-    float ms1, ms2;
-    if (!a.st->ms_init) { ms1 = m1; ms2 = m2; }
-    else {
-      const float c1 = a.one_minus_tau_b;  // Python double (1 - tau_b) cast to fp32 by the tensor multiply
-      ms1 = c1 * a.st->ms1 + a.tau_b * m1;
-      ms2 = c1 * a.st->ms2 + a.tau_b * m2;
-    }
-    sh_ms[0] = ms1; sh_ms[1] = ms2;
-    if (blockIdx.x == 0) { a.grads_tail[0] = ms1; a.grads_tail[1] = ms2; }
-  }
-  __syncthreads();  // also publishes dyn[] of phase 2
-  const float ms1 = sh_ms[0], ms2 = sh_ms[1];
   const float alpha = a.auto_alpha ? expf(la) : a.alpha_fixed;
-  TL_STAMP();  // 2: mean_std done
-  // ---- phase 3 ----
-  float acc[kLossPart];
-#pragma unroll
-  for (int k = 0; k < kLossPart; ++k) acc[k] = 0.f;
-  acc[10] = INFINITY; acc[11] = INFINITY;
-  if (mine) {
-    const int r = my_r;
-    float* o = dyn + (r - r_begin) * 16;
-    const float q1 = in_q1, raw1 = in_raw1, q2 = in_q2, raw2 = in_raw2;
-    const float std1 = softplus(raw1), std2 = softplus(raw2);
-    const float q1n = o[0], std1n = softplus(o[1]);
-    const float q2n = o[2], std2n = softplus(o[3]);
-    const float qn = fminf(q1n, q2n);
-    const float z5 = clampf(in_z5, -3.f, 3.f), z6 = clampf(in_z6, -3.f, 3.f);
-    const float qs = (q1n < q2n) ? (q1n + z5 * std1n) : (q2n + z6 * std2n);
-    const float rew = in_rew, nd = 1.0f - in_done;
-    const float lp2 = in_lp2;
-    const float tq = rew + nd * a.gamma * (qn - alpha * lp2);
-    const float tqs = rew + nd * a.gamma * (qs - alpha * lp2);
-    const CriticTerm c1 = critic_term(q1, std1, ms1, tq, tqs);
-    const CriticTerm c2 = critic_term(q2, std2, ms2, tq, tqs);
-    float dv[8];
-    dv[0] = c1.dq * a.inv_B;
-    dv[1] = c1.dstd * a.inv_B * softplus_grad(raw1);
-    dv[2] = c2.dq * a.inv_B;
-    dv[3] = c2.dstd * a.inv_B * softplus_grad(raw2);
-    // actor: mean(alpha*logp_new - min(q1p, q2p)); torch.min ties split the gradient evenly
-    const float q1p = o[4], q2p = o[6];
-    const float lpn = in_lpn;
-    const float w1 = q1p < q2p ? 1.0f : (q1p > q2p ? 0.0f : 0.5f);
-    dv[4] = -w1 * a.inv_B; dv[5] = 0.0f;
-    dv[6] = -(1.0f - w1) * a.inv_B; dv[7] = 0.0f;
+  TL_STAMP();  // 2: reductions done
+  // ---------------- 3: per-sample math (uniform across the wave) ----------------
+  const float q1n = o[0][0], std1n = softplus(o[0][1]);
+  const float q2n = o[1][0], std2n = softplus(o[1][1]);
+  const float qn = fminf(q1n, q2n);
+  const float z5 = clampf(in_z5, -3.f, 3.f), z6 = clampf(in_z6, -3.f, 3.f);
+  const float qs = (q1n < q2n) ? (q1n + z5 * std1n) : (q2n + z6 * std2n);
+  const float nd = 1.0f - in_done;
+  const float tq = rew + nd * a.gamma * (qn - alpha * lp2);
+  const float tqs = rew + nd * a.gamma * (qs - alpha * lp2);
+  const CriticTerm c1 = critic_term(q1, std1, ms1, tq, tqs);
+  const CriticTerm c2 = critic_term(q2, std2, ms2, tq, tqs);
+  float dv[8];
+  dv[0] = c1.dq * a.inv_B;
+  dv[1] = c1.dstd * a.inv_B * sg1;
+  dv[2] = c2.dq * a.inv_B;
+  dv[3] = c2.dstd * a.inv_B * sg2;
+  // actor: mean(alpha*logp_new - min(q1p, q2p)); torch.min ties split the gradient evenly
+  const float q1p = o[2][0], q2p = o[3][0];
+  const float w1 = q1p < q2p ? 1.0f : (q1p > q2p ? 0.0f : 0.5f);
+  dv[4] = -w1 * a.inv_B; dv[5] = 0.0f;
+  dv[6] = -(1.0f - w1) * a.inv_B; dv[7] = 0.0f;
+  if (lane == 0) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       a.dout[c][2 * r] = dv[2 * c]; a.dout[c][2 * r + 1] = dv[2 * c + 1];
-      o[8 + 2 * c] = dv[2 * c]; o[8 + 2 * c + 1] = dv[2 * c + 1];
+      float* dbg = c < 2 ? a.qout_t[c] : a.qout_p[c - 2];
+      dbg[2 * r] = o[c][0]; dbg[2 * r + 1] = o[c][1];
     }
-    acc[0] += c1.loss; acc[1] += c2.loss;
-    acc[2] += q1; acc[3] += q2; acc[4] += std1; acc[5] += std2;
-    acc[6] += alpha * lpn - fminf(q1p, q2p);
-    acc[7] += lpn;
-    acc[10] = fminf(acc[10], std1); acc[11] = fminf(acc[11], std2);
+    float* pl = a.part_loss + (size_t)r * kLossPart;
+    pl[0] = c1.loss; pl[1] = c2.loss; pl[2] = q1; pl[3] = q2; pl[4] = std1; pl[5] = std2;
+    pl[6] = alpha * lpn - fminf(q1p, q2p);
+    pl[7] = lpn;
+    pl[8] = r == 0 ? alpha : 0.0f;  // tb_info reports the alpha the losses used
+    pl[9] = 0.0f; pl[10] = std1; pl[11] = std2;
+    if (r == 0) { a.grads_tail[0] = ms1; a.grads_tail[1] = ms2; }
   }
+  TL_STAMP();  // 3: per-sample math done
+  // ---------------- 4: dZ of the last hidden layer ----------------
 #pragma unroll
-  for (int k = 0; k < kLossPart; ++k) {
-    const float v = k < 10 ? wave_sum(acc[k]) : wave_min(acc[k]);
-    if (lane == 0) red[wave * kLossPart + k] = v;
-  }
-  __syncthreads();
-  if (tid < kLossPart) {
-    const float v0 = red[tid], v1 = red[kLossPart + tid], v2 = red[2 * kLossPart + tid], v3 = red[3 * kLossPart + tid];
-    float pv = tid < 10 ? (v0 + v1) + (v2 + v3) : fminf(fminf(v0, v1), fminf(v2, v3));
-    if (tid == 8) pv = blockIdx.x == 0 ? alpha : 0.0f;  // tb_info reports the alpha the losses used
-    a.part_loss[blockIdx.x * kLossPart + tid] = pv;
-  }
-  TL_STAMP();  // 3: per-sample math + partial sums done
-  // ---- phase 4 ---- (dL/d(out) of my rows is staged in LDS)
-  const int W4 = (a.W + 3) >> 2;
-  const int per_chain = (r_end - r_begin) * W4;
-#pragma unroll 4
-  for (int e = tid; e < 4 * per_chain; e += kThreads) {
-    const int c = e / per_chain;
-    const int rem = e - c * per_chain;
-    const int r = r_begin + rem / W4, k = (rem % W4) * 4;
-    const float d0 = dyn[(r - r_begin) * 16 + 8 + 2 * c], d1 = dyn[(r - r_begin) * 16 + 9 + 2 * c];
-    const float* w0 = a.Wq[c & 1] + k;
-    const float* w1 = a.Wq[c & 1] + a.W + k;
-    const float* gp = a.Gl[c] + (size_t)r * a.W + k;
-    float* dz = a.dZl[c] + (size_t)r * a.W + k;
-    const f32x4 wv0 = *(const f32x4u*)w0, wv1 = *(const f32x4u*)w1, gv = *(const f32x4u*)gp;  // <= 12 B over-read
-    f32x4 o;
+  for (int c = 0; c < 4; ++c) {
+    const float d0 = dv[2 * c], d1 = dv[2 * c + 1];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = (d0 * wv0[q] + d1 * wv1[q]) * gv[q];
-    if (k + 3 < a.W) *(f32x4u*)dz = o;
-    else for (int q = 0; q < 4 && k + q < a.W; ++q) dz[q] = o[q];
+    for (int q = 0; q < NCH; ++q) {
+      const int k = q * 256 + lane * 4;
+      if (k < a.W) {
+        // chains q1c/q1p differentiate through q1's output layer (weights of chain 2), q2c/q2p through q2's (3)
+        const f32x4 w0 = wv[2 + (c & 1)][0][q], w1v = wv[2 + (c & 1)][1][q];
+        f32x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[e] = (d0 * w0[e] + d1 * w1v[e]) * gv[c][q][e];
+        float* dz = a.dZl[c] + (size_t)r * a.W + k;
+        if (k + 3 < a.W) *(f32x4u*)dz = ov;
+        else for (int e = 0; e < 4 && k + e < a.W; ++e) dz[e] = ov[e];
+      }
+    }
   }
   TL_STAMP();  // 4: dZ written
   TL_FLUSH(a.timeline, (int)blockIdx.x);
@@ -916,7 +937,8 @@ __global__ void __launch_bounds__(kThreads) k_loss(LossArgs a) {
 //   d loss_alpha / d log_alpha = -mean(logp_new + target_entropy)
 // ---------------------------------------------------------------------------------------------
 struct HeadsBwdArgs {
-  const float* dA[2];      // [B x A] dL/d new_act through q1 / q2 (tile stage bwdA: dZ1 . W1[:, O:O+A])
+  const float* dA[2];      // [B x ldA] dL/d new_act through q1 / q2 (tile stage bwdA: dZ1 . W1[:, O:O+A])
+  int ldA;
   const float* logits_pi;  // [B x 2A]
   const float* eps_new;
   const float* log_alpha;
@@ -953,7 +975,7 @@ __global__ void __launch_bounds__(kThreads) k_heads_bwd(HeadsBwdArgs a) {
     raw = a.logits_pi[(size_t)r * 2 * A + A + lane];
     eps = a.eps_new[(size_t)r * A + lane];
     scale = a.act_scale[lane];
-    dA = a.dA[0][(size_t)r * A + lane] + a.dA[1][(size_t)r * A + lane];
+    dA = a.dA[0][(size_t)r * a.ldA + lane] + a.dA[1][(size_t)r * a.ldA + lane];
   }
   // prefetch this lane's GELU' values of the row (used at the very end)
   f32x4 gv[NCH];
@@ -1019,53 +1041,71 @@ struct AdamArgs {
   int commit_ms;       // 1: take mean_std from g[n_total..n_total+1]
 };
 
+__device__ __forceinline__ void adam_classify(const AdamArgs& a, const DevState& st, long long base, bool delayed,
+                                              bool (&upd)[4], float (&ss)[4], float (&bc2)[4], bool& any) {
+  any = false;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const long long i = base + e;
+    if (i < a.n_q2) { upd[e] = true; ss[e] = st.ss_q; bc2[e] = st.bc2_q; }
+    else if (i < a.n_online3) { upd[e] = delayed; ss[e] = st.ss_pi; bc2[e] = st.bc2_pi; }
+    else { upd[e] = delayed && a.auto_alpha && i < a.n_total; ss[e] = st.ss_alpha; bc2[e] = st.bc2_alpha; }
+    any = any || upd[e];
+  }
+}
+
 __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
   const DevState st = *a.st;
-  const long long stride = (long long)gridDim.x * kThreads;
   const long long n4 = (a.n_total + 3) >> 2;
   const bool delayed = st.do_delayed != 0;
-  for (long long i4 = (long long)blockIdx.x * kThreads + threadIdx.x; i4 < n4; i4 += stride) {
-    const long long base = i4 << 2;
-    // elements [base, base+4) may straddle the q | policy | log_alpha boundaries: classify each
-    bool upd[4]; float ss[4], bc2[4];
-    bool any = false;
+  // each thread owns two float4 groups (i4 and i4 + half): all their loads are issued before any math
+  const long long half = (n4 + 1) >> 1;
+  const long long i0 = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (i0 < half) {
+    long long base[2] = {i0 << 2, (i0 + half) << 2};
+    bool upd[2][4], any[2], vec[2], tvec[2];
+    float ss[2][4], bc2[2][4];
+    f32x4 p[2], m[2], v[2], g[2], t[2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const long long i = base + e;
-      if (i < a.n_q2) { upd[e] = true; ss[e] = st.ss_q; bc2[e] = st.bc2_q; }
-      else if (i < a.n_online3) { upd[e] = delayed; ss[e] = st.ss_pi; bc2[e] = st.bc2_pi; }
-      else { upd[e] = delayed && a.auto_alpha && i < a.n_total; ss[e] = st.ss_alpha; bc2[e] = st.bc2_alpha; }
-      any = any || upd[e];
-    }
-    if (!any) continue;  // policy / alpha segments on the off iterations of the delayed update
-    if (base + 3 < a.n_total) {
-      f32x4 p = *(const f32x4*)(a.p + base), m = *(const f32x4*)(a.m + base), v = *(const f32x4*)(a.v + base);
-      const f32x4 g = *(const f32x4*)(a.g + base);
-      const bool tvec = delayed && base + 3 < a.n_online3;
-      f32x4 t = {0.f, 0.f, 0.f, 0.f};
-      if (tvec) t = *(const f32x4*)(a.tgt + base);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (upd[e]) {
-          float pe = p[e], me = m[e], ve = v[e];
-          adam_update(pe, me, ve, g[e], a.b1w, a.beta2, a.b2w, ss[e], bc2[e], a.eps);
-          p[e] = pe; m[e] = me; v[e] = ve;
-        }
-        if (tvec) t[e] = polyak_update(t[e], p[e], a.polyak, a.one_minus_polyak);
-        else if (delayed && base + e < a.n_online3) a.tgt[base + e] = polyak_update(a.tgt[base + e], p[e], a.polyak, a.one_minus_polyak);
+    for (int u = 0; u < 2; ++u) {
+      const bool exists = (base[u] >> 2) < n4 && (u == 0 || i0 + half < n4);
+      if (exists) adam_classify(a, st, base[u], delayed, upd[u], ss[u], bc2[u], any[u]); else any[u] = false;
+      vec[u] = any[u] && base[u] + 3 < a.n_total;
+      tvec[u] = vec[u] && delayed && base[u] + 3 < a.n_online3;
+      if (vec[u]) {
+        p[u] = *(const f32x4*)(a.p + base[u]); m[u] = *(const f32x4*)(a.m + base[u]);
+        v[u] = *(const f32x4*)(a.v + base[u]); g[u] = *(const f32x4*)(a.g + base[u]);
+        if (tvec[u]) t[u] = *(const f32x4*)(a.tgt + base[u]);
       }
-      *(f32x4*)(a.p + base) = p; *(f32x4*)(a.m + base) = m; *(f32x4*)(a.v + base) = v;
-      if (tvec) *(f32x4*)(a.tgt + base) = t;
-    } else {
-      for (int e = 0; e < 4 && base + e < a.n_total; ++e) {
-        const long long i = base + e;
-        float p = a.p[i];
-        if (upd[e]) {
-          float m = a.m[i], v = a.v[i];
-          adam_update(p, m, v, a.g[i], a.b1w, a.beta2, a.b2w, ss[e], bc2[e], a.eps);
-          a.p[i] = p; a.m[i] = m; a.v[i] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!any[u]) continue;  // policy / alpha segments on the off iterations of the delayed update
+      if (vec[u]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (upd[u][e]) {
+            float pe = p[u][e], me = m[u][e], ve = v[u][e];
+            adam_update(pe, me, ve, g[u][e], a.b1w, a.beta2, a.b2w, ss[u][e], bc2[u][e], a.eps);
+            p[u][e] = pe; m[u][e] = me; v[u][e] = ve;
+          }
+          if (tvec[u]) t[u][e] = polyak_update(t[u][e], p[u][e], a.polyak, a.one_minus_polyak);
+          else if (delayed && base[u] + e < a.n_online3)
+            a.tgt[base[u] + e] = polyak_update(a.tgt[base[u] + e], p[u][e], a.polyak, a.one_minus_polyak);
         }
-        if (delayed && i < a.n_online3) a.tgt[i] = polyak_update(a.tgt[i], p, a.polyak, a.one_minus_polyak);
+        *(f32x4*)(a.p + base[u]) = p[u]; *(f32x4*)(a.m + base[u]) = m[u]; *(f32x4*)(a.v + base[u]) = v[u];
+        if (tvec[u]) *(f32x4*)(a.tgt + base[u]) = t[u];
+      } else {
+        for (int e = 0; e < 4 && base[u] + e < a.n_total; ++e) {
+          const long long i = base[u] + e;
+          float pe = a.p[i];
+          if (upd[u][e]) {
+            float me = a.m[i], ve = a.v[i];
+            adam_update(pe, me, ve, a.g[i], a.b1w, a.beta2, a.b2w, ss[u][e], bc2[u][e], a.eps);
+            a.p[i] = pe; a.m[i] = me; a.v[i] = ve;
+          }
+          if (delayed && i < a.n_online3) a.tgt[i] = polyak_update(a.tgt[i], pe, a.polyak, a.one_minus_polyak);
+        }
       }
     }
   }
@@ -1113,14 +1153,14 @@ __global__ void k_stats(StatsArgs a) {
 }
 
 // strict data-parallel mode: local {sum std1, sum std2} for the pre-loss all-reduce
-struct StdSumArgs { const float* qout_c[2]; int B; float* out; };
+struct StdSumArgs { const float* qstd_c[2]; int B; float* out; };
 __global__ void __launch_bounds__(kThreads) k_std_sums(StdSumArgs a) {
   __shared__ float red[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float s1 = 0.f, s2 = 0.f;
   for (int r = tid; r < a.B; r += kThreads) {
-    s1 += softplus(a.qout_c[0][2 * r + 1]);
-    s2 += softplus(a.qout_c[1][2 * r + 1]);
+    s1 += a.qstd_c[0][2 * r];
+    s2 += a.qstd_c[1][2 * r];
   }
   s1 = wave_sum(s1); s2 = wave_sum(s2);
   if (lane == 0) { red[wave] = s1; red[4 + wave] = s2; }

@@ -24,9 +24,13 @@ for it in range(6):
 e.sync()
 raw = e.debug_read("timeline").view(np.int64).reshape(512, 8)
 raw = raw[raw[:,0] != 0]
+wall = raw[:,7]-raw[:,6]
+raw = raw.copy(); raw[:,6:] = 0
 ns = int((raw[0] != 0).sum())
 dur = raw[:,ns-1]-raw[:,0]
 print("stage %s: %d blocks, %d stamps; per-block duration min %d median %d max %d cycles" % (os.environ["STAGE"], len(raw), ns, dur.min(), np.median(dur), dur.max()))
+d0 = (raw[:,ns-1]-raw[:,0]).astype(float); w = wall.astype(float)
+print("   wall-clock (100 MHz) ticks per block: median %d -> %.2f us ; shader clock ~ %.2f GHz ; kernel span (first start -> last end) %.2f us" % (np.median(w), np.median(w)/100.0, np.median(d0)/np.median(w)*0.1, (e.debug_read("timeline").view(np.int64).reshape(512,8)[:len(raw),7].max() - e.debug_read("timeline").view(np.int64).reshape(512,8)[:len(raw),6].min())/100.0))
 for k in range(1, ns):
     seg = raw[:,k]-raw[:,k-1]; print("   seg %d: min %6d median %6d  max %6d" % (k, seg.min(), np.median(seg), seg.max()))
 PY
