@@ -36,6 +36,30 @@ def create_buffer(**kwargs):
     return getattr(module, cls)(**kwargs)
 
 
+def create_env(**kwargs):
+    """reference utils/initialization.py:9-45: module `<env_id>_data` exposing `env_creator(**kwargs)`
+    (or the CamelCase class); the environment itself is outside this repository's scope."""
+    name = kwargs["env_id"]
+    module = importlib.import_module(name + "_data")
+    if hasattr(module, "env_creator"):
+        return module.env_creator(**kwargs)
+    if hasattr(module, camel(name)):
+        return getattr(module, camel(name))(**kwargs)
+    raise NotImplementedError("environment %s is not properly defined" % name)
+
+
+def create_sampler(**kwargs):
+    from training.hip_sampler import HipOffSampler
+
+    return HipOffSampler(**kwargs)
+
+
+def create_evaluator(**kwargs):
+    from training.hip_trainer import HipEvaluator
+
+    return HipEvaluator(**kwargs)
+
+
 def create_trainer(alg, sampler, buffer, evaluator, **kwargs):
     from training.hip_trainer import HipOffSerialTrainer
 

@@ -1,0 +1,83 @@
+"""HipOffSampler -- env-stepping actor with the reference's OffSampler semantics
+(reference training/off_sampler.py:12-101), acting with the LIVE learner weights.
+
+The reference moves the whole module to the CPU around every sampling call
+(ModuleOnDevice, utils/common_utils.py:164-177; training/trainer.py:63-66). Here the parameters never
+leave HBM: `networks.policy(obs)` of an attached ApproxContainer runs the fused-MLP HIP forward
+(dsact_policy_forward) on the batch-1 observation and returns the logits on the host, where the
+tanh-Gaussian draw consumes the torch global generator exactly like TanhGaussDistribution.sample().
+
+Environment protocol (gym 0.23 style, what the reference's wrappers provide): `reset() -> (obs, info)`
+or `obs`; `step(a) -> (obs, r, done, info)` with `info["TimeLimit.truncated"]` on time-outs;
+`action_space.low/high`.
+"""
+import time
+
+import numpy as np
+import torch
+
+__all__ = ["HipOffSampler", "create_sampler"]
+
+SAMPLER_TIME_KEY = "Time/Sampler time [ms]-RL iter"  # reference utils/tensorboard_setup.py:150
+
+
+def _reset(env):
+    out = env.reset()
+    if isinstance(out, tuple) and len(out) == 2 and isinstance(out[1], dict):
+        return out
+    return out, {}
+
+
+class HipOffSampler:
+    def __init__(self, index=0, **kwargs):
+        from plugin import create_env
+
+        self.env = kwargs.get("env") or create_env(**kwargs)
+        if kwargs.get("seed") is not None and hasattr(self.env, "seed"):
+            self.env.seed(kwargs["seed"])  # reference set_seed(..., env) seeds with the plain seed
+        self.obs, self.info = _reset(self.env)
+        self.networks = kwargs.get("networks")  # the trainer assigns alg.networks (trainer.py:24-26)
+        self.noise_params = kwargs.get("noise_params")
+        if self.noise_params is not None:
+            raise NotImplementedError("exploration noise is not part of the DSAC-T path (default None)")
+        self.sample_batch_size = kwargs["batch_size_per_sampler"] if "batch_size_per_sampler" in kwargs \
+            else kwargs["sample_batch_size"]
+        self.action_type = kwargs.get("action_type", "continu")
+        self.reward_scale = kwargs.get("reward_scale", 1)
+        self.total_sample_number = 0
+
+    def load_state_dict(self, state_dict):
+        self.networks.load_state_dict(state_dict)
+
+    def sample(self):
+        self.total_sample_number += self.sample_batch_size
+        t0 = time.perf_counter()
+        batch = []
+        for _ in range(self.sample_batch_size):
+            obs_t = torch.from_numpy(np.expand_dims(self.obs, axis=0).astype("float32"))
+            with torch.no_grad():
+                logits = self.networks.policy(obs_t)
+                dist = self.networks.create_action_distributions(logits)
+                action, logp = dist.sample()
+            action = action.detach()[0].cpu().numpy()
+            logp = logp.detach()[0].cpu().numpy()
+            action = np.array(action)
+            clipped = action.clip(self.env.action_space.low, self.env.action_space.high)
+            next_obs, reward, done, next_info = self.env.step(clipped)
+            truncated = bool(next_info.get("TimeLimit.truncated", False))
+            next_info["TimeLimit.truncated"] = truncated
+            if truncated:
+                done = False  # time-outs are stored as non-terminal (off_sampler.py:70-73)
+            batch.append((self.obs.copy(), self.info, action, self.reward_scale * reward, next_obs.copy(), done,
+                          logp, next_info))
+            self.obs, self.info = next_obs, next_info
+            if done or truncated:
+                self.obs, self.info = _reset(self.env)
+        return batch, {SAMPLER_TIME_KEY: (time.perf_counter() - t0) * 1000}
+
+    def get_total_sample_number(self):
+        return self.total_sample_number
+
+
+def create_sampler(**kwargs):
+    return HipOffSampler(**kwargs)

@@ -1,0 +1,159 @@
+"""HipOffSerialTrainer -- the reference's serial off-policy loop (training/trainer.py:15-158) without
+the per-iteration device ping-pong and without per-step host syncs.
+
+    step():  sampler.sample() -> buffer.add_batch()           every sample_interval iterations
+             buffer.sample_batch(B) -> alg.local_update()     minibatch stays in HBM (HipBatch token)
+             log (reads the lazily materialised tb_info)      every log_save_interval
+             evaluator.run_evaluation()                       every eval_interval
+             torch.save(networks.state_dict())                every apprfunc_save_interval
+
+tensorboard is optional (not installed in every image): scalars always go to <save_folder>/scalars.jsonl,
+and to a SummaryWriter too when one can be imported.
+"""
+import json
+import os
+import time
+
+import torch
+
+__all__ = ["HipOffSerialTrainer", "HipEvaluator", "create_trainer", "create_evaluator"]
+
+TB = {  # reference utils/tensorboard_setup.py:142-153
+    "tar_iter": "Evaluation/1. TAR-RL iter", "tar_time": "Evaluation/2. TAR-Total time [s]",
+    "tar_samples": "Evaluation/3. TAR-Collected samples", "tar_replay": "Evaluation/4. TAR-Replay samples",
+    "ram": "RAM/RAM [MB]-RL iter",
+}
+
+
+class _Scalars:
+    def __init__(self, folder):
+        self.f = open(os.path.join(folder, "scalars.jsonl"), "a") if folder else None
+        self.tb = None
+        try:
+            from torch.utils.tensorboard import SummaryWriter  # needs the tensorboard package
+            self.tb = SummaryWriter(log_dir=folder, flush_secs=20) if folder else None
+        except Exception:
+            self.tb = None
+
+    def add(self, tag, value, step):
+        v = float(value)
+        if self.f:
+            self.f.write(json.dumps({"tag": tag, "step": int(step), "value": v}) + "\n")
+        if self.tb is not None:
+            self.tb.add_scalar(tag, v, step)
+
+    def add_dict(self, d, step):
+        for k, v in d.items():
+            self.add(k, v, step)
+
+    def flush(self):
+        if self.f:
+            self.f.flush()
+        if self.tb is not None:
+            self.tb.flush()
+
+
+class HipEvaluator:
+    """Deterministic-mode rollouts (reference training/evaluator.py:34-84): mean episode return of
+    `num_eval_episode` episodes acting with dist.mode()."""
+
+    def __init__(self, index=0, **kwargs):
+        from plugin import create_env
+
+        self.env = kwargs.get("eval_env") or kwargs.get("env") or create_env(**kwargs)
+        self.networks = kwargs.get("networks")
+        self.num_eval_episode = kwargs.get("num_eval_episode", 5)
+
+    def run_an_episode(self):
+        out = self.env.reset()
+        obs = out[0] if isinstance(out, tuple) else out
+        total, done = 0.0, False
+        while not done:
+            with torch.no_grad():
+                logits = self.networks.policy(torch.from_numpy(obs.astype("float32")[None]))
+                act = self.networks.create_action_distributions(logits).mode()[0].cpu().numpy()
+            obs, r, done, info = self.env.step(act)
+            total += float(r)
+            done = bool(done) or bool(info.get("TimeLimit.truncated", False))
+        return total
+
+    def run_evaluation(self, iteration):
+        return sum(self.run_an_episode() for _ in range(self.num_eval_episode)) / self.num_eval_episode
+
+
+class HipOffSerialTrainer:
+    def __init__(self, alg, sampler, buffer, evaluator, **kwargs):
+        self.alg, self.sampler, self.buffer, self.evaluator = alg, sampler, buffer, evaluator
+        self.networks = alg.networks
+        if sampler is not None:
+            sampler.networks = self.networks  # act with the live learner weights (trainer.py:24-26)
+        if evaluator is not None:
+            evaluator.networks = self.networks
+        if kwargs.get("ini_network_dir") is not None:
+            self.networks.load_state_dict(torch.load(kwargs["ini_network_dir"]))
+        self.replay_batch_size = kwargs["replay_batch_size"]
+        self.max_iteration = kwargs["max_iteration"]
+        self.sample_interval = kwargs.get("sample_interval", 1)
+        self.log_save_interval = kwargs["log_save_interval"]
+        self.apprfunc_save_interval = kwargs["apprfunc_save_interval"]
+        self.eval_interval = kwargs["eval_interval"]
+        self.save_folder = kwargs.get("save_folder")
+        self.best_tar = -float("inf")
+        self.iteration = 0
+        self.last_tar = None
+        if self.save_folder:
+            os.makedirs(os.path.join(self.save_folder, "apprfunc"), exist_ok=True)
+        self.writer = _Scalars(self.save_folder)
+        while sampler is not None and self.buffer.size < kwargs["buffer_warm_size"]:  # trainer.py:50-52
+            samples, _ = sampler.sample()
+            self.buffer.add_batch(samples)
+        self.start_time = time.time()
+
+    def step(self):
+        sampler_tb = {}
+        if self.sampler is not None and self.iteration % self.sample_interval == 0:
+            samples, sampler_tb = self.sampler.sample()
+            self.buffer.add_batch(samples)
+        batch = self.buffer.sample_batch(self.replay_batch_size)
+        alg_tb = self.alg.local_update(batch, self.iteration)
+        if self.iteration % self.log_save_interval == 0:
+            self.writer.add_dict(dict(alg_tb.items()), self.iteration)  # the only host sync of the update
+            self.writer.add_dict(sampler_tb, self.iteration)
+        if self.evaluator is not None and self.iteration % self.eval_interval == 0:
+            tar = self.evaluator.run_evaluation(self.iteration)
+            self.last_tar = tar
+            if tar >= self.best_tar and self.iteration >= self.max_iteration / 5 and self.save_folder:
+                self.best_tar = tar
+                d = os.path.join(self.save_folder, "apprfunc")
+                for fn in os.listdir(d):
+                    if fn.endswith("_opt.pkl"):
+                        os.remove(os.path.join(d, fn))
+                torch.save(self.networks.state_dict(), os.path.join(d, "apprfunc_{}_opt.pkl".format(self.iteration)))
+            self.writer.add(TB["ram"], self.buffer.__get_RAM__(), self.iteration)
+            self.writer.add(TB["tar_iter"], tar, self.iteration)
+            self.writer.add(TB["tar_replay"], tar, self.iteration * self.replay_batch_size)
+            self.writer.add(TB["tar_time"], tar, int(time.time() - self.start_time))
+            if self.sampler is not None:
+                self.writer.add(TB["tar_samples"], tar, self.sampler.get_total_sample_number())
+        if self.save_folder and self.iteration % self.apprfunc_save_interval == 0:
+            self.save_apprfunc()
+
+    def train(self):
+        while self.iteration < self.max_iteration:
+            self.step()
+            self.iteration += 1
+        if self.save_folder:
+            self.save_apprfunc()
+        self.writer.flush()
+
+    def save_apprfunc(self):
+        torch.save(self.networks.state_dict(),
+                   os.path.join(self.save_folder, "apprfunc", "apprfunc_{}.pkl".format(self.iteration)))
+
+
+def create_trainer(alg, sampler, buffer, evaluator, **kwargs):
+    return HipOffSerialTrainer(alg, sampler, buffer, evaluator, **kwargs)
+
+
+def create_evaluator(**kwargs):
+    return HipEvaluator(**kwargs)
