@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 def test_pendulum_end_to_end_learns(tmp_path):
     import plugin
     kw = hip_kwargs(3, 1, (256, 256, 256), 256, act_limit=2.0, env_id="synth_pendulum", sample_batch_size=20,
-                    reward_scale=1, buffer_warm_size=1000, buffer_max_size=100000, max_iteration=4001,
-                    log_save_interval=500, apprfunc_save_interval=2000, eval_interval=1000, num_eval_episode=5,
+                    reward_scale=1, buffer_warm_size=1000, buffer_max_size=100000, max_iteration=9001,
+                    log_save_interval=500, apprfunc_save_interval=4500, eval_interval=1500, num_eval_episode=5,
                     ini_network_dir=None, save_folder=str(tmp_path), seed=12345, sample_interval=1)
     torch.manual_seed(kw["seed"]); np.random.seed(kw["seed"])
     alg = plugin.create_alg(**kw)
@@ -30,11 +30,12 @@ def test_pendulum_end_to_end_learns(tmp_path):
     orig = ev.run_evaluation
     ev.run_evaluation = lambda it: tars.append(orig(it)) or tars[-1]
     tr.train()
-    print("eval TAR per 1000 iterations:", [round(t, 1) for t in tars])
-    assert len(tars) == 5 and all(np.isfinite(tars))
-    assert max(tars[2:]) > tars[0] + 300, tars          # the shipped reference run: -1476 -> -1104 @4k
+    print("eval TAR per 1500 iterations:", [round(t, 1) for t in tars])
+    assert len(tars) == 7 and all(np.isfinite(tars))
+    # the shipped reference run (results/DSAC_V2_gym_pendulum): -1476 @0, -1104 @4k, -264 @6k, -122 @8k
+    assert max(tars[3:]) > -900 and max(tars[3:]) > tars[0] + 300, tars
     st = alg.engine.read_stats()
     assert all(np.isfinite(v) for v in st.values())
     assert 0.05 < st["DSAC2/alpha-RL iter"] < 2.8       # alpha adapts downwards from e
-    assert os.path.exists(tmp_path / "apprfunc" / "apprfunc_4000.pkl")
-    assert alg.engine.get_state()["adam_steps"] == [4001, 2001, 2001]
+    assert os.path.exists(tmp_path / "apprfunc" / "apprfunc_9000.pkl")
+    assert alg.engine.get_state()["adam_steps"] == [9001, 4501, 4501]
