@@ -165,6 +165,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true")
     ap.add_argument("--replay-rows", type=int, default=N_REPLAY)
+    ap.add_argument("--batch", type=int, default=B, help="minibatch rows per GPU (BASELINE metric: 256)")
     args = ap.parse_args()
     steps = args.steps + (args.steps & 1)
     warmup = args.warmup + (args.warmup & 1)
@@ -186,7 +187,7 @@ def main():
         if rank != 0:
             entry.build()
     hidden = [int(x) for x in args.hidden.split(",")]
-    alg = make_alg(hidden, local, seed=0)
+    alg = make_alg(hidden, local, seed=0, batch=args.batch)
     e = alg.engine
     fill_replay(e, args.replay_rows, seed=100 + rank)  # every rank owns its own replay shard
     upload_indices(e, args.replay_rows, IDX_ROWS, seed=1 + rank)
@@ -207,18 +208,19 @@ def main():
     updates_per_s = steps / wall
     value = updates_per_s * world  # batch-256 gradient-step equivalents per second over the whole job
     lay = e.layout
-    flop = lay.flop_per_step(B)
-    byts = lay.bytes_per_step(B, 2)
+    Bb = args.batch
+    flop = lay.flop_per_step(Bb)
+    byts = lay.bytes_per_step(Bb, 2)
     out = {
-        "metric": "DSAC-T gradient steps/sec, batch=256 Humanoid (obs376/act17)",
+        "metric": "DSAC-T gradient steps/sec, batch=%d Humanoid (obs376/act17)" % args.batch,
         "value": value, "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": 1000.0 * wall / steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": "gym_humanoid-shaped DSAC_V2 update: obs 376, act 17, MLP %s GELU, batch 256 per GPU, "
+            "workload": "gym_humanoid-shaped DSAC_V2 update: obs 376, act 17, MLP %s GELU, batch %d per GPU, "
                         "%d-row replay ring in HBM per GPU, gather+forward+backward+Adam+Polyak every step"
-                        % ("x".join(map(str, hidden)), args.replay_rows),
-            "global_batch": B * world, "parallelism": "dp%d" % world, "hidden": hidden,
+                        % ("x".join(map(str, hidden)), args.batch, args.replay_rows),
+            "global_batch": args.batch * world, "parallelism": "dp%d" % world, "hidden": hidden,
             "noise": "device Philox4x32-10", "launch": "hipGraph (2 steps/graph)" if world == 1 else "eager + RCCL all-reduce",
             "unit_note": "value = synchronized updates/s x n_gpus (each rank contributes one batch-256 gradient per update)",
         },
@@ -247,7 +249,7 @@ def main():
             out["dominant_kernel"] = {"name": dom[0], "us": round(dom[1] * 1000, 2)}
         except Exception as ex:  # profiling is informational
             out["kernels_error"] = str(ex)
-    if world == 1 and not args.no_alt:
+    if world == 1 and not args.no_alt and args.batch == B:
         alt_hidden = [256, 256] if hidden != [256, 256] else [256, 256, 256]
         del alg
         alg2 = make_alg(alt_hidden, local, seed=0)
@@ -258,7 +260,7 @@ def main():
         out["alt"] = {"hidden": alt_hidden, "value": steps / w2, "unit": "steps/s",
                       "frac_fp32": l2.flop_per_step(B) * steps / w2 / 1e12 / FP32_PEAK_TFLOPS,
                       "frac_hbm": l2.bytes_per_step(B, 2) * steps / w2 / 1e9 / HBM_PEAK_GBS}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.batch == B:
         out["cpu_baseline"] = cpu_baseline(hidden)
     if rank == 0:
         print(json.dumps(out))
