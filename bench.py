@@ -124,13 +124,13 @@ def cpu_baseline(hidden, budget_s=12.0):
                       % (steps, "x".join(map(str, hidden)), dt, torch.__version__, threads, os.cpu_count())}
 
 
-def measure(alg, steps, warmup, world=1, dp=None):
+def measure(alg, steps, warmup, world=1, dp=None, flags=0):
     """returns (wall seconds for `steps` steps, hipEvent ms for the same region or None)"""
     import torch
 
     e = alg.engine
     if dp is None:
-        e.graph_build(2)
+        e.graph_build(2, flags)
         e.graph_run(0, warmup)
         e.sync()
         torch.cuda.synchronize()
@@ -164,6 +164,7 @@ def main():
                     help="reference default (example_train/*.py); BASELINE.json words it as 256,256 -> reported in `alt`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true")
+    ap.add_argument("--fast", action="store_true", help="primary number with DSACT_F_SKIP_ACTOR_ON_OFF_ITERS (default: strict; fast is reported in `fast`)")
     ap.add_argument("--replay-rows", type=int, default=N_REPLAY)
     ap.add_argument("--batch", type=int, default=B, help="minibatch rows per GPU (BASELINE metric: 256)")
     args = ap.parse_args()
@@ -196,7 +197,7 @@ def main():
 
         e.use_torch_stream()
         dp = DataParallelUpdater(e, broadcast_tensors=(e.online, e.target, e.adam_m, e.adam_v))
-    wall, ev_ms = measure(alg, steps, warmup, world, dp)
+    wall, ev_ms = measure(alg, steps, warmup, world, dp, flags=1 if args.fast else 0)
     if world > 1:
         import torch.distributed as dist
 
@@ -221,7 +222,8 @@ def main():
                         "%d-row replay ring in HBM per GPU, gather+forward+backward+Adam+Polyak every step"
                         % ("x".join(map(str, hidden)), args.batch, args.replay_rows),
             "global_batch": args.batch * world, "parallelism": "dp%d" % world, "hidden": hidden,
-            "noise": "device Philox4x32-10", "launch": "hipGraph (2 steps/graph)" if world == 1 else "eager + RCCL all-reduce",
+            "noise": "device Philox4x32-10", "mode": "fast (discarded actor backward skipped)" if args.fast else "strict (every gradient the reference computes)",
+            "launch": "hipGraph (2 steps/graph)" if world == 1 else "eager + RCCL all-reduce",
             "unit_note": "value = synchronized updates/s x n_gpus (each rank contributes one batch-256 gradient per update)",
         },
         "finite_stats": finite,
@@ -249,6 +251,13 @@ def main():
             out["dominant_kernel"] = {"name": dom[0], "us": round(dom[1] * 1000, 2)}
         except Exception as ex:  # profiling is informational
             out["kernels_error"] = str(ex)
+    if rank == 0 and world == 1 and not args.fast:
+        # same workload with the actor/alpha backward skipped on the off iterations of the delayed update: the
+        # reference computes and discards those gradients (dsac_v2.py:174-186 vs :324); bitwise-identical parameter
+        # trajectory (tests/test_hip_parity.py::test_skip_discarded_actor_backward_keeps_trajectory)
+        wf, _ = measure(alg, steps, warmup, flags=1)
+        out["fast"] = {"value": steps / wf, "unit": "steps/s", "ms_per_step": 1000.0 * wf / steps,
+                       "note": "DSACT_F_SKIP_ACTOR_ON_OFF_ITERS; not the headline value"}
     if world == 1 and not args.no_alt and args.batch == B:
         alt_hidden = [256, 256] if hidden != [256, 256] else [256, 256, 256]
         del alg

@@ -92,7 +92,7 @@ struct dsact_handle {
   GemmProb* d_tiles = nullptr;   // per-tile table of the weight/bias-gradient tiles: [q1 | q2 | policy]
   int n_dw_tiles = 0;
   int dw_off[4] = {0, 0, 0, 0};  // start of q1, q2, policy tiles, end
-  std::vector<Stage> fwd1, fwd2, bwdq, bwdpi, actf;
+  std::vector<Stage> fwd1, fwd2, bwdq, bwdq_critic, bwdpi, actf;
   Stage bwda;  // dA = dZ1(q_i(obs,new_act)) . W1_i[:, O:O+A]
   // replay ring
   long long cap = 0, ptr = 0, size = 0;
@@ -121,6 +121,8 @@ struct dsact_handle {
 };
 
 namespace {
+
+double dec7(float f);
 
 int fail(dsact_handle* h, int code, const char* fmt, ...) {
   if (h) {
@@ -341,11 +343,14 @@ int build_tasks(dsact_handle* h) {
     t.M = B; t.N = d.in[l]; t.K = d.out[l];
     return t;
   };
-  h->bwdq.clear(); h->bwdpi.clear();
+  h->bwdq.clear(); h->bwdq_critic.clear(); h->bwdpi.clear();
   for (int l = L - 1; l >= 1; --l) {
     Stage s = fresh("bwdQ_l" + std::to_string(l), 1);
     for (int ch : {C_Q1C, C_Q2C, C_Q1P, C_Q2P}) stage_add(s, bwd_prob(ch, l));
     h->bwdq.push_back(s);
+    Stage c = fresh("bwdQc_l" + std::to_string(l), 1);  // off iterations of the delayed update: critics only
+    for (int ch : {C_Q1C, C_Q2C}) stage_add(c, bwd_prob(ch, l));
+    h->bwdq_critic.push_back(c);
   }
   for (int l = L - 1; l >= 1; --l) {
     Stage s = fresh("bwdPi_l" + std::to_string(l), 1);
@@ -420,8 +425,25 @@ long long* tl_for(dsact_handle* h, const char* name) {
   return (want && !strcmp(want, name)) ? h->timeline : nullptr;
 }
 
+FusedOpt fused_opt(const dsact_handle* h, bool enable) {
+  FusedOpt f;
+  memset(&f, 0, sizeof(f));
+  f.st = enable ? h->st : nullptr;
+  f.online = h->online; f.target = h->target; f.adam_m = h->adam_m; f.adam_v = h->adam_v; f.grads = h->grads;
+  f.n_q2 = (long long)(2 * h->n_q); f.n_online3 = (long long)(2 * h->n_q + h->n_pi); f.n_total = (long long)h->n_online;
+  f.b1w = (float)(1.0 - dec7(h->cfg.adam_beta1));
+  f.beta2 = (float)dec7(h->cfg.adam_beta2);
+  f.b2w = (float)(1.0 - dec7(h->cfg.adam_beta2));
+  f.eps = h->cfg.adam_eps;
+  const double polyak = 1.0 - dec7(h->cfg.tau);
+  f.polyak = (float)polyak;
+  f.one_minus_polyak = (float)(1.0 - polyak);
+  f.auto_alpha = h->cfg.auto_alpha;
+  return f;
+}
+
 // runs a stage; tiles [x0, x1) of the weight-gradient table ride along in the same launch
-int run_stage(dsact_handle* h, const Stage& s0, int x0 = 0, int x1 = 0) {
+int run_stage(dsact_handle* h, const Stage& s0, int x0 = 0, int x1 = 0, bool fused = false) {
   if (s0.n_blocks == 0 && x1 <= x0) return DSACT_OK;
   Stage s = s0;
   const char* want = getenv("DSACT_TIMELINE_STAGE");
@@ -429,6 +451,7 @@ int run_stage(dsact_handle* h, const Stage& s0, int x0 = 0, int x1 = 0) {
   s.args.n_stage_blocks = s.n_blocks;
   s.args.extra = h->d_tiles + x0;
   s.args.n_extra = x1 > x0 ? x1 - x0 : 0;
+  s.args.fo = fused_opt(h, fused);
   const int grid = s.n_blocks + s.args.n_extra;
   size_t lds = tile_lds_bytes(s.max_k);
   if (s.args.n_extra && tile_lds_bytes(h->B) > lds) lds = tile_lds_bytes(h->B);
@@ -439,9 +462,15 @@ int run_stage(dsact_handle* h, const Stage& s0, int x0 = 0, int x1 = 0) {
   return launch(h, s.name.c_str(), k_stage<false, true, EPI_MULG>, dim3(grid), dim3(kThreads), lds, s.args);
 }
 
-int run_dw(dsact_handle* h, int x0, int x1) {
-  if (x1 <= x0) return DSACT_OK;
-  return launch(h, "dW", k_stage_table, dim3(x1 - x0), dim3(kThreads), tile_lds_bytes(h->B), (const GemmProb*)(h->d_tiles + x0));
+// weight-gradient tiles [x0, x1) as their own launch; `fused`: Adam/Polyak in the tile epilogue;
+// `finalize`: one extra block closes the update (alpha step, EMA commit, counters)
+int run_dw(dsact_handle* h, int x0, int x1, bool fused, bool finalize) {
+  if (x1 <= x0 && !finalize) return DSACT_OK;
+  TableArgs a;
+  a.tiles = h->d_tiles + x0; a.n_tiles = x1 > x0 ? x1 - x0 : 0;
+  a.fo = fused_opt(h, fused);
+  a.finalize = finalize ? 1 : 0;
+  return launch(h, "dW", k_stage_table, dim3(a.n_tiles + (finalize ? 1 : 0)), dim3(kThreads), tile_lds_bytes(h->B), a);
 }
 
 // dispatch on the number of 256-wide chunks of a hidden row (register arrays are statically indexed)
@@ -456,6 +485,7 @@ int run_dw(dsact_handle* h, int x0, int x1) {
 
 // exact decimal value a float config field was written as (0.9f -> 0.9, 1e-4f -> 1e-4): the
 // reference computes Adam's bias corrections from Python doubles
+double dec7(float f);
 double dec7(float f) {
   char buf[32];
   snprintf(buf, sizeof(buf), "%.7g", (double)f);
@@ -516,7 +546,7 @@ int enqueue_prologue(dsact_handle* h, int use_dev, long long it, int advance, in
 }
 
 // everything of __compute_gradient after the minibatch is staged (dsac_v2.py:150-206)
-int enqueue_grads(dsact_handle* h, bool actor_backward) {
+int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused) {
   const int L = h->L, B = h->B, A = h->A;
   for (int l = 0; l < L; ++l) TRY(run_stage(h, h->fwd1[l]));
   {
@@ -576,12 +606,19 @@ int enqueue_grads(dsact_handle* h, bool actor_backward) {
 #define CALL_LOSS(N) TRY(launch(h, "loss", k_loss<N>, dim3(h->n_loss_wg), dim3(kThreads), 0, a))
     NCH_DISPATCH(a.W, CALL_LOSS);
   }
+  if (!actor_backward) {
+    // off iteration of the delayed update: the reference computes the actor / alpha gradients and
+    // discards them (dsac_v2.py:174-186 vs :324) -- only the critics' backward is needed
+    for (size_t i = 0; i < h->bwdq_critic.size(); ++i) TRY(run_stage(h, h->bwdq_critic[i]));
+    TRY(run_dw(h, h->dw_off[0], h->dw_off[2], fused, fused));
+    return DSACT_OK;
+  }
   for (size_t i = 0; i < h->bwdq.size(); ++i) TRY(run_stage(h, h->bwdq[i]));
   {
     // the critics' weight-gradient tiles are independent of the actor path: they ride along in its
     // under-filled launches (q1's with bwdA, q2's with the first policy-backward stage)
     const bool q2_rides_pi = !h->bwdpi.empty();
-    TRY(run_stage(h, h->bwda, h->dw_off[0], q2_rides_pi ? h->dw_off[1] : h->dw_off[2]));
+    TRY(run_stage(h, h->bwda, h->dw_off[0], q2_rides_pi ? h->dw_off[1] : h->dw_off[2], fused));
     HeadsBwdArgs a;
     a.dA[0] = h->dA[0]; a.dA[1] = h->dA[1]; a.ldA = 32;
     a.logits_pi = h->logits_pi; a.eps_new = h->eps_new; a.log_alpha = h->online + h->n_online - 1;
@@ -598,9 +635,8 @@ int enqueue_grads(dsact_handle* h, bool actor_backward) {
     NCH_DISPATCH(a.WL, CALL_HBWD);
   }
   for (size_t i = 0; i < h->bwdpi.size(); ++i)
-    TRY(run_stage(h, h->bwdpi[i], i == 0 ? h->dw_off[1] : 0, i == 0 ? h->dw_off[2] : 0));
-  TRY(run_dw(h, h->dw_off[2], h->dw_off[3]));  // policy weight gradients
-  (void)actor_backward;
+    TRY(run_stage(h, h->bwdpi[i], i == 0 ? h->dw_off[1] : 0, i == 0 ? h->dw_off[2] : 0, fused));
+  TRY(run_dw(h, h->dw_off[2], h->dw_off[3], fused, fused));  // policy weight gradients (+ close of the update)
   return DSACT_OK;
 }
 
@@ -1012,7 +1048,7 @@ int dsact_compute_grads(dsact_handle* h, int64_t iteration, uint32_t flags) {
   TRY(check_ready(h, true));
   HIPCHK(h, hipSetDevice(h->device));
   TRY(enqueue_prologue(h, 0, iteration, 0, 1));
-  return enqueue_grads(h, !(flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) || (iteration % h->cfg.delay_update) == 0);
+  return enqueue_grads(h, !(flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) || (iteration % h->cfg.delay_update) == 0, false);
 }
 
 int dsact_apply_update(dsact_handle* h, int64_t iteration) {
@@ -1026,14 +1062,16 @@ int dsact_step(dsact_handle* h, int64_t iteration, uint32_t flags) {
   TRY(check_ready(h, true));
   HIPCHK(h, hipSetDevice(h->device));
   TRY(enqueue_prologue(h, 0, iteration, 1, 1));
-  TRY(enqueue_grads(h, !(flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) || (iteration % h->cfg.delay_update) == 0));
-  return enqueue_adam(h);
+  // single-GPU update: Adam / Polyak are applied by the weight-gradient tiles themselves (no k_adam)
+  return enqueue_grads(h, !(flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) || (iteration % h->cfg.delay_update) == 0, true);
 }
 
-static int enqueue_graph_step(dsact_handle* h) {
+// one replayed update (iteration and index-table row from device state). `iteration` is only used to
+// decide, at enqueue/capture time, whether this is an off iteration of the delayed update.
+static int enqueue_graph_step(dsact_handle* h, long long iteration, uint32_t flags) {
   TRY(enqueue_gather(h, h->idx_table, h->idx_rows, 1, 0, 1));
-  TRY(enqueue_grads(h, true));
-  return enqueue_adam(h);
+  const bool actor = !(flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) || (iteration % h->cfg.delay_update) == 0;
+  return enqueue_grads(h, actor, true);
 }
 
 int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) {
@@ -1046,9 +1084,11 @@ int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) 
   HIPCHK(h, hipStreamSynchronize(h->stream));
   const bool was_prof = h->profiling;
   h->profiling = false;
+  if ((flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) && steps_per_graph % h->cfg.delay_update)
+    return fail(h, DSACT_E_INVALID, "with DSACT_F_SKIP_ACTOR_ON_OFF_ITERS steps_per_graph must be a multiple of delay_update");
   HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
   int rc = DSACT_OK;
-  for (int s = 0; s < steps_per_graph && rc == DSACT_OK; ++s) rc = enqueue_graph_step(h);
+  for (int s = 0; s < steps_per_graph && rc == DSACT_OK; ++s) rc = enqueue_graph_step(h, s, flags);
   hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
   h->profiling = was_prof;
   if (rc != DSACT_OK) return rc;
@@ -1071,6 +1111,8 @@ int dsact_graph_run(dsact_handle* h, int64_t first_iteration, int64_t n_steps) {
   if (!h) return DSACT_E_INVALID;
   if (!h->graph_exec) return fail(h, DSACT_E_STATE, "dsact_graph_build first");
   if (n_steps % h->graph_steps) return fail(h, DSACT_E_INVALID, "n_steps must be a multiple of steps_per_graph");
+  if ((h->graph_flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) && first_iteration % h->cfg.delay_update)
+    return fail(h, DSACT_E_INVALID, "first_iteration must be a multiple of delay_update for a graph captured with DSACT_F_SKIP_ACTOR_ON_OFF_ITERS");
   HIPCHK(h, hipSetDevice(h->device));
   TRY(set_device_iteration(h, first_iteration));
   for (int64_t i = 0; i < n_steps / h->graph_steps; ++i) HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
@@ -1090,7 +1132,7 @@ int dsact_dp_enqueue_grads(dsact_handle* h, uint32_t flags) {
   (void)flags;
   TRY(enqueue_gather(h, h->idx_table, h->idx_rows, 1, 0, 0));
   h->have_batch = true;
-  return enqueue_grads(h, true);
+  return enqueue_grads(h, true, false);
 }
 
 int dsact_dp_enqueue_apply(dsact_handle* h) {
@@ -1133,11 +1175,12 @@ int dsact_time_steps(dsact_handle* h, int64_t first_iteration, int64_t n_steps, 
   if (use_graph) {
     if (!h->graph_exec) return fail(h, DSACT_E_STATE, "dsact_graph_build first");
     if (n_steps % h->graph_steps) return fail(h, DSACT_E_INVALID, "n_steps must be a multiple of steps_per_graph");
+    if ((h->graph_flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) && first_iteration % h->cfg.delay_update)
+      return fail(h, DSACT_E_INVALID, "first_iteration must be a multiple of delay_update");
     for (int64_t i = 0; i < n_steps / h->graph_steps; ++i) HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
   } else {
-    for (int64_t i = 0; i < n_steps; ++i) TRY(enqueue_graph_step(h));
+    for (int64_t i = 0; i < n_steps; ++i) TRY(enqueue_graph_step(h, first_iteration + i, flags));
   }
-  (void)flags;
   HIPCHK(h, hipEventRecord(e1, h->stream));
   HIPCHK(h, hipEventSynchronize(e1));
   HIPCHK(h, hipEventElapsedTime(ms_total, e0, e1));
@@ -1155,9 +1198,8 @@ int dsact_profile_step(dsact_handle* h, int64_t iteration, uint32_t flags, dsact
   for (auto& r : h->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   h->prof.clear();
   h->profiling = true;
-  int rc = enqueue_graph_step(h);
+  int rc = enqueue_graph_step(h, iteration, flags);
   h->profiling = false;
-  (void)flags;
   TRY(rc);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   int cnt = 0;

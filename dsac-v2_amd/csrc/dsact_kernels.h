@@ -431,6 +431,19 @@ struct GemmProb {
   int tile_end;         // exclusive end of this problem's block range inside its stage
 };
 
+// Optimiser fused into the weight-gradient tiles (single-GPU path): every parameter element is the
+// output of exactly ONE dW/db tile (K = batch is reduced inside the tile), so the tile applies Adam
+// (and Polyak on delayed steps) to its own 32x32 block right after writing the gradient and the
+// separate streaming pass over the arenas (k_adam) disappears. Arena element index of an output =
+// (C0 - grads) + m*ldc + n because grads / online / adam_m / adam_v / target mirror each other.
+struct FusedOpt {
+  DevState* st;            // nullptr: plain store (data-parallel path keeps k_adam after the all-reduce)
+  float* online; float* target; float* adam_m; float* adam_v; float* grads;
+  long long n_q2, n_online3, n_total;
+  float b1w, beta2, b2w, eps, polyak, one_minus_polyak;
+  int auto_alpha;
+};
+
 constexpr int kMaxPrefetchTiles = 7;  // K <= 448 is fetched completely up front (112 VGPRs)
 // dynamic LDS a tile kernel needs for contraction length K
 inline size_t tile_lds_bytes(int K) {
@@ -468,7 +481,7 @@ __device__ __forceinline__ OpCursor<MC> make_cursor(const float* base, int ld, i
 
 template <bool P_MC, bool Q_MC, int EPI>
 __device__ __forceinline__ void run_tile(const GemmProb& t, int m0, int n0, float* lds, long long* tl_buf = nullptr,
-                                         int tl_slot = 0) {
+                                         int tl_slot = 0, const FusedOpt* fo = nullptr) {
   TL_DECL
   TL_STAMP();  // 0: tile start (problem decoded)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -493,6 +506,25 @@ __device__ __forceinline__ void run_tile(const GemmProb& t, int m0, int n0, floa
   f32x4 epv = {0.f, 0.f, 0.f, 0.f};
   if (EPI == EPI_GELU) { if (in_range && full) epv = *(const f32x4u*)(t.aux + n); }
   else if (EPI == EPI_MULG) { if (in_range && full) epv = *(const f32x4u*)(t.aux + (size_t)m * t.ldaux + n); }
+  // fused optimiser: this lane's 4 parameters and their moments, fetched now
+  const bool fused = EPI == EPI_STORE && fo != nullptr && fo->st != nullptr;
+  long long oi = 0;
+  bool o_delayed = false, o_upd = false, o_tvec = false;
+  float o_ss = 0.f, o_bc2 = 1.f;
+  f32x4 op = {0.f, 0.f, 0.f, 0.f}, om = op, ov = op, ot = op;
+  if (fused && in_range) {
+    oi = (long long)((t.C0 + (size_t)m * t.ldc + n) - fo->grads);
+    o_delayed = fo->st->do_delayed != 0;
+    const bool is_q = oi < fo->n_q2;  // a tile never straddles nets: one tensor per problem
+    o_upd = is_q || o_delayed;
+    o_ss = is_q ? fo->st->ss_q : fo->st->ss_pi;
+    o_bc2 = is_q ? fo->st->bc2_q : fo->st->bc2_pi;
+    if (o_upd && full) {
+      op = *(const f32x4u*)(fo->online + oi); om = *(const f32x4u*)(fo->adam_m + oi); ov = *(const f32x4u*)(fo->adam_v + oi);
+      o_tvec = o_delayed;
+      if (o_tvec) ot = *(const f32x4u*)(fo->target + oi);
+    }
+  }
 #define DSACT_LOAD_TILE(IT, P0, P1, Q0, Q1)                                                         \
   do {                                                                                              \
     if ((IT) < Tfull && p_fast) {                                                                   \
@@ -575,6 +607,26 @@ __device__ __forceinline__ void run_tile(const GemmProb& t, int m0, int n0, floa
     float* c0 = t.C0 + (size_t)m * t.ldc + n;
     if (full) *(f32x4u*)c0 = acc;
     else for (int e = 0; e < 4 && n + e < t.N; ++e) c0[e] = acc[e];
+    if (fused && o_upd) {
+      if (full) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float pe = op[e], me = om[e], ve = ov[e];
+          adam_update(pe, me, ve, acc[e], fo->b1w, fo->beta2, fo->b2w, o_ss, o_bc2, fo->eps);
+          op[e] = pe; om[e] = me; ov[e] = ve;
+          if (o_tvec) ot[e] = polyak_update(ot[e], pe, fo->polyak, fo->one_minus_polyak);
+        }
+        *(f32x4u*)(fo->online + oi) = op; *(f32x4u*)(fo->adam_m + oi) = om; *(f32x4u*)(fo->adam_v + oi) = ov;
+        if (o_tvec) *(f32x4u*)(fo->target + oi) = ot;
+      } else {
+        for (int e = 0; e < 4 && n + e < t.N; ++e) {
+          float pe = fo->online[oi + e], me = fo->adam_m[oi + e], ve = fo->adam_v[oi + e];
+          adam_update(pe, me, ve, acc[e], fo->b1w, fo->beta2, fo->b2w, o_ss, o_bc2, fo->eps);
+          fo->online[oi + e] = pe; fo->adam_m[oi + e] = me; fo->adam_v[oi + e] = ve;
+          if (o_delayed) fo->target[oi + e] = polyak_update(fo->target[oi + e], pe, fo->polyak, fo->one_minus_polyak);
+        }
+      }
+    }
   }
   TL_STAMP();  // 4: epilogue stores issued
   TL_FLUSH(tl_buf, tl_slot);
@@ -599,6 +651,7 @@ struct StageArgs {
   int n_stage_blocks;      // blocks [0, n_stage_blocks) run the problems above ...
   const GemmProb* extra;   // ... the remaining blocks run per-tile table entries (weight gradients that
   int n_extra;             //     are independent of this stage and would otherwise idle-wait for it)
+  FusedOpt fo;             // optimiser applied by those tiles (fo.st == nullptr: plain gradient store)
   long long* timeline;     // DSACT_TIMELINE builds only (else unused)
 };
 
@@ -608,7 +661,7 @@ __global__ void __launch_bounds__(kThreads) k_stage(StageArgs s) {
   const int b = xcd_logical_block(blockIdx.x, gridDim.x);
   if (b >= s.n_stage_blocks) {  // ride-along weight-gradient tile (MC x MC, plain store)
     const GemmProb g = s.extra[b - s.n_stage_blocks];
-    run_tile<true, true, EPI_STORE>(g, g.tiles_n, g.tile_end, lds);
+    run_tile<true, true, EPI_STORE>(g, g.tiles_n, g.tile_end, lds, nullptr, 0, &s.fo);
     return;
   }
   int pi = 0;
@@ -624,10 +677,35 @@ __global__ void __launch_bounds__(kThreads) k_stage(StageArgs s) {
 // ---- stage launch form 2: many small problems (weight / bias gradients) from a device table ------
 // one GemmProb PER TILE (tiles_n / tile_end are reused as the tile origin m0 / n0): a single
 // dependent load per block. Every problem is an MC x MC product with a plain store.
-__global__ void __launch_bounds__(kThreads) k_stage_table(const GemmProb* __restrict__ tiles) {
+struct TableArgs {
+  const GemmProb* tiles; int n_tiles;
+  FusedOpt fo;
+  int finalize;   // 1: one extra block closes the update (alpha step, mean_std commit, counters)
+};
+
+// end-of-update duties of the fused path: Adam on log_alpha, commit of the mean_std EMA and of the
+// iteration / sequence counters (k_adam does the same on the unfused path)
+__device__ void finalize_update(const FusedOpt& fo) {
+  const DevState st = *fo.st;
+  const long long i = fo.n_total - 1;
+  if (st.do_delayed && fo.auto_alpha) {
+    float p = fo.online[i], m = fo.adam_m[i], v = fo.adam_v[i];
+    adam_update(p, m, v, fo.grads[i], fo.b1w, fo.beta2, fo.b2w, st.ss_alpha, st.bc2_alpha, fo.eps);
+    fo.online[i] = p; fo.adam_m[i] = m; fo.adam_v[i] = v;
+  }
+  fo.st->ms1 = fo.grads[fo.n_total]; fo.st->ms2 = fo.grads[fo.n_total + 1]; fo.st->ms_init = 1;
+  fo.st->it_next = st.it_cur + 1;
+  fo.st->seq_next = st.seq_next + 1;
+}
+
+__global__ void __launch_bounds__(kThreads) k_stage_table(TableArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const GemmProb g = tiles[xcd_logical_block(blockIdx.x, gridDim.x)];
-  run_tile<true, true, EPI_STORE>(g, g.tiles_n, g.tile_end, lds);
+  if ((int)blockIdx.x >= a.n_tiles) {
+    if (a.finalize && threadIdx.x == 0) finalize_update(a.fo);
+    return;
+  }
+  const GemmProb g = a.tiles[xcd_logical_block(blockIdx.x, a.n_tiles)];
+  run_tile<true, true, EPI_STORE>(g, g.tiles_n, g.tile_end, lds, nullptr, 0, &a.fo);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -357,3 +357,58 @@ def test_policy_forward_and_checkpoint_roundtrip(tmp_path):
     cpu = ApproxContainer(**hip_kwargs(O, A, hid, B))
     cpu.load_state_dict(torch.load(p, map_location="cpu"))
     assert torch.allclose(cpu.policy(obs), lg, atol=2e-5, rtol=1e-5)
+
+
+def _replay_pair(O, A, hid, B, N, seed):
+    alg, _ = make_pair(O, A, hid, B, seed=seed)
+    e = alg.engine
+    e.set_device_rng(4242)
+    e.buffer_create(N)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    e.buffer_fill_device(0, torch.randn(N, O, device="cuda", generator=g), torch.rand(N, A, device="cuda", generator=g) - .5,
+                         torch.randn(N, device="cuda", generator=g), torch.randn(N, O, device="cuda", generator=g),
+                         (torch.rand(N, device="cuda", generator=g) < .05).float())
+    np.random.seed(3)
+    e.upload_index_table(np.random.randint(0, N, size=(8, B)))
+    return alg
+
+
+def test_fused_optimizer_equals_split_update():
+    """dsact_step (Adam/Polyak fused into the weight-gradient tiles) == compute_grads + apply_update (k_adam)."""
+    O, A, hid, B = 23, 5, (64, 96, 64), 64
+    a1, _ = make_pair(O, A, hid, B, seed=9)
+    a2, _ = make_pair(O, A, hid, B, seed=9)
+    rng = np.random.default_rng(2)
+    for it in range(5):
+        data = synth_batch(rng, B, O, A, p_done=0.1)
+        torch.manual_seed(77 + it)
+        noise = draw_noise(B, A)
+        for a in (a1, a2):
+            a.engine.load_batch(*(data[k].numpy() for k in ("obs", "act", "rew", "obs2", "done")))
+            a.engine.set_noise(noise["eps_new"].numpy(), noise["eps_2"].numpy(), noise["z5"].numpy(), noise["z6"].numpy())
+        a1.engine.step(it)
+        a2.engine.compute_grads(it)
+        a2.engine.apply_update(it)
+    a1.engine.sync(); a2.engine.sync()
+    for name in ("online", "target", "adam_m", "adam_v"):
+        assert torch.equal(getattr(a1.engine, name), getattr(a2.engine, name)), name
+    assert a1.engine.get_state() == a2.engine.get_state()
+
+
+def test_skip_discarded_actor_backward_keeps_trajectory():
+    """DSACT_F_SKIP_ACTOR_ON_OFF_ITERS drops work whose result the reference throws away
+    (dsac_v2.py:174-186 vs :324): parameters, targets and optimiser state must not change by a bit."""
+    from dsact._ffi import F_SKIP_ACTOR_ON_OFF_ITERS
+    outs = []
+    for flags in (0, F_SKIP_ACTOR_ON_OFF_ITERS):
+        alg = _replay_pair(17, 4, (64, 64), 64, 4096, seed=4)
+        e = alg.engine
+        e.graph_build(2, flags)
+        e.graph_run(0, 8)
+        e.sync()
+        outs.append((e.online.clone(), e.target.clone(), e.adam_m.clone(), e.adam_v.clone(), e.get_state(), e.read_stats()))
+    for x, y in zip(outs[0][:4], outs[1][:4]):
+        assert torch.equal(x, y)
+    assert outs[0][4] == outs[1][4]
+    for k in outs[0][5]:
+        assert outs[0][5][k] == outs[1][5][k], k
