@@ -76,8 +76,7 @@ struct dsact_handle {
   float* W1p[4];  // zero-padded first-layer weights of q1, q2, q1_target, q2_target  [w0 x ldx]
   float* dout[4];
   float *dout_pi, *d_new_act;
-  float* dA[2];   // dL/d new_act through q1 / q2  [B x 32] (zero padded)
-  float* W1a[2];  // action columns of q1 / q2's first layer  [w0 x 32] (zero padded)
+  float* W1aT[2];  // transposed zero-padded action columns of q1 / q2's first layer  [32][w0]
   float *part_loss, *part_heads, *stats, *ones, *std_sums;
   long long* timeline;  // [512][8] stamps of the stage named by DSACT_TIMELINE_STAGE (instrumented builds)
   float *act_scale, *act_center;
@@ -93,7 +92,6 @@ struct dsact_handle {
   int n_dw_tiles = 0;
   int dw_off[4] = {0, 0, 0, 0};  // start of q1, q2, policy tiles, end
   std::vector<Stage> fwd1, fwd2, bwdq, bwdq_critic, bwdpi, actf;
-  Stage bwda;  // dA = dZ1(q_i(obs,new_act)) . W1_i[:, O:O+A]
   // replay ring
   long long cap = 0, ptr = 0, size = 0;
   float *rb_obs = nullptr, *rb_obs2 = nullptr, *rb_act = nullptr, *rb_rew = nullptr, *rb_done = nullptr, *rb_logp = nullptr;
@@ -242,10 +240,8 @@ void carve(dsact_handle* h, Carver& c) {
   for (int i = 0; i < 4; ++i) h->dout[i] = c.take<float>(B * 2);
   h->dout_pi = c.take<float>(B * 2 * A);
   h->d_new_act = c.take<float>(B * A);
-  h->dA[0] = c.take<float>(B * 32);
-  h->dA[1] = c.take<float>(B * 32);
-  h->W1a[0] = c.take<float>((size_t)h->w[0] * 32);
-  h->W1a[1] = c.take<float>((size_t)h->w[0] * 32);
+  h->W1aT[0] = c.take<float>((size_t)32 * h->w[0]);
+  h->W1aT[1] = c.take<float>((size_t)32 * h->w[0]);
   h->part_loss = c.take<float>(B * kLossPart);
   for (int i = 0; i < 4; ++i) h->W1p[i] = c.take<float>((size_t)h->w[0] * h->ldx);
   h->part_heads = c.take<float>((size_t)h->n_heads_wg * 2);
@@ -356,18 +352,6 @@ int build_tasks(dsact_handle* h) {
     Stage s = fresh("bwdPi_l" + std::to_string(l), 1);
     stage_add(s, bwd_prob(C_PI, l));
     h->bwdpi.push_back(s);
-  }
-  // action gradient through the first layer of q1 / q2: dA_i = dZ1_i . W1_i[:, O:O+A]
-  h->bwda = fresh("bwdA", 2);
-  for (int qi = 0; qi < 2; ++qi) {
-    const int ch = qi == 0 ? C_Q1P : C_Q2P;
-    GemmProb t;
-    memset(&t, 0, sizeof(t));
-    t.P = h->dZ[kDzSlot[ch]][0]; t.ldp = h->w[0];
-    t.Q = h->W1a[qi]; t.ldq = 32;   // zero-padded action columns (k_gather repack): a full 32-wide tile
-    t.C0 = h->dA[qi]; t.ldc = 32;
-    t.M = B; t.N = 32; t.K = h->w[0];
-    stage_add(h->bwda, t);
   }
   // stand-alone policy forward (kActRows rows)
   h->actf.clear();
@@ -512,7 +496,7 @@ RepackArgs repack_args(const dsact_handle* h, int n_blocks) {
   for (int i = 0; i < 4; ++i) { rp.src[i] = net_params(h, nets[i]) + h->qd.w_off[0]; rp.dst[i] = h->W1p[i]; }
   rp.rows = h->w[0]; rp.K = h->O + h->A; rp.ldp = h->ldx;
   rp.n_blocks = n_blocks;
-  rp.w1a[0] = h->W1a[0]; rp.w1a[1] = h->W1a[1]; rp.O = h->O; rp.A = h->A;
+  rp.w1at[0] = h->W1aT[0]; rp.w1at[1] = h->W1aT[1]; rp.O = h->O; rp.A = h->A;
   return rp;
 }
 int repack_blocks(const dsact_handle* h) {
@@ -615,12 +599,9 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused) {
   }
   for (size_t i = 0; i < h->bwdq.size(); ++i) TRY(run_stage(h, h->bwdq[i]));
   {
-    // the critics' weight-gradient tiles are independent of the actor path: they ride along in its
-    // under-filled launches (q1's with bwdA, q2's with the first policy-backward stage)
-    const bool q2_rides_pi = !h->bwdpi.empty();
-    TRY(run_stage(h, h->bwda, h->dw_off[0], q2_rides_pi ? h->dw_off[1] : h->dw_off[2], fused));
     HeadsBwdArgs a;
-    a.dA[0] = h->dA[0]; a.dA[1] = h->dA[1]; a.ldA = 32;
+    a.dZ1[0] = h->dZ[kDzSlot[C_Q1P]][0]; a.dZ1[1] = h->dZ[kDzSlot[C_Q2P]][0];
+    a.W1aT[0] = h->W1aT[0]; a.W1aT[1] = h->W1aT[1]; a.W0 = h->w[0];
     a.logits_pi = h->logits_pi; a.eps_new = h->eps_new; a.log_alpha = h->online + h->n_online - 1;
     a.Wout_pi = net_params(h, N_POL) + h->pd.w_off[L];
     a.G_pi = h->Gb[C_PI][L - 1]; a.dZ_pi = h->dZ[kDzSlot[C_PI]][L - 1];
@@ -634,9 +615,17 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused) {
 #define CALL_HBWD(N) TRY(launch(h, "heads_bwd", k_heads_bwd<N>, dim3((B + 3) / 4), dim3(kThreads), 0, a))
     NCH_DISPATCH(a.WL, CALL_HBWD);
   }
-  for (size_t i = 0; i < h->bwdpi.size(); ++i)
-    TRY(run_stage(h, h->bwdpi[i], i == 0 ? h->dw_off[1] : 0, i == 0 ? h->dw_off[2] : 0, fused));
-  TRY(run_dw(h, h->dw_off[2], h->dw_off[3], fused, fused));  // policy weight gradients (+ close of the update)
+  // the critics' weight-gradient tiles are independent of the actor path: they ride along in its
+  // under-filled launches (q1's with the first policy-backward stage, q2's with the second)
+  const size_t np = h->bwdpi.size();
+  for (size_t i = 0; i < np; ++i) {
+    int x0 = 0, x1 = 0;
+    if (i == 0) { x0 = h->dw_off[0]; x1 = np > 1 ? h->dw_off[1] : h->dw_off[2]; }
+    else if (i == 1) { x0 = h->dw_off[1]; x1 = h->dw_off[2]; }
+    TRY(run_stage(h, h->bwdpi[i], x0, x1, fused));
+  }
+  // policy weight gradients (+ the critics' when there was no launch to ride in) + close of the update
+  TRY(run_dw(h, np ? h->dw_off[2] : h->dw_off[0], h->dw_off[3], fused, fused));
   return DSACT_OK;
 }
 

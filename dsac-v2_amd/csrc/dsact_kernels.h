@@ -204,8 +204,8 @@ struct RepackArgs {
   const float* src[4]; float* dst[4];
   int rows, K, ldp;
   int n_blocks;        // blocks assigned to the repack (0 = none)
-  float* w1a[2];       // action columns of q1 / q2's first layer, [rows][32] zero padded (bwdA stage)
-  int O, A;
+  float* w1at[2];      // action columns of q1 / q2's first layer, TRANSPOSED [32 (j, zero padded)][rows]
+  int O, A;            //   (k_heads_bwd forms dL/d new_act from them with coalesced row loads)
 };
 __device__ void repack_rows(const RepackArgs& rp, int blk, int tid) {
   const int per_net = rp.rows * rp.ldp;
@@ -218,8 +218,8 @@ __device__ void repack_rows(const RepackArgs& rp, int blk, int tid) {
   const int nact = 2 * rp.rows * 32;
   for (int e = blk * kThreads + tid; e < nact; e += rp.n_blocks * kThreads) {
     const int net = e / (rp.rows * 32), rem = e - net * rp.rows * 32;
-    const int row = rem >> 5, j = rem & 31;
-    rp.w1a[net][rem] = j < rp.A ? rp.src[net][(size_t)row * rp.K + rp.O + j] : 0.0f;
+    const int j = rem / rp.rows, row = rem - j * rp.rows;   // consecutive threads -> consecutive rows of one j
+    rp.w1at[net][rem] = j < rp.A ? rp.src[net][(size_t)row * rp.K + rp.O + j] : 0.0f;
   }
 }
 __global__ void __launch_bounds__(kThreads) k_repack(RepackArgs rp) { repack_rows(rp, blockIdx.x, threadIdx.x); }
@@ -1008,15 +1008,17 @@ __global__ void __launch_bounds__(kThreads) k_loss(LossArgs a) {
 // ---------------------------------------------------------------------------------------------
 // k_heads_bwd: actor path between the Q nets' first layer and the policy's last hidden layer.
 //   dA[r][j]   = sum_k dZ1_q1p[r][k] W1_q1[k][O+j] + sum_k dZ1_q2p[r][k] W1_q2[k][O+j]
-//                (the two sums are tile-stage products "bwdA": P = dZ1, Q = W1[:, O:O+A], K = W0)
+//                (lanes over k; rows of the transposed action columns are fetched 8 at a time --
+//                 independent coalesced loads -- and reduced with DPP)
 //   (dmu,draw) = tanh-Gaussian rsample backward with dL/dlogp = alpha/B     (App. A.3)
 //   dZ_pi_last = ((dmu|draw) . Wout_pi) * GELU'(z_last)
 // one wave per row. Block 0 / wave 0 also finalises the alpha gradient (dsac_v2.py:312-318):
 //   d loss_alpha / d log_alpha = -mean(logp_new + target_entropy)
 // ---------------------------------------------------------------------------------------------
 struct HeadsBwdArgs {
-  const float* dA[2];      // [B x ldA] dL/d new_act through q1 / q2 (tile stage bwdA: dZ1 . W1[:, O:O+A])
-  int ldA;
+  const float* dZ1[2];     // [B x W0] first-hidden dZ of q1(obs,new_act), q2(obs,new_act)
+  const float* W1aT[2];    // [32][W0] transposed, zero padded action columns of q1 / q2's first layer
+  int W0;
   const float* logits_pi;  // [B x 2A]
   const float* eps_new;
   const float* log_alpha;
@@ -1053,7 +1055,52 @@ __global__ void __launch_bounds__(kThreads) k_heads_bwd(HeadsBwdArgs a) {
     raw = a.logits_pi[(size_t)r * 2 * A + A + lane];
     eps = a.eps_new[(size_t)r * A + lane];
     scale = a.act_scale[lane];
-    dA = a.dA[0][(size_t)r * a.ldA + lane] + a.dA[1][(size_t)r * a.ldA + lane];
+  }
+  {
+    // this lane's slice of the two dZ1 rows (4 hidden units per 256-chunk), zero beyond the row
+    f32x4 d1[4], d2[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k = c * 256 + lane * 4;
+      const int kc = k < a.W0 ? k : 0;
+      f32x4 v1 = *(const f32x4u*)(a.dZ1[0] + (size_t)r * a.W0 + kc);
+      f32x4 v2 = *(const f32x4u*)(a.dZ1[1] + (size_t)r * a.W0 + kc);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (k + e >= a.W0) { v1[e] = 0.f; v2[e] = 0.f; }
+      d1[c] = v1; d2[c] = v2;
+    }
+    const int nch0 = (a.W0 + 255) >> 8;
+    // groups of 12 action dimensions: 24 independent row loads per chunk, then 12 DPP reductions.
+    // Rows j >= A of the transposed copy are zero (repack), so no masking is needed up to 32
+    // (the last group clamps its row index).
+    constexpr int JG = 12;
+    for (int j0 = 0; j0 < A; j0 += JG) {
+      float sacc[JG];
+#pragma unroll
+      for (int q = 0; q < JG; ++q) sacc[q] = 0.f;
+      for (int c = 0; c < nch0; ++c) {
+        const int k = c * 256 + lane * 4;
+        const int kc = k < a.W0 ? k : 0;   // lanes beyond the row multiply by d = 0
+        f32x4 w1[JG], w2[JG];
+#pragma unroll
+        for (int q = 0; q < JG; ++q) {
+          const int j = j0 + q < 32 ? j0 + q : 31;
+          w1[q] = *(const f32x4u*)(a.W1aT[0] + (size_t)j * a.W0 + kc);
+          w2[q] = *(const f32x4u*)(a.W1aT[1] + (size_t)j * a.W0 + kc);
+        }
+        const f32x4 e1 = c == 0 ? d1[0] : c == 1 ? d1[1] : c == 2 ? d1[2] : d1[3];
+        const f32x4 e2 = c == 0 ? d2[0] : c == 1 ? d2[1] : c == 2 ? d2[2] : d2[3];
+#pragma unroll
+        for (int q = 0; q < JG; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sacc[q] += e1[e] * w1[q][e] + e2[e] * w2[q][e];
+      }
+#pragma unroll
+      for (int q = 0; q < JG; ++q) {
+        const float t = wave_sum(sacc[q]);
+        if (lane == j0 + q) dA = t;
+      }
+    }
   }
   // prefetch this lane's GELU' values of the row (used at the very end)
   f32x4 gv[NCH];
@@ -1063,7 +1110,7 @@ __global__ void __launch_bounds__(kThreads) k_heads_bwd(HeadsBwdArgs a) {
     gv[c] = *(const f32x4u*)(a.G_pi + (size_t)r * a.WL + (k < a.WL ? k : 0));
   }
   const float alpha = a.auto_alpha ? expf(a.log_alpha[0]) : a.alpha_fixed;
-  TL_STAMP();  // 1: inputs loaded
+  TL_STAMP();  // 1: dL/d new_act formed
   float dmu = 0.f, draw = 0.f;
   if (lane < A) {
     tanh_gauss_bwd(mu, raw, eps, scale, a.lo_ls, a.hi_ls, dA, alpha * a.inv_B, dmu, draw);
