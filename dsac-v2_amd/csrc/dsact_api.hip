@@ -56,6 +56,9 @@ struct dsact_handle {
   char err[512] = {0};
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t aux_stream = nullptr;   // forked branch: critics' dW + Adam run beside the actor backward chain
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool use_fork = false;
   // nets
   NetDesc qd, pd;
   size_t n_q = 0, n_pi = 0, n_online = 0, n_target = 0;
@@ -167,6 +170,14 @@ float* net_base(const dsact_handle* h, int net, float* online, float* target) {
 }
 float* net_params(const dsact_handle* h, int net) { return net_base(h, net, h->online, h->target); }
 float* net_grads(const dsact_handle* h, int net) { return net_base(h, net, h->grads, nullptr); }
+
+template <typename... KArgs, typename... Args>
+int launch_on(dsact_handle* h, hipStream_t stream, const char* name, void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, Args... args) {
+  hipLaunchKernelGGL(kernel, grid, block, shmem, stream, args...);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(h, DSACT_E_HIP, "launch %s failed: %s", name, hipGetErrorString(e));
+  return DSACT_OK;
+}
 
 template <typename... KArgs, typename... Args>
 int launch(dsact_handle* h, const char* name, void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, Args... args) {
@@ -448,12 +459,14 @@ int run_stage(dsact_handle* h, const Stage& s0, int x0 = 0, int x1 = 0, bool fus
 
 // weight-gradient tiles [x0, x1) as their own launch; `fused`: Adam/Polyak in the tile epilogue;
 // `finalize`: one extra block closes the update (alpha step, EMA commit, counters)
-int run_dw(dsact_handle* h, int x0, int x1, bool fused, bool finalize) {
+int run_dw(dsact_handle* h, int x0, int x1, bool fused, bool finalize, hipStream_t on = nullptr) {
   if (x1 <= x0 && !finalize) return DSACT_OK;
   TableArgs a;
   a.tiles = h->d_tiles + x0; a.n_tiles = x1 > x0 ? x1 - x0 : 0;
   a.fo = fused_opt(h, fused);
   a.finalize = finalize ? 1 : 0;
+  if (on)
+    return launch_on(h, on, "dW", k_stage_table, dim3(a.n_tiles + (finalize ? 1 : 0)), dim3(kThreads), tile_lds_bytes(h->B), a);
   return launch(h, "dW", k_stage_table, dim3(a.n_tiles + (finalize ? 1 : 0)), dim3(kThreads), tile_lds_bytes(h->B), a);
 }
 
@@ -598,6 +611,12 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused) {
     return DSACT_OK;
   }
   for (size_t i = 0; i < h->bwdq.size(); ++i) TRY(run_stage(h, h->bwdq[i]));
+  if (h->use_fork && !h->profiling) {
+    HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
+    TRY(run_dw(h, h->dw_off[0], h->dw_off[2], fused, false, h->aux_stream));
+    HIPCHK(h, hipEventRecord(h->ev_join, h->aux_stream));
+  }
   {
     HeadsBwdArgs a;
     a.dZ1[0] = h->dZ[kDzSlot[C_Q1P]][0]; a.dZ1[1] = h->dZ[kDzSlot[C_Q2P]][0];
@@ -615,9 +634,18 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused) {
 #define CALL_HBWD(N) TRY(launch(h, "heads_bwd", k_heads_bwd<N>, dim3((B + 3) / 4), dim3(kThreads), 0, a))
     NCH_DISPATCH(a.WL, CALL_HBWD);
   }
-  // the critics' weight-gradient tiles are independent of the actor path: they ride along in its
-  // under-filled launches (q1's with the first policy-backward stage, q2's with the second)
   const size_t np = h->bwdpi.size();
+  if (h->use_fork && !h->profiling) {
+    // The critics' weight gradients (+ their Adam/Polyak) depend only on the critic backward above,
+    // not on the actor chain (heads_bwd -> policy backward): they run on a forked branch -- a second
+    // HIP stream, captured as a parallel branch of the graph -- and join before the final launch.
+    // (heads_bwd was already enqueued on the main stream; the fork event is recorded before it.)
+    for (size_t i = 0; i < np; ++i) TRY(run_stage(h, h->bwdpi[i], 0, 0, fused));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    TRY(run_dw(h, h->dw_off[2], h->dw_off[3], fused, fused));
+    return DSACT_OK;
+  }
+  // unforked: the critics' tiles ride along in the under-filled policy-backward launches
   for (size_t i = 0; i < np; ++i) {
     int x0 = 0, x1 = 0;
     if (i == 0) { x0 = h->dw_off[0]; x1 = np > 1 ? h->dw_off[1] : h->dw_off[2]; }
@@ -720,6 +748,10 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   }
   HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   h->own_stream = true;
+  HIPCHK(h, hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+  HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  h->use_fork = getenv("DSACT_FORK") != nullptr;  // measured: a forked graph branch costs +20 us/update (cross-queue signals) -> opt-in only
   {
     const int max_lds = (int)tile_lds_bytes(BK * kMaxPrefetchTiles);  // 129 KB of the CU's 160 KB
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, false, EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
@@ -751,6 +783,9 @@ int dsact_destroy(dsact_handle* h) {
   for (float* p : {h->rb_obs, h->rb_obs2, h->rb_act, h->rb_rew, h->rb_done, h->rb_logp})
     if (p) hipFree(p);
   if (h->ws) hipFree(h->ws);
+  if (h->aux_stream) { hipStreamSynchronize(h->aux_stream); hipStreamDestroy(h->aux_stream); }
+  if (h->ev_fork) hipEventDestroy(h->ev_fork);
+  if (h->ev_join) hipEventDestroy(h->ev_join);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
   return DSACT_OK;
