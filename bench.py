@@ -230,11 +230,29 @@ def main():
     }
     if rank == 0:
         per_gpu_steps = updates_per_s
+        # dominant kernel = k_stage<KC,KC,bias+GELU> (the forward tile stages: 6 of the 15 launches, ~37% of the
+        # update): every forward stage is launched back to back on the engine's stream between two hipEvents
+        n_st = 2 * len(hidden)
+        st_ms, st_macs, reps = 0.0, 0.0, 300
+        for st in range(n_st):
+            ms_i, macs_i = e.time_stage(st, reps)
+            st_ms += ms_i
+            st_macs += macs_i
+        dur_us = 1000.0 * st_ms / (reps * n_st)
+        flop_launch = 2.0 * st_macs / n_st
         out["roofline"] = {
+            "bound": "mfma", "achieved": flop_launch / (dur_us * 1e-6) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": flop_launch / (dur_us * 1e-6) / 1e12 / FP32_PEAK_TFLOPS, "traffic": None,
+            "kernel": "dsact::k_stage<false,false,0> (forward tile stage, 4 GEMM problems per launch)",
+            "avg_launch_us": dur_us, "flop_per_launch": flop_launch,
+            "note": "fp32 MFMA peak; avg over the %d forward stages, %d back-to-back launches each (hipEvents on the engine's "
+                    "stream); algorithmic FLOP = 2*M*N*K of the stage's problems. traffic: see profiles/ (PMC FETCH_SIZE "
+                    "x2 ~3.8 MB/launch -- the working set is L2/MALL resident, HBM is not the bound)" % (n_st, reps),
+        }
+        out["roofline_step"] = {
             "bound": "mfma", "achieved": flop * per_gpu_steps / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": flop * per_gpu_steps / 1e12 / FP32_PEAK_TFLOPS, "traffic": None,
-            "note": "whole update step = one launch chain (one hipGraph replay = 2 steps); algorithmic FLOP/step "
-                    "= %.4g (SURVEY.md 8d), fp32 MFMA/VALU peak" % flop,
+            "frac": flop * per_gpu_steps / 1e12 / FP32_PEAK_TFLOPS,
+            "note": "whole update (one launch chain); algorithmic FLOP/step = %.4g (SURVEY.md 8d)" % flop,
         }
         out["roofline_hbm"] = {
             "bound": "hbm", "achieved": byts * per_gpu_steps / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

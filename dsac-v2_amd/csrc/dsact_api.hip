@@ -39,6 +39,7 @@ struct Stage {            // one k_stage launch: <= kMaxProb GEMM problems in th
   StageArgs args;
   int n_blocks = 0;
   int max_k = 0;          // longest contraction of the stage -> dynamic LDS
+  int ts = -1;            // >0: every problem is clean with K == ts*64 -> specialised kernel; 0: general
   int kind = 0;           // 0 forward (KC x KC, bias+GELU), 1 backward (KC x MC, * GELU'), 2 KC x MC plain store
 };
 
@@ -288,6 +289,8 @@ void stage_add(Stage& s, GemmProb g) {
   s.n_blocks += nt;
   g.tile_end = s.n_blocks;
   if (g.K > s.max_k) s.max_k = g.K;
+  const int clean = (g.M % TM == 0 && g.N % TN == 0 && g.K % BK == 0) ? g.K / BK : 0;
+  s.ts = s.ts < 0 ? clean : (s.ts == clean ? clean : 0);
   s.args.p[s.args.n_prob++] = g;
 }
 
@@ -450,6 +453,16 @@ int run_stage(dsact_handle* h, const Stage& s0, int x0 = 0, int x1 = 0, bool fus
   const int grid = s.n_blocks + s.args.n_extra;
   size_t lds = tile_lds_bytes(s.max_k);
   if (s.args.n_extra && tile_lds_bytes(h->B) > lds) lds = tile_lds_bytes(h->B);
+  // clean stages (hidden layers of 128 / 256 units at batch sizes that are multiples of 32) use the
+  // straight-line specialisations
+#define STAGE_TS(PM, QM, EP)                                                                                     \
+  do {                                                                                                           \
+    if (s.ts == 4) return launch(h, s.name.c_str(), k_stage<PM, QM, EP, 4>, dim3(grid), dim3(kThreads), lds, s.args); \
+    if (s.ts == 2) return launch(h, s.name.c_str(), k_stage<PM, QM, EP, 2>, dim3(grid), dim3(kThreads), lds, s.args); \
+  } while (0)
+  if (s.kind == 0) STAGE_TS(false, false, EPI_GELU);
+  if (s.kind == 1) STAGE_TS(false, true, EPI_MULG);
+#undef STAGE_TS
   if (s.kind == 0)
     return launch(h, s.name.c_str(), k_stage<false, false, EPI_GELU>, dim3(grid), dim3(kThreads), lds, s.args);
   if (s.kind == 2)
@@ -755,6 +768,10 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   {
     const int max_lds = (int)tile_lds_bytes(BK * kMaxPrefetchTiles);  // 129 KB of the CU's 160 KB
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, false, EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, false, EPI_GELU, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, false, EPI_GELU, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, true, EPI_MULG, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, true, EPI_MULG, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, true, EPI_MULG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage_table, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, true, EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
@@ -1210,6 +1227,35 @@ int dsact_time_steps(dsact_handle* h, int64_t first_iteration, int64_t n_steps, 
   HIPCHK(h, hipEventElapsedTime(ms_total, e0, e1));
   hipEventDestroy(e0);
   hipEventDestroy(e1);
+  return DSACT_OK;
+}
+
+int dsact_time_stage(dsact_handle* h, int32_t stage, int32_t reps, float* ms_total, double* macs) {
+  if (!h || !ms_total || reps < 1) return DSACT_E_INVALID;
+  TRY(check_ready(h, false));
+  const int L = h->L;
+  if (stage < 0 || stage >= 2 * L) return fail(h, DSACT_E_INVALID, "stage must be in 0..%d", 2 * L - 1);
+  HIPCHK(h, hipSetDevice(h->device));
+  const Stage& s = stage < L ? h->fwd1[stage] : h->fwd2[stage - L];
+  if (macs) {
+    double m = 0;
+    for (int i = 0; i < s.args.n_prob; ++i) m += (double)s.args.p[i].M * s.args.p[i].N * s.args.p[i].K;
+    *macs = m;
+  }
+  const bool was_prof = h->profiling;
+  h->profiling = false;
+  hipEvent_t e0, e1;
+  HIPCHK(h, hipEventCreate(&e0));
+  HIPCHK(h, hipEventCreate(&e1));
+  for (int i = 0; i < 20; ++i) TRY(run_stage(h, s));  // warm-up
+  HIPCHK(h, hipEventRecord(e0, h->stream));
+  for (int i = 0; i < reps; ++i) TRY(run_stage(h, s));
+  HIPCHK(h, hipEventRecord(e1, h->stream));
+  HIPCHK(h, hipEventSynchronize(e1));
+  HIPCHK(h, hipEventElapsedTime(ms_total, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  h->profiling = was_prof;
   return DSACT_OK;
 }
 

@@ -385,6 +385,10 @@ __device__ __forceinline__ f32x4 tile_load1(const float* __restrict__ base, int 
   }
 }
 
+__device__ __forceinline__ f32x4 gload4(const float* p) {  // global (not flat) dwordx4, 4-byte aligned
+  return *(const __attribute__((address_space(1))) f32x4u*)p;
+}
+
 template <bool MC>
 __device__ __forceinline__ void tile_store_lds(float* lds, int tid, const f32x4& r0, const f32x4& r1) {
   if (!MC) {
@@ -479,7 +483,9 @@ __device__ __forceinline__ OpCursor<MC> make_cursor(const float* base, int ld, i
   return c;
 }
 
-template <bool P_MC, bool Q_MC, int EPI>
+// TS > 0: compile-time specialisation for "clean" problems (M, N multiples of 32, K == TS*64): the load
+// block is straight-line code -- 4*TS dwordx4 loads back to back, no bounds logic, no branches.
+template <bool P_MC, bool Q_MC, int EPI, int TS = 0>
 __device__ __forceinline__ void run_tile(const GemmProb& t, int m0, int n0, float* lds, long long* tl_buf = nullptr,
                                          int tl_slot = 0, const FusedOpt* fo = nullptr) {
   TL_DECL
@@ -544,7 +550,27 @@ __device__ __forceinline__ void run_tile(const GemmProb& t, int m0, int n0, floa
       Q1 = tile_load1<Q_MC>(t.Q, t.ldq, n0, t.N, (IT) * BK, t.K, tid, 1);                           \
     }                                                                                               \
   } while (0)
-  if (T <= kMaxPrefetchTiles) {
+  if constexpr (TS > 0) {
+    f32x4 pr[TS][2], qr[TS][2];
+#pragma unroll
+    for (int it = 0; it < TS; ++it) {
+      pr[it][0] = gload4(pc.p0 + (size_t)it * pc.step);
+      pr[it][1] = gload4(pc.p1 + (size_t)it * pc.step);
+      qr[it][0] = gload4(qc.p0 + (size_t)it * qc.step);
+      qr[it][1] = gload4(qc.p1 + (size_t)it * qc.step);
+    }
+    TL_STAMP();  // 1: all loads issued
+#pragma unroll
+    for (int it = 0; it < TS; ++it) {
+      tile_store_lds<P_MC>(lds + it * 2 * TILE_LDS, tid, pr[it][0], pr[it][1]);
+      tile_store_lds<Q_MC>(lds + it * 2 * TILE_LDS + TILE_LDS, tid, qr[it][0], qr[it][1]);
+    }
+    __syncthreads();
+    TL_STAMP();  // 2: every k-tile landed and staged
+#pragma unroll
+    for (int it = 0; it < TS; ++it)
+      tile_mma<P_MC, Q_MC>(lds + it * 2 * TILE_LDS, lds + it * 2 * TILE_LDS + TILE_LDS, wr * 16 + i, wc * 16 + i, g, acc0, acc1);
+  } else if (T <= kMaxPrefetchTiles) {
     f32x4 pr[kMaxPrefetchTiles][2], qr[kMaxPrefetchTiles][2];
 #pragma unroll
     for (int it = 0; it < kMaxPrefetchTiles; ++it) {
@@ -655,7 +681,7 @@ struct StageArgs {
   long long* timeline;     // DSACT_TIMELINE builds only (else unused)
 };
 
-template <bool P_MC, bool Q_MC, int EPI>
+template <bool P_MC, bool Q_MC, int EPI, int TS = 0>
 __global__ void __launch_bounds__(kThreads) k_stage(StageArgs s) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // tile_lds_bytes(max K of the launch)
   const int b = xcd_logical_block(blockIdx.x, gridDim.x);
@@ -671,7 +697,7 @@ __global__ void __launch_bounds__(kThreads) k_stage(StageArgs s) {
   const GemmProb& g = s.p[pi];
   const int local = b - (pi ? s.p[pi - 1].tile_end : 0);
   const int mt = local / g.tiles_n, nt = local - mt * g.tiles_n;
-  run_tile<P_MC, Q_MC, EPI>(g, mt * TM, nt * TN, lds, s.timeline, (int)blockIdx.x);
+  run_tile<P_MC, Q_MC, EPI, TS>(g, mt * TM, nt * TN, lds, s.timeline, (int)blockIdx.x);
 }
 
 // ---- stage launch form 2: many small problems (weight / bias gradients) from a device table ------

@@ -230,6 +230,12 @@ class DsactEngine:
                                              1 if use_graph else 0, C.byref(ms)))
         return float(ms.value)
 
+    def time_stage(self, stage: int, reps: int = 200):
+        """(milliseconds for `reps` launches, multiply-accumulates per launch) of one forward tile stage"""
+        ms, macs = C.c_float(), C.c_double()
+        self._chk(self._lib.dsact_time_stage(self._h, int(stage), int(reps), C.byref(ms), C.byref(macs)))
+        return float(ms.value), float(macs.value)
+
     def profile_step(self, iteration: int, flags: int = 0):
         arr = (_ffi.KernelTime * 64)()
         n = C.c_int32()

@@ -159,6 +159,11 @@ int dsact_read_stats(dsact_handle* h, float out[16]);
 /* time n replays of the step on the handle's stream with hipEvents: total milliseconds */
 int dsact_time_steps(dsact_handle* h, int64_t first_iteration, int64_t n_steps, uint32_t flags,
                      int32_t use_graph, float* ms_total);
+/* hipEvent timing of `reps` back-to-back launches of ONE forward tile stage (k_stage<KC,KC,GELU>,
+ * stage index 0..2*n_hidden-1: group A layers then group B layers) on the handle's stream; also
+ * returns the stage's algorithmic multiply-accumulate count. Leaves the activations of that stage
+ * overwritten (measurement only). */
+int dsact_time_stage(dsact_handle* h, int32_t stage, int32_t reps, float* ms_total, double* macs);
 /* per-kernel hipEvent timing of ONE eager step: fills up to `cap` entries; returns count in *n */
 typedef struct dsact_kernel_time {
   char name[32];

@@ -412,3 +412,36 @@ def test_skip_discarded_actor_backward_keeps_trajectory():
     assert outs[0][4] == outs[1][4]
     for k in outs[0][5]:
         assert outs[0][5][k] == outs[1][5][k], k
+
+
+def test_data_parallel_halves_equal_graph_replay():
+    """dsact_dp_enqueue_grads + (all-reduce) + dsact_dp_enqueue_apply through the DataParallelUpdater
+    (world size 1 here: gpurun exposes one GPU) == the fused graph replay, bit for bit."""
+    import torch.distributed as dist
+    from dsact.dp import DataParallelUpdater
+
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        created = True
+    try:
+        a1 = _replay_pair(17, 4, (64, 64), 64, 4096, seed=4)
+        a1.engine.graph_build(2)
+        a1.engine.graph_run(0, 6)
+        a1.engine.sync()
+        a2 = _replay_pair(17, 4, (64, 64), 64, 4096, seed=4)
+        e = a2.engine
+        e.use_torch_stream()
+        dp = DataParallelUpdater(e, broadcast_tensors=(e.online, e.target, e.adam_m, e.adam_v))
+        e.dp_begin(0)
+        for _ in range(6):
+            dp.step()
+        torch.cuda.synchronize()
+        for name in ("online", "target", "adam_m", "adam_v"):
+            assert torch.equal(getattr(a1.engine, name), getattr(e, name)), name
+        assert a1.engine.get_state() == e.get_state()
+    finally:
+        if created:
+            dist.destroy_process_group()
