@@ -741,18 +741,27 @@ __global__ void __launch_bounds__(kThreads) k_stage_table(TableArgs a) {
 // dwordx4 loads -- a dependent L2/MALL round trip costs ~0.7 us, so N_out sequential dot products
 // would cost N_out round trips; a group costs one.
 // ---------------------------------------------------------------------------------------------
+// RAW row fetch: the elements beyond W are NOT zeroed here -- a select on a just-loaded register makes
+// the wave wait for that load before it can issue the next one. Callers apply row_mask() after all
+// their loads are in flight.
 template <int NCH>
 __device__ __forceinline__ void row_load(const float* x, int W, int lane, f32x4 (&r)[NCH]) {
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int k = c * 256 + lane * 4;
-    const int kc = k < W ? k : 0;
-    f32x4 v = *(const f32x4u*)(x + kc);   // may over-read <= 12 B inside the workspace
-    v.x = k < W ? v.x : 0.f;
-    v.y = k + 1 < W ? v.y : 0.f;
-    v.z = k + 2 < W ? v.z : 0.f;
-    v.w = k + 3 < W ? v.w : 0.f;
-    r[c] = v;
+    r[c] = *(const f32x4u*)(x + (k < W ? k : 0));   // may over-read <= 12 B inside the workspace
+  }
+}
+template <int NCH>
+__device__ __forceinline__ void row_mask(f32x4 (&r)[NCH], int W, int lane) {
+  if ((W & 255) == 0 && NCH * 256 == ((W + 255) & ~255)) return;  // every lane of every chunk is inside the row
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int k = c * 256 + lane * 4;
+    r[c].x = k < W ? r[c].x : 0.f;
+    r[c].y = k + 1 < W ? r[c].y : 0.f;
+    r[c].z = k + 2 < W ? r[c].z : 0.f;
+    r[c].w = k + 3 < W ? r[c].w : 0.f;
   }
 }
 
@@ -771,12 +780,16 @@ __device__ __forceinline__ void row_dots(const f32x4 (&h)[NCH], const float* w, 
       wv[q][c] = *(const f32x4u*)(w + (size_t)n * W + (k < W ? k : 0));
     }
   }
+  f32x4 hm[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) hm[c] = h[c];
+  row_mask<NCH>(hm, W, lane);   // h comes from row_load (raw): zero what lies beyond the row, now that the loads are out
 #pragma unroll
   for (int q = 0; q < G; ++q) {
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      s += h[c].x * wv[q][c].x; s += h[c].y * wv[q][c].y; s += h[c].z * wv[q][c].z; s += h[c].w * wv[q][c].w;
+      s += hm[c].x * wv[q][c].x; s += hm[c].y * wv[q][c].y; s += hm[c].z * wv[q][c].z; s += hm[c].w * wv[q][c].w;
     }
     out[q] = wave_sum(s);
   }
@@ -919,14 +932,29 @@ __global__ void __launch_bounds__(kThreads) k_loss(LossArgs a) {
   // ---------------- all loads ----------------
   float s1 = 0.f, s2 = 0.f;
   if (a.std_sums == nullptr) {
-    for (int rr = lane; rr < a.B; rr += 64) { s1 += a.qstd_c[0][2 * rr]; s2 += a.qstd_c[1][2 * rr]; }
+    // 4 independent (clamped) loads per column and trip: a plain accumulate loop compiles to
+    // load -> wait -> add per element, i.e. one memory round trip per 64 samples
+    for (int i0 = 0; i0 < a.B; i0 += 256) {
+      float v1[4], v2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = i0 + u * 64 + lane;
+        const int rc = rr < a.B ? rr : 0;
+        v1[u] = a.qstd_c[0][2 * rc]; v2[u] = a.qstd_c[1][2 * rc];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool ok = i0 + u * 64 + lane < a.B;
+        s1 += ok ? v1[u] : 0.f; s2 += ok ? v2[u] : 0.f;
+      }
+    }
   } else if (lane == 0) { s1 = a.std_sums[0]; s2 = a.std_sums[1]; }
   const float q1 = a.qout_c[0][2 * r], q2 = a.qout_c[1][2 * r];
   const float std1 = a.qstd_c[0][2 * r], sg1 = a.qstd_c[0][2 * r + 1];
   const float std2 = a.qstd_c[1][2 * r], sg2 = a.qstd_c[1][2 * r + 1];
   const float in_z5 = a.z5[r], in_z6 = a.z6[r], rew = a.rew[r], in_done = a.done[r];
   const float lp2 = a.logp2[r], lpn = a.logp_new[r];
-  const float la = a.auto_alpha ? a.log_alpha[0] : 0.f;
+  const float la = a.log_alpha[0];   // unconditional: a load inside a branch is drained at the join
   const float ms1_old = a.st->ms1, ms2_old = a.st->ms2;
   const int ms_init = a.st->ms_init;
   float bo[4][2];
@@ -946,6 +974,8 @@ __global__ void __launch_bounds__(kThreads) k_loss(LossArgs a) {
     }
   }
   TL_STAMP();  // 1: loads issued
+#pragma unroll
+  for (int c = 0; c < 4; ++c) row_mask<NCH>(h[c], a.W, lane);
   // ---------------- 2: output layers ----------------
   float o[4][2];
 #pragma unroll
@@ -1068,7 +1098,16 @@ __global__ void __launch_bounds__(kThreads) k_heads_bwd(HeadsBwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (blockIdx.x == 0 && wave == 0) {
     float s = 0.f;
-    for (int i = lane; i < a.n_part; i += 64) s += a.part_loss[i * kLossPart + 7];
+    for (int i0 = 0; i0 < a.n_part; i0 += 256) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 64 + lane;
+        v[u] = a.part_loss[(size_t)(i < a.n_part ? i : 0) * kLossPart + 7];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += (i0 + u * 64 + lane < a.n_part) ? v[u] : 0.f;
+    }
     s = wave_sum(s);
     if (lane == 0) a.grad_log_alpha[0] = a.auto_alpha ? -(s * a.inv_B + a.target_entropy) : 0.0f;
   }
@@ -1089,11 +1128,8 @@ __global__ void __launch_bounds__(kThreads) k_heads_bwd(HeadsBwdArgs a) {
     for (int c = 0; c < 4; ++c) {
       const int k = c * 256 + lane * 4;
       const int kc = k < a.W0 ? k : 0;
-      f32x4 v1 = *(const f32x4u*)(a.dZ1[0] + (size_t)r * a.W0 + kc);
-      f32x4 v2 = *(const f32x4u*)(a.dZ1[1] + (size_t)r * a.W0 + kc);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) if (k + e >= a.W0) { v1[e] = 0.f; v2[e] = 0.f; }
-      d1[c] = v1; d2[c] = v2;
+      d1[c] = *(const f32x4u*)(a.dZ1[0] + (size_t)r * a.W0 + kc);   // raw: zeroed beyond the row at use time
+      d2[c] = *(const f32x4u*)(a.dZ1[1] + (size_t)r * a.W0 + kc);
     }
     const int nch0 = (a.W0 + 255) >> 8;
     // groups of 12 action dimensions: 24 independent row loads per chunk, then 12 DPP reductions.
@@ -1114,8 +1150,10 @@ __global__ void __launch_bounds__(kThreads) k_heads_bwd(HeadsBwdArgs a) {
           w1[q] = *(const f32x4u*)(a.W1aT[0] + (size_t)j * a.W0 + kc);
           w2[q] = *(const f32x4u*)(a.W1aT[1] + (size_t)j * a.W0 + kc);
         }
-        const f32x4 e1 = c == 0 ? d1[0] : c == 1 ? d1[1] : c == 2 ? d1[2] : d1[3];
-        const f32x4 e2 = c == 0 ? d2[0] : c == 1 ? d2[1] : c == 2 ? d2[2] : d2[3];
+        f32x4 e1 = c == 0 ? d1[0] : c == 1 ? d1[1] : c == 2 ? d1[2] : d1[3];
+        f32x4 e2 = c == 0 ? d2[0] : c == 1 ? d2[1] : c == 2 ? d2[2] : d2[3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (k + e >= a.W0) { e1[e] = 0.f; e2[e] = 0.f; }
 #pragma unroll
         for (int q = 0; q < JG; ++q)
 #pragma unroll
