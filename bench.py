@@ -243,7 +243,7 @@ def main():
         out["roofline"] = {
             "bound": "mfma", "achieved": flop_launch / (dur_us * 1e-6) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": flop_launch / (dur_us * 1e-6) / 1e12 / FP32_PEAK_TFLOPS, "traffic": None,
-            "kernel": "dsact::k_stage<false,false,0> (forward tile stage, 4 GEMM problems per launch)",
+            "kernel": "dsact::k_stage<false,false,0,{0,4}> (forward tile stages: bias+GELU epilogue, 4 GEMM problems per launch)",
             "avg_launch_us": dur_us, "flop_per_launch": flop_launch,
             "note": "fp32 MFMA peak; avg over the %d forward stages, %d back-to-back launches each (hipEvents on the engine's "
                     "stream); algorithmic FLOP = 2*M*N*K of the stage's problems. traffic: see profiles/ (PMC FETCH_SIZE "
