@@ -445,3 +445,110 @@ def test_data_parallel_halves_equal_graph_replay():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_error_paths_are_loud():
+    from dsact._ffi import DsactError
+    from dsact.engine import DsactEngine
+
+    e = DsactEngine(7, 2, (32,), 8)
+    with pytest.raises(DsactError):       # arenas bound, but no action limits / minibatch yet
+        e.step(0)
+    e.set_action_limits(np.ones(2, np.float32), -np.ones(2, np.float32))
+    with pytest.raises(DsactError):       # no minibatch staged
+        e.step(0)
+    with pytest.raises(DsactError):       # gather before the ring exists
+        e.gather(np.zeros(8, np.int64))
+    e.buffer_create(16)
+    with pytest.raises(DsactError):       # empty ring (reference: np.random.randint(0, 0) raises too)
+        e.gather(np.zeros(8, np.int64))
+    e.buffer_add(np.zeros((4, 7), np.float32), np.zeros((4, 2), np.float32), np.zeros(4, np.float32),
+                 np.zeros((4, 7), np.float32), np.zeros(4, np.float32))
+    with pytest.raises(DsactError):       # index beyond `size`
+        e.gather(np.full(8, 4, np.int64))
+    with pytest.raises(DsactError):       # wrong batch
+        e.gather(np.zeros(5, np.int64))
+    with pytest.raises(DsactError):
+        e.set_action_limits(np.zeros(2, np.float32), np.zeros(2, np.float32))
+    with pytest.raises(DsactError):
+        DsactEngine(7, 40, (32,), 8)      # act_dim > 32
+    with pytest.raises(DsactError):
+        e.graph_build(2)                   # no index table
+    e.gather(np.array([0, 1, 2, 3, 3, 2, 1, 0], np.int64))
+    e.step(0)
+    assert all(np.isfinite(v) for v in e.read_stats().values())
+
+
+def test_state_save_restore_continues_identically():
+    """optimizer moments + Adam counters + mean_std EMA are not in the reference's checkpoints; the sidecar
+    (dsact_get_state/set_state + the arenas) must resume the run bit-for-bit."""
+    O, A, hid, B = 13, 3, (64, 64), 32
+    a1, _ = make_pair(O, A, hid, B, seed=5)
+    rng = np.random.default_rng(11)
+    batches = [synth_batch(rng, B, O, A) for _ in range(6)]
+    torch.manual_seed(21)
+    noises = [draw_noise(B, A) for _ in range(6)]
+
+    def run(alg, its):
+        for it in its:
+            d, n = batches[it], noises[it]
+            alg.engine.load_batch(*(d[k].numpy() for k in ("obs", "act", "rew", "obs2", "done")))
+            alg.engine.set_noise(n["eps_new"].numpy(), n["eps_2"].numpy(), n["z5"].numpy(), n["z6"].numpy())
+            alg.engine.step(it)
+        alg.engine.sync()
+
+    run(a1, range(3))
+    sd = {k: v.clone() for k, v in a1.networks.state_dict().items()}
+    side = dict(a1.engine.get_state(), m=a1.engine.adam_m.clone(), v=a1.engine.adam_v.clone())
+    run(a1, range(3, 6))
+    a2, _ = make_pair(O, A, hid, B, seed=99)          # different init, then restored
+    a2.networks.load_state_dict(sd)
+    a2.engine.adam_m.copy_(side["m"]); a2.engine.adam_v.copy_(side["v"])
+    torch.cuda.synchronize()
+    a2.engine.set_state(side["adam_steps"], side["mean_std"])
+    run(a2, range(3, 6))
+    assert torch.equal(a1.engine.online, a2.engine.online)
+    assert torch.equal(a1.engine.target, a2.engine.target)
+    assert a1.engine.get_state() == a2.engine.get_state()
+
+
+def test_full_size_replay_gather_and_determinism():
+    """BASELINE.json configs[1] sizes: 1M-row ring in HBM, batch 256 -- gathered rows equal torch's
+    index_select on the same device arrays (bit-exact), and two replays of the same 8 updates agree bit-for-bit."""
+    from dsact.engine import DsactEngine
+
+    O, A, B, N = 376, 17, 256, 1_000_000
+    outs = []
+    for rep in range(2):
+        alg, _ = make_pair(O, A, (256, 256), B, seed=1)
+        e = alg.engine
+        e.set_device_rng(7)
+        e.buffer_create(N)
+        g = torch.Generator(device="cuda").manual_seed(3)
+        cols = {}
+        for r0 in range(0, N, 250_000):
+            n = 250_000
+            obs = torch.randn(n, O, device="cuda", generator=g); obs2 = torch.randn(n, O, device="cuda", generator=g)
+            act = torch.rand(n, A, device="cuda", generator=g) - .5; rew = torch.randn(n, device="cuda", generator=g)
+            done = (torch.rand(n, device="cuda", generator=g) < .01).float()
+            e.buffer_fill_device(r0, obs, act, rew, obs2, done)
+            if r0 == 750_000:
+                cols = dict(obs=obs, obs2=obs2, act=act, rew=rew, done=done)
+        assert e.buffer_size == N and e.buffer_ptr == 0
+        np.random.seed(5)
+        idx = np.random.randint(750_000, N, size=B)
+        e.gather(idx)
+        got = e.read_batch(with_logp=False)
+        ti = torch.as_tensor(idx - 750_000, device="cuda")
+        for k in ("obs", "obs2", "act", "rew", "done"):
+            assert np.array_equal(got[k], cols[k].index_select(0, ti).cpu().numpy()), k
+        np.random.seed(6)
+        e.upload_index_table(np.random.randint(0, N, size=(8, B)))
+        e.graph_build(2)
+        e.graph_run(0, 8)
+        e.sync()
+        outs.append((e.online.clone(), e.read_stats()))
+        del alg, e, cols
+        torch.cuda.empty_cache()
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1]
