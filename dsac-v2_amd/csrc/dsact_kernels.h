@@ -389,24 +389,24 @@ __device__ __forceinline__ f32x4 gload4(const float* p) {  // global (not flat) 
   return *(const __attribute__((address_space(1))) f32x4u*)p;
 }
 
+// LDS image of a staged k-tile is ALWAYS [32 rows][KC_LD] with k contiguous, whatever the operand's
+// layout in memory: an MC operand (rows contiguous in memory) is transposed on the way in (4 scalar
+// ds_write_b32 per vector), so that every MFMA fragment is ONE ds_read_b128 instead of four ds_read_b32.
 template <bool MC>
 __device__ __forceinline__ void tile_store_lds(float* lds, int tid, const f32x4& r0, const f32x4& r1) {
   if (!MC) {
     *(f32x4*)(lds + (tid >> 4) * KC_LD + (tid & 15) * 4) = r0;
     *(f32x4*)(lds + ((tid >> 4) + 16) * KC_LD + (tid & 15) * 4) = r1;
   } else {
-    *(f32x4*)(lds + (tid >> 3) * MC_LD + (tid & 7) * 4) = r0;
-    *(f32x4*)(lds + ((tid >> 3) + 32) * MC_LD + (tid & 7) * 4) = r1;
+    const int k = tid >> 3, row = (tid & 7) * 4;
+    float* p = lds + row * KC_LD + k;
+    p[0] = r0.x; p[KC_LD] = r0.y; p[2 * KC_LD] = r0.z; p[3 * KC_LD] = r0.w;
+    p[32] = r1.x; p[KC_LD + 32] = r1.y; p[2 * KC_LD + 32] = r1.z; p[3 * KC_LD + 32] = r1.w;
   }
 }
 
-template <bool MC>
 __device__ __forceinline__ f32x4 frag_read(const float* lds, int row, int kk, int g) {
-  if (!MC) return *(const f32x4*)(lds + row * KC_LD + kk * 16 + 4 * g);
-  f32x4 v;
-  const float* p = lds + (kk * 16 + 4 * g) * MC_LD + row;
-  v.x = p[0]; v.y = p[MC_LD]; v.z = p[2 * MC_LD]; v.w = p[3 * MC_LD];
-  return v;
+  return *(const f32x4*)(lds + row * KC_LD + kk * 16 + 4 * g);
 }
 
 template <bool P_MC, bool Q_MC>
@@ -414,8 +414,8 @@ __device__ __forceinline__ void tile_mma(const float* ps, const float* qs, int p
                                          f32x4& acc1) {
 #pragma unroll
   for (int kk = 0; kk < BK / 16; ++kk) {
-    const f32x4 p = frag_read<P_MC>(ps, prow, kk, g);
-    const f32x4 q = frag_read<Q_MC>(qs, qrow, kk, g);
+    const f32x4 p = frag_read(ps, prow, kk, g);
+    const f32x4 q = frag_read(qs, qrow, kk, g);
     // D[row = n][col = m]: lane holds n = 4*g + reg, m = lane & 15
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.x, p.x, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.y, p.y, acc1, 0, 0, 0);
