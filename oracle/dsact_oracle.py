@@ -152,13 +152,12 @@ class DsactOracle:
 
     def __init__(self, cfg: Dict, state_dict: Optional[Dict[str, torch.Tensor]] = None):
         self.cfg = cfg
-        O, A, hid = cfg["obs_dim"], cfg["act_dim"], list(cfg["hidden"])
         self.act_high = torch.as_tensor(np.asarray(cfg["act_high"], dtype=np.float32))
         self.act_low = torch.as_tensor(np.asarray(cfg["act_low"], dtype=np.float32))
         # construction order of ApproxContainer.__init__ (dsac_v2.py:31-51)
-        q1 = _new_mlp_params([O + A] + hid + [2])
-        q2 = _new_mlp_params([O + A] + hid + [2])
-        pi = _new_mlp_params([O] + hid + [2 * A])
+        q1 = self._new_q_params()
+        q2 = self._new_q_params()
+        pi = self._new_pi_params()
         self.p = {
             "q1": q1, "q2": q2,
             "q1_target": [t.clone() for t in q1], "q2_target": [t.clone() for t in q2],
@@ -182,6 +181,21 @@ class DsactOracle:
         self.mean_std1 = -1.0  # dsac_v2.py:88-89 sentinel
         self.mean_std2 = -1.0
         self.inter = {}  # intermediates of the last compute_gradient (per-kernel parity tests)
+
+    # ---- networks: overridden by the CNN oracle (oracle/dsact_oracle_cnn.py) ----------------
+    def _new_q_params(self):
+        cfg = self.cfg
+        return _new_mlp_params([cfg["obs_dim"] + cfg["act_dim"]] + list(cfg["hidden"]) + [2])
+
+    def _new_pi_params(self):
+        cfg = self.cfg
+        return _new_mlp_params([cfg["obs_dim"]] + list(cfg["hidden"]) + [2 * cfg["act_dim"]])
+
+    def _pi(self, obs, params, collect=None):
+        return policy_forward(obs, params, self.cfg, collect)
+
+    def _q(self, obs, act, params, collect=None):
+        return q_forward(obs, act, params, collect)
 
     # ---- checkpoint format (training/trainer.py:148-152) -----------------
     def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
@@ -230,7 +244,7 @@ class DsactOracle:
             return [] if keep else None
 
         c_pi = col()
-        logits = policy_forward(obs, self.p["policy"], cfg, c_pi)
+        logits = self._pi(obs, self.p["policy"], c_pi)
         logits_mean, logits_std = torch.chunk(logits, chunks=2, dim=-1)
         policy_mean = torch.tanh(logits_mean).mean().item()
         policy_std = logits_std.mean().item()
@@ -239,11 +253,11 @@ class DsactOracle:
         for n in ("q1", "q2"):
             self.opt[n].zero_grad()
         # ---- __compute_loss_q (dsac_v2.py:218-290) ----
-        logits_2 = policy_forward(obs2, self.p["policy_target"], cfg)
+        logits_2 = self._pi(obs2, self.p["policy_target"])
         act2, log_prob_act2 = tanh_gauss_rsample(logits_2, noise["eps_2"], self.act_high, self.act_low)
         c_q1, c_q2 = col(), col()
-        q1, q1_std = q_forward(obs, act, self.p["q1"], c_q1)
-        q2, q2_std = q_forward(obs, act, self.p["q2"], c_q2)
+        q1, q1_std = self._q(obs, act, self.p["q1"], c_q1)
+        q2, q2_std = self._q(obs, act, self.p["q2"], c_q2)
         tau_b = cfg["tau_b"]
         if isinstance(self.mean_std1, float) and self.mean_std1 == -1.0:
             self.mean_std1 = torch.mean(q1_std.detach())
@@ -253,8 +267,8 @@ class DsactOracle:
             self.mean_std2 = torch.mean(q2_std.detach())
         else:
             self.mean_std2 = (1 - tau_b) * self.mean_std2 + tau_b * torch.mean(q2_std.detach())
-        q1_next, q1n_std = q_forward(obs2, act2, self.p["q1_target"])
-        q2_next, q2n_std = q_forward(obs2, act2, self.p["q2_target"])
+        q1_next, q1n_std = self._q(obs2, act2, self.p["q1_target"])
+        q2_next, q2n_std = self._q(obs2, act2, self.p["q2_target"])
         q1_next_sample = self._q_eval(q1_next, q1n_std, noise["z5"])
         q2_next_sample = self._q_eval(q2_next, q2n_std, noise["z6"])
         q_next = torch.min(q1_next, q2_next)
@@ -292,8 +306,8 @@ class DsactOracle:
                 t.requires_grad_(False)
         self.opt["policy"].zero_grad()
         c_q1p, c_q2p = col(), col()
-        q1_pi, _ = q_forward(obs, new_act, self.p["q1"], c_q1p)
-        q2_pi, _ = q_forward(obs, new_act, self.p["q2"], c_q2p)
+        q1_pi, _ = self._q(obs, new_act, self.p["q1"], c_q1p)
+        q2_pi, _ = self._q(obs, new_act, self.p["q2"], c_q2p)
         loss_policy = (alpha * new_log_prob - torch.min(q1_pi, q2_pi)).mean()
         entropy = -new_log_prob.detach().mean()
         if keep:

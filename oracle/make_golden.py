@@ -150,6 +150,41 @@ def gen_checkpoint_layout(ref, out_dir):
     print("wrote checkpoint_layout.json")
 
 
+def gen_cnn_case(ref, out_dir):
+    """CNN approximators: nets and minibatches regenerate from seeds
+    (torch.manual_seed / numpy default_rng are part of the recorded versions), so the fixture holds
+    digests only: tb_info, per-tensor gradient sums and L2 norms, per-tensor parameter sums after the
+    update -- a 2.4M-parameter container per net would not be a small fixture."""
+    from oracle.dsact_oracle_cnn import cnn_config, synth_image_batch
+
+    obs_shape, A, conv_type, B, steps = (3, 96, 96), 3, "type_2", 8, 3
+    kw = ref_loader.reference_kwargs(obs_shape, A, (256, 256, 256), act_limit=1.0)
+    for key in ("value", "policy"):
+        kw[key + "_func_type"] = "CNN"
+        kw[key + "_conv_type"] = conv_type
+        kw.pop(key + "_hidden_sizes")
+    torch.manual_seed(0)
+    alg = ref.DSAC_V2(**kw)
+    nets = alg.networks
+    cfg = cnn_config(obs_shape, A, conv_type)
+    out = {"cfg_obs_shape": np.array(obs_shape), "cfg_act_dim": A, "cfg_conv_type": conv_type, "cfg_batch": B,
+           "cfg_steps": steps, "versions": np.array([torch.__version__, np.__version__]),
+           "keys": np.array(list(nets.state_dict().keys())),
+           "shapes": np.array([str(list(v.shape)) for v in nets.state_dict().values()]),
+           "init_sums": np.array([float(v.double().sum()) for v in nets.state_dict().values()])}
+    for it in range(steps):
+        d = synth_image_batch(cfg, B, seed=it)
+        torch.manual_seed(1000 + it)
+        tb = alg.local_update({k: v.clone() for k, v in d.items()}, it)
+        out["s%d/tb" % it] = np.array([float(tb[k]) for k in TB_KEYS[:-1]], np.float64)
+        online = list(nets.q1.parameters()) + list(nets.q2.parameters()) + list(nets.policy.parameters())
+        out["s%d/grad_sum" % it] = np.array([float(p.grad.double().sum()) for p in online])
+        out["s%d/grad_l2" % it] = np.array([float(p.grad.double().norm()) for p in online])
+        out["s%d/param_sums" % it] = np.array([float(v.double().sum()) for v in nets.state_dict().values()])
+    np.savez_compressed(os.path.join(out_dir, "step_cnn_type2.npz"), **out)
+    print("wrote step_cnn_type2.npz")
+
+
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
@@ -159,6 +194,7 @@ def main():
         gen_step_case(ref, name, spec, out_dir)
     gen_replay(out_dir)
     gen_checkpoint_layout(ref, out_dir)
+    gen_cnn_case(ref, out_dir)
 
 
 if __name__ == "__main__":

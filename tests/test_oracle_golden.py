@@ -70,3 +70,32 @@ def test_index_draw_restatement_bit_exact(n):
     np.testing.assert_array_equal(got, want)
     np.random.seed(1)
     np.testing.assert_array_equal(np.random.randint(0, n, size=700), want)
+
+
+def test_cnn_step_matches_reference_golden():
+    """CNN approximators (networks/cnn.py, conv_type type_2): digests recorded from the unmodified
+    reference by oracle/make_golden.py::gen_cnn_case; nets and minibatches regenerate from seeds."""
+    from oracle.dsact_oracle import draw_noise
+    from oracle.dsact_oracle_cnn import DsactCnnOracle, cnn_config, synth_image_batch
+
+    torch.set_num_threads(2)
+    z = np.load(os.path.join(GOLDEN, "step_cnn_type2.npz"))
+    cfg = cnn_config(tuple(int(v) for v in z["cfg_obs_shape"]), int(z["cfg_act_dim"]), str(z["cfg_conv_type"]))
+    torch.manual_seed(0)
+    orc = DsactCnnOracle(cfg)
+    sd = orc.state_dict()
+    assert list(sd.keys()) == [str(k) for k in z["keys"]]
+    assert [str(list(v.shape)) for v in sd.values()] == [str(s) for s in z["shapes"]]
+    np.testing.assert_allclose([float(v.double().sum()) for v in sd.values()], z["init_sums"], rtol=1e-12, atol=1e-12)
+    B, A = int(z["cfg_batch"]), cfg["act_dim"]
+    for it in range(int(z["cfg_steps"])):
+        d = synth_image_batch(cfg, B, seed=it)
+        torch.manual_seed(1000 + it)
+        tb = orc.local_update(d, draw_noise(B, A), it)
+        got = np.array([float(tb[k]) for k in TB_KEYS[:-1]])
+        np.testing.assert_allclose(got, z["s%d/tb" % it], rtol=2e-6, atol=2e-6)
+        online = orc.p["q1"] + orc.p["q2"] + orc.p["policy"]
+        np.testing.assert_allclose([float(p.grad.double().sum()) for p in online], z["s%d/grad_sum" % it], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose([float(p.grad.double().norm()) for p in online], z["s%d/grad_l2" % it], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose([float(v.double().sum()) for v in orc.state_dict().values()], z["s%d/param_sums" % it],
+                                   rtol=1e-7, atol=1e-5)

@@ -41,3 +41,46 @@ def test_bit_exact_vs_live_reference(O, A, hid, B):
         assert torch.equal(gref, orc.flat_grads())
         sd, osd = nets.state_dict(), orc.state_dict()
         assert all(torch.equal(sd[k], osd[k]) for k in sd)
+
+
+def _cnn_kwargs(obs_shape, A, conv_type):
+    kw = ref_loader.reference_kwargs(obs_shape, A, (256, 256, 256), act_limit=1.0)
+    for key in ("value", "policy"):
+        kw[key + "_func_type"] = "CNN"
+        kw[key + "_conv_type"] = conv_type
+        kw.pop(key + "_hidden_sizes")
+    return kw
+
+
+@pytest.mark.parametrize("obs_shape,A,conv_type,B", [((3, 96, 96), 3, "type_2", 8), ((4, 84, 84), 2, "type_1", 4)])
+def test_cnn_bit_exact_vs_live_reference(obs_shape, A, conv_type, B):
+    """the CNN approximators (networks/cnn.py) through the same update."""
+    from oracle.dsact_oracle_cnn import DsactCnnOracle, cnn_config, synth_image_batch
+
+    torch.set_num_threads(2)
+    ref = ref_loader.import_reference()
+    kw = _cnn_kwargs(obs_shape, A, conv_type)
+    torch.manual_seed(0)
+    alg = ref.DSAC_V2(**kw)
+    cfg = cnn_config(obs_shape, A, conv_type)
+    torch.manual_seed(0)
+    same_seed = DsactCnnOracle(cfg)
+    sd = alg.networks.state_dict()
+    osd = same_seed.state_dict()
+    assert list(sd.keys()) == list(osd.keys())
+    assert all(torch.equal(sd[k], osd[k]) for k in sd)
+    orc = DsactCnnOracle(cfg, state_dict=sd)
+    for it in range(3):
+        d = synth_image_batch(cfg, B, seed=it)
+        torch.manual_seed(1000 + it)
+        tb_ref = alg.local_update({k: v.clone() for k, v in d.items()}, it)
+        torch.manual_seed(1000 + it)
+        tb = orc.local_update(d, draw_noise(B, A), it)
+        for k in TB_KEYS[:-1]:
+            assert float(tb_ref[k]) == float(tb[k]), k
+        nets = alg.networks
+        gref = torch.cat([p.grad.reshape(-1) for n in ("q1", "q2", "policy") for p in getattr(nets, n).parameters()]
+                         + [nets.log_alpha.grad.reshape(1)])
+        assert torch.equal(gref, orc.flat_grads())
+        sd, osd = nets.state_dict(), orc.state_dict()
+        assert all(torch.equal(sd[k], osd[k]) for k in sd)
