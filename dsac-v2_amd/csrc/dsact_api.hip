@@ -12,6 +12,7 @@
 
 #include "../../include/dsact.h"
 #include "dsact_kernels.h"
+#include "dsact_conv.h"
 
 using namespace dsact;
 
@@ -27,12 +28,22 @@ static const int kDzSlot[N_CHAIN] = {0, -1, 1, 2, -1, -1, 3, 4};
 constexpr int kMaxLin = DSACT_MAX_HIDDEN_LAYERS + 1;
 constexpr int kActRows = 64;  // rows of the stand-alone policy forward (sampler feed)
 
+// One approximator inside its arena. nblk == 2: the CNN nets' twin `mean` / `log_std` MLPs laid side
+// by side (networks/cnn.py:224-229,447-450): layer 0 is one dense (2*H0 x in) matrix, hidden layers are
+// two (H x H) blocks, the output layer is the (n_out x 2H) matrix [[w_mean,0],[0,w_ls]]; rows of every
+// activation are [mean trunk | log_std trunk]. in[] / out[] are full ROW widths.
 struct NetDesc {
   int n_lin = 0;
+  int nblk = 1;
   int in[kMaxLin], out[kMaxLin];
   size_t w_off[kMaxLin], b_off[kMaxLin];
+  int n_conv = 0;
+  size_t cw_off[kMaxConv], cb_off[kMaxConv];
   size_t count = 0;
 };
+
+// conv stacks: S_* = (net, image) pairs; the first three are differentiated
+enum ConvStack { S_Q1 = 0, S_Q2, S_PI, S_Q1T, S_Q2T, S_PIT, N_STACK };
 
 struct Stage {            // one k_stage launch: <= kMaxProb GEMM problems in the kernel arguments
   std::string name;
@@ -64,8 +75,25 @@ struct dsact_handle {
   NetDesc qd, pd;
   size_t n_q = 0, n_pi = 0, n_online = 0, n_target = 0;
   float *online = nullptr, *target = nullptr, *adam_m = nullptr, *adam_v = nullptr, *grads = nullptr;
-  // dims
-  int O = 0, A = 0, L = 0, B = 0, ldx = 0;
+  // dims (O: floats of one replay observation; F: observation part of an MLP input row -- == O for the
+  // MLP nets, the flattened conv features for the CNN nets)
+  int O = 0, F = 0, A = 0, L = 0, B = 0, ldx = 0;
+  // CNN encoders
+  bool cnn = false;
+  int n_conv = 0, Brows = 0;            // Brows = max(B, kActRows): rows the shared geometry tables cover
+  ConvGeom cg[kMaxConv];
+  int cP = 1;                           // pixels of the last conv layer
+  int* rowoff[kMaxConv];                // [Brows*OH*OW] patch origins
+  float* img[2];                        // staged minibatch images (obs, obs2), pixel-major
+  float* cact[N_STACK][kMaxConv];
+  float* cdy[3][kMaxConv];
+  float* dcol[3];
+  float* dfeat[3];
+  float* dwpart[3];
+  float *aimg, *aact[kMaxConv];         // stand-alone policy forward
+  float* stage_img = nullptr;           // device staging of a host minibatch's images (dsact_load_batch)
+  int* idx_iota = nullptr;
+  float* Xc[8];                         // MLP input rows per chain
   int w[DSACT_MAX_HIDDEN_LAYERS];
   // workspace
   char* ws = nullptr;
@@ -96,6 +124,7 @@ struct dsact_handle {
   int n_dw_tiles = 0;
   int dw_off[4] = {0, 0, 0, 0};  // start of q1, q2, policy tiles, end
   std::vector<Stage> fwd1, fwd2, bwdq, bwdq_critic, bwdpi, actf;
+  Stage dfeat_q, dfeat_pi;
   // replay ring
   long long cap = 0, ptr = 0, size = 0;
   float *rb_obs = nullptr, *rb_obs2 = nullptr, *rb_act = nullptr, *rb_rew = nullptr, *rb_done = nullptr, *rb_logp = nullptr;
@@ -142,14 +171,22 @@ int fail(dsact_handle* h, int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(h, DSACT_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
-void build_net(NetDesc& d, int in0, const int* hidden, int L, int n_out) {
+void build_net(NetDesc& d, int in0, const int* hidden, int L, int n_out, int nblk, int n_conv, const ConvGeom* cg) {
   d.n_lin = L + 1;
+  d.nblk = nblk;
+  d.n_conv = n_conv;
   size_t off = 0;
+  for (int j = 0; j < n_conv; ++j) {
+    d.cw_off[j] = off; off += (size_t)cg[j].Cout * cg[j].K;
+    d.cb_off[j] = off; off += cg[j].Cout;
+  }
   int in = in0;
   for (int l = 0; l <= L; ++l) {
-    const int out = l < L ? hidden[l] : n_out;
+    const int out = l < L ? nblk * hidden[l] : n_out;
     d.in[l] = in; d.out[l] = out;
-    d.w_off[l] = off; off += (size_t)in * out;
+    d.w_off[l] = off;
+    // hidden layers of twin trunks hold two (H x H) blocks; layer 0 and the output layer are dense
+    off += (nblk == 2 && l > 0 && l < L) ? (size_t)2 * (out / 2) * (in / 2) : (size_t)in * out;
     d.b_off[l] = off; off += out;
     in = out;
   }
@@ -206,6 +243,9 @@ int launch(dsact_handle* h, const char* name, void (*kernel)(KArgs...), dim3 gri
     if (rc_ != DSACT_OK) return rc_; \
   } while (0)
 
+// pixels per split of a conv weight-gradient contraction (multiple of 64)
+size_t conv_dw_chunk(size_t M) { return M >= 65536 ? 1024 : 256; }
+
 // ---- workspace carving ------------------------------------------------------------------------
 struct Carver {
   size_t off = 0;
@@ -226,6 +266,39 @@ void carve(dsact_handle* h, Carver& c) {
   h->X0 = c.take<float>(B * h->ldx);
   h->XP = c.take<float>(B * h->ldx);
   h->X2 = c.take<float>(B * h->ldx);
+  if (!h->cnn) {
+    // MLP nets read the observation itself: chains on the same (obs, action) source share one row buffer
+    h->Xc[C_PI] = h->Xc[C_Q1C] = h->Xc[C_Q2C] = h->X0;
+    h->Xc[C_PIT] = h->Xc[C_Q1T] = h->Xc[C_Q2T] = h->X2;
+    h->Xc[C_Q1P] = h->Xc[C_Q2P] = h->XP;
+  } else {
+    // CNN nets: every net has its own encoder, so every chain has its own [features | action] rows
+    h->Xc[C_Q1C] = h->X0; h->Xc[C_Q1P] = h->XP; h->Xc[C_Q1T] = h->X2;
+    for (int ch : {C_PI, C_PIT, C_Q2C, C_Q2T, C_Q2P}) h->Xc[ch] = c.take<float>(B * h->ldx);
+    const size_t R = h->Brows;
+    h->img[0] = c.take<float>(B * h->O);
+    h->img[1] = c.take<float>(B * h->O);
+    size_t dcol_max = 4, part_max = 4;
+    for (int j = 0; j < h->n_conv; ++j) {
+      const ConvGeom& g = h->cg[j];
+      const size_t M = B * g.OH * g.OW;
+      h->rowoff[j] = c.take<int>(R * g.OH * g.OW);
+      for (int st = 0; st < N_STACK; ++st) h->cact[st][j] = c.take<float>(M * g.Cout);
+      for (int st = 0; st < 3; ++st) h->cdy[st][j] = c.take<float>(M * g.Cout);
+      if (j > 0 && M * g.K > dcol_max) dcol_max = M * g.K;
+      const size_t chunks = (M + conv_dw_chunk(M) - 1) / conv_dw_chunk(M);
+      const size_t part = chunks * g.Cout * (g.K + 4);
+      if (part > part_max) part_max = part;
+      h->aact[j] = c.take<float>((size_t)kActRows * g.OH * g.OW * g.Cout);
+    }
+    for (int st = 0; st < 3; ++st) {
+      h->dcol[st] = c.take<float>(dcol_max);
+      h->dwpart[st] = c.take<float>(part_max);
+      h->dfeat[st] = c.take<float>(B * h->F);
+    }
+    h->aimg = c.take<float>((size_t)kActRows * h->O);
+    h->idx_iota = c.take<int>(R);
+  }
   h->rew = c.take<float>(B);
   h->done = c.take<float>(B);
   h->eps_new = c.take<float>(B * A);
@@ -273,13 +346,7 @@ void carve(dsact_handle* h, Carver& c) {
 }
 
 // ---- stage descriptions ---------------------------------------------------------------------------
-const float* chain_input(const dsact_handle* h, int ch) {
-  switch (ch) {
-    case C_PI: case C_Q1C: case C_Q2C: return h->X0;
-    case C_PIT: case C_Q1T: case C_Q2T: return h->X2;
-    default: return h->XP;
-  }
-}
+const float* chain_input(const dsact_handle* h, int ch) { return h->Xc[ch]; }
 
 int tiles_of(int n, int t) { return (n + t - 1) / t; }
 
@@ -291,32 +358,42 @@ void stage_add(Stage& s, GemmProb g) {
   if (g.K > s.max_k) s.max_k = g.K;
   const int clean = (g.M % TM == 0 && g.N % TN == 0 && g.K % BK == 0) ? g.K / BK : 0;
   s.ts = s.ts < 0 ? clean : (s.ts == clean ? clean : 0);
+  if (s.args.n_prob >= kMaxProb) abort();  // programming error: a stage never has more than 4 chains x 2 trunks
   s.args.p[s.args.n_prob++] = g;
 }
 
-GemmProb fwd_prob(const dsact_handle* h, int ch, int l, const float* x0, int ldx0, int M, float* const* Hrow, float* Grow) {
+// forward problems of layer l of chain ch: one dense product, or one per trunk for the hidden layers of
+// twin-trunk (CNN) nets
+void fwd_probs(const dsact_handle* h, int ch, int l, const float* x0, int ldx0, int M, float* const* Hrow, float* Grow,
+               std::vector<GemmProb>& out) {
   const int net = kChainNet[ch];
   const NetDesc& d = net_desc(h, net);
   const float* base = net_params(h, net);
-  GemmProb t;
-  memset(&t, 0, sizeof(t));
-  t.P = l == 0 ? x0 : Hrow[l - 1];
-  t.ldp = l == 0 ? ldx0 : d.out[l - 1];
-  t.Q = base + d.w_off[l];
-  t.ldq = d.in[l];
-  if (l == 0 && net != N_POL && net != N_POLT) {
-    // Q nets: rows of O+A floats are not 16-byte aligned -> use the zero-padded copy (k_gather repack)
-    const int slot = net == N_Q1 ? 0 : net == N_Q2 ? 1 : net == N_Q1T ? 2 : 3;
-    t.Q = h->W1p[slot];
-    t.ldq = h->ldx;
+  const int nb = (d.nblk == 2 && l > 0) ? 2 : 1;
+  const int hb = d.out[l] / nb, kb = d.in[l] / nb;
+  for (int b = 0; b < nb; ++b) {
+    GemmProb t;
+    memset(&t, 0, sizeof(t));
+    t.P = l == 0 ? x0 : Hrow[l - 1] + (size_t)b * kb;
+    t.ldp = l == 0 ? ldx0 : d.in[l];
+    t.Q = base + d.w_off[l] + (size_t)b * hb * kb;
+    t.ldq = kb;
+    if (l == 0 && net != N_POL && net != N_POLT) {
+      // Q nets: rows of F+A floats are not 16-byte aligned -> use the zero-padded copy (k_gather repack)
+      const int slot = net == N_Q1 ? 0 : net == N_Q2 ? 1 : net == N_Q1T ? 2 : 3;
+      t.Q = h->W1p[slot];
+      t.ldq = h->ldx;
+    }
+    t.aux = base + d.b_off[l] + (size_t)b * hb;
+    t.C0 = Hrow[l] + (size_t)b * hb;
+    t.C1 = Grow + (size_t)b * hb;
+    t.ldc = d.out[l];
+    t.M = M; t.N = hb; t.K = kb;
+    out.push_back(t);
   }
-  t.aux = base + d.b_off[l];
-  t.C0 = Hrow[l];
-  t.C1 = Grow;
-  t.ldc = d.out[l];
-  t.M = M; t.N = d.out[l]; t.K = d.in[l];
-  return t;
 }
+
+int build_conv_tasks(dsact_handle* h);
 
 int build_tasks(dsact_handle* h) {
   const int L = h->L, B = h->B;
@@ -326,53 +403,79 @@ int build_tasks(dsact_handle* h) {
     memset(&s.args, 0, sizeof(s.args));
     return s;
   };
+  std::vector<GemmProb> pv;
   // forward group A: policy(obs), policy_target(obs2), q1/q2(obs,act); group B: q1_t/q2_t(obs2,act2), q1/q2(obs,new_act)
   const int g1[4] = {C_PI, C_PIT, C_Q1C, C_Q2C}, g2[4] = {C_Q1T, C_Q2T, C_Q1P, C_Q2P};
   h->fwd1.clear(); h->fwd2.clear();
   for (int grp = 0; grp < 2; ++grp)
     for (int l = 0; l < L; ++l) {
       Stage s = fresh(std::string(grp == 0 ? "fwdA_l" : "fwdB_l") + std::to_string(l), 0);
+      pv.clear();
       for (int i = 0; i < 4; ++i) {
         const int ch = grp == 0 ? g1[i] : g2[i];
-        stage_add(s, fwd_prob(h, ch, l, chain_input(h, ch), h->ldx, B, h->Hb[ch], h->Gb[ch][l]));
+        fwd_probs(h, ch, l, chain_input(h, ch), h->ldx, B, h->Hb[ch], h->Gb[ch][l], pv);
       }
+      for (const GemmProb& g : pv) stage_add(s, g);
       (grp == 0 ? h->fwd1 : h->fwd2).push_back(s);
     }
-  // backward through hidden layers: dZ[l-1] = (dZ[l] W_l) * G[l-1]
-  auto bwd_prob = [&](int ch, int l) {
+  // backward through hidden layers: dZ[l-1] = (dZ[l] W_l) * G[l-1]   (per trunk for twin nets)
+  auto bwd_probs = [&](Stage& s, int ch, int l) {
     const int net = kChainNet[ch];
     const NetDesc& d = net_desc(h, net);
     const float* base = net_params(h, net);
     const int slot = kDzSlot[ch];
-    GemmProb t;
-    memset(&t, 0, sizeof(t));
-    t.P = h->dZ[slot][l]; t.ldp = d.out[l];
-    t.Q = base + d.w_off[l]; t.ldq = d.in[l];
-    t.aux = h->Gb[ch][l - 1]; t.ldaux = d.in[l];
-    t.C0 = h->dZ[slot][l - 1]; t.ldc = d.in[l];
-    t.M = B; t.N = d.in[l]; t.K = d.out[l];
-    return t;
+    const int nb = d.nblk;
+    const int hb = d.out[l] / nb, kb = d.in[l] / nb;
+    for (int b = 0; b < nb; ++b) {
+      GemmProb t;
+      memset(&t, 0, sizeof(t));
+      t.P = h->dZ[slot][l] + (size_t)b * hb; t.ldp = d.out[l];
+      t.Q = base + d.w_off[l] + (size_t)b * hb * kb; t.ldq = kb;
+      t.aux = h->Gb[ch][l - 1] + (size_t)b * kb; t.ldaux = d.in[l];
+      t.C0 = h->dZ[slot][l - 1] + (size_t)b * kb; t.ldc = d.in[l];
+      t.M = B; t.N = kb; t.K = hb;
+      stage_add(s, t);
+    }
   };
   h->bwdq.clear(); h->bwdq_critic.clear(); h->bwdpi.clear();
   for (int l = L - 1; l >= 1; --l) {
     Stage s = fresh("bwdQ_l" + std::to_string(l), 1);
-    for (int ch : {C_Q1C, C_Q2C, C_Q1P, C_Q2P}) stage_add(s, bwd_prob(ch, l));
+    for (int ch : {C_Q1C, C_Q2C, C_Q1P, C_Q2P}) bwd_probs(s, ch, l);
     h->bwdq.push_back(s);
     Stage c = fresh("bwdQc_l" + std::to_string(l), 1);  // off iterations of the delayed update: critics only
-    for (int ch : {C_Q1C, C_Q2C}) stage_add(c, bwd_prob(ch, l));
+    for (int ch : {C_Q1C, C_Q2C}) bwd_probs(c, ch, l);
     h->bwdq_critic.push_back(c);
   }
   for (int l = L - 1; l >= 1; --l) {
     Stage s = fresh("bwdPi_l" + std::to_string(l), 1);
-    stage_add(s, bwd_prob(C_PI, l));
+    bwd_probs(s, C_PI, l);
     h->bwdpi.push_back(s);
   }
   // stand-alone policy forward (kActRows rows)
   h->actf.clear();
   for (int l = 0; l < L; ++l) {
     Stage s = fresh("act_l" + std::to_string(l), 0);
-    stage_add(s, fwd_prob(h, C_PI, l, h->Xact, h->ldx, kActRows, h->Hact, h->Gact));
+    pv.clear();
+    fwd_probs(h, C_PI, l, h->Xact, h->ldx, kActRows, h->Hact, h->Gact, pv);
+    for (const GemmProb& g : pv) stage_add(s, g);
     h->actf.push_back(s);
+  }
+  // CNN nets: gradient w.r.t. the conv features, dFeat = dZ0 . W0[:, :F]  (plain store)
+  h->dfeat_q = fresh("dfeat_q", 2);
+  h->dfeat_pi = fresh("dfeat_pi", 2);
+  if (h->cnn) {
+    for (int ch : {C_Q1C, C_Q2C, C_PI}) {
+      const int net = kChainNet[ch];
+      const NetDesc& d = net_desc(h, net);
+      GemmProb t;
+      memset(&t, 0, sizeof(t));
+      t.P = h->dZ[kDzSlot[ch]][0]; t.ldp = d.out[0];
+      if (ch == C_PI) { t.Q = net_params(h, net) + d.w_off[0]; t.ldq = d.in[0]; }
+      else { t.Q = h->W1p[ch == C_Q1C ? 0 : 1]; t.ldq = h->ldx; }  // this step's pre-update copy
+      t.C0 = h->dfeat[ch == C_Q1C ? S_Q1 : ch == C_Q2C ? S_Q2 : S_PI]; t.ldc = h->F;
+      t.M = B; t.N = h->F; t.K = d.out[0];
+      stage_add(ch == C_PI ? h->dfeat_pi : h->dfeat_q, t);
+    }
   }
   // weight / bias gradients of q1, q2, policy: one table entry per 32x32 tile
   std::vector<GemmProb> tiles;
@@ -392,19 +495,28 @@ int build_tasks(dsact_handle* h) {
     float* g = net_grads(h, net);
     const int slot = kDzSlot[ch];
     for (int l = 0; l <= L; ++l) {
+      const float* dz; int lddz;
+      if (l < L) { dz = h->dZ[slot][l]; lddz = d.out[l]; }
+      else if (ch == C_PI) { dz = h->dout_pi; lddz = 2 * h->A; }
+      else { dz = h->dout[ch == C_Q1C ? 0 : 1]; lddz = 2; }
+      const int nb = (d.nblk == 2 && l > 0) ? 2 : 1;
+      const int hb = d.out[l] / nb, kb = d.in[l] / nb;
+      for (int b = 0; b < nb; ++b) {
+        GemmProb t;
+        memset(&t, 0, sizeof(t));
+        t.P = dz + (size_t)b * hb; t.ldp = lddz;
+        t.M = hb; t.K = B;
+        t.Q = l == 0 ? chain_input(h, ch) : h->Hb[ch][l - 1] + (size_t)b * kb;
+        t.ldq = l == 0 ? h->ldx : d.in[l];
+        t.N = kb;
+        if (l < L || nb == 1) { t.C0 = g + d.w_off[l] + (size_t)b * hb * kb; t.ldc = kb; }
+        else { t.C0 = g + d.w_off[l] + (size_t)b * hb * d.in[l] + (size_t)b * kb; t.ldc = d.in[l]; }  // [[w_mean,0],[0,w_ls]]
+        add_tiles(t);
+      }
+      // bias: Q = ones
       GemmProb t;
       memset(&t, 0, sizeof(t));
-      if (l < L) { t.P = h->dZ[slot][l]; t.ldp = d.out[l]; }
-      else if (ch == C_PI) { t.P = h->dout_pi; t.ldp = 2 * h->A; }
-      else { t.P = h->dout[ch == C_Q1C ? 0 : 1]; t.ldp = 2; }
-      t.M = d.out[l]; t.K = B;
-      // weights
-      t.Q = l == 0 ? h->X0 : h->Hb[ch][l - 1];
-      t.ldq = l == 0 ? h->ldx : d.out[l - 1];
-      t.N = d.in[l];
-      t.C0 = g + d.w_off[l]; t.ldc = d.in[l];
-      add_tiles(t);
-      // bias: Q = ones
+      t.P = dz; t.ldp = lddz; t.M = d.out[l]; t.K = B;
       t.Q = h->ones; t.ldq = 1; t.N = 1;
       t.C0 = g + d.b_off[l]; t.ldc = 1;
       add_tiles(t);
@@ -483,6 +595,144 @@ int run_dw(dsact_handle* h, int x0, int x1, bool fused, bool finalize, hipStream
   return launch(h, "dW", k_stage_table, dim3(a.n_tiles + (finalize ? 1 : 0)), dim3(kThreads), tile_lds_bytes(h->B), a);
 }
 
+
+// ---- CNN encoders -----------------------------------------------------------------------------------
+static const int kStackNet[N_STACK] = {N_Q1, N_Q2, N_POL, N_Q1T, N_Q2T, N_POLT};
+
+// conv stacks forward: one launch per layer carrying all six stacks, then the feature scatter into the
+// MLP input rows of the chains each stack feeds
+int enqueue_conv_forward(dsact_handle* h) {
+  const int B = h->B;
+  for (int j = 0; j < h->n_conv; ++j) {
+    const ConvGeom& g = h->cg[j];
+    ConvStageArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g = g; a.rowoff = h->rowoff[j];
+    const int M = B * g.OH * g.OW;
+    int blocks = 0;
+    for (int st = 0; st < N_STACK; ++st) {
+      const int net = kStackNet[st];
+      const NetDesc& d = net_desc(h, net);
+      ConvProb& p = a.p[a.n_prob++];
+      p.in = j == 0 ? h->img[st < 3 ? 0 : 1] : h->cact[st][j - 1];
+      p.w = net_params(h, net) + d.cw_off[j];
+      p.bias = net_params(h, net) + d.cb_off[j];
+      p.out = h->cact[st][j];
+      p.M = M;
+      p.tiles_n = tiles_of(g.Cout, TN);
+      blocks += tiles_of(M, TM) * p.tiles_n;
+      p.tile_end = blocks;
+    }
+    const std::string name = "conv_fwd_l" + std::to_string(j);
+    TRY(launch(h, name.c_str(), k_conv_fwd, dim3(blocks), dim3(kThreads), 0, a));
+  }
+  FeatArgs f;
+  memset(&f, 0, sizeof(f));
+  const int last = h->n_conv - 1;
+  const int d0[N_STACK] = {C_Q1C, C_Q2C, C_PI, C_Q1T, C_Q2T, C_PIT};
+  for (int st = 0; st < N_STACK; ++st) { f.act[st] = h->cact[st][last]; f.dst0[st] = h->Xc[d0[st]]; f.dst1[st] = nullptr; }
+  f.dst1[S_Q1] = h->Xc[C_Q1P]; f.dst1[S_Q2] = h->Xc[C_Q2P];
+  f.n_stack = N_STACK; f.B = B; f.P = h->cP; f.C = h->cg[last].Cout; f.ldx = h->ldx;
+  const long long n = (long long)B * h->F;
+  return launch(h, "feat_scatter", k_feat_scatter, dim3((unsigned)((n + kThreads - 1) / kThreads), N_STACK), dim3(kThreads), 0, f);
+}
+
+// conv stacks backward for the first n_st differentiated stacks (q1, q2[, policy]); dfeat[] must hold
+// dL/d(features). Per layer: weight/bias gradient partials + ordered reduce (+ Adam/Polyak when `fused`),
+// then dCol = dY W and the col2im gather into the previous layer's dY.
+int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused) {
+  const int B = h->B;
+  const int last = h->n_conv - 1;
+  {
+    FeatBwdArgs f;
+    memset(&f, 0, sizeof(f));
+    for (int st = 0; st < n_st; ++st) { f.dfeat[st] = h->dfeat[st]; f.act[st] = h->cact[st][last]; f.dy[st] = h->cdy[st][last]; }
+    f.n_stack = n_st; f.B = B; f.P = h->cP; f.C = h->cg[last].Cout;
+    const long long n = (long long)B * h->F;
+    TRY(launch(h, "feat_bwd", k_feat_bwd, dim3((unsigned)((n + kThreads - 1) / kThreads), n_st), dim3(kThreads), 0, f));
+  }
+  for (int j = last; j >= 0; --j) {
+    const ConvGeom& g = h->cg[j];
+    const int M = B * g.OH * g.OW;
+    const std::string sfx = "_l" + std::to_string(j);
+    const int chunk = (int)conv_dw_chunk(M), n_chunks = (M + chunk - 1) / chunk, K1p = g.K + 4;
+    {
+      ConvDwArgs a;
+      memset(&a, 0, sizeof(a));
+      a.g = g; a.rowoff = h->rowoff[j];
+      a.chunk = chunk; a.n_chunks = n_chunks; a.K1p = K1p;
+      a.tiles_co = tiles_of(g.Cout, TM); a.tiles_k = tiles_of(a.K1p, TN);
+      int blocks = 0;
+      for (int st = 0; st < n_st; ++st) {
+        ConvDwProb& p = a.p[a.n_prob++];
+        p.in = j == 0 ? h->img[0] : h->cact[st][j - 1];
+        p.dy = h->cdy[st][j];
+        p.part = h->dwpart[st];
+        p.M = M;
+        blocks += a.n_chunks * a.tiles_co * a.tiles_k;
+        p.block_end = blocks;
+      }
+      TRY(launch(h, ("conv_dw" + sfx).c_str(), k_conv_dw, dim3(blocks), dim3(kThreads), 0, a));
+    }
+    if (j > 0) {
+      // dCol[m][k] = sum_co dY[m][co] W[co][k]: dense KC x MC product, plain store
+      Stage s;
+      s.name = "conv_dcol" + sfx; s.kind = 2; s.n_blocks = 0;
+      memset(&s.args, 0, sizeof(s.args));
+      for (int st = 0; st < n_st; ++st) {
+        const int net = kStackNet[st];
+        const NetDesc& d = net_desc(h, net);
+        GemmProb t;
+        memset(&t, 0, sizeof(t));
+        t.P = h->cdy[st][j]; t.ldp = g.Cout;
+        t.Q = net_params(h, net) + d.cw_off[j]; t.ldq = g.K;
+        t.C0 = h->dcol[st]; t.ldc = g.K;
+        t.M = M; t.N = g.K; t.K = g.Cout;
+        stage_add(s, t);
+      }
+      TRY(run_stage(h, s));
+      Col2imArgs c;
+      memset(&c, 0, sizeof(c));
+      c.g = g; c.n_prob = n_st; c.B = B;
+      for (int st = 0; st < n_st; ++st) { c.dcol[st] = h->dcol[st]; c.x[st] = h->cact[st][j - 1]; c.dx[st] = h->cdy[st][j - 1]; }
+      const long long n = (long long)B * g.H * g.W * (g.Cin / 4);
+      TRY(launch(h, ("col2im" + sfx).c_str(), k_col2im, dim3((unsigned)((n + kThreads - 1) / kThreads), n_st), dim3(kThreads), 0, c));
+    }
+    {
+      // ordered reduce of the partials (+ Adam / Polyak when fused) -- AFTER dCol, which needs this
+      // layer's weights as the forward pass saw them
+      ConvReduceArgs r;
+      memset(&r, 0, sizeof(r));
+      for (int st = 0; st < n_st; ++st) {
+        const int net = kStackNet[st];
+        const NetDesc& d = net_desc(h, net);
+        r.p[st].part = h->dwpart[st];
+        r.p[st].w_idx = (long long)((net_grads(h, net) + d.cw_off[j]) - h->grads);
+        r.p[st].b_idx = (long long)((net_grads(h, net) + d.cb_off[j]) - h->grads);
+      }
+      r.n_prob = n_st; r.Cout = g.Cout; r.K = g.K; r.K1p = K1p; r.n_chunks = n_chunks;
+      r.quads = g.Cout * K1p / 4;
+      r.fo = fused_opt(h, fused);
+      TRY(launch(h, ("conv_dw_reduce" + sfx).c_str(), k_conv_dw_reduce, dim3((r.quads + 15) / 16, n_st), dim3(kThreads), 0, r));
+    }
+  }
+  return DSACT_OK;
+}
+
+// image rows -> staged pixel-major minibatch (+ replayed action / reward / done when `with_scalars`)
+int enqueue_gather_img(dsact_handle* h, const float* src_obs, const float* src_obs2, const int* table, int rows,
+                       int use_dev, bool with_scalars, float* img0, float* img2, int n_rows) {
+  ImgGatherArgs a;
+  memset(&a, 0, sizeof(a));
+  a.rb_obs = src_obs; a.rb_obs2 = src_obs2;
+  a.rb_act = with_scalars ? h->rb_act : nullptr; a.rb_rew = h->rb_rew; a.rb_done = h->rb_done;
+  a.idx_table = table; a.idx_rows = rows; a.use_dev = use_dev; a.host_row = 0; a.st = h->st;
+  a.img0 = img0; a.img2 = img2; a.Xa0 = h->Xc[C_Q1C]; a.Xa1 = h->Xc[C_Q2C]; a.rew = h->rew; a.done = h->done;
+  a.B = n_rows; a.C = h->cfg.img_c; a.HW = h->cfg.img_h * h->cfg.img_w; a.A = h->A; a.F = h->F; a.ldx = h->ldx;
+  a.chunks = 8;
+  return launch(h, "gather_img", k_gather_img, dim3(n_rows * a.chunks), dim3(kThreads), 0, a);
+}
+
 // dispatch on the number of 256-wide chunks of a hidden row (register arrays are statically indexed)
 #define NCH_DISPATCH(W, CALL)                  \
   do {                                         \
@@ -520,9 +770,9 @@ RepackArgs repack_args(const dsact_handle* h, int n_blocks) {
   RepackArgs rp;
   const int nets[4] = {N_Q1, N_Q2, N_Q1T, N_Q2T};
   for (int i = 0; i < 4; ++i) { rp.src[i] = net_params(h, nets[i]) + h->qd.w_off[0]; rp.dst[i] = h->W1p[i]; }
-  rp.rows = h->w[0]; rp.K = h->O + h->A; rp.ldp = h->ldx;
+  rp.rows = h->w[0]; rp.K = h->F + h->A; rp.ldp = h->ldx;
   rp.n_blocks = n_blocks;
-  rp.w1at[0] = h->W1aT[0]; rp.w1at[1] = h->W1aT[1]; rp.O = h->O; rp.A = h->A;
+  rp.w1at[0] = h->W1aT[0]; rp.w1at[1] = h->W1aT[1]; rp.O = h->F; rp.A = h->A;
   return rp;
 }
 int repack_blocks(const dsact_handle* h) {
@@ -531,7 +781,13 @@ int repack_blocks(const dsact_handle* h) {
   return nb < 1 ? 1 : (nb > 256 ? 256 : nb);
 }
 
+int enqueue_prologue(dsact_handle* h, int use_dev, long long it, int advance, int fill_noise);
+
 int enqueue_gather(dsact_handle* h, const int* table, int rows, int use_dev, long long it, int advance) {
+  if (h->cnn) {
+    TRY(enqueue_gather_img(h, h->rb_obs, h->rb_obs2, table, rows, use_dev, true, h->img[0], h->img[1], h->B));
+    return enqueue_prologue(h, use_dev, it, advance, 1);   // bookkeeping, device noise, padded-weight repack
+  }
   GatherArgs a;
   a.rb_obs = h->rb_obs; a.rb_obs2 = h->rb_obs2; a.rb_act = h->rb_act; a.rb_rew = h->rb_rew; a.rb_done = h->rb_done;
   a.idx_table = table; a.idx_rows = rows; a.use_dev = use_dev; a.host_it = it; a.host_row = 0;
@@ -558,6 +814,7 @@ int enqueue_prologue(dsact_handle* h, int use_dev, long long it, int advance, in
 // everything of __compute_gradient after the minibatch is staged (dsac_v2.py:150-206)
 int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused) {
   const int L = h->L, B = h->B, A = h->A;
+  if (h->cnn) TRY(enqueue_conv_forward(h));
   for (int l = 0; l < L; ++l) TRY(run_stage(h, h->fwd1[l]));
   {
     HeadsArgs a;
@@ -569,8 +826,10 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused) {
       a.Wout[i] = net_params(h, net) + d.w_off[L];
       a.bout[i] = net_params(h, net) + d.b_off[L];
     }
-    a.W = h->w[L - 1]; a.B = B; a.O = h->O; a.A = A; a.ldx = h->ldx;
-    a.eps_new = h->eps_new; a.eps_2 = h->eps_2; a.XP = h->XP; a.X2 = h->X2;
+    a.W = h->w[L - 1]; a.B = B; a.O = h->F; a.A = A; a.ldx = h->ldx;
+    a.eps_new = h->eps_new; a.eps_2 = h->eps_2;
+    a.XP = h->Xc[C_Q1P]; a.XPb = h->Xc[C_Q2P] != h->Xc[C_Q1P] ? h->Xc[C_Q2P] : nullptr;
+    a.X2 = h->Xc[C_Q1T]; a.X2b = h->Xc[C_Q2T] != h->Xc[C_Q1T] ? h->Xc[C_Q2T] : nullptr;
     a.logits_pi = h->logits_pi; a.logits_pit = h->logits_pit; a.logp_new = h->logp_new; a.logp2 = h->logp2;
     a.qout[0] = h->qout_c[0]; a.qout[1] = h->qout_c[1];
     a.qstd[0] = h->qstd_c[0]; a.qstd[1] = h->qstd_c[1];
@@ -620,10 +879,13 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused) {
     // off iteration of the delayed update: the reference computes the actor / alpha gradients and
     // discards them (dsac_v2.py:174-186 vs :324) -- only the critics' backward is needed
     for (size_t i = 0; i < h->bwdq_critic.size(); ++i) TRY(run_stage(h, h->bwdq_critic[i]));
+    if (h->cnn) TRY(run_stage(h, h->dfeat_q));
     TRY(run_dw(h, h->dw_off[0], h->dw_off[2], fused, fused));
+    if (h->cnn) TRY(enqueue_conv_backward(h, 2, fused));
     return DSACT_OK;
   }
   for (size_t i = 0; i < h->bwdq.size(); ++i) TRY(run_stage(h, h->bwdq[i]));
+  if (h->cnn) TRY(run_stage(h, h->dfeat_q));   // reads the step's padded copy of W0: safe against the fused Adam below
   if (h->use_fork && !h->profiling) {
     HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
@@ -638,7 +900,7 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused) {
     a.Wout_pi = net_params(h, N_POL) + h->pd.w_off[L];
     a.G_pi = h->Gb[C_PI][L - 1]; a.dZ_pi = h->dZ[kDzSlot[C_PI]][L - 1];
     a.dout_pi = h->dout_pi; a.d_new_act = h->d_new_act;
-    a.WL = h->w[L - 1]; a.B = B; a.O = h->O; a.A = A;
+    a.WL = h->w[L - 1]; a.B = B; a.O = h->F; a.A = A;
     a.inv_B = 1.0f / (float)B; a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed;
     a.act_scale = h->act_scale; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
     a.part_loss = h->part_loss; a.n_part = B; a.target_entropy = -(float)A;
@@ -665,8 +927,10 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused) {
     else if (i == 1) { x0 = h->dw_off[1]; x1 = h->dw_off[2]; }
     TRY(run_stage(h, h->bwdpi[i], x0, x1, fused));
   }
+  if (h->cnn) TRY(run_stage(h, h->dfeat_pi));  // needs the policy's W0 BEFORE the fused Adam of the next launch
   // policy weight gradients (+ the critics' when there was no launch to ride in) + close of the update
   TRY(run_dw(h, np ? h->dw_off[2] : h->dw_off[0], h->dw_off[3], fused, fused));
+  if (h->cnn) TRY(enqueue_conv_backward(h, 3, fused));
   return DSACT_OK;
 }
 
@@ -730,10 +994,42 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (h->cfg.global_batch < h->cfg.batch) h->cfg.global_batch = h->cfg.batch;
   HIPCHK(h, hipSetDevice(device));
   h->O = cfg->obs_dim; h->A = cfg->act_dim; h->L = cfg->n_hidden; h->B = cfg->batch;
-  for (int l = 0; l < h->L; ++l) h->w[l] = cfg->hidden[l];
-  h->ldx = (h->O + h->A + 3) & ~3;
-  build_net(h->qd, h->O + h->A, h->w, h->L, 2);
-  build_net(h->pd, h->O, h->w, h->L, 2 * h->A);
+  h->F = h->O;
+  h->Brows = h->B > kActRows ? h->B : kActRows;
+  int nblk = 1;
+  if (cfg->conv_type != DSACT_CONV_NONE) {
+    // networks/cnn.py:173-228: the two conv stacks the reference defines
+    static const int k1[] = {8, 4, 3}, c1[] = {32, 64, 64}, s1[] = {4, 2, 1};
+    static const int k2[] = {4, 3, 3, 3, 3, 3}, c2[] = {8, 16, 32, 64, 128, 256}, s2[] = {2, 2, 2, 2, 1, 1};
+    if (cfg->conv_type != DSACT_CONV_TYPE_1 && cfg->conv_type != DSACT_CONV_TYPE_2) return fail(h, DSACT_E_INVALID, "conv_type must be 0, 1 (type_1) or 2 (type_2)");
+    const bool t1 = cfg->conv_type == DSACT_CONV_TYPE_1;
+    const int* ks = t1 ? k1 : k2; const int* cs = t1 ? c1 : c2; const int* ss = t1 ? s1 : s2;
+    h->n_conv = t1 ? 3 : 6;
+    if (cfg->img_c < 1 || cfg->img_h < 1 || cfg->img_w < 1 || (long long)cfg->img_c * cfg->img_h * cfg->img_w != cfg->obs_dim)
+      return fail(h, DSACT_E_INVALID, "obs_dim must equal img_c*img_h*img_w for CNN nets");
+    if (cfg->obs_dim % 4) return fail(h, DSACT_E_INVALID, "img_c*img_h*img_w must be a multiple of 4");
+    int C = cfg->img_c, H = cfg->img_h, W = cfg->img_w;
+    for (int j = 0; j < h->n_conv; ++j) {
+      ConvGeom& g = h->cg[j];
+      g.H = H; g.W = W; g.Cin = C; g.KS = ks[j]; g.stride = ss[j]; g.Cout = cs[j];
+      g.OH = (H - g.KS) / g.stride + 1; g.OW = (W - g.KS) / g.stride + 1;
+      if (H < g.KS || W < g.KS || g.OH < 1 || g.OW < 1) return fail(h, DSACT_E_INVALID, "image %dx%d too small for conv layer %d", cfg->img_h, cfg->img_w, j);
+      g.K = g.KS * g.KS * g.Cin; g.KWC = g.KS * g.Cin; g.rowskip = g.W * g.Cin - g.KWC;
+      g.inv_kwc = 1.0f / (float)g.KWC;
+      if (g.KWC % 4) return fail(h, DSACT_E_INVALID, "kernel_width*channels of conv layer %d must be a multiple of 4 (got %d)", j, g.KWC);
+      C = g.Cout; H = g.OH; W = g.OW;
+    }
+    h->cnn = true;
+    h->cP = H * W;
+    h->F = C * H * W;
+    nblk = 2;
+  }
+  for (int l = 0; l < h->L; ++l) h->w[l] = nblk * cfg->hidden[l];   // activation row widths
+  for (int l = 0; l < h->L; ++l)
+    if (h->w[l] > kMaxWidth) return fail(h, DSACT_E_INVALID, "activation row width %d exceeds %d", h->w[l], kMaxWidth);
+  h->ldx = (h->F + h->A + 3) & ~3;
+  build_net(h->qd, h->F + h->A, cfg->hidden, h->L, 2, nblk, h->n_conv, h->cg);
+  build_net(h->pd, h->F, cfg->hidden, h->L, 2 * h->A, nblk, h->n_conv, h->cg);
   h->n_q = h->qd.count; h->n_pi = h->pd.count;
   h->n_online = 2 * h->n_q + h->n_pi + 1;
   h->n_target = 2 * h->n_q + h->n_pi;
@@ -759,12 +1055,28 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     std::vector<float> ones(h->B, 1.0f);
     HIPCHK(h, hipMemcpy(h->ones, ones.data(), h->B * sizeof(float), hipMemcpyHostToDevice));
   }
+  if (h->cnn) {
+    for (int j = 0; j < h->n_conv; ++j) {
+      const ConvGeom& g = h->cg[j];
+      std::vector<int> ro((size_t)h->Brows * g.OH * g.OW);
+      size_t m = 0;
+      for (int b = 0; b < h->Brows; ++b)
+        for (int oy = 0; oy < g.OH; ++oy)
+          for (int ox = 0; ox < g.OW; ++ox)
+            ro[m++] = (int)((((size_t)b * g.H + (size_t)oy * g.stride) * g.W + (size_t)ox * g.stride) * g.Cin);
+      if ((size_t)h->Brows * g.H * g.W * g.Cin > 2147483647ull) return fail(h, DSACT_E_INVALID, "batch x image too large for 32-bit patch offsets");
+      HIPCHK(h, hipMemcpy(h->rowoff[j], ro.data(), ro.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    std::vector<int> iota(h->Brows);
+    for (int i = 0; i < h->Brows; ++i) iota[i] = i;
+    HIPCHK(h, hipMemcpy(h->idx_iota, iota.data(), iota.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   h->own_stream = true;
   HIPCHK(h, hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
   HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-  h->use_fork = getenv("DSACT_FORK") != nullptr;  // measured: a forked graph branch costs +20 us/update (cross-queue signals) -> opt-in only
+  h->use_fork = getenv("DSACT_FORK") != nullptr && !h->cnn;  // measured: a forked graph branch costs +20 us/update (cross-queue signals) -> opt-in only
   {
     const int max_lds = (int)tile_lds_bytes(BK * kMaxPrefetchTiles);  // 129 KB of the CU's 160 KB
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, false, EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
@@ -797,6 +1109,7 @@ int dsact_destroy(dsact_handle* h) {
   if (h->d_tiles) hipFree(h->d_tiles);
   if (h->idx_table) hipFree(h->idx_table);
   if (h->stage_dev) hipFree(h->stage_dev);
+  if (h->stage_img) hipFree(h->stage_img);
   for (float* p : {h->rb_obs, h->rb_obs2, h->rb_act, h->rb_rew, h->rb_done, h->rb_logp})
     if (p) hipFree(p);
   if (h->ws) hipFree(h->ws);
@@ -950,6 +1263,15 @@ int dsact_buffer_add(dsact_handle* h, int64_t n, const float* obs, const float* 
   a.s_rew = s_rew + first; a.s_done = s_done + first; a.s_logp = logp ? s_logp + first : nullptr;
   a.rb_obs = h->rb_obs; a.rb_obs2 = h->rb_obs2; a.rb_act = h->rb_act; a.rb_rew = h->rb_rew; a.rb_done = h->rb_done; a.rb_logp = h->rb_logp;
   a.ptr = (h->ptr + first) % h->cap; a.cap = h->cap; a.n = (int)cnt; a.O = h->O; a.A = h->A;
+  if (h->cnn) {
+    // image rows are wide (C*H*W floats): a grid of blocks per row for the two images, the wave-per-row
+    // kernel for the narrow columns
+    ImgScatterArgs w;
+    w.s_obs = a.s_obs; w.s_obs2 = a.s_obs2; w.rb_obs = h->rb_obs; w.rb_obs2 = h->rb_obs2;
+    w.ptr = a.ptr; w.cap = h->cap; w.n = (int)cnt; w.O = h->O;
+    TRY(launch(h, "ring_write_img", k_ring_write_img, dim3(8, (unsigned)cnt), dim3(kThreads), 0, w));
+    a.O = 0;
+  }
   TRY(launch(h, "ring_write", k_ring_write, dim3((unsigned)((cnt + 3) / 4)), dim3(kThreads), 0, a));
   // host pointers may be reused by the caller right away
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -992,6 +1314,11 @@ int dsact_gather(dsact_handle* h, const int64_t* idx_host, int32_t batch) {
   HIPCHK(h, hipMemcpyAsync(h->idx_eager, h->h_idx[slot], batch * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipEventRecord(h->h_idx_ev[slot], h->stream));
   // bookkeeping (iteration, counters) is done by the step call; this gather only stages rows
+  if (h->cnn) {
+    TRY(enqueue_gather_img(h, h->rb_obs, h->rb_obs2, h->idx_eager, 1, 0, true, h->img[0], h->img[1], h->B));
+    h->have_batch = true;
+    return DSACT_OK;
+  }
   GatherArgs a;
   memset(&a, 0, sizeof(a));
   a.rb_obs = h->rb_obs; a.rb_obs2 = h->rb_obs2; a.rb_act = h->rb_act; a.rb_rew = h->rb_rew; a.rb_done = h->rb_done;
@@ -1012,9 +1339,24 @@ int dsact_read_batch(dsact_handle* h, float* obs, float* act, float* rew, float*
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   const size_t B = h->B, O = h->O, A = h->A, ld = h->ldx;
-  if (obs) HIPCHK(h, hipMemcpy2D(obs, O * 4, h->X0, ld * 4, O * 4, B, hipMemcpyDeviceToHost));
-  if (obs2) HIPCHK(h, hipMemcpy2D(obs2, O * 4, h->X2, ld * 4, O * 4, B, hipMemcpyDeviceToHost));
-  if (act) HIPCHK(h, hipMemcpy2D(act, A * 4, h->X0 + O, ld * 4, A * 4, B, hipMemcpyDeviceToHost));
+  if (h->cnn) {
+    // staged images are pixel-major; the caller gets (C,H,W) rows back (host-side permutation: slow path)
+    const size_t C = h->cfg.img_c, HW = (size_t)h->cfg.img_h * h->cfg.img_w;
+    std::vector<float> tmp(B * O);
+    for (int w = 0; w < 2; ++w) {
+      float* dst = w == 0 ? obs : obs2;
+      if (!dst) continue;
+      HIPCHK(h, hipMemcpy(tmp.data(), h->img[w], B * O * 4, hipMemcpyDeviceToHost));
+      for (size_t b = 0; b < B; ++b)
+        for (size_t p = 0; p < HW; ++p)
+          for (size_t c = 0; c < C; ++c) dst[b * O + c * HW + p] = tmp[b * O + p * C + c];
+    }
+    if (act) HIPCHK(h, hipMemcpy2D(act, A * 4, h->Xc[C_Q1C] + h->F, ld * 4, A * 4, B, hipMemcpyDeviceToHost));
+  } else {
+    if (obs) HIPCHK(h, hipMemcpy2D(obs, O * 4, h->X0, ld * 4, O * 4, B, hipMemcpyDeviceToHost));
+    if (obs2) HIPCHK(h, hipMemcpy2D(obs2, O * 4, h->X2, ld * 4, O * 4, B, hipMemcpyDeviceToHost));
+    if (act) HIPCHK(h, hipMemcpy2D(act, A * 4, h->X0 + O, ld * 4, A * 4, B, hipMemcpyDeviceToHost));
+  }
   if (rew) HIPCHK(h, hipMemcpy(rew, h->rew, B * 4, hipMemcpyDeviceToHost));
   if (done) HIPCHK(h, hipMemcpy(done, h->done, B * 4, hipMemcpyDeviceToHost));
   if (logp) {
@@ -1031,6 +1373,20 @@ int dsact_load_batch(dsact_handle* h, const float* obs, const float* act, const 
   HIPCHK(h, hipSetDevice(h->device));
   const size_t B = h->B, O = h->O, A = h->A, ld = h->ldx;
   hipStream_t s = h->stream;
+  if (h->cnn) {
+    const size_t R = h->Brows;
+    if (!h->stage_img) HIPCHK(h, hipMalloc(&h->stage_img, 2 * R * O * sizeof(float)));
+    HIPCHK(h, hipMemcpyAsync(h->stage_img, obs, B * O * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->stage_img + R * O, obs2, B * O * 4, hipMemcpyHostToDevice, s));
+    TRY(enqueue_gather_img(h, h->stage_img, h->stage_img + R * O, h->idx_iota, 1, 0, false, h->img[0], h->img[1], h->B));
+    HIPCHK(h, hipMemcpy2DAsync(h->Xc[C_Q1C] + h->F, ld * 4, act, A * 4, A * 4, B, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpy2DAsync(h->Xc[C_Q2C] + h->F, ld * 4, act, A * 4, A * 4, B, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->rew, rew, B * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->done, done, B * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    h->have_batch = true;
+    return DSACT_OK;
+  }
   HIPCHK(h, hipMemcpy2DAsync(h->X0, ld * 4, obs, O * 4, O * 4, B, hipMemcpyHostToDevice, s));
   HIPCHK(h, hipMemcpy2DAsync(h->XP, ld * 4, obs, O * 4, O * 4, B, hipMemcpyHostToDevice, s));
   HIPCHK(h, hipMemcpy2DAsync(h->X2, ld * 4, obs2, O * 4, O * 4, B, hipMemcpyHostToDevice, s));
@@ -1328,6 +1684,17 @@ int dsact_debug_read(dsact_handle* h, const char* name, float* out, size_t cap, 
       }
     }
   }
+  if (!src && h->cnn && (s.compare(0, 5, "cact.") == 0 || s.compare(0, 4, "cdy.") == 0 || s.compare(0, 6, "dfeat.") == 0)) {
+    const size_t d1 = s.find('.'), d2 = s.rfind('.');
+    const int st = atoi(s.c_str() + d1 + 1), j = d2 != d1 ? atoi(s.c_str() + d2 + 1) : 0;
+    if (st >= 0 && st < N_STACK && j >= 0 && j < h->n_conv) {
+      const ConvGeom& g = h->cg[j];
+      cnt = B * g.OH * g.OW * g.Cout;
+      if (s[1] == 'a') src = h->cact[st][j];
+      else if (s[1] == 'd' && st < 3) src = h->cdy[st][j];
+      else if (s[1] == 'f' && st < 3) { src = h->dfeat[st]; cnt = B * h->F; }
+    }
+  }
   if (!src) return fail(h, DSACT_E_INVALID, "unknown debug buffer '%s'", name);
   if (cnt > cap) return fail(h, DSACT_E_INVALID, "debug buffer '%s' needs %zu floats, cap %zu", name, cnt, cap);
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1342,7 +1709,32 @@ int dsact_policy_forward(dsact_handle* h, const float* obs_host, int32_t n, floa
   if (!h->online) return fail(h, DSACT_E_STATE, "arenas not bound");
   HIPCHK(h, hipSetDevice(h->device));
   const size_t O = h->O, ld = h->ldx;
-  HIPCHK(h, hipMemcpy2DAsync(h->Xact, ld * 4, obs_host, O * 4, O * 4, n, hipMemcpyHostToDevice, h->stream));
+  if (h->cnn) {
+    // conv stack of the online policy on n images: (C,H,W) rows -> pixel-major -> conv layers -> feature rows
+    if (!h->stage_img) HIPCHK(h, hipMalloc(&h->stage_img, 2 * (size_t)h->Brows * O * sizeof(float)));
+    HIPCHK(h, hipMemcpyAsync(h->stage_img, obs_host, (size_t)n * O * 4, hipMemcpyHostToDevice, h->stream));
+    TRY(enqueue_gather_img(h, h->stage_img, h->stage_img, h->idx_iota, 1, 0, false, h->aimg, h->aimg, n));
+    const NetDesc& d = h->pd;
+    for (int j = 0; j < h->n_conv; ++j) {
+      const ConvGeom& g = h->cg[j];
+      ConvStageArgs a;
+      memset(&a, 0, sizeof(a));
+      a.g = g; a.rowoff = h->rowoff[j]; a.n_prob = 1;
+      ConvProb& p = a.p[0];
+      p.in = j == 0 ? h->aimg : h->aact[j - 1];
+      p.w = net_params(h, N_POL) + d.cw_off[j]; p.bias = net_params(h, N_POL) + d.cb_off[j];
+      p.out = h->aact[j]; p.M = n * g.OH * g.OW; p.tiles_n = tiles_of(g.Cout, TN);
+      p.tile_end = tiles_of(p.M, TM) * p.tiles_n;
+      TRY(launch(h, "act_conv", k_conv_fwd, dim3(p.tile_end), dim3(kThreads), 0, a));
+    }
+    FeatArgs f;
+    memset(&f, 0, sizeof(f));
+    f.act[0] = h->aact[h->n_conv - 1]; f.dst0[0] = h->Xact; f.n_stack = 1; f.B = n; f.P = h->cP; f.C = h->cg[h->n_conv - 1].Cout; f.ldx = h->ldx;
+    const long long ne = (long long)n * h->F;
+    TRY(launch(h, "act_feat", k_feat_scatter, dim3((unsigned)((ne + kThreads - 1) / kThreads), 1), dim3(kThreads), 0, f));
+  } else {
+    HIPCHK(h, hipMemcpy2DAsync(h->Xact, ld * 4, obs_host, O * 4, O * 4, n, hipMemcpyHostToDevice, h->stream));
+  }
   for (int l = 0; l < h->L; ++l) TRY(run_stage(h, h->actf[l]));
   PolicyOutArgs a;
   a.H = h->Hact[h->L - 1];

@@ -1,0 +1,416 @@
+// dsact_conv.h -- gfx950 kernels of the CNN encoders (networks/cnn.py:30-53: Conv2d(k, stride, no
+// padding) + ReLU stacks; BASELINE.json configs[3]). HIP only, wave64, fp32 matrix cores.
+//
+// Layout: every activation is pixel-major ("NHWC"): act[m][c], m = (b, y, x). With the patch index
+// ordered (ky, kx, ci) one patch ROW (KW*Cin floats) is contiguous in memory, so the implicit-GEMM
+// operand  P(m, k) = in[rowoff[m] + k + (k / (KW*Cin)) * (W*Cin - KW*Cin)]  is fetched with the same
+// dwordx4 loads as a dense matrix (KW*Cin is a multiple of 4 for every layer of both conv types, the
+// first one included: 4*3 and 8*4). Conv weights live in the parameter arena as [Cout][KH][KW][Cin]
+// (the Python side exposes them to state_dict as permuted views), i.e. as a dense [Cout x K] matrix.
+//
+//   forward   Y[m][co]  = relu(sum_k P(m,k) W[co][k] + b[co])           k_conv_fwd  (32x32 tiles, MFMA)
+//   weights   dW[co][k] = sum_m dY[m][co] P(m,k),  db[co] = sum_m dY    k_conv_dw   (split over m, MFMA)
+//                                                                        k_conv_dw_reduce (+ Adam/Polyak)
+//   data      dCol[m][k] = sum_co dY[m][co] W[co][k]                     k_stage<KC,MC,STORE> (dsact_kernels.h)
+//             dX[b,y,x,ci] = relu'(x) * sum_{ky,kx} dCol[m(y-ky,x-kx)][ky,kx,ci]   k_col2im (deterministic gather)
+#pragma once
+#include "dsact_kernels.h"
+
+namespace dsact {
+
+constexpr int kMaxConv = 6;
+constexpr int kMaxConvProb = 6;
+
+struct ConvGeom {
+  int H, W, Cin, OH, OW, Cout, KS, stride;
+  int K;        // KS*KS*Cin
+  int KWC;      // KS*Cin: floats of one contiguous patch row
+  int rowskip;  // W*Cin - KWC
+  float inv_kwc;
+};
+
+__device__ __forceinline__ int conv_kmap(const ConvGeom& g, int k) {
+  const int ky = (int)(((float)k + 0.5f) * g.inv_kwc);  // exact: k < 2^16, KWC >= 12
+  return k + ky * g.rowskip;
+}
+
+struct ConvProb {
+  const float* in;    // [B*H*W][Cin]
+  const float* w;     // [Cout][K]
+  const float* bias;  // [Cout]
+  float* out;         // [M][Cout]
+  int M;
+  int tile_end;       // exclusive end of this problem's block range (one n-tile row per m-tile: Cout <= 32*tiles_n)
+  int tiles_n;
+};
+struct ConvStageArgs {
+  ConvGeom g;
+  const int* rowoff;  // [M] float offset of output pixel m's patch origin inside `in`
+  ConvProb p[kMaxConvProb];
+  int n_prob;
+};
+
+// ---------------------------------------------------------------------------------------------
+// forward: one 32 (pixels) x 32 (channels) tile per workgroup, K double-buffered through LDS
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) k_conv_fwd(ConvStageArgs s) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * TILE_LDS];
+  const int b = xcd_logical_block(blockIdx.x, gridDim.x);
+  int pi = 0;
+#pragma unroll
+  for (int q = 0; q + 1 < kMaxConvProb; ++q)
+    if (q + 1 < s.n_prob && b >= s.p[q].tile_end) pi = q + 1;
+  const ConvProb& t = s.p[pi];
+  const ConvGeom& g = s.g;
+  const int local = b - (pi ? s.p[pi - 1].tile_end : 0);
+  const int mt = local / t.tiles_n, nt = local - mt * t.tiles_n;
+  const int m0 = mt * TM, n0 = nt * TN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int i = lane & 15, gq = lane >> 4;
+  // operand cursors: 2 rows per thread, one k-quad
+  const int r0 = m0 + (tid >> 4), r1 = r0 + 16;
+  const bool pv0 = r0 < t.M, pv1 = r1 < t.M;
+  const int ro0 = s.rowoff[pv0 ? r0 : t.M - 1], ro1 = s.rowoff[pv1 ? r1 : t.M - 1];
+  const int c0 = n0 + (tid >> 4), c1 = c0 + 16;
+  const bool qv0 = c0 < g.Cout, qv1 = c1 < g.Cout;
+  const float* q0p = t.w + (size_t)(qv0 ? c0 : g.Cout - 1) * g.K;
+  const float* q1p = t.w + (size_t)(qv1 ? c1 : g.Cout - 1) * g.K;
+  const int kq = (tid & 15) * 4;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  auto load = [&](int it, f32x4& P0, f32x4& P1, f32x4& Q0, f32x4& Q1) {
+    const int k = it * BK + kq;
+    const bool kv = k < g.K;           // K % 4 == 0: a quad is entirely inside or outside
+    const int kc = kv ? k : 0;
+    const int km = conv_kmap(g, kc);
+    P0 = *(const f32x4u*)(t.in + ro0 + km);
+    P1 = *(const f32x4u*)(t.in + ro1 + km);
+    Q0 = *(const f32x4u*)(q0p + kc);
+    Q1 = *(const f32x4u*)(q1p + kc);
+    if (!(kv && pv0)) P0 = zero;
+    if (!(kv && pv1)) P1 = zero;
+    if (!(kv && qv0)) Q0 = zero;
+    if (!(kv && qv1)) Q1 = zero;
+  };
+  const int T = (g.K + BK - 1) / BK;
+  f32x4 acc0 = zero, acc1 = zero;
+  f32x4 p0, p1, q0, q1;
+  load(0, p0, p1, q0, q1);
+  // epilogue operand early
+  const int m = m0 + wr * 16 + i;
+  const int n = n0 + wc * 16 + 4 * gq;
+  const bool in_range = m < t.M && n < g.Cout;   // Cout % 4 == 0
+  f32x4 bv = zero;
+  if (in_range) bv = *(const f32x4u*)(t.bias + n);
+  for (int it = 0; it < T; ++it) {
+    const int bb = it & 1;
+    float* Ps = lds + bb * 2 * TILE_LDS;
+    float* Qs = Ps + TILE_LDS;
+    tile_store_lds<false>(Ps, tid, p0, p1);
+    tile_store_lds<false>(Qs, tid, q0, q1);
+    __syncthreads();
+    if (it + 1 < T) load(it + 1, p0, p1, q0, q1);
+    tile_mma<false, false>(Ps, Qs, wr * 16 + i, wc * 16 + i, gq, acc0, acc1);
+  }
+  if (!in_range) return;
+  f32x4 o = acc0 + acc1 + bv;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
+  *(f32x4u*)(t.out + (size_t)m * g.Cout + n) = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient, split over the pixel dimension: workgroup (problem, chunk, co-tile, k-tile) forms
+//   part[chunk][co][kidx] = sum_{m in chunk} dY[m][co] * P'(m, kidx),  kidx in [0, K]  (P'(m, K) = 1 -> bias)
+// Both operands are "row contiguous" in memory (dY: co contiguous, patch: k contiguous) and are
+// transposed into the k-contiguous LDS image on the way in (tile_store_lds<true>).
+// ---------------------------------------------------------------------------------------------
+struct ConvDwProb {
+  const float* in;    // layer input  [B*H*W][Cin]
+  const float* dy;    // [M][Cout]
+  float* part;        // [n_chunks][Cout][K1p]
+  int M;
+  int block_end;      // exclusive end of this problem's block range
+};
+struct ConvDwArgs {
+  ConvGeom g;
+  const int* rowoff;
+  ConvDwProb p[3];
+  int n_prob;
+  int chunk;          // pixels per chunk (multiple of 64)
+  int n_chunks, tiles_co, tiles_k;  // per problem: n_chunks * tiles_co * tiles_k blocks
+  int K1p;            // padded partial row length: K + 4
+};
+
+__global__ void __launch_bounds__(kThreads) k_conv_dw(ConvDwArgs s) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * TILE_LDS];
+  const int b = blockIdx.x;
+  int pi = 0;
+  if (s.n_prob > 1 && b >= s.p[0].block_end) pi = 1;
+  if (s.n_prob > 2 && b >= s.p[1].block_end) pi = 2;
+  const ConvDwProb& t = s.p[pi];
+  const ConvGeom& g = s.g;
+  int local = b - (pi ? s.p[pi - 1].block_end : 0);
+  const int per_chunk = s.tiles_co * s.tiles_k;
+  const int ch = local / per_chunk;
+  local -= ch * per_chunk;
+  const int ct = local / s.tiles_k, kt = local - ct * s.tiles_k;
+  const int co0 = ct * TM, k0 = kt * TN;
+  const int mb = ch * s.chunk;
+  const int me = mb + s.chunk < t.M ? mb + s.chunk : t.M;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int i = lane & 15, gq = lane >> 4;
+  // MC cursors: this thread's 4 consecutive rows (co / kidx) and its two m slots per 64-pixel tile
+  const int pc = co0 + (tid & 7) * 4;            // co quad
+  const bool pcv = pc < g.Cout;
+  const int qk = k0 + (tid & 7) * 4;             // kidx quad
+  const int qmode = qk < g.K ? 0 : (qk == g.K ? 1 : 2);  // gathered / bias column / padding
+  const int qmap = conv_kmap(g, qmode == 0 ? qk : 0);
+  const int ms = tid >> 3;                       // m slot 0 (slot 1 = +32)
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 one0 = {1.f, 0.f, 0.f, 0.f};
+  auto load = [&](int it, f32x4& P0, f32x4& P1, f32x4& Q0, f32x4& Q1) {
+    const int ma = mb + it * BK + ms, mc = ma + 32;
+    const bool va = ma < me, vc = mc < me;
+    const int mac = va ? ma : t.M - 1, mcc = vc ? mc : t.M - 1;
+    const int roa = s.rowoff[mac], roc = s.rowoff[mcc];
+    P0 = *(const f32x4u*)(t.dy + (size_t)mac * g.Cout + (pcv ? pc : 0));
+    P1 = *(const f32x4u*)(t.dy + (size_t)mcc * g.Cout + (pcv ? pc : 0));
+    Q0 = *(const f32x4u*)(t.in + roa + qmap);
+    Q1 = *(const f32x4u*)(t.in + roc + qmap);
+    if (!(va && pcv)) P0 = zero;                 // masking dY is enough: the other operand is finite
+    if (!(vc && pcv)) P1 = zero;
+    if (qmode == 1) { Q0 = one0; Q1 = one0; }
+    else if (qmode == 2) { Q0 = zero; Q1 = zero; }
+  };
+  const int T = (me - mb + BK - 1) / BK;
+  f32x4 acc0 = zero, acc1 = zero;
+  f32x4 p0, p1, q0, q1;
+  load(0, p0, p1, q0, q1);
+  for (int it = 0; it < T; ++it) {
+    const int bb = it & 1;
+    float* Ps = lds + bb * 2 * TILE_LDS;
+    float* Qs = Ps + TILE_LDS;
+    tile_store_lds<true>(Ps, tid, p0, p1);
+    tile_store_lds<true>(Qs, tid, q0, q1);
+    __syncthreads();
+    if (it + 1 < T) load(it + 1, p0, p1, q0, q1);
+    tile_mma<true, true>(Ps, Qs, wr * 16 + i, wc * 16 + i, gq, acc0, acc1);
+  }
+  const int co = co0 + wr * 16 + i;
+  const int kk = k0 + wc * 16 + 4 * gq;
+  if (co < g.Cout && kk < s.K1p)
+    *(f32x4u*)(t.part + ((size_t)ch * g.Cout + co) * s.K1p + kk) = acc0 + acc1;
+}
+
+// sums the partials in a fixed order, writes the gradient and (single-GPU path) applies Adam / Polyak
+struct ConvReduceProb {
+  const float* part;
+  long long w_idx, b_idx;   // arena index of this layer's weight / bias block
+};
+struct ConvReduceArgs {
+  ConvReduceProb p[3];
+  int n_prob;
+  int Cout, K, K1p, n_chunks;
+  int quads;                // Cout * K1p / 4 per problem
+  FusedOpt fo;
+};
+
+__global__ void __launch_bounds__(kThreads) k_conv_dw_reduce(ConvReduceArgs a) {
+  __shared__ f32x4 red[kThreads];
+  const int tid = threadIdx.x;
+  const int ql = tid & 15, cl = tid >> 4;             // 16 quads x 16 chunk lanes per block
+  const int pi = blockIdx.y;
+  const ConvReduceProb& t = a.p[pi];
+  const int q = blockIdx.x * 16 + ql;
+  const bool qv = q < a.quads;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (qv) {
+    // chunk lane cl sums chunks cl, cl+16, ...: 4 independent loads per trip
+    for (int c0 = cl; c0 < a.n_chunks; c0 += 64) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + 16 * u;
+        v[u] = *(const f32x4u*)(t.part + ((size_t)(c < a.n_chunks ? c : 0) * a.quads + q) * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (c0 + 16 * u < a.n_chunks) s += v[u];
+    }
+  }
+  red[tid] = s;
+  __syncthreads();
+  if (cl != 0 || !qv) return;
+#pragma unroll
+  for (int u = 1; u < 16; ++u) s += red[u * 16 + ql];
+  const int co = (q * 4) / a.K1p, kk = q * 4 - co * a.K1p;
+  if (kk > a.K) return;                               // padding quad
+  const FusedOpt& fo = a.fo;
+  const bool is_bias = kk == a.K;
+  const long long oi = is_bias ? t.b_idx + co : t.w_idx + (long long)co * a.K + kk;
+  const int nel = is_bias ? 1 : 4;
+  for (int e = 0; e < nel; ++e) fo.grads[oi + e] = s[e];
+  if (fo.st == nullptr) return;
+  const bool is_q = oi < fo.n_q2;
+  const bool delayed = fo.st->do_delayed != 0;
+  if (!(is_q || delayed)) return;
+  const float ss = is_q ? fo.st->ss_q : fo.st->ss_pi, bc2 = is_q ? fo.st->bc2_q : fo.st->bc2_pi;
+  for (int e = 0; e < nel; ++e) {
+    float pe = fo.online[oi + e], me = fo.adam_m[oi + e], ve = fo.adam_v[oi + e];
+    adam_update(pe, me, ve, s[e], fo.b1w, fo.beta2, fo.b2w, ss, bc2, fo.eps);
+    fo.online[oi + e] = pe; fo.adam_m[oi + e] = me; fo.adam_v[oi + e] = ve;
+    if (delayed) fo.target[oi + e] = polyak_update(fo.target[oi + e], pe, fo.polyak, fo.one_minus_polyak);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// col2im: dX[b,y,x,ci] = relu'(x[b,y,x,ci]) * sum over the (ky,kx) whose window covers (y,x) of
+//   dCol[(b,(y-ky)/s,(x-kx)/s)][(ky*KS+kx)*Cin + ci]; fixed (ky,kx) order => deterministic.
+// One thread per 4 channels of one input pixel.
+// ---------------------------------------------------------------------------------------------
+struct Col2imArgs {
+  ConvGeom g;
+  const float* dcol[3];   // [M][K]
+  const float* x[3];      // layer input activations (post-ReLU of the previous layer) [B*H*W][Cin]
+  float* dx[3];           // [B*H*W][Cin]
+  int n_prob;
+  int B;
+};
+__global__ void __launch_bounds__(kThreads) k_col2im(Col2imArgs a) {
+  const ConvGeom& g = a.g;
+  const int pi = blockIdx.y;
+  const int c4n = g.Cin >> 2;
+  const long long total = (long long)a.B * g.H * g.W * c4n;
+  const long long e = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (e >= total) return;
+  const int c4 = (int)(e % c4n);
+  long long pix = e / c4n;
+  const int x = (int)(pix % g.W); pix /= g.W;
+  const int y = (int)(pix % g.H);
+  const int b = (int)(pix / g.H);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  const float* dc = a.dcol[pi];
+  for (int ky = 0; ky < g.KS; ++ky) {
+    const int ty = y - ky;
+    if (ty < 0 || ty % g.stride) continue;
+    const int oy = ty / g.stride;
+    if (oy >= g.OH) continue;
+    for (int kx = 0; kx < g.KS; ++kx) {
+      const int tx = x - kx;
+      if (tx < 0 || tx % g.stride) continue;
+      const int ox = tx / g.stride;
+      if (ox >= g.OW) continue;
+      const size_t m = ((size_t)b * g.OH + oy) * g.OW + ox;
+      s += *(const f32x4u*)(dc + m * g.K + (ky * g.KS + kx) * g.Cin + c4 * 4);
+    }
+  }
+  const size_t o = (size_t)e * 4;
+  const f32x4 xv = *(const f32x4u*)(a.x[pi] + o);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) s[q] = xv[q] > 0.f ? s[q] : 0.f;
+  *(f32x4u*)(a.dx[pi] + o) = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// features: last conv activation [B*P][C] (pixel-major) <-> flattened NCHW feature columns of the MLP
+// input rows (img.view(B,-1), networks/cnn.py:233,455): X[b][c*P + p]
+// ---------------------------------------------------------------------------------------------
+struct FeatArgs {
+  const float* act[6];    // last-layer activations of the stacks
+  float* dst0[6]; float* dst1[6];   // MLP input rows fed by the stack (dst1 may be null)
+  int n_stack, B, P, C, ldx;
+};
+__global__ void __launch_bounds__(kThreads) k_feat_scatter(FeatArgs a) {
+  const int st = blockIdx.y;
+  const int F = a.P * a.C;
+  const long long e = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (e >= (long long)a.B * F) return;
+  const int b = (int)(e / F), f = (int)(e - (long long)b * F);
+  const int c = f / a.P, p = f - c * a.P;
+  const float v = a.act[st][((size_t)b * a.P + p) * a.C + c];
+  a.dst0[st][(size_t)b * a.ldx + f] = v;
+  if (a.dst1[st]) a.dst1[st][(size_t)b * a.ldx + f] = v;
+}
+struct FeatBwdArgs {
+  const float* dfeat[3];  // [B x F]
+  const float* act[3];    // last-layer activations (ReLU mask)
+  float* dy[3];           // [B*P][C]
+  int n_stack, B, P, C;
+};
+__global__ void __launch_bounds__(kThreads) k_feat_bwd(FeatBwdArgs a) {
+  const int st = blockIdx.y;
+  const int F = a.P * a.C;
+  const long long e = (long long)blockIdx.x * kThreads + threadIdx.x;
+  if (e >= (long long)a.B * F) return;
+  const int b = (int)(e / F);
+  const int r = (int)(e - (long long)b * F);   // (p, c) order: coalesced stores
+  const int p = r / a.C, c = r - p * a.C;
+  const float g = a.dfeat[st][(size_t)b * F + c * a.P + p];
+  a.dy[st][e] = a.act[st][e] > 0.f ? g : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// image minibatch gather (training/replay_buffer.py:85-90 for obsv_dim = (C,H,W)): replay rows hold the
+// image as the environment delivers it (C,H,W); the staged copy is pixel-major. Coalesced 16-byte
+// stores; the 4 source floats of a store come from <= 4 channel planes of neighbouring pixels.
+// ---------------------------------------------------------------------------------------------
+struct ImgGatherArgs {
+  const float* rb_obs; const float* rb_obs2; const float* rb_act; const float* rb_rew; const float* rb_done;
+  const int* idx_table; int idx_rows; int use_dev; int host_row;
+  const DevState* st;
+  float* img0; float* img2;
+  float* Xa0; float* Xa1;   // rows receiving the replayed action (q1 / q2 on (obs, act))
+  float* rew; float* done;
+  int B, C, HW, A, F, ldx;
+  int chunks;               // blocks per image
+};
+__global__ void __launch_bounds__(kThreads) k_gather_img(ImgGatherArgs a) {
+  const int r = blockIdx.x / a.chunks, ck = blockIdx.x - r * a.chunks;
+  const int trow = a.use_dev ? (int)(a.st->seq_next % a.idx_rows) : a.host_row;
+  const long long src = a.idx_table[(size_t)trow * a.B + r];
+  const size_t O = (size_t)a.C * a.HW;
+  const float* so = a.rb_obs + (size_t)src * O;
+  const float* so2 = a.rb_obs2 + (size_t)src * O;
+  float* d0 = a.img0 + (size_t)r * O;
+  float* d2 = a.img2 + (size_t)r * O;
+  const int n4 = (int)(O >> 2);   // C*HW % 4 == 0 is checked at create time
+  for (int q = ck * kThreads + threadIdx.x; q < n4; q += a.chunks * kThreads) {
+    f32x4 v, w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int o = q * 4 + e;
+      const int pix = o / a.C, c = o - pix * a.C;
+      v[e] = so[(size_t)c * a.HW + pix];
+      w[e] = so2[(size_t)c * a.HW + pix];
+    }
+    *(f32x4*)(d0 + (size_t)q * 4) = v;
+    *(f32x4*)(d2 + (size_t)q * 4) = w;
+  }
+  if (ck == 0) {
+    const int t = threadIdx.x;
+    if (a.rb_act && t < a.A) {
+      const float av = a.rb_act[(size_t)src * a.A + t];
+      a.Xa0[(size_t)r * a.ldx + a.F + t] = av;
+      a.Xa1[(size_t)r * a.ldx + a.F + t] = av;
+    }
+    if (a.rb_act && t == 0) { a.rew[r] = a.rb_rew[src]; a.done[r] = a.rb_done[src]; }
+  }
+}
+
+// replay ring write for image rows (wide rows: a block per row)
+struct ImgScatterArgs {
+  const float* s_obs; const float* s_obs2; float* rb_obs; float* rb_obs2;
+  long long ptr, cap; int n; long long O;
+};
+__global__ void __launch_bounds__(kThreads) k_ring_write_img(ImgScatterArgs a) {
+  const int i = blockIdx.y;
+  const long long dst = (a.ptr + i) % a.cap;
+  const long long n4 = a.O >> 2;
+  for (long long q = (long long)blockIdx.x * kThreads + threadIdx.x; q < n4; q += (long long)gridDim.x * kThreads) {
+    *(f32x4*)(a.rb_obs + dst * a.O + q * 4) = *(const f32x4*)(a.s_obs + (long long)i * a.O + q * 4);
+    *(f32x4*)(a.rb_obs2 + dst * a.O + q * 4) = *(const f32x4*)(a.s_obs2 + (long long)i * a.O + q * 4);
+  }
+}
+
+}  // namespace dsact

@@ -670,7 +670,7 @@ __device__ __forceinline__ int xcd_logical_block(int b, int nb) {
 }
 
 // ---- stage launch form 1: <= kMaxProb problems described in the kernel arguments ----------------
-constexpr int kMaxProb = 6;
+constexpr int kMaxProb = 8;   // 4 chains x 2 trunks (CNN nets) per stage
 struct StageArgs {
   GemmProb p[kMaxProb];
   int n_prob;
@@ -808,6 +808,7 @@ struct HeadsArgs {
   int W, B, O, A, ldx;
   const float* eps_new; const float* eps_2;
   float* XP; float* X2;
+  float* XPb; float* X2b;   // second destination of new_act / act2 (CNN nets: one input-row buffer per chain), or NULL
   float* logits_pi;   // [B x 2A] (mu | raw log-std) of policy(obs), kept for the backward
   float* logits_pit;  // [B x 2A] same for policy_target(obs2) (debug / parity only)
   float* logp_new; float* logp2;
@@ -862,6 +863,8 @@ __global__ void __launch_bounds__(kThreads) k_heads(HeadsArgs a) {
         lp = f.lp;
         float* X = chain == 0 ? a.XP : a.X2;
         X[(size_t)r * a.ldx + a.O + lane] = f.a;
+        float* Xb = chain == 0 ? a.XPb : a.X2b;
+        if (Xb) Xb[(size_t)r * a.ldx + a.O + lane] = f.a;
         if (chain == 0) { s_tanh = tanhf(mine); s_sig = f.sigma; }
       }
       float* lg = chain == 0 ? a.logits_pi : a.logits_pit;

@@ -34,7 +34,7 @@ if _PKG not in sys.path:
     sys.path.insert(0, _PKG)
 
 from dsact.engine import STAT_KEYS, DsactEngine, register_engine  # noqa: E402
-from dsact.layout import ArenaLayout  # noqa: E402
+from dsact.layout import CONV_TYPES, ArenaLayout, CnnArenaLayout  # noqa: E402
 
 ALG_TIME_KEY = "Time/Algorithm time [ms]-RL iter"  # reference utils/tensorboard_setup.py:149
 _LOG_EPS = 1e-6  # reference utils/act_distribution_cls.py:3
@@ -142,7 +142,84 @@ class HipStochaPolicy(nn.Module):
         return dist
 
 
+def _cnn(obs_shape, conv_type):
+    """Conv2d + ReLU stack, construction order of reference networks/cnn.py:30-53."""
+    _, ks, ch, st, _ = CONV_TYPES[conv_type]
+    layers, c = [], int(obs_shape[0])
+    for k, co, s in zip(ks, ch, st):
+        layers += [nn.Conv2d(c, co, k, s), nn.ReLU()]
+        c = co
+    return nn.Sequential(*layers)
+
+
+def _feat_dim(obs_shape, conv_type):
+    return CnnArenaLayout(obs_shape, 1, conv_type).feat_dim
+
+
+class HipCnnActionValueDistri(nn.Module):
+    """conv -> flatten -> cat(act) -> separate `mean` / `log_std` MLPs (reference networks/cnn.py:383-461)."""
+
+    def __init__(self, obs_shape, act_dim, conv_type):
+        super().__init__()
+        hidden = CONV_TYPES[conv_type][4]
+        self.conv = _cnn(obs_shape, conv_type)
+        sizes = [_feat_dim(obs_shape, conv_type) + act_dim] + list(hidden) + [1]
+        self.mean = _mlp(sizes)
+        self.log_std = _mlp(sizes)
+
+    def forward(self, obs, act):
+        img = self.conv(obs)
+        feature = torch.cat([img.reshape(img.size(0), -1), act], -1)
+        return torch.cat((self.mean(feature), nn.functional.softplus(self.log_std(feature))), dim=-1)
+
+
+class HipCnnStochaPolicy(nn.Module):
+    """conv -> flatten -> separate `mean` / `log_std` MLPs (reference networks/cnn.py:151-240)."""
+
+    def __init__(self, obs_shape, act_dim, conv_type, act_high, act_low, min_log_std, max_log_std):
+        super().__init__()
+        hidden = CONV_TYPES[conv_type][4]
+        self.conv = _cnn(obs_shape, conv_type)
+        sizes = [_feat_dim(obs_shape, conv_type)] + list(hidden) + [act_dim]
+        self.mean = _mlp(sizes)
+        self.log_std = _mlp(sizes)
+        self.min_log_std, self.max_log_std = float(min_log_std), float(max_log_std)
+        self.register_buffer("act_high_lim", torch.from_numpy(np.asarray(act_high, dtype=np.float32).copy()))
+        self.register_buffer("act_low_lim", torch.from_numpy(np.asarray(act_low, dtype=np.float32).copy()))
+        self._engine = None
+        self._obs_ndim = len(obs_shape)
+
+    def forward(self, obs):
+        if self._engine is not None:
+            lead = obs.shape[:-self._obs_ndim]
+            lg = self._engine.policy_forward(obs.detach().cpu().numpy())
+            return torch.from_numpy(lg).reshape(*lead, lg.shape[-1]).to(obs.device)
+        img = self.conv(obs)
+        feature = img.reshape(img.size(0), -1)
+        std = torch.clamp(self.log_std(feature), self.min_log_std, self.max_log_std).exp()
+        return torch.cat((self.mean(feature), std), dim=-1)
+
+    get_act_dist = HipStochaPolicy.get_act_dist
+
+
+def _conv_type(kwargs):
+    """None for the MLP nets, else the conv type shared by value and policy nets."""
+    vt, pt = kwargs.get("value_func_type", "MLP"), kwargs.get("policy_func_type", "MLP")
+    if vt == "MLP" and pt == "MLP":
+        return None
+    if vt != "CNN" or pt != "CNN":
+        raise NotImplementedError("DSAC_V2_HIP supports value/policy_func_type MLP+MLP or CNN+CNN (got %s / %s)" % (vt, pt))
+    cv, cp = kwargs.get("value_conv_type"), kwargs.get("policy_conv_type")
+    if cv != cp or cv not in CONV_TYPES:
+        raise NotImplementedError("value_conv_type and policy_conv_type must be the same one of %s (got %s / %s)"
+                                  % (sorted(CONV_TYPES), cv, cp))
+    return cv
+
+
 def _hidden_sizes(kwargs):
+    ct = _conv_type(kwargs)
+    if ct:
+        return list(CONV_TYPES[ct][4])
     hv, hp = list(kwargs["value_hidden_sizes"]), list(kwargs["policy_hidden_sizes"])
     if hv != hp:
         raise NotImplementedError("DSAC_V2_HIP needs value_hidden_sizes == policy_hidden_sizes (got %s / %s)" % (hv, hp))
@@ -150,8 +227,8 @@ def _hidden_sizes(kwargs):
 
 
 def _check_supported(kwargs):
-    for key, want in (("value_func_type", "MLP"), ("policy_func_type", "MLP"),
-                      ("value_hidden_activation", "gelu"), ("policy_hidden_activation", "gelu"),
+    _conv_type(kwargs)
+    for key, want in (("value_hidden_activation", "gelu"), ("policy_hidden_activation", "gelu"),
                       ("value_output_activation", "linear"), ("policy_output_activation", "linear"),
                       ("policy_act_distribution", "TanhGaussDistribution")):
         got = kwargs.get(key, want)
@@ -176,17 +253,26 @@ class ApproxContainer(nn.Module):
         super().__init__()
         _check_supported(kwargs)
         hidden = _hidden_sizes(kwargs)
-        O, A = int(kwargs["obsv_dim"]), int(kwargs["action_dim"])
+        ct = _conv_type(kwargs)
+        A = int(kwargs["action_dim"])
+        O = tuple(int(v) for v in kwargs["obsv_dim"]) if ct else int(kwargs["obsv_dim"])
         hi = np.asarray(kwargs["action_high_limit"], dtype=np.float32)
         lo = np.asarray(kwargs["action_low_limit"], dtype=np.float32)
-        # construction order == reference, so the same torch seed gives the same initial weights
-        self.q1 = HipActionValueDistri(O, A, hidden)
-        self.q2 = HipActionValueDistri(O, A, hidden)
-        self.q1_target = copy.deepcopy(self.q1)  # no RNG consumed, like the reference's deepcopy
-        self.q2_target = copy.deepcopy(self.q2)
         mn = kwargs.get("policy_min_log_std", -20.0)
         mx = kwargs.get("policy_max_log_std", 2.0)
-        self.policy = HipStochaPolicy(O, A, hidden, hi, lo, mn, mx)
+        # construction order == reference, so the same torch seed gives the same initial weights
+        if ct:
+            self.q1 = HipCnnActionValueDistri(O, A, ct)
+            self.q2 = HipCnnActionValueDistri(O, A, ct)
+        else:
+            self.q1 = HipActionValueDistri(O, A, hidden)
+            self.q2 = HipActionValueDistri(O, A, hidden)
+        self.q1_target = copy.deepcopy(self.q1)  # no RNG consumed, like the reference's deepcopy
+        self.q2_target = copy.deepcopy(self.q2)
+        if ct:
+            self.policy = HipCnnStochaPolicy(O, A, ct, hi, lo, mn, mx)
+        else:
+            self.policy = HipStochaPolicy(O, A, hidden, hi, lo, mn, mx)
         self.policy_target = copy.deepcopy(self.policy)
         for net in (self.policy_target, self.q1_target, self.q2_target):
             for p in net.parameters():
@@ -194,31 +280,33 @@ class ApproxContainer(nn.Module):
         self.log_alpha = nn.Parameter(torch.tensor(1, dtype=torch.float32))
         # nn.Module.__setattr__ would register these as sub-state; keep them out of state_dict
         object.__setattr__(self, "_engine", None)
-        object.__setattr__(self, "_layout", ArenaLayout(O, A, hidden))
+        object.__setattr__(self, "_layout", CnnArenaLayout(O, A, ct) if ct else ArenaLayout(O, A, hidden))
 
     # reference dsac_v2.py:61-62
     def create_action_distributions(self, logits):
         return self.policy.get_act_dist(logits)
 
     def _named_param_slots(self):
-        """[(parameter, arena_name, offset, shape)] for every parameter incl. log_alpha."""
+        """[(parameter, arena_name, storage offset, shape, strides)] for every parameter incl. log_alpha."""
         lay = self._layout
         out = []
         for net in ("q1", "q2", "policy", "q1_target", "q2_target", "policy_target"):
             mod = getattr(self, net)
             params = dict(mod.named_parameters())
-            for suffix, arena, off, shape in lay.param_slices(net):
-                out.append((params[suffix], arena, off, shape))
-        out.append((self.log_alpha, "online", lay.log_alpha_offset, ()))
+            for suffix, arena, off, shape, strides in lay.param_views(net):
+                out.append((params[suffix], arena, off, shape, strides))
+        out.append((self.log_alpha, "online", lay.log_alpha_offset, (), ()))
         return out
 
     def attach(self, engine: DsactEngine):
         """Move the current parameter values into the engine's arenas and alias them."""
         arenas = {"online": engine.online, "target": engine.target}
         with torch.no_grad():
-            for p, arena, off, shape in self._named_param_slots():
-                n = int(np.prod(shape)) if len(shape) else 1
-                view = arenas[arena][off:off + n].view(shape)
+            for p, arena, off, shape, strides in self._named_param_slots():
+                # a (possibly strided) window of the flat arena: conv weights are stored [Cout][KH][KW][Cin],
+                # the twin MLPs' output layers sit inside one (n_out x 2H) matrix (include/dsact.h)
+                view = torch.as_strided(arenas[arena], shape, strides, off)
+                assert tuple(view.shape) == tuple(p.shape), (tuple(view.shape), tuple(p.shape))
                 view.copy_(p.data.to(view.device))
                 p.data = view
             for pol in (self.policy, self.policy_target):
@@ -361,8 +449,10 @@ class DSAC_V2_HIP:
         self.strict_rng = bool(kwargs.get("strict_rng", False))
         self.flags = int(kwargs.get("hip_flags", 0))
         B = int(kwargs["replay_batch_size"])
+        ct = _conv_type(kwargs)
         self.engine = DsactEngine(
-            int(kwargs["obsv_dim"]), int(kwargs["action_dim"]), _hidden_sizes(kwargs), B,
+            tuple(kwargs["obsv_dim"]) if ct else int(kwargs["obsv_dim"]), int(kwargs["action_dim"]), _hidden_sizes(kwargs), B,
+            conv_type=ct,
             gamma=self.gamma, tau=self.tau, tau_b=self.tau_b, auto_alpha=bool(self.auto_alpha),
             alpha=float(self.alpha), delay_update=int(self.delay_update),
             lr_q=kwargs["value_learning_rate"], lr_pi=kwargs["policy_learning_rate"],
@@ -418,9 +508,8 @@ class DSAC_V2_HIP:
         out = {}
         for net in ("q1", "q2", "policy"):
             views = []
-            for _, _, off, shape in lay.param_slices(net):
-                n = int(np.prod(shape))
-                views.append(g[off:off + n].view(shape))
+            for _, _, off, shape, strides in lay.param_views(net):
+                views.append(torch.as_strided(g, shape, strides, off))
             out[net] = views
         out["log_alpha"] = g[lay.log_alpha_offset:lay.log_alpha_offset + 1].view(())
         return out

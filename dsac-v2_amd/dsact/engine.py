@@ -11,7 +11,7 @@ import numpy as np
 
 from . import _ffi
 from ._ffi import DsactError
-from .layout import ArenaLayout
+from .layout import ArenaLayout, CnnArenaLayout
 
 STAT_KEYS = [  # order of dsact_read_stats == dsac_v2.py:188-202
     "DSAC2/critic_avg_q1-RL iter", "DSAC2/critic_avg_q2-RL iter",
@@ -31,7 +31,9 @@ class DsactEngine:
     def __init__(self, obs_dim: int, act_dim: int, hidden: Sequence[int], batch: int, *,
                  gamma=0.99, tau=0.005, tau_b=None, auto_alpha=True, alpha=0.2, delay_update=2,
                  lr_q=1e-4, lr_pi=1e-4, lr_alpha=3e-4, min_log_std=-20.0, max_log_std=0.5,
-                 global_batch: Optional[int] = None, device: int = 0):
+                 global_batch: Optional[int] = None, device: int = 0, conv_type: Optional[str] = None):
+        """obs_dim: int for the MLP nets; with `conv_type` ("type_1" / "type_2", reference
+        networks/cnn.py:173-228) the (C, H, W) image shape, and `hidden` must be that type's MLP widths."""
         import torch
 
         self._lib = _ffi.load()
@@ -39,7 +41,16 @@ class DsactEngine:
             raise DsactError("DsactEngine needs an MI355X (torch.cuda.is_available() is False); "
                              "the DSAC-T update has no CPU fallback")
         self.torch = torch
-        self.layout = ArenaLayout(obs_dim, act_dim, list(hidden))
+        self.conv_type = conv_type
+        if conv_type:
+            self.layout = CnnArenaLayout(obs_dim, act_dim, conv_type)
+            if list(hidden) != self.layout.hidden:
+                raise DsactError("conv_type %s fixes the MLP widths to %s" % (conv_type, self.layout.hidden))
+            self.obs_shape = self.layout.obs_shape
+            obs_dim = self.layout.obs_dim
+        else:
+            self.layout = ArenaLayout(obs_dim, act_dim, list(hidden))
+            self.obs_shape = (int(obs_dim),)
         self.obs_dim, self.act_dim, self.batch = int(obs_dim), int(act_dim), int(batch)
         self.device_index = int(device)
         self.device = torch.device("cuda", self.device_index)
@@ -59,6 +70,9 @@ class DsactEngine:
         cfg.alpha_fixed = alpha
         cfg.min_log_std, cfg.max_log_std = min_log_std, max_log_std
         cfg.adam_beta1, cfg.adam_beta2, cfg.adam_eps = 0.9, 0.999, 1e-8
+        if conv_type:
+            cfg.conv_type = self.layout.conv_id
+            cfg.img_c, cfg.img_h, cfg.img_w = self.obs_shape
         self.cfg = cfg
         self._h = C.c_void_p()
         rc = self._lib.dsact_create(C.byref(cfg), self.device_index, C.byref(self._h))
@@ -69,8 +83,9 @@ class DsactEngine:
                 self._h = C.c_void_p()
             raise DsactError("dsact_create failed (%s): %s" % (_ffi.E_NAMES.get(rc, rc), msg))
         lay = self.layout
-        assert self._lib.dsact_online_count(self._h) == lay.n_online
+        assert self._lib.dsact_online_count(self._h) == lay.n_online, (self._lib.dsact_online_count(self._h), lay.n_online)
         assert self._lib.dsact_target_count(self._h) == lay.n_target
+        assert self._lib.dsact_q_count(self._h) == lay.n_q and self._lib.dsact_pi_count(self._h) == lay.n_pi
         # arenas: torch tensors, device pointers handed to the library
         dev = self.device
         self.online = torch.zeros(lay.n_online, dtype=torch.float32, device=dev)
@@ -157,8 +172,9 @@ class DsactEngine:
 
     def read_batch(self, with_logp=True) -> Dict[str, np.ndarray]:
         B, O, A = self.batch, self.obs_dim, self.act_dim
-        out = {"obs": np.empty((B, O), np.float32), "act": np.empty((B, A), np.float32),
-               "rew": np.empty(B, np.float32), "obs2": np.empty((B, O), np.float32),
+        shp = (B,) + tuple(self.obs_shape)
+        out = {"obs": np.empty(shp, np.float32), "act": np.empty((B, A), np.float32),
+               "rew": np.empty(B, np.float32), "obs2": np.empty(shp, np.float32),
                "done": np.empty(B, np.float32)}
         lp = np.empty(B, np.float32) if with_logp else None
         self._chk(self._lib.dsact_read_batch(self._h, _ffi.fptr(out["obs"]), _ffi.fptr(out["act"]),
@@ -170,7 +186,7 @@ class DsactEngine:
 
     def load_batch(self, obs, act, rew, obs2, done):
         obs, act, rew, obs2, done = _f32(obs), _f32(act), _f32(rew), _f32(obs2), _f32(done)
-        assert obs.shape == (self.batch, self.obs_dim), obs.shape
+        assert obs.size == self.batch * self.obs_dim and obs2.size == obs.size, obs.shape
         self._chk(self._lib.dsact_load_batch(self._h, _ffi.fptr(obs), _ffi.fptr(act), _ffi.fptr(rew),
                                              _ffi.fptr(obs2), _ffi.fptr(done)))
 

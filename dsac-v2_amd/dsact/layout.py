@@ -47,6 +47,14 @@ class ArenaLayout:
             off += o
         return out
 
+    def param_views(self, net: str):
+        """[(suffix, arena, storage_offset, shape, strides)] -- contiguous views for the MLP nets."""
+        out = []
+        for suffix, arena, off, shape in self.param_slices(net):
+            strides = (shape[1], 1) if len(shape) == 2 else (1,)
+            out.append((suffix, arena, off, shape, strides))
+        return out
+
     def state_dict_keys(self):
         """OrderedDict key -> shape in the reference's registration order."""
         sd = OrderedDict()
@@ -86,6 +94,161 @@ class ArenaLayout:
         O, A = self.obs_dim, self.act_dim
         n_on3 = 2 * self.n_q + self.n_pi
         gather = 4 * batch * (2 * O + A + 2) + 4 * batch
+        weights = 4 * (n_on3 + self.n_target)
+        adam_q = 24 * 2 * self.n_q
+        delayed = (24 * self.n_pi + 8 * n_on3) / float(delay_update)
+        return float(gather + weights + adam_q + delayed)
+
+
+# --------------------------------------------------------------------------------------------------
+# CNN approximators (reference networks/cnn.py:151-240,383-461; include/dsact.h "CNN nets")
+# --------------------------------------------------------------------------------------------------
+CONV_TYPES = {
+    # name: (id in dsact_config.conv_type, kernel sizes, channels, strides, hidden sizes of the mean / log_std MLPs)
+    "type_1": (1, [8, 4, 3], [32, 64, 64], [4, 2, 1], [512, 256]),
+    "type_2": (2, [4, 3, 3, 3, 3, 3], [8, 16, 32, 64, 128, 256], [2, 2, 2, 2, 1, 1], [256, 256, 256]),
+}
+
+
+def conv_geometry(obs_shape, conv_type):
+    """[(Cin, H, W, Cout, KS, stride, OH, OW)] per conv layer."""
+    _, ks, ch, st, _ = CONV_TYPES[conv_type]
+    c, h, w = [int(v) for v in obs_shape]
+    out = []
+    for k, co, s in zip(ks, ch, st):
+        oh, ow = (h - k) // s + 1, (w - k) // s + 1
+        if oh < 1 or ow < 1:
+            raise ValueError("image %s too small for conv_type %s" % (tuple(obs_shape), conv_type))
+        out.append((c, h, w, co, k, s, oh, ow))
+        c, h, w = co, oh, ow
+    return out
+
+
+class CnnArenaLayout:
+    """Arena layout of the CNN nets; same interface as ArenaLayout plus strided views.
+
+    inside a net: conv_j.weight as [Cout][KH][KW][Cin] | conv_j.bias | ... then the twin MLPs side by side:
+      layer 0        [mean.0.weight ; log_std.0.weight]  (2*H0 x in) | [mean.0.bias ; log_std.0.bias]
+      hidden layer l mean.W (H x Hprev) | log_std.W (H x Hprev) | [b_mean ; b_ls]
+      output layer   (n_out x 2H) = [[w_mean, 0], [0, w_ls]] | [b_mean ; b_ls]      (zero blocks structural)
+    """
+
+    def __init__(self, obs_shape, act_dim: int, conv_type: str):
+        self.obs_shape = tuple(int(v) for v in obs_shape)
+        self.obs_dim = int(self.obs_shape[0] * self.obs_shape[1] * self.obs_shape[2])
+        self.act_dim = int(act_dim)
+        self.conv_type = conv_type
+        self.conv_id, _, _, _, hidden = CONV_TYPES[conv_type]
+        self.hidden = list(hidden)
+        self.geom = conv_geometry(self.obs_shape, conv_type)
+        last = self.geom[-1]
+        self.feat_dim = last[3] * last[6] * last[7]
+        self._views = {}
+        self.n_q = self._build("q", self.feat_dim + self.act_dim, 1)
+        self.n_pi = self._build("policy", self.feat_dim, self.act_dim)
+        self.n_online = 2 * self.n_q + self.n_pi + 1
+        self.n_target = 2 * self.n_q + self.n_pi
+        self.net_offset = {
+            "q1": ("online", 0), "q2": ("online", self.n_q), "policy": ("online", 2 * self.n_q),
+            "q1_target": ("target", 0), "q2_target": ("target", self.n_q),
+            "policy_target": ("target", 2 * self.n_q),
+        }
+        self.log_alpha_offset = self.n_online - 1
+
+    def _build(self, kind, in0, nb):
+        """nb = outputs per trunk (1 for Q: mean / std; A for the policy). Returns the float count."""
+        views = []  # (suffix, offset, shape, strides)
+        off = 0
+        for j, (ci, _, _, co, k, _, _, _) in enumerate(self.geom):
+            K = k * k * ci
+            views.append(("conv.%d.weight" % (2 * j), off, (co, ci, k, k), (K, 1, k * ci, ci)))
+            off += co * K
+            views.append(("conv.%d.bias" % (2 * j), off, (co,), (1,)))
+            off += co
+        hid = self.hidden
+        L = len(hid)
+        mean, lstd = [], []
+        width_in = in0
+        for l in range(L + 1):
+            if l == 0:
+                h0 = hid[0]
+                mean.append(("mean.0.weight", off, (h0, in0), (in0, 1)))
+                lstd.append(("log_std.0.weight", off + h0 * in0, (h0, in0), (in0, 1)))
+                off += 2 * h0 * in0
+                mean.append(("mean.0.bias", off, (h0,), (1,)))
+                lstd.append(("log_std.0.bias", off + h0, (h0,), (1,)))
+                off += 2 * h0
+                width_in = h0
+            elif l < L:
+                h, hp = hid[l], width_in
+                mean.append(("mean.%d.weight" % (2 * l), off, (h, hp), (hp, 1)))
+                lstd.append(("log_std.%d.weight" % (2 * l), off + h * hp, (h, hp), (hp, 1)))
+                off += 2 * h * hp
+                mean.append(("mean.%d.bias" % (2 * l), off, (h,), (1,)))
+                lstd.append(("log_std.%d.bias" % (2 * l), off + h, (h,), (1,)))
+                off += 2 * h
+                width_in = h
+            else:
+                hp = width_in
+                mean.append(("mean.%d.weight" % (2 * l), off, (nb, hp), (2 * hp, 1)))
+                lstd.append(("log_std.%d.weight" % (2 * l), off + nb * 2 * hp + hp, (nb, hp), (2 * hp, 1)))
+                off += 2 * nb * 2 * hp
+                mean.append(("mean.%d.bias" % (2 * l), off, (nb,), (1,)))
+                lstd.append(("log_std.%d.bias" % (2 * l), off + nb, (nb,), (1,)))
+                off += 2 * nb
+        self._views[kind] = views + mean + lstd
+        return off
+
+    def param_views(self, net: str):
+        """[(suffix, arena, storage_offset, shape, strides)] in the reference's state_dict order."""
+        arena, base = self.net_offset[net]
+        kind = "policy" if net.startswith("policy") else "q"
+        return [(sfx, arena, base + off, shape, strides) for sfx, off, shape, strides in self._views[kind]]
+
+    def state_dict_keys(self):
+        sd = OrderedDict()
+        sd["log_alpha"] = ()
+        for net in ("q1", "q2", "q1_target", "q2_target", "policy", "policy_target"):
+            if net.startswith("policy"):
+                sd[net + ".act_high_lim"] = (self.act_dim,)
+                sd[net + ".act_low_lim"] = (self.act_dim,)
+            for suffix, _, _, shape, _ in self.param_views(net):
+                sd[net + "." + suffix] = shape
+        return sd
+
+    # ---- algorithmic cost model ---------------------------------------------------------------------
+    def conv_mac_per_sample(self):
+        return [oh * ow * co * k * k * ci for (ci, _, _, co, k, _, oh, ow) in self.geom]
+
+    def mac_per_sample(self):
+        """(forward, backward) MACs per sample of one update. Forward as the reference runs it: 2 policy +
+        6 Q passes, each with its own conv stack pass EXCEPT that the q(obs, new_act) passes reuse the conv
+        features of q(obs, act) (same net, same image). Backward: conv dW (all layers) + dX (layers >= 1) of
+        q1, q2, policy; MLPs as in the MLP layout with two trunks."""
+        conv = self.conv_mac_per_sample()
+        c_fwd = sum(conv)
+        c_bwd = sum(conv) + sum(conv[1:])
+        hid, A, F = self.hidden, self.act_dim, self.feat_dim
+
+        def trunk(in0, nb):
+            dims = [in0] + hid + [nb]
+            return [dims[i] * dims[i + 1] for i in range(len(dims) - 1)]
+
+        q, p = trunk(F + A, 1), trunk(F, A)
+        q_fwd, p_fwd = 2 * sum(q), 2 * sum(p)
+        fwd = 6 * c_fwd + 2 * p_fwd + 6 * q_fwd
+        crit = 2 * (q_fwd + 2 * sum(q[1:]) + 2 * hid[0] * F)          # dW all, dX hidden layers, dFeat
+        act = 2 * (2 * sum(q[1:]) + 2 * hid[0] * A)
+        pol = p_fwd + 2 * sum(p[1:]) + 2 * hid[0] * F
+        return fwd, crit + act + pol + 3 * c_bwd
+
+    def flop_per_step(self, batch: int) -> float:
+        f, b = self.mac_per_sample()
+        return 2.0 * (f + b) * batch
+
+    def bytes_per_step(self, batch: int, delay_update: int = 2) -> float:
+        n_on3 = 2 * self.n_q + self.n_pi
+        gather = 4 * batch * (2 * self.obs_dim + self.act_dim + 2) + 4 * batch
         weights = 4 * (n_on3 + self.n_target)
         adam_q = 24 * 2 * self.n_q
         delayed = (24 * self.n_pi + 8 * n_on3) / float(delay_update)

@@ -19,16 +19,24 @@ __all__ = ["HipReplayBuffer"]
 
 class HipReplayBuffer:
     def __init__(self, index=0, **kwargs):
-        self.obsv_dim = kwargs["obsv_dim"]
+        self.obsv_dim = kwargs["obsv_dim"]   # int, or the (C, H, W) tuple of the CNN configs (replay_buffer.py:22-31)
+        self._obs_shape = tuple(self.obsv_dim) if isinstance(self.obsv_dim, (tuple, list)) else (int(self.obsv_dim),)
+        self._obs_flat = int(np.prod(self._obs_shape))
         self.act_dim = kwargs["action_dim"]
         self.max_size = int(kwargs["buffer_max_size"])
         if kwargs.get("additional_info"):
             raise NotImplementedError("additional_info is not supported by HipReplayBuffer")
         eng = kwargs.get("hip_engine") or current_engine()
         B = int(kwargs["replay_batch_size"])
-        if eng is None or eng.obs_dim != self.obsv_dim or eng.act_dim != self.act_dim or eng.batch != B:
-            hidden = list(kwargs.get("value_hidden_sizes", [32]))
-            eng = DsactEngine(self.obsv_dim, self.act_dim, hidden, B, device=int(kwargs.get("hip_device", 0)))
+        if eng is None or eng.obs_dim != self._obs_flat or eng.act_dim != self.act_dim or eng.batch != B:
+            if len(self._obs_shape) == 3:
+                from dsact.layout import CONV_TYPES
+                ct = kwargs.get("value_conv_type", "type_2")
+                eng = DsactEngine(self._obs_shape, self.act_dim, CONV_TYPES[ct][4], B, conv_type=ct,
+                                  device=int(kwargs.get("hip_device", 0)))
+            else:
+                hidden = list(kwargs.get("value_hidden_sizes", [32]))
+                eng = DsactEngine(self._obs_flat, self.act_dim, hidden, B, device=int(kwargs.get("hip_device", 0)))
         self.engine = eng
         self.engine.buffer_create(self.max_size)
         self._serial = 0
@@ -45,7 +53,7 @@ class HipReplayBuffer:
         return self.size
 
     def __get_RAM__(self):
-        row_bytes = 4 * (2 * self.obsv_dim + self.act_dim + 3)
+        row_bytes = 4 * (2 * self._obs_flat + self.act_dim + 3)
         return row_bytes * self.size / 1e6  # MB resident in HBM
 
     def store(self, obs, info, act, rew, next_obs, done, logp, next_info):
@@ -55,7 +63,7 @@ class HipReplayBuffer:
         n = len(samples)
         if n == 0:
             return
-        O, A = self.obsv_dim, self.act_dim
+        O, A = self._obs_flat, self.act_dim
         obs = np.empty((n, O), np.float32)
         obs2 = np.empty((n, O), np.float32)
         act = np.empty((n, A), np.float32)
@@ -63,7 +71,8 @@ class HipReplayBuffer:
         done = np.empty(n, np.float32)
         logp = np.empty(n, np.float32)
         for i, s in enumerate(samples):
-            obs[i], act[i], rew[i], obs2[i], done[i], logp[i] = s[0], s[2], s[3], s[4], s[5], s[6]
+            obs[i], act[i], rew[i], done[i], logp[i] = np.asarray(s[0]).reshape(-1), s[2], s[3], s[5], s[6]
+            obs2[i] = np.asarray(s[4]).reshape(-1)
         self.engine.buffer_add(obs, act, rew, obs2, done, logp)
 
     def sample_batch(self, batch_size: int):

@@ -30,6 +30,13 @@
  *                   tail (the updated mean_std1/2 EMA, so that ONE all-reduce re-synchronises them)
  *     inside a net: [W0 (out x in, row-major, == nn.Linear.weight) | b0 | W1 | b1 | ...], i.e. the
  *     parameter order of torch's state_dict.
+ *     CNN nets (conv_type != 0): [conv0.w | conv0.b | ... | MLP part]. conv weights are stored
+ *     [Cout][KH][KW][Cin] (torch's [Cout][Cin][KH][KW] permuted: a dense [Cout x K] matrix whose K order
+ *     makes image patches contiguous). The MLP part holds the `mean` and `log_std` MLPs side by side:
+ *     layer 0 = [mean.0.weight ; log_std.0.weight] stacked by rows (2H0 x in) | [b_mean ; b_ls];
+ *     hidden layer l = mean.W_l (H x H) | log_std.W_l (H x H) | [b_mean ; b_ls];
+ *     output layer = (n_out x 2H) matrix [[w_mean, 0], [0, w_ls]] (the zero blocks are structural:
+ *     never written by the gradient path, never changed by Adam) | [b_mean ; b_ls].
  *   - all tensors fp32; replay indices int64 on the host API (int32 on device).
  */
 #ifndef DSACT_H
@@ -43,6 +50,9 @@ extern "C" {
 #endif
 
 #define DSACT_MAX_HIDDEN_LAYERS 6
+#define DSACT_CONV_NONE 0
+#define DSACT_CONV_TYPE_1 1
+#define DSACT_CONV_TYPE_2 2
 
 #define DSACT_OK 0
 #define DSACT_E_INVALID (-1)   /* bad argument / unsupported configuration */
@@ -68,6 +78,13 @@ typedef struct dsact_config {
   float alpha_fixed;                            /* alpha when !auto_alpha */
   float min_log_std, max_log_std;               /* policy_min/max_log_std */
   float adam_beta1, adam_beta2, adam_eps;       /* torch.optim.Adam defaults 0.9, 0.999, 1e-8 */
+  /* CNN approximators (value/policy_func_type == "CNN", networks/cnn.py:151-240,383-461):
+   * conv_type 0 = MLP nets; 1 = "type_1" (k 8,4,3 / ch 32,64,64 / stride 4,2,1, hidden 512,256);
+   * 2 = "type_2" (k 4,3,3,3,3,3 / ch 8..256 / stride 2,2,2,2,1,1, hidden 256,256,256).
+   * With conv_type != 0: obs_dim = img_c*img_h*img_w (replay rows hold the (C,H,W) image), `hidden`
+   * are the widths of the `mean` / `log_std` MLPs that follow the conv stack. */
+  int32_t conv_type;
+  int32_t img_c, img_h, img_w;
 } dsact_config;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

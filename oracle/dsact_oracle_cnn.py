@@ -94,6 +94,10 @@ class DsactCnnOracle(DsactOracle):
         self.n_conv = len(self.ks)
         oh, ow = conv_out_hw(H, W, self.ks, self.st)[-1]
         self.feat_dim = self.ch[-1] * oh * ow
+        # keep_conv: record the conv activations of every network call of the next compute_gradient as
+        # (net name, [post-ReLU activation per layer, grads retained]) -- per-layer parity / ReLU-kink checks
+        self.keep_conv = False
+        self.conv_acts = []
         super().__init__(cfg, state_dict)
 
     # parameter list of one net: conv (w,b)*n_conv | mean MLP (w,b)*(L+1) | log_std MLP (w,b)*(L+1)
@@ -116,10 +120,20 @@ class DsactCnnOracle(DsactOracle):
         nm = (len(params) - nc) // 2
         return params[:nc], params[nc:nc + nm], params[nc + nm:]
 
+    def _conv(self, obs, params, conv):
+        acts = [] if self.keep_conv else None
+        feat = conv_forward(obs, conv, self.st, acts)
+        if acts is not None:
+            for a in acts:
+                if a.requires_grad:
+                    a.retain_grad()
+            self.conv_acts.append((next(n for n in self.NETS if self.p[n] is params), acts))
+        return feat
+
     def _pi(self, obs, params, collect=None):
         """StochaPolicy.forward (networks/cnn.py:232-240)."""
         conv, mean, log_std = self._split(params)
-        feat = conv_forward(obs, conv, self.st)
+        feat = self._conv(obs, params, conv)
         a_mean = mlp_forward(feat, mean, collect)
         a_std = torch.clamp(mlp_forward(feat, log_std), self.cfg["min_log_std"], self.cfg["max_log_std"]).exp()
         return torch.cat((a_mean, a_std), dim=-1)
@@ -127,7 +141,7 @@ class DsactCnnOracle(DsactOracle):
     def _q(self, obs, act, params, collect=None):
         """ActionValueDistri.forward (networks/cnn.py:453-461) -> (mean, std)."""
         conv, mean, log_std = self._split(params)
-        feat = torch.cat([conv_forward(obs, conv, self.st), act], -1)
+        feat = torch.cat([self._conv(obs, params, conv), act], -1)
         v_mean = mlp_forward(feat, mean, collect)
         v_std = F.softplus(mlp_forward(feat, log_std))
         out = torch.cat((v_mean, v_std), dim=-1)

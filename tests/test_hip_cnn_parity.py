@@ -1,0 +1,214 @@
+"""Parity of the HIP path with the CNN approximators (BASELINE.json
+configs[3]) against the CNN oracle (oracle/dsact_oracle_cnn.py, pinned bit-exact to the live reference)
+and against the reference digests in tests/golden/step_cnn_type2.npz.
+
+Tolerances as in test_hip_parity.py: stats within 1e-4, gradients relative to each tensor's scale,
+parameters within 1e-4 absolute after an update; gathered replay rows bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, hip_kwargs
+from oracle.dsact_oracle import TB_KEYS, draw_noise
+from oracle.dsact_oracle_cnn import DsactCnnOracle, cnn_config, conv_forward, synth_image_batch
+from test_hip_parity import Report
+
+pytestmark = pytest.mark.gpu
+
+
+def cnn_kwargs(obs_shape, A, conv_type, B, **over):
+    kw = hip_kwargs(tuple(obs_shape), A, (256, 256, 256), B, act_limit=1.0, **over)
+    for key in ("value", "policy"):
+        kw[key + "_func_type"] = "CNN"
+        kw[key + "_conv_type"] = conv_type
+        kw.pop(key + "_hidden_sizes")
+    return kw
+
+
+def make_pair(obs_shape, A, conv_type, B, seed=0, **over):
+    from dsac_v2_hip import DSAC_V2_HIP
+
+    torch.manual_seed(seed)
+    alg = DSAC_V2_HIP(**cnn_kwargs(obs_shape, A, conv_type, B, strict_rng=True, **over))
+    cfg = cnn_config(obs_shape, A, conv_type)
+    orc = DsactCnnOracle(cfg, state_dict={k: v.cpu() for k, v in alg.networks.state_dict().items()})
+    return alg, orc, cfg
+
+
+def np_of(t):
+    return t.detach().cpu().contiguous().numpy()
+
+
+def run_case(title, obs_shape, A, conv_type, B, steps, golden=None):
+    rep = Report(title)
+    alg, orc, cfg = make_pair(obs_shape, A, conv_type, B)
+    e = alg.engine
+    names = {n: orc._names(n) for n in ("q1", "q2", "policy")}
+    kinked = set()   # nets in which a ReLU mask of the two implementations has disagreed so far
+    orc.keep_conv = True
+    for it in range(steps):
+        data = synth_image_batch(cfg, B, seed=it)
+        torch.manual_seed(1000 + it)
+        noise = draw_noise(B, A)
+        orc.conv_acts = []
+        tb_ref = orc.compute_gradient(data, noise, keep=(it == 0))
+        e.load_batch(*(data[k].numpy() for k in ("obs", "act", "rew", "obs2", "done")))
+        e.set_noise(noise["eps_new"].numpy(), noise["eps_2"].numpy(), noise["z5"].numpy(), noise["z6"].numpy())
+        e.compute_grads(it)
+        e.sync()
+        if it == 0:
+            # conv features of q1(obs) sit in the observation columns of the q1(obs, act) input rows
+            F = e.layout.feat_dim
+            ld = e.debug_read("X0").size // B
+            conv, _, _ = orc._split(orc.p["q1"])
+            with torch.no_grad():
+                feat = conv_forward(data["obs"], conv, orc.st)
+            rep.cmp("features q1(obs)", e.debug_read("X0").reshape(B, ld)[:, :F], feat, 1e-5, 1e-5)
+            rep.cmp("new_act", e.debug_read("XP").reshape(B, ld)[:, F:F + A], orc.inter["new_act"], 5e-6)
+            rep.cmp("q1", e.debug_read("qout_c0").reshape(B, 2)[:, 0], orc.inter["q1"], 5e-5)
+            rep.cmp("q1_pi", e.debug_read("qout_p0").reshape(B, 2)[:, 0], orc.inter["q1_pi"], 5e-5)
+            rep.cmp("d_new_act", e.debug_read("d_new_act"), orc.inter["d_new_act"], 1e-9, 3e-4)
+        # ReLU kinks: a pre-activation within rounding noise of 0 can land on different sides in the two
+        # implementations; the gradient is discontinuous there (the whole upstream gradient of that pixel
+        # appears or disappears). Locate such elements, require them to BE kinks (|activation| < 1e-5 on both
+        # sides) and widen the conv-gradient tolerance of the affected net by what they carry.
+        first = {}
+        for net, acts in orc.conv_acts:
+            first.setdefault(net, acts)     # first call of each online net: (obs) with gradients
+        kink_budget = {}
+        for st, net in enumerate(("q1", "q2", "policy")):
+            budget = 0.0
+            for j, a in enumerate(first[net]):
+                ref = a.detach().permute(0, 2, 3, 1).reshape(-1).numpy()
+                got = e.debug_read("cact.%d.%d" % (st, j))
+                rep.cmp("it%d act %s.conv.%d" % (it, net, 2 * j), got, ref, 1e-5 if net not in kinked else 5e-3, 1e-5)
+                flip = (got > 0) != (ref > 0)
+                if flip.any():
+                    assert float(np.abs(got[flip]).max()) < 1e-5 and float(np.abs(ref[flip]).max()) < 1e-5
+                    up = np.abs(a.grad.permute(0, 2, 3, 1).reshape(-1).numpy()[flip])
+                    budget += float(up.sum())
+                    kinked.add(net)
+            kink_budget[net] = budget
+        gv = alg._grad_views()
+        for net in ("q1", "q2", "policy"):
+            for name, g_hip, p_ref in zip(names[net], gv[net], orc.p[net]):
+                extra = 4.0 * kink_budget[net] if ".conv." in name else 0.0
+                rtol = 5e-4 if net not in kinked or kink_budget[net] > 0 or it == 0 else 2e-2
+                rep.cmp("it%d grad %s" % (it, name), np_of(g_hip), p_ref.grad, 1e-9 + extra, rtol)
+        rep.cmp("it%d grad log_alpha" % it, [float(gv["log_alpha"])], [float(orc.log_alpha.grad)], 1e-6, 1e-5)
+        e.apply_update(it)
+        orc.update(it)
+        st = e.read_stats()
+        for k in TB_KEYS[:-1]:
+            rep.cmp("it%d %s" % (it, k.split("/")[-1][:18]), [st[k]], [float(tb_ref[k])], 1e-4, 1e-4)
+        if golden is not None:
+            rep.cmp("it%d tb vs reference" % it, [st[k] for k in TB_KEYS[:-1]], golden["s%d/tb" % it], 1e-4, 1e-4)
+        sd, osd = alg.networks.state_dict(), orc.state_dict()
+        assert list(sd.keys()) == list(osd.keys())
+        # Adam's early steps move every weight by ~lr whatever |g| is, so an element whose gradient is at
+        # rounding-noise level (|g| < 1e-7) may take the opposite sign: 2*lr = 2e-4 there, 1e-4 everywhere else
+        gref = {"log_alpha": orc.log_alpha.grad}
+        for net in ("q1", "q2", "policy"):
+            for name, p_ref in zip(names[net], orc.p[net]):
+                gref[name] = p_ref.grad
+        worst_p, worst_t, worst_noise = 0.0, 0.0, 0.0
+        for k in sd:
+            diff = (sd[k].cpu() - osd[k]).abs()
+            if "_target" in k:
+                worst_t = max(worst_t, float(diff.max()))
+            elif k in gref:
+                noisy = gref[k].abs() < 1e-7
+                if bool(noisy.any()):
+                    worst_noise = max(worst_noise, float(diff[noisy].max()))
+                if bool((~noisy).any()):
+                    worst_p = max(worst_p, float(diff[~noisy].max()))
+        rep.cmp("it%d params (max over tensors)" % it, [worst_p], [0.0], 1e-4 if not kinked else 2.1e-4)
+        rep.cmp("it%d params with |g|<1e-7" % it, [worst_noise], [0.0], 2.1e-4)
+        rep.cmp("it%d targets (max over tensors)" % it, [worst_t], [0.0], 1e-5)
+        if golden is not None:
+            sums = [float(v.double().sum()) for v in sd.values()]
+            rep.cmp("it%d param sums vs reference" % it, sums, golden["s%d/param_sums" % it], 2e-3, 1e-5)
+    # structural zeros of the twin output layers stay exactly zero (include/dsact.h)
+    lay = e.layout
+    mask = torch.ones(lay.n_online, dtype=torch.bool)
+    for net in ("q1", "q2", "policy"):
+        for _, _, off, shape, strides in lay.param_views(net):
+            idx = torch.as_strided(torch.arange(lay.n_online), shape, strides, off).reshape(-1)
+            mask[idx] = False
+    mask[lay.log_alpha_offset] = False
+    assert int(mask.sum()) > 0
+    assert float(e.online.cpu()[mask].abs().max()) == 0.0
+    assert float(e.adam_m.cpu()[mask].abs().max()) == 0.0
+    assert e.get_state()["adam_steps"][0] == steps
+    rep.finish()
+
+
+def test_cnn_type2_vs_oracle_and_reference_golden():
+    z = np.load(os.path.join(GOLDEN, "step_cnn_type2.npz"))
+    run_case("cnn type_2 (3,96,96) B=8", tuple(int(v) for v in z["cfg_obs_shape"]), int(z["cfg_act_dim"]),
+             str(z["cfg_conv_type"]), int(z["cfg_batch"]), int(z["cfg_steps"]), golden=z)
+
+
+def test_cnn_type1():
+    run_case("cnn type_1 (4,84,84) B=4", (4, 84, 84), 2, "type_1", 4, steps=2)
+
+
+def test_cnn_type2_b256():
+    """BASELINE.json configs[3] at its full batch."""
+    run_case("cnn type_2 (3,96,96) B=256", (3, 96, 96), 3, "type_2", 256, steps=2)
+
+
+def test_cnn_fused_step_equals_split_path():
+    a1, _, cfg = make_pair((3, 96, 96), 3, "type_2", 16, seed=3)
+    a2, _, _ = make_pair((3, 96, 96), 3, "type_2", 16, seed=3)
+    for it in range(4):
+        d = synth_image_batch(cfg, 16, seed=10 + it)
+        torch.manual_seed(50 + it)
+        a1.local_update(d, it)                       # fused Adam in the gradient kernels
+        torch.manual_seed(50 + it)
+        _, info = a2.get_remote_update_info(d, it)   # gradients, then the streaming Adam kernel
+        a2.remote_update(info)
+    s1, s2 = a1.networks.state_dict(), a2.networks.state_dict()
+    for k in s1:
+        assert torch.equal(s1[k].cpu(), s2[k].cpu()), k
+
+
+def test_cnn_replay_rows_bit_exact_and_policy_forward():
+    from training.hip_replay_buffer import HipReplayBuffer
+
+    obs_shape, A, B = (3, 96, 96), 3, 8
+    alg, orc, cfg = make_pair(obs_shape, A, "type_2", B)
+    kw = cnn_kwargs(obs_shape, A, "type_2", B, buffer_max_size=40)
+    buf = HipReplayBuffer(**kw)
+    assert buf.engine is alg.engine
+    rng = np.random.default_rng(0)
+    rows = []
+    for i in range(55):   # wraps the ring
+        s = (rng.random(obs_shape, dtype=np.float32), {}, rng.uniform(-1, 1, A).astype(np.float32), float(rng.standard_normal()),
+             rng.random(obs_shape, dtype=np.float32), bool(rng.random() < 0.3), np.float32(0.0), {})
+        rows.append(s)
+    buf.add_batch(rows[:25])
+    buf.add_batch(rows[25:])
+    assert (buf.size, buf.ptr) == (40, 15)
+    ring = {}
+    for i, s in enumerate(rows):
+        ring[i % 40] = s
+    np.random.seed(4)
+    want_idx = np.random.randint(0, 40, size=B)
+    np.random.seed(4)
+    batch = buf.sample_batch(B)
+    got = {k: batch[k].numpy() for k in ("obs", "obs2", "act", "rew", "done")}
+    for r, i in enumerate(want_idx):
+        s = ring[int(i)]
+        assert np.array_equal(got["obs"][r], s[0]) and np.array_equal(got["obs2"][r], s[4])
+        assert np.array_equal(got["act"][r], s[2]) and got["rew"][r] == np.float32(s[3]) and got["done"][r] == float(s[5])
+    # sampler feed: conv stack + twin MLPs of the ONLINE policy through dsact_policy_forward
+    obs = torch.as_tensor(rng.random((5,) + obs_shape, dtype=np.float32))
+    with torch.no_grad():
+        want = orc._pi(obs, orc.p["policy"])
+    lg = alg.networks.policy(obs)
+    assert lg.shape == want.shape
+    assert float((lg.cpu() - want).abs().max()) < 2e-5
