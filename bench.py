@@ -79,6 +79,105 @@ def fill_replay(engine, n_rows, seed):
         engine.buffer_fill_device(r0, obs, act, rew, obs2, done)
 
 
+CNN_OBS, CNN_A, CNN_TYPE, CNN_ROWS = (3, 96, 96), 3, "type_2", 4096
+
+
+def make_cnn_alg(device, seed=0, batch=B):
+    """BASELINE.json configs[3]: DSAC_V2 with the reference's CNN approximators (networks/cnn.py, conv_type
+    type_2 at the (3,96,96) CarRacing image the shipped example uses)."""
+    import numpy as np
+    import torch
+    from dsac_v2_hip import DSAC_V2_HIP
+
+    torch.manual_seed(seed)
+    kw = dict(
+        algorithm="DSAC_V2_HIP", obsv_dim=CNN_OBS, action_dim=CNN_A, action_type="continu",
+        value_func_type="CNN", policy_func_type="CNN", value_conv_type=CNN_TYPE, policy_conv_type=CNN_TYPE,
+        value_hidden_activation="gelu", policy_hidden_activation="gelu",
+        value_output_activation="linear", policy_output_activation="linear",
+        policy_act_distribution="TanhGaussDistribution", policy_min_log_std=-20, policy_max_log_std=0.5,
+        value_learning_rate=1e-4, policy_learning_rate=1e-4, alpha_learning_rate=3e-4,
+        gamma=0.99, tau=0.005, auto_alpha=True, alpha=0.2, delay_update=2, cnn_shared=False,
+        replay_batch_size=batch, seed=seed + 1, hip_device=device,
+        action_high_limit=np.ones((CNN_A,), np.float32), action_low_limit=-np.ones((CNN_A,), np.float32),
+    )
+    return DSAC_V2_HIP(**kw)
+
+
+def fill_replay_images(engine, n_rows, seed):
+    """image ring: obs, obs2 ~ U[0,1) fp32 (pixel scale), act ~ U(-1,1), rew ~ N(0,1), done ~ Bern(.01)"""
+    import torch
+
+    engine.buffer_create(n_rows)
+    g = torch.Generator(device=engine.device).manual_seed(seed)
+    Oi, Ai = engine.obs_dim, engine.act_dim
+    chunk = 1024
+    for r0 in range(0, n_rows, chunk):
+        n = min(chunk, n_rows - r0)
+        obs = torch.rand(n, Oi, device=engine.device, generator=g)
+        obs2 = torch.rand(n, Oi, device=engine.device, generator=g)
+        act = torch.rand(n, Ai, device=engine.device, generator=g) * 2 - 1
+        rew = torch.randn(n, device=engine.device, generator=g)
+        done = (torch.rand(n, device=engine.device, generator=g) < 0.01).float()
+        engine.buffer_fill_device(r0, obs, act, rew, obs2, done)
+
+
+def cnn_cpu_baseline(batch, budget_s=8.0):
+    import torch
+    from oracle.dsact_oracle import draw_noise
+    from oracle.dsact_oracle_cnn import DsactCnnOracle, cnn_config, synth_image_batch
+
+    threads = 4
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    cfg = cnn_config(CNN_OBS, CNN_A, CNN_TYPE)
+    orc = DsactCnnOracle(cfg)
+    d = synth_image_batch(cfg, batch, seed=0)
+    orc.local_update(d, draw_noise(batch, CNN_A), 0)
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < budget_s or steps < 2:
+        orc.local_update(d, draw_noise(batch, CNN_A), 1 + steps)
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": "%d updates (batch %d, fixed minibatch, no replay gather) in %.1f s, torch %s CPU, %d of %d host cores"
+                      % (steps, batch, dt, torch.__version__, threads, os.cpu_count())}
+
+
+def bench_cnn(device, steps, warmup, batch=B, cpu=True):
+    """configs[3] as a secondary measurement (the headline metric is the Humanoid MLP workload)."""
+    alg = make_cnn_alg(device, seed=0, batch=batch)
+    e = alg.engine
+    fill_replay_images(e, CNN_ROWS, seed=100)
+    upload_indices(e, CNN_ROWS, 256, seed=1)
+    wall, ev_ms = measure(alg, steps, warmup)
+    stats = e.read_stats()
+    lay = e.layout
+    flop, byts = lay.flop_per_step(batch), lay.bytes_per_step(batch, 2)
+    sps = steps / wall
+    out = {
+        "workload": "gym_carracingraw-shaped DSAC_V2 update: image %s fp32, act %d, conv %s + twin 256x3 MLPs, batch %d, "
+                    "%d-row image replay ring in HBM" % ("x".join(map(str, CNN_OBS)), CNN_A, CNN_TYPE, batch, CNN_ROWS),
+        "value": sps, "unit": "steps/s", "ms_per_step": 1000.0 * wall / steps, "steps": steps,
+        "finite_stats": all(v == v and abs(v) < 1e30 for v in stats.values()),
+        "roofline_step": {"bound": "mfma", "achieved": flop * sps / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": flop * sps / 1e12 / FP32_PEAK_TFLOPS, "flop_per_step": flop},
+        "roofline_hbm": {"bound": "hbm", "achieved": byts * sps / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": byts * sps / 1e9 / HBM_PEAK_GBS, "bytes_per_step": byts,
+                         "note": "algorithmic: image gather 2*B*C*H*W*4 + weights + Adam/Polyak streams; activations assumed on-chip"},
+    }
+    try:
+        prof = e.profile_step(warmup + steps)
+        e.sync()
+        out["kernels"] = [{"name": n, "us": round(ms * 1000, 2), "blocks": b} for n, ms, b in prof]
+    except Exception as ex:
+        out["kernels_error"] = str(ex)
+    if cpu:
+        out["cpu_baseline"] = cnn_cpu_baseline(batch)
+    return out
+
+
 def upload_indices(engine, n_rows, rows, seed):
     import numpy as np
 
@@ -167,6 +266,8 @@ def main():
     ap.add_argument("--fast", action="store_true", help="primary number with DSACT_F_SKIP_ACTOR_ON_OFF_ITERS (default: strict; fast is reported in `fast`)")
     ap.add_argument("--replay-rows", type=int, default=N_REPLAY)
     ap.add_argument("--batch", type=int, default=B, help="minibatch rows per GPU (BASELINE metric: 256)")
+    ap.add_argument("--cnn-only", action="store_true", help="measure only the CNN workload (configs[3]); prints its object")
+    ap.add_argument("--cnn-steps", type=int, default=400)
     args = ap.parse_args()
     steps = args.steps + (args.steps & 1)
     warmup = args.warmup + (args.warmup & 1)
@@ -187,6 +288,9 @@ def main():
         dist.barrier()
         if rank != 0:
             entry.build()
+    if args.cnn_only:
+        print(json.dumps({"cnn": bench_cnn(local, args.cnn_steps, 40, cpu=not args.no_cpu_baseline)}))
+        return
     hidden = [int(x) for x in args.hidden.split(",")]
     alg = make_alg(hidden, local, seed=0, batch=args.batch)
     e = alg.engine
@@ -289,6 +393,11 @@ def main():
                       "frac_hbm": l2.bytes_per_step(B, 2) * steps / w2 / 1e9 / HBM_PEAK_GBS}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.batch == B:
         out["cpu_baseline"] = cpu_baseline(hidden)
+    if rank == 0 and world == 1 and not args.no_alt and args.batch == B:
+        try:
+            out["cnn"] = bench_cnn(local, args.cnn_steps, 40, cpu=not args.no_cpu_baseline)
+        except Exception as ex:  # secondary workload: never costs the headline line
+            out["cnn_error"] = repr(ex)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

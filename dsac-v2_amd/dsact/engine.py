@@ -253,9 +253,9 @@ class DsactEngine:
         return float(ms.value), float(macs.value)
 
     def profile_step(self, iteration: int, flags: int = 0):
-        arr = (_ffi.KernelTime * 64)()
+        arr = (_ffi.KernelTime * 128)()
         n = C.c_int32()
-        self._chk(self._lib.dsact_profile_step(self._h, int(iteration), int(flags), arr, 64, C.byref(n)))
+        self._chk(self._lib.dsact_profile_step(self._h, int(iteration), int(flags), arr, 128, C.byref(n)))
         return [(arr[i].name.decode(), float(arr[i].ms), int(arr[i].blocks)) for i in range(n.value)]
 
     def debug_read(self, name: str, cap: int = 1 << 24) -> np.ndarray:
