@@ -601,30 +601,62 @@ static const int kStackNet[N_STACK] = {N_Q1, N_Q2, N_POL, N_Q1T, N_Q2T, N_POLT};
 
 // conv stacks forward: one launch per layer carrying all six stacks, then the feature scatter into the
 // MLP input rows of the chains each stack feeds
+ConvIndex conv_index(const ConvGeom& g) {
+  ConvIndex ix;
+  ix.OHW = g.OH * g.OW;
+  ix.inv_ohw = 1.0f / (float)ix.OHW;
+  ix.inv_ow = 1.0f / (float)g.OW;
+  return ix;
+}
+
+// persistent grid of a forward conv launch: enough workgroups to fill the chip (4 per CU at 36.8 KB LDS)
+int conv_fwd_grid(int n_items) { return n_items < 1024 ? n_items : 1024; }
+
 int enqueue_conv_forward(dsact_handle* h) {
   const int B = h->B;
   for (int j = 0; j < h->n_conv; ++j) {
     const ConvGeom& g = h->cg[j];
     ConvStageArgs a;
     memset(&a, 0, sizeof(a));
-    a.g = g; a.rowoff = h->rowoff[j];
+    a.g = g; a.ix = conv_index(g);
     const int M = B * g.OH * g.OW;
-    int blocks = 0;
-    for (int st = 0; st < N_STACK; ++st) {
-      const int net = kStackNet[st];
-      const NetDesc& d = net_desc(h, net);
-      ConvProb& p = a.p[a.n_prob++];
-      p.in = j == 0 ? h->img[st < 3 ? 0 : 1] : h->cact[st][j - 1];
-      p.w = net_params(h, net) + d.cw_off[j];
-      p.bias = net_params(h, net) + d.cb_off[j];
-      p.out = h->cact[st][j];
+    if ((long long)M >= (1 << 24)) return fail(h, DSACT_E_INVALID, "batch x output pixels of conv layer %d exceeds 2^24", j);
+    int items = 0;
+    // layer 0: the three nets on `obs` (resp. `obs2`) read the same image -> one group each, weights
+    // concatenated along the channel dimension; deeper layers: one group per stack
+    const int per_group = j == 0 ? 3 : 1;
+    for (int st0 = 0; st0 < N_STACK; st0 += per_group) {
+      ConvGroup& p = a.p[a.n_prob++];
+      p.in = j == 0 ? h->img[st0 < 3 ? 0 : 1] : h->cact[st0][j - 1];
+      p.n_sub = per_group;
+      for (int u = 0; u < per_group; ++u) {
+        const int st = st0 + u, net = kStackNet[st];
+        const NetDesc& d = net_desc(h, net);
+        p.w[u] = net_params(h, net) + d.cw_off[j];
+        p.bias[u] = net_params(h, net) + d.cb_off[j];
+        p.out[u] = h->cact[st][j];
+      }
       p.M = M;
-      p.tiles_n = tiles_of(g.Cout, TN);
-      blocks += tiles_of(M, TM) * p.tiles_n;
-      p.tile_end = blocks;
+      p.tiles_n = tiles_of(per_group * g.Cout, TN);
+      items += tiles_of(M, TM) * p.tiles_n;
+      p.item_end = items;
     }
+    a.n_items = items;
     const std::string name = "conv_fwd_l" + std::to_string(j);
-    TRY(launch(h, name.c_str(), k_conv_fwd, dim3(blocks), dim3(kThreads), 0, a));
+    if (g.K <= 80 && per_group * g.Cout <= 32) {
+      // narrow layer: wave-autonomous register tiles (k_conv_fwd_narrow); work items are 32-pixel tiles
+      int it2 = 0;
+      for (int q = 0; q < a.n_prob; ++q) { it2 += tiles_of(M, 32); a.p[q].item_end = it2; a.p[q].tiles_n = 1; }
+      a.n_items = it2;
+      const int grid = (it2 + 3) / 4 < 1280 ? (it2 + 3) / 4 : 1280;
+      const bool one_block = per_group * g.Cout <= 16;
+      if (g.K <= 48 && one_block) TRY(launch(h, name.c_str(), (k_conv_fwd_narrow<3, 1>), dim3(grid), dim3(kThreads), 0, a));
+      else if (g.K <= 48) TRY(launch(h, name.c_str(), (k_conv_fwd_narrow<3, 2>), dim3(grid), dim3(kThreads), 0, a));
+      else if (one_block) TRY(launch(h, name.c_str(), (k_conv_fwd_narrow<5, 1>), dim3(grid), dim3(kThreads), 0, a));
+      else TRY(launch(h, name.c_str(), (k_conv_fwd_narrow<5, 2>), dim3(grid), dim3(kThreads), 0, a));
+      continue;
+    }
+    TRY(launch(h, name.c_str(), k_conv_fwd, dim3(conv_fwd_grid(items)), dim3(kThreads), 0, a));
   }
   FeatArgs f;
   memset(&f, 0, sizeof(f));
@@ -661,20 +693,38 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused) {
       memset(&a, 0, sizeof(a));
       a.g = g; a.rowoff = h->rowoff[j];
       a.chunk = chunk; a.n_chunks = n_chunks; a.K1p = K1p;
-      a.tiles_co = tiles_of(g.Cout, TM); a.tiles_k = tiles_of(a.K1p, TN);
+      a.tiles_k = tiles_of(a.K1p, TN);
       int blocks = 0;
-      for (int st = 0; st < n_st; ++st) {
+      // layer 0: every differentiated stack reads the staged `obs` image -> one problem, dY rows concatenated
+      const int per_prob = j == 0 ? n_st : 1;
+      for (int st0 = 0; st0 < n_st; st0 += per_prob) {
         ConvDwProb& p = a.p[a.n_prob++];
-        p.in = j == 0 ? h->img[0] : h->cact[st][j - 1];
-        p.dy = h->cdy[st][j];
-        p.part = h->dwpart[st];
+        p.in = j == 0 ? h->img[0] : h->cact[st0][j - 1];
+        p.n_sub = per_prob;
+        for (int u = 0; u < per_prob; ++u) { p.dy[u] = h->cdy[st0 + u][j]; p.part[u] = h->dwpart[st0 + u]; }
         p.M = M;
-        blocks += a.n_chunks * a.tiles_co * a.tiles_k;
+        p.tiles_co = tiles_of(per_prob * g.Cout, TM);
+        blocks += a.n_chunks * p.tiles_co * a.tiles_k;
         p.block_end = blocks;
       }
       TRY(launch(h, ("conv_dw" + sfx).c_str(), k_conv_dw, dim3(blocks), dim3(kThreads), 0, a));
     }
-    if (j > 0) {
+    const bool direct_dx = j > 0 && (g.Cin == 8 || g.Cin == 16) && g.Cout <= 32;
+    if (direct_dx) {
+      // narrow layers: no column buffer (see k_conv_dx_direct)
+      ConvDxArgs c;
+      memset(&c, 0, sizeof(c));
+      c.g = g; c.n_prob = n_st; c.B = B;
+      for (int st = 0; st < n_st; ++st) {
+        const int net = kStackNet[st];
+        c.dy[st] = h->cdy[st][j]; c.w[st] = net_params(h, net) + net_desc(h, net).cw_off[j];
+        c.x[st] = h->cact[st][j - 1]; c.dx[st] = h->cdy[st][j - 1];
+      }
+      const int Yq = (g.H + g.stride - 1) / g.stride, Xq = (g.W + g.stride - 1) / g.stride;   // largest parity class
+      const dim3 grid((unsigned)((B * Yq * Xq + kThreads - 1) / kThreads), n_st, g.stride * g.stride);
+      if (g.Cin == 8) TRY(launch(h, ("conv_dx" + sfx).c_str(), k_conv_dx_direct<2>, grid, dim3(kThreads), 0, c));
+      else TRY(launch(h, ("conv_dx" + sfx).c_str(), k_conv_dx_direct<4>, grid, dim3(kThreads), 0, c));
+    } else if (j > 0) {
       // dCol[m][k] = sum_co dY[m][co] W[co][k]: dense KC x MC product, plain store
       Stage s;
       s.name = "conv_dcol" + sfx; s.kind = 2; s.n_blocks = 0;
@@ -1719,13 +1769,15 @@ int dsact_policy_forward(dsact_handle* h, const float* obs_host, int32_t n, floa
       const ConvGeom& g = h->cg[j];
       ConvStageArgs a;
       memset(&a, 0, sizeof(a));
-      a.g = g; a.rowoff = h->rowoff[j]; a.n_prob = 1;
-      ConvProb& p = a.p[0];
+      a.g = g; a.ix = conv_index(g); a.n_prob = 1;
+      ConvGroup& p = a.p[0];
       p.in = j == 0 ? h->aimg : h->aact[j - 1];
-      p.w = net_params(h, N_POL) + d.cw_off[j]; p.bias = net_params(h, N_POL) + d.cb_off[j];
-      p.out = h->aact[j]; p.M = n * g.OH * g.OW; p.tiles_n = tiles_of(g.Cout, TN);
-      p.tile_end = tiles_of(p.M, TM) * p.tiles_n;
-      TRY(launch(h, "act_conv", k_conv_fwd, dim3(p.tile_end), dim3(kThreads), 0, a));
+      p.n_sub = 1;
+      p.w[0] = net_params(h, N_POL) + d.cw_off[j]; p.bias[0] = net_params(h, N_POL) + d.cb_off[j];
+      p.out[0] = h->aact[j]; p.M = n * g.OH * g.OW; p.tiles_n = tiles_of(g.Cout, TN);
+      p.item_end = tiles_of(p.M, TM) * p.tiles_n;
+      a.n_items = p.item_end;
+      TRY(launch(h, "act_conv", k_conv_fwd, dim3(conv_fwd_grid(a.n_items)), dim3(kThreads), 0, a));
     }
     FeatArgs f;
     memset(&f, 0, sizeof(f));

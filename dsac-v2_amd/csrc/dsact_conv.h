@@ -34,89 +34,265 @@ __device__ __forceinline__ int conv_kmap(const ConvGeom& g, int k) {
   return k + ky * g.rowskip;
 }
 
-struct ConvProb {
-  const float* in;    // [B*H*W][Cin]
-  const float* w;     // [Cout][K]
-  const float* bias;  // [Cout]
-  float* out;         // [M][Cout]
+// exact m / d for 0 <= m < 2^24 (float reciprocal + one correction either way)
+__device__ __forceinline__ int fast_div(int m, int d, float inv_d) {
+  int q = (int)((float)m * inv_d);
+  const int r = m - q * d;
+  q += (r >= d) ? 1 : 0;
+  q -= (r < 0) ? 1 : 0;
+  return q;
+}
+struct ConvIndex { int OHW; float inv_ohw, inv_ow; };
+// float offset of output pixel m's patch origin inside the pixel-major input
+__device__ __forceinline__ int conv_rowoff(const ConvGeom& g, const ConvIndex& ix, int m) {
+  const int b = fast_div(m, ix.OHW, ix.inv_ohw);
+  const int p = m - b * ix.OHW;
+  const int oy = fast_div(p, g.OW, ix.inv_ow);
+  const int ox = p - oy * g.OW;
+  return ((b * g.H + oy * g.stride) * g.W + ox * g.stride) * g.Cin;
+}
+
+// A forward "group": up to 3 conv layers of different nets applied to the SAME input (layer 0 of the
+// three nets that see `obs`, resp. `obs2`): their weights are concatenated along the channel dimension
+// so that one staged patch tile feeds all of them (N = n_sub*Cout). Deeper layers: n_sub = 1.
+struct ConvGroup {
+  const float* in;       // [B*H*W][Cin]
+  const float* w[3];     // [Cout][K] each
+  const float* bias[3];
+  float* out[3];         // [M][Cout] each
+  int n_sub;
   int M;
-  int tile_end;       // exclusive end of this problem's block range (one n-tile row per m-tile: Cout <= 32*tiles_n)
-  int tiles_n;
+  int tiles_n;           // ceil(n_sub*Cout / 32)
+  int item_end;          // exclusive end of this group's work-item range
 };
 struct ConvStageArgs {
   ConvGeom g;
-  const int* rowoff;  // [M] float offset of output pixel m's patch origin inside `in`
-  ConvProb p[kMaxConvProb];
+  ConvIndex ix;
+  ConvGroup p[kMaxConvProb];
   int n_prob;
+  int n_items;           // total (group, m-tile, n-tile) work items
 };
 
 // ---------------------------------------------------------------------------------------------
-// forward: one 32 (pixels) x 32 (channels) tile per workgroup, K double-buffered through LDS
+// forward: persistent workgroups; each walks (group, m-tile, n-tile) work items, one 32 (pixels) x 32
+// (channels) tile per item. The (item, k-tile) sequence is software pipelined: the global loads of the
+// NEXT k-tile (possibly of the next item) are in flight while the current one is multiplied, so the
+// L2 round trip is paid once per workgroup, not once per tile.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kThreads) k_conv_fwd(ConvStageArgs s) {
   __shared__ __attribute__((aligned(16))) float lds[4 * TILE_LDS];
-  const int b = xcd_logical_block(blockIdx.x, gridDim.x);
-  int pi = 0;
-#pragma unroll
-  for (int q = 0; q + 1 < kMaxConvProb; ++q)
-    if (q + 1 < s.n_prob && b >= s.p[q].tile_end) pi = q + 1;
-  const ConvProb& t = s.p[pi];
   const ConvGeom& g = s.g;
-  const int local = b - (pi ? s.p[pi - 1].tile_end : 0);
-  const int mt = local / t.tiles_n, nt = local - mt * t.tiles_n;
-  const int m0 = mt * TM, n0 = nt * TN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int i = lane & 15, gq = lane >> 4;
-  // operand cursors: 2 rows per thread, one k-quad
-  const int r0 = m0 + (tid >> 4), r1 = r0 + 16;
-  const bool pv0 = r0 < t.M, pv1 = r1 < t.M;
-  const int ro0 = s.rowoff[pv0 ? r0 : t.M - 1], ro1 = s.rowoff[pv1 ? r1 : t.M - 1];
-  const int c0 = n0 + (tid >> 4), c1 = c0 + 16;
-  const bool qv0 = c0 < g.Cout, qv1 = c1 < g.Cout;
-  const float* q0p = t.w + (size_t)(qv0 ? c0 : g.Cout - 1) * g.K;
-  const float* q1p = t.w + (size_t)(qv1 ? c1 : g.Cout - 1) * g.K;
   const int kq = (tid & 15) * 4;
+  const int T = (g.K + BK - 1) / BK;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  auto load = [&](int it, f32x4& P0, f32x4& P1, f32x4& Q0, f32x4& Q1) {
-    const int k = it * BK + kq;
+  // per-item state of the loader (rows / weight rows this thread fetches)
+  struct Cur { const float* in; const float* q0p; const float* q1p; int ro0, ro1; bool pv0, pv1, qv0, qv1; };
+  auto decode = [&](int item, int& pi, int& m0, int& n0) {
+    pi = 0;
+#pragma unroll
+    for (int q = 0; q + 1 < kMaxConvProb; ++q)
+      if (q + 1 < s.n_prob && item >= s.p[q].item_end) pi = q + 1;
+    const int local = item - (pi ? s.p[pi - 1].item_end : 0);
+    const int tn = s.p[pi].tiles_n;
+    const int mt = local / tn, nt = local - mt * tn;
+    m0 = mt * TM; n0 = nt * TN;
+  };
+  auto cursor = [&](int item) {
+    Cur c;
+    int pi, m0, n0;
+    decode(item, pi, m0, n0);
+    const ConvGroup& t = s.p[pi];
+    const int r0 = m0 + (tid >> 4), r1 = r0 + 16;
+    c.pv0 = r0 < t.M; c.pv1 = r1 < t.M;
+    c.ro0 = conv_rowoff(g, s.ix, c.pv0 ? r0 : t.M - 1);
+    c.ro1 = conv_rowoff(g, s.ix, c.pv1 ? r1 : t.M - 1);
+    c.in = t.in;
+    const int ntot = t.n_sub * g.Cout;
+    const int c0 = n0 + (tid >> 4), c1 = c0 + 16;
+    c.qv0 = c0 < ntot; c.qv1 = c1 < ntot;
+    const int cc0 = c.qv0 ? c0 : 0, cc1 = c.qv1 ? c1 : 0;
+    const int s0 = cc0 / g.Cout, s1 = cc1 / g.Cout;
+    c.q0p = t.w[s0] + (size_t)(cc0 - s0 * g.Cout) * g.K;
+    c.q1p = t.w[s1] + (size_t)(cc1 - s1 * g.Cout) * g.K;
+    return c;
+  };
+  auto load = [&](const Cur& c, int kt, f32x4& P0, f32x4& P1, f32x4& Q0, f32x4& Q1) {
+    const int k = kt * BK + kq;
     const bool kv = k < g.K;           // K % 4 == 0: a quad is entirely inside or outside
     const int kc = kv ? k : 0;
     const int km = conv_kmap(g, kc);
-    P0 = *(const f32x4u*)(t.in + ro0 + km);
-    P1 = *(const f32x4u*)(t.in + ro1 + km);
-    Q0 = *(const f32x4u*)(q0p + kc);
-    Q1 = *(const f32x4u*)(q1p + kc);
-    if (!(kv && pv0)) P0 = zero;
-    if (!(kv && pv1)) P1 = zero;
-    if (!(kv && qv0)) Q0 = zero;
-    if (!(kv && qv1)) Q1 = zero;
+    P0 = *(const f32x4u*)(c.in + c.ro0 + km);
+    P1 = *(const f32x4u*)(c.in + c.ro1 + km);
+    Q0 = *(const f32x4u*)(c.q0p + kc);
+    Q1 = *(const f32x4u*)(c.q1p + kc);
+    if (!(kv && c.pv0)) P0 = zero;
+    if (!(kv && c.pv1)) P1 = zero;
+    if (!(kv && c.qv0)) Q0 = zero;
+    if (!(kv && c.qv1)) Q1 = zero;
   };
-  const int T = (g.K + BK - 1) / BK;
-  f32x4 acc0 = zero, acc1 = zero;
+  int item = blockIdx.x;
+  if (item >= s.n_items) return;
+  Cur cur = cursor(item);
   f32x4 p0, p1, q0, q1;
-  load(0, p0, p1, q0, q1);
-  // epilogue operand early
-  const int m = m0 + wr * 16 + i;
-  const int n = n0 + wc * 16 + 4 * gq;
-  const bool in_range = m < t.M && n < g.Cout;   // Cout % 4 == 0
-  f32x4 bv = zero;
-  if (in_range) bv = *(const f32x4u*)(t.bias + n);
-  for (int it = 0; it < T; ++it) {
-    const int bb = it & 1;
-    float* Ps = lds + bb * 2 * TILE_LDS;
-    float* Qs = Ps + TILE_LDS;
-    tile_store_lds<false>(Ps, tid, p0, p1);
-    tile_store_lds<false>(Qs, tid, q0, q1);
-    __syncthreads();
-    if (it + 1 < T) load(it + 1, p0, p1, q0, q1);
-    tile_mma<false, false>(Ps, Qs, wr * 16 + i, wc * 16 + i, gq, acc0, acc1);
-  }
-  if (!in_range) return;
-  f32x4 o = acc0 + acc1 + bv;
+  load(cur, 0, p0, p1, q0, q1);
+  int step = 0;
+  while (item < s.n_items) {
+    int pi, m0, n0;
+    decode(item, pi, m0, n0);
+    const ConvGroup& t = s.p[pi];
+    // epilogue operands of this item, fetched before the MFMA run
+    const int m = m0 + wr * 16 + i;
+    const int n = n0 + wc * 16 + 4 * gq;
+    const bool in_range = m < t.M && n < t.n_sub * g.Cout;   // Cout % 4 == 0
+    const int sub = in_range ? n / g.Cout : 0;
+    const int co = n - sub * g.Cout;
+    f32x4 bv = zero;
+    if (in_range) bv = *(const f32x4u*)(t.bias[sub] + co);
+    const int next_item = item + gridDim.x;
+    Cur nxt = cur;
+    f32x4 acc0 = zero, acc1 = zero;
+    for (int kt = 0; kt < T; ++kt, ++step) {
+      float* Ps = lds + (step & 1) * 2 * TILE_LDS;
+      float* Qs = Ps + TILE_LDS;
+      tile_store_lds<false>(Ps, tid, p0, p1);
+      tile_store_lds<false>(Qs, tid, q0, q1);
+      __syncthreads();
+      if (kt + 1 < T) load(cur, kt + 1, p0, p1, q0, q1);
+      else if (next_item < s.n_items) { nxt = cursor(next_item); load(nxt, 0, p0, p1, q0, q1); }
+      tile_mma<false, false>(Ps, Qs, wr * 16 + i, wc * 16 + i, gq, acc0, acc1);
+    }
+    if (in_range) {
+      f32x4 o = acc0 + acc1 + bv;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
-  *(f32x4u*)(t.out + (size_t)m * g.Cout + n) = o;
+      for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
+      *(f32x4u*)(t.out[sub] + (size_t)m * g.Cout + co) = o;
+    }
+    cur = nxt;
+    item = next_item;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward, narrow layers (K <= 16*NKK <= 80, n_sub*Cout <= 32: the first two layers of conv type_2, which
+// hold 2/3 of the stack's pixels): WAVE-autonomous tiles, no LDS, no barriers. A lane (i = lane&15,
+// g = lane>>4) feeds the matrix core with row i of both operands and the four k = 16*kk + 4*g + e of MFMA
+// e -- exactly one dwordx4 of a patch row / weight row, so fragments are loaded straight from L2 into
+// registers. The weight fragments of a group stay in registers across all of the wave's tiles; the patch
+// fragments of the next tile are in flight while the current 32 x 32 tile is multiplied.
+// ---------------------------------------------------------------------------------------------
+template <int NKK, int NB>   // k groups of 16, channel blocks of 16
+__global__ void __launch_bounds__(kThreads) k_conv_fwd_narrow(ConvStageArgs s) {
+  const ConvGeom& g = s.g;
+  const int lane = threadIdx.x & 63;
+  const int i = lane & 15, gq = lane >> 4;
+  const int wave_global = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  const int n_waves = gridDim.x * (kThreads / 64);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  int km[NKK]; bool kv[NKK];
+#pragma unroll
+  for (int kk = 0; kk < NKK; ++kk) {
+    const int k = 16 * kk + 4 * gq;
+    kv[kk] = k < g.K;
+    km[kk] = conv_kmap(g, kv[kk] ? k : 0);
+  }
+  auto decode = [&](int item, int& pi, int& m0) {
+    pi = 0;
+#pragma unroll
+    for (int q = 0; q + 1 < kMaxConvProb; ++q)
+      if (q + 1 < s.n_prob && item >= s.p[q].item_end) pi = q + 1;
+    m0 = (item - (pi ? s.p[pi - 1].item_end : 0)) * 32;
+  };
+  auto load_p = [&](int item, f32x4 (&P)[2][NKK]) {
+    int pi, m0;
+    decode(item, pi, m0);
+    const ConvGroup& t = s.p[pi];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const int m = m0 + mb * 16 + i;
+      const bool mv = m < t.M;
+      const float* base = t.in + conv_rowoff(g, s.ix, mv ? m : t.M - 1);
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) P[mb][kk] = *(const f32x4u*)(base + km[kk]);
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) if (!(mv && kv[kk])) P[mb][kk] = zero;
+    }
+  };
+  f32x4 Q[NB][NKK], bv[NB];
+  int cur_pi = -1;
+  auto load_q = [&](int pi) {
+    const ConvGroup& t = s.p[pi];
+    const int ntot = t.n_sub * g.Cout;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = nb * 16 + i;
+      const bool nv = n < ntot;
+      const int nc = nv ? n : 0;
+      const int sub = nc / g.Cout;
+      const float* wrow = t.w[sub] + (size_t)(nc - sub * g.Cout) * g.K;
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        Q[nb][kk] = *(const f32x4u*)(wrow + (kv[kk] ? 16 * kk + 4 * gq : 0));
+        if (!(nv && kv[kk])) Q[nb][kk] = zero;
+      }
+      const int nq = nb * 16 + 4 * gq;   // this lane's output channels of block nb
+      const bool qv = nq < ntot;
+      const int sq = qv ? nq / g.Cout : 0;
+      bv[nb] = qv ? *(const f32x4u*)(t.bias[sq] + (nq - sq * g.Cout)) : zero;
+    }
+  };
+  auto compute = [&](int item, const f32x4 (&P)[2][NKK]) {
+    int pi, m0;
+    decode(item, pi, m0);
+    if (pi != cur_pi) { load_q(pi); cur_pi = pi; }
+    const ConvGroup& t = s.p[pi];
+    const int ntot = t.n_sub * g.Cout;
+    f32x4 acc[2][NB];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = zero;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Q[nb][kk][e], P[mb][kk][e], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const int m = m0 + mb * 16 + i;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = nb * 16 + 4 * gq;
+        if (m < t.M && n < ntot) {
+          const int sub = n / g.Cout, co = n - sub * g.Cout;
+          f32x4 o = acc[mb][nb] + bv[nb];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
+          *(f32x4u*)(t.out[sub] + (size_t)m * g.Cout + co) = o;
+        }
+      }
+    }
+  };
+  int item = wave_global;
+  if (item >= s.n_items) return;
+  f32x4 Pa[2][NKK], Pb[2][NKK];
+  load_p(item, Pa);
+  while (true) {
+    const int nx = item + n_waves;
+    if (nx < s.n_items) load_p(nx, Pb);
+    compute(item, Pa);
+    if (nx >= s.n_items) break;
+    item = nx + n_waves;
+    if (item < s.n_items) load_p(item, Pa);
+    compute(nx, Pb);
+    if (item >= s.n_items) break;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -124,13 +300,17 @@ __global__ void __launch_bounds__(kThreads) k_conv_fwd(ConvStageArgs s) {
 //   part[chunk][co][kidx] = sum_{m in chunk} dY[m][co] * P'(m, kidx),  kidx in [0, K]  (P'(m, K) = 1 -> bias)
 // Both operands are "row contiguous" in memory (dY: co contiguous, patch: k contiguous) and are
 // transposed into the k-contiguous LDS image on the way in (tile_store_lds<true>).
+// Like the forward groups, a problem may carry up to 3 dY's that share the input (layer 0 of the nets
+// that see `obs`): their channel rows are concatenated so that the gathered patch tile is staged once.
 // ---------------------------------------------------------------------------------------------
 struct ConvDwProb {
-  const float* in;    // layer input  [B*H*W][Cin]
-  const float* dy;    // [M][Cout]
-  float* part;        // [n_chunks][Cout][K1p]
+  const float* in;       // layer input  [B*H*W][Cin]
+  const float* dy[3];    // [M][Cout] each
+  float* part[3];        // [n_chunks][Cout][K1p] each
+  int n_sub;
   int M;
-  int block_end;      // exclusive end of this problem's block range
+  int tiles_co;          // ceil(n_sub*Cout / 32)
+  int block_end;         // exclusive end of this problem's block range
 };
 struct ConvDwArgs {
   ConvGeom g;
@@ -138,7 +318,7 @@ struct ConvDwArgs {
   ConvDwProb p[3];
   int n_prob;
   int chunk;          // pixels per chunk (multiple of 64)
-  int n_chunks, tiles_co, tiles_k;  // per problem: n_chunks * tiles_co * tiles_k blocks
+  int n_chunks, tiles_k;  // per problem: n_chunks * tiles_co * tiles_k blocks
   int K1p;            // padded partial row length: K + 4
 };
 
@@ -151,7 +331,7 @@ __global__ void __launch_bounds__(kThreads) k_conv_dw(ConvDwArgs s) {
   const ConvDwProb& t = s.p[pi];
   const ConvGeom& g = s.g;
   int local = b - (pi ? s.p[pi - 1].block_end : 0);
-  const int per_chunk = s.tiles_co * s.tiles_k;
+  const int per_chunk = t.tiles_co * s.tiles_k;
   const int ch = local / per_chunk;
   local -= ch * per_chunk;
   const int ct = local / s.tiles_k, kt = local - ct * s.tiles_k;
@@ -161,9 +341,12 @@ __global__ void __launch_bounds__(kThreads) k_conv_dw(ConvDwArgs s) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int i = lane & 15, gq = lane >> 4;
+  const int ntot = t.n_sub * g.Cout;
   // MC cursors: this thread's 4 consecutive rows (co / kidx) and its two m slots per 64-pixel tile
-  const int pc = co0 + (tid & 7) * 4;            // co quad
-  const bool pcv = pc < g.Cout;
+  const int pc = co0 + (tid & 7) * 4;            // (concatenated) co quad; Cout % 4 == 0: one sub per quad
+  const bool pcv = pc < ntot;
+  const int psub = pcv ? pc / g.Cout : 0;
+  const float* dyp = t.dy[psub] + (pcv ? pc - psub * g.Cout : 0);
   const int qk = k0 + (tid & 7) * 4;             // kidx quad
   const int qmode = qk < g.K ? 0 : (qk == g.K ? 1 : 2);  // gathered / bias column / padding
   const int qmap = conv_kmap(g, qmode == 0 ? qk : 0);
@@ -175,8 +358,8 @@ __global__ void __launch_bounds__(kThreads) k_conv_dw(ConvDwArgs s) {
     const bool va = ma < me, vc = mc < me;
     const int mac = va ? ma : t.M - 1, mcc = vc ? mc : t.M - 1;
     const int roa = s.rowoff[mac], roc = s.rowoff[mcc];
-    P0 = *(const f32x4u*)(t.dy + (size_t)mac * g.Cout + (pcv ? pc : 0));
-    P1 = *(const f32x4u*)(t.dy + (size_t)mcc * g.Cout + (pcv ? pc : 0));
+    P0 = *(const f32x4u*)(dyp + (size_t)mac * g.Cout);
+    P1 = *(const f32x4u*)(dyp + (size_t)mcc * g.Cout);
     Q0 = *(const f32x4u*)(t.in + roa + qmap);
     Q1 = *(const f32x4u*)(t.in + roc + qmap);
     if (!(va && pcv)) P0 = zero;                 // masking dY is enough: the other operand is finite
@@ -198,10 +381,81 @@ __global__ void __launch_bounds__(kThreads) k_conv_dw(ConvDwArgs s) {
     if (it + 1 < T) load(it + 1, p0, p1, q0, q1);
     tile_mma<true, true>(Ps, Qs, wr * 16 + i, wc * 16 + i, gq, acc0, acc1);
   }
-  const int co = co0 + wr * 16 + i;
+  const int cot = co0 + wr * 16 + i;
   const int kk = k0 + wc * 16 + 4 * gq;
-  if (co < g.Cout && kk < s.K1p)
-    *(f32x4u*)(t.part + ((size_t)ch * g.Cout + co) * s.K1p + kk) = acc0 + acc1;
+  if (cot < ntot && kk < s.K1p) {
+    const int sub = cot / g.Cout, co = cot - sub * g.Cout;
+    *(f32x4u*)(t.part[sub] + ((size_t)ch * g.Cout + co) * s.K1p + kk) = acc0 + acc1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// data gradient of the narrow layers (Cin <= 16) without a column buffer:
+//   dX[b,y,x,:] = relu'(x) * sum_{ky,kx valid} sum_co dY[b,(y-ky)/s,(x-kx)/s,co] * W[co][ky][kx][:]
+// one thread per input pixel, all Cin channels in registers. A workgroup handles pixels of ONE parity
+// class (y mod s, x mod s), so the set of contributing taps -- and with it every weight address -- is
+// wave-uniform: weights arrive through the scalar cache and feed v_fmac as SGPR operands; the only vector
+// loads are the dY rows. These layers have a huge pixel count and 8-16 channels: matrix-core tiles would be
+// mostly padding, and the [M x K] column buffer of the dCol/col2im route is 4.5x the size of dX.
+// ---------------------------------------------------------------------------------------------
+struct ConvDxArgs {
+  ConvGeom g;
+  const float* dy[3];     // [M][Cout]
+  const float* w[3];      // [Cout][K]
+  const float* x[3];      // layer input activations [B*H*W][Cin] (ReLU mask)
+  float* dx[3];           // [B*H*W][Cin]
+  int n_prob;
+  int B;
+};
+template <int NQ>   // Cin / 4
+__global__ void __launch_bounds__(kThreads) k_conv_dx_direct(ConvDxArgs a) {
+  const ConvGeom& g = a.g;
+  const int pi = blockIdx.y;
+  const int st = g.stride;
+  const int py = blockIdx.z / st, px = blockIdx.z - py * st;
+  const int Yq = (g.H - py + st - 1) / st, Xq = (g.W - px + st - 1) / st;
+  const int idx = blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= a.B * Yq * Xq) return;
+  const int xq = idx % Xq;
+  const int t1 = idx / Xq;
+  const int yq = t1 % Yq, b = t1 / Yq;
+  f32x4 acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* __restrict__ dyb = a.dy[pi];
+  const float* __restrict__ wb = a.w[pi];
+  for (int ky = py, ay = 0; ky < g.KS; ky += st, ++ay) {
+    const int oy = yq - ay;
+    const bool vy = oy >= 0 && oy < g.OH;
+    for (int kx = px, ax = 0; kx < g.KS; kx += st, ++ax) {
+      const int ox = xq - ax;
+      const bool v = vy && ox >= 0 && ox < g.OW;
+      const float* dyp = dyb + (((size_t)b * g.OH + (v ? oy : 0)) * g.OW + (v ? ox : 0)) * g.Cout;
+      const float* wt = wb + (ky * g.KS + kx) * g.Cin;   // uniform across the workgroup
+      for (int c4 = 0; c4 < g.Cout; c4 += 4) {
+        f32x4 d = *(const f32x4u*)(dyp + c4);
+        if (!v) d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float* wr_ = wt + (size_t)(c4 + e) * g.K;
+          const f32x4 dv = {d[e], d[e], d[e], d[e]};
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)   // explicit fma (the build disables contraction): packed v_pk_fma_f32
+            acc[q] = __builtin_elementwise_fma(dv, *(const f32x4u*)(wr_ + 4 * q), acc[q]);
+        }
+      }
+    }
+  }
+  const int y = yq * st + py, x = xq * st + px;
+  const size_t o = (((size_t)b * g.H + y) * g.W + x) * (4 * NQ);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const f32x4 xv = *(const f32x4u*)(a.x[pi] + o + 4 * q);
+    f32x4 r = acc[q];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = xv[e] > 0.f ? r[e] : 0.f;
+    *(f32x4u*)(a.dx[pi] + o + 4 * q) = r;
+  }
 }
 
 // sums the partials in a fixed order, writes the gradient and (single-GPU path) applies Adam / Polyak
