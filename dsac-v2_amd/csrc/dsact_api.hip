@@ -149,6 +149,7 @@ struct dsact_handle {
   // strict DP
   bool use_std_sums = false;
   bool auto_std_sums = false;
+  float* std_sums_own = nullptr;
 };
 
 namespace {
@@ -862,8 +863,11 @@ int enqueue_prologue(dsact_handle* h, int use_dev, long long it, int advance, in
 }
 
 // everything of __compute_gradient after the minibatch is staged (dsac_v2.py:150-206)
-int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused) {
+// phase 0: everything; 1: forward part up to the local {sum std1, sum std2} (strict data-parallel mode: the
+// caller all-reduces those two floats); 2: loss + backward (+ fused update)
+int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 0) {
   const int L = h->L, B = h->B, A = h->A;
+  if (phase != 2) {
   if (h->cnn) TRY(enqueue_conv_forward(h));
   for (int l = 0; l < L; ++l) TRY(run_stage(h, h->fwd1[l]));
   {
@@ -897,6 +901,8 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused) {
     s.qstd_c[0] = h->qstd_c[0]; s.qstd_c[1] = h->qstd_c[1]; s.B = B; s.out = h->std_sums;
     TRY(launch(h, "std_sums", k_std_sums, dim3(1), dim3(kThreads), 0, s));
   }
+  }  // phase != 2
+  if (phase == 1) return DSACT_OK;
   {
     LossArgs a;
     const int chs[4] = {C_Q1T, C_Q2T, C_Q1P, C_Q2P};
@@ -1580,6 +1586,36 @@ int dsact_dp_enqueue_grads(dsact_handle* h, uint32_t flags) {
   TRY(enqueue_gather(h, h->idx_table, h->idx_rows, 1, 0, 0));
   h->have_batch = true;
   return enqueue_grads(h, true, false);
+}
+
+int dsact_dp_set_strict(dsact_handle* h, float* std_sums_dev) {
+  if (!h) return DSACT_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->graph_exec) return fail(h, DSACT_E_STATE, "data-parallel mode is baked into the captured graph");
+  if (!h->std_sums_own) h->std_sums_own = h->std_sums;
+  h->use_std_sums = std_sums_dev != nullptr;
+  h->std_sums = std_sums_dev ? std_sums_dev : h->std_sums_own;
+  return DSACT_OK;
+}
+
+int dsact_dp_enqueue_forward(dsact_handle* h, uint32_t flags) {
+  TRY(check_ready(h, false));
+  if (!h->idx_table) return fail(h, DSACT_E_STATE, "upload an index table first");
+  if (!h->use_std_sums) return fail(h, DSACT_E_STATE, "dsact_dp_set_strict first");
+  HIPCHK(h, hipSetDevice(h->device));
+  (void)flags;
+  TRY(enqueue_gather(h, h->idx_table, h->idx_rows, 1, 0, 0));
+  h->have_batch = true;
+  return enqueue_grads(h, true, false, 1);
+}
+
+int dsact_dp_enqueue_backward(dsact_handle* h, uint32_t flags) {
+  TRY(check_ready(h, true));
+  if (!h->use_std_sums) return fail(h, DSACT_E_STATE, "dsact_dp_set_strict first");
+  HIPCHK(h, hipSetDevice(h->device));
+  (void)flags;
+  return enqueue_grads(h, true, false, 2);
 }
 
 int dsact_dp_enqueue_apply(dsact_handle* h) {

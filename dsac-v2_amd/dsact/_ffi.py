@@ -78,6 +78,9 @@ SYMBOLS = [
     ("dsact_graph_run", C.c_int, [_P, C.c_int64, C.c_int64]),
     ("dsact_dp_begin", C.c_int, [_P, C.c_int64]),
     ("dsact_dp_enqueue_grads", C.c_int, [_P, C.c_uint32]),
+    ("dsact_dp_set_strict", C.c_int, [_P, _P]),
+    ("dsact_dp_enqueue_forward", C.c_int, [_P, C.c_uint32]),
+    ("dsact_dp_enqueue_backward", C.c_int, [_P, C.c_uint32]),
     ("dsact_dp_enqueue_apply", C.c_int, [_P]),
     ("dsact_read_stats", C.c_int, [_P, _FP]),
     ("dsact_time_steps", C.c_int, [_P, C.c_int64, C.c_int64, C.c_uint32, C.c_int32, _FP]),

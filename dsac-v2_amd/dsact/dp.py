@@ -13,6 +13,11 @@ Local losses are local means, so the average over ranks is the gradient of the g
 The two trailing floats carry the updated `mean_std` EMA so that the replicated state stays bitwise
 identical across ranks without a second collective ("fast" mode).
 
+`strict=True` adds the reference-exact variant: every rank's loss uses the GLOBAL
+batch mean of the critics' std in the mean_std EMA, which costs a second, 2-float all-reduce between the
+forward and the loss (engine.dp_forward / engine.std_sums / engine.dp_backward); the averaged gradients
+then equal the single-process global-batch gradients to fp32 summation order, first step included.
+
 `engine` is anything exposing `.grads` (flat torch tensor), `.dp_grads()`, `.dp_apply()` -- the
 DsactEngine in production; the CPU tests drive the same coordinator with an oracle-backed stand-in
 over the gloo backend.
@@ -22,13 +27,16 @@ import torch.distributed as dist
 
 
 class DataParallelUpdater:
-    def __init__(self, engine, group=None, broadcast_tensors=()):
+    def __init__(self, engine, group=None, broadcast_tensors=(), strict=False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.engine, self.group = engine, group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self._avg = dist.get_backend(group) == "nccl"  # RCCL supports ReduceOp.AVG; gloo does not
+        self.strict = bool(strict)
+        if self.strict:
+            engine.dp_set_strict(True)
         # replicas must start identical: rank 0's parameters / optimiser state win
         for t in broadcast_tensors:
             dist.broadcast(t, src=0, group=group)
@@ -44,6 +52,12 @@ class DataParallelUpdater:
             g.div_(self.world)
 
     def step(self):
-        self.engine.dp_grads()
+        if self.strict:
+            self.engine.dp_forward()
+            if self.world > 1:
+                dist.all_reduce(self.engine.std_sums, op=dist.ReduceOp.SUM, group=self.group)
+            self.engine.dp_backward()
+        else:
+            self.engine.dp_grads()
         self.allreduce_grads()
         self.engine.dp_apply()

@@ -229,6 +229,22 @@ class DsactEngine:
     def dp_grads(self, flags: int = 0):
         self._chk(self._lib.dsact_dp_enqueue_grads(self._h, int(flags)))
 
+    def dp_set_strict(self, enable: bool = True):
+        """strict data-parallel mode: `std_sums` (2 floats, torch-owned) is all-reduced by the caller between
+        dp_forward() and dp_backward()"""
+        if enable:
+            self.std_sums = self.torch.zeros(2, dtype=self.torch.float32, device=self.device)
+            self._chk(self._lib.dsact_dp_set_strict(self._h, self.std_sums.data_ptr()))
+        else:
+            self._chk(self._lib.dsact_dp_set_strict(self._h, None))
+            self.std_sums = None
+
+    def dp_forward(self, flags: int = 0):
+        self._chk(self._lib.dsact_dp_enqueue_forward(self._h, int(flags)))
+
+    def dp_backward(self, flags: int = 0):
+        self._chk(self._lib.dsact_dp_enqueue_backward(self._h, int(flags)))
+
     def dp_apply(self):
         self._chk(self._lib.dsact_dp_enqueue_apply(self._h))
 

@@ -164,6 +164,17 @@ int dsact_graph_run(dsact_handle* h, int64_t first_iteration, int64_t n_steps);
  * dsact_dp_begin sets the first iteration (synchronous). */
 int dsact_dp_begin(dsact_handle* h, int64_t first_iteration);
 int dsact_dp_enqueue_grads(dsact_handle* h, uint32_t flags);
+/* STRICT data-parallel mode: the mean_std EMA of every rank uses the GLOBAL batch
+ * mean of the critics' std, which needs one 2-float all-reduce between the forward and the loss:
+ *   dsact_dp_set_strict(h, buf)      buf = 2 device floats owned by the caller (a torch tensor the caller
+ *                                    all-reduces with SUM); NULL switches back to the one-collective mode
+ *   dsact_dp_enqueue_forward         gather + forward + local {sum std1, sum std2} -> buf
+ *   [all_reduce(buf, SUM)]
+ *   dsact_dp_enqueue_backward        loss (mean over cfg.global_batch) + backward -> gradient arena
+ *   [all_reduce(grads) / world]      then dsact_dp_enqueue_apply as in the one-collective mode */
+int dsact_dp_set_strict(dsact_handle* h, float* std_sums_dev);
+int dsact_dp_enqueue_forward(dsact_handle* h, uint32_t flags);
+int dsact_dp_enqueue_backward(dsact_handle* h, uint32_t flags);
 int dsact_dp_enqueue_apply(dsact_handle* h);
 
 /* 14 numeric tb_info entries of the last update in the order of dsac_v2.py:188-202

@@ -259,14 +259,19 @@ class DsactOracle:
         q1, q1_std = self._q(obs, act, self.p["q1"], c_q1)
         q2, q2_std = self._q(obs, act, self.p["q2"], c_q2)
         tau_b = cfg["tau_b"]
+        m1, m2 = torch.mean(q1_std.detach()), torch.mean(q2_std.detach())
+        if getattr(self, "std_mean_override", None) is not None:
+            # strict data-parallel restatement: the batch means over the GLOBAL batch,
+            # supplied by the test harness after its 2-float all-reduce; not part of the reference
+            m1, m2 = self.std_mean_override
         if isinstance(self.mean_std1, float) and self.mean_std1 == -1.0:
-            self.mean_std1 = torch.mean(q1_std.detach())
+            self.mean_std1 = m1
         else:
-            self.mean_std1 = (1 - tau_b) * self.mean_std1 + tau_b * torch.mean(q1_std.detach())
+            self.mean_std1 = (1 - tau_b) * self.mean_std1 + tau_b * m1
         if isinstance(self.mean_std2, float) and self.mean_std2 == -1.0:
-            self.mean_std2 = torch.mean(q2_std.detach())
+            self.mean_std2 = m2
         else:
-            self.mean_std2 = (1 - tau_b) * self.mean_std2 + tau_b * torch.mean(q2_std.detach())
+            self.mean_std2 = (1 - tau_b) * self.mean_std2 + tau_b * m2
         q1_next, q1n_std = self._q(obs2, act2, self.p["q1_target"])
         q2_next, q2n_std = self._q(obs2, act2, self.p["q2_target"])
         q1_next_sample = self._q_eval(q1_next, q1n_std, noise["z5"])

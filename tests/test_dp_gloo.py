@@ -34,6 +34,22 @@ class OracleDPEngine:
         n = orc.flat_params().numel()
         self.grads = torch.zeros(n + 2)
 
+    # strict mode: local std sums -> (coordinator all-reduces std_sums) -> loss with the global means
+    def dp_set_strict(self, enable=True):
+        self.std_sums = torch.zeros(2) if enable else None
+
+    def dp_forward(self):
+        b = self.batches[self.k]
+        with torch.no_grad():
+            _, s1 = self.orc._q(b["obs"], b["act"], self.orc.p["q1"])
+            _, s2 = self.orc._q(b["obs"], b["act"], self.orc.p["q2"])
+        self.std_sums[0], self.std_sums[1] = s1.sum(), s2.sum()
+
+    def dp_backward(self):
+        self.orc.std_mean_override = (self.std_sums[0] / self.global_batch, self.std_sums[1] / self.global_batch)
+        self.dp_grads()
+        self.orc.std_mean_override = None
+
     def dp_grads(self):
         self.orc.compute_gradient(self.batches[self.k], self.noises[self.k])
         self.grads[:-2] = self.orc.flat_grads()
@@ -53,7 +69,7 @@ class OracleDPEngine:
         self.k += 1
 
 
-def _worker(rank, world, port, out_q):
+def _worker(rank, world, port, out_q, strict=False):
     for p in (ROOT, os.path.join(ROOT, "dsac-v2_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -78,11 +94,17 @@ def _worker(rank, world, port, out_q):
     sb = [{k: v[lo:hi] for k, v in b.items()} for b in gb]
     sn = [{k: (v[lo:hi] if torch.is_tensor(v) else v) for k, v in n.items()} for n in gn]
     eng = OracleDPEngine(orc, sb, sn)
+    eng.global_batch = B
     flat = [t for n in DsactOracle.NETS for t in orc.p[n]] + [orc.log_alpha]
-    dp = DataParallelUpdater(eng, broadcast_tensors=[t.data for t in flat])
+    dp = DataParallelUpdater(eng, broadcast_tensors=[t.data for t in flat], strict=strict)
     grads0 = None
     for k in range(steps):
-        eng.dp_grads()
+        if strict:
+            eng.dp_forward()
+            dist.all_reduce(eng.std_sums, op=dist.ReduceOp.SUM)
+            eng.dp_backward()
+        else:
+            eng.dp_grads()
         dp.allreduce_grads()
         if k == 0:
             grads0 = eng.grads.clone()
@@ -133,3 +155,31 @@ def test_two_rank_data_parallel_matches_global_batch():
     assert abs(ms0 - msr) <= 1e-6
     # (3) parameters after 4 updates track the single-process run (Adam moves ~lr per step)
     assert np.abs(p0 - pr).max() <= 5e-4
+
+
+def test_two_rank_strict_mode_equals_global_batch_gradient():
+    """strict=True: the 2-float pre-loss all-reduce makes the averaged shard gradients EQUAL the single-process
+    global-batch gradients (fp32 summation order only), sentinel step included."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world + 1):
+        item = q.get(timeout=180)
+        got[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g0, p0, ms0 = got[0]
+    g1, p1, ms1 = got[1]
+    gr, pr, msr = got["ref"]
+    np.testing.assert_array_equal(p0, p1)
+    np.testing.assert_array_equal(g0, g1)
+    n = gr.size
+    assert np.abs(g0[:n] - gr).max() <= 2e-6 * np.abs(gr).max() + 1e-9
+    assert abs(ms0 - msr) <= 1e-6
+    assert np.abs(p0 - pr).max() <= 2.1e-4   # Adam sign ambiguity of rounding-level gradients: 2*lr

@@ -447,6 +447,71 @@ def test_data_parallel_halves_equal_graph_replay():
             dist.destroy_process_group()
 
 
+def test_strict_data_parallel_shards_equal_global_batch():
+    """SURVEY.md section 8e, strict mode: two replicas on the halves of one minibatch, with the 2-float
+    pre-loss exchange of {sum std1, sum std2} (emulated in-process: gpurun exposes one GPU), average to the
+    gradient of ONE engine on the whole minibatch -- sentinel step (mean_std = -1) included -- and agree on
+    the mean_std EMA. The one-collective ("fast") mode differs on that step by the local-vs-global mean."""
+    O, A, hid, B, N = 17, 4, (64, 64), 64, 512
+    from dsac_v2_hip import DSAC_V2_HIP
+
+    def build(batch):
+        torch.manual_seed(11)
+        alg = DSAC_V2_HIP(**hip_kwargs(O, A, hid, batch, strict_rng=True, global_batch=B))
+        e = alg.engine
+        e.buffer_create(N)
+        g = torch.Generator(device="cuda").manual_seed(7)
+        e.buffer_fill_device(0, torch.randn(N, O, device="cuda", generator=g), torch.rand(N, A, device="cuda", generator=g) - .5,
+                             torch.randn(N, device="cuda", generator=g), torch.randn(N, O, device="cuda", generator=g),
+                             (torch.rand(N, device="cuda", generator=g) < .05).float())
+        return alg
+
+    full, h0, h1 = build(B), build(B // 2), build(B // 2)
+    np.random.seed(3)
+    idx = np.random.randint(0, N, size=(1, B))
+    torch.manual_seed(5)
+    noise = draw_noise(B, A)
+    n = {k: noise[k].numpy() for k in ("eps_new", "eps_2", "z5", "z6")}
+    full.engine.upload_index_table(idx)
+    full.engine.set_noise(n["eps_new"], n["eps_2"], n["z5"], n["z6"])
+    halves = (h0.engine, h1.engine)
+    for r, e in enumerate(halves):
+        lo, hi = r * B // 2, (r + 1) * B // 2
+        e.upload_index_table(idx[:, lo:hi])
+        e.set_noise(n["eps_new"][lo:hi], n["eps_2"][lo:hi], n["z5"][lo:hi], n["z6"][lo:hi])
+        e.dp_set_strict(True)
+    fe = full.engine
+    fe.dp_begin(0)
+    fe.dp_grads()
+    fe.sync()
+    for e in halves:
+        e.dp_begin(0)
+        e.dp_forward()
+        e.sync()
+    total = halves[0].std_sums + halves[1].std_sums     # the all-reduce(SUM) of the real job
+    for e in halves:
+        e.std_sums.copy_(total)
+    torch.cuda.synchronize()
+    for e in halves:
+        e.dp_backward()
+        e.sync()
+    g_avg = (halves[0].grads + halves[1].grads) / 2
+    nn_ = fe.layout.n_online
+    rep = Report("strict data-parallel halves vs global batch")
+    rep.cmp("grad (avg of shards)", g_avg[:nn_].cpu().numpy(), fe.grads[:nn_].cpu(), 1e-9, 5e-6)
+    rep.cmp("mean_std (tail of the arena)", g_avg[nn_:].cpu().numpy(), fe.grads[nn_:].cpu(), 1e-7)
+    assert torch.equal(halves[0].grads[nn_:], halves[1].grads[nn_:])
+    # fast mode on the same shards: not equal on the sentinel step (documents why strict exists)
+    f0 = build(B // 2).engine
+    f0.upload_index_table(idx[:, :B // 2])
+    f0.set_noise(n["eps_new"][:B // 2], n["eps_2"][:B // 2], n["z5"][:B // 2], n["z6"][:B // 2])
+    f0.dp_begin(0)
+    f0.dp_grads()
+    f0.sync()
+    assert not torch.equal(f0.grads[nn_:], halves[0].grads[nn_:])
+    rep.finish()
+
+
 def test_error_paths_are_loud():
     from dsact._ffi import DsactError
     from dsact.engine import DsactEngine

@@ -3,6 +3,7 @@ import ctypes
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -107,3 +108,57 @@ def test_plugin_discovery_rules():
     assert hasattr(m, "HipReplayBuffer")
     m = importlib.import_module("dsac_v2_hip")
     assert hasattr(m, "DSAC_V2_HIP") and hasattr(m, "ApproxContainer")
+
+
+def test_cnn_arena_layout_views_are_disjoint_and_preserve_the_networks():
+    """CNN nets: conv weights live in the arena as [Cout][KH][KW][Cin] and the twin
+    mean/log_std output layers inside one (n_out x 2H) matrix; the state_dict tensors are strided views of it.
+    Emulates ApproxContainer.attach on CPU arenas: no two parameters alias, values and forward passes survive."""
+    import numpy as np
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "dsac-v2_amd"))
+    import dsac_v2_hip as m
+    from helpers import hip_kwargs
+
+    obs_shape, A = (3, 96, 96), 3
+    kw = hip_kwargs(obs_shape, A, (256, 256, 256), 8, act_limit=1.0)
+    for key in ("value", "policy"):
+        kw[key + "_func_type"] = "CNN"
+        kw[key + "_conv_type"] = "type_2"
+        kw.pop(key + "_hidden_sizes")
+    torch.manual_seed(0)
+    c = m.ApproxContainer(**kw)
+    lay = c._layout
+    assert lay.feat_dim == 256 and lay.n_online == 2 * lay.n_q + lay.n_pi + 1
+    before = {k: v.clone() for k, v in c.state_dict().items()}
+    obs = torch.rand(2, *obs_shape)
+    act = torch.rand(2, A)
+    with torch.no_grad():
+        q_before, pi_before = c.q1(obs, act), c.policy(obs)
+    arenas = {"online": torch.zeros(lay.n_online), "target": torch.zeros(lay.n_target)}
+    owner = {"online": torch.full((lay.n_online,), -1, dtype=torch.long), "target": torch.full((lay.n_target,), -1, dtype=torch.long)}
+    with torch.no_grad():
+        for i, (p, arena, off, shape, strides) in enumerate(c._named_param_slots()):
+            view = torch.as_strided(arenas[arena], shape, strides, off)
+            ids = torch.as_strided(owner[arena], shape, strides, off)
+            assert int((ids != -1).sum()) == 0, "parameter %d overlaps an earlier one" % i
+            ids.fill_(i)
+            view.copy_(p.data)
+            p.data = view
+    # everything not owned by a parameter is a structural zero of a twin output layer: 2*H floats per Q net,
+    # 2*A*H per policy net (include/dsact.h)
+    H = lay.hidden[-1]
+    assert int((owner["online"] == -1).sum()) == 2 * (2 * H) + 2 * A * H
+    assert int((owner["target"] == -1).sum()) == 2 * (2 * H) + 2 * A * H
+    after = c.state_dict()
+    assert list(after.keys()) == list(before.keys()) == list(lay.state_dict_keys().keys())
+    for k in before:
+        assert torch.equal(before[k], after[k]), k
+    with torch.no_grad():
+        # strided weights may take another BLAS path: values agree to rounding
+        assert torch.allclose(c.q1(obs, act), q_before, atol=1e-6) and torch.allclose(c.policy(obs), pi_before, atol=1e-6)
+    # conv weight memory order is [Cout][KH][KW][Cin]
+    w = c.q1.conv[2].weight
+    flat = arenas["online"][lay.param_views("q1")[2][2]:][: w.numel()].view(w.shape[0], w.shape[2], w.shape[3], w.shape[1])
+    assert torch.equal(flat.permute(0, 3, 1, 2), w)
