@@ -83,7 +83,6 @@ struct dsact_handle {
   int n_conv = 0, Brows = 0;            // Brows = max(B, kActRows): rows the shared geometry tables cover
   ConvGeom cg[kMaxConv];
   int cP = 1;                           // pixels of the last conv layer
-  int* rowoff[kMaxConv];                // [Brows*OH*OW] patch origins
   float* img[2];                        // staged minibatch images (obs, obs2), pixel-major
   float* cact[N_STACK][kMaxConv];
   float* cdy[3][kMaxConv];
@@ -283,7 +282,6 @@ void carve(dsact_handle* h, Carver& c) {
     for (int j = 0; j < h->n_conv; ++j) {
       const ConvGeom& g = h->cg[j];
       const size_t M = B * g.OH * g.OW;
-      h->rowoff[j] = c.take<int>(R * g.OH * g.OW);
       for (int st = 0; st < N_STACK; ++st) h->cact[st][j] = c.take<float>(M * g.Cout);
       for (int st = 0; st < 3; ++st) h->cdy[st][j] = c.take<float>(M * g.Cout);
       if (j > 0 && M * g.K > dcol_max) dcol_max = M * g.K;
@@ -692,7 +690,7 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused) {
     {
       ConvDwArgs a;
       memset(&a, 0, sizeof(a));
-      a.g = g; a.rowoff = h->rowoff[j];
+      a.g = g; a.ix = conv_index(g);
       a.chunk = chunk; a.n_chunks = n_chunks; a.K1p = K1p;
       a.tiles_k = tiles_of(a.K1p, TN);
       int blocks = 0;
@@ -722,9 +720,16 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused) {
         c.x[st] = h->cact[st][j - 1]; c.dx[st] = h->cdy[st][j - 1];
       }
       const int Yq = (g.H + g.stride - 1) / g.stride, Xq = (g.W + g.stride - 1) / g.stride;   // largest parity class
-      const dim3 grid((unsigned)((B * Yq * Xq + kThreads - 1) / kThreads), n_st, g.stride * g.stride);
-      if (g.Cin == 8) TRY(launch(h, ("conv_dx" + sfx).c_str(), k_conv_dx_direct<2>, grid, dim3(kThreads), 0, c));
-      else TRY(launch(h, ("conv_dx" + sfx).c_str(), k_conv_dx_direct<4>, grid, dim3(kThreads), 0, c));
+      if (g.KS == 3 && g.stride == 2) {
+        // one thread per 2x2 pixel block (all four parity classes)
+        const dim3 gb((unsigned)((B * Yq * Xq + kThreads - 1) / kThreads), n_st);
+        if (g.Cin == 8) TRY(launch(h, ("conv_dx" + sfx).c_str(), (k_conv_dx_block<2, 3, 2>), gb, dim3(kThreads), 0, c));
+        else TRY(launch(h, ("conv_dx" + sfx).c_str(), (k_conv_dx_block<4, 3, 2>), gb, dim3(kThreads), 0, c));
+      } else {
+        const dim3 grid((unsigned)((B * Yq * Xq + kThreads - 1) / kThreads), n_st, g.stride * g.stride);
+        if (g.Cin == 8) TRY(launch(h, ("conv_dx" + sfx).c_str(), k_conv_dx_direct<2>, grid, dim3(kThreads), 0, c));
+        else TRY(launch(h, ("conv_dx" + sfx).c_str(), k_conv_dx_direct<4>, grid, dim3(kThreads), 0, c));
+      }
     } else if (j > 0) {
       // dCol[m][k] = sum_co dY[m][co] W[co][k]: dense KC x MC product, plain store
       Stage s;
@@ -764,7 +769,8 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused) {
       r.n_prob = n_st; r.Cout = g.Cout; r.K = g.K; r.K1p = K1p; r.n_chunks = n_chunks;
       r.quads = g.Cout * K1p / 4;
       r.fo = fused_opt(h, fused);
-      TRY(launch(h, ("conv_dw_reduce" + sfx).c_str(), k_conv_dw_reduce, dim3((r.quads + 15) / 16, n_st), dim3(kThreads), 0, r));
+      if (n_chunks > 16) TRY(launch(h, ("conv_dw_reduce" + sfx).c_str(), k_conv_dw_reduce<16>, dim3((r.quads + 15) / 16, n_st), dim3(kThreads), 0, r));
+      else TRY(launch(h, ("conv_dw_reduce" + sfx).c_str(), k_conv_dw_reduce<1>, dim3((r.quads + kThreads - 1) / kThreads, n_st), dim3(kThreads), 0, r));
     }
   }
   return DSACT_OK;
@@ -1114,14 +1120,9 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (h->cnn) {
     for (int j = 0; j < h->n_conv; ++j) {
       const ConvGeom& g = h->cg[j];
-      std::vector<int> ro((size_t)h->Brows * g.OH * g.OW);
-      size_t m = 0;
-      for (int b = 0; b < h->Brows; ++b)
-        for (int oy = 0; oy < g.OH; ++oy)
-          for (int ox = 0; ox < g.OW; ++ox)
-            ro[m++] = (int)((((size_t)b * g.H + (size_t)oy * g.stride) * g.W + (size_t)ox * g.stride) * g.Cin);
-      if ((size_t)h->Brows * g.H * g.W * g.Cin > 2147483647ull) return fail(h, DSACT_E_INVALID, "batch x image too large for 32-bit patch offsets");
-      HIPCHK(h, hipMemcpy(h->rowoff[j], ro.data(), ro.size() * sizeof(int), hipMemcpyHostToDevice));
+      // patch origins are 32-bit float offsets, pixel indices go through an exact float-reciprocal division
+      if ((size_t)h->Brows * g.H * g.W * g.Cin > 2147483647ull || (size_t)h->Brows * g.OH * g.OW >= (1u << 24))
+        return fail(h, DSACT_E_INVALID, "batch x image too large for the conv index arithmetic (layer %d)", j);
     }
     std::vector<int> iota(h->Brows);
     for (int i = 0; i < h->Brows; ++i) iota[i] = i;

@@ -314,7 +314,8 @@ struct ConvDwProb {
 };
 struct ConvDwArgs {
   ConvGeom g;
-  const int* rowoff;
+  ConvIndex ix;          // patch origins are computed (two exact reciprocal divisions), not looked up: a table
+                         // lookup is a dependent load in front of every gathered load
   ConvDwProb p[3];
   int n_prob;
   int chunk;          // pixels per chunk (multiple of 64)
@@ -357,7 +358,7 @@ __global__ void __launch_bounds__(kThreads) k_conv_dw(ConvDwArgs s) {
     const int ma = mb + it * BK + ms, mc = ma + 32;
     const bool va = ma < me, vc = mc < me;
     const int mac = va ? ma : t.M - 1, mcc = vc ? mc : t.M - 1;
-    const int roa = s.rowoff[mac], roc = s.rowoff[mcc];
+    const int roa = conv_rowoff(g, s.ix, mac), roc = conv_rowoff(g, s.ix, mcc);
     P0 = *(const f32x4u*)(dyp + (size_t)mac * g.Cout);
     P1 = *(const f32x4u*)(dyp + (size_t)mcc * g.Cout);
     Q0 = *(const f32x4u*)(t.in + roa + qmap);
@@ -458,6 +459,89 @@ __global__ void __launch_bounds__(kThreads) k_conv_dx_direct(ConvDxArgs a) {
   }
 }
 
+// Same contraction, one thread per S x S block of input pixels (all stride-parity classes at once): the block's
+// pixels share the (KS/S)^2 neighbouring dY rows, which are loaded once, and the thread writes S adjacent pixels
+// per image row -- whole cache lines across the wave instead of every other pixel.
+template <int NQ, int KS, int S>
+__global__ void __launch_bounds__(kThreads) k_conv_dx_block(ConvDxArgs a) {
+  constexpr int AY = (KS + S - 1) / S;
+  const ConvGeom& g = a.g;
+  const int pi = blockIdx.y;
+  const int Yb = (g.H + S - 1) / S, Xb = (g.W + S - 1) / S;
+  const int idx = blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= a.B * Yb * Xb) return;
+  const int xq = idx % Xb;
+  const int t1 = idx / Xb;
+  const int yq = t1 % Yb, b = t1 / Yb;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[S * S][NQ];
+#pragma unroll
+  for (int c = 0; c < S * S; ++c)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[c][q] = zero;
+  const float* __restrict__ wb = a.w[pi];
+  const float* dyp[AY][AY];
+  bool dv[AY][AY];
+#pragma unroll
+  for (int ay = 0; ay < AY; ++ay)
+#pragma unroll
+    for (int ax = 0; ax < AY; ++ax) {
+      const int oy = yq - ay, ox = xq - ax;
+      dv[ay][ax] = oy >= 0 && oy < g.OH && ox >= 0 && ox < g.OW;
+      dyp[ay][ax] = a.dy[pi] + (((size_t)b * g.OH + (dv[ay][ax] ? oy : 0)) * g.OW + (dv[ay][ax] ? ox : 0)) * g.Cout;
+    }
+  for (int c4 = 0; c4 < g.Cout; c4 += 4) {
+    // (loading all 16 channels' quads of a trip up front was measured slower: 118-168 VGPRs and spilled SGPRs)
+    f32x4 d[AY][AY];
+#pragma unroll
+    for (int ay = 0; ay < AY; ++ay)
+#pragma unroll
+      for (int ax = 0; ax < AY; ++ax) d[ay][ax] = *(const f32x4u*)(dyp[ay][ax] + c4);
+#pragma unroll
+    for (int ay = 0; ay < AY; ++ay)
+#pragma unroll
+      for (int ax = 0; ax < AY; ++ax) if (!dv[ay][ax]) d[ay][ax] = zero;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float* wrow = wb + (size_t)(c4 + e) * g.K;   // wave-uniform: scalar loads
+#pragma unroll
+      for (int py = 0; py < S; ++py)
+#pragma unroll
+        for (int px = 0; px < S; ++px)
+#pragma unroll
+          for (int ay = 0; ay < AY; ++ay)
+#pragma unroll
+            for (int ax = 0; ax < AY; ++ax) {
+              const int ky = py + S * ay, kx = px + S * ax;
+              if (ky < KS && kx < KS) {
+                const float de = d[ay][ax][e];
+                const f32x4 dd = {de, de, de, de};
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                  acc[py * S + px][q] = __builtin_elementwise_fma(dd, *(const f32x4u*)(wrow + (ky * KS + kx) * (4 * NQ) + 4 * q), acc[py * S + px][q]);
+              }
+            }
+    }
+  }
+#pragma unroll
+  for (int py = 0; py < S; ++py)
+#pragma unroll
+    for (int px = 0; px < S; ++px) {
+      const int y = yq * S + py, x = xq * S + px;
+      if (y < g.H && x < g.W) {
+        const size_t o = (((size_t)b * g.H + y) * g.W + x) * (4 * NQ);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const f32x4 xv = *(const f32x4u*)(a.x[pi] + o + 4 * q);
+          f32x4 r = acc[py * S + px][q];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[e] = xv[e] > 0.f ? r[e] : 0.f;
+          *(f32x4u*)(a.dx[pi] + o + 4 * q) = r;
+        }
+      }
+    }
+}
+
 // sums the partials in a fixed order, writes the gradient and (single-GPU path) applies Adam / Polyak
 struct ConvReduceProb {
   const float* part;
@@ -471,33 +555,37 @@ struct ConvReduceArgs {
   FusedOpt fo;
 };
 
+template <int CL>   // chunk lanes per quad: 16 (many chunks: tree over lanes) or 1 (few chunks: one thread per quad)
 __global__ void __launch_bounds__(kThreads) k_conv_dw_reduce(ConvReduceArgs a) {
   __shared__ f32x4 red[kThreads];
+  constexpr int QL = kThreads / CL;
   const int tid = threadIdx.x;
-  const int ql = tid & 15, cl = tid >> 4;             // 16 quads x 16 chunk lanes per block
+  const int ql = tid % QL, cl = tid / QL;
   const int pi = blockIdx.y;
   const ConvReduceProb& t = a.p[pi];
-  const int q = blockIdx.x * 16 + ql;
+  const int q = blockIdx.x * QL + ql;
   const bool qv = q < a.quads;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (qv) {
-    // chunk lane cl sums chunks cl, cl+16, ...: 4 independent loads per trip
-    for (int c0 = cl; c0 < a.n_chunks; c0 += 64) {
+    // chunk lane cl sums chunks cl, cl+CL, ...: 4 independent loads per trip
+    for (int c0 = cl; c0 < a.n_chunks; c0 += 4 * CL) {
       f32x4 v[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int c = c0 + 16 * u;
+        const int c = c0 + CL * u;
         v[u] = *(const f32x4u*)(t.part + ((size_t)(c < a.n_chunks ? c : 0) * a.quads + q) * 4);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) if (c0 + 16 * u < a.n_chunks) s += v[u];
+      for (int u = 0; u < 4; ++u) if (c0 + CL * u < a.n_chunks) s += v[u];
     }
   }
-  red[tid] = s;
-  __syncthreads();
-  if (cl != 0 || !qv) return;
+  if (CL > 1) {
+    red[tid] = s;
+    __syncthreads();
+    if (cl != 0 || !qv) return;
 #pragma unroll
-  for (int u = 1; u < 16; ++u) s += red[u * 16 + ql];
+    for (int u = 1; u < CL; ++u) s += red[u * QL + ql];
+  } else if (!qv) return;
   const int co = (q * 4) / a.K1p, kk = q * 4 - co * a.K1p;
   if (kk > a.K) return;                               // padding quad
   const FusedOpt& fo = a.fo;
@@ -629,12 +717,13 @@ __global__ void __launch_bounds__(kThreads) k_gather_img(ImgGatherArgs a) {
   float* d0 = a.img0 + (size_t)r * O;
   float* d2 = a.img2 + (size_t)r * O;
   const int n4 = (int)(O >> 2);   // C*HW % 4 == 0 is checked at create time
+  const float inv_c = 1.0f / (float)a.C;
   for (int q = ck * kThreads + threadIdx.x; q < n4; q += a.chunks * kThreads) {
     f32x4 v, w;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int o = q * 4 + e;
-      const int pix = o / a.C, c = o - pix * a.C;
+      const int pix = fast_div(o, a.C, inv_c), c = o - pix * a.C;
       v[e] = so[(size_t)c * a.HW + pix];
       w[e] = so2[(size_t)c * a.HW + pix];
     }
