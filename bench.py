@@ -279,10 +279,16 @@ def main():
     import torch
 
     dp = None
-    if world > 1:
+    # DSACT_BENCH_FORCE_DP=1: take the data-parallel (RCCL) code path even with one rank -- the only way to
+    # exercise it on a 1-GPU box
+    use_dp = world > 1 or os.environ.get("DSACT_BENCH_FORCE_DP") == "1"
+    if use_dp:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         dist.barrier()
@@ -296,13 +302,18 @@ def main():
     e = alg.engine
     fill_replay(e, args.replay_rows, seed=100 + rank)  # every rank owns its own replay shard
     upload_indices(e, args.replay_rows, IDX_ROWS, seed=1 + rank)
-    if world > 1:
+    if use_dp:
         from dsact.dp import DataParallelUpdater
 
         e.use_torch_stream()
-        dp = DataParallelUpdater(e, broadcast_tensors=(e.online, e.target, e.adam_m, e.adam_v))
+        # default: ONE all-reduce after the whole backward. DSACT_DP_OVERLAP=1 all-reduces the critics' 2/3 of the
+        # arena asynchronously under the actor's backward -- measured on one rank the second collective call and
+        # its cross-stream events cost +40 us/step against +14.5 us for the single call, so it is opt-in
+        dp = DataParallelUpdater(e, broadcast_tensors=(e.online, e.target, e.adam_m, e.adam_v),
+                                 overlap=os.environ.get("DSACT_DP_OVERLAP", "0") == "1")
+        dp.force_collective = os.environ.get("DSACT_DP_FORCE_COLLECTIVE") == "1"
     wall, ev_ms = measure(alg, steps, warmup, world, dp, flags=1 if args.fast else 0)
-    if world > 1:
+    if use_dp:
         import torch.distributed as dist
 
         t = torch.tensor([wall], device="cuda")
@@ -327,7 +338,7 @@ def main():
                         % ("x".join(map(str, hidden)), args.batch, args.replay_rows),
             "global_batch": args.batch * world, "parallelism": "dp%d" % world, "hidden": hidden,
             "noise": "device Philox4x32-10", "mode": "fast (discarded actor backward skipped)" if args.fast else "strict (every gradient the reference computes)",
-            "launch": "hipGraph (2 steps/graph)" if world == 1 else "eager + RCCL all-reduce",
+            "launch": "hipGraph (2 steps/graph)" if not use_dp else ("eager + RCCL all-reduce (%s)" % ("critics' segment overlapped with the actor backward" if dp.overlap else "single")),
             "unit_note": "value = synchronized updates/s x n_gpus (each rank contributes one batch-256 gradient per update)",
         },
         "finite_stats": finite,
@@ -373,14 +384,14 @@ def main():
             out["dominant_kernel"] = {"name": dom[0], "us": round(dom[1] * 1000, 2)}
         except Exception as ex:  # profiling is informational
             out["kernels_error"] = str(ex)
-    if rank == 0 and world == 1 and not args.fast:
+    if rank == 0 and not use_dp and not args.fast:
         # same workload with the actor/alpha backward skipped on the off iterations of the delayed update: the
         # reference computes and discards those gradients (dsac_v2.py:174-186 vs :324); bitwise-identical parameter
         # trajectory (tests/test_hip_parity.py::test_skip_discarded_actor_backward_keeps_trajectory)
         wf, _ = measure(alg, steps, warmup, flags=1)
         out["fast"] = {"value": steps / wf, "unit": "steps/s", "ms_per_step": 1000.0 * wf / steps,
                        "note": "DSACT_F_SKIP_ACTOR_ON_OFF_ITERS; not the headline value"}
-    if world == 1 and not args.no_alt and args.batch == B:
+    if not use_dp and not args.no_alt and args.batch == B:
         alt_hidden = [256, 256] if hidden != [256, 256] else [256, 256, 256]
         del alg
         alg2 = make_alg(alt_hidden, local, seed=0)
@@ -391,16 +402,16 @@ def main():
         out["alt"] = {"hidden": alt_hidden, "value": steps / w2, "unit": "steps/s",
                       "frac_fp32": l2.flop_per_step(B) * steps / w2 / 1e12 / FP32_PEAK_TFLOPS,
                       "frac_hbm": l2.bytes_per_step(B, 2) * steps / w2 / 1e9 / HBM_PEAK_GBS}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.batch == B:
+    if rank == 0 and not use_dp and not args.no_cpu_baseline and args.batch == B:
         out["cpu_baseline"] = cpu_baseline(hidden)
-    if rank == 0 and world == 1 and not args.no_alt and args.batch == B:
+    if rank == 0 and not use_dp and not args.no_alt and args.batch == B:
         try:
             out["cnn"] = bench_cnn(local, args.cnn_steps, 40, cpu=not args.no_cpu_baseline)
         except Exception as ex:  # secondary workload: never costs the headline line
             out["cnn_error"] = repr(ex)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dp:
         import torch.distributed as dist
 
         dist.barrier()

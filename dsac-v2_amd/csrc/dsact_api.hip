@@ -671,13 +671,15 @@ int enqueue_conv_forward(dsact_handle* h) {
 // conv stacks backward for the first n_st differentiated stacks (q1, q2[, policy]); dfeat[] must hold
 // dL/d(features). Per layer: weight/bias gradient partials + ordered reduce (+ Adam/Polyak when `fused`),
 // then dCol = dY W and the col2im gather into the previous layer's dY.
-int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused) {
+// stacks [st_lo, st_lo + n_st) of (q1, q2, policy)
+int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) {
   const int B = h->B;
   const int last = h->n_conv - 1;
+  auto S = [st_lo](int st) { return st_lo + st; };
   {
     FeatBwdArgs f;
     memset(&f, 0, sizeof(f));
-    for (int st = 0; st < n_st; ++st) { f.dfeat[st] = h->dfeat[st]; f.act[st] = h->cact[st][last]; f.dy[st] = h->cdy[st][last]; }
+    for (int st = 0; st < n_st; ++st) { f.dfeat[st] = h->dfeat[S(st)]; f.act[st] = h->cact[S(st)][last]; f.dy[st] = h->cdy[S(st)][last]; }
     f.n_stack = n_st; f.B = B; f.P = h->cP; f.C = h->cg[last].Cout;
     const long long n = (long long)B * h->F;
     TRY(launch(h, "feat_bwd", k_feat_bwd, dim3((unsigned)((n + kThreads - 1) / kThreads), n_st), dim3(kThreads), 0, f));
@@ -698,9 +700,9 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused) {
       const int per_prob = j == 0 ? n_st : 1;
       for (int st0 = 0; st0 < n_st; st0 += per_prob) {
         ConvDwProb& p = a.p[a.n_prob++];
-        p.in = j == 0 ? h->img[0] : h->cact[st0][j - 1];
+        p.in = j == 0 ? h->img[0] : h->cact[S(st0)][j - 1];
         p.n_sub = per_prob;
-        for (int u = 0; u < per_prob; ++u) { p.dy[u] = h->cdy[st0 + u][j]; p.part[u] = h->dwpart[st0 + u]; }
+        for (int u = 0; u < per_prob; ++u) { p.dy[u] = h->cdy[S(st0 + u)][j]; p.part[u] = h->dwpart[S(st0 + u)]; }
         p.M = M;
         p.tiles_co = tiles_of(per_prob * g.Cout, TM);
         blocks += a.n_chunks * p.tiles_co * a.tiles_k;
@@ -715,9 +717,9 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused) {
       memset(&c, 0, sizeof(c));
       c.g = g; c.n_prob = n_st; c.B = B;
       for (int st = 0; st < n_st; ++st) {
-        const int net = kStackNet[st];
-        c.dy[st] = h->cdy[st][j]; c.w[st] = net_params(h, net) + net_desc(h, net).cw_off[j];
-        c.x[st] = h->cact[st][j - 1]; c.dx[st] = h->cdy[st][j - 1];
+        const int net = kStackNet[S(st)];
+        c.dy[st] = h->cdy[S(st)][j]; c.w[st] = net_params(h, net) + net_desc(h, net).cw_off[j];
+        c.x[st] = h->cact[S(st)][j - 1]; c.dx[st] = h->cdy[S(st)][j - 1];
       }
       const int Yq = (g.H + g.stride - 1) / g.stride, Xq = (g.W + g.stride - 1) / g.stride;   // largest parity class
       if (g.KS == 3 && g.stride == 2) {
@@ -736,13 +738,13 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused) {
       s.name = "conv_dcol" + sfx; s.kind = 2; s.n_blocks = 0;
       memset(&s.args, 0, sizeof(s.args));
       for (int st = 0; st < n_st; ++st) {
-        const int net = kStackNet[st];
+        const int net = kStackNet[S(st)];
         const NetDesc& d = net_desc(h, net);
         GemmProb t;
         memset(&t, 0, sizeof(t));
-        t.P = h->cdy[st][j]; t.ldp = g.Cout;
+        t.P = h->cdy[S(st)][j]; t.ldp = g.Cout;
         t.Q = net_params(h, net) + d.cw_off[j]; t.ldq = g.K;
-        t.C0 = h->dcol[st]; t.ldc = g.K;
+        t.C0 = h->dcol[S(st)]; t.ldc = g.K;
         t.M = M; t.N = g.K; t.K = g.Cout;
         stage_add(s, t);
       }
@@ -750,7 +752,7 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused) {
       Col2imArgs c;
       memset(&c, 0, sizeof(c));
       c.g = g; c.n_prob = n_st; c.B = B;
-      for (int st = 0; st < n_st; ++st) { c.dcol[st] = h->dcol[st]; c.x[st] = h->cact[st][j - 1]; c.dx[st] = h->cdy[st][j - 1]; }
+      for (int st = 0; st < n_st; ++st) { c.dcol[st] = h->dcol[S(st)]; c.x[st] = h->cact[S(st)][j - 1]; c.dx[st] = h->cdy[S(st)][j - 1]; }
       const long long n = (long long)B * g.H * g.W * (g.Cin / 4);
       TRY(launch(h, ("col2im" + sfx).c_str(), k_col2im, dim3((unsigned)((n + kThreads - 1) / kThreads), n_st), dim3(kThreads), 0, c));
     }
@@ -760,9 +762,9 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused) {
       ConvReduceArgs r;
       memset(&r, 0, sizeof(r));
       for (int st = 0; st < n_st; ++st) {
-        const int net = kStackNet[st];
+        const int net = kStackNet[S(st)];
         const NetDesc& d = net_desc(h, net);
-        r.p[st].part = h->dwpart[st];
+        r.p[st].part = h->dwpart[S(st)];
         r.p[st].w_idx = (long long)((net_grads(h, net) + d.cw_off[j]) - h->grads);
         r.p[st].b_idx = (long long)((net_grads(h, net) + d.cb_off[j]) - h->grads);
       }
@@ -870,9 +872,13 @@ int enqueue_prologue(dsact_handle* h, int use_dev, long long it, int advance, in
 
 // everything of __compute_gradient after the minibatch is staged (dsac_v2.py:150-206)
 // phase 0: everything; 1: forward part up to the local {sum std1, sum std2} (strict data-parallel mode: the
-// caller all-reduces those two floats); 2: loss + backward (+ fused update)
+// caller all-reduces those two floats); 2: loss + backward (+ fused update);
+// 3 / 4 (data-parallel overlap, unfused): 3 = everything up to and including the critics' gradients (q1 | q2
+// segment of the arena final), 4 = actor part (policy | log_alpha | mean_std tail) -- the caller starts the
+// all-reduce of the first segment between the two
 int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 0) {
   const int L = h->L, B = h->B, A = h->A;
+  if (phase == 4) goto actor_part;
   if (phase != 2) {
   if (h->cnn) TRY(enqueue_conv_forward(h));
   for (int l = 0; l < L; ++l) TRY(run_stage(h, h->fwd1[l]));
@@ -948,6 +954,12 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
   }
   for (size_t i = 0; i < h->bwdq.size(); ++i) TRY(run_stage(h, h->bwdq[i]));
   if (h->cnn) TRY(run_stage(h, h->dfeat_q));   // reads the step's padded copy of W0: safe against the fused Adam below
+  if (phase == 3) {
+    TRY(run_dw(h, h->dw_off[0], h->dw_off[2], false, false));
+    if (h->cnn) TRY(enqueue_conv_backward(h, 2, false));
+    return DSACT_OK;
+  }
+actor_part:
   if (h->use_fork && !h->profiling) {
     HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
@@ -980,6 +992,13 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
     for (size_t i = 0; i < np; ++i) TRY(run_stage(h, h->bwdpi[i], 0, 0, fused));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
     TRY(run_dw(h, h->dw_off[2], h->dw_off[3], fused, fused));
+    return DSACT_OK;
+  }
+  if (phase == 4) {
+    for (size_t i = 0; i < np; ++i) TRY(run_stage(h, h->bwdpi[i]));
+    if (h->cnn) TRY(run_stage(h, h->dfeat_pi));
+    TRY(run_dw(h, h->dw_off[2], h->dw_off[3], false, false));
+    if (h->cnn) TRY(enqueue_conv_backward(h, 1, false, 2));
     return DSACT_OK;
   }
   // unforked: the critics' tiles ride along in the under-filled policy-backward launches
@@ -1587,6 +1606,24 @@ int dsact_dp_enqueue_grads(dsact_handle* h, uint32_t flags) {
   TRY(enqueue_gather(h, h->idx_table, h->idx_rows, 1, 0, 0));
   h->have_batch = true;
   return enqueue_grads(h, true, false);
+}
+
+int dsact_dp_enqueue_grads_critic(dsact_handle* h, uint32_t flags) {
+  TRY(check_ready(h, false));
+  if (!h->idx_table) return fail(h, DSACT_E_STATE, "upload an index table first");
+  if (h->use_std_sums) return fail(h, DSACT_E_STATE, "the split gradient halves are for the one-collective mode (strict mode has its own halves)");
+  HIPCHK(h, hipSetDevice(h->device));
+  (void)flags;
+  TRY(enqueue_gather(h, h->idx_table, h->idx_rows, 1, 0, 0));
+  h->have_batch = true;
+  return enqueue_grads(h, true, false, 3);
+}
+
+int dsact_dp_enqueue_grads_actor(dsact_handle* h, uint32_t flags) {
+  TRY(check_ready(h, true));
+  HIPCHK(h, hipSetDevice(h->device));
+  (void)flags;
+  return enqueue_grads(h, true, false, 4);
 }
 
 int dsact_dp_set_strict(dsact_handle* h, float* std_sums_dev) {

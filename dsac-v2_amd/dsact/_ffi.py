@@ -78,6 +78,8 @@ SYMBOLS = [
     ("dsact_graph_run", C.c_int, [_P, C.c_int64, C.c_int64]),
     ("dsact_dp_begin", C.c_int, [_P, C.c_int64]),
     ("dsact_dp_enqueue_grads", C.c_int, [_P, C.c_uint32]),
+    ("dsact_dp_enqueue_grads_critic", C.c_int, [_P, C.c_uint32]),
+    ("dsact_dp_enqueue_grads_actor", C.c_int, [_P, C.c_uint32]),
     ("dsact_dp_set_strict", C.c_int, [_P, _P]),
     ("dsact_dp_enqueue_forward", C.c_int, [_P, C.c_uint32]),
     ("dsact_dp_enqueue_backward", C.c_int, [_P, C.c_uint32]),

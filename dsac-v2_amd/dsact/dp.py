@@ -27,23 +27,26 @@ import torch.distributed as dist
 
 
 class DataParallelUpdater:
-    def __init__(self, engine, group=None, broadcast_tensors=(), strict=False):
+    def __init__(self, engine, group=None, broadcast_tensors=(), strict=False, overlap=False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.engine, self.group = engine, group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self._avg = dist.get_backend(group) == "nccl"  # RCCL supports ReduceOp.AVG; gloo does not
+        self.force_collective = False   # measurement aid: issue the all-reduce even with one rank
         self.strict = bool(strict)
         if self.strict:
             engine.dp_set_strict(True)
+        # overlap: all-reduce the critics' segment (2/3 of the arena) while the actor's backward still runs
+        self.overlap = bool(overlap) and not self.strict and hasattr(engine, "dp_grads_critic")
         # replicas must start identical: rank 0's parameters / optimiser state win
         for t in broadcast_tensors:
             dist.broadcast(t, src=0, group=group)
 
     def allreduce_grads(self):
         g = self.engine.grads
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return
         if self._avg:
             dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
@@ -51,7 +54,29 @@ class DataParallelUpdater:
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
             g.div_(self.world)
 
+    def _reduce_async(self, t):
+        if self._avg:
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def step_overlapped(self):
+        """critic half -> async all-reduce of grads[:n_c] on the collective's stream -> actor half ->
+        all-reduce of the rest -> wait both -> apply. Same arithmetic as step()."""
+        e = self.engine
+        g, n_c = e.grads, e.critic_grad_count
+        e.dp_grads_critic()
+        w1 = self._reduce_async(g[:n_c])
+        e.dp_grads_actor()
+        w2 = self._reduce_async(g[n_c:])
+        w1.wait()
+        w2.wait()
+        if not self._avg:
+            g.div_(self.world)
+        e.dp_apply()
+
     def step(self):
+        if self.overlap:
+            return self.step_overlapped()
         if self.strict:
             self.engine.dp_forward()
             if self.world > 1:

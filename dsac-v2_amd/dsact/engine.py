@@ -229,6 +229,17 @@ class DsactEngine:
     def dp_grads(self, flags: int = 0):
         self._chk(self._lib.dsact_dp_enqueue_grads(self._h, int(flags)))
 
+    def dp_grads_critic(self, flags: int = 0):
+        """first half of dp_grads: afterwards grads[:2*n_q] (q1 | q2) is final"""
+        self._chk(self._lib.dsact_dp_enqueue_grads_critic(self._h, int(flags)))
+
+    def dp_grads_actor(self, flags: int = 0):
+        self._chk(self._lib.dsact_dp_enqueue_grads_actor(self._h, int(flags)))
+
+    @property
+    def critic_grad_count(self):
+        return 2 * self.layout.n_q
+
     def dp_set_strict(self, enable: bool = True):
         """strict data-parallel mode: `std_sums` (2 floats, torch-owned) is all-reduced by the caller between
         dp_forward() and dp_backward()"""

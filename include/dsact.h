@@ -164,6 +164,11 @@ int dsact_graph_run(dsact_handle* h, int64_t first_iteration, int64_t n_steps);
  * dsact_dp_begin sets the first iteration (synchronous). */
 int dsact_dp_begin(dsact_handle* h, int64_t first_iteration);
 int dsact_dp_enqueue_grads(dsact_handle* h, uint32_t flags);
+/* dsact_dp_enqueue_grads in two halves so that the all-reduce of the critics' segment overlaps the actor's
+ * backward: after _critic the q1|q2 segment of the gradient arena is final; _actor fills policy | log_alpha |
+ * mean_std tail. [all_reduce(q1|q2) async] ... [all_reduce(rest)] ... dsact_dp_enqueue_apply. */
+int dsact_dp_enqueue_grads_critic(dsact_handle* h, uint32_t flags);
+int dsact_dp_enqueue_grads_actor(dsact_handle* h, uint32_t flags);
 /* STRICT data-parallel mode: the mean_std EMA of every rank uses the GLOBAL batch
  * mean of the critics' std, which needs one 2-float all-reduce between the forward and the loss:
  *   dsact_dp_set_strict(h, buf)      buf = 2 device floats owned by the caller (a torch tensor the caller
