@@ -178,6 +178,23 @@ def bench_cnn(device, steps, warmup, batch=B, cpu=True):
     return out
 
 
+def pmc_traffic_forward_stage():
+    """HBM-side bytes per launch of the forward tile stage from the committed PMC passes (profiles/r01_pmc_traffic.json,
+    produced by scripts/gpu_pmc2.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this bench, FETCH_SIZE doubled per the
+    MI355X guide's gfx950 note). Not measurable live (needs rocprofv3); None if the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        d = json.load(open(path))["mlp"]
+    except (OSError, KeyError, ValueError):
+        return None
+    tot, n = 0.0, 0
+    for k, v in d.items():
+        if "k_stage<false, false, 0" in k:
+            tot += (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0 * v["launches"]
+            n += v["launches"]
+    return tot / n if n else None
+
+
 def upload_indices(engine, n_rows, rows, seed):
     import numpy as np
 
@@ -357,12 +374,13 @@ def main():
         flop_launch = 2.0 * st_macs / n_st
         out["roofline"] = {
             "bound": "mfma", "achieved": flop_launch / (dur_us * 1e-6) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": flop_launch / (dur_us * 1e-6) / 1e12 / FP32_PEAK_TFLOPS, "traffic": None,
+            "frac": flop_launch / (dur_us * 1e-6) / 1e12 / FP32_PEAK_TFLOPS, "traffic": pmc_traffic_forward_stage(),
             "kernel": "dsact::k_stage<false,false,0,{0,4}> (forward tile stages: bias+GELU epilogue, 4 GEMM problems per launch)",
             "avg_launch_us": dur_us, "flop_per_launch": flop_launch,
             "note": "fp32 MFMA peak; avg over the %d forward stages, %d back-to-back launches each (hipEvents on the engine's "
-                    "stream); algorithmic FLOP = 2*M*N*K of the stage's problems. traffic: see profiles/ (PMC FETCH_SIZE "
-                    "x2 ~3.8 MB/launch -- the working set is L2/MALL resident, HBM is not the bound)" % (n_st, reps),
+                    "stream); algorithmic FLOP = 2*M*N*K of the stage's problems. traffic = bytes/launch (2*FETCH_SIZE + WRITE_SIZE) "
+                    "from the committed PMC passes (profiles/r01_pmc_summary.txt): ~5.4 MB against 4.2 MB of operands + outputs "
+                    "-- memory-side traffic is not what bounds this kernel" % (n_st, reps),
         }
         out["roofline_step"] = {
             "bound": "mfma", "achieved": flop * per_gpu_steps / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",

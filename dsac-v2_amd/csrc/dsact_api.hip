@@ -694,7 +694,11 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
       memset(&a, 0, sizeof(a));
       a.g = g; a.ix = conv_index(g);
       a.chunk = chunk; a.n_chunks = n_chunks; a.K1p = K1p;
-      a.tiles_k = tiles_of(a.K1p, TN);
+      const int kt_all = tiles_of(a.K1p, TN);
+      // k-tiles per workgroup (the dY tile would be staged once for all of them): measured slower than one
+      // k-tile per workgroup on every layer (fewer, longer dependent chains) -> 1
+      const int nkt = getenv("DSACT_CONV_DW_NKT") ? atoi(getenv("DSACT_CONV_DW_NKT")) : 1;
+      a.tiles_k = tiles_of(kt_all, nkt);             // k-groups
       int blocks = 0;
       // layer 0: every differentiated stack reads the staged `obs` image -> one problem, dY rows concatenated
       const int per_prob = j == 0 ? n_st : 1;
@@ -708,7 +712,11 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
         blocks += a.n_chunks * p.tiles_co * a.tiles_k;
         p.block_end = blocks;
       }
-      TRY(launch(h, ("conv_dw" + sfx).c_str(), k_conv_dw, dim3(blocks), dim3(kThreads), 0, a));
+      const size_t lds = (size_t)2 * (1 + nkt) * TILE_LDS * sizeof(float);
+      if (nkt == 1) TRY(launch(h, ("conv_dw" + sfx).c_str(), k_conv_dw<1>, dim3(blocks), dim3(kThreads), lds, a));
+      else if (nkt == 2) TRY(launch(h, ("conv_dw" + sfx).c_str(), k_conv_dw<2>, dim3(blocks), dim3(kThreads), lds, a));
+      else if (nkt == 3) TRY(launch(h, ("conv_dw" + sfx).c_str(), k_conv_dw<3>, dim3(blocks), dim3(kThreads), lds, a));
+      else return fail(h, DSACT_E_INVALID, "DSACT_CONV_DW_NKT must be 1..3");
     }
     const bool direct_dx = j > 0 && (g.Cin == 8 || g.Cin == 16) && g.Cout <= 32;
     if (direct_dx) {
@@ -1163,6 +1171,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, true, EPI_MULG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage_table, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, true, EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_conv_dw<3>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
   }
   for (int i = 0; i < 8; ++i) {
     HIPCHK(h, hipHostMalloc((void**)&h->h_idx[i], (size_t)h->B * sizeof(int), hipHostMallocDefault));

@@ -323,8 +323,12 @@ struct ConvDwArgs {
   int K1p;            // padded partial row length: K + 4
 };
 
+// NKT = k-tiles (32 patch columns each) per workgroup: the dY tile of a step is staged once and multiplied
+// with NKT patch tiles, so dY is not re-read per k-tile (PMC: the weight gradient was the largest consumer
+// of memory-side traffic, 2-3x its algorithmic bytes, when every k-tile had its own workgroup).
+template <int NKT>
 __global__ void __launch_bounds__(kThreads) k_conv_dw(ConvDwArgs s) {
-  __shared__ __attribute__((aligned(16))) float lds[4 * TILE_LDS];
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x (1 + NKT) tiles
   const int b = blockIdx.x;
   int pi = 0;
   if (s.n_prob > 1 && b >= s.p[0].block_end) pi = 1;
@@ -332,11 +336,11 @@ __global__ void __launch_bounds__(kThreads) k_conv_dw(ConvDwArgs s) {
   const ConvDwProb& t = s.p[pi];
   const ConvGeom& g = s.g;
   int local = b - (pi ? s.p[pi - 1].block_end : 0);
-  const int per_chunk = t.tiles_co * s.tiles_k;
+  const int per_chunk = t.tiles_co * s.tiles_k;   // tiles_k counts k-GROUPS of NKT tiles here
   const int ch = local / per_chunk;
   local -= ch * per_chunk;
-  const int ct = local / s.tiles_k, kt = local - ct * s.tiles_k;
-  const int co0 = ct * TM, k0 = kt * TN;
+  const int ct = local / s.tiles_k, kg = local - ct * s.tiles_k;
+  const int co0 = ct * TM, k0 = kg * NKT * TN;
   const int mb = ch * s.chunk;
   const int me = mb + s.chunk < t.M ? mb + s.chunk : t.M;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -348,45 +352,68 @@ __global__ void __launch_bounds__(kThreads) k_conv_dw(ConvDwArgs s) {
   const bool pcv = pc < ntot;
   const int psub = pcv ? pc / g.Cout : 0;
   const float* dyp = t.dy[psub] + (pcv ? pc - psub * g.Cout : 0);
-  const int qk = k0 + (tid & 7) * 4;             // kidx quad
-  const int qmode = qk < g.K ? 0 : (qk == g.K ? 1 : 2);  // gathered / bias column / padding
-  const int qmap = conv_kmap(g, qmode == 0 ? qk : 0);
+  int qmode[NKT], qmap[NKT];
+#pragma unroll
+  for (int u = 0; u < NKT; ++u) {
+    const int qk = k0 + u * TN + (tid & 7) * 4;  // kidx quad of k-tile u
+    qmode[u] = qk < g.K ? 0 : (qk == g.K ? 1 : 2);  // gathered / bias column / padding
+    qmap[u] = conv_kmap(g, qmode[u] == 0 ? qk : 0);
+  }
   const int ms = tid >> 3;                       // m slot 0 (slot 1 = +32)
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   const f32x4 one0 = {1.f, 0.f, 0.f, 0.f};
-  auto load = [&](int it, f32x4& P0, f32x4& P1, f32x4& Q0, f32x4& Q1) {
+  auto load = [&](int it, f32x4& P0, f32x4& P1, f32x4 (&Q0)[NKT], f32x4 (&Q1)[NKT]) {
     const int ma = mb + it * BK + ms, mc = ma + 32;
     const bool va = ma < me, vc = mc < me;
     const int mac = va ? ma : t.M - 1, mcc = vc ? mc : t.M - 1;
     const int roa = conv_rowoff(g, s.ix, mac), roc = conv_rowoff(g, s.ix, mcc);
     P0 = *(const f32x4u*)(dyp + (size_t)mac * g.Cout);
     P1 = *(const f32x4u*)(dyp + (size_t)mcc * g.Cout);
-    Q0 = *(const f32x4u*)(t.in + roa + qmap);
-    Q1 = *(const f32x4u*)(t.in + roc + qmap);
+#pragma unroll
+    for (int u = 0; u < NKT; ++u) {
+      Q0[u] = *(const f32x4u*)(t.in + roa + qmap[u]);
+      Q1[u] = *(const f32x4u*)(t.in + roc + qmap[u]);
+    }
     if (!(va && pcv)) P0 = zero;                 // masking dY is enough: the other operand is finite
     if (!(vc && pcv)) P1 = zero;
-    if (qmode == 1) { Q0 = one0; Q1 = one0; }
-    else if (qmode == 2) { Q0 = zero; Q1 = zero; }
+#pragma unroll
+    for (int u = 0; u < NKT; ++u) {
+      if (qmode[u] == 1) { Q0[u] = one0; Q1[u] = one0; }
+      else if (qmode[u] == 2) { Q0[u] = zero; Q1[u] = zero; }
+    }
   };
   const int T = (me - mb + BK - 1) / BK;
-  f32x4 acc0 = zero, acc1 = zero;
-  f32x4 p0, p1, q0, q1;
-  load(0, p0, p1, q0, q1);
-  for (int it = 0; it < T; ++it) {
-    const int bb = it & 1;
-    float* Ps = lds + bb * 2 * TILE_LDS;
-    float* Qs = Ps + TILE_LDS;
-    tile_store_lds<true>(Ps, tid, p0, p1);
-    tile_store_lds<true>(Qs, tid, q0, q1);
+  f32x4 acc0[NKT], acc1[NKT];
+#pragma unroll
+  for (int u = 0; u < NKT; ++u) { acc0[u] = zero; acc1[u] = zero; }
+  // two steps of global loads in flight (register sets a / b alternate): one step's L2/MALL round trip is
+  // longer than its 16 MFMAs + LDS staging, and a chunk is a dependent chain of 4-16 steps
+  f32x4 pa0, pa1, qa0[NKT], qa1[NKT], pb0, pb1, qb0[NKT], qb1[NKT];
+  load(0, pa0, pa1, qa0, qa1);
+  if (T > 1) load(1, pb0, pb1, qb0, qb1);
+  auto step = [&](int it, f32x4& P0, f32x4& P1, f32x4 (&Q0)[NKT], f32x4 (&Q1)[NKT]) {
+    float* Ps = lds + (it & 1) * (1 + NKT) * TILE_LDS;
+    tile_store_lds<true>(Ps, tid, P0, P1);
+#pragma unroll
+    for (int u = 0; u < NKT; ++u) tile_store_lds<true>(Ps + (1 + u) * TILE_LDS, tid, Q0[u], Q1[u]);
     __syncthreads();
-    if (it + 1 < T) load(it + 1, p0, p1, q0, q1);
-    tile_mma<true, true>(Ps, Qs, wr * 16 + i, wc * 16 + i, gq, acc0, acc1);
+    if (it + 2 < T) load(it + 2, P0, P1, Q0, Q1);
+#pragma unroll
+    for (int u = 0; u < NKT; ++u)
+      tile_mma<true, true>(Ps, Ps + (1 + u) * TILE_LDS, wr * 16 + i, wc * 16 + i, gq, acc0[u], acc1[u]);
+  };
+  for (int it = 0; it < T; it += 2) {
+    step(it, pa0, pa1, qa0, qa1);
+    if (it + 1 < T) step(it + 1, pb0, pb1, qb0, qb1);
   }
   const int cot = co0 + wr * 16 + i;
-  const int kk = k0 + wc * 16 + 4 * gq;
-  if (cot < ntot && kk < s.K1p) {
+  if (cot < ntot) {
     const int sub = cot / g.Cout, co = cot - sub * g.Cout;
-    *(f32x4u*)(t.part[sub] + ((size_t)ch * g.Cout + co) * s.K1p + kk) = acc0 + acc1;
+#pragma unroll
+    for (int u = 0; u < NKT; ++u) {
+      const int kk = k0 + u * TN + wc * 16 + 4 * gq;
+      if (kk < s.K1p) *(f32x4u*)(t.part[sub] + ((size_t)ch * g.Cout + co) * s.K1p + kk) = acc0[u] + acc1[u];
+    }
   }
 }
 
@@ -468,8 +495,9 @@ __global__ void __launch_bounds__(kThreads) k_conv_dx_block(ConvDxArgs a) {
   const ConvGeom& g = a.g;
   const int pi = blockIdx.y;
   const int Yb = (g.H + S - 1) / S, Xb = (g.W + S - 1) / S;
-  const int idx = blockIdx.x * kThreads + threadIdx.x;
-  if (idx >= a.B * Yb * Xb) return;
+  const int idx0 = blockIdx.x * kThreads + threadIdx.x;
+  const bool live = idx0 < a.B * Yb * Xb;       // dead threads compute on clamped indices and store nothing
+  const int idx = live ? idx0 : 0;
   const int xq = idx % Xb;
   const int t1 = idx / Xb;
   const int yq = t1 % Yb, b = t1 / Yb;
@@ -523,23 +551,46 @@ __global__ void __launch_bounds__(kThreads) k_conv_dx_block(ConvDxArgs a) {
             }
     }
   }
+  // Epilogue. Written naively each store instruction would put 16 B per lane at a 16*NC-byte stride: partial
+  // cache lines, which the memory side answers with fills and repeated write-backs (PMC: 2.2x the algorithmic
+  // WRITE_SIZE, +75 % FETCH_SIZE). The wave's row segment is therefore transposed through a wave-private LDS
+  // strip so that lane L of store j handles 16-byte chunk j*64 + L of it: whole lines per instruction, for
+  // the ReLU-mask read as well.
+  constexpr int NC = S * NQ;                 // 16-byte chunks per thread and image row
+  __shared__ f32x4 stg[kThreads / 64][64 * NC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int total = a.B * Yb * Xb;
+  const int wave_base = blockIdx.x * kThreads + wave * 64;
+  const float inv_xb = 1.0f / (float)Xb, inv_yb = 1.0f / (float)Yb;
 #pragma unroll
-  for (int py = 0; py < S; ++py)
+  for (int py = 0; py < S; ++py) {
 #pragma unroll
-    for (int px = 0; px < S; ++px) {
-      const int y = yq * S + py, x = xq * S + px;
-      if (y < g.H && x < g.W) {
-        const size_t o = (((size_t)b * g.H + y) * g.W + x) * (4 * NQ);
+    for (int px = 0; px < S; ++px)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const f32x4 xv = *(const f32x4u*)(a.x[pi] + o + 4 * q);
-          f32x4 r = acc[py * S + px][q];
+      for (int q = 0; q < NQ; ++q) stg[wave][lane * NC + px * NQ + q] = acc[py * S + px][q];
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the strip is written
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-          for (int e = 0; e < 4; ++e) r[e] = xv[e] > 0.f ? r[e] : 0.f;
-          *(f32x4u*)(a.dx[pi] + o + 4 * q) = r;
-        }
-      }
+    for (int j = 0; j < NC; ++j) {
+      const int w = j * 64 + lane;
+      const int src = w / NC, c = w - src * NC;          // NC is a power of two
+      const int sidx = wave_base + src;
+      const int sx = sidx - fast_div(sidx, Xb, inv_xb) * Xb;
+      const int st1 = fast_div(sidx, Xb, inv_xb);
+      const int sb = fast_div(st1, Yb, inv_yb);
+      const int sy = st1 - sb * Yb;
+      const int pxx = c / NQ, qq = c - pxx * NQ;
+      const int y = sy * S + py, x = sx * S + pxx;
+      const bool ok = sidx < total && y < g.H && x < g.W;
+      const size_t o = (((size_t)(ok ? sb : 0) * g.H + (ok ? y : 0)) * g.W + (ok ? x : 0)) * (4 * NQ) + 4 * qq;
+      const f32x4 xv = *(const f32x4u*)(a.x[pi] + o);
+      f32x4 r = stg[wave][w];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = xv[e] > 0.f ? r[e] : 0.f;
+      if (ok) *(f32x4u*)(a.dx[pi] + o) = r;
     }
+    __builtin_amdgcn_wave_barrier();         // the strip is reused by the next row
+  }
 }
 
 // sums the partials in a fixed order, writes the gradient and (single-GPU path) applies Adam / Polyak
