@@ -150,6 +150,43 @@ def gen_checkpoint_layout(ref, out_dir):
     print("wrote checkpoint_layout.json")
 
 
+def gen_v1_case(out_dir):
+    """DSAC_V1 (reference dsac_v1.py), tiny nets, same file format as step_<name>.npz"""
+    import importlib
+
+    from oracle.dsac_v1_oracle import V1_TB_KEYS, draw_noise_v1
+
+    v1 = importlib.import_module("dsac_v1")
+    O, A, hid, B, lim, steps = 9, 2, (32, 32), 32, 0.7, 4
+    kw = ref_loader.reference_kwargs(O, A, hid, act_limit=lim, algorithm="DSAC_V1", TD_bound=10)
+    torch.manual_seed(4321)
+    alg = v1.DSAC_V1(**kw)
+    nets = alg.networks
+    out = {"cfg_obs_dim": O, "cfg_act_dim": A, "cfg_hidden": np.array(hid), "cfg_batch": B, "cfg_act_limit": lim,
+           "cfg_steps": steps, "cfg_td_bound": 10.0, "versions": np.array([torch.__version__, np.__version__])}
+    for k, v in nets.state_dict().items():
+        out["init/" + k] = v.numpy().copy()
+    rng = np.random.default_rng(17)
+    for it in range(steps):
+        b = synth_batch(rng, B, O, A, lim)
+        torch.manual_seed(2000 + it)
+        noise = draw_noise_v1(B, A)
+        torch.manual_seed(2000 + it)
+        tb = alg.local_update({k: torch.as_tensor(v) for k, v in b.items()}, it)
+        for k, v in b.items():
+            out["s%d/%s" % (it, k)] = v
+        for k in ("eps_new", "eps_2", "z_t"):
+            out["s%d/%s" % (it, k)] = noise[k].numpy()
+        out["s%d/tb" % it] = np.array([float(tb[k]) for k in V1_TB_KEYS[:-1]], np.float64)
+        online = list(nets.q.parameters()) + list(nets.policy.parameters())
+        ga = nets.log_alpha.grad if nets.log_alpha.grad is not None else torch.zeros(())
+        out["s%d/grad" % it] = torch.cat([p.grad.reshape(-1) for p in online] + [ga.reshape(1)]).numpy().copy()
+        out["s%d/params" % it] = np.concatenate([flat(online), nets.log_alpha.detach().reshape(1).numpy()])
+        out["s%d/targets" % it] = flat(list(nets.q_target.parameters()) + list(nets.policy_target.parameters()))
+    np.savez_compressed(os.path.join(out_dir, "step_v1_tiny.npz"), **out)
+    print("wrote step_v1_tiny.npz")
+
+
 def gen_cnn_case(ref, out_dir):
     """CNN approximators: nets and minibatches regenerate from seeds
     (torch.manual_seed / numpy default_rng are part of the recorded versions), so the fixture holds
@@ -195,6 +232,7 @@ def main():
     gen_replay(out_dir)
     gen_checkpoint_layout(ref, out_dir)
     gen_cnn_case(ref, out_dir)
+    gen_v1_case(out_dir)
 
 
 if __name__ == "__main__":

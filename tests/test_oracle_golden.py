@@ -99,3 +99,24 @@ def test_cnn_step_matches_reference_golden():
         np.testing.assert_allclose([float(p.grad.double().norm()) for p in online], z["s%d/grad_l2" % it], rtol=1e-5, atol=1e-9)
         np.testing.assert_allclose([float(v.double().sum()) for v in orc.state_dict().values()], z["s%d/param_sums" % it],
                                    rtol=1e-7, atol=1e-5)
+
+
+def test_v1_step_matches_reference_golden():
+    """DSAC_V1 restatement (oracle/dsac_v1_oracle.py) vs vectors recorded from the unmodified reference."""
+    from oracle.dsact_oracle import default_config
+    from oracle.dsac_v1_oracle import V1_TB_KEYS, DsacV1Oracle
+
+    torch.set_num_threads(1)
+    z = np.load(os.path.join(GOLDEN, "step_v1_tiny.npz"))
+    cfg = default_config(int(z["cfg_obs_dim"]), int(z["cfg_act_dim"]), [int(h) for h in z["cfg_hidden"]],
+                         act_limit=float(z["cfg_act_limit"]), TD_bound=float(z["cfg_td_bound"]))
+    init = {k[len("init/"):]: torch.as_tensor(z[k]) for k in z.files if k.startswith("init/")}
+    orc = DsacV1Oracle(cfg, state_dict=init)
+    for it in range(int(z["cfg_steps"])):
+        data = {k: torch.as_tensor(z["s%d/%s" % (it, k)]) for k in ("obs", "obs2", "act", "rew", "done")}
+        noise = {k: torch.as_tensor(z["s%d/%s" % (it, k)]) for k in ("eps_new", "eps_2", "z_t")}
+        tb = orc.local_update(data, noise, it)
+        np.testing.assert_allclose([float(tb[k]) for k in V1_TB_KEYS[:-1]], z["s%d/tb" % it], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(orc.flat_grads().numpy(), z["s%d/grad" % it], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(orc.flat_params().numpy(), z["s%d/params" % it], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(orc.flat_targets().numpy(), z["s%d/targets" % it], rtol=0, atol=2e-6)

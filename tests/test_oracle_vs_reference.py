@@ -84,3 +84,40 @@ def test_cnn_bit_exact_vs_live_reference(obs_shape, A, conv_type, B):
         assert torch.equal(gref, orc.flat_grads())
         sd, osd = nets.state_dict(), orc.state_dict()
         assert all(torch.equal(sd[k], osd[k]) for k in sd)
+
+
+@pytest.mark.parametrize("O,A,hid,B", [(11, 3, (64, 64), 32), (376, 17, (256, 256, 256), 64), (3, 1, (32, 32), 16)])
+def test_v1_bit_exact_vs_live_reference(O, A, hid, B):
+    """DSAC_V1 (reference dsac_v1.py) restated in oracle/dsac_v1_oracle.py."""
+    import importlib
+
+    from oracle.dsac_v1_oracle import V1_TB_KEYS, DsacV1Oracle, draw_noise_v1
+
+    torch.set_num_threads(2)
+    ref_loader.import_reference()
+    v1 = importlib.import_module("dsac_v1")
+    kw = ref_loader.reference_kwargs(O, A, hid, algorithm="DSAC_V1", TD_bound=10)
+    torch.manual_seed(0)
+    alg = v1.DSAC_V1(**kw)
+    cfg = default_config(O, A, hid, TD_bound=10)
+    torch.manual_seed(0)
+    same_seed = DsacV1Oracle(cfg)
+    sd, osd = alg.networks.state_dict(), same_seed.state_dict()
+    assert list(sd.keys()) == list(osd.keys())
+    assert all(torch.equal(sd[k], osd[k]) for k in sd)
+    orc = DsacV1Oracle(cfg, state_dict=sd)
+    rng = np.random.default_rng(0)
+    for it in range(4):
+        d = synth_batch(rng, B, O, A)
+        torch.manual_seed(1000 + it)
+        tb_ref = alg.local_update({k: v.clone() for k, v in d.items()}, it)
+        torch.manual_seed(1000 + it)
+        tb = orc.local_update(d, draw_noise_v1(B, A), it)
+        for k in V1_TB_KEYS[:-1]:
+            assert float(tb_ref[k]) == float(tb[k]), k
+        nets = alg.networks
+        gref = torch.cat([p.grad.reshape(-1) for n in ("q", "policy") for p in getattr(nets, n).parameters()]
+                         + [nets.log_alpha.grad.reshape(1)])
+        assert torch.equal(gref, orc.flat_grads())
+        sd, osd = nets.state_dict(), orc.state_dict()
+        assert all(torch.equal(sd[k], osd[k]) for k in sd)
