@@ -41,7 +41,7 @@ def env_int(k, d):
     return int(os.environ.get(k, d))
 
 
-def make_alg(hidden, device, seed=0, batch=B):
+def make_alg(hidden, device, seed=0, batch=B, v1=False):
     import numpy as np
     import torch
     from dsac_v2_hip import DSAC_V2_HIP
@@ -58,6 +58,10 @@ def make_alg(hidden, device, seed=0, batch=B):
         replay_batch_size=batch, seed=seed + 1, hip_device=device,
         action_high_limit=np.full((A,), 0.4, np.float32), action_low_limit=np.full((A,), -0.4, np.float32),
     )
+    if v1:
+        from dsac_v1_hip import DSAC_V1_HIP
+
+        return DSAC_V1_HIP(**dict(kw, algorithm="DSAC_V1_HIP", TD_bound=10))
     return DSAC_V2_HIP(**kw)
 
 
@@ -420,6 +424,19 @@ def main():
         out["alt"] = {"hidden": alt_hidden, "value": steps / w2, "unit": "steps/s",
                       "frac_fp32": l2.flop_per_step(B) * steps / w2 / 1e12 / FP32_PEAK_TFLOPS,
                       "frac_hbm": l2.bytes_per_step(B, 2) * steps / w2 / 1e9 / HBM_PEAK_GBS}
+    if rank == 0 and not use_dp and not args.no_alt and args.batch == B:
+        # the reference's DSAC_V1 (one critic) on the same kernels, same shapes
+        try:
+            alg1 = make_alg(hidden, local, seed=0, v1=True)
+            fill_replay(alg1.engine, min(args.replay_rows, 200_000), seed=100)
+            upload_indices(alg1.engine, min(args.replay_rows, 200_000), IDX_ROWS, seed=1)
+            w1, _ = measure(alg1, steps, warmup)
+            l1 = alg1.engine.layout
+            out["dsac_v1"] = {"value": steps / w1, "unit": "steps/s", "ms_per_step": 1000.0 * w1 / steps,
+                              "frac_fp32": l1.flop_per_step(B) * steps / w1 / 1e12 / FP32_PEAK_TFLOPS}
+            del alg1
+        except Exception as ex:
+            out["dsac_v1_error"] = repr(ex)
     if rank == 0 and not use_dp and not args.no_cpu_baseline and args.batch == B:
         out["cpu_baseline"] = cpu_baseline(hidden)
     if rank == 0 and not use_dp and not args.no_alt and args.batch == B:

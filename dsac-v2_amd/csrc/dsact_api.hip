@@ -72,6 +72,7 @@ struct dsact_handle {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool use_fork = false;
   // nets
+  int nq = 2;            // critics: 2 (DSAC_V2) or 1 (DSAC_V1)
   NetDesc qd, pd;
   size_t n_q = 0, n_pi = 0, n_online = 0, n_target = 0;
   float *online = nullptr, *target = nullptr, *adam_m = nullptr, *adam_v = nullptr, *grads = nullptr;
@@ -197,13 +198,14 @@ const NetDesc& net_desc(const dsact_handle* h, int net) { return (net == N_POL |
 
 // base pointer of a net's parameters inside its arena (online or target)
 float* net_base(const dsact_handle* h, int net, float* online, float* target) {
+  const size_t q2 = h->nq == 2 ? h->n_q : 0;   // DSAC_V1 has one critic: the q2 slots alias q1 (never written)
   switch (net) {
     case N_Q1: return online;
-    case N_Q2: return online + h->n_q;
-    case N_POL: return online + 2 * h->n_q;
+    case N_Q2: return online + q2;
+    case N_POL: return online + h->nq * h->n_q;
     case N_Q1T: return target;
-    case N_Q2T: return target + h->n_q;
-    default: return target + 2 * h->n_q;
+    case N_Q2T: return target + q2;
+    default: return target + h->nq * h->n_q;
   }
 }
 float* net_params(const dsact_handle* h, int net) { return net_base(h, net, h->online, h->target); }
@@ -404,13 +406,15 @@ int build_tasks(dsact_handle* h) {
   };
   std::vector<GemmProb> pv;
   // forward group A: policy(obs), policy_target(obs2), q1/q2(obs,act); group B: q1_t/q2_t(obs2,act2), q1/q2(obs,new_act)
-  const int g1[4] = {C_PI, C_PIT, C_Q1C, C_Q2C}, g2[4] = {C_Q1T, C_Q2T, C_Q1P, C_Q2P};
+  const bool twin = h->nq == 2;
+  const std::vector<int> g1 = twin ? std::vector<int>{C_PI, C_PIT, C_Q1C, C_Q2C} : std::vector<int>{C_PI, C_PIT, C_Q1C};
+  const std::vector<int> g2 = twin ? std::vector<int>{C_Q1T, C_Q2T, C_Q1P, C_Q2P} : std::vector<int>{C_Q1T, C_Q1P};
   h->fwd1.clear(); h->fwd2.clear();
   for (int grp = 0; grp < 2; ++grp)
     for (int l = 0; l < L; ++l) {
       Stage s = fresh(std::string(grp == 0 ? "fwdA_l" : "fwdB_l") + std::to_string(l), 0);
       pv.clear();
-      for (int i = 0; i < 4; ++i) {
+      for (size_t i = 0; i < (grp == 0 ? g1 : g2).size(); ++i) {
         const int ch = grp == 0 ? g1[i] : g2[i];
         fwd_probs(h, ch, l, chain_input(h, ch), h->ldx, B, h->Hb[ch], h->Gb[ch][l], pv);
       }
@@ -439,10 +443,10 @@ int build_tasks(dsact_handle* h) {
   h->bwdq.clear(); h->bwdq_critic.clear(); h->bwdpi.clear();
   for (int l = L - 1; l >= 1; --l) {
     Stage s = fresh("bwdQ_l" + std::to_string(l), 1);
-    for (int ch : {C_Q1C, C_Q2C, C_Q1P, C_Q2P}) bwd_probs(s, ch, l);
+    for (int ch : twin ? std::vector<int>{C_Q1C, C_Q2C, C_Q1P, C_Q2P} : std::vector<int>{C_Q1C, C_Q1P}) bwd_probs(s, ch, l);
     h->bwdq.push_back(s);
     Stage c = fresh("bwdQc_l" + std::to_string(l), 1);  // off iterations of the delayed update: critics only
-    for (int ch : {C_Q1C, C_Q2C}) bwd_probs(c, ch, l);
+    for (int ch : twin ? std::vector<int>{C_Q1C, C_Q2C} : std::vector<int>{C_Q1C}) bwd_probs(c, ch, l);
     h->bwdq_critic.push_back(c);
   }
   for (int l = L - 1; l >= 1; --l) {
@@ -489,6 +493,7 @@ int build_tasks(dsact_handle* h) {
   int which = 0;
   for (int ch : {C_Q1C, C_Q2C, C_PI}) {
     h->dw_off[which++] = (int)tiles.size();
+    if (ch == C_Q2C && !twin) continue;   // DSAC_V1: no second critic (empty tile range)
     const int net = kChainNet[ch];
     const NetDesc& d = net_desc(h, net);
     float* g = net_grads(h, net);
@@ -539,7 +544,7 @@ FusedOpt fused_opt(const dsact_handle* h, bool enable) {
   memset(&f, 0, sizeof(f));
   f.st = enable ? h->st : nullptr;
   f.online = h->online; f.target = h->target; f.adam_m = h->adam_m; f.adam_v = h->adam_v; f.grads = h->grads;
-  f.n_q2 = (long long)(2 * h->n_q); f.n_online3 = (long long)(2 * h->n_q + h->n_pi); f.n_total = (long long)h->n_online;
+  f.n_q2 = (long long)(h->nq * h->n_q); f.n_online3 = (long long)(h->nq * h->n_q + h->n_pi); f.n_total = (long long)h->n_online;
   f.b1w = (float)(1.0 - dec7(h->cfg.adam_beta1));
   f.beta2 = (float)dec7(h->cfg.adam_beta2);
   f.b2w = (float)(1.0 - dec7(h->cfg.adam_beta2));
@@ -892,7 +897,10 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
   for (int l = 0; l < L; ++l) TRY(run_stage(h, h->fwd1[l]));
   {
     HeadsArgs a;
+    memset(&a, 0, sizeof(a));
     const int chs[4] = {C_PI, C_PIT, C_Q1C, C_Q2C};
+    const int n_heads = h->nq == 2 ? 4 : 3;
+    a.v1_stats = h->nq == 1;
     for (int i = 0; i < 4; ++i) {
       const int net = kChainNet[chs[i]];
       const NetDesc& d = net_desc(h, net);
@@ -910,7 +918,7 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
     a.part_heads = h->part_heads; a.act_scale = h->act_scale; a.act_center = h->act_center;
     a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
     a.timeline = tl_for(h, "heads");
-#define CALL_HEADS(N) TRY(launch(h, "heads", k_heads<N>, dim3(h->n_heads_wg, 4), dim3(kThreads), 0, a))
+#define CALL_HEADS(N) TRY(launch(h, "heads", k_heads<N>, dim3(h->n_heads_wg, n_heads), dim3(kThreads), 0, a))
     NCH_DISPATCH(a.W, CALL_HEADS);
   }
   for (int l = 0; l < L; ++l) TRY(run_stage(h, h->fwd2[l]));
@@ -923,7 +931,31 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
   }
   }  // phase != 2
   if (phase == 1) return DSACT_OK;
-  {
+  if (h->nq == 1) {
+    LossV1Args a;
+    memset(&a, 0, sizeof(a));
+    const int chs[2] = {C_Q1T, C_Q1P};
+    for (int i = 0; i < 2; ++i) {
+      const int net = kChainNet[chs[i]];
+      a.Hl[i] = h->Hb[chs[i]][L - 1];
+      a.Wout[i] = net_params(h, net) + h->qd.w_off[L];
+      a.bout[i] = net_params(h, net) + h->qd.b_off[L];
+    }
+    const int dch[2] = {C_Q1C, C_Q1P};
+    for (int i = 0; i < 2; ++i) {
+      a.Gl[i] = h->Gb[dch[i]][L - 1];
+      a.dZl[i] = h->dZ[kDzSlot[dch[i]]][L - 1];
+    }
+    a.dout[0] = h->dout[0]; a.dout[1] = h->dout[2];   // same slots as DSAC_V2's q1c / q1p
+    a.qout_c = h->qout_c[0]; a.qstd_c = h->qstd_c[0]; a.qout_t = h->qout_t[0]; a.qout_p = h->qout_p[0];
+    a.rew = h->rew; a.done = h->done; a.logp2 = h->logp2; a.logp_new = h->logp_new; a.z_t = h->z5;
+    a.log_alpha = h->online + h->n_online - 1;
+    a.part_loss = h->part_loss; a.grads_tail = h->grads + h->n_online;
+    a.W = h->w[L - 1]; a.B = B; a.inv_B = 1.0f / (float)B;
+    a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.gamma = h->cfg.gamma; a.td_bound = h->cfg.td_bound;
+#define CALL_LOSS1(N) TRY(launch(h, "loss", k_loss_v1<N>, dim3(h->n_loss_wg), dim3(kThreads), 0, a))
+    NCH_DISPATCH(a.W, CALL_LOSS1);
+  } else {
     LossArgs a;
     const int chs[4] = {C_Q1T, C_Q2T, C_Q1P, C_Q2P};
     for (int i = 0; i < 4; ++i) {
@@ -1026,7 +1058,7 @@ actor_part:
 int enqueue_adam(dsact_handle* h) {
   AdamArgs a;
   a.p = h->online; a.tgt = h->target; a.m = h->adam_m; a.v = h->adam_v; a.g = h->grads;
-  a.n_q2 = (long long)(2 * h->n_q); a.n_online3 = (long long)(2 * h->n_q + h->n_pi); a.n_total = (long long)h->n_online;
+  a.n_q2 = (long long)(h->nq * h->n_q); a.n_online3 = (long long)(h->nq * h->n_q + h->n_pi); a.n_total = (long long)h->n_online;
   a.st = h->st;
   a.b1w = (float)(1.0 - dec7(h->cfg.adam_beta1));
   a.beta2 = (float)dec7(h->cfg.adam_beta2);
@@ -1120,8 +1152,11 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   build_net(h->qd, h->F + h->A, cfg->hidden, h->L, 2, nblk, h->n_conv, h->cg);
   build_net(h->pd, h->F, cfg->hidden, h->L, 2 * h->A, nblk, h->n_conv, h->cg);
   h->n_q = h->qd.count; h->n_pi = h->pd.count;
-  h->n_online = 2 * h->n_q + h->n_pi + 1;
-  h->n_target = 2 * h->n_q + h->n_pi;
+  if (cfg->algo != DSACT_ALGO_DSAC_V2 && cfg->algo != DSACT_ALGO_DSAC_V1) return fail(h, DSACT_E_INVALID, "algo must be 0 (DSAC_V2) or 1 (DSAC_V1)");
+  h->nq = cfg->algo == DSACT_ALGO_DSAC_V1 ? 1 : 2;
+  if (h->nq == 1 && h->cnn) return fail(h, DSACT_E_INVALID, "DSAC_V1 is built for the MLP nets only");
+  h->n_online = h->nq * h->n_q + h->n_pi + 1;
+  h->n_target = h->nq * h->n_q + h->n_pi;
   h->n_heads_wg = (h->B + 3) / 4;
   h->n_loss_wg = (h->B + 3) / 4;  // one wave per sample
   h->loss_rows = 4;

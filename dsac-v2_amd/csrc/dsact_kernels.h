@@ -818,6 +818,7 @@ struct HeadsArgs {
   const float* act_scale; const float* act_center;  // (hi-lo)/2, (hi+lo)/2
   float lo_ls, hi_ls;
   long long* timeline;
+  int v1_stats;   // DSAC_V1 reports tanh(logits[...,0]) and logits[...,1] only (dsac_v1.py:145-146)
 };
 
 template <int NCH>
@@ -865,7 +866,14 @@ __global__ void __launch_bounds__(kThreads) k_heads(HeadsArgs a) {
         X[(size_t)r * a.ldx + a.O + lane] = f.a;
         float* Xb = chain == 0 ? a.XPb : a.X2b;
         if (Xb) Xb[(size_t)r * a.ldx + a.O + lane] = f.a;
-        if (chain == 0) { s_tanh = tanhf(mine); s_sig = f.sigma; }
+        if (chain == 0) {
+          if (!a.v1_stats) { s_tanh = tanhf(mine); s_sig = f.sigma; }
+          else {
+            s_tanh = lane == 0 ? tanhf(mine) : 0.f;
+            // logits = (mean_0..mean_{A-1}, std_0..): element 1 is mean_1, or std_0 for a one-dimensional action
+            s_sig = A >= 2 ? (lane == 1 ? mine : 0.f) : f.sigma;
+          }
+        }
       }
       float* lg = chain == 0 ? a.logits_pi : a.logits_pit;
       if (lane < 2 * A) lg[(size_t)r * 2 * A + lane] = mine;
@@ -1062,6 +1070,120 @@ __global__ void __launch_bounds__(kThreads) k_loss(LossArgs a) {
   }
   TL_STAMP();  // 4: dZ written
   TL_FLUSH(a.timeline, (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_loss_v1: DSAC_V1 (dsac_v1.py:194-253), one wave per sample like k_loss. One critic:
+//   q_next_sample = mean_t + clamp(z,+-3) * std_t          (q_target(obs2, act2), dsac_v1.py:184-192)
+//   target_q = r + (1-d) gamma (q_next_sample - alpha logp2); target_q_bound = q + clamp(target_q - q, +-TD_bound)
+//   L_q = mean( -(target_q - q)/(std^2 + 0.1) * q - ((q - target_q_bound)^2 - std^2)/(std^3 + 0.1) * std )
+//         with detached coefficients  ->  dL/dq, dL/dstd are the coefficients themselves / B
+//   actor: mean(alpha logp_new - q(obs,new_act))  ->  dL/dq_pi = -1/B
+// chains: [0] q_target(obs2,act2) (forward only), [1] q(obs,new_act); differentiated: q(obs,act) via Gl[0]/dZl[0],
+// q(obs,new_act) via Gl[1]/dZl[1]. part_loss row: [2] q, [4] std, [6] actor term, [7] logp_new, [8] alpha.
+// ---------------------------------------------------------------------------------------------
+struct LossV1Args {
+  const float* Hl[2];    // last hidden activations of q_target(obs2,act2), q(obs,new_act)
+  const float* Wout[2];  // out weights of q_target, q   [2 x W]
+  const float* bout[2];
+  const float* Gl[2];    // GELU' of the last hidden layer of q(obs,act), q(obs,new_act)
+  float* dZl[2];
+  const float* qout_c;   // raw outs of q(obs,act)  [B x 2]
+  const float* qstd_c;   // (std, d std / d raw)    [B x 2]
+  float* qout_t; float* qout_p;   // debug
+  float* dout[2];        // dL/d(out) [B x 2] of q(obs,act), q(obs,new_act)
+  const float* rew; const float* done; const float* logp2; const float* logp_new; const float* z_t;
+  const float* log_alpha;
+  float* part_loss; float* grads_tail;
+  int W, B;
+  float inv_B;
+  int auto_alpha; float alpha_fixed, gamma, td_bound;
+};
+
+template <int NCH>
+__global__ void __launch_bounds__(kThreads) k_loss_v1(LossV1Args a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= a.B) return;
+  const float q = a.qout_c[2 * r], std = a.qstd_c[2 * r], sg = a.qstd_c[2 * r + 1];
+  const float in_z = a.z_t[r], rew = a.rew[r], in_done = a.done[r], lp2 = a.logp2[r], lpn = a.logp_new[r];
+  const float la = a.log_alpha[0];
+  float bo[2][2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) { bo[c][0] = a.bout[c][0]; bo[c][1] = a.bout[c][1]; }
+  f32x4 h[2][NCH], wv[2][2][NCH], gv[2][NCH];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    row_load<NCH>(a.Hl[c] + (size_t)r * a.W, a.W, lane, h[c]);
+#pragma unroll
+    for (int qq = 0; qq < NCH; ++qq) {
+      const int k = qq * 256 + lane * 4;
+      const int kc = k < a.W ? k : 0;
+      wv[c][0][qq] = *(const f32x4u*)(a.Wout[c] + kc);
+      wv[c][1][qq] = *(const f32x4u*)(a.Wout[c] + a.W + kc);
+      gv[c][qq] = *(const f32x4u*)(a.Gl[c] + (size_t)r * a.W + kc);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) row_mask<NCH>(h[c], a.W, lane);
+  float o[2][2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int qq = 0; qq < NCH; ++qq) {
+        s += h[c][qq].x * wv[c][j][qq].x; s += h[c][qq].y * wv[c][j][qq].y;
+        s += h[c][qq].z * wv[c][j][qq].z; s += h[c][qq].w * wv[c][j][qq].w;
+      }
+      o[c][j] = wave_sum(s) + bo[c][j];
+    }
+  const float alpha = a.auto_alpha ? expf(la) : a.alpha_fixed;
+  const float qn = o[0][0], stdn = softplus(o[0][1]);
+  const float qs = qn + clampf(in_z, -3.f, 3.f) * stdn;
+  const float tq = rew + (1.0f - in_done) * a.gamma * (qs - alpha * lp2);
+  const float tqb = q + clampf(tq - q, -a.td_bound, a.td_bound);
+  const float sd = fmaxf(std, 0.0f);
+  const float dq = -(tq - q) / (sd * sd + 0.1f);
+  const float e = q - tqb;
+  const float dstd = -((e * e - sd * sd) / (sd * sd * sd + 0.1f));
+  float dv[4];
+  dv[0] = dq * a.inv_B;
+  dv[1] = dstd * a.inv_B * sg;
+  dv[2] = -a.inv_B; dv[3] = 0.0f;
+  const float q_pi = o[1][0];
+  if (lane == 0) {
+    a.dout[0][2 * r] = dv[0]; a.dout[0][2 * r + 1] = dv[1];
+    a.dout[1][2 * r] = dv[2]; a.dout[1][2 * r + 1] = dv[3];
+    a.qout_t[2 * r] = o[0][0]; a.qout_t[2 * r + 1] = o[0][1];
+    a.qout_p[2 * r] = o[1][0]; a.qout_p[2 * r + 1] = o[1][1];
+    float* pl = a.part_loss + (size_t)r * kLossPart;
+    pl[0] = dq * q + dstd * std; pl[1] = 0.f; pl[2] = q; pl[3] = 0.f; pl[4] = std; pl[5] = 0.f;
+    pl[6] = alpha * lpn - q_pi;
+    pl[7] = lpn;
+    pl[8] = r == 0 ? alpha : 0.0f;
+    pl[9] = 0.0f; pl[10] = std; pl[11] = std;
+    if (r == 0) { a.grads_tail[0] = 0.f; a.grads_tail[1] = 0.f; }
+  }
+  // dZ of the last hidden layer of q(obs,act) and q(obs,new_act): both through q's output layer (chain 1's weights)
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const float d0 = dv[2 * c], d1 = dv[2 * c + 1];
+#pragma unroll
+    for (int qq = 0; qq < NCH; ++qq) {
+      const int k = qq * 256 + lane * 4;
+      if (k < a.W) {
+        const f32x4 w0 = wv[1][0][qq], w1v = wv[1][1][qq];
+        f32x4 ov;
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) ov[e2] = (d0 * w0[e2] + d1 * w1v[e2]) * gv[c][qq][e2];
+        float* dz = a.dZl[c] + (size_t)r * a.W + k;
+        if (k + 3 < a.W) *(f32x4u*)dz = ov;
+        else for (int e2 = 0; e2 < 4 && k + e2 < a.W; ++e2) dz[e2] = ov[e2];
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -290,7 +290,7 @@ class ApproxContainer(nn.Module):
         """[(parameter, arena_name, storage offset, shape, strides)] for every parameter incl. log_alpha."""
         lay = self._layout
         out = []
-        for net in ("q1", "q2", "policy", "q1_target", "q2_target", "policy_target"):
+        for net in lay.all_nets:
             mod = getattr(self, net)
             params = dict(mod.named_parameters())
             for suffix, arena, off, shape, strides in lay.param_views(net):
@@ -506,7 +506,7 @@ class DSAC_V2_HIP:
     def _grad_views(self):
         lay, g = self.engine.layout, self.engine.grads
         out = {}
-        for net in ("q1", "q2", "policy"):
+        for net in lay.online_nets:
             views = []
             for _, _, off, shape, strides in lay.param_views(net):
                 views.append(torch.as_strided(g, shape, strides, off))

@@ -33,6 +33,7 @@ class Config(C.Structure):
         ("min_log_std", C.c_float), ("max_log_std", C.c_float),
         ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float),
         ("conv_type", C.c_int32), ("img_c", C.c_int32), ("img_h", C.c_int32), ("img_w", C.c_int32),
+        ("algo", C.c_int32), ("td_bound", C.c_float),
     ]
 
 

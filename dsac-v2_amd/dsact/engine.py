@@ -31,7 +31,8 @@ class DsactEngine:
     def __init__(self, obs_dim: int, act_dim: int, hidden: Sequence[int], batch: int, *,
                  gamma=0.99, tau=0.005, tau_b=None, auto_alpha=True, alpha=0.2, delay_update=2,
                  lr_q=1e-4, lr_pi=1e-4, lr_alpha=3e-4, min_log_std=-20.0, max_log_std=0.5,
-                 global_batch: Optional[int] = None, device: int = 0, conv_type: Optional[str] = None):
+                 global_batch: Optional[int] = None, device: int = 0, conv_type: Optional[str] = None,
+                 algo: str = "DSAC_V2", td_bound: float = 20.0):
         """obs_dim: int for the MLP nets; with `conv_type` ("type_1" / "type_2", reference
         networks/cnn.py:173-228) the (C, H, W) image shape, and `hidden` must be that type's MLP widths."""
         import torch
@@ -42,6 +43,11 @@ class DsactEngine:
                              "the DSAC-T update has no CPU fallback")
         self.torch = torch
         self.conv_type = conv_type
+        self.algo = algo
+        if algo not in ("DSAC_V2", "DSAC_V1"):
+            raise DsactError("algo must be DSAC_V2 or DSAC_V1")
+        if conv_type and algo != "DSAC_V2":
+            raise DsactError("the CNN approximators are built for DSAC_V2 only")
         if conv_type:
             self.layout = CnnArenaLayout(obs_dim, act_dim, conv_type)
             if list(hidden) != self.layout.hidden:
@@ -49,7 +55,7 @@ class DsactEngine:
             self.obs_shape = self.layout.obs_shape
             obs_dim = self.layout.obs_dim
         else:
-            self.layout = ArenaLayout(obs_dim, act_dim, list(hidden))
+            self.layout = ArenaLayout(obs_dim, act_dim, list(hidden), n_critics=2 if algo == "DSAC_V2" else 1)
             self.obs_shape = (int(obs_dim),)
         self.obs_dim, self.act_dim, self.batch = int(obs_dim), int(act_dim), int(batch)
         self.device_index = int(device)
@@ -73,6 +79,8 @@ class DsactEngine:
         if conv_type:
             cfg.conv_type = self.layout.conv_id
             cfg.img_c, cfg.img_h, cfg.img_w = self.obs_shape
+        cfg.algo = 0 if algo == "DSAC_V2" else 1
+        cfg.td_bound = float(td_bound)
         self.cfg = cfg
         self._h = C.c_void_p()
         rc = self._lib.dsact_create(C.byref(cfg), self.device_index, C.byref(self._h))

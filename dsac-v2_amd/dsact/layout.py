@@ -17,20 +17,38 @@ def mlp_sizes(in_dim: int, hidden: List[int], out_dim: int) -> List[Tuple[int, i
 
 
 class ArenaLayout:
-    def __init__(self, obs_dim: int, act_dim: int, hidden: List[int]):
+    def __init__(self, obs_dim: int, act_dim: int, hidden: List[int], n_critics: int = 2):
+        """n_critics = 2: DSAC_V2 (q1, q2); 1: DSAC_V1 (a single `q`; online = q | policy | log_alpha)."""
         self.obs_dim, self.act_dim, self.hidden = int(obs_dim), int(act_dim), [int(h) for h in hidden]
+        self.n_critics = int(n_critics)
         self.q_shapes = mlp_sizes(obs_dim + act_dim, self.hidden, 2)
         self.pi_shapes = mlp_sizes(obs_dim, self.hidden, 2 * act_dim)
         self.n_q = sum(o * i + o for o, i in self.q_shapes)
         self.n_pi = sum(o * i + o for o, i in self.pi_shapes)
-        self.n_online = 2 * self.n_q + self.n_pi + 1
-        self.n_target = 2 * self.n_q + self.n_pi
-        self.net_offset = {  # (arena, offset)
-            "q1": ("online", 0), "q2": ("online", self.n_q), "policy": ("online", 2 * self.n_q),
-            "q1_target": ("target", 0), "q2_target": ("target", self.n_q),
-            "policy_target": ("target", 2 * self.n_q),
-        }
+        nq = self.n_critics
+        self.n_online = nq * self.n_q + self.n_pi + 1
+        self.n_target = nq * self.n_q + self.n_pi
+        if nq == 2:
+            self.net_offset = {  # (arena, offset)
+                "q1": ("online", 0), "q2": ("online", self.n_q), "policy": ("online", 2 * self.n_q),
+                "q1_target": ("target", 0), "q2_target": ("target", self.n_q),
+                "policy_target": ("target", 2 * self.n_q),
+            }
+        else:
+            self.net_offset = {"q": ("online", 0), "policy": ("online", self.n_q),
+                               "q_target": ("target", 0), "policy_target": ("target", self.n_q)}
         self.log_alpha_offset = self.n_online - 1
+
+    @property
+    def online_nets(self):
+        return ("q1", "q2", "policy") if self.n_critics == 2 else ("q", "policy")
+
+    @property
+    def all_nets(self):
+        """registration order of the reference's ApproxContainer (state_dict order)"""
+        if self.n_critics == 2:
+            return ("q1", "q2", "q1_target", "q2_target", "policy", "policy_target")
+        return ("q", "q_target", "policy", "policy_target")
 
     def net_shapes(self, net: str):
         return self.pi_shapes if net.startswith("policy") else self.q_shapes
@@ -59,7 +77,7 @@ class ArenaLayout:
         """OrderedDict key -> shape in the reference's registration order."""
         sd = OrderedDict()
         sd["log_alpha"] = ()
-        for net in ("q1", "q2", "q1_target", "q2_target", "policy", "policy_target"):
+        for net in self.all_nets:
             if net.startswith("policy"):
                 sd[net + ".act_high_lim"] = (self.act_dim,)
                 sd[net + ".act_low_lim"] = (self.act_dim,)
@@ -74,14 +92,15 @@ class ArenaLayout:
         p_layers = [(o, i) for o, i in self.pi_shapes]
         q_fwd = sum(o * i for o, i in q_layers)
         p_fwd = sum(o * i for o, i in p_layers)
-        fwd = 2 * p_fwd + 6 * q_fwd
-        # critic: dW all layers + dX of layers >= 1 (x2 nets)
+        nq = self.n_critics
+        fwd = 2 * p_fwd + 3 * nq * q_fwd
+        # critic: dW all layers + dX of layers >= 1 (per critic)
         q_dw = q_fwd
         q_dx = sum(o * i for o, i in q_layers[1:])
-        crit = 2 * (q_dw + q_dx)
-        # actor through q1,q2: dX only; first layer only the action columns
+        crit = nq * (q_dw + q_dx)
+        # actor through the critics: dX only; first layer only the action columns
         w0 = q_layers[0][0]
-        act = 2 * (q_dx + w0 * self.act_dim)
+        act = nq * (q_dx + w0 * self.act_dim)
         # policy: dW all + dX of layers >= 1
         pol = p_fwd + sum(o * i for o, i in p_layers[1:])
         return fwd, crit + act + pol
@@ -92,10 +111,10 @@ class ArenaLayout:
 
     def bytes_per_step(self, batch: int, delay_update: int = 2) -> float:
         O, A = self.obs_dim, self.act_dim
-        n_on3 = 2 * self.n_q + self.n_pi
+        n_on3 = self.n_critics * self.n_q + self.n_pi
         gather = 4 * batch * (2 * O + A + 2) + 4 * batch
         weights = 4 * (n_on3 + self.n_target)
-        adam_q = 24 * 2 * self.n_q
+        adam_q = 24 * self.n_critics * self.n_q
         delayed = (24 * self.n_pi + 8 * n_on3) / float(delay_update)
         return float(gather + weights + adam_q + delayed)
 
@@ -154,6 +173,10 @@ class CnnArenaLayout:
             "policy_target": ("target", 2 * self.n_q),
         }
         self.log_alpha_offset = self.n_online - 1
+
+    n_critics = 2
+    online_nets = ("q1", "q2", "policy")
+    all_nets = ("q1", "q2", "q1_target", "q2_target", "policy", "policy_target")
 
     def _build(self, kind, in0, nb):
         """nb = outputs per trunk (1 for Q: mean / std; A for the policy). Returns the float count."""

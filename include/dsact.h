@@ -50,6 +50,8 @@ extern "C" {
 #endif
 
 #define DSACT_MAX_HIDDEN_LAYERS 6
+#define DSACT_ALGO_DSAC_V2 0
+#define DSACT_ALGO_DSAC_V1 1
 #define DSACT_CONV_NONE 0
 #define DSACT_CONV_TYPE_1 1
 #define DSACT_CONV_TYPE_2 2
@@ -85,6 +87,11 @@ typedef struct dsact_config {
    * are the widths of the `mean` / `log_std` MLPs that follow the conv stack. */
   int32_t conv_type;
   int32_t img_c, img_h, img_w;
+  /* algo 0 = DSAC_V2 (DSAC-T: twin critics, mean_std refinements); 1 = DSAC_V1 (reference dsac_v1.py: ONE critic
+   * `q` + `q_target`, fixed TD_bound, variance-weighted critic pseudo-loss :217-226). With algo 1 the arenas are
+   * online = q | policy | log_alpha and target = q_target | policy_target; MLP nets only. */
+  int32_t algo;
+  float td_bound;                               /* TD_bound (DSAC_V1 only; reference default 20) */
 } dsact_config;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

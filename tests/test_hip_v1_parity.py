@@ -1,0 +1,110 @@
+"""DSAC_V1_HIP (reference dsac_v1.py on the shared kernels) against the V1 oracle
+(oracle/dsac_v1_oracle.py, pinned bit-exact to the live reference) and the reference golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, hip_kwargs, synth_batch
+from oracle.dsact_oracle import default_config
+from oracle.dsac_v1_oracle import V1_TB_KEYS, DsacV1Oracle, draw_noise_v1
+from test_hip_parity import Report
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(O, A, hid, B, act_limit=0.4, seed=0, init=None, td_bound=10.0, **over):
+    from dsac_v1_hip import DSAC_V1_HIP
+
+    torch.manual_seed(seed)
+    alg = DSAC_V1_HIP(**hip_kwargs(O, A, hid, B, act_limit=act_limit, strict_rng=True, algorithm="DSAC_V1_HIP",
+                                   TD_bound=td_bound, **over))
+    if init is not None:
+        alg.networks.load_state_dict(init)
+    cfg = default_config(O, A, hid, act_limit=act_limit, TD_bound=td_bound)
+    orc = DsacV1Oracle(cfg, state_dict={k: v.cpu() for k, v in alg.networks.state_dict().items()})
+    return alg, orc
+
+
+def run_case(title, O, A, hid, B, steps, act_limit=0.4, init=None, golden=None):
+    rep = Report(title)
+    alg, orc = make_pair(O, A, hid, B, act_limit=act_limit, init=init)
+    e = alg.engine
+    lay = e.layout
+    assert lay.n_online == orc.flat_params().numel()
+    rng = np.random.default_rng(9)
+    for it in range(steps):
+        if golden is not None:
+            data = {k: torch.as_tensor(golden["s%d/%s" % (it, k)]) for k in ("obs", "obs2", "act", "rew", "done")}
+            noise = {k: torch.as_tensor(golden["s%d/%s" % (it, k)]) for k in ("eps_new", "eps_2", "z_t")}
+        else:
+            data = synth_batch(rng, B, O, A, lim=act_limit, p_done=0.05)
+            torch.manual_seed(3000 + it)
+            noise = draw_noise_v1(B, A)
+        tb_ref = orc.compute_gradient(data, noise)
+        e.load_batch(*(data[k].numpy() for k in ("obs", "act", "rew", "obs2", "done")))
+        e.set_noise(noise["eps_new"].numpy(), noise["eps_2"].numpy(), noise["z_t"].numpy(), noise["z_t"].numpy())
+        e.compute_grads(it)
+        e.sync()
+        g, g_ref = e.grads.cpu().numpy(), orc.flat_grads().numpy()
+        off = 0
+        for net, n in (("q", lay.n_q), ("policy", lay.n_pi), ("log_alpha", 1)):
+            rep.cmp("it%d grad.%s" % (it, net), g[off:off + n], g_ref[off:off + n], 1e-9, 3e-4)
+            off += n
+        e.apply_update(it)
+        orc.update(it)
+        from dsac_v1_hip import LazyTbInfoV1
+        alg._serial += 1
+        tb = LazyTbInfoV1(alg, alg._serial, 0.0)
+        assert list(tb.keys()) == V1_TB_KEYS
+        for k in V1_TB_KEYS[:-1]:
+            rep.cmp("it%d %s" % (it, k.split("/")[-1][:18]), [float(tb[k])], [float(tb_ref[k])], 1e-4, 1e-4)
+        if golden is not None:
+            rep.cmp("it%d tb vs reference" % it, [float(tb[k]) for k in V1_TB_KEYS[:-1]], golden["s%d/tb" % it], 1e-4, 1e-4)
+            rep.cmp("it%d params vs reference" % it, e.online.cpu().numpy(), golden["s%d/params" % it], 1e-4)
+            rep.cmp("it%d targets vs reference" % it, e.target.cpu().numpy(), golden["s%d/targets" % it], 1e-5)
+        rep.cmp("it%d params" % it, e.online.cpu().numpy(), orc.flat_params(), 1e-4)
+        rep.cmp("it%d targets" % it, e.target.cpu().numpy(), orc.flat_targets(), 1e-5)
+    assert e.get_state()["adam_steps"][0] == steps
+    rep.finish()
+
+
+def test_v1_against_reference_golden():
+    z = np.load(os.path.join(GOLDEN, "step_v1_tiny.npz"))
+    init = {k[len("init/"):]: torch.as_tensor(z[k]) for k in z.files if k.startswith("init/")}
+    run_case("v1 golden tiny", int(z["cfg_obs_dim"]), int(z["cfg_act_dim"]), tuple(int(h) for h in z["cfg_hidden"]),
+             int(z["cfg_batch"]), int(z["cfg_steps"]), act_limit=float(z["cfg_act_limit"]), init=init, golden=z)
+
+
+def test_v1_humanoid_shapes():
+    run_case("v1 humanoid 3x256 B=256", 376, 17, (256, 256, 256), 256, steps=3)
+
+
+def test_v1_ragged_and_one_dim_action():
+    run_case("v1 ragged O=11 A=3 (96,40) B=50", 11, 3, (96, 40), 50, steps=3)
+    run_case("v1 O=3 A=1 (64,64) B=64", 3, 1, (64, 64), 64, steps=3, act_limit=2.0)
+
+
+def test_v1_local_update_surface_and_fused_equals_split():
+    a1, orc = make_pair(11, 3, (64, 64), 64, seed=2)
+    a2, _ = make_pair(11, 3, (64, 64), 64, seed=2)
+    rng = np.random.default_rng(1)
+    for it in range(4):
+        data = synth_batch(rng, 64, 11, 3)
+        torch.manual_seed(40 + it)
+        noise = draw_noise_v1(64, 3)
+        torch.manual_seed(40 + it)
+        tb = a1.local_update(data, it)            # strict_rng: draws the reference's 5 tensors from the global RNG
+        ref = orc.local_update(data, noise, it)
+        assert list(tb.keys()) == V1_TB_KEYS
+        for k in V1_TB_KEYS[:-1]:
+            assert abs(float(tb[k]) - float(ref[k])) <= 1e-4 * max(1.0, abs(float(ref[k]))), (it, k)
+        torch.manual_seed(40 + it)
+        _, info = a2.get_remote_update_info(data, it)
+        assert set(info) == {"q_grad", "policy_grad", "log_alpha_grad", "iteration"}
+        a2.remote_update(info)
+    s1, s2 = a1.networks.state_dict(), a2.networks.state_dict()
+    assert list(s1.keys())[:2] == ["log_alpha", "q.q.0.weight"]
+    for k in s1:
+        assert torch.equal(s1[k].cpu(), s2[k].cpu()), k

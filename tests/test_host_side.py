@@ -162,3 +162,14 @@ def test_cnn_arena_layout_views_are_disjoint_and_preserve_the_networks():
     w = c.q1.conv[2].weight
     flat = arenas["online"][lay.param_views("q1")[2][2]:][: w.numel()].view(w.shape[0], w.shape[2], w.shape[3], w.shape[1])
     assert torch.equal(flat.permute(0, 3, 1, 2), w)
+
+
+def test_v1_layout_matches_the_v1_oracle():
+    from dsact.layout import ArenaLayout
+    from oracle.dsac_v1_oracle import DsacV1Oracle
+
+    lay = ArenaLayout(11, 3, [32, 32], n_critics=1)
+    orc = DsacV1Oracle(default_config(11, 3, (32, 32)))
+    assert lay.n_online == orc.flat_params().numel() and lay.n_target == orc.flat_targets().numel()
+    assert list(lay.state_dict_keys().keys()) == list(orc.state_dict().keys())
+    assert lay.online_nets == ("q", "policy")
