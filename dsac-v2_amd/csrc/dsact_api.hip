@@ -648,11 +648,12 @@ int enqueue_conv_forward(dsact_handle* h) {
     a.n_items = items;
     const std::string name = "conv_fwd_l" + std::to_string(j);
     if (g.K <= 80 && per_group * g.Cout <= 32) {
-      // narrow layer: wave-autonomous register tiles (k_conv_fwd_narrow); work items are 32-pixel tiles
-      int it2 = 0;
-      for (int q = 0; q < a.n_prob; ++q) { it2 += tiles_of(M, 32); a.p[q].item_end = it2; a.p[q].tiles_n = 1; }
-      a.n_items = it2;
-      const int grid = (it2 + 3) / 4 < 1280 ? (it2 + 3) / 4 : 1280;
+      // narrow layer: wave-autonomous register tiles (k_conv_fwd_narrow); every wave works on one group
+      const int waves_total = 5120;                       // ~20 waves per CU
+      int wpg = waves_total / a.n_prob;
+      if (wpg > tiles_of(M, 32)) wpg = tiles_of(M, 32);
+      a.n_items = wpg;                                    // waves per group
+      const int grid = (a.n_prob * wpg + 3) / 4;
       const bool one_block = per_group * g.Cout <= 16;
       if (g.K <= 48 && one_block) TRY(launch(h, name.c_str(), (k_conv_fwd_narrow<3, 1>), dim3(grid), dim3(kThreads), 0, a));
       else if (g.K <= 48) TRY(launch(h, name.c_str(), (k_conv_fwd_narrow<3, 2>), dim3(grid), dim3(kThreads), 0, a));

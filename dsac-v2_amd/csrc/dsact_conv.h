@@ -119,6 +119,9 @@ __global__ void __launch_bounds__(kThreads) k_conv_fwd(ConvStageArgs s) {
     c.q1p = t.w[s1] + (size_t)(cc1 - s1 * g.Cout) * g.K;
     return c;
   };
+  // raw loads only: a select on a just-loaded register would make the wave wait for that load right here and
+  // the "prefetch" would not overlap anything -- the masks travel as flags and are applied at LDS-store time
+  struct Msk { bool p0, p1, q0, q1; };
   auto load = [&](const Cur& c, int kt, f32x4& P0, f32x4& P1, f32x4& Q0, f32x4& Q1) {
     const int k = kt * BK + kq;
     const bool kv = k < g.K;           // K % 4 == 0: a quad is entirely inside or outside
@@ -128,16 +131,15 @@ __global__ void __launch_bounds__(kThreads) k_conv_fwd(ConvStageArgs s) {
     P1 = *(const f32x4u*)(c.in + c.ro1 + km);
     Q0 = *(const f32x4u*)(c.q0p + kc);
     Q1 = *(const f32x4u*)(c.q1p + kc);
-    if (!(kv && c.pv0)) P0 = zero;
-    if (!(kv && c.pv1)) P1 = zero;
-    if (!(kv && c.qv0)) Q0 = zero;
-    if (!(kv && c.qv1)) Q1 = zero;
+    Msk m;
+    m.p0 = kv && c.pv0; m.p1 = kv && c.pv1; m.q0 = kv && c.qv0; m.q1 = kv && c.qv1;
+    return m;
   };
   int item = blockIdx.x;
   if (item >= s.n_items) return;
   Cur cur = cursor(item);
   f32x4 p0, p1, q0, q1;
-  load(cur, 0, p0, p1, q0, q1);
+  Msk mk = load(cur, 0, p0, p1, q0, q1);
   int step = 0;
   while (item < s.n_items) {
     int pi, m0, n0;
@@ -157,11 +159,15 @@ __global__ void __launch_bounds__(kThreads) k_conv_fwd(ConvStageArgs s) {
     for (int kt = 0; kt < T; ++kt, ++step) {
       float* Ps = lds + (step & 1) * 2 * TILE_LDS;
       float* Qs = Ps + TILE_LDS;
+      if (!mk.p0) p0 = zero;
+      if (!mk.p1) p1 = zero;
+      if (!mk.q0) q0 = zero;
+      if (!mk.q1) q1 = zero;
       tile_store_lds<false>(Ps, tid, p0, p1);
       tile_store_lds<false>(Qs, tid, q0, q1);
       __syncthreads();
-      if (kt + 1 < T) load(cur, kt + 1, p0, p1, q0, q1);
-      else if (next_item < s.n_items) { nxt = cursor(next_item); load(nxt, 0, p0, p1, q0, q1); }
+      if (kt + 1 < T) mk = load(cur, kt + 1, p0, p1, q0, q1);
+      else if (next_item < s.n_items) { nxt = cursor(next_item); mk = load(nxt, 0, p0, p1, q0, q1); }
       tile_mma<false, false>(Ps, Qs, wr * 16 + i, wc * 16 + i, gq, acc0, acc1);
     }
     if (in_range) {
@@ -189,66 +195,65 @@ __global__ void __launch_bounds__(kThreads) k_conv_fwd_narrow(ConvStageArgs s) {
   const int lane = threadIdx.x & 63;
   const int i = lane & 15, gq = lane >> 4;
   const int wave_global = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-  const int n_waves = gridDim.x * (kThreads / 64);
+  // a wave works on ONE group (s.n_items = waves per group here): its weight fragments are loaded once, before
+  // the tile loop, so that nothing but patch loads, MFMAs and stores remains inside it
+  const int wpg = s.n_items;
+  const int pi = wave_global / wpg;
+  if (pi >= s.n_prob) return;
+  const int wv = wave_global - pi * wpg;
+  const ConvGroup& t = s.p[pi];
+  const int ntot = t.n_sub * g.Cout;
+  const int n_tiles = (t.M + 31) >> 5;
+  if (wv >= n_tiles) return;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  int km[NKK]; bool kv[NKK];
+  int km[NKK];
 #pragma unroll
   for (int kk = 0; kk < NKK; ++kk) {
     const int k = 16 * kk + 4 * gq;
-    kv[kk] = k < g.K;
-    km[kk] = conv_kmap(g, kv[kk] ? k : 0);
+    km[kk] = conv_kmap(g, k < g.K ? k : 0);
   }
-  auto decode = [&](int item, int& pi, int& m0) {
-    pi = 0;
+  // weights: zero beyond K (the patch operand is NOT masked: whatever it holds there multiplies 0) and beyond the
+  // group's channels
+  f32x4 Q[NB][NKK], bv[NB];
 #pragma unroll
-    for (int q = 0; q + 1 < kMaxConvProb; ++q)
-      if (q + 1 < s.n_prob && item >= s.p[q].item_end) pi = q + 1;
-    m0 = (item - (pi ? s.p[pi - 1].item_end : 0)) * 32;
-  };
-  auto load_p = [&](int item, f32x4 (&P)[2][NKK]) {
-    int pi, m0;
-    decode(item, pi, m0);
-    const ConvGroup& t = s.p[pi];
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = nb * 16 + i;
+    const bool nv = n < ntot;
+    const int nc = nv ? n : 0;
+    const int sub = nc / g.Cout;
+    const float* wrow = t.w[sub] + (size_t)(nc - sub * g.Cout) * g.K;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      const bool kvv = 16 * kk + 4 * gq < g.K;
+      Q[nb][kk] = *(const f32x4u*)(wrow + (kvv ? 16 * kk + 4 * gq : 0));
+      if (!(nv && kvv)) Q[nb][kk] = zero;
+    }
+    const int nq = nb * 16 + 4 * gq;   // this lane's output channels of block nb
+    const bool qv = nq < ntot;
+    const int sq = qv ? nq / g.Cout : 0;
+    bv[nb] = qv ? *(const f32x4u*)(t.bias[sq] + (nq - sq * g.Cout)) : zero;
+  }
+  // output addressing of this lane (constant across tiles)
+  int o_sub[NB], o_co[NB]; bool o_ok[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = nb * 16 + 4 * gq;
+    o_ok[nb] = n < ntot;
+    o_sub[nb] = o_ok[nb] ? n / g.Cout : 0;
+    o_co[nb] = n - o_sub[nb] * g.Cout;
+  }
+  // RAW patch loads (rows clamped into the matrix, nothing selected on the loaded registers: a select would make
+  // the wave wait for the load at issue time and the prefetch would overlap nothing)
+  auto load_p = [&](int tile, f32x4 (&P)[2][NKK]) {
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
-      const int m = m0 + mb * 16 + i;
-      const bool mv = m < t.M;
-      const float* base = t.in + conv_rowoff(g, s.ix, mv ? m : t.M - 1);
+      const int m = tile * 32 + mb * 16 + i;
+      const float* base = t.in + conv_rowoff(g, s.ix, m < t.M ? m : t.M - 1);
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) P[mb][kk] = *(const f32x4u*)(base + km[kk]);
-#pragma unroll
-      for (int kk = 0; kk < NKK; ++kk) if (!(mv && kv[kk])) P[mb][kk] = zero;
     }
   };
-  f32x4 Q[NB][NKK], bv[NB];
-  int cur_pi = -1;
-  auto load_q = [&](int pi) {
-    const ConvGroup& t = s.p[pi];
-    const int ntot = t.n_sub * g.Cout;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int n = nb * 16 + i;
-      const bool nv = n < ntot;
-      const int nc = nv ? n : 0;
-      const int sub = nc / g.Cout;
-      const float* wrow = t.w[sub] + (size_t)(nc - sub * g.Cout) * g.K;
-#pragma unroll
-      for (int kk = 0; kk < NKK; ++kk) {
-        Q[nb][kk] = *(const f32x4u*)(wrow + (kv[kk] ? 16 * kk + 4 * gq : 0));
-        if (!(nv && kv[kk])) Q[nb][kk] = zero;
-      }
-      const int nq = nb * 16 + 4 * gq;   // this lane's output channels of block nb
-      const bool qv = nq < ntot;
-      const int sq = qv ? nq / g.Cout : 0;
-      bv[nb] = qv ? *(const f32x4u*)(t.bias[sq] + (nq - sq * g.Cout)) : zero;
-    }
-  };
-  auto compute = [&](int item, const f32x4 (&P)[2][NKK]) {
-    int pi, m0;
-    decode(item, pi, m0);
-    if (pi != cur_pi) { load_q(pi); cur_pi = pi; }
-    const ConvGroup& t = s.p[pi];
-    const int ntot = t.n_sub * g.Cout;
+  auto compute = [&](int tile, const f32x4 (&P)[2][NKK]) {
     f32x4 acc[2][NB];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
@@ -265,33 +270,29 @@ __global__ void __launch_bounds__(kThreads) k_conv_fwd_narrow(ConvStageArgs s) {
             acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Q[nb][kk][e], P[mb][kk][e], acc[mb][nb], 0, 0, 0);
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
-      const int m = m0 + mb * 16 + i;
+      const int m = tile * 32 + mb * 16 + i;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const int n = nb * 16 + 4 * gq;
-        if (m < t.M && n < ntot) {
-          const int sub = n / g.Cout, co = n - sub * g.Cout;
+        if (m < t.M && o_ok[nb]) {
           f32x4 o = acc[mb][nb] + bv[nb];
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
-          *(f32x4u*)(t.out[sub] + (size_t)m * g.Cout + co) = o;
+          *(f32x4u*)(t.out[o_sub[nb]] + (size_t)m * g.Cout + o_co[nb]) = o;
         }
       }
     }
   };
-  int item = wave_global;
-  if (item >= s.n_items) return;
   f32x4 Pa[2][NKK], Pb[2][NKK];
-  load_p(item, Pa);
-  while (true) {
-    const int nx = item + n_waves;
-    if (nx < s.n_items) load_p(nx, Pb);
-    compute(item, Pa);
-    if (nx >= s.n_items) break;
-    item = nx + n_waves;
-    if (item < s.n_items) load_p(item, Pa);
+  const int last = n_tiles - 1;
+  load_p(wv, Pa);
+  for (int tile = wv; tile < n_tiles; tile += 2 * wpg) {
+    const int nx = tile + wpg;
+    load_p(nx < last ? nx : last, Pb);        // unconditional (clamped): no branch between the loads and the MFMAs
+    compute(tile, Pa);
+    if (nx >= n_tiles) break;
+    const int n2 = nx + wpg;
+    load_p(n2 < last ? n2 : last, Pa);
     compute(nx, Pb);
-    if (item >= s.n_items) break;
   }
 }
 
@@ -362,10 +363,10 @@ __global__ void __launch_bounds__(kThreads) k_conv_dw(ConvDwArgs s) {
   const int ms = tid >> 3;                       // m slot 0 (slot 1 = +32)
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   const f32x4 one0 = {1.f, 0.f, 0.f, 0.f};
+  // raw loads; the masks (pixel validity of the two slots) are applied at LDS-store time -- see k_conv_fwd
   auto load = [&](int it, f32x4& P0, f32x4& P1, f32x4 (&Q0)[NKT], f32x4 (&Q1)[NKT]) {
     const int ma = mb + it * BK + ms, mc = ma + 32;
-    const bool va = ma < me, vc = mc < me;
-    const int mac = va ? ma : t.M - 1, mcc = vc ? mc : t.M - 1;
+    const int mac = ma < me ? ma : t.M - 1, mcc = mc < me ? mc : t.M - 1;
     const int roa = conv_rowoff(g, s.ix, mac), roc = conv_rowoff(g, s.ix, mcc);
     P0 = *(const f32x4u*)(dyp + (size_t)mac * g.Cout);
     P1 = *(const f32x4u*)(dyp + (size_t)mcc * g.Cout);
@@ -374,8 +375,11 @@ __global__ void __launch_bounds__(kThreads) k_conv_dw(ConvDwArgs s) {
       Q0[u] = *(const f32x4u*)(t.in + roa + qmap[u]);
       Q1[u] = *(const f32x4u*)(t.in + roc + qmap[u]);
     }
-    if (!(va && pcv)) P0 = zero;                 // masking dY is enough: the other operand is finite
-    if (!(vc && pcv)) P1 = zero;
+  };
+  auto mask = [&](int it, f32x4& P0, f32x4& P1, f32x4 (&Q0)[NKT], f32x4 (&Q1)[NKT]) {
+    const int ma = mb + it * BK + ms, mc = ma + 32;
+    if (!(ma < me && pcv)) P0 = zero;            // masking dY is enough: the other operand is finite
+    if (!(mc < me && pcv)) P1 = zero;
 #pragma unroll
     for (int u = 0; u < NKT; ++u) {
       if (qmode[u] == 1) { Q0[u] = one0; Q1[u] = one0; }
@@ -393,6 +397,7 @@ __global__ void __launch_bounds__(kThreads) k_conv_dw(ConvDwArgs s) {
   if (T > 1) load(1, pb0, pb1, qb0, qb1);
   auto step = [&](int it, f32x4& P0, f32x4& P1, f32x4 (&Q0)[NKT], f32x4 (&Q1)[NKT]) {
     float* Ps = lds + (it & 1) * (1 + NKT) * TILE_LDS;
+    mask(it, P0, P1, Q0, Q1);
     tile_store_lds<true>(Ps, tid, P0, P1);
 #pragma unroll
     for (int u = 0; u < NKT; ++u) tile_store_lds<true>(Ps + (1 + u) * TILE_LDS, tid, Q0[u], Q1[u]);
@@ -519,7 +524,8 @@ __global__ void __launch_bounds__(kThreads) k_conv_dx_block(ConvDxArgs a) {
       dyp[ay][ax] = a.dy[pi] + (((size_t)b * g.OH + (dv[ay][ax] ? oy : 0)) * g.OW + (dv[ay][ax] ? ox : 0)) * g.Cout;
     }
   for (int c4 = 0; c4 < g.Cout; c4 += 4) {
-    // (loading all 16 channels' quads of a trip up front was measured slower: 118-168 VGPRs and spilled SGPRs)
+    // measured slower: all 16 channels' quads of a trip up front (118-168 VGPRs, spilled SGPRs), and a ping-pong
+    // prefetch of the next channel quad (34 -> 42 us on layer 1)
     f32x4 d[AY][AY];
 #pragma unroll
     for (int ay = 0; ay < AY; ++ay)
