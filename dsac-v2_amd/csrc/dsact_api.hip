@@ -123,6 +123,10 @@ struct dsact_handle {
   GemmProb* d_tiles = nullptr;   // per-tile table of the weight/bias-gradient tiles: [q1 | q2 | policy]
   int n_dw_tiles = 0;
   int dw_off[4] = {0, 0, 0, 0};  // start of q1, q2, policy tiles, end
+  // split-K weight gradients at batch > 448: dw_chunks chunks of 256 samples, one partial gradient arena each
+  int dw_chunks = 1;
+  float* dw_parts = nullptr;     // [dw_chunks][dw_part_stride]
+  size_t dw_part_stride = 0;
   std::vector<Stage> fwd1, fwd2, bwdq, bwdq_critic, bwdpi, actf;
   Stage dfeat_q, dfeat_pi;
   // replay ring
@@ -335,6 +339,7 @@ void carve(dsact_handle* h, Carver& c) {
   h->ones = c.take<float>(B);
   h->std_sums = c.take<float>(2);
   h->timeline = c.take<long long>(512 * 8);
+  h->dw_parts = c.take<float>(h->dw_chunks > 1 ? (size_t)h->dw_chunks * h->dw_part_stride : 4);
   h->act_scale = c.take<float>(A);
   h->act_center = c.take<float>(A);
   h->idx_eager = c.take<int>(B);
@@ -350,6 +355,8 @@ void carve(dsact_handle* h, Carver& c) {
 const float* chain_input(const dsact_handle* h, int ch) { return h->Xc[ch]; }
 
 int tiles_of(int n, int t) { return (n + t - 1) / t; }
+// contraction length of one weight-gradient tile
+int dw_k(const dsact_handle* h) { return h->dw_chunks > 1 ? 256 : h->B; }
 
 void stage_add(Stage& s, GemmProb g) {
   g.tiles_n = tiles_of(g.N, TN);
@@ -482,13 +489,24 @@ int build_tasks(dsact_handle* h) {
   }
   // weight / bias gradients of q1, q2, policy: one table entry per 32x32 tile
   std::vector<GemmProb> tiles;
-  auto add_tiles = [&](GemmProb t) {
+  // split-K: the batch-long contraction is cut into chunks of 256 samples (the size the tile kernel is tuned for:
+  // whole-K register prefetch, one barrier); chunk c accumulates into its own partial arena, k_sum_parts adds them
+  const int chunks = h->dw_chunks;
+  auto add_tiles = [&](GemmProb t0) {
+   for (int c = 0; c < chunks; ++c) {
+    GemmProb t = t0;
+    if (chunks > 1) {
+      const size_t k0 = (size_t)c * 256;
+      t.P = t0.P + k0 * t0.ldp; t.Q = t0.Q + k0 * t0.ldq; t.K = 256;
+      t.C0 = h->dw_parts + (size_t)c * h->dw_part_stride + (t0.C0 - h->grads);
+    }
     for (int m0 = 0; m0 < t.M; m0 += TM)
       for (int n0 = 0; n0 < t.N; n0 += TN) {
         GemmProb q = t;
         q.tiles_n = m0; q.tile_end = n0;  // table form: tile origin
         tiles.push_back(q);
       }
+   }
   };
   int which = 0;
   for (int ch : {C_Q1C, C_Q2C, C_PI}) {
@@ -542,7 +560,7 @@ long long* tl_for(dsact_handle* h, const char* name) {
 FusedOpt fused_opt(const dsact_handle* h, bool enable) {
   FusedOpt f;
   memset(&f, 0, sizeof(f));
-  f.st = enable ? h->st : nullptr;
+  f.st = (enable && h->dw_chunks == 1) ? h->st : nullptr;   // split-K partials: the optimiser runs after k_sum_parts
   f.online = h->online; f.target = h->target; f.adam_m = h->adam_m; f.adam_v = h->adam_v; f.grads = h->grads;
   f.n_q2 = (long long)(h->nq * h->n_q); f.n_online3 = (long long)(h->nq * h->n_q + h->n_pi); f.n_total = (long long)h->n_online;
   f.b1w = (float)(1.0 - dec7(h->cfg.adam_beta1));
@@ -566,9 +584,32 @@ int run_stage(dsact_handle* h, const Stage& s0, int x0 = 0, int x1 = 0, bool fus
   s.args.extra = h->d_tiles + x0;
   s.args.n_extra = x1 > x0 ? x1 - x0 : 0;
   s.args.fo = fused_opt(h, fused);
+  // large batches: 64x64 tiles (k_stage64) when every problem of the stage allows it and nothing rides along
+  if (s.args.n_extra == 0 && (s.kind == 0 || s.kind == 1) && getenv("DSACT_NO_TILE64") == nullptr) {
+    bool ok = true;
+    int blocks = 0;
+    StageArgs a64 = s.args;
+    for (int q = 0; q < a64.n_prob && ok; ++q) {
+      GemmProb& g = a64.p[q];
+      int K = g.K;
+      if (K % 4) {   // first layer of the Q nets: both operands are zero padded to ld (k_gather / repack)
+        const int K4 = (K + 3) & ~3;
+        if (s.kind == 0 && g.ldp >= K4 && g.ldq >= K4) K = K4; else ok = false;
+      }
+      ok = ok && g.M >= 512 && g.M % 64 == 0 && g.N % 64 == 0;
+      g.K = K;
+      g.tiles_n = g.N / 64;
+      blocks += (g.M / 64) * g.tiles_n;
+      g.tile_end = blocks;
+    }
+    if (ok) {
+      if (s.kind == 0) return launch(h, s.name.c_str(), k_stage64<false, EPI_GELU>, dim3(blocks), dim3(kThreads64), tile64_lds_bytes(), a64);
+      return launch(h, s.name.c_str(), k_stage64<true, EPI_MULG>, dim3(blocks), dim3(kThreads64), tile64_lds_bytes(), a64);
+    }
+  }
   const int grid = s.n_blocks + s.args.n_extra;
   size_t lds = tile_lds_bytes(s.max_k);
-  if (s.args.n_extra && tile_lds_bytes(h->B) > lds) lds = tile_lds_bytes(h->B);
+  if (s.args.n_extra && tile_lds_bytes(dw_k(h)) > lds) lds = tile_lds_bytes(dw_k(h));
   // clean stages (hidden layers of 128 / 256 units at batch sizes that are multiples of 32) use the
   // straight-line specialisations
 #define STAGE_TS(PM, QM, EP)                                                                                     \
@@ -595,8 +636,8 @@ int run_dw(dsact_handle* h, int x0, int x1, bool fused, bool finalize, hipStream
   a.fo = fused_opt(h, fused);
   a.finalize = finalize ? 1 : 0;
   if (on)
-    return launch_on(h, on, "dW", k_stage_table, dim3(a.n_tiles + (finalize ? 1 : 0)), dim3(kThreads), tile_lds_bytes(h->B), a);
-  return launch(h, "dW", k_stage_table, dim3(a.n_tiles + (finalize ? 1 : 0)), dim3(kThreads), tile_lds_bytes(h->B), a);
+    return launch_on(h, on, "dW", k_stage_table, dim3(a.n_tiles + (finalize ? 1 : 0)), dim3(kThreads), tile_lds_bytes(dw_k(h)), a);
+  return launch(h, "dW", k_stage_table, dim3(a.n_tiles + (finalize ? 1 : 0)), dim3(kThreads), tile_lds_bytes(dw_k(h)), a);
 }
 
 
@@ -885,6 +926,18 @@ int enqueue_prologue(dsact_handle* h, int use_dev, long long it, int advance, in
 }
 
 // everything of __compute_gradient after the minibatch is staged (dsac_v2.py:150-206)
+int enqueue_adam(dsact_handle* h);
+
+// split-K: gradient arena [lo, hi) = sum of the chunk partials
+int sum_parts(dsact_handle* h, size_t lo, size_t hi) {
+  if (h->dw_chunks == 1 || hi <= lo) return DSACT_OK;
+  SumPartsArgs a;
+  a.part = h->dw_parts + lo; a.stride = (long long)h->dw_part_stride; a.n_part = h->dw_chunks;
+  a.g = h->grads + lo; a.n = (long long)(hi - lo);
+  const long long quads = (a.n + 3) / 4;
+  return launch(h, "sum_parts", k_sum_parts, dim3((unsigned)((quads + kThreads - 1) / kThreads)), dim3(kThreads), 0, a);
+}
+
 // phase 0: everything; 1: forward part up to the local {sum std1, sum std2} (strict data-parallel mode: the
 // caller all-reduces those two floats); 2: loss + backward (+ fused update);
 // 3 / 4 (data-parallel overlap, unfused): 3 = everything up to and including the critics' gradients (q1 | q2
@@ -989,8 +1042,15 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
     // discards them (dsac_v2.py:174-186 vs :324) -- only the critics' backward is needed
     for (size_t i = 0; i < h->bwdq_critic.size(); ++i) TRY(run_stage(h, h->bwdq_critic[i]));
     if (h->cnn) TRY(run_stage(h, h->dfeat_q));
-    TRY(run_dw(h, h->dw_off[0], h->dw_off[2], fused, fused));
-    if (h->cnn) TRY(enqueue_conv_backward(h, 2, fused));
+    if (h->dw_chunks == 1) {
+      TRY(run_dw(h, h->dw_off[0], h->dw_off[2], fused, fused));
+      if (h->cnn) TRY(enqueue_conv_backward(h, 2, fused));
+    } else {
+      TRY(run_dw(h, h->dw_off[0], h->dw_off[2], false, false));
+      if (h->cnn) TRY(enqueue_conv_backward(h, 2, false));
+      TRY(sum_parts(h, 0, (size_t)h->nq * h->n_q));
+      if (fused) TRY(enqueue_adam(h));
+    }
     return DSACT_OK;
   }
   for (size_t i = 0; i < h->bwdq.size(); ++i) TRY(run_stage(h, h->bwdq[i]));
@@ -998,6 +1058,7 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
   if (phase == 3) {
     TRY(run_dw(h, h->dw_off[0], h->dw_off[2], false, false));
     if (h->cnn) TRY(enqueue_conv_backward(h, 2, false));
+    TRY(sum_parts(h, 0, (size_t)h->nq * h->n_q));
     return DSACT_OK;
   }
 actor_part:
@@ -1040,6 +1101,7 @@ actor_part:
     if (h->cnn) TRY(run_stage(h, h->dfeat_pi));
     TRY(run_dw(h, h->dw_off[2], h->dw_off[3], false, false));
     if (h->cnn) TRY(enqueue_conv_backward(h, 1, false, 2));
+    TRY(sum_parts(h, (size_t)h->nq * h->n_q, h->n_online - 1));
     return DSACT_OK;
   }
   // unforked: the critics' tiles ride along in the under-filled policy-backward launches
@@ -1051,8 +1113,15 @@ actor_part:
   }
   if (h->cnn) TRY(run_stage(h, h->dfeat_pi));  // needs the policy's W0 BEFORE the fused Adam of the next launch
   // policy weight gradients (+ the critics' when there was no launch to ride in) + close of the update
-  TRY(run_dw(h, np ? h->dw_off[2] : h->dw_off[0], h->dw_off[3], fused, fused));
-  if (h->cnn) TRY(enqueue_conv_backward(h, 3, fused));
+  if (h->dw_chunks == 1) {
+    TRY(run_dw(h, np ? h->dw_off[2] : h->dw_off[0], h->dw_off[3], fused, fused));
+    if (h->cnn) TRY(enqueue_conv_backward(h, 3, fused));
+  } else {
+    TRY(run_dw(h, np ? h->dw_off[2] : h->dw_off[0], h->dw_off[3], false, false));
+    if (h->cnn) TRY(enqueue_conv_backward(h, 3, false));
+    TRY(sum_parts(h, 0, h->n_online - 1));
+    if (fused) TRY(enqueue_adam(h));
+  }
   return DSACT_OK;
 }
 
@@ -1162,6 +1231,8 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->n_loss_wg = (h->B + 3) / 4;  // one wave per sample
   h->loss_rows = 4;
   h->auto_std_sums = h->B > 1024;   // large batches: the std column is summed once, not by every wave
+  h->dw_chunks = (h->B > 448 && h->B % 256 == 0 && getenv("DSACT_NO_SPLITK") == nullptr) ? h->B / 256 : 1;
+  h->dw_part_stride = (h->n_online + 2 + 63) & ~(size_t)63;
   Carver c0;
   carve(h, c0);
   h->ws_bytes = c0.off + 256;
@@ -1196,7 +1267,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   HIPCHK(h, hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
   HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-  h->use_fork = getenv("DSACT_FORK") != nullptr && !h->cnn;  // measured: a forked graph branch costs +20 us/update (cross-queue signals) -> opt-in only
+  h->use_fork = getenv("DSACT_FORK") != nullptr && !h->cnn && h->dw_chunks == 1;  // measured: a forked graph branch costs +20 us/update (cross-queue signals) -> opt-in only
   {
     const int max_lds = (int)tile_lds_bytes(BK * kMaxPrefetchTiles);  // 129 KB of the CU's 160 KB
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, false, EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
@@ -1208,6 +1279,8 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage_table, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, true, EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_conv_dw<3>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<false, EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<true, EPI_MULG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
   }
   for (int i = 0; i < 8; ++i) {
     HIPCHK(h, hipHostMalloc((void**)&h->h_idx[i], (size_t)h->B * sizeof(int), hipHostMallocDefault));

@@ -700,6 +700,125 @@ __global__ void __launch_bounds__(kThreads) k_stage(StageArgs s) {
   run_tile<P_MC, Q_MC, EPI, TS>(g, mt * TM, nt * TN, lds, s.timeline, (int)blockIdx.x);
 }
 
+// ---- large batches: 64x64 output tiles, 512 threads ---------------------------------------------------
+// At batch >= 512 a stage has >= 4x the tiles of the batch-256 case and is bound by operand traffic (a 32x32 tile
+// moves 64 KB per 0.5 MFLOP). A 64x64 tile halves the bytes per FLOP. 8 waves: wave (wr = w>>2, wc = w&3) owns
+// rows wr*32..+31 x columns wc*16..+15 (two accumulator tiles sharing one weight fragment). k-tiles of 64 are
+// double-buffered through LDS with the next tile's global loads in flight; the masks of the (padded) k tail are
+// applied at LDS-store time. Requirements (checked by the host): M % 64 == 0, N % 64 == 0, K % 4 == 0.
+constexpr int kThreads64 = 512;
+constexpr int TILE64_LDS = 64 * KC_LD;   // floats per staged operand tile
+inline size_t tile64_lds_bytes() { return (size_t)2 * 2 * TILE64_LDS * sizeof(float); }
+
+// raw loads of one staged operand tile; k quads / k rows beyond K are clamped to k = 0 (masked at store time)
+template <bool MC>
+__device__ __forceinline__ void tile64_load(const float* __restrict__ base, int ld, int row0, int kt, int K, int tid, f32x4& r0, f32x4& r1) {
+  if (!MC) {        // (row, k) at base[row*ld + k]: rows (tid>>4) and +32, k quad tid&15
+    const int k = kt * BK + (tid & 15) * 4;
+    const float* p = base + (size_t)(row0 + (tid >> 4)) * ld + (k < K ? k : 0);
+    r0 = gload4(p);
+    r1 = gload4(p + (size_t)32 * ld);
+  } else {          // (row, k) at base[k*ld + row]: row quad tid&15, k = (tid>>4) and +32
+    const int ka = kt * BK + (tid >> 4), kb = ka + 32;
+    const float* p = base + row0 + (tid & 15) * 4;
+    r0 = gload4(p + (size_t)(ka < K ? ka : 0) * ld);
+    r1 = gload4(p + (size_t)(kb < K ? kb : 0) * ld);
+  }
+}
+template <bool MC>
+__device__ __forceinline__ void tile64_store_lds(float* lds, int tid, const f32x4& r0, const f32x4& r1) {
+  if (!MC) {
+    *(f32x4*)(lds + (tid >> 4) * KC_LD + (tid & 15) * 4) = r0;
+    *(f32x4*)(lds + ((tid >> 4) + 32) * KC_LD + (tid & 15) * 4) = r1;
+  } else {
+    const int k = tid >> 4, row = (tid & 15) * 4;
+    float* p = lds + row * KC_LD + k;
+    p[0] = r0.x; p[KC_LD] = r0.y; p[2 * KC_LD] = r0.z; p[3 * KC_LD] = r0.w;
+    p[32] = r1.x; p[KC_LD + 32] = r1.y; p[2 * KC_LD + 32] = r1.z; p[3 * KC_LD + 32] = r1.w;
+  }
+}
+
+template <bool Q_MC, int EPI>
+__device__ __forceinline__ void run_tile64(const GemmProb& t, int m0, int n0, float* lds) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int i = lane & 15, g = lane >> 4;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const int T = (t.K + BK - 1) / BK;
+  // k validity of this thread's quads: KC operand: quad (tid&15) of the tile; MC operand: rows k = tid>>4, +32
+  auto kvalid_kc = [&](int kt) { return kt * BK + (tid & 15) * 4 < t.K; };
+  auto kvalid_mc = [&](int kt, int j) { return kt * BK + (tid >> 4) + 32 * j < t.K; };
+  auto load = [&](int kt, f32x4& p0, f32x4& p1, f32x4& q0, f32x4& q1) {
+    tile64_load<false>(t.P, t.ldp, m0, kt, t.K, tid, p0, p1);
+    tile64_load<Q_MC>(t.Q, t.ldq, n0, kt, t.K, tid, q0, q1);
+  };
+  // epilogue operands first (bias / GELU' quads of this lane's two output blocks)
+  const int n = n0 + wc * 16 + 4 * g;
+  f32x4 epv[2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const int m = m0 + wr * 32 + mb * 16 + i;
+    if (EPI == EPI_GELU) epv[mb] = gload4(t.aux + n);
+    else epv[mb] = gload4(t.aux + (size_t)m * t.ldaux + n);
+  }
+  f32x4 acc[2] = {zero, zero};
+  f32x4 p0, p1, q0, q1;
+  load(0, p0, p1, q0, q1);
+  for (int kt = 0; kt < T; ++kt) {
+    float* Ps = lds + (kt & 1) * 2 * TILE64_LDS;
+    float* Qs = Ps + TILE64_LDS;
+    if (!kvalid_kc(kt)) { p0 = zero; p1 = zero; if (!Q_MC) { q0 = zero; q1 = zero; } }
+    if (Q_MC) { if (!kvalid_mc(kt, 0)) q0 = zero; if (!kvalid_mc(kt, 1)) q1 = zero; }
+    tile64_store_lds<false>(Ps, tid, p0, p1);
+    tile64_store_lds<Q_MC>(Qs, tid, q0, q1);
+    __syncthreads();
+    if (kt + 1 < T) load(kt + 1, p0, p1, q0, q1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const f32x4 q = frag_read(Qs, wc * 16 + i, kk, g);
+      const f32x4 pa = frag_read(Ps, wr * 32 + i, kk, g);
+      const f32x4 pb = frag_read(Ps, wr * 32 + 16 + i, kk, g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[e], pa[e], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[e], pb[e], acc[1], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const int m = m0 + wr * 32 + mb * 16 + i;
+    float* c0 = t.C0 + (size_t)m * t.ldc + n;
+    if (EPI == EPI_GELU) {
+      f32x4 hv, gd;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float hh, gg;
+        gelu_fwd_grad(acc[mb][e] + epv[mb][e], hh, gg);
+        hv[e] = hh; gd[e] = gg;
+      }
+      *(f32x4u*)c0 = hv;
+      *(f32x4u*)(t.C1 + (size_t)m * t.ldc + n) = gd;
+    } else {
+      *(f32x4u*)c0 = acc[mb] * epv[mb];
+    }
+  }
+}
+
+template <bool Q_MC, int EPI>
+__global__ void __launch_bounds__(kThreads64) k_stage64(StageArgs s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int b = xcd_logical_block(blockIdx.x, gridDim.x);
+  int pi = 0;
+#pragma unroll
+  for (int q = 0; q + 1 < kMaxProb; ++q)
+    if (q + 1 < s.n_prob && b >= s.p[q].tile_end) pi = q + 1;
+  const GemmProb& g = s.p[pi];
+  const int local = b - (pi ? s.p[pi - 1].tile_end : 0);
+  const int mt = local / g.tiles_n, nt = local - mt * g.tiles_n;
+  run_tile64<Q_MC, EPI>(g, mt * 64, nt * 64, lds);
+}
+
 // ---- stage launch form 2: many small problems (weight / bias gradients) from a device table ------
 // one GemmProb PER TILE (tiles_n / tile_end are reused as the tile origin m0 / n0): a single
 // dependent load per block. Every problem is an MC x MC product with a plain store.
@@ -1427,6 +1546,26 @@ __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
     if (a.commit_ms) { a.st->ms1 = a.g[a.n_total]; a.st->ms2 = a.g[a.n_total + 1]; a.st->ms_init = 1; }
     a.st->it_next = st.it_cur + 1;
     a.st->seq_next = st.seq_next + 1;
+  }
+}
+
+// split-K weight gradients (batch > 448): every 256-sample chunk of the batch writes its own partial gradient arena;
+// this pass adds them in chunk order into the gradient arena [0, n) (log_alpha's gradient and the mean_std tail are
+// produced elsewhere and left alone)
+struct SumPartsArgs { const float* part; long long stride; int n_part; float* g; long long n; };
+__global__ void __launch_bounds__(kThreads) k_sum_parts(SumPartsArgs a) {
+  const long long i4 = ((long long)blockIdx.x * kThreads + threadIdx.x) * 4;
+  if (i4 >= a.n) return;
+  if (i4 + 3 < a.n) {
+    f32x4 s = *(const f32x4u*)(a.part + i4);
+    for (int c = 1; c < a.n_part; ++c) s += *(const f32x4u*)(a.part + c * a.stride + i4);
+    *(f32x4u*)(a.g + i4) = s;
+  } else {
+    for (long long i = i4; i < a.n; ++i) {
+      float s = a.part[i];
+      for (int c = 1; c < a.n_part; ++c) s += a.part[c * a.stride + i];
+      a.g[i] = s;
+    }
   }
 }
 

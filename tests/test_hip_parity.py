@@ -167,6 +167,19 @@ def test_large_batch_and_width():
     run_case("B=1024 hidden 512x2", 24, 6, (512, 512), 1024, steps=2)
 
 
+def test_humanoid_b512_large_batch_tiles():
+    """batch >= 512 switches the forward / hidden-backward stages to 64x64 tiles (k_stage64), including the Q nets'
+    first layer whose K = 393 is served from the zero-padded operands."""
+    run_case("humanoid 3x256 B=512 (64x64 stage tiles)", 376, 17, (256, 256, 256), 512, steps=3)
+
+
+def test_humanoid_b2048_split_k_weight_gradients():
+    """batch > 448 (multiple of 256): the weight gradients are split over 256-sample chunks of the batch (one
+    partial gradient arena per chunk, k_sum_parts, then the streaming Adam/Polyak kernel) instead of one
+    batch-long contraction per tile."""
+    run_case("humanoid 3x256 B=2048 (split-K weight gradients)", 376, 17, (256, 256, 256), 2048, steps=2)
+
+
 @pytest.mark.parametrize("name", STEP_CASES)
 def test_against_reference_golden(name):
     z, cfg, init = load_step_case(name)
