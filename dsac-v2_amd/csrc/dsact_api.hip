@@ -926,7 +926,7 @@ int enqueue_prologue(dsact_handle* h, int use_dev, long long it, int advance, in
 }
 
 // everything of __compute_gradient after the minibatch is staged (dsac_v2.py:150-206)
-int enqueue_adam(dsact_handle* h);
+int enqueue_adam(dsact_handle* h, bool from_parts = false);
 
 // split-K: gradient arena [lo, hi) = sum of the chunk partials
 int sum_parts(dsact_handle* h, size_t lo, size_t hi) {
@@ -1048,8 +1048,8 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
     } else {
       TRY(run_dw(h, h->dw_off[0], h->dw_off[2], false, false));
       if (h->cnn) TRY(enqueue_conv_backward(h, 2, false));
-      TRY(sum_parts(h, 0, (size_t)h->nq * h->n_q));
-      if (fused) TRY(enqueue_adam(h));
+      if (fused) TRY(enqueue_adam(h, true));   // policy segment: not updated on off iterations, partials ignored
+      else TRY(sum_parts(h, 0, (size_t)h->nq * h->n_q));
     }
     return DSACT_OK;
   }
@@ -1119,14 +1119,17 @@ actor_part:
   } else {
     TRY(run_dw(h, np ? h->dw_off[2] : h->dw_off[0], h->dw_off[3], false, false));
     if (h->cnn) TRY(enqueue_conv_backward(h, 3, false));
-    TRY(sum_parts(h, 0, h->n_online - 1));
-    if (fused) TRY(enqueue_adam(h));
+    if (fused) TRY(enqueue_adam(h, true));
+    else TRY(sum_parts(h, 0, h->n_online - 1));
   }
   return DSACT_OK;
 }
 
-int enqueue_adam(dsact_handle* h) {
+// from_parts: split-K flow of the fused step -- the optimiser sums the chunk partials itself (no k_sum_parts pass)
+int enqueue_adam(dsact_handle* h, bool from_parts) {
   AdamArgs a;
+  memset(&a, 0, sizeof(a));
+  if (from_parts && h->dw_chunks > 1) { a.part = h->dw_parts; a.part_stride = (long long)h->dw_part_stride; a.n_part = h->dw_chunks; }
   a.p = h->online; a.tgt = h->target; a.m = h->adam_m; a.v = h->adam_v; a.g = h->grads;
   a.n_q2 = (long long)(h->nq * h->n_q); a.n_online3 = (long long)(h->nq * h->n_q + h->n_pi); a.n_total = (long long)h->n_online;
   a.st = h->st;

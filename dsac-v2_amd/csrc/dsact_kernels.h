@@ -1472,7 +1472,25 @@ struct AdamArgs {
   float polyak, one_minus_polyak;
   int auto_alpha;
   int commit_ms;       // 1: take mean_std from g[n_total..n_total+1]
+  // split-K weight gradients (batch > 448): the gradient of element i < n_total-1 is the sum of n_part chunk partials
+  // (log_alpha's gradient and the mean_std tail always come from g); NULL: gradients are in g
+  const float* part; long long part_stride; int n_part;
 };
+
+__device__ __forceinline__ f32x4 adam_grad4(const AdamArgs& a, long long base) {
+  if (a.part == nullptr) return *(const f32x4*)(a.g + base);
+  f32x4 s = *(const f32x4*)(a.part + base);
+  for (int c = 1; c < a.n_part; ++c) s += *(const f32x4*)(a.part + c * a.part_stride + base);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) if (base + e >= a.n_total - 1) s[e] = a.g[base + e];
+  return s;
+}
+__device__ __forceinline__ float adam_grad1(const AdamArgs& a, long long i) {
+  if (a.part == nullptr || i >= a.n_total - 1) return a.g[i];
+  float s = a.part[i];
+  for (int c = 1; c < a.n_part; ++c) s += a.part[c * a.part_stride + i];
+  return s;
+}
 
 __device__ __forceinline__ void adam_classify(const AdamArgs& a, const DevState& st, long long base, bool delayed,
                                               bool (&upd)[4], float (&ss)[4], float (&bc2)[4], bool& any) {
@@ -1507,7 +1525,7 @@ __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
       tvec[u] = vec[u] && delayed && base[u] + 3 < a.n_online3;
       if (vec[u]) {
         p[u] = *(const f32x4*)(a.p + base[u]); m[u] = *(const f32x4*)(a.m + base[u]);
-        v[u] = *(const f32x4*)(a.v + base[u]); g[u] = *(const f32x4*)(a.g + base[u]);
+        v[u] = *(const f32x4*)(a.v + base[u]); g[u] = adam_grad4(a, base[u]);
         if (tvec[u]) t[u] = *(const f32x4*)(a.tgt + base[u]);
       }
     }
@@ -1534,7 +1552,7 @@ __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
           float pe = a.p[i];
           if (upd[u][e]) {
             float me = a.m[i], ve = a.v[i];
-            adam_update(pe, me, ve, a.g[i], a.b1w, a.beta2, a.b2w, ss[u][e], bc2[u][e], a.eps);
+            adam_update(pe, me, ve, adam_grad1(a, i), a.b1w, a.beta2, a.b2w, ss[u][e], bc2[u][e], a.eps);
             a.p[i] = pe; a.m[i] = me; a.v[i] = ve;
           }
           if (delayed && i < a.n_online3) a.tgt[i] = polyak_update(a.tgt[i], pe, a.polyak, a.one_minus_polyak);

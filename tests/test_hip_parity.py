@@ -408,6 +408,29 @@ def test_fused_optimizer_equals_split_update():
     assert a1.engine.get_state() == a2.engine.get_state()
 
 
+def test_split_k_step_equals_split_k_halves():
+    """batch 512 (two 256-sample chunks): dsact_step (k_adam sums the chunk partials itself) ==
+    compute_grads (k_sum_parts -> gradient arena) + apply_update, bit for bit."""
+    O, A, hid, B = 23, 5, (64, 96, 64), 512
+    a1, _ = make_pair(O, A, hid, B, seed=9)
+    a2, _ = make_pair(O, A, hid, B, seed=9)
+    rng = np.random.default_rng(2)
+    for it in range(4):
+        data = synth_batch(rng, B, O, A, p_done=0.1)
+        torch.manual_seed(77 + it)
+        noise = draw_noise(B, A)
+        for a in (a1, a2):
+            a.engine.load_batch(*(data[k].numpy() for k in ("obs", "act", "rew", "obs2", "done")))
+            a.engine.set_noise(noise["eps_new"].numpy(), noise["eps_2"].numpy(), noise["z5"].numpy(), noise["z6"].numpy())
+        a1.engine.step(it)
+        a2.engine.compute_grads(it)
+        a2.engine.apply_update(it)
+    a1.engine.sync(); a2.engine.sync()
+    for name in ("online", "target", "adam_m", "adam_v"):
+        assert torch.equal(getattr(a1.engine, name), getattr(a2.engine, name)), name
+    assert a1.engine.get_state() == a2.engine.get_state()
+
+
 def test_skip_discarded_actor_backward_keeps_trajectory():
     """DSACT_F_SKIP_ACTOR_ON_OFF_ITERS drops work whose result the reference throws away
     (dsac_v2.py:174-186 vs :324): parameters, targets and optimiser state must not change by a bit."""
