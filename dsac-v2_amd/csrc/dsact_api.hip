@@ -928,9 +928,25 @@ int enqueue_prologue(dsact_handle* h, int use_dev, long long it, int advance, in
 // everything of __compute_gradient after the minibatch is staged (dsac_v2.py:150-206)
 int enqueue_adam(dsact_handle* h, bool from_parts = false);
 
-// split-K: gradient arena [lo, hi) = sum of the chunk partials
+int sum_parts_range(dsact_handle* h, size_t lo, size_t hi);
+
+// split-K: gradient arena [lo, hi) = sum of the chunk partials -- per net, skipping the conv parameters of the CNN
+// nets (their gradients are reduced by k_conv_dw_reduce straight into the arena)
 int sum_parts(dsact_handle* h, size_t lo, size_t hi) {
   if (h->dw_chunks == 1 || hi <= lo) return DSACT_OK;
+  if (!h->cnn) return sum_parts_range(h, lo, hi);
+  const int nets[3] = {N_Q1, N_Q2, N_POL};
+  for (int i = 0; i < 3; ++i) {
+    const NetDesc& d = net_desc(h, nets[i]);
+    const size_t b = (size_t)(net_grads(h, nets[i]) - h->grads);
+    const size_t s0 = b + d.w_off[0], s1 = b + d.count;
+    const size_t x0 = s0 > lo ? s0 : lo, x1 = s1 < hi ? s1 : hi;
+    if (x1 > x0) TRY(sum_parts_range(h, x0, x1));
+  }
+  return DSACT_OK;
+}
+
+int sum_parts_range(dsact_handle* h, size_t lo, size_t hi) {
   SumPartsArgs a;
   a.part = h->dw_parts + lo; a.stride = (long long)h->dw_part_stride; a.n_part = h->dw_chunks;
   a.g = h->grads + lo; a.n = (long long)(hi - lo);
@@ -1129,7 +1145,14 @@ actor_part:
 int enqueue_adam(dsact_handle* h, bool from_parts) {
   AdamArgs a;
   memset(&a, 0, sizeof(a));
-  if (from_parts && h->dw_chunks > 1) { a.part = h->dw_parts; a.part_stride = (long long)h->dw_part_stride; a.n_part = h->dw_chunks; }
+  if (from_parts && h->dw_chunks > 1) {
+    a.part = h->dw_parts; a.part_stride = (long long)h->dw_part_stride; a.n_part = h->dw_chunks;
+    const int nets[3] = {N_Q1, N_Q2, N_POL};
+    for (int i = 0; i < 3; ++i) {   // conv parameters (CNN nets) are reduced by their own kernel straight into `grads`
+      const long long b = (long long)(net_grads(h, nets[i]) - h->grads);
+      a.direct_lo[i] = b; a.direct_hi[i] = b + (long long)net_desc(h, nets[i]).w_off[0];
+    }
+  }
   a.p = h->online; a.tgt = h->target; a.m = h->adam_m; a.v = h->adam_v; a.g = h->grads;
   a.n_q2 = (long long)(h->nq * h->n_q); a.n_online3 = (long long)(h->nq * h->n_q + h->n_pi); a.n_total = (long long)h->n_online;
   a.st = h->st;

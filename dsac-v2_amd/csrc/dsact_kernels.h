@@ -1475,18 +1475,23 @@ struct AdamArgs {
   // split-K weight gradients (batch > 448): the gradient of element i < n_total-1 is the sum of n_part chunk partials
   // (log_alpha's gradient and the mean_std tail always come from g); NULL: gradients are in g
   const float* part; long long part_stride; int n_part;
+  long long direct_lo[3], direct_hi[3];   // conv parameters of q1 / q2 / policy: their gradients are always in g
 };
 
+__device__ __forceinline__ bool adam_direct(const AdamArgs& a, long long i) {
+  return i >= a.n_total - 1 || (i >= a.direct_lo[0] && i < a.direct_hi[0]) || (i >= a.direct_lo[1] && i < a.direct_hi[1]) ||
+         (i >= a.direct_lo[2] && i < a.direct_hi[2]);
+}
 __device__ __forceinline__ f32x4 adam_grad4(const AdamArgs& a, long long base) {
   if (a.part == nullptr) return *(const f32x4*)(a.g + base);
   f32x4 s = *(const f32x4*)(a.part + base);
   for (int c = 1; c < a.n_part; ++c) s += *(const f32x4*)(a.part + c * a.part_stride + base);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) if (base + e >= a.n_total - 1) s[e] = a.g[base + e];
+  for (int e = 0; e < 4; ++e) if (adam_direct(a, base + e)) s[e] = a.g[base + e];
   return s;
 }
 __device__ __forceinline__ float adam_grad1(const AdamArgs& a, long long i) {
-  if (a.part == nullptr || i >= a.n_total - 1) return a.g[i];
+  if (a.part == nullptr || adam_direct(a, i)) return a.g[i];
   float s = a.part[i];
   for (int c = 1; c < a.n_part; ++c) s += a.part[c * a.part_stride + i];
   return s;

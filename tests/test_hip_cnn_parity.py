@@ -161,13 +161,22 @@ def test_cnn_type2_b256():
     run_case("cnn type_2 (3,96,96) B=256", (3, 96, 96), 3, "type_2", 256, steps=2)
 
 
-def test_cnn_fused_step_equals_split_path():
-    a1, _, cfg = make_pair((3, 96, 96), 3, "type_2", 16, seed=3)
-    a2, _, _ = make_pair((3, 96, 96), 3, "type_2", 16, seed=3)
-    for it in range(4):
-        d = synth_image_batch(cfg, 16, seed=10 + it)
+def test_cnn_type2_b512_large_batch_paths():
+    """batch 512: the twin-trunk MLP part runs on the 64x64 stage tiles and split-K weight gradients while the conv
+    stacks keep their own chunked weight gradient; the optimiser is the streaming kernel for both."""
+    run_case("cnn type_2 (3,96,96) B=512", (3, 96, 96), 3, "type_2", 512, steps=1)
+
+
+@pytest.mark.parametrize("B,steps", [(16, 4), (512, 2)])
+def test_cnn_fused_step_equals_split_path(B, steps):
+    """fused step == gradient halves + streaming Adam, bit for bit; at batch 512 the fused step's Adam kernel sums
+    the MLP part's split-K partials itself while the conv gradients come from the gradient arena."""
+    a1, _, cfg = make_pair((3, 96, 96), 3, "type_2", B, seed=3)
+    a2, _, _ = make_pair((3, 96, 96), 3, "type_2", B, seed=3)
+    for it in range(steps):
+        d = synth_image_batch(cfg, B, seed=10 + it)
         torch.manual_seed(50 + it)
-        a1.local_update(d, it)                       # fused Adam in the gradient kernels
+        a1.local_update(d, it)                       # fused step
         torch.manual_seed(50 + it)
         _, info = a2.get_remote_update_info(d, it)   # gradients, then the streaming Adam kernel
         a2.remote_update(info)

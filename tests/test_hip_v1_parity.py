@@ -81,6 +81,10 @@ def test_v1_humanoid_shapes():
     run_case("v1 humanoid 3x256 B=256", 376, 17, (256, 256, 256), 256, steps=3)
 
 
+def test_v1_large_batch_tiles_and_split_k():
+    run_case("v1 humanoid 3x256 B=512 (64x64 stage tiles, split-K dW)", 376, 17, (256, 256, 256), 512, steps=2)
+
+
 def test_v1_ragged_and_one_dim_action():
     run_case("v1 ragged O=11 A=3 (96,40) B=50", 11, 3, (96, 40), 50, steps=3)
     run_case("v1 O=3 A=1 (64,64) B=64", 3, 1, (64, 64), 64, steps=3, act_limit=2.0)
