@@ -161,6 +161,10 @@ def test_ragged_shapes():
     # widths not multiples of the 32x32 tile, batch not a multiple of 4, one action dim
     run_case("ragged O=11 A=3 (96,40) B=50", 11, 3, (96, 40), 50, steps=3)
     run_case("ragged O=5 A=1 (33,) B=7", 5, 1, (33,), 7, steps=3, act_limit=2.0)
+    # batch > 448 but neither a multiple of 64 nor of 256: no 64x64 tiles, no split-K -- the generic long-K tile path
+    run_case("ragged O=11 A=3 (96,40) B=600", 11, 3, (96, 40), 600, steps=2)
+    # multiple of 256 with widths that are not multiples of 64: split-K weight gradients on the 32x32 stage tiles
+    run_case("ragged O=11 A=3 (96,40) B=768", 11, 3, (96, 40), 768, steps=2)
 
 
 def test_large_batch_and_width():
