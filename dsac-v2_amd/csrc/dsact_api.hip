@@ -89,7 +89,7 @@ struct dsact_handle {
   float* cdy[3][kMaxConv];
   float* dcol[3];
   float* dfeat[3];
-  float* dwpart[3];
+  float* dwpart[3][kMaxConv];           // weight-gradient partials per differentiated stack and layer
   float *aimg, *aact[kMaxConv];         // stand-alone policy forward
   float* stage_img = nullptr;           // device staging of a host minibatch's images (dsact_load_batch)
   int* idx_iota = nullptr;
@@ -284,7 +284,7 @@ void carve(dsact_handle* h, Carver& c) {
     const size_t R = h->Brows;
     h->img[0] = c.take<float>(B * h->O);
     h->img[1] = c.take<float>(B * h->O);
-    size_t dcol_max = 4, part_max = 4;
+    size_t dcol_max = 4;
     for (int j = 0; j < h->n_conv; ++j) {
       const ConvGeom& g = h->cg[j];
       const size_t M = B * g.OH * g.OW;
@@ -292,13 +292,11 @@ void carve(dsact_handle* h, Carver& c) {
       for (int st = 0; st < 3; ++st) h->cdy[st][j] = c.take<float>(M * g.Cout);
       if (j > 0 && M * g.K > dcol_max) dcol_max = M * g.K;
       const size_t chunks = (M + conv_dw_chunk(M) - 1) / conv_dw_chunk(M);
-      const size_t part = chunks * g.Cout * (g.K + 4);
-      if (part > part_max) part_max = part;
+      for (int st = 0; st < 3; ++st) h->dwpart[st][j] = c.take<float>(chunks * g.Cout * (g.K + 4));
       h->aact[j] = c.take<float>((size_t)kActRows * g.OH * g.OW * g.Cout);
     }
     for (int st = 0; st < 3; ++st) {
       h->dcol[st] = c.take<float>(dcol_max);
-      h->dwpart[st] = c.take<float>(part_max);
       h->dfeat[st] = c.take<float>(B * h->F);
     }
     h->aimg = c.take<float>((size_t)kActRows * h->O);
@@ -753,7 +751,7 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
         ConvDwProb& p = a.p[a.n_prob++];
         p.in = j == 0 ? h->img[0] : h->cact[S(st0)][j - 1];
         p.n_sub = per_prob;
-        for (int u = 0; u < per_prob; ++u) { p.dy[u] = h->cdy[S(st0 + u)][j]; p.part[u] = h->dwpart[S(st0 + u)]; }
+        for (int u = 0; u < per_prob; ++u) { p.dy[u] = h->cdy[S(st0 + u)][j]; p.part[u] = h->dwpart[S(st0 + u)][j]; }
         p.M = M;
         p.tiles_co = tiles_of(per_prob * g.Cout, TM);
         blocks += a.n_chunks * p.tiles_co * a.tiles_k;
@@ -811,24 +809,34 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
       const long long n = (long long)B * g.H * g.W * (g.Cin / 4);
       TRY(launch(h, ("col2im" + sfx).c_str(), k_col2im, dim3((unsigned)((n + kThreads - 1) / kThreads), n_st), dim3(kThreads), 0, c));
     }
-    {
-      // ordered reduce of the partials (+ Adam / Polyak when fused) -- AFTER dCol, which needs this
-      // layer's weights as the forward pass saw them
-      ConvReduceArgs r;
-      memset(&r, 0, sizeof(r));
+  }
+  {
+    // ordered reduce of the partials of ALL layers (+ Adam / Polyak when fused) in one launch, after the whole conv
+    // backward: every dCol / direct data gradient above read the weights as the forward pass saw them
+    ConvReduceArgs r;
+    memset(&r, 0, sizeof(r));
+    int blocks = 0;
+    for (int j = 0; j <= last; ++j) {
+      const ConvGeom& g = h->cg[j];
+      const int M = B * g.OH * g.OW;
+      const int chunk = (int)conv_dw_chunk(M);
+      ConvReduceLayer& Ly = r.L[j];
+      Ly.Cout = g.Cout; Ly.K = g.K; Ly.K1p = g.K + 4; Ly.n_chunks = (M + chunk - 1) / chunk;
+      Ly.quads = g.Cout * Ly.K1p / 4;
+      Ly.wide = Ly.n_chunks > 16 ? 1 : 0;
+      Ly.block_begin = blocks;
+      blocks += Ly.wide ? (Ly.quads + 15) / 16 : (Ly.quads + kThreads - 1) / kThreads;
       for (int st = 0; st < n_st; ++st) {
         const int net = kStackNet[S(st)];
         const NetDesc& d = net_desc(h, net);
-        r.p[st].part = h->dwpart[S(st)];
-        r.p[st].w_idx = (long long)((net_grads(h, net) + d.cw_off[j]) - h->grads);
-        r.p[st].b_idx = (long long)((net_grads(h, net) + d.cb_off[j]) - h->grads);
+        r.p[j][st].part = h->dwpart[S(st)][j];
+        r.p[j][st].w_idx = (long long)((net_grads(h, net) + d.cw_off[j]) - h->grads);
+        r.p[j][st].b_idx = (long long)((net_grads(h, net) + d.cb_off[j]) - h->grads);
       }
-      r.n_prob = n_st; r.Cout = g.Cout; r.K = g.K; r.K1p = K1p; r.n_chunks = n_chunks;
-      r.quads = g.Cout * K1p / 4;
-      r.fo = fused_opt(h, fused);
-      if (n_chunks > 16) TRY(launch(h, ("conv_dw_reduce" + sfx).c_str(), k_conv_dw_reduce<16>, dim3((r.quads + 15) / 16, n_st), dim3(kThreads), 0, r));
-      else TRY(launch(h, ("conv_dw_reduce" + sfx).c_str(), k_conv_dw_reduce<1>, dim3((r.quads + kThreads - 1) / kThreads, n_st), dim3(kThreads), 0, r));
     }
+    r.n_layers = last + 1; r.n_prob = n_st;
+    r.fo = fused_opt(h, fused);
+    TRY(launch(h, "conv_dw_reduce", k_conv_dw_reduce, dim3(blocks, n_st), dim3(kThreads), 0, r));
   }
   return DSACT_OK;
 }

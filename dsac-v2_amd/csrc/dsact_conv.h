@@ -599,55 +599,63 @@ __global__ void __launch_bounds__(kThreads) k_conv_dx_block(ConvDxArgs a) {
   }
 }
 
-// sums the partials in a fixed order, writes the gradient and (single-GPU path) applies Adam / Polyak
+// sums the partials in a fixed order, writes the gradient and (single-GPU path) applies Adam / Polyak.
+// ONE launch for all layers of all differentiated stacks (it runs after the whole conv backward, so every use of the
+// pre-update weights is behind it): six tiny reduces as separate launches cost 65 us of launch latency per update.
+struct ConvReduceLayer {
+  int Cout, K, K1p, n_chunks, quads;   // quads = Cout * K1p / 4
+  int block_begin;                     // first block (grid.x) of this layer
+  int wide;                            // 1: 16 quads x 16 chunk lanes per block (many chunks); 0: 256 quads x 1 lane
+};
 struct ConvReduceProb {
   const float* part;
   long long w_idx, b_idx;   // arena index of this layer's weight / bias block
 };
 struct ConvReduceArgs {
-  ConvReduceProb p[3];
-  int n_prob;
-  int Cout, K, K1p, n_chunks;
-  int quads;                // Cout * K1p / 4 per problem
+  ConvReduceLayer L[kMaxConv];
+  ConvReduceProb p[kMaxConv][3];
+  int n_layers, n_prob;
   FusedOpt fo;
 };
 
-template <int CL>   // chunk lanes per quad: 16 (many chunks: tree over lanes) or 1 (few chunks: one thread per quad)
 __global__ void __launch_bounds__(kThreads) k_conv_dw_reduce(ConvReduceArgs a) {
   __shared__ f32x4 red[kThreads];
-  constexpr int QL = kThreads / CL;
+  int j = 0;
+#pragma unroll
+  for (int q = 1; q < kMaxConv; ++q) if (q < a.n_layers && (int)blockIdx.x >= a.L[q].block_begin) j = q;
+  const ConvReduceLayer& Ly = a.L[j];
+  const ConvReduceProb& t = a.p[j][blockIdx.y];
   const int tid = threadIdx.x;
+  const int QL = Ly.wide ? 16 : kThreads, CL = Ly.wide ? 16 : 1;
   const int ql = tid % QL, cl = tid / QL;
-  const int pi = blockIdx.y;
-  const ConvReduceProb& t = a.p[pi];
-  const int q = blockIdx.x * QL + ql;
-  const bool qv = q < a.quads;
+  const int q = ((int)blockIdx.x - Ly.block_begin) * QL + ql;
+  const bool qv = q < Ly.quads;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (qv) {
     // chunk lane cl sums chunks cl, cl+CL, ...: 4 independent loads per trip
-    for (int c0 = cl; c0 < a.n_chunks; c0 += 4 * CL) {
+    for (int c0 = cl; c0 < Ly.n_chunks; c0 += 4 * CL) {
       f32x4 v[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int c = c0 + CL * u;
-        v[u] = *(const f32x4u*)(t.part + ((size_t)(c < a.n_chunks ? c : 0) * a.quads + q) * 4);
+        v[u] = *(const f32x4u*)(t.part + ((size_t)(c < Ly.n_chunks ? c : 0) * Ly.quads + q) * 4);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) if (c0 + CL * u < a.n_chunks) s += v[u];
+      for (int u = 0; u < 4; ++u) if (c0 + CL * u < Ly.n_chunks) s += v[u];
     }
   }
-  if (CL > 1) {
+  if (Ly.wide) {               // uniform per block
     red[tid] = s;
     __syncthreads();
     if (cl != 0 || !qv) return;
 #pragma unroll
-    for (int u = 1; u < CL; ++u) s += red[u * QL + ql];
+    for (int u = 1; u < 16; ++u) s += red[u * 16 + ql];
   } else if (!qv) return;
-  const int co = (q * 4) / a.K1p, kk = q * 4 - co * a.K1p;
-  if (kk > a.K) return;                               // padding quad
+  const int co = (q * 4) / Ly.K1p, kk = q * 4 - co * Ly.K1p;
+  if (kk > Ly.K) return;                               // padding quad
   const FusedOpt& fo = a.fo;
-  const bool is_bias = kk == a.K;
-  const long long oi = is_bias ? t.b_idx + co : t.w_idx + (long long)co * a.K + kk;
+  const bool is_bias = kk == Ly.K;
+  const long long oi = is_bias ? t.b_idx + co : t.w_idx + (long long)co * Ly.K + kk;
   const int nel = is_bias ? 1 : 4;
   for (int e = 0; e < nel; ++e) fo.grads[oi + e] = s[e];
   if (fo.st == nullptr) return;
