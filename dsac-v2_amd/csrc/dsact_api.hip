@@ -842,17 +842,29 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
 }
 
 // image rows -> staged pixel-major minibatch (+ replayed action / reward / done when `with_scalars`)
+RepackArgs repack_args(const dsact_handle* h, int n_blocks);
+int repack_blocks(const dsact_handle* h);
+StepHyper step_hyper(const dsact_handle* h);
+NoiseArgs noise_args(const dsact_handle* h);
+
+// step_it >= -1: fused step flow (bookkeeping for iteration step_it, or the device iteration when use_dev; device
+// noise; weight repack) rides in the same launch; -2: plain staging
 int enqueue_gather_img(dsact_handle* h, const float* src_obs, const float* src_obs2, const int* table, int rows,
-                       int use_dev, bool with_scalars, float* img0, float* img2, int n_rows) {
+                       int use_dev, bool with_scalars, float* img0, float* img2, int n_rows,
+                       long long step_it = -2, int advance = 0) {
   ImgGatherArgs a;
   memset(&a, 0, sizeof(a));
+  if (step_it >= -1) {
+    a.bookkeeping = 1; a.advance_counters = advance; a.host_it = step_it; a.stw = h->st;
+    a.hp = step_hyper(h); a.nz = noise_args(h); a.rp = repack_args(h, repack_blocks(h));
+  }
   a.rb_obs = src_obs; a.rb_obs2 = src_obs2;
   a.rb_act = with_scalars ? h->rb_act : nullptr; a.rb_rew = h->rb_rew; a.rb_done = h->rb_done;
   a.idx_table = table; a.idx_rows = rows; a.use_dev = use_dev; a.host_row = 0; a.st = h->st;
   a.img0 = img0; a.img2 = img2; a.Xa0 = h->Xc[C_Q1C]; a.Xa1 = h->Xc[C_Q2C]; a.rew = h->rew; a.done = h->done;
   a.B = n_rows; a.C = h->cfg.img_c; a.HW = h->cfg.img_h * h->cfg.img_w; a.A = h->A; a.F = h->F; a.ldx = h->ldx;
   a.chunks = 8;
-  return launch(h, "gather_img", k_gather_img, dim3(n_rows * a.chunks), dim3(kThreads), 0, a);
+  return launch(h, "gather_img", k_gather_img, dim3(n_rows * a.chunks + a.rp.n_blocks), dim3(kThreads), 0, a);
 }
 
 // dispatch on the number of 256-wide chunks of a hidden row (register arrays are statically indexed)
@@ -907,8 +919,9 @@ int enqueue_prologue(dsact_handle* h, int use_dev, long long it, int advance, in
 
 int enqueue_gather(dsact_handle* h, const int* table, int rows, int use_dev, long long it, int advance) {
   if (h->cnn) {
-    TRY(enqueue_gather_img(h, h->rb_obs, h->rb_obs2, table, rows, use_dev, true, h->img[0], h->img[1], h->B));
-    return enqueue_prologue(h, use_dev, it, advance, 1);   // bookkeeping, device noise, padded-weight repack
+    // bookkeeping, device noise and the padded-weight repack ride in the same launch
+    return enqueue_gather_img(h, h->rb_obs, h->rb_obs2, table, rows, use_dev, true, h->img[0], h->img[1], h->B,
+                              use_dev ? -1 : it, advance);
   }
   GatherArgs a;
   a.rb_obs = h->rb_obs; a.rb_obs2 = h->rb_obs2; a.rb_act = h->rb_act; a.rb_rew = h->rb_rew; a.rb_done = h->rb_done;

@@ -771,8 +771,17 @@ struct ImgGatherArgs {
   float* rew; float* done;
   int B, C, HW, A, F, ldx;
   int chunks;               // blocks per image
+  // fused step flows: block 0 does the per-step bookkeeping, chunk-0 blocks draw the device noise of their row,
+  // spare blocks [B*chunks, ...) refresh the padded first-layer weight copies (as k_gather does for the MLP nets)
+  int bookkeeping, advance_counters; long long host_it;
+  DevState* stw;
+  StepHyper hp; NoiseArgs nz; RepackArgs rp;
 };
 __global__ void __launch_bounds__(kThreads) k_gather_img(ImgGatherArgs a) {
+  if ((int)blockIdx.x >= a.B * a.chunks) {
+    repack_rows(a.rp, (int)blockIdx.x - a.B * a.chunks, threadIdx.x);
+    return;
+  }
   const int r = blockIdx.x / a.chunks, ck = blockIdx.x - r * a.chunks;
   const int trow = a.use_dev ? (int)(a.st->seq_next % a.idx_rows) : a.host_row;
   const long long src = a.idx_table[(size_t)trow * a.B + r];
@@ -803,6 +812,11 @@ __global__ void __launch_bounds__(kThreads) k_gather_img(ImgGatherArgs a) {
       a.Xa1[(size_t)r * a.ldx + a.F + t] = av;
     }
     if (a.rb_act && t == 0) { a.rew[r] = a.rb_rew[src]; a.done[r] = a.rb_done[src]; }
+    if (a.bookkeeping) {
+      const long long it = a.use_dev ? a.st->it_next : a.host_it;
+      if (a.nz.seed != 0) fill_noise_rows(a.nz, it, r, r + 1, a.A, t, kThreads);
+      if (blockIdx.x == 0 && t == 0) prologue_duties(a.stw, it, a.advance_counters, a.hp);
+    }
   }
 }
 
