@@ -72,3 +72,31 @@ def test_cnn_image_env_end_to_end_learns(tmp_path):
     assert all(np.isfinite(v) for v in st.values())
     sd = torch.load(tmp_path / "apprfunc" / "apprfunc_5500.pkl")
     assert len(sd) == 173 and tuple(sd["policy.conv.0.weight"].shape) == (8, 3, 4, 4)
+
+
+def test_v1_pendulum_end_to_end_learns(tmp_path):
+    """DSAC_V1_HIP (reference dsac_v1.py on the shared kernels) through the same plugin stack."""
+    import plugin
+    kw = hip_kwargs(3, 1, (256, 256, 256), 256, act_limit=2.0, env_id="synth_pendulum", sample_batch_size=20,
+                    reward_scale=1, buffer_warm_size=1000, buffer_max_size=100000, max_iteration=9001,
+                    log_save_interval=500, apprfunc_save_interval=4500, eval_interval=1500, num_eval_episode=5,
+                    ini_network_dir=None, save_folder=str(tmp_path), seed=12345, sample_interval=1,
+                    algorithm="DSAC_V1_HIP", TD_bound=10)
+    torch.manual_seed(kw["seed"]); np.random.seed(kw["seed"])
+    alg = plugin.create_alg(**kw)
+    assert type(alg).__name__ == "DSAC_V1_HIP"
+    sampler = plugin.create_sampler(**kw)
+    buf = plugin.create_buffer(**kw)
+    assert buf.engine is alg.engine
+    ev = plugin.create_evaluator(**kw)
+    tr = plugin.create_trainer(alg, sampler, buf, ev, **kw)
+    tars = []
+    orig = ev.run_evaluation
+    ev.run_evaluation = lambda it: tars.append(orig(it)) or tars[-1]
+    tr.train()
+    print("DSAC_V1 eval TAR per 1500 iterations:", [round(t, 1) for t in tars])
+    assert len(tars) == 7 and all(np.isfinite(tars))
+    assert max(tars[3:]) > -900 and max(tars[3:]) > tars[0] + 300, tars
+    sd = torch.load(tmp_path / "apprfunc" / "apprfunc_9000.pkl")
+    assert list(sd.keys())[:2] == ["log_alpha", "q.q.0.weight"] and "q_target.q.0.weight" in sd
+    assert alg.engine.get_state()["adam_steps"] == [9001, 4501, 4501]
