@@ -304,6 +304,7 @@ def main():
     ap.add_argument("--batch", type=int, default=B, help="minibatch rows per GPU (BASELINE metric: 256)")
     ap.add_argument("--cnn-only", action="store_true", help="measure only the CNN workload (configs[3]); prints its object")
     ap.add_argument("--cnn-steps", type=int, default=400)
+    ap.add_argument("--cnn-type", type=str, default="type_2", help="type_2 at (3,96,96) (default) or type_1 at (4,84,84) (SURVEY.md D3)")
     args = ap.parse_args()
     steps = args.steps + (args.steps & 1)
     warmup = args.warmup + (args.warmup & 1)
@@ -331,6 +332,9 @@ def main():
         if rank != 0:
             entry.build()
     if args.cnn_only:
+        if args.cnn_type == "type_1":
+            global CNN_OBS, CNN_A, CNN_TYPE
+            CNN_OBS, CNN_A, CNN_TYPE = (4, 84, 84), 3, "type_1"
         print(json.dumps({"cnn": bench_cnn(local, args.cnn_steps, 40, cpu=not args.no_cpu_baseline)}))
         return
     hidden = [int(x) for x in args.hidden.split(",")]

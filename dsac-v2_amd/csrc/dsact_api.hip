@@ -106,6 +106,7 @@ struct dsact_handle {
   float *logits_pi, *logits_pit, *logp_new, *logp2;
   float *qout_c[2], *qout_t[2], *qout_p[2], *qstd_c[2];
   float* W1p[4];  // zero-padded first-layer weights of q1, q2, q1_target, q2_target  [w0 x ldx]
+  bool use_w1p = true;   // false for very wide first layers: copying them every step costs more than unaligned rows
   float* dout[4];
   float *dout_pi, *d_new_act;
   float* W1aT[2];  // transposed zero-padded action columns of q1 / q2's first layer  [32][w0]
@@ -331,7 +332,7 @@ void carve(dsact_handle* h, Carver& c) {
   h->W1aT[0] = c.take<float>((size_t)32 * h->w[0]);
   h->W1aT[1] = c.take<float>((size_t)32 * h->w[0]);
   h->part_loss = c.take<float>(B * kLossPart);
-  for (int i = 0; i < 4; ++i) h->W1p[i] = c.take<float>((size_t)h->w[0] * h->ldx);
+  for (int i = 0; i < 4; ++i) h->W1p[i] = c.take<float>(h->use_w1p ? (size_t)h->w[0] * h->ldx : 4);
   h->part_heads = c.take<float>((size_t)h->n_heads_wg * 2);
   h->stats = c.take<float>(16);
   h->ones = c.take<float>(B);
@@ -384,7 +385,7 @@ void fwd_probs(const dsact_handle* h, int ch, int l, const float* x0, int ldx0, 
     t.ldp = l == 0 ? ldx0 : d.in[l];
     t.Q = base + d.w_off[l] + (size_t)b * hb * kb;
     t.ldq = kb;
-    if (l == 0 && net != N_POL && net != N_POLT) {
+    if (l == 0 && net != N_POL && net != N_POLT && h->use_w1p) {
       // Q nets: rows of F+A floats are not 16-byte aligned -> use the zero-padded copy (k_gather repack)
       const int slot = net == N_Q1 ? 0 : net == N_Q2 ? 1 : net == N_Q1T ? 2 : 3;
       t.Q = h->W1p[slot];
@@ -479,7 +480,8 @@ int build_tasks(dsact_handle* h) {
       memset(&t, 0, sizeof(t));
       t.P = h->dZ[kDzSlot[ch]][0]; t.ldp = d.out[0];
       if (ch == C_PI) { t.Q = net_params(h, net) + d.w_off[0]; t.ldq = d.in[0]; }
-      else { t.Q = h->W1p[ch == C_Q1C ? 0 : 1]; t.ldq = h->ldx; }  // this step's pre-update copy
+      else if (h->use_w1p) { t.Q = h->W1p[ch == C_Q1C ? 0 : 1]; t.ldq = h->ldx; }  // this step's pre-update copy
+      else { t.Q = net_params(h, net) + d.w_off[0]; t.ldq = d.in[0]; }              // (dfeat_q runs before the critics' update)
       t.C0 = h->dfeat[ch == C_Q1C ? S_Q1 : ch == C_Q2C ? S_Q2 : S_PI]; t.ldc = h->F;
       t.M = B; t.N = h->F; t.K = d.out[0];
       stage_add(ch == C_PI ? h->dfeat_pi : h->dfeat_q, t);
@@ -907,10 +909,11 @@ RepackArgs repack_args(const dsact_handle* h, int n_blocks) {
   rp.rows = h->w[0]; rp.K = h->F + h->A; rp.ldp = h->ldx;
   rp.n_blocks = n_blocks;
   rp.w1at[0] = h->W1aT[0]; rp.w1at[1] = h->W1aT[1]; rp.O = h->F; rp.A = h->A;
+  rp.skip_pad = h->use_w1p ? 0 : 1;
   return rp;
 }
 int repack_blocks(const dsact_handle* h) {
-  const int total4 = 4 * h->w[0] * h->ldx;
+  const int total4 = h->use_w1p ? 4 * h->w[0] * h->ldx : 2 * 32 * h->w[0];
   int nb = (total4 + kThreads * 8 - 1) / (kThreads * 8);
   return nb < 1 ? 1 : (nb > 256 ? 256 : nb);
 }
@@ -1266,6 +1269,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   for (int l = 0; l < h->L; ++l)
     if (h->w[l] > kMaxWidth) return fail(h, DSACT_E_INVALID, "activation row width %d exceeds %d", h->w[l], kMaxWidth);
   h->ldx = (h->F + h->A + 3) & ~3;
+  h->use_w1p = (size_t)4 * nblk * cfg->hidden[0] * h->ldx <= ((size_t)4 << 20);
   build_net(h->qd, h->F + h->A, cfg->hidden, h->L, 2, nblk, h->n_conv, h->cg);
   build_net(h->pd, h->F, cfg->hidden, h->L, 2 * h->A, nblk, h->n_conv, h->cg);
   h->n_q = h->qd.count; h->n_pi = h->pd.count;

@@ -206,10 +206,11 @@ struct RepackArgs {
   int n_blocks;        // blocks assigned to the repack (0 = none)
   float* w1at[2];      // action columns of q1 / q2's first layer, TRANSPOSED [32 (j, zero padded)][rows]
   int O, A;            //   (k_heads_bwd forms dL/d new_act from them with coalesced row loads)
+  int skip_pad;        // 1: wide first layers (e.g. 3136 conv features): no padded copies, the stages read the arena rows
 };
 __device__ void repack_rows(const RepackArgs& rp, int blk, int tid) {
   const int per_net = rp.rows * rp.ldp;
-  const int total = 4 * per_net;
+  const int total = rp.skip_pad ? 0 : 4 * per_net;
   for (int e = blk * kThreads + tid; e < total; e += rp.n_blocks * kThreads) {
     const int net = e / per_net, rem = e - net * per_net;
     const int row = rem / rp.ldp, col = rem - row * rp.ldp;
