@@ -400,7 +400,6 @@ void fwd_probs(const dsact_handle* h, int ch, int l, const float* x0, int ldx0, 
   }
 }
 
-int build_conv_tasks(dsact_handle* h);
 
 int build_tasks(dsact_handle* h) {
   const int L = h->L, B = h->B;
