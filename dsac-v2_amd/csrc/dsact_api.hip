@@ -1101,6 +1101,13 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
     return DSACT_OK;
   }
 actor_part:
+  // The critics' weight-gradient tiles ride along in the under-filled launches of the actor chain: heads_bwd (B/4 row
+  // blocks) and the policy-backward stages (one problem each). Spread evenly so that each launch stays within one
+  // round of workgroups (64 + 177 <= 256 CUs at batch 256; two carriers made it 64 + 265).
+  const int n_carriers = (int)h->bwdpi.size() + 1;
+  const int crit_tiles = h->dw_off[2] - h->dw_off[0];
+  int ride_hb = 0;
+  if (phase == 0 && !(h->use_fork && !h->profiling) && getenv("DSACT_NO_HB_RIDE") == nullptr) ride_hb = crit_tiles / n_carriers;
   if (h->use_fork && !h->profiling) {
     HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
@@ -1121,7 +1128,12 @@ actor_part:
     a.part_loss = h->part_loss; a.n_part = B; a.target_entropy = -(float)A;
     a.grad_log_alpha = h->grads + h->n_online - 1;
     a.timeline = tl_for(h, "heads_bwd");
-#define CALL_HBWD(N) TRY(launch(h, "heads_bwd", k_heads_bwd<N>, dim3((B + 3) / 4), dim3(kThreads), 0, a))
+    a.n_row_blocks = (B + 3) / 4;
+    a.extra = h->d_tiles; a.n_extra = 0;
+    a.fo = fused_opt(h, fused);
+    if (ride_hb > 0) { a.extra = h->d_tiles + h->dw_off[0]; a.n_extra = ride_hb; }
+    const size_t hb_lds = a.n_extra ? tile_lds_bytes(dw_k(h)) : 0;
+#define CALL_HBWD(N) TRY(launch(h, "heads_bwd", k_heads_bwd<N>, dim3(a.n_row_blocks + a.n_extra), dim3(kThreads), hb_lds, a))
     NCH_DISPATCH(a.WL, CALL_HBWD);
   }
   const size_t np = h->bwdpi.size();
@@ -1143,20 +1155,24 @@ actor_part:
     TRY(sum_parts(h, (size_t)h->nq * h->n_q, h->n_online - 1));
     return DSACT_OK;
   }
-  // unforked: the critics' tiles ride along in the under-filled policy-backward launches
-  for (size_t i = 0; i < np; ++i) {
-    int x0 = 0, x1 = 0;
-    if (i == 0) { x0 = h->dw_off[0]; x1 = np > 1 ? h->dw_off[1] : h->dw_off[2]; }
-    else if (i == 1) { x0 = h->dw_off[1]; x1 = h->dw_off[2]; }
-    TRY(run_stage(h, h->bwdpi[i], x0, x1, fused));
+  // unforked: the rest of the critics' tiles ride along in the policy-backward launches, evenly
+  {
+    int x = h->dw_off[0] + ride_hb;
+    for (size_t i = 0; i < np; ++i) {
+      const int left = h->dw_off[2] - x;
+      const int take = i + 1 == np ? left : left / (int)(np - i);
+      TRY(run_stage(h, h->bwdpi[i], x, x + take, fused));
+      x += take;
+    }
+    if (np == 0 && ride_hb) { /* no policy-backward stage: the final launch takes what heads_bwd did not */ }
   }
   if (h->cnn) TRY(run_stage(h, h->dfeat_pi));  // needs the policy's W0 BEFORE the fused Adam of the next launch
   // policy weight gradients (+ the critics' when there was no launch to ride in) + close of the update
   if (h->dw_chunks == 1) {
-    TRY(run_dw(h, np ? h->dw_off[2] : h->dw_off[0], h->dw_off[3], fused, fused));
+    TRY(run_dw(h, np ? h->dw_off[2] : h->dw_off[0] + ride_hb, h->dw_off[3], fused, fused));
     if (h->cnn) TRY(enqueue_conv_backward(h, 3, fused));
   } else {
-    TRY(run_dw(h, np ? h->dw_off[2] : h->dw_off[0], h->dw_off[3], false, false));
+    TRY(run_dw(h, np ? h->dw_off[2] : h->dw_off[0] + ride_hb, h->dw_off[3], false, false));
     if (h->cnn) TRY(enqueue_conv_backward(h, 3, false));
     if (fused) TRY(enqueue_adam(h, true));
     else TRY(sum_parts(h, 0, h->n_online - 1));
@@ -1327,6 +1343,10 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, true, EPI_MULG, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, true, EPI_MULG>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage_table, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_heads_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_heads_bwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_heads_bwd<3>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_heads_bwd<4>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, true, EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_conv_dw<3>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<false, EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));

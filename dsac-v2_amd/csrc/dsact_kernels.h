@@ -1333,11 +1333,21 @@ struct HeadsBwdArgs {
   const float* act_scale; float lo_ls, hi_ls;
   const float* part_loss; int n_part; float target_entropy; float* grad_log_alpha;
   long long* timeline;
+  // ride-along weight-gradient tiles of the critics (blocks >= n_row_blocks): this launch has only B/4 row blocks, and
+  // the critics' dW is complete (and their weights free) as soon as the critic backward is
+  const GemmProb* extra; int n_extra; int n_row_blocks;
+  FusedOpt fo;
 };
 
 template <int NCH>
 __global__ void __launch_bounds__(kThreads) k_heads_bwd(HeadsBwdArgs a) {
   __shared__ float sh_dout[4][64];
+  extern __shared__ __attribute__((aligned(16))) float tile_lds[];
+  if ((int)blockIdx.x >= a.n_row_blocks) {
+    const GemmProb g = a.extra[blockIdx.x - a.n_row_blocks];
+    run_tile<true, true, EPI_STORE>(g, g.tiles_n, g.tile_end, tile_lds, nullptr, 0, &a.fo);
+    return;
+  }
   TL_DECL
   TL_STAMP();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
