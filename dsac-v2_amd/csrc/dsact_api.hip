@@ -124,6 +124,8 @@ struct dsact_handle {
   GemmProb* d_tiles = nullptr;   // per-tile table of the weight/bias-gradient tiles: [q1 | q2 | policy]
   int n_dw_tiles = 0;
   int dw_off[4] = {0, 0, 0, 0};  // start of q1, q2, policy tiles, end
+  int dw_pol_rest = 0;           // the policy's OUTPUT-layer tiles come first in its range ([dw_off[2], dw_pol_rest)): they
+                                 // only need heads_bwd's results and may ride along in the policy-backward launches
   // split-K weight gradients at batch > 448: dw_chunks chunks of 256 samples, one partial gradient arena each
   int dw_chunks = 1;
   float* dw_parts = nullptr;     // [dw_chunks][dw_part_stride]
@@ -515,7 +517,10 @@ int build_tasks(dsact_handle* h) {
     const NetDesc& d = net_desc(h, net);
     float* g = net_grads(h, net);
     const int slot = kDzSlot[ch];
-    for (int l = 0; l <= L; ++l) {
+    for (int li = 0; li <= L; ++li) {
+      // policy: output layer first (see dw_pol_rest); critics: layer order
+      const int l = ch == C_PI ? (li == 0 ? L : li - 1) : li;
+      if (ch == C_PI && li == 1) h->dw_pol_rest = (int)tiles.size();
       const float* dz; int lddz;
       if (l < L) { dz = h->dZ[slot][l]; lddz = d.out[l]; }
       else if (ch == C_PI) { dz = h->dout_pi; lddz = 2 * h->A; }
@@ -914,7 +919,10 @@ RepackArgs repack_args(const dsact_handle* h, int n_blocks) {
 int repack_blocks(const dsact_handle* h) {
   const int total4 = h->use_w1p ? 4 * h->w[0] * h->ldx : 2 * 32 * h->w[0];
   int nb = (total4 + kThreads * 8 - 1) / (kThreads * 8);
-  return nb < 1 ? 1 : (nb > 256 ? 256 : nb);
+  // the repack blocks share the gather launch: keep the launch within one round of workgroups (256 CUs)
+  const int gather_blocks = h->cnn ? 0 : (h->B + 3) / 4;
+  const int cap = gather_blocks < 224 ? 256 - gather_blocks : 32;
+  return nb < 1 ? 1 : (nb > cap ? cap : nb);
 }
 
 int enqueue_prologue(dsact_handle* h, int use_dev, long long it, int advance, int fill_noise);
@@ -1106,8 +1114,13 @@ actor_part:
   // round of workgroups (64 + 177 <= 256 CUs at batch 256; two carriers made it 64 + 265).
   const int n_carriers = (int)h->bwdpi.size() + 1;
   const int crit_tiles = h->dw_off[2] - h->dw_off[0];
+  // tiles that may ride: the critics' + (behind heads_bwd only) the policy's output layer
+  const int ride_end = h->bwdpi.empty() ? h->dw_off[2] : h->dw_pol_rest;
   int ride_hb = 0;
-  if (phase == 0 && !(h->use_fork && !h->profiling) && getenv("DSACT_NO_HB_RIDE") == nullptr) ride_hb = crit_tiles / n_carriers;
+  if (phase == 0 && !(h->use_fork && !h->profiling) && getenv("DSACT_NO_HB_RIDE") == nullptr) {
+    ride_hb = (ride_end - h->dw_off[0]) / n_carriers;
+    if (ride_hb > crit_tiles) ride_hb = crit_tiles;
+  }
   if (h->use_fork && !h->profiling) {
     HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
@@ -1159,7 +1172,7 @@ actor_part:
   {
     int x = h->dw_off[0] + ride_hb;
     for (size_t i = 0; i < np; ++i) {
-      const int left = h->dw_off[2] - x;
+      const int left = ride_end - x;
       const int take = i + 1 == np ? left : left / (int)(np - i);
       TRY(run_stage(h, h->bwdpi[i], x, x + take, fused));
       x += take;
@@ -1169,10 +1182,10 @@ actor_part:
   if (h->cnn) TRY(run_stage(h, h->dfeat_pi));  // needs the policy's W0 BEFORE the fused Adam of the next launch
   // policy weight gradients (+ the critics' when there was no launch to ride in) + close of the update
   if (h->dw_chunks == 1) {
-    TRY(run_dw(h, np ? h->dw_off[2] : h->dw_off[0] + ride_hb, h->dw_off[3], fused, fused));
+    TRY(run_dw(h, np ? ride_end : h->dw_off[0] + ride_hb, h->dw_off[3], fused, fused));
     if (h->cnn) TRY(enqueue_conv_backward(h, 3, fused));
   } else {
-    TRY(run_dw(h, np ? h->dw_off[2] : h->dw_off[0] + ride_hb, h->dw_off[3], false, false));
+    TRY(run_dw(h, np ? ride_end : h->dw_off[0] + ride_hb, h->dw_off[3], false, false));
     if (h->cnn) TRY(enqueue_conv_backward(h, 3, false));
     if (fused) TRY(enqueue_adam(h, true));
     else TRY(sum_parts(h, 0, h->n_online - 1));
