@@ -173,3 +173,14 @@ def test_v1_layout_matches_the_v1_oracle():
     assert lay.n_online == orc.flat_params().numel() and lay.n_target == orc.flat_targets().numel()
     assert list(lay.state_dict_keys().keys()) == list(orc.state_dict().keys())
     assert lay.online_nets == ("q", "policy")
+
+
+def test_bench_helpers():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    for steps, warm in ((20000, 2000), (4000, 400), (10, 2), (400, 40), (7000, 500), (2, 0)):
+        g = bench.graph_steps(steps, warm)
+        assert g % 2 == 0 and 2 <= g <= 64 and steps % g == 0 and (warm % g == 0)
+    t = bench.pmc_traffic_forward_stage()
+    assert t is None or 1e6 < t < 5e7      # bytes per launch of the forward tile stage, from the committed PMC pass
