@@ -244,6 +244,39 @@ def cpu_baseline(hidden, budget_s=12.0):
                       % (steps, "x".join(map(str, hidden)), dt, torch.__version__, threads, os.cpu_count())}
 
 
+def boundary_rates(alg, n):
+    """The drop-in boundary when the minibatch is NOT in the HIP ring: `local_update(data, it)` with the reference
+    ReplayBuffer's CPU tensors (PCIe-inclusive: pageable host -> HBM every step) and with the `.cuda()` tensors the
+    reference trainer makes of them (training/trainer.py:72-74; device-to-device). Eager launches, host-synchronous
+    staging -- reported beside the headline, never as `value`."""
+    import numpy as np
+    import torch
+
+    e = alg.engine
+    rng = np.random.default_rng(5)
+    O, A, Bt = e.obs_dim, e.act_dim, e.batch
+    cpu = {"obs": torch.as_tensor(rng.standard_normal((Bt, O), dtype=np.float32)),
+           "obs2": torch.as_tensor(rng.standard_normal((Bt, O), dtype=np.float32)),
+           "act": torch.as_tensor(rng.uniform(-0.4, 0.4, (Bt, A)).astype(np.float32)),
+           "rew": torch.as_tensor(rng.standard_normal(Bt, dtype=np.float32)),
+           "done": torch.zeros(Bt)}
+    res = {}
+    for name, d in (("host_batch", cpu), ("cuda_batch", {k: v.cuda(e.device_index) for k, v in cpu.items()})):
+        for it in range(20):
+            alg.local_update(d, it)
+        e.sync()
+        t0 = time.perf_counter()
+        for it in range(n):
+            alg.local_update(d, it)
+        e.sync()
+        w = time.perf_counter() - t0
+        res[name] = {"value": n / w, "unit": "steps/s", "ms_per_step": 1000.0 * w / n}
+    res["bytes_per_step"] = 4 * Bt * (2 * O + A + 2)
+    res["note"] = ("local_update(data) with a minibatch from outside the HIP ring, %d eager updates each: host_batch = "
+                   "CPU tensors (PCIe-inclusive), cuda_batch = CUDA tensors; not the headline value" % n)
+    return res
+
+
 def graph_steps(steps, warmup, cap=64):
     """updates captured per hipGraph: the largest even divisor (<= cap) of both the timed and the warm-up step count.
     Measured: 2 -> 9,248, 8 -> 9,416, 40 -> 9,473 steps/s (the gap between graph launches amortises)."""
@@ -432,6 +465,11 @@ def main():
         wf, _ = measure(alg, steps, warmup, flags=1)
         out["fast"] = {"value": steps / wf, "unit": "steps/s", "ms_per_step": 1000.0 * wf / steps,
                        "note": "DSACT_F_SKIP_ACTOR_ON_OFF_ITERS; not the headline value"}
+    if rank == 0 and not use_dp and not args.no_alt and args.batch == B:
+        try:
+            out["boundary"] = boundary_rates(alg, min(steps, 600))
+        except Exception as ex:  # informational leg
+            out["boundary_error"] = repr(ex)
     if not use_dp and not args.no_alt and args.batch == B:
         alt_hidden = [256, 256] if hidden != [256, 256] else [256, 256, 256]
         del alg

@@ -1653,24 +1653,24 @@ int dsact_load_batch(dsact_handle* h, const float* obs, const float* act, const 
   if (h->cnn) {
     const size_t R = h->Brows;
     if (!h->stage_img) HIPCHK(h, hipMalloc(&h->stage_img, 2 * R * O * sizeof(float)));
-    HIPCHK(h, hipMemcpyAsync(h->stage_img, obs, B * O * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(h->stage_img + R * O, obs2, B * O * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->stage_img, obs, B * O * 4, hipMemcpyDefault, s));
+    HIPCHK(h, hipMemcpyAsync(h->stage_img + R * O, obs2, B * O * 4, hipMemcpyDefault, s));
     TRY(enqueue_gather_img(h, h->stage_img, h->stage_img + R * O, h->idx_iota, 1, 0, false, h->img[0], h->img[1], h->B));
-    HIPCHK(h, hipMemcpy2DAsync(h->Xc[C_Q1C] + h->F, ld * 4, act, A * 4, A * 4, B, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpy2DAsync(h->Xc[C_Q2C] + h->F, ld * 4, act, A * 4, A * 4, B, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(h->rew, rew, B * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(h->done, done, B * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpy2DAsync(h->Xc[C_Q1C] + h->F, ld * 4, act, A * 4, A * 4, B, hipMemcpyDefault, s));
+    HIPCHK(h, hipMemcpy2DAsync(h->Xc[C_Q2C] + h->F, ld * 4, act, A * 4, A * 4, B, hipMemcpyDefault, s));
+    HIPCHK(h, hipMemcpyAsync(h->rew, rew, B * 4, hipMemcpyDefault, s));
+    HIPCHK(h, hipMemcpyAsync(h->done, done, B * 4, hipMemcpyDefault, s));
     HIPCHK(h, hipStreamSynchronize(s));
     h->have_batch = true;
     return DSACT_OK;
   }
-  HIPCHK(h, hipMemcpy2DAsync(h->X0, ld * 4, obs, O * 4, O * 4, B, hipMemcpyHostToDevice, s));
-  HIPCHK(h, hipMemcpy2DAsync(h->XP, ld * 4, obs, O * 4, O * 4, B, hipMemcpyHostToDevice, s));
-  HIPCHK(h, hipMemcpy2DAsync(h->X2, ld * 4, obs2, O * 4, O * 4, B, hipMemcpyHostToDevice, s));
-  HIPCHK(h, hipMemcpy2DAsync(h->X0 + O, ld * 4, act, A * 4, A * 4, B, hipMemcpyHostToDevice, s));
-  HIPCHK(h, hipMemcpyAsync(h->rew, rew, B * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(h, hipMemcpyAsync(h->done, done, B * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(h, hipStreamSynchronize(s));  // host buffers are the caller's
+  HIPCHK(h, hipMemcpy2DAsync(h->X0, ld * 4, obs, O * 4, O * 4, B, hipMemcpyDefault, s));
+  HIPCHK(h, hipMemcpy2DAsync(h->XP, ld * 4, h->X0, ld * 4, O * 4, B, hipMemcpyDeviceToDevice, s));  // obs crosses the bus once
+  HIPCHK(h, hipMemcpy2DAsync(h->X2, ld * 4, obs2, O * 4, O * 4, B, hipMemcpyDefault, s));
+  HIPCHK(h, hipMemcpy2DAsync(h->X0 + O, ld * 4, act, A * 4, A * 4, B, hipMemcpyDefault, s));
+  HIPCHK(h, hipMemcpyAsync(h->rew, rew, B * 4, hipMemcpyDefault, s));
+  HIPCHK(h, hipMemcpyAsync(h->done, done, B * 4, hipMemcpyDefault, s));
+  HIPCHK(h, hipStreamSynchronize(s));  // the source buffers are the caller's
   h->have_batch = true;
   return DSACT_OK;
 }

@@ -482,8 +482,9 @@ class DSAC_V2_HIP:
     def _stage(self, data):
         if isinstance(data, HipBatch) and data.engine is self.engine:
             return  # already in HBM (HipReplayBuffer fast path)
-        g = lambda k: data[k].detach().cpu().numpy()
-        self.engine.load_batch(g("obs"), g("act"), g("rew"), g("obs2"), g("done"))
+        # CPU tensors (reference ReplayBuffer.sample_batch) or the CUDA tensors the reference trainer makes of them
+        # (training/trainer.py:72-74); CUDA ones are copied device-to-device
+        self.engine.load_batch(data["obs"], data["act"], data["rew"], data["obs2"], data["done"])
 
     def _noise(self):
         if not self.strict_rng:

@@ -192,11 +192,28 @@ class DsactEngine:
             out["logp"] = lp
         return out
 
+    def _src(self, a, n):
+        """float* for dsact_load_batch: a CUDA tensor on this engine's GPU is passed by device address (no trip
+        through the host), anything else as a contiguous host float32 array. Returns (pointer, keep-alive)."""
+        torch = self.torch
+        if isinstance(a, torch.Tensor) and a.is_cuda and a.device.index == self.device_index:
+            t = a.detach().to(torch.float32).contiguous()
+            assert t.numel() == n, (tuple(t.shape), n)
+            return C.cast(C.c_void_p(t.data_ptr()), _ffi._FP), t
+        if isinstance(a, torch.Tensor):
+            a = a.detach().cpu().numpy()
+        a = _f32(a)
+        assert a.size == n, (a.shape, n)
+        return _ffi.fptr(a), a
+
     def load_batch(self, obs, act, rew, obs2, done):
-        obs, act, rew, obs2, done = _f32(obs), _f32(act), _f32(rew), _f32(obs2), _f32(done)
-        assert obs.size == self.batch * self.obs_dim and obs2.size == obs.size, obs.shape
-        self._chk(self._lib.dsact_load_batch(self._h, _ffi.fptr(obs), _ffi.fptr(act), _ffi.fptr(rew),
-                                             _ffi.fptr(obs2), _ffi.fptr(done)))
+        """Stage a minibatch that lives outside the HIP ring: numpy / CPU tensors or CUDA tensors (mixed is fine)."""
+        torch, B = self.torch, self.batch
+        srcs = [self._src(obs, B * self.obs_dim), self._src(act, B * self.act_dim), self._src(rew, B),
+                self._src(obs2, B * self.obs_dim), self._src(done, B)]
+        if any(isinstance(k, torch.Tensor) for _, k in srcs):
+            torch.cuda.current_stream(self.device).synchronize()   # the producers of the CUDA sources have finished
+        self._chk(self._lib.dsact_load_batch(self._h, *[p for p, _ in srcs]))
 
     def upload_index_table(self, idx):
         idx = np.ascontiguousarray(np.asarray(idx, dtype=np.int64))

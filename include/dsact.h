@@ -136,7 +136,10 @@ int dsact_gather(dsact_handle* h, const int64_t* idx_host, int32_t batch);
  * the ring (it is not part of the staging area the update reads). */
 int dsact_read_batch(dsact_handle* h, float* obs, float* act, float* rew, float* obs2, float* done,
                      float* logp);
-/* stage a host minibatch produced elsewhere (reference ReplayBuffer + new algorithm mix) */
+/* stage a minibatch produced elsewhere (reference ReplayBuffer + new algorithm mix). Each pointer may be a HOST
+ * array (the reference's CPU batch) or a DEVICE array on the handle's GPU (the reference trainer's `.cuda()`
+ * tensors, training/trainer.py:72-74: no round trip through the host); the copies are issued on the handle's
+ * stream and completed before the call returns, so the caller must have finished writing the sources. */
 int dsact_load_batch(dsact_handle* h, const float* obs, const float* act, const float* rew,
                      const float* obs2, const float* done);
 /* index table for graph replay: rows x batch indices, row r is consumed by the r-th replayed step */

@@ -23,4 +23,6 @@ tail -2 $OUT/bench.log
 echo "== rocprof" | tee -a $OUT/steps.log
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-alt > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?" | tee -a $OUT/steps.log
 ls -R $OUT/prof | head -20
+f=$(find $OUT/prof -name "*kernel_trace.csv" | head -1)
+[ -n "$f" ] && python scripts/step_trace.py "$f" 1000 > $OUT/step_trace.txt
 fi

@@ -221,3 +221,24 @@ def test_cnn_replay_rows_bit_exact_and_policy_forward():
     lg = alg.networks.policy(obs)
     assert lg.shape == want.shape
     assert float((lg.cpu() - want).abs().max()) < 2e-5
+
+
+def test_cnn_load_batch_from_cuda_tensors_equals_host_staging():
+    """dsact_load_batch with device pointers (the reference trainer's `.cuda()` image batch) stages the same
+    pixel-major images and action columns as the host path."""
+    from oracle.dsact_oracle_cnn import cnn_config, synth_image_batch
+    from dsact.engine import DsactEngine
+
+    cfg = cnn_config((3, 96, 96), 3, "type_2")
+    B = 8
+    data = synth_image_batch(cfg, B, seed=3)
+    outs = []
+    for on_gpu in (False, True):
+        e = DsactEngine(cfg["obs_dim"], 3, list(cfg["hidden"]), B, conv_type="type_2")
+        src = {k: (v.cuda() if on_gpu else v.numpy()) for k, v in data.items()}
+        e.load_batch(src["obs"], src["act"], src["rew"], src["obs2"], src["done"])
+        outs.append(e.read_batch(with_logp=False))
+        e.close()
+    for k in ("obs", "act", "rew", "obs2", "done"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+        assert np.array_equal(outs[0][k].reshape(-1), data[k].numpy().reshape(-1)), k

@@ -670,3 +670,31 @@ def test_full_size_replay_gather_and_determinism():
         torch.cuda.empty_cache()
     assert torch.equal(outs[0][0], outs[1][0])
     assert outs[0][1] == outs[1][1]
+
+
+def test_local_update_takes_cuda_tensors_like_the_reference_trainer():
+    """The reference trainer hands `local_update` per-key `.cuda()` tensors (training/trainer.py:72-74).
+    dsact_load_batch takes them by device address: the staged rows are bit-identical to staging the CPU batch,
+    and so is the update that follows (mixed CPU/CUDA dicts included)."""
+    O, A, hid, B = 23, 5, (64, 96, 64), 64
+    a_cpu, _ = make_pair(O, A, hid, B, seed=4)
+    a_gpu, _ = make_pair(O, A, hid, B, seed=4)
+    a_mix, _ = make_pair(O, A, hid, B, seed=4)
+    rng = np.random.default_rng(8)
+    for it in range(3):
+        data = synth_batch(rng, B, O, A, p_done=0.1)
+        on_gpu = {k: v.cuda() for k, v in data.items()}
+        mixed = {k: (v.cuda() if k in ("obs", "rew") else v) for k, v in data.items()}
+        for alg, d in ((a_cpu, data), (a_gpu, on_gpu), (a_mix, mixed)):
+            torch.manual_seed(100 + it)     # strict_rng: the same 8 host draws for each
+            alg.local_update(d, it)
+        want = a_cpu.engine.read_batch(with_logp=False)
+        for alg in (a_gpu, a_mix):
+            got = alg.engine.read_batch(with_logp=False)
+            for k in ("obs", "act", "rew", "obs2", "done"):
+                assert np.array_equal(got[k], want[k]), k
+    for alg in (a_cpu, a_gpu, a_mix):
+        alg.engine.sync()
+    for name in ("online", "target", "adam_m", "adam_v"):
+        assert torch.equal(getattr(a_cpu.engine, name), getattr(a_gpu.engine, name)), name
+        assert torch.equal(getattr(a_cpu.engine, name), getattr(a_mix.engine, name)), name
