@@ -411,7 +411,7 @@ def main():
                         % ("x".join(map(str, hidden)), args.batch, args.replay_rows),
             "global_batch": args.batch * world, "parallelism": "dp%d" % world, "hidden": hidden,
             "noise": "device Philox4x32-10", "mode": "fast (discarded actor backward skipped)" if args.fast else "strict (every gradient the reference computes)",
-            "launch": ("hipGraph (%d steps/graph)" % graph_steps(steps, warmup)) if not use_dp else ("eager + RCCL all-reduce (%s)" % ("critics' segment overlapped with the actor backward" if dp.overlap else "single")),
+            "launch": ("hipGraph (%d steps/graph; the next update's gather rides in the loss launch)" % graph_steps(steps, warmup)) if not use_dp else ("eager + RCCL all-reduce (%s)" % ("critics' segment overlapped with the actor backward" if dp.overlap else "single")),
             "unit_note": "value = synchronized updates/s x n_gpus (each rank contributes one batch-256 gradient per update)",
         },
         "finite_stats": finite,

@@ -132,6 +132,21 @@ struct dsact_handle {
   size_t dw_part_stride = 0;
   std::vector<Stage> fwd1, fwd2, bwdq, bwdq_critic, bwdpi, actf;
   Stage dfeat_q, dfeat_pi;
+  // Second batch set (MLP nets): graph replays stage update s+1's minibatch while update s still reads its own
+  // (the gather rides in the loss launch, see RideArgs). `alt` holds the set that is NOT selected; select_set()
+  // swaps the two, so every enqueue function keeps reading h->X0, h->fwd1, h->d_tiles ... of the selected set.
+  struct BatchSet {
+    float *X0 = nullptr, *XP = nullptr, *X2 = nullptr, *rew = nullptr, *done = nullptr;
+    float *eps_new = nullptr, *eps_2 = nullptr, *z5 = nullptr, *z6 = nullptr;
+    float* Xc[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float* W1aT[2] = {nullptr, nullptr};
+    std::vector<Stage> fwd1, fwd2;
+    GemmProb* d_tiles = nullptr;
+  } alt;
+  char* alt_ws = nullptr;
+  int cur_set = 0;             // 0 outside of graph capture
+  bool mirror_w0 = false;      // set while the merged-gather graph is being captured (see FusedOpt::mir_*)
+  bool merged_graph = false;   // the captured graph uses the merged-gather flow
   // replay ring
   long long cap = 0, ptr = 0, size = 0;
   float *rb_obs = nullptr, *rb_obs2 = nullptr, *rb_act = nullptr, *rb_rew = nullptr, *rb_done = nullptr, *rb_logp = nullptr;
@@ -403,6 +418,43 @@ void fwd_probs(const dsact_handle* h, int ch, int l, const float* x0, int ldx0, 
 }
 
 
+void select_set(dsact_handle* h, int set) {
+  if (set == h->cur_set) return;
+  dsact_handle::BatchSet& a = h->alt;
+  std::swap(h->X0, a.X0); std::swap(h->XP, a.XP); std::swap(h->X2, a.X2); std::swap(h->rew, a.rew); std::swap(h->done, a.done);
+  std::swap(h->eps_new, a.eps_new); std::swap(h->eps_2, a.eps_2); std::swap(h->z5, a.z5); std::swap(h->z6, a.z6);
+  for (int i = 0; i < 8; ++i) std::swap(h->Xc[i], a.Xc[i]);
+  for (int i = 0; i < 2; ++i) std::swap(h->W1aT[i], a.W1aT[i]);
+  h->fwd1.swap(a.fwd1); h->fwd2.swap(a.fwd2);
+  std::swap(h->d_tiles, a.d_tiles);
+  h->cur_set = set;
+}
+
+// the second batch set's buffers (MLP nets only); zeroed like the workspace
+int alloc_alt_set(dsact_handle* h) {
+  if (h->cnn || h->alt_ws) return DSACT_OK;
+  const size_t B = h->B;
+  const int A = h->A;
+  for (int pass = 0; pass < 2; ++pass) {
+    Carver c;
+    c.base = pass ? h->alt_ws : nullptr;
+    dsact_handle::BatchSet& a = h->alt;
+    a.X0 = c.take<float>(B * h->ldx); a.XP = c.take<float>(B * h->ldx); a.X2 = c.take<float>(B * h->ldx);
+    a.rew = c.take<float>(B); a.done = c.take<float>(B);
+    a.eps_new = c.take<float>(B * A); a.eps_2 = c.take<float>(B * A); a.z5 = c.take<float>(B); a.z6 = c.take<float>(B);
+    a.W1aT[0] = c.take<float>((size_t)32 * h->w[0]); a.W1aT[1] = c.take<float>((size_t)32 * h->w[0]);
+    if (!pass) {
+      HIPCHK(h, hipMalloc((void**)&h->alt_ws, c.off + 256));
+      HIPCHK(h, hipMemset(h->alt_ws, 0, c.off + 256));
+    }
+  }
+  dsact_handle::BatchSet& a = h->alt;
+  a.Xc[C_PI] = a.Xc[C_Q1C] = a.Xc[C_Q2C] = a.X0;
+  a.Xc[C_PIT] = a.Xc[C_Q1T] = a.Xc[C_Q2T] = a.X2;
+  a.Xc[C_Q1P] = a.Xc[C_Q2P] = a.XP;
+  return DSACT_OK;
+}
+
 int build_tasks(dsact_handle* h) {
   const int L = h->L, B = h->B;
   auto fresh = [](const std::string& name, int kind) {
@@ -575,6 +627,17 @@ FusedOpt fused_opt(const dsact_handle* h, bool enable) {
   f.polyak = (float)polyak;
   f.one_minus_polyak = (float)(1.0 - polyak);
   f.auto_alpha = h->cfg.auto_alpha;
+  if (h->mirror_w0 && f.st) {
+    // merged-gather graph replays: no per-step repack -- the first-layer tiles of the Q nets keep the copies fresh
+    const int on[2] = {N_Q1, N_Q2};
+    f.mir_n = h->nq;
+    f.mir_ldp = h->ldx; f.mir_O = h->F; f.mir_A = h->A; f.mir_rows = h->w[0];
+    for (int i = 0; i < h->nq; ++i) {
+      f.mir_lo[i] = (long long)(net_grads(h, on[i]) - h->grads) + (long long)h->qd.w_off[0];
+      f.mir_w[i] = h->W1p[i]; f.mir_wt[i] = h->W1p[2 + i];
+      f.mir_at[i] = h->alt.W1aT[i];   // the NEXT update's copy (this one is being read by k_heads_bwd)
+    }
+  }
   return f;
 }
 
@@ -927,21 +990,31 @@ int repack_blocks(const dsact_handle* h) {
 
 int enqueue_prologue(dsact_handle* h, int use_dev, long long it, int advance, int fill_noise);
 
-int enqueue_gather(dsact_handle* h, const int* table, int rows, int use_dev, long long it, int advance) {
+// gather arguments of the SELECTED batch set (no repack blocks)
+GatherArgs gather_args(const dsact_handle* h, const int* table, int rows, int use_dev, long long it, int advance);
+
+int enqueue_gather(dsact_handle* h, const int* table, int rows, int use_dev, long long it, int advance, int bookkeeping = 1) {
   if (h->cnn) {
     // bookkeeping, device noise and the padded-weight repack ride in the same launch
     return enqueue_gather_img(h, h->rb_obs, h->rb_obs2, table, rows, use_dev, true, h->img[0], h->img[1], h->B,
                               use_dev ? -1 : it, advance);
   }
+  GatherArgs a = gather_args(h, table, rows, use_dev, it, advance);
+  a.bookkeeping = bookkeeping;
+  a.rp = repack_args(h, repack_blocks(h));
+  return launch(h, "gather", k_gather, dim3(a.n_gather_blocks + a.rp.n_blocks), dim3(kThreads), 0, a);
+}
+
+GatherArgs gather_args(const dsact_handle* h, const int* table, int rows, int use_dev, long long it, int advance) {
   GatherArgs a;
+  memset(&a, 0, sizeof(a));
   a.rb_obs = h->rb_obs; a.rb_obs2 = h->rb_obs2; a.rb_act = h->rb_act; a.rb_rew = h->rb_rew; a.rb_done = h->rb_done;
   a.idx_table = table; a.idx_rows = rows; a.use_dev = use_dev; a.host_it = it; a.host_row = 0;
   a.X0 = h->X0; a.XP = h->XP; a.X2 = h->X2; a.rew = h->rew; a.done = h->done;
   a.B = h->B; a.O = h->O; a.A = h->A; a.ldx = h->ldx;
   a.st = h->st; a.bookkeeping = 1; a.advance_counters = advance; a.hp = step_hyper(h); a.nz = noise_args(h);
   a.n_gather_blocks = (h->B + 3) / 4;
-  a.rp = repack_args(h, repack_blocks(h));
-  return launch(h, "gather", k_gather, dim3(a.n_gather_blocks + a.rp.n_blocks), dim3(kThreads), 0, a);
+  return a;
 }
 
 int enqueue_prologue(dsact_handle* h, int use_dev, long long it, int advance, int fill_noise) {
@@ -990,7 +1063,9 @@ int sum_parts_range(dsact_handle* h, size_t lo, size_t hi) {
 // 3 / 4 (data-parallel overlap, unfused): 3 = everything up to and including the critics' gradients (q1 | q2
 // segment of the arena final), 4 = actor part (policy | log_alpha | mean_std tail) -- the caller starts the
 // all-reduce of the first segment between the two
-int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 0) {
+// `ride` (graph replays with the merged gather): nullptr, or the riders of the loss launch -- this update's
+// bookkeeping and, when ride->n_gather > 0, the next update's gather into the other batch set
+int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 0, const RideArgs* ride = nullptr) {
   const int L = h->L, B = h->B, A = h->A;
   if (phase == 4) goto actor_part;
   if (phase != 2) {
@@ -1054,10 +1129,14 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
     a.part_loss = h->part_loss; a.grads_tail = h->grads + h->n_online;
     a.W = h->w[L - 1]; a.B = B; a.inv_B = 1.0f / (float)B;
     a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.gamma = h->cfg.gamma; a.td_bound = h->cfg.td_bound;
-#define CALL_LOSS1(N) TRY(launch(h, "loss", k_loss_v1<N>, dim3(h->n_loss_wg), dim3(kThreads), 0, a))
+    if (ride) a.ride = *ride;
+    a.ride.n_loss_blocks = h->n_loss_wg;
+    const int n_riders = ride ? ride->n_gather + (ride->bookkeeping ? 1 : 0) : 0;
+#define CALL_LOSS1(N) TRY(launch(h, "loss", k_loss_v1<N>, dim3(h->n_loss_wg + n_riders), dim3(kThreads), 0, a))
     NCH_DISPATCH(a.W, CALL_LOSS1);
   } else {
     LossArgs a;
+    memset(&a, 0, sizeof(a));
     const int chs[4] = {C_Q1T, C_Q2T, C_Q1P, C_Q2P};
     for (int i = 0; i < 4; ++i) {
       const int net = kChainNet[chs[i]];
@@ -1081,7 +1160,10 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
     a.std_sums = (h->use_std_sums || h->auto_std_sums) ? h->std_sums : nullptr;
     a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.gamma = h->cfg.gamma; a.tau_b = h->cfg.tau_b; a.one_minus_tau_b = (float)(1.0 - dec7(h->cfg.tau_b));
     a.timeline = tl_for(h, "loss");
-#define CALL_LOSS(N) TRY(launch(h, "loss", k_loss<N>, dim3(h->n_loss_wg), dim3(kThreads), 0, a))
+    if (ride) a.ride = *ride;
+    a.ride.n_loss_blocks = h->n_loss_wg;
+    const int n_riders = ride ? ride->n_gather + (ride->bookkeeping ? 1 : 0) : 0;
+#define CALL_LOSS(N) TRY(launch(h, "loss", k_loss<N>, dim3(h->n_loss_wg + n_riders), dim3(kThreads), 0, a))
     NCH_DISPATCH(a.W, CALL_LOSS);
   }
   if (!actor_backward) {
@@ -1384,6 +1466,8 @@ int dsact_destroy(dsact_handle* h) {
     if (h->h_idx_ev[i]) hipEventDestroy(h->h_idx_ev[i]);
   }
   if (h->d_tiles) hipFree(h->d_tiles);
+  if (h->alt.d_tiles) hipFree(h->alt.d_tiles);
+  if (h->alt_ws) hipFree(h->alt_ws);
   if (h->idx_table) hipFree(h->idx_table);
   if (h->stage_dev) hipFree(h->stage_dev);
   if (h->stage_img) hipFree(h->stage_img);
@@ -1427,7 +1511,15 @@ int dsact_bind_arenas(dsact_handle* h, float* online, float* target, float* adam
   HIPCHK(h, hipSetDevice(h->device));
   if (h->graph_exec) return fail(h, DSACT_E_STATE, "cannot rebind arenas after dsact_graph_build");
   h->online = online; h->target = target; h->adam_m = adam_m; h->adam_v = adam_v; h->grads = grads;
-  return build_tasks(h);
+  TRY(build_tasks(h));
+  if (!h->cnn) {   // the same task lists over the second batch set
+    TRY(alloc_alt_set(h));
+    select_set(h, 1);
+    int rc = build_tasks(h);
+    select_set(h, 0);
+    TRY(rc);
+  }
+  return DSACT_OK;
 }
 
 int dsact_set_action_limits(dsact_handle* h, const float* high, const float* low) {
@@ -1760,9 +1852,37 @@ int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) 
   h->profiling = false;
   if ((flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) && steps_per_graph % h->cfg.delay_update)
     return fail(h, DSACT_E_INVALID, "with DSACT_F_SKIP_ACTOR_ON_OFF_ITERS steps_per_graph must be a multiple of delay_update");
+  // Merged gather (MLP nets, fused single-launch-chain update): one gather launch opens the graph; every update's
+  // loss launch carries the bookkeeping and the NEXT update's gather into the other batch set; the per-step repack
+  // of the padded first-layer copies is done by the weight-gradient tiles themselves (FusedOpt::mir_*).
+  // Update s of n uses set (n-1-s)&1, so the last staged minibatch sits in set 0 like after eager updates.
+  const bool merged = !h->cnn && h->use_w1p && h->dw_chunks == 1 && !h->use_fork && !h->use_std_sums && h->alt_ws != nullptr &&
+                      getenv("DSACT_NO_MERGED_GATHER") == nullptr;
+  h->merged_graph = merged;
   HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
   int rc = DSACT_OK;
-  for (int s = 0; s < steps_per_graph && rc == DSACT_OK; ++s) rc = enqueue_graph_step(h, s, flags);
+  if (!merged) {
+    for (int s = 0; s < steps_per_graph && rc == DSACT_OK; ++s) rc = enqueue_graph_step(h, s, flags);
+  } else {
+    const int n = steps_per_graph;
+    h->mirror_w0 = true;
+    select_set(h, (n - 1) & 1);
+    rc = enqueue_gather(h, h->idx_table, h->idx_rows, 1, 0, 1, /*bookkeeping=*/0);
+    for (int s = 0; s < n && rc == DSACT_OK; ++s) {
+      const int set = (n - 1 - s) & 1;
+      RideArgs ride;
+      memset(&ride, 0, sizeof(ride));
+      select_set(h, set ^ 1);   // destination of the riding gather
+      ride.g = gather_args(h, h->idx_table, h->idx_rows, 1, 0, 1);
+      ride.n_gather = s + 1 < n ? ride.g.n_gather_blocks : 0;
+      ride.bookkeeping = 1;
+      select_set(h, set);
+      const bool actor = !(flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) || (s % h->cfg.delay_update) == 0;
+      rc = enqueue_grads(h, actor, true, 0, &ride);
+    }
+    select_set(h, 0);
+    h->mirror_w0 = false;
+  }
   hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
   h->profiling = was_prof;
   if (rc != DSACT_OK) return rc;

@@ -242,15 +242,10 @@ struct GatherArgs {
   int n_gather_blocks;
 };
 
-__global__ void __launch_bounds__(kThreads) k_gather(GatherArgs a) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if ((int)blockIdx.x >= a.n_gather_blocks) {  // spare blocks: weight repack (independent of the gather)
-    repack_rows(a.rp, (int)blockIdx.x - a.n_gather_blocks, tid);
-    return;
-  }
-  const long long it = a.use_dev ? a.st->it_next : a.host_it;
-  const int trow = a.use_dev ? (int)(a.st->seq_next % a.idx_rows) : a.host_row;
-  const int r0 = blockIdx.x * 4;
+// rows [4*blk, 4*blk+4) of the minibatch of iteration `it` (index-table row `trow`) + their noise
+__device__ __forceinline__ void gather_block(const GatherArgs& a, int blk, long long it, int trow, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r0 = blk * 4;
   const int r = r0 + wave;
   if (r < a.B) {
     const long long src = a.idx_table[(size_t)trow * a.B + r];
@@ -294,7 +289,40 @@ __global__ void __launch_bounds__(kThreads) k_gather(GatherArgs a) {
     const int r1 = r0 + 4 < a.B ? r0 + 4 : a.B;
     if (r0 < a.B) fill_noise_rows(a.nz, it, r0, r1, a.A, tid, kThreads);
   }
+}
+
+__global__ void __launch_bounds__(kThreads) k_gather(GatherArgs a) {
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= a.n_gather_blocks) {  // spare blocks: weight repack (independent of the gather)
+    repack_rows(a.rp, (int)blockIdx.x - a.n_gather_blocks, tid);
+    return;
+  }
+  const long long it = a.use_dev ? a.st->it_next : a.host_it;
+  const int trow = a.use_dev ? (int)(a.st->seq_next % a.idx_rows) : a.host_row;
+  gather_block(a, (int)blockIdx.x, it, trow, tid);
   if (a.bookkeeping && blockIdx.x == 0 && tid == 0) prologue_duties(a.st, it, a.advance_counters, a.hp);
+}
+
+// Riders of the loss launch in graph replays (k_loss has B/4 blocks: three quarters of the chip idle). Blocks
+// [n_loss_blocks, +n_gather) stage the NEXT update's minibatch into the other batch set (iteration it_next + 1,
+// table row seq_next + 1: the counters advance when this update closes); one more block does THIS update's
+// bookkeeping (nothing before the first weight-gradient tile reads what prologue_duties writes).
+struct RideArgs {
+  GatherArgs g;          // destination pointers = the other set; g.st / g.hp also serve the bookkeeping
+  int n_loss_blocks;     // blocks of the loss itself (always set)
+  int n_gather;          // 0: no gather rides (last update of a graph, eager flows)
+  int bookkeeping;       // 1: block n_loss_blocks + n_gather runs prologue_duties for this update
+};
+__device__ __forceinline__ bool loss_rider(const RideArgs& r) {
+  const int b = (int)blockIdx.x - r.n_loss_blocks;
+  if (b < 0) return false;
+  if (b < r.n_gather) {
+    const DevState* st = r.g.st;
+    gather_block(r.g, b, st->it_next + 1, (int)((st->seq_next + 1) % r.g.idx_rows), threadIdx.x);
+  } else if (r.bookkeeping && threadIdx.x == 0) {
+    prologue_duties(r.g.st, r.g.st->it_next, 1, r.g.hp);
+  }
+  return true;
 }
 
 // stand-alone bookkeeping for the flows that do not gather (host-staged minibatch, apply-only)
@@ -447,6 +475,15 @@ struct FusedOpt {
   long long n_q2, n_online3, n_total;
   float b1w, beta2, b2w, eps, polyak, one_minus_polyak;
   int auto_alpha;
+  // Graph replays whose gather rides in the previous update's loss launch (no per-step k_gather, hence no per-step
+  // repack pass): the tiles that update the Q nets' first-layer weights also refresh the zero-padded copies the next
+  // forward reads (mir_w / mir_wt) and the transposed action columns the NEXT update's k_heads_bwd reads (mir_at: the
+  // other batch set's copy -- this update's own copy is still being read while these tiles run). mir_n == 0: off.
+  int mir_n;                          // number of Q nets (0 = off)
+  int mir_ldp, mir_O, mir_A, mir_rows;
+  long long mir_lo[2];                // arena index of W0 of q1 / q2
+  float* mir_w[2]; float* mir_wt[2];  // padded copies [rows x ldp]: online, target
+  float* mir_at[2];                   // [32][rows]
 };
 
 constexpr int kMaxPrefetchTiles = 7;  // K <= 448 is fetched completely up front (112 VGPRs)
@@ -650,7 +687,24 @@ __device__ __forceinline__ void run_tile(const GemmProb& t, int m0, int n0, floa
           float pe = fo->online[oi + e], me = fo->adam_m[oi + e], ve = fo->adam_v[oi + e];
           adam_update(pe, me, ve, acc[e], fo->b1w, fo->beta2, fo->b2w, o_ss, o_bc2, fo->eps);
           fo->online[oi + e] = pe; fo->adam_m[oi + e] = me; fo->adam_v[oi + e] = ve;
-          if (o_delayed) fo->target[oi + e] = polyak_update(fo->target[oi + e], pe, fo->polyak, fo->one_minus_polyak);
+          op[e] = pe;
+          if (o_delayed) { ot[e] = polyak_update(fo->target[oi + e], pe, fo->polyak, fo->one_minus_polyak); fo->target[oi + e] = ot[e]; }
+        }
+      }
+      // first-layer weights of a Q net: refresh the padded / transposed copies (see FusedOpt::mir_*)
+      for (int q = 0; q < fo->mir_n; ++q) {
+        if (t.C0 != fo->grads + fo->mir_lo[q]) continue;   // uniform: one tensor per problem
+        float* mw = fo->mir_w[q] + (size_t)m * fo->mir_ldp + n;
+        float* mt = fo->mir_wt[q] + (size_t)m * fo->mir_ldp + n;
+        if (full) {
+          *(f32x4*)mw = op;
+          if (o_delayed) *(f32x4*)mt = ot;
+        } else {
+          for (int e = 0; e < 4 && n + e < t.N; ++e) { mw[e] = op[e]; if (o_delayed) mt[e] = ot[e]; }
+        }
+        for (int e = 0; e < 4; ++e) {
+          const int j = n + e - fo->mir_O;
+          if (j >= 0 && j < fo->mir_A && n + e < t.N) fo->mir_at[q][(size_t)j * fo->mir_rows + m] = op[e];
         }
       }
     }
@@ -1051,10 +1105,12 @@ struct LossArgs {
   const float* std_sums;   // {sum std1, sum std2} computed elsewhere (large B / strict data-parallel); else NULL
   int auto_alpha; float alpha_fixed, gamma, tau_b, one_minus_tau_b;
   long long* timeline;
+  RideArgs ride;
 };
 
 template <int NCH>
 __global__ void __launch_bounds__(kThreads) k_loss(LossArgs a) {
+  if (loss_rider(a.ride)) return;
   TL_DECL
   TL_STAMP();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1218,10 +1274,12 @@ struct LossV1Args {
   int W, B;
   float inv_B;
   int auto_alpha; float alpha_fixed, gamma, td_bound;
+  RideArgs ride;
 };
 
 template <int NCH>
 __global__ void __launch_bounds__(kThreads) k_loss_v1(LossV1Args a) {
+  if (loss_rider(a.ride)) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = blockIdx.x * 4 + wave;
   if (r >= a.B) return;

@@ -3,8 +3,8 @@
 
 usage: python scripts/step_trace.py gpurun_out/prof/bench_kernel_trace.csv [update_index] > profiles/rNN_step_trace.txt
 
-An update starts at a `k_gather` dispatch; prints two consecutive updates (kernel, grid, duration, gap to the
-previous launch's end) and the sums, so the per-launch numbers quoted in DESIGN.md can be re-derived.
+Prints two consecutive updates (kernel, grid, duration, gap to the previous launch's end) and the sums, so the
+per-launch numbers quoted in DESIGN.md can be re-derived.
 """
 import csv
 import sys
@@ -20,13 +20,21 @@ def main():
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
                              int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"])))
     rows.sort()
-    starts = [i for i, r in enumerate(rows) if "k_gather(" in r[2]]
-    if len(starts) < which + 3:
-        which = max(0, len(starts) - 3)
-    print("rocprofv3 --kernel-trace, %s: updates %d and %d of %d (an update = k_gather .. last launch before the next k_gather)"
-          % (path.split("/")[-1], which, which + 1, len(starts)))
+    # an update ends with the launch that closes it (k_stage_table, or k_adam on the unfused path); a k_gather in front
+    # of it belongs to it (graph replays with the merged gather have one k_gather per graph, not per update)
+    updates, cur = [], []
+    for r in rows:
+        cur.append(r)
+        if "k_stage_table(" in r[2] or "k_adam(" in r[2]:
+            updates.append(cur)
+            cur = []
+    if len(updates) < which + 2:
+        which = max(0, len(updates) - 2)
+    n_gather = sum(1 for r in rows if "k_gather(" in r[2])
+    print("rocprofv3 --kernel-trace, %s: updates %d and %d of %d (%d k_gather launches in the trace)"
+          % (path.split("/")[-1], which, which + 1, len(updates), n_gather))
     for u in (which, which + 1):
-        seg = rows[starts[u]:starts[u + 1]]
+        seg = updates[u]
         print("update %d" % u)
         total, prev_end = 0.0, None
         for s, e, name, grid, wg in seg:
