@@ -23,6 +23,35 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // dword-aligned dwordx4 is legal (weight rows of the Q nets have odd leading dimension O+A).
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
+// 4-wide device form of gelu_fwd_grad (dsact_math.h): the same FMA sequence per element, written on vectors so that
+// the polynomial chains compile to packed v_pk_fma_f32 (two elements per instruction)
+__device__ __forceinline__ f32x4 vfma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
+__device__ __forceinline__ void gelu4(const f32x4 z, f32x4& h, f32x4& g) {
+  const f32x4 x = z * kInvSqrt2;
+  const f32x4 t = __builtin_elementwise_min(__builtin_elementwise_abs(x), splat4(kErfHi));
+  const f32x4 s = x * x;
+  f32x4 rs = splat4(kErfS[5]);
+#pragma unroll
+  for (int k = 4; k >= 0; --k) rs = vfma4(rs, s, splat4(kErfS[k]));
+  const f32x4 small = vfma4(rs, x, x);
+  f32x4 rl = splat4(kErfL[8]);
+#pragma unroll
+  for (int k = 7; k >= 0; --k) rl = vfma4(rl, t, splat4(kErfL[k]));
+  const f32x4 arg = vfma4(rl, t, -t) * kLog2e;
+  const f32x4 parg = (z * -0.5f) * z * kLog2e;
+  f32x4 erf, pdf;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float large = copysignf(1.0f - __builtin_amdgcn_exp2f(arg[e]), x[e]);
+    erf[e] = t[e] > kErfT0 ? large : small[e];
+    pdf[e] = kInvSqrt2Pi * __builtin_amdgcn_exp2f(parg[e]);
+  }
+  const f32x4 cdf = vfma4(erf, splat4(0.5f), splat4(0.5f));
+  h = z * cdf;
+  g = vfma4(z, pdf, cdf);
+}
+
 constexpr int kWave = 64;
 constexpr int kThreads = 256;  // 4 waves, one per SIMD
 constexpr int kMaxWidth = 1024;
@@ -648,14 +677,10 @@ __device__ __forceinline__ void run_tile(const GemmProb& t, int m0, int n0, floa
   TL_STAMP();  // 3: MFMA loop done
   if (!in_range) { TL_FLUSH(tl_buf, tl_slot); return; }
   if (EPI == EPI_GELU) {
-    f32x4 h, gd;
+    f32x4 h, gd, zv;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float z = acc[e] + (full ? epv[e] : (n + e < t.N ? t.aux[n + e] : 0.0f));
-      float hh, gg;
-      gelu_fwd_grad(z, hh, gg);
-      h[e] = hh; gd[e] = gg;
-    }
+    for (int e = 0; e < 4; ++e) zv[e] = acc[e] + (full ? epv[e] : (n + e < t.N ? t.aux[n + e] : 0.0f));
+    gelu4(zv, h, gd);
     float* c0 = t.C0 + (size_t)m * t.ldc + n;
     float* c1 = t.C1 + (size_t)m * t.ldc + n;
     if (full) { *(f32x4u*)c0 = h; *(f32x4u*)c1 = gd; }
@@ -846,12 +871,7 @@ __device__ __forceinline__ void run_tile64(const GemmProb& t, int m0, int n0, fl
     float* c0 = t.C0 + (size_t)m * t.ldc + n;
     if (EPI == EPI_GELU) {
       f32x4 hv, gd;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float hh, gg;
-        gelu_fwd_grad(acc[mb][e] + epv[mb][e], hh, gg);
-        hv[e] = hh; gd[e] = gg;
-      }
+      gelu4(acc[mb] + epv[mb], hv, gd);
       *(f32x4u*)c0 = hv;
       *(f32x4u*)(t.C1 + (size_t)m * t.ldc + n) = gd;
     } else {

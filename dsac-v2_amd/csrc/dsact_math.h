@@ -25,12 +25,47 @@ constexpr float kInvSqrt2Pi = 0.39894228040143267794f;
 constexpr float kLogSqrt2Pi = 0.91893853320467274178f;  // math.log(math.sqrt(2*math.pi))
 constexpr float kTanhEps = 1e-6f;                        // act_distribution_cls.py:3
 
+// ---- GELU (exact-erf form) and its derivative -------------------------------------------------------
+// erf(x), |error| <= 7.7e-8 (1.3 ulp): two-interval fit made for this kernel (Chebyshev-node fits in double, rounded
+// to fp32; scripts/probes/fit_erf.py regenerates the coefficients and the error figures):
+//   |x| <= 0.9375 : erf = x + x*S(x^2)                         (degree 5)
+//   |x| >  0.9375 : erf = sign(x) * (1 - exp(-t + t*L(t))),  t = min(|x|, 4.1)   (degree 8; erf(4.1) == 1 in fp32)
+// Branch-free on purpose: a tile stage runs ONE wave per SIMD, so the epilogue is a serial VALU chain -- both
+// intervals are evaluated with FMAs (packed v_pk_fma_f32 in the 4-wide device form, gelu4 in dsact_kernels.h) and
+// selected, instead of the library erff/expf with their range branches. exp goes through the hardware 2^x.
+constexpr float kErfT0 = 0.9375f, kErfHi = 4.1f, kLog2e = 1.4426950408889634f;
+constexpr float kErfS[6] = {1.283791512e-01f, -3.761247694e-01f, 1.128162965e-01f, -2.675944008e-02f, 4.982214887e-03f,
+                            -5.933305947e-04f};
+constexpr float kErfL[9] = {-1.287695765e-01f, -6.346949339e-01f, -1.069155484e-01f, 2.425363660e-02f, -3.802132560e-03f,
+                            3.235395125e-04f,  2.627512004e-06f,  -3.285806315e-06f, 2.156770051e-07f};
+
+DSACT_HD float exp2_hw(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_exp2f(x);  // v_exp_f32: ~1 ulp, denormal results flush to 0
+#else
+  return exp2f(x);
+#endif
+}
+
+DSACT_HD float erf_2fit(float x) {
+  const float t = fminf(fabsf(x), kErfHi);
+  const float s = x * x;
+  float rs = kErfS[5];
+  for (int k = 4; k >= 0; --k) rs = fmaf(rs, s, kErfS[k]);
+  const float small = fmaf(rs, x, x);
+  float rl = kErfL[8];
+  for (int k = 7; k >= 0; --k) rl = fmaf(rl, t, kErfL[k]);
+  const float e = exp2_hw(fmaf(rl, t, -t) * kLog2e);
+  const float large = copysignf(1.0f - e, x);
+  return t > kErfT0 ? large : small;
+}
+
 // gelu(z) and d gelu / dz share the erf; both are stored by the forward epilogue.
 DSACT_HD void gelu_fwd_grad(float z, float& h, float& g) {
-  const float cdf = 0.5f * (1.0f + erff(z * kInvSqrt2));
-  const float pdf = kInvSqrt2Pi * expf(-0.5f * z * z);
+  const float cdf = fmaf(erf_2fit(z * kInvSqrt2), 0.5f, 0.5f);
+  const float pdf = kInvSqrt2Pi * exp2_hw((-0.5f * z) * z * kLog2e);
   h = z * cdf;
-  g = cdf + z * pdf;
+  g = fmaf(z, pdf, cdf);
 }
 
 DSACT_HD float softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
