@@ -378,7 +378,7 @@ def main():
     if use_dp:
         from dsact.dp import DataParallelUpdater
 
-        e.use_torch_stream()
+        # the updater issues its collectives on the engine's own stream (engine.torch_stream)
         # default: ONE all-reduce after the whole backward. DSACT_DP_OVERLAP=1 all-reduces the critics' 2/3 of the
         # arena asynchronously under the actor's backward -- measured on one rank the second collective call and
         # its cross-stream events cost +40 us/step against +14.5 us for the single call, so it is opt-in

@@ -1493,6 +1493,8 @@ int dsact_set_stream(dsact_handle* h, void* s) {
   return DSACT_OK;
 }
 
+void* dsact_get_stream(const dsact_handle* h) { return h ? (void*)h->stream : nullptr; }
+
 int dsact_sync(dsact_handle* h) {
   if (!h) return DSACT_E_INVALID;
   HIPCHK(h, hipSetDevice(h->device));

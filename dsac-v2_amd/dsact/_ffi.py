@@ -52,6 +52,7 @@ SYMBOLS = [
     ("dsact_destroy", C.c_int, [_P]),
     ("dsact_last_error", C.c_char_p, [_P]),
     ("dsact_set_stream", C.c_int, [_P, _P]),
+    ("dsact_get_stream", C.c_void_p, [_P]),
     ("dsact_sync", C.c_int, [_P]),
     ("dsact_online_count", C.c_size_t, [_P]),
     ("dsact_target_count", C.c_size_t, [_P]),

@@ -21,7 +21,14 @@ then equal the single-process global-batch gradients to fp32 summation order, fi
 `engine` is anything exposing `.grads` (flat torch tensor), `.dp_grads()`, `.dp_apply()` -- the
 DsactEngine in production; the CPU tests drive the same coordinator with an oracle-backed stand-in
 over the gloo backend.
+
+Stream ordering: the engine's kernels run on the engine's own HIP stream, and a torch.distributed collective
+orders itself against torch's *current* stream. Every collective (and the division that follows a SUM) is
+therefore issued under `torch.cuda.stream(engine.torch_stream)` -- the engine's stream seen as a torch stream --
+so "gradients complete -> all-reduce -> optimiser" is one stream-ordered chain without host synchronisation.
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -41,18 +48,24 @@ class DataParallelUpdater:
         # overlap: all-reduce the critics' segment (2/3 of the arena) while the actor's backward still runs
         self.overlap = bool(overlap) and not self.strict and hasattr(engine, "dp_grads_critic")
         # replicas must start identical: rank 0's parameters / optimiser state win
-        for t in broadcast_tensors:
-            dist.broadcast(t, src=0, group=group)
+        with self._on_engine_stream():
+            for t in broadcast_tensors:
+                dist.broadcast(t, src=0, group=group)
+
+    def _on_engine_stream(self):
+        ts = getattr(self.engine, "torch_stream", None)   # CPU stand-ins (gloo tests) have no stream
+        return torch.cuda.stream(ts) if ts is not None else contextlib.nullcontext()
 
     def allreduce_grads(self):
         g = self.engine.grads
         if self.world == 1 and not self.force_collective:
             return
-        if self._avg:
-            dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
-        else:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
-            g.div_(self.world)
+        with self._on_engine_stream():
+            if self._avg:
+                dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+                g.div_(self.world)
 
     def _reduce_async(self, t):
         if self._avg:
@@ -64,14 +77,15 @@ class DataParallelUpdater:
         all-reduce of the rest -> wait both -> apply. Same arithmetic as step()."""
         e = self.engine
         g, n_c = e.grads, e.critic_grad_count
-        e.dp_grads_critic()
-        w1 = self._reduce_async(g[:n_c])
-        e.dp_grads_actor()
-        w2 = self._reduce_async(g[n_c:])
-        w1.wait()
-        w2.wait()
-        if not self._avg:
-            g.div_(self.world)
+        with self._on_engine_stream():
+            e.dp_grads_critic()
+            w1 = self._reduce_async(g[:n_c])      # starts behind the critic half on the engine's stream
+            e.dp_grads_actor()
+            w2 = self._reduce_async(g[n_c:])
+            w1.wait()                             # the engine's stream waits for both results
+            w2.wait()
+            if not self._avg:
+                g.div_(self.world)
         e.dp_apply()
 
     def step(self):
@@ -79,8 +93,9 @@ class DataParallelUpdater:
             return self.step_overlapped()
         if self.strict:
             self.engine.dp_forward()
-            if self.world > 1:
-                dist.all_reduce(self.engine.std_sums, op=dist.ReduceOp.SUM, group=self.group)
+            if self.world > 1 or self.force_collective:
+                with self._on_engine_stream():
+                    dist.all_reduce(self.engine.std_sums, op=dist.ReduceOp.SUM, group=self.group)
             self.engine.dp_backward()
         else:
             self.engine.dp_grads()

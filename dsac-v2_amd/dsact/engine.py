@@ -123,9 +123,29 @@ class DsactEngine:
             pass
 
     def use_torch_stream(self):
-        """Run on torch's current stream (orders the kernels with torch ops such as all_reduce)."""
+        """Run on torch's current stream. The legacy default stream has no handle to pass (its `cuda_stream` is 0,
+        which `dsact_set_stream` reads as "handle-owned stream"): enter a `torch.cuda.stream(...)` context first, or --
+        simpler -- leave the engine on its own stream and issue the torch work on `engine.torch_stream`."""
         s = self.torch.cuda.current_stream(self.device).cuda_stream
+        if not s:
+            raise DsactError("torch's current stream is the legacy default stream (handle 0); run torch work under "
+                             "`with torch.cuda.stream(engine.torch_stream):` instead")
         self._chk(self._lib.dsact_set_stream(self._h, C.c_void_p(s)))
+        self._torch_stream = None
+
+    @property
+    def stream_ptr(self) -> int:
+        return int(self._lib.dsact_get_stream(self._h) or 0)
+
+    @property
+    def torch_stream(self):
+        """The engine's HIP stream as a torch stream: torch ops issued under `torch.cuda.stream(engine.torch_stream)`
+        (collectives on `engine.grads`, tensor math on the arenas) are stream-ordered with the engine's kernels."""
+        ts = getattr(self, "_torch_stream", None)
+        if ts is None or ts.cuda_stream != self.stream_ptr:
+            ts = self.torch.cuda.ExternalStream(self.stream_ptr, device=self.device)
+            self._torch_stream = ts
+        return ts
 
     def sync(self):
         self._chk(self._lib.dsact_sync(self._h))

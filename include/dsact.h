@@ -102,6 +102,10 @@ int dsact_destroy(dsact_handle* h);
 const char* dsact_last_error(const dsact_handle* h);
 /* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL -> handle-owned stream */
 int dsact_set_stream(dsact_handle* h, void* hip_stream);
+/* the hipStream_t every call on this handle enqueues on -- host code that interleaves its own device work
+ * (torch.distributed collectives on the gradient arena, dsac_v2.py:107-138 seam) must issue it on THIS stream
+ * (torch.cuda.ExternalStream) or order against it with events; never NULL after dsact_create */
+void* dsact_get_stream(const dsact_handle* h);
 int dsact_sync(dsact_handle* h); /* blocks until the handle's stream is idle */
 
 /* ---- parameters (ApproxContainer, dsac_v2.py:19-62) ------------------------------------------- */

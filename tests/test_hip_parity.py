@@ -473,28 +473,30 @@ def test_data_parallel_halves_equal_graph_replay():
         a1.engine.sync()
         a2 = _replay_pair(17, 4, (64, 64), 64, 4096, seed=4)
         e = a2.engine
-        e.use_torch_stream()
         dp = DataParallelUpdater(e, broadcast_tensors=(e.online, e.target, e.adam_m, e.adam_v))
-        e.dp_begin(0)
+        dp.force_collective = True   # one rank: still issue the all-reduce -- it runs on the collective's own stream
+        e.dp_begin(0)                # and must be ordered against the engine's kernels both ways
         for _ in range(6):
             dp.step()
         torch.cuda.synchronize()
         for name in ("online", "target", "adam_m", "adam_v"):
             assert torch.equal(getattr(a1.engine, name), getattr(e, name)), name
         assert a1.engine.get_state() == e.get_state()
-        # overlapped variant: critic half -> async all-reduce(q1|q2) -> actor half -> all-reduce(rest) -> apply
-        a3 = _replay_pair(17, 4, (64, 64), 64, 4096, seed=4)
-        e3 = a3.engine
-        e3.use_torch_stream()
-        dp3 = DataParallelUpdater(e3, broadcast_tensors=(e3.online, e3.target, e3.adam_m, e3.adam_v), overlap=True)
-        assert dp3.overlap
-        e3.dp_begin(0)
-        for _ in range(6):
-            dp3.step()
-        torch.cuda.synchronize()
-        for name in ("online", "target", "adam_m", "adam_v"):
-            assert torch.equal(getattr(a1.engine, name), getattr(e3, name)), name
-        assert a1.engine.get_state() == e3.get_state()
+        # overlapped variant: critic half -> async all-reduce(q1|q2) -> actor half -> all-reduce(rest) -> apply.
+        # Repeated: an ordering bug between the engine's stream and the collective's shows up as a flaky mismatch
+        # (it did: 8 of 12 runs before the collectives were issued on engine.torch_stream)
+        for rep_i in range(6):
+            a3 = _replay_pair(17, 4, (64, 64), 64, 4096, seed=4)
+            e3 = a3.engine
+            dp3 = DataParallelUpdater(e3, broadcast_tensors=(e3.online, e3.target, e3.adam_m, e3.adam_v), overlap=True)
+            assert dp3.overlap
+            e3.dp_begin(0)
+            for _ in range(6):
+                dp3.step()
+            torch.cuda.synchronize()
+            for name in ("online", "target", "adam_m", "adam_v"):
+                assert torch.equal(getattr(a1.engine, name), getattr(e3, name)), (name, rep_i)
+            assert a1.engine.get_state() == e3.get_state()
     finally:
         if created:
             dist.destroy_process_group()
