@@ -276,35 +276,53 @@ __device__ __forceinline__ void gather_block(const GatherArgs& a, int blk, long 
   const int lane = tid & 63, wave = tid >> 6;
   const int r0 = blk * 4;
   const int r = r0 + wave;
-  if (r < a.B) {
-    const long long src = a.idx_table[(size_t)trow * a.B + r];
-    const float* __restrict__ so = a.rb_obs + (size_t)src * a.O;
-    const float* __restrict__ so2 = a.rb_obs2 + (size_t)src * a.O;
-    float* __restrict__ d0 = a.X0 + (size_t)r * a.ldx;
-    float* __restrict__ dp = a.XP + (size_t)r * a.ldx;
-    float* __restrict__ d2 = a.X2 + (size_t)r * a.ldx;
-    // all loads of the row first (HBM latency paid once), then the stores
-    const int ja = lane < a.A ? lane : 0;
-    const float av = a.rb_act[(size_t)src * a.A + ja];
-    const float rw = a.rb_rew[src], dn = a.rb_done[src];
-    if ((a.O & 3) == 0) {
+  const bool row = r < a.B;
+  // one trip of dwordx4 loads covers the row (O % 4 == 0, O <= 512): loads -> noise (VALU work under the HBM latency
+  // of the random rows) -> stores. Other shapes: the row is copied before the noise.
+  const bool one_trip = (a.O & 3) == 0 && a.O <= 512;
+  const long long src = row ? a.idx_table[(size_t)trow * a.B + r] : 0;
+  const float* __restrict__ so = a.rb_obs + (size_t)src * a.O;
+  const float* __restrict__ so2 = a.rb_obs2 + (size_t)src * a.O;
+  float* __restrict__ d0 = a.X0 + (size_t)(row ? r : 0) * a.ldx;
+  float* __restrict__ dp = a.XP + (size_t)(row ? r : 0) * a.ldx;
+  float* __restrict__ d2 = a.X2 + (size_t)(row ? r : 0) * a.ldx;
+  const int ka = lane * 4, kb = ka + 256;
+  f32x4 va = {0.f, 0.f, 0.f, 0.f}, wa = va, vb = va, wb = va;
+  float av = 0.f, rw = 0.f, dn = 0.f;
+  if (row) {
+    av = a.rb_act[(size_t)src * a.A + (lane < a.A ? lane : 0)];
+    rw = a.rb_rew[src]; dn = a.rb_done[src];
+    if (one_trip) {
+      if (ka < a.O) { va = *(const f32x4*)(so + ka); wa = *(const f32x4*)(so2 + ka); }
+      if (kb < a.O) { vb = *(const f32x4*)(so + kb); wb = *(const f32x4*)(so2 + kb); }
+    } else if ((a.O & 3) == 0) {
       for (int k0 = 0; k0 < a.O; k0 += 512) {
-        const int ka = k0 + lane * 4, kb = ka + 256;
-        f32x4 va = {0.f, 0.f, 0.f, 0.f}, wa = va, vb = va, wb = va;
-        if (ka < a.O) { va = *(const f32x4*)(so + ka); wa = *(const f32x4*)(so2 + ka); }
-        if (kb < a.O) { vb = *(const f32x4*)(so + kb); wb = *(const f32x4*)(so2 + kb); }
-        if (ka < a.O) { *(f32x4*)(d0 + ka) = va; *(f32x4*)(dp + ka) = va; *(f32x4*)(d2 + ka) = wa; }
-        if (kb < a.O) { *(f32x4*)(d0 + kb) = vb; *(f32x4*)(dp + kb) = vb; *(f32x4*)(d2 + kb) = wb; }
+        const int k1 = k0 + lane * 4, k2 = k1 + 256;
+        f32x4 xa = {0.f, 0.f, 0.f, 0.f}, ya = xa, xb = xa, yb = xa;
+        if (k1 < a.O) { xa = *(const f32x4*)(so + k1); ya = *(const f32x4*)(so2 + k1); }
+        if (k2 < a.O) { xb = *(const f32x4*)(so + k2); yb = *(const f32x4*)(so2 + k2); }
+        if (k1 < a.O) { *(f32x4*)(d0 + k1) = xa; *(f32x4*)(dp + k1) = xa; *(f32x4*)(d2 + k1) = ya; }
+        if (k2 < a.O) { *(f32x4*)(d0 + k2) = xb; *(f32x4*)(dp + k2) = xb; *(f32x4*)(d2 + k2) = yb; }
       }
     } else {
       for (int k0 = 0; k0 < a.O; k0 += 128) {
-        const int ka = k0 + lane, kb = ka + 64;
-        float va = 0.f, wa = 0.f, vb = 0.f, wb = 0.f;
-        if (ka < a.O) { va = so[ka]; wa = so2[ka]; }
-        if (kb < a.O) { vb = so[kb]; wb = so2[kb]; }
-        if (ka < a.O) { d0[ka] = va; dp[ka] = va; d2[ka] = wa; }
-        if (kb < a.O) { d0[kb] = vb; dp[kb] = vb; d2[kb] = wb; }
+        const int k1 = k0 + lane, k2 = k1 + 64;
+        float xa = 0.f, ya = 0.f, xb = 0.f, yb = 0.f;
+        if (k1 < a.O) { xa = so[k1]; ya = so2[k1]; }
+        if (k2 < a.O) { xb = so[k2]; yb = so2[k2]; }
+        if (k1 < a.O) { d0[k1] = xa; dp[k1] = xa; d2[k1] = ya; }
+        if (k2 < a.O) { d0[k2] = xb; dp[k2] = xb; d2[k2] = yb; }
       }
+    }
+  }
+  if (a.nz.seed != 0) {
+    const int r1 = r0 + 4 < a.B ? r0 + 4 : a.B;
+    if (r0 < a.B) fill_noise_rows(a.nz, it, r0, r1, a.A, tid, kThreads);
+  }
+  if (row) {
+    if (one_trip) {
+      if (ka < a.O) { *(f32x4*)(d0 + ka) = va; *(f32x4*)(dp + ka) = va; *(f32x4*)(d2 + ka) = wa; }
+      if (kb < a.O) { *(f32x4*)(d0 + kb) = vb; *(f32x4*)(dp + kb) = vb; *(f32x4*)(d2 + kb) = wb; }
     }
     // action columns + zero padding up to ldx (A <= 32 < 64 lanes)
     for (int k = a.O + lane; k < a.ldx; k += 64) {
@@ -313,10 +331,6 @@ __device__ __forceinline__ void gather_block(const GatherArgs& a, int blk, long 
       if (j >= a.A) { dp[k] = 0.0f; d2[k] = 0.0f; }
     }
     if (lane == 0) { a.rew[r] = rw; a.done[r] = dn; }
-  }
-  if (a.nz.seed != 0) {
-    const int r1 = r0 + 4 < a.B ? r0 + 4 : a.B;
-    if (r0 < a.B) fill_noise_rows(a.nz, it, r0, r1, a.A, tid, kThreads);
   }
 }
 

@@ -161,6 +161,7 @@ class DSAC_V1_HIP(_v2.DSAC_V2_HIP):
         self._stage(data)
         self._noise()
         self.engine.compute_grads(int(iteration), self.flags)
+        self.engine.sync()   # the caller reads the returned gradient tensors with torch ops on torch's stream
         self._serial += 1
         tb = LazyTbInfoV1(self, self._serial, (time.time() - t0) * 1000)
         v = self._grad_views()

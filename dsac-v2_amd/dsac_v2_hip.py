@@ -312,8 +312,16 @@ class ApproxContainer(nn.Module):
             for pol in (self.policy, self.policy_target):
                 pol.act_high_lim = pol.act_high_lim.to(engine.device)
                 pol.act_low_lim = pol.act_low_lim.to(engine.device)
+        # the copies above ran on torch's stream; the engine's kernels run on its own
+        torch.cuda.current_stream(engine.device).synchronize()
         object.__setattr__(self, "_engine", engine)
         self.policy._engine = engine
+        # the other nets' forward() is plain torch over views of the arenas (evaluation / debugging): let the
+        # engine's in-flight update finish first (its kernels run on their own stream)
+        for child in self.children():
+            if child is not self.policy and not getattr(child, "_dsact_sync_hook", False):
+                child.register_forward_pre_hook(lambda _m, _a, _e=engine: _e.sync())
+                child._dsact_sync_hook = True
         engine.set_action_limits(self.policy.act_high_lim.cpu().numpy(), self.policy.act_low_lim.cpu().numpy())
 
     def _apply(self, fn, *a, **k):
@@ -330,6 +338,7 @@ class ApproxContainer(nn.Module):
             state_dict = {k: v.to(self._engine.device) for k, v in state_dict.items()}
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         if self._engine is not None:
+            torch.cuda.current_stream(self._engine.device).synchronize()   # torch's copies land before the next update
             self._engine.set_action_limits(self.policy.act_high_lim.cpu().numpy(),
                                            self.policy.act_low_lim.cpu().numpy())
         return out
@@ -520,6 +529,7 @@ class DSAC_V2_HIP:
         self._stage(data)
         self._noise()
         self.engine.compute_grads(int(iteration), self.flags)
+        self.engine.sync()   # the caller reads the returned gradient tensors with torch ops on torch's stream
         self._serial += 1
         tb = LazyTbInfo(self, self._serial, (time.time() - t0) * 1000)
         v = self._grad_views()
