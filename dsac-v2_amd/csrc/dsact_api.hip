@@ -2030,6 +2030,7 @@ int dsact_time_steps(dsact_handle* h, int64_t first_iteration, int64_t n_steps, 
   HIPCHK(h, hipEventElapsedTime(ms_total, e0, e1));
   hipEventDestroy(e0);
   hipEventDestroy(e1);
+  h->have_batch = true;   // the last update's minibatch stays staged
   return DSACT_OK;
 }
 

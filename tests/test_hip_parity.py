@@ -297,11 +297,21 @@ def test_buffer_fast_path_equals_host_path():
     assert torch.equal(a1.engine.online, a2.engine.online)
 
 
-def test_graph_replay_equals_eager_steps():
-    O, A, B, N = 17, 4, 64, 4096
+@pytest.mark.parametrize("O,A,hid,B,per_graph,total", [
+    (17, 4, (64, 64), 64, 2, 8),
+    (17, 4, (64, 64), 64, 3, 6),          # odd updates per graph: both orders of the two batch sets
+    (11, 3, (96, 40), 50, 4, 8),          # ragged widths / batch: edge tiles, a partial last gather block
+    (5, 1, (33,), 7, 1, 4),               # one update per graph: nothing rides, only the bookkeeping block
+    (376, 17, (256, 256, 256), 256, 8, 16),
+])
+def test_graph_replay_equals_eager_steps(O, A, hid, B, per_graph, total):
+    """Graph replays (one gather per graph; each update's loss launch stages the NEXT update's minibatch into the other
+    batch set and does the bookkeeping; the first-layer weight tiles keep the padded copies fresh) == eager updates
+    (own gather + repack per update), bit for bit -- parameters, targets, optimiser state, and the staged minibatch."""
+    N = 4096
     algs = []
     for mode in ("eager", "graph"):
-        alg, _ = make_pair(O, A, (64, 64), B, seed=4)
+        alg, _ = make_pair(O, A, hid, B, seed=4)
         e = alg.engine
         e.set_device_rng(12345)
         e.buffer_create(N)
@@ -313,18 +323,23 @@ def test_graph_replay_equals_eager_steps():
         idx = np.random.randint(0, N, size=(8, B))
         e.upload_index_table(idx)
         if mode == "graph":
-            e.graph_build(2)
-            e.graph_run(0, 8)
+            e.graph_build(per_graph)
+            e.graph_run(0, total)
         else:
-            ms = e.time_steps(0, 8, use_graph=False)
+            ms = e.time_steps(0, total, use_graph=False)
             assert ms > 0
         e.sync()
         algs.append(alg)
-    assert torch.equal(algs[0].engine.online, algs[1].engine.online)
-    assert torch.equal(algs[0].engine.target, algs[1].engine.target)
+    for name in ("online", "target", "adam_m", "adam_v"):
+        assert torch.equal(getattr(algs[0].engine, name), getattr(algs[1].engine, name)), name
     st = algs[1].engine.get_state()
-    assert st["adam_steps"] == [8, 4, 4]
+    assert st == algs[0].engine.get_state()
+    assert st["adam_steps"] == [total, (total + 1) // 2, (total + 1) // 2]
     assert torch.isfinite(algs[1].engine.online).all()
+    # the minibatch of the LAST update is the one left staged, in both flows
+    b0, b1 = algs[0].engine.read_batch(with_logp=False), algs[1].engine.read_batch(with_logp=False)
+    for k in ("obs", "act", "rew", "obs2", "done"):
+        assert np.array_equal(b0[k], b1[k]), k
 
 
 def test_device_rng_is_standard_normal():
