@@ -145,6 +145,11 @@ struct dsact_handle {
   } alt;
   char* alt_ws = nullptr;
   int cur_set = 0;             // 0 outside of graph capture
+  // environment switches, read once at dsact_create (getenv walks the whole environment: ~20 calls per eager update
+  // were host time on the launch path)
+  std::string env_timeline_stage;   // DSACT_TIMELINE_STAGE
+  bool env_no_tile64 = false, env_no_hb_ride = false, env_no_merged_gather = false;
+  int env_conv_dw_nkt = 1;
   bool mirror_w0 = false;      // set while the merged-gather graph is being captured (see FusedOpt::mir_*)
   bool merged_graph = false;   // the captured graph uses the merged-gather flow
   // replay ring
@@ -609,8 +614,7 @@ int build_tasks(dsact_handle* h) {
 }
 
 long long* tl_for(dsact_handle* h, const char* name) {
-  const char* want = getenv("DSACT_TIMELINE_STAGE");
-  return (want && !strcmp(want, name)) ? h->timeline : nullptr;
+  return (!h->env_timeline_stage.empty() && h->env_timeline_stage == name) ? h->timeline : nullptr;
 }
 
 FusedOpt fused_opt(const dsact_handle* h, bool enable) {
@@ -645,14 +649,13 @@ FusedOpt fused_opt(const dsact_handle* h, bool enable) {
 int run_stage(dsact_handle* h, const Stage& s0, int x0 = 0, int x1 = 0, bool fused = false) {
   if (s0.n_blocks == 0 && x1 <= x0) return DSACT_OK;
   Stage s = s0;
-  const char* want = getenv("DSACT_TIMELINE_STAGE");
-  s.args.timeline = (want && s.name == want) ? h->timeline : nullptr;
+  s.args.timeline = (!h->env_timeline_stage.empty() && s.name == h->env_timeline_stage) ? h->timeline : nullptr;
   s.args.n_stage_blocks = s.n_blocks;
   s.args.extra = h->d_tiles + x0;
   s.args.n_extra = x1 > x0 ? x1 - x0 : 0;
   s.args.fo = fused_opt(h, fused);
   // large batches: 64x64 tiles (k_stage64) when every problem of the stage allows it and nothing rides along
-  if (s.args.n_extra == 0 && (s.kind == 0 || s.kind == 1) && getenv("DSACT_NO_TILE64") == nullptr) {
+  if (s.args.n_extra == 0 && (s.kind == 0 || s.kind == 1) && !h->env_no_tile64) {
     bool ok = true;
     int blocks = 0;
     StageArgs a64 = s.args;
@@ -811,7 +814,7 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
       const int kt_all = tiles_of(a.K1p, TN);
       // k-tiles per workgroup (the dY tile would be staged once for all of them): measured slower than one
       // k-tile per workgroup on every layer (fewer, longer dependent chains) -> 1
-      const int nkt = getenv("DSACT_CONV_DW_NKT") ? atoi(getenv("DSACT_CONV_DW_NKT")) : 1;
+      const int nkt = h->env_conv_dw_nkt;
       a.tiles_k = tiles_of(kt_all, nkt);             // k-groups
       int blocks = 0;
       // layer 0: every differentiated stack reads the staged `obs` image -> one problem, dY rows concatenated
@@ -1199,7 +1202,7 @@ actor_part:
   // tiles that may ride: the critics' + (behind heads_bwd only) the policy's output layer
   const int ride_end = h->bwdpi.empty() ? h->dw_off[2] : h->dw_pol_rest;
   int ride_hb = 0;
-  if (phase == 0 && !(h->use_fork && !h->profiling) && getenv("DSACT_NO_HB_RIDE") == nullptr) {
+  if (phase == 0 && !(h->use_fork && !h->profiling) && !h->env_no_hb_ride) {
     ride_hb = (ride_end - h->dw_off[0]) / n_carriers;
     if (ride_hb > crit_tiles) ride_hb = crit_tiles;
   }
@@ -1392,6 +1395,11 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->n_loss_wg = (h->B + 3) / 4;  // one wave per sample
   h->loss_rows = 4;
   h->auto_std_sums = h->B > 1024;   // large batches: the std column is summed once, not by every wave
+  if (const char* v = getenv("DSACT_TIMELINE_STAGE")) h->env_timeline_stage = v;
+  h->env_no_tile64 = getenv("DSACT_NO_TILE64") != nullptr;
+  h->env_no_hb_ride = getenv("DSACT_NO_HB_RIDE") != nullptr;
+  h->env_no_merged_gather = getenv("DSACT_NO_MERGED_GATHER") != nullptr;
+  if (const char* v = getenv("DSACT_CONV_DW_NKT")) h->env_conv_dw_nkt = atoi(v);
   h->dw_chunks = (h->B > 448 && h->B % 256 == 0 && getenv("DSACT_NO_SPLITK") == nullptr) ? h->B / 256 : 1;
   h->dw_part_stride = (h->n_online + 2 + 63) & ~(size_t)63;
   Carver c0;
@@ -1859,7 +1867,7 @@ int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) 
   // of the padded first-layer copies is done by the weight-gradient tiles themselves (FusedOpt::mir_*).
   // Update s of n uses set (n-1-s)&1, so the last staged minibatch sits in set 0 like after eager updates.
   const bool merged = !h->cnn && h->use_w1p && h->dw_chunks == 1 && !h->use_fork && !h->use_std_sums && h->alt_ws != nullptr &&
-                      getenv("DSACT_NO_MERGED_GATHER") == nullptr;
+                      !h->env_no_merged_gather;
   h->merged_graph = merged;
   HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
   int rc = DSACT_OK;
