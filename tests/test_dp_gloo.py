@@ -56,6 +56,22 @@ class OracleDPEngine:
         self.grads[-2] = float(self.orc.mean_std1)
         self.grads[-1] = float(self.orc.mean_std2)
 
+    # overlapped mode: the critics' segment of the arena is final (and all-reduced) before the actor's
+    @property
+    def critic_grad_count(self):
+        return sum(t.numel() for n in ("q1", "q2") for t in self.orc.p[n])
+
+    def dp_grads_critic(self):
+        self.orc.compute_gradient(self.batches[self.k], self.noises[self.k])
+        n_c = self.critic_grad_count
+        self.grads[:n_c] = self.orc.flat_grads()[:n_c]
+
+    def dp_grads_actor(self):
+        n_c = self.critic_grad_count
+        self.grads[n_c:-2] = self.orc.flat_grads()[n_c:]
+        self.grads[-2] = float(self.orc.mean_std1)
+        self.grads[-1] = float(self.orc.mean_std2)
+
     def dp_apply(self):
         off = 0
         for n in ("q1", "q2", "policy"):
@@ -69,7 +85,7 @@ class OracleDPEngine:
         self.k += 1
 
 
-def _worker(rank, world, port, out_q, strict=False):
+def _worker(rank, world, port, out_q, strict=False, overlap=False):
     for p in (ROOT, os.path.join(ROOT, "dsac-v2_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -96,9 +112,20 @@ def _worker(rank, world, port, out_q, strict=False):
     eng = OracleDPEngine(orc, sb, sn)
     eng.global_batch = B
     flat = [t for n in DsactOracle.NETS for t in orc.p[n]] + [orc.log_alpha]
-    dp = DataParallelUpdater(eng, broadcast_tensors=[t.data for t in flat], strict=strict)
+    dp = DataParallelUpdater(eng, broadcast_tensors=[t.data for t in flat], strict=strict, overlap=overlap)
+    assert dp.overlap == overlap
     grads0 = None
     for k in range(steps):
+        if overlap:
+            # the coordinator's own step(): critic half -> async all-reduce -> actor half -> all-reduce -> apply
+            applied = eng.dp_apply
+            eng.dp_apply = lambda: None
+            dp.step()
+            eng.dp_apply = applied
+            if k == 0:
+                grads0 = eng.grads.clone()
+            eng.dp_apply()
+            continue
         if strict:
             eng.dp_forward()
             dist.all_reduce(eng.std_sums, op=dist.ReduceOp.SUM)
@@ -183,3 +210,30 @@ def test_two_rank_strict_mode_equals_global_batch_gradient():
     assert np.abs(g0[:n] - gr).max() <= 2e-6 * np.abs(gr).max() + 1e-9
     assert abs(ms0 - msr) <= 1e-6
     assert np.abs(p0 - pr).max() <= 2.1e-4   # Adam sign ambiguity of rounding-level gradients: 2*lr
+
+
+def test_two_rank_overlapped_step_equals_plain_step():
+    """overlap=True (critics' segment all-reduced asynchronously, the rest after the actor half) is the same
+    arithmetic as the single all-reduce: replicas identical, same gradients and parameters as the plain run."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    runs = {}
+    for overlap in (False, True):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, q, False, overlap)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = {}
+        for _ in range(world + 1):
+            item = q.get(timeout=180)
+            got[item[0]] = item[1:]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        runs[overlap] = got
+    for r in (0, 1):
+        for a, b in zip(runs[False][r], runs[True][r]):
+            np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+    np.testing.assert_array_equal(runs[True][0][1], runs[True][1][1])
+
