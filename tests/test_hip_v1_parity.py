@@ -112,3 +112,36 @@ def test_v1_local_update_surface_and_fused_equals_split():
     assert list(s1.keys())[:2] == ["log_alpha", "q.q.0.weight"]
     for k in s1:
         assert torch.equal(s1[k].cpu(), s2[k].cpu()), k
+
+
+@pytest.mark.parametrize("per_graph,total", [(2, 8), (3, 6)])
+def test_v1_graph_replay_equals_eager_steps(per_graph, total):
+    """DSAC_V1 through the graph flow (gather of the next update and the bookkeeping ride in k_loss_v1's launch, the
+    single critic's first-layer tiles keep the padded copies fresh) == eager updates, bit for bit."""
+    O, A, hid, B, N = 17, 4, (64, 64), 64, 2048
+    engines = []
+    for mode in ("eager", "graph"):
+        alg, _ = make_pair(O, A, hid, B, seed=4)
+        e = alg.engine
+        e.set_device_rng(777)
+        e.buffer_create(N)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        e.buffer_fill_device(0, torch.randn(N, O, device="cuda", generator=g), torch.rand(N, A, device="cuda", generator=g) - .5,
+                             torch.randn(N, device="cuda", generator=g), torch.randn(N, O, device="cuda", generator=g),
+                             (torch.rand(N, device="cuda", generator=g) < .05).float())
+        np.random.seed(1)
+        e.upload_index_table(np.random.randint(0, N, size=(8, B)))
+        if mode == "graph":
+            e.graph_build(per_graph)
+            e.graph_run(0, total)
+        else:
+            assert e.time_steps(0, total, use_graph=False) > 0
+        e.sync()
+        engines.append(e)
+    for name in ("online", "target", "adam_m", "adam_v"):
+        assert torch.equal(getattr(engines[0], name), getattr(engines[1], name)), name
+    assert engines[0].get_state() == engines[1].get_state()
+    assert torch.isfinite(engines[1].online).all()
+    b0, b1 = engines[0].read_batch(with_logp=False), engines[1].read_batch(with_logp=False)
+    for k in ("obs", "act", "rew", "obs2", "done"):
+        assert np.array_equal(b0[k], b1[k]), k
