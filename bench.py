@@ -454,6 +454,9 @@ def main():
             prof = e.profile_step(warmup + steps)
             e.sync()
             out["kernels"] = [{"name": n, "us": round(ms * 1000, 2), "blocks": b} for n, ms, b in prof]
+            out["kernels_note"] = ("hipEvent-bracketed launches of ONE EAGER update (own gather launch, event overhead "
+                                   "included); the timed graph replay has no per-update gather (it rides in `loss`) -- "
+                                   "in-graph durations: profiles/r01_final_step_trace.txt")
             dom = max(prof, key=lambda r: r[1])
             out["dominant_kernel"] = {"name": dom[0], "us": round(dom[1] * 1000, 2)}
         except Exception as ex:  # profiling is informational
