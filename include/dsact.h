@@ -166,7 +166,10 @@ int dsact_apply_update(dsact_handle* h, int64_t iteration);
 int dsact_step(dsact_handle* h, int64_t iteration, uint32_t flags); /* compute_grads + apply_update */
 /* hipGraph path: captures `steps_per_graph` consecutive updates (gather from the index table +
  * step, iteration read from device state) and replays them; dsact_graph_run enqueues n_steps
- * updates starting at `first_iteration` (n_steps % steps_per_graph == 0). */
+ * updates starting at `first_iteration` (n_steps % steps_per_graph == 0). The replay ring must not
+ * be written while a graph runs: inside a graph the minibatch of update s+1 is gathered while
+ * update s is still in flight (it rides in that update's loss launch); results are bit-identical
+ * to the same updates issued one by one. The last update's minibatch stays staged. */
 int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags);
 int dsact_graph_run(dsact_handle* h, int64_t first_iteration, int64_t n_steps);
 
