@@ -12,6 +12,7 @@
 
 #include "../../include/dsact.h"
 #include "dsact_kernels.h"
+#include "dsact_chain.h"
 #include "dsact_conv.h"
 
 using namespace dsact;
@@ -173,6 +174,20 @@ struct dsact_handle {
   // profiling
   bool profiling = false;
   std::vector<ProfRec> prof;
+  // row-slice fused chains (dsact_chain.h): MLP nets, equal hidden widths of 64 / 128 / 256, batch % 16 == 0
+  bool chain_ok = false;
+  int cW = 0, cNT = 0;                  // hidden width, W / 64
+  int c_obs = 0, c_act = 0, CoT = 0;    // chunks: observation / action segment of a first layer, policy outputs (2A)
+  int n_slices = 0;
+  char* pk_ws = nullptr;                // the fragment-major copies
+  float* pk_fwd[N_NET][kMaxLin];        // forward copies per net and layer (index L: output layer)
+  float* pk_bwd[3][kMaxLin];            // q1, q2, policy: W_l^T for l >= 1 (policy: index L = Wout^T)
+  float* pk_w1at[2];                    // q1, q2: (W0[:, F:])^T
+  MirrorDesc* d_mir = nullptr;          // [3 nets][L+1]: what the Adam tiles of each weight tensor refresh
+  PackJob* d_pack = nullptr; int n_pack_jobs = 0, pack_blocks = 0;
+  float* zobs[4];                       // first-layer accumulators after the observation part: q1, q2 (obs), q1_t, q2_t (obs2)
+  float* dAq[2];                        // dL/d new_act through q1 / q2  [B][32]
+  int n_heads_parts = 0;                // partial (tanh, sigma) sums the last forward wrote
   // strict DP
   bool use_std_sums = false;
   bool auto_std_sums = false;
@@ -359,8 +374,10 @@ void carve(dsact_handle* h, Carver& c) {
   h->stats = c.take<float>(16);
   h->ones = c.take<float>(B);
   h->std_sums = c.take<float>(2);
-  h->timeline = c.take<long long>(512 * 8);
+  h->timeline = c.take<long long>(512 * 16);
   h->dw_parts = c.take<float>(h->dw_chunks > 1 ? (size_t)h->dw_chunks * h->dw_part_stride : 4);
+  for (int i = 0; i < 4; ++i) h->zobs[i] = c.take<float>(B * h->w[0]);
+  for (int i = 0; i < 2; ++i) h->dAq[i] = c.take<float>(B * 32);
   h->act_scale = c.take<float>(A);
   h->act_center = c.take<float>(A);
   h->idx_eager = c.take<int>(B);
@@ -458,6 +475,96 @@ int alloc_alt_set(dsact_handle* h) {
   a.Xc[C_PIT] = a.Xc[C_Q1T] = a.Xc[C_Q2T] = a.X2;
   a.Xc[C_Q1P] = a.Xc[C_Q2P] = a.XP;
   return DSACT_OK;
+}
+
+
+// ---- row-slice fused chains: packed copies, mirror descriptors, pack jobs -------------------------------------
+int roundup(int v, int m) { return (v + m - 1) / m * m; }
+
+int build_chain(dsact_handle* h) {
+  if (!h->chain_ok) return DSACT_OK;
+  if (h->pk_ws) return DSACT_OK;   // sized by the configuration, not by the arenas: built once
+  const int L = h->L, W = h->cW, F = h->F, A = h->A;
+  const int tiles = W / 16, CH = W / 16;
+  const int C0q = h->c_obs + h->c_act, C0p = h->c_obs;
+  const int nth_q = 1, nth_p = (2 * A + 15) / 16, nta = (A + 15) / 16;
+  // carve the packed copies
+  for (int pass = 0; pass < 2; ++pass) {
+    Carver c;
+    c.base = pass ? h->pk_ws : nullptr;
+    for (int net = 0; net < N_NET; ++net) {
+      const bool pol = net == N_POL || net == N_POLT;
+      h->pk_fwd[net][0] = c.take<float>((size_t)tiles * (pol ? C0p : C0q) * 256);
+      for (int l = 1; l < L; ++l) h->pk_fwd[net][l] = c.take<float>((size_t)tiles * CH * 256);
+      h->pk_fwd[net][L] = c.take<float>((size_t)(pol ? nth_p : nth_q) * CH * 256);
+    }
+    for (int n3 = 0; n3 < 3; ++n3) {
+      for (int l = 0; l <= L; ++l) h->pk_bwd[n3][l] = nullptr;
+      for (int l = 1; l < L; ++l) h->pk_bwd[n3][l] = c.take<float>((size_t)tiles * CH * 256);
+    }
+    h->pk_bwd[2][L] = c.take<float>((size_t)tiles * h->CoT * 256);
+    for (int i = 0; i < 2; ++i) h->pk_w1at[i] = c.take<float>((size_t)nta * CH * 256);
+    if (!pass) {
+      HIPCHK(h, hipMalloc((void**)&h->pk_ws, c.off + 256));
+      HIPCHK(h, hipMemset(h->pk_ws, 0, c.off + 256));   // the zero padding of every copy is written here, once
+    }
+  }
+  // what the Adam tiles of (q1, q2, policy) x layer refresh
+  const int on3[3] = {N_Q1, N_Q2, N_POL}, tg3[3] = {N_Q1T, N_Q2T, N_POLT};
+  std::vector<MirrorDesc> mir((size_t)3 * (L + 1));
+  for (int n3 = 0; n3 < 3; ++n3)
+    for (int l = 0; l <= L; ++l) {
+      MirrorDesc& m = mir[(size_t)n3 * (L + 1) + l];
+      memset(&m, 0, sizeof(m));
+      const bool pol = n3 == 2;
+      m.fwd = h->pk_fwd[on3[n3]][l]; m.fwd_t = h->pk_fwd[tg3[n3]][l];
+      m.fwd_C = l == 0 ? (pol ? C0p : C0q) : CH;
+      m.F = (l == 0 && !pol) ? F : (1 << 30); m.Fp = 16 * h->c_obs;
+      if (l >= 1 && l < L) { m.bwd = h->pk_bwd[n3][l]; m.bwd_C = CH; m.bwd_k0 = 0; }
+      if (l == 0 && !pol) { m.bwd = h->pk_w1at[n3]; m.bwd_C = CH; m.bwd_k0 = F; }
+      if (l == L && pol) { m.bwd = h->pk_bwd[2][L]; m.bwd_C = h->CoT; m.bwd_k0 = 0; }
+    }
+  HIPCHK(h, hipMalloc((void**)&h->d_mir, mir.size() * sizeof(MirrorDesc)));
+  HIPCHK(h, hipMemcpy(h->d_mir, mir.data(), mir.size() * sizeof(MirrorDesc), hipMemcpyHostToDevice));
+  return DSACT_OK;
+}
+
+// jobs of k_pack: every weight tensor of the six nets -> its packed copies (needs the arenas)
+int build_pack_jobs(dsact_handle* h) {
+  if (!h->chain_ok) return DSACT_OK;
+  const int L = h->L;
+  std::vector<MirrorDesc> mir((size_t)3 * (L + 1));
+  HIPCHK(h, hipMemcpy(mir.data(), h->d_mir, mir.size() * sizeof(MirrorDesc), hipMemcpyDeviceToHost));
+  std::vector<PackJob> jobs;
+  int blocks = 0;
+  for (int net = 0; net < N_NET; ++net) {
+    const NetDesc& d = net_desc(h, net);
+    const bool target = net >= N_Q1T;
+    const int n3 = net % 3;
+    for (int l = 0; l <= L; ++l) {
+      PackJob j;
+      memset(&j, 0, sizeof(j));
+      j.src = net_params(h, net) + d.w_off[l]; j.N = d.out[l]; j.K = d.in[l];
+      j.m = mir[(size_t)n3 * (L + 1) + l];
+      if (target) { j.m.fwd = j.m.fwd_t; j.m.bwd = nullptr; }
+      j.m.fwd_t = nullptr;
+      blocks += (j.N + 15) / 16;
+      j.block_end = blocks;
+      jobs.push_back(j);
+    }
+  }
+  if (h->d_pack) { hipFree(h->d_pack); h->d_pack = nullptr; }
+  HIPCHK(h, hipMalloc((void**)&h->d_pack, jobs.size() * sizeof(PackJob)));
+  HIPCHK(h, hipMemcpy(h->d_pack, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+  h->n_pack_jobs = (int)jobs.size();
+  h->pack_blocks = blocks;
+  return DSACT_OK;
+}
+
+int enqueue_pack(dsact_handle* h) {
+  PackArgs a;
+  a.jobs = h->d_pack; a.n_jobs = h->n_pack_jobs;
+  return launch(h, "pack", k_pack, dim3(h->pack_blocks), dim3(kThreads), 0, a);
 }
 
 int build_tasks(dsact_handle* h) {
@@ -594,6 +701,7 @@ int build_tasks(dsact_handle* h) {
         t.N = kb;
         if (l < L || nb == 1) { t.C0 = g + d.w_off[l] + (size_t)b * hb * kb; t.ldc = kb; }
         else { t.C0 = g + d.w_off[l] + (size_t)b * hb * d.in[l] + (size_t)b * kb; t.ldc = d.in[l]; }  // [[w_mean,0],[0,w_ls]]
+        if (h->d_mir) t.mir = h->d_mir + (size_t)(which - 1) * (L + 1) + l;   // chain mode: packed copies of this tensor
         add_tiles(t);
       }
       // bias: Q = ones
@@ -631,7 +739,7 @@ FusedOpt fused_opt(const dsact_handle* h, bool enable) {
   f.polyak = (float)polyak;
   f.one_minus_polyak = (float)(1.0 - polyak);
   f.auto_alpha = h->cfg.auto_alpha;
-  if (h->mirror_w0 && f.st) {
+  if (h->mirror_w0 && f.st && !h->chain_ok) {
     // merged-gather graph replays: no per-step repack -- the first-layer tiles of the Q nets keep the copies fresh
     const int on[2] = {N_Q1, N_Q2};
     f.mir_n = h->nq;
@@ -980,9 +1088,12 @@ RepackArgs repack_args(const dsact_handle* h, int n_blocks) {
   rp.n_blocks = n_blocks;
   rp.w1at[0] = h->W1aT[0]; rp.w1at[1] = h->W1aT[1]; rp.O = h->F; rp.A = h->A;
   rp.skip_pad = h->use_w1p ? 0 : 1;
+  rp.pk_jobs = nullptr; rp.pk_n_jobs = 0;
+  if (h->chain_ok && n_blocks > 0) { rp.pk_jobs = h->d_pack; rp.pk_n_jobs = h->n_pack_jobs; rp.n_blocks = h->pack_blocks; }
   return rp;
 }
 int repack_blocks(const dsact_handle* h) {
+  if (h->chain_ok) return h->pack_blocks;   // one block per 16 source rows of every weight tensor
   const int total4 = h->use_w1p ? 4 * h->w[0] * h->ldx : 2 * 32 * h->w[0];
   int nb = (total4 + kThreads * 8 - 1) / (kThreads * 8);
   // the repack blocks share the gather launch: keep the launch within one round of workgroups (256 CUs)
@@ -1025,6 +1136,7 @@ int enqueue_prologue(dsact_handle* h, int use_dev, long long it, int advance, in
   a.st = h->st; a.use_dev = use_dev; a.host_it = it; a.advance_counters = advance; a.fill_noise = fill_noise;
   a.hp = step_hyper(h); a.nz = noise_args(h); a.B = h->B; a.A = h->A;
   TRY(launch(h, "prologue", k_prologue, dim3(1), dim3(kThreads), 0, a));
+  if ((fill_noise || !advance) && h->chain_ok) return enqueue_pack(h);   // a forward pass follows: refresh the packed copies
   if (fill_noise || !advance) {  // a forward pass follows: refresh the padded first-layer weights
     const int nb = repack_blocks(h);
     if (nb) TRY(launch(h, "repack", k_repack, dim3(nb), dim3(kThreads), 0, repack_args(h, nb)));
@@ -1061,6 +1173,180 @@ int sum_parts_range(dsact_handle* h, size_t lo, size_t hi) {
   return launch(h, "sum_parts", k_sum_parts, dim3((unsigned)((quads + kThreads - 1) / kThreads)), dim3(kThreads), 0, a);
 }
 
+
+// ---- row-slice fused update (dsact_chain.h) ---------------------------------------------------------------------
+#define CHAIN_NT(CALL)                         \
+  do {                                         \
+    if (h->cNT == 1) { CALL(1); }              \
+    else if (h->cNT == 2) { CALL(2); }         \
+    else { CALL(4); }                          \
+  } while (0)
+
+FwdUnit fwd_unit(const dsact_handle* h, int ch, int seg, int head) {
+  FwdUnit u;
+  memset(&u, 0, sizeof(u));
+  const int net = kChainNet[ch];
+  const NetDesc& d = net_desc(h, net);
+  const float* base = net_params(h, net);
+  for (int l = 0; l <= h->L; ++l) { u.wf[l] = h->pk_fwd[net][l]; u.bias[l] = base + d.b_off[l]; }
+  u.x = h->Xc[ch];
+  u.seg = seg;
+  u.c_act = (net == N_POL || net == N_POLT) ? 0 : h->c_act;
+  if (seg != SEG_OBS_ONLY)
+    for (int l = 0; l < h->L; ++l) { u.H[l] = h->Hb[ch][l]; u.G[l] = h->Gb[ch][l]; }
+  u.head = head;
+  return u;
+}
+
+int launch_chain_fwd(dsact_handle* h, const char* name, FwdArgs& a) {
+  a.n_slices = h->n_slices; a.B = h->B; a.F = h->F; a.A = h->A; a.L = h->L; a.ldx = h->ldx;
+  a.c_obs = h->c_obs; a.c_act = h->c_act; a.v1_stats = 0;
+  a.act_scale = h->act_scale; a.act_center = h->act_center; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
+  a.timeline = tl_for(h, name);
+  const int grid = chain_grid(a.n_units, a.n_slices);
+  const size_t lds = (size_t)chain_lds(16 * (h->c_obs + h->c_act), h->cW).total * sizeof(float);
+#define CALL_CF(N) return launch(h, name, k_chain_fwd<N>, dim3(grid), dim3(kThreads), lds, a)
+  CHAIN_NT(CALL_CF);
+#undef CALL_CF
+}
+
+// group A: policy(obs), policy_target(obs2), q1/q2(obs,act) + observation part of q1_t/q2_t(obs2, .)
+int enqueue_chain_fwd_a(dsact_handle* h) {
+  FwdArgs a;
+  memset(&a, 0, sizeof(a));
+  FwdUnit& pi = a.u[0] = fwd_unit(h, C_PI, SEG_FULL, HEAD_POLICY);
+  pi.logits = h->logits_pi; pi.logp = h->logp_new; pi.eps = h->eps_new; pi.xact = h->Xc[C_Q1P]; pi.part_heads = h->part_heads;
+  FwdUnit& pt = a.u[1] = fwd_unit(h, C_PIT, SEG_FULL, HEAD_POLICY);
+  pt.logits = h->logits_pit; pt.logp = h->logp2; pt.eps = h->eps_2; pt.xact = h->Xc[C_Q1T];
+  for (int i = 0; i < 2; ++i) {
+    FwdUnit& qc = a.u[2 + i] = fwd_unit(h, C_Q1C + i, SEG_FULL_SAVE, HEAD_Q);
+    qc.zsave = h->zobs[i]; qc.qout = h->qout_c[i]; qc.qstd = h->qstd_c[i];
+    FwdUnit& qt = a.u[4 + i] = fwd_unit(h, C_Q1T + i, SEG_OBS_ONLY, HEAD_NONE);
+    qt.zsave = h->zobs[2 + i];
+  }
+  a.n_units = 6;
+  h->n_heads_parts = h->n_slices;
+  return launch_chain_fwd(h, "chain_fwd_a", a);
+}
+
+// group B: q1_t/q2_t(obs2,act2), q1/q2(obs,new_act): saved observation part + action part, hidden layers, heads
+int enqueue_chain_fwd_b(dsact_handle* h) {
+  FwdArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int i = 0; i < 2; ++i) {
+    FwdUnit& qt = a.u[i] = fwd_unit(h, C_Q1T + i, SEG_ACT_FROM_SAVED, HEAD_Q);
+    qt.zinit = h->zobs[2 + i]; qt.qout = h->qout_t[i];
+    for (int l = 0; l < h->L; ++l) qt.G[l] = nullptr;   // never differentiated
+    FwdUnit& qp = a.u[2 + i] = fwd_unit(h, C_Q1P + i, SEG_ACT_FROM_SAVED, HEAD_Q);
+    qp.zinit = h->zobs[i]; qp.qout = h->qout_p[i];
+  }
+  a.n_units = 4;
+  return launch_chain_fwd(h, "chain_fwd_b", a);
+}
+
+// loss + dZ chains of the critics (n_units 2: q1c, q2c only -- off iterations of the delayed update) and of
+// q1/q2(obs,new_act); riders as in the loss launch of the tile path
+int enqueue_chain_bwd_q(dsact_handle* h, int n_units, const RideArgs* ride) {
+  BwdQArgs a;
+  memset(&a, 0, sizeof(a));
+  const int L = h->L;
+  const int chs[4] = {C_Q1C, C_Q2C, C_Q1P, C_Q2P};
+  for (int w = 0; w < n_units; ++w) {
+    BwdQUnit& u = a.u[w];
+    const int net = kChainNet[chs[w]], n3 = net == N_Q1 ? 0 : 1;
+    for (int l = 1; l < L; ++l) u.wb[l] = h->pk_bwd[n3][l];
+    u.wout = net_params(h, net) + h->qd.w_off[L];
+    for (int l = 0; l < L; ++l) { u.G[l] = h->Gb[chs[w]][l]; u.dZ[l] = h->dZ[kDzSlot[chs[w]]][l]; }
+    u.dout = h->dout[w];
+    if (w >= 2) { u.w1at = h->pk_w1at[n3]; u.dA = h->dAq[n3]; }
+    u.which = w;
+  }
+  a.n_units = n_units; a.n_slices = h->n_slices; a.B = h->B; a.A = h->A; a.L = L;
+  for (int i = 0; i < 2; ++i) { a.qout_c[i] = h->qout_c[i]; a.qstd_c[i] = h->qstd_c[i]; a.qout_t[i] = h->qout_t[i]; a.qout_p[i] = h->qout_p[i]; }
+  a.rew = h->rew; a.done = h->done; a.logp2 = h->logp2; a.logp_new = h->logp_new; a.z5 = h->z5; a.z6 = h->z6;
+  a.log_alpha = h->online + h->n_online - 1;
+  a.part_loss = h->part_loss; a.grads_tail = h->grads + h->n_online; a.st = h->st;
+  a.inv_B = 1.0f / (float)h->B;
+  a.inv_Bg = h->use_std_sums ? 1.0f / (float)h->cfg.global_batch : 1.0f / (float)h->B;
+  a.std_sums = h->use_std_sums ? h->std_sums : nullptr;
+  a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.gamma = h->cfg.gamma; a.tau_b = h->cfg.tau_b;
+  a.one_minus_tau_b = (float)(1.0 - dec7(h->cfg.tau_b));
+  a.n_chain_blocks = chain_grid(n_units, h->n_slices);
+  a.timeline = tl_for(h, "chain_bwd_q");
+  if (ride) a.ride = *ride;
+  a.ride.n_loss_blocks = a.n_chain_blocks;
+  const int n_riders = ride ? ride->n_gather + (ride->bookkeeping ? 1 : 0) : 0;
+  const size_t lds = (size_t)chain_lds(h->cW, h->cW).total * sizeof(float);
+#define CALL_CQ(N) return launch(h, "chain_bwd_q", k_chain_bwd_q<N>, dim3(a.n_chain_blocks + n_riders), dim3(kThreads), lds, a)
+  CHAIN_NT(CALL_CQ);
+#undef CALL_CQ
+}
+
+// rsample backward + policy dZ chain; weight-gradient tiles [x0, x1) ride along on the other CUs
+int enqueue_chain_bwd_pi(dsact_handle* h, int x0, int x1, bool fused) {
+  BwdPiArgs a;
+  memset(&a, 0, sizeof(a));
+  const int L = h->L;
+  a.dA[0] = h->dAq[0]; a.dA[1] = h->dAq[1];
+  a.logits_pi = h->logits_pi; a.eps_new = h->eps_new; a.log_alpha = h->online + h->n_online - 1;
+  a.woutT = h->pk_bwd[2][L]; a.CoT = h->CoT;
+  for (int l = 1; l < L; ++l) a.wb[l] = h->pk_bwd[2][l];
+  for (int l = 0; l < L; ++l) { a.G[l] = h->Gb[C_PI][l]; a.dZ[l] = h->dZ[kDzSlot[C_PI]][l]; }
+  a.dout_pi = h->dout_pi; a.d_new_act = h->d_new_act;
+  a.n_slices = h->n_slices; a.B = h->B; a.A = h->A; a.L = L;
+  a.inv_B = 1.0f / (float)h->B; a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed;
+  a.act_scale = h->act_scale; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
+  a.part_loss = h->part_loss; a.n_part = h->B; a.target_entropy = -(float)h->A;
+  a.grad_log_alpha = h->grads + h->n_online - 1;
+  a.n_chain_blocks = h->n_slices;
+  a.timeline = tl_for(h, "chain_bwd_pi");
+  a.extra = h->d_tiles + x0; a.n_extra = x1 > x0 ? x1 - x0 : 0;
+  a.fo = fused_opt(h, fused);
+  size_t lds = (size_t)chain_lds(16 * h->CoT, h->cW).total * sizeof(float);
+  if (a.n_extra && tile_lds_bytes(dw_k(h)) > lds) lds = tile_lds_bytes(dw_k(h));
+#define CALL_CP(N) return launch(h, "chain_bwd_pi", k_chain_bwd_pi<N>, dim3(a.n_chain_blocks + a.n_extra), dim3(kThreads), lds, a)
+  CHAIN_NT(CALL_CP);
+#undef CALL_CP
+}
+
+// same contract as enqueue_grads (phases, fused optimiser, riders of the loss launch)
+int enqueue_grads_chain(dsact_handle* h, bool actor_backward, bool fused, int phase, const RideArgs* ride) {
+  if (phase == 4) goto actor_part;
+  if (phase != 2) {
+    TRY(enqueue_chain_fwd_a(h));
+    TRY(enqueue_chain_fwd_b(h));
+    if (h->use_std_sums) {
+      StdSumArgs s;
+      s.qstd_c[0] = h->qstd_c[0]; s.qstd_c[1] = h->qstd_c[1]; s.B = h->B; s.out = h->std_sums;
+      TRY(launch(h, "std_sums", k_std_sums, dim3(1), dim3(kThreads), 0, s));
+    }
+  }
+  if (phase == 1) return DSACT_OK;
+  TRY(enqueue_chain_bwd_q(h, actor_backward ? 4 : 2, ride));
+  if (!actor_backward) {
+    if (h->dw_chunks == 1) return run_dw(h, h->dw_off[0], h->dw_off[2], fused, fused);
+    TRY(run_dw(h, h->dw_off[0], h->dw_off[2], false, false));
+    if (fused) return enqueue_adam(h, true);
+    return sum_parts(h, 0, (size_t)h->nq * h->n_q);
+  }
+  if (phase == 3) {
+    TRY(run_dw(h, h->dw_off[0], h->dw_off[2], false, false));
+    return sum_parts(h, 0, (size_t)h->nq * h->n_q);
+  }
+actor_part:
+  if (phase == 4) {
+    TRY(enqueue_chain_bwd_pi(h, 0, 0, false));
+    TRY(run_dw(h, h->dw_off[2], h->dw_off[3], false, false));
+    return sum_parts(h, (size_t)h->nq * h->n_q, h->n_online - 1);
+  }
+  // the critics' dW (+ Adam) tiles ride in the policy-backward launch: 16 chain workgroups + 240 idle CUs
+  TRY(enqueue_chain_bwd_pi(h, h->dw_off[0], h->dw_off[2], fused));
+  if (h->dw_chunks == 1) return run_dw(h, h->dw_off[2], h->dw_off[3], fused, fused);
+  TRY(run_dw(h, h->dw_off[2], h->dw_off[3], false, false));
+  if (fused) return enqueue_adam(h, true);
+  return sum_parts(h, 0, h->n_online - 1);
+}
+
 // phase 0: everything; 1: forward part up to the local {sum std1, sum std2} (strict data-parallel mode: the
 // caller all-reduces those two floats); 2: loss + backward (+ fused update);
 // 3 / 4 (data-parallel overlap, unfused): 3 = everything up to and including the critics' gradients (q1 | q2
@@ -1069,6 +1355,7 @@ int sum_parts_range(dsact_handle* h, size_t lo, size_t hi) {
 // `ride` (graph replays with the merged gather): nullptr, or the riders of the loss launch -- this update's
 // bookkeeping and, when ride->n_gather > 0, the next update's gather into the other batch set
 int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 0, const RideArgs* ride = nullptr) {
+  if (h->chain_ok) return enqueue_grads_chain(h, actor_backward, fused, phase, ride);
   const int L = h->L, B = h->B, A = h->A;
   if (phase == 4) goto actor_part;
   if (phase != 2) {
@@ -1402,6 +1689,20 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (const char* v = getenv("DSACT_CONV_DW_NKT")) h->env_conv_dw_nkt = atoi(v);
   h->dw_chunks = (h->B > 448 && h->B % 256 == 0 && getenv("DSACT_NO_SPLITK") == nullptr) ? h->B / 256 : 1;
   h->dw_part_stride = (h->n_online + 2 + 63) & ~(size_t)63;
+  {
+    // row-slice fused chains: MLP nets of DSAC_V2 with equal hidden widths of 64 / 128 / 256, batch a multiple of 16
+    bool ok = !h->cnn && h->nq == 2 && h->B % kChRows == 0 && h->F % 4 == 0 && getenv("DSACT_NO_CHAIN") == nullptr;
+    for (int l = 0; l < h->L; ++l) ok = ok && cfg->hidden[l] == cfg->hidden[0];
+    const int W0 = cfg->hidden[0];
+    ok = ok && (W0 == 64 || W0 == 128 || W0 == 256);
+    h->c_obs = roundup((h->F + 15) / 16, kDc);
+    h->c_act = roundup((h->A + 15) / 16, kDc);
+    h->CoT = roundup((2 * h->A + 15) / 16, kDc);
+    // LDS: input slice + two hidden slices + partial tiles must fit beside nothing else (one workgroup per CU)
+    ok = ok && (size_t)chain_lds(16 * (h->c_obs + h->c_act), W0).total * sizeof(float) <= 150 * 1024;
+    h->chain_ok = ok;
+    h->cW = W0; h->cNT = W0 / 64; h->n_slices = h->B / kChRows;
+  }
   Carver c0;
   carve(h, c0);
   h->ws_bytes = c0.off + 256;
@@ -1452,6 +1753,15 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     HIPCHK(h, hipFuncSetAttribute((const void*)k_heads_bwd<4>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, true, EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_conv_dw<3>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<1>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<2>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<4>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<1>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<2>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<4>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<false, EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<true, EPI_MULG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
   }
@@ -1476,6 +1786,9 @@ int dsact_destroy(dsact_handle* h) {
   if (h->d_tiles) hipFree(h->d_tiles);
   if (h->alt.d_tiles) hipFree(h->alt.d_tiles);
   if (h->alt_ws) hipFree(h->alt_ws);
+  if (h->pk_ws) hipFree(h->pk_ws);
+  if (h->d_mir) hipFree(h->d_mir);
+  if (h->d_pack) hipFree(h->d_pack);
   if (h->idx_table) hipFree(h->idx_table);
   if (h->stage_dev) hipFree(h->stage_dev);
   if (h->stage_img) hipFree(h->stage_img);
@@ -1521,6 +1834,8 @@ int dsact_bind_arenas(dsact_handle* h, float* online, float* target, float* adam
   HIPCHK(h, hipSetDevice(h->device));
   if (h->graph_exec) return fail(h, DSACT_E_STATE, "cannot rebind arenas after dsact_graph_build");
   h->online = online; h->target = target; h->adam_m = adam_m; h->adam_v = adam_v; h->grads = grads;
+  TRY(build_chain(h));
+  TRY(build_pack_jobs(h));
   TRY(build_tasks(h));
   if (!h->cnn) {   // the same task lists over the second batch set
     TRY(alloc_alt_set(h));
@@ -1999,7 +2314,7 @@ int dsact_read_stats(dsact_handle* h, float out[16]) {
   TRY(check_ready(h, false));
   HIPCHK(h, hipSetDevice(h->device));
   StatsArgs a;
-  a.part_loss = h->part_loss; a.n_loss = h->B; a.part_heads = h->part_heads; a.n_heads = h->n_heads_wg;
+  a.part_loss = h->part_loss; a.n_loss = h->B; a.part_heads = h->part_heads; a.n_heads = h->chain_ok ? h->n_heads_parts : h->n_heads_wg;
   a.log_alpha = h->online + h->n_online - 1; a.st = h->st;
   a.inv_B = 1.0f / (float)h->B; a.inv_BA = 1.0f / ((float)h->B * (float)h->A);
   a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.out = h->stats;
@@ -2099,6 +2414,8 @@ int dsact_profile_step(dsact_handle* h, int64_t iteration, uint32_t flags, dsact
   return DSACT_OK;
 }
 
+int dsact_chain_active(const dsact_handle* h) { return h && h->chain_ok ? 1 : 0; }
+
 const char* dsact_debug_names(void) {
   return "X0,XP,X2,rew,done,eps_new,eps_2,z5,z6,logits_pi,logits_pit,logp_new,logp2,"
          "qout_c0,qout_c1,qout_t0,qout_t1,qout_p0,qout_p1,dout0,dout1,dout2,dout3,dout_pi,d_new_act,"
@@ -2122,7 +2439,7 @@ int dsact_debug_read(dsact_handle* h, const char* name, float* out, size_t cap, 
       {"dout0", h->dout[0], 2 * B}, {"dout1", h->dout[1], 2 * B}, {"dout2", h->dout[2], 2 * B}, {"dout3", h->dout[3], 2 * B},
       {"dout_pi", h->dout_pi, B * 2 * A}, {"d_new_act", h->d_new_act, B * A},
       {"part_loss", h->part_loss, (size_t)h->B * kLossPart}, {"part_heads", h->part_heads, (size_t)h->n_heads_wg * 2},
-      {"timeline", (const float*)h->timeline, (size_t)512 * 8 * 2},
+      {"timeline", (const float*)h->timeline, (size_t)512 * 16 * 2},
   };
   for (const E& e : tab) if (s == e.k) { src = e.p; cnt = e.c; }
   if (!src && s.size() > 4 && (s[0] == 'H' || s[0] == 'G' || s.compare(0, 2, "dZ") == 0)) {

@@ -52,6 +52,70 @@ __device__ __forceinline__ void gelu4(const f32x4 z, f32x4& h, f32x4& g) {
   g = vfma4(z, pdf, cdf);
 }
 
+// ---- fragment-major copy of a row-major [N x K] matrix -------------------------------------------------------
+// tiles of 16 rows x chunks of 16 k; inside a (tile, chunk) block lane (g = (k%16)/4, i = n%16) owns the 4 floats
+// k%4 = 0..3 -- exactly the operand of 4 consecutive MFMA steps (k-slot trick, dsact_kernels.h). C = chunks per tile.
+__host__ __device__ inline size_t pk_index(int n, int k, int C) {
+  return (((size_t)(n >> 4) * C + (k >> 4)) * 64 + (size_t)((((k & 15) >> 2) << 4) + (n & 15))) * 4 + (k & 3);
+}
+
+// What the owner of a weight tensor keeps fresh besides the arena (single-GPU fused optimiser: the dW/Adam tile;
+// every other flow: k_pack at the start of the step).
+struct MirrorDesc {
+  float* fwd;      // pack of W [N x K'] (forward chains); K' = k for k < F, Fp + (k - F) beyond (first layer of a Q net:
+  float* fwd_t;    //   observation columns padded to whole chunk groups, action columns behind); fwd_t: target net's copy
+  int fwd_C;
+  int F, Fp;       // F >= K: identity
+  float* bwd;      // pack of (W[:, bwd_k0:])^T  [K - bwd_k0 x N] (backward chains); nullptr: none
+  int bwd_C, bwd_k0;
+};
+
+// one lane's 4 consecutive-k values of row n (k % 4 == 0, all inside one segment) -> the copies
+__device__ __forceinline__ void mirror_store4(const MirrorDesc& m, int n, int k, int K, const f32x4& v, bool target, const f32x4& vt) {
+  if (m.fwd) {
+    const int kk = k < m.F ? k : m.Fp + (k - m.F);
+    const size_t o = pk_index(n, kk, m.fwd_C);
+    if (k + 3 < K) {
+      *(f32x4*)(m.fwd + o) = v;
+      if (target && m.fwd_t) *(f32x4*)(m.fwd_t + o) = vt;
+    } else {
+      for (int e = 0; e < 4 && k + e < K; ++e) { m.fwd[o + e] = v[e]; if (target && m.fwd_t) m.fwd_t[o + e] = vt[e]; }
+    }
+  }
+  if (m.bwd) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = k + e - m.bwd_k0;
+      if (r >= 0 && k + e < K) m.bwd[pk_index(r, n, m.bwd_C)] = v[e];
+    }
+  }
+}
+
+// ---- k_pack: rebuild every packed copy from the arenas (eager flows, start of a graph launch, external writes) ----
+struct PackJob {
+  const float* src; int N, K;   // row-major source (arena)
+  MirrorDesc m;                 // destinations (fwd_t unused: the target nets are jobs of their own)
+  int block_end;                // exclusive end of this job's block range (one block per 16 source rows)
+};
+__device__ __forceinline__ void pack_block(const PackJob* jobs, int n_jobs, int b, int tid) {
+  int ji = 0;
+  for (int q = 0; q + 1 < n_jobs; ++q) if (b >= jobs[q].block_end) ji = q + 1;
+  const PackJob J = jobs[ji];
+  const int n0 = (b - (ji ? jobs[ji - 1].block_end : 0)) * 16;
+  const int kq = (J.K + 3) >> 2;
+  for (int e = tid; e < 16 * kq; e += 256) {
+    const int n = n0 + e / kq, k = (e % kq) * 4;
+    if (n >= J.N) continue;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const float* s = J.src + (size_t)n * J.K + k;
+    if (k + 3 < J.K) v = *(const f32x4u*)s;
+    else for (int c = 0; c < 4 && k + c < J.K; ++c) v[c] = s[c];
+    mirror_store4(J.m, n, k, J.K, v, false, v);
+  }
+}
+struct PackArgs { const PackJob* jobs; int n_jobs; };
+__global__ void __launch_bounds__(256) k_pack(PackArgs a) { pack_block(a.jobs, a.n_jobs, (int)blockIdx.x, threadIdx.x); }
+
 constexpr int kWave = 64;
 constexpr int kThreads = 256;  // 4 waves, one per SIMD
 constexpr int kMaxWidth = 1024;
@@ -236,8 +300,10 @@ struct RepackArgs {
   float* w1at[2];      // action columns of q1 / q2's first layer, TRANSPOSED [32 (j, zero padded)][rows]
   int O, A;            //   (k_heads_bwd forms dL/d new_act from them with coalesced row loads)
   int skip_pad;        // 1: wide first layers (e.g. 3136 conv features): no padded copies, the stages read the arena rows
+  const PackJob* pk_jobs; int pk_n_jobs;   // chain mode (dsact_chain.h): the blocks rebuild the fragment-major copies instead
 };
 __device__ void repack_rows(const RepackArgs& rp, int blk, int tid) {
+  if (rp.pk_jobs) { pack_block(rp.pk_jobs, rp.pk_n_jobs, blk, tid); return; }
   const int per_net = rp.rows * rp.ldp;
   const int total = rp.skip_pad ? 0 : 4 * per_net;
   for (int e = blk * kThreads + tid; e < total; e += rp.n_blocks * kThreads) {
@@ -505,6 +571,7 @@ struct GemmProb {
   int M, N, K;
   int tiles_n;          // n-tiles per m-tile row
   int tile_end;         // exclusive end of this problem's block range inside its stage
+  const MirrorDesc* mir;  // weight-gradient tiles with the fused optimiser: packed copies of the tensor to refresh (or nullptr)
 };
 
 // Optimiser fused into the weight-gradient tiles (single-GPU path): every parameter element is the
@@ -730,6 +797,8 @@ __device__ __forceinline__ void run_tile(const GemmProb& t, int m0, int n0, floa
           if (o_delayed) { ot[e] = polyak_update(fo->target[oi + e], pe, fo->polyak, fo->one_minus_polyak); fo->target[oi + e] = ot[e]; }
         }
       }
+      // fragment-major copies the chain kernels read (dsact_chain.h)
+      if (t.mir) mirror_store4(*t.mir, m, n, t.N, op, o_delayed, ot);
       // first-layer weights of a Q net: refresh the padded / transposed copies (see FusedOpt::mir_*)
       for (int q = 0; q < fo->mir_n; ++q) {
         if (t.C0 != fo->grads + fo->mir_lo[q]) continue;   // uniform: one tensor per problem

@@ -89,6 +89,7 @@ SYMBOLS = [
     ("dsact_read_stats", C.c_int, [_P, _FP]),
     ("dsact_time_steps", C.c_int, [_P, C.c_int64, C.c_int64, C.c_uint32, C.c_int32, _FP]),
     ("dsact_time_stage", C.c_int, [_P, C.c_int32, C.c_int32, _FP, C.POINTER(C.c_double)]),
+    ("dsact_chain_active", C.c_int, [_P]),
     ("dsact_profile_step", C.c_int, [_P, C.c_int64, C.c_uint32, C.POINTER(KernelTime), C.c_int32,
                                      C.POINTER(C.c_int32)]),
     ("dsact_debug_read", C.c_int, [_P, C.c_char_p, _FP, C.c_size_t, C.POINTER(C.c_size_t)]),
