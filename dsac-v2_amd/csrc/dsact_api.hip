@@ -177,7 +177,8 @@ struct dsact_handle {
   // row-slice fused chains (dsact_chain.h): MLP nets, equal hidden widths of 64 / 128 / 256, batch % 16 == 0
   bool chain_ok = false;
   int cW = 0, cNT = 0;                  // hidden width, W / 64
-  int c_obs = 0, c_act = 0, CoT = 0;    // chunks: observation / action segment of a first layer, policy outputs (2A)
+  int s_obs = 0, s_act = 0, SoT = 0;    // stream steps (4 k each): observation / action segment of a first layer, policy outputs (2A)
+  int cRG = 2;                          // row groups of 4 per chain workgroup (8 rows)
   int n_slices = 0;
   char* pk_ws = nullptr;                // the fragment-major copies
   float* pk_fwd[N_NET][kMaxLin];        // forward copies per net and layer (index L: output layer)
@@ -485,8 +486,8 @@ int build_chain(dsact_handle* h) {
   if (!h->chain_ok) return DSACT_OK;
   if (h->pk_ws) return DSACT_OK;   // sized by the configuration, not by the arenas: built once
   const int L = h->L, W = h->cW, F = h->F, A = h->A;
-  const int tiles = W / 16, CH = W / 16;
-  const int C0q = h->c_obs + h->c_act, C0p = h->c_obs;
+  const int tiles = W / 64, SH = W / 4, CH = W / 16;       // style 44: 64-row tiles, k4 steps; style 16: chunks of 16 k
+  const int C0q = h->s_obs + h->s_act, C0p = h->s_obs;
   const int nth_q = 1, nth_p = (2 * A + 15) / 16, nta = (A + 15) / 16;
   // carve the packed copies
   for (int pass = 0; pass < 2; ++pass) {
@@ -495,14 +496,14 @@ int build_chain(dsact_handle* h) {
     for (int net = 0; net < N_NET; ++net) {
       const bool pol = net == N_POL || net == N_POLT;
       h->pk_fwd[net][0] = c.take<float>((size_t)tiles * (pol ? C0p : C0q) * 256);
-      for (int l = 1; l < L; ++l) h->pk_fwd[net][l] = c.take<float>((size_t)tiles * CH * 256);
+      for (int l = 1; l < L; ++l) h->pk_fwd[net][l] = c.take<float>((size_t)tiles * SH * 256);
       h->pk_fwd[net][L] = c.take<float>((size_t)(pol ? nth_p : nth_q) * CH * 256);
     }
     for (int n3 = 0; n3 < 3; ++n3) {
       for (int l = 0; l <= L; ++l) h->pk_bwd[n3][l] = nullptr;
-      for (int l = 1; l < L; ++l) h->pk_bwd[n3][l] = c.take<float>((size_t)tiles * CH * 256);
+      for (int l = 1; l < L; ++l) h->pk_bwd[n3][l] = c.take<float>((size_t)tiles * SH * 256);
     }
-    h->pk_bwd[2][L] = c.take<float>((size_t)tiles * h->CoT * 256);
+    h->pk_bwd[2][L] = c.take<float>((size_t)tiles * h->SoT * 256);
     for (int i = 0; i < 2; ++i) h->pk_w1at[i] = c.take<float>((size_t)nta * CH * 256);
     if (!pass) {
       HIPCHK(h, hipMalloc((void**)&h->pk_ws, c.off + 256));
@@ -518,11 +519,12 @@ int build_chain(dsact_handle* h) {
       memset(&m, 0, sizeof(m));
       const bool pol = n3 == 2;
       m.fwd = h->pk_fwd[on3[n3]][l]; m.fwd_t = h->pk_fwd[tg3[n3]][l];
-      m.fwd_C = l == 0 ? (pol ? C0p : C0q) : CH;
-      m.F = (l == 0 && !pol) ? F : (1 << 30); m.Fp = 16 * h->c_obs;
-      if (l >= 1 && l < L) { m.bwd = h->pk_bwd[n3][l]; m.bwd_C = CH; m.bwd_k0 = 0; }
-      if (l == 0 && !pol) { m.bwd = h->pk_w1at[n3]; m.bwd_C = CH; m.bwd_k0 = F; }
-      if (l == L && pol) { m.bwd = h->pk_bwd[2][L]; m.bwd_C = h->CoT; m.bwd_k0 = 0; }
+      m.fwd_44 = l < L ? 1 : 0;                                   // the output layers are narrow products (style 16)
+      m.fwd_C = l == 0 ? (pol ? C0p : C0q) : (l < L ? SH : CH);
+      m.F = (l == 0 && !pol) ? F : (1 << 30); m.Fp = 4 * h->s_obs;
+      if (l >= 1 && l < L) { m.bwd = h->pk_bwd[n3][l]; m.bwd_44 = 1; m.bwd_C = SH; m.bwd_k0 = 0; }
+      if (l == 0 && !pol) { m.bwd = h->pk_w1at[n3]; m.bwd_44 = 0; m.bwd_C = CH; m.bwd_k0 = F; }
+      if (l == L && pol) { m.bwd = h->pk_bwd[2][L]; m.bwd_44 = 1; m.bwd_C = h->SoT; m.bwd_k0 = 0; }
     }
   HIPCHK(h, hipMalloc((void**)&h->d_mir, mir.size() * sizeof(MirrorDesc)));
   HIPCHK(h, hipMemcpy(h->d_mir, mir.data(), mir.size() * sizeof(MirrorDesc), hipMemcpyHostToDevice));
@@ -1177,9 +1179,9 @@ int sum_parts_range(dsact_handle* h, size_t lo, size_t hi) {
 // ---- row-slice fused update (dsact_chain.h) ---------------------------------------------------------------------
 #define CHAIN_NT(CALL)                         \
   do {                                         \
-    if (h->cNT == 1) { CALL(1); }              \
-    else if (h->cNT == 2) { CALL(2); }         \
-    else { CALL(4); }                          \
+    if (h->cNT == 1) { CALL(1, 2); }           \
+    else if (h->cNT == 2) { CALL(2, 2); }      \
+    else { CALL(4, 2); }                       \
   } while (0)
 
 FwdUnit fwd_unit(const dsact_handle* h, int ch, int seg, int head) {
@@ -1191,7 +1193,7 @@ FwdUnit fwd_unit(const dsact_handle* h, int ch, int seg, int head) {
   for (int l = 0; l <= h->L; ++l) { u.wf[l] = h->pk_fwd[net][l]; u.bias[l] = base + d.b_off[l]; }
   u.x = h->Xc[ch];
   u.seg = seg;
-  u.c_act = (net == N_POL || net == N_POLT) ? 0 : h->c_act;
+  u.s_act = (net == N_POL || net == N_POLT) ? 0 : h->s_act;
   if (seg != SEG_OBS_ONLY)
     for (int l = 0; l < h->L; ++l) { u.H[l] = h->Hb[ch][l]; u.G[l] = h->Gb[ch][l]; }
   u.head = head;
@@ -1200,12 +1202,12 @@ FwdUnit fwd_unit(const dsact_handle* h, int ch, int seg, int head) {
 
 int launch_chain_fwd(dsact_handle* h, const char* name, FwdArgs& a) {
   a.n_slices = h->n_slices; a.B = h->B; a.F = h->F; a.A = h->A; a.L = h->L; a.ldx = h->ldx;
-  a.c_obs = h->c_obs; a.c_act = h->c_act; a.v1_stats = 0;
+  a.s_obs = h->s_obs; a.s_act = h->s_act; a.v1_stats = 0;
   a.act_scale = h->act_scale; a.act_center = h->act_center; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
   a.timeline = tl_for(h, name);
   const int grid = chain_grid(a.n_units, a.n_slices);
-  const size_t lds = (size_t)chain_lds(16 * (h->c_obs + h->c_act), h->cW).total * sizeof(float);
-#define CALL_CF(N) return launch(h, name, k_chain_fwd<N>, dim3(grid), dim3(kThreads), lds, a)
+  const size_t lds = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 4 * h->cRG).total * sizeof(float);
+#define CALL_CF(N, G) return launch(h, name, k_chain_fwd<N, G>, dim3(grid), dim3(64 * N), lds, a)
   CHAIN_NT(CALL_CF);
 #undef CALL_CF
 }
@@ -1218,6 +1220,7 @@ int enqueue_chain_fwd_a(dsact_handle* h) {
   pi.logits = h->logits_pi; pi.logp = h->logp_new; pi.eps = h->eps_new; pi.xact = h->Xc[C_Q1P]; pi.part_heads = h->part_heads;
   FwdUnit& pt = a.u[1] = fwd_unit(h, C_PIT, SEG_FULL, HEAD_POLICY);
   pt.logits = h->logits_pit; pt.logp = h->logp2; pt.eps = h->eps_2; pt.xact = h->Xc[C_Q1T];
+  for (int l = 0; l < h->L; ++l) pt.G[l] = nullptr;   // never differentiated
   for (int i = 0; i < 2; ++i) {
     FwdUnit& qc = a.u[2 + i] = fwd_unit(h, C_Q1C + i, SEG_FULL_SAVE, HEAD_Q);
     qc.zsave = h->zobs[i]; qc.qout = h->qout_c[i]; qc.qstd = h->qstd_c[i];
@@ -1276,8 +1279,8 @@ int enqueue_chain_bwd_q(dsact_handle* h, int n_units, const RideArgs* ride) {
   if (ride) a.ride = *ride;
   a.ride.n_loss_blocks = a.n_chain_blocks;
   const int n_riders = ride ? ride->n_gather + (ride->bookkeeping ? 1 : 0) : 0;
-  const size_t lds = (size_t)chain_lds(h->cW, h->cW).total * sizeof(float);
-#define CALL_CQ(N) return launch(h, "chain_bwd_q", k_chain_bwd_q<N>, dim3(a.n_chain_blocks + n_riders), dim3(kThreads), lds, a)
+  const size_t lds = (size_t)chain_lds(h->cW, h->cW, 4 * h->cRG).total * sizeof(float);
+#define CALL_CQ(N, G) return launch(h, "chain_bwd_q", k_chain_bwd_q<N, G>, dim3(a.n_chain_blocks + n_riders), dim3(kThreads), lds, a)
   CHAIN_NT(CALL_CQ);
 #undef CALL_CQ
 }
@@ -1289,7 +1292,7 @@ int enqueue_chain_bwd_pi(dsact_handle* h, int x0, int x1, bool fused) {
   const int L = h->L;
   a.dA[0] = h->dAq[0]; a.dA[1] = h->dAq[1];
   a.logits_pi = h->logits_pi; a.eps_new = h->eps_new; a.log_alpha = h->online + h->n_online - 1;
-  a.woutT = h->pk_bwd[2][L]; a.CoT = h->CoT;
+  a.woutT = h->pk_bwd[2][L]; a.SoT = h->SoT;
   for (int l = 1; l < L; ++l) a.wb[l] = h->pk_bwd[2][l];
   for (int l = 0; l < L; ++l) { a.G[l] = h->Gb[C_PI][l]; a.dZ[l] = h->dZ[kDzSlot[C_PI]][l]; }
   a.dout_pi = h->dout_pi; a.d_new_act = h->d_new_act;
@@ -1302,9 +1305,9 @@ int enqueue_chain_bwd_pi(dsact_handle* h, int x0, int x1, bool fused) {
   a.timeline = tl_for(h, "chain_bwd_pi");
   a.extra = h->d_tiles + x0; a.n_extra = x1 > x0 ? x1 - x0 : 0;
   a.fo = fused_opt(h, fused);
-  size_t lds = (size_t)chain_lds(16 * h->CoT, h->cW).total * sizeof(float);
+  size_t lds = (size_t)chain_lds(4 * h->SoT, h->cW, 4 * h->cRG).total * sizeof(float);
   if (a.n_extra && tile_lds_bytes(dw_k(h)) > lds) lds = tile_lds_bytes(dw_k(h));
-#define CALL_CP(N) return launch(h, "chain_bwd_pi", k_chain_bwd_pi<N>, dim3(a.n_chain_blocks + a.n_extra), dim3(kThreads), lds, a)
+#define CALL_CP(N, G) return launch(h, "chain_bwd_pi", k_chain_bwd_pi<N, G>, dim3(a.n_chain_blocks + a.n_extra), dim3(kThreads), lds, a)
   CHAIN_NT(CALL_CP);
 #undef CALL_CP
 }
@@ -1691,17 +1694,18 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->dw_part_stride = (h->n_online + 2 + 63) & ~(size_t)63;
   {
     // row-slice fused chains: MLP nets of DSAC_V2 with equal hidden widths of 64 / 128 / 256, batch a multiple of 16
-    bool ok = !h->cnn && h->nq == 2 && h->B % kChRows == 0 && h->F % 4 == 0 && getenv("DSACT_NO_CHAIN") == nullptr;
+    const int R = 4 * h->cRG;
+    bool ok = !h->cnn && h->nq == 2 && h->B % R == 0 && h->F % 4 == 0 && getenv("DSACT_NO_CHAIN") == nullptr;
     for (int l = 0; l < h->L; ++l) ok = ok && cfg->hidden[l] == cfg->hidden[0];
     const int W0 = cfg->hidden[0];
     ok = ok && (W0 == 64 || W0 == 128 || W0 == 256);
-    h->c_obs = roundup((h->F + 15) / 16, kDc);
-    h->c_act = roundup((h->A + 15) / 16, kDc);
-    h->CoT = roundup((2 * h->A + 15) / 16, kDc);
+    h->s_obs = roundup((h->F + 3) / 4, kPD);
+    h->s_act = roundup((h->A + 3) / 4, kPD);
+    h->SoT = roundup((2 * h->A + 3) / 4, kPD);
     // LDS: input slice + two hidden slices + partial tiles must fit beside nothing else (one workgroup per CU)
-    ok = ok && (size_t)chain_lds(16 * (h->c_obs + h->c_act), W0).total * sizeof(float) <= 150 * 1024;
+    ok = ok && (size_t)chain_lds(4 * (h->s_obs + h->s_act), W0, R).total * sizeof(float) <= 150 * 1024;
     h->chain_ok = ok;
-    h->cW = W0; h->cNT = W0 / 64; h->n_slices = h->B / kChRows;
+    h->cW = W0; h->cNT = W0 / 64; h->n_slices = h->B / R;
   }
   Carver c0;
   carve(h, c0);
@@ -1753,15 +1757,15 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     HIPCHK(h, hipFuncSetAttribute((const void*)k_heads_bwd<4>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, true, EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_conv_dw<3>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<2>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<1>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<2>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<4>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<1>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<2>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<4>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<false, EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<true, EPI_MULG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
   }

@@ -52,29 +52,35 @@ __device__ __forceinline__ void gelu4(const f32x4 z, f32x4& h, f32x4& g) {
   g = vfma4(z, pdf, cdf);
 }
 
-// ---- fragment-major copy of a row-major [N x K] matrix -------------------------------------------------------
-// tiles of 16 rows x chunks of 16 k; inside a (tile, chunk) block lane (g = (k%16)/4, i = n%16) owns the 4 floats
-// k%4 = 0..3 -- exactly the operand of 4 consecutive MFMA steps (k-slot trick, dsact_kernels.h). C = chunks per tile.
+// ---- fragment-major ("packed") copies of a row-major [N x K] matrix -------------------------------------------
+// style 16 (v_mfma_f32_16x16x4_f32 operands; the narrow products: output layers, dL/d action):
+//   tiles of 16 rows x chunks of 16 k; inside a (tile, chunk) block lane (g = (k%16)/4, i = n%16) owns the 4 floats
+//   k%4 = 0..3 -- the operand of 4 consecutive MFMA steps (k-slot trick below). C = chunks per tile.
+// style 44 (v_mfma_f32_4x4x1_16b_f32 operands; every full-width layer): lane <-> row n of a 64-row tile, one wave-load
+//   = the 64 rows' 4 consecutive k = 1 KB contiguous: [n/64][k/4][n%64][k%4]. C = k4 steps per tile.
 __host__ __device__ inline size_t pk_index(int n, int k, int C) {
   return (((size_t)(n >> 4) * C + (k >> 4)) * 64 + (size_t)((((k & 15) >> 2) << 4) + (n & 15))) * 4 + (k & 3);
+}
+__host__ __device__ inline size_t pk44_index(int n, int k, int C) {
+  return (((size_t)(n >> 6) * C + (k >> 2)) * 64 + (size_t)(n & 63)) * 4 + (k & 3);
 }
 
 // What the owner of a weight tensor keeps fresh besides the arena (single-GPU fused optimiser: the dW/Adam tile;
 // every other flow: k_pack at the start of the step).
 struct MirrorDesc {
   float* fwd;      // pack of W [N x K'] (forward chains); K' = k for k < F, Fp + (k - F) beyond (first layer of a Q net:
-  float* fwd_t;    //   observation columns padded to whole chunk groups, action columns behind); fwd_t: target net's copy
-  int fwd_C;
+  float* fwd_t;    //   observation columns padded to whole step groups, action columns behind); fwd_t: target net's copy
+  int fwd_C, fwd_44;   // chunks (style 16) or k4 steps (style 44) per tile; fwd_44: 1 = style 44
   int F, Fp;       // F >= K: identity
   float* bwd;      // pack of (W[:, bwd_k0:])^T  [K - bwd_k0 x N] (backward chains); nullptr: none
-  int bwd_C, bwd_k0;
+  int bwd_C, bwd_44, bwd_k0;
 };
 
 // one lane's 4 consecutive-k values of row n (k % 4 == 0, all inside one segment) -> the copies
 __device__ __forceinline__ void mirror_store4(const MirrorDesc& m, int n, int k, int K, const f32x4& v, bool target, const f32x4& vt) {
   if (m.fwd) {
     const int kk = k < m.F ? k : m.Fp + (k - m.F);
-    const size_t o = pk_index(n, kk, m.fwd_C);
+    const size_t o = m.fwd_44 ? pk44_index(n, kk, m.fwd_C) : pk_index(n, kk, m.fwd_C);
     if (k + 3 < K) {
       *(f32x4*)(m.fwd + o) = v;
       if (target && m.fwd_t) *(f32x4*)(m.fwd_t + o) = vt;
@@ -86,7 +92,7 @@ __device__ __forceinline__ void mirror_store4(const MirrorDesc& m, int n, int k,
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int r = k + e - m.bwd_k0;
-      if (r >= 0 && k + e < K) m.bwd[pk_index(r, n, m.bwd_C)] = v[e];
+      if (r >= 0 && k + e < K) m.bwd[m.bwd_44 ? pk44_index(r, n, m.bwd_C) : pk_index(r, n, m.bwd_C)] = v[e];
     }
   }
 }
