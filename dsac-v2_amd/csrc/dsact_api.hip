@@ -151,6 +151,7 @@ struct dsact_handle {
   std::string env_timeline_stage;   // DSACT_TIMELINE_STAGE
   bool env_no_tile64 = false, env_no_hb_ride = false, env_no_merged_gather = false;
   int env_conv_dw_nkt = 1;
+  int env_ride_slots = 0;           // DSACT_RIDE_SLOTS: weight-gradient tiles riding in the policy-backward launch (default: one round)
   bool mirror_w0 = false;      // set while the merged-gather graph is being captured (see FusedOpt::mir_*)
   bool merged_graph = false;   // the captured graph uses the merged-gather flow
   // replay ring
@@ -188,6 +189,9 @@ struct dsact_handle {
   PackJob* d_pack = nullptr; int n_pack_jobs = 0, pack_blocks = 0;
   float* zobs[4];                       // first-layer accumulators after the observation part: q1, q2 (obs), q1_t, q2_t (obs2)
   float* dAq[2];                        // dL/d new_act through q1 / q2  [B][32]
+  float* doutT[3];                      // transposed packs of dL/d(out): q1, q2 [32 x B], policy [roundup32(2A) x B]
+  float* X0t = nullptr;                 // transposed pack of the staged minibatch [roundup32(F+A) x B]
+  int dw2_off[4] = {0, 0, 0, 0};        // tile ranges of q1, q2, policy in the dw2 problem list
   int n_heads_parts = 0;                // partial (tanh, sigma) sums the last forward wrote
   // strict DP
   bool use_std_sums = false;
@@ -379,6 +383,9 @@ void carve(dsact_handle* h, Carver& c) {
   h->dw_parts = c.take<float>(h->dw_chunks > 1 ? (size_t)h->dw_chunks * h->dw_part_stride : 4);
   for (int i = 0; i < 4; ++i) h->zobs[i] = c.take<float>(B * h->w[0]);
   for (int i = 0; i < 2; ++i) h->dAq[i] = c.take<float>(B * 32);
+  for (int i = 0; i < 2; ++i) h->doutT[i] = c.take<float>(B * 32);
+  h->doutT[2] = c.take<float>(B * (size_t)((2 * A + 31) / 32 * 32));
+  h->X0t = c.take<float>(B * (size_t)((h->F + A + 31) / 32 * 32));
   h->act_scale = c.take<float>(A);
   h->act_center = c.take<float>(A);
   h->idx_eager = c.take<int>(B);
@@ -815,6 +822,7 @@ int run_dw(dsact_handle* h, int x0, int x1, bool fused, bool finalize, hipStream
   a.tiles = h->d_tiles + x0; a.n_tiles = x1 > x0 ? x1 - x0 : 0;
   a.fo = fused_opt(h, fused);
   a.finalize = finalize ? 1 : 0;
+  a.timeline = tl_for(h, "dW");
   if (on)
     return launch_on(h, on, "dW", k_stage_table, dim3(a.n_tiles + (finalize ? 1 : 0)), dim3(kThreads), tile_lds_bytes(dw_k(h)), a);
   return launch(h, "dW", k_stage_table, dim3(a.n_tiles + (finalize ? 1 : 0)), dim3(kThreads), tile_lds_bytes(dw_k(h)), a);
@@ -1176,6 +1184,49 @@ int sum_parts_range(dsact_handle* h, size_t lo, size_t hi) {
 }
 
 
+// ---- dw2: weight-gradient tiles on the transposed packs the chain kernels write --------------------------------
+Dw2Args dw2_args(dsact_handle* h, bool fused) {
+  Dw2Args a;
+  memset(&a, 0, sizeof(a));
+  const int L = h->L;
+  const int chs[3] = {C_Q1C, C_Q2C, C_PI};
+  int tiles = 0;
+  for (int n3 = 0; n3 < 3; ++n3) {
+    h->dw2_off[n3] = tiles;
+    const int ch = chs[n3], net = kChainNet[ch], slot = kDzSlot[ch];
+    const NetDesc& d = net_desc(h, net);
+    const long long base = (long long)(net_grads(h, net) - h->grads);
+    for (int l = 0; l <= L; ++l) {
+      DwProb& P = a.p[a.n_prob++];
+      P.At = l < L ? h->dZ[slot][l] : h->doutT[n3];
+      P.Xt = l == 0 ? h->X0t : h->Hb[ch][l - 1];
+      P.M = d.out[l]; P.N = d.in[l];
+      P.w_idx = base + (long long)d.w_off[l]; P.b_idx = base + (long long)d.b_off[l];
+      P.tiles_n = (P.N + 31) / 32;
+      tiles += ((P.M + 31) / 32) * P.tiles_n;
+      P.tile_end = tiles;
+      P.mir = h->d_mir ? h->d_mir + (size_t)n3 * (L + 1) + l : nullptr;
+    }
+  }
+  h->dw2_off[3] = tiles;
+  a.C = h->B / 16;
+  a.ct = a.C < 16 ? a.C : 16;
+  a.n_base = tiles;
+  a.gout = h->dw_chunks > 1 ? h->dw_parts : h->grads;
+  a.part_stride = h->dw_chunks > 1 ? (long long)h->dw_part_stride : 0;
+  a.fo = fused_opt(h, fused);
+  return a;
+}
+
+// base tiles [x0, x1) of every batch range; `finalize`: one extra block closes the update
+int run_dw2(dsact_handle* h, int x0, int x1, bool fused, bool finalize) {
+  if (x1 <= x0 && !finalize) return DSACT_OK;
+  Dw2Launch L;
+  L.a = dw2_args(h, fused);
+  L.tile0 = x0; L.n_tiles = x1 > x0 ? x1 - x0 : 0; L.finalize = finalize ? 1 : 0;
+  return launch(h, "dW", k_dw2, dim3(L.n_tiles + (finalize ? 1 : 0), h->dw_chunks), dim3(kThreads), 0, L);
+}
+
 // ---- row-slice fused update (dsact_chain.h) ---------------------------------------------------------------------
 #define CHAIN_NT(CALL)                         \
   do {                                         \
@@ -1202,7 +1253,7 @@ FwdUnit fwd_unit(const dsact_handle* h, int ch, int seg, int head) {
 
 int launch_chain_fwd(dsact_handle* h, const char* name, FwdArgs& a) {
   a.n_slices = h->n_slices; a.B = h->B; a.F = h->F; a.A = h->A; a.L = h->L; a.ldx = h->ldx;
-  a.s_obs = h->s_obs; a.s_act = h->s_act; a.v1_stats = 0;
+  a.s_obs = h->s_obs; a.s_act = h->s_act; a.v1_stats = 0; a.Cb = h->B / 16;
   a.act_scale = h->act_scale; a.act_center = h->act_center; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
   a.timeline = tl_for(h, name);
   const int grid = chain_grid(a.n_units, a.n_slices);
@@ -1224,6 +1275,7 @@ int enqueue_chain_fwd_a(dsact_handle* h) {
   for (int i = 0; i < 2; ++i) {
     FwdUnit& qc = a.u[2 + i] = fwd_unit(h, C_Q1C + i, SEG_FULL_SAVE, HEAD_Q);
     qc.zsave = h->zobs[i]; qc.qout = h->qout_c[i]; qc.qstd = h->qstd_c[i];
+    if (i == 0) qc.x0t = h->X0t;
     FwdUnit& qt = a.u[4 + i] = fwd_unit(h, C_Q1T + i, SEG_OBS_ONLY, HEAD_NONE);
     qt.zsave = h->zobs[2 + i];
   }
@@ -1261,10 +1313,11 @@ int enqueue_chain_bwd_q(dsact_handle* h, int n_units, const RideArgs* ride) {
     u.wout = net_params(h, net) + h->qd.w_off[L];
     for (int l = 0; l < L; ++l) { u.G[l] = h->Gb[chs[w]][l]; u.dZ[l] = h->dZ[kDzSlot[chs[w]]][l]; }
     u.dout = h->dout[w];
+    if (w < 2) u.doutT = h->doutT[w];
     if (w >= 2) { u.w1at = h->pk_w1at[n3]; u.dA = h->dAq[n3]; }
     u.which = w;
   }
-  a.n_units = n_units; a.n_slices = h->n_slices; a.B = h->B; a.A = h->A; a.L = L;
+  a.n_units = n_units; a.n_slices = h->n_slices; a.B = h->B; a.A = h->A; a.L = L; a.Cb = h->B / 16;
   for (int i = 0; i < 2; ++i) { a.qout_c[i] = h->qout_c[i]; a.qstd_c[i] = h->qstd_c[i]; a.qout_t[i] = h->qout_t[i]; a.qout_p[i] = h->qout_p[i]; }
   a.rew = h->rew; a.done = h->done; a.logp2 = h->logp2; a.logp_new = h->logp_new; a.z5 = h->z5; a.z6 = h->z6;
   a.log_alpha = h->online + h->n_online - 1;
@@ -1295,25 +1348,26 @@ int enqueue_chain_bwd_pi(dsact_handle* h, int x0, int x1, bool fused) {
   a.woutT = h->pk_bwd[2][L]; a.SoT = h->SoT;
   for (int l = 1; l < L; ++l) a.wb[l] = h->pk_bwd[2][l];
   for (int l = 0; l < L; ++l) { a.G[l] = h->Gb[C_PI][l]; a.dZ[l] = h->dZ[kDzSlot[C_PI]][l]; }
-  a.dout_pi = h->dout_pi; a.d_new_act = h->d_new_act;
-  a.n_slices = h->n_slices; a.B = h->B; a.A = h->A; a.L = L;
+  a.dout_pi = h->dout_pi; a.d_new_act = h->d_new_act; a.dout_piT = h->doutT[2];
+  a.n_slices = h->n_slices; a.B = h->B; a.A = h->A; a.L = L; a.Cb = h->B / 16;
   a.inv_B = 1.0f / (float)h->B; a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed;
   a.act_scale = h->act_scale; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
   a.part_loss = h->part_loss; a.n_part = h->B; a.target_entropy = -(float)h->A;
   a.grad_log_alpha = h->grads + h->n_online - 1;
   a.n_chain_blocks = h->n_slices;
   a.timeline = tl_for(h, "chain_bwd_pi");
-  a.extra = h->d_tiles + x0; a.n_extra = x1 > x0 ? x1 - x0 : 0;
-  a.fo = fused_opt(h, fused);
+  a.dw = dw2_args(h, fused);
+  a.tile0 = x0; a.n_extra = x1 > x0 ? x1 - x0 : 0;
   size_t lds = (size_t)chain_lds(4 * h->SoT, h->cW, 4 * h->cRG).total * sizeof(float);
-  if (a.n_extra && tile_lds_bytes(dw_k(h)) > lds) lds = tile_lds_bytes(dw_k(h));
-#define CALL_CP(N, G) return launch(h, "chain_bwd_pi", k_chain_bwd_pi<N, G>, dim3(a.n_chain_blocks + a.n_extra), dim3(kThreads), lds, a)
+  if (lds < kDw2LdsFloats * sizeof(float)) lds = kDw2LdsFloats * sizeof(float);
+#define CALL_CP(N, G) return launch(h, "chain_bwd_pi", k_chain_bwd_pi<N, G>, dim3(a.n_chain_blocks + a.n_extra * h->dw_chunks), dim3(kThreads), lds, a)
   CHAIN_NT(CALL_CP);
 #undef CALL_CP
 }
 
 // same contract as enqueue_grads (phases, fused optimiser, riders of the loss launch)
 int enqueue_grads_chain(dsact_handle* h, bool actor_backward, bool fused, int phase, const RideArgs* ride) {
+  const int* off = h->dw2_off;
   if (phase == 4) goto actor_part;
   if (phase != 2) {
     TRY(enqueue_chain_fwd_a(h));
@@ -1327,25 +1381,29 @@ int enqueue_grads_chain(dsact_handle* h, bool actor_backward, bool fused, int ph
   if (phase == 1) return DSACT_OK;
   TRY(enqueue_chain_bwd_q(h, actor_backward ? 4 : 2, ride));
   if (!actor_backward) {
-    if (h->dw_chunks == 1) return run_dw(h, h->dw_off[0], h->dw_off[2], fused, fused);
-    TRY(run_dw(h, h->dw_off[0], h->dw_off[2], false, false));
+    if (h->dw_chunks == 1) return run_dw2(h, off[0], off[2], fused, fused);
+    TRY(run_dw2(h, off[0], off[2], false, false));
     if (fused) return enqueue_adam(h, true);
     return sum_parts(h, 0, (size_t)h->nq * h->n_q);
   }
   if (phase == 3) {
-    TRY(run_dw(h, h->dw_off[0], h->dw_off[2], false, false));
+    TRY(run_dw2(h, off[0], off[2], false, false));
     return sum_parts(h, 0, (size_t)h->nq * h->n_q);
   }
 actor_part:
   if (phase == 4) {
     TRY(enqueue_chain_bwd_pi(h, 0, 0, false));
-    TRY(run_dw(h, h->dw_off[2], h->dw_off[3], false, false));
+    TRY(run_dw2(h, h->dw2_off[2], h->dw2_off[3], false, false));
     return sum_parts(h, (size_t)h->nq * h->n_q, h->n_online - 1);
   }
-  // the critics' dW (+ Adam) tiles ride in the policy-backward launch: 16 chain workgroups + 240 idle CUs
-  TRY(enqueue_chain_bwd_pi(h, h->dw_off[0], h->dw_off[2], fused));
-  if (h->dw_chunks == 1) return run_dw(h, h->dw_off[2], h->dw_off[3], fused, fused);
-  TRY(run_dw(h, h->dw_off[2], h->dw_off[3], false, false));
+  // the critics' dW (+ Adam) tiles ride in the policy-backward launch on the CUs its 32 chain workgroups leave idle
+  {
+    int ride_end = h->dw2_off[2];
+    if (h->env_ride_slots > 0 && ride_end - h->dw2_off[0] > h->env_ride_slots) ride_end = h->dw2_off[0] + h->env_ride_slots;
+    TRY(enqueue_chain_bwd_pi(h, h->dw2_off[0], ride_end, fused));
+    if (h->dw_chunks == 1) return run_dw2(h, ride_end, h->dw2_off[3], fused, fused);
+    TRY(run_dw2(h, ride_end, h->dw2_off[3], false, false));
+  }
   if (fused) return enqueue_adam(h, true);
   return sum_parts(h, 0, h->n_online - 1);
 }
@@ -1690,12 +1748,14 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->env_no_hb_ride = getenv("DSACT_NO_HB_RIDE") != nullptr;
   h->env_no_merged_gather = getenv("DSACT_NO_MERGED_GATHER") != nullptr;
   if (const char* v = getenv("DSACT_CONV_DW_NKT")) h->env_conv_dw_nkt = atoi(v);
+  if (const char* v = getenv("DSACT_RIDE_SLOTS")) h->env_ride_slots = atoi(v);
   h->dw_chunks = (h->B > 448 && h->B % 256 == 0 && getenv("DSACT_NO_SPLITK") == nullptr) ? h->B / 256 : 1;
   h->dw_part_stride = (h->n_online + 2 + 63) & ~(size_t)63;
   {
     // row-slice fused chains: MLP nets of DSAC_V2 with equal hidden widths of 64 / 128 / 256, batch a multiple of 16
     const int R = 4 * h->cRG;
-    bool ok = !h->cnn && h->nq == 2 && h->B % R == 0 && h->F % 4 == 0 && getenv("DSACT_NO_CHAIN") == nullptr;
+    bool ok = !h->cnn && h->nq == 2 && h->B % R == 0 && h->B % 16 == 0 && (h->B <= 256 || h->B % 256 == 0) && h->F % 4 == 0 &&
+              getenv("DSACT_NO_CHAIN") == nullptr;
     for (int l = 0; l < h->L; ++l) ok = ok && cfg->hidden[l] == cfg->hidden[0];
     const int W0 = cfg->hidden[0];
     ok = ok && (W0 == 64 || W0 == 128 || W0 == 256);
@@ -1841,6 +1901,7 @@ int dsact_bind_arenas(dsact_handle* h, float* online, float* target, float* adam
   TRY(build_chain(h));
   TRY(build_pack_jobs(h));
   TRY(build_tasks(h));
+  if (h->chain_ok) (void)dw2_args(h, false);   // tile ranges of the dw2 problem list
   if (!h->cnn) {   // the same task lists over the second batch set
     TRY(alloc_alt_set(h));
     select_set(h, 1);
@@ -2432,6 +2493,7 @@ int dsact_debug_read(dsact_handle* h, const char* name, float* out, size_t cap, 
   const size_t B = h->B, A = h->A;
   const float* src = nullptr;
   size_t cnt = 0;
+  int unpack_w = 0;
   std::string s(name);
   struct E { const char* k; const float* p; size_t c; };
   const E tab[] = {
@@ -2458,6 +2520,7 @@ int dsact_debug_read(dsact_handle* h, const char* name, float* out, size_t cap, 
         if (kind == "H") src = h->Hb[ch][l];
         else if (kind == "G") src = h->Gb[ch][l];
         else if (kind == "dZ" && kDzSlot[ch] >= 0) src = h->dZ[kDzSlot[ch]][l];
+        unpack_w = h->chain_ok ? h->w[l] : 0;   // chain mode keeps these as transposed packs [feature][batch]
       }
     }
   }
@@ -2475,7 +2538,15 @@ int dsact_debug_read(dsact_handle* h, const char* name, float* out, size_t cap, 
   if (!src) return fail(h, DSACT_E_INVALID, "unknown debug buffer '%s'", name);
   if (cnt > cap) return fail(h, DSACT_E_INVALID, "debug buffer '%s' needs %zu floats, cap %zu", name, cnt, cap);
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipMemcpy(out, src, cnt * sizeof(float), hipMemcpyDeviceToHost));
+  if (unpack_w) {
+    std::vector<float> raw(cnt);
+    HIPCHK(h, hipMemcpy(raw.data(), src, cnt * sizeof(float), hipMemcpyDeviceToHost));
+    const int C = h->B / 16;
+    for (int b = 0; b < h->B; ++b)
+      for (int f = 0; f < unpack_w; ++f) out[(size_t)b * unpack_w + f] = raw[pk_index(f, b, C)];
+  } else {
+    HIPCHK(h, hipMemcpy(out, src, cnt * sizeof(float), hipMemcpyDeviceToHost));
+  }
   *n = cnt;
   return DSACT_OK;
 }

@@ -43,7 +43,6 @@ constexpr int kPD = 16;        // weight steps (4 k of a 64-output tile = 1 KB p
 #define CTL(buf, k) do {} while (0)
 #endif
 
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ---- the weight stream (style-44 tensors: [tile of 64 rows][step][lane][4]) ---------------------------------------
 struct WStr { f32x4 b[kPD]; };
@@ -181,6 +180,172 @@ __host__ __device__ inline ChainLds chain_lds(int k_in /*floats of the widest st
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// dw2: weight / bias gradients + fused Adam / Polyak from TRANSPOSED fragment-major operands
+//   dW[m][n] = sum_b dZ[b][m] X[b][n]: the chain kernels leave dZ^T, H^T, X0^T as style-16 packs [feature][batch]
+//   (16-byte stores from their lane = feature layout), so a tile streams its MFMA operands L2 -> registers: no LDS
+//   staging, no transposition, tile descriptors in the kernel arguments. A 256-thread workgroup owns a 32x32 block;
+//   the batch contraction of the tile (<= 16 chunks of 16 rows) is split over the 4 waves, each multiplying the whole
+//   block (2x2 MFMA tiles, 4 KB of operands per 16 MFMAs = 32 B/clk per CU); the 4 partial blocks meet in LDS and
+//   wave w finishes 16x16 block w (Adam, Polyak, packed weight mirrors exactly as the tile path's epilogue).
+//   Tiles of the first column (n0 == 0) also reduce the bias gradient from the dZ^T fragments they hold.
+// ---------------------------------------------------------------------------------------------------------------
+struct DwProb {
+  const float* At; const float* Xt;   // style-16 packs, C chunks per row tile: [M_pad x B] (output features), [N_pad x B] (inputs)
+  long long w_idx, b_idx;             // arena index of W[0][0] and bias[0] (gradient, parameter, moment and target arenas mirror each other)
+  int M, N;
+  int tiles_n, tile_end;              // 32-wide column tiles; exclusive end of this problem's tile range
+  const MirrorDesc* mir;
+};
+constexpr int kMaxDwProb = 3 * (kChMaxL + 1);
+struct Dw2Args {
+  DwProb p[kMaxDwProb]; int n_prob;
+  int C, ct;              // chunks (16 batch rows) per operand row tile; chunks per tile (<= 16)
+  int n_base;             // tiles of one batch range (split-K: tile index = range * n_base + base tile)
+  float* gout;            // gradient destination arena (grads; split-K: partial arena 0)
+  long long part_stride;  // split-K: floats between the partial arenas
+  FusedOpt fo;            // fo.st == nullptr: plain gradient store
+};
+constexpr int kDw2LdsFloats = 4 * 4 * 64 * 4 + 4 * 2 * 64;
+
+__device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, g = lane >> 4, lane4 = lane * 4;
+  const int range = t / a.n_base, bt = t - range * a.n_base;
+  int pi = 0;
+#pragma unroll
+  for (int q = 0; q + 1 < kMaxDwProb; ++q)
+    if (q + 1 < a.n_prob && bt >= a.p[q].tile_end) pi = q + 1;
+  const DwProb& P = a.p[pi];
+  const int local = bt - (pi ? a.p[pi - 1].tile_end : 0);
+  const int mt = local / P.tiles_n, nt = local - mt * P.tiles_n;
+  const int m0 = 32 * mt, n0 = 32 * nt;
+  // ---- operand fragments of this wave's share of the contraction: chunks c_lo + wave*cw + q
+  const int cw = (a.ct + 3) >> 2;
+  const int c_lo = range * a.ct;
+  f32x4 fa[4][2], fx[4][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool ok = q < cw && wave * cw + q < a.ct;
+    const int c = c_lo + (ok ? wave * cw + q : 0);
+#pragma unroll
+    for (int b2 = 0; b2 < 2; ++b2) {
+      fa[q][b2] = gload4(P.At + ((size_t)(2 * mt + b2) * a.C + c) * 256 + lane4);
+      fx[q][b2] = gload4(P.Xt + ((size_t)(2 * nt + b2) * a.C + c) * 256 + lane4);
+    }
+  }
+  // ---- this lane's share of the epilogue: 16x16 block (wave>>1, wave&1), rows m, columns n .. n+3
+  const int m = m0 + 16 * (wave >> 1) + i, n = n0 + 16 * (wave & 1) + 4 * g;
+  const bool in_range = m < P.M && n < P.N, full = n + 3 < P.N;
+  const bool fused = a.fo.st != nullptr;
+  const long long oi = P.w_idx + (long long)m * P.N + n;
+  bool o_delayed = false, o_upd = false;
+  float o_ss = 0.f, o_bc2 = 1.f;
+  f32x4 op = {0.f, 0.f, 0.f, 0.f}, om = op, ov = op, ot = op;
+  if (fused) {
+    o_delayed = a.fo.st->do_delayed != 0;
+    const bool is_q = P.w_idx < a.fo.n_q2;
+    o_upd = is_q || o_delayed;
+    o_ss = is_q ? a.fo.st->ss_q : a.fo.st->ss_pi;
+    o_bc2 = is_q ? a.fo.st->bc2_q : a.fo.st->bc2_pi;
+    if (o_upd && in_range && full) {
+      op = *(const f32x4u*)(a.fo.online + oi); om = *(const f32x4u*)(a.fo.adam_m + oi); ov = *(const f32x4u*)(a.fo.adam_v + oi);
+      if (o_delayed) ot = *(const f32x4u*)(a.fo.target + oi);
+    }
+  }
+  // ---- MFMA: D[row = input feature 4g+reg][col = output feature i]
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int bm = 0; bm < 2; ++bm)
+#pragma unroll
+    for (int bn = 0; bn < 2; ++bn) acc[bm][bn] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float sb[2] = {0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q < cw && wave * cw + q < a.ct) {   // wave-uniform
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int bm = 0; bm < 2; ++bm)
+#pragma unroll
+          for (int bn = 0; bn < 2; ++bn)
+            acc[bm][bn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fx[q][bn][e], fa[q][bm][e], acc[bm][bn], 0, 0, 0);
+#pragma unroll
+      for (int bm = 0; bm < 2; ++bm) sb[bm] += (fa[q][bm][0] + fa[q][bm][1]) + (fa[q][bm][2] + fa[q][bm][3]);
+    }
+  }
+  // ---- partial blocks -> LDS -> block `wave`
+  const bool bias = nt == 0 && P.b_idx >= 0;
+#pragma unroll
+  for (int bm = 0; bm < 2; ++bm)
+#pragma unroll
+    for (int bn = 0; bn < 2; ++bn) *(f32x4*)(lds + ((wave * 4 + 2 * bm + bn) * 64 + lane) * 4) = acc[bm][bn];
+  if (bias) { lds[4096 + (wave * 2 + 0) * 64 + lane] = sb[0]; lds[4096 + (wave * 2 + 1) * 64 + lane] = sb[1]; }
+  lds_barrier();
+  f32x4 v = *(const f32x4*)(lds + ((0 * 4 + wave) * 64 + lane) * 4);
+#pragma unroll
+  for (int w = 1; w < 4; ++w) v += *(const f32x4*)(lds + ((w * 4 + wave) * 64 + lane) * 4);
+  float* C = a.gout + range * a.part_stride;
+  if (in_range) {
+    float* c0 = C + oi;
+    if (full) *(f32x4u*)c0 = v;
+    else for (int e = 0; e < 4 && n + e < P.N; ++e) c0[e] = v[e];
+    if (fused && o_upd) {
+      if (full) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float pe = op[e], me = om[e], ve = ov[e];
+          adam_update(pe, me, ve, v[e], a.fo.b1w, a.fo.beta2, a.fo.b2w, o_ss, o_bc2, a.fo.eps);
+          op[e] = pe; om[e] = me; ov[e] = ve;
+          if (o_delayed) ot[e] = polyak_update(ot[e], pe, a.fo.polyak, a.fo.one_minus_polyak);
+        }
+        *(f32x4u*)(a.fo.online + oi) = op; *(f32x4u*)(a.fo.adam_m + oi) = om; *(f32x4u*)(a.fo.adam_v + oi) = ov;
+        if (o_delayed) *(f32x4u*)(a.fo.target + oi) = ot;
+      } else {
+        for (int e = 0; e < 4 && n + e < P.N; ++e) {
+          float pe = a.fo.online[oi + e], me = a.fo.adam_m[oi + e], ve = a.fo.adam_v[oi + e];
+          adam_update(pe, me, ve, v[e], a.fo.b1w, a.fo.beta2, a.fo.b2w, o_ss, o_bc2, a.fo.eps);
+          a.fo.online[oi + e] = pe; a.fo.adam_m[oi + e] = me; a.fo.adam_v[oi + e] = ve;
+          op[e] = pe;
+          if (o_delayed) { ot[e] = polyak_update(a.fo.target[oi + e], pe, a.fo.polyak, a.fo.one_minus_polyak); a.fo.target[oi + e] = ot[e]; }
+        }
+      }
+      if (P.mir) mirror_store4(*P.mir, m, n, P.N, op, o_delayed, ot);
+    }
+  }
+  // ---- bias gradient of rows m0 .. m0+31: sum of the 4 waves' x 4 lane groups' row sums
+  if (bias && tid < 32) {
+    const int mb = m0 + tid;
+    if (mb < P.M) {
+      float sbias = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) sbias += lds[4096 + (w * 2 + (tid >> 4)) * 64 + gg * 16 + (tid & 15)];
+      const long long bi = P.b_idx + mb;
+      C[bi] = sbias;
+      if (fused && o_upd) {
+        float pe = a.fo.online[bi], me = a.fo.adam_m[bi], ve = a.fo.adam_v[bi];
+        adam_update(pe, me, ve, sbias, a.fo.b1w, a.fo.beta2, a.fo.b2w, o_ss, o_bc2, a.fo.eps);
+        a.fo.online[bi] = pe; a.fo.adam_m[bi] = me; a.fo.adam_v[bi] = ve;
+        if (o_delayed) a.fo.target[bi] = polyak_update(a.fo.target[bi], pe, a.fo.polyak, a.fo.one_minus_polyak);
+      }
+    }
+  }
+}
+
+// grid (n_tiles [+ 1], batch ranges): base tiles tile0 .. tile0 + n_tiles - 1 of every range; the extra block closes the update
+struct Dw2Launch { Dw2Args a; int tile0, n_tiles, finalize; };
+__global__ void __launch_bounds__(kThreads) k_dw2(Dw2Launch L) {
+  __shared__ __attribute__((aligned(16))) float lds[kDw2LdsFloats];
+  if ((int)blockIdx.x >= L.n_tiles) {
+    if (L.finalize && blockIdx.y == 0 && threadIdx.x == 0) finalize_update(L.a.fo);
+    return;
+  }
+  dw2_tile(L.a, (int)blockIdx.y * L.a.n_base + L.tile0 + (int)blockIdx.x, lds);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k_chain_fwd
 // ---------------------------------------------------------------------------------------------------------------
 enum : int { SEG_FULL = 0, SEG_OBS_ONLY = 1, SEG_ACT_FROM_SAVED = 2, SEG_FULL_SAVE = 3 };
@@ -193,7 +358,8 @@ struct FwdUnit {
   int seg;                          // SEG_*
   int s_act;                        // steps of this net's action segment (0: policy nets)
   float* zsave; const float* zinit; // [B][W] first-layer accumulators after the observation part
-  float* H[kChMaxL]; float* G[kChMaxL];   // gelu(z), gelu'(z) per layer; nullptr: not kept
+  float* H[kChMaxL]; float* G[kChMaxL];   // gelu(z), gelu'(z) per layer, TRANSPOSED style-16 packs [feature][batch]; nullptr: not kept
+  float* x0t;                       // transposed pack of the staged input rows [F+A][batch] (one unit writes it), or nullptr
   int head;                         // HEAD_*
   float* logits; float* logp; const float* eps;   // policy head: [B][2A], [B], [B][A]
   float* xact; float* xact2;        // policy head: rows whose action columns (at F) receive the sampled action
@@ -205,6 +371,7 @@ struct FwdArgs {
   FwdUnit u[kMaxFwdUnits];
   int n_units, n_slices;
   int B, F, A, L, ldx;
+  int Cb;                           // B / 16: chunks per row tile of the transposed packs
   int s_obs, s_act;                 // steps of the first layer's observation segment / widest action segment (multiples of kPD)
   int v1_stats;
   const float* act_scale; const float* act_center; float lo_ls, hi_ls;
@@ -294,6 +461,17 @@ __global__ void __launch_bounds__(64 * NW) k_chain_fwd(FwdArgs a) {
   }
   lds_barrier();
   CTL(a.timeline, 1);
+  if (u.x0t) {   // the dW tiles of every first layer read the minibatch as [input feature][batch]
+    const int K0 = F + (do_act ? A : 0);
+    for (int e = tid; e < K0 * RG; e += NTHR) {
+      const int k = e / RG, g4 = e % RG;
+      const int kk = k < F ? k : 4 * a.s_obs + (k - F);
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = lds[xin + (4 * g4 + r) * S.ld_in + kk];
+      *(f32x4*)(u.x0t + pk_index(k, row0 + 4 * g4, a.Cb)) = v;
+    }
+  }
   const int xs_in = xin + (lane & 3) * S.ld_in;
   // ---- first layer
   const bool more = L > 1;
@@ -328,11 +506,9 @@ __global__ void __launch_bounds__(64 * NW) k_chain_fwd(FwdArgs a) {
       f32x4 hv, gd;
       gelu4(z, hv, gd);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        lds[hn + (4 * g + r) * S.ld_h + n] = hv[r];
-        if (u.H[l]) u.H[l][(size_t)(row0 + 4 * g + r) * W + n] = hv[r];
-        if (u.G[l]) u.G[l][(size_t)(row0 + 4 * g + r) * W + n] = gd[r];
-      }
+      for (int r = 0; r < 4; ++r) lds[hn + (4 * g + r) * S.ld_h + n] = hv[r];
+      if (u.H[l]) *(f32x4*)(u.H[l] + pk_index(n, row0 + 4 * g, a.Cb)) = hv;   // rows row0+4g .. +3 of feature n: 16 contiguous bytes
+      if (u.G[l]) *(f32x4*)(u.G[l] + pk_index(n, row0 + 4 * g, a.Cb)) = gd;
       acc[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = acc[g][0];
     }
     lds_barrier();
@@ -404,16 +580,17 @@ __global__ void __launch_bounds__(64 * NW) k_chain_fwd(FwdArgs a) {
 struct BwdQUnit {
   const float* wb[kChMaxL];        // style-44 packed W_l^T, l = 1..L-1
   const float* wout;               // row-major output layer [2][W] of this chain's net
-  const float* G[kChMaxL];         // gelu' of this chain
-  float* dZ[kChMaxL];
+  const float* G[kChMaxL];         // gelu' of this chain, transposed pack [feature][batch]
+  float* dZ[kChMaxL];              // transposed packs [feature][batch]
   float* dout;                     // [B][2]
+  float* doutT;                    // transposed pack of dout [2 (16-row tile)][batch] (critic chains: operand of the output layer's dW)
   const float* w1at; float* dA;    // actor chains: style-16 packed (W0[:, F:])^T [16*nta x W], dL/d new_act partial [B][32]
   int which;                       // 0 q1c, 1 q2c, 2 q1p, 3 q2p
 };
 struct BwdQArgs {
   BwdQUnit u[4];
   int n_units, n_slices;
-  int B, A, L;
+  int B, A, L, Cb;
   // loss inputs (dsac_v2.py:218-318), as k_loss
   const float* qout_c[2]; const float* qstd_c[2]; const float* qout_t[2]; const float* qout_p[2];
   const float* rew; const float* done; const float* logp2; const float* logp_new; const float* z5; const float* z6;
@@ -456,16 +633,14 @@ __global__ void __launch_bounds__(256) k_chain_bwd_q(BwdQArgs a) {
     s1 = wave_sum(s1); s2 = wave_sum(s2);
     if (lane == 0) { sc[wave] = s1; sc[4 + wave] = s2; }
   }
-  // this thread's share of the output-layer backward: row m, hidden units [R*j, R*j + R)
+  // row phase: TPR consecutive lanes per batch row
   const int m = tid / TPR, j = tid % TPR;
   const int r = row0 + m;
-  f32x4 w0v[RG], w1v[RG], gv[RG];
+  // lane = hidden unit n for the output-layer backward: Wout[:, n], gelu'(z_last)[rows][n]
+  const float wo0 = u.wout[n], wo1 = u.wout[W + n];
+  f32x4 gl[RG];
 #pragma unroll
-  for (int q = 0; q < RG; ++q) {
-    const int k = R * j + 4 * q;
-    w0v[q] = gload4(u.wout + k); w1v[q] = gload4(u.wout + W + k);
-    gv[q] = gload4(u.G[L - 1] + (size_t)r * W + k);
-  }
+  for (int g = 0; g < RG; ++g) gl[g] = gload4(u.G[L - 1] + pk_index(n, row0 + 4 * g, a.Cb));
   const float q1 = a.qout_c[0][2 * r], q2 = a.qout_c[1][2 * r];
   const float std1 = a.qstd_c[0][2 * r], sg1 = a.qstd_c[0][2 * r + 1];
   const float std2 = a.qstd_c[1][2 * r], sg2 = a.qstd_c[1][2 * r + 1];
@@ -506,6 +681,8 @@ __global__ void __launch_bounds__(256) k_chain_bwd_q(BwdQArgs a) {
   else { d0 = -(1.0f - wq1) * a.inv_B; d1 = 0.0f; }
   if (j == 0) {
     u.dout[2 * r] = d0; u.dout[2 * r + 1] = d1;
+    sc[16 + 2 * m] = d0; sc[16 + 2 * m + 1] = d1;
+    if (u.doutT) { u.doutT[pk_index(0, r, a.Cb)] = d0; u.doutT[pk_index(1, r, a.Cb)] = d1; }
     if (u.which == 0) {
       float* pl = a.part_loss + (size_t)r * kLossPart;
       pl[0] = c1.loss; pl[1] = c2.loss; pl[2] = q1; pl[3] = q2; pl[4] = std1; pl[5] = std2;
@@ -516,15 +693,16 @@ __global__ void __launch_bounds__(256) k_chain_bwd_q(BwdQArgs a) {
       if (r == 0) { a.grads_tail[0] = ms1; a.grads_tail[1] = ms2; }
     }
   }
-  // ---- dZ of the last hidden layer: (dOut . Wout) * gelu'
+  lds_barrier();
+  // ---- dZ of the last hidden layer: (dOut . Wout) * gelu'   (lane = hidden unit, registers = batch rows)
 #pragma unroll
-  for (int q = 0; q < RG; ++q) {
-    const int k = R * j + 4 * q;
+  for (int g = 0; g < RG; ++g) {
     f32x4 ov;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) ov[e] = (d0 * w0v[q][e] + d1 * w1v[q][e]) * gv[q][e];
-    *(f32x4*)(lds + S.off_h0 + m * S.ld_h + k) = ov;
-    *(f32x4*)(u.dZ[L - 1] + (size_t)r * W + k) = ov;
+    for (int rr = 0; rr < 4; ++rr) ov[rr] = (sc[16 + 2 * (4 * g + rr)] * wo0 + sc[16 + 2 * (4 * g + rr) + 1] * wo1) * gl[g][rr];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) lds[S.off_h0 + (4 * g + rr) * S.ld_h + n] = ov[rr];
+    *(f32x4*)(u.dZ[L - 1] + pk_index(n, row0 + 4 * g, a.Cb)) = ov;
   }
   NarrowFrags<2> af;
   const int nta = (a.A + 15) >> 4;
@@ -539,9 +717,7 @@ __global__ void __launch_bounds__(256) k_chain_bwd_q(BwdQArgs a) {
     for (int g = 0; g < RG; ++g) { acc[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = acc[g][0]; }
     f32x4 gq[RG];
 #pragma unroll
-    for (int g = 0; g < RG; ++g)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) gq[g][rr] = u.G[l - 1][(size_t)(row0 + 4 * g + rr) * W + n];
+    for (int g = 0; g < RG; ++g) gq[g] = gload4(u.G[l - 1] + pk_index(n, row0 + 4 * g, a.Cb));
     const bool has_nxt = l > 1;
     gemm44_seg<RG>(ws, u.wb[l] + (size_t)wave * SH * 256, 0, SH, u.wb[has_nxt ? l - 1 : l] + (size_t)wave * SH * 256, 0, has_nxt,
                    lds, (cur ? S.off_h1 : S.off_h0) + (lane & 3) * S.ld_h, S.ld_h, lane4, acc);
@@ -552,10 +728,8 @@ __global__ void __launch_bounds__(256) k_chain_bwd_q(BwdQArgs a) {
     for (int g = 0; g < RG; ++g) {
       const f32x4 dz = (acc[g][0] + acc[g][1]) * gq[g];
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        lds[hn + (4 * g + rr) * S.ld_h + n] = dz[rr];
-        u.dZ[l - 1][(size_t)(row0 + 4 * g + rr) * W + n] = dz[rr];
-      }
+      for (int rr = 0; rr < 4; ++rr) lds[hn + (4 * g + rr) * S.ld_h + n] = dz[rr];
+      *(f32x4*)(u.dZ[l - 1] + pk_index(n, row0 + 4 * g, a.Cb)) = dz;
     }
     cur ^= 1;
     lds_barrier();
@@ -578,25 +752,26 @@ struct BwdPiArgs {
   const float* logits_pi; const float* eps_new; const float* log_alpha;
   const float* woutT; int SoT;     // style-44 packed Wout_pi^T [W x 4*SoT]
   const float* wb[kChMaxL];        // style-44 packed policy layers (transposed)
-  const float* G[kChMaxL];
+  const float* G[kChMaxL];         // transposed packs [feature][batch]
   float* dZ[kChMaxL];
   float* dout_pi; float* d_new_act;
-  int n_slices, B, A, L;
+  float* dout_piT;                 // transposed pack of dout_pi [2A (16-row tiles)][batch]
+  int n_slices, B, A, L, Cb;
   float inv_B; int auto_alpha; float alpha_fixed;
   const float* act_scale; float lo_ls, hi_ls;
   const float* part_loss; int n_part; float target_entropy; float* grad_log_alpha;
   int n_chain_blocks;
-  const GemmProb* extra; int n_extra;
+  int tile0, n_extra;              // riders: weight-gradient tiles [tile0, tile0 + n_extra) of `dw`
   long long* timeline;
-  FusedOpt fo;
+  Dw2Args dw;
 };
 
 template <int NW, int RG>
 __global__ void __launch_bounds__(256) k_chain_bwd_pi(BwdPiArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if ((int)blockIdx.x >= a.n_chain_blocks) {
-    const GemmProb gp = a.extra[blockIdx.x - a.n_chain_blocks];
-    run_tile<true, true, EPI_STORE>(gp, gp.tiles_n, gp.tile_end, lds, nullptr, 0, &a.fo);
+    const int idx = (int)blockIdx.x - a.n_chain_blocks;
+    dw2_tile(a.dw, (idx / a.n_extra) * a.dw.n_base + a.tile0 + idx % a.n_extra, lds);
     return;
   }
   const int slice = (int)blockIdx.x;
@@ -638,6 +813,8 @@ __global__ void __launch_bounds__(256) k_chain_bwd_pi(BwdPiArgs a) {
     tanh_gauss_bwd(mu, raw, a.eps_new[(size_t)r * A + d], a.act_scale[d], a.lo_ls, a.hi_ls, dA, alpha * a.inv_B, dmu, draw);
     a.dout_pi[(size_t)r * 2 * A + d] = dmu;
     a.dout_pi[(size_t)r * 2 * A + A + d] = draw;
+    a.dout_piT[pk_index(d, r, a.Cb)] = dmu;
+    a.dout_piT[pk_index(A + d, r, a.Cb)] = draw;
     a.d_new_act[(size_t)r * A + d] = dA;
     xdo[m * S.ld_in + d] = dmu;
     xdo[m * S.ld_in + A + d] = draw;
@@ -651,9 +828,7 @@ __global__ void __launch_bounds__(256) k_chain_bwd_pi(BwdPiArgs a) {
     for (int g = 0; g < RG; ++g) { acc[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = acc[g][0]; }
     f32x4 gq[RG];
 #pragma unroll
-    for (int g = 0; g < RG; ++g)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) gq[g][rr] = a.G[L - 1][(size_t)(row0 + 4 * g + rr) * W + n];
+    for (int g = 0; g < RG; ++g) gq[g] = gload4(a.G[L - 1] + pk_index(n, row0 + 4 * g, a.Cb));
     const bool has_nxt = L > 1;
     gemm44_seg<RG>(ws, wo, 0, a.SoT, has_nxt ? a.wb[L - 1] + (size_t)wave * SH * 256 : wo, 0, has_nxt,
                    lds, S.off_in + (lane & 3) * S.ld_in, S.ld_in, lane4, acc);
@@ -661,10 +836,8 @@ __global__ void __launch_bounds__(256) k_chain_bwd_pi(BwdPiArgs a) {
     for (int g = 0; g < RG; ++g) {
       const f32x4 dz = (acc[g][0] + acc[g][1]) * gq[g];
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        lds[S.off_h0 + (4 * g + rr) * S.ld_h + n] = dz[rr];
-        a.dZ[L - 1][(size_t)(row0 + 4 * g + rr) * W + n] = dz[rr];
-      }
+      for (int rr = 0; rr < 4; ++rr) lds[S.off_h0 + (4 * g + rr) * S.ld_h + n] = dz[rr];
+      *(f32x4*)(a.dZ[L - 1] + pk_index(n, row0 + 4 * g, a.Cb)) = dz;
     }
     lds_barrier();
     CTL(a.timeline, 2);
@@ -675,9 +848,7 @@ __global__ void __launch_bounds__(256) k_chain_bwd_pi(BwdPiArgs a) {
     for (int g = 0; g < RG; ++g) { acc[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = acc[g][0]; }
     f32x4 gq[RG];
 #pragma unroll
-    for (int g = 0; g < RG; ++g)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) gq[g][rr] = a.G[l - 1][(size_t)(row0 + 4 * g + rr) * W + n];
+    for (int g = 0; g < RG; ++g) gq[g] = gload4(a.G[l - 1] + pk_index(n, row0 + 4 * g, a.Cb));
     const bool has_nxt = l > 1;
     gemm44_seg<RG>(ws, a.wb[l] + (size_t)wave * SH * 256, 0, SH, a.wb[has_nxt ? l - 1 : l] + (size_t)wave * SH * 256, 0, has_nxt,
                    lds, (cur ? S.off_h1 : S.off_h0) + (lane & 3) * S.ld_h, S.ld_h, lane4, acc);
@@ -686,10 +857,8 @@ __global__ void __launch_bounds__(256) k_chain_bwd_pi(BwdPiArgs a) {
     for (int g = 0; g < RG; ++g) {
       const f32x4 dz = (acc[g][0] + acc[g][1]) * gq[g];
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        lds[hn + (4 * g + rr) * S.ld_h + n] = dz[rr];
-        a.dZ[l - 1][(size_t)(row0 + 4 * g + rr) * W + n] = dz[rr];
-      }
+      for (int rr = 0; rr < 4; ++rr) lds[hn + (4 * g + rr) * S.ld_h + n] = dz[rr];
+      *(f32x4*)(a.dZ[l - 1] + pk_index(n, row0 + 4 * g, a.Cb)) = dz;
     }
     cur ^= 1;
     if (l > 1) lds_barrier();

@@ -990,6 +990,7 @@ struct TableArgs {
   const GemmProb* tiles; int n_tiles;
   FusedOpt fo;
   int finalize;   // 1: one extra block closes the update (alpha step, mean_std commit, counters)
+  long long* timeline;   // DSACT_TIMELINE builds only
 };
 
 // end-of-update duties of the fused path: Adam on log_alpha, commit of the mean_std EMA and of the
@@ -1007,6 +1008,10 @@ __device__ void finalize_update(const FusedOpt& fo) {
   fo.st->seq_next = st.seq_next + 1;
 }
 
+// workgroup barrier that orders LDS only: __syncthreads() also waits for vmcnt(0), i.e. for every global load AND store
+// in flight (prefetched operands, an epilogue's stores)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __global__ void __launch_bounds__(kThreads) k_stage_table(TableArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if ((int)blockIdx.x >= a.n_tiles) {
@@ -1014,7 +1019,7 @@ __global__ void __launch_bounds__(kThreads) k_stage_table(TableArgs a) {
     return;
   }
   const GemmProb g = a.tiles[xcd_logical_block(blockIdx.x, a.n_tiles)];
-  run_tile<true, true, EPI_STORE>(g, g.tiles_n, g.tile_end, lds, nullptr, 0, &a.fo);
+  run_tile<true, true, EPI_STORE>(g, g.tiles_n, g.tile_end, lds, a.timeline, (int)blockIdx.x, &a.fo);
 }
 
 // ---------------------------------------------------------------------------------------------
