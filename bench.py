@@ -12,10 +12,20 @@ every step gathers a fresh minibatch, draws fresh noise (device Philox), compute
 their gradients, runs Adam for q1/q2 (policy/alpha/Polyak every `delay_update`-th step as the
 reference does).
 
-Prints ONE JSON line (rank 0). Extra objects: `roofline` (FP32-compute bound of the whole step, the
-binding roofline per SURVEY.md section 8d), `roofline_hbm` (the HBM view north_star asks for),
-`kernels` (per-launch hipEvent times of one eager step), `cpu_baseline` (the oracle port on the host
-cores, bounded sample), `alt` (the other hidden-layer setting of SURVEY.md D1).
+`--gpus N` without a torch.distributed environment re-executes itself under torch.distributed.run with N ranks
+(one per GPU) and fails loudly when fewer than N devices exist. N > 1: every rank owns its replay shard and its
+sampler-side state; the data-parallel update (gather -> gradients -> RCCL all-reduce -> Adam/Polyak) is captured
+in ONE hipGraph per rank through the library's own communicator (dsact_comm_init), BASELINE.json configs[4].
+
+Timing: W untimed warm-up steps, then R timed regions of EXACTLY K steps each, every region bracketed by a
+barrier + device synchronisation on both sides, MAX over ranks per region; `value` is the MEDIAN region
+(R = 5 for K <= 10000, else 3; all regions are listed in `regions_ms`).
+
+Prints ONE JSON line (rank 0). Extra objects: `roofline` (the dominant kernel: algorithmic FLOP per launch / its
+average in-chain duration, measured live with the dispatch's own start/stop events), `roofline_step` (whole
+update vs the FP32 peak, the binding roofline per SURVEY.md section 8d), `roofline_hbm` (the HBM view north_star
+asks for), `kernels`, `cpu_baseline` (the unmodified reference when it is mounted, else the oracle port; 1M-row
+host buffer, 4 threads and all cores), `alt` (the other hidden-layer setting of SURVEY.md D1).
 """
 import argparse
 import json
@@ -155,7 +165,7 @@ def bench_cnn(device, steps, warmup, batch=B, cpu=True):
     e = alg.engine
     fill_replay_images(e, CNN_ROWS, seed=100)
     upload_indices(e, CNN_ROWS, 256, seed=1)
-    wall, ev_ms = measure(alg, steps, warmup)
+    wall, _, ev_ms = measure(alg, steps, warmup)
     stats = e.read_stats()
     lay = e.layout
     flop, byts = lay.flop_per_step(batch), lay.bytes_per_step(batch, 2)
@@ -182,23 +192,6 @@ def bench_cnn(device, steps, warmup, batch=B, cpu=True):
     return out
 
 
-def pmc_traffic_forward_stage():
-    """HBM-side bytes per launch of the forward tile stage from the committed PMC passes (profiles/r01_pmc_traffic.json,
-    produced by scripts/gpu_pmc2.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this bench, FETCH_SIZE doubled per the
-    MI355X guide's gfx950 note). Not measurable live (needs rocprofv3); None if the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        d = json.load(open(path))["mlp"]
-    except (OSError, KeyError, ValueError):
-        return None
-    tot, n = 0.0, 0
-    for k, v in d.items():
-        if "k_stage<false, false, 0" in k:
-            tot += (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0 * v["launches"]
-            n += v["launches"]
-    return tot / n if n else None
-
-
 def upload_indices(engine, n_rows, rows, seed):
     import numpy as np
 
@@ -206,42 +199,129 @@ def upload_indices(engine, n_rows, rows, seed):
     engine.upload_index_table(np.random.randint(0, n_rows, size=(rows, engine.batch)))
 
 
-def cpu_baseline(hidden, budget_s=12.0):
-    """The oracle port (oracle/dsact_oracle.py == reference arithmetic, pinned bit-exact against the live
-    reference in tests/test_oracle_vs_reference.py) timed on the host cores: sample_batch + local_update,
-    4 torch threads like the reference (utils/init_args.py:14)."""
+CPU_ROWS = 100_000   # host buffer of the CPU leg: first touch of fresh pages costs ~20 MB/s in this sandbox (a 1M-row,
+                      # 3.1 GB buffer = minutes); sample_batch is 2 % of the CPU step even at 1M rows
+
+
+def _cpu_fill(bufs, n_rows):
+    """SURVEY.md 8(d) buffer recipe written IN PLACE into the buffer's own arrays: np.random.default_rng(0); obs, obs2 ~
+    N(0,1); act ~ U(-.4,.4); rew ~ N(0,1); done ~ Bernoulli(.01); logp = 0"""
+    import numpy as np
+
+    rng = np.random.default_rng(0)
+    for k in ("obs", "obs2"):
+        rng.standard_normal(out=bufs[k].reshape(-1), dtype=np.float32)
+    bufs["act"][:] = rng.uniform(-0.4, 0.4, (n_rows, A)).astype(np.float32)
+    rng.standard_normal(out=bufs["rew"].reshape(-1), dtype=np.float32)
+    bufs["done"][:] = (rng.random(n_rows) < 0.01).astype(np.float32).reshape(bufs["done"].shape)
+
+
+def cpu_baseline_child(hidden, n_rows=CPU_ROWS, warm=50, timed=300, budget_s=12.0):
+    """The reference CPU path beside the GPU number (BASELINE.md section 3 / SURVEY.md 8d): the UNMODIFIED reference
+    (`create_alg` -> DSAC_V2, `create_buffer` -> ReplayBuffer, imported in place through oracle/ref_loader.py) when
+    /root/reference is mounted -- kind "reference"; otherwise (the GPU box) the oracle port of the same arithmetic,
+    pinned bit-exact against it in tests/test_oracle_vs_reference.py -- kind "port". Timed loop =
+    sample_batch(B) + local_update, `warm` warm-up + up to `timed` updates, every loop bounded by budget_s, at 4 torch
+    threads (the reference's own setting, utils/init_args.py:14) and at os.cpu_count() threads (skipped when one
+    update at that thread count takes longer than 2 s: an over-subscribed container)."""
     import numpy as np
     import torch
-    from oracle.dsact_oracle import DsactOracle, ReplayOracle, default_config, draw_noise
+    from oracle import ref_loader
 
-    threads = 4
-    torch.set_num_threads(threads)
-    torch.manual_seed(0)
-    orc = DsactOracle(default_config(O, A, hidden))
-    n = 100_000
-    buf = ReplayOracle(O, A, n)
-    rng = np.random.default_rng(0)
-    buf.buf["obs"][:] = rng.standard_normal((n, O), dtype=np.float32)
-    buf.buf["obs2"][:] = rng.standard_normal((n, O), dtype=np.float32)
-    buf.buf["act"][:] = rng.uniform(-0.4, 0.4, (n, A)).astype(np.float32)
-    buf.buf["rew"][:] = rng.standard_normal(n, dtype=np.float32)
-    buf.buf["done"][:] = (rng.random(n) < 0.01).astype(np.float32)
-    buf.size = n
-    np.random.seed(1)
+    use_ref = ref_loader.reference_available()
+    if use_ref:
+        ref_loader.import_reference()
+        from utils.initialization import create_alg, create_buffer   # the reference's own factories
+
+        kw = ref_loader.reference_kwargs(O, A, tuple(hidden), buffer_max_size=n_rows, replay_batch_size=B)
+        torch.manual_seed(0)
+        alg = create_alg(**kw)
+        buf = create_buffer(**kw)
+        _cpu_fill(buf.buf, n_rows)
+        buf.size, buf.ptr = n_rows, 0
+
+        def step(it):
+            alg.local_update(buf.sample_batch(B), it)
+    else:
+        from oracle.dsact_oracle import DsactOracle, ReplayOracle, default_config, draw_noise
+
+        torch.manual_seed(0)
+        orc = DsactOracle(default_config(O, A, hidden))
+        buf = ReplayOracle(O, A, n_rows)
+        _cpu_fill(buf.buf, n_rows)
+        buf.size = n_rows
+
+        def step(it):
+            orc.local_update(buf.sample_batch(B), draw_noise(B, A), it)
+    legs = {}
+    ncpu = os.cpu_count() or 4
     it = 0
-    for _ in range(10):
-        orc.local_update(buf.sample_batch(B), draw_noise(B, A), it)
+    def probe(threads):   # a cheap stand-in for one layer: is this thread count usable at all in this container?
+        torch.set_num_threads(threads)
+        x, w = torch.randn(256, 512), torch.randn(512, 256)
+        (x @ w).sum().item()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            torch.nn.functional.gelu(x @ w)
+        return time.perf_counter() - t0
+
+    p4 = probe(4)
+    for threads in sorted({4, ncpu}):
+        if threads != 4:
+            pn = probe(threads)
+            if pn > 3.0 * p4:
+                legs[threads] = {"skipped": "%d torch threads are over-subscribed in this container: a 256x512x256 layer runs %.0fx slower "
+                                            "than at 4 threads" % (threads, pn / p4)}
+                continue
+        torch.set_num_threads(threads)
+        np.random.seed(1)
+        step(it)   # thread-pool start-up
         it += 1
-    t0 = time.perf_counter()
-    steps = 0
-    while time.perf_counter() - t0 < budget_s:
-        orc.local_update(buf.sample_batch(B), draw_noise(B, A), it)
+        t0 = time.perf_counter()
+        step(it)
         it += 1
-        steps += 1
-    dt = time.perf_counter() - t0
-    return {"value": steps / dt, "unit": "steps/s", "cores": threads, "kind": "port",
-            "sample": "%d updates (batch 256, hidden %s, 100k-row host ring) in %.1f s, torch %s CPU, %d of %d host cores"
-                      % (steps, "x".join(map(str, hidden)), dt, torch.__version__, threads, os.cpu_count())}
+        one = time.perf_counter() - t0
+        if one > 2.0:
+            legs[threads] = {"skipped": "one update takes %.1f s at %d torch threads" % (one, threads)}
+            continue
+        t0 = time.perf_counter()
+        nw = 2
+        while nw < warm and time.perf_counter() - t0 < budget_s / 2:
+            step(it)
+            it += 1
+            nw += 1
+        t0 = time.perf_counter()
+        n = 0
+        while n < timed and time.perf_counter() - t0 < budget_s:
+            step(it)
+            it += 1
+            n += 1
+        dt = time.perf_counter() - t0
+        legs[threads] = {"value": n / dt, "updates": n, "seconds": dt, "warmup": nw}
+    v4 = legs[4]
+    who = ("unmodified reference (create_alg -> DSAC_V2, create_buffer -> ReplayBuffer)" if use_ref else
+           "oracle port of the reference arithmetic (the reference is not mounted on this box)")
+    return {"value": v4.get("value"), "unit": "steps/s", "cores": 4, "kind": "reference" if use_ref else "port",
+            "all_cores": dict(legs[ncpu], cores=ncpu),
+            "sample": "%s: sample_batch(256) + local_update, hidden %s, %d-row host buffer (SURVEY 8d recipe; 1M rows = minutes of first-touch page faults in this sandbox), %s warm-up + "
+                      "%s timed updates in %.1f s at 4 torch threads, torch %s / numpy %s CPU, %d host cores"
+                      % (who, "x".join(map(str, hidden)), n_rows, v4.get("warmup"), v4.get("updates"), v4.get("seconds", 0.0),
+                         torch.__version__, np.__version__, ncpu)}
+
+
+def cpu_baseline(hidden, timeout_s=150):
+    """runs cpu_baseline_child in its own process under a hard timeout: a CPU leg can never stall the GPU measurement"""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--hidden", ",".join(map(str, hidden))]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "steps/s", "cores": 4, "kind": "port", "sample": "CPU baseline leg exceeded %d s and was stopped" % timeout_s}
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"value": None, "unit": "steps/s", "cores": 4, "kind": "port", "sample": "CPU baseline leg failed: %s" % r.stderr[-300:]}
+    return json.loads(lines[-1])
 
 
 def boundary_rates(alg, n):
@@ -277,50 +357,172 @@ def boundary_rates(alg, n):
     return res
 
 
-def graph_steps(steps, warmup, cap=64):
-    """updates captured per hipGraph: the largest even divisor (<= cap) of both the timed and the warm-up step count.
-    Measured: 2 -> 9,248, 8 -> 9,416, 40 -> 9,473 steps/s (the gap between graph launches amortises)."""
+def graph_steps(steps, warmup, cap=64, even=False):
+    """updates captured per hipGraph: the largest divisor (<= cap) of both the timed and the warm-up step count, so
+    that exactly W and exactly K steps are replayed (measured: 2/graph -> 9,248, 8 -> 9,416, 40 -> 9,473 steps/s on the
+    round-1 chain: the gap between graph launches amortises). even: the fast mode needs whole delay_update periods."""
     import math
 
     if os.environ.get("DSACT_BENCH_GRAPH_STEPS"):
         return int(os.environ["DSACT_BENCH_GRAPH_STEPS"])
     g = math.gcd(int(steps), int(warmup)) if warmup else int(steps)
-    best = 2
-    for d in range(2, cap + 1, 2):
-        if g % d == 0:
+    best = 1
+    for d in range(1, cap + 1):
+        if g % d == 0 and (not even or d % 2 == 0):
             best = d
     return best
 
 
+def n_regions(steps):
+    return 5 if steps <= 10000 else 3
+
+
 def measure(alg, steps, warmup, world=1, dp=None, flags=0):
-    """returns (wall seconds for `steps` steps, hipEvent ms for the same region or None)"""
+    """W warm-up steps, then R regions of exactly `steps` steps; returns (median region wall seconds, all regions [s],
+    hipEvent ms of the median region or None). Every region: barrier + device sync, clock, K steps, device sync +
+    barrier, clock; MAX over ranks."""
     import torch
 
     e = alg.engine
+    regions, evs = [], []
+    R = n_regions(steps)
+    gs = graph_steps(steps, warmup, even=bool(flags & 1))
+    short = steps <= 64 and not (flags & 1 and steps & 1)   # short runs: the timed region is ONE graph of exactly K steps
     if dp is None:
-        e.graph_build(graph_steps(steps, warmup), flags)
-        e.graph_run(0, warmup)
+        if short:
+            gs = steps
+            if warmup:
+                e.time_steps(0, warmup, use_graph=False, flags=flags)   # exactly W eager warm-up updates
+            e.graph_build(gs, flags)
+        else:
+            e.graph_build(gs, flags)
+            if warmup:
+                e.graph_run(0, warmup)
         e.sync()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ms = e.time_steps(warmup, steps, use_graph=True)  # hipEvents on the engine's stream + host sync
-        wall = time.perf_counter() - t0
-        return wall, ms
-    import torch.distributed as dist
+        it = warmup
+        for _ in range(R):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ms = e.time_steps(it, steps, use_graph=True)  # hipEvents on the engine's stream + host sync
+            regions.append(time.perf_counter() - t0)
+            evs.append(ms)
+            it += steps
+    else:
+        import torch.distributed as dist
 
-    e.dp_begin(0)
-    for _ in range(warmup):
-        dp.step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        dp.step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    wall = time.perf_counter() - t0
-    return wall, None
+        native = getattr(dp, "native", False)
+        if native:
+            if short:
+                gs = steps
+                e.dp_begin(0)
+                for _ in range(warmup):
+                    dp.step()
+                dp.build_graph(gs)
+            else:
+                dp.build_graph(gs)
+                if warmup:
+                    dp.run_graph(0, warmup)
+        else:
+            e.dp_begin(0)
+            for _ in range(warmup):
+                dp.step()
+        e.sync()
+        it = warmup
+        for _ in range(R):
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if native:
+                dp.run_graph(it, steps)
+            else:
+                for _ in range(steps):
+                    dp.step()
+            e.sync()
+            torch.cuda.synchronize()
+            dist.barrier()
+            w = time.perf_counter() - t0
+            t = torch.tensor([w], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            regions.append(float(t.item()))
+            evs.append(None)
+            it += steps
+    order = sorted(range(R), key=lambda i: regions[i])
+    mid = order[R // 2]
+    measure.last_graph_steps = gs
+    return regions[mid], regions, evs[mid]
+
+
+def chain_flops(lay, batch):
+    """algorithmic FLOP per launch of the five launches of the chain path (2 x multiply-accumulates, elementwise
+    work ignored): forward A / B, loss + critic backward, policy backward (+ the critics' weight gradients riding in
+    it), the policy's weight gradients."""
+    F, A_, W, L = lay.obs_dim, lay.act_dim, lay.hidden[0], len(lay.hidden)
+    hid = (L - 1) * W * W
+    pi = F * W + hid + W * 2 * A_
+    q = (F + A_) * W + hid + W * 2
+    dw_q = q            # dW of a net: one MAC per parameter per sample
+    dw_pi = pi
+    per_row = {
+        "chain_fwd_a": 2 * pi + 2 * q + 2 * F * W,
+        "chain_fwd_b": 4 * (A_ * W + hid + 2 * W),
+        "chain_bwd_q": 4 * (2 * W + hid) + 2 * A_ * W,
+        "chain_bwd_pi": 2 * A_ * W + hid + 2 * dw_q,
+        "dW": dw_pi,
+    }
+    return {k: 2.0 * v * batch for k, v in per_row.items()}
+
+
+def pmc_traffic(kernel_substr):
+    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r02_pmc_traffic.json, produced
+    by scripts/gpu_pmc2.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this bench with --kernel-trace only,
+    FETCH_SIZE doubled per the MI355X guide's gfx950 note). Not measurable live (needs rocprofv3); None if absent."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    try:
+        d = json.load(open(path))["mlp"]
+    except (OSError, KeyError, ValueError):
+        return None
+    tot, n = 0.0, 0
+    for k, v in d.items():
+        if kernel_substr in k:
+            tot += (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0 * v["launches"]
+            n += v["launches"]
+    return tot / n if n else None
+
+
+def profile_kernels(e, first_it, n_steps=12, skip=2):
+    """average in-chain duration per launch name over n_steps eager updates (the dispatch's own start/stop events)"""
+    acc, cnt, blocks, order = {}, {}, {}, []
+    for i in range(n_steps):
+        prof = e.profile_step(first_it + i)
+        e.sync()
+        if i < skip:
+            continue
+        for name, ms, b in prof:
+            if name not in acc:
+                acc[name], cnt[name], blocks[name] = 0.0, 0, b
+                order.append(name)
+            acc[name] += ms
+            cnt[name] += 1
+    return [(n, acc[n] / cnt[n], blocks[n]) for n in order]
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a torch.distributed environment: re-execute under torch.distributed.run with N
+    ranks on this node. Never measures fewer GPUs than were asked for."""
+    import subprocess
+
+    if not args.dry_run_cpu:
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d requested but only %d device(s) visible -- refusing to measure a smaller job\n" % (args.gpus, have))
+            sys.exit(2)
+    port = 29500 + (os.getpid() % 400)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
 
 
 def main():
@@ -338,16 +540,50 @@ def main():
     ap.add_argument("--cnn-only", action="store_true", help="measure only the CNN workload (configs[3]); prints its object")
     ap.add_argument("--cnn-steps", type=int, default=400)
     ap.add_argument("--cnn-type", type=str, default="type_2", help="type_2 at (3,96,96) (default) or type_1 at (4,84,84) (SURVEY.md D3)")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="launcher check without GPUs: the ranks rendezvous over gloo, all-reduce one tensor and rank 0 prints the line")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: print the cpu_baseline object and exit")
+    ap.add_argument("--dp-eager", action="store_true", help="data-parallel leg through torch.distributed eagerly instead of the graph-captured native RCCL path")
     args = ap.parse_args()
-    steps = args.steps + (args.steps & 1)
-    warmup = args.warmup + (args.warmup & 1)
+    steps, warmup = int(args.steps), int(args.warmup)
+    if args.fast:   # whole delay_update periods per graph
+        steps += steps & 1
+        warmup += warmup & 1
+
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline_child([int(x) for x in args.hidden.split(",")])))
+        return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)
+    rank, world, local = env_int("RANK", 0), env_int("WORLD_SIZE", 1), env_int("LOCAL_RANK", 0)
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s)\n" % (args.gpus, world))
+        sys.exit(2)
+    if args.dry_run_cpu:
+        import torch
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("gloo")
+        t = torch.ones(4) * (rank + 1)
+        dist.all_reduce(t)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "sum": float(t[0].item()), "steps": steps, "warmup": warmup}))
+        dist.destroy_process_group()
+        return
 
     import __graft_entry__ as entry
-    rank, world, local = env_int("RANK", 0), env_int("WORLD_SIZE", 1), env_int("LOCAL_RANK", 0)
     if rank == 0:
         entry.build()
     import torch
 
+    if torch.cuda.device_count() < max(1, world):
+        sys.stderr.write("bench.py: %d rank(s) but %d device(s) visible\n" % (world, torch.cuda.device_count()))
+        sys.exit(2)
     dp = None
     # DSACT_BENCH_FORCE_DP=1: take the data-parallel (RCCL) code path even with one rank -- the only way to
     # exercise it on a 1-GPU box
@@ -375,31 +611,35 @@ def main():
     e = alg.engine
     fill_replay(e, args.replay_rows, seed=100 + rank)  # every rank owns its own replay shard
     upload_indices(e, args.replay_rows, IDX_ROWS, seed=1 + rank)
+    dp_mode = None
     if use_dp:
         from dsact.dp import DataParallelUpdater
 
-        # the updater issues its collectives on the engine's own stream (engine.torch_stream)
-        # default: ONE all-reduce after the whole backward. DSACT_DP_OVERLAP=1 all-reduces the critics' 2/3 of the
-        # arena asynchronously under the actor's backward -- measured on one rank the second collective call and
-        # its cross-stream events cost +40 us/step against +14.5 us for the single call, so it is opt-in
-        dp = DataParallelUpdater(e, broadcast_tensors=(e.online, e.target, e.adam_m, e.adam_v),
-                                 overlap=os.environ.get("DSACT_DP_OVERLAP", "0") == "1")
-        dp.force_collective = os.environ.get("DSACT_DP_FORCE_COLLECTIVE") == "1"
-    wall, ev_ms = measure(alg, steps, warmup, world, dp, flags=1 if args.fast else 0)
-    if use_dp:
-        import torch.distributed as dist
-
-        t = torch.tensor([wall], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+        native = not args.dp_eager
+        try:
+            # native: the library's own RCCL communicator; the whole update (gather -> gradients -> all-reduce ->
+            # Adam/Polyak) is captured in one hipGraph per rank
+            dp = DataParallelUpdater(e, broadcast_tensors=(e.online, e.target, e.adam_m, e.adam_v), native=native,
+                                     overlap=(not native) and os.environ.get("DSACT_DP_OVERLAP", "0") == "1")
+        except Exception as ex:
+            if not native:
+                raise
+            sys.stderr.write("bench.py: native RCCL communicator unavailable (%r): eager torch.distributed collectives\n" % (ex,))
+            dp = DataParallelUpdater(e, broadcast_tensors=(e.online, e.target, e.adam_m, e.adam_v))
+        dp.force_collective = world == 1   # forced-DP runs on one rank still issue the collective
+        dp_mode = "hipGraph (gather -> gradients -> ncclAllReduce -> Adam/Polyak, library-owned RCCL communicator)" if dp.native \
+            else "eager launches + torch.distributed all-reduce (%s)" % ("critics' segment overlapped" if dp.overlap else "single")
+    wall, regions, ev_ms = measure(alg, steps, warmup, world, dp, flags=1 if args.fast else 0)
     stats = e.read_stats()
     finite = all(v == v and abs(v) < 1e30 for v in stats.values())
     updates_per_s = steps / wall
-    value = updates_per_s * world  # batch-256 gradient-step equivalents per second over the whole job
+    value = updates_per_s * world  # batch-B gradient-step equivalents per second over the whole job
     lay = e.layout
     Bb = args.batch
     flop = lay.flop_per_step(Bb)
     byts = lay.bytes_per_step(Bb, 2)
+    gs = getattr(measure, "last_graph_steps", graph_steps(steps, warmup, even=args.fast))
+    chain = bool(e.chain_active)
     out = {
         "metric": "DSAC-T gradient steps/sec, batch=%d Humanoid (obs376/act17)" % args.batch,
         "value": value, "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -411,33 +651,18 @@ def main():
                         % ("x".join(map(str, hidden)), args.batch, args.replay_rows),
             "global_batch": args.batch * world, "parallelism": "dp%d" % world, "hidden": hidden,
             "noise": "device Philox4x32-10", "mode": "fast (discarded actor backward skipped)" if args.fast else "strict (every gradient the reference computes)",
-            "launch": ("hipGraph (%d steps/graph; the next update's gather rides in the loss launch)" % graph_steps(steps, warmup)) if not use_dp else ("eager + RCCL all-reduce (%s)" % ("critics' segment overlapped with the actor backward" if dp.overlap else "single")),
-            "unit_note": "value = synchronized updates/s x n_gpus (each rank contributes one batch-256 gradient per update)",
+            "launch": dp_mode if use_dp else "hipGraph (%d steps/graph; the next update's gather rides in the loss launch)" % gs,
+            "kernels": "row-slice fused chains + transposed-operand weight-gradient tiles (5 launches/update)" if chain else "per-layer tile stages",
+            "timing": "median of %d timed regions of exactly %d steps (each bracketed by barrier + device sync; max over ranks)" % (len(regions), steps),
+            "replay_fill": "torch device generator, the distributions of SURVEY.md 8(d) (a host np.random.default_rng(0) fill would push "
+                           "3 GB through PCIe); indices: np.random.seed(1 + rank) + np.random.randint, a %d-row table cycled" % IDX_ROWS,
+            "unit_note": "value = synchronized updates/s x n_gpus (each rank contributes one batch-%d gradient per update)" % args.batch,
         },
+        "regions_ms": [round(1000.0 * r, 4) for r in regions],
         "finite_stats": finite,
     }
     if rank == 0:
         per_gpu_steps = updates_per_s
-        # dominant kernel = k_stage<KC,KC,bias+GELU> (the forward tile stages: 6 of the 15 launches, ~37% of the
-        # update): every forward stage is launched back to back on the engine's stream between two hipEvents
-        n_st = 2 * len(hidden)
-        st_ms, st_macs, reps = 0.0, 0.0, 300
-        for st in range(n_st):
-            ms_i, macs_i = e.time_stage(st, reps)
-            st_ms += ms_i
-            st_macs += macs_i
-        dur_us = 1000.0 * st_ms / (reps * n_st)
-        flop_launch = 2.0 * st_macs / n_st
-        out["roofline"] = {
-            "bound": "mfma", "achieved": flop_launch / (dur_us * 1e-6) / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": flop_launch / (dur_us * 1e-6) / 1e12 / FP32_PEAK_TFLOPS, "traffic": pmc_traffic_forward_stage(),
-            "kernel": "dsact::k_stage<false,false,0,{0,4}> (forward tile stages: bias+GELU epilogue, 4 GEMM problems per launch)",
-            "avg_launch_us": dur_us, "flop_per_launch": flop_launch,
-            "note": "fp32 MFMA peak; avg over the %d forward stages, %d back-to-back launches each (hipEvents on the engine's "
-                    "stream); algorithmic FLOP = 2*M*N*K of the stage's problems. traffic = bytes/launch (2*FETCH_SIZE + WRITE_SIZE) "
-                    "from the committed PMC passes (profiles/r01_pmc_summary.txt): ~5.4 MB against 4.2 MB of operands + outputs "
-                    "-- memory-side traffic is not what bounds this kernel" % (n_st, reps),
-        }
         out["roofline_step"] = {
             "bound": "mfma", "achieved": flop * per_gpu_steps / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": flop * per_gpu_steps / 1e12 / FP32_PEAK_TFLOPS,
@@ -451,26 +676,48 @@ def main():
         if ev_ms is not None:
             out["hip_event_ms_per_step"] = ev_ms / steps
         try:
-            prof = e.profile_step(warmup + steps)
-            e.sync()
+            prof = profile_kernels(e, warmup + steps * len(regions))
             out["kernels"] = [{"name": n, "us": round(ms * 1000, 2), "blocks": b} for n, ms, b in prof]
-            out["kernels_note"] = ("hipEvent-bracketed launches of ONE EAGER update (own gather launch, event overhead "
-                                   "included); the timed graph replay has no per-update gather (it rides in `loss`) -- "
-                                   "in-graph durations: profiles/r01_final_step_trace.txt")
-            dom = max(prof, key=lambda r: r[1])
+            out["kernels_note"] = ("average in-chain duration per launch over 10 eager updates: start/stop events attached to each "
+                                   "dispatch (hipExtLaunchKernelGGL), i.e. the kernel's own begin/end timestamps as rocprofv3 reports "
+                                   "them (profiles/r02_final_bench_kernel_stats.csv); the eager update has its own gather launch, the timed "
+                                   "graph replay does not (the gather rides in the loss launch)")
+            timed = [r for r in prof if r[0] not in ("gather", "pack")]
+            dom = max(timed, key=lambda r: r[1])
             out["dominant_kernel"] = {"name": dom[0], "us": round(dom[1] * 1000, 2)}
+            if chain and Bb % 256 == 0 or chain and Bb <= 256:
+                fl = chain_flops(lay, Bb)
+                kname = {"chain_fwd_a": "dsact::k_chain_fwd (group A)", "chain_fwd_b": "dsact::k_chain_fwd (group B)",
+                         "chain_bwd_q": "dsact::k_chain_bwd_q", "chain_bwd_pi": "dsact::k_chain_bwd_pi (+ riding k_dw2 tiles)",
+                         "dW": "dsact::k_dw2"}.get(dom[0], dom[0])
+                if dom[0] in fl:
+                    dur_us = dom[1] * 1000.0
+                    ach = fl[dom[0]] / (dur_us * 1e-6) / 1e12
+                    out["roofline"] = {
+                        "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
+                        "traffic": pmc_traffic("k_chain_fwd" if "fwd" in dom[0] else dom[0]),
+                        "kernel": kname, "avg_launch_us": dur_us, "flop_per_launch": fl[dom[0]],
+                        "note": "dominant launch of the update by in-chain duration; achieved = algorithmic FLOP of the launch (2 x MAC of "
+                                "the layers its workgroups run, elementwise ignored) / its average duration (dispatch start/stop events, "
+                                "10 eager updates); fp32 MFMA peak == fp32 vector peak. The launch runs %d workgroups on 256 CUs: the "
+                                "chip-level fraction is bounded by that occupancy (per-workgroup phase timeline: profiles/r02_chain_*_timeline.txt); "
+                                "traffic = bytes/launch (2*FETCH_SIZE + WRITE_SIZE) from the committed PMC passes, or null" % dom[2],
+                    }
         except Exception as ex:  # profiling is informational
             out["kernels_error"] = str(ex)
+        if "roofline" not in out:
+            out["roofline"] = dict(out["roofline_step"], note="whole update (no per-kernel profile available on this path)")
     if rank == 0 and not use_dp and not args.fast:
         # same workload with the actor/alpha backward skipped on the off iterations of the delayed update: the
         # reference computes and discards those gradients (dsac_v2.py:174-186 vs :324); bitwise-identical parameter
         # trajectory (tests/test_hip_parity.py::test_skip_discarded_actor_backward_keeps_trajectory)
-        wf, _ = measure(alg, steps, warmup, flags=1)
-        out["fast"] = {"value": steps / wf, "unit": "steps/s", "ms_per_step": 1000.0 * wf / steps,
+        fs, fw = steps + (steps & 1), warmup + (warmup & 1)
+        wf, _, _ = measure(alg, fs, fw, flags=1)
+        out["fast"] = {"value": fs / wf, "unit": "steps/s", "ms_per_step": 1000.0 * wf / fs,
                        "note": "DSACT_F_SKIP_ACTOR_ON_OFF_ITERS; not the headline value"}
     if rank == 0 and not use_dp and not args.no_alt and args.batch == B:
         try:
-            out["boundary"] = boundary_rates(alg, min(steps, 600))
+            out["boundary"] = boundary_rates(alg, min(max(steps, 100), 600))
         except Exception as ex:  # informational leg
             out["boundary_error"] = repr(ex)
     if not use_dp and not args.no_alt and args.batch == B:
@@ -479,26 +726,29 @@ def main():
         alg2 = make_alg(alt_hidden, local, seed=0)
         fill_replay(alg2.engine, min(args.replay_rows, 200_000), seed=100)
         upload_indices(alg2.engine, min(args.replay_rows, 200_000), IDX_ROWS, seed=1)
-        w2, _ = measure(alg2, steps, warmup)
+        w2, _, _ = measure(alg2, steps, warmup)
         l2 = alg2.engine.layout
         out["alt"] = {"hidden": alt_hidden, "value": steps / w2, "unit": "steps/s",
                       "frac_fp32": l2.flop_per_step(B) * steps / w2 / 1e12 / FP32_PEAK_TFLOPS,
                       "frac_hbm": l2.bytes_per_step(B, 2) * steps / w2 / 1e9 / HBM_PEAK_GBS}
     if rank == 0 and not use_dp and not args.no_alt and args.batch == B:
-        # the reference's DSAC_V1 (one critic) on the same kernels, same shapes
+        # the reference's DSAC_V1 (one critic) on the tile-stage kernels, same shapes
         try:
             alg1 = make_alg(hidden, local, seed=0, v1=True)
             fill_replay(alg1.engine, min(args.replay_rows, 200_000), seed=100)
             upload_indices(alg1.engine, min(args.replay_rows, 200_000), IDX_ROWS, seed=1)
-            w1, _ = measure(alg1, steps, warmup)
+            w1, _, _ = measure(alg1, steps, warmup)
             l1 = alg1.engine.layout
             out["dsac_v1"] = {"value": steps / w1, "unit": "steps/s", "ms_per_step": 1000.0 * w1 / steps,
                               "frac_fp32": l1.flop_per_step(B) * steps / w1 / 1e12 / FP32_PEAK_TFLOPS}
             del alg1
         except Exception as ex:
             out["dsac_v1_error"] = repr(ex)
-    if rank == 0 and not use_dp and not args.no_cpu_baseline and args.batch == B:
-        out["cpu_baseline"] = cpu_baseline(hidden)
+    if rank == 0 and not args.no_cpu_baseline and args.batch == B:
+        try:
+            out["cpu_baseline"] = cpu_baseline(hidden)
+        except Exception as ex:
+            out["cpu_baseline_error"] = repr(ex)
     if rank == 0 and not use_dp and not args.no_alt and args.batch == B:
         try:
             out["cnn"] = bench_cnn(local, args.cnn_steps, 40, cpu=not args.no_cpu_baseline)

@@ -1,6 +1,8 @@
 // dsact_api.hip -- host side of libdsact.so: handle, HBM layout, task tables, launch sequence,
 // hipGraph capture and the extern "C" entry points declared in include/dsact.h.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <math.h>
@@ -193,6 +195,9 @@ struct dsact_handle {
   float* X0t = nullptr;                 // transposed pack of the staged minibatch [roundup32(F+A) x B]
   int dw2_off[4] = {0, 0, 0, 0};        // tile ranges of q1, q2, policy in the dw2 problem list
   int n_heads_parts = 0;                // partial (tanh, sigma) sums the last forward wrote
+  // native collective (RCCL): communicator of this rank, see dsact_comm_init
+  void* comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
   // strict DP
   bool use_std_sums = false;
   bool auto_std_sums = false;
@@ -202,6 +207,36 @@ struct dsact_handle {
 namespace {
 
 double dec7(float f);
+
+// ---- librccl, opened at run time (no link-time dependency: the library also serves single-GPU users) ----------
+struct NcclUid { char internal[128]; };
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(NcclUid*) = nullptr;
+  int (*CommInitRank)(void**, int, NcclUid, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+constexpr int kNcclFloat = 7, kNcclSum = 0, kNcclAvg = 4;
+
+const char* rccl_load(const char* path) {
+  if (g_rccl.lib) return nullptr;
+  const char* cand[3] = {path && path[0] ? path : "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void* lib = nullptr;
+  for (int i = 0; i < 3 && !lib; ++i) lib = dlopen(cand[i], RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) return "librccl.so not found";
+  g_rccl.GetUniqueId = (int (*)(NcclUid*))dlsym(lib, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(void**, int, NcclUid, int))dlsym(lib, "ncclCommInitRank");
+  g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(lib, "ncclAllReduce");
+  g_rccl.CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+  g_rccl.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) return "librccl.so lacks the nccl* entry points";
+  g_rccl.lib = lib;
+  return nullptr;
+}
+const char* rccl_err(int rc) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "rccl error"; }
 
 int fail(dsact_handle* h, int code, const char* fmt, ...) {
   if (h) {
@@ -274,9 +309,9 @@ int launch(dsact_handle* h, const char* name, void (*kernel)(KArgs...), dim3 gri
     r.blocks = (int)(grid.x * grid.y * grid.z);
     HIPCHK(h, hipEventCreate(&r.e0));
     HIPCHK(h, hipEventCreate(&r.e1));
-    HIPCHK(h, hipEventRecord(r.e0, h->stream));
-    hipLaunchKernelGGL(kernel, grid, block, shmem, h->stream, args...);
-    HIPCHK(h, hipEventRecord(r.e1, h->stream));
+    // start / stop events attached to the dispatch itself: the kernel's own begin and end timestamps (what rocprofv3
+    // reports as its duration), not the stream time between two event-record commands
+    hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)shmem, h->stream, r.e0, r.e1, 0, args...);
     h->prof.push_back(r);
   } else {
     hipLaunchKernelGGL(kernel, grid, block, shmem, h->stream, args...);
@@ -1756,6 +1791,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     const int R = 4 * h->cRG;
     bool ok = !h->cnn && h->nq == 2 && h->B % R == 0 && h->B % 16 == 0 && (h->B <= 256 || h->B % 256 == 0) && h->F % 4 == 0 &&
               getenv("DSACT_NO_CHAIN") == nullptr;
+    ok = ok && h->L <= kChMaxL;
     for (int l = 0; l < h->L; ++l) ok = ok && cfg->hidden[l] == cfg->hidden[0];
     const int W0 = cfg->hidden[0];
     ok = ok && (W0 == 64 || W0 == 128 || W0 == 256);
@@ -1842,6 +1878,7 @@ int dsact_destroy(dsact_handle* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
   if (h->graph) hipGraphDestroy(h->graph);
+  if (h->comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   for (auto& r : h->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   for (int i = 0; i < 8; ++i) {
     if (h->h_idx[i]) hipHostFree(h->h_idx[i]);
@@ -2224,7 +2261,31 @@ int dsact_step(dsact_handle* h, int64_t iteration, uint32_t flags) {
 
 // one replayed update (iteration and index-table row from device state). `iteration` is only used to
 // decide, at enqueue/capture time, whether this is an off iteration of the delayed update.
+static int enqueue_allreduce(dsact_handle* h, float* buf, size_t count, int op) {
+  if (!h->comm) return fail(h, DSACT_E_STATE, "no communicator (dsact_comm_init)");
+  const int rc = g_rccl.AllReduce(buf, buf, count, kNcclFloat, op, h->comm, h->stream);
+  if (rc != 0) return fail(h, DSACT_E_HIP, "ncclAllReduce failed: %s", rccl_err(rc));
+  return DSACT_OK;
+}
+
+// one replayed data-parallel update: gather -> local gradients -> all-reduce -> Adam/Polyak (dsac_v2.py:107-138 with the
+// collective in the seam); strict mode: also the 2-float all-reduce of the std sums between the forward and the loss
+static int enqueue_graph_step_dp(dsact_handle* h) {
+  TRY(enqueue_gather(h, h->idx_table, h->idx_rows, 1, 0, 0));
+  if (h->use_std_sums) {
+    TRY(enqueue_grads(h, true, false, 1));
+    TRY(enqueue_allreduce(h, h->std_sums, 2, kNcclSum));
+    TRY(enqueue_grads(h, true, false, 2));
+  } else {
+    TRY(enqueue_grads(h, true, false));
+  }
+  TRY(enqueue_allreduce(h, h->grads, h->n_online + 2, kNcclAvg));
+  TRY(enqueue_prologue(h, 1, 0, 1, 0));
+  return enqueue_adam(h);
+}
+
 static int enqueue_graph_step(dsact_handle* h, long long iteration, uint32_t flags) {
+  if (flags & DSACT_F_DATA_PARALLEL) return enqueue_graph_step_dp(h);
   TRY(enqueue_gather(h, h->idx_table, h->idx_rows, 1, 0, 1));
   const bool actor = !(flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) || (iteration % h->cfg.delay_update) == 0;
   return enqueue_grads(h, actor, true);
@@ -2246,8 +2307,9 @@ int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) 
   // loss launch carries the bookkeeping and the NEXT update's gather into the other batch set; the per-step repack
   // of the padded first-layer copies is done by the weight-gradient tiles themselves (FusedOpt::mir_*).
   // Update s of n uses set (n-1-s)&1, so the last staged minibatch sits in set 0 like after eager updates.
+  if ((flags & DSACT_F_DATA_PARALLEL) && !h->comm) return fail(h, DSACT_E_STATE, "DSACT_F_DATA_PARALLEL needs dsact_comm_init");
   const bool merged = !h->cnn && h->use_w1p && h->dw_chunks == 1 && !h->use_fork && !h->use_std_sums && h->alt_ws != nullptr &&
-                      !h->env_no_merged_gather;
+                      !h->env_no_merged_gather && !(flags & DSACT_F_DATA_PARALLEL);
   h->merged_graph = merged;
   HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
   int rc = DSACT_OK;
@@ -2372,6 +2434,47 @@ int dsact_dp_enqueue_apply(dsact_handle* h) {
   HIPCHK(h, hipSetDevice(h->device));
   TRY(enqueue_prologue(h, 1, 0, 1, 0));
   return enqueue_adam(h);
+}
+
+int dsact_comm_unique_id(const char* rccl_path, uint8_t id[128]) {
+  if (!id) return DSACT_E_INVALID;
+  if (rccl_load(rccl_path)) return DSACT_E_STATE;
+  NcclUid u;
+  memset(&u, 0, sizeof(u));
+  if (g_rccl.GetUniqueId(&u) != 0) return DSACT_E_HIP;
+  memcpy(id, u.internal, 128);
+  return DSACT_OK;
+}
+
+int dsact_comm_init(dsact_handle* h, int32_t rank, int32_t world, const uint8_t id[128], const char* rccl_path) {
+  if (!h || !id || world < 1 || rank < 0 || rank >= world) return DSACT_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->graph_exec) return fail(h, DSACT_E_STATE, "the communicator is baked into the captured graph");
+  if (const char* e = rccl_load(rccl_path)) return fail(h, DSACT_E_STATE, "%s", e);
+  if (h->comm) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
+  NcclUid u;
+  memcpy(u.internal, id, 128);
+  const int rc = g_rccl.CommInitRank(&h->comm, world, u, rank);
+  if (rc != 0) { h->comm = nullptr; return fail(h, DSACT_E_HIP, "ncclCommInitRank failed: %s", rccl_err(rc)); }
+  h->comm_rank = rank; h->comm_world = world;
+  return DSACT_OK;
+}
+
+int dsact_comm_destroy(dsact_handle* h) {
+  if (!h) return DSACT_E_INVALID;
+  if (h->comm) {
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    g_rccl.CommDestroy(h->comm);
+    h->comm = nullptr;
+  }
+  return DSACT_OK;
+}
+
+int dsact_dp_enqueue_allreduce(dsact_handle* h) {
+  TRY(check_ready(h, false));
+  HIPCHK(h, hipSetDevice(h->device));
+  return enqueue_allreduce(h, h->grads, h->n_online + 2, kNcclAvg);
 }
 
 int dsact_read_stats(dsact_handle* h, float out[16]) {

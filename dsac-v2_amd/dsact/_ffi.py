@@ -86,6 +86,10 @@ SYMBOLS = [
     ("dsact_dp_enqueue_forward", C.c_int, [_P, C.c_uint32]),
     ("dsact_dp_enqueue_backward", C.c_int, [_P, C.c_uint32]),
     ("dsact_dp_enqueue_apply", C.c_int, [_P]),
+    ("dsact_comm_unique_id", C.c_int, [C.c_char_p, C.POINTER(C.c_uint8)]),
+    ("dsact_comm_init", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_uint8), C.c_char_p]),
+    ("dsact_comm_destroy", C.c_int, [_P]),
+    ("dsact_dp_enqueue_allreduce", C.c_int, [_P]),
     ("dsact_read_stats", C.c_int, [_P, _FP]),
     ("dsact_time_steps", C.c_int, [_P, C.c_int64, C.c_int64, C.c_uint32, C.c_int32, _FP]),
     ("dsact_time_stage", C.c_int, [_P, C.c_int32, C.c_int32, _FP, C.POINTER(C.c_double)]),

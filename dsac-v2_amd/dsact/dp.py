@@ -33,8 +33,11 @@ import torch
 import torch.distributed as dist
 
 
+F_DATA_PARALLEL = 2   # dsact.h DSACT_F_DATA_PARALLEL
+
+
 class DataParallelUpdater:
-    def __init__(self, engine, group=None, broadcast_tensors=(), strict=False, overlap=False):
+    def __init__(self, engine, group=None, broadcast_tensors=(), strict=False, overlap=False, native=False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.engine, self.group = engine, group
@@ -45,6 +48,14 @@ class DataParallelUpdater:
         self.strict = bool(strict)
         if self.strict:
             engine.dp_set_strict(True)
+        # native: the library's own RCCL communicator (dsact_comm_init) instead of torch.distributed collectives: the
+        # all-reduce is then a stream operation of the engine and the whole update can live in one hipGraph
+        # (build_graph / run_graph). torch.distributed is still what ships the communicator id and the initial state.
+        self.native = bool(native)
+        if self.native:
+            ids = [engine.comm_unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0, group=group)
+            engine.comm_init(self.rank, self.world, ids[0])
         # overlap: all-reduce the critics' segment (2/3 of the arena) while the actor's backward still runs
         self.overlap = bool(overlap) and not self.strict and hasattr(engine, "dp_grads_critic")
         # replicas must start identical: rank 0's parameters / optimiser state win
@@ -56,9 +67,21 @@ class DataParallelUpdater:
         ts = getattr(self.engine, "torch_stream", None)   # CPU stand-ins (gloo tests) have no stream
         return torch.cuda.stream(ts) if ts is not None else contextlib.nullcontext()
 
+    def build_graph(self, steps_per_graph: int):
+        """capture gather -> gradients -> RCCL all-reduce -> Adam/Polyak, `steps_per_graph` updates per hipGraph"""
+        if not self.native:
+            raise RuntimeError("the graph-captured data-parallel update needs native=True (dsact_comm_init)")
+        self.engine.graph_build(steps_per_graph, F_DATA_PARALLEL)
+
+    def run_graph(self, first_iteration: int, n_steps: int):
+        self.engine.graph_run(first_iteration, n_steps)
+
     def allreduce_grads(self):
         g = self.engine.grads
         if self.world == 1 and not self.force_collective:
+            return
+        if self.native:
+            self.engine.dp_allreduce()
             return
         with self._on_engine_stream():
             if self._avg:

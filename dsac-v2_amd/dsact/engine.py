@@ -5,6 +5,7 @@ arenas (so `state_dict()`, `torch.save`, `torch.distributed.all_reduce` work on 
 it provides the stream. All arithmetic of the update runs in the HIP kernels behind the C-ABI.
 """
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -304,6 +305,34 @@ class DsactEngine:
     def dp_apply(self):
         self._chk(self._lib.dsact_dp_enqueue_apply(self._h))
 
+    # native collective: RCCL opened by the library itself (the copy torch ships, so one RCCL serves the process)
+    @staticmethod
+    def _rccl_path():
+        import torch
+
+        p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        return p.encode() if os.path.exists(p) else None
+
+    def comm_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * 128)()
+        rc = self._lib.dsact_comm_unique_id(self._rccl_path(), buf)
+        if rc != 0:
+            raise DsactError("dsact_comm_unique_id failed (%s)" % _ffi.E_NAMES.get(rc, rc))
+        return bytes(buf)
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        assert len(unique_id) == 128
+        buf = (C.c_uint8 * 128)(*unique_id)
+        self._chk(self._lib.dsact_comm_init(self._h, int(rank), int(world), buf, self._rccl_path()))
+        self.comm_world = int(world)
+
+    def comm_destroy(self):
+        self._chk(self._lib.dsact_comm_destroy(self._h))
+
+    def dp_allreduce(self):
+        """average of the gradient arena (+ mean_std tail) over the ranks, on the engine's stream (RCCL)"""
+        self._chk(self._lib.dsact_dp_enqueue_allreduce(self._h))
+
     def read_stats(self) -> Dict[str, float]:
         out = (C.c_float * 16)()
         self._chk(self._lib.dsact_read_stats(self._h, out))
@@ -323,6 +352,11 @@ class DsactEngine:
         ms, macs = C.c_float(), C.c_double()
         self._chk(self._lib.dsact_time_stage(self._h, int(stage), int(reps), C.byref(ms), C.byref(macs)))
         return float(ms.value), float(macs.value)
+
+    @property
+    def chain_active(self) -> bool:
+        """True when this engine runs the update as row-slice fused chains (csrc/dsact_chain.h)"""
+        return bool(self._lib.dsact_chain_active(self._h))
 
     def profile_step(self, iteration: int, flags: int = 0):
         arr = (_ffi.KernelTime * 128)()

@@ -157,6 +157,7 @@ int dsact_set_noise(dsact_handle* h, const float* eps_new, const float* eps_2, c
 int dsact_set_device_rng(dsact_handle* h, uint64_t seed);
 
 /* ---- the update ----------------------------------------------------------------------------------- */
+#define DSACT_F_DATA_PARALLEL 2u           /* dsact_graph_build: capture gather -> grads -> all-reduce (dsact_comm_init) -> apply */
 #define DSACT_F_SKIP_ACTOR_ON_OFF_ITERS 1u /* "fast": skip actor/alpha backward when it % delay != 0
                                               (their gradients are discarded by the reference,
                                               dsac_v2.py:174-186 vs :324); parameter trajectory is
@@ -198,6 +199,23 @@ int dsact_dp_set_strict(dsact_handle* h, float* std_sums_dev);
 int dsact_dp_enqueue_forward(dsact_handle* h, uint32_t flags);
 int dsact_dp_enqueue_backward(dsact_handle* h, uint32_t flags);
 int dsact_dp_enqueue_apply(dsact_handle* h);
+
+/* ---- native collective (RCCL over xGMI) ------------------------------------------------------------------
+ * The all-reduce of the data-parallel seam (dsac_v2.py:107-138: gradients out of get_remote_update_info, into
+ * remote_update) issued by the library itself on the handle's stream, so that a whole data-parallel update
+ * -- gather -> gradients -> all-reduce -> Adam/Polyak -- is ONE hipGraph (BASELINE.json configs[4]) with no
+ * per-step host call. librccl is opened at run time (`rccl_path`: the copy torch already loaded, so that one
+ * RCCL serves the process; NULL: "librccl.so").
+ *   dsact_comm_unique_id   rank 0 creates the 128-byte ncclUniqueId; the caller ships it to the other ranks
+ *   dsact_comm_init        every rank joins (ncclCommInitRank); the communicator lives in the handle
+ *   dsact_dp_enqueue_allreduce   average of the gradient arena (+ the 2-float mean_std tail) over the ranks,
+ *                          enqueued between dsact_dp_enqueue_grads and dsact_dp_enqueue_apply
+ *   dsact_graph_build(..., DSACT_F_DATA_PARALLEL)  captures that chain per step; in strict mode
+ *                          (dsact_dp_set_strict) also the 2-float all-reduce of the std sums before the loss */
+int dsact_comm_unique_id(const char* rccl_path, uint8_t id[128]);
+int dsact_comm_init(dsact_handle* h, int32_t rank, int32_t world, const uint8_t id[128], const char* rccl_path);
+int dsact_comm_destroy(dsact_handle* h);
+int dsact_dp_enqueue_allreduce(dsact_handle* h);
 
 /* 14 numeric tb_info entries of the last update in the order of dsac_v2.py:188-202
  * (avg_q1, avg_q2, avg_std1, avg_std2, min_std1, min_std2, loss_actor, loss_critic, policy_mean,

@@ -517,6 +517,56 @@ def test_data_parallel_halves_equal_graph_replay():
             dist.destroy_process_group()
 
 
+def test_native_rccl_graph_captured_data_parallel_update():
+    """dsact_comm_init (the library's own RCCL communicator) + dsact_graph_build(DSACT_F_DATA_PARALLEL): gather ->
+    gradients -> ncclAllReduce -> Adam/Polyak captured in ONE hipGraph (BASELINE.json configs[4]). World size 1 here
+    (gpurun exposes one GPU): the average over one rank is the identity, so the result must equal the fused
+    single-GPU graph replay bit for bit -- with the collective really in the graph; also the eager native path."""
+    import torch.distributed as dist
+    from dsact.dp import DataParallelUpdater
+
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        created = True
+    try:
+        for shape in ((17, 4, (64, 64), 64), (376, 17, (256, 256, 256), 256)):
+            O, A, hid, B = shape
+            a1 = _replay_pair(O, A, hid, B, 4096, seed=4)
+            a1.engine.graph_build(2)
+            a1.engine.graph_run(0, 6)
+            a1.engine.sync()
+            # graph-captured data-parallel update
+            a2 = _replay_pair(O, A, hid, B, 4096, seed=4)
+            e2 = a2.engine
+            dp2 = DataParallelUpdater(e2, broadcast_tensors=(e2.online, e2.target, e2.adam_m, e2.adam_v), native=True)
+            dp2.build_graph(3)
+            dp2.run_graph(0, 6)
+            e2.sync()
+            torch.cuda.synchronize()
+            for name in ("online", "target", "adam_m", "adam_v"):
+                assert torch.equal(getattr(a1.engine, name), getattr(e2, name)), (shape, "graph", name)
+            assert a1.engine.get_state() == e2.get_state()
+            # eager halves with the native all-reduce in the seam
+            a3 = _replay_pair(O, A, hid, B, 4096, seed=4)
+            e3 = a3.engine
+            dp3 = DataParallelUpdater(e3, broadcast_tensors=(e3.online, e3.target, e3.adam_m, e3.adam_v), native=True)
+            dp3.force_collective = True
+            e3.dp_begin(0)
+            for _ in range(6):
+                dp3.step()
+            e3.sync()
+            torch.cuda.synchronize()
+            for name in ("online", "target", "adam_m", "adam_v"):
+                assert torch.equal(getattr(a1.engine, name), getattr(e3, name)), (shape, "eager", name)
+            e2.comm_destroy(); e3.comm_destroy()
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_strict_data_parallel_shards_equal_global_batch():
     """SURVEY.md section 8e, strict mode: two replicas on the halves of one minibatch, with the 2-float
     pre-loss exchange of {sum std1, sum std2} (emulated in-process: gpurun exposes one GPU), average to the

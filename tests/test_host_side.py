@@ -176,11 +176,36 @@ def test_v1_layout_matches_the_v1_oracle():
 
 
 def test_bench_helpers():
-    sys.path.insert(0, ROOT)
+    """graph sizing replays exactly W and exactly K steps; roofline helper accounts every launch of the chain path"""
     import bench
-
-    for steps, warm in ((20000, 2000), (4000, 400), (10, 2), (400, 40), (7000, 500), (2, 0)):
+    for steps, warm in ((20, 5), (20, 6), (4000, 400), (20000, 2000), (7, 3), (300, 0)):
         g = bench.graph_steps(steps, warm)
-        assert g % 2 == 0 and 2 <= g <= 64 and steps % g == 0 and (warm % g == 0)
-    t = bench.pmc_traffic_forward_stage()
-    assert t is None or 1e6 < t < 5e7      # bytes per launch of the forward tile stage, from the committed PMC pass
+        assert 1 <= g <= 64 and steps % g == 0 and (warm % g == 0 or warm == 0), (steps, warm, g)
+    assert bench.graph_steps(20, 6, even=True) % 2 == 0
+    assert bench.n_regions(20) == 5 and bench.n_regions(20000) == 3
+    from dsact.layout import ArenaLayout
+    lay = ArenaLayout(376, 17, [256, 256, 256])
+    fl = bench.chain_flops(lay, 256)
+    # forward A+B = every forward MAC of SURVEY 8(d) (1,865,216 per sample); the shared obs part is counted once
+    fwd = (fl["chain_fwd_a"] + fl["chain_fwd_b"]) / (2.0 * 256)
+    assert abs(fwd - (1865216 - 2 * 376 * 256)) < 1, fwd
+    assert bench.pmc_traffic("no-such-kernel") is None
+
+
+def test_bench_gpus_flag_spawns_ranks_and_never_underreports(tmp_path):
+    """`python bench.py --gpus 2` without a torch.distributed environment re-executes itself with 2 ranks (gloo dry run
+    here: no GPU); without --dry-run-cpu and with fewer than N devices it refuses instead of printing n_gpus: 1."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run-cpu"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["dry_run"] and d["n_gpus"] == 2 and d["sum"] == 3.0 and d["steps"] == 20 and d["warmup"] == 5
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2 and "refusing" in r.stderr, (r.returncode, r.stderr[-500:])
+    assert "n_gpus" not in r.stdout
