@@ -151,11 +151,16 @@ struct dsact_handle {
   // environment switches, read once at dsact_create (getenv walks the whole environment: ~20 calls per eager update
   // were host time on the launch path)
   std::string env_timeline_stage;   // DSACT_TIMELINE_STAGE
-  bool env_no_tile64 = false, env_no_hb_ride = false, env_no_merged_gather = false;
+  bool env_no_tile64 = false, env_no_hb_ride = false, env_no_merged_gather = false, env_no_lead_graph = false;
   int env_conv_dw_nkt = 1;
   int env_ride_slots = 0;           // DSACT_RIDE_SLOTS: weight-gradient tiles riding in the policy-backward launch (default: one round)
   bool mirror_w0 = false;      // set while the merged-gather graph is being captured (see FusedOpt::mir_*)
   bool merged_graph = false;   // the captured graph uses the merged-gather flow
+  bool have_local_tail = false;   // the gradient arena's tail holds mean_std of a gradient computed HERE and not yet committed
+  long long dev_it_next = -1;  // host shadow of DevState::it_next after graph replays (-1: unknown, upload it)
+  hipEvent_t tev0 = nullptr, tev1 = nullptr;   // dsact_time_steps' events, created once
+  hipEvent_t uev0 = nullptr, uev1 = nullptr;   // around the last eager update (dsact_step / dsact_compute_grads)
+  bool uev_valid = false;
   // replay ring
   long long cap = 0, ptr = 0, size = 0;
   float *rb_obs = nullptr, *rb_obs2 = nullptr, *rb_act = nullptr, *rb_rew = nullptr, *rb_done = nullptr, *rb_logp = nullptr;
@@ -172,6 +177,11 @@ struct dsact_handle {
   // graph
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
+  // the first group of a replay call runs as a short lead graph + the tail: hipGraphLaunch prepares every node before
+  // the first one is dispatched, so the long graph's launch cost hides behind the lead's execution
+  hipGraph_t lead_graph = nullptr, tail_graph = nullptr;
+  hipGraphExec_t lead_exec = nullptr, tail_exec = nullptr;
+  int lead_steps = 0;
   int graph_steps = 0;
   uint32_t graph_flags = 0;
   // profiling
@@ -206,7 +216,6 @@ struct dsact_handle {
 
 namespace {
 
-double dec7(float f);
 
 // ---- librccl, opened at run time (no link-time dependency: the library also serves single-GPU users) ----------
 struct NcclUid { char internal[128]; };
@@ -411,7 +420,7 @@ void carve(dsact_handle* h, Carver& c) {
   h->part_loss = c.take<float>(B * kLossPart);
   for (int i = 0; i < 4; ++i) h->W1p[i] = c.take<float>(h->use_w1p ? (size_t)h->w[0] * h->ldx : 4);
   h->part_heads = c.take<float>((size_t)h->n_heads_wg * 2);
-  h->stats = c.take<float>(16);
+  h->stats = c.take<float>(16 * (1 + DSACT_STATS_SLOTS));   // [0]: dsact_read_stats; [1 + slot]: the snapshot ring
   h->ones = c.take<float>(B);
   h->std_sums = c.take<float>(2);
   h->timeline = c.take<long long>(512 * 16);
@@ -775,11 +784,11 @@ FusedOpt fused_opt(const dsact_handle* h, bool enable) {
   f.st = (enable && h->dw_chunks == 1) ? h->st : nullptr;   // split-K partials: the optimiser runs after k_sum_parts
   f.online = h->online; f.target = h->target; f.adam_m = h->adam_m; f.adam_v = h->adam_v; f.grads = h->grads;
   f.n_q2 = (long long)(h->nq * h->n_q); f.n_online3 = (long long)(h->nq * h->n_q + h->n_pi); f.n_total = (long long)h->n_online;
-  f.b1w = (float)(1.0 - dec7(h->cfg.adam_beta1));
-  f.beta2 = (float)dec7(h->cfg.adam_beta2);
-  f.b2w = (float)(1.0 - dec7(h->cfg.adam_beta2));
+  f.b1w = (float)(1.0 - h->cfg.adam_beta1);
+  f.beta2 = (float)h->cfg.adam_beta2;
+  f.b2w = (float)(1.0 - h->cfg.adam_beta2);
   f.eps = h->cfg.adam_eps;
-  const double polyak = 1.0 - dec7(h->cfg.tau);
+  const double polyak = 1.0 - h->cfg.tau;
   f.polyak = (float)polyak;
   f.one_minus_polyak = (float)(1.0 - polyak);
   f.auto_alpha = h->cfg.auto_alpha;
@@ -1102,20 +1111,11 @@ int enqueue_gather_img(dsact_handle* h, const float* src_obs, const float* src_o
     else { CALL(4); }                          \
   } while (0)
 
-// exact decimal value a float config field was written as (0.9f -> 0.9, 1e-4f -> 1e-4): the
-// reference computes Adam's bias corrections from Python doubles
-double dec7(float f);
-double dec7(float f) {
-  char buf[32];
-  snprintf(buf, sizeof(buf), "%.7g", (double)f);
-  return strtod(buf, nullptr);
-}
-
 StepHyper step_hyper(const dsact_handle* h) {
   StepHyper hp;
   hp.delay_update = h->cfg.delay_update;
-  hp.lr_q = dec7(h->cfg.lr_q); hp.lr_pi = dec7(h->cfg.lr_pi); hp.lr_alpha = dec7(h->cfg.lr_alpha);
-  hp.beta1 = dec7(h->cfg.adam_beta1); hp.beta2 = dec7(h->cfg.adam_beta2);
+  hp.lr_q = h->cfg.lr_q; hp.lr_pi = h->cfg.lr_pi; hp.lr_alpha = h->cfg.lr_alpha;
+  hp.beta1 = h->cfg.adam_beta1; hp.beta2 = h->cfg.adam_beta2;
   return hp;
 }
 NoiseArgs noise_args(const dsact_handle* h) {
@@ -1250,6 +1250,7 @@ Dw2Args dw2_args(dsact_handle* h, bool fused) {
   a.gout = h->dw_chunks > 1 ? h->dw_parts : h->grads;
   a.part_stride = h->dw_chunks > 1 ? (long long)h->dw_part_stride : 0;
   a.fo = fused_opt(h, fused);
+  a.store_g = !(fused && h->mirror_w0 && h->dw_chunks == 1);
   return a;
 }
 
@@ -1361,7 +1362,7 @@ int enqueue_chain_bwd_q(dsact_handle* h, int n_units, const RideArgs* ride) {
   a.inv_Bg = h->use_std_sums ? 1.0f / (float)h->cfg.global_batch : 1.0f / (float)h->B;
   a.std_sums = h->use_std_sums ? h->std_sums : nullptr;
   a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.gamma = h->cfg.gamma; a.tau_b = h->cfg.tau_b;
-  a.one_minus_tau_b = (float)(1.0 - dec7(h->cfg.tau_b));
+  a.one_minus_tau_b = (float)(1.0 - h->cfg.tau_b);
   a.n_chain_blocks = chain_grid(n_units, h->n_slices);
   a.timeline = tl_for(h, "chain_bwd_q");
   if (ride) a.ride = *ride;
@@ -1451,6 +1452,7 @@ actor_part:
 // `ride` (graph replays with the merged gather): nullptr, or the riders of the loss launch -- this update's
 // bookkeeping and, when ride->n_gather > 0, the next update's gather into the other batch set
 int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 0, const RideArgs* ride = nullptr) {
+  h->have_local_tail = true;
   if (h->chain_ok) return enqueue_grads_chain(h, actor_backward, fused, phase, ride);
   const int L = h->L, B = h->B, A = h->A;
   if (phase == 4) goto actor_part;
@@ -1544,7 +1546,7 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
     a.inv_B = 1.0f / (float)B;
     a.inv_Bg = h->use_std_sums ? 1.0f / (float)h->cfg.global_batch : 1.0f / (float)B;
     a.std_sums = (h->use_std_sums || h->auto_std_sums) ? h->std_sums : nullptr;
-    a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.gamma = h->cfg.gamma; a.tau_b = h->cfg.tau_b; a.one_minus_tau_b = (float)(1.0 - dec7(h->cfg.tau_b));
+    a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.gamma = h->cfg.gamma; a.tau_b = h->cfg.tau_b; a.one_minus_tau_b = (float)(1.0 - h->cfg.tau_b);
     a.timeline = tl_for(h, "loss");
     if (ride) a.ride = *ride;
     a.ride.n_loss_blocks = h->n_loss_wg;
@@ -1676,17 +1678,27 @@ int enqueue_adam(dsact_handle* h, bool from_parts) {
   a.p = h->online; a.tgt = h->target; a.m = h->adam_m; a.v = h->adam_v; a.g = h->grads;
   a.n_q2 = (long long)(h->nq * h->n_q); a.n_online3 = (long long)(h->nq * h->n_q + h->n_pi); a.n_total = (long long)h->n_online;
   a.st = h->st;
-  a.b1w = (float)(1.0 - dec7(h->cfg.adam_beta1));
-  a.beta2 = (float)dec7(h->cfg.adam_beta2);
-  a.b2w = (float)(1.0 - dec7(h->cfg.adam_beta2));
+  a.b1w = (float)(1.0 - h->cfg.adam_beta1);
+  a.beta2 = (float)h->cfg.adam_beta2;
+  a.b2w = (float)(1.0 - h->cfg.adam_beta2);
   a.eps = h->cfg.adam_eps;
-  const double polyak = 1.0 - dec7(h->cfg.tau);  // dsac_v2.py:331
+  const double polyak = 1.0 - h->cfg.tau;  // dsac_v2.py:331
   a.polyak = (float)polyak;
   a.one_minus_polyak = (float)(1.0 - polyak);
   a.auto_alpha = h->cfg.auto_alpha;
-  a.commit_ms = 1;
+  a.commit_ms = h->have_local_tail ? 1 : 0;   // dsac_v2.py remote_update never touches mean_std: commit only a tail this handle computed
+  h->have_local_tail = false;
   const int blocks = (int)((h->n_online + kThreads * 8 - 1) / (kThreads * 8));  // 2 float4 groups per thread
   return launch(h, "adam_polyak", k_adam, dim3(blocks), dim3(kThreads), 0, a);
+}
+
+void drop_graphs(dsact_handle* h) {
+  for (hipGraphExec_t* e : {&h->graph_exec, &h->lead_exec, &h->tail_exec})
+    if (*e) { hipGraphExecDestroy(*e); *e = nullptr; }
+  for (hipGraph_t* g : {&h->graph, &h->lead_graph, &h->tail_graph})
+    if (*g) { hipGraphDestroy(*g); *g = nullptr; }
+  h->graph_steps = 0;
+  h->lead_steps = 0;
 }
 
 int check_ready(dsact_handle* h, bool need_batch) {
@@ -1694,6 +1706,7 @@ int check_ready(dsact_handle* h, bool need_batch) {
   if (!h->online || !h->grads) return fail(h, DSACT_E_STATE, "arenas not bound (dsact_bind_arenas)");
   if (!h->limits_set) return fail(h, DSACT_E_STATE, "action limits not set (dsact_set_action_limits)");
   if (need_batch && !h->have_batch) return fail(h, DSACT_E_STATE, "no minibatch staged (dsact_gather / dsact_load_batch)");
+  h->dev_it_next = -1;   // every update entry point except the graph replays passes through here
   return DSACT_OK;
 }
 
@@ -1782,6 +1795,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->env_no_tile64 = getenv("DSACT_NO_TILE64") != nullptr;
   h->env_no_hb_ride = getenv("DSACT_NO_HB_RIDE") != nullptr;
   h->env_no_merged_gather = getenv("DSACT_NO_MERGED_GATHER") != nullptr;
+  h->env_no_lead_graph = getenv("DSACT_NO_LEAD_GRAPH") != nullptr;
   if (const char* v = getenv("DSACT_CONV_DW_NKT")) h->env_conv_dw_nkt = atoi(v);
   if (const char* v = getenv("DSACT_RIDE_SLOTS")) h->env_ride_slots = atoi(v);
   h->dw_chunks = (h->B > 448 && h->B % 256 == 0 && getenv("DSACT_NO_SPLITK") == nullptr) ? h->B / 256 : 1;
@@ -1876,10 +1890,11 @@ int dsact_destroy(dsact_handle* h) {
   if (!h) return DSACT_E_INVALID;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
-  if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
-  if (h->graph) hipGraphDestroy(h->graph);
+  drop_graphs(h);
   if (h->comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   for (auto& r : h->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  if (h->tev0) { hipEventDestroy(h->tev0); hipEventDestroy(h->tev1); }
+  if (h->uev0) { hipEventDestroy(h->uev0); hipEventDestroy(h->uev1); }
   for (int i = 0; i < 8; ++i) {
     if (h->h_idx[i]) hipHostFree(h->h_idx[i]);
     if (h->h_idx_ev[i]) hipEventDestroy(h->h_idx_ev[i]);
@@ -1984,7 +1999,7 @@ int dsact_set_state(dsact_handle* h, const int32_t adam_steps[3], const float me
   HIPCHK(h, hipMemcpy(&st, h->st, sizeof(st), hipMemcpyDeviceToHost));
   if (adam_steps) {
     st.t_q = adam_steps[0]; st.t_pi = adam_steps[1]; st.t_alpha = adam_steps[2];
-    const double b1 = dec7(h->cfg.adam_beta1), b2 = dec7(h->cfg.adam_beta2);
+    const double b1 = h->cfg.adam_beta1, b2 = h->cfg.adam_beta2;
     st.b1p_q = pow(b1, st.t_q); st.b2p_q = pow(b2, st.t_q);
     st.b1p_pi = pow(b1, st.t_pi); st.b2p_pi = pow(b2, st.t_pi);
     st.b1p_alpha = pow(b1, st.t_alpha); st.b2p_alpha = pow(b2, st.t_alpha);
@@ -1998,6 +2013,34 @@ int dsact_set_state(dsact_handle* h, const int32_t adam_steps[3], const float me
 }
 
 // ---- replay ring ---------------------------------------------------------------------------------
+int dsact_set_hyper(dsact_handle* h, int32_t which, double value) {
+  if (!h) return DSACT_E_INVALID;
+  if (!(value == value)) return fail(h, DSACT_E_INVALID, "hyper-parameter is NaN");
+  switch (which) {
+    case DSACT_HYPER_GAMMA: h->cfg.gamma = value; break;
+    case DSACT_HYPER_TAU:
+      if (value < 0.0 || value > 1.0) return fail(h, DSACT_E_INVALID, "tau outside [0, 1]");
+      h->cfg.tau = value; break;
+    case DSACT_HYPER_TAU_B:
+      if (value < 0.0 || value > 1.0) return fail(h, DSACT_E_INVALID, "tau_b outside [0, 1]");
+      h->cfg.tau_b = value; break;
+    case DSACT_HYPER_AUTO_ALPHA: h->cfg.auto_alpha = value != 0.0 ? 1 : 0; break;
+    case DSACT_HYPER_ALPHA: h->cfg.alpha_fixed = value; break;
+    case DSACT_HYPER_DELAY_UPDATE:
+      if (value < 1.0 || value != (double)(int32_t)value) return fail(h, DSACT_E_INVALID, "delay_update must be a positive integer");
+      h->cfg.delay_update = (int32_t)value; break;
+    case DSACT_HYPER_TD_BOUND:
+      if (h->cfg.algo != 1) return fail(h, DSACT_E_INVALID, "TD_bound is a DSAC_V1 parameter");
+      h->cfg.td_bound = value; break;
+    default: return fail(h, DSACT_E_INVALID, "unknown hyper-parameter %d", (int)which);
+  }
+  // every launch reads h->cfg when it is enqueued; only a captured graph holds old values
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  drop_graphs(h);
+  return DSACT_OK;
+}
+
 int dsact_buffer_create(dsact_handle* h, int64_t capacity) {
   if (!h || capacity < 1) return DSACT_E_INVALID;
   if (capacity > 2147483647LL) return fail(h, DSACT_E_INVALID, "capacity must fit int32 (device indices)");
@@ -2237,11 +2280,25 @@ int dsact_set_device_rng(dsact_handle* h, uint64_t seed) {
 }
 
 // ---- update --------------------------------------------------------------------------------------
+// device time of the last eager update (the reference's "Time/Algorithm time" is the wall time of a synchronous CPU
+// update; here the call returns after the enqueue, so the honest figure is the stream time between these two events)
+static int mark_update(dsact_handle* h, bool end) {
+  if (!h->uev0) {
+    HIPCHK(h, hipEventCreate(&h->uev0));
+    HIPCHK(h, hipEventCreate(&h->uev1));
+  }
+  HIPCHK(h, hipEventRecord(end ? h->uev1 : h->uev0, h->stream));
+  h->uev_valid = end;
+  return DSACT_OK;
+}
+
 int dsact_compute_grads(dsact_handle* h, int64_t iteration, uint32_t flags) {
   TRY(check_ready(h, true));
   HIPCHK(h, hipSetDevice(h->device));
+  TRY(mark_update(h, false));
   TRY(enqueue_prologue(h, 0, iteration, 0, 1));
-  return enqueue_grads(h, !(flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) || (iteration % h->cfg.delay_update) == 0, false);
+  TRY(enqueue_grads(h, !(flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) || (iteration % h->cfg.delay_update) == 0, false));
+  return mark_update(h, true);
 }
 
 int dsact_apply_update(dsact_handle* h, int64_t iteration) {
@@ -2254,9 +2311,11 @@ int dsact_apply_update(dsact_handle* h, int64_t iteration) {
 int dsact_step(dsact_handle* h, int64_t iteration, uint32_t flags) {
   TRY(check_ready(h, true));
   HIPCHK(h, hipSetDevice(h->device));
+  TRY(mark_update(h, false));
   TRY(enqueue_prologue(h, 0, iteration, 1, 1));
   // single-GPU update: Adam / Polyak are applied by the weight-gradient tiles themselves (no k_adam)
-  return enqueue_grads(h, !(flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) || (iteration % h->cfg.delay_update) == 0, true);
+  TRY(enqueue_grads(h, !(flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) || (iteration % h->cfg.delay_update) == 0, true));
+  return mark_update(h, true);
 }
 
 // one replayed update (iteration and index-table row from device state). `iteration` is only used to
@@ -2291,32 +2350,13 @@ static int enqueue_graph_step(dsact_handle* h, long long iteration, uint32_t fla
   return enqueue_grads(h, actor, true);
 }
 
-int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) {
-  TRY(check_ready(h, false));
-  if (steps_per_graph < 1) return fail(h, DSACT_E_INVALID, "steps_per_graph must be >= 1");
-  if (!h->idx_table) return fail(h, DSACT_E_STATE, "upload an index table first (dsact_upload_index_table)");
-  HIPCHK(h, hipSetDevice(h->device));
-  if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
-  if (h->graph) { hipGraphDestroy(h->graph); h->graph = nullptr; }
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  const bool was_prof = h->profiling;
-  h->profiling = false;
-  if ((flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) && steps_per_graph % h->cfg.delay_update)
-    return fail(h, DSACT_E_INVALID, "with DSACT_F_SKIP_ACTOR_ON_OFF_ITERS steps_per_graph must be a multiple of delay_update");
-  // Merged gather (MLP nets, fused single-launch-chain update): one gather launch opens the graph; every update's
-  // loss launch carries the bookkeeping and the NEXT update's gather into the other batch set; the per-step repack
-  // of the padded first-layer copies is done by the weight-gradient tiles themselves (FusedOpt::mir_*).
-  // Update s of n uses set (n-1-s)&1, so the last staged minibatch sits in set 0 like after eager updates.
-  if ((flags & DSACT_F_DATA_PARALLEL) && !h->comm) return fail(h, DSACT_E_STATE, "DSACT_F_DATA_PARALLEL needs dsact_comm_init");
-  const bool merged = !h->cnn && h->use_w1p && h->dw_chunks == 1 && !h->use_fork && !h->use_std_sums && h->alt_ws != nullptr &&
-                      !h->env_no_merged_gather && !(flags & DSACT_F_DATA_PARALLEL);
-  h->merged_graph = merged;
+// captures `n` updates on the handle's stream into (*graph, *exec)
+static int capture_updates(dsact_handle* h, int n, uint32_t flags, bool merged, hipGraph_t* graph, hipGraphExec_t* exec) {
   HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
   int rc = DSACT_OK;
   if (!merged) {
-    for (int s = 0; s < steps_per_graph && rc == DSACT_OK; ++s) rc = enqueue_graph_step(h, s, flags);
+    for (int s = 0; s < n && rc == DSACT_OK; ++s) rc = enqueue_graph_step(h, s, flags);
   } else {
-    const int n = steps_per_graph;
     h->mirror_w0 = true;
     select_set(h, (n - 1) & 1);
     rc = enqueue_gather(h, h->idx_table, h->idx_rows, 1, 0, 1, /*bookkeeping=*/0);
@@ -2335,21 +2375,67 @@ int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) 
     select_set(h, 0);
     h->mirror_w0 = false;
   }
-  hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
-  h->profiling = was_prof;
+  hipError_t e = hipStreamEndCapture(h->stream, graph);
   if (rc != DSACT_OK) return rc;
   if (e != hipSuccess) return fail(h, DSACT_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-  HIPCHK(h, hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+  HIPCHK(h, hipGraphInstantiate(exec, *graph, nullptr, nullptr, 0));
+  return DSACT_OK;
+}
+
+int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) {
+  TRY(check_ready(h, false));
+  if (steps_per_graph < 1) return fail(h, DSACT_E_INVALID, "steps_per_graph must be >= 1");
+  if (!h->idx_table) return fail(h, DSACT_E_STATE, "upload an index table first (dsact_upload_index_table)");
+  HIPCHK(h, hipSetDevice(h->device));
+  drop_graphs(h);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if ((flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) && steps_per_graph % h->cfg.delay_update)
+    return fail(h, DSACT_E_INVALID, "with DSACT_F_SKIP_ACTOR_ON_OFF_ITERS steps_per_graph must be a multiple of delay_update");
+  // Merged gather (MLP nets, fused single-launch-chain update): one gather launch opens the graph; every update's
+  // loss launch carries the bookkeeping and the NEXT update's gather into the other batch set; the per-step repack
+  // of the padded first-layer copies is done by the weight-gradient tiles themselves (FusedOpt::mir_*).
+  // Update s of n uses set (n-1-s)&1, so the last staged minibatch sits in set 0 like after eager updates.
+  if ((flags & DSACT_F_DATA_PARALLEL) && !h->comm) return fail(h, DSACT_E_STATE, "DSACT_F_DATA_PARALLEL needs dsact_comm_init");
+  const bool merged = !h->cnn && h->use_w1p && h->dw_chunks == 1 && !h->use_fork && !h->use_std_sums && h->alt_ws != nullptr &&
+                      !h->env_no_merged_gather && !(flags & DSACT_F_DATA_PARALLEL);
+  h->merged_graph = merged;
+  const bool was_prof = h->profiling;
+  h->profiling = false;
+  int rc = capture_updates(h, steps_per_graph, flags, merged, &h->graph, &h->graph_exec);
+  // lead + tail of the first group (see the handle): the lead is the shortest run that keeps the capture-time
+  // decisions (off iterations of the delayed update) aligned
+  const int lead = (flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) ? h->cfg.delay_update : 2;
+  if (rc == DSACT_OK && !h->env_no_lead_graph && steps_per_graph >= lead + 4) {
+    rc = capture_updates(h, lead, flags, merged, &h->lead_graph, &h->lead_exec);
+    if (rc == DSACT_OK) rc = capture_updates(h, steps_per_graph - lead, flags, merged, &h->tail_graph, &h->tail_exec);
+    if (rc == DSACT_OK) h->lead_steps = lead;
+  }
+  h->profiling = was_prof;
+  if (rc != DSACT_OK) { drop_graphs(h); return rc; }
   h->graph_steps = steps_per_graph;
   h->graph_flags = flags;
   h->have_batch = true;
   return DSACT_OK;
 }
 
+// n_groups back-to-back replays of the captured updates
+static int launch_groups(dsact_handle* h, int64_t n_groups) {
+  int64_t i = 0;
+  if (h->lead_steps && n_groups > 0) {
+    HIPCHK(h, hipGraphLaunch(h->lead_exec, h->stream));
+    HIPCHK(h, hipGraphLaunch(h->tail_exec, h->stream));
+    i = 1;
+  }
+  for (; i < n_groups; ++i) HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
+  return DSACT_OK;
+}
+
 static int set_device_iteration(dsact_handle* h, long long it) {
-  // it_next lives at offset 0 of DevState
+  // it_next lives at offset 0 of DevState; back-to-back graph replays leave it where the next one starts
+  if (h->dev_it_next == it) return DSACT_OK;
   HIPCHK(h, hipMemcpyAsync(&h->st->it_next, &it, sizeof(long long), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->dev_it_next = it;
   return DSACT_OK;
 }
 
@@ -2361,7 +2447,8 @@ int dsact_graph_run(dsact_handle* h, int64_t first_iteration, int64_t n_steps) {
     return fail(h, DSACT_E_INVALID, "first_iteration must be a multiple of delay_update for a graph captured with DSACT_F_SKIP_ACTOR_ON_OFF_ITERS");
   HIPCHK(h, hipSetDevice(h->device));
   TRY(set_device_iteration(h, first_iteration));
-  for (int64_t i = 0; i < n_steps / h->graph_steps; ++i) HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
+  TRY(launch_groups(h, n_steps / h->graph_steps));
+  h->dev_it_next = first_iteration + n_steps;
   return DSACT_OK;
 }
 
@@ -2477,21 +2564,47 @@ int dsact_dp_enqueue_allreduce(dsact_handle* h) {
   return enqueue_allreduce(h, h->grads, h->n_online + 2, kNcclAvg);
 }
 
-int dsact_read_stats(dsact_handle* h, float out[16]) {
-  if (!h || !out) return DSACT_E_INVALID;
-  TRY(check_ready(h, false));
-  HIPCHK(h, hipSetDevice(h->device));
+static int enqueue_stats(dsact_handle* h, float* dst) {
   StatsArgs a;
   a.part_loss = h->part_loss; a.n_loss = h->B; a.part_heads = h->part_heads; a.n_heads = h->chain_ok ? h->n_heads_parts : h->n_heads_wg;
   a.log_alpha = h->online + h->n_online - 1; a.st = h->st;
   a.inv_B = 1.0f / (float)h->B; a.inv_BA = 1.0f / ((float)h->B * (float)h->A);
-  a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.out = h->stats;
+  a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.out = dst;
+  // a gradient computed here and not yet applied (get_remote_update_info): report the mean_std its loss used
+  a.ms_tail = h->have_local_tail && h->cfg.algo == 0 ? h->grads + h->n_online : nullptr;
   const bool was_prof = h->profiling;
   h->profiling = false;
   int rc = launch(h, "stats", k_stats, dim3(1), dim3(64), 0, a);
   h->profiling = was_prof;
-  TRY(rc);
+  return rc;
+}
+
+int dsact_read_stats(dsact_handle* h, float out[16]) {
+  if (!h || !out) return DSACT_E_INVALID;
+  TRY(check_ready(h, false));
+  HIPCHK(h, hipSetDevice(h->device));
+  TRY(enqueue_stats(h, h->stats));
   HIPCHK(h, hipMemcpyAsync(out, h->stats, 16 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  out[15] = -1.0f;
+  if (h->uev_valid) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->uev0, h->uev1) == hipSuccess) out[15] = ms;
+  }
+  return DSACT_OK;
+}
+
+int dsact_stats_snapshot(dsact_handle* h, int32_t slot) {
+  if (!h || slot < 0 || slot >= DSACT_STATS_SLOTS) return DSACT_E_INVALID;
+  TRY(check_ready(h, false));
+  HIPCHK(h, hipSetDevice(h->device));
+  return enqueue_stats(h, h->stats + 16 * (1 + slot));
+}
+
+int dsact_stats_read(dsact_handle* h, int32_t slot, float out[16]) {
+  if (!h || !out || slot < 0 || slot >= DSACT_STATS_SLOTS) return DSACT_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(out, h->stats + 16 * (1 + slot), 16 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return DSACT_OK;
 }
@@ -2499,28 +2612,31 @@ int dsact_read_stats(dsact_handle* h, float out[16]) {
 // ---- measurement -----------------------------------------------------------------------------------
 int dsact_time_steps(dsact_handle* h, int64_t first_iteration, int64_t n_steps, uint32_t flags, int32_t use_graph, float* ms_total) {
   if (!h || !ms_total || n_steps < 1) return DSACT_E_INVALID;
+  const long long shadow = h->dev_it_next;
   TRY(check_ready(h, false));
+  if (use_graph) h->dev_it_next = shadow;   // replays keep the device iteration in step with the host's view
   HIPCHK(h, hipSetDevice(h->device));
   if (!h->idx_table) return fail(h, DSACT_E_STATE, "upload an index table first");
-  hipEvent_t e0, e1;
-  HIPCHK(h, hipEventCreate(&e0));
-  HIPCHK(h, hipEventCreate(&e1));
+  if (!h->tev0) {
+    HIPCHK(h, hipEventCreate(&h->tev0));
+    HIPCHK(h, hipEventCreate(&h->tev1));
+  }
   TRY(set_device_iteration(h, first_iteration));
-  HIPCHK(h, hipEventRecord(e0, h->stream));
+  HIPCHK(h, hipEventRecord(h->tev0, h->stream));
   if (use_graph) {
     if (!h->graph_exec) return fail(h, DSACT_E_STATE, "dsact_graph_build first");
     if (n_steps % h->graph_steps) return fail(h, DSACT_E_INVALID, "n_steps must be a multiple of steps_per_graph");
     if ((h->graph_flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) && first_iteration % h->cfg.delay_update)
       return fail(h, DSACT_E_INVALID, "first_iteration must be a multiple of delay_update");
-    for (int64_t i = 0; i < n_steps / h->graph_steps; ++i) HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
+    TRY(launch_groups(h, n_steps / h->graph_steps));
+    h->dev_it_next = first_iteration + n_steps;
   } else {
+    h->dev_it_next = -1;
     for (int64_t i = 0; i < n_steps; ++i) TRY(enqueue_graph_step(h, first_iteration + i, flags));
   }
-  HIPCHK(h, hipEventRecord(e1, h->stream));
-  HIPCHK(h, hipEventSynchronize(e1));
-  HIPCHK(h, hipEventElapsedTime(ms_total, e0, e1));
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  HIPCHK(h, hipEventRecord(h->tev1, h->stream));
+  HIPCHK(h, hipEventSynchronize(h->tev1));
+  HIPCHK(h, hipEventElapsedTime(ms_total, h->tev0, h->tev1));
   h->have_batch = true;   // the last update's minibatch stays staged
   return DSACT_OK;
 }

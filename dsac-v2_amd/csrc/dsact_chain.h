@@ -204,6 +204,7 @@ struct Dw2Args {
   float* gout;            // gradient destination arena (grads; split-K: partial arena 0)
   long long part_stride;  // split-K: floats between the partial arenas
   FusedOpt fo;            // fo.st == nullptr: plain gradient store
+  int store_g;            // 0: fused graph replays -- nothing reads the gradient arena, skip its 4.6 MB of stores
 };
 constexpr int kDw2LdsFloats = 4 * 4 * 64 * 4 + 4 * 2 * 64;
 
@@ -288,8 +289,10 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds) {
   float* C = a.gout + range * a.part_stride;
   if (in_range) {
     float* c0 = C + oi;
-    if (full) *(f32x4u*)c0 = v;
-    else for (int e = 0; e < 4 && n + e < P.N; ++e) c0[e] = v[e];
+    if (a.store_g) {
+      if (full) *(f32x4u*)c0 = v;
+      else for (int e = 0; e < 4 && n + e < P.N; ++e) c0[e] = v[e];
+    }
     if (fused && o_upd) {
       if (full) {
 #pragma unroll
@@ -323,7 +326,7 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds) {
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg) sbias += lds[4096 + (w * 2 + (tid >> 4)) * 64 + gg * 16 + (tid & 15)];
       const long long bi = P.b_idx + mb;
-      C[bi] = sbias;
+      if (a.store_g) C[bi] = sbias;
       if (fused && o_upd) {
         float pe = a.fo.online[bi], me = a.fo.adam_m[bi], ve = a.fo.adam_v[bi];
         adam_update(pe, me, ve, sbias, a.fo.b1w, a.fo.beta2, a.fo.b2w, o_ss, o_bc2, a.fo.eps);
@@ -469,7 +472,7 @@ __global__ void __launch_bounds__(64 * NW) k_chain_fwd(FwdArgs a) {
       f32x4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = lds[xin + (4 * g4 + r) * S.ld_in + kk];
-      *(f32x4*)(u.x0t + pk_index(k, row0 + 4 * g4, a.Cb)) = v;
+      nt_store4(u.x0t + pk_index(k, row0 + 4 * g4, a.Cb), v);
     }
   }
   const int xs_in = xin + (lane & 3) * S.ld_in;
@@ -507,8 +510,8 @@ __global__ void __launch_bounds__(64 * NW) k_chain_fwd(FwdArgs a) {
       gelu4(z, hv, gd);
 #pragma unroll
       for (int r = 0; r < 4; ++r) lds[hn + (4 * g + r) * S.ld_h + n] = hv[r];
-      if (u.H[l]) *(f32x4*)(u.H[l] + pk_index(n, row0 + 4 * g, a.Cb)) = hv;   // rows row0+4g .. +3 of feature n: 16 contiguous bytes
-      if (u.G[l]) *(f32x4*)(u.G[l] + pk_index(n, row0 + 4 * g, a.Cb)) = gd;
+      if (u.H[l]) nt_store4(u.H[l] + pk_index(n, row0 + 4 * g, a.Cb), hv);   // rows row0+4g .. +3 of feature n: 16 contiguous bytes
+      if (u.G[l]) nt_store4(u.G[l] + pk_index(n, row0 + 4 * g, a.Cb), gd);
       acc[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = acc[g][0];
     }
     lds_barrier();
@@ -702,7 +705,7 @@ __global__ void __launch_bounds__(256) k_chain_bwd_q(BwdQArgs a) {
     for (int rr = 0; rr < 4; ++rr) ov[rr] = (sc[16 + 2 * (4 * g + rr)] * wo0 + sc[16 + 2 * (4 * g + rr) + 1] * wo1) * gl[g][rr];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) lds[S.off_h0 + (4 * g + rr) * S.ld_h + n] = ov[rr];
-    *(f32x4*)(u.dZ[L - 1] + pk_index(n, row0 + 4 * g, a.Cb)) = ov;
+    nt_store4(u.dZ[L - 1] + pk_index(n, row0 + 4 * g, a.Cb), ov);
   }
   NarrowFrags<2> af;
   const int nta = (a.A + 15) >> 4;
@@ -729,7 +732,7 @@ __global__ void __launch_bounds__(256) k_chain_bwd_q(BwdQArgs a) {
       const f32x4 dz = (acc[g][0] + acc[g][1]) * gq[g];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) lds[hn + (4 * g + rr) * S.ld_h + n] = dz[rr];
-      *(f32x4*)(u.dZ[l - 1] + pk_index(n, row0 + 4 * g, a.Cb)) = dz;
+      nt_store4(u.dZ[l - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz);
     }
     cur ^= 1;
     lds_barrier();
@@ -837,7 +840,7 @@ __global__ void __launch_bounds__(256) k_chain_bwd_pi(BwdPiArgs a) {
       const f32x4 dz = (acc[g][0] + acc[g][1]) * gq[g];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) lds[S.off_h0 + (4 * g + rr) * S.ld_h + n] = dz[rr];
-      *(f32x4*)(a.dZ[L - 1] + pk_index(n, row0 + 4 * g, a.Cb)) = dz;
+      nt_store4(a.dZ[L - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz);
     }
     lds_barrier();
     CTL(a.timeline, 2);
@@ -858,7 +861,7 @@ __global__ void __launch_bounds__(256) k_chain_bwd_pi(BwdPiArgs a) {
       const f32x4 dz = (acc[g][0] + acc[g][1]) * gq[g];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) lds[hn + (4 * g + rr) * S.ld_h + n] = dz[rr];
-      *(f32x4*)(a.dZ[l - 1] + pk_index(n, row0 + 4 * g, a.Cb)) = dz;
+      nt_store4(a.dZ[l - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz);
     }
     cur ^= 1;
     if (l > 1) lds_barrier();

@@ -27,6 +27,18 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 // the polynomial chains compile to packed v_pk_fma_f32 (two elements per instruction)
 __device__ __forceinline__ f32x4 vfma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
+// Activations / gradients written for the NEXT launch (read by other XCDs, never again by this one): streaming stores
+// leave the L2 as they are issued instead of in the kernel-end write-back.
+#ifndef DSACT_NT_STORES
+#define DSACT_NT_STORES 1
+#endif
+__device__ __forceinline__ void nt_store4(float* p, f32x4 v) {
+#if DSACT_NT_STORES
+  __builtin_nontemporal_store(v, (f32x4*)p);
+#else
+  *(f32x4*)p = v;
+#endif
+}
 __device__ __forceinline__ void gelu4(const f32x4 z, f32x4& h, f32x4& g) {
   const f32x4 x = z * kInvSqrt2;
   const f32x4 t = __builtin_elementwise_min(__builtin_elementwise_abs(x), splat4(kErfHi));
@@ -1783,6 +1795,7 @@ struct StatsArgs {
   const float* part_loss; int n_loss; const float* part_heads; int n_heads;
   const float* log_alpha; const DevState* st; float inv_B; float inv_BA; int auto_alpha; float alpha_fixed;
   float* out;  // [16]
+  const float* ms_tail;   // nullptr, or mean_std1/2 of the gradient that is pending (not yet committed to DevState)
 };
 __global__ void k_stats(StatsArgs a) {
   const int lane = threadIdx.x;
@@ -1806,7 +1819,7 @@ __global__ void k_stats(StatsArgs a) {
     o[8] = h0 * a.inv_BA; o[9] = h1 * a.inv_BA;
     o[10] = -(s[7] * a.inv_B);
     o[11] = s[8];
-    o[12] = a.st->ms1; o[13] = a.st->ms2;
+    o[12] = a.ms_tail ? a.ms_tail[0] : a.st->ms1; o[13] = a.ms_tail ? a.ms_tail[1] : a.st->ms2;
     o[14] = (float)a.st->it_cur; o[15] = 0.f;
   }
 }

@@ -81,10 +81,7 @@ class LazyTbInfoV1(_v2.LazyTbInfo):
     def _materialize(self):
         if self._done:
             return
-        if self._alg._serial != self._serial:
-            raise RuntimeError("tb_info of an earlier update was read after a newer update was issued; "
-                               "device statistics are kept for the last update only")
-        stats = self._alg.engine.read_stats()
+        stats = self._stats()
         vals = list(stats.values())
         A = self._alg.engine.act_dim
         for k, i in V1_KEYS:
@@ -105,6 +102,17 @@ class LazyTbInfoV1(_v2.LazyTbInfo):
 
 class DSAC_V1_HIP(_v2.DSAC_V2_HIP):
     """kwargs: the reference's flat dict (dsac_v1.py:68-82) plus the additive HIP keys of DSAC_V2_HIP."""
+
+    TD_bound = _v2._Hyper("TD_bound")
+
+    @property
+    def bound(self):
+        return True
+
+    @bound.setter
+    def bound(self, value):
+        if not value:   # dsac_v1.py:217 `if self.bound:` -- the unbounded critic loss is not implemented in the HIP path
+            raise NotImplementedError("DSAC_V1_HIP implements the bounded critic loss only (bound=True)")
 
     def __init__(self, **kwargs):
         _check_supported(kwargs)
@@ -150,6 +158,7 @@ class DSAC_V1_HIP(_v2.DSAC_V2_HIP):
 
     def local_update(self, data: Dict, iteration: int) -> dict:
         t0 = time.time()
+        self._keep_previous_stats()
         self._stage(data)
         self._noise()
         self.engine.step(int(iteration), self.flags)
@@ -158,6 +167,7 @@ class DSAC_V1_HIP(_v2.DSAC_V2_HIP):
 
     def get_remote_update_info(self, data: Dict, iteration: int) -> Tuple[dict, dict]:
         t0 = time.time()
+        self._keep_previous_stats()
         self._stage(data)
         self._noise()
         self.engine.compute_grads(int(iteration), self.flags)

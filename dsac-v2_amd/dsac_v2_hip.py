@@ -358,13 +358,21 @@ class LazyTbInfo(dict):
         self._alg, self._serial, self._done = alg, serial, False
         dict.__setitem__(self, ALG_TIME_KEY, alg_time_ms)
 
+    def _stats(self):
+        """the last update: reduced on demand; one of the STATS_SLOTS-1 updates before it: the snapshot the algorithm
+        took when it issued the next update (a reference-style caller may log the previous tb_info late)"""
+        alg = self._alg
+        if alg._serial == self._serial:
+            return alg.engine.read_stats()
+        if 0 < alg._serial - self._serial < alg.engine.STATS_SLOTS:
+            return alg.engine.read_stats(slot=self._serial)
+        raise RuntimeError("tb_info of update %d was read %d updates later; device statistics are kept for the last "
+                           "%d updates only" % (self._serial, alg._serial - self._serial, alg.engine.STATS_SLOTS))
+
     def _materialize(self):
         if self._done:
             return
-        if self._alg._serial != self._serial:
-            raise RuntimeError("tb_info of an earlier update was read after a newer update was issued; "
-                               "device statistics are kept for the last update only")
-        stats = self._alg.engine.read_stats()
+        stats = self._stats()
         for k in STAT_KEYS:
             v = stats[k]
             if k in ("DSAC2/mean_std1", "DSAC2/mean_std2"):
@@ -408,15 +416,24 @@ class LazyTbInfo(dict):
 
 class HipBatch(dict):
     """Token returned by HipReplayBuffer.sample_batch: the minibatch is already staged inside the
-    engine (`engine_id`), so local_update skips the host round trip. Behaves like the reference's
-    dict of tensors when somebody else indexes it (materialised on demand)."""
+    engine, so local_update skips the host round trip. Behaves like the reference's dict of tensors when somebody
+    else indexes it (materialised on demand). The engine stages ONE minibatch at a time: a token that is no longer the
+    staged one (the caller sampled ahead, or fed another batch in between) re-gathers its own rows by the indices it
+    was drawn with before it is trained on or read."""
 
-    def __init__(self, engine, serial):
+    def __init__(self, engine, idxs):
         super().__init__()
-        self.engine, self.serial = engine, serial
+        self.engine, self.idxs = engine, np.array(idxs, dtype=np.int64, copy=True)
+        self.serial = engine.stage_serial
+
+    def restage(self):
+        if self.serial != self.engine.stage_serial:
+            self.engine.gather(self.idxs)
+            self.serial = self.engine.stage_serial
 
     def _fill(self):
         if not dict.__len__(self):
+            self.restage()
             b = self.engine.read_batch(with_logp=True)
             for k in ("obs", "obs2", "act", "rew", "done", "logp"):
                 dict.__setitem__(self, k, torch.from_numpy(b[k]))
@@ -438,12 +455,31 @@ class HipBatch(dict):
         return dict.__iter__(self)
 
 
+class _Hyper:
+    """An `adjustable_parameters` entry (dsac_v2.py:92-99): the reference re-reads the attribute on every update,
+    so assignment after construction must reach the engine (dsact_set_hyper; drops a captured graph)."""
+
+    def __init__(self, name):
+        self.name, self.slot = name, "_hp_" + name
+
+    def __get__(self, obj, cls=None):
+        return self if obj is None else obj.__dict__[self.slot]
+
+    def __set__(self, obj, value):
+        eng = obj.__dict__.get("engine")
+        if eng is not None:
+            eng.set_hyper(self.name, value)   # raises DsactError on an invalid value; the attribute keeps the old one
+        obj.__dict__[self.slot] = value
+
+
 class DSAC_V2_HIP:
     """DSAC-T on MI355X. kwargs are the reference's flat dict (dsac_v2.py:27-59,81-90) plus additive
     keys: `replay_batch_size` (minibatch rows), `hip_device` (default 0), `strict_rng` (default
     False: device Philox noise; True: draw the 8 torch.randn tensors of App. A.1 on the host in the
     reference's order and inject them -- bit-identical noise to the reference after the same seed),
     `hip_flags` (DSACT_F_*), `global_batch` (data parallel)."""
+
+    gamma, tau, auto_alpha, alpha, delay_update = (_Hyper(n) for n in ("gamma", "tau", "auto_alpha", "alpha", "delay_update"))
 
     def __init__(self, **kwargs):
         _check_supported(kwargs)
@@ -490,7 +526,8 @@ class DSAC_V2_HIP:
     # ---- staging -------------------------------------------------------------------------------
     def _stage(self, data):
         if isinstance(data, HipBatch) and data.engine is self.engine:
-            return  # already in HBM (HipReplayBuffer fast path)
+            data.restage()   # no-op when this token is the staged minibatch (HipReplayBuffer fast path)
+            return
         # CPU tensors (reference ReplayBuffer.sample_batch) or the CUDA tensors the reference trainer makes of them
         # (training/trainer.py:72-74); CUDA ones are copied device-to-device
         self.engine.load_batch(data["obs"], data["act"], data["rew"], data["obs2"], data["done"])
@@ -505,8 +542,13 @@ class DSAC_V2_HIP:
         self.engine.set_noise(eps_new.numpy(), eps_2.numpy(), z[2].numpy(), z[3].numpy())
 
     # ---- reference surface ------------------------------------------------------------------------
+    def _keep_previous_stats(self):
+        if self._serial:
+            self.engine.stats_snapshot(self._serial)   # asynchronous; see LazyTbInfo._stats
+
     def local_update(self, data: Dict, iteration: int) -> dict:
         t0 = time.time()
+        self._keep_previous_stats()
         self._stage(data)
         self._noise()
         self.engine.step(int(iteration), self.flags)
@@ -526,6 +568,7 @@ class DSAC_V2_HIP:
 
     def get_remote_update_info(self, data: Dict, iteration: int) -> Tuple[dict, dict]:
         t0 = time.time()
+        self._keep_previous_stats()
         self._stage(data)
         self._noise()
         self.engine.compute_grads(int(iteration), self.flags)

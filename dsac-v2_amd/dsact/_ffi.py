@@ -27,13 +27,13 @@ class Config(C.Structure):
         ("hidden", C.c_int32 * MAX_HIDDEN),
         ("batch", C.c_int32), ("global_batch", C.c_int32),
         ("auto_alpha", C.c_int32), ("delay_update", C.c_int32),
-        ("gamma", C.c_float), ("tau", C.c_float), ("tau_b", C.c_float),
-        ("lr_q", C.c_float), ("lr_pi", C.c_float), ("lr_alpha", C.c_float),
-        ("alpha_fixed", C.c_float),
-        ("min_log_std", C.c_float), ("max_log_std", C.c_float),
-        ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float),
+        ("gamma", C.c_double), ("tau", C.c_double), ("tau_b", C.c_double),
+        ("lr_q", C.c_double), ("lr_pi", C.c_double), ("lr_alpha", C.c_double),
+        ("alpha_fixed", C.c_double),
+        ("min_log_std", C.c_double), ("max_log_std", C.c_double),
+        ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
         ("conv_type", C.c_int32), ("img_c", C.c_int32), ("img_h", C.c_int32), ("img_w", C.c_int32),
-        ("algo", C.c_int32), ("td_bound", C.c_float),
+        ("algo", C.c_int32), ("td_bound", C.c_double),
     ]
 
 
@@ -62,6 +62,7 @@ SYMBOLS = [
     ("dsact_set_action_limits", C.c_int, [_P, _FP, _FP]),
     ("dsact_get_state", C.c_int, [_P, C.POINTER(C.c_int32), _FP]),
     ("dsact_set_state", C.c_int, [_P, C.POINTER(C.c_int32), _FP]),
+    ("dsact_set_hyper", C.c_int, [_P, C.c_int32, C.c_double]),
     ("dsact_buffer_create", C.c_int, [_P, C.c_int64]),
     ("dsact_buffer_add", C.c_int, [_P, C.c_int64, _FP, _FP, _FP, _FP, _FP, _FP]),
     ("dsact_buffer_size", C.c_int64, [_P]),
@@ -91,6 +92,8 @@ SYMBOLS = [
     ("dsact_comm_destroy", C.c_int, [_P]),
     ("dsact_dp_enqueue_allreduce", C.c_int, [_P]),
     ("dsact_read_stats", C.c_int, [_P, _FP]),
+    ("dsact_stats_snapshot", C.c_int, [_P, C.c_int32]),
+    ("dsact_stats_read", C.c_int, [_P, C.c_int32, _FP]),
     ("dsact_time_steps", C.c_int, [_P, C.c_int64, C.c_int64, C.c_uint32, C.c_int32, _FP]),
     ("dsact_time_stage", C.c_int, [_P, C.c_int32, C.c_int32, _FP, C.POINTER(C.c_double)]),
     ("dsact_chain_active", C.c_int, [_P]),

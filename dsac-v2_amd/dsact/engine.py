@@ -106,6 +106,7 @@ class DsactEngine:
             self._h, self.online.data_ptr(), self.target.data_ptr(), self.adam_m.data_ptr(),
             self.adam_v.data_ptr(), self.grads.data_ptr()))
         self._graph_steps = 0
+        self.stage_serial = 0
 
     # ---- plumbing -----------------------------------------------------------------------------
     def _chk(self, rc):
@@ -167,6 +168,13 @@ class DsactEngine:
         ms = (C.c_float * 2)(*mean_std) if mean_std is not None else None
         self._chk(self._lib.dsact_set_state(self._h, st, ms))
 
+    HYPER = {"gamma": 0, "tau": 1, "tau_b": 2, "auto_alpha": 3, "alpha": 4, "delay_update": 5, "TD_bound": 6}
+
+    def set_hyper(self, name: str, value):
+        """dsact_set_hyper: the next enqueued update uses `value`; a captured graph is dropped (build it again)"""
+        self._chk(self._lib.dsact_set_hyper(self._h, self.HYPER[name], float(value)))
+        self._graph_steps = 0
+
     # ---- replay ring -------------------------------------------------------------------------------
     def buffer_create(self, capacity: int):
         self._chk(self._lib.dsact_buffer_create(self._h, int(capacity)))
@@ -198,6 +206,7 @@ class DsactEngine:
     def gather(self, idx):
         idx = np.ascontiguousarray(np.asarray(idx, dtype=np.int64))
         self._chk(self._lib.dsact_gather(self._h, idx.ctypes.data_as(C.POINTER(C.c_int64)), int(idx.shape[0])))
+        self.stage_serial += 1   # which minibatch sits in the staging set (HipBatch tokens compare against it)
 
     def read_batch(self, with_logp=True) -> Dict[str, np.ndarray]:
         B, O, A = self.batch, self.obs_dim, self.act_dim
@@ -235,6 +244,7 @@ class DsactEngine:
         if any(isinstance(k, torch.Tensor) for _, k in srcs):
             torch.cuda.current_stream(self.device).synchronize()   # the producers of the CUDA sources have finished
         self._chk(self._lib.dsact_load_batch(self._h, *[p for p, _ in srcs]))
+        self.stage_serial += 1
 
     def upload_index_table(self, idx):
         idx = np.ascontiguousarray(np.asarray(idx, dtype=np.int64))
@@ -266,6 +276,7 @@ class DsactEngine:
         self._graph_steps = int(steps_per_graph)
 
     def graph_run(self, first_iteration: int, n_steps: int):
+        self.stage_serial += 1   # the index table's device-side gather replaces the staged minibatch
         self._chk(self._lib.dsact_graph_run(self._h, int(first_iteration), int(n_steps)))
 
     # data-parallel halves (iteration and index-table row come from device state)
@@ -273,10 +284,12 @@ class DsactEngine:
         self._chk(self._lib.dsact_dp_begin(self._h, int(first_iteration)))
 
     def dp_grads(self, flags: int = 0):
+        self.stage_serial += 1   # the index table's device-side gather replaces the staged minibatch
         self._chk(self._lib.dsact_dp_enqueue_grads(self._h, int(flags)))
 
     def dp_grads_critic(self, flags: int = 0):
         """first half of dp_grads: afterwards grads[:2*n_q] (q1 | q2) is final"""
+        self.stage_serial += 1   # the index table's device-side gather replaces the staged minibatch
         self._chk(self._lib.dsact_dp_enqueue_grads_critic(self._h, int(flags)))
 
     def dp_grads_actor(self, flags: int = 0):
@@ -297,6 +310,7 @@ class DsactEngine:
             self.std_sums = None
 
     def dp_forward(self, flags: int = 0):
+        self.stage_serial += 1   # the index table's device-side gather replaces the staged minibatch
         self._chk(self._lib.dsact_dp_enqueue_forward(self._h, int(flags)))
 
     def dp_backward(self, flags: int = 0):
@@ -333,9 +347,18 @@ class DsactEngine:
         """average of the gradient arena (+ mean_std tail) over the ranks, on the engine's stream (RCCL)"""
         self._chk(self._lib.dsact_dp_enqueue_allreduce(self._h))
 
-    def read_stats(self) -> Dict[str, float]:
+    STATS_SLOTS = 16
+
+    def stats_snapshot(self, slot: int):
+        """asynchronous: reduce the last update's statistics into ring slot `slot` (read later with read_stats(slot))"""
+        self._chk(self._lib.dsact_stats_snapshot(self._h, int(slot) % self.STATS_SLOTS))
+
+    def read_stats(self, slot=None) -> Dict[str, float]:
         out = (C.c_float * 16)()
-        self._chk(self._lib.dsact_read_stats(self._h, out))
+        if slot is None:
+            self._chk(self._lib.dsact_read_stats(self._h, out))
+        else:
+            self._chk(self._lib.dsact_stats_read(self._h, int(slot) % self.STATS_SLOTS, out))
         d = {k: float(out[i]) for i, k in enumerate(STAT_KEYS)}
         d["_iteration"] = float(out[14])
         return d
@@ -343,6 +366,7 @@ class DsactEngine:
     # ---- measurement ------------------------------------------------------------------------------------
     def time_steps(self, first_iteration: int, n_steps: int, use_graph: bool = True, flags: int = 0) -> float:
         ms = C.c_float()
+        self.stage_serial += 1   # the index table's device-side gather replaces the staged minibatch
         self._chk(self._lib.dsact_time_steps(self._h, int(first_iteration), int(n_steps), int(flags),
                                              1 if use_graph else 0, C.byref(ms)))
         return float(ms.value)
@@ -361,6 +385,7 @@ class DsactEngine:
     def profile_step(self, iteration: int, flags: int = 0):
         arr = (_ffi.KernelTime * 128)()
         n = C.c_int32()
+        self.stage_serial += 1   # the index table's device-side gather replaces the staged minibatch
         self._chk(self._lib.dsact_profile_step(self._h, int(iteration), int(flags), arr, 128, C.byref(n)))
         return [(arr[i].name.decode(), float(arr[i].ms), int(arr[i].blocks)) for i in range(n.value)]
 

@@ -39,7 +39,6 @@ class HipReplayBuffer:
                 eng = DsactEngine(self._obs_flat, self.act_dim, hidden, B, device=int(kwargs.get("hip_device", 0)))
         self.engine = eng
         self.engine.buffer_create(self.max_size)
-        self._serial = 0
 
     @property
     def size(self):
@@ -80,5 +79,4 @@ class HipReplayBuffer:
 
         idxs = np.random.randint(0, self.size, size=batch_size)  # reference replay_buffer.py:86
         self.engine.gather(idxs)
-        self._serial += 1
-        return HipBatch(self.engine, self._serial)
+        return HipBatch(self.engine, idxs)

@@ -75,11 +75,14 @@ typedef struct dsact_config {
   int32_t global_batch;                         /* batch summed over data-parallel ranks (>= batch) */
   int32_t auto_alpha;                           /* auto_alpha */
   int32_t delay_update;                         /* delay_update */
-  float gamma, tau, tau_b;                      /* gamma, tau, tau_b (= tau when absent) */
-  float lr_q, lr_pi, lr_alpha;                  /* value/policy/alpha_learning_rate */
-  float alpha_fixed;                            /* alpha when !auto_alpha */
-  float min_log_std, max_log_std;               /* policy_min/max_log_std */
-  float adam_beta1, adam_beta2, adam_eps;       /* torch.optim.Adam defaults 0.9, 0.999, 1e-8 */
+  /* Hyper-parameters cross the boundary as the Python doubles the reference holds: torch.optim.Adam computes its
+   * step size and bias corrections, and dsac_v2.py:331 its Polyak factor, in double arithmetic before touching an
+   * fp32 tensor -- so does this library, for any value (not only short decimals). */
+  double gamma, tau, tau_b;                     /* gamma, tau, tau_b (= tau when absent) */
+  double lr_q, lr_pi, lr_alpha;                 /* value/policy/alpha_learning_rate */
+  double alpha_fixed;                           /* alpha when !auto_alpha */
+  double min_log_std, max_log_std;              /* policy_min/max_log_std */
+  double adam_beta1, adam_beta2, adam_eps;      /* torch.optim.Adam defaults 0.9, 0.999, 1e-8 */
   /* CNN approximators (value/policy_func_type == "CNN", networks/cnn.py:151-240,383-461):
    * conv_type 0 = MLP nets; 1 = "type_1" (k 8,4,3 / ch 32,64,64 / stride 4,2,1, hidden 512,256);
    * 2 = "type_2" (k 4,3,3,3,3,3 / ch 8..256 / stride 2,2,2,2,1,1, hidden 256,256,256).
@@ -91,7 +94,7 @@ typedef struct dsact_config {
    * `q` + `q_target`, fixed TD_bound, variance-weighted critic pseudo-loss :217-226). With algo 1 the arenas are
    * online = q | policy | log_alpha and target = q_target | policy_target; MLP nets only. */
   int32_t algo;
-  float td_bound;                               /* TD_bound (DSAC_V1 only; reference default 20) */
+  double td_bound;                              /* TD_bound (DSAC_V1 only; reference default 20) */
 } dsact_config;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */
@@ -121,6 +124,19 @@ int dsact_set_action_limits(dsact_handle* h, const float* high, const float* low
  * mean_std < 0 encodes the reference's -1.0 "not yet initialised" sentinel. Synchronous. */
 int dsact_get_state(dsact_handle* h, int32_t adam_steps[3], float mean_std[2]);
 int dsact_set_state(dsact_handle* h, const int32_t adam_steps[3], const float mean_std[2]);
+/* The reference re-reads its `adjustable_parameters` (dsac_v2.py:92-99: gamma, tau, auto_alpha, alpha, delay_update;
+ * dsac_v1.py adds TD_bound) on every update, so assigning one between updates takes effect on the next. Same here:
+ * the value is used from the next enqueued update on; a captured graph (dsact_graph_build) has the old value baked
+ * in and is dropped -- build it again. tau also sets tau_b when `also_tau_b` semantics apply (DSACT_HYPER_TAU keeps
+ * tau_b untouched; set DSACT_HYPER_TAU_B explicitly). */
+#define DSACT_HYPER_GAMMA 0
+#define DSACT_HYPER_TAU 1
+#define DSACT_HYPER_TAU_B 2
+#define DSACT_HYPER_AUTO_ALPHA 3
+#define DSACT_HYPER_ALPHA 4
+#define DSACT_HYPER_DELAY_UPDATE 5
+#define DSACT_HYPER_TD_BOUND 6
+int dsact_set_hyper(dsact_handle* h, int32_t which, double value);
 
 /* ---- replay buffer (training/replay_buffer.py) -------------------------------------------------- */
 int dsact_buffer_create(dsact_handle* h, int64_t capacity);
@@ -219,9 +235,19 @@ int dsact_dp_enqueue_allreduce(dsact_handle* h);
 
 /* 14 numeric tb_info entries of the last update in the order of dsac_v2.py:188-202
  * (avg_q1, avg_q2, avg_std1, avg_std2, min_std1, min_std2, loss_actor, loss_critic, policy_mean,
- *  policy_std, entropy, alpha, mean_std1, mean_std2) + out[14] = iteration, out[15] = reserved.
+ *  policy_std, entropy, alpha, mean_std1, mean_std2) + out[14] = iteration, out[15] = device milliseconds of the
+ *  last dsact_step / dsact_compute_grads (stream events around it; -1 when the last update was a graph replay or a
+ *  snapshot slot is read). With a gradient computed and not yet applied (dsact_compute_grads without
+ *  dsact_apply_update) mean_std1/2 are the values that gradient's loss used, as the reference reports them.
  * Synchronous (this is the only per-step host sync, and only when the trainer logs). */
 int dsact_read_stats(dsact_handle* h, float out[16]);
+/* A reference-style caller may keep the tb_info dict of update k and read it after update k+1 has been issued
+ * (deferred logging). dsact_stats_snapshot reduces the LAST update's statistics into ring slot `slot`
+ * (0 .. DSACT_STATS_SLOTS-1) asynchronously -- one 64-thread launch, no host sync; dsact_stats_read copies a slot
+ * out (synchronous). Same 16 floats as dsact_read_stats. */
+#define DSACT_STATS_SLOTS 16
+int dsact_stats_snapshot(dsact_handle* h, int32_t slot);
+int dsact_stats_read(dsact_handle* h, int32_t slot, float out[16]);
 
 /* ---- measurement / debugging -------------------------------------------------------------------- */
 /* time n replays of the step on the handle's stream with hipEvents: total milliseconds */

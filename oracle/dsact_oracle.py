@@ -133,6 +133,30 @@ def tanh_gauss_rsample(logits, eps, act_high, act_low):
     return action_limited, log_prob
 
 
+def seeded_state_dict(template, seed):
+    """Initial values that regenerate WITHOUT the reference (the GPU box): every Linear weight / bias of the online
+    nets drawn by numpy's default_rng(seed) from torch.nn.Linear's own default range U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+    (networks/mlp.py builds plain nn.Linear stacks), in state_dict order; the target nets copy
+    their online net (dsac_v2.py:44-52 deep copies); every other entry (log_alpha, action limits) keeps the
+    template's value. `template`: a state_dict of the right shapes (the reference's or the HIP container's)."""
+    rng = np.random.default_rng(seed)
+    out, fan_in = {}, 1
+    for k, v in template.items():
+        net = k.split(".")[0]
+        if net.endswith("_target") or not (k.endswith(".weight") or k.endswith(".bias")):
+            continue
+        if k.endswith(".weight"):
+            fan_in = int(v.shape[1])
+        b = 1.0 / np.sqrt(fan_in)
+        out[k] = torch.as_tensor(rng.uniform(-b, b, tuple(v.shape)).astype(np.float32))
+    full = {}
+    for k, v in template.items():
+        net = k.split(".")[0]
+        src = k.replace(net, net[: -len("_target")], 1) if net.endswith("_target") else k
+        full[k] = out[src].clone() if src in out else v.detach().clone()
+    return full
+
+
 def draw_noise(batch, act_dim, generator=None):
     """The 8 draws one __compute_gradient consumes from the torch global generator, in order
     (SURVEY.md App. A.1): eps_new[B,A], eps_2[B,A], z3..z8[B]. z3,z4,z7,z8 are drawn and

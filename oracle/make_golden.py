@@ -16,6 +16,11 @@ What is stored per case (`step_<name>.npz`):
   s<k>/grad             flat gradient [q1 | q2 | policy | log_alpha] after __compute_gradient
   s<k>/params,targets   flat online / target parameters after __update
 `replay.npz`: reference ReplayBuffer ring semantics + np.random.randint index draws.
+`step_humanoid_digest.npz`: the BASELINE.json configuration itself (obs 376 / act 17, 3x256, batch 256), 4 updates of
+the unmodified reference. 1.2 M parameters per step would not be a small fixture, so nets, minibatches and noise
+regenerate from seeds (oracle.dsact_oracle.seeded_state_dict / synth_batch / draw_noise) and the file keeps digests:
+tb_info, every DIGEST_STRIDE-th element of the flat gradient / parameter / target arenas, per-net max |g|, per-tensor
+gradient L2 norms and parameter abs-sums, and checksums of the regenerated inputs.
 """
 import os
 import sys
@@ -28,7 +33,7 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 
 from oracle import ref_loader  # noqa: E402
-from oracle.dsact_oracle import TB_KEYS, draw_noise  # noqa: E402
+from oracle.dsact_oracle import TB_KEYS, draw_noise, seeded_state_dict  # noqa: E402
 
 CASES = {
     # name: (obs, act, hidden, batch, act_limit, steps, extra kwargs)
@@ -91,6 +96,56 @@ def gen_step_case(ref, name, spec, out_dir):
         out["s%d/targets" % it] = flat(targets)
     np.savez_compressed(os.path.join(out_dir, "step_%s.npz" % name), **out)
     print("wrote step_%s.npz" % name)
+
+
+DIGEST_STRIDE = 499
+HUMANOID = dict(O=376, A=17, hid=(256, 256, 256), B=256, lim=0.4, steps=4, init_seed=20240, batch_seed=7, noise_seed0=1000)
+
+
+def humanoid_inputs(it, rng):
+    """(minibatch, noise) of update `it` of the digest case; rng: np.random.default_rng(HUMANOID['batch_seed']),
+    advanced by the caller in iteration order"""
+    H = HUMANOID
+    b = synth_batch(rng, H["B"], H["O"], H["A"], H["lim"])
+    torch.manual_seed(H["noise_seed0"] + it)
+    return b, draw_noise(H["B"], H["A"])
+
+
+def gen_humanoid_digest(ref, out_dir):
+    H = HUMANOID
+    kw = ref_loader.reference_kwargs(H["O"], H["A"], H["hid"], act_limit=H["lim"])
+    torch.manual_seed(0)
+    alg = ref.DSAC_V2(**kw)
+    nets = alg.networks
+    nets.load_state_dict(seeded_state_dict(nets.state_dict(), H["init_seed"]))
+    out = {"cfg_obs_dim": H["O"], "cfg_act_dim": H["A"], "cfg_hidden": np.array(H["hid"]), "cfg_batch": H["B"],
+           "cfg_act_limit": H["lim"], "cfg_steps": H["steps"], "cfg_stride": DIGEST_STRIDE,
+           "cfg_seeds": np.array([H["init_seed"], H["batch_seed"], H["noise_seed0"]]),
+           "versions": np.array([torch.__version__, np.__version__]),
+           "init_abs_sums": np.array([float(v.double().abs().sum()) for v in nets.state_dict().values()])}
+    rng = np.random.default_rng(H["batch_seed"])
+    for it in range(H["steps"]):
+        b, noise = humanoid_inputs(it, rng)
+        out["s%d/in_sums" % it] = np.array([float(np.float64(b[k]).sum()) for k in ("obs", "obs2", "act", "rew", "done")]
+                                           + [float(noise[k].double().sum()) for k in ("eps_new", "eps_2", "z5", "z6")])
+        torch.manual_seed(H["noise_seed0"] + it)   # the reference draws the same stream draw_noise just did
+        tb = alg.local_update({k: torch.as_tensor(v) for k, v in b.items()}, it)
+        out["s%d/tb" % it] = np.array([float(tb[k]) for k in TB_KEYS[:-1]], np.float64)
+        groups = (list(nets.q1.parameters()), list(nets.q2.parameters()), list(nets.policy.parameters()))
+        online = [p for g in groups for p in g]
+        ga = nets.log_alpha.grad if nets.log_alpha.grad is not None else torch.zeros(())
+        grad = torch.cat([p.grad.reshape(-1) for p in online] + [ga.reshape(1)]).numpy()
+        params = np.concatenate([flat(online), nets.log_alpha.detach().reshape(1).numpy()])
+        targets = flat(list(nets.q1_target.parameters()) + list(nets.q2_target.parameters())
+                       + list(nets.policy_target.parameters()))
+        out["s%d/grad_s" % it] = grad[::DIGEST_STRIDE].copy()
+        out["s%d/params_s" % it] = params[::DIGEST_STRIDE].copy()
+        out["s%d/targets_s" % it] = targets[::DIGEST_STRIDE].copy()
+        out["s%d/grad_max" % it] = np.array([max(float(p.grad.abs().max()) for p in g) for g in groups] + [abs(float(ga))])
+        out["s%d/grad_l2" % it] = np.array([float(p.grad.double().norm()) for p in online])
+        out["s%d/param_abs_sums" % it] = np.array([float(p.detach().double().abs().sum()) for p in online])
+    np.savez_compressed(os.path.join(out_dir, "step_humanoid_digest.npz"), **out)
+    print("wrote step_humanoid_digest.npz")
 
 
 def gen_replay(out_dir):
@@ -233,6 +288,7 @@ def main():
     gen_checkpoint_layout(ref, out_dir)
     gen_cnn_case(ref, out_dir)
     gen_v1_case(out_dir)
+    gen_humanoid_digest(ref, out_dir)
 
 
 if __name__ == "__main__":

@@ -63,3 +63,27 @@ def hip_kwargs(O, A, hidden, B, act_limit=0.4, **over):
     )
     kw.update(over)
     return kw
+
+
+def humanoid_digest():
+    """tests/golden/step_humanoid_digest.npz (the BASELINE.json configuration run by the unmodified reference) plus
+    the regenerated nets / minibatches / noise; checks the regeneration against the checksums the file holds."""
+    from oracle.dsact_oracle import seeded_state_dict
+    from oracle.make_golden import HUMANOID, humanoid_inputs
+
+    z = np.load(os.path.join(GOLDEN, "step_humanoid_digest.npz"))
+    H = HUMANOID
+    assert [int(v) for v in z["cfg_seeds"]] == [H["init_seed"], H["batch_seed"], H["noise_seed0"]]
+    cfg = default_config(H["O"], H["A"], hidden=list(H["hid"]), act_limit=H["lim"])
+    template = DsactOracle(cfg).state_dict()
+    init = seeded_state_dict(template, H["init_seed"])
+    np.testing.assert_allclose([float(v.double().abs().sum()) for v in init.values()], z["init_abs_sums"], rtol=1e-12)
+    rng = np.random.default_rng(H["batch_seed"])
+    steps = []
+    for it in range(int(z["cfg_steps"])):
+        b, noise = humanoid_inputs(it, rng)
+        sums = [float(np.float64(b[k]).sum()) for k in ("obs", "obs2", "act", "rew", "done")] + \
+               [float(noise[k].double().sum()) for k in ("eps_new", "eps_2", "z5", "z6")]
+        np.testing.assert_allclose(sums, z["s%d/in_sums" % it], rtol=1e-12, atol=1e-12)
+        steps.append(({k: torch.as_tensor(v) for k, v in b.items()}, noise))
+    return z, cfg, init, steps

@@ -2,8 +2,10 @@
 configs[3]) against the CNN oracle (oracle/dsact_oracle_cnn.py, pinned bit-exact to the live reference)
 and against the reference digests in tests/golden/step_cnn_type2.npz.
 
-Tolerances as in test_hip_parity.py: stats within 1e-4, gradients relative to each tensor's scale,
-parameters within 1e-4 absolute after an update; gathered replay rows bit-exact.
+Gates as in test_hip_parity.py: tb_info within 1e-4 absolute (critic loss 1e-5 relative); gradients relative to each
+tensor's scale, with the ReLU-kink elements located, verified to be kinks and budgeted; parameters within 1e-5 of the
+oracle for every element except the enumerated ill-conditioned ones, which must be explained by their own measured
+gradient difference through Adam (AdamNoise); gathered replay rows bit-exact.
 """
 import os
 
@@ -14,7 +16,7 @@ import torch
 from helpers import GOLDEN, hip_kwargs
 from oracle.dsact_oracle import TB_KEYS, draw_noise
 from oracle.dsact_oracle_cnn import DsactCnnOracle, cnn_config, conv_forward, synth_image_batch
-from test_hip_parity import Report
+from test_hip_parity import AdamNoise, Report
 
 pytestmark = pytest.mark.gpu
 
@@ -49,6 +51,8 @@ def run_case(title, obs_shape, A, conv_type, B, steps, golden=None):
     names = {n: orc._names(n) for n in ("q1", "q2", "policy")}
     kinked = set()   # nets in which a ReLU mask of the two implementations has disagreed so far
     orc.keep_conv = True
+    lrs = {"q1": orc.cfg["lr_q"], "q2": orc.cfg["lr_q"], "policy": orc.cfg["lr_pi"]}
+    adam_noise = {name: AdamNoise([(net, p.numel(), lrs[net])]) for net in names for name, p in zip(names[net], orc.p[net])}
     for it in range(steps):
         data = synth_image_batch(cfg, B, seed=it)
         torch.manual_seed(1000 + it)
@@ -99,35 +103,43 @@ def run_case(title, obs_shape, A, conv_type, B, steps, golden=None):
                 rtol = 5e-4 if net not in kinked or kink_budget[net] > 0 or it == 0 else 2e-2
                 rep.cmp("it%d grad %s" % (it, name), np_of(g_hip), p_ref.grad, 1e-9 + extra, rtol)
         rep.cmp("it%d grad log_alpha" % it, [float(gv["log_alpha"])], [float(orc.log_alpha.grad)], 1e-6, 1e-5)
+        delayed = it % orc.cfg["delay_update"] == 0
+        for net in ("q1", "q2", "policy"):
+            if net == "policy" and not delayed:
+                continue
+            for name, g_hip, p_ref in zip(names[net], gv[net], orc.p[net]):
+                adam_noise[name].step(np_of(p_ref.grad).reshape(-1), np_of(g_hip).reshape(-1), (net,))
         e.apply_update(it)
         orc.update(it)
         st = e.read_stats()
         for k in TB_KEYS[:-1]:
-            rep.cmp("it%d %s" % (it, k.split("/")[-1][:18]), [st[k]], [float(tb_ref[k])], 1e-4, 1e-4)
+            if k.startswith("Loss/Critic"):
+                rep.cmp("it%d %s" % (it, k.split("/")[-1][:18]), [st[k]], [float(tb_ref[k])], 1e-6, 1e-5)
+            else:
+                rep.cmp("it%d %s" % (it, k.split("/")[-1][:18]), [st[k]], [float(tb_ref[k])], 1e-4)
         if golden is not None:
-            rep.cmp("it%d tb vs reference" % it, [st[k] for k in TB_KEYS[:-1]], golden["s%d/tb" % it], 1e-4, 1e-4)
+            crit = TB_KEYS.index("Loss/Critic loss-RL iter")
+            keep_i = [i for i in range(len(TB_KEYS) - 1) if i != crit]
+            tb_g = np.asarray(golden["s%d/tb" % it], np.float64)
+            rep.cmp("it%d tb vs reference" % it, [st[TB_KEYS[i]] for i in keep_i], tb_g[keep_i], 1e-4)
+            rep.cmp("it%d critic loss vs reference" % it, [st[TB_KEYS[crit]]], [tb_g[crit]], 1e-6, 1e-5)
         sd, osd = alg.networks.state_dict(), orc.state_dict()
         assert list(sd.keys()) == list(osd.keys())
-        # Adam's early steps move every weight by ~lr whatever |g| is, so an element whose gradient is at
-        # rounding-noise level (|g| < 1e-7) may take the opposite sign: 2*lr = 2e-4 there, 1e-4 everywhere else
-        gref = {"log_alpha": orc.log_alpha.grad}
-        for net in ("q1", "q2", "policy"):
-            for name, p_ref in zip(names[net], orc.p[net]):
-                gref[name] = p_ref.grad
-        worst_p, worst_t, worst_noise = 0.0, 0.0, 0.0
+        # every element within 1e-5, except elements whose own measured gradient difference (summation order, a ReLU
+        # kink upstream) explains more through Adam's division by sqrt(v_hat) -- enumerated per tensor
+        got_all, want_all, bound_all, lr_steps = [], [], [], 0.0
+        worst_t = 0.0
         for k in sd:
-            diff = (sd[k].cpu() - osd[k]).abs()
             if "_target" in k:
-                worst_t = max(worst_t, float(diff.max()))
-            elif k in gref:
-                noisy = gref[k].abs() < 1e-7
-                if bool(noisy.any()):
-                    worst_noise = max(worst_noise, float(diff[noisy].max()))
-                if bool((~noisy).any()):
-                    worst_p = max(worst_p, float(diff[~noisy].max()))
-        rep.cmp("it%d params (max over tensors)" % it, [worst_p], [0.0], 1e-4 if not kinked else 2.1e-4)
-        rep.cmp("it%d params with |g|<1e-7" % it, [worst_noise], [0.0], 2.1e-4)
-        rep.cmp("it%d targets (max over tensors)" % it, [worst_t], [0.0], 1e-5)
+                worst_t = max(worst_t, float((sd[k].cpu() - osd[k]).abs().max()))
+            elif k in adam_noise:
+                got_all.append(np_of(sd[k]).reshape(-1))
+                want_all.append(np_of(osd[k]).reshape(-1))
+                bound_all.append(adam_noise[k].bound)
+                lr_steps = max(lr_steps, adam_noise[k].lr_steps)
+        rep.cmp_params("it%d params" % it, np.concatenate(got_all), np.concatenate(want_all), np.concatenate(bound_all), 1e-5,
+                       lr_steps)
+        rep.cmp("it%d targets (max over tensors)" % it, [worst_t], [0.0], 2e-6)
         if golden is not None:
             sums = [float(v.double().sum()) for v in sd.values()]
             rep.cmp("it%d param sums vs reference" % it, sums, golden["s%d/param_sums" % it], 2e-3, 1e-5)

@@ -1,10 +1,17 @@
 """Parity of the HIP path (through the C-ABI) against the oracle and the reference golden vectors.
 
-Tolerances (BASELINE.json north_star): losses / stats within 1e-4 of the reference CPU path; replay
-index draws and gathered rows bit-exact. Gradients are compared relative to their own scale
-(fp32 summation order differs between the MFMA k-ordering and the CPU BLAS); parameters after an
-update within 1e-4 absolute (Adam's first steps move every weight by ~lr regardless of |g|, so a
-sign flip of a ~1e-9 gradient element is the worst case: 2*lr = 2e-4).
+Gates (BASELINE.json north_star: "losses / stats within 1e-4 of the reference CPU path"):
+  * tb_info statistics and the actor loss: 1e-4 ABSOLUTE (no relative slack); the critic loss (a sum of
+    squared TD terms, O(1..100)) 1e-5 RELATIVE
+  * gradients: 3e-5 of the largest element of the same net (fp32 summation order differs between the MFMA
+    k-ordering and the CPU BLAS; measured ~2e-5 on the policy, ~1e-6 on the critics)
+  * parameters after the update: 1e-6 absolute for every element, EXCEPT the enumerated ill-conditioned ones: Adam
+    divides by sqrt(v_hat) ~ |g|, so an element whose gradient is within a few ulp-of-the-net's-scale of zero gets
+    its 1e-8 gradient difference amplified to a visible step difference. Those elements are counted, must stay
+    below 0.2 % of the arena, must each be EXPLAINED by their own measured gradient difference
+    (|dp_i| <= 1e-6 + 4 * sum_t lr * |dg_i,t| / (sqrt(v_hat_i,t) + eps), see AdamNoise) and can never exceed the
+    2*lr-per-update worst case of a sign flip. Polyak targets: 1e-7 + tau x the parameter bound.
+  * replay index draws and gathered rows: bit-exact
 """
 import os
 
@@ -12,7 +19,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import STEP_CASES, hip_kwargs, load_step_case, step_inputs, synth_batch
+from helpers import STEP_CASES, hip_kwargs, humanoid_digest, load_step_case, step_inputs, synth_batch
 from oracle.dsact_oracle import TB_KEYS, DsactOracle, ReplayOracle, default_config, draw_noise
 
 pytestmark = pytest.mark.gpu
@@ -37,6 +44,25 @@ class Report:
             self.bad.append(name)
         return ok
 
+    def cmp_params(self, name, got, want, noise, atol, lr_steps):
+        """every element within atol, except elements whose own gradient-noise bound (AdamNoise.bound) explains more;
+        those are enumerated (count, fraction, worst) and capped at the sign-flip worst case 2 * lr * updates."""
+        got = np.asarray(got, dtype=np.float64).reshape(-1)
+        want = np.asarray(want.detach().cpu().numpy() if torch.is_tensor(want) else want, dtype=np.float64).reshape(-1)
+        assert got.shape == want.shape == noise.shape, (name, got.shape, want.shape, noise.shape)
+        err = np.abs(got - want)
+        over = err > atol
+        n_over = int(over.sum())
+        unexplained = int((err > atol + noise).sum())
+        worst = float(err.max()) if err.size else 0.0
+        ratio = float((err[over] / (atol + noise[over])).max()) if n_over else 0.0
+        ok = bool(np.isfinite(got).all() and unexplained == 0 and n_over <= 2e-3 * got.size and worst <= 2.0 * lr_steps + atol)
+        self.rows.append(("%s [%d of %d over %.0e, worst/bound %.2f]" % (name, n_over, got.size, atol, ratio),
+                          worst, float(np.max(np.abs(want))), atol, ok))
+        if not ok:
+            self.bad.append(name)
+        return ok
+
     def finish(self):
         lines = ["== %s ==" % self.title]
         for name, err, scale, tol, ok in self.rows:
@@ -50,6 +76,37 @@ class Report:
         except OSError:
             pass
         assert not self.bad, "parity failures in %s: %s" % (self.title, self.bad)
+
+
+class AdamNoise:
+    """Per-element bound on the parameter difference that the measured gradient difference dg = |g_hip - g_ref| can
+    cause through torch.optim.Adam (dsac_v2.py:80-86 optimizers): one update moves p by lr * m_hat / (sqrt(v_hat)+eps);
+    perturbing g by dg moves m_hat by <= dg and sqrt(v_hat) by <= dg, and m keeps a perturbation for ~1/(1-beta1)
+    updates -- bound = 4 * sum_t lr * dg_t / (sqrt(v_hat_t) + eps), v_hat from the REFERENCE gradients."""
+
+    def __init__(self, segs, b2=0.999, eps=1e-8):
+        # segs: [(name, n, lr)] in arena order
+        self.segs, self.b2, self.eps = segs, b2, eps
+        n = sum(s[1] for s in segs)
+        self.v = np.zeros(n)
+        self.t = {s[0]: 0 for s in segs}
+        self.bound = np.zeros(n)
+        self.lr_steps = 0.0
+
+    def step(self, g_ref, g_hip, updated):
+        g_ref, g_hip = np.asarray(g_ref, np.float64), np.asarray(g_hip, np.float64)
+        off, lr_max = 0, 0.0
+        for name, n, lr in self.segs:
+            sl = slice(off, off + n)
+            off += n
+            if name not in updated:
+                continue
+            self.t[name] += 1
+            self.v[sl] = self.b2 * self.v[sl] + (1 - self.b2) * g_ref[sl] ** 2
+            vhat = self.v[sl] / (1 - self.b2 ** self.t[name])
+            self.bound[sl] += 4.0 * lr * np.abs(g_hip[sl] - g_ref[sl]) / (np.sqrt(vhat) + self.eps)
+            lr_max = max(lr_max, lr)
+        self.lr_steps += lr_max
 
 
 def make_pair(O, A, hid, B, act_limit=0.4, seed=0, init=None, **over):
@@ -104,6 +161,10 @@ def run_case(title, O, A, hid, B, steps, act_limit=0.4, init=None, golden=None, 
     L = len(hid)
     rng = np.random.default_rng(5)
     lay = e.layout
+    cfg = orc.cfg
+    noise_b = AdamNoise([("q1", lay.n_q, cfg["lr_q"]), ("q2", lay.n_q, cfg["lr_q"]), ("policy", lay.n_pi, cfg["lr_pi"]),
+                         ("log_alpha", 1, cfg["lr_alpha"])])
+    tau = cfg["tau"]
     for it in range(steps):
         if golden is not None:
             data, noise = step_inputs(golden, it)
@@ -123,21 +184,34 @@ def run_case(title, O, A, hid, B, steps, act_limit=0.4, init=None, golden=None, 
         g_ref = orc.flat_grads().numpy()
         off = 0
         for net, n in (("q1", lay.n_q), ("q2", lay.n_q), ("policy", lay.n_pi), ("log_alpha", 1)):
-            rep.cmp("it%d grad.%s" % (it, net), g[off:off + n], g_ref[off:off + n], 1e-9, 3e-4)
+            rep.cmp("it%d grad.%s" % (it, net), g[off:off + n], g_ref[off:off + n], 1e-9, 3e-5)
             off += n
+        delayed = it % cfg["delay_update"] == 0
+        noise_b.step(g_ref, g, ("q1", "q2") + (("policy",) + (("log_alpha",) if cfg["auto_alpha"] else ()) if delayed else ()))
         e.apply_update(it)
         orc.update(it)
         st = e.read_stats()  # synchronous
         for k in TB_KEYS[:-1]:
             want = float(tb_ref[k])
-            rep.cmp("it%d %s" % (it, k.split("/")[-1][:18]), [st[k]], [want], 1e-4, 1e-4)
+            if k.startswith("Loss/Critic"):
+                rep.cmp("it%d %s" % (it, k.split("/")[-1][:18]), [st[k]], [want], 1e-6, 1e-5)
+            else:
+                rep.cmp("it%d %s" % (it, k.split("/")[-1][:18]), [st[k]], [want], 1e-4)
+        p_hip, t_hip = e.online.cpu().numpy(), e.target.cpu().numpy()
+        nb = noise_b.bound
+        n_t = t_hip.size
         if golden is not None:
             # the same numbers straight from the unmodified reference
-            rep.cmp("it%d tb vs reference" % it, [st[k] for k in TB_KEYS[:-1]], golden["s%d/tb" % it], 1e-4, 1e-4)
-            rep.cmp("it%d params vs reference" % it, e.online.cpu().numpy(), golden["s%d/params" % it], 1e-4)
-            rep.cmp("it%d targets vs reference" % it, e.target.cpu().numpy(), golden["s%d/targets" % it], 1e-5)
-        rep.cmp("it%d params" % it, e.online.cpu().numpy(), orc.flat_params(), 1e-4)
-        rep.cmp("it%d targets" % it, e.target.cpu().numpy(), orc.flat_targets(), 1e-5)
+            tb_g = np.asarray(golden["s%d/tb" % it], np.float64)
+            crit = TB_KEYS.index("Loss/Critic loss-RL iter")
+            keep_i = [i for i in range(len(TB_KEYS) - 1) if i != crit]
+            rep.cmp("it%d tb vs reference" % it, [st[TB_KEYS[i]] for i in keep_i], tb_g[keep_i], 1e-4)
+            rep.cmp("it%d critic loss vs reference" % it, [st[TB_KEYS[crit]]], [tb_g[crit]], 1e-6, 1e-5)
+            rep.cmp_params("it%d params vs reference" % it, p_hip, golden["s%d/params" % it], nb, 1e-6, noise_b.lr_steps)
+            rep.cmp_params("it%d targets vs reference" % it, t_hip, golden["s%d/targets" % it], tau * (it + 1) * nb[:n_t], 1e-7,
+                           tau * (it + 1) * noise_b.lr_steps)
+        rep.cmp_params("it%d params" % it, p_hip, orc.flat_params(), nb, 1e-6, noise_b.lr_steps)
+        rep.cmp_params("it%d targets" % it, t_hip, orc.flat_targets(), tau * (it + 1) * nb[:n_t], 1e-7, tau * (it + 1) * noise_b.lr_steps)
         state = e.get_state()
         rep.cmp("it%d mean_std" % it, state["mean_std"], [float(orc.mean_std1), float(orc.mean_std2)], 1e-5, 1e-5)
     # Adam moments of q1 (first parameter tensor) against torch.optim.Adam's state
@@ -192,6 +266,72 @@ def test_against_reference_golden(name):
              steps=int(z["cfg_steps"]), act_limit=float(z["cfg_act_limit"]), init=init, golden=z, **over)
 
 
+def test_humanoid_b256_against_reference_digest():
+    """BASELINE.json's own configuration against numbers the UNMODIFIED reference produced (tests/golden/
+    step_humanoid_digest.npz, oracle/make_golden.py): tb_info, every 499th gradient / parameter / target element,
+    per-tensor gradient norms -- same gates as the oracle comparisons above."""
+    from dsac_v2_hip import DSAC_V2_HIP
+
+    z, cfg, init, steps = humanoid_digest()
+    O, A, hid, B = cfg["obs_dim"], cfg["act_dim"], tuple(cfg["hidden"]), int(z["cfg_batch"])
+    alg = DSAC_V2_HIP(**hip_kwargs(O, A, hid, B, act_limit=float(z["cfg_act_limit"]), strict_rng=True))
+    alg.networks.load_state_dict(init)
+    e, lay, stride = alg.engine, alg.engine.layout, int(z["cfg_stride"])
+    rep = Report("humanoid 3x256 B=256 vs reference digest")
+    n_tot = 2 * lay.n_q + lay.n_pi + 1
+    idx = np.arange(0, n_tot, stride)
+    bounds = np.cumsum([0, lay.n_q, lay.n_q, lay.n_pi, 1])
+    names = ("q1", "q2", "policy", "log_alpha")
+    seg_of = np.searchsorted(bounds, idx, side="right") - 1
+    lrs = (cfg["lr_q"], cfg["lr_q"], cfg["lr_pi"], cfg["lr_alpha"])
+    noise_b = AdamNoise([(names[k], int((seg_of == k).sum()), lrs[k]) for k in range(4)])
+    crit = TB_KEYS.index("Loss/Critic loss-RL iter")
+    keep_i = [i for i in range(len(TB_KEYS) - 1) if i != crit]
+    for it, (data, noise) in enumerate(steps):
+        e.load_batch(*(data[k].numpy() for k in ("obs", "act", "rew", "obs2", "done")))
+        e.set_noise(noise["eps_new"].numpy(), noise["eps_2"].numpy(), noise["z5"].numpy(), noise["z6"].numpy())
+        e.compute_grads(it)
+        e.sync()
+        g = e.grads.cpu().numpy()[:n_tot]
+        gs, gs_ref, gmax = g[idx], z["s%d/grad_s" % it], z["s%d/grad_max" % it]
+        for k in range(4):
+            m = seg_of == k
+            rep.cmp("it%d grad.%s (sampled)" % (it, names[k]), gs[m], gs_ref[m], 1e-9 + 3e-5 * float(gmax[k]))
+        # per-tensor L2 norms of the whole gradient (state_dict order inside each net)
+        l2, off = [], 0
+        for net_name, sd_prefix in (("q1", "q1."), ("q2", "q2."), ("policy", "policy.")):
+            for k_, v in init.items():
+                if k_.startswith(sd_prefix) and (k_.endswith(".weight") or k_.endswith(".bias")):
+                    n = v.numel()
+                    l2.append(float(np.linalg.norm(g[off:off + n].astype(np.float64))))
+                    off += n
+        rep.cmp("it%d per-tensor |grad|_2" % it, np.array(l2) / z["s%d/grad_l2" % it], np.ones(len(l2)), 3e-5)
+        delayed = it % cfg["delay_update"] == 0
+        noise_b.step(gs_ref, gs, ("q1", "q2") + (("policy", "log_alpha") if delayed else ()))
+        e.apply_update(it)
+        st = e.read_stats()
+        tb_g = np.asarray(z["s%d/tb" % it], np.float64)
+        rep.cmp("it%d tb vs reference" % it, [st[TB_KEYS[i]] for i in keep_i], tb_g[keep_i], 1e-4)
+        rep.cmp("it%d critic loss vs reference" % it, [st[TB_KEYS[crit]]], [tb_g[crit]], 1e-6, 1e-5)
+        p_hip, t_hip = e.online.cpu().numpy()[:n_tot], e.target.cpu().numpy()
+        rep.cmp_params("it%d params vs reference (sampled)" % it, p_hip[idx], z["s%d/params_s" % it], noise_b.bound, 1e-6,
+                       noise_b.lr_steps)
+        n_t = t_hip.size
+        idx_t = idx[idx < n_t]
+        tau = cfg["tau"]
+        rep.cmp_params("it%d targets vs reference (sampled)" % it, t_hip[idx_t], z["s%d/targets_s" % it],
+                       tau * (it + 1) * noise_b.bound[:idx_t.size], 1e-7, tau * (it + 1) * noise_b.lr_steps)
+        sums, off = [], 0
+        for sd_prefix in ("q1.", "q2.", "policy."):
+            for k_, v in init.items():
+                if k_.startswith(sd_prefix) and (k_.endswith(".weight") or k_.endswith(".bias")):
+                    n = v.numel()
+                    sums.append(float(np.abs(p_hip[off:off + n].astype(np.float64)).sum()))
+                    off += n
+        rep.cmp("it%d per-tensor sum|param|" % it, np.array(sums) / z["s%d/param_abs_sums" % it], np.ones(len(sums)), 1e-5)
+    rep.finish()
+
+
 def test_local_update_surface_and_lazy_stats():
     alg, orc = make_pair(11, 3, (64, 64), 64)
     rng = np.random.default_rng(0)
@@ -206,10 +346,100 @@ def test_local_update_surface_and_lazy_stats():
         for k in TB_KEYS[:-1]:
             assert abs(float(tb[k]) - float(ref[k])) <= 1e-4 * max(1.0, abs(float(ref[k]))), (it, k)
         assert torch.is_tensor(tb["DSAC2/mean_std1"])
-    stale = alg.local_update(data, 4)
-    alg.local_update(data, 5)
+    # a reference-style caller may log the PREVIOUS update's dict after issuing the next update: the statistics of the
+    # last STATS_SLOTS-1 updates stay readable (snapshot ring), older ones raise
+    torch.manual_seed(99)
+    noise = draw_noise(64, 3)
+    torch.manual_seed(99)
+    held = alg.local_update(data, 4)
+    ref = orc.local_update(data, noise, 4)
+    very_old = held.__class__(alg, alg._serial, 0.0)
+    for it in range(5, 8):
+        torch.manual_seed(100 + it)
+        alg.local_update(data, it)
+    for k in TB_KEYS[:-1]:
+        assert abs(float(held[k]) - float(ref[k])) <= 1e-4 * max(1.0, abs(float(ref[k]))), k
+    for it in range(8, 8 + alg.engine.STATS_SLOTS):
+        alg.local_update(data, it)
     with pytest.raises(RuntimeError):
-        stale["Loss/Critic loss-RL iter"]
+        very_old["Loss/Critic loss-RL iter"]
+
+
+def test_adjustable_parameters_reach_the_engine():
+    """dsac_v2.py:92-99: gamma / tau / alpha / auto_alpha / delay_update are re-read by the reference on every update;
+    assigning them on the HIP algorithm must change the NEXT update the same way."""
+    alg, orc = make_pair(11, 3, (64, 64), 64, seed=2)
+    assert set(alg.adjustable_parameters) == {"gamma", "tau", "auto_alpha", "alpha", "delay_update"}
+    rng = np.random.default_rng(3)
+    changes = {1: ("gamma", 0.9), 2: ("tau", 0.05), 3: ("delay_update", 1), 4: ("auto_alpha", False), 5: ("alpha", 0.7)}
+    for it in range(7):
+        if it in changes:
+            name, val = changes[it]
+            setattr(alg, name, val)
+            assert getattr(alg, name) == val
+            orc.cfg[name] = val
+        data = synth_batch(rng, 64, 11, 3)
+        torch.manual_seed(40 + it)
+        noise = draw_noise(64, 3)
+        torch.manual_seed(40 + it)
+        tb = alg.local_update(data, it)
+        ref = orc.local_update(data, noise, it)
+        for k in TB_KEYS[:-1]:
+            assert abs(float(tb[k]) - float(ref[k])) <= 1e-4 * max(1.0, abs(float(ref[k]))), (it, k)
+    alg.engine.sync()
+    assert np.abs(alg.engine.target.cpu().numpy() - orc.flat_targets().numpy()).max() < 1e-5   # tau and delay_update took effect
+    with pytest.raises(Exception):
+        alg.delay_update = 0
+    assert alg.delay_update == 1
+
+
+def test_remote_flow_reports_fresh_mean_std_and_foreign_gradients_leave_it_alone():
+    """get_remote_update_info's tb_info carries the mean_std the loss just used (dsac_v2.py:201-202), not the previous
+    EMA; remote_update on a learner that did not compute the gradient never touches mean_std."""
+    worker, orc = make_pair(11, 3, (64, 64), 64, seed=6)
+    learner, _ = make_pair(11, 3, (64, 64), 64, seed=6)
+    rng = np.random.default_rng(8)
+    for it in range(3):
+        data = synth_batch(rng, 64, 11, 3)
+        torch.manual_seed(70 + it)
+        noise = draw_noise(64, 3)
+        torch.manual_seed(70 + it)
+        tb, info = worker.get_remote_update_info(data, it)
+        ref = orc.compute_gradient(data, noise)
+        for k in ("DSAC2/mean_std1", "DSAC2/mean_std2"):
+            assert abs(float(tb[k]) - float(ref[k])) <= 1e-5, (it, k)   # read BEFORE the update is applied
+        learner.remote_update({k: ([g.clone() for g in v] if isinstance(v, list) else (v.clone() if torch.is_tensor(v) else v))
+                               for k, v in info.items()})
+        worker.remote_update(info)
+        orc.update(it)
+    learner.engine.sync(); worker.engine.sync()
+    assert torch.equal(learner.engine.online, worker.engine.online)
+    assert learner.engine.get_state()["mean_std"] == [-1.0, -1.0]            # never initialised on the pure learner
+    w = worker.engine.get_state()["mean_std"]
+    assert abs(w[0] - float(orc.mean_std1)) < 1e-5 and abs(w[1] - float(orc.mean_std2)) < 1e-5
+
+
+def test_sampling_ahead_restages_the_older_token():
+    """two sample_batch() calls before local_update(): the engine stages one minibatch at a time, so the older token
+    re-gathers its rows (same indices) instead of silently training on the newer ones."""
+    from training.hip_replay_buffer import HipReplayBuffer
+
+    O, A, B, N = 11, 3, 64, 512
+    alg, _ = make_pair(O, A, (64, 64), B, seed=5)
+    kw = hip_kwargs(O, A, (64, 64), B, buffer_max_size=N)
+    buf = HipReplayBuffer(**kw)
+    assert buf.engine is alg.engine
+    rng = np.random.default_rng(2)
+    buf.add_batch([(rng.standard_normal(O).astype(np.float32), {}, rng.uniform(-.4, .4, A).astype(np.float32), float(i),
+                    rng.standard_normal(O).astype(np.float32), False, 0.0, {}) for i in range(N)])
+    np.random.seed(3)
+    first, second = buf.sample_batch(B), buf.sample_batch(B)
+    want_first = first.idxs.astype(np.float32)      # the reward of row i is i
+    alg.local_update(first, 0)
+    alg.engine.sync()
+    assert np.array_equal(alg.engine.read_batch()["rew"], want_first)
+    assert np.array_equal(second["rew"].numpy(), second.idxs.astype(np.float32))
+    assert np.array_equal(first["rew"].numpy(), want_first)
 
 
 def test_remote_update_seam_equals_local_update():
@@ -302,7 +532,9 @@ def test_buffer_fast_path_equals_host_path():
     (17, 4, (64, 64), 64, 3, 6),          # odd updates per graph: both orders of the two batch sets
     (11, 3, (96, 40), 50, 4, 8),          # ragged widths / batch: edge tiles, a partial last gather block
     (5, 1, (33,), 7, 1, 4),               # one update per graph: nothing rides, only the bookkeeping block
-    (376, 17, (256, 256, 256), 256, 8, 16),
+    (376, 17, (256, 256, 256), 256, 8, 16),   # first group: 2-update lead graph + 6-update tail, second: the 8-update graph
+    (17, 4, (64, 64), 64, 6, 12),             # lead 2 + tail 4
+    (17, 4, (64, 64), 64, 7, 14),             # lead 2 + tail 5 (odd tail: the other order of the batch sets)
 ])
 def test_graph_replay_equals_eager_steps(O, A, hid, B, per_graph, total):
     """Graph replays (one gather per graph; each update's loss launch stages the NEXT update's minibatch into the other

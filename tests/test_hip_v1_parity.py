@@ -9,7 +9,7 @@ import torch
 from helpers import GOLDEN, hip_kwargs, synth_batch
 from oracle.dsact_oracle import default_config
 from oracle.dsac_v1_oracle import V1_TB_KEYS, DsacV1Oracle, draw_noise_v1
-from test_hip_parity import Report
+from test_hip_parity import AdamNoise, Report
 
 pytestmark = pytest.mark.gpu
 
@@ -34,6 +34,9 @@ def run_case(title, O, A, hid, B, steps, act_limit=0.4, init=None, golden=None):
     lay = e.layout
     assert lay.n_online == orc.flat_params().numel()
     rng = np.random.default_rng(9)
+    cfg = orc.cfg
+    noise_b = AdamNoise([("q", lay.n_q, cfg["lr_q"]), ("policy", lay.n_pi, cfg["lr_pi"]), ("log_alpha", 1, cfg["lr_alpha"])])
+    tau = cfg["tau"]
     for it in range(steps):
         if golden is not None:
             data = {k: torch.as_tensor(golden["s%d/%s" % (it, k)]) for k in ("obs", "obs2", "act", "rew", "done")}
@@ -50,8 +53,10 @@ def run_case(title, O, A, hid, B, steps, act_limit=0.4, init=None, golden=None):
         g, g_ref = e.grads.cpu().numpy(), orc.flat_grads().numpy()
         off = 0
         for net, n in (("q", lay.n_q), ("policy", lay.n_pi), ("log_alpha", 1)):
-            rep.cmp("it%d grad.%s" % (it, net), g[off:off + n], g_ref[off:off + n], 1e-9, 3e-4)
+            rep.cmp("it%d grad.%s" % (it, net), g[off:off + n], g_ref[off:off + n], 1e-9, 3e-5)
             off += n
+        delayed = it % cfg["delay_update"] == 0
+        noise_b.step(g_ref, g, ("q",) + (("policy", "log_alpha") if delayed else ()))
         e.apply_update(it)
         orc.update(it)
         from dsac_v1_hip import LazyTbInfoV1
@@ -59,13 +64,24 @@ def run_case(title, O, A, hid, B, steps, act_limit=0.4, init=None, golden=None):
         tb = LazyTbInfoV1(alg, alg._serial, 0.0)
         assert list(tb.keys()) == V1_TB_KEYS
         for k in V1_TB_KEYS[:-1]:
-            rep.cmp("it%d %s" % (it, k.split("/")[-1][:18]), [float(tb[k])], [float(tb_ref[k])], 1e-4, 1e-4)
+            if k.startswith("Loss/Critic"):
+                rep.cmp("it%d %s" % (it, k.split("/")[-1][:18]), [float(tb[k])], [float(tb_ref[k])], 1e-6, 1e-5)
+            else:
+                rep.cmp("it%d %s" % (it, k.split("/")[-1][:18]), [float(tb[k])], [float(tb_ref[k])], 1e-4)
+        p_hip, t_hip, nb = e.online.cpu().numpy(), e.target.cpu().numpy(), noise_b.bound
+        n_t = t_hip.size
+        tb_t = tau * (it + 1)
         if golden is not None:
-            rep.cmp("it%d tb vs reference" % it, [float(tb[k]) for k in V1_TB_KEYS[:-1]], golden["s%d/tb" % it], 1e-4, 1e-4)
-            rep.cmp("it%d params vs reference" % it, e.online.cpu().numpy(), golden["s%d/params" % it], 1e-4)
-            rep.cmp("it%d targets vs reference" % it, e.target.cpu().numpy(), golden["s%d/targets" % it], 1e-5)
-        rep.cmp("it%d params" % it, e.online.cpu().numpy(), orc.flat_params(), 1e-4)
-        rep.cmp("it%d targets" % it, e.target.cpu().numpy(), orc.flat_targets(), 1e-5)
+            crit = [i for i, k in enumerate(V1_TB_KEYS[:-1]) if k.startswith("Loss/Critic")]
+            keep_i = [i for i in range(len(V1_TB_KEYS) - 1) if i not in crit]
+            tb_g = np.asarray(golden["s%d/tb" % it], np.float64)
+            rep.cmp("it%d tb vs reference" % it, [float(tb[V1_TB_KEYS[i]]) for i in keep_i], tb_g[keep_i], 1e-4)
+            rep.cmp("it%d critic loss vs reference" % it, [float(tb[V1_TB_KEYS[i]]) for i in crit], tb_g[crit], 1e-6, 1e-5)
+            rep.cmp_params("it%d params vs reference" % it, p_hip, golden["s%d/params" % it], nb, 1e-6, noise_b.lr_steps)
+            rep.cmp_params("it%d targets vs reference" % it, t_hip, golden["s%d/targets" % it], tb_t * nb[:n_t], 1e-7,
+                           tb_t * noise_b.lr_steps)
+        rep.cmp_params("it%d params" % it, p_hip, orc.flat_params(), nb, 1e-6, noise_b.lr_steps)
+        rep.cmp_params("it%d targets" % it, t_hip, orc.flat_targets(), tb_t * nb[:n_t], 1e-7, tb_t * noise_b.lr_steps)
     assert e.get_state()["adam_steps"][0] == steps
     rep.finish()
 

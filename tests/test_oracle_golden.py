@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle.dsact_oracle import TB_KEYS, DsactOracle, MT19937, ReplayOracle, randint_legacy
-from helpers import GOLDEN, STEP_CASES, load_step_case, step_inputs
+from helpers import GOLDEN, STEP_CASES, humanoid_digest, load_step_case, step_inputs
 
 
 @pytest.mark.parametrize("name", STEP_CASES)
@@ -25,6 +25,24 @@ def test_step_matches_reference_golden(name):
         np.testing.assert_allclose(orc.flat_grads().numpy(), z["s%d/grad" % it], rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(orc.flat_params().numpy(), z["s%d/params" % it], rtol=0, atol=2e-6)
         np.testing.assert_allclose(orc.flat_targets().numpy(), z["s%d/targets" % it], rtol=0, atol=2e-6)
+
+
+def test_humanoid_b256_matches_reference_digest():
+    """the BASELINE.json configuration (obs 376 / act 17, 3x256, batch 256): oracle vs the digests the unmodified
+    reference produced from the same seeded nets, minibatches and noise"""
+    torch.set_num_threads(1)
+    z, cfg, init, steps = humanoid_digest()
+    orc = DsactOracle(cfg, state_dict=init)
+    stride = int(z["cfg_stride"])
+    for it, (data, noise) in enumerate(steps):
+        tb = orc.local_update(data, noise, it)
+        got = np.array([float(tb[k]) for k in TB_KEYS[:-1]])
+        np.testing.assert_allclose(got, z["s%d/tb" % it], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(orc.flat_grads().numpy()[::stride], z["s%d/grad_s" % it], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(orc.flat_params().numpy()[::stride], z["s%d/params_s" % it], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(orc.flat_targets().numpy()[::stride], z["s%d/targets_s" % it], rtol=0, atol=2e-6)
+        l2 = [float(g.double().norm()) for n in ("q1", "q2", "policy") for g in (p.grad for p in orc.p[n])]
+        np.testing.assert_allclose(l2, z["s%d/grad_l2" % it], rtol=1e-5)
 
 
 def test_state_dict_layout_matches_reference():
