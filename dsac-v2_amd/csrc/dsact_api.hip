@@ -151,7 +151,7 @@ struct dsact_handle {
   // environment switches, read once at dsact_create (getenv walks the whole environment: ~20 calls per eager update
   // were host time on the launch path)
   std::string env_timeline_stage;   // DSACT_TIMELINE_STAGE
-  bool env_no_tile64 = false, env_no_hb_ride = false, env_no_merged_gather = false, env_no_lead_graph = false;
+  bool env_no_tile64 = false, env_no_hb_ride = false, env_no_merged_gather = false;
   int env_conv_dw_nkt = 1;
   int env_ride_slots = 0;           // DSACT_RIDE_SLOTS: weight-gradient tiles riding in the policy-backward launch (default: one round)
   bool mirror_w0 = false;      // set while the merged-gather graph is being captured (see FusedOpt::mir_*)
@@ -177,11 +177,6 @@ struct dsact_handle {
   // graph
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
-  // the first group of a replay call runs as a short lead graph + the tail: hipGraphLaunch prepares every node before
-  // the first one is dispatched, so the long graph's launch cost hides behind the lead's execution
-  hipGraph_t lead_graph = nullptr, tail_graph = nullptr;
-  hipGraphExec_t lead_exec = nullptr, tail_exec = nullptr;
-  int lead_steps = 0;
   int graph_steps = 0;
   uint32_t graph_flags = 0;
   // profiling
@@ -191,7 +186,8 @@ struct dsact_handle {
   bool chain_ok = false;
   int cW = 0, cNT = 0;                  // hidden width, W / 64
   int s_obs = 0, s_act = 0, SoT = 0;    // stream steps (4 k each): observation / action segment of a first layer, policy outputs (2A)
-  int cRG = 2;                          // row groups of 4 per chain workgroup (8 rows)
+  int cRG = 2;                          // row groups of 4 per chain workgroup (8 rows) when 4-row workgroups would oversubscribe the CUs
+  int env_chain_rg = 0;                 // DSACT_CHAIN_RG=1|2: force
   int n_slices = 0;
   char* pk_ws = nullptr;                // the fragment-major copies
   float* pk_fwd[N_NET][kMaxLin];        // forward copies per net and layer (index L: output layer)
@@ -1264,12 +1260,26 @@ int run_dw2(dsact_handle* h, int x0, int x1, bool fused, bool finalize) {
 }
 
 // ---- row-slice fused update (dsact_chain.h) ---------------------------------------------------------------------
-#define CHAIN_NT(CALL)                         \
+#define CHAIN_NT(CALL, RGV)                    \
   do {                                         \
-    if (h->cNT == 1) { CALL(1, 2); }           \
-    else if (h->cNT == 2) { CALL(2, 2); }      \
-    else { CALL(4, 2); }                       \
+    if ((RGV) == 1) {                          \
+      if (h->cNT == 1) { CALL(1, 1); }         \
+      else if (h->cNT == 2) { CALL(2, 1); }    \
+      else { CALL(4, 1); }                     \
+    } else {                                   \
+      if (h->cNT == 1) { CALL(1, 2); }         \
+      else if (h->cNT == 2) { CALL(2, 2); }    \
+      else { CALL(4, 2); }                     \
+    }                                          \
   } while (0)
+
+// Row groups (of 4 rows) per chain workgroup of one launch. A workgroup streams its unit's whole weight set whatever
+// its row count, and a step costs ~45 cycles on top of its 32 * RG MFMA cycles: 4-row workgroups finish a layer in
+// 0.75x the time of 8-row ones -- as long as every workgroup still gets a CU of its own (n_units * B/4 <= 256 CUs).
+int chain_rg(const dsact_handle* h, int n_units) {
+  if (h->env_chain_rg) return h->env_chain_rg;
+  return n_units * (h->B / 4) <= 256 ? 1 : h->cRG;
+}
 
 FwdUnit fwd_unit(const dsact_handle* h, int ch, int seg, int head) {
   FwdUnit u;
@@ -1288,14 +1298,16 @@ FwdUnit fwd_unit(const dsact_handle* h, int ch, int seg, int head) {
 }
 
 int launch_chain_fwd(dsact_handle* h, const char* name, FwdArgs& a) {
-  a.n_slices = h->n_slices; a.B = h->B; a.F = h->F; a.A = h->A; a.L = h->L; a.ldx = h->ldx;
+  const int rg = chain_rg(h, a.n_units);
+  a.n_slices = h->B / (4 * rg); a.B = h->B; a.F = h->F; a.A = h->A; a.L = h->L; a.ldx = h->ldx;
   a.s_obs = h->s_obs; a.s_act = h->s_act; a.v1_stats = 0; a.Cb = h->B / 16;
   a.act_scale = h->act_scale; a.act_center = h->act_center; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
   a.timeline = tl_for(h, name);
   const int grid = chain_grid(a.n_units, a.n_slices);
-  const size_t lds = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 4 * h->cRG).total * sizeof(float);
+  const size_t lds = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 4 * rg).total * sizeof(float);
+  if (a.u[0].part_heads) h->n_heads_parts = a.n_slices;
 #define CALL_CF(N, G) return launch(h, name, k_chain_fwd<N, G>, dim3(grid), dim3(64 * N), lds, a)
-  CHAIN_NT(CALL_CF);
+  CHAIN_NT(CALL_CF, rg);
 #undef CALL_CF
 }
 
@@ -1316,7 +1328,6 @@ int enqueue_chain_fwd_a(dsact_handle* h) {
     qt.zsave = h->zobs[2 + i];
   }
   a.n_units = 6;
-  h->n_heads_parts = h->n_slices;
   return launch_chain_fwd(h, "chain_fwd_a", a);
 }
 
@@ -1353,7 +1364,8 @@ int enqueue_chain_bwd_q(dsact_handle* h, int n_units, const RideArgs* ride) {
     if (w >= 2) { u.w1at = h->pk_w1at[n3]; u.dA = h->dAq[n3]; }
     u.which = w;
   }
-  a.n_units = n_units; a.n_slices = h->n_slices; a.B = h->B; a.A = h->A; a.L = L; a.Cb = h->B / 16;
+  const int rg = chain_rg(h, n_units);
+  a.n_units = n_units; a.n_slices = h->B / (4 * rg); a.B = h->B; a.A = h->A; a.L = L; a.Cb = h->B / 16;
   for (int i = 0; i < 2; ++i) { a.qout_c[i] = h->qout_c[i]; a.qstd_c[i] = h->qstd_c[i]; a.qout_t[i] = h->qout_t[i]; a.qout_p[i] = h->qout_p[i]; }
   a.rew = h->rew; a.done = h->done; a.logp2 = h->logp2; a.logp_new = h->logp_new; a.z5 = h->z5; a.z6 = h->z6;
   a.log_alpha = h->online + h->n_online - 1;
@@ -1363,14 +1375,14 @@ int enqueue_chain_bwd_q(dsact_handle* h, int n_units, const RideArgs* ride) {
   a.std_sums = h->use_std_sums ? h->std_sums : nullptr;
   a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.gamma = h->cfg.gamma; a.tau_b = h->cfg.tau_b;
   a.one_minus_tau_b = (float)(1.0 - h->cfg.tau_b);
-  a.n_chain_blocks = chain_grid(n_units, h->n_slices);
+  a.n_chain_blocks = chain_grid(n_units, a.n_slices);
   a.timeline = tl_for(h, "chain_bwd_q");
   if (ride) a.ride = *ride;
   a.ride.n_loss_blocks = a.n_chain_blocks;
   const int n_riders = ride ? ride->n_gather + (ride->bookkeeping ? 1 : 0) : 0;
-  const size_t lds = (size_t)chain_lds(h->cW, h->cW, 4 * h->cRG).total * sizeof(float);
+  const size_t lds = (size_t)chain_lds(h->cW, h->cW, 4 * rg).total * sizeof(float);
 #define CALL_CQ(N, G) return launch(h, "chain_bwd_q", k_chain_bwd_q<N, G>, dim3(a.n_chain_blocks + n_riders), dim3(kThreads), lds, a)
-  CHAIN_NT(CALL_CQ);
+  CHAIN_NT(CALL_CQ, rg);
 #undef CALL_CQ
 }
 
@@ -1385,19 +1397,22 @@ int enqueue_chain_bwd_pi(dsact_handle* h, int x0, int x1, bool fused) {
   for (int l = 1; l < L; ++l) a.wb[l] = h->pk_bwd[2][l];
   for (int l = 0; l < L; ++l) { a.G[l] = h->Gb[C_PI][l]; a.dZ[l] = h->dZ[kDzSlot[C_PI]][l]; }
   a.dout_pi = h->dout_pi; a.d_new_act = h->d_new_act; a.dout_piT = h->doutT[2];
-  a.n_slices = h->n_slices; a.B = h->B; a.A = h->A; a.L = L; a.Cb = h->B / 16;
+  // the policy chain shares its launch with ~2 rounds of weight-gradient tiles, which bound it: 8-row workgroups leave
+  // them 32 more CUs (measured: 15.7 us vs 16.3 us with 4-row workgroups at batch 256)
+  const int rg = h->env_chain_rg ? h->env_chain_rg : (h->B >= 8 ? h->cRG : 1);
+  a.n_slices = h->B / (4 * rg); a.B = h->B; a.A = h->A; a.L = L; a.Cb = h->B / 16;
   a.inv_B = 1.0f / (float)h->B; a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed;
   a.act_scale = h->act_scale; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
   a.part_loss = h->part_loss; a.n_part = h->B; a.target_entropy = -(float)h->A;
   a.grad_log_alpha = h->grads + h->n_online - 1;
-  a.n_chain_blocks = h->n_slices;
+  a.n_chain_blocks = a.n_slices;
   a.timeline = tl_for(h, "chain_bwd_pi");
   a.dw = dw2_args(h, fused);
   a.tile0 = x0; a.n_extra = x1 > x0 ? x1 - x0 : 0;
-  size_t lds = (size_t)chain_lds(4 * h->SoT, h->cW, 4 * h->cRG).total * sizeof(float);
+  size_t lds = (size_t)chain_lds(4 * h->SoT, h->cW, 4 * rg).total * sizeof(float);
   if (lds < kDw2LdsFloats * sizeof(float)) lds = kDw2LdsFloats * sizeof(float);
 #define CALL_CP(N, G) return launch(h, "chain_bwd_pi", k_chain_bwd_pi<N, G>, dim3(a.n_chain_blocks + a.n_extra * h->dw_chunks), dim3(kThreads), lds, a)
-  CHAIN_NT(CALL_CP);
+  CHAIN_NT(CALL_CP, rg);
 #undef CALL_CP
 }
 
@@ -1693,12 +1708,9 @@ int enqueue_adam(dsact_handle* h, bool from_parts) {
 }
 
 void drop_graphs(dsact_handle* h) {
-  for (hipGraphExec_t* e : {&h->graph_exec, &h->lead_exec, &h->tail_exec})
-    if (*e) { hipGraphExecDestroy(*e); *e = nullptr; }
-  for (hipGraph_t* g : {&h->graph, &h->lead_graph, &h->tail_graph})
-    if (*g) { hipGraphDestroy(*g); *g = nullptr; }
+  if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+  if (h->graph) { hipGraphDestroy(h->graph); h->graph = nullptr; }
   h->graph_steps = 0;
-  h->lead_steps = 0;
 }
 
 int check_ready(dsact_handle* h, bool need_batch) {
@@ -1795,9 +1807,9 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->env_no_tile64 = getenv("DSACT_NO_TILE64") != nullptr;
   h->env_no_hb_ride = getenv("DSACT_NO_HB_RIDE") != nullptr;
   h->env_no_merged_gather = getenv("DSACT_NO_MERGED_GATHER") != nullptr;
-  h->env_no_lead_graph = getenv("DSACT_NO_LEAD_GRAPH") != nullptr;
   if (const char* v = getenv("DSACT_CONV_DW_NKT")) h->env_conv_dw_nkt = atoi(v);
   if (const char* v = getenv("DSACT_RIDE_SLOTS")) h->env_ride_slots = atoi(v);
+  if (const char* v = getenv("DSACT_CHAIN_RG")) h->env_chain_rg = atoi(v) == 1 ? 1 : 2;
   h->dw_chunks = (h->B > 448 && h->B % 256 == 0 && getenv("DSACT_NO_SPLITK") == nullptr) ? h->B / 256 : 1;
   h->dw_part_stride = (h->n_online + 2 + 63) & ~(size_t)63;
   {
@@ -1868,14 +1880,23 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, true, EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_conv_dw<3>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<false, EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<true, EPI_MULG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
   }
@@ -2402,14 +2423,6 @@ int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) 
   const bool was_prof = h->profiling;
   h->profiling = false;
   int rc = capture_updates(h, steps_per_graph, flags, merged, &h->graph, &h->graph_exec);
-  // lead + tail of the first group (see the handle): the lead is the shortest run that keeps the capture-time
-  // decisions (off iterations of the delayed update) aligned
-  const int lead = (flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) ? h->cfg.delay_update : 2;
-  if (rc == DSACT_OK && !h->env_no_lead_graph && steps_per_graph >= lead + 4) {
-    rc = capture_updates(h, lead, flags, merged, &h->lead_graph, &h->lead_exec);
-    if (rc == DSACT_OK) rc = capture_updates(h, steps_per_graph - lead, flags, merged, &h->tail_graph, &h->tail_exec);
-    if (rc == DSACT_OK) h->lead_steps = lead;
-  }
   h->profiling = was_prof;
   if (rc != DSACT_OK) { drop_graphs(h); return rc; }
   h->graph_steps = steps_per_graph;
@@ -2421,11 +2434,6 @@ int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) 
 // n_groups back-to-back replays of the captured updates
 static int launch_groups(dsact_handle* h, int64_t n_groups) {
   int64_t i = 0;
-  if (h->lead_steps && n_groups > 0) {
-    HIPCHK(h, hipGraphLaunch(h->lead_exec, h->stream));
-    HIPCHK(h, hipGraphLaunch(h->tail_exec, h->stream));
-    i = 1;
-  }
   for (; i < n_groups; ++i) HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
   return DSACT_OK;
 }

@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """Launch-by-launch view of one update from a rocprofv3 --kernel-trace CSV.
 
-usage: python scripts/step_trace.py gpurun_out/prof/bench_kernel_trace.csv [update_index] > profiles/rNN_step_trace.txt
+usage: python scripts/step_trace.py gpurun_out/prof/bench_kernel_trace.csv [update_index] [--bursts] > profiles/rNN_step_trace.txt
 
 Prints two consecutive updates (kernel, grid, duration, gap to the previous launch's end) and the sums, so the
-per-launch numbers quoted in DESIGN.md can be re-derived.
+per-launch numbers quoted in DESIGN.md can be re-derived. --bursts: additionally one line per burst of launches
+(bursts are separated by > 300 us of idle GPU: the timed regions of a short bench run) with its span, the sum of its
+kernel durations and its idle time -- where a short region's time goes.
 """
 import csv
 import sys
 
 
 def main():
-    path = sys.argv[1]
-    which = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    path = args[0]
+    which = int(args[1]) if len(args) > 1 else 1000
     rows = []
     with open(path) as f:
         for r in csv.DictReader(f):
@@ -22,10 +25,15 @@ def main():
     rows.sort()
     # an update ends with the launch that closes it (k_stage_table, or k_adam on the unfused path); a k_gather in front
     # of it belongs to it (graph replays with the merged gather have one k_gather per graph, not per update)
+    # (row-slice chain path: k_dw2 closes it unless the unfused optimiser pass k_adam / the split-K sum follows)
     updates, cur = [], []
-    for r in rows:
+    for i, r in enumerate(rows):
         cur.append(r)
-        if "k_stage_table(" in r[2] or "k_adam(" in r[2]:
+        nxt = rows[i + 1][2] if i + 1 < len(rows) else ""
+        closes = "k_stage_table(" in r[2] or "k_adam(" in r[2] or \
+            ("k_dw2(" in r[2] and "k_adam(" not in nxt and "k_sum_parts(" not in nxt and "k_dw2(" not in nxt
+             and "AllReduce" not in nxt)
+        if closes:
             updates.append(cur)
             cur = []
     if len(updates) < which + 2:
@@ -45,6 +53,26 @@ def main():
             prev_end = e
         span = (seg[-1][1] - seg[0][0]) / 1000.0
         print("  sum of durations %.1f us; first start -> last end %.1f us; launches %d" % (total, span, len(seg)))
+    if "--bursts" in sys.argv:
+        bursts(rows)
+
+
+def bursts(rows, idle_us=300.0):
+    out, cur = [], [rows[0]]
+    for r in rows[1:]:
+        if (r[0] - cur[-1][1]) / 1000.0 > idle_us:
+            out.append(cur)
+            cur = []
+        cur.append(r)
+    out.append(cur)
+    print("bursts of launches (separated by > %.0f us idle): %d" % (idle_us, len(out)))
+    for b in out[-12:]:
+        span = (b[-1][1] - b[0][0]) / 1000.0
+        busy = sum(e - s for s, e, *_ in b) / 1000.0
+        closers = sum(1 for r in b if "k_dw2(" in r[2] or "k_stage_table(" in r[2])
+        first = ", ".join("%s %.1f" % (r[2].split("::")[-1].split("(")[0][:14], (r[1] - r[0]) / 1000.0) for r in b[:7])
+        print("  %4d launches (%3d closing)  span %9.1f us  busy %9.1f us  idle %7.1f us | first: %s"
+              % (len(b), closers, span, busy, span - busy, first))
 
 
 if __name__ == "__main__":

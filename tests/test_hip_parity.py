@@ -532,9 +532,8 @@ def test_buffer_fast_path_equals_host_path():
     (17, 4, (64, 64), 64, 3, 6),          # odd updates per graph: both orders of the two batch sets
     (11, 3, (96, 40), 50, 4, 8),          # ragged widths / batch: edge tiles, a partial last gather block
     (5, 1, (33,), 7, 1, 4),               # one update per graph: nothing rides, only the bookkeeping block
-    (376, 17, (256, 256, 256), 256, 8, 16),   # first group: 2-update lead graph + 6-update tail, second: the 8-update graph
-    (17, 4, (64, 64), 64, 6, 12),             # lead 2 + tail 4
-    (17, 4, (64, 64), 64, 7, 14),             # lead 2 + tail 5 (odd tail: the other order of the batch sets)
+    (376, 17, (256, 256, 256), 256, 8, 16),
+    (17, 4, (64, 64), 64, 7, 14),
 ])
 def test_graph_replay_equals_eager_steps(O, A, hid, B, per_graph, total):
     """Graph replays (one gather per graph; each update's loss launch stages the NEXT update's minibatch into the other
