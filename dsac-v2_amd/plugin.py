@@ -15,6 +15,22 @@ if _PKG not in sys.path:
     sys.path.insert(0, _PKG)
 
 
+def install():
+    """One call for a reference checkout: makes `training.hip_replay_buffer` (and the other training/hip_*.py modules)
+    importable INSIDE the reference's own `training` package, which is where `utils/initialization.py:93-110`
+    (`importlib.import_module("training." + buffer_name)`) looks for a buffer -- without copying files into the
+    reference. Works whichever `training` package was imported first: the package's search path ends up holding
+    both directories. `dsac_v2_hip` / `dsac_v1_hip` need nothing: they are top-level modules of this directory."""
+    import training
+
+    ours = os.path.join(_PKG, "training")
+    dirs = [ours] + [os.path.join(p, "training") for p in sys.path if p and os.path.isdir(os.path.join(p, "training"))]
+    for d in dirs:
+        if d not in list(training.__path__):
+            training.__path__.append(d)
+    importlib.invalidate_caches()
+
+
 def camel(name: str) -> str:
     return "".join(part[:1].upper() + part[1:] for part in name.split("_"))
 

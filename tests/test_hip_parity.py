@@ -996,3 +996,83 @@ def test_local_update_takes_cuda_tensors_like_the_reference_trainer():
     for name in ("online", "target", "adam_m", "adam_v"):
         assert torch.equal(getattr(a_cpu.engine, name), getattr(a_gpu.engine, name)), name
         assert torch.equal(getattr(a_cpu.engine, name), getattr(a_mix.engine, name)), name
+
+
+class _ModuleOnDevice:
+    """what the reference's trainer / evaluator wrap every sampling call in (utils/common_utils.py:164-177:
+    remember the device of the first parameter, `.to(new)` on enter, `.to(previous)` on exit), restated for the test"""
+
+    def __init__(self, module, device):
+        self.module, self.new = module, device
+        self.prev = next(module.parameters()).device.type
+        self.moved = self.prev != device
+
+    def __enter__(self):
+        if self.moved:
+            self.module.to(self.new)
+
+    def __exit__(self, *exc):
+        if self.moved:
+            self.module.to(self.prev)
+
+
+def test_attached_container_survives_the_reference_device_ping_pong():
+    """the reference trainer moves `networks` to the CPU around every sampler / evaluator
+    call and back (training/trainer.py:63-66, ModuleOnDevice). With the container attached to the engine the
+    parameters ARE the HIP arenas: `.to("cpu")`, `.cpu()`, `.cuda()`, the context manager must neither re-home them
+    nor break acting with CPU observations, and training must continue on the same storage."""
+    O, A, B = 11, 3, 64
+    alg, orc = make_pair(O, A, (64, 64), B, seed=8)
+    nets, e = alg.networks, alg.engine
+    ptr0 = [p.data_ptr() for p in nets.parameters()]
+    lo, hi = e.online.data_ptr(), e.online.data_ptr() + 4 * e.online.numel()
+    assert all(p.is_cuda for p in nets.parameters())
+    rng = np.random.default_rng(4)
+    obs1 = torch.as_tensor(rng.standard_normal((1, O), dtype=np.float32))
+
+    def act_logits():
+        with torch.no_grad():
+            lg = nets.policy(obs1)                 # CPU observation in, CPU logits out (off_sampler.py:44-51)
+        assert lg.device.type == "cpu" and lg.shape == (1, 2 * A)
+        dist = nets.create_action_distributions(lg)
+        a, lp = dist.sample()
+        assert a.shape == (1, A) and lp.shape == (1,)
+        return lg
+
+    before = act_logits()
+    for move in (lambda: nets.to("cpu"), lambda: nets.cpu(), lambda: nets.cuda(), lambda: nets.to("cuda:0"),
+                 lambda: nets.to(torch.device("cpu"))):
+        out = move()
+        assert out is nets
+        assert [p.data_ptr() for p in nets.parameters()] == ptr0
+        assert all(p.is_cuda and lo <= p.data_ptr() < hi for n, p in nets.named_parameters() if "target" not in n)
+    with _ModuleOnDevice(nets, "cpu") as _:
+        inside = act_logits()                       # the sampler's view of the module
+        assert [p.data_ptr() for p in nets.parameters()] == ptr0
+    assert torch.equal(before, inside)
+    # the logits are the live learner weights: identical to the oracle's torch forward of the same parameters
+    with torch.no_grad():
+        want = orc._pi(obs1, orc.p["policy"])
+    assert torch.allclose(before, want, atol=2e-5, rtol=1e-5)
+    # training continues on the same storage, and the next acting call sees the UPDATED weights
+    for it in range(3):
+        data = synth_batch(rng, B, O, A)
+        torch.manual_seed(60 + it)
+        noise = draw_noise(B, A)
+        torch.manual_seed(60 + it)
+        with _ModuleOnDevice(nets, "cpu"):
+            pass                                    # trainer.py:63-66 around sampler.sample()
+        tb = alg.local_update({k: v.cuda() for k, v in data.items()}, it)   # trainer.py:72-74
+        ref = orc.local_update(data, noise, it)
+        assert abs(float(tb["Loss/Critic loss-RL iter"]) - float(ref["Loss/Critic loss-RL iter"])) <= 1e-5 * max(1.0, abs(float(ref["Loss/Critic loss-RL iter"])))
+    after = act_logits()
+    assert not torch.equal(after, before)
+    with torch.no_grad():
+        want = orc._pi(obs1, orc.p["policy"])
+    assert torch.allclose(after, want, atol=2e-5, rtol=1e-5)
+    assert [p.data_ptr() for p in nets.parameters()] == ptr0
+    # state_dict round trip through the CPU (the reference's save / sampler.load_state_dict path)
+    sd_cpu = {k: v.detach().cpu().clone() for k, v in nets.state_dict().items()}
+    nets.load_state_dict(sd_cpu)
+    assert [p.data_ptr() for p in nets.parameters()] == ptr0
+    assert torch.equal(act_logits(), after)

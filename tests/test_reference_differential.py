@@ -1,0 +1,132 @@
+"""Differential tests against the LIVE reference: the unmodified reference's own
+factories and sampler, run in this process through oracle/ref_loader.py, side by side with the HIP host layer.
+Skipped where /root/reference is absent (the GPU box); no GPU is needed -- the acting path of a CPU container is torch.
+
+  * reference `OffSampler(algorithm="DSAC_V2_HIP")` finds `dsac_v2_hip.ApproxContainer` by the reference's own
+    discovery rule (training/off_sampler.py:19-23) and produces, transition for transition, what `HipOffSampler`
+    produces from the same seeds (training/off_sampler.py:38-97)
+  * reference `create_alg` / `create_buffer` (utils/initialization.py:48-110) resolve the HIP module and class names;
+    without a GPU construction fails LOUDLY in the HIP layer (no silent CPU fallback)
+  * the reference `ReplayBuffer` and the host mirror of the HIP ring agree on ptr/size/sample indices
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import hip_kwargs
+from oracle import ref_loader
+
+pytestmark = pytest.mark.skipif(not ref_loader.reference_available(), reason="reference not mounted")
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(os.path.dirname(HERE), "dsac-v2_amd")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    mod = ref_loader.import_reference()
+    for p in (PKG, os.path.join(HERE, "envs")):
+        if p not in sys.path:
+            sys.path.append(p)     # AFTER the reference root: `training`, `utils` stay the reference's packages
+    import plugin
+
+    plugin.install()
+    return mod
+
+
+def sampler_kwargs(**over):
+    kw = hip_kwargs(3, 1, (32, 32), 16, act_limit=2.0, env_id="synth_pendulum", sample_batch_size=25,
+                    batch_size_per_sampler=25, noise_params=None, reward_scale=1, seed=11, max_episode_steps=60)
+    kw.update(over)
+    return kw
+
+
+def test_reference_sampler_with_hip_container_equals_hip_sampler(ref):
+    import training.off_sampler as ref_sampler_mod          # the reference's
+    from training.hip_sampler import HipOffSampler          # ours, found inside the same package after plugin.install()
+    from utils.initialization import create_env as ref_create_env
+
+    assert ref_sampler_mod.__file__.startswith(ref_loader.REFERENCE_ROOT)
+    kw = sampler_kwargs()
+    torch.manual_seed(5)
+    ref_s = ref_sampler_mod.OffSampler(**kw)                # __import__("dsac_v2_hip").ApproxContainer(**kw)
+    import dsac_v2_hip
+    assert type(ref_s.networks) is dsac_v2_hip.ApproxContainer
+    env = ref_create_env(**kw)                              # the same wrapper stack the reference sampler acts in
+    env.seed(kw["seed"])
+    hip_s = HipOffSampler(env=env, **kw)
+    hip_s.networks = dsac_v2_hip.ApproxContainer(**kw)
+    hip_s.load_state_dict(ref_s.networks.state_dict())
+    assert np.array_equal(ref_s.obs, hip_s.obs)
+    n_trunc = 0
+    for call in range(6):                                   # 150 transitions: two 60-step time limits are crossed
+        torch.manual_seed(100 + call)
+        a, tb_a = ref_s.sample()
+        torch.manual_seed(100 + call)
+        b, tb_b = hip_s.sample()
+        assert list(tb_a.keys()) == list(tb_b.keys()) == ["Time/Sampler time [ms]-RL iter"]
+        assert len(a) == len(b) == kw["sample_batch_size"]
+        for ta, tb_ in zip(a, b):
+            obs_a, info_a, act_a, rew_a, obs2_a, done_a, logp_a, info2_a = ta
+            obs_b, info_b, act_b, rew_b, obs2_b, done_b, logp_b, info2_b = tb_
+            assert np.array_equal(obs_a, obs_b) and np.array_equal(obs2_a, obs2_b)
+            assert np.array_equal(act_a, act_b) and act_a.dtype == act_b.dtype
+            assert float(rew_a) == float(rew_b) and bool(done_a) == bool(done_b)
+            assert np.array_equal(logp_a, logp_b)
+            assert bool(info2_a["TimeLimit.truncated"]) == bool(info2_b["TimeLimit.truncated"])
+            n_trunc += bool(info2_a["TimeLimit.truncated"])
+    assert n_trunc == 2
+    assert ref_s.get_total_sample_number() == hip_s.get_total_sample_number() == 150
+
+
+def test_reference_factories_resolve_the_hip_modules(ref):
+    from utils.initialization import create_alg, create_buffer
+    from dsact._ffi import DsactError
+
+    kw = sampler_kwargs(buffer_max_size=256)
+    # the reference's rule: module algorithm.lower(), class algorithm -- reaches DSAC_V2_HIP.__init__, which refuses to
+    # run without its GPU library / device instead of falling back to a CPU update
+    with pytest.raises((DsactError, RuntimeError)) as ei:
+        create_alg(**kw)
+    assert "DSAC_V2_HIP" in "".join(str(f) for f in ei.traceback) or "dsac_v2_hip" in "".join(str(f.path) for f in ei.traceback)
+    # "training." + buffer_name.lower(), class CamelCase(buffer_name): the module is found INSIDE the reference's package
+    import importlib
+    mod = importlib.import_module("training." + kw["buffer_name"])
+    assert mod.__file__.startswith(PKG) and hasattr(mod, "HipReplayBuffer")
+    import training.replay_buffer as ref_rb
+    assert ref_rb.__file__.startswith(ref_loader.REFERENCE_ROOT)       # the reference's own buffer is still there
+    with pytest.raises((DsactError, RuntimeError)) as ei:
+        create_buffer(**kw)
+    assert "hip_replay_buffer" in "".join(str(f.path) for f in ei.traceback)
+    # DSAC_V1_HIP by the same rule
+    with pytest.raises((DsactError, RuntimeError)):
+        create_alg(**dict(kw, algorithm="DSAC_V1_HIP", TD_bound=10))
+
+
+def test_reference_replay_buffer_vs_host_mirror(ref):
+    """reference ReplayBuffer (training/replay_buffer.py:20-90) vs oracle ReplayOracle, which the GPU tests compare the
+    HIP ring against bit for bit (tests/test_hip_parity.py::test_replay_ring_and_gather_bit_exact): ptr / size after
+    every add_batch, and the sampled rows after the same np.random.seed."""
+    import training.replay_buffer as ref_rb
+    from oracle.dsact_oracle import ReplayOracle
+
+    O, A, N = 5, 2, 37
+    kw = dict(trainer="off_serial_trainer", seed=0, obsv_dim=O, action_dim=A, buffer_max_size=N, additional_info={})
+    a, b = ref_rb.ReplayBuffer(**kw), ReplayOracle(O, A, N)
+    rng = np.random.default_rng(4)
+    for n in (1, 10, 26, 3, 37, 5):      # fills, wraps, a batch as large as the ring
+        samples = [(rng.standard_normal(O).astype(np.float32), {}, rng.uniform(-1, 1, A).astype(np.float32),
+                    float(rng.standard_normal()), rng.standard_normal(O).astype(np.float32), bool(rng.random() < .2),
+                    np.float32(rng.standard_normal()), {}) for _ in range(n)]
+        a.add_batch(samples)
+        b.add_batch(samples)
+        assert (a.size, a.ptr) == (b.size, b.ptr)
+        np.random.seed(n)
+        sa = a.sample_batch(16)
+        np.random.seed(n)
+        sb = b.sample_batch(16)
+        for k in ("obs", "obs2", "act", "rew", "done", "logp"):
+            assert torch.equal(sa[k], sb[k]), k
