@@ -351,6 +351,31 @@ def boundary_rates(alg, n):
         e.sync()
         w = time.perf_counter() - t0
         res[name] = {"value": n / w, "unit": "steps/s", "ms_per_step": 1000.0 * w / n}
+    # the sampler side of the boundary (training/off_sampler.py:44-51,82 -> trainer.py:58-61): the batch-1 policy
+    # forward that acts with the live learner weights (dsact_policy_forward: H2D of one observation, fused MLP forward,
+    # D2H of the logits, synchronous) -- the device part of "Time/Sampler time" -- and add_batch of 20 transitions
+    # (pinned staging, one H2D, asynchronous ring write)
+    obs1 = torch.as_tensor(rng.standard_normal((1, O), dtype=np.float32))
+    for _ in range(20):
+        alg.networks.policy(obs1)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        alg.networks.policy(obs1)
+    res["sampler_policy_forward_us"] = (time.perf_counter() - t0) / 200 * 1e6
+    if e.buffer_size > 0:
+        nb = 20
+        cols = (rng.standard_normal((nb, O), dtype=np.float32), rng.uniform(-.4, .4, (nb, A)).astype(np.float32),
+                rng.standard_normal(nb, dtype=np.float32), rng.standard_normal((nb, O), dtype=np.float32),
+                np.zeros(nb, np.float32), np.zeros(nb, np.float32))
+        for _ in range(10):
+            e.buffer_add(*cols)
+        e.sync()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            e.buffer_add(*cols)
+        res["buffer_add_20_call_us"] = (time.perf_counter() - t0) / 200 * 1e6   # host time of the call (no sync inside)
+        e.sync()
+        res["buffer_add_20_drained_us"] = (time.perf_counter() - t0) / 200 * 1e6
     res["bytes_per_step"] = 4 * Bt * (2 * O + A + 2)
     res["note"] = ("local_update(data) with a minibatch from outside the HIP ring, %d eager updates each: host_batch = "
                    "CPU tensors (PCIe-inclusive), cuda_batch = CUDA tensors; not the headline value" % n)

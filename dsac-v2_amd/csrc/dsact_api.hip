@@ -164,8 +164,12 @@ struct dsact_handle {
   // replay ring
   long long cap = 0, ptr = 0, size = 0;
   float *rb_obs = nullptr, *rb_obs2 = nullptr, *rb_act = nullptr, *rb_rew = nullptr, *rb_done = nullptr, *rb_logp = nullptr;
-  float* stage_dev = nullptr;  // staging for ring writes
+  float* stage_dev = nullptr;  // device staging for ring writes
   size_t stage_rows = 0;
+  float* stage_pin[2] = {nullptr, nullptr};   // pinned host staging, two slots: dsact_buffer_add returns without a sync
+  hipEvent_t stage_ev[2] = {nullptr, nullptr};
+  unsigned stage_k = 0;
+  float* logp_stage = nullptr;                // [B] gathered logp for dsact_read_batch
   // pinned host staging
   int* h_idx[8];
   hipEvent_t h_idx_ev[8];
@@ -1928,6 +1932,11 @@ int dsact_destroy(dsact_handle* h) {
   if (h->d_pack) hipFree(h->d_pack);
   if (h->idx_table) hipFree(h->idx_table);
   if (h->stage_dev) hipFree(h->stage_dev);
+  for (int i = 0; i < 2; ++i) {
+    if (h->stage_pin[i]) hipHostFree(h->stage_pin[i]);
+    if (h->stage_ev[i]) hipEventDestroy(h->stage_ev[i]);
+  }
+  if (h->logp_stage) hipFree(h->logp_stage);
   if (h->stage_img) hipFree(h->stage_img);
   for (float* p : {h->rb_obs, h->rb_obs2, h->rb_act, h->rb_rew, h->rb_done, h->rb_logp})
     if (p) hipFree(p);
@@ -2099,22 +2108,37 @@ int dsact_buffer_add(dsact_handle* h, int64_t n, const float* obs, const float* 
   if ((size_t)n > h->stage_rows) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->stage_dev) hipFree(h->stage_dev);
+    for (int i = 0; i < 2; ++i)
+      if (h->stage_pin[i]) { hipHostFree(h->stage_pin[i]); h->stage_pin[i] = nullptr; }
     h->stage_rows = (size_t)n < 64 ? 64 : (size_t)n;
     HIPCHK(h, hipMalloc(&h->stage_dev, h->stage_rows * row_f * sizeof(float)));
+    for (int i = 0; i < 2; ++i) {
+      HIPCHK(h, hipHostMalloc((void**)&h->stage_pin[i], h->stage_rows * row_f * sizeof(float), hipHostMallocDefault));
+      if (!h->stage_ev[i]) HIPCHK(h, hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming));
+    }
   }
-  const size_t R = h->stage_rows;
+  // The caller's arrays are copied into a pinned slot here (they may be reused right away); the H2D copy and the ring
+  // write are stream-ordered behind whatever the handle is doing and nothing waits for them: the sampler's next
+  // env.step overlaps the transfer. A slot is reused two calls later, after its copy has left it.
+  const int slot = (int)(h->stage_k++ & 1);
+  HIPCHK(h, hipEventSynchronize(h->stage_ev[slot]));
+  float* pin = h->stage_pin[slot];
+  size_t off = 0;
+  auto put = [&](const float* src, size_t count) {
+    if (src) memcpy(pin + off, src, count * sizeof(float));
+    off += count;
+  };
+  put(obs, (size_t)n * O); put(obs2, (size_t)n * O); put(act, (size_t)n * A); put(rew, (size_t)n); put(done, (size_t)n);
+  put(logp, (size_t)n);   // absent: the ring's logp column keeps its old values (a.s_logp == nullptr below)
+  const size_t R = (size_t)n;   // the staged columns are packed for THIS call's n
   float* s_obs = h->stage_dev;
   float* s_obs2 = s_obs + R * O;
   float* s_act = s_obs2 + R * O;
   float* s_rew = s_act + R * A;
   float* s_done = s_rew + R;
   float* s_logp = s_done + R;
-  HIPCHK(h, hipMemcpyAsync(s_obs, obs, n * O * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(s_obs2, obs2, n * O * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(s_act, act, n * A * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(s_rew, rew, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(s_done, done, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  if (logp) HIPCHK(h, hipMemcpyAsync(s_logp, logp, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->stage_dev, pin, off * sizeof(float), hipMemcpyHostToDevice, h->stream));   // ONE copy
+  HIPCHK(h, hipEventRecord(h->stage_ev[slot], h->stream));
   // if n exceeds the capacity only the last `cap` rows survive (same as sequential store())
   long long first = 0, cnt = n;
   if (n > h->cap) { first = n - h->cap; cnt = h->cap; }
@@ -2133,8 +2157,6 @@ int dsact_buffer_add(dsact_handle* h, int64_t n, const float* obs, const float* 
     a.O = 0;
   }
   TRY(launch(h, "ring_write", k_ring_write, dim3((unsigned)((cnt + 3) / 4)), dim3(kThreads), 0, a));
-  // host pointers may be reused by the caller right away
-  HIPCHK(h, hipStreamSynchronize(h->stream));
   h->ptr = (h->ptr + n) % h->cap;
   h->size = h->size + n > h->cap ? h->cap : h->size + n;
   return DSACT_OK;
@@ -2221,9 +2243,13 @@ int dsact_read_batch(dsact_handle* h, float* obs, float* act, float* rew, float*
   if (done) HIPCHK(h, hipMemcpy(done, h->done, B * 4, hipMemcpyDeviceToHost));
   if (logp) {
     if (!h->rb_logp) return fail(h, DSACT_E_STATE, "buffer not created");
-    std::vector<int> idx(B);
-    HIPCHK(h, hipMemcpy(idx.data(), h->idx_eager, B * sizeof(int), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < B; ++i) HIPCHK(h, hipMemcpy(logp + i, h->rb_logp + idx[i], 4, hipMemcpyDeviceToHost));
+    // one gather launch + ONE device-to-host copy (was one 4-byte copy per row)
+    if (!h->logp_stage) HIPCHK(h, hipMalloc(&h->logp_stage, B * sizeof(float)));
+    TakeArgs t;
+    t.src = h->rb_logp; t.idx = h->idx_eager; t.dst = h->logp_stage; t.n = (int)B;
+    TRY(launch(h, "take_logp", k_take, dim3((unsigned)((B + kThreads - 1) / kThreads)), dim3(kThreads), 0, t));
+    HIPCHK(h, hipMemcpyAsync(logp, h->logp_stage, B * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
   }
   return DSACT_OK;
 }

@@ -1791,6 +1791,13 @@ __global__ void __launch_bounds__(kThreads) k_sum_parts(SumPartsArgs a) {
 // k_stats: the 14 numeric tb_info entries (dsac_v2.py:188-202) from the partial sums; launched
 // only when the host asks (trainer logs every log_save_interval iterations).
 // ---------------------------------------------------------------------------------------------
+// dst[i] = src[idx[i]]  (dsact_read_batch: the sampled rows' logp column, one launch + one copy)
+struct TakeArgs { const float* src; const int* idx; float* dst; int n; };
+__global__ void k_take(TakeArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < a.n) a.dst[i] = a.src[a.idx[i]];
+}
+
 struct StatsArgs {
   const float* part_loss; int n_loss; const float* part_heads; int n_heads;
   const float* log_alpha; const DevState* st; float inv_B; float inv_BA; int auto_alpha; float alpha_fixed;

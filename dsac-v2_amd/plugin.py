@@ -76,6 +76,13 @@ def create_evaluator(**kwargs):
     return HipEvaluator(**kwargs)
 
 
+def save_tb_to_csv(path):
+    """reference utils/tensorboard_setup.py:121-139 for a folder written by HipOffSerialTrainer"""
+    from training.hip_trainer import save_tb_to_csv as f
+
+    return f(path)
+
+
 def create_trainer(alg, sampler, buffer, evaluator, **kwargs):
     from training.hip_trainer import HipOffSerialTrainer
 

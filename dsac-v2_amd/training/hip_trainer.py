@@ -16,13 +16,66 @@ import time
 
 import torch
 
-__all__ = ["HipOffSerialTrainer", "HipEvaluator", "create_trainer", "create_evaluator"]
+__all__ = ["HipOffSerialTrainer", "HipEvaluator", "create_trainer", "create_evaluator", "save_tb_to_csv", "TB_TAGS"]
 
-TB = {  # reference utils/tensorboard_setup.py:142-153
-    "tar_iter": "Evaluation/1. TAR-RL iter", "tar_time": "Evaluation/2. TAR-Total time [s]",
-    "tar_samples": "Evaluation/3. TAR-Collected samples", "tar_replay": "Evaluation/4. TAR-Replay samples",
-    "ram": "RAM/RAM [MB]-RL iter",
+TB_TAGS = {  # the reference's tag set, same keys and strings (utils/tensorboard_setup.py:142-153)
+    "TAR of RL iteration": "Evaluation/1. TAR-RL iter",
+    "TAR of total time": "Evaluation/2. TAR-Total time [s]",
+    "TAR of collected samples": "Evaluation/3. TAR-Collected samples",
+    "TAR of replay samples": "Evaluation/4. TAR-Replay samples",
+    "Buffer RAM of RL iteration": "RAM/RAM [MB]-RL iter",
+    "loss_actor": "Loss/Actor loss-RL iter",
+    "loss_critic": "Loss/Critic loss-RL iter",
+    "alg_time": "Time/Algorithm time [ms]-RL iter",
+    "sampler_time": "Time/Sampler time [ms]-RL iter",
+    "critic_avg_value": "Train/Critic avg value-RL iter",
 }
+TB = {"tar_iter": TB_TAGS["TAR of RL iteration"], "tar_time": TB_TAGS["TAR of total time"],
+      "tar_samples": TB_TAGS["TAR of collected samples"], "tar_replay": TB_TAGS["TAR of replay samples"],
+      "ram": TB_TAGS["Buffer RAM of RL iteration"]}
+
+
+def read_scalars(path):
+    """{tag: {"x": steps, "y": values}} of <path>/scalars.jsonl in first-seen tag order -- what the reference's
+    read_tensorboard (utils/tensorboard_setup.py:14-36) returns from the event files. Values are rounded through
+    float32 like a tensorboard scalar summary stores them."""
+    import numpy as np
+
+    out = {}
+    fn = os.path.join(path, "scalars.jsonl")
+    if not os.path.exists(fn):
+        return out
+    with open(fn) as f:
+        for line in f:
+            if not line.strip():
+                continue
+            r = json.loads(line)
+            d = out.setdefault(r["tag"], {"x": [], "y": []})
+            d["x"].append(int(r["step"]))
+            d["y"].append(float(np.float32(r["value"])))
+    return {k: {"x": np.array(v["x"]), "y": np.array(v["y"])} for k, v in out.items()}
+
+
+def save_tb_to_csv(path):
+    """The reference's post-training export (utils/tensorboard_setup.py:121-139, called by every example script after
+    trainer.train()): one `<path>/data/<tag with / -> _>.csv` per scalar tag with the columns `Step,Value`. Reads the
+    scalars.jsonl this trainer writes (tensorboard is not needed); returns the list of files written."""
+    import csv
+
+    files = []
+    data = read_scalars(path)
+    for tag, d in data.items():
+        name = tag.replace("\\", "/").replace("/", "_")
+        csv_dir = os.path.join(path, "data")
+        os.makedirs(csv_dir, exist_ok=True)
+        fn = os.path.join(csv_dir, "{}.csv".format(name))
+        with open(fn, "w", newline="") as f:
+            w = csv.writer(f, lineterminator="\n")
+            w.writerow(["Step", "Value"])
+            for x, y in zip(d["x"], d["y"]):
+                w.writerow([int(x), repr(float(y))])
+        files.append(fn)
+    return files
 
 
 class _Scalars:
@@ -104,6 +157,9 @@ class HipOffSerialTrainer:
         if self.save_folder:
             os.makedirs(os.path.join(self.save_folder, "apprfunc"), exist_ok=True)
         self.writer = _Scalars(self.save_folder)
+        # the reference opens its log with these two at step 0 (training/trainer.py:43-47)
+        self.writer.add_dict({TB_TAGS["alg_time"]: 0, TB_TAGS["sampler_time"]: 0}, 0)
+        self.writer.flush()
         while sampler is not None and self.buffer.size < kwargs["buffer_warm_size"]:  # trainer.py:50-52
             samples, _ = sampler.sample()
             self.buffer.add_batch(samples)
@@ -145,6 +201,8 @@ class HipOffSerialTrainer:
         if self.save_folder:
             self.save_apprfunc()
         self.writer.flush()
+        if self.save_folder:
+            save_tb_to_csv(self.save_folder)   # what the reference's example scripts do right after train()
 
     def save_apprfunc(self):
         torch.save(self.networks.state_dict(),

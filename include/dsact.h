@@ -141,7 +141,10 @@ int dsact_set_hyper(dsact_handle* h, int32_t which, double value);
 /* ---- replay buffer (training/replay_buffer.py) -------------------------------------------------- */
 int dsact_buffer_create(dsact_handle* h, int64_t capacity);
 /* n transitions, SoA host arrays (obs[n*O], act[n*A], rew[n], obs2[n*O], done[n], logp[n]); ring
- * write at ptr with the reference's ptr/size semantics (replay_buffer.py:58-79). */
+ * write at ptr with the reference's ptr/size semantics (replay_buffer.py:58-79). ASYNCHRONOUS: the arrays are copied
+ * into a pinned staging slot before the call returns (the caller may reuse them at once), one H2D copy and the ring
+ * write are enqueued on the handle's stream and nothing waits for them; every later call on the handle is ordered
+ * behind them. dsact_buffer_size / dsact_buffer_ptr reflect the add immediately. */
 int dsact_buffer_add(dsact_handle* h, int64_t n, const float* obs, const float* act, const float* rew,
                      const float* obs2, const float* done, const float* logp);
 int64_t dsact_buffer_size(const dsact_handle* h);

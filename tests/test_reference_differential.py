@@ -130,3 +130,40 @@ def test_reference_replay_buffer_vs_host_mirror(ref):
         sb = b.sample_batch(16)
         for k in ("obs", "obs2", "act", "rew", "done", "logp"):
             assert torch.equal(sa[k], sb[k]), k
+
+
+def test_csv_export_equals_the_reference_export(ref, tmp_path):
+    """f3: after training the reference's scripts call save_tb_to_csv(save_folder) (utils/tensorboard_setup.py:121-139).
+    The HIP trainer logs to scalars.jsonl; its export must produce the same files with the same bytes as the
+    reference's own function fed with the same scalars (its event-file reader swapped for ours -- tensorboard is
+    not installed here), and the tag dictionary must be the reference's."""
+    import shutil
+
+    import utils.tensorboard_setup as ref_tb
+    from training.hip_trainer import TB_TAGS, _Scalars, read_scalars, save_tb_to_csv
+
+    assert TB_TAGS == ref_tb.tb_tags
+    ours, theirs = tmp_path / "ours", tmp_path / "theirs"
+    ours.mkdir(); theirs.mkdir()
+    w = _Scalars(str(ours))
+    rng = np.random.default_rng(0)
+    w.add_dict({TB_TAGS["alg_time"]: 0, TB_TAGS["sampler_time"]: 0}, 0)
+    for it in range(0, 50, 10):
+        w.add_dict({TB_TAGS["loss_critic"]: float(rng.standard_normal()) * 3.7, TB_TAGS["loss_actor"]: float(rng.standard_normal()),
+                    "DSAC2/mean_std1": torch.tensor(0.1 * it + 1e-3), TB_TAGS["alg_time"]: 0.0712}, it)
+        w.add(TB_TAGS["TAR of total time"], -1234.5678, it // 3)
+        w.add(TB_TAGS["Buffer RAM of RL iteration"], 3092.0, it)
+    w.flush()
+    files = save_tb_to_csv(str(ours))
+    shutil.copy(ours / "scalars.jsonl", theirs / "scalars.jsonl")
+    orig = ref_tb.read_tensorboard
+    ref_tb.read_tensorboard = read_scalars          # same {tag: {"x", "y"}} contract (tensorboard_setup.py:14-36)
+    try:
+        ref_tb.save_tb_to_csv(str(theirs))          # the reference's naming + pandas formatting, unmodified
+    finally:
+        ref_tb.read_tensorboard = orig
+    names = sorted(os.listdir(theirs / "data"))
+    assert names == sorted(os.path.basename(f) for f in files) and len(names) == 7
+    assert "Time_Algorithm time [ms]-RL iter.csv" in names and "Evaluation_2. TAR-Total time [s].csv" in names
+    for n in names:
+        assert (ours / "data" / n).read_bytes() == (theirs / "data" / n).read_bytes(), n

@@ -74,3 +74,10 @@ def test_sampler_and_trainer_loop(tmp_path):
     assert list(sd.keys())[0] == "log_alpha" and "policy.policy.0.weight" in sd
     tags = {json.loads(l)["tag"] for l in open(tmp_path / "scalars.jsonl")}
     assert "Loss/Critic loss-RL iter" in tags and "Evaluation/1. TAR-RL iter" in tags
+    # the reference opens the log with alg/sampler time 0 at step 0 (trainer.py:43-47) and its scripts export CSVs
+    first = [json.loads(l) for l in open(tmp_path / "scalars.jsonl")][:2]
+    assert [r["tag"] for r in first] == ["Time/Algorithm time [ms]-RL iter", "Time/Sampler time [ms]-RL iter"]
+    assert all(r["step"] == 0 and r["value"] == 0 for r in first)
+    csvs = sorted(os.listdir(tmp_path / "data"))
+    assert "Loss_Critic loss-RL iter.csv" in csvs and "Evaluation_1. TAR-RL iter.csv" in csvs
+    assert open(tmp_path / "data" / "Loss_Critic loss-RL iter.csv").readline() == "Step,Value\n"
