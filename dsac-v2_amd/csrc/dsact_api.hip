@@ -1260,7 +1260,7 @@ int run_dw2(dsact_handle* h, int x0, int x1, bool fused, bool finalize) {
   Dw2Launch L;
   L.a = dw2_args(h, fused);
   L.tile0 = x0; L.n_tiles = x1 > x0 ? x1 - x0 : 0; L.finalize = finalize ? 1 : 0;
-  return launch(h, "dW", k_dw2, dim3(L.n_tiles + (finalize ? 1 : 0), h->dw_chunks), dim3(kThreads), 0, L);
+  return launch(h, "dW", k_dw2, dim3(xcd_chunk_grid(L.n_tiles) + (finalize ? 1 : 0), h->dw_chunks), dim3(kThreads), 0, L);
 }
 
 // ---- row-slice fused update (dsact_chain.h) ---------------------------------------------------------------------
@@ -1409,13 +1409,13 @@ int enqueue_chain_bwd_pi(dsact_handle* h, int x0, int x1, bool fused) {
   a.act_scale = h->act_scale; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
   a.part_loss = h->part_loss; a.n_part = h->B; a.target_entropy = -(float)h->A;
   a.grad_log_alpha = h->grads + h->n_online - 1;
-  a.n_chain_blocks = a.n_slices;
+  a.n_chain_blocks = roundup(a.n_slices, 8);   // the riders' first block lands on XCD 0 (xcd_chunk)
   a.timeline = tl_for(h, "chain_bwd_pi");
   a.dw = dw2_args(h, fused);
   a.tile0 = x0; a.n_extra = x1 > x0 ? x1 - x0 : 0;
   size_t lds = (size_t)chain_lds(4 * h->SoT, h->cW, 4 * rg).total * sizeof(float);
   if (lds < kDw2LdsFloats * sizeof(float)) lds = kDw2LdsFloats * sizeof(float);
-#define CALL_CP(N, G) return launch(h, "chain_bwd_pi", k_chain_bwd_pi<N, G>, dim3(a.n_chain_blocks + a.n_extra * h->dw_chunks), dim3(kThreads), lds, a)
+#define CALL_CP(N, G) return launch(h, "chain_bwd_pi", k_chain_bwd_pi<N, G>, dim3(a.n_chain_blocks + xcd_chunk_grid(a.n_extra) * h->dw_chunks), dim3(kThreads), lds, a)
   CHAIN_NT(CALL_CP, rg);
 #undef CALL_CP
 }

@@ -337,15 +337,30 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds) {
   }
 }
 
-// grid (n_tiles [+ 1], batch ranges): base tiles tile0 .. tile0 + n_tiles - 1 of every range; the extra block closes the update
+// Tile order is (layer, row block, column block): neighbours share operands. The dispatcher deals consecutive block
+// ids round-robin over the 8 XCDs, so handing out tiles in block order makes every L2 fetch every layer's operands
+// (~6 MB x 8 over the fabric per update). Instead XCD x takes the x-th contiguous eighth of the tile list: an L2 sees
+// the operands of one or two layers only. b: block index of a launch whose first tile block sits on XCD 0
+// (grid = xcd_chunk_grid(n) blocks); false: padding block.
+__host__ __device__ inline int xcd_chunk_grid(int n) { return 8 * ((n + 7) >> 3); }
+__device__ __forceinline__ bool xcd_chunk(int b, int n, int& t) {
+  const int per = (n + 7) >> 3;
+  t = (b & 7) * per + (b >> 3);
+  return t < n && (b >> 3) < per;
+}
+
+// grid (xcd_chunk_grid(n_tiles) [+ 1], batch ranges): base tiles tile0 .. tile0 + n_tiles - 1 of every range; the
+// extra block closes the update
 struct Dw2Launch { Dw2Args a; int tile0, n_tiles, finalize; };
 __global__ void __launch_bounds__(kThreads) k_dw2(Dw2Launch L) {
   __shared__ __attribute__((aligned(16))) float lds[kDw2LdsFloats];
-  if ((int)blockIdx.x >= L.n_tiles) {
+  if ((int)blockIdx.x >= xcd_chunk_grid(L.n_tiles)) {
     if (L.finalize && blockIdx.y == 0 && threadIdx.x == 0) finalize_update(L.a.fo);
     return;
   }
-  dw2_tile(L.a, (int)blockIdx.y * L.a.n_base + L.tile0 + (int)blockIdx.x, lds);
+  int t;
+  if (!xcd_chunk((int)blockIdx.x, L.n_tiles, t)) return;
+  dw2_tile(L.a, (int)blockIdx.y * L.a.n_base + L.tile0 + t, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -774,7 +789,10 @@ __global__ void __launch_bounds__(256) k_chain_bwd_pi(BwdPiArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if ((int)blockIdx.x >= a.n_chain_blocks) {
     const int idx = (int)blockIdx.x - a.n_chain_blocks;
-    dw2_tile(a.dw, (idx / a.n_extra) * a.dw.n_base + a.tile0 + idx % a.n_extra, lds);
+    const int per_range = xcd_chunk_grid(a.n_extra);   // n_chain_blocks is a multiple of 8: riders start on XCD 0
+    int t;
+    if (!xcd_chunk(idx % per_range, a.n_extra, t)) return;
+    dw2_tile(a.dw, (idx / per_range) * a.dw.n_base + a.tile0 + t, lds);
     return;
   }
   const int slice = (int)blockIdx.x;
