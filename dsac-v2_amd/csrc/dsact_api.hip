@@ -1403,7 +1403,8 @@ int enqueue_chain_bwd_pi(dsact_handle* h, int x0, int x1, bool fused) {
   a.dout_pi = h->dout_pi; a.d_new_act = h->d_new_act; a.dout_piT = h->doutT[2];
   // the policy chain shares its launch with ~2 rounds of weight-gradient tiles, which bound it: 8-row workgroups leave
   // them 32 more CUs (measured: 15.7 us vs 16.3 us with 4-row workgroups at batch 256)
-  const int rg = h->env_chain_rg ? h->env_chain_rg : (h->B >= 8 ? h->cRG : 1);
+  const int rg_pi = getenv("DSACT_CHAIN_RG_PI") ? atoi(getenv("DSACT_CHAIN_RG_PI")) : 0;   // experiments
+  const int rg = rg_pi ? rg_pi : h->env_chain_rg ? h->env_chain_rg : (h->B >= 8 ? h->cRG : 1);
   a.n_slices = h->B / (4 * rg); a.B = h->B; a.A = h->A; a.L = L; a.Cb = h->B / 16;
   a.inv_B = 1.0f / (float)h->B; a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed;
   a.act_scale = h->act_scale; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;

@@ -39,8 +39,11 @@ constexpr int kPD = 16;        // weight steps (4 k of a 64-output tile = 1 KB p
 // phase stamps of the chain kernels (instrumented builds, -DDSACT_TIMELINE): [block][16] shader-clock values
 #ifdef DSACT_TIMELINE
 #define CTL(buf, k) do { if ((buf) && threadIdx.x == 0 && blockIdx.x < 256) (buf)[blockIdx.x * 16 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+// slots 14 / 15: workgroup begin / end on the chip-wide 100 MHz counter (the cycle counter is per XCD: no skew across them)
+#define CTLR(buf, k) do { if ((buf) && threadIdx.x == 0 && blockIdx.x < 512) (buf)[blockIdx.x * 16 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define CTL(buf, k) do {} while (0)
+#define CTLR(buf, k) do {} while (0)
 #endif
 
 
@@ -422,6 +425,26 @@ __global__ void __launch_bounds__(64 * NW) k_chain_fwd(FwdArgs a) {
   float bq[kChMaxL];
 #pragma unroll
   for (int l = 0; l < kChMaxL; ++l) bq[l] = u.bias[l < L ? l : 0][n];
+  // operands of the head's row phase (TPR lanes per row, action dim d = jr, jr + TPR): fetched now -- a global load
+  // issued where it is used would sit on the critical path of the kernel's tail (~1 us each round trip)
+  const int mr = tid / TPR, jr = tid % TPR;
+  constexpr int NQ = (32 + TPR - 1) / TPR;      // act_dim <= 32
+  float pre_eps[NQ], pre_bmu[NQ], pre_braw[NQ], pre_s[NQ], pre_c[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) { pre_eps[q] = 0.f; pre_bmu[q] = 0.f; pre_braw[q] = 0.f; pre_s[q] = 1.f; pre_c[q] = 0.f; }
+  if (u.head == HEAD_POLICY) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int d = jr + q * TPR;
+      if (d < A) {
+        pre_eps[q] = u.eps[(size_t)(row0 + mr) * A + d];
+        pre_bmu[q] = u.bias[L][d]; pre_braw[q] = u.bias[L][A + d];
+        pre_s[q] = a.act_scale[d]; pre_c[q] = a.act_center[d];
+      }
+    }
+  } else if (u.head == HEAD_Q && jr == 0) {
+    pre_bmu[0] = u.bias[L][0]; pre_braw[0] = u.bias[L][1];
+  }
   f32x4 zi[RG];
   if (u.seg == SEG_ACT_FROM_SAVED) {
 #pragma unroll
@@ -545,12 +568,12 @@ __global__ void __launch_bounds__(64 * NW) k_chain_fwd(FwdArgs a) {
   narrow_mma<4>(hf, nto, wave, lds, hl + ((lane & 15) & (R - 1)) * S.ld_h + 4 * (lane >> 4), red, lane);
   lds_barrier();
   CTL(a.timeline, 12);
-  const int m = tid / TPR, j = tid % TPR;      // row phase: TPR consecutive lanes per batch row
+  const int m = mr, j = jr;                    // row phase: TPR consecutive lanes per batch row
   const int r = row0 + m;
   if (u.head == HEAD_Q) {
     if (j == 0) {
-      const float mean = narrow_get<4, NW>(lds, red, m, 0) + u.bias[L][0];
-      const float raw = narrow_get<4, NW>(lds, red, m, 1) + u.bias[L][1];
+      const float mean = narrow_get<4, NW>(lds, red, m, 0) + pre_bmu[0];
+      const float raw = narrow_get<4, NW>(lds, red, m, 1) + pre_braw[0];
       u.qout[2 * r] = mean; u.qout[2 * r + 1] = raw;
       if (u.qstd) { u.qstd[2 * r] = softplus(raw); u.qstd[2 * r + 1] = softplus_grad(raw); }
     }
@@ -559,11 +582,13 @@ __global__ void __launch_bounds__(64 * NW) k_chain_fwd(FwdArgs a) {
   }
   // policy: (mu, raw log-std) -> tanh-Gaussian rsample (act_distribution_cls.py:44-54)
   float lp = 0.f, s_tanh = 0.f, s_sig = 0.f;
-  for (int d = j; d < A; d += TPR) {
-    const float mu = narrow_get<4, NW>(lds, red, m, d) + u.bias[L][d];
-    const float raw = narrow_get<4, NW>(lds, red, m, A + d) + u.bias[L][A + d];
-    const float eps = u.eps[(size_t)r * A + d];
-    const TanhGaussFwd f = tanh_gauss_fwd(mu, raw, eps, a.act_scale[d], a.act_center[d], a.lo_ls, a.hi_ls);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int d = j + q * TPR;
+    if (d >= A) break;
+    const float mu = narrow_get<4, NW>(lds, red, m, d) + pre_bmu[q];
+    const float raw = narrow_get<4, NW>(lds, red, m, A + d) + pre_braw[q];
+    const TanhGaussFwd f = tanh_gauss_fwd(mu, raw, pre_eps[q], pre_s[q], pre_c[q], a.lo_ls, a.hi_ls);
     lp += f.lp;
     u.xact[(size_t)r * a.ldx + F + d] = f.a;
     if (u.xact2) u.xact2[(size_t)r * a.ldx + F + d] = f.a;
@@ -792,7 +817,9 @@ __global__ void __launch_bounds__(256) k_chain_bwd_pi(BwdPiArgs a) {
     const int per_range = xcd_chunk_grid(a.n_extra);   // n_chain_blocks is a multiple of 8: riders start on XCD 0
     int t;
     if (!xcd_chunk(idx % per_range, a.n_extra, t)) return;
+    CTLR(a.timeline, 14);
     dw2_tile(a.dw, (idx / per_range) * a.dw.n_base + a.tile0 + t, lds);
+    CTLR(a.timeline, 15);
     return;
   }
   const int slice = (int)blockIdx.x;
@@ -808,9 +835,25 @@ __global__ void __launch_bounds__(256) k_chain_bwd_pi(BwdPiArgs a) {
   const ChainLds S = chain_lds(4 * a.SoT, W, R);
   float* xdo = lds + S.off_in;
   CTL(a.timeline, 0);
+  CTLR(a.timeline, 14);
   WStr ws;
   const float* wo = a.woutT + (size_t)wave * a.SoT * 256;
   stream_prologue(ws, wo, 0, lane4);
+  const int m = tid / TPR, j = tid % TPR;
+  const int r = row0 + m;
+  // the row phase's inputs, fetched before anything waits (each would otherwise be a round trip on the critical path)
+  constexpr int NQ = (32 + TPR - 1) / TPR;      // act_dim <= 32
+  float pdA[NQ], pmu[NQ], praw[NQ], peps[NQ], psc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int d = j + q * TPR;
+    const bool ok = d < A;
+    pdA[q] = ok ? a.dA[0][(size_t)r * 32 + d] + a.dA[1][(size_t)r * 32 + d] : 0.f;
+    pmu[q] = ok ? a.logits_pi[(size_t)r * 2 * A + d] : 0.f;
+    praw[q] = ok ? a.logits_pi[(size_t)r * 2 * A + A + d] : 0.f;
+    peps[q] = ok ? a.eps_new[(size_t)r * A + d] : 0.f;
+    psc[q] = ok ? a.act_scale[d] : 1.f;
+  }
   // alpha gradient (dsac_v2.py:312-318): -mean(logp_new + target_entropy)
   if (slice == 0 && wave == 0) {
     float s = 0.f;
@@ -821,17 +864,17 @@ __global__ void __launch_bounds__(256) k_chain_bwd_pi(BwdPiArgs a) {
     s = wave_sum(s);
     if (lane == 0) a.grad_log_alpha[0] = a.auto_alpha ? -(s * a.inv_B + a.target_entropy) : 0.0f;
   }
-  const int m = tid / TPR, j = tid % TPR;
-  const int r = row0 + m;
   const float alpha = a.auto_alpha ? expf(a.log_alpha[0]) : a.alpha_fixed;
   // zero the operand rows (padding included), then fill (dmu | draw)
   for (int e = tid; e < R * 4 * a.SoT; e += NTHR) xdo[(e / (4 * a.SoT)) * S.ld_in + e % (4 * a.SoT)] = 0.0f;
   lds_barrier();
-  for (int d = j; d < A; d += TPR) {
-    const float dA = a.dA[0][(size_t)r * 32 + d] + a.dA[1][(size_t)r * 32 + d];
-    const float mu = a.logits_pi[(size_t)r * 2 * A + d], raw = a.logits_pi[(size_t)r * 2 * A + A + d];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int d = j + q * TPR;
+    if (d >= A) break;
+    const float dA = pdA[q];
     float dmu, draw;
-    tanh_gauss_bwd(mu, raw, a.eps_new[(size_t)r * A + d], a.act_scale[d], a.lo_ls, a.hi_ls, dA, alpha * a.inv_B, dmu, draw);
+    tanh_gauss_bwd(pmu[q], praw[q], peps[q], psc[q], a.lo_ls, a.hi_ls, dA, alpha * a.inv_B, dmu, draw);
     a.dout_pi[(size_t)r * 2 * A + d] = dmu;
     a.dout_pi[(size_t)r * 2 * A + A + d] = draw;
     a.dout_piT[pk_index(d, r, a.Cb)] = dmu;
@@ -885,6 +928,7 @@ __global__ void __launch_bounds__(256) k_chain_bwd_pi(BwdPiArgs a) {
     if (l > 1) lds_barrier();
     CTL(a.timeline, 3 + (L - 1 - l));
   }
+  CTLR(a.timeline, 15);
 }
 
 }  // namespace dsact

@@ -23,7 +23,19 @@ for it in range(8):
     e.load_batch(*(d[k].numpy() for k in ("obs","act","rew","obs2","done")))
     e.step(it)
 e.sync()
-raw = e.debug_read("timeline").view(np.int64).reshape(512, 16)[:256]
+full = e.debug_read("timeline").view(np.int64).reshape(512, 16)
+rt = full[(full[:,14] != 0) & (full[:,15] != 0)]
+if len(rt):
+    # chip-wide 100 MHz stamps (slots 14/15): chain workgroups have cycle stamps too, riders only these
+    t00 = rt[:,14].min()
+    for nm, sel in (("chain workgroups", rt[:,0] != 0), ("rider tiles", rt[:,0] == 0)):
+        g = rt[sel]
+        if len(g):
+            b, en = (g[:,14]-t00)/100.0, (g[:,15]-t00)/100.0
+            print("  realtime, %d %s: begin median %.2f max %.2f us; end median %.2f p90 %.2f max %.2f us; duration median %.2f max %.2f us"
+                  % (len(g), nm, np.median(b), b.max(), np.median(en), np.percentile(en, 90), en.max(), np.median(en-b), (en-b).max()))
+raw = full[:256].copy()
+raw[:,14:] = 0
 raw = raw[raw[:,0] != 0]
 print("stage %s: %d workgroups stamped" % (os.environ["STAGE"], len(raw)))
 t0 = raw[:,0].min()
