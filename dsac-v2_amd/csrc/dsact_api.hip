@@ -65,6 +65,9 @@ struct ProfRec {
 
 }  // namespace
 
+constexpr int kChainFlagSlices = 64;                 // slices per unit of a merged forward launch (batch <= 256, >= 4 rows each)
+constexpr int kChainFlags = 6 * kChainFlagSlices;
+
 struct dsact_handle {
   dsact_config cfg;
   int device = 0;
@@ -191,7 +194,8 @@ struct dsact_handle {
   int cW = 0, cNT = 0;                  // hidden width, W / 64
   int s_obs = 0, s_act = 0, SoT = 0;    // stream steps (4 k each): observation / action segment of a first layer, policy outputs (2A)
   int cRG = 2;                          // row groups of 4 per chain workgroup (8 rows) when 4-row workgroups would oversubscribe the CUs
-  int env_chain_rg = 0;                 // DSACT_CHAIN_RG=1|2: force
+  int env_chain_rg = 0;                 // DSACT_CHAIN_RG=1|2|4: force
+  bool rg4_ok = false;                  // 16-row chain workgroups fit (LDS) and divide the batch
   int n_slices = 0;
   char* pk_ws = nullptr;                // the fragment-major copies
   float* pk_fwd[N_NET][kMaxLin];        // forward copies per net and layer (index L: output layer)
@@ -199,6 +203,8 @@ struct dsact_handle {
   float* pk_w1at[2];                    // q1, q2: (W0[:, F:])^T
   MirrorDesc* d_mir = nullptr;          // [3 nets][L+1]: what the Adam tiles of each weight tensor refresh
   PackJob* d_pack = nullptr; int n_pack_jobs = 0, pack_blocks = 0;
+  int* chain_flags = nullptr;           // ready flags of the merged forward launch + timeout word at [kChainFlags]
+  bool fwd_merge = false;               // launches A and B as one (batch <= 256)
   float* zobs[4];                       // first-layer accumulators after the observation part: q1, q2 (obs), q1_t, q2_t (obs2)
   float* dAq[2];                        // dL/d new_act through q1 / q2  [B][32]
   float* doutT[3];                      // transposed packs of dL/d(out): q1, q2 [32 x B], policy [roundup32(2A) x B]
@@ -426,6 +432,7 @@ void carve(dsact_handle* h, Carver& c) {
   h->timeline = c.take<long long>(512 * 16);
   h->dw_parts = c.take<float>(h->dw_chunks > 1 ? (size_t)h->dw_chunks * h->dw_part_stride : 4);
   for (int i = 0; i < 4; ++i) h->zobs[i] = c.take<float>(B * h->w[0]);
+  h->chain_flags = c.take<int>(kChainFlags + 64);   // [unit 0..5][slice] ready flags of the merged forward launch, then the spin-timeout word
   for (int i = 0; i < 2; ++i) h->dAq[i] = c.take<float>(B * 32);
   for (int i = 0; i < 2; ++i) h->doutT[i] = c.take<float>(B * 32);
   h->doutT[2] = c.take<float>(B * (size_t)((2 * A + 31) / 32 * 32));
@@ -1270,6 +1277,10 @@ int run_dw2(dsact_handle* h, int x0, int x1, bool fused, bool finalize) {
       if (h->cNT == 1) { CALL(1, 1); }         \
       else if (h->cNT == 2) { CALL(2, 1); }    \
       else { CALL(4, 1); }                     \
+    } else if ((RGV) == 4) {                   \
+      if (h->cNT == 1) { CALL(1, 4); }         \
+      else if (h->cNT == 2) { CALL(2, 4); }    \
+      else { CALL(4, 4); }                     \
     } else {                                   \
       if (h->cNT == 1) { CALL(1, 2); }         \
       else if (h->cNT == 2) { CALL(2, 2); }    \
@@ -1280,9 +1291,15 @@ int run_dw2(dsact_handle* h, int x0, int x1, bool fused, bool finalize) {
 // Row groups (of 4 rows) per chain workgroup of one launch. A workgroup streams its unit's whole weight set whatever
 // its row count, and a step costs ~45 cycles on top of its 32 * RG MFMA cycles: 4-row workgroups finish a layer in
 // 0.75x the time of 8-row ones -- as long as every workgroup still gets a CU of its own (n_units * B/4 <= 256 CUs).
-int chain_rg(const dsact_handle* h, int n_units) {
+// Large batches: 16-row workgroups (RG 4) halve the weight bytes per FLOP. Measured at batch 4096 / 1024: the critics'
+// backward gains (81.5 -> 63.7 us / 21.8 -> 20.3 us), the forward launches lose (209 -> 228 us: one fat workgroup per CU
+// hides less latency than two 8-row ones), the policy backward is even -- so only the critics' backward asks for it
+// (`allow4`), and only when even 16-row slices give every CU a workgroup.
+int chain_rg(const dsact_handle* h, int n_units, bool allow4 = false) {
   if (h->env_chain_rg) return h->env_chain_rg;
-  return n_units * (h->B / 4) <= 256 ? 1 : h->cRG;
+  if (n_units * (h->B / 4) <= 256) return 1;
+  if (allow4 && h->rg4_ok && n_units * (h->B / 16) >= 256) return 4;
+  return h->cRG;
 }
 
 FwdUnit fwd_unit(const dsact_handle* h, int ch, int seg, int head) {
@@ -1301,23 +1318,16 @@ FwdUnit fwd_unit(const dsact_handle* h, int ch, int seg, int head) {
   return u;
 }
 
-int launch_chain_fwd(dsact_handle* h, const char* name, FwdArgs& a) {
-  const int rg = chain_rg(h, a.n_units);
+void fill_fwd_common(dsact_handle* h, FwdArgs& a, int rg, const char* name) {
   a.n_slices = h->B / (4 * rg); a.B = h->B; a.F = h->F; a.A = h->A; a.L = h->L; a.ldx = h->ldx;
   a.s_obs = h->s_obs; a.s_act = h->s_act; a.v1_stats = 0; a.Cb = h->B / 16;
   a.act_scale = h->act_scale; a.act_center = h->act_center; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
   a.timeline = tl_for(h, name);
-  const int grid = chain_grid(a.n_units, a.n_slices);
-  const size_t lds = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 4 * rg).total * sizeof(float);
-  if (a.u[0].part_heads) h->n_heads_parts = a.n_slices;
-#define CALL_CF(N, G) return launch(h, name, k_chain_fwd<N, G>, dim3(grid), dim3(64 * N), lds, a)
-  CHAIN_NT(CALL_CF, rg);
-#undef CALL_CF
+  a.spin_timeout = h->chain_flags + kChainFlags;
 }
 
 // group A: policy(obs), policy_target(obs2), q1/q2(obs,act) + observation part of q1_t/q2_t(obs2, .)
-int enqueue_chain_fwd_a(dsact_handle* h) {
-  FwdArgs a;
+void fwd_args_a(dsact_handle* h, FwdArgs& a) {
   memset(&a, 0, sizeof(a));
   FwdUnit& pi = a.u[0] = fwd_unit(h, C_PI, SEG_FULL, HEAD_POLICY);
   pi.logits = h->logits_pi; pi.logp = h->logp_new; pi.eps = h->eps_new; pi.xact = h->Xc[C_Q1P]; pi.part_heads = h->part_heads;
@@ -1332,12 +1342,10 @@ int enqueue_chain_fwd_a(dsact_handle* h) {
     qt.zsave = h->zobs[2 + i];
   }
   a.n_units = 6;
-  return launch_chain_fwd(h, "chain_fwd_a", a);
 }
 
 // group B: q1_t/q2_t(obs2,act2), q1/q2(obs,new_act): saved observation part + action part, hidden layers, heads
-int enqueue_chain_fwd_b(dsact_handle* h) {
-  FwdArgs a;
+void fwd_args_b(dsact_handle* h, FwdArgs& a) {
   memset(&a, 0, sizeof(a));
   for (int i = 0; i < 2; ++i) {
     FwdUnit& qt = a.u[i] = fwd_unit(h, C_Q1T + i, SEG_ACT_FROM_SAVED, HEAD_Q);
@@ -1347,7 +1355,63 @@ int enqueue_chain_fwd_b(dsact_handle* h) {
     qp.zinit = h->zobs[i]; qp.qout = h->qout_p[i];
   }
   a.n_units = 4;
+}
+
+int launch_chain_fwd(dsact_handle* h, const char* name, FwdArgs& a) {
+  const int rg = chain_rg(h, a.n_units);
+  fill_fwd_common(h, a, rg, name);
+  const int grid = chain_grid(a.n_units, a.n_slices);
+  const size_t lds = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 4 * rg).total * sizeof(float);
+  if (a.u[0].part_heads) h->n_heads_parts = a.n_slices;
+#define CALL_CF(N, G) return launch(h, name, k_chain_fwd<N, G>, dim3(grid), dim3(64 * N), lds, a)
+  CHAIN_NT(CALL_CF, rg);
+#undef CALL_CF
+}
+
+int enqueue_chain_fwd_a(dsact_handle* h) {
+  FwdArgs a;
+  fwd_args_a(h, a);
+  return launch_chain_fwd(h, "chain_fwd_a", a);
+}
+
+int enqueue_chain_fwd_b(dsact_handle* h) {
+  FwdArgs a;
+  fwd_args_b(h, a);
   return launch_chain_fwd(h, "chain_fwd_b", a);
+}
+
+// A and B in ONE launch (batch <= 256: every workgroup of both groups fits on the chip at once): group B's workgroups
+// wait for the ready flags of the group-A slices they read (k_chain_fwd2); k_chain_bwd_q clears the flags.
+int enqueue_chain_fwd_merged(dsact_handle* h) {
+  Fwd2Args m;
+  fwd_args_a(h, m.A);
+  fwd_args_b(h, m.B);
+  const int rga = chain_rg(h, m.A.n_units), rgb = chain_rg(h, m.B.n_units);
+  fill_fwd_common(h, m.A, rga, "chain_fwd");
+  fill_fwd_common(h, m.B, rgb, "chain_fwd");
+  h->n_heads_parts = m.A.n_slices;
+  int* f = h->chain_flags;
+  for (int k = 0; k < 6; ++k) m.A.u[k].done = f + k * kChainFlagSlices;   // pi, pit, q1c, q2c, q1t(obs), q2t(obs)
+  for (int i = 0; i < 2; ++i) {
+    FwdUnit& qt = m.B.u[i];       // q_t(obs2, act2): action from pit, observation part from the obs-only unit
+    qt.wait0 = f + 1 * kChainFlagSlices; qt.wait1 = f + (4 + i) * kChainFlagSlices; qt.wait_rows = 4 * rga;
+    FwdUnit& qp = m.B.u[2 + i];   // q(obs, new_act): action from pi, observation part from q_c
+    qp.wait0 = f + 0 * kChainFlagSlices; qp.wait1 = f + (2 + i) * kChainFlagSlices; qp.wait_rows = 4 * rga;
+  }
+  m.n_a = chain_grid(m.A.n_units, m.A.n_slices);
+  const int grid = m.n_a + chain_grid(m.B.n_units, m.B.n_slices);
+  const size_t la = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 4 * rga).total * sizeof(float);
+  const size_t lb = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 4 * rgb).total * sizeof(float);
+  const size_t lds = la > lb ? la : lb;
+#define CALL_CF2(N)                                                                                           \
+  do {                                                                                                        \
+    if (rga == 2) return launch(h, "chain_fwd", k_chain_fwd2<N, 2, 1>, dim3(grid), dim3(64 * N), lds, m);      \
+    return launch(h, "chain_fwd", k_chain_fwd2<N, 1, 1>, dim3(grid), dim3(64 * N), lds, m);                    \
+  } while (0)
+  if (h->cNT == 1) CALL_CF2(1);
+  else if (h->cNT == 2) CALL_CF2(2);
+  else CALL_CF2(4);
+#undef CALL_CF2
 }
 
 // loss + dZ chains of the critics (n_units 2: q1c, q2c only -- off iterations of the delayed update) and of
@@ -1368,7 +1432,7 @@ int enqueue_chain_bwd_q(dsact_handle* h, int n_units, const RideArgs* ride) {
     if (w >= 2) { u.w1at = h->pk_w1at[n3]; u.dA = h->dAq[n3]; }
     u.which = w;
   }
-  const int rg = chain_rg(h, n_units);
+  const int rg = chain_rg(h, n_units, true);
   a.n_units = n_units; a.n_slices = h->B / (4 * rg); a.B = h->B; a.A = h->A; a.L = L; a.Cb = h->B / 16;
   for (int i = 0; i < 2; ++i) { a.qout_c[i] = h->qout_c[i]; a.qstd_c[i] = h->qstd_c[i]; a.qout_t[i] = h->qout_t[i]; a.qout_p[i] = h->qout_p[i]; }
   a.rew = h->rew; a.done = h->done; a.logp2 = h->logp2; a.logp_new = h->logp_new; a.z5 = h->z5; a.z6 = h->z6;
@@ -1381,6 +1445,7 @@ int enqueue_chain_bwd_q(dsact_handle* h, int n_units, const RideArgs* ride) {
   a.one_minus_tau_b = (float)(1.0 - h->cfg.tau_b);
   a.n_chain_blocks = chain_grid(n_units, a.n_slices);
   a.timeline = tl_for(h, "chain_bwd_q");
+  if (h->fwd_merge) { a.flags_reset = h->chain_flags; a.n_flags = kChainFlags; }
   if (ride) a.ride = *ride;
   a.ride.n_loss_blocks = a.n_chain_blocks;
   const int n_riders = ride ? ride->n_gather + (ride->bookkeeping ? 1 : 0) : 0;
@@ -1426,8 +1491,12 @@ int enqueue_grads_chain(dsact_handle* h, bool actor_backward, bool fused, int ph
   const int* off = h->dw2_off;
   if (phase == 4) goto actor_part;
   if (phase != 2) {
-    TRY(enqueue_chain_fwd_a(h));
-    TRY(enqueue_chain_fwd_b(h));
+    if (h->fwd_merge) {
+      TRY(enqueue_chain_fwd_merged(h));
+    } else {
+      TRY(enqueue_chain_fwd_a(h));
+      TRY(enqueue_chain_fwd_b(h));
+    }
     if (h->use_std_sums) {
       StdSumArgs s;
       s.qstd_c[0] = h->qstd_c[0]; s.qstd_c[1] = h->qstd_c[1]; s.B = h->B; s.out = h->std_sums;
@@ -1814,7 +1883,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->env_no_merged_gather = getenv("DSACT_NO_MERGED_GATHER") != nullptr;
   if (const char* v = getenv("DSACT_CONV_DW_NKT")) h->env_conv_dw_nkt = atoi(v);
   if (const char* v = getenv("DSACT_RIDE_SLOTS")) h->env_ride_slots = atoi(v);
-  if (const char* v = getenv("DSACT_CHAIN_RG")) h->env_chain_rg = atoi(v) == 1 ? 1 : 2;
+  if (const char* v = getenv("DSACT_CHAIN_RG")) h->env_chain_rg = atoi(v) == 1 ? 1 : atoi(v) == 4 ? 4 : 2;
   h->dw_chunks = (h->B > 448 && h->B % 256 == 0 && getenv("DSACT_NO_SPLITK") == nullptr) ? h->B / 256 : 1;
   h->dw_part_stride = (h->n_online + 2 + 63) & ~(size_t)63;
   {
@@ -1833,6 +1902,10 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     ok = ok && (size_t)chain_lds(4 * (h->s_obs + h->s_act), W0, R).total * sizeof(float) <= 150 * 1024;
     h->chain_ok = ok;
     h->cW = W0; h->cNT = W0 / 64; h->n_slices = h->B / R;
+    h->rg4_ok = ok && h->B % 16 == 0 && getenv("DSACT_NO_RG4") == nullptr &&
+                (size_t)chain_lds(4 * (h->s_obs + h->s_act), W0, 16).total * sizeof(float) <= 150 * 1024;
+    // merged forward launch: both groups resident at once (4-row group-B workgroups: batch <= 256), one flag per slice
+    h->fwd_merge = ok && h->B <= 256 && h->B / 4 <= kChainFlagSlices && chain_rg(h, 4) == 1 && getenv("DSACT_NO_FWD_MERGE") == nullptr;
   }
   Carver c0;
   carve(h, c0);
@@ -1885,22 +1958,37 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, true, EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_conv_dw<3>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<1, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<2, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<4, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<2, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<4, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<false, EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<true, EPI_MULG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
@@ -2607,6 +2695,7 @@ static int enqueue_stats(dsact_handle* h, float* dst) {
   a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.out = dst;
   // a gradient computed here and not yet applied (get_remote_update_info): report the mean_std its loss used
   a.ms_tail = h->have_local_tail && h->cfg.algo == 0 ? h->grads + h->n_online : nullptr;
+  a.spin_timeout = h->chain_flags ? h->chain_flags + kChainFlags : nullptr;
   const bool was_prof = h->profiling;
   h->profiling = false;
   int rc = launch(h, "stats", k_stats, dim3(1), dim3(64), 0, a);

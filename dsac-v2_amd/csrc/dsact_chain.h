@@ -38,7 +38,7 @@ constexpr int kPD = 16;        // weight steps (4 k of a 64-output tile = 1 KB p
 
 // phase stamps of the chain kernels (instrumented builds, -DDSACT_TIMELINE): [block][16] shader-clock values
 #ifdef DSACT_TIMELINE
-#define CTL(buf, k) do { if ((buf) && threadIdx.x == 0 && blockIdx.x < 256) (buf)[blockIdx.x * 16 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define CTL(buf, k) do { if ((buf) && threadIdx.x == 0 && blockIdx.x < 512) (buf)[blockIdx.x * 16 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
 // slots 14 / 15: workgroup begin / end on the chip-wide 100 MHz counter (the cycle counter is per XCD: no skew across them)
 #define CTLR(buf, k) do { if ((buf) && threadIdx.x == 0 && blockIdx.x < 512) (buf)[blockIdx.x * 16 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -386,6 +386,9 @@ struct FwdUnit {
   float* xact; float* xact2;        // policy head: rows whose action columns (at F) receive the sampled action
   float* qout; float* qstd;         // q head: raw (mean, pre-softplus std) [B][2]; (std, d std/d raw) [B][2] or nullptr
   float* part_heads;                // policy head: [slices][2] sums of tanh(mu), sigma; nullptr: none
+  // merged A+B launch (k_chain_fwd2): a producer raises done[slice] when everything it wrote is visible chip-wide; a
+  // consumer waits for wait0/wait1[its first row / wait_rows] before it reads what the producers wrote. nullptr: no flags
+  int* done; const int* wait0; const int* wait1; int wait_rows;
 };
 constexpr int kMaxFwdUnits = 6;
 struct FwdArgs {
@@ -397,13 +400,42 @@ struct FwdArgs {
   int v1_stats;
   const float* act_scale; const float* act_center; float lo_ls, hi_ls;
   long long* timeline;
+  int* spin_timeout;                // merged launch: set to 1 by a consumer that gave up waiting (surfaces as NaN statistics)
 };
 
+// Data handed from a producer to a consumer INSIDE the merged launch (sampled actions, saved first-layer accumulators)
+// is written and read with agent-scope accesses (sc1: through to memory / past the non-coherent cache levels), so
+// neither side needs an L2-wide write-back or invalidate -- a release fence per producer costs an XCD-wide buffer_wbl2
+// (measured: the merged launch ran 46 us with fences, 31 us as two launches).
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// producer side of the merged launch: every wave's stores have been acknowledged (the barrier waits vmcnt(0)), then one
+// thread writes this XCD's L2 back and raises the flag at agent scope
+__device__ __forceinline__ void chain_publish(int* flag) {
+  if (!flag) return;      // workgroup-uniform
+  __syncthreads();        // s_waitcnt vmcnt(0) in every wave: its agent-scope stores have been acknowledged
+  if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// consumer side: thread 0 polls (bounded: a lost flag must not hang the GPU)
+__device__ __forceinline__ void chain_wait(const int* f0, const int* f1, int* timeout) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    for (;;) {
+      const int a0 = f0 ? __hip_atomic_load(f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1;
+      const int a1 = f1 ? __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1;
+      if (a0 && a1) break;
+      if (++spins > (1 << 17)) { if (timeout) *timeout = 1; break; }   // ~0.1 s
+      __builtin_amdgcn_s_sleep(16);
+    }
+  }
+  __syncthreads();        // the consumer's loads of the handed-over data are ld_agent: no cache invalidate needed
+}
+
 template <int NW, int RG>
-__global__ void __launch_bounds__(64 * NW) k_chain_fwd(FwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void chain_fwd_body(const FwdArgs& a, int block, float* lds) {
   int unit, slice;
-  if (!chain_decode((int)blockIdx.x, a.n_units, a.n_slices, unit, slice)) return;
+  if (!chain_decode(block, a.n_units, a.n_slices, unit, slice)) return;
   const FwdUnit& u = a.u[unit];
   constexpr int W = 64 * NW, SH = W / 4, R = 4 * RG, NTHR = 64 * NW, TPR = NTHR / R;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -416,6 +448,7 @@ __global__ void __launch_bounds__(64 * NW) k_chain_fwd(FwdArgs a) {
   const ChainLds S = chain_lds(4 * (a.s_obs + a.s_act), W, R);
   const int xin = S.off_in, red = S.off_red;
   CTL(a.timeline, 0);
+  CTLR(a.timeline, 14);
   // ---- the weight stream starts before anything else
   const bool do_obs = u.seg != SEG_ACT_FROM_SAVED;
   const bool do_act = u.seg != SEG_OBS_ONLY && u.s_act > 0;
@@ -445,12 +478,17 @@ __global__ void __launch_bounds__(64 * NW) k_chain_fwd(FwdArgs a) {
   } else if (u.head == HEAD_Q && jr == 0) {
     pre_bmu[0] = u.bias[L][0]; pre_braw[0] = u.bias[L][1];
   }
+  // merged launch: the weight stream and the loads above are already in flight while this waits for its producers
+  if (u.wait0 || u.wait1) {
+    const int ps = row0 / u.wait_rows;
+    chain_wait(u.wait0 ? u.wait0 + ps : nullptr, u.wait1 ? u.wait1 + ps : nullptr, a.spin_timeout);
+  }
   f32x4 zi[RG];
   if (u.seg == SEG_ACT_FROM_SAVED) {
 #pragma unroll
     for (int g = 0; g < RG; ++g)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) zi[g][r] = u.zinit[(size_t)(row0 + 4 * g + r) * W + n];
+      for (int r = 0; r < 4; ++r) zi[g][r] = ld_agent(u.zinit + (size_t)(row0 + 4 * g + r) * W + n);
   }
   // ---- stage the input rows: xin[r][k'] (observation part, zero padding to 4*s_obs, action part, zero padding).
   //      Four independent loads per thread and trip, stores after (a load -> wait -> store loop is one round trip per trip)
@@ -488,7 +526,7 @@ __global__ void __launch_bounds__(64 * NW) k_chain_fwd(FwdArgs a) {
         const int r = e / aq, k = (e % aq) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const float* s = u.x + (size_t)(row0 + r) * a.ldx + F + k;
-        for (int c = 0; c < 4; ++c) if (k + c < A) v[c] = s[c];
+        for (int c = 0; c < 4; ++c) if (k + c < A) v[c] = ld_agent(s + c);
         *(f32x4*)(lds + xin + r * S.ld_in + Fp + k) = v;
       }
     }
@@ -526,11 +564,11 @@ __global__ void __launch_bounds__(64 * NW) k_chain_fwd(FwdArgs a) {
       for (int g = 0; g < RG; ++g) {
         const f32x4 v = acc[g][0] + acc[g][1];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) u.zsave[(size_t)(row0 + 4 * g + r) * W + n] = v[r];
+        for (int r = 0; r < 4; ++r) st_agent(u.zsave + (size_t)(row0 + 4 * g + r) * W + n, v[r]);
       }
     }
     CTL(a.timeline, 2);
-    if (u.seg == SEG_OBS_ONLY) return;
+    if (u.seg == SEG_OBS_ONLY) { CTLR(a.timeline, 15); chain_publish(u.done ? u.done + slice : nullptr); return; }
   }
   if (do_act) gemm44_seg<RG>(ws, w0, a.s_obs, S0, w1, 0, more, lds, xs_in, S.ld_in, lane4, acc);
   CTL(a.timeline, 3);
@@ -562,7 +600,7 @@ __global__ void __launch_bounds__(64 * NW) k_chain_fwd(FwdArgs a) {
       CTL(a.timeline, 5 + 2 * l);
     }
   }
-  if (u.head == HEAD_NONE) return;
+  if (u.head == HEAD_NONE) { CTLR(a.timeline, 15); chain_publish(u.done ? u.done + slice : nullptr); return; }
   // ---- output layer: 16x16x4 tiles, contraction split over the waves, partials through LDS
   const int hl = ((L - 1) & 1) ? S.off_h1 : S.off_h0;
   narrow_mma<4>(hf, nto, wave, lds, hl + ((lane & 15) & (R - 1)) * S.ld_h + 4 * (lane >> 4), red, lane);
@@ -578,6 +616,8 @@ __global__ void __launch_bounds__(64 * NW) k_chain_fwd(FwdArgs a) {
       if (u.qstd) { u.qstd[2 * r] = softplus(raw); u.qstd[2 * r + 1] = softplus_grad(raw); }
     }
     CTL(a.timeline, 13);
+    CTLR(a.timeline, 15);
+    chain_publish(u.done ? u.done + slice : nullptr);
     return;
   }
   // policy: (mu, raw log-std) -> tanh-Gaussian rsample (act_distribution_cls.py:44-54)
@@ -590,8 +630,8 @@ __global__ void __launch_bounds__(64 * NW) k_chain_fwd(FwdArgs a) {
     const float raw = narrow_get<4, NW>(lds, red, m, A + d) + pre_braw[q];
     const TanhGaussFwd f = tanh_gauss_fwd(mu, raw, pre_eps[q], pre_s[q], pre_c[q], a.lo_ls, a.hi_ls);
     lp += f.lp;
-    u.xact[(size_t)r * a.ldx + F + d] = f.a;
-    if (u.xact2) u.xact2[(size_t)r * a.ldx + F + d] = f.a;
+    st_agent(u.xact + (size_t)r * a.ldx + F + d, f.a);
+    if (u.xact2) st_agent(u.xact2 + (size_t)r * a.ldx + F + d, f.a);
     u.logits[(size_t)r * 2 * A + d] = mu;
     u.logits[(size_t)r * 2 * A + A + d] = raw;
     if (!a.v1_stats) { s_tanh += tanhf(mu); s_sig += f.sigma; }
@@ -615,6 +655,27 @@ __global__ void __launch_bounds__(64 * NW) k_chain_fwd(FwdArgs a) {
       u.part_heads[2 * slice + 1] = t1;
     }
   }
+  CTLR(a.timeline, 15);
+  chain_publish(u.done ? u.done + slice : nullptr);
+}
+
+template <int NW, int RG>
+__global__ void __launch_bounds__(64 * NW, RG >= 4 ? 1 : 2) k_chain_fwd(FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  chain_fwd_body<NW, RG>(a, (int)blockIdx.x, lds);
+}
+
+// Launches A and B in one: blocks [0, n_a) run group A with RGA row groups, blocks [n_a, ..) group B with RGB. Every
+// group-A block has a lower id than any group-B block, so the dispatcher places all producers before any consumer, and
+// producers never wait: the bounded spins of the consumers cannot deadlock. A consumer's weight stream is in flight
+// while it waits; it starts the moment ITS slice's producers are done instead of after the whole of launch A plus a
+// kernel boundary.
+struct Fwd2Args { FwdArgs A, B; int n_a; };
+template <int NW, int RGA, int RGB>
+__global__ void __launch_bounds__(64 * NW, 2) k_chain_fwd2(Fwd2Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if ((int)blockIdx.x < a.n_a) chain_fwd_body<NW, RGA>(a.A, (int)blockIdx.x, lds);
+  else chain_fwd_body<NW, RGB>(a.B, (int)blockIdx.x - a.n_a, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -644,12 +705,15 @@ struct BwdQArgs {
   int n_chain_blocks;
   long long* timeline;
   RideArgs ride;
+  int* flags_reset; int n_flags;   // the merged forward launch's ready flags: cleared here, after it and before the next one
 };
 
 template <int NW, int RG>
 __global__ void __launch_bounds__(256) k_chain_bwd_q(BwdQArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if ((int)blockIdx.x >= a.n_chain_blocks) { loss_rider(a.ride); return; }   // riders are 256-thread blocks
+  if (a.flags_reset && threadIdx.x == 0)
+    for (int i = (int)blockIdx.x; i < a.n_flags; i += a.n_chain_blocks) a.flags_reset[i] = 0;
   int unit, slice;
   if (!chain_decode((int)blockIdx.x, a.n_units, a.n_slices, unit, slice)) return;
   constexpr int W = 64 * NW, SH = W / 4, R = 4 * RG, NTHR = 64 * NW, TPR = NTHR / R;

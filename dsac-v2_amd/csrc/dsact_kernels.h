@@ -1803,6 +1803,7 @@ struct StatsArgs {
   const float* log_alpha; const DevState* st; float inv_B; float inv_BA; int auto_alpha; float alpha_fixed;
   float* out;  // [16]
   const float* ms_tail;   // nullptr, or mean_std1/2 of the gradient that is pending (not yet committed to DevState)
+  const int* spin_timeout;   // merged forward launch: a consumer gave up waiting for its producers -> every statistic reads NaN
 };
 __global__ void k_stats(StatsArgs a) {
   const int lane = threadIdx.x;
@@ -1828,6 +1829,8 @@ __global__ void k_stats(StatsArgs a) {
     o[11] = s[8];
     o[12] = a.ms_tail ? a.ms_tail[0] : a.st->ms1; o[13] = a.ms_tail ? a.ms_tail[1] : a.st->ms2;
     o[14] = (float)a.st->it_cur; o[15] = 0.f;
+    if (a.spin_timeout && *a.spin_timeout)
+      for (int k = 0; k < 14; ++k) o[k] = NAN;
   }
 }
 
