@@ -683,7 +683,7 @@ def main():
             "global_batch": args.batch * world, "parallelism": "dp%d" % world, "hidden": hidden,
             "noise": "device Philox4x32-10", "mode": "fast (discarded actor backward skipped)" if args.fast else "strict (every gradient the reference computes)",
             "launch": dp_mode if use_dp else "hipGraph (%d steps/graph; the next update's gather rides in the loss launch)" % gs,
-            "kernels": "row-slice fused chains + transposed-operand weight-gradient tiles (5 launches/update)" if chain else "per-layer tile stages",
+            "kernels": ("row-slice fused chains + transposed-operand weight-gradient tiles (%d launches/update)" % (4 if Bb <= 256 else 5)) if chain else "per-layer tile stages",
             "timing": "median of %d timed regions of exactly %d steps (each bracketed by barrier + device sync; max over ranks)" % (len(regions), steps),
             "replay_fill": "torch device generator, the distributions of SURVEY.md 8(d) (a host np.random.default_rng(0) fill would push "
                            "3 GB through PCIe); indices: np.random.seed(1 + rank) + np.random.randint, a %d-row table cycled" % IDX_ROWS,

@@ -28,13 +28,16 @@ rt = full[(full[:,14] != 0) & (full[:,15] != 0)]
 if len(rt):
     # chip-wide 100 MHz stamps (slots 14/15): chain workgroups have cycle stamps too, riders only these
     t00 = rt[:,14].min()
-    for nm, sel in (("chain workgroups", rt[:,0] != 0), ("rider tiles", rt[:,0] == 0)):
+    # merged forward launch: group-B workgroups are the ones whose first cycle stamp after 0 is 1 then 3 (no stamp 2)
+    isB = (rt[:,0] != 0) & (rt[:,2] == 0) & (rt[:,3] != 0)
+    groups_rt = (("chain workgroups", (rt[:,0] != 0) & ~isB), ("group-B chain workgroups (merged launch)", isB), ("rider tiles", rt[:,0] == 0))
+    for nm, sel in groups_rt:
         g = rt[sel]
         if len(g):
             b, en = (g[:,14]-t00)/100.0, (g[:,15]-t00)/100.0
             print("  realtime, %d %s: begin median %.2f max %.2f us; end median %.2f p90 %.2f max %.2f us; duration median %.2f max %.2f us"
                   % (len(g), nm, np.median(b), b.max(), np.median(en), np.percentile(en, 90), en.max(), np.median(en-b), (en-b).max()))
-raw = full[:256].copy()
+raw = full[:512].copy()
 raw[:,14:] = 0
 raw = raw[raw[:,0] != 0]
 print("stage %s: %d workgroups stamped" % (os.environ["STAGE"], len(raw)))
