@@ -90,7 +90,8 @@ class LazyTbInfoV1(_v2.LazyTbInfo):
                 v *= A   # the kernel normalises by B*A; DSAC_V1 reports ONE logits element averaged over B
             dict.__setitem__(self, k, v)
         t = dict.pop(self, ALG_TIME_KEY)
-        dict.__setitem__(self, ALG_TIME_KEY, t)
+        dev = stats.get("_device_ms", -1.0)
+        dict.__setitem__(self, ALG_TIME_KEY, dev if dev >= 0.0 and dev > t else t)
         self._done = True
 
     def __contains__(self, k):

@@ -379,7 +379,10 @@ class LazyTbInfo(dict):
                 v = torch.tensor(v)  # 0-dim tensors in the reference (dsac_v2.py:201-202)
             dict.__setitem__(self, k, v)
         t = dict.pop(self, ALG_TIME_KEY)
-        dict.__setitem__(self, ALG_TIME_KEY, t)  # keep the reference's key order (time last)
+        # the reference times a synchronous CPU update; here the call returns after the enqueue, so once the statistics
+        # are fetched (the sync has been paid) the update's own device time replaces the enqueue time when it is known
+        dev = stats.get("_device_ms", -1.0)
+        dict.__setitem__(self, ALG_TIME_KEY, dev if dev >= 0.0 and dev > t else t)  # key order of the reference (time last)
         self._done = True
 
     def __getitem__(self, k):

@@ -361,6 +361,7 @@ class DsactEngine:
             self._chk(self._lib.dsact_stats_read(self._h, int(slot) % self.STATS_SLOTS, out))
         d = {k: float(out[i]) for i, k in enumerate(STAT_KEYS)}
         d["_iteration"] = float(out[14])
+        d["_device_ms"] = float(out[15]) if slot is None else -1.0   # stream time of the last eager update (-1: unknown)
         return d
 
     # ---- measurement ------------------------------------------------------------------------------------

@@ -114,24 +114,28 @@ class HipEvaluator:
         from plugin import create_env
 
         self.env = kwargs.get("eval_env") or kwargs.get("env") or create_env(**kwargs)
+        if kwargs.get("seed") is not None and hasattr(self.env, "seed"):
+            self.env.seed(kwargs["seed"])  # reference evaluator.py:15: set_seed(..., env) seeds with the plain seed
         self.networks = kwargs.get("networks")
         self.num_eval_episode = kwargs.get("num_eval_episode", 5)
 
     def run_an_episode(self):
         out = self.env.reset()
         obs = out[0] if isinstance(out, tuple) else out
-        total, done = 0.0, False
+        rewards, done = [], False
         while not done:
             with torch.no_grad():
                 logits = self.networks.policy(torch.from_numpy(obs.astype("float32")[None]))
                 act = self.networks.create_action_distributions(logits).mode()[0].cpu().numpy()
             obs, r, done, info = self.env.step(act)
-            total += float(r)
+            rewards.append(r)
             done = bool(done) or bool(info.get("TimeLimit.truncated", False))
-        return total
+        return sum(rewards)   # the reference's own reduction (evaluator.py:71): same value to the last bit
 
     def run_evaluation(self, iteration):
-        return sum(self.run_an_episode() for _ in range(self.num_eval_episode)) / self.num_eval_episode
+        import numpy as np
+
+        return np.mean([self.run_an_episode() for _ in range(self.num_eval_episode)])   # evaluator.py:74-78
 
 
 class HipOffSerialTrainer:

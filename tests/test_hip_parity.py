@@ -1076,3 +1076,50 @@ def test_attached_container_survives_the_reference_device_ping_pong():
     nets.load_state_dict(sd_cpu)
     assert [p.data_ptr() for p in nets.parameters()] == ptr0
     assert torch.equal(act_logits(), after)
+
+
+@pytest.mark.parametrize("O,A,hid,B", [(376, 17, (256, 256, 256), 256), (24, 6, (128, 128), 64), (12, 3, (64, 64), 16)])
+def test_merged_forward_launch_equals_two_launches(O, A, hid, B, monkeypatch):
+    """k_chain_fwd2 (forward groups A and B in one launch, group B waiting on per-slice ready flags) == the two
+    launches it replaces (DSACT_NO_FWD_MERGE=1), bit for bit over 6 updates -- eager steps and a graph replay; and the
+    spin-timeout word stays clear (statistics finite)."""
+    algs = []
+    for merged in (True, False):
+        if merged:
+            monkeypatch.delenv("DSACT_NO_FWD_MERGE", raising=False)
+        else:
+            monkeypatch.setenv("DSACT_NO_FWD_MERGE", "1")
+        alg, _ = make_pair(O, A, hid, B, seed=21)
+        assert alg.engine.chain_active
+        algs.append(alg)
+    monkeypatch.delenv("DSACT_NO_FWD_MERGE", raising=False)
+    rng = np.random.default_rng(12)
+    for it in range(3):
+        data = synth_batch(rng, B, O, A, p_done=0.1)
+        torch.manual_seed(300 + it)
+        noise = draw_noise(B, A)
+        for a in algs:
+            a.engine.load_batch(*(data[k].numpy() for k in ("obs", "act", "rew", "obs2", "done")))
+            a.engine.set_noise(noise["eps_new"].numpy(), noise["eps_2"].numpy(), noise["z5"].numpy(), noise["z6"].numpy())
+            a.engine.step(it)
+    N = 2048
+    for a in algs:
+        e = a.engine
+        e.set_device_rng(99)
+        e.buffer_create(N)
+        g = torch.Generator(device="cuda").manual_seed(4)
+        e.buffer_fill_device(0, torch.randn(N, O, device="cuda", generator=g), torch.rand(N, A, device="cuda", generator=g) - .5,
+                             torch.randn(N, device="cuda", generator=g), torch.randn(N, O, device="cuda", generator=g),
+                             (torch.rand(N, device="cuda", generator=g) < .05).float())
+        np.random.seed(2)
+        e.upload_index_table(np.random.randint(0, N, size=(4, B)))
+        e.graph_build(3)
+        e.graph_run(3, 3)
+        e.sync()
+    for name in ("online", "target", "adam_m", "adam_v"):
+        assert torch.equal(getattr(algs[0].engine, name), getattr(algs[1].engine, name)), name
+    st0, st1 = algs[0].engine.read_stats(), algs[1].engine.read_stats()
+    assert st0 == st1 and all(np.isfinite(v) for v in st0.values())
+    names = [[k for k, _, _ in a.engine.profile_step(6)] for a in algs]
+    assert "chain_fwd" in names[0] and "chain_fwd_a" not in names[0]
+    assert "chain_fwd_a" in names[1] and "chain_fwd_b" in names[1] and "chain_fwd" not in names[1]

@@ -167,3 +167,26 @@ def test_csv_export_equals_the_reference_export(ref, tmp_path):
     assert "Time_Algorithm time [ms]-RL iter.csv" in names and "Evaluation_2. TAR-Total time [s].csv" in names
     for n in names:
         assert (ours / "data" / n).read_bytes() == (theirs / "data" / n).read_bytes(), n
+
+
+def test_reference_evaluator_with_hip_container_equals_hip_evaluator(ref, tmp_path):
+    """f3: the reference `Evaluator(algorithm="DSAC_V2_HIP")` (training/evaluator.py:9-84: mode() actions, episode
+    return = sum of rewards, mean over num_eval_episode) against `HipEvaluator` on the same seeded environment and the
+    same weights: identical evaluation returns, episode after episode."""
+    import training.evaluator as ref_eval_mod
+    from training.hip_trainer import HipEvaluator
+    from utils.initialization import create_env as ref_create_env
+    import dsac_v2_hip
+
+    kw = sampler_kwargs(num_eval_episode=3, is_render=False, save_folder=str(tmp_path), eval_save=False, max_episode_steps=40)
+    torch.manual_seed(9)
+    ref_e = ref_eval_mod.Evaluator(**dict(kw))
+    assert type(ref_e.networks) is dsac_v2_hip.ApproxContainer
+    env = ref_create_env(**dict(kw, reward_scale=None, repeat_num=None))     # what the reference evaluator builds (:12-14)
+    hip_e = HipEvaluator(eval_env=env, **kw)
+    hip_e.networks = dsac_v2_hip.ApproxContainer(**kw)
+    hip_e.networks.load_state_dict(ref_e.networks.state_dict())
+    for it in range(3):
+        a, b = ref_e.run_evaluation(it), hip_e.run_evaluation(it)
+        assert float(a) == float(b) and np.isfinite(a), (it, a, b)
+        assert abs(float(a)) > 1.0          # a real return, not an empty episode
