@@ -608,6 +608,7 @@ int build_pack_jobs(dsact_handle* h) {
       j.m = mir[(size_t)n3 * (L + 1) + l];
       if (target) { j.m.fwd = j.m.fwd_t; j.m.bwd = nullptr; }
       j.m.fwd_t = nullptr;
+      j.is_target = target ? 1 : 0;
       blocks += (j.N + 15) / 16;
       j.block_end = blocks;
       jobs.push_back(j);
@@ -621,9 +622,12 @@ int build_pack_jobs(dsact_handle* h) {
   return DSACT_OK;
 }
 
-int enqueue_pack(dsact_handle* h) {
+// after_update: the pack follows this update's optimiser pass (data-parallel graph) -- the target nets' copies are
+// rebuilt only on delayed-update steps; otherwise (start of an eager step: anything may have written the arenas) all
+int enqueue_pack(dsact_handle* h, bool after_update = false) {
   PackArgs a;
   a.jobs = h->d_pack; a.n_jobs = h->n_pack_jobs;
+  a.targets_if = after_update ? &h->st->do_delayed : nullptr;
   return launch(h, "pack", k_pack, dim3(h->pack_blocks), dim3(kThreads), 0, a);
 }
 
@@ -2506,7 +2510,16 @@ static int capture_updates(dsact_handle* h, int n, uint32_t flags, bool merged, 
       ride.bookkeeping = 1;
       select_set(h, set);
       const bool actor = !(flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) || (s % h->cfg.delay_update) == 0;
-      rc = enqueue_grads(h, actor, true, 0, &ride);
+      if (flags & DSACT_F_DATA_PARALLEL) {
+        // local gradients (the next update's gather and this one's bookkeeping ride in the loss launch as on the single-GPU
+        // path) -> all-reduce -> streaming Adam/Polyak -> packed weight copies rebuilt for the next forward
+        rc = enqueue_grads(h, true, false, 0, &ride);
+        if (rc == DSACT_OK) rc = enqueue_allreduce(h, h->grads, h->n_online + 2, kNcclAvg);
+        if (rc == DSACT_OK) rc = enqueue_adam(h);
+        if (rc == DSACT_OK) rc = enqueue_pack(h, true);
+      } else {
+        rc = enqueue_grads(h, actor, true, 0, &ride);
+      }
     }
     select_set(h, 0);
     h->mirror_w0 = false;
@@ -2532,8 +2545,9 @@ int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) 
   // of the padded first-layer copies is done by the weight-gradient tiles themselves (FusedOpt::mir_*).
   // Update s of n uses set (n-1-s)&1, so the last staged minibatch sits in set 0 like after eager updates.
   if ((flags & DSACT_F_DATA_PARALLEL) && !h->comm) return fail(h, DSACT_E_STATE, "DSACT_F_DATA_PARALLEL needs dsact_comm_init");
+  // (data parallel: only on the chain path, whose packed copies k_pack can rebuild after the streaming optimiser)
   const bool merged = !h->cnn && h->use_w1p && h->dw_chunks == 1 && !h->use_fork && !h->use_std_sums && h->alt_ws != nullptr &&
-                      !h->env_no_merged_gather && !(flags & DSACT_F_DATA_PARALLEL);
+                      !h->env_no_merged_gather && (!(flags & DSACT_F_DATA_PARALLEL) || h->chain_ok);
   h->merged_graph = merged;
   const bool was_prof = h->profiling;
   h->profiling = false;

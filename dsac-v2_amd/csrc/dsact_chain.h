@@ -316,8 +316,12 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds) {
           if (o_delayed) { ot[e] = polyak_update(a.fo.target[oi + e], pe, a.fo.polyak, a.fo.one_minus_polyak); a.fo.target[oi + e] = ot[e]; }
         }
       }
-      if (P.mir) mirror_store4(*P.mir, m, n, P.N, op, o_delayed, ot);
     }
+  }
+  // the packed copies; every lane takes part (the transposed copy is assembled across lane quads with DPP)
+  if (fused && o_upd && P.mir) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    mirror_store4_quad(*P.mir, m, n, P.N, P.M, in_range, in_range ? op : zero, o_delayed, ot, lane);
   }
   // ---- bias gradient of rows m0 .. m0+31: sum of the 4 waves' x 4 lane groups' row sums
   if (bias && tid < 32) {

@@ -109,30 +109,79 @@ __device__ __forceinline__ void mirror_store4(const MirrorDesc& m, int n, int k,
   }
 }
 
+// 4x4 transpose inside a lane quad: lane j (= lane & 3) of the quad holds v_j; returns (v_0[j], v_1[j], v_2[j], v_3[j]).
+template <int CTRL>
+__device__ __forceinline__ float quad_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float sel4(const f32x4& v, int i) { return i == 0 ? v[0] : i == 1 ? v[1] : i == 2 ? v[2] : v[3]; }
+__device__ __forceinline__ f32x4 quad_transpose(const f32x4& v, int q /* lane & 3 */) {
+  // rotation r: lane j reads from lane c = (j + r) & 3 the component c exposes for it, v_c[(c - r) & 3] = v_c[j]
+  const float t0 = sel4(v, q);
+  const float t1 = quad_mov<0x39>(sel4(v, (q - 1) & 3));   // quad_perm [1,2,3,0]
+  const float t2 = quad_mov<0x4E>(sel4(v, (q - 2) & 3));   // quad_perm [2,3,0,1]
+  const float t3 = quad_mov<0x93>(sel4(v, (q - 3) & 3));   // quad_perm [3,0,1,2]
+  f32x4 o;   // t_r belongs at component (q + r) & 3
+  o[0] = q == 0 ? t0 : q == 3 ? t1 : q == 2 ? t2 : t3;
+  o[1] = q == 1 ? t0 : q == 0 ? t1 : q == 3 ? t2 : t3;
+  o[2] = q == 2 ? t0 : q == 1 ? t1 : q == 0 ? t2 : t3;
+  o[3] = q == 3 ? t0 : q == 2 ? t1 : q == 1 ? t2 : t3;
+  return o;
+}
+// mirror_store4 for callers whose lane quads hold 4 CONSECUTIVE rows n (n % 4 == lane % 4) at the same k: the transposed
+// copy gets one 16-byte store per lane (row k + lane%4 of W^T, columns n&~3 .. +3) instead of four scattered 4-byte ones.
+// Every lane of the quad must call it (DPP); `valid`: this lane's row exists (v must be zero otherwise).
+__device__ __forceinline__ void mirror_store4_quad(const MirrorDesc& m, int n, int k, int K, int N, bool valid, const f32x4& v,
+                                                   bool target, const f32x4& vt, int lane) {
+  if (m.fwd && valid) {
+    const int kk = k < m.F ? k : m.Fp + (k - m.F);
+    const size_t o = m.fwd_44 ? pk44_index(n, kk, m.fwd_C) : pk_index(n, kk, m.fwd_C);
+    if (k + 3 < K) {
+      *(f32x4*)(m.fwd + o) = v;
+      if (target && m.fwd_t) *(f32x4*)(m.fwd_t + o) = vt;
+    } else {
+      for (int e = 0; e < 4 && k + e < K; ++e) { m.fwd[o + e] = v[e]; if (target && m.fwd_t) m.fwd_t[o + e] = vt[e]; }
+    }
+  }
+  if (m.bwd) {
+    const int q = lane & 3;
+    const f32x4 t = quad_transpose(v, q);
+    const int kr = k + q, r = kr - m.bwd_k0, n4 = n & ~3;
+    if (r >= 0 && kr < K && n4 < N) *(f32x4*)(m.bwd + (m.bwd_44 ? pk44_index(r, n4, m.bwd_C) : pk_index(r, n4, m.bwd_C))) = t;
+  }
+}
+
 // ---- k_pack: rebuild every packed copy from the arenas (eager flows, start of a graph launch, external writes) ----
 struct PackJob {
   const float* src; int N, K;   // row-major source (arena)
   MirrorDesc m;                 // destinations (fwd_t unused: the target nets are jobs of their own)
   int block_end;                // exclusive end of this job's block range (one block per 16 source rows)
+  int is_target;                // a target net: unchanged on the off iterations of the delayed update
 };
-__device__ __forceinline__ void pack_block(const PackJob* jobs, int n_jobs, int b, int tid) {
+// targets_if: nullptr, or DevState::do_delayed -- skip the target nets' jobs when the update in flight left them alone
+__device__ __forceinline__ void pack_block(const PackJob* jobs, int n_jobs, int b, int tid, const int* targets_if = nullptr) {
   int ji = 0;
   for (int q = 0; q + 1 < n_jobs; ++q) if (b >= jobs[q].block_end) ji = q + 1;
   const PackJob J = jobs[ji];
+  if (J.is_target && targets_if && !*targets_if) return;
   const int n0 = (b - (ji ? jobs[ji - 1].block_end : 0)) * 16;
   const int kq = (J.K + 3) >> 2;
-  for (int e = tid; e < 16 * kq; e += 256) {
-    const int n = n0 + e / kq, k = (e % kq) * 4;
-    if (n >= J.N) continue;
+  // 16 consecutive lanes = the block's 16 rows at one k group: a lane quad holds 4 consecutive rows (mirror_store4_quad)
+  for (int e0 = 0; e0 < 16 * kq; e0 += 256) {
+    const int e = e0 + tid;
+    const int n = n0 + (e & 15), k = (e >> 4) * 4;
+    const bool valid = e < 16 * kq && n < J.N;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    const float* s = J.src + (size_t)n * J.K + k;
-    if (k + 3 < J.K) v = *(const f32x4u*)s;
-    else for (int c = 0; c < 4 && k + c < J.K; ++c) v[c] = s[c];
-    mirror_store4(J.m, n, k, J.K, v, false, v);
+    if (valid) {
+      const float* s = J.src + (size_t)n * J.K + k;
+      if (k + 3 < J.K) v = *(const f32x4u*)s;
+      else for (int c = 0; c < 4 && k + c < J.K; ++c) v[c] = s[c];
+    }
+    mirror_store4_quad(J.m, n, e < 16 * kq ? k : J.K, J.K, J.N, valid, v, false, v, tid);
   }
 }
-struct PackArgs { const PackJob* jobs; int n_jobs; };
-__global__ void __launch_bounds__(256) k_pack(PackArgs a) { pack_block(a.jobs, a.n_jobs, (int)blockIdx.x, threadIdx.x); }
+struct PackArgs { const PackJob* jobs; int n_jobs; const int* targets_if; };
+__global__ void __launch_bounds__(256) k_pack(PackArgs a) { pack_block(a.jobs, a.n_jobs, (int)blockIdx.x, threadIdx.x, a.targets_if); }
 
 constexpr int kWave = 64;
 constexpr int kThreads = 256;  // 4 waves, one per SIMD
