@@ -33,7 +33,10 @@
 namespace dsact {
 
 constexpr int kChMaxL = 4;     // == DSACT_MAX_HIDDEN_LAYERS
-constexpr int kPD = 16;        // weight steps (4 k of a 64-output tile = 1 KB per wave-load) in flight per wave; every
+#ifndef DSACT_KPD
+#define DSACT_KPD 16
+#endif
+constexpr int kPD = DSACT_KPD;        // weight steps (4 k of a 64-output tile = 1 KB per wave-load) in flight per wave; every
                                // stream segment is a multiple of kPD steps (64 k) long
 
 // phase stamps of the chain kernels (instrumented builds, -DDSACT_TIMELINE): [block][16] shader-clock values
