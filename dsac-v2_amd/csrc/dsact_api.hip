@@ -2109,6 +2109,11 @@ int dsact_get_state(dsact_handle* h, int32_t adam_steps[3], float mean_std[2]) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   DevState st;
   HIPCHK(h, hipMemcpy(&st, h->st, sizeof(st), hipMemcpyDeviceToHost));
+  if (h->chain_flags) {   // merged forward launch: a consumer that gave up waiting leaves this word set (statistics read NaN too)
+    int timed_out = 0;
+    HIPCHK(h, hipMemcpy(&timed_out, h->chain_flags + kChainFlags, sizeof(int), hipMemcpyDeviceToHost));
+    if (timed_out) return fail(h, DSACT_E_HIP, "a forward workgroup timed out waiting for its producers' ready flags (results are invalid)");
+  }
   if (adam_steps) { adam_steps[0] = st.t_q; adam_steps[1] = st.t_pi; adam_steps[2] = st.t_alpha; }
   if (mean_std) { mean_std[0] = st.ms_init ? st.ms1 : -1.0f; mean_std[1] = st.ms_init ? st.ms2 : -1.0f; }
   return DSACT_OK;
