@@ -154,7 +154,7 @@ struct dsact_handle {
   // environment switches, read once at dsact_create (getenv walks the whole environment: ~20 calls per eager update
   // were host time on the launch path)
   std::string env_timeline_stage;   // DSACT_TIMELINE_STAGE
-  bool env_no_tile64 = false, env_no_hb_ride = false, env_no_merged_gather = false;
+  bool env_no_tile64 = false, env_no_hb_ride = false, env_no_merged_gather = false, env_no_adam_pack = false;
   int env_conv_dw_nkt = 1;
   int env_ride_slots = 0;           // DSACT_RIDE_SLOTS: weight-gradient tiles riding in the policy-backward launch (default: one round)
   bool mirror_w0 = false;      // set while the merged-gather graph is being captured (see FusedOpt::mir_*)
@@ -203,6 +203,8 @@ struct dsact_handle {
   float* pk_w1at[2];                    // q1, q2: (W0[:, F:])^T
   MirrorDesc* d_mir = nullptr;          // [3 nets][L+1]: what the Adam tiles of each weight tensor refresh
   PackJob* d_pack = nullptr; int n_pack_jobs = 0, pack_blocks = 0;
+  AdamPackJob* d_apjobs = nullptr;      // k_adam_pack job table (data-parallel graph)
+  int n_apjobs = 0, ap_blocks = 0;
   int* chain_flags = nullptr;           // ready flags of the merged forward launch + timeout word at [kChainFlags]
   bool fwd_merge = false;               // launches A and B as one (batch <= 256)
   float* zobs[4];                       // first-layer accumulators after the observation part: q1, q2 (obs), q1_t, q2_t (obs2)
@@ -629,6 +631,46 @@ int enqueue_pack(dsact_handle* h, bool after_update = false) {
   a.jobs = h->d_pack; a.n_jobs = h->n_pack_jobs;
   a.targets_if = after_update ? &h->st->do_delayed : nullptr;
   return launch(h, "pack", k_pack, dim3(h->pack_blocks), dim3(kThreads), 0, a);
+}
+
+// job table of k_adam_pack: the weight tensors of the online nets in arena order, 16 rows x 256 columns per block
+int build_adam_pack_jobs(dsact_handle* h) {
+  const int L = h->L;
+  const int chs[3] = {C_Q1C, C_Q2C, C_PI};
+  std::vector<AdamPackJob> jobs;
+  int blocks = 0;
+  for (int n3 = 0; n3 < 3; ++n3) {
+    const int net = kChainNet[chs[n3]];
+    const NetDesc& d = net_desc(h, net);
+    const long long base = (long long)(net_grads(h, net) - h->grads);
+    for (int l = 0; l <= L; ++l) {
+      AdamPackJob j;
+      memset(&j, 0, sizeof(j));
+      j.w_idx = base + (long long)d.w_off[l]; j.b_idx = base + (long long)d.b_off[l];
+      j.N = d.out[l]; j.K = d.in[l]; j.col_chunks = (j.K + 255) / 256;
+      j.mir = h->d_mir ? h->d_mir + (size_t)n3 * (L + 1) + l : nullptr;
+      blocks += ((j.N + 15) / 16) * j.col_chunks;
+      j.block_end = blocks;
+      jobs.push_back(j);
+    }
+  }
+  if (h->d_apjobs) { hipFree(h->d_apjobs); h->d_apjobs = nullptr; }
+  HIPCHK(h, hipMalloc((void**)&h->d_apjobs, jobs.size() * sizeof(AdamPackJob)));
+  HIPCHK(h, hipMemcpy(h->d_apjobs, jobs.data(), jobs.size() * sizeof(AdamPackJob), hipMemcpyHostToDevice));
+  h->n_apjobs = (int)jobs.size();
+  h->ap_blocks = blocks;
+  return DSACT_OK;
+}
+
+FusedOpt fused_opt(const dsact_handle* h, bool enable);
+
+// Adam / Polyak on the (averaged) gradient arena + the packed copies, one pass; the extra block closes the update
+int enqueue_adam_pack(dsact_handle* h) {
+  AdamPackArgs a;
+  a.jobs = h->d_apjobs; a.n_jobs = h->n_apjobs; a.n_blocks = h->ap_blocks;
+  a.fo = fused_opt(h, true);
+  h->have_local_tail = false;   // finalize_update commits the tail (the data-parallel graph always computed it here)
+  return launch(h, "adam_pack", k_adam_pack, dim3(h->ap_blocks + 1), dim3(kThreads), 0, a);
 }
 
 int build_tasks(dsact_handle* h) {
@@ -1885,6 +1927,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->env_no_tile64 = getenv("DSACT_NO_TILE64") != nullptr;
   h->env_no_hb_ride = getenv("DSACT_NO_HB_RIDE") != nullptr;
   h->env_no_merged_gather = getenv("DSACT_NO_MERGED_GATHER") != nullptr;
+  h->env_no_adam_pack = getenv("DSACT_NO_ADAM_PACK") != nullptr;
   if (const char* v = getenv("DSACT_CONV_DW_NKT")) h->env_conv_dw_nkt = atoi(v);
   if (const char* v = getenv("DSACT_RIDE_SLOTS")) h->env_ride_slots = atoi(v);
   if (const char* v = getenv("DSACT_CHAIN_RG")) h->env_chain_rg = atoi(v) == 1 ? 1 : atoi(v) == 4 ? 4 : 2;
@@ -2022,6 +2065,7 @@ int dsact_destroy(dsact_handle* h) {
   if (h->alt_ws) hipFree(h->alt_ws);
   if (h->pk_ws) hipFree(h->pk_ws);
   if (h->d_mir) hipFree(h->d_mir);
+  if (h->d_apjobs) hipFree(h->d_apjobs);
   if (h->d_pack) hipFree(h->d_pack);
   if (h->idx_table) hipFree(h->idx_table);
   if (h->stage_dev) hipFree(h->stage_dev);
@@ -2075,6 +2119,7 @@ int dsact_bind_arenas(dsact_handle* h, float* online, float* target, float* adam
   h->online = online; h->target = target; h->adam_m = adam_m; h->adam_v = adam_v; h->grads = grads;
   TRY(build_chain(h));
   TRY(build_pack_jobs(h));
+  if (h->chain_ok) TRY(build_adam_pack_jobs(h));
   TRY(build_tasks(h));
   if (h->chain_ok) (void)dw2_args(h, false);   // tile ranges of the dw2 problem list
   if (!h->cnn) {   // the same task lists over the second batch set
@@ -2520,8 +2565,8 @@ static int capture_updates(dsact_handle* h, int n, uint32_t flags, bool merged, 
         // path) -> all-reduce -> streaming Adam/Polyak -> packed weight copies rebuilt for the next forward
         rc = enqueue_grads(h, true, false, 0, &ride);
         if (rc == DSACT_OK) rc = enqueue_allreduce(h, h->grads, h->n_online + 2, kNcclAvg);
-        if (rc == DSACT_OK) rc = enqueue_adam(h);
-        if (rc == DSACT_OK) rc = enqueue_pack(h, true);
+        if (rc == DSACT_OK) rc = h->env_no_adam_pack ? enqueue_adam(h) : enqueue_adam_pack(h);
+        if (rc == DSACT_OK && h->env_no_adam_pack) rc = enqueue_pack(h, true);
       } else {
         rc = enqueue_grads(h, actor, true, 0, &ride);
       }

@@ -374,6 +374,80 @@ __global__ void __launch_bounds__(kThreads) k_dw2(Dw2Launch L) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_adam_pack: the optimiser of the data-parallel graph. After the all-reduce the gradient arena holds the averaged
+// gradient; one pass applies Adam (+ Polyak on delayed-update steps) to every weight tensor AND writes its packed
+// copies (what the fused weight-gradient tiles do on the single-GPU path) -- instead of a streaming k_adam followed by a
+// k_pack that reads the arenas again. Same per-element arithmetic as dw2_tile's epilogue / k_adam (tested bitwise).
+// Block = 16 rows x 256 columns of one tensor; lanes are laid out like pack_block (a lane quad = 4 consecutive rows).
+// ---------------------------------------------------------------------------------------------------------------
+struct AdamPackJob {
+  long long w_idx, b_idx;   // arena indices of the weight matrix [N x K] and its bias [N]
+  int N, K, col_chunks;     // col_chunks = ceil(K / 256)
+  const MirrorDesc* mir;
+  int block_end;            // exclusive end of this job's block range (row blocks x col_chunks)
+};
+struct AdamPackArgs { const AdamPackJob* jobs; int n_jobs, n_blocks; FusedOpt fo; };
+__global__ void __launch_bounds__(256) k_adam_pack(AdamPackArgs a) {
+  const int b = (int)blockIdx.x, tid = threadIdx.x;
+  if (b >= a.n_blocks) {
+    if (tid == 0) finalize_update(a.fo);
+    return;
+  }
+  int ji = 0;
+  for (int q = 0; q + 1 < a.n_jobs; ++q) if (b >= a.jobs[q].block_end) ji = q + 1;
+  const AdamPackJob J = a.jobs[ji];
+  const int local = b - (ji ? a.jobs[ji - 1].block_end : 0);
+  const int n0 = (local / J.col_chunks) * 16, k_lo = (local % J.col_chunks) * 256;
+  const FusedOpt& fo = a.fo;
+  const bool o_delayed = fo.st->do_delayed != 0;
+  const bool is_q = J.w_idx < fo.n_q2;
+  if (!(is_q || o_delayed)) return;   // the policy is left alone on the off iterations of the delayed update
+  const float o_ss = is_q ? fo.st->ss_q : fo.st->ss_pi, o_bc2 = is_q ? fo.st->bc2_q : fo.st->bc2_pi;
+#pragma unroll 1
+  for (int it = 0; it < 4; ++it) {
+    const int e = it * 256 + tid;
+    const int n = n0 + (e & 15), k = k_lo + (e >> 4) * 4;
+    const bool valid = n < J.N && k < J.K;
+    f32x4 op = {0.f, 0.f, 0.f, 0.f}, ot = op;
+    if (valid) {
+      const long long oi = J.w_idx + (long long)n * J.K + k;
+      if (k + 3 < J.K) {
+        const f32x4 g = *(const f32x4u*)(fo.grads + oi);
+        f32x4 om = *(const f32x4u*)(fo.adam_m + oi), ov = *(const f32x4u*)(fo.adam_v + oi);
+        op = *(const f32x4u*)(fo.online + oi);
+        if (o_delayed) ot = *(const f32x4u*)(fo.target + oi);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float pe = op[c], me = om[c], ve = ov[c];
+          adam_update(pe, me, ve, g[c], fo.b1w, fo.beta2, fo.b2w, o_ss, o_bc2, fo.eps);
+          op[c] = pe; om[c] = me; ov[c] = ve;
+          if (o_delayed) ot[c] = polyak_update(ot[c], pe, fo.polyak, fo.one_minus_polyak);
+        }
+        *(f32x4u*)(fo.online + oi) = op; *(f32x4u*)(fo.adam_m + oi) = om; *(f32x4u*)(fo.adam_v + oi) = ov;
+        if (o_delayed) *(f32x4u*)(fo.target + oi) = ot;
+      } else {
+        for (int c = 0; c < 4 && k + c < J.K; ++c) {
+          float pe = fo.online[oi + c], me = fo.adam_m[oi + c], ve = fo.adam_v[oi + c];
+          adam_update(pe, me, ve, fo.grads[oi + c], fo.b1w, fo.beta2, fo.b2w, o_ss, o_bc2, fo.eps);
+          fo.online[oi + c] = pe; fo.adam_m[oi + c] = me; fo.adam_v[oi + c] = ve;
+          op[c] = pe;
+          if (o_delayed) { ot[c] = polyak_update(fo.target[oi + c], pe, fo.polyak, fo.one_minus_polyak); fo.target[oi + c] = ot[c]; }
+        }
+      }
+    }
+    // k stays real for a lane whose ROW is past the end: it still owns row k + lane%4 of the transposed block
+    if (J.mir) mirror_store4_quad(*J.mir, n, k < J.K ? k : J.K, J.K, J.N, valid, op, o_delayed, ot, tid);
+  }
+  if (k_lo == 0 && tid < 16 && n0 + tid < J.N) {
+    const long long bi = J.b_idx + n0 + tid;
+    float pe = fo.online[bi], me = fo.adam_m[bi], ve = fo.adam_v[bi];
+    adam_update(pe, me, ve, fo.grads[bi], fo.b1w, fo.beta2, fo.b2w, o_ss, o_bc2, fo.eps);
+    fo.online[bi] = pe; fo.adam_m[bi] = me; fo.adam_v[bi] = ve;
+    if (o_delayed) fo.target[bi] = polyak_update(fo.target[bi], pe, fo.polyak, fo.one_minus_polyak);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k_chain_fwd
 // ---------------------------------------------------------------------------------------------------------------
 enum : int { SEG_FULL = 0, SEG_OBS_ONLY = 1, SEG_ACT_FROM_SAVED = 2, SEG_FULL_SAVE = 3 };
