@@ -431,7 +431,8 @@ def measure(alg, steps, warmup, world=1, dp=None, flags=0):
         for _ in range(R):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            ms = e.time_steps(it, steps, use_graph=True)  # hipEvents on the engine's stream + host sync
+            ms = e.time_steps(it, steps, use_graph=True)  # hipEvents on the engine's stream + host wait for the end event
+            torch.cuda.synchronize()
             regions.append(time.perf_counter() - t0)
             evs.append(ms)
             it += steps

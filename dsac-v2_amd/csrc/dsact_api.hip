@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <dlfcn.h>
+#include <chrono>
 #include <stdarg.h>
 #include <stdio.h>
 #include <math.h>
@@ -2823,7 +2824,16 @@ int dsact_time_steps(dsact_handle* h, int64_t first_iteration, int64_t n_steps, 
     for (int64_t i = 0; i < n_steps; ++i) TRY(enqueue_graph_step(h, first_iteration + i, flags));
   }
   HIPCHK(h, hipEventRecord(h->tev1, h->stream));
-  HIPCHK(h, hipEventSynchronize(h->tev1));
+  {
+    // wait for the end event by polling first: a blocking wait sleeps the thread and its wake-up (tens of us) would
+    // be charged to a short timed region; after ~5 ms of polling fall back to the blocking wait
+    hipError_t q = hipErrorNotReady;
+    const auto t_poll = std::chrono::steady_clock::now();
+    while ((q = hipEventQuery(h->tev1)) == hipErrorNotReady) {
+      if (std::chrono::steady_clock::now() - t_poll > std::chrono::milliseconds(5)) break;
+    }
+    if (q != hipSuccess) HIPCHK(h, hipEventSynchronize(h->tev1));
+  }
   HIPCHK(h, hipEventElapsedTime(ms_total, h->tev0, h->tev1));
   h->have_batch = true;   // the last update's minibatch stays staged
   return DSACT_OK;
