@@ -500,6 +500,7 @@ def chain_flops(lay, batch):
         "dW": dw_pi,
     }
     per_row["chain_fwd"] = per_row["chain_fwd_a"] + per_row["chain_fwd_b"]   # merged A+B launch (batch <= 256)
+    per_row["chain_bwd"] = per_row["chain_bwd_q"] + per_row["chain_bwd_pi"] + per_row["dW"]   # merged backward + optimiser launch
     return {k: 2.0 * v * batch for k, v in per_row.items()}
 
 
@@ -719,7 +720,8 @@ def main():
             out["dominant_kernel"] = {"name": dom[0], "us": round(dom[1] * 1000, 2)}
             if chain and Bb % 256 == 0 or chain and Bb <= 256:
                 fl = chain_flops(lay, Bb)
-                kname = {"chain_fwd": "dsact::k_chain_fwd2 (groups A + B in one launch)", "chain_fwd_a": "dsact::k_chain_fwd (group A)", "chain_fwd_b": "dsact::k_chain_fwd (group B)",
+                kname = {"chain_bwd": "dsact::k_chain_bwd2 (critics' + policy backward + all dW/Adam tiles in one launch)",
+                         "chain_fwd": "dsact::k_chain_fwd2 (groups A + B in one launch)", "chain_fwd_a": "dsact::k_chain_fwd (group A)", "chain_fwd_b": "dsact::k_chain_fwd (group B)",
                          "chain_bwd_q": "dsact::k_chain_bwd_q", "chain_bwd_pi": "dsact::k_chain_bwd_pi (+ riding k_dw2 tiles)",
                          "dW": "dsact::k_dw2"}.get(dom[0], dom[0])
                 if dom[0] in fl:
@@ -727,7 +729,7 @@ def main():
                     ach = fl[dom[0]] / (dur_us * 1e-6) / 1e12
                     out["roofline"] = {
                         "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
-                        "traffic": pmc_traffic({"chain_fwd": "k_chain_fwd2", "chain_fwd_a": "k_chain_fwd", "chain_fwd_b": "k_chain_fwd", "chain_bwd_q": "k_chain_bwd_q",
+                        "traffic": pmc_traffic({"chain_bwd": "k_chain_bwd2", "chain_fwd": "k_chain_fwd2", "chain_fwd_a": "k_chain_fwd", "chain_fwd_b": "k_chain_fwd", "chain_bwd_q": "k_chain_bwd_q",
                                                 "chain_bwd_pi": "k_chain_bwd_pi", "dW": "k_dw2"}.get(dom[0], dom[0]),
                                                "min" if dom[0] == "chain_fwd_b" else "max"),
                         "kernel": kname, "avg_launch_us": dur_us, "flop_per_launch": fl[dom[0]],

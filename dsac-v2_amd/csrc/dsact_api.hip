@@ -208,6 +208,9 @@ struct dsact_handle {
   int n_apjobs = 0, ap_blocks = 0;
   int* chain_flags = nullptr;           // ready flags of the merged forward launch + timeout word at [kChainFlags]
   bool fwd_merge = false;               // launches A and B as one (batch <= 256)
+  FusedOpt* d_fin = nullptr;            // device copy of the fused-optimiser constants for k_chain_bwd2's closing block
+  bool d_fin_dirty = true;
+  bool bwd_merge = false;               // critics' backward, policy backward and all weight-gradient/Adam tiles as one launch
   float* zobs[4];                       // first-layer accumulators after the observation part: q1, q2 (obs), q1_t, q2_t (obs2)
   float* dAq[2];                        // dL/d new_act through q1 / q2  [B][32]
   float* doutT[3];                      // transposed packs of dL/d(out): q1, q2 [32 x B], policy [roundup32(2A) x B]
@@ -435,7 +438,7 @@ void carve(dsact_handle* h, Carver& c) {
   h->timeline = c.take<long long>(512 * 16);
   h->dw_parts = c.take<float>(h->dw_chunks > 1 ? (size_t)h->dw_chunks * h->dw_part_stride : 4);
   for (int i = 0; i < 4; ++i) h->zobs[i] = c.take<float>(B * h->w[0]);
-  h->chain_flags = c.take<int>(kChainFlags + 64);   // [unit 0..5][slice] ready flags of the merged forward launch, then the spin-timeout word
+  h->chain_flags = c.take<int>(kChainFlags + 128);   // [unit 0..5][slice] ready flags of the merged forward launch, then the spin-timeout word
   for (int i = 0; i < 2; ++i) h->dAq[i] = c.take<float>(B * 32);
   for (int i = 0; i < 2; ++i) h->doutT[i] = c.take<float>(B * 32);
   h->doutT[2] = c.take<float>(B * (size_t)((2 * A + 31) / 32 * 32));
@@ -1371,6 +1374,7 @@ void fill_fwd_common(dsact_handle* h, FwdArgs& a, int rg, const char* name) {
   a.act_scale = h->act_scale; a.act_center = h->act_center; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
   a.timeline = tl_for(h, name);
   a.spin_timeout = h->chain_flags + kChainFlags;
+  if (h->bwd_merge) { a.bwd_counters = h->chain_flags + kChainFlags + 1; a.n_bwd_counters = 8 + kChainFlagSlices; }
 }
 
 // group A: policy(obs), policy_target(obs2), q1/q2(obs,act) + observation part of q1_t/q2_t(obs2, .)
@@ -1463,8 +1467,8 @@ int enqueue_chain_fwd_merged(dsact_handle* h) {
 
 // loss + dZ chains of the critics (n_units 2: q1c, q2c only -- off iterations of the delayed update) and of
 // q1/q2(obs,new_act); riders as in the loss launch of the tile path
-int enqueue_chain_bwd_q(dsact_handle* h, int n_units, const RideArgs* ride) {
-  BwdQArgs a;
+// arguments of the critics' backward; returns the row groups per workgroup and the rider count
+void bwd_q_args(dsact_handle* h, int n_units, const RideArgs* ride, BwdQArgs& a, int& rg_out, int& n_riders_out) {
   memset(&a, 0, sizeof(a));
   const int L = h->L;
   const int chs[4] = {C_Q1C, C_Q2C, C_Q1P, C_Q2P};
@@ -1495,7 +1499,14 @@ int enqueue_chain_bwd_q(dsact_handle* h, int n_units, const RideArgs* ride) {
   if (h->fwd_merge) { a.flags_reset = h->chain_flags; a.n_flags = kChainFlags; }
   if (ride) a.ride = *ride;
   a.ride.n_loss_blocks = a.n_chain_blocks;
-  const int n_riders = ride ? ride->n_gather + (ride->bookkeeping ? 1 : 0) : 0;
+  n_riders_out = ride ? ride->n_gather + (ride->bookkeeping ? 1 : 0) : 0;
+  rg_out = rg;
+}
+
+int enqueue_chain_bwd_q(dsact_handle* h, int n_units, const RideArgs* ride) {
+  BwdQArgs a;
+  int rg, n_riders;
+  bwd_q_args(h, n_units, ride, a, rg, n_riders);
   const size_t lds = (size_t)chain_lds(h->cW, h->cW, 4 * rg).total * sizeof(float);
 #define CALL_CQ(N, G) return launch(h, "chain_bwd_q", k_chain_bwd_q<N, G>, dim3(a.n_chain_blocks + n_riders), dim3(kThreads), lds, a)
   CHAIN_NT(CALL_CQ, rg);
@@ -1503,8 +1514,7 @@ int enqueue_chain_bwd_q(dsact_handle* h, int n_units, const RideArgs* ride) {
 }
 
 // rsample backward + policy dZ chain; weight-gradient tiles [x0, x1) ride along on the other CUs
-int enqueue_chain_bwd_pi(dsact_handle* h, int x0, int x1, bool fused) {
-  BwdPiArgs a;
+void bwd_pi_args(dsact_handle* h, int x0, int x1, bool fused, BwdPiArgs& a, int& rg_out) {
   memset(&a, 0, sizeof(a));
   const int L = h->L;
   a.dA[0] = h->dAq[0]; a.dA[1] = h->dAq[1];
@@ -1526,11 +1536,55 @@ int enqueue_chain_bwd_pi(dsact_handle* h, int x0, int x1, bool fused) {
   a.timeline = tl_for(h, "chain_bwd_pi");
   a.dw = dw2_args(h, fused);
   a.tile0 = x0; a.n_extra = x1 > x0 ? x1 - x0 : 0;
+  rg_out = rg;
+}
+
+int enqueue_chain_bwd_pi(dsact_handle* h, int x0, int x1, bool fused) {
+  BwdPiArgs a;
+  int rg;
+  bwd_pi_args(h, x0, x1, fused, a, rg);
   size_t lds = (size_t)chain_lds(4 * h->SoT, h->cW, 4 * rg).total * sizeof(float);
   if (lds < kDw2LdsFloats * sizeof(float)) lds = kDw2LdsFloats * sizeof(float);
 #define CALL_CP(N, G) return launch(h, "chain_bwd_pi", k_chain_bwd_pi<N, G>, dim3(a.n_chain_blocks + xcd_chunk_grid(a.n_extra) * h->dw_chunks), dim3(kThreads), lds, a)
   CHAIN_NT(CALL_CP, rg);
 #undef CALL_CP
+}
+
+// the whole backward + optimiser of one update in ONE launch (k_chain_bwd2; batch <= 256)
+int enqueue_chain_bwd_merged(dsact_handle* h, bool fused, const RideArgs* ride) {
+  Bwd2Args m;
+  memset(&m, 0, sizeof(m));
+  int rgq, rgp, n_riders;
+  bwd_q_args(h, 4, ride, m.q, rgq, n_riders);
+  bwd_pi_args(h, 0, 0, fused, m.p, rgp);
+  int* cnt = h->chain_flags + kChainFlags + 1;   // [0] critics + riders arrived, [1] policy slices arrived, [8 + s] dL/da of slice s
+  m.cnt_q = cnt; m.cnt_pi = cnt + 1; m.spin_timeout = h->chain_flags + kChainFlags;
+  m.q.agent = 1; m.q.cnt_q = m.cnt_q; m.q.cnt_dA = cnt + 8; m.q.dA_rows = 4 * rgp;
+  m.p.agent = 1; m.p.cnt_dA = cnt + 8; m.p.dA_need = 2 * (rgp / rgq); m.p.cnt_pi = m.cnt_pi; m.p.spin_timeout = m.spin_timeout;
+  m.p.dw.agent_st = 1;
+  m.nq = m.q.n_chain_blocks; m.nr = n_riders; m.npad = roundup(n_riders, 8) - n_riders;
+  m.np = roundup(m.p.n_slices, 8);
+  m.nt_q = h->dw2_off[2]; m.nt_pi = h->dw2_off[3] - h->dw2_off[2];
+  m.need_q = 4 * m.q.n_slices + n_riders; m.need_pi = m.p.n_slices;
+  m.fin = fused ? h->d_fin : nullptr;
+  m.fin_part_loss = m.p.part_loss; m.fin_n_part = m.p.n_part; m.fin_inv_B = m.p.inv_B; m.fin_target_entropy = m.p.target_entropy;
+  m.fin_grad_log_alpha = m.p.grad_log_alpha; m.fin_auto_alpha = m.p.auto_alpha;
+  if (fused && h->d_fin_dirty) return fail(h, DSACT_E_STATE, "merged backward: optimiser constants not uploaded (ensure_fin)");
+  const int grid = m.nq + m.nr + m.npad + m.np + xcd_chunk_grid(m.nt_q) + xcd_chunk_grid(m.nt_pi) + 1;
+  size_t lds = (size_t)chain_lds(h->cW, h->cW, 4 * rgq).total * sizeof(float);
+  const size_t lp = (size_t)chain_lds(4 * h->SoT, h->cW, 4 * rgp).total * sizeof(float);
+  if (lp > lds) lds = lp;
+  if (lds < kDw2LdsFloats * sizeof(float)) lds = kDw2LdsFloats * sizeof(float);
+#define CALL_B2(N)                                                                                               \
+  do {                                                                                                           \
+    if (rgq == 1 && rgp == 2) return launch(h, "chain_bwd", k_chain_bwd2<N, 1, 2>, dim3(grid), dim3(kThreads), lds, m);  \
+    if (rgq == 1 && rgp == 1) return launch(h, "chain_bwd", k_chain_bwd2<N, 1, 1>, dim3(grid), dim3(kThreads), lds, m);  \
+    return fail(h, DSACT_E_STATE, "merged backward: unsupported row-group combination");                         \
+  } while (0)
+  if (h->cNT == 1) CALL_B2(1);
+  else if (h->cNT == 2) CALL_B2(2);
+  else CALL_B2(4);
+#undef CALL_B2
 }
 
 // same contract as enqueue_grads (phases, fused optimiser, riders of the loss launch)
@@ -1551,6 +1605,7 @@ int enqueue_grads_chain(dsact_handle* h, bool actor_backward, bool fused, int ph
     }
   }
   if (phase == 1) return DSACT_OK;
+  if (h->bwd_merge && phase == 0 && actor_backward && h->dw_chunks == 1) return enqueue_chain_bwd_merged(h, fused, ride);
   TRY(enqueue_chain_bwd_q(h, actor_backward ? 4 : 2, ride));
   if (!actor_backward) {
     if (h->dw_chunks == 1) return run_dw2(h, off[0], off[2], fused, fused);
@@ -1828,6 +1883,18 @@ int enqueue_adam(dsact_handle* h, bool from_parts) {
   return launch(h, "adam_polyak", k_adam, dim3(blocks), dim3(kThreads), 0, a);
 }
 
+// device copy of the fused-optimiser constants (k_chain_bwd2's closing block reads them from memory): refreshed outside
+// any capture, whenever the arenas were (re)bound or a hyper-parameter changed
+int ensure_fin(dsact_handle* h) {
+  if (!h->bwd_merge || !h->d_fin_dirty || !h->online) return DSACT_OK;
+  if (!h->d_fin) HIPCHK(h, hipMalloc((void**)&h->d_fin, sizeof(FusedOpt)));
+  const FusedOpt fo = fused_opt(h, true);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(h->d_fin, &fo, sizeof(fo), hipMemcpyHostToDevice));
+  h->d_fin_dirty = false;
+  return DSACT_OK;
+}
+
 void drop_graphs(dsact_handle* h) {
   if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
   if (h->graph) { hipGraphDestroy(h->graph); h->graph = nullptr; }
@@ -1840,7 +1907,7 @@ int check_ready(dsact_handle* h, bool need_batch) {
   if (!h->limits_set) return fail(h, DSACT_E_STATE, "action limits not set (dsact_set_action_limits)");
   if (need_batch && !h->have_batch) return fail(h, DSACT_E_STATE, "no minibatch staged (dsact_gather / dsact_load_batch)");
   h->dev_it_next = -1;   // every update entry point except the graph replays passes through here
-  return DSACT_OK;
+  return ensure_fin(h);
 }
 
 }  // namespace
@@ -1953,6 +2020,8 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     h->rg4_ok = ok && h->B % 16 == 0 && getenv("DSACT_NO_RG4") == nullptr &&
                 (size_t)chain_lds(4 * (h->s_obs + h->s_act), W0, 16).total * sizeof(float) <= 150 * 1024;
     // merged forward launch: both groups resident at once (4-row group-B workgroups: batch <= 256), one flag per slice
+    // (opt-in: correct -- the parity tests pass with it -- but measured slower than the three launches it replaces)
+    h->bwd_merge = ok && h->B <= 256 && h->B / 4 <= kChainFlagSlices && getenv("DSACT_BWD_MERGE") != nullptr;
     h->fwd_merge = ok && h->B <= 256 && h->B / 4 <= kChainFlagSlices && chain_rg(h, 4) == 1 && getenv("DSACT_NO_FWD_MERGE") == nullptr;
   }
   Carver c0;
@@ -2067,6 +2136,7 @@ int dsact_destroy(dsact_handle* h) {
   if (h->pk_ws) hipFree(h->pk_ws);
   if (h->d_mir) hipFree(h->d_mir);
   if (h->d_apjobs) hipFree(h->d_apjobs);
+  if (h->d_fin) hipFree(h->d_fin);
   if (h->d_pack) hipFree(h->d_pack);
   if (h->idx_table) hipFree(h->idx_table);
   if (h->stage_dev) hipFree(h->stage_dev);
@@ -2118,6 +2188,7 @@ int dsact_bind_arenas(dsact_handle* h, float* online, float* target, float* adam
   HIPCHK(h, hipSetDevice(h->device));
   if (h->graph_exec) return fail(h, DSACT_E_STATE, "cannot rebind arenas after dsact_graph_build");
   h->online = online; h->target = target; h->adam_m = adam_m; h->adam_v = adam_v; h->grads = grads;
+  h->d_fin_dirty = true;
   TRY(build_chain(h));
   TRY(build_pack_jobs(h));
   if (h->chain_ok) TRY(build_adam_pack_jobs(h));
@@ -2208,6 +2279,7 @@ int dsact_set_hyper(dsact_handle* h, int32_t which, double value) {
       h->cfg.td_bound = value; break;
     default: return fail(h, DSACT_E_INVALID, "unknown hyper-parameter %d", (int)which);
   }
+  h->d_fin_dirty = true;
   // every launch reads h->cfg when it is enqueued; only a captured graph holds old values
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -1056,17 +1056,23 @@ struct TableArgs {
 
 // end-of-update duties of the fused path: Adam on log_alpha, commit of the mean_std EMA and of the
 // iteration / sequence counters (k_adam does the same on the unfused path)
-__device__ void finalize_update(const FusedOpt& fo) {
-  const DevState st = *fo.st;
-  const long long i = fo.n_total - 1;
-  if (st.do_delayed && fo.auto_alpha) {
-    float p = fo.online[i], m = fo.adam_m[i], v = fo.adam_v[i];
-    adam_update(p, m, v, fo.grads[i], fo.b1w, fo.beta2, fo.b2w, st.ss_alpha, st.bc2_alpha, fo.eps);
-    fo.online[i] = p; fo.adam_m[i] = m; fo.adam_v[i] = v;
+__device__ __forceinline__ void finalize_update_s(DevState* stp, float* online, float* adam_m, float* adam_v, const float* grads,
+                                                  long long n_total, int auto_alpha, float b1w, float beta2, float b2w, float eps) {
+  const int do_delayed = stp->do_delayed;
+  const float ss_alpha = stp->ss_alpha, bc2_alpha = stp->bc2_alpha;
+  const long long it_cur = stp->it_cur, seq = stp->seq_next;
+  const long long i = n_total - 1;
+  if (do_delayed && auto_alpha) {
+    float p = online[i], m = adam_m[i], v = adam_v[i];
+    adam_update(p, m, v, grads[i], b1w, beta2, b2w, ss_alpha, bc2_alpha, eps);
+    online[i] = p; adam_m[i] = m; adam_v[i] = v;
   }
-  fo.st->ms1 = fo.grads[fo.n_total]; fo.st->ms2 = fo.grads[fo.n_total + 1]; fo.st->ms_init = 1;
-  fo.st->it_next = st.it_cur + 1;
-  fo.st->seq_next = st.seq_next + 1;
+  stp->ms1 = grads[n_total]; stp->ms2 = grads[n_total + 1]; stp->ms_init = 1;
+  stp->it_next = it_cur + 1;
+  stp->seq_next = seq + 1;
+}
+__device__ __forceinline__ void finalize_update(const FusedOpt& fo) {
+  finalize_update_s(fo.st, fo.online, fo.adam_m, fo.adam_v, fo.grads, fo.n_total, fo.auto_alpha, fo.b1w, fo.beta2, fo.b2w, fo.eps);
 }
 
 // workgroup barrier that orders LDS only: __syncthreads() also waits for vmcnt(0), i.e. for every global load AND store
