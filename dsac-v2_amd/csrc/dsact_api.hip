@@ -206,7 +206,15 @@ struct dsact_handle {
   PackJob* d_pack = nullptr; int n_pack_jobs = 0, pack_blocks = 0;
   AdamPackJob* d_apjobs = nullptr;      // k_adam_pack job table (data-parallel graph)
   int n_apjobs = 0, ap_blocks = 0;
-  int* chain_flags = nullptr;           // ready flags of the merged forward launch + timeout word at [kChainFlags]
+  int* chain_flags = nullptr;           // ready flags of the merged forward launch (+ the merged backward's arrival counters behind them)
+  bool flags_dirty = false;             // a merged forward was enqueued and nothing has cleared its ready flags since
+  // in-launch hand-overs: a consumer that gives up waiting (bounded spin) writes this word, which lives in mapped pinned
+  // HOST memory -- every entry point checks it without a device sync and fails the call (check_handoff)
+  int* handoff_host = nullptr; int* handoff_dev = nullptr;
+  bool in_handoff = false;
+  int handoff_failures = 0;
+  int debug_withhold = 0;               // dsact_debug_set("withhold_flag"): tests force the timeout path
+  int env_chain_rg_pi = 0;              // DSACT_CHAIN_RG_PI (experiments)
   bool fwd_merge = false;               // launches A and B as one (batch <= 256)
   FusedOpt* d_fin = nullptr;            // device copy of the fused-optimiser constants for k_chain_bwd2's closing block
   bool d_fin_dirty = true;
@@ -1373,7 +1381,8 @@ void fill_fwd_common(dsact_handle* h, FwdArgs& a, int rg, const char* name) {
   a.s_obs = h->s_obs; a.s_act = h->s_act; a.v1_stats = 0; a.Cb = h->B / 16;
   a.act_scale = h->act_scale; a.act_center = h->act_center; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
   a.timeline = tl_for(h, name);
-  a.spin_timeout = h->chain_flags + kChainFlags;
+  a.spin_timeout = h->handoff_dev;
+  a.debug_withhold = h->debug_withhold;
   if (h->bwd_merge) { a.bwd_counters = h->chain_flags + kChainFlags + 1; a.n_bwd_counters = 8 + kChainFlagSlices; }
 }
 
@@ -1451,6 +1460,11 @@ int enqueue_chain_fwd_merged(dsact_handle* h) {
   }
   m.n_a = chain_grid(m.A.n_units, m.A.n_slices);
   const int grid = m.n_a + chain_grid(m.B.n_units, m.B.n_slices);
+  // The ready flags are cleared by the critics' backward, which follows every forward of a complete update. A forward
+  // that follows another forward (dsact_dp_enqueue_forward twice, or one never followed by its backward) would find them
+  // raised and its consumers would not wait: clear them first (a memset node when captured).
+  if (h->flags_dirty) HIPCHK(h, hipMemsetAsync(h->chain_flags, 0, kChainFlags * sizeof(int), h->stream));
+  h->flags_dirty = true;
   const size_t la = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 4 * rga).total * sizeof(float);
   const size_t lb = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 4 * rgb).total * sizeof(float);
   const size_t lds = la > lb ? la : lb;
@@ -1496,7 +1510,7 @@ void bwd_q_args(dsact_handle* h, int n_units, const RideArgs* ride, BwdQArgs& a,
   a.one_minus_tau_b = (float)(1.0 - h->cfg.tau_b);
   a.n_chain_blocks = chain_grid(n_units, a.n_slices);
   a.timeline = tl_for(h, "chain_bwd_q");
-  if (h->fwd_merge) { a.flags_reset = h->chain_flags; a.n_flags = kChainFlags; }
+  if (h->fwd_merge) { a.flags_reset = h->chain_flags; a.n_flags = kChainFlags; h->flags_dirty = false; }
   if (ride) a.ride = *ride;
   a.ride.n_loss_blocks = a.n_chain_blocks;
   n_riders_out = ride ? ride->n_gather + (ride->bookkeeping ? 1 : 0) : 0;
@@ -1525,7 +1539,7 @@ void bwd_pi_args(dsact_handle* h, int x0, int x1, bool fused, BwdPiArgs& a, int&
   a.dout_pi = h->dout_pi; a.d_new_act = h->d_new_act; a.dout_piT = h->doutT[2];
   // the policy chain shares its launch with ~2 rounds of weight-gradient tiles, which bound it: 8-row workgroups leave
   // them 32 more CUs (measured: 15.7 us vs 16.3 us with 4-row workgroups at batch 256)
-  const int rg_pi = getenv("DSACT_CHAIN_RG_PI") ? atoi(getenv("DSACT_CHAIN_RG_PI")) : 0;   // experiments
+  const int rg_pi = h->env_chain_rg_pi;   // experiments
   const int rg = rg_pi ? rg_pi : h->env_chain_rg ? h->env_chain_rg : (h->B >= 8 ? h->cRG : 1);
   a.n_slices = h->B / (4 * rg); a.B = h->B; a.A = h->A; a.L = L; a.Cb = h->B / 16;
   a.inv_B = 1.0f / (float)h->B; a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed;
@@ -1558,7 +1572,7 @@ int enqueue_chain_bwd_merged(dsact_handle* h, bool fused, const RideArgs* ride) 
   bwd_q_args(h, 4, ride, m.q, rgq, n_riders);
   bwd_pi_args(h, 0, 0, fused, m.p, rgp);
   int* cnt = h->chain_flags + kChainFlags + 1;   // [0] critics + riders arrived, [1] policy slices arrived, [8 + s] dL/da of slice s
-  m.cnt_q = cnt; m.cnt_pi = cnt + 1; m.spin_timeout = h->chain_flags + kChainFlags;
+  m.cnt_q = cnt; m.cnt_pi = cnt + 1; m.spin_timeout = h->handoff_dev;
   m.q.agent = 1; m.q.cnt_q = m.cnt_q; m.q.cnt_dA = cnt + 8; m.q.dA_rows = 4 * rgp;
   m.p.agent = 1; m.p.cnt_dA = cnt + 8; m.p.dA_need = 2 * (rgp / rgq); m.p.cnt_pi = m.cnt_pi; m.p.spin_timeout = m.spin_timeout;
   m.p.dw.agent_st = 1;
@@ -1644,6 +1658,7 @@ actor_part:
 // bookkeeping and, when ride->n_gather > 0, the next update's gather into the other batch set
 int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 0, const RideArgs* ride = nullptr) {
   h->have_local_tail = true;
+  h->uev_valid = false;   // dsact_step / dsact_compute_grads set it again once their closing event is recorded
   if (h->chain_ok) return enqueue_grads_chain(h, actor_backward, fused, phase, ride);
   const int L = h->L, B = h->B, A = h->A;
   if (phase == 4) goto actor_part;
@@ -1901,8 +1916,39 @@ void drop_graphs(dsact_handle* h) {
   h->graph_steps = 0;
 }
 
+// In-launch hand-overs (merged forward / backward launches) use BOUNDED spins: a consumer that waited ~0.1 s for its
+// producers' flags gives up, computes on whatever it finds and writes the hand-off word in mapped host memory. Every
+// entry point comes through here: the call fails (DSACT_E_HIP), the merged launches are switched off for this handle
+// (the plain multi-launch chain has no in-launch dependencies) and a captured graph is captured again without them, so
+// the NEXT call runs -- on device state the caller must treat as invalid (restore a checkpoint / re-bind the arenas).
+int check_handoff(dsact_handle* h) {
+  if (!h->handoff_host || h->in_handoff || !*(volatile int*)h->handoff_host) return DSACT_OK;
+  h->in_handoff = true;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  *(volatile int*)h->handoff_host = 0;
+  const bool had_graph = h->graph_exec != nullptr;
+  const int steps = h->graph_steps;
+  const uint32_t gflags = h->graph_flags;
+  h->fwd_merge = false;
+  h->bwd_merge = false;
+  h->handoff_failures += 1;
+  drop_graphs(h);
+  if (h->chain_flags) hipMemset(h->chain_flags, 0, (kChainFlags + 128) * sizeof(int));
+  h->flags_dirty = false;
+  int rebuilt = DSACT_E_STATE;
+  if (had_graph) rebuilt = dsact_graph_build(h, steps, gflags);
+  h->in_handoff = false;
+  return fail(h, DSACT_E_HIP,
+              "an in-launch hand-over timed out: a workgroup waited > 0.1 s for its producers' ready flags, so every result "
+              "since the last successful call is invalid. Merged launches are now disabled for this handle%s",
+              had_graph ? (rebuilt == DSACT_OK ? "; the graph was captured again without them" : "; re-capturing the graph failed")
+                        : "");
+}
+
 int check_ready(dsact_handle* h, bool need_batch) {
   if (!h) return DSACT_E_INVALID;
+  TRY(check_handoff(h));
   if (!h->online || !h->grads) return fail(h, DSACT_E_STATE, "arenas not bound (dsact_bind_arenas)");
   if (!h->limits_set) return fail(h, DSACT_E_STATE, "action limits not set (dsact_set_action_limits)");
   if (need_batch && !h->have_batch) return fail(h, DSACT_E_STATE, "no minibatch staged (dsact_gather / dsact_load_batch)");
@@ -1998,6 +2044,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->env_no_adam_pack = getenv("DSACT_NO_ADAM_PACK") != nullptr;
   if (const char* v = getenv("DSACT_CONV_DW_NKT")) h->env_conv_dw_nkt = atoi(v);
   if (const char* v = getenv("DSACT_RIDE_SLOTS")) h->env_ride_slots = atoi(v);
+  if (const char* v = getenv("DSACT_CHAIN_RG_PI")) h->env_chain_rg_pi = atoi(v);
   if (const char* v = getenv("DSACT_CHAIN_RG")) h->env_chain_rg = atoi(v) == 1 ? 1 : atoi(v) == 4 ? 4 : 2;
   h->dw_chunks = (h->B > 448 && h->B % 256 == 0 && getenv("DSACT_NO_SPLITK") == nullptr) ? h->B / 256 : 1;
   h->dw_part_stride = (h->n_online + 2 + 63) & ~(size_t)63;
@@ -2110,6 +2157,18 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<false, EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<true, EPI_MULG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
   }
+  HIPCHK(h, hipHostMalloc((void**)&h->handoff_host, 64, hipHostMallocMapped));
+  memset(h->handoff_host, 0, 64);
+  HIPCHK(h, hipHostGetDevicePointer((void**)&h->handoff_dev, h->handoff_host, 0));
+  if (h->fwd_merge) {
+    // the merged forward is sized for both groups' workgroups being resident at once: two per CU (speed, not
+    // correctness -- consumers only wait for lower block ids, which are always dispatched first)
+    int per_cu = 0;
+    const size_t la = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 4 * chain_rg(h, 6)).total * sizeof(float);
+    const void* fn = h->cNT == 1 ? (const void*)k_chain_fwd2<1, 2, 1> : h->cNT == 2 ? (const void*)k_chain_fwd2<2, 2, 1> : (const void*)k_chain_fwd2<4, 2, 1>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * h->cNT, la) != hipSuccess || per_cu < 2) h->fwd_merge = false;
+    (void)hipGetLastError();
+  }
   for (int i = 0; i < 8; ++i) {
     HIPCHK(h, hipHostMalloc((void**)&h->h_idx[i], (size_t)h->B * sizeof(int), hipHostMallocDefault));
     HIPCHK(h, hipEventCreateWithFlags(&h->h_idx_ev[i], hipEventDisableTiming));
@@ -2130,6 +2189,7 @@ int dsact_destroy(dsact_handle* h) {
     if (h->h_idx[i]) hipHostFree(h->h_idx[i]);
     if (h->h_idx_ev[i]) hipEventDestroy(h->h_idx_ev[i]);
   }
+  if (h->handoff_host) hipHostFree(h->handoff_host);
   if (h->d_tiles) hipFree(h->d_tiles);
   if (h->alt.d_tiles) hipFree(h->alt.d_tiles);
   if (h->alt_ws) hipFree(h->alt_ws);
@@ -2174,7 +2234,7 @@ int dsact_sync(dsact_handle* h) {
   if (!h) return DSACT_E_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  return DSACT_OK;
+  return check_handoff(h);
 }
 
 size_t dsact_online_count(const dsact_handle* h) { return h ? h->n_online : 0; }
@@ -2226,11 +2286,7 @@ int dsact_get_state(dsact_handle* h, int32_t adam_steps[3], float mean_std[2]) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   DevState st;
   HIPCHK(h, hipMemcpy(&st, h->st, sizeof(st), hipMemcpyDeviceToHost));
-  if (h->chain_flags) {   // merged forward launch: a consumer that gave up waiting leaves this word set (statistics read NaN too)
-    int timed_out = 0;
-    HIPCHK(h, hipMemcpy(&timed_out, h->chain_flags + kChainFlags, sizeof(int), hipMemcpyDeviceToHost));
-    if (timed_out) return fail(h, DSACT_E_HIP, "a forward workgroup timed out waiting for its producers' ready flags (results are invalid)");
-  }
+  TRY(check_handoff(h));
   if (adam_steps) { adam_steps[0] = st.t_q; adam_steps[1] = st.t_pi; adam_steps[2] = st.t_alpha; }
   if (mean_std) { mean_std[0] = st.ms_init ? st.ms1 : -1.0f; mean_std[1] = st.ms_init ? st.ms2 : -1.0f; }
   return DSACT_OK;
@@ -2661,6 +2717,10 @@ int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) 
   HIPCHK(h, hipSetDevice(h->device));
   drop_graphs(h);
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->flags_dirty && h->chain_flags) {   // not inside the graph: the captured updates clear the flags themselves
+    HIPCHK(h, hipMemset(h->chain_flags, 0, kChainFlags * sizeof(int)));
+    h->flags_dirty = false;
+  }
   if ((flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) && steps_per_graph % h->cfg.delay_update)
     return fail(h, DSACT_E_INVALID, "with DSACT_F_SKIP_ACTOR_ON_OFF_ITERS steps_per_graph must be a multiple of delay_update");
   // Merged gather (MLP nets, fused single-launch-chain update): one gather launch opens the graph; every update's
@@ -2685,6 +2745,7 @@ int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) 
 
 // n_groups back-to-back replays of the captured updates
 static int launch_groups(dsact_handle* h, int64_t n_groups) {
+  h->uev_valid = false;
   int64_t i = 0;
   for (; i < n_groups; ++i) HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
   return DSACT_OK;
@@ -2701,6 +2762,7 @@ static int set_device_iteration(dsact_handle* h, long long it) {
 
 int dsact_graph_run(dsact_handle* h, int64_t first_iteration, int64_t n_steps) {
   if (!h) return DSACT_E_INVALID;
+  TRY(check_handoff(h));
   if (!h->graph_exec) return fail(h, DSACT_E_STATE, "dsact_graph_build first");
   if (n_steps % h->graph_steps) return fail(h, DSACT_E_INVALID, "n_steps must be a multiple of steps_per_graph");
   if ((h->graph_flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) && first_iteration % h->cfg.delay_update)
@@ -2832,7 +2894,7 @@ static int enqueue_stats(dsact_handle* h, float* dst) {
   a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.out = dst;
   // a gradient computed here and not yet applied (get_remote_update_info): report the mean_std its loss used
   a.ms_tail = h->have_local_tail && h->cfg.algo == 0 ? h->grads + h->n_online : nullptr;
-  a.spin_timeout = h->chain_flags ? h->chain_flags + kChainFlags : nullptr;
+  a.spin_timeout = nullptr;   // a timed-out hand-over fails the reading call itself (check_handoff)
   const bool was_prof = h->profiling;
   h->profiling = false;
   int rc = launch(h, "stats", k_stats, dim3(1), dim3(64), 0, a);
@@ -2847,6 +2909,7 @@ int dsact_read_stats(dsact_handle* h, float out[16]) {
   TRY(enqueue_stats(h, h->stats));
   HIPCHK(h, hipMemcpyAsync(out, h->stats, 16 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  TRY(check_handoff(h));
   out[15] = -1.0f;
   if (h->uev_valid) {
     float ms = 0.f;
@@ -2867,7 +2930,7 @@ int dsact_stats_read(dsact_handle* h, int32_t slot, float out[16]) {
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpyAsync(out, h->stats + 16 * (1 + slot), 16 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  return DSACT_OK;
+  return check_handoff(h);
 }
 
 // ---- measurement -----------------------------------------------------------------------------------
@@ -2908,7 +2971,7 @@ int dsact_time_steps(dsact_handle* h, int64_t first_iteration, int64_t n_steps, 
   }
   HIPCHK(h, hipEventElapsedTime(ms_total, h->tev0, h->tev1));
   h->have_batch = true;   // the last update's minibatch stays staged
-  return DSACT_OK;
+  return check_handoff(h);
 }
 
 int dsact_time_stage(dsact_handle* h, int32_t stage, int32_t reps, float* ms_total, double* macs) {
@@ -3037,6 +3100,59 @@ int dsact_debug_read(dsact_handle* h, const char* name, float* out, size_t cap, 
     HIPCHK(h, hipMemcpy(out, src, cnt * sizeof(float), hipMemcpyDeviceToHost));
   }
   *n = cnt;
+  return DSACT_OK;
+}
+
+namespace {
+__global__ void k_debug_fill(float* p, long long rows, long long ld, int col0, int ncols, float v) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * ncols) return;
+  p[(i / ncols) * ld + col0 + (i % ncols)] = v;
+}
+int debug_fill(dsact_handle* h, float* p, long long rows, long long ld, int col0, int ncols, float v) {
+  if (!p || rows * ncols <= 0) return DSACT_OK;
+  const long long n = rows * ncols;
+  hipLaunchKernelGGL(k_debug_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, p, rows, ld, col0, ncols, v);
+  return hipGetLastError() == hipSuccess ? DSACT_OK : fail(h, DSACT_E_HIP, "debug fill failed");
+}
+}  // namespace
+
+int dsact_debug_set(dsact_handle* h, const char* name, double value) {
+  if (!h || !name) return DSACT_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!strcmp(name, "withhold_flag")) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    drop_graphs(h);   // the switch travels in the kernel arguments
+    h->debug_withhold = value != 0.0 ? 1 : 0;
+    return DSACT_OK;
+  }
+  if (!strcmp(name, "poison_handover")) {
+    // everything a merged launch hands from producers to consumers: the saved observation parts of the critics' first
+    // layers and the action columns the policy heads fill (both batch sets). A consumer that does not wait for -- or
+    // does not see -- its producer's stores then computes on `value` (tests pass NaN).
+    const float v = (float)value;
+    for (int i = 0; i < 4; ++i) TRY(debug_fill(h, h->zobs[i], 1, 0, 0, h->B * h->w[0], v));
+    float* rows[4] = {h->XP, h->X2, h->alt.XP, h->alt.X2};
+    for (float* r : rows) TRY(debug_fill(h, r, h->B, h->ldx, h->F, h->A, v));
+    for (int i = 0; i < 2; ++i) TRY(debug_fill(h, h->dAq[i], 1, 0, 0, h->B * 32, v));
+    return DSACT_OK;
+  }
+  if (!strcmp(name, "fwd_merge")) {   // A/B switch of the merged forward launch on a live handle (tests)
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    drop_graphs(h);
+    h->fwd_merge = value != 0.0 && h->chain_ok && h->B <= 256 && h->B / 4 <= kChainFlagSlices && chain_rg(h, 4) == 1;
+    return DSACT_OK;
+  }
+  return fail(h, DSACT_E_INVALID, "dsact_debug_set: unknown name '%s'", name);
+}
+
+int dsact_debug_get(const dsact_handle* h, const char* name, double* value) {
+  if (!h || !name || !value) return DSACT_E_INVALID;
+  if (!strcmp(name, "fwd_merge")) *value = h->fwd_merge ? 1.0 : 0.0;
+  else if (!strcmp(name, "bwd_merge")) *value = h->bwd_merge ? 1.0 : 0.0;
+  else if (!strcmp(name, "handoff_failures")) *value = (double)h->handoff_failures;
+  else if (!strcmp(name, "graph_steps")) *value = (double)h->graph_steps;
+  else return DSACT_E_INVALID;
   return DSACT_OK;
 }
 

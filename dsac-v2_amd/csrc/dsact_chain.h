@@ -495,7 +495,9 @@ struct FwdArgs {
   int v1_stats;
   const float* act_scale; const float* act_center; float lo_ls, hi_ls;
   long long* timeline;
-  int* spin_timeout;                // merged launch: set to 1 by a consumer that gave up waiting (surfaces as NaN statistics)
+  int* spin_timeout;                // merged launch: set to 1 by a consumer that gave up waiting. The word lives in mapped
+                                    // HOST memory: every entry point of the library checks it and fails the call
+  int debug_withhold;               // tests only (dsact_debug_set "withhold_flag"): unit 0 / slice 0 never raises its flag
   int* bwd_counters; int n_bwd_counters;   // arrival counters of the merged backward launch: cleared by the forward launch
 };
 
@@ -514,11 +516,16 @@ __device__ __forceinline__ void pack_store4(float* p, const f32x4& v, int agent)
     nt_store4(p, v);
   }
 }
+// every outstanding vector-memory operation of this wave (stores included) has been acknowledged, then the workgroup
+// barrier: what the producers of an in-launch hand-over run before they raise a flag / bump a counter
+__device__ __forceinline__ void stores_acked_barrier() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 // arrival counters of the merged backward launch: a finished producer workgroup adds 1 (after its stores are
 // acknowledged); a consumer waits until `need` producers have arrived (bounded, like chain_wait)
 __device__ __forceinline__ void chain_arrive(int* c0, int* c1) {
   if (!c0 && !c1) return;      // workgroup-uniform
-  __syncthreads();
+  stores_acked_barrier();
   if (threadIdx.x == 0) {
     if (c0) __hip_atomic_fetch_add(c0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (c1) __hip_atomic_fetch_add(c1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -538,12 +545,14 @@ __device__ __forceinline__ void chain_wait_count(const int* c, int need, int* ti
   __syncthreads();
 }
 
-// producer side of the merged launch: every wave's stores have been acknowledged (the barrier waits vmcnt(0)), then one
-// thread writes this XCD's L2 back and raises the flag at agent scope
-__device__ __forceinline__ void chain_publish(int* flag) {
+// producer side of the merged launch: every wave waits until its agent-scope (write-through) stores have been
+// acknowledged, the workgroup meets, then one thread raises the flag at agent scope. The wait is EXPLICIT: on gfx950
+// hipcc lowers __syncthreads() to a bare s_barrier when it sees no LDS/global dependency of its own, so the flag store
+// could otherwise overtake the hand-over data.
+__device__ __forceinline__ void chain_publish(int* flag, int value = 1) {
   if (!flag) return;      // workgroup-uniform
-  __syncthreads();        // s_waitcnt vmcnt(0) in every wave: its agent-scope stores have been acknowledged
-  if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  stores_acked_barrier();
+  if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // consumer side: thread 0 polls (bounded: a lost flag must not hang the GPU)
 __device__ __forceinline__ void chain_wait(const int* f0, const int* f1, int* timeout) {
@@ -568,6 +577,7 @@ __device__ __forceinline__ void chain_fwd_body(const FwdArgs& a, int block, floa
   if (!chain_decode(block, a.n_units, a.n_slices, unit, slice)) return;
   const FwdUnit& u = a.u[unit];
   constexpr int W = 64 * NW, SH = W / 4, R = 4 * RG, NTHR = 64 * NW, TPR = NTHR / R;
+  int* const done_flag = (u.done && !(a.debug_withhold && unit == 0 && slice == 0)) ? u.done + slice : nullptr;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane4 = lane * 4;
@@ -698,7 +708,7 @@ __device__ __forceinline__ void chain_fwd_body(const FwdArgs& a, int block, floa
       }
     }
     CTL(a.timeline, 2);
-    if (u.seg == SEG_OBS_ONLY) { CTLR(a.timeline, 15); chain_publish(u.done ? u.done + slice : nullptr); return; }
+    if (u.seg == SEG_OBS_ONLY) { CTLR(a.timeline, 15); chain_publish(done_flag); return; }
   }
   if (do_act) gemm44_seg<RG>(ws, w0, a.s_obs, S0, w1, 0, more, lds, xs_in, S.ld_in, lane4, acc);
   CTL(a.timeline, 3);
@@ -730,7 +740,7 @@ __device__ __forceinline__ void chain_fwd_body(const FwdArgs& a, int block, floa
       CTL(a.timeline, 5 + 2 * l);
     }
   }
-  if (u.head == HEAD_NONE) { CTLR(a.timeline, 15); chain_publish(u.done ? u.done + slice : nullptr); return; }
+  if (u.head == HEAD_NONE) { CTLR(a.timeline, 15); chain_publish(done_flag); return; }
   // ---- output layer: 16x16x4 tiles, contraction split over the waves, partials through LDS
   const int hl = ((L - 1) & 1) ? S.off_h1 : S.off_h0;
   narrow_mma<4>(hf, nto, wave, lds, hl + ((lane & 15) & (R - 1)) * S.ld_h + 4 * (lane >> 4), red, lane);
@@ -747,7 +757,7 @@ __device__ __forceinline__ void chain_fwd_body(const FwdArgs& a, int block, floa
     }
     CTL(a.timeline, 13);
     CTLR(a.timeline, 15);
-    chain_publish(u.done ? u.done + slice : nullptr);
+    chain_publish(done_flag);
     return;
   }
   // policy: (mu, raw log-std) -> tanh-Gaussian rsample (act_distribution_cls.py:44-54)
@@ -786,7 +796,7 @@ __device__ __forceinline__ void chain_fwd_body(const FwdArgs& a, int block, floa
     }
   }
   CTLR(a.timeline, 15);
-  chain_publish(u.done ? u.done + slice : nullptr);
+  chain_publish(done_flag);
 }
 
 template <int NW, int RG>

@@ -1075,8 +1075,10 @@ __device__ __forceinline__ void finalize_update(const FusedOpt& fo) {
   finalize_update_s(fo.st, fo.online, fo.adam_m, fo.adam_v, fo.grads, fo.n_total, fo.auto_alpha, fo.b1w, fo.beta2, fo.b2w, fo.eps);
 }
 
-// workgroup barrier that orders LDS only: __syncthreads() also waits for vmcnt(0), i.e. for every global load AND store
-// in flight (prefetched operands, an epilogue's stores)
+// workgroup barrier that orders LDS only. (__syncthreads() may ALSO drain vmcnt -- every global load and store in
+// flight: prefetched operands, an epilogue's stores -- when the compiler sees memory operations around it, and may
+// emit a bare s_barrier when it does not: code that needs either behaviour says so explicitly, here and in
+// stores_acked_barrier() of dsact_chain.h.)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __global__ void __launch_bounds__(kThreads) k_stage_table(TableArgs a) {

@@ -103,6 +103,7 @@ class LazyTbInfoV1(_v2.LazyTbInfo):
 
 class DSAC_V1_HIP(_v2.DSAC_V2_HIP):
     """kwargs: the reference's flat dict (dsac_v1.py:68-82) plus the additive HIP keys of DSAC_V2_HIP."""
+    _tb_cls = LazyTbInfoV1
 
     TD_bound = _v2._Hyper("TD_bound")
 
@@ -143,6 +144,7 @@ class DSAC_V1_HIP(_v2.DSAC_V2_HIP):
             seed = kwargs.get("seed") or 0
             self.engine.set_device_rng((int(seed) * 0x9E3779B97F4A7C15 + 0x1234567) % (1 << 63) or 1)
         self._serial = 0
+        self._last_tb = None
 
     @property
     def adjustable_parameters(self):
@@ -163,8 +165,7 @@ class DSAC_V1_HIP(_v2.DSAC_V2_HIP):
         self._stage(data)
         self._noise()
         self.engine.step(int(iteration), self.flags)
-        self._serial += 1
-        return LazyTbInfoV1(self, self._serial, (time.time() - t0) * 1000)
+        return self._new_tb(t0)
 
     def get_remote_update_info(self, data: Dict, iteration: int) -> Tuple[dict, dict]:
         t0 = time.time()
@@ -173,8 +174,7 @@ class DSAC_V1_HIP(_v2.DSAC_V2_HIP):
         self._noise()
         self.engine.compute_grads(int(iteration), self.flags)
         self.engine.sync()   # the caller reads the returned gradient tensors with torch ops on torch's stream
-        self._serial += 1
-        tb = LazyTbInfoV1(self, self._serial, (time.time() - t0) * 1000)
+        tb = self._new_tb(t0)
         v = self._grad_views()
         info = {"q_grad": v["q"], "policy_grad": v["policy"], "iteration": iteration}
         if self.auto_alpha:

@@ -428,9 +428,26 @@ class HipBatch(dict):
         super().__init__()
         self.engine, self.idxs = engine, np.array(idxs, dtype=np.int64, copy=True)
         self.serial = engine.stage_serial
+        # ring write position when the rows were sampled: the reference's batch is a COPY taken at sample time
+        # (replay_buffer.py:85-90), so a late re-gather must not silently train on rows add_batch has replaced
+        self._ptr0, self._added0 = engine.buffer_ptr, engine.rows_added
+
+    def _overwritten(self):
+        cap, written = self.engine.buffer_capacity, self.engine.rows_added - self._added0
+        if written <= 0 or cap <= 0:
+            return 0
+        if written >= cap:
+            return int(self.idxs.size)
+        return int((((self.idxs - self._ptr0) % cap) < written).sum())
 
     def restage(self):
         if self.serial != self.engine.stage_serial:
+            n = self._overwritten()
+            if n:
+                raise RuntimeError(
+                    "HipBatch: %d of the %d sampled ring rows were overwritten by add_batch after sample_batch; the "
+                    "token re-gathers by index, so it would train on other transitions than the ones sampled. Use the "
+                    "token before adding to the buffer, or sample again." % (n, self.idxs.size))
             self.engine.gather(self.idxs)
             self.serial = self.engine.stage_serial
 
@@ -483,6 +500,7 @@ class DSAC_V2_HIP:
     `hip_flags` (DSACT_F_*), `global_batch` (data parallel)."""
 
     gamma, tau, auto_alpha, alpha, delay_update = (_Hyper(n) for n in ("gamma", "tau", "auto_alpha", "alpha", "delay_update"))
+    _tb_cls = LazyTbInfo
 
     def __init__(self, **kwargs):
         _check_supported(kwargs)
@@ -513,6 +531,7 @@ class DSAC_V2_HIP:
             seed = kwargs.get("seed") or 0
             self.engine.set_device_rng((int(seed) * 0x9E3779B97F4A7C15 + 0x1234567) % (1 << 63) or 1)
         self._serial = 0
+        self._last_tb = None
 
     @property
     def adjustable_parameters(self):
@@ -546,8 +565,20 @@ class DSAC_V2_HIP:
 
     # ---- reference surface ------------------------------------------------------------------------
     def _keep_previous_stats(self):
-        if self._serial:
+        """A reference-style caller may read update k's tb_info after issuing update k+1: its statistics are reduced
+        into a snapshot slot first -- unless nobody can read them any more (the dict was collected) or they already
+        have been (materialised): the common case of a trainer that logs every log_save_interval."""
+        prev = self._last_tb() if self._last_tb is not None else None
+        if self._serial and prev is not None and not prev._done:
             self.engine.stats_snapshot(self._serial)   # asynchronous; see LazyTbInfo._stats
+
+    def _new_tb(self, t0):
+        import weakref
+
+        self._serial += 1
+        tb = self._tb_cls(self, self._serial, (time.time() - t0) * 1000)
+        self._last_tb = weakref.ref(tb)
+        return tb
 
     def local_update(self, data: Dict, iteration: int) -> dict:
         t0 = time.time()
@@ -555,8 +586,7 @@ class DSAC_V2_HIP:
         self._stage(data)
         self._noise()
         self.engine.step(int(iteration), self.flags)
-        self._serial += 1
-        return LazyTbInfo(self, self._serial, (time.time() - t0) * 1000)
+        return self._new_tb(t0)
 
     def _grad_views(self):
         lay, g = self.engine.layout, self.engine.grads
@@ -576,8 +606,7 @@ class DSAC_V2_HIP:
         self._noise()
         self.engine.compute_grads(int(iteration), self.flags)
         self.engine.sync()   # the caller reads the returned gradient tensors with torch ops on torch's stream
-        self._serial += 1
-        tb = LazyTbInfo(self, self._serial, (time.time() - t0) * 1000)
+        tb = self._new_tb(t0)
         v = self._grad_views()
         info = {"q1_grad": v["q1"], "q2_grad": v["q2"], "policy_grad": v["policy"], "iteration": iteration}
         if self.auto_alpha:

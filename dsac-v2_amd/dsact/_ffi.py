@@ -101,6 +101,8 @@ SYMBOLS = [
                                      C.POINTER(C.c_int32)]),
     ("dsact_debug_read", C.c_int, [_P, C.c_char_p, _FP, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("dsact_debug_names", C.c_char_p, []),
+    ("dsact_debug_set", C.c_int, [_P, C.c_char_p, C.c_double]),
+    ("dsact_debug_get", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double)]),
     ("dsact_policy_forward", C.c_int, [_P, _FP, C.c_int32, _FP]),
 ]
 

@@ -107,6 +107,8 @@ class DsactEngine:
             self.adam_v.data_ptr(), self.grads.data_ptr()))
         self._graph_steps = 0
         self.stage_serial = 0
+        self.buffer_capacity = 0
+        self.rows_added = 0      # rows ever written to the ring (HipBatch tokens detect overwritten rows with it)
 
     # ---- plumbing -----------------------------------------------------------------------------
     def _chk(self, rc):
@@ -178,6 +180,7 @@ class DsactEngine:
     # ---- replay ring -------------------------------------------------------------------------------
     def buffer_create(self, capacity: int):
         self._chk(self._lib.dsact_buffer_create(self._h, int(capacity)))
+        self.buffer_capacity = int(capacity)
 
     def buffer_add(self, obs, act, rew, obs2, done, logp=None):
         obs, act, rew, obs2, done = _f32(obs), _f32(act), _f32(rew), _f32(obs2), _f32(done)
@@ -185,6 +188,7 @@ class DsactEngine:
         lp = _f32(logp) if logp is not None else None
         self._chk(self._lib.dsact_buffer_add(self._h, n, _ffi.fptr(obs), _ffi.fptr(act), _ffi.fptr(rew),
                                              _ffi.fptr(obs2), _ffi.fptr(done), _ffi.fptr(lp)))
+        self.rows_added += n
 
     def buffer_fill_device(self, row0, obs, act, rew, obs2, done):
         """rows from torch CUDA tensors (synthetic benchmark buffers stay on the device)."""
@@ -194,6 +198,7 @@ class DsactEngine:
         self.torch.cuda.current_stream(self.device).synchronize()
         self._chk(self._lib.dsact_buffer_fill_device(self._h, int(row0), n, obs.data_ptr(), act.data_ptr(),
                                                      rew.data_ptr(), obs2.data_ptr(), done.data_ptr()))
+        self.rows_added += n
 
     @property
     def buffer_size(self):
@@ -395,6 +400,16 @@ class DsactEngine:
         n = C.c_size_t()
         self._chk(self._lib.dsact_debug_read(self._h, name.encode(), _ffi.fptr(buf), cap, C.byref(n)))
         return buf[: n.value].copy()
+
+    def debug_set(self, name: str, value: float):
+        self._chk(self._lib.dsact_debug_set(self._h, name.encode(), float(value)))
+        if name in ("withhold_flag", "fwd_merge"):
+            self._graph_steps = 0   # the library dropped the captured graph
+
+    def debug_get(self, name: str) -> float:
+        v = C.c_double()
+        self._chk(self._lib.dsact_debug_get(self._h, name.encode(), C.byref(v)))
+        return float(v.value)
 
     def policy_forward(self, obs) -> np.ndarray:
         obs = _f32(obs).reshape(-1, self.obs_dim)

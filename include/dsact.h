@@ -277,6 +277,16 @@ int dsact_profile_step(dsact_handle* h, int64_t iteration, uint32_t flags, dsact
  * names: see dsact_debug_names(). */
 int dsact_debug_read(dsact_handle* h, const char* name, float* out, size_t cap, size_t* n);
 const char* dsact_debug_names(void);
+/* Test hooks for the in-launch producer/consumer hand-overs of the merged launches (no reference counterpart: the
+ * reference's update is one synchronous CPU call, dsac_v2.py:102-105). A consumer workgroup waits a BOUNDED time for
+ * its producers; when it gives up, the next entry point of this library fails with DSACT_E_HIP, the merged launches are
+ * disabled for the handle and a captured graph is captured again without them.
+ *   dsact_debug_set(h, "withhold_flag", 1)      one producer never raises its flag (forces the timeout path)
+ *   dsact_debug_set(h, "poison_handover", v)    fills every buffer handed from producers to consumers with v (e.g. NaN)
+ *   dsact_debug_set(h, "fwd_merge", 0|1)        merged forward launch off / on (when the shape allows it)
+ *   dsact_debug_get(h, "fwd_merge" | "bwd_merge" | "handoff_failures" | "graph_steps", &v) */
+int dsact_debug_set(dsact_handle* h, const char* name, double value);
+int dsact_debug_get(const dsact_handle* h, const char* name, double* value);
 /* stand-alone fused-MLP forward of the policy net on a host batch (sampler / evaluator feed):
  * logits[n*2A] = (mean | std) exactly as StochaPolicy.forward returns (networks/mlp.py:79-100) */
 int dsact_policy_forward(dsact_handle* h, const float* obs_host, int32_t n, float* logits_host);

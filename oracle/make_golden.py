@@ -141,6 +141,9 @@ def gen_humanoid_digest(ref, out_dir):
         out["s%d/grad_s" % it] = grad[::DIGEST_STRIDE].copy()
         out["s%d/params_s" % it] = params[::DIGEST_STRIDE].copy()
         out["s%d/targets_s" % it] = targets[::DIGEST_STRIDE].copy()
+        # the stride misses the arena's last element: log_alpha's gradient and value are stored on their own
+        out["s%d/grad_log_alpha" % it] = grad[-1:].copy()
+        out["s%d/log_alpha" % it] = params[-1:].copy()
         out["s%d/grad_max" % it] = np.array([max(float(p.grad.abs().max()) for p in g) for g in groups] + [abs(float(ga))])
         out["s%d/grad_l2" % it] = np.array([float(p.grad.double().norm()) for p in online])
         out["s%d/param_abs_sums" % it] = np.array([float(p.detach().double().abs().sum()) for p in online])

@@ -294,9 +294,13 @@ def test_humanoid_b256_against_reference_digest():
         e.sync()
         g = e.grads.cpu().numpy()[:n_tot]
         gs, gs_ref, gmax = g[idx], z["s%d/grad_s" % it], z["s%d/grad_max" % it]
-        for k in range(4):
+        for k in range(3):
             m = seg_of == k
+            assert m.any()
             rep.cmp("it%d grad.%s (sampled)" % (it, names[k]), gs[m], gs_ref[m], 1e-9 + 3e-5 * float(gmax[k]))
+        # the stride misses the arena's last element: log_alpha's gradient is pinned on its own (the alpha gradient is
+        # -mean(logp + target_entropy), dsac_v2.py:312-318 -- a mean of B terms of size ~10: 1e-4 absolute like tb_info)
+        rep.cmp("it%d grad.log_alpha" % it, g[n_tot - 1:n_tot], z["s%d/grad_log_alpha" % it], 1e-4)
         # per-tensor L2 norms of the whole gradient (state_dict order inside each net)
         l2, off = [], 0
         for net_name, sd_prefix in (("q1", "q1."), ("q2", "q2."), ("policy", "policy.")):
@@ -316,6 +320,7 @@ def test_humanoid_b256_against_reference_digest():
         p_hip, t_hip = e.online.cpu().numpy()[:n_tot], e.target.cpu().numpy()
         rep.cmp_params("it%d params vs reference (sampled)" % it, p_hip[idx], z["s%d/params_s" % it], noise_b.bound, 1e-6,
                        noise_b.lr_steps)
+        rep.cmp("it%d log_alpha vs reference" % it, p_hip[n_tot - 1:n_tot], z["s%d/log_alpha" % it], 1e-6)
         n_t = t_hip.size
         idx_t = idx[idx < n_t]
         tau = cfg["tau"]
@@ -439,6 +444,16 @@ def test_sampling_ahead_restages_the_older_token():
     alg.engine.sync()
     assert np.array_equal(alg.engine.read_batch()["rew"], want_first)
     assert np.array_equal(second["rew"].numpy(), second.idxs.astype(np.float32))
+    # rows replaced after sampling: the reference's batch is a copy taken at sample time; a token that is no
+    # longer the staged minibatch re-gathers by index and must refuse once add_batch has overwritten its rows
+    third, fourth = buf.sample_batch(B), buf.sample_batch(B)
+    buf.add_batch([(rng.standard_normal(O).astype(np.float32), {}, rng.uniform(-.4, .4, A).astype(np.float32), -1.0,
+                    rng.standard_normal(O).astype(np.float32), False, 0.0, {}) for _ in range(N)])
+    with pytest.raises(RuntimeError, match="overwritten"):
+        alg.local_update(third, 1)
+    alg.local_update(fourth, 1)      # still the staged minibatch: the staging area IS the copy taken at sample time
+    alg.engine.sync()
+    assert np.array_equal(alg.engine.read_batch()["rew"], fourth.idxs.astype(np.float32))
     assert np.array_equal(first["rew"].numpy(), want_first)
 
 
@@ -1168,3 +1183,119 @@ def test_merged_backward_launch_optin_equals_default(monkeypatch):
     assert algs[0].engine.get_state() == algs[1].engine.get_state()
     names = [k for k, _, _ in algs[0].engine.profile_step(7)]
     assert "chain_bwd" in names and "chain_bwd_q" not in names
+
+
+def _fill_ring(e, N, O, A, seed):
+    e.buffer_create(N)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    e.buffer_fill_device(0, torch.randn(N, O, device="cuda", generator=g), torch.rand(N, A, device="cuda", generator=g) - .5,
+                         torch.randn(N, device="cuda", generator=g), torch.randn(N, O, device="cuda", generator=g),
+                         (torch.rand(N, device="cuda", generator=g) < .05).float())
+
+
+def test_handover_buffers_poisoned_between_updates():
+    """ADVICE r2 (ordering of the in-launch hand-over): everything the merged forward hands from producer to consumer
+    workgroups (saved observation parts `zobs`, the sampled-action columns, dL/da) is filled with NaN before EVERY
+    update. A consumer that passed its flag before the producer's stores had landed -- or that read a stale cached
+    copy -- would compute on NaN. 40 updates at the BASELINE shape: merged == two launches bit for bit, all finite."""
+    O, A, hid, B = 376, 17, (256, 256, 256), 256
+    algs = [make_pair(O, A, hid, B, seed=31)[0] for _ in range(2)]
+    algs[1].engine.debug_set("fwd_merge", 0)
+    assert algs[0].engine.debug_get("fwd_merge") == 1.0 and algs[1].engine.debug_get("fwd_merge") == 0.0
+    rng = np.random.default_rng(14)
+    for it in range(40):
+        data = synth_batch(rng, B, O, A, p_done=0.1)
+        torch.manual_seed(500 + it)
+        noise = draw_noise(B, A)
+        for a in algs:
+            e = a.engine
+            e.load_batch(*(data[k].numpy() for k in ("obs", "act", "rew", "obs2", "done")))
+            e.set_noise(noise["eps_new"].numpy(), noise["eps_2"].numpy(), noise["z5"].numpy(), noise["z6"].numpy())
+            e.debug_set("poison_handover", float("nan"))
+            e.step(it)
+    for name in ("online", "target", "adam_m", "adam_v"):
+        t0, t1 = getattr(algs[0].engine, name), getattr(algs[1].engine, name)
+        assert bool(torch.isfinite(t0).all()), name
+        assert torch.equal(t0, t1), name
+    st = algs[0].engine.read_stats()
+    assert all(np.isfinite(v) for k, v in st.items())
+    assert algs[0].engine.debug_get("handoff_failures") == 0.0
+
+
+def test_forced_handover_timeout_fails_the_call_and_falls_back():
+    """a consumer that gives up waiting must FAIL the call, not poison the statistics. One producer
+    withholds its ready flag ("withhold_flag"): the next synchronising entry point returns DSACT_E_HIP, the handle drops
+    to the unmerged launches (and re-captures its graph without the merged one), and from restored state it trains on,
+    bit-identical to an engine that never merged."""
+    from dsact._ffi import DsactError
+
+    O, A, hid, B, N = 24, 6, (128, 128), 64, 1024
+    alg, _ = make_pair(O, A, hid, B, seed=41)
+    ref, _ = make_pair(O, A, hid, B, seed=41)
+    ref.engine.debug_set("fwd_merge", 0)
+    e, r = alg.engine, ref.engine
+    assert e.debug_get("fwd_merge") == 1.0
+    for x in (e, r):
+        _fill_ring(x, N, O, A, 8)
+        x.set_device_rng(5)
+        np.random.seed(4)
+        x.upload_index_table(np.random.randint(0, N, size=(8, B)))
+    snap = {k: v.clone() for k, v in alg.networks.state_dict().items()}
+    arenas = {n: getattr(e, n).clone() for n in ("adam_m", "adam_v")}
+    state = e.get_state()
+    # --- a graph replay with a withheld flag: the launch succeeds, the first synchronising call fails
+    e.debug_set("withhold_flag", 1)
+    e.graph_build(2)
+    e.graph_run(0, 2)                 # asynchronous: returns before the consumers give up
+    with pytest.raises(DsactError, match="hand-over timed out"):
+        e.sync()
+    assert e.debug_get("handoff_failures") == 1.0 and e.debug_get("fwd_merge") == 0.0
+    assert e.debug_get("graph_steps") == 2.0     # captured again, without the merged launch
+    assert "chain_fwd_a" in [k for k, _, _ in e.profile_step(0)]
+    e.sync()                                      # the word was consumed: no second error
+    # --- restore the state the failed call invalidated, then both engines run the same updates
+    alg.networks.load_state_dict(snap)
+    for n, t in arenas.items():
+        getattr(e, n).copy_(t)
+    torch.cuda.synchronize()
+    e.set_state(adam_steps=state["adam_steps"], mean_std=state["mean_std"])
+    r.graph_build(2)
+    for x in (e, r):
+        x.graph_run(0, 4)
+        x.sync()
+    for name in ("online", "target", "adam_m", "adam_v"):
+        assert torch.equal(getattr(e, name), getattr(r, name)), name
+    st = e.read_stats()
+    assert all(np.isfinite(v) for v in st.values())
+    # eager path after the fallback too
+    with pytest.raises(DsactError):
+        e.debug_set("no_such_switch", 1)
+
+
+def test_repeated_forward_half_clears_its_ready_flags():
+    """dsact_dp_enqueue_forward may be called twice (or never be followed by its backward); the second merged
+    forward must not find the first one's ready flags raised. Two forwards + backward == one forward + backward."""
+    O, A, hid, B, N = 24, 6, (128, 128), 64, 512
+    outs = []
+    for reps in (1, 2):
+        alg, _ = make_pair(O, A, hid, B, seed=43)
+        e = alg.engine
+        assert e.debug_get("fwd_merge") == 1.0
+        _fill_ring(e, N, O, A, 9)
+        np.random.seed(6)
+        e.upload_index_table(np.random.randint(0, N, size=(2, B)))
+        torch.manual_seed(8)
+        noise = draw_noise(B, A)
+        e.set_noise(noise["eps_new"].numpy(), noise["eps_2"].numpy(), noise["z5"].numpy(), noise["z6"].numpy())
+        e.dp_set_strict(True)
+        e.dp_begin(0)
+        for k in range(reps):
+            e.dp_forward()
+            if k + 1 < reps:
+                e.debug_set("poison_handover", float("nan"))
+        e.sync()
+        e.dp_backward()
+        e.sync()
+        outs.append(e.grads.clone())
+        assert e.debug_get("handoff_failures") == 0.0
+    assert bool(torch.isfinite(outs[0]).all()) and torch.equal(outs[0], outs[1])

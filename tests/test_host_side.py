@@ -209,3 +209,39 @@ def test_bench_gpus_flag_spawns_ranks_and_never_underreports(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 2 and "refusing" in r.stderr, (r.returncode, r.stderr[-500:])
     assert "n_gpus" not in r.stdout
+
+
+def test_hip_batch_detects_rows_overwritten_after_sampling():
+    """a HipBatch token re-gathers by ring index when it is no longer the staged minibatch; the reference's
+    batch is a copy taken at sample time (training/replay_buffer.py:85-90), so the token must notice that add_batch has
+    replaced its rows (host-side logic only: a fake engine records the calls)."""
+    from dsac_v2_hip import HipBatch
+
+    class FakeEngine:
+        def __init__(self, cap, ptr):
+            self.buffer_capacity, self.buffer_ptr, self.rows_added, self.stage_serial, self.gathers = cap, ptr, 0, 0, 0
+
+        def gather(self, idx):
+            self.gathers += 1
+            self.stage_serial += 1
+
+        def add(self, n):
+            self.rows_added += n
+            self.buffer_ptr = (self.buffer_ptr + n) % self.buffer_capacity
+
+    e = FakeEngine(100, 90)
+    e.stage_serial = 1
+    tok = HipBatch(e, np.array([0, 5, 89, 95]))
+    tok.restage()
+    assert e.gathers == 0                       # it IS the staged minibatch
+    e.stage_serial += 1                         # somebody else staged another one
+    e.add(5)                                    # rows 90..94: none of the token's
+    tok.restage()
+    assert e.gathers == 1
+    e.stage_serial += 1
+    e.add(6)                                    # rows 95..99, 0: two of the token's rows are gone
+    assert tok._overwritten() == 2
+    with pytest.raises(RuntimeError, match="2 of the 4 sampled ring rows were overwritten"):
+        tok.restage()
+    e.add(200)
+    assert tok._overwritten() == 4

@@ -41,6 +41,9 @@ def test_humanoid_b256_matches_reference_digest():
         np.testing.assert_allclose(orc.flat_grads().numpy()[::stride], z["s%d/grad_s" % it], rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(orc.flat_params().numpy()[::stride], z["s%d/params_s" % it], rtol=0, atol=2e-6)
         np.testing.assert_allclose(orc.flat_targets().numpy()[::stride], z["s%d/targets_s" % it], rtol=0, atol=2e-6)
+        # the arena's last element (log_alpha) is not on the stride: pinned explicitly
+        np.testing.assert_allclose(orc.flat_grads().numpy()[-1:], z["s%d/grad_log_alpha" % it], rtol=1e-6)
+        np.testing.assert_allclose(orc.flat_params().numpy()[-1:], z["s%d/log_alpha" % it], rtol=0, atol=1e-7)
         l2 = [float(g.double().norm()) for n in ("q1", "q2", "policy") for g in (p.grad for p in orc.p[n])]
         np.testing.assert_allclose(l2, z["s%d/grad_l2" % it], rtol=1e-5)
 
