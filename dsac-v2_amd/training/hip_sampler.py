@@ -21,6 +21,13 @@ __all__ = ["HipOffSampler", "create_sampler"]
 SAMPLER_TIME_KEY = "Time/Sampler time [ms]-RL iter"  # reference utils/tensorboard_setup.py:150
 
 
+def _container(**kwargs):
+    """`__import__(algorithm.lower()).ApproxContainer(**kwargs)` -- the reference's rule (off_sampler.py:19-23,
+    evaluator.py:16-20): a plain CPU torch module until the learner's attached container replaces it"""
+    module = __import__(kwargs["algorithm"].lower())
+    return getattr(module, "ApproxContainer")(**kwargs)
+
+
 def _reset(env):
     out = env.reset()
     if isinstance(out, tuple) and len(out) == 2 and isinstance(out[1], dict):
@@ -36,7 +43,12 @@ class HipOffSampler:
         if kwargs.get("seed") is not None and hasattr(self.env, "seed"):
             self.env.seed(kwargs["seed"])  # reference set_seed(..., env) seeds with the plain seed
         self.obs, self.info = _reset(self.env)
-        self.networks = kwargs.get("networks")  # the trainer assigns alg.networks (trainer.py:24-26)
+        # The reference builds its own ApproxContainer here (off_sampler.py:19-23) -- the trainer replaces it with the
+        # learner's (trainer.py:24-26), but its random initialisation consumes the torch global generator, so a run
+        # from the same seed only follows the reference's trajectory if this one is built too.
+        self.networks = kwargs.get("networks")
+        if self.networks is None and "algorithm" in kwargs:
+            self.networks = _container(**kwargs)
         self.noise_params = kwargs.get("noise_params")
         if self.noise_params is not None:
             raise NotImplementedError("exploration noise is not part of the DSAC-T path (default None)")

@@ -117,6 +117,9 @@ class HipEvaluator:
         if kwargs.get("seed") is not None and hasattr(self.env, "seed"):
             self.env.seed(kwargs["seed"])  # reference evaluator.py:15: set_seed(..., env) seeds with the plain seed
         self.networks = kwargs.get("networks")
+        if self.networks is None and "algorithm" in kwargs:   # evaluator.py:16-20: consumes the torch generator like the reference
+            from training.hip_sampler import _container
+            self.networks = _container(**kwargs)
         self.num_eval_episode = kwargs.get("num_eval_episode", 5)
 
     def run_an_episode(self):

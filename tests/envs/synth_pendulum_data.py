@@ -50,4 +50,9 @@ class SynthPendulum:
 
 
 def env_creator(**kwargs):
-    return SynthPendulum(seed=kwargs.get("seed", 0) or 0)
+    env = SynthPendulum(seed=kwargs.get("seed", 0) or 0)
+    if kwargs.get("max_episode_steps"):
+        # the reference wraps the env in TimeLimit(max_episode_steps) (utils/wrapping_env.py:102-105); flagging the same
+        # step here makes the bare env (GPU box: no reference, no wrappers) behave like the wrapped one
+        env.max_episode_steps = int(kwargs["max_episode_steps"])
+    return env

@@ -1,0 +1,164 @@
+"""Row a4 (OffSerialTrainer.step / train, training/trainer.py:60-152): the training LOOP against the unmodified reference.
+
+  * CPU, where /root/reference is mounted: the reference's own algorithm and replay buffer are plugged into
+    HipOffSerialTrainer + HipOffSampler + HipEvaluator and the run is compared with the reference's loop driven by its
+    own factories (oracle/trainer_trajectory.py::run_reference) -- same seed, same env. With the arithmetic identical
+    on both sides the loop logic must agree EXACTLY: replay indices, ring size/ptr, the ordered (tag, step, value) list
+    of every scalar written, checkpoint file names and their order, evaluation returns, every update's tb_info.
+  * `-m gpu`: the whole HIP stack (DSAC_V2_HIP + HipReplayBuffer + HIP acting forward, strict_rng) against the committed
+    trajectory tests/golden/trainer_trajectory.json the reference produced: indices / cadence / file names exactly,
+    statistics and evaluation returns at the parity gates of DESIGN section 5.
+"""
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_loader
+from oracle.trainer_trajectory import ENVS, GOLDEN, TIME_TAGS, TRAINER_CASE, Hooks, run_reference, tb_floats
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(os.path.dirname(HERE), "dsac-v2_amd")
+RAM_TAG = "RAM/RAM [MB]-RL iter"
+
+
+def derived_kwargs(case, save_folder, **over):
+    """what utils/init_args.py:11-83 adds to the argument dict (shapes and limits from the env, bookkeeping keys, the
+    global seeds of utils/common_utils.py:140-157) -- restated here because init_args itself is outside the path and
+    the GPU box has no reference checkout"""
+    import plugin
+
+    kw = dict(case, save_folder=save_folder, **over)
+    env = plugin.create_env(**kw)
+    kw["use_gpu"] = bool(kw.get("enable_cuda", False))
+    kw["batch_size_per_sampler"] = kw["sample_batch_size"]
+    kw["obsv_dim"] = env.observation_space.shape[0]
+    kw["action_dim"] = env.action_space.shape[0]
+    kw["action_high_limit"] = env.action_space.high.astype("float32")
+    kw["action_low_limit"] = env.action_space.low.astype("float32")
+    kw["additional_info"] = {}
+    kw["cnn_shared"] = False
+    os.makedirs(os.path.join(save_folder, "apprfunc"), exist_ok=True)
+    seed = int(kw["seed"])
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    return kw
+
+
+def run_hip_loop(kw, alg, buffer):
+    """our sampler / evaluator / trainer around (alg, buffer); returns the same trajectory dict as run_reference"""
+    import plugin
+
+    sampler = plugin.create_sampler(**kw)
+    evaluator = plugin.create_evaluator(**kw)
+    updates, evals, buf_state = [], [], []
+    with Hooks() as hk:
+        trainer = plugin.create_trainer(alg, sampler, buffer, evaluator, **kw)
+        inner_update, inner_eval, inner_sample = alg.local_update, evaluator.run_evaluation, buffer.sample_batch
+
+        def local_update(data, it):
+            tb = inner_update(data, it)
+            updates.append(tb_floats(tb))     # read at once: device statistics are kept for the last 16 updates only
+            return tb
+
+        alg.local_update = local_update
+        evaluator.run_evaluation = lambda it: (lambda r: (evals.append([int(it), float(r)]), r)[1])(inner_eval(it))
+        buffer.sample_batch = lambda n: (buf_state.append([int(buffer.size), int(buffer.ptr)]), inner_sample(n))[1]
+        trainer.train()
+    scalars = [[r["tag"], r["step"], r["value"]] for r in map(json.loads, open(os.path.join(kw["save_folder"], "scalars.jsonl")))]
+    return {"indices": hk.indices, "buffer": buf_state, "scalars": scalars, "saved": hk.saved,
+            "apprfunc_dir": sorted(os.listdir(os.path.join(kw["save_folder"], "apprfunc"))), "evals": evals,
+            "tb_info": updates, "samples": int(sampler.get_total_sample_number())}
+
+
+def check_cadence(got, want):
+    """everything about the loop that does not depend on floating point"""
+    assert got["indices"] == want["indices"]
+    assert got["buffer"] == want["buffer"]
+    assert [s[:2] for s in got["scalars"]] == [s[:2] for s in want["scalars"]]
+    assert got["saved"] == want["saved"] and got["apprfunc_dir"] == want["apprfunc_dir"]
+    assert [e[0] for e in got["evals"]] == [e[0] for e in want["evals"]]
+    assert got["samples"] == want["samples"] and len(got["tb_info"]) == len(want["tb_info"])
+
+
+@pytest.mark.skipif(not ref_loader.reference_available(), reason="reference not mounted")
+def test_trainer_loop_equals_the_reference_loop_exactly(tmp_path):
+    ref_loader.import_reference()
+    for p in (PKG, ENVS):
+        if p not in sys.path:
+            sys.path.append(p)      # AFTER the reference root: `training`, `utils` stay the reference's packages
+    import plugin
+
+    plugin.install()
+    want = run_reference(str(tmp_path / "ref"))
+    # --- the same run with OUR loop around the reference's algorithm and buffer (arithmetic identical on both sides)
+    from utils.initialization import create_alg, create_buffer
+
+    kw = derived_kwargs(TRAINER_CASE, str(tmp_path / "hip"))
+    alg = create_alg(**kw)
+    # the reference builds sampler, buffer, evaluator in this order (example_train/main.py:160-168); run_hip_loop builds
+    # the sampler and the evaluator (both draw a container from the torch generator), the buffer draws nothing
+    buffer = create_buffer(**kw)
+    got = run_hip_loop(kw, alg, buffer)
+    check_cadence(got, want)
+    assert got["tb_info"] == want["tb_info"]
+    assert got["evals"] == want["evals"]
+    for g, w in zip(got["scalars"], want["scalars"]):
+        if g[0] in TIME_TAGS:
+            continue
+        assert g[2] == w[2] or (g[0] == RAM_TAG), (g, w)
+    # the trainer's post-training CSV export exists for every tag the reference wrote
+    tags = {s[0] for s in want["scalars"]}
+    assert len(os.listdir(tmp_path / "hip" / "data")) == len(tags)
+
+
+def test_committed_trajectory_is_what_the_reference_produces_here(tmp_path):
+    """the fixture the GPU test compares against is regenerated where the reference is mounted"""
+    if not ref_loader.reference_available():
+        pytest.skip("reference not mounted")
+    want = json.load(open(GOLDEN))
+    got = run_reference(str(tmp_path))
+    check_cadence(got, want)
+    assert got["tb_info"] == want["tb_info"] and got["evals"] == want["evals"]
+
+
+@pytest.mark.gpu
+def test_hip_stack_follows_the_reference_trajectory(tmp_path):
+    for p in (PKG, ENVS):
+        if p not in sys.path:
+            sys.path.append(p)
+    import plugin
+
+    want = json.load(open(GOLDEN))
+    case = dict(want["case"], algorithm="DSAC_V2_HIP", buffer_name="hip_replay_buffer")
+    kw = derived_kwargs(case, str(tmp_path), strict_rng=True)
+    alg = plugin.create_alg(**kw)
+    buffer = plugin.create_buffer(**kw)
+    assert buffer.engine is alg.engine
+    got = run_hip_loop(kw, alg, buffer)
+    check_cadence(got, want)
+    crit = 7   # Loss/Critic loss: a sum of squared TD terms -> relative gate
+    for it, (g, w) in enumerate(zip(got["tb_info"], want["tb_info"])):
+        for k, (a, b) in enumerate(zip(g, w)):
+            tol = 1e-6 + 1e-5 * abs(b) if k == crit else 1e-4
+            assert abs(a - b) <= tol, (it, k, a, b)
+    # evaluation: mean over 2 episodes of a sum of 60 rewards of magnitude <= 16 computed in the env's float64; the only
+    # difference is the HIP acting forward (logits within 2e-5 of the CPU module) -> 1e-4 relative
+    for (i0, a), (i1, b) in zip(got["evals"], want["evals"]):
+        assert i0 == i1 and abs(a - b) <= 1e-4 * abs(b), (i0, a, b)
+    vals = {}
+    for g, w in zip(got["scalars"], want["scalars"]):
+        if g[0] in TIME_TAGS or g[0] == RAM_TAG:
+            continue
+        tol = 1e-4 * max(1.0, abs(w[2]))
+        assert abs(g[2] - w[2]) <= tol, (g, w)
+        vals[g[0]] = g[2]
+    assert len(vals) >= 15
+    # checkpoints load back into a reference-shaped container (state_dict keys of dsac_v2.py:19-62)
+    sd = torch.load(os.path.join(str(tmp_path), "apprfunc", "apprfunc_40.pkl"))
+    assert list(sd.keys())[0] == "log_alpha" and len(sd) == 41
