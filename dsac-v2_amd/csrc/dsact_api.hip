@@ -67,7 +67,7 @@ struct ProfRec {
 }  // namespace
 
 constexpr int kChainFlagSlices = 64;                 // slices per unit of a merged forward launch (batch <= 256, >= 4 rows each)
-constexpr int kChainFlags = 6 * kChainFlagSlices;
+constexpr int kChainFlags = 8 * kChainFlagSlices;   // done[6 units] + zdone[q1c, q2c]
 
 struct dsact_handle {
   dsact_config cfg;
@@ -215,10 +215,8 @@ struct dsact_handle {
   int handoff_failures = 0;
   int debug_withhold = 0;               // dsact_debug_set("withhold_flag"): tests force the timeout path
   int env_chain_rg_pi = 0;              // DSACT_CHAIN_RG_PI (experiments)
+  bool env_no_mixed_rg = false;         // DSACT_NO_MIXED_RG: every unit of the merged forward's group A runs 8-row workgroups (A/B)
   bool fwd_merge = false;               // launches A and B as one (batch <= 256)
-  FusedOpt* d_fin = nullptr;            // device copy of the fused-optimiser constants for k_chain_bwd2's closing block
-  bool d_fin_dirty = true;
-  bool bwd_merge = false;               // critics' backward, policy backward and all weight-gradient/Adam tiles as one launch
   float* zobs[4];                       // first-layer accumulators after the observation part: q1, q2 (obs), q1_t, q2_t (obs2)
   float* dAq[2];                        // dL/d new_act through q1 / q2  [B][32]
   float* doutT[3];                      // transposed packs of dL/d(out): q1, q2 [32 x B], policy [roundup32(2A) x B]
@@ -1376,14 +1374,19 @@ FwdUnit fwd_unit(const dsact_handle* h, int ch, int seg, int head) {
   return u;
 }
 
-void fill_fwd_common(dsact_handle* h, FwdArgs& a, int rg, const char* name) {
-  a.n_slices = h->B / (4 * rg); a.B = h->B; a.F = h->F; a.A = h->A; a.L = h->L; a.ldx = h->ldx;
+// rg: rows per workgroup / 4 of every unit that has not chosen its own (FwdUnit::rg != 0); map: nullptr = uniform placement
+void fill_fwd_common(dsact_handle* h, FwdArgs& a, int rg, const char* name, const XcdMap* map = nullptr) {
+  for (int k = 0; k < a.n_units; ++k) {
+    if (!a.u[k].rg) a.u[k].rg = rg;
+    a.u[k].n_slices = h->B / (4 * a.u[k].rg);
+  }
+  a.map = map ? *map : xcd_map_uniform(a.n_units);
+  a.B = h->B; a.F = h->F; a.A = h->A; a.L = h->L; a.ldx = h->ldx;
   a.s_obs = h->s_obs; a.s_act = h->s_act; a.v1_stats = 0; a.Cb = h->B / 16;
   a.act_scale = h->act_scale; a.act_center = h->act_center; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
   a.timeline = tl_for(h, name);
   a.spin_timeout = h->handoff_dev;
   a.debug_withhold = h->debug_withhold;
-  if (h->bwd_merge) { a.bwd_counters = h->chain_flags + kChainFlags + 1; a.n_bwd_counters = 8 + kChainFlagSlices; }
 }
 
 // group A: policy(obs), policy_target(obs2), q1/q2(obs,act) + observation part of q1_t/q2_t(obs2, .)
@@ -1420,9 +1423,9 @@ void fwd_args_b(dsact_handle* h, FwdArgs& a) {
 int launch_chain_fwd(dsact_handle* h, const char* name, FwdArgs& a) {
   const int rg = chain_rg(h, a.n_units);
   fill_fwd_common(h, a, rg, name);
-  const int grid = chain_grid(a.n_units, a.n_slices);
+  const int grid = fwd_grid(a);
   const size_t lds = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 4 * rg).total * sizeof(float);
-  if (a.u[0].part_heads) h->n_heads_parts = a.n_slices;
+  if (a.u[0].part_heads) h->n_heads_parts = a.u[0].n_slices;
 #define CALL_CF(N, G) return launch(h, name, k_chain_fwd<N, G>, dim3(grid), dim3(64 * N), lds, a)
   CHAIN_NT(CALL_CF, rg);
 #undef CALL_CF
@@ -1447,36 +1450,42 @@ int enqueue_chain_fwd_merged(dsact_handle* h) {
   fwd_args_a(h, m.A);
   fwd_args_b(h, m.B);
   const int rga = chain_rg(h, m.A.n_units), rgb = chain_rg(h, m.B.n_units);
-  fill_fwd_common(h, m.A, rga, "chain_fwd");
+  // Group A at batch 256 with 8-row workgroups is 192 workgroups on 6 XCDs, and the policy chain -- whose sampled action
+  // every q(obs, new_act) consumer waits for -- is the critical path. Mixed row counts: the two policy units run 4-row
+  // workgroups (0.75x the layer time) on two XCDs each, the four critic units 8-row ones on one XCD each: 256
+  // workgroups, one per CU, 8 XCDs busy; with group B's 256 that is exactly two per CU.
+  XcdMap mixed_map;
+  const bool mixed = rga == 2 && h->B % 8 == 0 && 2 * (h->B / 4) + 4 * (h->B / 8) <= 256 && !h->env_no_mixed_rg;
+  if (mixed) {
+    m.A.u[0].rg = m.A.u[1].rg = 1;
+    const int share[6] = {2, 2, 1, 1, 1, 1};
+    mixed_map = xcd_map_shares(6, share);
+  }
+  fill_fwd_common(h, m.A, rga, "chain_fwd", mixed ? &mixed_map : nullptr);
   fill_fwd_common(h, m.B, rgb, "chain_fwd");
-  h->n_heads_parts = m.A.n_slices;
+  h->n_heads_parts = m.A.u[0].n_slices;
   int* f = h->chain_flags;
   for (int k = 0; k < 6; ++k) m.A.u[k].done = f + k * kChainFlagSlices;   // pi, pit, q1c, q2c, q1t(obs), q2t(obs)
   for (int i = 0; i < 2; ++i) {
+    m.A.u[2 + i].zdone = f + (6 + i) * kChainFlagSlices;   // q_c: the saved observation part is ready
     FwdUnit& qt = m.B.u[i];       // q_t(obs2, act2): action from pit, observation part from the obs-only unit
-    qt.wait0 = f + 1 * kChainFlagSlices; qt.wait1 = f + (4 + i) * kChainFlagSlices; qt.wait_rows = 4 * rga;
-    FwdUnit& qp = m.B.u[2 + i];   // q(obs, new_act): action from pi, observation part from q_c
-    qp.wait0 = f + 0 * kChainFlagSlices; qp.wait1 = f + (2 + i) * kChainFlagSlices; qp.wait_rows = 4 * rga;
+    qt.wait0 = m.A.u[1].done; qt.wait_rows0 = 4 * m.A.u[1].rg;
+    qt.wait1 = m.A.u[4 + i].done; qt.wait_rows1 = 4 * m.A.u[4 + i].rg;
+    FwdUnit& qp = m.B.u[2 + i];   // q(obs, new_act): action from pi, observation part from q_c (its early flag)
+    qp.wait0 = m.A.u[0].done; qp.wait_rows0 = 4 * m.A.u[0].rg;
+    qp.wait1 = m.A.u[2 + i].zdone; qp.wait_rows1 = 4 * m.A.u[2 + i].rg;
   }
-  m.n_a = chain_grid(m.A.n_units, m.A.n_slices);
-  const int grid = m.n_a + chain_grid(m.B.n_units, m.B.n_slices);
+  m.n_a = fwd_grid(m.A);
+  const int grid = m.n_a + fwd_grid(m.B);
   // The ready flags are cleared by the critics' backward, which follows every forward of a complete update. A forward
   // that follows another forward (dsact_dp_enqueue_forward twice, or one never followed by its backward) would find them
   // raised and its consumers would not wait: clear them first (a memset node when captured).
   if (h->flags_dirty) HIPCHK(h, hipMemsetAsync(h->chain_flags, 0, kChainFlags * sizeof(int), h->stream));
   h->flags_dirty = true;
-  const size_t la = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 4 * rga).total * sizeof(float);
-  const size_t lb = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 4 * rgb).total * sizeof(float);
-  const size_t lds = la > lb ? la : lb;
-#define CALL_CF2(N)                                                                                           \
-  do {                                                                                                        \
-    if (rga == 2) return launch(h, "chain_fwd", k_chain_fwd2<N, 2, 1>, dim3(grid), dim3(64 * N), lds, m);      \
-    return launch(h, "chain_fwd", k_chain_fwd2<N, 1, 1>, dim3(grid), dim3(64 * N), lds, m);                    \
-  } while (0)
-  if (h->cNT == 1) CALL_CF2(1);
-  else if (h->cNT == 2) CALL_CF2(2);
-  else CALL_CF2(4);
-#undef CALL_CF2
+  const size_t lds = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 4 * (rga > rgb ? rga : rgb)).total * sizeof(float);
+  if (h->cNT == 1) return launch(h, "chain_fwd", k_chain_fwd2<1>, dim3(grid), dim3(64), lds, m);
+  if (h->cNT == 2) return launch(h, "chain_fwd", k_chain_fwd2<2>, dim3(grid), dim3(128), lds, m);
+  return launch(h, "chain_fwd", k_chain_fwd2<4>, dim3(grid), dim3(256), lds, m);
 }
 
 // loss + dZ chains of the critics (n_units 2: q1c, q2c only -- off iterations of the delayed update) and of
@@ -1564,43 +1573,6 @@ int enqueue_chain_bwd_pi(dsact_handle* h, int x0, int x1, bool fused) {
 #undef CALL_CP
 }
 
-// the whole backward + optimiser of one update in ONE launch (k_chain_bwd2; batch <= 256)
-int enqueue_chain_bwd_merged(dsact_handle* h, bool fused, const RideArgs* ride) {
-  Bwd2Args m;
-  memset(&m, 0, sizeof(m));
-  int rgq, rgp, n_riders;
-  bwd_q_args(h, 4, ride, m.q, rgq, n_riders);
-  bwd_pi_args(h, 0, 0, fused, m.p, rgp);
-  int* cnt = h->chain_flags + kChainFlags + 1;   // [0] critics + riders arrived, [1] policy slices arrived, [8 + s] dL/da of slice s
-  m.cnt_q = cnt; m.cnt_pi = cnt + 1; m.spin_timeout = h->handoff_dev;
-  m.q.agent = 1; m.q.cnt_q = m.cnt_q; m.q.cnt_dA = cnt + 8; m.q.dA_rows = 4 * rgp;
-  m.p.agent = 1; m.p.cnt_dA = cnt + 8; m.p.dA_need = 2 * (rgp / rgq); m.p.cnt_pi = m.cnt_pi; m.p.spin_timeout = m.spin_timeout;
-  m.p.dw.agent_st = 1;
-  m.nq = m.q.n_chain_blocks; m.nr = n_riders; m.npad = roundup(n_riders, 8) - n_riders;
-  m.np = roundup(m.p.n_slices, 8);
-  m.nt_q = h->dw2_off[2]; m.nt_pi = h->dw2_off[3] - h->dw2_off[2];
-  m.need_q = 4 * m.q.n_slices + n_riders; m.need_pi = m.p.n_slices;
-  m.fin = fused ? h->d_fin : nullptr;
-  m.fin_part_loss = m.p.part_loss; m.fin_n_part = m.p.n_part; m.fin_inv_B = m.p.inv_B; m.fin_target_entropy = m.p.target_entropy;
-  m.fin_grad_log_alpha = m.p.grad_log_alpha; m.fin_auto_alpha = m.p.auto_alpha;
-  if (fused && h->d_fin_dirty) return fail(h, DSACT_E_STATE, "merged backward: optimiser constants not uploaded (ensure_fin)");
-  const int grid = m.nq + m.nr + m.npad + m.np + xcd_chunk_grid(m.nt_q) + xcd_chunk_grid(m.nt_pi) + 1;
-  size_t lds = (size_t)chain_lds(h->cW, h->cW, 4 * rgq).total * sizeof(float);
-  const size_t lp = (size_t)chain_lds(4 * h->SoT, h->cW, 4 * rgp).total * sizeof(float);
-  if (lp > lds) lds = lp;
-  if (lds < kDw2LdsFloats * sizeof(float)) lds = kDw2LdsFloats * sizeof(float);
-#define CALL_B2(N)                                                                                               \
-  do {                                                                                                           \
-    if (rgq == 1 && rgp == 2) return launch(h, "chain_bwd", k_chain_bwd2<N, 1, 2>, dim3(grid), dim3(kThreads), lds, m);  \
-    if (rgq == 1 && rgp == 1) return launch(h, "chain_bwd", k_chain_bwd2<N, 1, 1>, dim3(grid), dim3(kThreads), lds, m);  \
-    return fail(h, DSACT_E_STATE, "merged backward: unsupported row-group combination");                         \
-  } while (0)
-  if (h->cNT == 1) CALL_B2(1);
-  else if (h->cNT == 2) CALL_B2(2);
-  else CALL_B2(4);
-#undef CALL_B2
-}
-
 // same contract as enqueue_grads (phases, fused optimiser, riders of the loss launch)
 int enqueue_grads_chain(dsact_handle* h, bool actor_backward, bool fused, int phase, const RideArgs* ride) {
   const int* off = h->dw2_off;
@@ -1619,7 +1591,6 @@ int enqueue_grads_chain(dsact_handle* h, bool actor_backward, bool fused, int ph
     }
   }
   if (phase == 1) return DSACT_OK;
-  if (h->bwd_merge && phase == 0 && actor_backward && h->dw_chunks == 1) return enqueue_chain_bwd_merged(h, fused, ride);
   TRY(enqueue_chain_bwd_q(h, actor_backward ? 4 : 2, ride));
   if (!actor_backward) {
     if (h->dw_chunks == 1) return run_dw2(h, off[0], off[2], fused, fused);
@@ -1898,18 +1869,6 @@ int enqueue_adam(dsact_handle* h, bool from_parts) {
   return launch(h, "adam_polyak", k_adam, dim3(blocks), dim3(kThreads), 0, a);
 }
 
-// device copy of the fused-optimiser constants (k_chain_bwd2's closing block reads them from memory): refreshed outside
-// any capture, whenever the arenas were (re)bound or a hyper-parameter changed
-int ensure_fin(dsact_handle* h) {
-  if (!h->bwd_merge || !h->d_fin_dirty || !h->online) return DSACT_OK;
-  if (!h->d_fin) HIPCHK(h, hipMalloc((void**)&h->d_fin, sizeof(FusedOpt)));
-  const FusedOpt fo = fused_opt(h, true);
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipMemcpy(h->d_fin, &fo, sizeof(fo), hipMemcpyHostToDevice));
-  h->d_fin_dirty = false;
-  return DSACT_OK;
-}
-
 void drop_graphs(dsact_handle* h) {
   if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
   if (h->graph) { hipGraphDestroy(h->graph); h->graph = nullptr; }
@@ -1931,7 +1890,6 @@ int check_handoff(dsact_handle* h) {
   const int steps = h->graph_steps;
   const uint32_t gflags = h->graph_flags;
   h->fwd_merge = false;
-  h->bwd_merge = false;
   h->handoff_failures += 1;
   drop_graphs(h);
   if (h->chain_flags) hipMemset(h->chain_flags, 0, (kChainFlags + 128) * sizeof(int));
@@ -1953,7 +1911,7 @@ int check_ready(dsact_handle* h, bool need_batch) {
   if (!h->limits_set) return fail(h, DSACT_E_STATE, "action limits not set (dsact_set_action_limits)");
   if (need_batch && !h->have_batch) return fail(h, DSACT_E_STATE, "no minibatch staged (dsact_gather / dsact_load_batch)");
   h->dev_it_next = -1;   // every update entry point except the graph replays passes through here
-  return ensure_fin(h);
+  return DSACT_OK;
 }
 
 }  // namespace
@@ -2045,6 +2003,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (const char* v = getenv("DSACT_CONV_DW_NKT")) h->env_conv_dw_nkt = atoi(v);
   if (const char* v = getenv("DSACT_RIDE_SLOTS")) h->env_ride_slots = atoi(v);
   if (const char* v = getenv("DSACT_CHAIN_RG_PI")) h->env_chain_rg_pi = atoi(v);
+  h->env_no_mixed_rg = getenv("DSACT_NO_MIXED_RG") != nullptr;
   if (const char* v = getenv("DSACT_CHAIN_RG")) h->env_chain_rg = atoi(v) == 1 ? 1 : atoi(v) == 4 ? 4 : 2;
   h->dw_chunks = (h->B > 448 && h->B % 256 == 0 && getenv("DSACT_NO_SPLITK") == nullptr) ? h->B / 256 : 1;
   h->dw_part_stride = (h->n_online + 2 + 63) & ~(size_t)63;
@@ -2067,8 +2026,6 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     h->rg4_ok = ok && h->B % 16 == 0 && getenv("DSACT_NO_RG4") == nullptr &&
                 (size_t)chain_lds(4 * (h->s_obs + h->s_act), W0, 16).total * sizeof(float) <= 150 * 1024;
     // merged forward launch: both groups resident at once (4-row group-B workgroups: batch <= 256), one flag per slice
-    // (opt-in: correct -- the parity tests pass with it -- but measured slower than the three launches it replaces)
-    h->bwd_merge = ok && h->B <= 256 && h->B / 4 <= kChainFlagSlices && getenv("DSACT_BWD_MERGE") != nullptr;
     h->fwd_merge = ok && h->B <= 256 && h->B / 4 <= kChainFlagSlices && chain_rg(h, 4) == 1 && getenv("DSACT_NO_FWD_MERGE") == nullptr;
   }
   Carver c0;
@@ -2129,13 +2086,10 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<1, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<2, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<4, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<2, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<4, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
@@ -2165,7 +2119,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     // correctness -- consumers only wait for lower block ids, which are always dispatched first)
     int per_cu = 0;
     const size_t la = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 4 * chain_rg(h, 6)).total * sizeof(float);
-    const void* fn = h->cNT == 1 ? (const void*)k_chain_fwd2<1, 2, 1> : h->cNT == 2 ? (const void*)k_chain_fwd2<2, 2, 1> : (const void*)k_chain_fwd2<4, 2, 1>;
+    const void* fn = h->cNT == 1 ? (const void*)k_chain_fwd2<1> : h->cNT == 2 ? (const void*)k_chain_fwd2<2> : (const void*)k_chain_fwd2<4>;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * h->cNT, la) != hipSuccess || per_cu < 2) h->fwd_merge = false;
     (void)hipGetLastError();
   }
@@ -2196,7 +2150,6 @@ int dsact_destroy(dsact_handle* h) {
   if (h->pk_ws) hipFree(h->pk_ws);
   if (h->d_mir) hipFree(h->d_mir);
   if (h->d_apjobs) hipFree(h->d_apjobs);
-  if (h->d_fin) hipFree(h->d_fin);
   if (h->d_pack) hipFree(h->d_pack);
   if (h->idx_table) hipFree(h->idx_table);
   if (h->stage_dev) hipFree(h->stage_dev);
@@ -2248,7 +2201,6 @@ int dsact_bind_arenas(dsact_handle* h, float* online, float* target, float* adam
   HIPCHK(h, hipSetDevice(h->device));
   if (h->graph_exec) return fail(h, DSACT_E_STATE, "cannot rebind arenas after dsact_graph_build");
   h->online = online; h->target = target; h->adam_m = adam_m; h->adam_v = adam_v; h->grads = grads;
-  h->d_fin_dirty = true;
   TRY(build_chain(h));
   TRY(build_pack_jobs(h));
   if (h->chain_ok) TRY(build_adam_pack_jobs(h));
@@ -2335,7 +2287,6 @@ int dsact_set_hyper(dsact_handle* h, int32_t which, double value) {
       h->cfg.td_bound = value; break;
     default: return fail(h, DSACT_E_INVALID, "unknown hyper-parameter %d", (int)which);
   }
-  h->d_fin_dirty = true;
   // every launch reads h->cfg when it is enqueued; only a captured graph holds old values
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -3149,7 +3100,6 @@ int dsact_debug_set(dsact_handle* h, const char* name, double value) {
 int dsact_debug_get(const dsact_handle* h, const char* name, double* value) {
   if (!h || !name || !value) return DSACT_E_INVALID;
   if (!strcmp(name, "fwd_merge")) *value = h->fwd_merge ? 1.0 : 0.0;
-  else if (!strcmp(name, "bwd_merge")) *value = h->bwd_merge ? 1.0 : 0.0;
   else if (!strcmp(name, "handoff_failures")) *value = (double)h->handoff_failures;
   else if (!strcmp(name, "graph_steps")) *value = (double)h->graph_steps;
   else return DSACT_E_INVALID;

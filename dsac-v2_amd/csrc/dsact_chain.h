@@ -168,6 +168,27 @@ inline int chain_grid(int n_units, int n_slices) {
   const int rep = n_units >= 5 ? 1 : (n_units >= 3 ? 2 : (n_units == 2 ? 4 : 8));
   return 8 * ((n_slices + rep - 1) / rep);
 }
+// The same placement as a table, for launches whose units differ in rows per workgroup (hence in slice count): the block
+// on XCD x = b & 7 in dispatch round b >> 3 runs slice base[x] + stride[x] * round of unit[x] (unit < 0: XCD idle).
+struct XcdMap { int unit[8], base[8], stride[8]; };
+inline XcdMap xcd_map_uniform(int n_units) {
+  XcdMap m;
+  const int rep = n_units >= 5 ? 1 : (n_units >= 3 ? 2 : (n_units == 2 ? 4 : 8));
+  for (int x = 0; x < 8; ++x) {
+    const bool on = x < n_units * rep;
+    m.unit[x] = on ? x % n_units : -1; m.base[x] = on ? x / n_units : 0; m.stride[x] = rep;
+  }
+  return m;
+}
+// unit u gets share[u] consecutive XCDs (sum of shares <= 8), its slices dealt round-robin over them
+inline XcdMap xcd_map_shares(int n_units, const int* share) {
+  XcdMap m;
+  int x = 0;
+  for (int u = 0; u < n_units; ++u)
+    for (int k = 0; k < share[u] && x < 8; ++k, ++x) { m.unit[x] = u; m.base[x] = k; m.stride[x] = share[u]; }
+  for (; x < 8; ++x) { m.unit[x] = -1; m.base[x] = 0; m.stride[x] = 1; }
+  return m;
+}
 
 // LDS carve-up shared by the chain kernels (floats)
 struct ChainLds {
@@ -188,9 +209,6 @@ __host__ __device__ inline ChainLds chain_lds(int k_in /*floats of the widest st
 // agent-scope (sc1) scalar accesses: through to memory / past the non-coherent cache levels (in-launch hand-overs)
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void hand_store(float* p, float v, int agent) {
-  if (agent) st_agent(p, v); else *p = v;
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // dw2: weight / bias gradients + fused Adam / Polyak from TRANSPOSED fragment-major operands
@@ -218,7 +236,6 @@ struct Dw2Args {
   long long part_stride;  // split-K: floats between the partial arenas
   FusedOpt fo;            // fo.st == nullptr: plain gradient store
   int store_g;            // 0: fused graph replays -- nothing reads the gradient arena, skip its 4.6 MB of stores
-  int agent_st;           // merged backward launch: the step state was written INSIDE this launch -- read it past the L2
 };
 constexpr int kDw2LdsFloats = 4 * 4 * 64 * 4 + 4 * 2 * 64;
 
@@ -259,15 +276,9 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds) {
   f32x4 op = {0.f, 0.f, 0.f, 0.f}, om = op, ov = op, ot = op;
   if (fused) {
     const bool is_q = P.w_idx < a.fo.n_q2;
-    if (a.agent_st) {
-      o_delayed = __hip_atomic_load(&a.fo.st->do_delayed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-      o_ss = ld_agent(is_q ? &a.fo.st->ss_q : &a.fo.st->ss_pi);
-      o_bc2 = ld_agent(is_q ? &a.fo.st->bc2_q : &a.fo.st->bc2_pi);
-    } else {
-      o_delayed = a.fo.st->do_delayed != 0;
-      o_ss = is_q ? a.fo.st->ss_q : a.fo.st->ss_pi;
-      o_bc2 = is_q ? a.fo.st->bc2_q : a.fo.st->bc2_pi;
-    }
+    o_delayed = a.fo.st->do_delayed != 0;
+    o_ss = is_q ? a.fo.st->ss_q : a.fo.st->ss_pi;
+    o_bc2 = is_q ? a.fo.st->bc2_q : a.fo.st->bc2_pi;
     o_upd = is_q || o_delayed;
     if (o_upd && in_range && full) {
       op = *(const f32x4u*)(a.fo.online + oi); om = *(const f32x4u*)(a.fo.adam_m + oi); ov = *(const f32x4u*)(a.fo.adam_v + oi);
@@ -483,12 +494,16 @@ struct FwdUnit {
   float* part_heads;                // policy head: [slices][2] sums of tanh(mu), sigma; nullptr: none
   // merged A+B launch (k_chain_fwd2): a producer raises done[slice] when everything it wrote is visible chip-wide; a
   // consumer waits for wait0/wait1[its first row / wait_rows] before it reads what the producers wrote. nullptr: no flags
-  int* done; const int* wait0; const int* wait1; int wait_rows;
+  int* done; const int* wait0; const int* wait1; int wait_rows0, wait_rows1;
+  int* zdone;                       // SEG_FULL_SAVE producers: raised as soon as zsave is written (the consumers of the saved
+                                    // observation part do not wait for the rest of this unit's chain)
+  int rg, n_slices;                 // rows per workgroup / 4 and slices of THIS unit (units of one launch may differ)
 };
 constexpr int kMaxFwdUnits = 6;
 struct FwdArgs {
   FwdUnit u[kMaxFwdUnits];
-  int n_units, n_slices;
+  int n_units;
+  XcdMap map;                       // block -> (unit, slice)
   int B, F, A, L, ldx;
   int Cb;                           // B / 16: chunks per row tile of the transposed packs
   int s_obs, s_act;                 // steps of the first layer's observation segment / widest action segment (multiples of kPD)
@@ -498,7 +513,6 @@ struct FwdArgs {
   int* spin_timeout;                // merged launch: set to 1 by a consumer that gave up waiting. The word lives in mapped
                                     // HOST memory: every entry point of the library checks it and fails the call
   int debug_withhold;               // tests only (dsact_debug_set "withhold_flag"): unit 0 / slice 0 never raises its flag
-  int* bwd_counters; int n_bwd_counters;   // arrival counters of the merged backward launch: cleared by the forward launch
 };
 
 // Data handed from a producer to a consumer INSIDE the merged launch (sampled actions, saved first-layer accumulators)
@@ -506,45 +520,11 @@ struct FwdArgs {
 // neither side needs an L2-wide write-back or invalidate -- a release fence per producer costs an XCD-wide buffer_wbl2
 // (measured: the merged launch ran 46 us with fences, 31 us as two launches).
 
-// 16 bytes of hand-over data (a transposed-pack element): four agent-scope dword stores when the consumer runs in the SAME
-// launch (merged backward), the streaming 16-byte store otherwise
-__device__ __forceinline__ void pack_store4(float* p, const f32x4& v, int agent) {
-  if (agent) {
-    // one 16-byte agent-scope store (four dword ones are four partial-line write-throughs: measured far slower)
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
-  } else {
-    nt_store4(p, v);
-  }
-}
 // every outstanding vector-memory operation of this wave (stores included) has been acknowledged, then the workgroup
 // barrier: what the producers of an in-launch hand-over run before they raise a flag / bump a counter
 __device__ __forceinline__ void stores_acked_barrier() {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-// arrival counters of the merged backward launch: a finished producer workgroup adds 1 (after its stores are
-// acknowledged); a consumer waits until `need` producers have arrived (bounded, like chain_wait)
-__device__ __forceinline__ void chain_arrive(int* c0, int* c1) {
-  if (!c0 && !c1) return;      // workgroup-uniform
-  stores_acked_barrier();
-  if (threadIdx.x == 0) {
-    if (c0) __hip_atomic_fetch_add(c0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (c1) __hip_atomic_fetch_add(c1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-template <int SLEEP>
-__device__ __forceinline__ void chain_wait_count(const int* c, int need, int* timeout) {
-  if (threadIdx.x == 0) {
-    int spins = 0;
-    // SLEEP x 64 cycles between polls: short for the few waiters on the critical path (policy slices, policy tiles, the
-    // closing block), ~3 us for the critics' 480 tiles, which have 10 us of slack and would otherwise storm one word
-    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-      if (++spins > (1 << 22) / SLEEP) { if (timeout) *timeout = 1; break; }   // ~0.1 s
-      __builtin_amdgcn_s_sleep(SLEEP);
-    }
-  }
-  __syncthreads();
-}
-
 // producer side of the merged launch: every wave waits until its agent-scope (write-through) stores have been
 // acknowledged, the workgroup meets, then one thread raises the flag at agent scope. The wait is EXPLICIT: on gfx950
 // hipcc lowers __syncthreads() to a bare s_barrier when it sees no LDS/global dependency of its own, so the flag store
@@ -569,12 +549,27 @@ __device__ __forceinline__ void chain_wait(const int* f0, const int* f1, int* ti
   __syncthreads();        // the consumer's loads of the handed-over data are ld_agent: no cache invalidate needed
 }
 
+// block -> (unit, slice) of a forward launch; false: padding block
+__device__ __forceinline__ bool fwd_decode(const FwdArgs& a, int b, int& unit, int& slice) {
+  const int x = b & 7;
+  unit = a.map.unit[x];
+  if (unit < 0) return false;
+  slice = a.map.base[x] + a.map.stride[x] * (b >> 3);
+  return slice < a.u[unit].n_slices;
+}
+inline int fwd_grid(const FwdArgs& a) {
+  int rounds = 0;
+  for (int x = 0; x < 8; ++x) {
+    if (a.map.unit[x] < 0) continue;
+    const int n = a.u[a.map.unit[x]].n_slices - a.map.base[x];
+    const int r = n > 0 ? (n + a.map.stride[x] - 1) / a.map.stride[x] : 0;
+    rounds = r > rounds ? r : rounds;
+  }
+  return 8 * rounds;
+}
+
 template <int NW, int RG>
-__device__ __forceinline__ void chain_fwd_body(const FwdArgs& a, int block, float* lds) {
-  if (a.bwd_counters && block == 0)
-    for (int i = (int)threadIdx.x; i < a.n_bwd_counters; i += (int)blockDim.x) a.bwd_counters[i] = 0;
-  int unit, slice;
-  if (!chain_decode(block, a.n_units, a.n_slices, unit, slice)) return;
+__device__ __forceinline__ void chain_fwd_body(const FwdArgs& a, int unit, int slice, float* lds) {
   const FwdUnit& u = a.u[unit];
   constexpr int W = 64 * NW, SH = W / 4, R = 4 * RG, NTHR = 64 * NW, TPR = NTHR / R;
   int* const done_flag = (u.done && !(a.debug_withhold && unit == 0 && slice == 0)) ? u.done + slice : nullptr;
@@ -619,10 +614,8 @@ __device__ __forceinline__ void chain_fwd_body(const FwdArgs& a, int block, floa
     pre_bmu[0] = u.bias[L][0]; pre_braw[0] = u.bias[L][1];
   }
   // merged launch: the weight stream and the loads above are already in flight while this waits for its producers
-  if (u.wait0 || u.wait1) {
-    const int ps = row0 / u.wait_rows;
-    chain_wait(u.wait0 ? u.wait0 + ps : nullptr, u.wait1 ? u.wait1 + ps : nullptr, a.spin_timeout);
-  }
+  if (u.wait0 || u.wait1)
+    chain_wait(u.wait0 ? u.wait0 + row0 / u.wait_rows0 : nullptr, u.wait1 ? u.wait1 + row0 / u.wait_rows1 : nullptr, a.spin_timeout);
   f32x4 zi[RG];
   if (u.seg == SEG_ACT_FROM_SAVED) {
 #pragma unroll
@@ -706,6 +699,7 @@ __device__ __forceinline__ void chain_fwd_body(const FwdArgs& a, int block, floa
 #pragma unroll
         for (int r = 0; r < 4; ++r) st_agent(u.zsave + (size_t)(row0 + 4 * g + r) * W + n, v[r]);
       }
+      if (u.zdone) chain_publish(u.zdone + slice);   // drains this wave's prefetch queue once (~1 us) -- off the critical path
     }
     CTL(a.timeline, 2);
     if (u.seg == SEG_OBS_ONLY) { CTLR(a.timeline, 15); chain_publish(done_flag); return; }
@@ -802,7 +796,9 @@ __device__ __forceinline__ void chain_fwd_body(const FwdArgs& a, int block, floa
 template <int NW, int RG>
 __global__ void __launch_bounds__(64 * NW, RG >= 4 ? 1 : 2) k_chain_fwd(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  chain_fwd_body<NW, RG>(a, (int)blockIdx.x, lds);
+  int unit, slice;
+  if (!fwd_decode(a, (int)blockIdx.x, unit, slice)) return;
+  chain_fwd_body<NW, RG>(a, unit, slice, lds);
 }
 
 // Launches A and B in one: blocks [0, n_a) run group A with RGA row groups, blocks [n_a, ..) group B with RGB. Every
@@ -811,11 +807,17 @@ __global__ void __launch_bounds__(64 * NW, RG >= 4 ? 1 : 2) k_chain_fwd(FwdArgs 
 // while it waits; it starts the moment ITS slice's producers are done instead of after the whole of launch A plus a
 // kernel boundary.
 struct Fwd2Args { FwdArgs A, B; int n_a; };
-template <int NW, int RGA, int RGB>
+static_assert(sizeof(Fwd2Args) <= 4096, "kernel arguments are limited to 4 KB");
+// every unit runs 4-row (rg 1) or 8-row (rg 2) workgroups; the choice is per unit (FwdUnit::rg)
+template <int NW>
 __global__ void __launch_bounds__(64 * NW, 2) k_chain_fwd2(Fwd2Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  if ((int)blockIdx.x < a.n_a) chain_fwd_body<NW, RGA>(a.A, (int)blockIdx.x, lds);
-  else chain_fwd_body<NW, RGB>(a.B, (int)blockIdx.x - a.n_a, lds);
+  const bool in_a = (int)blockIdx.x < a.n_a;
+  const FwdArgs& f = in_a ? a.A : a.B;
+  int unit, slice;
+  if (!fwd_decode(f, in_a ? (int)blockIdx.x : (int)blockIdx.x - a.n_a, unit, slice)) return;
+  if (f.u[unit].rg == 1) chain_fwd_body<NW, 1>(f, unit, slice, lds);
+  else chain_fwd_body<NW, 2>(f, unit, slice, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -846,8 +848,6 @@ struct BwdQArgs {
   long long* timeline;
   RideArgs ride;
   int* flags_reset; int n_flags;   // the merged forward launch's ready flags: cleared here, after it and before the next one
-  // merged backward launch (k_chain_bwd2): hand-over stores at agent scope, arrival counters
-  int agent; int* cnt_q; int* cnt_dA; int dA_rows;   // cnt_dA[first row / dA_rows]: the q(obs,new_act) units' dL/da is there
 };
 
 template <int NW, int RG>
@@ -929,15 +929,15 @@ __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* 
   if (j == 0) {
     u.dout[2 * r] = d0; u.dout[2 * r + 1] = d1;
     sc[16 + 2 * m] = d0; sc[16 + 2 * m + 1] = d1;
-    if (u.doutT) { hand_store(u.doutT + pk_index(0, r, a.Cb), d0, a.agent); hand_store(u.doutT + pk_index(1, r, a.Cb), d1, a.agent); }
+    if (u.doutT) { u.doutT[pk_index(0, r, a.Cb)] = d0; u.doutT[pk_index(1, r, a.Cb)] = d1; }
     if (u.which == 0) {
       float* pl = a.part_loss + (size_t)r * kLossPart;
       pl[0] = c1.loss; pl[1] = c2.loss; pl[2] = q1; pl[3] = q2; pl[4] = std1; pl[5] = std2;
       pl[6] = alpha * lpn - fminf(q1p, q2p);
-      hand_store(pl + 7, lpn, a.agent);
+      pl[7] = lpn;
       pl[8] = r == 0 ? alpha : 0.0f;
       pl[9] = 0.0f; pl[10] = std1; pl[11] = std2;
-      if (r == 0) { hand_store(a.grads_tail, ms1, a.agent); hand_store(a.grads_tail + 1, ms2, a.agent); }
+      if (r == 0) { a.grads_tail[0] = ms1; a.grads_tail[1] = ms2; }
     }
   }
   lds_barrier();
@@ -949,7 +949,7 @@ __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* 
     for (int rr = 0; rr < 4; ++rr) ov[rr] = (sc[16 + 2 * (4 * g + rr)] * wo0 + sc[16 + 2 * (4 * g + rr) + 1] * wo1) * gl[g][rr];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) lds[S.off_h0 + (4 * g + rr) * S.ld_h + n] = ov[rr];
-    pack_store4(u.dZ[L - 1] + pk_index(n, row0 + 4 * g, a.Cb), ov, a.agent);
+    nt_store4(u.dZ[L - 1] + pk_index(n, row0 + 4 * g, a.Cb), ov);
   }
   NarrowFrags<2> af;
   const int nta = (a.A + 15) >> 4;
@@ -976,19 +976,18 @@ __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* 
       const f32x4 dz = (acc[g][0] + acc[g][1]) * gq[g];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) lds[hn + (4 * g + rr) * S.ld_h + n] = dz[rr];
-      pack_store4(u.dZ[l - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz, a.agent);
+      nt_store4(u.dZ[l - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz);
     }
     cur ^= 1;
     lds_barrier();
     CTL(a.timeline, 4 + 2 * (L - 1 - l));
   }
-  if (!u.w1at) { chain_arrive(a.cnt_q, nullptr); return; }
+  if (!u.w1at) return;
   // ---- dL/d new_act through this critic: dZ0 . W0[:, F:F+A]   (contraction over the hidden units, split over waves)
   narrow_mma<2>(af, nta, wave, lds, (cur ? S.off_h1 : S.off_h0) + ((lane & 15) & (R - 1)) * S.ld_h + 4 * (lane >> 4), red, lane);
   lds_barrier();
-  for (int d = j; d < 16 * nta; d += TPR) hand_store(u.dA + (size_t)r * 32 + d, d < a.A ? narrow_get<2, NW>(lds, red, m, d) : 0.0f, a.agent);
+  for (int d = j; d < 16 * nta; d += TPR) u.dA[(size_t)r * 32 + d] = d < a.A ? narrow_get<2, NW>(lds, red, m, d) : 0.0f;
   CTL(a.timeline, 12);
-  chain_arrive(a.cnt_q, a.cnt_dA ? a.cnt_dA + row0 / a.dA_rows : nullptr);
 }
 
 template <int NW, int RG>
@@ -1019,9 +1018,6 @@ struct BwdPiArgs {
   int tile0, n_extra;              // riders: weight-gradient tiles [tile0, tile0 + n_extra) of `dw`
   long long* timeline;
   Dw2Args dw;
-  // merged backward launch (k_chain_bwd2): wait for the dL/da producers of this slice, hand-over stores at agent scope,
-  // arrival counter of the policy slices; the alpha gradient moves to the block that closes the update
-  int agent; const int* cnt_dA; int dA_need; int* cnt_pi; int* spin_timeout;
 };
 
 template <int NW, int RG>
@@ -1044,7 +1040,6 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
   stream_prologue(ws, wo, 0, lane4);
   const int m = tid / TPR, j = tid % TPR;
   const int r = row0 + m;
-  if (a.cnt_dA) chain_wait_count<4>(a.cnt_dA + slice, a.dA_need, a.spin_timeout);   // merged launch: this slice's dL/da is there
   // the row phase's inputs, fetched before anything waits (each would otherwise be a round trip on the critical path)
   constexpr int NQ = (32 + TPR - 1) / TPR;      // act_dim <= 32
   float pdA[NQ], pmu[NQ], praw[NQ], peps[NQ], psc[NQ];
@@ -1059,7 +1054,7 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
     psc[q] = ok ? a.act_scale[d] : 1.f;
   }
   // alpha gradient (dsac_v2.py:312-318): -mean(logp_new + target_entropy)
-  if (slice == 0 && wave == 0 && !a.cnt_dA) {   // (merged launch: done by the block that closes the update)
+  if (slice == 0 && wave == 0) {
     float s = 0.f;
     for (int r0 = 0; r0 < a.n_part; r0 += 64) {
       const int rr = r0 + lane;
@@ -1081,8 +1076,8 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
     tanh_gauss_bwd(pmu[q], praw[q], peps[q], psc[q], a.lo_ls, a.hi_ls, dA, alpha * a.inv_B, dmu, draw);
     a.dout_pi[(size_t)r * 2 * A + d] = dmu;
     a.dout_pi[(size_t)r * 2 * A + A + d] = draw;
-    hand_store(a.dout_piT + pk_index(d, r, a.Cb), dmu, a.agent);
-    hand_store(a.dout_piT + pk_index(A + d, r, a.Cb), draw, a.agent);
+    a.dout_piT[pk_index(d, r, a.Cb)] = dmu;
+    a.dout_piT[pk_index(A + d, r, a.Cb)] = draw;
     a.d_new_act[(size_t)r * A + d] = dA;
     xdo[m * S.ld_in + d] = dmu;
     xdo[m * S.ld_in + A + d] = draw;
@@ -1105,7 +1100,7 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
       const f32x4 dz = (acc[g][0] + acc[g][1]) * gq[g];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) lds[S.off_h0 + (4 * g + rr) * S.ld_h + n] = dz[rr];
-      pack_store4(a.dZ[L - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz, a.agent);
+      nt_store4(a.dZ[L - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz);
     }
     lds_barrier();
     CTL(a.timeline, 2);
@@ -1126,13 +1121,13 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
       const f32x4 dz = (acc[g][0] + acc[g][1]) * gq[g];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) lds[hn + (4 * g + rr) * S.ld_h + n] = dz[rr];
-      pack_store4(a.dZ[l - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz, a.agent);
+      nt_store4(a.dZ[l - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz);
     }
     cur ^= 1;
     if (l > 1) lds_barrier();
     CTL(a.timeline, 3 + (L - 1 - l));
   }
-  CTLR(a.timeline, 15);  chain_arrive(a.cnt_pi, nullptr);
+  CTLR(a.timeline, 15);
 }
 
 template <int NW, int RG>
@@ -1149,92 +1144,6 @@ __global__ void __launch_bounds__(256) k_chain_bwd_pi(BwdPiArgs a) {
     return;
   }
   bwd_pi_body<NW, RG>(a, (int)blockIdx.x, lds);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// k_chain_bwd2: the whole backward + optimiser of one update in ONE launch (batch <= 256). Block ranges, in id order:
-//   [0, nq)            critics' backward (bwd_q_body) -- producers only
-//   [nq, nq + nr)      the loss launch's riders (next update's gather, bookkeeping)
-//   [.., + np)         policy backward slices: wait for their rows' dL/da (cnt_dA), then bwd_pi_body
-//   [.., + xcd(nt_q))  the critics' weight-gradient/Adam tiles: wait until EVERY critic workgroup has arrived (the tiles
-//                      overwrite packed weights the q(obs,new_act) units still read), then dw2_tile
-//   [.., + xcd(nt_pi)) the policy's tiles: wait for every policy slice
-//   last block         alpha gradient + finalize_update: waits for both
-// A workgroup only ever waits for workgroups with LOWER block ids, which the dispatcher has already placed: the bounded
-// spins cannot deadlock whatever the residency. Hand-over data (dZ packs, dL/da, ...) is stored at agent scope; nobody
-// reads those lines before the counter says they are complete, so plain loads see them (no L2-wide fence anywhere).
-// ---------------------------------------------------------------------------------------------------------------
-struct Bwd2Args {
-  BwdQArgs q; BwdPiArgs p;
-  int nq, nr, npad, np, nt_q, nt_pi;   // block counts (nq, nr + npad, np multiples of 8; tile counts before xcd padding)
-  int need_q, need_pi;             // real workgroups behind cnt_q / cnt_pi
-  int* cnt_q; int* cnt_pi; int* spin_timeout;
-  // What the closing block needs lives in DEVICE memory (fin): with Adam-on-log_alpha code reading its operands from this
-  // kernel-argument struct the compiler kept a private copy of the whole 2.7 KB argument in every thread (scratch; the
-  // launch ran 170 us instead of ~27) -- whatever the access path (reference, local copy, scalar parameters, noinline).
-  const FusedOpt* fin;             // nullptr: no fused optimiser (data-parallel flows): only the alpha gradient is due
-  const float* fin_part_loss; int fin_n_part; float fin_inv_B, fin_target_entropy; float* fin_grad_log_alpha; int fin_auto_alpha;
-};
-template <int NW, int RGQ, int RGP>
-__global__ void __launch_bounds__(256) k_chain_bwd2(Bwd2Args a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  int b = (int)blockIdx.x;
-  if (b < a.nq) { bwd_q_body<NW, RGQ>(a.q, b, lds); return; }
-  b -= a.nq;
-  if (b < a.nr) {
-    // riders arrive too: the closing block must not advance the step counters before the gather riders have read them,
-    // and the tiles read the Adam scalars the bookkeeping rider (the last one) writes -- it publishes them with a fence
-    // (one XCD-wide write-back per update; every other hand-over is agent-scope stores)
-    loss_rider(a.q.ride);
-    if (a.q.ride.bookkeeping && b == a.nr - 1 && threadIdx.x == 0) __threadfence();
-    chain_arrive(a.cnt_q, nullptr);
-    return;
-  }
-  b -= a.nr;
-  if (b < a.npad) return;
-  b -= a.npad;
-  if (b < a.np) {
-    if (b < a.p.n_slices && (int)threadIdx.x < 64 * NW) bwd_pi_body<NW, RGP>(a.p, b, lds);
-    return;
-  }
-  b -= a.np;
-  const int gq = xcd_chunk_grid(a.nt_q), gp = xcd_chunk_grid(a.nt_pi);
-  int t;
-  if (b < gq) {
-    if (!xcd_chunk(b, a.nt_q, t)) return;
-    chain_wait_count<127>(a.cnt_q, a.need_q, a.spin_timeout);
-    dw2_tile(a.p.dw, t, lds);
-    return;
-  }
-  b -= gq;
-  if (b < gp) {
-    if (!xcd_chunk(b, a.nt_pi, t)) return;
-    chain_wait_count<16>(a.cnt_pi, a.need_pi, a.spin_timeout);
-    dw2_tile(a.p.dw, a.nt_q + t, lds);
-    return;
-  }
-  // closes the update: alpha gradient (dsac_v2.py:312-318: -mean(logp_new + target_entropy)), then Adam on log_alpha,
-  // mean_std commit, step counters
-  chain_wait_count<8>(a.cnt_q, a.need_q, a.spin_timeout);
-  chain_wait_count<8>(a.cnt_pi, a.need_pi, a.spin_timeout);
-  if (threadIdx.x < 64) {
-    const int lane = threadIdx.x;
-    float s = 0.f;
-    for (int r0 = 0; r0 < a.fin_n_part; r0 += 64) {
-      const int rr = r0 + lane;
-      s += rr < a.fin_n_part ? ld_agent(a.fin_part_loss + (size_t)rr * kLossPart + 7) : 0.f;
-    }
-    s = wave_sum(s);
-    if (lane == 0) {
-      a.fin_grad_log_alpha[0] = a.fin_auto_alpha ? -(s * a.fin_inv_B + a.fin_target_entropy) : 0.0f;
-      // this XCD's L2 may hold the step state as the critic workgroups read it before the bookkeeping rider wrote it
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      if (a.fin) {
-        const FusedOpt fo = *a.fin;
-        finalize_update(fo);
-      }
-    }
-  }
 }
 
 }  // namespace dsact

@@ -444,6 +444,7 @@ def test_sampling_ahead_restages_the_older_token():
     alg.engine.sync()
     assert np.array_equal(alg.engine.read_batch()["rew"], want_first)
     assert np.array_equal(second["rew"].numpy(), second.idxs.astype(np.float32))
+    assert np.array_equal(first["rew"].numpy(), want_first)
     # rows replaced after sampling: the reference's batch is a copy taken at sample time; a token that is no
     # longer the staged minibatch re-gathers by index and must refuse once add_batch has overwritten its rows
     third, fourth = buf.sample_batch(B), buf.sample_batch(B)
@@ -454,7 +455,6 @@ def test_sampling_ahead_restages_the_older_token():
     alg.local_update(fourth, 1)      # still the staged minibatch: the staging area IS the copy taken at sample time
     alg.engine.sync()
     assert np.array_equal(alg.engine.read_batch()["rew"], fourth.idxs.astype(np.float32))
-    assert np.array_equal(first["rew"].numpy(), want_first)
 
 
 def test_remote_update_seam_equals_local_update():
@@ -1141,50 +1141,6 @@ def test_merged_forward_launch_equals_two_launches(O, A, hid, B, monkeypatch):
     assert "chain_fwd_a" in names[1] and "chain_fwd_b" in names[1] and "chain_fwd" not in names[1]
 
 
-def test_merged_backward_launch_optin_equals_default(monkeypatch):
-    """DSACT_BWD_MERGE=1 (opt-in): critics' backward, policy backward, every weight-gradient/Adam tile
-    and the closing block in ONE launch (k_chain_bwd2: arrival counters, agent-scope hand-over stores) == the three
-    launches of the default path, bit for bit -- eager steps and a graph replay; no spin time-out."""
-    O, A, hid, B = 376, 17, (256, 256, 256), 256
-    algs = []
-    for merged in (True, False):
-        if merged:
-            monkeypatch.setenv("DSACT_BWD_MERGE", "1")
-        else:
-            monkeypatch.delenv("DSACT_BWD_MERGE", raising=False)
-        alg, _ = make_pair(O, A, hid, B, seed=23)
-        algs.append(alg)
-    monkeypatch.delenv("DSACT_BWD_MERGE", raising=False)
-    rng = np.random.default_rng(13)
-    for it in range(3):
-        data = synth_batch(rng, B, O, A, p_done=0.1)
-        torch.manual_seed(400 + it)
-        noise = draw_noise(B, A)
-        for a in algs:
-            a.engine.load_batch(*(data[k].numpy() for k in ("obs", "act", "rew", "obs2", "done")))
-            a.engine.set_noise(noise["eps_new"].numpy(), noise["eps_2"].numpy(), noise["z5"].numpy(), noise["z6"].numpy())
-            a.engine.step(it)
-    N = 2048
-    for a in algs:
-        e = a.engine
-        e.set_device_rng(77)
-        e.buffer_create(N)
-        g = torch.Generator(device="cuda").manual_seed(6)
-        e.buffer_fill_device(0, torch.randn(N, O, device="cuda", generator=g), torch.rand(N, A, device="cuda", generator=g) - .5,
-                             torch.randn(N, device="cuda", generator=g), torch.randn(N, O, device="cuda", generator=g),
-                             (torch.rand(N, device="cuda", generator=g) < .05).float())
-        np.random.seed(3)
-        e.upload_index_table(np.random.randint(0, N, size=(4, B)))
-        e.graph_build(4)
-        e.graph_run(3, 4)
-        e.sync()
-    for name in ("online", "target", "adam_m", "adam_v"):
-        assert torch.equal(getattr(algs[0].engine, name), getattr(algs[1].engine, name)), name
-    assert algs[0].engine.get_state() == algs[1].engine.get_state()
-    names = [k for k, _, _ in algs[0].engine.profile_step(7)]
-    assert "chain_bwd" in names and "chain_bwd_q" not in names
-
-
 def _fill_ring(e, N, O, A, seed):
     e.buffer_create(N)
     g = torch.Generator(device="cuda").manual_seed(seed)
@@ -1253,13 +1209,18 @@ def test_forced_handover_timeout_fails_the_call_and_falls_back():
     assert e.debug_get("graph_steps") == 2.0     # captured again, without the merged launch
     assert "chain_fwd_a" in [k for k, _, _ in e.profile_step(0)]
     e.sync()                                      # the word was consumed: no second error
-    # --- restore the state the failed call invalidated, then both engines run the same updates
-    alg.networks.load_state_dict(snap)
-    for n, t in arenas.items():
-        getattr(e, n).copy_(t)
-    torch.cuda.synchronize()
-    e.set_state(adam_steps=state["adam_steps"], mean_std=state["mean_std"])
+    # --- restore the state the failed call invalidated, then both engines run the same updates (the reference engine
+    #     replays the same three updates first so that both index-table cursors agree, and is restored the same way)
     r.graph_build(2)
+    r.graph_run(0, 2)
+    r.profile_step(0)
+    r.sync()
+    for a_, x in ((alg, e), (ref, r)):
+        a_.networks.load_state_dict(snap)
+        for n, t in arenas.items():
+            getattr(x, n).copy_(t)
+        torch.cuda.synchronize()
+        x.set_state(adam_steps=state["adam_steps"], mean_std=state["mean_std"])
     for x in (e, r):
         x.graph_run(0, 4)
         x.sync()
