@@ -19,7 +19,7 @@ in ONE hipGraph per rank through the library's own communicator (dsact_comm_init
 
 Timing: W untimed warm-up steps, then R timed regions of EXACTLY K steps each, every region bracketed by a
 barrier + device synchronisation on both sides, MAX over ranks per region; `value` is the MEDIAN region
-(R = 15 for K <= 100, 5 for K <= 10000, else 3; all regions are listed in `regions_ms`).
+(R = 61 for K <= 100, 5 for K <= 10000, else 3; all regions are listed in `regions_ms`).
 
 Prints ONE JSON line (rank 0). Extra objects: `roofline` (the dominant kernel: algorithmic FLOP per launch / its
 average in-chain duration, measured live with the dispatch's own start/stop events), `roofline_step` (whole
@@ -401,8 +401,9 @@ def graph_steps(steps, warmup, cap=64, even=False):
 def n_regions(steps):
     if os.environ.get("DSACT_BENCH_REGIONS"):   # experiments only
         return int(os.environ["DSACT_BENCH_REGIONS"])
-    # short regions drift for the first ~8 repeats after an idle GPU (1.53 -> 1.43 ms at K = 20)
-    return 15 if steps <= 100 else 5 if steps <= 10000 else 3
+    # short regions drift while the clocks ramp after an idle GPU (1.48 -> 1.33 ms over 15 regions at K = 20, DESIGN.md
+    # section 6a): 61 regions of K <= 100 steps are still < 0.1 s of GPU time and put the median in the settled regime
+    return 61 if steps <= 100 else 5 if steps <= 10000 else 3
 
 
 def measure(alg, steps, warmup, world=1, dp=None, flags=0):

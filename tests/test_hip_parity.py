@@ -1135,6 +1135,11 @@ def test_merged_forward_launch_equals_two_launches(O, A, hid, B, monkeypatch):
         assert torch.equal(getattr(algs[0].engine, name), getattr(algs[1].engine, name)), name
     st0, st1 = algs[0].engine.read_stats(), algs[1].engine.read_stats()
     st0.pop("_device_ms"); st1.pop("_device_ms")   # a timing, not a statistic
+    # policy_mean / policy_std are sums of per-slice partials: the merged launch runs the policy in 4-row slices, the two
+    # launches in 8-row ones -- same values, another summation order
+    for k in ("DSAC2/policy_mean-RL iter", "DSAC2/policy_std-RL iter"):
+        a0, a1 = st0.pop(k), st1.pop(k)
+        assert abs(a0 - a1) <= 1e-6 * max(abs(a1), 1e-3), (k, a0, a1)
     assert st0 == st1 and all(np.isfinite(v) for v in st0.values())
     names = [[k for k, _, _ in a.engine.profile_step(6)] for a in algs]
     assert "chain_fwd" in names[0] and "chain_fwd_a" not in names[0]
