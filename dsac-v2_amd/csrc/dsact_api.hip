@@ -16,6 +16,7 @@
 #include "../../include/dsact.h"
 #include "dsact_kernels.h"
 #include "dsact_chain.h"
+#include "dsact_fat.h"
 #include "dsact_conv.h"
 
 using namespace dsact;
@@ -194,6 +195,9 @@ struct dsact_handle {
   bool chain_ok = false;
   int cW = 0, cNT = 0;                  // hidden width, W / 64
   int s_obs = 0, s_act = 0, SoT = 0;    // stream steps (4 k each): observation / action segment of a first layer, policy outputs (2A)
+  bool fat = false;                     // throughput-regime kernels (dsact_fat.h): 16x16x4 MFMA, 16/32-row slices, style-16 packs
+  int c_obs = 0, c_act = 0, c_out = 0;  // fat mode: 16-k chunks of the observation / action segment of a first layer, of the policy outputs (2A)
+  int env_fat_rt = 0;                   // DSACT_FAT_RT=1|2: force the rows per fat workgroup (16 / 32)
   int cRG = 2;                          // row groups of 4 per chain workgroup (8 rows) when 4-row workgroups would oversubscribe the CUs
   int env_chain_rg = 0;                 // DSACT_CHAIN_RG=1|2|4: force
   bool rg4_ok = false;                  // 16-row chain workgroups fit (LDS) and divide the batch
@@ -557,7 +561,11 @@ int build_chain(dsact_handle* h) {
   if (h->pk_ws) return DSACT_OK;   // sized by the configuration, not by the arenas: built once
   const int L = h->L, W = h->cW, F = h->F, A = h->A;
   const int tiles = W / 64, SH = W / 4, CH = W / 16;       // style 44: 64-row tiles, k4 steps; style 16: chunks of 16 k
-  const int C0q = h->s_obs + h->s_act, C0p = h->s_obs;
+  // fat mode (dsact_fat.h): EVERY pack is style 16 (16-row tiles x chunks of 16 k; a tile-chunk block is 256 floats like
+  // a style-44 step, so the sizes below count blocks either way)
+  const bool fat = h->fat;
+  const int tiles_f = fat ? W / 16 : tiles, S_hid = fat ? CH : SH, S_out = fat ? h->c_out : h->SoT;
+  const int C0q = fat ? h->c_obs + h->c_act : h->s_obs + h->s_act, C0p = fat ? h->c_obs : h->s_obs;
   const int nth_q = 1, nth_p = (2 * A + 15) / 16, nta = (A + 15) / 16;
   // carve the packed copies
   for (int pass = 0; pass < 2; ++pass) {
@@ -565,15 +573,15 @@ int build_chain(dsact_handle* h) {
     c.base = pass ? h->pk_ws : nullptr;
     for (int net = 0; net < N_NET; ++net) {
       const bool pol = net == N_POL || net == N_POLT;
-      h->pk_fwd[net][0] = c.take<float>((size_t)tiles * (pol ? C0p : C0q) * 256);
-      for (int l = 1; l < L; ++l) h->pk_fwd[net][l] = c.take<float>((size_t)tiles * SH * 256);
+      h->pk_fwd[net][0] = c.take<float>((size_t)tiles_f * (pol ? C0p : C0q) * 256);
+      for (int l = 1; l < L; ++l) h->pk_fwd[net][l] = c.take<float>((size_t)tiles_f * S_hid * 256);
       h->pk_fwd[net][L] = c.take<float>((size_t)(pol ? nth_p : nth_q) * CH * 256);
     }
     for (int n3 = 0; n3 < 3; ++n3) {
       for (int l = 0; l <= L; ++l) h->pk_bwd[n3][l] = nullptr;
-      for (int l = 1; l < L; ++l) h->pk_bwd[n3][l] = c.take<float>((size_t)tiles * SH * 256);
+      for (int l = 1; l < L; ++l) h->pk_bwd[n3][l] = c.take<float>((size_t)tiles_f * S_hid * 256);
     }
-    h->pk_bwd[2][L] = c.take<float>((size_t)tiles * h->SoT * 256);
+    h->pk_bwd[2][L] = c.take<float>((size_t)tiles_f * S_out * 256);
     for (int i = 0; i < 2; ++i) h->pk_w1at[i] = c.take<float>((size_t)nta * CH * 256);
     if (!pass) {
       HIPCHK(h, hipMalloc((void**)&h->pk_ws, c.off + 256));
@@ -589,12 +597,12 @@ int build_chain(dsact_handle* h) {
       memset(&m, 0, sizeof(m));
       const bool pol = n3 == 2;
       m.fwd = h->pk_fwd[on3[n3]][l]; m.fwd_t = h->pk_fwd[tg3[n3]][l];
-      m.fwd_44 = l < L ? 1 : 0;                                   // the output layers are narrow products (style 16)
-      m.fwd_C = l == 0 ? (pol ? C0p : C0q) : (l < L ? SH : CH);
-      m.F = (l == 0 && !pol) ? F : (1 << 30); m.Fp = 4 * h->s_obs;
-      if (l >= 1 && l < L) { m.bwd = h->pk_bwd[n3][l]; m.bwd_44 = 1; m.bwd_C = SH; m.bwd_k0 = 0; }
+      m.fwd_44 = (l < L && !fat) ? 1 : 0;                         // the output layers are narrow products (style 16)
+      m.fwd_C = l == 0 ? (pol ? C0p : C0q) : (l < L ? S_hid : CH);
+      m.F = (l == 0 && !pol) ? F : (1 << 30); m.Fp = fat ? 16 * h->c_obs : 4 * h->s_obs;
+      if (l >= 1 && l < L) { m.bwd = h->pk_bwd[n3][l]; m.bwd_44 = fat ? 0 : 1; m.bwd_C = S_hid; m.bwd_k0 = 0; }
       if (l == 0 && !pol) { m.bwd = h->pk_w1at[n3]; m.bwd_44 = 0; m.bwd_C = CH; m.bwd_k0 = F; }
-      if (l == L && pol) { m.bwd = h->pk_bwd[2][L]; m.bwd_44 = 1; m.bwd_C = h->SoT; m.bwd_k0 = 0; }
+      if (l == L && pol) { m.bwd = h->pk_bwd[2][L]; m.bwd_44 = fat ? 0 : 1; m.bwd_C = S_out; m.bwd_k0 = 0; }
     }
   HIPCHK(h, hipMalloc((void**)&h->d_mir, mir.size() * sizeof(MirrorDesc)));
   HIPCHK(h, hipMemcpy(h->d_mir, mir.data(), mir.size() * sizeof(MirrorDesc), hipMemcpyHostToDevice));
@@ -1367,7 +1375,7 @@ FwdUnit fwd_unit(const dsact_handle* h, int ch, int seg, int head) {
   for (int l = 0; l <= h->L; ++l) { u.wf[l] = h->pk_fwd[net][l]; u.bias[l] = base + d.b_off[l]; }
   u.x = h->Xc[ch];
   u.seg = seg;
-  u.s_act = (net == N_POL || net == N_POLT) ? 0 : h->s_act;
+  u.s_act = (net == N_POL || net == N_POLT) ? 0 : (h->fat ? h->c_act : h->s_act);
   if (seg != SEG_OBS_ONLY)
     for (int l = 0; l < h->L; ++l) { u.H[l] = h->Hb[ch][l]; u.G[l] = h->Gb[ch][l]; }
   u.head = head;
@@ -1382,7 +1390,7 @@ void fill_fwd_common(dsact_handle* h, FwdArgs& a, int rg, const char* name, cons
   }
   a.map = map ? *map : xcd_map_uniform(a.n_units);
   a.B = h->B; a.F = h->F; a.A = h->A; a.L = h->L; a.ldx = h->ldx;
-  a.s_obs = h->s_obs; a.s_act = h->s_act; a.v1_stats = 0; a.Cb = h->B / 16;
+  a.s_obs = h->fat ? h->c_obs : h->s_obs; a.s_act = h->fat ? h->c_act : h->s_act; a.v1_stats = 0; a.Cb = h->B / 16;
   a.act_scale = h->act_scale; a.act_center = h->act_center; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
   a.timeline = tl_for(h, name);
   a.spin_timeout = h->handoff_dev;
@@ -1420,7 +1428,34 @@ void fwd_args_b(dsact_handle* h, FwdArgs& a) {
   a.n_units = 4;
 }
 
+// fat mode: 32-row workgroups when even those fill the chip twice over, else 16-row ones
+int fat_rt(const dsact_handle* h, int n_units) {
+  if (h->env_fat_rt) return h->env_fat_rt;
+  return (n_units * (h->B / 32) >= 512 && h->B % 32 == 0) ? 2 : 1;
+}
+
+#define FAT_NT(CALL, RTV)                      \
+  do {                                         \
+    if ((RTV) == 2) {                          \
+      if (h->cNT == 2) { CALL(2, 2); }         \
+      else { CALL(4, 2); }                     \
+    } else {                                   \
+      if (h->cNT == 2) { CALL(2, 1); }         \
+      else { CALL(4, 1); }                     \
+    }                                          \
+  } while (0)
+
 int launch_chain_fwd(dsact_handle* h, const char* name, FwdArgs& a) {
+  if (h->fat) {
+    const int rt = fat_rt(h, a.n_units);
+    fill_fwd_common(h, a, 4 * rt, name);
+    const int grid = a.n_units * a.u[0].n_slices;
+    const size_t lds = (size_t)fat_lds(h->cW, 16 * rt, 0).total * sizeof(float);
+    if (a.u[0].part_heads) h->n_heads_parts = a.u[0].n_slices;
+#define CALL_FF(N, T) return launch(h, name, k_fat_fwd<N, T>, dim3(grid), dim3(64 * N), lds, a)
+    FAT_NT(CALL_FF, rt);
+#undef CALL_FF
+  }
   const int rg = chain_rg(h, a.n_units);
   fill_fwd_common(h, a, rg, name);
   const int grid = fwd_grid(a);
@@ -1506,7 +1541,7 @@ void bwd_q_args(dsact_handle* h, int n_units, const RideArgs* ride, BwdQArgs& a,
     if (w >= 2) { u.w1at = h->pk_w1at[n3]; u.dA = h->dAq[n3]; }
     u.which = w;
   }
-  const int rg = chain_rg(h, n_units, true);
+  const int rg = h->fat ? 4 * fat_rt(h, n_units) : chain_rg(h, n_units, true);
   a.n_units = n_units; a.n_slices = h->B / (4 * rg); a.B = h->B; a.A = h->A; a.L = L; a.Cb = h->B / 16;
   for (int i = 0; i < 2; ++i) { a.qout_c[i] = h->qout_c[i]; a.qstd_c[i] = h->qstd_c[i]; a.qout_t[i] = h->qout_t[i]; a.qout_p[i] = h->qout_p[i]; }
   a.rew = h->rew; a.done = h->done; a.logp2 = h->logp2; a.logp_new = h->logp_new; a.z5 = h->z5; a.z6 = h->z6;
@@ -1517,7 +1552,7 @@ void bwd_q_args(dsact_handle* h, int n_units, const RideArgs* ride, BwdQArgs& a,
   a.std_sums = h->use_std_sums ? h->std_sums : nullptr;
   a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.gamma = h->cfg.gamma; a.tau_b = h->cfg.tau_b;
   a.one_minus_tau_b = (float)(1.0 - h->cfg.tau_b);
-  a.n_chain_blocks = chain_grid(n_units, a.n_slices);
+  a.n_chain_blocks = h->fat ? n_units * a.n_slices : chain_grid(n_units, a.n_slices);
   a.timeline = tl_for(h, "chain_bwd_q");
   if (h->fwd_merge) { a.flags_reset = h->chain_flags; a.n_flags = kChainFlags; h->flags_dirty = false; }
   if (ride) a.ride = *ride;
@@ -1530,6 +1565,13 @@ int enqueue_chain_bwd_q(dsact_handle* h, int n_units, const RideArgs* ride) {
   BwdQArgs a;
   int rg, n_riders;
   bwd_q_args(h, n_units, ride, a, rg, n_riders);
+  if (h->fat) {
+    const int rt = rg / 4;
+    const size_t flds = (size_t)fat_lds(h->cW, 16 * rt, 0).total * sizeof(float);
+#define CALL_FQ(N, T) return launch(h, "chain_bwd_q", k_fat_bwd_q<N, T>, dim3(a.n_chain_blocks + n_riders), dim3(kThreads), flds, a)
+    FAT_NT(CALL_FQ, rt);
+#undef CALL_FQ
+  }
   const size_t lds = (size_t)chain_lds(h->cW, h->cW, 4 * rg).total * sizeof(float);
 #define CALL_CQ(N, G) return launch(h, "chain_bwd_q", k_chain_bwd_q<N, G>, dim3(a.n_chain_blocks + n_riders), dim3(kThreads), lds, a)
   CHAIN_NT(CALL_CQ, rg);
@@ -1542,14 +1584,14 @@ void bwd_pi_args(dsact_handle* h, int x0, int x1, bool fused, BwdPiArgs& a, int&
   const int L = h->L;
   a.dA[0] = h->dAq[0]; a.dA[1] = h->dAq[1];
   a.logits_pi = h->logits_pi; a.eps_new = h->eps_new; a.log_alpha = h->online + h->n_online - 1;
-  a.woutT = h->pk_bwd[2][L]; a.SoT = h->SoT;
+  a.woutT = h->pk_bwd[2][L]; a.SoT = h->fat ? h->c_out : h->SoT;
   for (int l = 1; l < L; ++l) a.wb[l] = h->pk_bwd[2][l];
   for (int l = 0; l < L; ++l) { a.G[l] = h->Gb[C_PI][l]; a.dZ[l] = h->dZ[kDzSlot[C_PI]][l]; }
   a.dout_pi = h->dout_pi; a.d_new_act = h->d_new_act; a.dout_piT = h->doutT[2];
   // the policy chain shares its launch with ~2 rounds of weight-gradient tiles, which bound it: 8-row workgroups leave
   // them 32 more CUs (measured: 15.7 us vs 16.3 us with 4-row workgroups at batch 256)
   const int rg_pi = h->env_chain_rg_pi;   // experiments
-  const int rg = rg_pi ? rg_pi : h->env_chain_rg ? h->env_chain_rg : (h->B >= 8 ? h->cRG : 1);
+  const int rg = h->fat ? 4 * fat_rt(h, 1) : rg_pi ? rg_pi : h->env_chain_rg ? h->env_chain_rg : (h->B >= 8 ? h->cRG : 1);
   a.n_slices = h->B / (4 * rg); a.B = h->B; a.A = h->A; a.L = L; a.Cb = h->B / 16;
   a.inv_B = 1.0f / (float)h->B; a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed;
   a.act_scale = h->act_scale; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
@@ -1566,6 +1608,14 @@ int enqueue_chain_bwd_pi(dsact_handle* h, int x0, int x1, bool fused) {
   BwdPiArgs a;
   int rg;
   bwd_pi_args(h, x0, x1, fused, a, rg);
+  if (h->fat) {
+    const int rt = rg / 4;
+    size_t flds = (size_t)fat_lds(h->cW, 16 * rt, 16 * h->c_out).total * sizeof(float);
+    if (flds < kDw2LdsFloats * sizeof(float)) flds = kDw2LdsFloats * sizeof(float);
+#define CALL_FP(N, T) return launch(h, "chain_bwd_pi", k_fat_bwd_pi<N, T>, dim3(a.n_chain_blocks + xcd_chunk_grid(a.n_extra) * h->dw_chunks), dim3(kThreads), flds, a)
+    FAT_NT(CALL_FP, rt);
+#undef CALL_FP
+  }
   size_t lds = (size_t)chain_lds(4 * h->SoT, h->cW, 4 * rg).total * sizeof(float);
   if (lds < kDw2LdsFloats * sizeof(float)) lds = kDw2LdsFloats * sizeof(float);
 #define CALL_CP(N, G) return launch(h, "chain_bwd_pi", k_chain_bwd_pi<N, G>, dim3(a.n_chain_blocks + xcd_chunk_grid(a.n_extra) * h->dw_chunks), dim3(kThreads), lds, a)
@@ -2026,6 +2076,13 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     h->rg4_ok = ok && h->B % 16 == 0 && getenv("DSACT_NO_RG4") == nullptr &&
                 (size_t)chain_lds(4 * (h->s_obs + h->s_act), W0, 16).total * sizeof(float) <= 150 * 1024;
     // merged forward launch: both groups resident at once (4-row group-B workgroups: batch <= 256), one flag per slice
+    h->c_obs = (h->F + 15) / 16; h->c_act = (h->A + 15) / 16; h->c_out = (2 * h->A + 15) / 16;
+    {
+      const char* fm = getenv("DSACT_FAT_MIN");
+      const int fat_min = fm ? atoi(fm) : 1024;
+      h->fat = ok && h->B >= fat_min && h->B % 32 == 0 && (W0 == 128 || W0 == 256) && getenv("DSACT_NO_FAT") == nullptr;
+      if (const char* v = getenv("DSACT_FAT_RT")) h->env_fat_rt = atoi(v) == 2 ? 2 : 1;
+    }
     h->fwd_merge = ok && h->B <= 256 && h->B / 4 <= kChainFlagSlices && chain_rg(h, 4) == 1 && getenv("DSACT_NO_FWD_MERGE") == nullptr;
   }
   Carver c0;

@@ -258,6 +258,22 @@ def test_humanoid_b2048_split_k_weight_gradients():
     run_case("humanoid 3x256 B=2048 (split-K weight gradients)", 376, 17, (256, 256, 256), 2048, steps=2)
 
 
+@pytest.mark.parametrize("B,hid,env", [
+    (1024, (256, 256, 256), {}),                              # 16-row workgroups (default choice at this batch)
+    (1024, (256, 256, 256), {"DSACT_FAT_RT": "2"}),           # 32-row workgroups forced
+    (512, (128, 128), {"DSACT_FAT_MIN": "512"}),              # two waves per workgroup (hidden width 128), two layers
+    (4096, (256, 256, 256), {}),                              # 32-row workgroups by choice, split-K weight gradients x16
+])
+def test_throughput_regime_kernels(B, hid, env, monkeypatch):
+    """dsact_fat.h (batch >= 1024): v_mfma_f32_16x16x4 slices of 16 / 32 rows, style-16 packs of every layer, in-place
+    LDS activations -- every intermediate, gradient, statistic and parameter against the oracle, same gates."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    run_case("fat B=%d hidden %s %s" % (B, "x".join(map(str, hid)), env), 376, 17, hid, B, steps=2)
+    for k in env:
+        monkeypatch.delenv(k, raising=False)
+
+
 @pytest.mark.parametrize("name", STEP_CASES)
 def test_against_reference_golden(name):
     z, cfg, init = load_step_case(name)
