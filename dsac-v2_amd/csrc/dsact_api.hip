@@ -3157,6 +3157,7 @@ int dsact_debug_set(dsact_handle* h, const char* name, double value) {
 int dsact_debug_get(const dsact_handle* h, const char* name, double* value) {
   if (!h || !name || !value) return DSACT_E_INVALID;
   if (!strcmp(name, "fwd_merge")) *value = h->fwd_merge ? 1.0 : 0.0;
+  else if (!strcmp(name, "fat")) *value = h->fat ? 1.0 : 0.0;
   else if (!strcmp(name, "handoff_failures")) *value = (double)h->handoff_failures;
   else if (!strcmp(name, "graph_steps")) *value = (double)h->graph_steps;
   else return DSACT_E_INVALID;

@@ -284,7 +284,7 @@ const char* dsact_debug_names(void);
  *   dsact_debug_set(h, "withhold_flag", 1)      one producer never raises its flag (forces the timeout path)
  *   dsact_debug_set(h, "poison_handover", v)    fills every buffer handed from producers to consumers with v (e.g. NaN)
  *   dsact_debug_set(h, "fwd_merge", 0|1)        merged forward launch off / on (when the shape allows it)
- *   dsact_debug_get(h, "fwd_merge" | "handoff_failures" | "graph_steps", &v) */
+ *   dsact_debug_get(h, "fwd_merge" | "fat" | "handoff_failures" | "graph_steps", &v) */
 int dsact_debug_set(dsact_handle* h, const char* name, double value);
 int dsact_debug_get(const dsact_handle* h, const char* name, double* value);
 /* stand-alone fused-MLP forward of the policy net on a host batch (sampler / evaluator feed):
