@@ -195,7 +195,10 @@ struct dsact_handle {
   bool chain_ok = false;
   int cW = 0, cNT = 0;                  // hidden width, W / 64
   int s_obs = 0, s_act = 0, SoT = 0;    // stream steps (4 k each): observation / action segment of a first layer, policy outputs (2A)
-  bool fat = false;                     // throughput-regime kernels (dsact_fat.h): 16x16x4 MFMA, 16/32-row slices, style-16 packs
+  // throughput-regime kernels (dsact_fat.h): 16x16x4 MFMA, 16/32-row slices, style-16 packs. Chosen per direction: the
+  // forward launches win from batch 1024 on (33 vs 58 us for group A), the backward ones -- fewer units per launch,
+  // hence fewer workgroups -- only from batch 4096 on (measured, profiles/r03_fat_batches.txt)
+  bool fat = false, fat_bwd = false;
   int c_obs = 0, c_act = 0, c_out = 0;  // fat mode: 16-k chunks of the observation / action segment of a first layer, of the policy outputs (2A)
   int env_fat_rt = 0;                   // DSACT_FAT_RT=1|2: force the rows per fat workgroup (16 / 32)
   int cRG = 2;                          // row groups of 4 per chain workgroup (8 rows) when 4-row workgroups would oversubscribe the CUs
@@ -563,8 +566,9 @@ int build_chain(dsact_handle* h) {
   const int tiles = W / 64, SH = W / 4, CH = W / 16;       // style 44: 64-row tiles, k4 steps; style 16: chunks of 16 k
   // fat mode (dsact_fat.h): EVERY pack is style 16 (16-row tiles x chunks of 16 k; a tile-chunk block is 256 floats like
   // a style-44 step, so the sizes below count blocks either way)
-  const bool fat = h->fat;
-  const int tiles_f = fat ? W / 16 : tiles, S_hid = fat ? CH : SH, S_out = fat ? h->c_out : h->SoT;
+  const bool fat = h->fat, fatb = h->fat_bwd;
+  const int tiles_f = fat ? W / 16 : tiles, S_hid = fat ? CH : SH;
+  const int tiles_b = fatb ? W / 16 : tiles, S_hidb = fatb ? CH : SH, S_out = fatb ? h->c_out : h->SoT;
   const int C0q = fat ? h->c_obs + h->c_act : h->s_obs + h->s_act, C0p = fat ? h->c_obs : h->s_obs;
   const int nth_q = 1, nth_p = (2 * A + 15) / 16, nta = (A + 15) / 16;
   // carve the packed copies
@@ -579,9 +583,9 @@ int build_chain(dsact_handle* h) {
     }
     for (int n3 = 0; n3 < 3; ++n3) {
       for (int l = 0; l <= L; ++l) h->pk_bwd[n3][l] = nullptr;
-      for (int l = 1; l < L; ++l) h->pk_bwd[n3][l] = c.take<float>((size_t)tiles_f * S_hid * 256);
+      for (int l = 1; l < L; ++l) h->pk_bwd[n3][l] = c.take<float>((size_t)tiles_b * S_hidb * 256);
     }
-    h->pk_bwd[2][L] = c.take<float>((size_t)tiles_f * S_out * 256);
+    h->pk_bwd[2][L] = c.take<float>((size_t)tiles_b * S_out * 256);
     for (int i = 0; i < 2; ++i) h->pk_w1at[i] = c.take<float>((size_t)nta * CH * 256);
     if (!pass) {
       HIPCHK(h, hipMalloc((void**)&h->pk_ws, c.off + 256));
@@ -600,9 +604,9 @@ int build_chain(dsact_handle* h) {
       m.fwd_44 = (l < L && !fat) ? 1 : 0;                         // the output layers are narrow products (style 16)
       m.fwd_C = l == 0 ? (pol ? C0p : C0q) : (l < L ? S_hid : CH);
       m.F = (l == 0 && !pol) ? F : (1 << 30); m.Fp = fat ? 16 * h->c_obs : 4 * h->s_obs;
-      if (l >= 1 && l < L) { m.bwd = h->pk_bwd[n3][l]; m.bwd_44 = fat ? 0 : 1; m.bwd_C = S_hid; m.bwd_k0 = 0; }
+      if (l >= 1 && l < L) { m.bwd = h->pk_bwd[n3][l]; m.bwd_44 = fatb ? 0 : 1; m.bwd_C = S_hidb; m.bwd_k0 = 0; }
       if (l == 0 && !pol) { m.bwd = h->pk_w1at[n3]; m.bwd_44 = 0; m.bwd_C = CH; m.bwd_k0 = F; }
-      if (l == L && pol) { m.bwd = h->pk_bwd[2][L]; m.bwd_44 = fat ? 0 : 1; m.bwd_C = S_out; m.bwd_k0 = 0; }
+      if (l == L && pol) { m.bwd = h->pk_bwd[2][L]; m.bwd_44 = fatb ? 0 : 1; m.bwd_C = S_out; m.bwd_k0 = 0; }
     }
   HIPCHK(h, hipMalloc((void**)&h->d_mir, mir.size() * sizeof(MirrorDesc)));
   HIPCHK(h, hipMemcpy(h->d_mir, mir.data(), mir.size() * sizeof(MirrorDesc), hipMemcpyHostToDevice));
@@ -1316,7 +1320,7 @@ Dw2Args dw2_args(dsact_handle* h, bool fused) {
   }
   h->dw2_off[3] = tiles;
   a.C = h->B / 16;
-  a.ct = a.C < 16 ? a.C : 16;
+  a.ct = a.C / h->dw_chunks;   // chunks per batch range (batch <= 256: one round of <= 16; else rounds of 16 inside the tile)
   a.n_base = tiles;
   a.gout = h->dw_chunks > 1 ? h->dw_parts : h->grads;
   a.part_stride = h->dw_chunks > 1 ? (long long)h->dw_part_stride : 0;
@@ -1541,7 +1545,7 @@ void bwd_q_args(dsact_handle* h, int n_units, const RideArgs* ride, BwdQArgs& a,
     if (w >= 2) { u.w1at = h->pk_w1at[n3]; u.dA = h->dAq[n3]; }
     u.which = w;
   }
-  const int rg = h->fat ? 4 * fat_rt(h, n_units) : chain_rg(h, n_units, true);
+  const int rg = h->fat_bwd ? 4 * fat_rt(h, n_units) : chain_rg(h, n_units, true);
   a.n_units = n_units; a.n_slices = h->B / (4 * rg); a.B = h->B; a.A = h->A; a.L = L; a.Cb = h->B / 16;
   for (int i = 0; i < 2; ++i) { a.qout_c[i] = h->qout_c[i]; a.qstd_c[i] = h->qstd_c[i]; a.qout_t[i] = h->qout_t[i]; a.qout_p[i] = h->qout_p[i]; }
   a.rew = h->rew; a.done = h->done; a.logp2 = h->logp2; a.logp_new = h->logp_new; a.z5 = h->z5; a.z6 = h->z6;
@@ -1552,7 +1556,7 @@ void bwd_q_args(dsact_handle* h, int n_units, const RideArgs* ride, BwdQArgs& a,
   a.std_sums = h->use_std_sums ? h->std_sums : nullptr;
   a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.gamma = h->cfg.gamma; a.tau_b = h->cfg.tau_b;
   a.one_minus_tau_b = (float)(1.0 - h->cfg.tau_b);
-  a.n_chain_blocks = h->fat ? n_units * a.n_slices : chain_grid(n_units, a.n_slices);
+  a.n_chain_blocks = h->fat_bwd ? n_units * a.n_slices : chain_grid(n_units, a.n_slices);
   a.timeline = tl_for(h, "chain_bwd_q");
   if (h->fwd_merge) { a.flags_reset = h->chain_flags; a.n_flags = kChainFlags; h->flags_dirty = false; }
   if (ride) a.ride = *ride;
@@ -1565,7 +1569,7 @@ int enqueue_chain_bwd_q(dsact_handle* h, int n_units, const RideArgs* ride) {
   BwdQArgs a;
   int rg, n_riders;
   bwd_q_args(h, n_units, ride, a, rg, n_riders);
-  if (h->fat) {
+  if (h->fat_bwd) {
     const int rt = rg / 4;
     const size_t flds = (size_t)fat_lds(h->cW, 16 * rt, 0).total * sizeof(float);
 #define CALL_FQ(N, T) return launch(h, "chain_bwd_q", k_fat_bwd_q<N, T>, dim3(a.n_chain_blocks + n_riders), dim3(kThreads), flds, a)
@@ -1584,14 +1588,14 @@ void bwd_pi_args(dsact_handle* h, int x0, int x1, bool fused, BwdPiArgs& a, int&
   const int L = h->L;
   a.dA[0] = h->dAq[0]; a.dA[1] = h->dAq[1];
   a.logits_pi = h->logits_pi; a.eps_new = h->eps_new; a.log_alpha = h->online + h->n_online - 1;
-  a.woutT = h->pk_bwd[2][L]; a.SoT = h->fat ? h->c_out : h->SoT;
+  a.woutT = h->pk_bwd[2][L]; a.SoT = h->fat_bwd ? h->c_out : h->SoT;
   for (int l = 1; l < L; ++l) a.wb[l] = h->pk_bwd[2][l];
   for (int l = 0; l < L; ++l) { a.G[l] = h->Gb[C_PI][l]; a.dZ[l] = h->dZ[kDzSlot[C_PI]][l]; }
   a.dout_pi = h->dout_pi; a.d_new_act = h->d_new_act; a.dout_piT = h->doutT[2];
   // the policy chain shares its launch with ~2 rounds of weight-gradient tiles, which bound it: 8-row workgroups leave
   // them 32 more CUs (measured: 15.7 us vs 16.3 us with 4-row workgroups at batch 256)
   const int rg_pi = h->env_chain_rg_pi;   // experiments
-  const int rg = h->fat ? 4 * fat_rt(h, 1) : rg_pi ? rg_pi : h->env_chain_rg ? h->env_chain_rg : (h->B >= 8 ? h->cRG : 1);
+  const int rg = h->fat_bwd ? 4 * fat_rt(h, 1) : rg_pi ? rg_pi : h->env_chain_rg ? h->env_chain_rg : (h->B >= 8 ? h->cRG : 1);
   a.n_slices = h->B / (4 * rg); a.B = h->B; a.A = h->A; a.L = L; a.Cb = h->B / 16;
   a.inv_B = 1.0f / (float)h->B; a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed;
   a.act_scale = h->act_scale; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
@@ -1608,7 +1612,7 @@ int enqueue_chain_bwd_pi(dsact_handle* h, int x0, int x1, bool fused) {
   BwdPiArgs a;
   int rg;
   bwd_pi_args(h, x0, x1, fused, a, rg);
-  if (h->fat) {
+  if (h->fat_bwd) {
     const int rt = rg / 4;
     size_t flds = (size_t)fat_lds(h->cW, 16 * rt, 16 * h->c_out).total * sizeof(float);
     if (flds < kDw2LdsFloats * sizeof(float)) flds = kDw2LdsFloats * sizeof(float);
@@ -2055,7 +2059,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (const char* v = getenv("DSACT_CHAIN_RG_PI")) h->env_chain_rg_pi = atoi(v);
   h->env_no_mixed_rg = getenv("DSACT_NO_MIXED_RG") != nullptr;
   if (const char* v = getenv("DSACT_CHAIN_RG")) h->env_chain_rg = atoi(v) == 1 ? 1 : atoi(v) == 4 ? 4 : 2;
-  h->dw_chunks = (h->B > 448 && h->B % 256 == 0 && getenv("DSACT_NO_SPLITK") == nullptr) ? h->B / 256 : 1;
+  h->dw_chunks = (h->B > 448 && h->B % 256 == 0 && getenv("DSACT_NO_SPLITK") == nullptr) ? h->B / 256 : 1;   // (chain path: below)
   h->dw_part_stride = (h->n_online + 2 + 63) & ~(size_t)63;
   {
     // row-slice fused chains: MLP nets of DSAC_V2 with equal hidden widths of 64 / 128 / 256, batch a multiple of 16
@@ -2072,6 +2076,13 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     // LDS: input slice + two hidden slices + partial tiles must fit beside nothing else (one workgroup per CU)
     ok = ok && (size_t)chain_lds(4 * (h->s_obs + h->s_act), W0, R).total * sizeof(float) <= 150 * 1024;
     h->chain_ok = ok;
+    if (ok) {
+      // chain path: a weight-gradient tile contracts up to 1024 batch rows itself (rounds of 256, dw2_tile), so up to
+      // batch 1024 there is ONE gradient arena and the optimiser stays fused into the tiles (no split-K partials, no
+      // streaming Adam pass, and the graph keeps the riding gather); beyond that one partial arena per 1024 rows
+      const int per = (h->B > 1024 && h->B % 1024 == 0 && getenv("DSACT_DW_RANGE_256") == nullptr) ? 1024 : 256;
+      h->dw_chunks = h->B > 1024 || (h->B > 256 && getenv("DSACT_DW_RANGE_256") != nullptr) ? h->B / per : 1;
+    }
     h->cW = W0; h->cNT = W0 / 64; h->n_slices = h->B / R;
     h->rg4_ok = ok && h->B % 16 == 0 && getenv("DSACT_NO_RG4") == nullptr &&
                 (size_t)chain_lds(4 * (h->s_obs + h->s_act), W0, 16).total * sizeof(float) <= 150 * 1024;
@@ -2080,7 +2091,10 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     {
       const char* fm = getenv("DSACT_FAT_MIN");
       const int fat_min = fm ? atoi(fm) : 1024;
+      const char* fb = getenv("DSACT_FAT_BWD_MIN");
+      const int fat_bwd_min = fb ? atoi(fb) : 4096;
       h->fat = ok && h->B >= fat_min && h->B % 32 == 0 && (W0 == 128 || W0 == 256) && getenv("DSACT_NO_FAT") == nullptr;
+      h->fat_bwd = h->fat && h->B >= fat_bwd_min;
       if (const char* v = getenv("DSACT_FAT_RT")) h->env_fat_rt = atoi(v) == 2 ? 2 : 1;
     }
     h->fwd_merge = ok && h->B <= 256 && h->B / 4 <= kChainFlagSlices && chain_rg(h, 4) == 1 && getenv("DSACT_NO_FWD_MERGE") == nullptr;
@@ -3157,7 +3171,7 @@ int dsact_debug_set(dsact_handle* h, const char* name, double value) {
 int dsact_debug_get(const dsact_handle* h, const char* name, double* value) {
   if (!h || !name || !value) return DSACT_E_INVALID;
   if (!strcmp(name, "fwd_merge")) *value = h->fwd_merge ? 1.0 : 0.0;
-  else if (!strcmp(name, "fat")) *value = h->fat ? 1.0 : 0.0;
+  else if (!strcmp(name, "fat")) *value = (h->fat ? 1.0 : 0.0) + (h->fat_bwd ? 2.0 : 0.0);
   else if (!strcmp(name, "handoff_failures")) *value = (double)h->handoff_failures;
   else if (!strcmp(name, "graph_steps")) *value = (double)h->graph_steps;
   else return DSACT_E_INVALID;

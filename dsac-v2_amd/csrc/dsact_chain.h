@@ -230,7 +230,7 @@ struct DwProb {
 constexpr int kMaxDwProb = 3 * (kChMaxL + 1);
 struct Dw2Args {
   DwProb p[kMaxDwProb]; int n_prob;
-  int C, ct;              // chunks (16 batch rows) per operand row tile; chunks per tile (<= 16)
+  int C, ct;              // chunks (16 batch rows) per operand row tile; chunks per tile (<= 16 per round, rounds as needed)
   int n_base;             // tiles of one batch range (split-K: tile index = range * n_base + base tile)
   float* gout;            // gradient destination arena (grads; split-K: partial arena 0)
   long long part_stride;  // split-K: floats between the partial arenas
@@ -252,20 +252,26 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds) {
   const int local = bt - (pi ? a.p[pi - 1].tile_end : 0);
   const int mt = local / P.tiles_n, nt = local - mt * P.tiles_n;
   const int m0 = 32 * mt, n0 = 32 * nt;
-  // ---- operand fragments of this wave's share of the contraction: chunks c_lo + wave*cw + q
-  const int cw = (a.ct + 3) >> 2;
+  // ---- the contraction runs in rounds of <= 16 chunks (256 batch rows): per round the 4 waves split the chunks, chunk
+  //      c_lo + cb + wave*cw + q; batch <= 256 is one round (the fragments below are loaded before the optimiser state)
   const int c_lo = range * a.ct;
+  auto round_cw = [&](int cb) { const int ctr = a.ct - cb < 16 ? a.ct - cb : 16; return (ctr + 3) >> 2; };
+  auto round_n = [&](int cb) { return a.ct - cb < 16 ? a.ct - cb : 16; };
   f32x4 fa[4][2], fx[4][2];
+  auto load_round = [&](int cb) {
+    const int cw = round_cw(cb), ctr = round_n(cb);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const bool ok = q < cw && wave * cw + q < a.ct;
-    const int c = c_lo + (ok ? wave * cw + q : 0);
+    for (int q = 0; q < 4; ++q) {
+      const bool ok = q < cw && wave * cw + q < ctr;
+      const int c = c_lo + cb + (ok ? wave * cw + q : 0);
 #pragma unroll
-    for (int b2 = 0; b2 < 2; ++b2) {
-      fa[q][b2] = gload4(P.At + ((size_t)(2 * mt + b2) * a.C + c) * 256 + lane4);
-      fx[q][b2] = gload4(P.Xt + ((size_t)(2 * nt + b2) * a.C + c) * 256 + lane4);
+      for (int b2 = 0; b2 < 2; ++b2) {
+        fa[q][b2] = gload4(P.At + ((size_t)(2 * mt + b2) * a.C + c) * 256 + lane4);
+        fx[q][b2] = gload4(P.Xt + ((size_t)(2 * nt + b2) * a.C + c) * 256 + lane4);
+      }
     }
-  }
+  };
+  load_round(0);
   // ---- this lane's share of the epilogue: 16x16 block (wave>>1, wave&1), rows m, columns n .. n+3
   const int m = m0 + 16 * (wave >> 1) + i, n = n0 + 16 * (wave & 1) + 4 * g;
   const bool in_range = m < P.M && n < P.N, full = n + 3 < P.N;
@@ -292,18 +298,22 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds) {
 #pragma unroll
     for (int bn = 0; bn < 2; ++bn) acc[bm][bn] = f32x4{0.f, 0.f, 0.f, 0.f};
   float sb[2] = {0.f, 0.f};
+  for (int cb = 0; cb < a.ct; cb += 16) {
+    if (cb) load_round(cb);
+    const int cw = round_cw(cb), ctr = round_n(cb);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    if (q < cw && wave * cw + q < a.ct) {   // wave-uniform
+    for (int q = 0; q < 4; ++q) {
+      if (q < cw && wave * cw + q < ctr) {   // wave-uniform
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int bm = 0; bm < 2; ++bm)
+          for (int bm = 0; bm < 2; ++bm)
 #pragma unroll
-          for (int bn = 0; bn < 2; ++bn)
-            acc[bm][bn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fx[q][bn][e], fa[q][bm][e], acc[bm][bn], 0, 0, 0);
+            for (int bn = 0; bn < 2; ++bn)
+              acc[bm][bn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fx[q][bn][e], fa[q][bm][e], acc[bm][bn], 0, 0, 0);
 #pragma unroll
-      for (int bm = 0; bm < 2; ++bm) sb[bm] += (fa[q][bm][0] + fa[q][bm][1]) + (fa[q][bm][2] + fa[q][bm][3]);
+        for (int bm = 0; bm < 2; ++bm) sb[bm] += (fa[q][bm][0] + fa[q][bm][1]) + (fa[q][bm][2] + fa[q][bm][3]);
+      }
     }
   }
   // ---- partial blocks -> LDS -> block `wave`

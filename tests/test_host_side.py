@@ -182,7 +182,7 @@ def test_bench_helpers():
         g = bench.graph_steps(steps, warm)
         assert 1 <= g <= 64 and steps % g == 0 and (warm % g == 0 or warm == 0), (steps, warm, g)
     assert bench.graph_steps(20, 6, even=True) % 2 == 0
-    assert bench.n_regions(20) == 15 and bench.n_regions(4000) == 5 and bench.n_regions(20000) == 3
+    assert bench.n_regions(20) == 61 and bench.n_regions(4000) == 5 and bench.n_regions(20000) == 3
     from dsact.layout import ArenaLayout
     lay = ArenaLayout(376, 17, [256, 256, 256])
     fl = bench.chain_flops(lay, 256)
