@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -17,6 +18,7 @@
 #include "dsact_kernels.h"
 #include "dsact_chain.h"
 #include "dsact_fat.h"
+#include "dsact_act.h"
 #include "dsact_conv.h"
 
 using namespace dsact;
@@ -221,6 +223,12 @@ struct dsact_handle {
   bool in_handoff = false;
   int handoff_failures = 0;
   int debug_withhold = 0;               // dsact_debug_set("withhold_flag"): tests force the timeout path
+  // single-launch acting forward (dsact_act.h): mapped host block = [hand-off word | done counter | logits], device scratch
+  int* act_done_host = nullptr; int* act_done_dev = nullptr;
+  float* act_out_host = nullptr; float* act_out_dev = nullptr;
+  float* act_h = nullptr; int* act_cnt = nullptr;   // device: [2][kMaxWidth] activations, [kActMaxLayers] arrival counters
+  int act_call = 0;
+  bool env_no_fast_act = false;         // DSACT_NO_FAST_ACT: the sampler's forward through the copy + tile-stage path (A/B)
   int env_chain_rg_pi = 0;              // DSACT_CHAIN_RG_PI (experiments)
   bool env_no_mixed_rg = false;         // DSACT_NO_MIXED_RG: every unit of the merged forward's group A runs 8-row workgroups (A/B)
   bool fwd_merge = false;               // launches A and B as one (batch <= 256)
@@ -2182,9 +2190,15 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<false, EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<true, EPI_MULG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
   }
-  HIPCHK(h, hipHostMalloc((void**)&h->handoff_host, 64, hipHostMallocMapped));
-  memset(h->handoff_host, 0, 64);
+  HIPCHK(h, hipHostMalloc((void**)&h->handoff_host, 1024, hipHostMallocMapped));
+  memset(h->handoff_host, 0, 1024);
   HIPCHK(h, hipHostGetDevicePointer((void**)&h->handoff_dev, h->handoff_host, 0));
+  h->act_done_host = h->handoff_host + 16; h->act_done_dev = h->handoff_dev + 16;
+  h->act_out_host = (float*)(h->handoff_host + 32); h->act_out_dev = (float*)(h->handoff_dev + 32);
+  h->env_no_fast_act = getenv("DSACT_NO_FAST_ACT") != nullptr;
+  HIPCHK(h, hipMalloc((void**)&h->act_h, (2 * kMaxWidth + 64) * sizeof(float)));
+  HIPCHK(h, hipMemset(h->act_h, 0, (2 * kMaxWidth + 64) * sizeof(float)));
+  h->act_cnt = (int*)(h->act_h + 2 * kMaxWidth);
   if (h->fwd_merge) {
     // the merged forward is sized for both groups' workgroups being resident at once: two per CU (speed, not
     // correctness -- consumers only wait for lower block ids, which are always dispatched first)
@@ -2215,6 +2229,7 @@ int dsact_destroy(dsact_handle* h) {
     if (h->h_idx_ev[i]) hipEventDestroy(h->h_idx_ev[i]);
   }
   if (h->handoff_host) hipHostFree(h->handoff_host);
+  if (h->act_h) hipFree(h->act_h);
   if (h->d_tiles) hipFree(h->d_tiles);
   if (h->alt.d_tiles) hipFree(h->alt.d_tiles);
   if (h->alt_ws) hipFree(h->alt_ws);
@@ -3184,6 +3199,46 @@ int dsact_policy_forward(dsact_handle* h, const float* obs_host, int32_t n, floa
   if (!h->online) return fail(h, DSACT_E_STATE, "arenas not bound");
   HIPCHK(h, hipSetDevice(h->device));
   const size_t O = h->O, ld = h->ldx;
+  if (!h->cnn && n == 1 && h->O <= kActMaxObs && h->L + 1 <= kActMaxLayers && !h->env_no_fast_act) {
+    // one launch: observation in the kernel arguments, logits back through mapped host memory (dsact_act.h)
+    TRY(check_handoff(h));
+    ActArgs a;
+    a.n_layers = h->L + 1;
+    const float* base = net_params(h, N_POL);
+    int wg = 0;
+    for (int l = 0; l <= h->L; ++l) {
+      a.ly[l].W = base + h->pd.w_off[l]; a.ly[l].b = base + h->pd.b_off[l];
+      a.ly[l].K = h->pd.in[l]; a.ly[l].N = h->pd.out[l];
+      a.wg_begin[l] = wg;
+      wg += (h->pd.out[l] + 3) / 4;
+    }
+    a.wg_begin[h->L + 1] = wg;
+    const int wg_out = wg - a.wg_begin[h->L];
+    if (h->act_call >= (1 << 22)) {   // keep the monotone counters far from wrapping
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      HIPCHK(h, hipMemset(h->act_cnt, 0, 64 * sizeof(int)));
+      *(volatile int*)h->act_done_host = 0;
+      h->act_call = 0;
+    }
+    a.h[0] = h->act_h; a.h[1] = h->act_h + kMaxWidth; a.cnt = h->act_cnt;
+    a.call = ++h->act_call;
+    a.A = h->A; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
+    a.out = h->act_out_dev; a.done = h->act_done_dev; a.timeout = h->handoff_dev;
+    memcpy(a.x, obs_host, O * sizeof(float));
+    TRY(launch(h, "act_mlp", k_act_mlp, dim3(wg), dim3(256), 0, a));
+    const int target = a.call * wg_out;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned polls = 0;
+    while (*(volatile int*)h->act_done_host - target < 0) {
+      if ((++polls & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));   // surfaces a device fault, if that is what happened
+        if (*(volatile int*)h->act_done_host - target < 0) return fail(h, DSACT_E_HIP, "acting forward did not complete");
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    memcpy(logits_host, h->act_out_host, (size_t)2 * h->A * sizeof(float));
+    return check_handoff(h);
+  }
   if (h->cnn) {
     // conv stack of the online policy on n images: (C,H,W) rows -> pixel-major -> conv layers -> feature rows
     if (!h->stage_img) HIPCHK(h, hipMalloc(&h->stage_img, 2 * (size_t)h->Brows * O * sizeof(float)));

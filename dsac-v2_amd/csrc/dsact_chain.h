@@ -252,26 +252,35 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds) {
   const int local = bt - (pi ? a.p[pi - 1].tile_end : 0);
   const int mt = local / P.tiles_n, nt = local - mt * P.tiles_n;
   const int m0 = 32 * mt, n0 = 32 * nt;
-  // ---- the contraction runs in rounds of <= 16 chunks (256 batch rows): per round the 4 waves split the chunks, chunk
-  //      c_lo + cb + wave*cw + q; batch <= 256 is one round (the fragments below are loaded before the optimiser state)
+  // ---- the contraction runs in rounds of <= 16 chunks (256 batch rows); in a round the 4 waves split the chunks (wave w:
+  //      chunks cb + w*cw + q, q < cw <= 4). The fragments travel in two register sets of two chunks each (half rounds):
+  //      both are loaded up front -- batch <= 256 is exactly that, one round -- and a set is refilled with the half round
+  //      two ahead as soon as its MFMAs are issued, so longer contractions (batch 512 .. 1024 per range) stream.
   const int c_lo = range * a.ct;
-  auto round_cw = [&](int cb) { const int ctr = a.ct - cb < 16 ? a.ct - cb : 16; return (ctr + 3) >> 2; };
-  auto round_n = [&](int cb) { return a.ct - cb < 16 ? a.ct - cb : 16; };
-  f32x4 fa[4][2], fx[4][2];
-  auto load_round = [&](int cb) {
-    const int cw = round_cw(cb), ctr = round_n(cb);
+  const int n_half = 2 * ((a.ct + 15) >> 4);
+  f32x4 fa[2][2][2], fx[2][2][2];
+  auto half_ok = [&](int hr, int q2, int& c) {
+    const int cb = (hr >> 1) << 4;
+    const int ctr = a.ct - cb < 16 ? a.ct - cb : 16, cw = (ctr + 3) >> 2;
+    const int q = 2 * (hr & 1) + q2;
+    const bool ok = q < cw && wave * cw + q < ctr;
+    c = c_lo + cb + (ok ? wave * cw + q : 0);
+    return ok;
+  };
+  auto load_half = [&](int set, int hr) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const bool ok = q < cw && wave * cw + q < ctr;
-      const int c = c_lo + cb + (ok ? wave * cw + q : 0);
+    for (int q2 = 0; q2 < 2; ++q2) {
+      int c;
+      (void)half_ok(hr, q2, c);
 #pragma unroll
       for (int b2 = 0; b2 < 2; ++b2) {
-        fa[q][b2] = gload4(P.At + ((size_t)(2 * mt + b2) * a.C + c) * 256 + lane4);
-        fx[q][b2] = gload4(P.Xt + ((size_t)(2 * nt + b2) * a.C + c) * 256 + lane4);
+        fa[set][q2][b2] = gload4(P.At + ((size_t)(2 * mt + b2) * a.C + c) * 256 + lane4);
+        fx[set][q2][b2] = gload4(P.Xt + ((size_t)(2 * nt + b2) * a.C + c) * 256 + lane4);
       }
     }
   };
-  load_round(0);
+  load_half(0, 0);
+  load_half(1, 1);
   // ---- this lane's share of the epilogue: 16x16 block (wave>>1, wave&1), rows m, columns n .. n+3
   const int m = m0 + 16 * (wave >> 1) + i, n = n0 + 16 * (wave & 1) + 4 * g;
   const bool in_range = m < P.M && n < P.N, full = n + 3 < P.N;
@@ -298,23 +307,29 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds) {
 #pragma unroll
     for (int bn = 0; bn < 2; ++bn) acc[bm][bn] = f32x4{0.f, 0.f, 0.f, 0.f};
   float sb[2] = {0.f, 0.f};
-  for (int cb = 0; cb < a.ct; cb += 16) {
-    if (cb) load_round(cb);
-    const int cw = round_cw(cb), ctr = round_n(cb);
+  auto mma_half = [&](int set, int hr) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (q < cw && wave * cw + q < ctr) {   // wave-uniform
+    for (int q2 = 0; q2 < 2; ++q2) {
+      int c;
+      if (half_ok(hr, q2, c)) {   // wave-uniform
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int bm = 0; bm < 2; ++bm)
 #pragma unroll
             for (int bn = 0; bn < 2; ++bn)
-              acc[bm][bn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fx[q][bn][e], fa[q][bm][e], acc[bm][bn], 0, 0, 0);
+              acc[bm][bn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fx[set][q2][bn][e], fa[set][q2][bm][e], acc[bm][bn], 0, 0, 0);
 #pragma unroll
-        for (int bm = 0; bm < 2; ++bm) sb[bm] += (fa[q][bm][0] + fa[q][bm][1]) + (fa[q][bm][2] + fa[q][bm][3]);
+        for (int bm = 0; bm < 2; ++bm)
+          sb[bm] += (fa[set][q2][bm][0] + fa[set][q2][bm][1]) + (fa[set][q2][bm][2] + fa[set][q2][bm][3]);
       }
     }
+  };
+  for (int hr = 0; hr < n_half; hr += 2) {
+    mma_half(0, hr);
+    if (hr + 2 < n_half) load_half(0, hr + 2);
+    mma_half(1, hr + 1);
+    if (hr + 3 < n_half) load_half(1, hr + 3);
   }
   // ---- partial blocks -> LDS -> block `wave`
   const bool bias = nt == 0 && P.b_idx >= 0;

@@ -678,6 +678,48 @@ def test_policy_forward_and_checkpoint_roundtrip(tmp_path):
     assert torch.allclose(cpu.policy(obs), lg, atol=2e-5, rtol=1e-5)
 
 
+def test_single_launch_acting_forward(monkeypatch):
+    """dsact_act.h: the sampler's batch-1 `networks.policy(obs)` as one launch (observation in the kernel arguments,
+    logits through mapped host memory) == the copy + tile-stage path, follows the live weights through updates, and
+    survives thousands of calls (monotone arrival counters)."""
+    O, A, hid, B = 376, 17, (256, 256, 256), 256
+    alg, orc = make_pair(O, A, hid, B, seed=51)
+    e = alg.engine
+    from oracle.dsact_oracle import policy_forward
+    rng = np.random.default_rng(3)
+    obs = rng.standard_normal((64, O)).astype(np.float32)
+    slow = e.policy_forward(obs)                       # n = 64: the batched path
+    fast = np.concatenate([e.policy_forward(obs[i:i + 1]) for i in range(64)])
+    assert fast.shape == slow.shape == (64, 2 * A)
+    np.testing.assert_allclose(fast, slow, atol=2e-6, rtol=1e-6)
+    want = policy_forward(torch.as_tensor(obs), [p.detach() for p in orc.p["policy"]], orc.cfg).numpy()
+    np.testing.assert_allclose(fast, want, atol=2e-5, rtol=1e-5)
+    # the forward reads the parameter arena itself: after an update (issued asynchronously on the same stream) the
+    # next call sees the new policy
+    data = synth_batch(rng, B, O, A)
+    torch.manual_seed(1)
+    alg.local_update(data, 0)
+    after = e.policy_forward(obs[:1])
+    assert np.abs(after - fast[:1]).max() > 1e-6
+    sd = [p.detach().cpu() for p in alg.networks.policy.policy.parameters()]
+    x = torch.as_tensor(obs[:1])
+    for k in range(0, len(sd) - 2, 2):
+        x = torch.nn.functional.gelu(x @ sd[k].T + sd[k + 1])
+    out = x @ sd[-2].T + sd[-1]
+    ref = torch.cat([out[:, :A], torch.clamp(out[:, A:], -20.0, 0.5).exp()], dim=-1).numpy()
+    np.testing.assert_allclose(after, ref, atol=2e-5, rtol=1e-5)
+    for i in range(3000):                                # counters, mapped completion word, no leaks
+        got = e.policy_forward(obs[i % 64:i % 64 + 1])
+    np.testing.assert_allclose(got, e.policy_forward(obs[(2999 % 64):(2999 % 64) + 1]), atol=0, rtol=0)
+    assert e.debug_get("handoff_failures") == 0.0
+    # narrow / ragged nets take the same path
+    alg2, orc2 = make_pair(5, 1, (33,), 7, act_limit=2.0, seed=52)
+    o2 = rng.standard_normal((3, 5)).astype(np.float32)
+    f2 = np.concatenate([alg2.engine.policy_forward(o2[i:i + 1]) for i in range(3)])
+    w2 = policy_forward(torch.as_tensor(o2), [p.detach() for p in orc2.p["policy"]], orc2.cfg).numpy()
+    np.testing.assert_allclose(f2, w2, atol=2e-5, rtol=1e-5)
+
+
 def _replay_pair(O, A, hid, B, N, seed):
     alg, _ = make_pair(O, A, hid, B, seed=seed)
     e = alg.engine
