@@ -301,8 +301,12 @@ def cpu_baseline_child(hidden, n_rows=CPU_ROWS, warm=50, timed=300, budget_s=12.
     v4 = legs[4]
     who = ("unmodified reference (create_alg -> DSAC_V2, create_buffer -> ReplayBuffer)" if use_ref else
            "oracle port of the reference arithmetic (the reference is not mounted on this box)")
+    try:
+        e2e = e2e_cpu(hidden)
+    except Exception as ex:   # informational leg
+        e2e = {"error": repr(ex)}
     return {"value": v4.get("value"), "unit": "steps/s", "cores": 4, "kind": "reference" if use_ref else "port",
-            "all_cores": dict(legs[ncpu], cores=ncpu),
+            "all_cores": dict(legs[ncpu], cores=ncpu), "e2e": e2e,
             "sample": "%s: sample_batch(256) + local_update, hidden %s, %d-row host buffer (SURVEY 8d recipe; 1M rows = minutes of first-touch page faults in this sandbox), %s warm-up + "
                       "%s timed updates in %.1f s at 4 torch threads, torch %s / numpy %s CPU, %d host cores"
                       % (who, "x".join(map(str, hidden)), n_rows, v4.get("warmup"), v4.get("updates"), v4.get("seconds", 0.0),
@@ -322,6 +326,158 @@ def cpu_baseline(hidden, timeout_s=150):
     if r.returncode != 0 or not lines:
         return {"value": None, "unit": "steps/s", "cores": 4, "kind": "port", "sample": "CPU baseline leg failed: %s" % r.stderr[-300:]}
     return json.loads(lines[-1])
+
+
+E2E_ENV = "synth_humanoid"
+
+
+def e2e_kwargs(hidden, batch, **over):
+    """the flat argument dict of example_train/dsacv2_mlp_mujoco_offserial.py for the end-to-end loop on the
+    Humanoid-SHAPED synthetic environment (tests/envs/synth_humanoid_data.py: obs 376, act 17, a table lookup per step)"""
+    import numpy as np
+
+    envs = os.path.join(ROOT, "tests", "envs")
+    if envs not in sys.path:
+        sys.path.append(envs)
+    kw = dict(
+        env_id=E2E_ENV, algorithm="DSAC_V2_HIP", seed=7, action_type="continu", reward_scale=1, is_render=False,
+        value_func_name="ActionValueDistri", value_func_type="MLP", value_hidden_sizes=list(hidden),
+        value_hidden_activation="gelu", value_output_activation="linear", value_min_log_std=-8, value_max_log_std=8,
+        policy_func_name="StochaPolicy", policy_func_type="MLP", policy_act_distribution="TanhGaussDistribution",
+        policy_hidden_sizes=list(hidden), policy_hidden_activation="gelu", policy_output_activation="linear",
+        policy_min_log_std=-20, policy_max_log_std=0.5, value_learning_rate=1e-4, policy_learning_rate=1e-4,
+        alpha_learning_rate=3e-4, gamma=0.99, tau=0.005, auto_alpha=True, alpha=0.2, delay_update=2, TD_bound=1, bound=True,
+        trainer="off_serial_trainer", ini_network_dir=None, buffer_name="hip_replay_buffer", buffer_warm_size=2000,
+        buffer_max_size=100000, replay_batch_size=batch, sample_interval=1, sample_batch_size=20, batch_size_per_sampler=20,
+        noise_params=None, num_eval_episode=1, eval_interval=10 ** 9, eval_save=False, save_folder=None,
+        apprfunc_save_interval=10 ** 9, log_save_interval=10 ** 9, max_iteration=10 ** 9, use_gpu=True, enable_cuda=True,
+        obsv_dim=O, action_dim=A, action_high_limit=np.full((A,), 0.4, np.float32),
+        action_low_limit=np.full((A,), -0.4, np.float32), additional_info={}, cnn_shared=False,
+    )
+    kw.update(over)
+    return kw
+
+
+def _timed_loop(trainer, sampler, warm, iters, sync):
+    """`warm` + `iters` iterations of trainer.step(); returns (seconds, sampler seconds) of the timed part"""
+    acc = {"s": 0.0}
+    inner = sampler.sample
+
+    def sample():
+        t0 = time.perf_counter()
+        out = inner()
+        acc["s"] += time.perf_counter() - t0
+        return out
+
+    sampler.sample = sample
+    for _ in range(warm):
+        trainer.step()
+        trainer.iteration += 1
+    sync()
+    acc["s"] = 0.0
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        trainer.step()
+        trainer.iteration += 1
+    sync()
+    return time.perf_counter() - t0, acc["s"]
+
+
+def e2e_gpu(hidden, device, iters=400, warm=60):
+    """BASELINE.json configs[1] END TO END through the drop-in surface (training/trainer.py:60-82): per iteration the
+    sampler takes 20 environment steps acting with the live learner weights (single-launch HIP forward, dsact_act.h),
+    add_batch writes them to the HBM ring, sample_batch draws 256 indices (np.random.randint) and gathers, local_update
+    enqueues one update. Nothing is logged or evaluated inside the timed part. Not the headline value."""
+    import plugin
+
+    kw = e2e_kwargs(hidden, B, hip_device=device)
+    alg = plugin.create_alg(**kw)
+    sampler = plugin.create_sampler(**kw)
+    buf = plugin.create_buffer(**kw)
+    trainer = plugin.create_trainer(alg, sampler, buf, None, **kw)
+    w, ws = _timed_loop(trainer, sampler, warm, iters, alg.engine.sync)
+    e = alg.engine
+    obs1 = sampler.obs[None].astype("float32")
+    for _ in range(50):
+        e.policy_forward(obs1)
+    t0 = time.perf_counter()
+    for _ in range(500):
+        e.policy_forward(obs1)
+    fwd_us = (time.perf_counter() - t0) / 500 * 1e6
+    return {"value": iters / w, "unit": "iterations/s", "ms_per_iteration": 1000.0 * w / iters,
+            "sampler_ms_per_iteration": 1000.0 * ws / iters, "env_steps_per_iteration": kw["sample_batch_size"],
+            "policy_forward_us": fwd_us, "iterations": iters,
+            "note": "HipOffSerialTrainer.step(): 20 env steps (Humanoid-shaped table-lookup env, ~2 us/step: the figure is the "
+                    "framework's cost, not MuJoCo's) + add_batch + sample_batch(256) + local_update; policy_forward_us = one acting "
+                    "forward call (observation in the kernel arguments, logits through mapped host memory)"}
+
+
+def e2e_cpu(hidden, budget_s=10.0):
+    """the same loop on the host cores: the UNMODIFIED reference trainer (its own factories, CPU nets) where
+    /root/reference is mounted -- kind "reference"; elsewhere our loop around the oracle port of the update and a CPU
+    container for acting -- kind "port". A handful of iterations: one CPU update is ~20 ms."""
+    import tempfile
+
+    import numpy as np
+    import torch
+    from oracle import ref_loader
+
+    torch.set_num_threads(4)
+    kw = e2e_kwargs(hidden, B, algorithm="DSAC_V2", buffer_name="replay_buffer", use_gpu=False, enable_cuda=False,
+                    buffer_warm_size=400, buffer_max_size=20000, eval_interval=10 ** 9, max_episode_steps=None)
+    d = tempfile.mkdtemp()
+    os.makedirs(os.path.join(d, "apprfunc"), exist_ok=True)
+    kw["save_folder"] = d
+    if ref_loader.reference_available():
+        from oracle.trainer_trajectory import install_writer_stub
+
+        ref_loader.import_reference()
+        install_writer_stub()
+        from training.evaluator import create_evaluator
+        from training.off_sampler import create_sampler
+        from training.trainer import create_trainer
+        from utils.initialization import create_alg, create_buffer
+
+        torch.manual_seed(0)
+        alg = create_alg(**kw)
+        sampler, buf = create_sampler(**kw), create_buffer(**kw)
+        ev = create_evaluator(**dict(kw, max_episode_steps=20))
+        trainer = create_trainer(alg, sampler, buf, ev, **kw)
+        trainer.iteration = 1          # iteration 0 would evaluate and checkpoint
+        kind = "reference"
+    else:
+        import plugin
+        from dsac_v2_hip import ApproxContainer
+        from oracle.dsact_oracle import DsactOracle, ReplayOracle, default_config, draw_noise
+
+        torch.manual_seed(0)
+        orc = DsactOracle(default_config(O, A, hidden))
+
+        class PortAlg:
+            networks = ApproxContainer(**dict(kw, algorithm="DSAC_V2_HIP"))
+
+            def local_update(self, data, it):
+                return orc.local_update(data, draw_noise(B, A), it)
+
+        class PortBuffer:
+            r = ReplayOracle(O, A, kw["buffer_max_size"])
+            size = property(lambda self: self.r.size)
+            add_batch = lambda self, s: self.r.add_batch(s)
+            sample_batch = lambda self, n: self.r.sample_batch(n)
+            __get_RAM__ = lambda self: 0.0
+
+        alg, buf = PortAlg(), PortBuffer()
+        sampler = plugin.create_sampler(**dict(kw, algorithm="DSAC_V2_HIP"))
+        trainer = plugin.create_trainer(alg, sampler, buf, None, **dict(kw, save_folder=None))
+        trainer.iteration = 1
+        kind = "port"
+    t0 = time.perf_counter()
+    trainer.step(); trainer.iteration += 1
+    one = time.perf_counter() - t0
+    iters = max(3, min(40, int(budget_s / max(one, 1e-3))))
+    w, ws = _timed_loop(trainer, sampler, 1, iters, lambda: None)
+    return {"value": iters / w, "unit": "iterations/s", "ms_per_iteration": 1000.0 * w / iters,
+            "sampler_ms_per_iteration": 1000.0 * ws / iters, "cores": 4, "kind": kind, "iterations": iters}
 
 
 def boundary_rates(alg, n):
@@ -505,14 +661,22 @@ def chain_flops(lay, batch):
     return {k: 2.0 * v * batch for k, v in per_row.items()}
 
 
+PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json")
+
+
 def pmc_traffic(kernel_substr, pick="max"):
     """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r02_pmc_traffic.json, produced
     by scripts/gpu_pmc2.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this bench with --kernel-trace only,
     FETCH_SIZE doubled per the MI355X guide's gfx950 note). Not measurable live (needs rocprofv3); None if absent."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    try:
-        d = json.load(open(path))["mlp"]
-    except (OSError, KeyError, ValueError):
+    d = None
+    for name in PMC_FILES:
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))["mlp"]
+            pmc_traffic.source = "profiles/" + name
+            break
+        except (OSError, KeyError, ValueError):
+            continue
+    if d is None:
         return None
     # several instantiations may match (k_chain_fwd<4, 2> = group A, <4, 1> = group B at batch 256): `pick` chooses
     best = None
@@ -686,7 +850,7 @@ def main():
             "global_batch": args.batch * world, "parallelism": "dp%d" % world, "hidden": hidden,
             "noise": "device Philox4x32-10", "mode": "fast (discarded actor backward skipped)" if args.fast else "strict (every gradient the reference computes)",
             "launch": dp_mode if use_dp else "hipGraph (%d steps/graph; the next update's gather rides in the loss launch)" % gs,
-            "kernels": ("row-slice fused chains + transposed-operand weight-gradient tiles (%d launches/update)" % (4 if Bb <= 256 else 5)) if chain else "per-layer tile stages",
+            "kernels": ("row-slice fused chains + transposed-operand weight-gradient tiles (%d launches/update)%s" % (4 if Bb <= 256 else 5 if Bb <= 1024 else 6, "; throughput-regime kernels (dsact_fat.h) for the forward launches" + (" and the backward launches" if Bb >= 4096 else "") if Bb >= 1024 else "")) if chain else "per-layer tile stages",
             "timing": "median of %d timed regions of exactly %d steps (each bracketed by barrier + device sync; max over ranks)" % (len(regions), steps),
             "replay_fill": "torch device generator, the distributions of SURVEY.md 8(d) (a host np.random.default_rng(0) fill would push "
                            "3 GB through PCIe); indices: np.random.seed(1 + rank) + np.random.randint, a %d-row table cycled" % IDX_ROWS,
@@ -716,6 +880,27 @@ def main():
                                    "dispatch (hipExtLaunchKernelGGL), i.e. the kernel's own begin/end timestamps as rocprofv3 reports "
                                    "them (profiles/r02_final_bench_kernel_stats.csv); the eager update has its own gather launch, the timed "
                                    "graph replay does not (the gather rides in the loss launch)")
+            # the two streaming parts of the update, reported separately
+            kus = {n: ms * 1000.0 for n, ms, _ in prof}
+            if "gather" in kus:
+                gb = 4.0 * Bb * (2 * lay.obs_dim + lay.act_dim + 2)
+                out["roofline_gather"] = {
+                    "bound": "hbm", "bytes": gb, "avg_launch_us": kus["gather"], "achieved": gb / kus["gather"] / 1e3, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": gb / kus["gather"] / 1e3 / HBM_PEAK_GBS,
+                    "note": "k_gather as its own launch (eager updates): %d random replay rows of %d B -- two dependent HBM round trips, "
+                            "latency- not bandwidth-bound at this size; in the timed graph replays the gather of update s+1 rides in the "
+                            "critics' backward launch of update s and costs no launch of its own" % (Bb, 4 * lay.obs_dim)}
+            opt_names = [n for n in ("chain_bwd_pi", "dW", "adam_polyak") if n in kus]
+            if chain and opt_names:
+                n_on = 2 * lay.n_q + lay.n_pi
+                ob = 24.0 * 2 * lay.n_q + (24.0 * lay.n_pi + 8.0 * n_on) / 2.0
+                ous = sum(kus[n] for n in opt_names)
+                out["roofline_adam"] = {
+                    "bound": "hbm", "bytes": ob, "us": ous, "achieved": ob / ous / 1e3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ob / ous / 1e3 / HBM_PEAK_GBS, "launches": opt_names,
+                    "note": "Adam (24 B/param: read and write p, m, v) + Polyak (8 B/param on every 2nd update) of SURVEY.md 8(d). The "
+                            "optimiser has no launch of its own: it is the epilogue of the weight-gradient tiles, so `us` is the duration of "
+                            "the launches that carry those tiles (which also hold the policy backward chain and the tiles' MFMA work)"}
             timed = [r for r in prof if r[0] not in ("gather", "pack")]
             dom = max(timed, key=lambda r: r[1])
             out["dominant_kernel"] = {"name": dom[0], "us": round(dom[1] * 1000, 2)}
@@ -733,6 +918,7 @@ def main():
                         "traffic": pmc_traffic({"chain_bwd": "k_chain_bwd2", "chain_fwd": "k_chain_fwd2", "chain_fwd_a": "k_chain_fwd", "chain_fwd_b": "k_chain_fwd", "chain_bwd_q": "k_chain_bwd_q",
                                                 "chain_bwd_pi": "k_chain_bwd_pi", "dW": "k_dw2"}.get(dom[0], dom[0]),
                                                "min" if dom[0] == "chain_fwd_b" else "max"),
+                        "traffic_source": "%s (a committed rocprofv3 --pmc pass of this bench; NOT measured in this run)" % getattr(pmc_traffic, "source", None),
                         "kernel": kname, "avg_launch_us": dur_us, "flop_per_launch": fl[dom[0]],
                         "note": "dominant launch of the update by in-chain duration; achieved = algorithmic FLOP of the launch (2 x MAC of "
                                 "the layers its workgroups run, elementwise ignored) / its average duration (dispatch start/stop events, "
@@ -757,6 +943,11 @@ def main():
             out["boundary"] = boundary_rates(alg, min(max(steps, 100), 600))
         except Exception as ex:  # informational leg
             out["boundary_error"] = repr(ex)
+    if rank == 0 and not use_dp and not args.no_alt and args.batch == B:
+        try:
+            out["e2e"] = e2e_gpu(hidden, local)
+        except Exception as ex:  # informational leg
+            out["e2e_error"] = repr(ex)
     if not use_dp and not args.no_alt and args.batch == B:
         alt_hidden = [256, 256] if hidden != [256, 256] else [256, 256, 256]
         del alg
@@ -784,6 +975,8 @@ def main():
     if rank == 0 and not args.no_cpu_baseline and args.batch == B:
         try:
             out["cpu_baseline"] = cpu_baseline(hidden)
+            if "e2e" in out and isinstance(out["cpu_baseline"].get("e2e"), dict):
+                out["e2e"]["cpu"] = out["cpu_baseline"].pop("e2e")   # the same loop on the host cores, beside the GPU figure
         except Exception as ex:
             out["cpu_baseline_error"] = repr(ex)
     if rank == 0 and not use_dp and not args.no_alt and args.batch == B:
