@@ -404,7 +404,11 @@ def e2e_gpu(hidden, device, iters=400, warm=60):
     for _ in range(500):
         e.policy_forward(obs1)
     fwd_us = (time.perf_counter() - t0) / 500 * 1e6
-    return {"value": iters / w, "unit": "iterations/s", "ms_per_iteration": 1000.0 * w / iters,
+    try:
+        fwd_split = {"launch_call_us": e.debug_get("act_launch_us"), "completion_spin_us": e.debug_get("act_wait_us")}
+    except Exception:
+        fwd_split = None
+    return {"policy_forward_split": fwd_split, "value": iters / w, "unit": "iterations/s", "ms_per_iteration": 1000.0 * w / iters,
             "sampler_ms_per_iteration": 1000.0 * ws / iters, "env_steps_per_iteration": kw["sample_batch_size"],
             "policy_forward_us": fwd_us, "iterations": iters,
             "note": "HipOffSerialTrainer.step(): 20 env steps (Humanoid-shaped table-lookup env, ~2 us/step: the figure is the "

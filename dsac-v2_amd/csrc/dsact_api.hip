@@ -228,6 +228,7 @@ struct dsact_handle {
   float* act_out_host = nullptr; float* act_out_dev = nullptr;
   float* act_h = nullptr; int* act_cnt = nullptr;   // device: [2][kMaxWidth] activations, [kActMaxLayers] arrival counters
   int act_call = 0;
+  double act_launch_us = 0.0, act_wait_us = 0.0;   // host time of the last fast acting forward: launch call, completion spin
   bool env_no_fast_act = false;         // DSACT_NO_FAST_ACT: the sampler's forward through the copy + tile-stage path (A/B)
   int env_chain_rg_pi = 0;              // DSACT_CHAIN_RG_PI (experiments)
   bool env_no_mixed_rg = false;         // DSACT_NO_MIXED_RG: every unit of the merged forward's group A runs 8-row workgroups (A/B)
@@ -677,7 +678,7 @@ int build_adam_pack_jobs(dsact_handle* h) {
       AdamPackJob j;
       memset(&j, 0, sizeof(j));
       j.w_idx = base + (long long)d.w_off[l]; j.b_idx = base + (long long)d.b_off[l];
-      j.N = d.out[l]; j.K = d.in[l]; j.col_chunks = (j.K + 255) / 256;
+      j.N = d.out[l]; j.K = d.in[l]; j.col_chunks = (j.K + 63) / 64;
       j.mir = h->d_mir ? h->d_mir + (size_t)n3 * (L + 1) + l : nullptr;
       blocks += ((j.N + 15) / 16) * j.col_chunks;
       j.block_end = blocks;
@@ -3186,6 +3187,8 @@ int dsact_debug_set(dsact_handle* h, const char* name, double value) {
 int dsact_debug_get(const dsact_handle* h, const char* name, double* value) {
   if (!h || !name || !value) return DSACT_E_INVALID;
   if (!strcmp(name, "fwd_merge")) *value = h->fwd_merge ? 1.0 : 0.0;
+  else if (!strcmp(name, "act_launch_us")) *value = h->act_launch_us;
+  else if (!strcmp(name, "act_wait_us")) *value = h->act_wait_us;
   else if (!strcmp(name, "fat")) *value = (h->fat ? 1.0 : 0.0) + (h->fat_bwd ? 2.0 : 0.0);
   else if (!strcmp(name, "handoff_failures")) *value = (double)h->handoff_failures;
   else if (!strcmp(name, "graph_steps")) *value = (double)h->graph_steps;
@@ -3225,9 +3228,11 @@ int dsact_policy_forward(dsact_handle* h, const float* obs_host, int32_t n, floa
     a.A = h->A; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
     a.out = h->act_out_dev; a.done = h->act_done_dev; a.timeout = h->handoff_dev;
     memcpy(a.x, obs_host, O * sizeof(float));
+    const auto tl = std::chrono::steady_clock::now();
     TRY(launch(h, "act_mlp", k_act_mlp, dim3(wg), dim3(256), 0, a));
     const int target = a.call * wg_out;
     const auto t0 = std::chrono::steady_clock::now();
+    h->act_launch_us = std::chrono::duration<double, std::micro>(t0 - tl).count();
     unsigned polls = 0;
     while (*(volatile int*)h->act_done_host - target < 0) {
       if ((++polls & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
@@ -3236,6 +3241,7 @@ int dsact_policy_forward(dsact_handle* h, const float* obs_host, int32_t n, floa
       }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+    h->act_wait_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     memcpy(logits_host, h->act_out_host, (size_t)2 * h->A * sizeof(float));
     return check_handoff(h);
   }

@@ -428,11 +428,12 @@ __global__ void __launch_bounds__(kThreads) k_dw2(Dw2Launch L) {
 // gradient; one pass applies Adam (+ Polyak on delayed-update steps) to every weight tensor AND writes its packed
 // copies (what the fused weight-gradient tiles do on the single-GPU path) -- instead of a streaming k_adam followed by a
 // k_pack that reads the arenas again. Same per-element arithmetic as dw2_tile's epilogue / k_adam (tested bitwise).
-// Block = 16 rows x 256 columns of one tensor; lanes are laid out like pack_block (a lane quad = 4 consecutive rows).
+// Block = 16 rows x 64 columns of one tensor (~690 blocks at Humanoid 3x256: 16 x 256 blocks were 172, fewer than the CUs);
+// lanes are laid out like pack_block (a lane quad = 4 consecutive rows).
 // ---------------------------------------------------------------------------------------------------------------
 struct AdamPackJob {
   long long w_idx, b_idx;   // arena indices of the weight matrix [N x K] and its bias [N]
-  int N, K, col_chunks;     // col_chunks = ceil(K / 256)
+  int N, K, col_chunks;     // col_chunks = ceil(K / 64)
   const MirrorDesc* mir;
   int block_end;            // exclusive end of this job's block range (row blocks x col_chunks)
 };
@@ -447,15 +448,14 @@ __global__ void __launch_bounds__(256) k_adam_pack(AdamPackArgs a) {
   for (int q = 0; q + 1 < a.n_jobs; ++q) if (b >= a.jobs[q].block_end) ji = q + 1;
   const AdamPackJob J = a.jobs[ji];
   const int local = b - (ji ? a.jobs[ji - 1].block_end : 0);
-  const int n0 = (local / J.col_chunks) * 16, k_lo = (local % J.col_chunks) * 256;
+  const int n0 = (local / J.col_chunks) * 16, k_lo = (local % J.col_chunks) * 64;
   const FusedOpt& fo = a.fo;
   const bool o_delayed = fo.st->do_delayed != 0;
   const bool is_q = J.w_idx < fo.n_q2;
   if (!(is_q || o_delayed)) return;   // the policy is left alone on the off iterations of the delayed update
   const float o_ss = is_q ? fo.st->ss_q : fo.st->ss_pi, o_bc2 = is_q ? fo.st->bc2_q : fo.st->bc2_pi;
-#pragma unroll 1
-  for (int it = 0; it < 4; ++it) {
-    const int e = it * 256 + tid;
+  {
+    const int e = tid;
     const int n = n0 + (e & 15), k = k_lo + (e >> 4) * 4;
     const bool valid = n < J.N && k < J.K;
     f32x4 op = {0.f, 0.f, 0.f, 0.f}, ot = op;

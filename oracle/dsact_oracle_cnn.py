@@ -74,11 +74,25 @@ def _new_linears(sizes):
     return ps
 
 
-def conv_forward(x, params, strides, collect=None):
-    """Conv2d + ReLU per layer; returns the flattened features (img.view(B, -1), NCHW order)."""
+def conv_forward(x, params, strides, collect=None, masks=None, kink_log=None):
+    """Conv2d + ReLU per layer; returns the flattened features (img.view(B, -1), NCHW order).
+
+    masks (parity tests only): per layer a bool tensor -- the ReLU decisions ANOTHER implementation made on the same
+    input. ReLU is not differentiable at 0: a pre-activation within rounding noise of 0 lands on either side depending on
+    the summation order, and both subgradients are valid. With `masks` the layer computes z * mask instead of relu(z):
+    identical wherever the two implementations agree, the other implementation's (equally valid) choice where they do
+    not; every disagreement is logged to kink_log as (layer, count, max |z|) so the caller can require |z| ~ 0 there."""
     h = x
     for j, s in enumerate(strides):
-        h = F.relu(F.conv2d(h, params[2 * j], params[2 * j + 1], stride=s))
+        z = F.conv2d(h, params[2 * j], params[2 * j + 1], stride=s)
+        if masks is None:
+            h = F.relu(z)
+        else:
+            m = masks[j]
+            flip = m != (z > 0)
+            if kink_log is not None and bool(flip.any()):
+                kink_log.append((j, int(flip.sum()), float(z.detach()[flip].abs().max())))
+            h = z * m.to(z.dtype)
         if collect is not None:
             collect.append(h)
     return h.reshape(h.shape[0], -1)
@@ -98,6 +112,9 @@ class DsactCnnOracle(DsactOracle):
         # (net name, [post-ReLU activation per layer, grads retained]) -- per-layer parity / ReLU-kink checks
         self.keep_conv = False
         self.conv_acts = []
+        # parity tests: relu_masks[net] = per-layer ReLU decisions of the implementation under test for the conv stack of
+        # `net` on the image batch `mask_input` (see conv_forward); kinks collects what that changed
+        self.relu_masks, self.mask_input, self.kinks = {}, None, []
         super().__init__(cfg, state_dict)
 
     # parameter list of one net: conv (w,b)*n_conv | mean MLP (w,b)*(L+1) | log_std MLP (w,b)*(L+1)
@@ -122,12 +139,17 @@ class DsactCnnOracle(DsactOracle):
 
     def _conv(self, obs, params, conv):
         acts = [] if self.keep_conv else None
-        feat = conv_forward(obs, conv, self.st, acts)
+        net_name = next(n for n in self.NETS if self.p[n] is params)
+        masks = self.relu_masks.get(net_name) if obs is self.mask_input else None
+        log = [] if masks is not None else None
+        feat = conv_forward(obs, conv, self.st, acts, masks, log)
+        if log:
+            self.kinks += [(net_name,) + e for e in log]
         if acts is not None:
             for a in acts:
                 if a.requires_grad:
                     a.retain_grad()
-            self.conv_acts.append((next(n for n in self.NETS if self.p[n] is params), acts))
+            self.conv_acts.append((net_name, acts))
         return feat
 
     def _pi(self, obs, params, collect=None):

@@ -15,7 +15,7 @@ import torch
 
 from helpers import GOLDEN, hip_kwargs
 from oracle.dsact_oracle import TB_KEYS, draw_noise
-from oracle.dsact_oracle_cnn import DsactCnnOracle, cnn_config, conv_forward, synth_image_batch
+from oracle.dsact_oracle_cnn import conv_out_hw, DsactCnnOracle, cnn_config, conv_forward, synth_image_batch
 from test_hip_parity import AdamNoise, Report
 
 pytestmark = pytest.mark.gpu
@@ -49,20 +49,40 @@ def run_case(title, obs_shape, A, conv_type, B, steps, golden=None):
     alg, orc, cfg = make_pair(obs_shape, A, conv_type, B)
     e = alg.engine
     names = {n: orc._names(n) for n in ("q1", "q2", "policy")}
-    kinked = set()   # nets in which a ReLU mask of the two implementations has disagreed so far
     orc.keep_conv = True
     lrs = {"q1": orc.cfg["lr_q"], "q2": orc.cfg["lr_q"], "policy": orc.cfg["lr_pi"]}
     adam_noise = {name: AdamNoise([(net, p.numel(), lrs[net])]) for net in names for name, p in zip(names[net], orc.p[net])}
+    n_kinks = 0
     for it in range(steps):
         data = synth_image_batch(cfg, B, seed=it)
         torch.manual_seed(1000 + it)
         noise = draw_noise(B, A)
-        orc.conv_acts = []
-        tb_ref = orc.compute_gradient(data, noise, keep=(it == 0))
         e.load_batch(*(data[k].numpy() for k in ("obs", "act", "rew", "obs2", "done")))
         e.set_noise(noise["eps_new"].numpy(), noise["eps_2"].numpy(), noise["z5"].numpy(), noise["z6"].numpy())
         e.compute_grads(it)
         e.sync()
+        # ReLU kinks. A pre-activation within rounding noise of 0 lands on either side of the ReLU depending on the
+        # summation order, and the gradient is discontinuous there (the whole upstream gradient of that pixel appears or
+        # disappears) -- both choices are valid subgradients. The reference is therefore evaluated with the ReLU decisions
+        # the HIP kernels made on the same images (oracle conv_forward(masks=...)): identical wherever the two agree,
+        # HIP's choice where they do not, and every such element must BE a kink (|z| < 1e-5 in the reference's own
+        # arithmetic). No tolerance below is widened for it, in this or any later iteration.
+        C_, H_, W_ = cfg["obs_dim"]
+        dims = conv_out_hw(H_, W_, orc.ks, orc.st)
+        orc.relu_masks, orc.mask_input, orc.kinks = {}, data["obs"], []
+        hip_act = {}
+        for st_, net in enumerate(("q1", "q2", "policy")):
+            ms = []
+            for j, (oh, ow) in enumerate(dims):
+                a = e.debug_read("cact.%d.%d" % (st_, j))
+                hip_act[(net, j)] = a
+                ms.append(torch.as_tensor(a.reshape(B, oh, ow, orc.ch[j]) > 0).permute(0, 3, 1, 2).contiguous())
+            orc.relu_masks[net] = ms
+        orc.conv_acts = []
+        tb_ref = orc.compute_gradient(data, noise, keep=(it == 0))
+        for net, j, cnt, zmax in orc.kinks:
+            assert zmax < 1e-5, "ReLU decisions differ at a pre-activation of %g (%s conv %d): not a kink" % (zmax, net, j)
+            n_kinks += cnt
         if it == 0:
             # conv features of q1(obs) sit in the observation columns of the q1(obs, act) input rows
             F = e.layout.feat_dim
@@ -75,33 +95,17 @@ def run_case(title, obs_shape, A, conv_type, B, steps, golden=None):
             rep.cmp("q1", e.debug_read("qout_c0").reshape(B, 2)[:, 0], orc.inter["q1"], 5e-5)
             rep.cmp("q1_pi", e.debug_read("qout_p0").reshape(B, 2)[:, 0], orc.inter["q1_pi"], 5e-5)
             rep.cmp("d_new_act", e.debug_read("d_new_act"), orc.inter["d_new_act"], 1e-9, 3e-4)
-        # ReLU kinks: a pre-activation within rounding noise of 0 can land on different sides in the two
-        # implementations; the gradient is discontinuous there (the whole upstream gradient of that pixel
-        # appears or disappears). Locate such elements, require them to BE kinks (|activation| < 1e-5 on both
-        # sides) and widen the conv-gradient tolerance of the affected net by what they carry.
         first = {}
         for net, acts in orc.conv_acts:
             first.setdefault(net, acts)     # first call of each online net: (obs) with gradients
-        kink_budget = {}
-        for st, net in enumerate(("q1", "q2", "policy")):
-            budget = 0.0
+        for net in ("q1", "q2", "policy"):
             for j, a in enumerate(first[net]):
                 ref = a.detach().permute(0, 2, 3, 1).reshape(-1).numpy()
-                got = e.debug_read("cact.%d.%d" % (st, j))
-                rep.cmp("it%d act %s.conv.%d" % (it, net, 2 * j), got, ref, 1e-5 if net not in kinked else 5e-3, 1e-5)
-                flip = (got > 0) != (ref > 0)
-                if flip.any():
-                    assert float(np.abs(got[flip]).max()) < 1e-5 and float(np.abs(ref[flip]).max()) < 1e-5
-                    up = np.abs(a.grad.permute(0, 2, 3, 1).reshape(-1).numpy()[flip])
-                    budget += float(up.sum())
-                    kinked.add(net)
-            kink_budget[net] = budget
+                rep.cmp("it%d act %s.conv.%d" % (it, net, 2 * j), hip_act[(net, j)], ref, 1e-5, 1e-5)
         gv = alg._grad_views()
         for net in ("q1", "q2", "policy"):
             for name, g_hip, p_ref in zip(names[net], gv[net], orc.p[net]):
-                extra = 4.0 * kink_budget[net] if ".conv." in name else 0.0
-                rtol = 5e-4 if net not in kinked or kink_budget[net] > 0 or it == 0 else 2e-2
-                rep.cmp("it%d grad %s" % (it, name), np_of(g_hip), p_ref.grad, 1e-9 + extra, rtol)
+                rep.cmp("it%d grad %s" % (it, name), np_of(g_hip), p_ref.grad, 1e-9, 5e-4)
         rep.cmp("it%d grad log_alpha" % it, [float(gv["log_alpha"])], [float(orc.log_alpha.grad)], 1e-6, 1e-5)
         delayed = it % orc.cfg["delay_update"] == 0
         for net in ("q1", "q2", "policy"):
@@ -140,9 +144,18 @@ def run_case(title, obs_shape, A, conv_type, B, steps, golden=None):
         rep.cmp_params("it%d params" % it, np.concatenate(got_all), np.concatenate(want_all), np.concatenate(bound_all), 1e-5,
                        lr_steps)
         rep.cmp("it%d targets (max over tensors)" % it, [worst_t], [0.0], 2e-6)
-        if golden is not None:
-            sums = [float(v.double().sum()) for v in sd.values()]
-            rep.cmp("it%d param sums vs reference" % it, sums, golden["s%d/param_sums" % it], 2e-3, 1e-5)
+        if golden is not None and n_kinks == 0:
+            # per-tensor parameter sums against the UNMODIFIED reference's digest. Budget per tensor, enumerated: what its
+            # elements may differ by (1e-6 rounding each, adding up like a random walk: 3 sqrt(N) 1e-6, plus each element's
+            # own Adam noise bound from the measured gradient difference) + the fp32 rounding of the sum itself. (After a
+            # verified ReLU kink the reference's digest took the other subgradient: HIP is then compared with the oracle
+            # only -- above, at unchanged tolerances.)
+            keys = list(sd.keys())
+            sums = np.array([float(v.double().sum()) for v in sd.values()])
+            want = np.asarray(golden["s%d/param_sums" % it], np.float64)
+            tol = np.array([1e-6 * abs(w_) + 3e-6 * np.sqrt(sd[k].numel()) + (float(adam_noise[k].bound.sum()) if k in adam_noise else 0.0)
+                            for k, w_ in zip(keys, want)])
+            rep.cmp_each("it%d param sums vs reference" % it, sums, want, tol)
     # structural zeros of the twin output layers stay exactly zero (include/dsact.h)
     lay = e.layout
     mask = torch.ones(lay.n_online, dtype=torch.bool)
@@ -238,7 +251,7 @@ def test_cnn_replay_rows_bit_exact_and_policy_forward():
 def test_cnn_load_batch_from_cuda_tensors_equals_host_staging():
     """dsact_load_batch with device pointers (the reference trainer's `.cuda()` image batch) stages the same
     pixel-major images and action columns as the host path."""
-    from oracle.dsact_oracle_cnn import cnn_config, synth_image_batch
+    from oracle.dsact_oracle_cnn import conv_out_hw, cnn_config, synth_image_batch
     from dsact.engine import DsactEngine
 
     cfg = cnn_config((3, 96, 96), 3, "type_2")
