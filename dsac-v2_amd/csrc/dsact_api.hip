@@ -226,7 +226,6 @@ struct dsact_handle {
   // single-launch acting forward (dsact_act.h): mapped host block = [hand-off word | done counter | logits], device scratch
   int* act_done_host = nullptr; int* act_done_dev = nullptr;
   float* act_out_host = nullptr; float* act_out_dev = nullptr;
-  float* act_h = nullptr; int* act_cnt = nullptr;   // device: [2][kMaxWidth] activations, [kActMaxLayers] arrival counters
   int act_call = 0;
   double act_launch_us = 0.0, act_wait_us = 0.0;   // host time of the last fast acting forward: launch call, completion spin
   bool env_no_fast_act = false;         // DSACT_NO_FAST_ACT: the sampler's forward through the copy + tile-stage path (A/B)
@@ -2197,9 +2196,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->act_done_host = h->handoff_host + 16; h->act_done_dev = h->handoff_dev + 16;
   h->act_out_host = (float*)(h->handoff_host + 32); h->act_out_dev = (float*)(h->handoff_dev + 32);
   h->env_no_fast_act = getenv("DSACT_NO_FAST_ACT") != nullptr;
-  HIPCHK(h, hipMalloc((void**)&h->act_h, (2 * kMaxWidth + 64) * sizeof(float)));
-  HIPCHK(h, hipMemset(h->act_h, 0, (2 * kMaxWidth + 64) * sizeof(float)));
-  h->act_cnt = (int*)(h->act_h + 2 * kMaxWidth);
+
   if (h->fwd_merge) {
     // the merged forward is sized for both groups' workgroups being resident at once: two per CU (speed, not
     // correctness -- consumers only wait for lower block ids, which are always dispatched first)
@@ -2230,7 +2227,6 @@ int dsact_destroy(dsact_handle* h) {
     if (h->h_idx_ev[i]) hipEventDestroy(h->h_idx_ev[i]);
   }
   if (h->handoff_host) hipHostFree(h->handoff_host);
-  if (h->act_h) hipFree(h->act_h);
   if (h->d_tiles) hipFree(h->d_tiles);
   if (h->alt.d_tiles) hipFree(h->alt.d_tiles);
   if (h->alt_ws) hipFree(h->alt_ws);
@@ -3208,36 +3204,25 @@ int dsact_policy_forward(dsact_handle* h, const float* obs_host, int32_t n, floa
     ActArgs a;
     a.n_layers = h->L + 1;
     const float* base = net_params(h, N_POL);
-    int wg = 0;
     for (int l = 0; l <= h->L; ++l) {
       a.ly[l].W = base + h->pd.w_off[l]; a.ly[l].b = base + h->pd.b_off[l];
       a.ly[l].K = h->pd.in[l]; a.ly[l].N = h->pd.out[l];
-      a.wg_begin[l] = wg;
-      wg += (h->pd.out[l] + 3) / 4;
     }
-    a.wg_begin[h->L + 1] = wg;
-    const int wg_out = wg - a.wg_begin[h->L];
-    if (h->act_call >= (1 << 22)) {   // keep the monotone counters far from wrapping
-      HIPCHK(h, hipStreamSynchronize(h->stream));
-      HIPCHK(h, hipMemset(h->act_cnt, 0, 64 * sizeof(int)));
-      *(volatile int*)h->act_done_host = 0;
-      h->act_call = 0;
-    }
-    a.h[0] = h->act_h; a.h[1] = h->act_h + kMaxWidth; a.cnt = h->act_cnt;
+    if (h->act_call == 0x7fffffff) h->act_call = 0;
     a.call = ++h->act_call;
     a.A = h->A; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
-    a.out = h->act_out_dev; a.done = h->act_done_dev; a.timeout = h->handoff_dev;
+    a.out = h->act_out_dev; a.done = h->act_done_dev;
     memcpy(a.x, obs_host, O * sizeof(float));
     const auto tl = std::chrono::steady_clock::now();
-    TRY(launch(h, "act_mlp", k_act_mlp, dim3(wg), dim3(256), 0, a));
-    const int target = a.call * wg_out;
+    TRY(launch(h, "act_mlp", k_act_mlp, dim3(1), dim3(64 * kActWaves), 0, a));
+    const int target = a.call;
     const auto t0 = std::chrono::steady_clock::now();
     h->act_launch_us = std::chrono::duration<double, std::micro>(t0 - tl).count();
     unsigned polls = 0;
-    while (*(volatile int*)h->act_done_host - target < 0) {
+    while (*(volatile int*)h->act_done_host != target) {
       if ((++polls & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
         HIPCHK(h, hipStreamSynchronize(h->stream));   // surfaces a device fault, if that is what happened
-        if (*(volatile int*)h->act_done_host - target < 0) return fail(h, DSACT_E_HIP, "acting forward did not complete");
+        if (*(volatile int*)h->act_done_host != target) return fail(h, DSACT_E_HIP, "acting forward did not complete");
       }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
