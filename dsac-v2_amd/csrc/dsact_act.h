@@ -6,11 +6,16 @@
 // sync -- 67 us, twenty times per iteration, against a 65 us update. Here:
 //   * the observation travels INSIDE the kernel arguments (<= 768 floats), the logits come back through mapped host
 //     memory, and the host spins on a mapped counter: no memcpy calls, no stream synchronisation;
-//   * ONE workgroup of 16 waves runs the whole net: wave w computes output features w, w + 16, ... of a layer (its
-//     weight rows are read coalesced straight from the parameter arena -- always the live weights, no packed copy to
-//     keep fresh), the activations are handed from layer to layer through LDS. 0.94 MB of weights through one CU's L2
-//     port is ~6 us; the first version spread the layers over 200 workgroups with arrival counters, and paid ~6 us PER
-//     LAYER for the agent-scope (cross-XCD) store / counter / load round trips (45 us per call end to end).
+//   * every layer is a block range of the same grid: wave w of layer l computes ONE output feature (its weight row is
+//     read coalesced straight from the parameter arena -- always the live weights, no packed copy to keep fresh --
+//     before anything waits). Layers hand their activations over as (value, call number) PAIRS written with one 8-byte
+//     agent-scope store; a consumer lane spins on the pair it needs until the tag is this call's -- the data IS the flag
+//     (the low-latency protocol of collective libraries): the critical path of a layer boundary is one write-through
+//     plus one load, ~3 us. Consumers only wait for lower block ids, which the dispatcher has placed before them: the
+//     bounded spins cannot deadlock. The logits reach the host the same way: (value, call) pairs in mapped memory.
+//   Measured (profiles/r03_acting_forward.txt): separate arrival counters + data cost ~6 us per layer (store ack, atomic,
+//   poll, load: 34.5 us from launch to the host seeing the result); ONE workgroup for the whole net avoids the exchange
+//   but pulls 0.94 MB through a single CU with ~48 KB in flight: 40 us.
 #pragma once
 #include "dsact_chain.h"
 
@@ -23,69 +28,77 @@ struct ActLayer { const float* W; const float* b; int K, N; };   // row-major [N
 struct ActArgs {
   ActLayer ly[kActMaxLayers];
   int n_layers;                     // hidden layers + the output layer
+  int wg_begin[kActMaxLayers + 1];  // block range of each layer (4 output features per workgroup)
+  unsigned long long* h;            // device scratch [kActMaxLayers][kMaxWidth]: (call << 32 | float bits) per activation
   int call;                         // 1-based number of this launch
   int A; float lo_ls, hi_ls;
-  float* out;                       // MAPPED HOST memory: (mean | std), 2A floats
-  int* done;                        // MAPPED HOST memory: set to `call` when the logits are there
+  unsigned long long* out;          // MAPPED HOST memory: 2A pairs (call << 32 | float bits) of (mean | std)
+  int* timeout;                     // the hand-off word (mapped host memory, see check_handoff)
   float x[kActMaxObs];              // the observation
 };
 static_assert(sizeof(ActArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
-constexpr int kActWaves = 16;
-__global__ void __launch_bounds__(64 * kActWaves) k_act_mlp(ActArgs a) {
-  __shared__ float hbuf[2][kMaxWidth];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // the observation sits in the kernel-argument segment: read it as memory (indexing the by-value struct with a
-  // lane-dependent index would make the compiler spill the whole 4 KB argument to scratch)
-  typedef __attribute__((address_space(4))) const char KChar;
-  typedef __attribute__((address_space(4))) const float KFloat;
-  KFloat* xk = (KFloat*)((KChar*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ActArgs, x));
-  for (int k = tid; k < a.ly[0].K; k += 64 * kActWaves) hbuf[1][k] = xk[k];   // layer l reads hbuf[(l + 1) & 1]
-  __syncthreads();
+__device__ __forceinline__ unsigned long long act_pair(float v, int call) {
+  return ((unsigned long long)(unsigned)call << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v);
+}
+
+__global__ void __launch_bounds__(256) k_act_mlp(ActArgs a) {
+  const int b = (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int l = 0;
+#pragma unroll
+  for (int q = 1; q < kActMaxLayers; ++q) if (q < a.n_layers && b >= a.wg_begin[q]) l = q;
+  const ActLayer& Ly = a.ly[l];
+  const int n = (b - a.wg_begin[l]) * 4 + wave;
+  if (n >= Ly.N) return;                      // whole wave
+  // this wave's weight row, fetched before anything waits: lane k, k + 64, ...
   constexpr int NJ = (kMaxWidth > kActMaxObs ? kMaxWidth : kActMaxObs) / 64;
-  for (int l = 0; l < a.n_layers; ++l) {
-    const ActLayer Ly = a.ly[l];
-    const float* in = hbuf[(l + 1) & 1];
-    float* outb = hbuf[l & 1];
-    const bool last = l + 1 == a.n_layers;
-    float xin[NJ];
+  float w[NJ];
+  const float* wr = Ly.W + (size_t)n * Ly.K;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) xin[j] = 64 * j + lane < Ly.K ? in[64 * j + lane] : 0.f;
-    // two output features per trip: their weight rows are in flight together
-    for (int n0 = wave; n0 < Ly.N; n0 += 2 * kActWaves) {
-      const int n1 = n0 + kActWaves;
-      const bool v1 = n1 < Ly.N;
-      const float* w0 = Ly.W + (size_t)n0 * Ly.K;
-      const float* w1 = Ly.W + (size_t)(v1 ? n1 : n0) * Ly.K;
-      float r0[NJ], r1[NJ];
+  for (int j = 0; j < NJ; ++j) w[j] = 64 * j + lane < Ly.K ? wr[64 * j + lane] : 0.f;
+  const float bias = Ly.b[n];
+  float acc = 0.f;
+  if (l == 0) {
+    // the observation sits in the kernel-argument segment: read it as memory (indexing the by-value struct with a
+    // lane-dependent index would make the compiler spill the whole 4 KB argument to scratch)
+    typedef __attribute__((address_space(4))) const char KChar;
+    typedef __attribute__((address_space(4))) const float KFloat;
+    KFloat* xk = (KFloat*)((KChar*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ActArgs, x));
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const bool kv = 64 * j < Ly.K;      // wave-uniform: whole trips beyond K are skipped
-        r0[j] = kv && 64 * j + lane < Ly.K ? w0[64 * j + lane] : 0.f;
-        r1[j] = kv && 64 * j + lane < Ly.K ? w1[64 * j + lane] : 0.f;
-      }
-      float a0 = 0.f, a1 = 0.f;
+    for (int j = 0; j < NJ; ++j)
+      if (64 * j + lane < Ly.K) acc = fmaf(w[j], xk[64 * j + lane], acc);
+  } else {
+    const unsigned long long* hin = a.h + (size_t)(l - 1) * kMaxWidth;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) { a0 = fmaf(r0[j], xin[j], a0); a1 = fmaf(r1[j], xin[j], a1); }
-      a0 = wave_sum(a0) + Ly.b[n0];
-      a1 = wave_sum(a1) + (v1 ? Ly.b[n1] : 0.f);
-      if (lane == 0) {
-        if (!last) {
-          float hv, gd;
-          gelu_fwd_grad(a0, hv, gd); outb[n0] = hv;
-          if (v1) { gelu_fwd_grad(a1, hv, gd); outb[n1] = hv; }
-        } else {
-          // output layer: (mean | exp(clamp(log_std))) as StochaPolicy.forward returns them (networks/mlp.py:85-100)
-          __hip_atomic_store(a.out + n0, n0 < a.A ? a0 : expf(clampf(a0, a.lo_ls, a.hi_ls)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          if (v1) __hip_atomic_store(a.out + n1, n1 < a.A ? a1 : expf(clampf(a1, a.lo_ls, a.hi_ls)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int j = 0; j < NJ; ++j) {
+      if (64 * j < Ly.K) {                    // wave-uniform
+        const int k = 64 * j + lane;
+        float v = 0.f;
+        if (k < Ly.K) {
+          unsigned long long p;
+          int spins = 0;
+          for (;;) {
+            p = __hip_atomic_load(hin + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int)(p >> 32) == a.call) break;
+            if (++spins > (1 << 20)) { if (a.timeout) *a.timeout = 1; break; }
+          }
+          v = __builtin_bit_cast(float, (unsigned)p);
         }
+        acc = fmaf(w[j], v, acc);
       }
     }
-    if (!last) __syncthreads();
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: the logits are in host memory before the word moves
-  stores_acked_barrier();
-  if (tid == 0) __hip_atomic_store(a.done, a.call, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  acc = wave_sum(acc) + bias;
+  if (lane != 0) return;
+  if (l + 1 < a.n_layers) {
+    float hv, gd;
+    gelu_fwd_grad(acc, hv, gd);
+    __hip_atomic_store(a.h + (size_t)l * kMaxWidth + n, act_pair(hv, a.call), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  // output layer: (mean | exp(clamp(log_std))) as StochaPolicy.forward returns them (networks/mlp.py:85-100)
+  const float v = n < a.A ? acc : expf(clampf(acc, a.lo_ls, a.hi_ls));
+  __hip_atomic_store(a.out + n, act_pair(v, a.call), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace dsact

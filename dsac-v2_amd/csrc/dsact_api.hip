@@ -224,8 +224,8 @@ struct dsact_handle {
   int handoff_failures = 0;
   int debug_withhold = 0;               // dsact_debug_set("withhold_flag"): tests force the timeout path
   // single-launch acting forward (dsact_act.h): mapped host block = [hand-off word | done counter | logits], device scratch
-  int* act_done_host = nullptr; int* act_done_dev = nullptr;
-  float* act_out_host = nullptr; float* act_out_dev = nullptr;
+  unsigned long long* act_out_host = nullptr; unsigned long long* act_out_dev = nullptr;   // 64 (value, call) pairs
+  unsigned long long* act_h = nullptr;  // device: [kActMaxLayers][kMaxWidth] (value, call) pairs
   int act_call = 0;
   double act_launch_us = 0.0, act_wait_us = 0.0;   // host time of the last fast acting forward: launch call, completion spin
   bool env_no_fast_act = false;         // DSACT_NO_FAST_ACT: the sampler's forward through the copy + tile-stage path (A/B)
@@ -2193,8 +2193,9 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   HIPCHK(h, hipHostMalloc((void**)&h->handoff_host, 1024, hipHostMallocMapped));
   memset(h->handoff_host, 0, 1024);
   HIPCHK(h, hipHostGetDevicePointer((void**)&h->handoff_dev, h->handoff_host, 0));
-  h->act_done_host = h->handoff_host + 16; h->act_done_dev = h->handoff_dev + 16;
-  h->act_out_host = (float*)(h->handoff_host + 32); h->act_out_dev = (float*)(h->handoff_dev + 32);
+  h->act_out_host = (unsigned long long*)(h->handoff_host + 32); h->act_out_dev = (unsigned long long*)(h->handoff_dev + 32);
+  HIPCHK(h, hipMalloc((void**)&h->act_h, (size_t)kActMaxLayers * kMaxWidth * sizeof(unsigned long long)));
+  HIPCHK(h, hipMemset(h->act_h, 0, (size_t)kActMaxLayers * kMaxWidth * sizeof(unsigned long long)));
   h->env_no_fast_act = getenv("DSACT_NO_FAST_ACT") != nullptr;
 
   if (h->fwd_merge) {
@@ -2227,6 +2228,7 @@ int dsact_destroy(dsact_handle* h) {
     if (h->h_idx_ev[i]) hipEventDestroy(h->h_idx_ev[i]);
   }
   if (h->handoff_host) hipHostFree(h->handoff_host);
+  if (h->act_h) hipFree(h->act_h);
   if (h->d_tiles) hipFree(h->d_tiles);
   if (h->alt.d_tiles) hipFree(h->alt.d_tiles);
   if (h->alt_ws) hipFree(h->alt_ws);
@@ -3204,30 +3206,46 @@ int dsact_policy_forward(dsact_handle* h, const float* obs_host, int32_t n, floa
     ActArgs a;
     a.n_layers = h->L + 1;
     const float* base = net_params(h, N_POL);
+    int wg = 0;
     for (int l = 0; l <= h->L; ++l) {
       a.ly[l].W = base + h->pd.w_off[l]; a.ly[l].b = base + h->pd.b_off[l];
       a.ly[l].K = h->pd.in[l]; a.ly[l].N = h->pd.out[l];
+      a.wg_begin[l] = wg;
+      wg += (h->pd.out[l] + 3) / 4;
     }
-    if (h->act_call == 0x7fffffff) h->act_call = 0;
-    a.call = ++h->act_call;
+    a.wg_begin[h->L + 1] = wg;
+    if (h->act_call >= 0x7ffffff0) {   // the tags only have to differ from call to call: restart far from the sign bit
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      HIPCHK(h, hipMemset(h->act_h, 0, (size_t)kActMaxLayers * kMaxWidth * sizeof(unsigned long long)));
+      memset(h->act_out_host, 0, 64 * sizeof(unsigned long long));
+      h->act_call = 0;
+    }
+    a.h = h->act_h; a.call = ++h->act_call;
     a.A = h->A; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
-    a.out = h->act_out_dev; a.done = h->act_done_dev;
+    a.out = h->act_out_dev; a.timeout = h->handoff_dev;
     memcpy(a.x, obs_host, O * sizeof(float));
     const auto tl = std::chrono::steady_clock::now();
-    TRY(launch(h, "act_mlp", k_act_mlp, dim3(1), dim3(64 * kActWaves), 0, a));
-    const int target = a.call;
+    TRY(launch(h, "act_mlp", k_act_mlp, dim3(wg), dim3(256), 0, a));
     const auto t0 = std::chrono::steady_clock::now();
     h->act_launch_us = std::chrono::duration<double, std::micro>(t0 - tl).count();
+    const int n_out = 2 * h->A;
+    const unsigned want = (unsigned)a.call;
     unsigned polls = 0;
-    while (*(volatile int*)h->act_done_host != target) {
+    for (int k = 0; k < n_out;) {   // the data is the flag: every logit arrives as a (value, call) pair
+      const unsigned long long pr = ((volatile unsigned long long*)h->act_out_host)[k];
+      if ((unsigned)(pr >> 32) == want) {
+        const unsigned bits = (unsigned)pr;
+        memcpy(logits_host + k, &bits, sizeof(float));
+        ++k;
+        continue;
+      }
       if ((++polls & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
         HIPCHK(h, hipStreamSynchronize(h->stream));   // surfaces a device fault, if that is what happened
-        if (*(volatile int*)h->act_done_host != target) return fail(h, DSACT_E_HIP, "acting forward did not complete");
+        TRY(check_handoff(h));
+        return fail(h, DSACT_E_HIP, "acting forward did not complete");
       }
     }
-    std::atomic_thread_fence(std::memory_order_acquire);
     h->act_wait_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    memcpy(logits_host, h->act_out_host, (size_t)2 * h->A * sizeof(float));
     return check_handoff(h);
   }
   if (h->cnn) {
