@@ -81,6 +81,11 @@ struct dsact_handle {
   hipStream_t aux_stream = nullptr;   // forked branch: critics' dW + Adam run beside the actor backward chain
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool use_fork = false;
+  // conv backward on two queues: the data-gradient chain (dCol -> col2im / direct dX, layer by layer) on the handle's
+  // stream, the weight-gradient launches of the same layers on aux_stream -- they only need dY[j], which is ready when the
+  // data-gradient launch of layer j starts. ev_conv[j]: dY[j] complete.
+  bool conv_fork = false;
+  hipEvent_t ev_conv[kMaxConv + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // nets
   int nq = 2;            // critics: 2 (DSAC_V2) or 1 (DSAC_V1)
   NetDesc qd, pd;
@@ -1046,6 +1051,8 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
     const long long n = (long long)B * h->F;
     TRY(launch(h, "feat_bwd", k_feat_bwd, dim3((unsigned)((n + kThreads - 1) / kThreads), n_st), dim3(kThreads), 0, f));
   }
+  const bool fork = h->conv_fork && !h->profiling;   // (the per-kernel profile runs everything on one stream)
+  if (fork) HIPCHK(h, hipEventRecord(h->ev_conv[last], h->stream));
   for (int j = last; j >= 0; --j) {
     const ConvGeom& g = h->cg[j];
     const int M = B * g.OH * g.OW;
@@ -1075,6 +1082,11 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
         p.block_end = blocks;
       }
       const size_t lds = (size_t)2 * (1 + nkt) * TILE_LDS * sizeof(float);
+      if (fork) {
+        HIPCHK(h, hipStreamWaitEvent(h->aux_stream, h->ev_conv[j], 0));
+        if (nkt != 1) return fail(h, DSACT_E_INVALID, "DSACT_CONV_FORK needs DSACT_CONV_DW_NKT=1");
+        TRY(launch_on(h, h->aux_stream, ("conv_dw" + sfx).c_str(), k_conv_dw<1>, dim3(blocks), dim3(kThreads), lds, a));
+      } else
       if (nkt == 1) TRY(launch(h, ("conv_dw" + sfx).c_str(), k_conv_dw<1>, dim3(blocks), dim3(kThreads), lds, a));
       else if (nkt == 2) TRY(launch(h, ("conv_dw" + sfx).c_str(), k_conv_dw<2>, dim3(blocks), dim3(kThreads), lds, a));
       else if (nkt == 3) TRY(launch(h, ("conv_dw" + sfx).c_str(), k_conv_dw<3>, dim3(blocks), dim3(kThreads), lds, a));
@@ -1126,6 +1138,11 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
       const long long n = (long long)B * g.H * g.W * (g.Cin / 4);
       TRY(launch(h, ("col2im" + sfx).c_str(), k_col2im, dim3((unsigned)((n + kThreads - 1) / kThreads), n_st), dim3(kThreads), 0, c));
     }
+    if (fork && j > 0) HIPCHK(h, hipEventRecord(h->ev_conv[j - 1], h->stream));   // dY[j-1] is complete
+  }
+  if (fork) {
+    HIPCHK(h, hipEventRecord(h->ev_join, h->aux_stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
   }
   {
     // ordered reduce of the partials of ALL layers (+ Adam / Polyak when fused) in one launch, after the whole conv
@@ -2141,6 +2158,8 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   HIPCHK(h, hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
   HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
   HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  for (int j = 0; j <= kMaxConv; ++j) HIPCHK(h, hipEventCreateWithFlags(&h->ev_conv[j], hipEventDisableTiming));
+  h->conv_fork = h->cnn && getenv("DSACT_CONV_FORK") != nullptr;
   h->use_fork = getenv("DSACT_FORK") != nullptr && !h->cnn && h->dw_chunks == 1;  // measured: a forked graph branch costs +20 us/update (cross-queue signals) -> opt-in only
   {
     const int max_lds = (int)tile_lds_bytes(BK * kMaxPrefetchTiles);  // 129 KB of the CU's 160 KB
@@ -2248,6 +2267,7 @@ int dsact_destroy(dsact_handle* h) {
     if (p) hipFree(p);
   if (h->ws) hipFree(h->ws);
   if (h->aux_stream) { hipStreamSynchronize(h->aux_stream); hipStreamDestroy(h->aux_stream); }
+  for (int j = 0; j <= kMaxConv; ++j) if (h->ev_conv[j]) hipEventDestroy(h->ev_conv[j]);
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_join) hipEventDestroy(h->ev_join);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
