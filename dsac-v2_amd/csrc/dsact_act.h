@@ -32,6 +32,7 @@ struct ActArgs {
   unsigned long long* h;            // device scratch [kActMaxLayers][kMaxWidth]: (call << 32 | float bits) per activation
   int call;                         // 1-based number of this launch
   int A; float lo_ls, hi_ls;
+  int act;                          // the policy's hidden activation (ACT_*)
   unsigned long long* out;          // MAPPED HOST memory: 2A pairs (call << 32 | float bits) of (mean | std)
   int* timeout;                     // the hand-off word (mapped host memory, see check_handoff)
   float x[kActMaxObs];              // the observation
@@ -92,7 +93,7 @@ __global__ void __launch_bounds__(256) k_act_mlp(ActArgs a) {
   if (lane != 0) return;
   if (l + 1 < a.n_layers) {
     float hv, gd;
-    gelu_fwd_grad(acc, hv, gd);
+    act_fwd_grad(a.act, acc, hv, gd);
     __hip_atomic_store(a.h + (size_t)l * kMaxWidth + n, act_pair(hv, a.call), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }

@@ -323,7 +323,11 @@ void build_net(NetDesc& d, int in0, const int* hidden, int L, int n_out, int nbl
   d.count = off;
 }
 
+int net_act(const dsact_handle* h, int net);
 const NetDesc& net_desc(const dsact_handle* h, int net) { return (net == N_POL || net == N_POLT) ? h->pd : h->qd; }
+
+// hidden activation of a net's MLP layers (value_hidden_activation / policy_hidden_activation, common_utils.py:16-45)
+int net_act(const dsact_handle* h, int net) { return (net == N_POL || net == N_POLT) ? h->cfg.policy_act : h->cfg.value_act; }
 
 // base pointer of a net's parameters inside its arena (online or target)
 float* net_base(const dsact_handle* h, int net, float* online, float* target) {
@@ -526,6 +530,7 @@ void fwd_probs(const dsact_handle* h, int ch, int l, const float* x0, int ldx0, 
     t.C1 = Grow + (size_t)b * hb;
     t.ldc = d.out[l];
     t.M = M; t.N = hb; t.K = kb;
+    t.act = net_act(h, net);
     out.push_back(t);
   }
 }
@@ -1408,6 +1413,7 @@ FwdUnit fwd_unit(const dsact_handle* h, int ch, int seg, int head) {
   if (seg != SEG_OBS_ONLY)
     for (int l = 0; l < h->L; ++l) { u.H[l] = h->Hb[ch][l]; u.G[l] = h->Gb[ch][l]; }
   u.head = head;
+  u.act = net_act(h, net);
   return u;
 }
 
@@ -1772,7 +1778,7 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
     a.log_alpha = h->online + h->n_online - 1;
     a.part_loss = h->part_loss; a.grads_tail = h->grads + h->n_online;
     a.W = h->w[L - 1]; a.B = B; a.inv_B = 1.0f / (float)B;
-    a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.gamma = h->cfg.gamma; a.td_bound = h->cfg.td_bound;
+    a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.gamma = h->cfg.gamma; a.td_bound = h->cfg.td_bound; a.bound = h->cfg.v1_unbounded ? 0 : 1;
     if (ride) a.ride = *ride;
     a.ride.n_loss_blocks = h->n_loss_wg;
     const int n_riders = ride ? ride->n_gather + (ride->bookkeeping ? 1 : 0) : 0;
@@ -2024,6 +2030,8 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     if (cfg->hidden[l] < 1 || cfg->hidden[l] > kMaxWidth) return fail(h, DSACT_E_INVALID, "hidden width must be 1..%d", kMaxWidth);
   if (cfg->batch < 1) return fail(h, DSACT_E_INVALID, "batch must be >= 1");
   if (cfg->delay_update < 1) return fail(h, DSACT_E_INVALID, "delay_update must be >= 1");
+  if (cfg->value_act < 0 || cfg->value_act > ACT_TANH || cfg->policy_act < 0 || cfg->policy_act > ACT_TANH)
+    return fail(h, DSACT_E_INVALID, "hidden activation must be 0..5 (gelu, relu, elu, selu, sigmoid, tanh)");
   if (h->cfg.global_batch < h->cfg.batch) h->cfg.global_batch = h->cfg.batch;
   HIPCHK(h, hipSetDevice(device));
   h->O = cfg->obs_dim; h->A = cfg->act_dim; h->L = cfg->n_hidden; h->B = cfg->batch;
@@ -2390,6 +2398,9 @@ int dsact_set_hyper(dsact_handle* h, int32_t which, double value) {
     case DSACT_HYPER_TD_BOUND:
       if (h->cfg.algo != 1) return fail(h, DSACT_E_INVALID, "TD_bound is a DSAC_V1 parameter");
       h->cfg.td_bound = value; break;
+    case DSACT_HYPER_V1_BOUND:
+      if (h->cfg.algo != 1) return fail(h, DSACT_E_INVALID, "bound is a DSAC_V1 parameter");
+      h->cfg.v1_unbounded = value != 0.0 ? 0 : 1; break;
     default: return fail(h, DSACT_E_INVALID, "unknown hyper-parameter %d", (int)which);
   }
   // every launch reads h->cfg when it is enqueued; only a captured graph holds old values
@@ -3241,7 +3252,7 @@ int dsact_policy_forward(dsact_handle* h, const float* obs_host, int32_t n, floa
       h->act_call = 0;
     }
     a.h = h->act_h; a.call = ++h->act_call;
-    a.A = h->A; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
+    a.A = h->A; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std; a.act = h->cfg.policy_act;
     a.out = h->act_out_dev; a.timeout = h->handoff_dev;
     memcpy(a.x, obs_host, O * sizeof(float));
     const auto tl = std::chrono::steady_clock::now();

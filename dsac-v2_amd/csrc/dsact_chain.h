@@ -522,7 +522,9 @@ struct FwdUnit {
   int* done; const int* wait0; const int* wait1; int wait_rows0, wait_rows1;
   int* zdone;                       // SEG_FULL_SAVE producers: raised as soon as zsave is written (the consumers of the saved
                                     // observation part do not wait for the rest of this unit's chain)
-  int rg, n_slices;                 // rows per workgroup / 4 and slices of THIS unit (units of one launch may differ)
+  short rg, act;                    // rows per workgroup / 4 of THIS unit (units of one launch may differ); hidden activation
+                                    // of its net (ACT_*, dsact_math.h). (shorts: two FwdArgs must fit the 4 KB of kernel arguments)
+  int n_slices;                     // slices of this unit
 };
 constexpr int kMaxFwdUnits = 6;
 struct FwdArgs {
@@ -742,7 +744,7 @@ __device__ __forceinline__ void chain_fwd_body(const FwdArgs& a, int unit, int s
     for (int g = 0; g < RG; ++g) {
       const f32x4 z = acc[g][0] + acc[g][1] + bl;
       f32x4 hv, gd;
-      gelu4(z, hv, gd);
+      act4(u.act, z, hv, gd);
 #pragma unroll
       for (int r = 0; r < 4; ++r) lds[hn + (4 * g + r) * S.ld_h + n] = hv[r];
       if (u.H[l]) nt_store4(u.H[l] + pk_index(n, row0 + 4 * g, a.Cb), hv);   // rows row0+4g .. +3 of feature n: 16 contiguous bytes

@@ -275,7 +275,7 @@ __device__ __forceinline__ void fat_fwd_body(const FwdArgs& a, int unit, int sli
       for (int nt = 0; nt < 4; ++nt) {
         const f32x4 z = acc[rt][nt] + bl[nt];
         f32x4 hv, gd;
-        gelu4(z, hv, gd);
+        act4(u.act, z, hv, gd);
         if (u.H[l]) nt_store4(u.H[l] + pk_index(nf[nt], row0 + 16 * rt + 4 * g, a.Cb), hv);
         if (u.G[l]) nt_store4(u.G[l] + pk_index(nf[nt], row0 + 16 * rt + 4 * g, a.Cb), gd);
         acc[rt][nt] = hv;

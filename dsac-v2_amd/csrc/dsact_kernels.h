@@ -64,6 +64,13 @@ __device__ __forceinline__ void gelu4(const f32x4 z, f32x4& h, f32x4& g) {
   g = vfma4(z, pdf, cdf);
 }
 
+// act(z), act'(z) on 4 values; `act` is wave-uniform (a net's hidden activation): GELU takes the packed path above
+__device__ __forceinline__ void act4(int act, const f32x4 z, f32x4& h, f32x4& g) {
+  if (act == ACT_GELU) { gelu4(z, h, g); return; }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { float hv, gv; act_fwd_grad(act, z[e], hv, gv); h[e] = hv; g[e] = gv; }
+}
+
 // ---- fragment-major ("packed") copies of a row-major [N x K] matrix -------------------------------------------
 // style 16 (v_mfma_f32_16x16x4_f32 operands; the narrow products: output layers, dL/d action):
 //   tiles of 16 rows x chunks of 16 k; inside a (tile, chunk) block lane (g = (k%16)/4, i = n%16) owns the 4 floats
@@ -639,6 +646,7 @@ struct GemmProb {
   int tiles_n;          // n-tiles per m-tile row
   int tile_end;         // exclusive end of this problem's block range inside its stage
   const MirrorDesc* mir;  // weight-gradient tiles with the fused optimiser: packed copies of the tensor to refresh (or nullptr)
+  int act;                // EPI_GELU stages: hidden activation of this problem's net (ACT_*, dsact_math.h)
 };
 
 // Optimiser fused into the weight-gradient tiles (single-GPU path): every parameter element is the
@@ -828,7 +836,7 @@ __device__ __forceinline__ void run_tile(const GemmProb& t, int m0, int n0, floa
     f32x4 h, gd, zv;
 #pragma unroll
     for (int e = 0; e < 4; ++e) zv[e] = acc[e] + (full ? epv[e] : (n + e < t.N ? t.aux[n + e] : 0.0f));
-    gelu4(zv, h, gd);
+    act4(t.act, zv, h, gd);
     float* c0 = t.C0 + (size_t)m * t.ldc + n;
     float* c1 = t.C1 + (size_t)m * t.ldc + n;
     if (full) { *(f32x4u*)c0 = h; *(f32x4u*)c1 = gd; }
@@ -1021,7 +1029,7 @@ __device__ __forceinline__ void run_tile64(const GemmProb& t, int m0, int n0, fl
     float* c0 = t.C0 + (size_t)m * t.ldc + n;
     if (EPI == EPI_GELU) {
       f32x4 hv, gd;
-      gelu4(acc[mb] + epv[mb], hv, gd);
+      act4(t.act, acc[mb] + epv[mb], hv, gd);
       *(f32x4u*)c0 = hv;
       *(f32x4u*)(t.C1 + (size_t)m * t.ldc + n) = gd;
     } else {
@@ -1457,6 +1465,7 @@ struct LossV1Args {
   int W, B;
   float inv_B;
   int auto_alpha; float alpha_fixed, gamma, td_bound;
+  int bound;             // dsac_v1.py:217: 1 = variance-weighted pseudo-loss with the clipped target; 0 = -Normal(q, std).log_prob(target)
   RideArgs ride;
 };
 
@@ -1506,9 +1515,17 @@ __global__ void __launch_bounds__(kThreads) k_loss_v1(LossV1Args a) {
   const float tq = rew + (1.0f - in_done) * a.gamma * (qs - alpha * lp2);
   const float tqb = q + clampf(tq - q, -a.td_bound, a.td_bound);
   const float sd = fmaxf(std, 0.0f);
-  const float dq = -(tq - q) / (sd * sd + 0.1f);
+  float dq = -(tq - q) / (sd * sd + 0.1f);
   const float e = q - tqb;
-  const float dstd = -((e * e - sd * sd) / (sd * sd * sd + 0.1f));
+  float dstd = -((e * e - sd * sd) / (sd * sd * sd + 0.1f));
+  float loss_row = dq * q + dstd * std;
+  if (!a.bound) {
+    // dsac_v1.py:227-228: -Normal(q, std).log_prob(tq) = (tq - q)^2 / (2 std^2) + log std + log sqrt(2 pi)
+    const float d = tq - q, var = std * std;
+    dq = -d / var;
+    dstd = 1.0f / std - (d * d) / (var * std);
+    loss_row = (d * d) / (2.0f * var) + logf(std) + kLogSqrt2Pi;
+  }
   float dv[4];
   dv[0] = dq * a.inv_B;
   dv[1] = dstd * a.inv_B * sg;
@@ -1520,7 +1537,7 @@ __global__ void __launch_bounds__(kThreads) k_loss_v1(LossV1Args a) {
     a.qout_t[2 * r] = o[0][0]; a.qout_t[2 * r + 1] = o[0][1];
     a.qout_p[2 * r] = o[1][0]; a.qout_p[2 * r + 1] = o[1][1];
     float* pl = a.part_loss + (size_t)r * kLossPart;
-    pl[0] = dq * q + dstd * std; pl[1] = 0.f; pl[2] = q; pl[3] = 0.f; pl[4] = std; pl[5] = 0.f;
+    pl[0] = loss_row; pl[1] = 0.f; pl[2] = q; pl[3] = 0.f; pl[4] = std; pl[5] = 0.f;
     pl[6] = alpha * lpn - q_pi;
     pl[7] = lpn;
     pl[8] = r == 0 ? alpha : 0.0f;

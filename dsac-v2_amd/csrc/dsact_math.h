@@ -68,6 +68,29 @@ DSACT_HD void gelu_fwd_grad(float z, float& h, float& g) {
   g = fmaf(z, pdf, cdf);
 }
 
+// ---- hidden activations of the MLPs (utils/common_utils.py:16-45 -> nn.ReLU / ELU / GELU / SELU / Sigmoid / Tanh with
+// their default arguments). Every forward epilogue stores h = act(z) AND g = act'(z); the backward only ever multiplies
+// by the stored g, so the activation exists in exactly one place per kernel family.
+enum : int { ACT_GELU = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SELU = 3, ACT_SIGMOID = 4, ACT_TANH = 5 };
+constexpr float kSeluAlpha = 1.6732632423543772848170429916717f, kSeluScale = 1.0507009873554804934193349852946f;
+DSACT_HD void act_fwd_grad(int act, float z, float& h, float& g) {
+  switch (act) {
+    case ACT_RELU: h = z > 0.0f ? z : 0.0f; g = z > 0.0f ? 1.0f : 0.0f; break;
+    case ACT_ELU: {      // alpha = 1: torch backward uses the result: grad * (h + alpha) below 0
+      const float e = expm1f(z);
+      h = z > 0.0f ? z : e; g = z > 0.0f ? 1.0f : e + 1.0f; break;
+    }
+    case ACT_SELU: {
+      const float e = expm1f(z);
+      h = kSeluScale * (z > 0.0f ? z : kSeluAlpha * e);
+      g = z > 0.0f ? kSeluScale : kSeluScale * kSeluAlpha * (e + 1.0f); break;
+    }
+    case ACT_SIGMOID: { const float sg = 1.0f / (1.0f + expf(-z)); h = sg; g = sg * (1.0f - sg); break; }
+    case ACT_TANH: { const float t = tanhf(z); h = t; g = 1.0f - t * t; break; }
+    default: gelu_fwd_grad(z, h, g); break;
+  }
+}
+
 DSACT_HD float softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 // d softplus / dx (torch: grad * (x*beta > threshold ? 1 : z/(z+1)), z = exp(x))
 DSACT_HD float softplus_grad(float x) {

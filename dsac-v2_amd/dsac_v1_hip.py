@@ -50,8 +50,6 @@ def _check_supported(kwargs):
     if kwargs.get("value_func_type", "MLP") != "MLP" or kwargs.get("policy_func_type", "MLP") != "MLP":
         raise NotImplementedError("DSAC_V1_HIP is built for the MLP approximators")
     _v2._check_supported(kwargs)
-    if not kwargs.get("bound", True):
-        raise NotImplementedError("DSAC_V1_HIP implements the reference default bound=True (dsac_v1.py:217-226)")
 
 
 class ApproxContainer(_v2.ApproxContainer):
@@ -64,10 +62,10 @@ class ApproxContainer(_v2.ApproxContainer):
         O, A = int(kwargs["obsv_dim"]), int(kwargs["action_dim"])
         hi = np.asarray(kwargs["action_high_limit"], dtype=np.float32)
         lo = np.asarray(kwargs["action_low_limit"], dtype=np.float32)
-        self.q = _v2.HipActionValueDistri(O, A, hidden)
+        self.q = _v2.HipActionValueDistri(O, A, hidden, kwargs.get("value_hidden_activation", "gelu"))
         self.q_target = copy.deepcopy(self.q)
         self.policy = _v2.HipStochaPolicy(O, A, hidden, hi, lo, kwargs.get("policy_min_log_std", -20.0),
-                                          kwargs.get("policy_max_log_std", 2.0))
+                                          kwargs.get("policy_max_log_std", 2.0), kwargs.get("policy_hidden_activation", "gelu"))
         self.policy_target = copy.deepcopy(self.policy)
         for net in (self.policy_target, self.q_target):
             for p in net.parameters():
@@ -106,15 +104,7 @@ class DSAC_V1_HIP(_v2.DSAC_V2_HIP):
     _tb_cls = LazyTbInfoV1
 
     TD_bound = _v2._Hyper("TD_bound")
-
-    @property
-    def bound(self):
-        return True
-
-    @bound.setter
-    def bound(self, value):
-        if not value:   # dsac_v1.py:217 `if self.bound:` -- the unbounded critic loss is not implemented in the HIP path
-            raise NotImplementedError("DSAC_V1_HIP implements the bounded critic loss only (bound=True)")
+    bound = _v2._Hyper("bound")   # dsac_v1.py:217 `if self.bound:` -- variance-weighted pseudo-loss, else the Gaussian NLL (:227-228)
 
     def __init__(self, **kwargs):
         _check_supported(kwargs)
@@ -137,7 +127,9 @@ class DSAC_V1_HIP(_v2.DSAC_V2_HIP):
             lr_pi=kwargs["policy_learning_rate"], lr_alpha=kwargs["alpha_learning_rate"],
             min_log_std=kwargs.get("policy_min_log_std", -20.0), max_log_std=kwargs.get("policy_max_log_std", 2.0),
             global_batch=kwargs.get("global_batch"), device=int(kwargs.get("hip_device", 0)),
-            algo="DSAC_V1", td_bound=float(self.TD_bound))
+            algo="DSAC_V1", td_bound=float(self.TD_bound), v1_bound=bool(self.bound),
+            value_act=_v2.ACTIVATIONS[kwargs.get("value_hidden_activation", "gelu")][0],
+            policy_act=_v2.ACTIVATIONS[kwargs.get("policy_hidden_activation", "gelu")][0])
         self.networks.attach(self.engine)
         register_engine(self.engine)
         if not self.strict_rng:

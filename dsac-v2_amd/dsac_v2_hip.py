@@ -95,20 +95,25 @@ class TanhGaussDistribution:
 # --------------------------------------------------------------------------------------------------
 # networks: torch modules whose parameters become views of the HIP arenas once attached
 # --------------------------------------------------------------------------------------------------
-def _mlp(sizes):
+# value_hidden_activation / policy_hidden_activation (reference utils/common_utils.py:16-45), id = dsact_config value
+ACTIVATIONS = {"gelu": (0, nn.GELU), "relu": (1, nn.ReLU), "elu": (2, nn.ELU), "selu": (3, nn.SELU),
+               "sigmoid": (4, nn.Sigmoid), "tanh": (5, nn.Tanh)}
+
+
+def _mlp(sizes, activation="gelu"):
     layers = []
     for j in range(len(sizes) - 1):
         layers.append(nn.Linear(sizes[j], sizes[j + 1]))
-        layers.append(nn.GELU() if j < len(sizes) - 2 else nn.Identity())
+        layers.append(ACTIVATIONS[activation][1]() if j < len(sizes) - 2 else nn.Identity())
     return nn.Sequential(*layers)
 
 
 class HipActionValueDistri(nn.Module):
     """Distributional Q(s,a) -> (mean, std); parameter names as reference networks/mlp.py:109-127."""
 
-    def __init__(self, obs_dim, act_dim, hidden):
+    def __init__(self, obs_dim, act_dim, hidden, activation="gelu"):
         super().__init__()
-        self.q = _mlp([obs_dim + act_dim] + list(hidden) + [2])
+        self.q = _mlp([obs_dim + act_dim] + list(hidden) + [2], activation)
 
     def forward(self, obs, act):
         out = self.q(torch.cat([obs, act], dim=-1))
@@ -118,9 +123,9 @@ class HipActionValueDistri(nn.Module):
 class HipStochaPolicy(nn.Module):
     """Stochastic policy obs -> (mean | std); parameter names as reference networks/mlp.py:28-100."""
 
-    def __init__(self, obs_dim, act_dim, hidden, act_high, act_low, min_log_std, max_log_std):
+    def __init__(self, obs_dim, act_dim, hidden, act_high, act_low, min_log_std, max_log_std, activation="gelu"):
         super().__init__()
-        self.policy = _mlp([obs_dim] + list(hidden) + [2 * act_dim])
+        self.policy = _mlp([obs_dim] + list(hidden) + [2 * act_dim], activation)
         self.min_log_std, self.max_log_std = float(min_log_std), float(max_log_std)
         self.register_buffer("act_high_lim", torch.from_numpy(np.asarray(act_high, dtype=np.float32).copy()))
         self.register_buffer("act_low_lim", torch.from_numpy(np.asarray(act_low, dtype=np.float32).copy()))
@@ -159,13 +164,13 @@ def _feat_dim(obs_shape, conv_type):
 class HipCnnActionValueDistri(nn.Module):
     """conv -> flatten -> cat(act) -> separate `mean` / `log_std` MLPs (reference networks/cnn.py:383-461)."""
 
-    def __init__(self, obs_shape, act_dim, conv_type):
+    def __init__(self, obs_shape, act_dim, conv_type, activation="gelu"):
         super().__init__()
         hidden = CONV_TYPES[conv_type][4]
         self.conv = _cnn(obs_shape, conv_type)
         sizes = [_feat_dim(obs_shape, conv_type) + act_dim] + list(hidden) + [1]
-        self.mean = _mlp(sizes)
-        self.log_std = _mlp(sizes)
+        self.mean = _mlp(sizes, activation)
+        self.log_std = _mlp(sizes, activation)
 
     def forward(self, obs, act):
         img = self.conv(obs)
@@ -176,13 +181,13 @@ class HipCnnActionValueDistri(nn.Module):
 class HipCnnStochaPolicy(nn.Module):
     """conv -> flatten -> separate `mean` / `log_std` MLPs (reference networks/cnn.py:151-240)."""
 
-    def __init__(self, obs_shape, act_dim, conv_type, act_high, act_low, min_log_std, max_log_std):
+    def __init__(self, obs_shape, act_dim, conv_type, act_high, act_low, min_log_std, max_log_std, activation="gelu"):
         super().__init__()
         hidden = CONV_TYPES[conv_type][4]
         self.conv = _cnn(obs_shape, conv_type)
         sizes = [_feat_dim(obs_shape, conv_type)] + list(hidden) + [act_dim]
-        self.mean = _mlp(sizes)
-        self.log_std = _mlp(sizes)
+        self.mean = _mlp(sizes, activation)
+        self.log_std = _mlp(sizes, activation)
         self.min_log_std, self.max_log_std = float(min_log_std), float(max_log_std)
         self.register_buffer("act_high_lim", torch.from_numpy(np.asarray(act_high, dtype=np.float32).copy()))
         self.register_buffer("act_low_lim", torch.from_numpy(np.asarray(act_low, dtype=np.float32).copy()))
@@ -228,8 +233,10 @@ def _hidden_sizes(kwargs):
 
 def _check_supported(kwargs):
     _conv_type(kwargs)
-    for key, want in (("value_hidden_activation", "gelu"), ("policy_hidden_activation", "gelu"),
-                      ("value_output_activation", "linear"), ("policy_output_activation", "linear"),
+    for key in ("value_hidden_activation", "policy_hidden_activation"):
+        if kwargs.get(key, "gelu") not in ACTIVATIONS:
+            raise NotImplementedError("DSAC_V2_HIP supports %s in %s (got %r)" % (key, sorted(ACTIVATIONS), kwargs.get(key)))
+    for key, want in (("value_output_activation", "linear"), ("policy_output_activation", "linear"),
                       ("policy_act_distribution", "TanhGaussDistribution")):
         got = kwargs.get(key, want)
         if got != want:
@@ -261,18 +268,19 @@ class ApproxContainer(nn.Module):
         mn = kwargs.get("policy_min_log_std", -20.0)
         mx = kwargs.get("policy_max_log_std", 2.0)
         # construction order == reference, so the same torch seed gives the same initial weights
+        va, pa = kwargs.get("value_hidden_activation", "gelu"), kwargs.get("policy_hidden_activation", "gelu")
         if ct:
-            self.q1 = HipCnnActionValueDistri(O, A, ct)
-            self.q2 = HipCnnActionValueDistri(O, A, ct)
+            self.q1 = HipCnnActionValueDistri(O, A, ct, va)
+            self.q2 = HipCnnActionValueDistri(O, A, ct, va)
         else:
-            self.q1 = HipActionValueDistri(O, A, hidden)
-            self.q2 = HipActionValueDistri(O, A, hidden)
+            self.q1 = HipActionValueDistri(O, A, hidden, va)
+            self.q2 = HipActionValueDistri(O, A, hidden, va)
         self.q1_target = copy.deepcopy(self.q1)  # no RNG consumed, like the reference's deepcopy
         self.q2_target = copy.deepcopy(self.q2)
         if ct:
-            self.policy = HipCnnStochaPolicy(O, A, ct, hi, lo, mn, mx)
+            self.policy = HipCnnStochaPolicy(O, A, ct, hi, lo, mn, mx, pa)
         else:
-            self.policy = HipStochaPolicy(O, A, hidden, hi, lo, mn, mx)
+            self.policy = HipStochaPolicy(O, A, hidden, hi, lo, mn, mx, pa)
         self.policy_target = copy.deepcopy(self.policy)
         for net in (self.policy_target, self.q1_target, self.q2_target):
             for p in net.parameters():
@@ -524,7 +532,9 @@ class DSAC_V2_HIP:
             lr_q=kwargs["value_learning_rate"], lr_pi=kwargs["policy_learning_rate"],
             lr_alpha=kwargs["alpha_learning_rate"],
             min_log_std=kwargs.get("policy_min_log_std", -20.0), max_log_std=kwargs.get("policy_max_log_std", 2.0),
-            global_batch=kwargs.get("global_batch"), device=int(kwargs.get("hip_device", 0)))
+            global_batch=kwargs.get("global_batch"), device=int(kwargs.get("hip_device", 0)),
+            value_act=ACTIVATIONS[kwargs.get("value_hidden_activation", "gelu")][0],
+            policy_act=ACTIVATIONS[kwargs.get("policy_hidden_activation", "gelu")][0])
         self.networks.attach(self.engine)
         register_engine(self.engine)
         if not self.strict_rng:

@@ -95,6 +95,13 @@ typedef struct dsact_config {
    * online = q | policy | log_alpha and target = q_target | policy_target; MLP nets only. */
   int32_t algo;
   double td_bound;                              /* TD_bound (DSAC_V1 only; reference default 20) */
+  int32_t v1_unbounded;                         /* DSAC_V1 `bound` kwarg NEGATED (0 = the reference default bound=True, the
+                                                 * variance-weighted pseudo-loss of dsac_v1.py:217-226; 1 = bound=False, the plain
+                                                 * Gaussian negative log-likelihood of :227-228) */
+  /* value_hidden_activation / policy_hidden_activation (utils/common_utils.py:16-45): 0 gelu (every shipped example),
+   * 1 relu, 2 elu, 3 selu, 4 sigmoid, 5 tanh -- torch's default arguments. Output activations are linear. */
+  int32_t value_act, policy_act;
+  int32_t reserved0;
 } dsact_config;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */
@@ -135,6 +142,7 @@ int dsact_set_state(dsact_handle* h, const int32_t adam_steps[3], const float me
 #define DSACT_HYPER_AUTO_ALPHA 3
 #define DSACT_HYPER_ALPHA 4
 #define DSACT_HYPER_DELAY_UPDATE 5
+#define DSACT_HYPER_V1_BOUND 7      /* DSAC_V1 `bound` (0 / 1) */
 #define DSACT_HYPER_TD_BOUND 6
 int dsact_set_hyper(dsact_handle* h, int32_t which, double value);
 

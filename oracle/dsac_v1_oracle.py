@@ -4,7 +4,7 @@
     dsac_v1.py:17-53     ApproxContainer: q, q_target, policy, policy_target, log_alpha, 3 Adam
     dsac_v1.py:140-182   __compute_gradient (5 standard-normal draws per call, see draw_noise_v1)
     dsac_v1.py:184-192   __q_evaluate
-    dsac_v1.py:194-227   __compute_loss_q   (bound=True branch: variance-weighted pseudo-loss)
+    dsac_v1.py:194-229   __compute_loss_q   (bound=True: variance-weighted pseudo-loss; bound=False: Gaussian NLL)
     dsac_v1.py:229-236   __compute_target_q (fixed TD_bound)
     dsac_v1.py:238-253   __compute_loss_policy / __compute_loss_alpha
     dsac_v1.py:255-279   __update
@@ -70,6 +70,7 @@ class DsacV1Oracle:
                     "alpha": Adam([self.log_alpha], lr=cfg["lr_alpha"])}
         self.target_entropy = -A
         self.TD_bound = cfg.get("TD_bound", 20)            # dsac_v1.py:78
+        self.bound = bool(cfg.get("bound", True))          # dsac_v1.py:81
 
     def state_dict(self):
         sd = OrderedDict()
@@ -110,8 +111,8 @@ class DsacV1Oracle:
         # ---- __compute_loss_q ----
         logits_2 = policy_forward(obs2, self.p["policy_target"], cfg)
         act2, log_prob_act2 = tanh_gauss_rsample(logits_2, noise["eps_2"], self.act_high, self.act_low)
-        q, q_std = q_forward(obs, act, self.p["q"])
-        qn_mean, qn_std = q_forward(obs2, act2, self.p["q_target"])
+        q, q_std = q_forward(obs, act, self.p["q"], None, cfg.get("value_act", "gelu"))
+        qn_mean, qn_std = q_forward(obs2, act2, self.p["q_target"], None, cfg.get("value_act", "gelu"))
         q_next_sample = qn_mean + torch.mul(torch.clamp(noise["z_t"], -3, 3), qn_std)
         alpha = self._alpha()
         target_q = rew + (1 - done) * cfg["gamma"] * (q_next_sample.detach() - alpha * log_prob_act2.detach())
@@ -120,14 +121,17 @@ class DsacV1Oracle:
         target_q = target_q.detach()
         q_std_detach = torch.clamp(q_std, min=0.).detach()
         bias = 0.1
-        q_loss = torch.mean(
-            -(target_q - q).detach() / (torch.pow(q_std_detach, 2) + bias) * q
-            - ((torch.pow(q.detach() - target_q_bound, 2) - q_std_detach.pow(2)) / (torch.pow(q_std_detach, 3) + bias)) * q_std)
+        if self.bound:
+            q_loss = torch.mean(
+                -(target_q - q).detach() / (torch.pow(q_std_detach, 2) + bias) * q
+                - ((torch.pow(q.detach() - target_q_bound, 2) - q_std_detach.pow(2)) / (torch.pow(q_std_detach, 3) + bias)) * q_std)
+        else:   # dsac_v1.py:227-228: the plain Gaussian negative log-likelihood of the (unbounded) target
+            q_loss = -torch.distributions.Normal(q, q_std).log_prob(target_q).mean()
         q_loss.backward()
         for t in self.p["q"]:
             t.requires_grad_(False)
         self.opt["policy"].zero_grad()
-        q_pi, _ = q_forward(obs, new_act, self.p["q"])
+        q_pi, _ = q_forward(obs, new_act, self.p["q"], None, cfg.get("value_act", "gelu"))
         loss_policy = (alpha * new_log_prob - q_pi).mean()
         entropy = -new_log_prob.detach().mean()
         loss_policy.backward()

@@ -86,29 +86,53 @@ def _new_mlp_params(sizes: List[int]) -> List[torch.Tensor]:
     return ps
 
 
-def mlp_forward(x, params, collect=None):
-    """Linear-GELU(erf) ... Linear (identity output), networks/mlp.py:15-20."""
+# value_hidden_activation / policy_hidden_activation (utils/common_utils.py:16-45: torch modules, default arguments)
+ACTIVATIONS = {"gelu": F.gelu, "relu": F.relu, "elu": F.elu, "selu": F.selu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}
+SELU_ALPHA, SELU_SCALE = 1.6732632423543772848170429916717, 1.0507009873554804934193349852946
+
+
+def _act_with_side(z, act, pos):
+    """relu / selu with the side of 0 chosen by `pos` (bool tensor) instead of by sign(z). Both activations have a kink
+    at 0 (their derivative jumps): a pre-activation within rounding noise of 0 lands on either side depending on the
+    summation order, and both subgradients are valid. Parity tests pass the decisions of the implementation under test;
+    wherever `pos == (z > 0)` this is the activation itself."""
+    if act == "relu":
+        return z * pos.to(z.dtype)
+    return SELU_SCALE * torch.where(pos, z, SELU_ALPHA * torch.expm1(z))
+
+
+def mlp_forward(x, params, collect=None, act="gelu", sides=None, kink_log=None):
+    """Linear-act ... Linear (identity output), networks/mlp.py:15-20. sides (parity tests, relu / selu only): per hidden
+    layer the bool tensor `z > 0` as another implementation decided it; disagreements are logged as max |z|."""
     n_lin = len(params) // 2
     h = x
     for j in range(n_lin):
         z = F.linear(h, params[2 * j], params[2 * j + 1])
         if collect is not None:
             collect.append(z)
-        h = F.gelu(z) if j < n_lin - 1 else z
+        if j == n_lin - 1:
+            h = z
+        elif sides is not None and act in ("relu", "selu"):
+            flip = sides[j] != (z > 0)
+            if kink_log is not None and bool(flip.any()):
+                kink_log.append((j, int(flip.sum()), float(z.detach()[flip].abs().max())))
+            h = _act_with_side(z, act, sides[j])
+        else:
+            h = ACTIVATIONS[act](z)
     return h
 
 
-def policy_forward(obs, params, cfg, collect=None):
+def policy_forward(obs, params, cfg, collect=None, sides=None, kink_log=None):
     """StochaPolicy.forward, std_type == mlp_shared (networks/mlp.py:85-100)."""
-    logits = mlp_forward(obs, params, collect)
+    logits = mlp_forward(obs, params, collect, cfg.get("policy_act", "gelu"), sides, kink_log)
     mean, log_std = torch.chunk(logits, chunks=2, dim=-1)
     std = torch.clamp(log_std, cfg["min_log_std"], cfg["max_log_std"]).exp()
     return torch.cat((mean, std), dim=-1)
 
 
-def q_forward(obs, act, params, collect=None):
+def q_forward(obs, act, params, collect=None, hidden_act="gelu", sides=None, kink_log=None):
     """ActionValueDistri.forward (networks/mlp.py:122-127) -> (mean, std)."""
-    logits = mlp_forward(torch.cat([obs, act], dim=-1), params, collect)
+    logits = mlp_forward(torch.cat([obs, act], dim=-1), params, collect, hidden_act, sides, kink_log)
     value_mean, value_std = torch.chunk(logits, chunks=2, dim=-1)
     value_std = F.softplus(value_std)
     out = torch.cat((value_mean, value_std), dim=-1)
@@ -215,11 +239,34 @@ class DsactOracle:
         cfg = self.cfg
         return _new_mlp_params([cfg["obs_dim"]] + list(cfg["hidden"]) + [2 * cfg["act_dim"]])
 
+    # Parity tests with relu / selu hidden activations: act_sides[chain] = per hidden layer the bool tensor `z > 0` as the
+    # implementation under test decided it, for the differentiated chains "pi", "q1c", "q2c" (first evaluation of the
+    # net in an update: (obs, act)) and "q1p", "q2p" (second: (obs, new_act)); act_kinks collects the disagreements.
+    act_sides, act_kinks = None, None
+
+    def _chain_of(self, params):
+        for n in ("policy", "q1", "q2"):
+            if self.p[n] is params:
+                k = self._calls.get(n, 0)
+                self._calls[n] = k + 1
+                return "pi" if n == "policy" else n + ("c" if k == 0 else "p")
+        return None
+
     def _pi(self, obs, params, collect=None):
-        return policy_forward(obs, params, self.cfg, collect)
+        ch = self._chain_of(params) if self.act_sides else None
+        log = [] if ch in (self.act_sides or {}) else None
+        out = policy_forward(obs, params, self.cfg, collect, (self.act_sides or {}).get(ch), log)
+        if log:
+            self.act_kinks += [(ch,) + e for e in log]
+        return out
 
     def _q(self, obs, act, params, collect=None):
-        return q_forward(obs, act, params, collect)
+        ch = self._chain_of(params) if self.act_sides else None
+        log = [] if ch in (self.act_sides or {}) else None
+        out = q_forward(obs, act, params, collect, self.cfg.get("value_act", "gelu"), (self.act_sides or {}).get(ch), log)
+        if log:
+            self.act_kinks += [(ch,) + e for e in log]
+        return out
 
     # ---- checkpoint format (training/trainer.py:148-152) -----------------
     def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
@@ -263,6 +310,7 @@ class DsactOracle:
         cfg = self.cfg
         obs, act, rew, obs2, done = data["obs"], data["act"], data["rew"], data["obs2"], data["done"]
         I = {} if keep else None
+        self._calls, self.act_kinks = {}, []
 
         def col():
             return [] if keep else None

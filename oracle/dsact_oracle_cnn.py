@@ -156,16 +156,16 @@ class DsactCnnOracle(DsactOracle):
         """StochaPolicy.forward (networks/cnn.py:232-240)."""
         conv, mean, log_std = self._split(params)
         feat = self._conv(obs, params, conv)
-        a_mean = mlp_forward(feat, mean, collect)
-        a_std = torch.clamp(mlp_forward(feat, log_std), self.cfg["min_log_std"], self.cfg["max_log_std"]).exp()
+        a_mean = mlp_forward(feat, mean, collect, self.cfg.get("policy_act", "gelu"))
+        a_std = torch.clamp(mlp_forward(feat, log_std, None, self.cfg.get("policy_act", "gelu")), self.cfg["min_log_std"], self.cfg["max_log_std"]).exp()
         return torch.cat((a_mean, a_std), dim=-1)
 
     def _q(self, obs, act, params, collect=None):
         """ActionValueDistri.forward (networks/cnn.py:453-461) -> (mean, std)."""
         conv, mean, log_std = self._split(params)
         feat = torch.cat([self._conv(obs, params, conv), act], -1)
-        v_mean = mlp_forward(feat, mean, collect)
-        v_std = F.softplus(mlp_forward(feat, log_std))
+        v_mean = mlp_forward(feat, mean, collect, self.cfg.get("value_act", "gelu"))
+        v_std = F.softplus(mlp_forward(feat, log_std, None, self.cfg.get("value_act", "gelu")))
         out = torch.cat((v_mean, v_std), dim=-1)
         return out[..., 0], out[..., -1]
 

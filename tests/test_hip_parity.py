@@ -131,7 +131,8 @@ def make_pair(O, A, hid, B, act_limit=0.4, seed=0, init=None, **over):
     alg = DSAC_V2_HIP(**hip_kwargs(O, A, hid, B, act_limit=act_limit, strict_rng=True, **over))
     if init is not None:
         alg.networks.load_state_dict(init)
-    cfg = default_config(O, A, hid, act_limit=act_limit,
+    cfg = default_config(O, A, hid, act_limit=act_limit, value_act=over.get("value_hidden_activation", "gelu"),
+                         policy_act=over.get("policy_hidden_activation", "gelu"),
                          **{k: over[k] for k in ("auto_alpha", "alpha", "delay_update") if k in over})
     orc = DsactOracle(cfg, state_dict={k: v.cpu() for k, v in alg.networks.state_dict().items()})
     return alg, orc
@@ -139,6 +140,32 @@ def make_pair(O, A, hid, B, act_limit=0.4, seed=0, init=None, **over):
 
 def gelu_np(z):
     return torch.nn.functional.gelu(z).numpy()
+
+
+KINKED = ("relu", "selu")     # hidden activations whose derivative jumps at 0
+
+
+def act_np(z, act):
+    from oracle.dsact_oracle import ACTIVATIONS
+    return ACTIVATIONS[act](z).numpy()
+
+
+def hip_act_sides(e, cfg, L, B):
+    """the side of 0 the HIP kernels put every hidden pre-activation of the differentiated chains on (read back from the
+    stored act'(z): relu 0 / 1, selu scale*alpha*exp(z) / scale), for the oracle's `act_sides` (oracle/dsact_oracle.py:
+    at a pre-activation within rounding noise of 0 either subgradient is valid; the reference is evaluated with the
+    kernels' choice and every disagreement must be such a kink)"""
+    sides = {}
+    for ch in ("pi", "q1c", "q2c", "q1p", "q2p"):
+        act = cfg["policy_act"] if ch == "pi" else cfg["value_act"]
+        if act not in KINKED:
+            continue
+        per = []
+        for l in range(L):
+            g = torch.as_tensor(e.debug_read("G.%s.%d" % (ch, l)).reshape(B, -1))
+            per.append(g > 0.5 if act == "relu" else (g - 1.0507009873554805).abs() < 1e-3)
+        sides[ch] = per
+    return sides
 
 
 def compare_intermediates(rep, alg, orc, L, B, A):
@@ -172,7 +199,7 @@ def compare_intermediates(rep, alg, orc, L, B, A):
         rep.cmp(q, d("qout_p%d" % i).reshape(B, 2)[:, 0], I[q], 2e-5)
     for ch, key in (("pi", "z_pi"), ("q1c", "z_q1"), ("q2c", "z_q2"), ("q1p", "z_q1p"), ("q2p", "z_q2p")):
         for l in range(L):
-            rep.cmp("H.%s.%d" % (ch, l), d("H.%s.%d" % (ch, l)), gelu_np(I[key][l]), 2e-6, 2e-5)
+            rep.cmp("H.%s.%d" % (ch, l), d("H.%s.%d" % (ch, l)), act_np(I[key][l], orc.cfg["policy_act" if ch == "pi" else "value_act"]), 2e-6, 2e-5)
     rep.cmp("d_new_act", d("d_new_act"), I["d_new_act"], 1e-9, 2e-4)
     for ch, key in (("q1c", "dz_q1"), ("q2c", "dz_q2"), ("q1p", "dz_q1p"), ("q2p", "dz_q2p"), ("pi", "dz_pi")):
         for l in range(L):
@@ -198,11 +225,15 @@ def run_case(title, O, A, hid, B, steps, act_limit=0.4, init=None, golden=None, 
             torch.manual_seed(1000 + it)
             noise = draw_noise(B, A)
         keep = it in (0, steps - 1)
-        tb_ref = orc.compute_gradient(data, noise, keep=keep)
         e.load_batch(*(data[k].numpy() for k in ("obs", "act", "rew", "obs2", "done")))
         e.set_noise(noise["eps_new"].numpy(), noise["eps_2"].numpy(), noise["z5"].numpy(), noise["z6"].numpy())
         e.compute_grads(it)
         e.sync()  # the engine runs on its own stream; torch reads below are on torch's
+        if cfg["value_act"] in KINKED or cfg["policy_act"] in KINKED:
+            orc.act_sides = hip_act_sides(e, cfg, L, B)
+        tb_ref = orc.compute_gradient(data, noise, keep=keep)
+        for ch, j, cnt, zmax in (orc.act_kinks or []):
+            assert zmax < 1e-5, "activation sides differ at a pre-activation of %g (%s layer %d): not a kink" % (zmax, ch, j)
         if keep:
             compare_intermediates(rep, alg, orc, L, B, A)
         g = e.grads.cpu().numpy()
@@ -281,6 +312,24 @@ def test_humanoid_b2048_split_k_weight_gradients():
     partial gradient arena per chunk, k_sum_parts, then the streaming Adam/Polyak kernel) instead of one
     batch-long contraction per tile."""
     run_case("humanoid 3x256 B=2048 (split-K weight gradients)", 376, 17, (256, 256, 256), 2048, steps=2)
+
+
+@pytest.mark.parametrize("va,pa", [("relu", "tanh"), ("elu", "selu"), ("sigmoid", "relu"), ("tanh", "elu"), ("selu", "sigmoid")])
+def test_hidden_activations(va, pa):
+    """value_hidden_activation / policy_hidden_activation other than the examples' gelu (reference
+    utils/common_utils.py:16-45): the activation lives in the forward epilogues only (h and act'(z) are both stored) --
+    the row-slice chains at the BASELINE shape, the tile path on a ragged shape, the acting forward."""
+    run_case("humanoid 3x256 B=256 %s/%s" % (va, pa), 376, 17, (256, 256, 256), 256, steps=3,
+             value_hidden_activation=va, policy_hidden_activation=pa)
+    run_case("ragged O=11 A=3 (96,40) B=50 %s/%s" % (va, pa), 11, 3, (96, 40), 50, steps=2,
+             value_hidden_activation=va, policy_hidden_activation=pa)
+    alg, orc = make_pair(24, 6, (64, 64), 16, seed=3, value_hidden_activation=va, policy_hidden_activation=pa)
+    from oracle.dsact_oracle import policy_forward
+    obs = np.random.default_rng(0).standard_normal((3, 24)).astype(np.float32)
+    want = policy_forward(torch.as_tensor(obs), [p.detach() for p in orc.p["policy"]], orc.cfg).numpy()
+    got = np.concatenate([alg.engine.policy_forward(obs[i:i + 1]) for i in range(3)])
+    np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(alg.engine.policy_forward(obs), want, atol=2e-5, rtol=1e-5)
 
 
 @pytest.mark.parametrize("B,hid,env", [

@@ -22,14 +22,14 @@ def make_pair(O, A, hid, B, act_limit=0.4, seed=0, init=None, td_bound=10.0, **o
                                    TD_bound=td_bound, **over))
     if init is not None:
         alg.networks.load_state_dict(init)
-    cfg = default_config(O, A, hid, act_limit=act_limit, TD_bound=td_bound)
+    cfg = default_config(O, A, hid, act_limit=act_limit, TD_bound=td_bound, bound=over.get("bound", True))
     orc = DsacV1Oracle(cfg, state_dict={k: v.cpu() for k, v in alg.networks.state_dict().items()})
     return alg, orc
 
 
-def run_case(title, O, A, hid, B, steps, act_limit=0.4, init=None, golden=None):
+def run_case(title, O, A, hid, B, steps, act_limit=0.4, init=None, golden=None, **over):
     rep = Report(title)
-    alg, orc = make_pair(O, A, hid, B, act_limit=act_limit, init=init)
+    alg, orc = make_pair(O, A, hid, B, act_limit=act_limit, init=init, **over)
     e = alg.engine
     lay = e.layout
     assert lay.n_online == orc.flat_params().numel()
@@ -95,6 +95,25 @@ def test_v1_against_reference_golden():
 
 def test_v1_humanoid_shapes():
     run_case("v1 humanoid 3x256 B=256", 376, 17, (256, 256, 256), 256, steps=3)
+
+
+def test_v1_unbounded_critic_loss():
+    """`bound=False` (dsac_v1.py:227-228): the critic loss is -Normal(q, std).log_prob(target_q); also switchable on a live
+    algorithm through `adjustable_parameters`."""
+    run_case("v1 bound=False O=11 A=3 (64,64) B=64", 11, 3, (64, 64), 64, steps=3, bound=False)
+    run_case("v1 bound=False humanoid 3x256 B=256", 376, 17, (256, 256, 256), 256, steps=2, bound=False)
+    a1, _ = make_pair(11, 3, (64, 64), 64, seed=4)
+    a2, _ = make_pair(11, 3, (64, 64), 64, seed=4, bound=False)
+    assert "bound" in a1.adjustable_parameters and a1.bound is True and a2.bound is False
+    a1.bound = False                       # reaches the engine like the reference's attribute is re-read every update
+    rng = np.random.default_rng(1)
+    for it in range(3):
+        data = synth_batch(rng, 64, 11, 3)
+        for a in (a1, a2):
+            torch.manual_seed(70 + it)
+            a.local_update(data, it)
+    a1.engine.sync(); a2.engine.sync()
+    assert torch.equal(a1.engine.online, a2.engine.online)
 
 
 def test_v1_large_batch_tiles_and_split_k():

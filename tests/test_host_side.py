@@ -95,7 +95,18 @@ def test_unsupported_configs_raise():
     with pytest.raises(NotImplementedError):
         ApproxContainer(**hip_kwargs(4, 2, (32,), 8, value_func_type="CNN"))
     with pytest.raises(NotImplementedError):
-        ApproxContainer(**hip_kwargs(4, 2, (32,), 8, policy_hidden_activation="relu"))
+        ApproxContainer(**hip_kwargs(4, 2, (32,), 8, policy_hidden_activation="swish"))   # not one of the reference's six
+    with pytest.raises(NotImplementedError):
+        ApproxContainer(**hip_kwargs(4, 2, (32,), 8, value_output_activation="tanh"))
+    # the reference's hidden activations (utils/common_utils.py:16-45) build the matching torch modules
+    import torch
+    from oracle.dsact_oracle import DsactOracle, default_config, policy_forward
+    for act in ("relu", "elu", "selu", "sigmoid", "tanh", "gelu"):
+        torch.manual_seed(3)
+        c = ApproxContainer(**hip_kwargs(6, 2, (16, 16), 8, policy_hidden_activation=act, value_hidden_activation=act))
+        orc = DsactOracle(default_config(6, 2, (16, 16), policy_act=act, value_act=act), state_dict=c.state_dict())
+        x = torch.randn(5, 6)
+        assert torch.equal(c.policy(x), policy_forward(x, orc.p["policy"], orc.cfg).detach()), act
     with pytest.raises(NotImplementedError):
         ApproxContainer(**hip_kwargs(4, 2, (32,), 8, value_hidden_sizes=[16]))
 

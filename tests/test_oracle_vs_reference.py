@@ -11,14 +11,17 @@ from helpers import synth_batch
 pytestmark = pytest.mark.skipif(not ref_loader.reference_available(), reason="reference not mounted")
 
 
-@pytest.mark.parametrize("O,A,hid,B", [(376, 17, (256, 256, 256), 256), (376, 17, (256, 256), 128), (3, 1, (64, 64, 64), 64)])
-def test_bit_exact_vs_live_reference(O, A, hid, B):
+@pytest.mark.parametrize("O,A,hid,B,va,pa", [
+    (376, 17, (256, 256, 256), 256, "gelu", "gelu"), (376, 17, (256, 256), 128, "gelu", "gelu"), (3, 1, (64, 64, 64), 64, "gelu", "gelu"),
+    # value_hidden_activation / policy_hidden_activation other than the examples' gelu (utils/common_utils.py:16-45)
+    (24, 6, (64, 64), 64, "relu", "tanh"), (24, 6, (64, 64), 64, "elu", "selu"), (24, 6, (64, 64), 64, "sigmoid", "relu")])
+def test_bit_exact_vs_live_reference(O, A, hid, B, va, pa):
     torch.set_num_threads(2)
     ref = ref_loader.import_reference()
-    kw = ref_loader.reference_kwargs(O, A, hid)
+    kw = ref_loader.reference_kwargs(O, A, hid, value_hidden_activation=va, policy_hidden_activation=pa)
     torch.manual_seed(0)
     alg = ref.DSAC_V2(**kw)
-    cfg = default_config(O, A, hid)
+    cfg = default_config(O, A, hid, value_act=va, policy_act=pa)
     torch.manual_seed(0)
     same_seed = DsactOracle(cfg)  # same construction order => same init from the same seed
     sd = alg.networks.state_dict()
@@ -86,9 +89,11 @@ def test_cnn_bit_exact_vs_live_reference(obs_shape, A, conv_type, B):
         assert all(torch.equal(sd[k], osd[k]) for k in sd)
 
 
-@pytest.mark.parametrize("O,A,hid,B", [(11, 3, (64, 64), 32), (376, 17, (256, 256, 256), 64), (3, 1, (32, 32), 16)])
-def test_v1_bit_exact_vs_live_reference(O, A, hid, B):
-    """DSAC_V1 (reference dsac_v1.py) restated in oracle/dsac_v1_oracle.py."""
+@pytest.mark.parametrize("O,A,hid,B,bound", [(11, 3, (64, 64), 32, True), (376, 17, (256, 256, 256), 64, True), (3, 1, (32, 32), 16, True),
+                                             (11, 3, (64, 64), 32, False)])
+def test_v1_bit_exact_vs_live_reference(O, A, hid, B, bound):
+    """DSAC_V1 (reference dsac_v1.py) restated in oracle/dsac_v1_oracle.py -- both critic
+    losses (`bound` True: dsac_v1.py:217-226, False: :227-228)."""
     import importlib
 
     from oracle.dsac_v1_oracle import V1_TB_KEYS, DsacV1Oracle, draw_noise_v1
@@ -96,10 +101,10 @@ def test_v1_bit_exact_vs_live_reference(O, A, hid, B):
     torch.set_num_threads(2)
     ref_loader.import_reference()
     v1 = importlib.import_module("dsac_v1")
-    kw = ref_loader.reference_kwargs(O, A, hid, algorithm="DSAC_V1", TD_bound=10)
+    kw = ref_loader.reference_kwargs(O, A, hid, algorithm="DSAC_V1", TD_bound=10, bound=bound)
     torch.manual_seed(0)
     alg = v1.DSAC_V1(**kw)
-    cfg = default_config(O, A, hid, TD_bound=10)
+    cfg = default_config(O, A, hid, TD_bound=10, bound=bound)
     torch.manual_seed(0)
     same_seed = DsacV1Oracle(cfg)
     sd, osd = alg.networks.state_dict(), same_seed.state_dict()
