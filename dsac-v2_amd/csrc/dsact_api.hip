@@ -326,6 +326,8 @@ void build_net(NetDesc& d, int in0, const int* hidden, int L, int n_out, int nbl
 int net_act(const dsact_handle* h, int net);
 const NetDesc& net_desc(const dsact_handle* h, int net) { return (net == N_POL || net == N_POLT) ? h->pd : h->qd; }
 
+// any net with a hidden activation other than GELU: the forward chains run their generic-activation instantiations
+bool generic_act(const dsact_handle* h) { return h->cfg.value_act != ACT_GELU || h->cfg.policy_act != ACT_GELU; }
 // hidden activation of a net's MLP layers (value_hidden_activation / policy_hidden_activation, common_utils.py:16-45)
 int net_act(const dsact_handle* h, int net) { return (net == N_POL || net == N_POLT) ? h->cfg.policy_act : h->cfg.value_act; }
 
@@ -1488,8 +1490,11 @@ int launch_chain_fwd(dsact_handle* h, const char* name, FwdArgs& a) {
     const size_t lds = (size_t)fat_lds(h->cW, 16 * rt, 0).total * sizeof(float);
     if (a.u[0].part_heads) h->n_heads_parts = a.u[0].n_slices;
 #define CALL_FF(N, T) return launch(h, name, k_fat_fwd<N, T>, dim3(grid), dim3(64 * N), lds, a)
+#define CALL_FFG(N, T) return launch(h, name, k_fat_fwd<N, T, true>, dim3(grid), dim3(64 * N), lds, a)
+    if (generic_act(h)) FAT_NT(CALL_FFG, rt);
     FAT_NT(CALL_FF, rt);
 #undef CALL_FF
+#undef CALL_FFG
   }
   const int rg = chain_rg(h, a.n_units);
   fill_fwd_common(h, a, rg, name);
@@ -1497,8 +1502,11 @@ int launch_chain_fwd(dsact_handle* h, const char* name, FwdArgs& a) {
   const size_t lds = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 4 * rg).total * sizeof(float);
   if (a.u[0].part_heads) h->n_heads_parts = a.u[0].n_slices;
 #define CALL_CF(N, G) return launch(h, name, k_chain_fwd<N, G>, dim3(grid), dim3(64 * N), lds, a)
+#define CALL_CFG(N, G) return launch(h, name, k_chain_fwd<N, G, true>, dim3(grid), dim3(64 * N), lds, a)
+  if (generic_act(h)) CHAIN_NT(CALL_CFG, rg);
   CHAIN_NT(CALL_CF, rg);
 #undef CALL_CF
+#undef CALL_CFG
 }
 
 int enqueue_chain_fwd_a(dsact_handle* h) {
@@ -1553,6 +1561,11 @@ int enqueue_chain_fwd_merged(dsact_handle* h) {
   if (h->flags_dirty) HIPCHK(h, hipMemsetAsync(h->chain_flags, 0, kChainFlags * sizeof(int), h->stream));
   h->flags_dirty = true;
   const size_t lds = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 4 * (rga > rgb ? rga : rgb)).total * sizeof(float);
+  if (generic_act(h)) {
+    if (h->cNT == 1) return launch(h, "chain_fwd", k_chain_fwd2<1, true>, dim3(grid), dim3(64), lds, m);
+    if (h->cNT == 2) return launch(h, "chain_fwd", k_chain_fwd2<2, true>, dim3(grid), dim3(128), lds, m);
+    return launch(h, "chain_fwd", k_chain_fwd2<4, true>, dim3(grid), dim3(256), lds, m);
+  }
   if (h->cNT == 1) return launch(h, "chain_fwd", k_chain_fwd2<1>, dim3(grid), dim3(64), lds, m);
   if (h->cNT == 2) return launch(h, "chain_fwd", k_chain_fwd2<2>, dim3(grid), dim3(128), lds, m);
   return launch(h, "chain_fwd", k_chain_fwd2<4>, dim3(grid), dim3(256), lds, m);
@@ -2185,17 +2198,29 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage<false, true, EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_conv_dw<3>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<1, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<1, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<2, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd<4, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));

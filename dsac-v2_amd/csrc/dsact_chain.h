@@ -4,12 +4,13 @@
 // row, so ONE workgroup can take a slice of the minibatch through a whole network chain: first layer -> hidden
 // layers -> output layer -> tanh-Gaussian rsample / softplus epilogue (forward), or loss -> output-layer backward ->
 // hidden layers -> dL/d(action) (backward), with the activations in LDS and no inter-workgroup synchronisation.
-// One update becomes 5 launches (the tile path: 14):
-//   k_chain_fwd  A   policy(obs), policy_target(obs2), q1/q2(obs,act), + the obs2 part of q1_t/q2_t's first layer
-//   k_chain_fwd  B   q1_t/q2_t(obs2,act2), q1/q2(obs,new_act): first layer = saved obs part + K=A action part
-//   k_chain_bwd_q    DSAC-T loss (dsac_v2.py:218-318) + dZ chains of q1c,q2c,q1p,q2p + dL/d new_act
+// One update becomes 4 launches (the tile path: 14):
+//   k_chain_fwd2     group A: policy(obs), policy_target(obs2), q1/q2(obs,act), + the obs2 part of q1_t/q2_t's first layer;
+//                    group B (same launch, per-slice ready flags): q1_t/q2_t(obs2,act2), q1/q2(obs,new_act): first layer =
+//                    saved obs part + K=A action part            (batch > 256: two launches, k_chain_fwd A then B)
+//   k_chain_bwd_q    DSAC-T loss (dsac_v2.py:218-318) + dZ chains of q1c,q2c,q1p,q2p + dL/d new_act (+ the next update's gather)
 //   k_chain_bwd_pi   rsample backward + policy dZ chain   (+ the critics' dW/Adam tiles on the idle CUs)
-//   k_stage_table    policy dW/Adam tiles + close of the update
+//   k_dw2            policy dW/Adam(/Polyak) tiles + close of the update
 // Reference math: networks/mlp.py:79-127, utils/act_distribution_cls.py:44-54, dsac_v2.py:150-318.
 //
 // Shape of a chain workgroup (measurements: scripts/ubench/{slice_gemm,slice_gemm44,cu_stream,mfma_operands}.hip,
@@ -595,7 +596,9 @@ inline int fwd_grid(const FwdArgs& a) {
   return 8 * rounds;
 }
 
-template <int NW, int RG>
+// GA ("generic activation"): false compiles the GELU-only epilogue every shipped example uses -- the other activations'
+// expm1f / tanhf / expf bodies cost the hot kernel registers and ~1 us per launch even when not taken
+template <int NW, int RG, bool GA = false>
 __device__ __forceinline__ void chain_fwd_body(const FwdArgs& a, int unit, int slice, float* lds) {
   const FwdUnit& u = a.u[unit];
   constexpr int W = 64 * NW, SH = W / 4, R = 4 * RG, NTHR = 64 * NW, TPR = NTHR / R;
@@ -744,7 +747,7 @@ __device__ __forceinline__ void chain_fwd_body(const FwdArgs& a, int unit, int s
     for (int g = 0; g < RG; ++g) {
       const f32x4 z = acc[g][0] + acc[g][1] + bl;
       f32x4 hv, gd;
-      act4(u.act, z, hv, gd);
+      if (GA) act4(u.act, z, hv, gd); else gelu4(z, hv, gd);
 #pragma unroll
       for (int r = 0; r < 4; ++r) lds[hn + (4 * g + r) * S.ld_h + n] = hv[r];
       if (u.H[l]) nt_store4(u.H[l] + pk_index(n, row0 + 4 * g, a.Cb), hv);   // rows row0+4g .. +3 of feature n: 16 contiguous bytes
@@ -820,12 +823,12 @@ __device__ __forceinline__ void chain_fwd_body(const FwdArgs& a, int unit, int s
   chain_publish(done_flag);
 }
 
-template <int NW, int RG>
+template <int NW, int RG, bool GA = false>
 __global__ void __launch_bounds__(64 * NW, RG >= 4 ? 1 : 2) k_chain_fwd(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int unit, slice;
   if (!fwd_decode(a, (int)blockIdx.x, unit, slice)) return;
-  chain_fwd_body<NW, RG>(a, unit, slice, lds);
+  chain_fwd_body<NW, RG, GA>(a, unit, slice, lds);
 }
 
 // Launches A and B in one: blocks [0, n_a) run group A with RGA row groups, blocks [n_a, ..) group B with RGB. Every
@@ -836,15 +839,15 @@ __global__ void __launch_bounds__(64 * NW, RG >= 4 ? 1 : 2) k_chain_fwd(FwdArgs 
 struct Fwd2Args { FwdArgs A, B; int n_a; };
 static_assert(sizeof(Fwd2Args) <= 4096, "kernel arguments are limited to 4 KB");
 // every unit runs 4-row (rg 1) or 8-row (rg 2) workgroups; the choice is per unit (FwdUnit::rg)
-template <int NW>
+template <int NW, bool GA = false>
 __global__ void __launch_bounds__(64 * NW, 2) k_chain_fwd2(Fwd2Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const bool in_a = (int)blockIdx.x < a.n_a;
   const FwdArgs& f = in_a ? a.A : a.B;
   int unit, slice;
   if (!fwd_decode(f, in_a ? (int)blockIdx.x : (int)blockIdx.x - a.n_a, unit, slice)) return;
-  if (f.u[unit].rg == 1) chain_fwd_body<NW, 1>(f, unit, slice, lds);
-  else chain_fwd_body<NW, 2>(f, unit, slice, lds);
+  if (f.u[unit].rg == 1) chain_fwd_body<NW, 1, GA>(f, unit, slice, lds);
+  else chain_fwd_body<NW, 2, GA>(f, unit, slice, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

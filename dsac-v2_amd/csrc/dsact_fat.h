@@ -185,7 +185,7 @@ __device__ __forceinline__ float fat_row_sum(float v) {
 // ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
-template <int NW, int RT>
+template <int NW, int RT, bool GA = false>
 __device__ __forceinline__ void fat_fwd_body(const FwdArgs& a, int unit, int slice, float* lds) {
   const FwdUnit& u = a.u[unit];
   constexpr int W = 64 * NW, R = 16 * RT, NTHR = 64 * NW, TPR = NTHR / R, CW = W / 16;
@@ -275,7 +275,7 @@ __device__ __forceinline__ void fat_fwd_body(const FwdArgs& a, int unit, int sli
       for (int nt = 0; nt < 4; ++nt) {
         const f32x4 z = acc[rt][nt] + bl[nt];
         f32x4 hv, gd;
-        act4(u.act, z, hv, gd);
+        if (GA) act4(u.act, z, hv, gd); else gelu4(z, hv, gd);
         if (u.H[l]) nt_store4(u.H[l] + pk_index(nf[nt], row0 + 16 * rt + 4 * g, a.Cb), hv);
         if (u.G[l]) nt_store4(u.G[l] + pk_index(nf[nt], row0 + 16 * rt + 4 * g, a.Cb), gd);
         acc[rt][nt] = hv;
@@ -357,13 +357,13 @@ __device__ __forceinline__ void fat_fwd_body(const FwdArgs& a, int unit, int sli
 
 // blocks are unit-major (block = unit * n_slices + slice): the chip works on one or two units at a time, whose weights
 // (<= 1 MB each) stay hot in every XCD's L2 while their slices stream through
-template <int NW, int RT>
+template <int NW, int RT, bool GA = false>
 __global__ void __launch_bounds__(64 * NW, 2) k_fat_fwd(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int ns = a.u[0].n_slices;
   const int unit = (int)blockIdx.x / ns, slice = (int)blockIdx.x - unit * ns;
   if (unit >= a.n_units) return;
-  fat_fwd_body<NW, RT>(a, unit, slice, lds);
+  fat_fwd_body<NW, RT, GA>(a, unit, slice, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
