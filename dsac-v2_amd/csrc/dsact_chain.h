@@ -240,6 +240,7 @@ struct Dw2Args {
 };
 constexpr int kDw2LdsFloats = 4 * 4 * 64 * 4 + 4 * 2 * 64;
 
+template <int NSET = 2>
 __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -254,12 +255,14 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds) {
   const int mt = local / P.tiles_n, nt = local - mt * P.tiles_n;
   const int m0 = 32 * mt, n0 = 32 * nt;
   // ---- the contraction runs in rounds of <= 16 chunks (256 batch rows); in a round the 4 waves split the chunks (wave w:
-  //      chunks cb + w*cw + q, q < cw <= 4). The fragments travel in two register sets of two chunks each (half rounds):
-  //      both are loaded up front -- batch <= 256 is exactly that, one round -- and a set is refilled with the half round
-  //      two ahead as soon as its MFMAs are issued, so longer contractions (batch 512 .. 1024 per range) stream.
+  //      chunks cb + w*cw + q, q < cw <= 4). The fragments travel in NSET register sets of two chunks each (half rounds):
+  //      all are loaded up front -- batch <= 256 is exactly two of them, one round -- and a set is refilled with the half
+  //      round NSET ahead as soon as its MFMAs are issued, so longer contractions (batch 512 .. 1024 per range) stream.
+  //      NSET = 2 keeps a load 32 MFMAs (~0.4 us) ahead of its use, NSET = 4 (k_dw2 at batch >= 512: 128 fragment
+  //      registers) 96 MFMAs (~1.3 us) -- past the L2 / MALL latency under load. Same accumulation order either way.
   const int c_lo = range * a.ct;
   const int n_half = 2 * ((a.ct + 15) >> 4);
-  f32x4 fa[2][2][2], fx[2][2][2];
+  f32x4 fa[NSET][2][2], fx[NSET][2][2];
   auto half_ok = [&](int hr, int q2, int& c) {
     const int cb = (hr >> 1) << 4;
     const int ctr = a.ct - cb < 16 ? a.ct - cb : 16, cw = (ctr + 3) >> 2;
@@ -280,8 +283,9 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds) {
       }
     }
   };
-  load_half(0, 0);
-  load_half(1, 1);
+#pragma unroll
+  for (int st = 0; st < NSET; ++st)
+    if (st < n_half) load_half(st, st);
   // ---- this lane's share of the epilogue: 16x16 block (wave>>1, wave&1), rows m, columns n .. n+3
   const int m = m0 + 16 * (wave >> 1) + i, n = n0 + 16 * (wave & 1) + 4 * g;
   const bool in_range = m < P.M && n < P.N, full = n + 3 < P.N;
@@ -326,11 +330,13 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds) {
       }
     }
   };
-  for (int hr = 0; hr < n_half; hr += 2) {
-    mma_half(0, hr);
-    if (hr + 2 < n_half) load_half(0, hr + 2);
-    mma_half(1, hr + 1);
-    if (hr + 3 < n_half) load_half(1, hr + 3);
+  for (int hr = 0; hr < n_half; hr += NSET) {
+#pragma unroll
+    for (int st = 0; st < NSET; ++st)
+      if (hr + st < n_half) {
+        mma_half(st, hr + st);
+        if (hr + st + NSET < n_half) load_half(st, hr + st + NSET);
+      }
   }
   // ---- partial blocks -> LDS -> block `wave`
   const bool bias = nt == 0 && P.b_idx >= 0;
@@ -413,6 +419,7 @@ __device__ __forceinline__ bool xcd_chunk(int b, int n, int& t) {
 // grid (xcd_chunk_grid(n_tiles) [+ 1], batch ranges): base tiles tile0 .. tile0 + n_tiles - 1 of every range; the
 // extra block closes the update
 struct Dw2Launch { Dw2Args a; int tile0, n_tiles, finalize; };
+template <int NSET>
 __global__ void __launch_bounds__(kThreads) k_dw2(Dw2Launch L) {
   __shared__ __attribute__((aligned(16))) float lds[kDw2LdsFloats];
   if ((int)blockIdx.x >= xcd_chunk_grid(L.n_tiles)) {
@@ -421,7 +428,7 @@ __global__ void __launch_bounds__(kThreads) k_dw2(Dw2Launch L) {
   }
   int t;
   if (!xcd_chunk((int)blockIdx.x, L.n_tiles, t)) return;
-  dw2_tile(L.a, (int)blockIdx.y * L.a.n_base + L.tile0 + t, lds);
+  dw2_tile<NSET>(L.a, (int)blockIdx.y * L.a.n_base + L.tile0 + t, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

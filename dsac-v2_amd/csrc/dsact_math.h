@@ -109,6 +109,10 @@ struct TanhGaussFwd {
 };
 DSACT_HD TanhGaussFwd tanh_gauss_fwd(float mu, float raw, float eps, float s, float c, float lo_ls,
                                      float hi_ls) {
+  // Every product below is rounded on its own, as the reference's separate tensor ops are: the tanh correction
+  // log(1 + 1e-6 - t^2) of a saturated action divides by ~1e-6 .. 1e-3, and a t*t left unrounded inside a fused
+  // multiply-add moves it (and the gradient through it) by up to 1e-4 relative.
+#pragma clang fp contract(off)
   TanhGaussFwd o;
   o.sigma = expf(clampf(raw, lo_ls, hi_ls));
   const float x = mu + eps * o.sigma;  // Normal.rsample: loc + eps*scale
@@ -118,7 +122,8 @@ DSACT_HD TanhGaussFwd tanh_gauss_fwd(float mu, float raw, float eps, float s, fl
   const float var = o.sigma * o.sigma;
   // Normal.log_prob: -((v-loc)^2)/(2 var) - log(scale) - log(sqrt(2 pi))
   float lp = -(d * d) / (2.0f * var) - logf(o.sigma) - kLogSqrt2Pi;
-  lp -= logf(1.0f + kTanhEps - o.t * o.t);
+  const float t2 = o.t * o.t;          // torch.pow(tanh(action), 2)
+  lp -= logf((1.0f + kTanhEps) - t2);
   lp -= logf(s);
   o.lp = lp;
   return o;
@@ -127,11 +132,13 @@ DSACT_HD TanhGaussFwd tanh_gauss_fwd(float mu, float raw, float eps, float s, fl
 // backward of the above: given dL/da (gA) and dL/dlogp (gLp) returns dL/dmu, dL/draw.
 DSACT_HD void tanh_gauss_bwd(float mu, float raw, float eps, float s, float lo_ls, float hi_ls, float gA,
                              float gLp, float& dmu, float& draw) {
+#pragma clang fp contract(off)
   const float sigma = expf(clampf(raw, lo_ls, hi_ls));
   const float x = mu + eps * sigma;
   const float t = tanhf(x);
-  const float omt2 = 1.0f - t * t;
-  const float g = 2.0f * t * omt2 / (1.0f + kTanhEps - t * t);  // d logp / d x (tanh correction)
+  const float omt2 = fmaf(-t, t, 1.0f);   // tanh backward: 1 - y*y in one rounding (ATen's vectorised kernel fuses it)
+  const float t2 = t * t;                 // pow(t, 2): rounded, then subtracted from the rounded 1 + 1e-6
+  const float g = 2.0f * t * omt2 / ((1.0f + kTanhEps) - t2);  // d logp / d x (tanh correction)
   const float dadx = s * omt2;
   dmu = gA * dadx + gLp * g;
   const float dsigma = gA * dadx * eps + gLp * (-1.0f / sigma + eps * g);

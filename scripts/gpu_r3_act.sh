@@ -15,7 +15,7 @@ import bench, torch
 alg = bench.make_alg([256, 256, 256], 0)
 e = alg.engine
 obs = np.random.default_rng(0).standard_normal((1, 376)).astype(np.float32)
-for label, env in (("one workgroup, observation in the kernel arguments, logits through mapped host memory", None),):
+for label, env in (("one launch, (value, call) pair hand-over, observation in the kernel arguments, logits through mapped host memory", None),):
     for _ in range(100): e.policy_forward(obs)
     t0 = time.perf_counter()
     for _ in range(2000): e.policy_forward(obs)

@@ -31,7 +31,7 @@ def main():
         cur.append(r)
         nxt = rows[i + 1][2] if i + 1 < len(rows) else ""
         closes = "k_stage_table(" in r[2] or "k_adam(" in r[2] or \
-            ("k_dw2(" in r[2] and "k_adam(" not in nxt and "k_sum_parts(" not in nxt and "k_dw2(" not in nxt
+            ("k_dw2<" in r[2] and "k_adam(" not in nxt and "k_sum_parts(" not in nxt and "k_dw2(" not in nxt
              and "AllReduce" not in nxt)
         if closes:
             updates.append(cur)
@@ -69,7 +69,7 @@ def bursts(rows, idle_us=300.0):
     for b in out[-12:]:
         span = (b[-1][1] - b[0][0]) / 1000.0
         busy = sum(e - s for s, e, *_ in b) / 1000.0
-        closers = sum(1 for r in b if "k_dw2(" in r[2] or "k_stage_table(" in r[2])
+        closers = sum(1 for r in b if "k_dw2<" in r[2] or "k_stage_table(" in r[2])
         first = ", ".join("%s %.1f" % (r[2].split("::")[-1].split("(")[0][:14], (r[1] - r[0]) / 1000.0) for r in b[:7])
         print("  %4d launches (%3d closing)  span %9.1f us  busy %9.1f us  idle %7.1f us | first: %s"
               % (len(b), closers, span, busy, span - busy, first))
