@@ -258,8 +258,8 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds) {
   //      chunks cb + w*cw + q, q < cw <= 4). The fragments travel in NSET register sets of two chunks each (half rounds):
   //      all are loaded up front -- batch <= 256 is exactly two of them, one round -- and a set is refilled with the half
   //      round NSET ahead as soon as its MFMAs are issued, so longer contractions (batch 512 .. 1024 per range) stream.
-  //      NSET = 2 keeps a load 32 MFMAs (~0.4 us) ahead of its use, NSET = 4 (k_dw2 at batch >= 512: 128 fragment
-  //      registers) 96 MFMAs (~1.3 us) -- past the L2 / MALL latency under load. Same accumulation order either way.
+  //      NSET = 2 keeps a load 32 MFMAs (~0.4 us) ahead of its use; NSET = 4 (128 fragment registers, 96 MFMAs ahead)
+  //      bought nothing at batch 512 / 1024 -- a wave's 16 chunks x 16 MFMAs are the time. Same accumulation order.
   const int c_lo = range * a.ct;
   const int n_half = 2 * ((a.ct + 15) >> 4);
   f32x4 fa[NSET][2][2], fx[NSET][2][2];
