@@ -71,6 +71,8 @@ struct ProfRec {
 
 constexpr int kChainFlagSlices = 64;                 // slices per unit of a merged forward launch (batch <= 256, >= 4 rows each)
 constexpr int kChainFlags = 8 * kChainFlagSlices;   // done[6 units] + zdone[q1c, q2c]
+constexpr int kChainCounters = 8 * kArriveStride;   // behind the flags (+128 ints of padding): arrival counter replicas of the merged policy backward
+constexpr int kChainFlagInts = kChainFlags + 128 + kChainCounters;
 
 struct dsact_handle {
   dsact_config cfg;
@@ -237,6 +239,7 @@ struct dsact_handle {
   int env_chain_rg_pi = 0;              // DSACT_CHAIN_RG_PI (experiments)
   bool env_no_mixed_rg = false;         // DSACT_NO_MIXED_RG: every unit of the merged forward's group A runs 8-row workgroups (A/B)
   bool fwd_merge = false;               // launches A and B as one (batch <= 256)
+  bool pi_merge = false;                // the policy's weight-gradient tiles + the closing block inside the policy-backward launch (batch <= 256)
   float* zobs[4];                       // first-layer accumulators after the observation part: q1, q2 (obs), q1_t, q2_t (obs2)
   float* dAq[2];                        // dL/d new_act through q1 / q2  [B][32]
   float* doutT[3];                      // transposed packs of dL/d(out): q1, q2 [32 x B], policy [roundup32(2A) x B]
@@ -470,7 +473,7 @@ void carve(dsact_handle* h, Carver& c) {
   h->timeline = c.take<long long>(512 * 16);
   h->dw_parts = c.take<float>(h->dw_chunks > 1 ? (size_t)h->dw_chunks * h->dw_part_stride : 4);
   for (int i = 0; i < 4; ++i) h->zobs[i] = c.take<float>(B * h->w[0]);
-  h->chain_flags = c.take<int>(kChainFlags + 128);   // [unit 0..5][slice] ready flags of the merged forward launch, then the spin-timeout word
+  h->chain_flags = c.take<int>(kChainFlagInts);   // [unit 0..5][slice] ready flags of the merged forward launch, then the spin-timeout word
   for (int i = 0; i < 2; ++i) h->dAq[i] = c.take<float>(B * 32);
   for (int i = 0; i < 2; ++i) h->doutT[i] = c.take<float>(B * 32);
   h->doutT[2] = c.take<float>(B * (size_t)((2 * A + 31) / 32 * 32));
@@ -1099,6 +1102,7 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
       else if (nkt == 3) TRY(launch(h, ("conv_dw" + sfx).c_str(), k_conv_dw<3>, dim3(blocks), dim3(kThreads), lds, a));
       else return fail(h, DSACT_E_INVALID, "DSACT_CONV_DW_NKT must be 1..3");
     }
+    // (the 16-channel layer through dCol + col2im instead: 49.5 + 23.8 us vs 42 us direct, measured round 3)
     const bool direct_dx = j > 0 && (g.Cin == 8 || g.Cin == 16) && g.Cout <= 32;
     if (direct_dx) {
       // narrow layers: no column buffer (see k_conv_dx_direct)
@@ -1433,7 +1437,7 @@ void fill_fwd_common(dsact_handle* h, FwdArgs& a, int rg, const char* name, cons
   a.act_scale = h->act_scale; a.act_center = h->act_center; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
   a.timeline = tl_for(h, name);
   a.spin_timeout = h->handoff_dev;
-  a.debug_withhold = h->debug_withhold;
+  a.debug_withhold = h->debug_withhold == 1;
 }
 
 // group A: policy(obs), policy_target(obs2), q1/q2(obs,act) + observation part of q1_t/q2_t(obs2, .)
@@ -1605,6 +1609,7 @@ void bwd_q_args(dsact_handle* h, int n_units, const RideArgs* ride, BwdQArgs& a,
   a.n_chain_blocks = h->fat_bwd ? n_units * a.n_slices : chain_grid(n_units, a.n_slices);
   a.timeline = tl_for(h, "chain_bwd_q");
   if (h->fwd_merge) { a.flags_reset = h->chain_flags; a.n_flags = kChainFlags; h->flags_dirty = false; }
+  if (h->pi_merge) { a.flags_reset = h->chain_flags; a.n_flags = kChainFlagInts; h->flags_dirty = false; }   // + the arrival counters
   if (ride) a.ride = *ride;
   a.ride.n_loss_blocks = a.n_chain_blocks;
   n_riders_out = ride ? ride->n_gather + (ride->bookkeeping ? 1 : 0) : 0;
@@ -1629,7 +1634,8 @@ int enqueue_chain_bwd_q(dsact_handle* h, int n_units, const RideArgs* ride) {
 }
 
 // rsample backward + policy dZ chain; weight-gradient tiles [x0, x1) ride along on the other CUs
-void bwd_pi_args(dsact_handle* h, int x0, int x1, bool fused, BwdPiArgs& a, int& rg_out) {
+// merge: the policy's tiles [x1, dw2_off[3]) and (fused) the closing block ride behind the riders [x0, x1)
+void bwd_pi_args(dsact_handle* h, int x0, int x1, bool fused, BwdPiArgs& a, int& rg_out, bool merge = false) {
   memset(&a, 0, sizeof(a));
   const int L = h->L;
   a.dA[0] = h->dAq[0]; a.dA[1] = h->dAq[1];
@@ -1651,13 +1657,19 @@ void bwd_pi_args(dsact_handle* h, int x0, int x1, bool fused, BwdPiArgs& a, int&
   a.timeline = tl_for(h, "chain_bwd_pi");
   a.dw = dw2_args(h, fused);
   a.tile0 = x0; a.n_extra = x1 > x0 ? x1 - x0 : 0;
+  if (merge) {
+    a.merge_dw = 1; a.pi_tile0 = x1; a.n_pi_tiles = h->dw2_off[3] - x1; a.finalize = fused ? 1 : 0;
+    a.cnt_pi = h->chain_flags + kChainFlags + 128;
+    a.spin_timeout = (int*)h->handoff_dev;
+    a.debug_withhold = h->debug_withhold == 2;
+  }
   rg_out = rg;
 }
 
-int enqueue_chain_bwd_pi(dsact_handle* h, int x0, int x1, bool fused) {
+int enqueue_chain_bwd_pi(dsact_handle* h, int x0, int x1, bool fused, bool merge = false) {
   BwdPiArgs a;
   int rg;
-  bwd_pi_args(h, x0, x1, fused, a, rg);
+  bwd_pi_args(h, x0, x1, fused, a, rg, merge);
   if (h->fat_bwd) {
     const int rt = rg / 4;
     size_t flds = (size_t)fat_lds(h->cW, 16 * rt, 16 * h->c_out).total * sizeof(float);
@@ -1668,7 +1680,8 @@ int enqueue_chain_bwd_pi(dsact_handle* h, int x0, int x1, bool fused) {
   }
   size_t lds = (size_t)chain_lds(4 * h->SoT, h->cW, 4 * rg).total * sizeof(float);
   if (lds < kDw2LdsFloats * sizeof(float)) lds = kDw2LdsFloats * sizeof(float);
-#define CALL_CP(N, G) return launch(h, "chain_bwd_pi", k_chain_bwd_pi<N, G>, dim3(a.n_chain_blocks + xcd_chunk_grid(a.n_extra) * h->dw_chunks), dim3(kThreads), lds, a)
+  const int tail = merge ? xcd_chunk_grid(a.n_extra) + xcd_chunk_grid(a.n_pi_tiles) + 1 : xcd_chunk_grid(a.n_extra) * h->dw_chunks;
+#define CALL_CP(N, G) return launch(h, "chain_bwd_pi", k_chain_bwd_pi<N, G>, dim3(a.n_chain_blocks + tail), dim3(kThreads), lds, a)
   CHAIN_NT(CALL_CP, rg);
 #undef CALL_CP
 }
@@ -1712,6 +1725,9 @@ actor_part:
   {
     int ride_end = h->dw2_off[2];
     if (h->env_ride_slots > 0 && ride_end - h->dw2_off[0] > h->env_ride_slots) ride_end = h->dw2_off[0] + h->env_ride_slots;
+    // batch <= 256: the policy's own tiles and the closing block ride in the same launch behind the riders and wait for
+    // the chain's arrival counter (k_chain_bwd_pi, merge_dw) -- one launch and one kernel boundary less per update
+    if (h->pi_merge && h->dw_chunks == 1 && ride_end == h->dw2_off[2]) return enqueue_chain_bwd_pi(h, h->dw2_off[0], ride_end, fused, true);
     TRY(enqueue_chain_bwd_pi(h, h->dw2_off[0], ride_end, fused));
     if (h->dw_chunks == 1) return run_dw2(h, ride_end, h->dw2_off[3], fused, fused);
     TRY(run_dw2(h, ride_end, h->dw2_off[3], false, false));
@@ -1990,9 +2006,10 @@ int check_handoff(dsact_handle* h) {
   const int steps = h->graph_steps;
   const uint32_t gflags = h->graph_flags;
   h->fwd_merge = false;
+  h->pi_merge = false;
   h->handoff_failures += 1;
   drop_graphs(h);
-  if (h->chain_flags) hipMemset(h->chain_flags, 0, (kChainFlags + 128) * sizeof(int));
+  if (h->chain_flags) hipMemset(h->chain_flags, 0, kChainFlagInts * sizeof(int));
   h->flags_dirty = false;
   int rebuilt = DSACT_E_STATE;
   if (had_graph) rebuilt = dsact_graph_build(h, steps, gflags);
@@ -2146,6 +2163,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
       if (const char* v = getenv("DSACT_FAT_RT")) h->env_fat_rt = atoi(v) == 2 ? 2 : 1;
     }
     h->fwd_merge = ok && h->B <= 256 && h->B / 4 <= kChainFlagSlices && chain_rg(h, 4) == 1 && getenv("DSACT_NO_FWD_MERGE") == nullptr;
+    h->pi_merge = ok && h->B <= 256 && !h->fat_bwd && getenv("DSACT_NO_PI_MERGE") == nullptr;
   }
   Carver c0;
   carve(h, c0);
@@ -3217,7 +3235,7 @@ int dsact_debug_set(dsact_handle* h, const char* name, double value) {
   if (!strcmp(name, "withhold_flag")) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     drop_graphs(h);   // the switch travels in the kernel arguments
-    h->debug_withhold = value != 0.0 ? 1 : 0;
+    h->debug_withhold = (int)value;   // 1: a forward producer's ready flag; 2: a policy-backward slice's arrival
     return DSACT_OK;
   }
   if (!strcmp(name, "poison_handover")) {
@@ -3229,6 +3247,8 @@ int dsact_debug_set(dsact_handle* h, const char* name, double value) {
     float* rows[4] = {h->XP, h->X2, h->alt.XP, h->alt.X2};
     for (float* r : rows) TRY(debug_fill(h, r, h->B, h->ldx, h->F, h->A, v));
     for (int i = 0; i < 2; ++i) TRY(debug_fill(h, h->dAq[i], 1, 0, 0, h->B * 32, v));
+    // merged policy backward: the policy's dZ packs its weight-gradient tiles wait for
+    if (h->chain_ok) for (int l = 0; l < h->L; ++l) TRY(debug_fill(h, h->dZ[kDzSlot[C_PI]][l], 1, 0, 0, h->B * h->w[l], v));
     return DSACT_OK;
   }
   if (!strcmp(name, "fwd_merge")) {   // A/B switch of the merged forward launch on a live handle (tests)
@@ -3237,12 +3257,21 @@ int dsact_debug_set(dsact_handle* h, const char* name, double value) {
     h->fwd_merge = value != 0.0 && h->chain_ok && h->B <= 256 && h->B / 4 <= kChainFlagSlices && chain_rg(h, 4) == 1;
     return DSACT_OK;
   }
+  if (!strcmp(name, "pi_merge")) {    // same for the merged policy-backward / policy weight-gradient launch
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    drop_graphs(h);
+    h->pi_merge = value != 0.0 && h->chain_ok && h->B <= 256 && !h->fat_bwd;
+    if (h->chain_flags) HIPCHK(h, hipMemset(h->chain_flags, 0, kChainFlagInts * sizeof(int)));
+    h->flags_dirty = false;
+    return DSACT_OK;
+  }
   return fail(h, DSACT_E_INVALID, "dsact_debug_set: unknown name '%s'", name);
 }
 
 int dsact_debug_get(const dsact_handle* h, const char* name, double* value) {
   if (!h || !name || !value) return DSACT_E_INVALID;
   if (!strcmp(name, "fwd_merge")) *value = h->fwd_merge ? 1.0 : 0.0;
+  else if (!strcmp(name, "pi_merge")) *value = h->pi_merge ? 1.0 : 0.0;
   else if (!strcmp(name, "act_launch_us")) *value = h->act_launch_us;
   else if (!strcmp(name, "act_wait_us")) *value = h->act_wait_us;
   else if (!strcmp(name, "fat")) *value = (h->fat ? 1.0 : 0.0) + (h->fat_bwd ? 2.0 : 0.0);

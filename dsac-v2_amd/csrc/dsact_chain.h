@@ -240,8 +240,12 @@ struct Dw2Args {
 };
 constexpr int kDw2LdsFloats = 4 * 4 * 64 * 4 + 4 * 2 * 64;
 
-template <int NSET = 2>
-__device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds) {
+// `wait`: called between the loads of everything the tile needs from EARLIER launches (the X-side fragments, the Adam /
+// Polyak operands) and the first load of the dZ-side fragments -- the policy's tiles of the merged policy-backward
+// launch wait there for the policy chain's arrival counter with their other operands already in flight.
+struct NoWait { __device__ __forceinline__ void operator()() const {} };
+template <int NSET = 2, typename Wait = NoWait>
+__device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds, Wait wait = Wait()) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4, lane4 = lane * 4;
@@ -271,21 +275,28 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds) {
     c = c_lo + cb + (ok ? wave * cw + q : 0);
     return ok;
   };
-  auto load_half = [&](int set, int hr) {
+  auto load_half_x = [&](int set, int hr) {
 #pragma unroll
     for (int q2 = 0; q2 < 2; ++q2) {
       int c;
       (void)half_ok(hr, q2, c);
 #pragma unroll
-      for (int b2 = 0; b2 < 2; ++b2) {
-        fa[set][q2][b2] = gload4(P.At + ((size_t)(2 * mt + b2) * a.C + c) * 256 + lane4);
-        fx[set][q2][b2] = gload4(P.Xt + ((size_t)(2 * nt + b2) * a.C + c) * 256 + lane4);
-      }
+      for (int b2 = 0; b2 < 2; ++b2) fx[set][q2][b2] = gload4(P.Xt + ((size_t)(2 * nt + b2) * a.C + c) * 256 + lane4);
     }
   };
+  auto load_half_a = [&](int set, int hr) {
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2) {
+      int c;
+      (void)half_ok(hr, q2, c);
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) fa[set][q2][b2] = gload4(P.At + ((size_t)(2 * mt + b2) * a.C + c) * 256 + lane4);
+    }
+  };
+  auto load_half = [&](int set, int hr) { load_half_a(set, hr); load_half_x(set, hr); };
 #pragma unroll
   for (int st = 0; st < NSET; ++st)
-    if (st < n_half) load_half(st, st);
+    if (st < n_half) load_half_x(st, st);
   // ---- this lane's share of the epilogue: 16x16 block (wave>>1, wave&1), rows m, columns n .. n+3
   const int m = m0 + 16 * (wave >> 1) + i, n = n0 + 16 * (wave & 1) + 4 * g;
   const bool in_range = m < P.M && n < P.N, full = n + 3 < P.N;
@@ -305,6 +316,10 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds) {
       if (o_delayed) ot = *(const f32x4u*)(a.fo.target + oi);
     }
   }
+  wait();
+#pragma unroll
+  for (int st = 0; st < NSET; ++st)
+    if (st < n_half) load_half_a(st, st);
   // ---- MFMA: D[row = input feature 4g+reg][col = output feature i]
   f32x4 acc[2][2];
 #pragma unroll
@@ -583,6 +598,39 @@ __device__ __forceinline__ void chain_wait(const int* f0, const int* f1, int* ti
   }
   __syncthreads();        // the consumer's loads of the handed-over data are ld_agent: no cache invalidate needed
 }
+
+// ---- merged policy-backward + policy weight-gradient launch (k_chain_bwd_pi with merge_dw): the policy chain's slices
+// hand their dZ packs to the policy's dW/Adam tiles of the SAME launch. Producers store the packs write-through (sc1: the
+// consumers run on other XCDs, whose L2 the data never enters before they ask for it), wait for the acknowledgements and
+// bump an arrival counter; the counter has one replica per XCD (64 ints apart) so that the ~240 waiting tile workgroups
+// do not all poll one word (polling one word from 480 workgroups slowed its producers down measurably in round 2).
+constexpr int kArriveStride = 64;                 // ints between the replicas
+__device__ __forceinline__ void pack_store4(float* p, const f32x4& v, int agent) {
+  if (agent) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");   // ONE 16-byte write-through
+  else nt_store4(p, v);
+}
+__device__ __forceinline__ void hand_store(float* p, float v, int agent) {
+  if (agent) st_agent(p, v); else *p = v;
+}
+__device__ __forceinline__ void chain_arrive(int* cnt) {
+  if (!cnt) return;        // workgroup-uniform
+  stores_acked_barrier();
+  if (threadIdx.x < 8) __hip_atomic_fetch_add(cnt + threadIdx.x * kArriveStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+struct ArriveWait {
+  const int* cnt; int need; int* timeout;
+  __device__ __forceinline__ void operator()() const {
+    if (threadIdx.x == 0) {
+      const int* c = cnt + ((int)blockIdx.x & 7) * kArriveStride;
+      int spins = 0;
+      while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        if (++spins > (1 << 17)) { if (timeout) *timeout = 1; break; }   // ~0.1 s, then the hand-off word
+        __builtin_amdgcn_s_sleep(24);
+      }
+    }
+    asm volatile("s_barrier" ::: "memory");   // the waves keep their operand loads in flight (no vmcnt wait here)
+  }
+};
 
 // block -> (unit, slice) of a forward launch; false: padding block
 __device__ __forceinline__ bool fwd_decode(const FwdArgs& a, int b, int& unit, int& slice) {
@@ -1053,9 +1101,24 @@ struct BwdPiArgs {
   const float* part_loss; int n_part; float target_entropy; float* grad_log_alpha;
   int n_chain_blocks;
   int tile0, n_extra;              // riders: weight-gradient tiles [tile0, tile0 + n_extra) of `dw`
+  // merged launch (dw_chunks == 1): the policy's own tiles [pi_tile0, pi_tile0 + n_pi_tiles) follow the riders and wait for
+  // the arrival counter of the chain's slices; one more block closes the update (alpha gradient, finalize_update)
+  int merge_dw, pi_tile0, n_pi_tiles, finalize;
+  int* cnt_pi; int* spin_timeout;
+  int debug_withhold;              // tests only (dsact_debug_set "withhold_flag" 2): slice 0 never arrives
   long long* timeline;
   Dw2Args dw;
 };
+
+__device__ __forceinline__ void bwd_pi_alpha_grad(const BwdPiArgs& a, int lane) {
+  float s = 0.f;
+  for (int r0 = 0; r0 < a.n_part; r0 += 64) {
+    const int rr = r0 + lane;
+    s += rr < a.n_part ? a.part_loss[(size_t)rr * kLossPart + 7] : 0.f;
+  }
+  s = wave_sum(s);
+  if (lane == 0) a.grad_log_alpha[0] = a.auto_alpha ? -(s * a.inv_B + a.target_entropy) : 0.0f;
+}
 
 template <int NW, int RG>
 __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float* lds) {
@@ -1091,15 +1154,8 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
     psc[q] = ok ? a.act_scale[d] : 1.f;
   }
   // alpha gradient (dsac_v2.py:312-318): -mean(logp_new + target_entropy)
-  if (slice == 0 && wave == 0) {
-    float s = 0.f;
-    for (int r0 = 0; r0 < a.n_part; r0 += 64) {
-      const int rr = r0 + lane;
-      s += rr < a.n_part ? a.part_loss[(size_t)rr * kLossPart + 7] : 0.f;
-    }
-    s = wave_sum(s);
-    if (lane == 0) a.grad_log_alpha[0] = a.auto_alpha ? -(s * a.inv_B + a.target_entropy) : 0.0f;
-  }
+  if (slice == 0 && wave == 0 && !a.merge_dw) bwd_pi_alpha_grad(a, lane);   // merged launch: the closing block does it
+  const int agent = a.merge_dw;
   const float alpha = a.auto_alpha ? expf(a.log_alpha[0]) : a.alpha_fixed;
   // zero the operand rows (padding included), then fill (dmu | draw)
   for (int e = tid; e < R * 4 * a.SoT; e += NTHR) xdo[(e / (4 * a.SoT)) * S.ld_in + e % (4 * a.SoT)] = 0.0f;
@@ -1113,8 +1169,8 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
     tanh_gauss_bwd(pmu[q], praw[q], peps[q], psc[q], a.lo_ls, a.hi_ls, dA, alpha * a.inv_B, dmu, draw);
     a.dout_pi[(size_t)r * 2 * A + d] = dmu;
     a.dout_pi[(size_t)r * 2 * A + A + d] = draw;
-    a.dout_piT[pk_index(d, r, a.Cb)] = dmu;
-    a.dout_piT[pk_index(A + d, r, a.Cb)] = draw;
+    hand_store(a.dout_piT + pk_index(d, r, a.Cb), dmu, agent);
+    hand_store(a.dout_piT + pk_index(A + d, r, a.Cb), draw, agent);
     a.d_new_act[(size_t)r * A + d] = dA;
     xdo[m * S.ld_in + d] = dmu;
     xdo[m * S.ld_in + A + d] = draw;
@@ -1137,7 +1193,7 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
       const f32x4 dz = (acc[g][0] + acc[g][1]) * gq[g];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) lds[S.off_h0 + (4 * g + rr) * S.ld_h + n] = dz[rr];
-      nt_store4(a.dZ[L - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz);
+      pack_store4(a.dZ[L - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz, agent);
     }
     lds_barrier();
     CTL(a.timeline, 2);
@@ -1158,28 +1214,50 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
       const f32x4 dz = (acc[g][0] + acc[g][1]) * gq[g];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) lds[hn + (4 * g + rr) * S.ld_h + n] = dz[rr];
-      nt_store4(a.dZ[l - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz);
+      pack_store4(a.dZ[l - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz, agent);
     }
     cur ^= 1;
     if (l > 1) lds_barrier();
     CTL(a.timeline, 3 + (L - 1 - l));
   }
   CTLR(a.timeline, 15);
+  if (a.merge_dw && !(a.debug_withhold && slice == 0)) chain_arrive(a.cnt_pi);
 }
 
-template <int NW, int RG>
-__global__ void __launch_bounds__(256) k_chain_bwd_pi(BwdPiArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  if ((int)blockIdx.x >= a.n_chain_blocks) {
-    const int idx = (int)blockIdx.x - a.n_chain_blocks;
-    const int per_range = xcd_chunk_grid(a.n_extra);   // n_chain_blocks is a multiple of 8: riders start on XCD 0
-    int t;
+// blocks past the chain's: riders (xcd_chunk_grid(n_extra) per batch range), then -- merged launch -- the policy's
+// tiles and the closing block
+__device__ __forceinline__ void bwd_pi_tail_blocks(const BwdPiArgs& a, int idx, float* lds) {
+  const int per_range = xcd_chunk_grid(a.n_extra);   // n_chain_blocks is a multiple of 8: riders start on XCD 0
+  const int n_rider_blocks = a.merge_dw ? per_range : 0x7fffffff;   // (unmerged: every remaining block is a rider, ranges in y)
+  int t;
+  if (idx < n_rider_blocks) {
     if (!xcd_chunk(idx % per_range, a.n_extra, t)) return;
     CTLR(a.timeline, 14);
     dw2_tile(a.dw, (idx / per_range) * a.dw.n_base + a.tile0 + t, lds);
     CTLR(a.timeline, 15);
     return;
   }
+  idx -= n_rider_blocks;
+  if (idx < xcd_chunk_grid(a.n_pi_tiles)) {
+    if (!xcd_chunk(idx, a.n_pi_tiles, t)) return;
+    dw2_tile<2, ArriveWait>(a.dw, a.pi_tile0 + t, lds, ArriveWait{a.cnt_pi, a.n_slices, a.spin_timeout});
+    return;
+  }
+  // closing block: waits for the chain as well -- its slices read log_alpha (alpha = exp(log_alpha)) when they start, and
+  // this block's Adam step on log_alpha must not overtake them (found by the merged == split test at a small shape, where
+  // the block is dispatched within a microsecond of the chain). The alpha gradient reads the loss launch's partial sums (an
+  // earlier launch); the step state finalize_update commits is not what the tiles read.
+  ArriveWait{a.cnt_pi, a.n_slices, a.spin_timeout}();
+  if (threadIdx.x < 64) {
+    bwd_pi_alpha_grad(a, (int)threadIdx.x);
+    if (a.finalize && threadIdx.x == 0) finalize_update(a.dw.fo);
+  }
+}
+
+template <int NW, int RG>
+__global__ void __launch_bounds__(256) k_chain_bwd_pi(BwdPiArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if ((int)blockIdx.x >= a.n_chain_blocks) { bwd_pi_tail_blocks(a, (int)blockIdx.x - a.n_chain_blocks, lds); return; }
   bwd_pi_body<NW, RG>(a, (int)blockIdx.x, lds);
 }
 

@@ -11,7 +11,9 @@ run() { local label=$1; shift
   grep "^{" $OUT/bench_$label.log | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
-print('   value %.0f  us %.1f  frac %.3f  launches %d' % (d['value'], 1000 * d['ms_per_step'], d['roofline_step']['frac'], len(d.get('kernels', []))))
+d = d.get('cnn', d)
+print('   steps/s %.0f  us %.1f  launches %d' % (d['value'], 1000 * d['ms_per_step'], len(d.get('kernels', []))))
+print('   ' + ' '.join('%s=%.1f' % (k['name'], k['us']) for k in d.get('kernels', [])))
 "; }
 run default A=0
 i=0

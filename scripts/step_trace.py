@@ -14,6 +14,7 @@ import sys
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    close_on = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--close=")]   # e.g. --close=k_conv_dw_reduce (CNN)
     path = args[0]
     which = int(args[1]) if len(args) > 1 else 1000
     rows = []
@@ -31,8 +32,10 @@ def main():
         cur.append(r)
         nxt = rows[i + 1][2] if i + 1 < len(rows) else ""
         closes = "k_stage_table(" in r[2] or "k_adam(" in r[2] or \
-            ("k_dw2<" in r[2] and "k_adam(" not in nxt and "k_sum_parts(" not in nxt and "k_dw2(" not in nxt
-             and "AllReduce" not in nxt)
+            (("k_dw2<" in r[2] or "k_chain_bwd_pi<" in r[2]) and "k_adam(" not in nxt and "k_sum_parts(" not in nxt
+             and "k_dw2<" not in nxt and "AllReduce" not in nxt)
+        if close_on:
+            closes = any(c in r[2] for c in close_on)
         if closes:
             updates.append(cur)
             cur = []

@@ -1315,6 +1315,61 @@ def test_merged_forward_launch_equals_two_launches(O, A, hid, B, monkeypatch):
     assert "chain_fwd_a" in names[1] and "chain_fwd_b" in names[1] and "chain_fwd" not in names[1]
 
 
+@pytest.mark.parametrize("O,A,hid,B", [(376, 17, (256, 256, 256), 256), (24, 6, (128, 128), 64), (12, 3, (64, 64), 16)])
+def test_merged_policy_backward_equals_two_launches(O, A, hid, B, monkeypatch):
+    """k_chain_bwd_pi with merge_dw (the policy's weight-gradient / Adam tiles and the closing block in the policy-backward
+    launch, waiting for the chain's arrival counter) == policy backward + k_dw2 as two launches (DSACT_NO_PI_MERGE=1), bit
+    for bit: gradients of the unfused entry point, then 4 fused eager updates (both delayed-update parities) and a graph
+    replay; every statistic equal; the hand-off word stays clear."""
+    algs = []
+    for merged in (True, False):
+        if merged:
+            monkeypatch.delenv("DSACT_NO_PI_MERGE", raising=False)
+        else:
+            monkeypatch.setenv("DSACT_NO_PI_MERGE", "1")
+        alg, _ = make_pair(O, A, hid, B, seed=23)
+        assert alg.engine.chain_active and alg.engine.debug_get("pi_merge") == (1.0 if merged else 0.0)
+        algs.append(alg)
+    monkeypatch.delenv("DSACT_NO_PI_MERGE", raising=False)
+    rng = np.random.default_rng(13)
+    for it in range(5):
+        data = synth_batch(rng, B, O, A, p_done=0.1)
+        torch.manual_seed(400 + it)
+        noise = draw_noise(B, A)
+        for a in algs:
+            e = a.engine
+            e.load_batch(*(data[k].numpy() for k in ("obs", "act", "rew", "obs2", "done")))
+            e.set_noise(noise["eps_new"].numpy(), noise["eps_2"].numpy(), noise["z5"].numpy(), noise["z6"].numpy())
+            if it == 0:
+                e.compute_grads(it)
+                e.sync()
+                e.apply_update(it)
+            else:
+                e.step(it)
+        if it == 0:
+            assert torch.equal(algs[0].engine.grads, algs[1].engine.grads)
+            assert bool(torch.isfinite(algs[0].engine.grads).all())
+    N = 2048
+    for a in algs:
+        e = a.engine
+        _fill_ring(e, N, O, A, 4)
+        e.set_device_rng(98)
+        np.random.seed(3)
+        e.upload_index_table(np.random.randint(0, N, size=(4, B)))
+        e.graph_build(4)
+        e.graph_run(5, 4)
+        e.sync()
+    for name in ("online", "target", "adam_m", "adam_v"):
+        assert torch.equal(getattr(algs[0].engine, name), getattr(algs[1].engine, name)), name
+    st0, st1 = algs[0].engine.read_stats(), algs[1].engine.read_stats()
+    st0.pop("_device_ms"); st1.pop("_device_ms")
+    assert st0 == st1 and all(np.isfinite(v) for v in st0.values())
+    assert algs[0].engine.get_state() == algs[1].engine.get_state()
+    names = [[k for k, _, _ in a.engine.profile_step(9)] for a in algs]
+    assert "dW" not in names[0] and "dW" in names[1] and "chain_bwd_pi" in names[0]
+    assert algs[0].engine.debug_get("handoff_failures") == 0.0
+
+
 def _fill_ring(e, N, O, A, seed):
     e.buffer_create(N)
     g = torch.Generator(device="cuda").manual_seed(seed)
@@ -1324,14 +1379,16 @@ def _fill_ring(e, N, O, A, seed):
 
 
 def test_handover_buffers_poisoned_between_updates():
-    """ADVICE r2 (ordering of the in-launch hand-over): everything the merged forward hands from producer to consumer
-    workgroups (saved observation parts `zobs`, the sampled-action columns, dL/da) is filled with NaN before EVERY
-    update. A consumer that passed its flag before the producer's stores had landed -- or that read a stale cached
+    """ADVICE r2 (ordering of the in-launch hand-over): everything the merged launches hand from producer to consumer
+    workgroups (forward: saved observation parts `zobs`, the sampled-action columns, dL/da; policy backward: the policy's
+    dZ packs its weight-gradient tiles wait for) is filled with NaN before EVERY update. A consumer that passed its flag before the producer's stores had landed -- or that read a stale cached
     copy -- would compute on NaN. 40 updates at the BASELINE shape: merged == two launches bit for bit, all finite."""
     O, A, hid, B = 376, 17, (256, 256, 256), 256
     algs = [make_pair(O, A, hid, B, seed=31)[0] for _ in range(2)]
     algs[1].engine.debug_set("fwd_merge", 0)
+    algs[1].engine.debug_set("pi_merge", 0)
     assert algs[0].engine.debug_get("fwd_merge") == 1.0 and algs[1].engine.debug_get("fwd_merge") == 0.0
+    assert algs[0].engine.debug_get("pi_merge") == 1.0 and algs[1].engine.debug_get("pi_merge") == 0.0
     rng = np.random.default_rng(14)
     for it in range(40):
         data = synth_batch(rng, B, O, A, p_done=0.1)
@@ -1352,19 +1409,21 @@ def test_handover_buffers_poisoned_between_updates():
     assert algs[0].engine.debug_get("handoff_failures") == 0.0
 
 
-def test_forced_handover_timeout_fails_the_call_and_falls_back():
+@pytest.mark.parametrize("which", [1, 2])
+def test_forced_handover_timeout_fails_the_call_and_falls_back(which):
     """a consumer that gives up waiting must FAIL the call, not poison the statistics. One producer
-    withholds its ready flag ("withhold_flag"): the next synchronising entry point returns DSACT_E_HIP, the handle drops
-    to the unmerged launches (and re-captures its graph without the merged one), and from restored state it trains on,
-    bit-identical to an engine that never merged."""
+    withholds its ready flag ("withhold_flag" 1: a forward unit's; 2: a policy-backward slice never arrives): the next
+    synchronising entry point returns DSACT_E_HIP, the handle drops to the unmerged launches (and re-captures its graph
+    without the merged ones), and from restored state it trains on, bit-identical to an engine that never merged."""
     from dsact._ffi import DsactError
 
     O, A, hid, B, N = 24, 6, (128, 128), 64, 1024
     alg, _ = make_pair(O, A, hid, B, seed=41)
     ref, _ = make_pair(O, A, hid, B, seed=41)
     ref.engine.debug_set("fwd_merge", 0)
+    ref.engine.debug_set("pi_merge", 0)
     e, r = alg.engine, ref.engine
-    assert e.debug_get("fwd_merge") == 1.0
+    assert e.debug_get("fwd_merge") == 1.0 and e.debug_get("pi_merge") == 1.0
     for x in (e, r):
         _fill_ring(x, N, O, A, 8)
         x.set_device_rng(5)
@@ -1374,14 +1433,15 @@ def test_forced_handover_timeout_fails_the_call_and_falls_back():
     arenas = {n: getattr(e, n).clone() for n in ("adam_m", "adam_v")}
     state = e.get_state()
     # --- a graph replay with a withheld flag: the launch succeeds, the first synchronising call fails
-    e.debug_set("withhold_flag", 1)
+    e.debug_set("withhold_flag", which)
     e.graph_build(2)
     e.graph_run(0, 2)                 # asynchronous: returns before the consumers give up
     with pytest.raises(DsactError, match="hand-over timed out"):
         e.sync()
-    assert e.debug_get("handoff_failures") == 1.0 and e.debug_get("fwd_merge") == 0.0
-    assert e.debug_get("graph_steps") == 2.0     # captured again, without the merged launch
-    assert "chain_fwd_a" in [k for k, _, _ in e.profile_step(0)]
+    assert e.debug_get("handoff_failures") == 1.0 and e.debug_get("fwd_merge") == 0.0 and e.debug_get("pi_merge") == 0.0
+    assert e.debug_get("graph_steps") == 2.0     # captured again, without the merged launches
+    names = [k for k, _, _ in e.profile_step(0)]
+    assert "chain_fwd_a" in names and "dW" in names
     e.sync()                                      # the word was consumed: no second error
     # --- restore the state the failed call invalidated, then both engines run the same updates (the reference engine
     #     replays the same three updates first so that both index-table cursors agree, and is restored the same way)
