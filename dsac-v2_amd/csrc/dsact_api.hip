@@ -239,7 +239,7 @@ struct dsact_handle {
   int env_chain_rg_pi = 0;              // DSACT_CHAIN_RG_PI (experiments)
   bool env_no_mixed_rg = false;         // DSACT_NO_MIXED_RG: every unit of the merged forward's group A runs 8-row workgroups (A/B)
   bool fwd_merge = false;               // launches A and B as one (batch <= 256)
-  bool pi_merge = false;                // the policy's weight-gradient tiles + the closing block inside the policy-backward launch (batch <= 256)
+  bool pi_merge = false;                // the policy's weight-gradient tiles + the closing block inside the policy-backward launch (batch <= 512; measured equal-to-slower at 1024)
   float* zobs[4];                       // first-layer accumulators after the observation part: q1, q2 (obs), q1_t, q2_t (obs2)
   float* dAq[2];                        // dL/d new_act through q1 / q2  [B][32]
   float* doutT[3];                      // transposed packs of dL/d(out): q1, q2 [32 x B], policy [roundup32(2A) x B]
@@ -1097,6 +1097,7 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
         if (nkt != 1) return fail(h, DSACT_E_INVALID, "DSACT_CONV_FORK needs DSACT_CONV_DW_NKT=1");
         TRY(launch_on(h, h->aux_stream, ("conv_dw" + sfx).c_str(), k_conv_dw<1>, dim3(blocks), dim3(kThreads), lds, a));
       } else
+      // (three / four steps of loads in flight, k_conv_dw<1, 3|4>: 46.4-48.3 us vs 45 us on layers 0 / 1 -- not latency-bound)
       if (nkt == 1) TRY(launch(h, ("conv_dw" + sfx).c_str(), k_conv_dw<1>, dim3(blocks), dim3(kThreads), lds, a));
       else if (nkt == 2) TRY(launch(h, ("conv_dw" + sfx).c_str(), k_conv_dw<2>, dim3(blocks), dim3(kThreads), lds, a));
       else if (nkt == 3) TRY(launch(h, ("conv_dw" + sfx).c_str(), k_conv_dw<3>, dim3(blocks), dim3(kThreads), lds, a));
@@ -1209,6 +1210,10 @@ int enqueue_gather_img(dsact_handle* h, const float* src_obs, const float* src_o
   a.img0 = img0; a.img2 = img2; a.Xa0 = h->Xc[C_Q1C]; a.Xa1 = h->Xc[C_Q2C]; a.rew = h->rew; a.done = h->done;
   a.B = n_rows; a.C = h->cfg.img_c; a.HW = h->cfg.img_h * h->cfg.img_w; a.A = h->A; a.F = h->F; a.ldx = h->ldx;
   a.chunks = 8;
+  if (a.C == 3 && a.HW % 4 == 0) {   // RGB fast path: a thread per pixel quad -- exactly one trip per thread when it divides (96 x 96: 9 blocks)
+    const int per = (a.HW / 4 + kThreads - 1) / kThreads;
+    a.chunks = per < 1 ? 1 : (per > 16 ? 16 : per);
+  }
   return launch(h, "gather_img", k_gather_img, dim3(n_rows * a.chunks + a.rp.n_blocks), dim3(kThreads), 0, a);
 }
 
@@ -2163,7 +2168,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
       if (const char* v = getenv("DSACT_FAT_RT")) h->env_fat_rt = atoi(v) == 2 ? 2 : 1;
     }
     h->fwd_merge = ok && h->B <= 256 && h->B / 4 <= kChainFlagSlices && chain_rg(h, 4) == 1 && getenv("DSACT_NO_FWD_MERGE") == nullptr;
-    h->pi_merge = ok && h->B <= 256 && !h->fat_bwd && getenv("DSACT_NO_PI_MERGE") == nullptr;
+    h->pi_merge = ok && h->B <= 512 && !h->fat_bwd && getenv("DSACT_NO_PI_MERGE") == nullptr;
   }
   Carver c0;
   carve(h, c0);
@@ -3260,7 +3265,7 @@ int dsact_debug_set(dsact_handle* h, const char* name, double value) {
   if (!strcmp(name, "pi_merge")) {    // same for the merged policy-backward / policy weight-gradient launch
     HIPCHK(h, hipStreamSynchronize(h->stream));
     drop_graphs(h);
-    h->pi_merge = value != 0.0 && h->chain_ok && h->B <= 256 && !h->fat_bwd;
+    h->pi_merge = value != 0.0 && h->chain_ok && h->B <= 512 && !h->fat_bwd;
     if (h->chain_flags) HIPCHK(h, hipMemset(h->chain_flags, 0, kChainFlagInts * sizeof(int)));
     h->flags_dirty = false;
     return DSACT_OK;

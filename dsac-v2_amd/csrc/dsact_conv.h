@@ -74,6 +74,9 @@ struct ConvStageArgs {
 };
 
 // ---------------------------------------------------------------------------------------------
+// (round 3: a flattened version of this loop with three k-tiles of unconditional loads in flight and LDS-only barriers
+//  measured SLOWER on layers 2-4 -- 47.8 / 32.0 / 33.4 us vs 39.5 / 26.0 / 31.0 -- at 156 VGPRs = 3 workgroups per CU
+//  instead of 4: these tiles are bound by their LDS staging / address arithmetic per 16 MFMAs, not by load latency)
 // forward: persistent workgroups; each walks (group, m-tile, n-tile) work items, one 32 (pixels) x 32
 // (channels) tile per item. The (item, k-tile) sequence is software pipelined: the global loads of the
 // NEXT k-tile (possibly of the next item) are in flight while the current one is multiplied, so the
@@ -194,7 +197,7 @@ __global__ void __launch_bounds__(kThreads) k_conv_fwd_narrow(ConvStageArgs s) {
   const ConvGeom& g = s.g;
   const int lane = threadIdx.x & 63;
   const int i = lane & 15, gq = lane >> 4;
-  const int wave_global = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  const int wave_global = __builtin_amdgcn_readfirstlane(blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6));
   // a wave works on ONE group (s.n_items = waves per group here): its weight fragments are loaded once, before
   // the tile loop, so that nothing but patch loads, MFMAs and stores remains inside it
   const int wpg = s.n_items;
@@ -234,13 +237,20 @@ __global__ void __launch_bounds__(kThreads) k_conv_fwd_narrow(ConvStageArgs s) {
     bv[nb] = qv ? *(const f32x4u*)(t.bias[sq] + (nq - sq * g.Cout)) : zero;
   }
   // output addressing of this lane (constant across tiles)
-  int o_sub[NB], o_co[NB]; bool o_ok[NB];
+  // (the output pointer is selected HERE from three scalar loads: `t.out[o_sub]` with a per-lane index inside the tile
+  //  loop was a vector load of the pointer + s_waitcnt vmcnt(0) in front of every store -- the next tile's patch loads,
+  //  which are supposed to be in flight during the MFMAs, were drained there; round 3, disassembly)
+  typedef __attribute__((address_space(4))) const ConvStageArgs KArgs;
+  KArgs* ka = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  float* const out0 = ka->p[pi].out[0]; float* const out1 = ka->p[pi].out[1]; float* const out2 = ka->p[pi].out[2];
+  int o_co[NB]; bool o_ok[NB]; float* o_ptr[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int n = nb * 16 + 4 * gq;
     o_ok[nb] = n < ntot;
-    o_sub[nb] = o_ok[nb] ? n / g.Cout : 0;
-    o_co[nb] = n - o_sub[nb] * g.Cout;
+    const int o_sub = o_ok[nb] ? n / g.Cout : 0;
+    o_co[nb] = n - o_sub * g.Cout;
+    o_ptr[nb] = o_sub == 0 ? out0 : (o_sub == 1 ? out1 : out2);
   }
   // RAW patch loads (rows clamped into the matrix, nothing selected on the loaded registers: a select would make
   // the wave wait for the load at issue time and the prefetch would overlap nothing)
@@ -277,7 +287,7 @@ __global__ void __launch_bounds__(kThreads) k_conv_fwd_narrow(ConvStageArgs s) {
           f32x4 o = acc[mb][nb] + bv[nb];
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
-          *(f32x4u*)(t.out[o_sub[nb]] + (size_t)m * g.Cout + o_co[nb]) = o;
+          *(f32x4u*)(o_ptr[nb] + (size_t)m * g.Cout + o_co[nb]) = o;
         }
       }
     }
@@ -327,7 +337,8 @@ struct ConvDwArgs {
 // NKT = k-tiles (32 patch columns each) per workgroup: the dY tile of a step is staged once and multiplied
 // with NKT patch tiles, so dY is not re-read per k-tile (PMC: the weight gradient was the largest consumer
 // of memory-side traffic, 2-3x its algorithmic bytes, when every k-tile had its own workgroup).
-template <int NKT>
+// NS = steps of global loads in flight (register sets).
+template <int NKT, int NS = 2>
 __global__ void __launch_bounds__(kThreads) k_conv_dw(ConvDwArgs s) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x (1 + NKT) tiles
   const int b = blockIdx.x;
@@ -390,27 +401,34 @@ __global__ void __launch_bounds__(kThreads) k_conv_dw(ConvDwArgs s) {
   f32x4 acc0[NKT], acc1[NKT];
 #pragma unroll
   for (int u = 0; u < NKT; ++u) { acc0[u] = zero; acc1[u] = zero; }
-  // two steps of global loads in flight (register sets a / b alternate): one step's L2/MALL round trip is
-  // longer than its 16 MFMAs + LDS staging, and a chunk is a dependent chain of 4-16 steps
-  f32x4 pa0, pa1, qa0[NKT], qa1[NKT], pb0, pb1, qb0[NKT], qb1[NKT];
-  load(0, pa0, pa1, qa0, qa1);
-  if (T > 1) load(1, pb0, pb1, qb0, qb1);
+  // NS steps of global loads in flight (register sets rotate): one step's L2/MALL round trip is longer than its
+  // 16 MFMAs + LDS staging, and a chunk is a dependent chain of 4-16 steps. The refill of a set is UNCONDITIONAL (step index
+  // clamped to the last one): with a branch around it hipcc's wait-count pass falls back to s_waitcnt vmcnt(0) at the
+  // next use -- every step then waited for the loads issued one step earlier (found in the disassembly, round 3).
+  f32x4 ps0[NS], ps1[NS], qs0[NS][NKT], qs1[NS][NKT];
+#pragma unroll
+  for (int st = 0; st < NS; ++st) load(st < T ? st : T - 1, ps0[st], ps1[st], qs0[st], qs1[st]);
   auto step = [&](int it, f32x4& P0, f32x4& P1, f32x4 (&Q0)[NKT], f32x4 (&Q1)[NKT]) {
     float* Ps = lds + (it & 1) * (1 + NKT) * TILE_LDS;
     mask(it, P0, P1, Q0, Q1);
     tile_store_lds<true>(Ps, tid, P0, P1);
 #pragma unroll
     for (int u = 0; u < NKT; ++u) tile_store_lds<true>(Ps + (1 + u) * TILE_LDS, tid, Q0[u], Q1[u]);
-    __syncthreads();
-    if (it + 2 < T) load(it + 2, P0, P1, Q0, Q1);
+    lds_barrier();
+    load(it + NS < T ? it + NS : T - 1, P0, P1, Q0, Q1);
 #pragma unroll
     for (int u = 0; u < NKT; ++u)
       tile_mma<true, true>(Ps, Ps + (1 + u) * TILE_LDS, wr * 16 + i, wc * 16 + i, gq, acc0[u], acc1[u]);
   };
-  for (int it = 0; it < T; it += 2) {
-    step(it, pa0, pa1, qa0, qa1);
-    if (it + 1 < T) step(it + 1, pb0, pb1, qb0, qb1);
+  int it = 0;
+  for (; it + NS <= T; it += NS) {
+#pragma unroll
+    for (int st = 0; st < NS; ++st) step(it + st, ps0[st], ps1[st], qs0[st], qs1[st]);
   }
+  // tail (T % NS steps): the sets hold steps it, it + 1, ... in order
+#pragma unroll
+  for (int st = 0; st < NS - 1; ++st)
+    if (it + st < T) step(it + st, ps0[st], ps1[st], qs0[st], qs1[st]);
   const int cot = co0 + wr * 16 + i;
   if (cot < ntot) {
     const int sub = cot / g.Cout, co = cot - sub * g.Cout;
@@ -792,6 +810,32 @@ __global__ void __launch_bounds__(kThreads) k_gather_img(ImgGatherArgs a) {
   float* d2 = a.img2 + (size_t)r * O;
   const int n4 = (int)(O >> 2);   // C*HW % 4 == 0 is checked at create time
   const float inv_c = 1.0f / (float)a.C;
+  if (a.C == 3 && (a.HW & 3) == 0) {
+    // RGB planes: a thread takes 4 consecutive pixels -- one 16-byte load per plane and image, the 3 x 4 block transposed
+    // in registers, three 16-byte stores per image (dword loads of the generic loop below: 4x the load instructions,
+    // 33 us for the 115 MB of this launch)
+    const int nq = a.HW >> 2;
+    for (int q = ck * kThreads + threadIdx.x; q < nq; q += a.chunks * kThreads) {
+      f32x4 p[3], p2[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        p[c] = *(const f32x4*)(so + (size_t)c * a.HW + 4 * q);
+        p2[c] = *(const f32x4*)(so2 + (size_t)c * a.HW + 4 * q);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {     // output quad j holds elements 4j .. 4j+3 of (pixel e, channel c) = e*3 + c
+        f32x4 v, w;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const int o = 4 * j + e4;
+          v[e4] = p[o % 3][o / 3];
+          w[e4] = p2[o % 3][o / 3];
+        }
+        *(f32x4*)(d0 + (size_t)q * 12 + 4 * j) = v;
+        *(f32x4*)(d2 + (size_t)q * 12 + 4 * j) = w;
+      }
+    }
+  } else
   for (int q = ck * kThreads + threadIdx.x; q < n4; q += a.chunks * kThreads) {
     f32x4 v, w;
 #pragma unroll
