@@ -4,13 +4,15 @@
 // row, so ONE workgroup can take a slice of the minibatch through a whole network chain: first layer -> hidden
 // layers -> output layer -> tanh-Gaussian rsample / softplus epilogue (forward), or loss -> output-layer backward ->
 // hidden layers -> dL/d(action) (backward), with the activations in LDS and no inter-workgroup synchronisation.
-// One update becomes 4 launches (the tile path: 14):
+// One update becomes 3 launches at batch <= 256 (4 at 512, 5 above; the tile path: 14):
 //   k_chain_fwd2     group A: policy(obs), policy_target(obs2), q1/q2(obs,act), + the obs2 part of q1_t/q2_t's first layer;
 //                    group B (same launch, per-slice ready flags): q1_t/q2_t(obs2,act2), q1/q2(obs,new_act): first layer =
 //                    saved obs part + K=A action part            (batch > 256: two launches, k_chain_fwd A then B)
 //   k_chain_bwd_q    DSAC-T loss (dsac_v2.py:218-318) + dZ chains of q1c,q2c,q1p,q2p + dL/d new_act (+ the next update's gather)
-//   k_chain_bwd_pi   rsample backward + policy dZ chain   (+ the critics' dW/Adam tiles on the idle CUs)
-//   k_dw2            policy dW/Adam(/Polyak) tiles + close of the update
+//   k_chain_bwd_pi   rsample backward + policy dZ chain   (+ the critics' dW/Adam tiles on the idle CUs; batch <= 512: + the
+//                    policy's own dW/Adam(/Polyak) tiles, which wait for the chain's arrival counter, + the block that closes
+//                    the update)
+//   k_dw2            policy dW/Adam(/Polyak) tiles + close of the update, where they do not ride in k_chain_bwd_pi
 // Reference math: networks/mlp.py:79-127, utils/act_distribution_cls.py:44-54, dsac_v2.py:150-318.
 //
 // Shape of a chain workgroup (measurements: scripts/ubench/{slice_gemm,slice_gemm44,cu_stream,mfma_operands}.hip,
