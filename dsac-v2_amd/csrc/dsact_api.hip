@@ -237,6 +237,7 @@ struct dsact_handle {
   double act_launch_us = 0.0, act_wait_us = 0.0;   // host time of the last fast acting forward: launch call, completion spin
   bool env_no_fast_act = false;         // DSACT_NO_FAST_ACT: the sampler's forward through the copy + tile-stage path (A/B)
   int env_chain_rg_pi = 0;              // DSACT_CHAIN_RG_PI (experiments)
+  bool env_dw_4wave = false;            // DSACT_DW_4WAVE: k_dw2 keeps 4 waves per tile at every batch (A/B)
   bool env_no_mixed_rg = false;         // DSACT_NO_MIXED_RG: every unit of the merged forward's group A runs 8-row workgroups (A/B)
   bool fwd_merge = false;               // launches A and B as one (batch <= 256)
   bool pi_merge = false;                // the policy's weight-gradient tiles + the closing block inside the policy-backward launch (batch <= 512; measured equal-to-slower at 1024)
@@ -1379,6 +1380,9 @@ int run_dw2(dsact_handle* h, int x0, int x1, bool fused, bool finalize) {
   L.tile0 = x0; L.n_tiles = x1 > x0 ? x1 - x0 : 0; L.finalize = finalize ? 1 : 0;
   // (k_dw2<4>, fragments four half rounds ahead, measured at batch 512 / 1024: 8.76 vs 8.91 us and 13.10 vs 13.21 us --
   //  the tiles are MFMA-bound there, not load-latency-bound; not instantiated)
+  // long contractions (batch >= 512 per range) with one tile per CU: 8 waves per tile, two per SIMD (dsact_chain.h: dw2_tile NWV)
+  if (L.a.ct >= 32 && !h->env_dw_4wave)
+    return launch(h, "dW", (k_dw2<2, 8>), dim3(xcd_chunk_grid(L.n_tiles) + (finalize ? 1 : 0), h->dw_chunks), dim3(512), 0, L);
   return launch(h, "dW", k_dw2<2>, dim3(xcd_chunk_grid(L.n_tiles) + (finalize ? 1 : 0), h->dw_chunks), dim3(kThreads), 0, L);
 }
 
@@ -2129,6 +2133,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (const char* v = getenv("DSACT_RIDE_SLOTS")) h->env_ride_slots = atoi(v);
   if (const char* v = getenv("DSACT_CHAIN_RG_PI")) h->env_chain_rg_pi = atoi(v);
   h->env_no_mixed_rg = getenv("DSACT_NO_MIXED_RG") != nullptr;
+  h->env_dw_4wave = getenv("DSACT_DW_4WAVE") != nullptr;
   if (const char* v = getenv("DSACT_CHAIN_RG")) h->env_chain_rg = atoi(v) == 1 ? 1 : atoi(v) == 4 ? 4 : 2;
   h->dw_chunks = (h->B > 448 && h->B % 256 == 0 && getenv("DSACT_NO_SPLITK") == nullptr) ? h->B / 256 : 1;   // (chain path: below)
   h->dw_part_stride = (h->n_online + 2 + 63) & ~(size_t)63;

@@ -241,12 +241,16 @@ struct Dw2Args {
   int store_g;            // 0: fused graph replays -- nothing reads the gradient arena, skip its 4.6 MB of stores
 };
 constexpr int kDw2LdsFloats = 4 * 4 * 64 * 4 + 4 * 2 * 64;
+constexpr int dw2_lds_floats(int nwv) { return nwv * 4 * 64 * 4 + nwv * 2 * 64; }   // NWV waves per tile (4: the above)
 
 // `wait`: called between the loads of everything the tile needs from EARLIER launches (the X-side fragments, the Adam /
 // Polyak operands) and the first load of the dZ-side fragments -- the policy's tiles of the merged policy-backward
 // launch wait there for the policy chain's arrival counter with their other operands already in flight.
 struct NoWait { __device__ __forceinline__ void operator()() const {} };
-template <int NSET = 2, typename Wait = NoWait>
+// NWV = waves per tile: the contraction of a round (4 * NWV chunks) is split over them; NWV = 8 (k_dw2 as its own launch
+// at batch >= 1024, one tile per CU: two waves per SIMD instead of one hide each other's operand waits) -- the first four
+// waves finish the tile as before, summing 8 partial blocks instead of 4 (fixed order).
+template <int NSET = 2, typename Wait = NoWait, int NWV = 4>
 __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds, Wait wait = Wait()) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -266,12 +270,14 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds, Wa
   //      round NSET ahead as soon as its MFMAs are issued, so longer contractions (batch 512 .. 1024 per range) stream.
   //      NSET = 2 keeps a load 32 MFMAs (~0.4 us) ahead of its use; NSET = 4 (128 fragment registers, 96 MFMAs ahead)
   //      bought nothing at batch 512 / 1024 -- a wave's 16 chunks x 16 MFMAs are the time. Same accumulation order.
+  constexpr int RC = 4 * NWV;           // chunks per round
+  constexpr int PB = NWV * 4 * 64 * 4;  // floats of the partial blocks in LDS; the bias row sums follow
   const int c_lo = range * a.ct;
-  const int n_half = 2 * ((a.ct + 15) >> 4);
+  const int n_half = 2 * ((a.ct + RC - 1) / RC);
   f32x4 fa[NSET][2][2], fx[NSET][2][2];
   auto half_ok = [&](int hr, int q2, int& c) {
-    const int cb = (hr >> 1) << 4;
-    const int ctr = a.ct - cb < 16 ? a.ct - cb : 16, cw = (ctr + 3) >> 2;
+    const int cb = (hr >> 1) * RC;
+    const int ctr = a.ct - cb < RC ? a.ct - cb : RC, cw = (ctr + NWV - 1) / NWV;
     const int q = 2 * (hr & 1) + q2;
     const bool ok = q < cw && wave * cw + q < ctr;
     c = c_lo + cb + (ok ? wave * cw + q : 0);
@@ -300,8 +306,9 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds, Wa
   for (int st = 0; st < NSET; ++st)
     if (st < n_half) load_half_x(st, st);
   // ---- this lane's share of the epilogue: 16x16 block (wave>>1, wave&1), rows m, columns n .. n+3
-  const int m = m0 + 16 * (wave >> 1) + i, n = n0 + 16 * (wave & 1) + 4 * g;
-  const bool in_range = m < P.M && n < P.N, full = n + 3 < P.N;
+  const bool fin = wave < 4;            // the waves that finish the tile (NWV = 8: the other four only multiply)
+  const int m = m0 + 16 * ((wave & 3) >> 1) + i, n = n0 + 16 * (wave & 1) + 4 * g;
+  const bool in_range = fin && m < P.M && n < P.N, full = n + 3 < P.N;
   const bool fused = a.fo.st != nullptr;
   const long long oi = P.w_idx + (long long)m * P.N + n;
   bool o_delayed = false, o_upd = false;
@@ -361,11 +368,12 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds, Wa
   for (int bm = 0; bm < 2; ++bm)
 #pragma unroll
     for (int bn = 0; bn < 2; ++bn) *(f32x4*)(lds + ((wave * 4 + 2 * bm + bn) * 64 + lane) * 4) = acc[bm][bn];
-  if (bias) { lds[4096 + (wave * 2 + 0) * 64 + lane] = sb[0]; lds[4096 + (wave * 2 + 1) * 64 + lane] = sb[1]; }
+  if (bias) { lds[PB + (wave * 2 + 0) * 64 + lane] = sb[0]; lds[PB + (wave * 2 + 1) * 64 + lane] = sb[1]; }
   lds_barrier();
+  if (NWV > 4 && !fin) return;          // (after the barrier; nothing below synchronises the workgroup)
   f32x4 v = *(const f32x4*)(lds + ((0 * 4 + wave) * 64 + lane) * 4);
 #pragma unroll
-  for (int w = 1; w < 4; ++w) v += *(const f32x4*)(lds + ((w * 4 + wave) * 64 + lane) * 4);
+  for (int w = 1; w < NWV; ++w) v += *(const f32x4*)(lds + ((w * 4 + wave) * 64 + lane) * 4);
   float* C = a.gout + range * a.part_stride;
   if (in_range) {
     float* c0 = C + oi;
@@ -406,9 +414,9 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds, Wa
     if (mb < P.M) {
       float sbias = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w)
+      for (int w = 0; w < NWV; ++w)
 #pragma unroll
-        for (int gg = 0; gg < 4; ++gg) sbias += lds[4096 + (w * 2 + (tid >> 4)) * 64 + gg * 16 + (tid & 15)];
+        for (int gg = 0; gg < 4; ++gg) sbias += lds[PB + (w * 2 + (tid >> 4)) * 64 + gg * 16 + (tid & 15)];
       const long long bi = P.b_idx + mb;
       if (a.store_g) C[bi] = sbias;
       if (fused && o_upd) {
@@ -436,16 +444,16 @@ __device__ __forceinline__ bool xcd_chunk(int b, int n, int& t) {
 // grid (xcd_chunk_grid(n_tiles) [+ 1], batch ranges): base tiles tile0 .. tile0 + n_tiles - 1 of every range; the
 // extra block closes the update
 struct Dw2Launch { Dw2Args a; int tile0, n_tiles, finalize; };
-template <int NSET>
-__global__ void __launch_bounds__(kThreads) k_dw2(Dw2Launch L) {
-  __shared__ __attribute__((aligned(16))) float lds[kDw2LdsFloats];
+template <int NSET, int NWV = 4>
+__global__ void __launch_bounds__(64 * NWV) k_dw2(Dw2Launch L) {
+  __shared__ __attribute__((aligned(16))) float lds[dw2_lds_floats(NWV)];
   if ((int)blockIdx.x >= xcd_chunk_grid(L.n_tiles)) {
     if (L.finalize && blockIdx.y == 0 && threadIdx.x == 0) finalize_update(L.a.fo);
     return;
   }
   int t;
   if (!xcd_chunk((int)blockIdx.x, L.n_tiles, t)) return;
-  dw2_tile<NSET>(L.a, (int)blockIdx.y * L.a.n_base + L.tile0 + t, lds);
+  dw2_tile<NSET, NoWait, NWV>(L.a, (int)blockIdx.y * L.a.n_base + L.tile0 + t, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
