@@ -1381,7 +1381,9 @@ int run_dw2(dsact_handle* h, int x0, int x1, bool fused, bool finalize) {
   // (k_dw2<4>, fragments four half rounds ahead, measured at batch 512 / 1024: 8.76 vs 8.91 us and 13.10 vs 13.21 us --
   //  the tiles are MFMA-bound there, not load-latency-bound; not instantiated)
   // long contractions (batch >= 512 per range) with one tile per CU: 8 waves per tile, two per SIMD (dsact_chain.h: dw2_tile NWV)
-  if (L.a.ct >= 32 && !h->env_dw_4wave)
+  // (batch 1024: 13.8 -> 11.8 us, 8,611 -> 8,787 steps/s; batch 4096 with its 960 split-K tiles -- several per CU anyway --
+  //  is 0.5 % slower with it, hence the tile-count condition; profiles/r03_ab_dw_8wave.txt)
+  if (L.a.ct >= 32 && (long long)L.n_tiles * h->dw_chunks <= 512 && !h->env_dw_4wave)
     return launch(h, "dW", (k_dw2<2, 8>), dim3(xcd_chunk_grid(L.n_tiles) + (finalize ? 1 : 0), h->dw_chunks), dim3(512), 0, L);
   return launch(h, "dW", k_dw2<2>, dim3(xcd_chunk_grid(L.n_tiles) + (finalize ? 1 : 0), h->dw_chunks), dim3(kThreads), 0, L);
 }
