@@ -24,6 +24,9 @@ for b in 128; do
   timeout 300 python bench.py --steps 4000 --warmup 400 --batch $b --no-cpu-baseline --no-alt > $OUT/bench_b$b.log 2>&1; echo "batch $b rc=$?"; summ $OUT/bench_b$b.log
   DSACT_BENCH_FORCE_DP=1 timeout 300 python bench.py --steps 4000 --warmup 400 --batch $b --no-cpu-baseline --no-alt > $OUT/bench_b${b}_dp.log 2>&1; echo "batch $b dp rc=$?"; summ $OUT/bench_b${b}_dp.log
 done
+for b in 512 2048; do
+  timeout 300 python bench.py --steps 2000 --warmup 400 --batch $b --no-cpu-baseline --no-alt > $OUT/bench_b$b.log 2>&1; echo "batch $b rc=$?"; summ $OUT/bench_b$b.log
+done
 DSACT_BENCH_FORCE_DP=1 timeout 300 python bench.py --steps 4000 --warmup 400 --no-cpu-baseline --no-alt > $OUT/bench_dp_native.log 2>&1; echo "dp native rc=$?"; summ $OUT/bench_dp_native.log
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-alt > $OUT/rocprof.log 2>&1; echo "rocprof rc=$?"
 f=$(find $OUT/prof -name "*kernel_trace.csv" | head -1)
