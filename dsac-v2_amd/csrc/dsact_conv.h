@@ -253,14 +253,39 @@ __global__ void __launch_bounds__(kThreads) k_conv_fwd_narrow(ConvStageArgs s) {
     o_ptr[nb] = o_sub == 0 ? out0 : (o_sub == 1 ? out1 : out2);
   }
   // RAW patch loads (rows clamped into the matrix, nothing selected on the loaded registers: a select would make
-  // the wave wait for the load at issue time and the prefetch would overlap nothing)
-  auto load_p = [&](int tile, f32x4 (&P)[2][NKK]) {
+  // the wave wait for the load at issue time and the prefetch would overlap nothing). The loader visits the wave's tiles
+  // in order (tile wv, wv + wpg, ...: 32 * wpg pixels apart) and keeps (ox, oy, offset) of its two rows incrementally --
+  // see k_conv_dw: two reciprocal divisions + five quarter-rate multiplies per row and tile were a quarter of a tile's
+  // 24-48 MFMAs.
+  const int SX = g.stride * g.Cin, SY = g.stride * g.W * g.Cin, SB = g.H * g.W * g.Cin;
+  const int adv = 32 * wpg;                                       // pixels between consecutive tiles of this wave (uniform)
+  const int adb = adv / s.ix.OHW, adr = adv - adb * s.ix.OHW, ady = adr / g.OW, adx = adr - ady * g.OW;
+  const int adoff = adb * SB + ady * SY + adx * SX, wrapx = SY - g.OW * SX, wrapy = SB - g.OH * SY;
+  const int off_last = conv_rowoff(g, s.ix, t.M - 1);
+  int pm[2], pox[2], poy[2], poff[2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const int m = wv * 32 + mb * 16 + i;
+    const int mc_ = m < t.M ? m : t.M - 1;
+    const int b_ = fast_div(mc_, s.ix.OHW, s.ix.inv_ohw);
+    const int p_ = mc_ - b_ * s.ix.OHW;
+    poy[mb] = fast_div(p_, g.OW, s.ix.inv_ow);
+    pox[mb] = p_ - poy[mb] * g.OW;
+    poff[mb] = b_ * SB + poy[mb] * SY + pox[mb] * SX;
+    pm[mb] = m;
+  }
+  // loads the loader's current tile, then moves it one tile on (rows past the end read the last pixel's patch)
+  auto load_next = [&](f32x4 (&P)[2][NKK]) {
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
-      const int m = tile * 32 + mb * 16 + i;
-      const float* base = t.in + conv_rowoff(g, s.ix, m < t.M ? m : t.M - 1);
+      const float* base = t.in + (pm[mb] < t.M ? poff[mb] : off_last);
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) P[mb][kk] = *(const f32x4u*)(base + km[kk]);
+      pm[mb] += adv;
+      pox[mb] += adx; poff[mb] += adoff;
+      if (pox[mb] >= g.OW) { pox[mb] -= g.OW; poy[mb] += 1; poff[mb] += wrapx; }
+      poy[mb] += ady;
+      if (poy[mb] >= g.OH) { poy[mb] -= g.OH; poff[mb] += wrapy; }
     }
   };
   auto compute = [&](int tile, const f32x4 (&P)[2][NKK]) {
@@ -293,15 +318,13 @@ __global__ void __launch_bounds__(kThreads) k_conv_fwd_narrow(ConvStageArgs s) {
     }
   };
   f32x4 Pa[2][NKK], Pb[2][NKK];
-  const int last = n_tiles - 1;
-  load_p(wv, Pa);
+  load_next(Pa);
   for (int tile = wv; tile < n_tiles; tile += 2 * wpg) {
     const int nx = tile + wpg;
-    load_p(nx < last ? nx : last, Pb);        // unconditional (clamped): no branch between the loads and the MFMAs
+    load_next(Pb);                            // unconditional (clamped inside): no branch between the loads and the MFMAs
     compute(tile, Pa);
     if (nx >= n_tiles) break;
-    const int n2 = nx + wpg;
-    load_p(n2 < last ? n2 : last, Pa);
+    load_next(Pa);
     compute(nx, Pb);
   }
 }
@@ -374,18 +397,51 @@ __global__ void __launch_bounds__(kThreads) k_conv_dw(ConvDwArgs s) {
   const int ms = tid >> 3;                       // m slot 0 (slot 1 = +32)
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   const f32x4 one0 = {1.f, 0.f, 0.f, 0.f};
-  // raw loads; the masks (pixel validity of the two slots) are applied at LDS-store time -- see k_conv_fwd
-  auto load = [&](int it, f32x4& P0, f32x4& P1, f32x4 (&Q0)[NKT], f32x4 (&Q1)[NKT]) {
-    const int ma = mb + it * BK + ms, mc = ma + 32;
-    const int mac = ma < me ? ma : t.M - 1, mcc = mc < me ? mc : t.M - 1;
-    const int roa = conv_rowoff(g, s.ix, mac), roc = conv_rowoff(g, s.ix, mcc);
-    P0 = *(const f32x4u*)(dyp + (size_t)mac * g.Cout);
-    P1 = *(const f32x4u*)(dyp + (size_t)mcc * g.Cout);
+  // raw loads; the masks (pixel validity of the two slots) are applied at LDS-store time -- see k_conv_fwd.
+  // The loader walks its two pixel slots 64 pixels per step INCREMENTALLY: (ox, oy, float offset of the patch origin) are
+  // advanced by the decomposition of 64 = db*OH*OW + doy*OW + dox with two compare / subtract carries, instead of two
+  // reciprocal divisions + five integer multiplies per slot and step -- v_mul_lo_u32 is quarter rate and f32 VALU work
+  // shares the lanes with the MFMAs: the address arithmetic was as long as the step's 16 MFMAs (disassembly, round 3).
+  const int SX = g.stride * g.Cin, SY = g.stride * g.W * g.Cin, SB = g.H * g.W * g.Cin;
+  const int db64 = BK / s.ix.OHW, r64 = BK - db64 * s.ix.OHW, doy64 = r64 / g.OW, dox64 = r64 - doy64 * g.OW;   // uniform
+  const int doff64 = db64 * SB + doy64 * SY + dox64 * SX, wrapx = SY - g.OW * SX, wrapy = SB - g.OH * SY;
+  const int off_last = conv_rowoff(g, s.ix, t.M - 1);
+  const size_t dy_last = (size_t)(t.M - 1) * g.Cout;
+  struct Pix { int m, ox, oy, off; };
+  auto pix_at = [&](int m) {
+    Pix px;
+    const int mc_ = m < t.M ? m : t.M - 1;     // (decomposed once per block; steps past the end are masked by m >= me)
+    const int b_ = fast_div(mc_, s.ix.OHW, s.ix.inv_ohw);
+    const int p_ = mc_ - b_ * s.ix.OHW;
+    px.oy = fast_div(p_, g.OW, s.ix.inv_ow);
+    px.ox = p_ - px.oy * g.OW;
+    px.off = b_ * SB + px.oy * SY + px.ox * SX;
+    px.m = m;
+    return px;
+  };
+  auto pix_next = [&](Pix& px) {
+    px.m += BK;
+    px.ox += dox64; px.off += doff64;
+    if (px.ox >= g.OW) { px.ox -= g.OW; px.oy += 1; px.off += wrapx; }
+    px.oy += doy64;
+    if (px.oy >= g.OH) { px.oy -= g.OH; px.off += wrapy; }
+  };
+  Pix pxa = pix_at(mb + ms), pxc = pix_at(mb + ms + 32);
+  auto load_next = [&](f32x4& P0, f32x4& P1, f32x4 (&Q0)[NKT], f32x4 (&Q1)[NKT]) {
+    const bool oka = pxa.m < me, okc = pxc.m < me;
+    const int roa = oka ? pxa.off : off_last, roc = okc ? pxc.off : off_last;
+    // Lanes whose quad lies outside the operand (channel quads past n_sub*Cout, the bias / padding columns of the last
+    // k-tile -- HALF the lanes on the 8- and 16-channel layers) read ONE fixed address instead of a row-dependent one:
+    // what they load is replaced at LDS-store time, but every distinct cache line a wave-load touches is a request to
+    // the CU's L1, and these 16-bytes-per-lane gathers are bound by exactly that request rate.
+    P0 = *(const f32x4u*)(dyp + (pcv ? (oka ? (size_t)pxa.m * g.Cout : dy_last) : 0));
+    P1 = *(const f32x4u*)(dyp + (pcv ? (okc ? (size_t)pxc.m * g.Cout : dy_last) : 0));
 #pragma unroll
     for (int u = 0; u < NKT; ++u) {
-      Q0[u] = *(const f32x4u*)(t.in + roa + qmap[u]);
-      Q1[u] = *(const f32x4u*)(t.in + roc + qmap[u]);
+      Q0[u] = *(const f32x4u*)(t.in + (qmode[u] == 0 ? roa + qmap[u] : 0));
+      Q1[u] = *(const f32x4u*)(t.in + (qmode[u] == 0 ? roc + qmap[u] : 0));
     }
+    pix_next(pxa); pix_next(pxc);
   };
   auto mask = [&](int it, f32x4& P0, f32x4& P1, f32x4 (&Q0)[NKT], f32x4 (&Q1)[NKT]) {
     const int ma = mb + it * BK + ms, mc = ma + 32;
@@ -407,7 +463,7 @@ __global__ void __launch_bounds__(kThreads) k_conv_dw(ConvDwArgs s) {
   // next use -- every step then waited for the loads issued one step earlier (found in the disassembly, round 3).
   f32x4 ps0[NS], ps1[NS], qs0[NS][NKT], qs1[NS][NKT];
 #pragma unroll
-  for (int st = 0; st < NS; ++st) load(st < T ? st : T - 1, ps0[st], ps1[st], qs0[st], qs1[st]);
+  for (int st = 0; st < NS; ++st) load_next(ps0[st], ps1[st], qs0[st], qs1[st]);   // steps 0 .. NS-1 (past T: masked, clamped)
   auto step = [&](int it, f32x4& P0, f32x4& P1, f32x4 (&Q0)[NKT], f32x4 (&Q1)[NKT]) {
     float* Ps = lds + (it & 1) * (1 + NKT) * TILE_LDS;
     mask(it, P0, P1, Q0, Q1);
@@ -415,7 +471,7 @@ __global__ void __launch_bounds__(kThreads) k_conv_dw(ConvDwArgs s) {
 #pragma unroll
     for (int u = 0; u < NKT; ++u) tile_store_lds<true>(Ps + (1 + u) * TILE_LDS, tid, Q0[u], Q1[u]);
     lds_barrier();
-    load(it + NS < T ? it + NS : T - 1, P0, P1, Q0, Q1);
+    load_next(P0, P1, Q0, Q1);                 // step it + NS of the loader
 #pragma unroll
     for (int u = 0; u < NKT; ++u)
       tile_mma<true, true>(Ps, Ps + (1 + u) * TILE_LDS, wr * 16 + i, wc * 16 + i, gq, acc0[u], acc1[u]);

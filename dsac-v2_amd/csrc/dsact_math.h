@@ -109,9 +109,10 @@ struct TanhGaussFwd {
 };
 DSACT_HD TanhGaussFwd tanh_gauss_fwd(float mu, float raw, float eps, float s, float c, float lo_ls,
                                      float hi_ls) {
-  // Every product below is rounded on its own, as the reference's separate tensor ops are: the tanh correction
-  // log(1 + 1e-6 - t^2) of a saturated action divides by ~1e-6 .. 1e-3, and a t*t left unrounded inside a fused
-  // multiply-add moves it (and the gradient through it) by up to 1e-4 relative.
+  // Every product below is rounded on its own, as the reference's separate tensor ops are (the library is built with
+  // -ffp-contract=off; the pragma keeps that true for this function whatever the build says): the tanh correction
+  // log(1 + 1e-6 - t^2) of a saturated action divides by ~1e-6 .. 1e-3, where one rounding more or less of t*t moves it
+  // (and the gradient through it) by up to 1e-4 relative.
 #pragma clang fp contract(off)
   TanhGaussFwd o;
   o.sigma = expf(clampf(raw, lo_ls, hi_ls));
@@ -136,7 +137,8 @@ DSACT_HD void tanh_gauss_bwd(float mu, float raw, float eps, float s, float lo_l
   const float sigma = expf(clampf(raw, lo_ls, hi_ls));
   const float x = mu + eps * sigma;
   const float t = tanhf(x);
-  const float omt2 = fmaf(-t, t, 1.0f);   // tanh backward: 1 - y*y in one rounding (ATen's vectorised kernel fuses it)
+  const float omt2 = fmaf(-t, t, 1.0f);   // tanh backward: 1 - y*y in ONE rounding, which is what ATen's vectorised kernel does
+                                          // (until round 3 this was 1.0f - t*t, two roundings: 6e-5 relative on saturated rows)
   const float t2 = t * t;                 // pow(t, 2): rounded, then subtracted from the rounded 1 + 1e-6
   const float g = 2.0f * t * omt2 / ((1.0f + kTanhEps) - t2);  // d logp / d x (tanh correction)
   const float dadx = s * omt2;
