@@ -166,7 +166,9 @@ struct dsact_handle {
   // were host time on the launch path)
   std::string env_timeline_stage;   // DSACT_TIMELINE_STAGE
   bool env_no_tile64 = false, env_no_hb_ride = false, env_no_merged_gather = false, env_no_adam_pack = false;
+  int n_cu = 256;                       // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   int env_conv_dw_nkt = 1;
+  bool env_conv_dw_fixed_chunk = false; // DSACT_CONV_DW_FIXED_CHUNK: every layer uses conv_dw_chunk(M) (A/B of conv_dw_pick_chunk)
   int env_ride_slots = 0;           // DSACT_RIDE_SLOTS: weight-gradient tiles riding in the policy-backward launch (default: one round)
   bool mirror_w0 = false;      // set while the merged-gather graph is being captured (see FusedOpt::mir_*)
   bool merged_graph = false;   // the captured graph uses the merged-gather flow
@@ -384,7 +386,8 @@ int launch(dsact_handle* h, const char* name, void (*kernel)(KArgs...), dim3 gri
     if (rc_ != DSACT_OK) return rc_; \
   } while (0)
 
-// pixels per split of a conv weight-gradient contraction (multiple of 64)
+// pixels per split of a conv weight-gradient contraction (multiple of 64): the SMALLEST the launch may use -- the partial
+// buffers are sized for it
 size_t conv_dw_chunk(size_t M) { return M >= 65536 ? 1024 : 256; }
 
 // ---- workspace carving ------------------------------------------------------------------------
@@ -1050,6 +1053,30 @@ int enqueue_conv_forward(dsact_handle* h) {
 // dL/d(features). Per layer: weight/bias gradient partials + ordered reduce (+ Adam/Polyak when `fused`),
 // then dCol = dY W and the col2im gather into the previous layer's dY.
 // stacks [st_lo, st_lo + n_st) of (q1, q2, policy)
+// Chunk actually used by layer j's k_conv_dw launch. A k_conv_dw workgroup holds 2 x (1 + NKT) LDS tiles, four fit a CU:
+// the chip runs 1,024 of them at a time and a launch of 1,106 (layer 0 at the minimum chunk) takes two full rounds, the
+// second one for 82 workgroups (found round 3: 44 us where ~25 are due; neither deeper prefetch nor half the address
+// arithmetic nor fewer L1 requests had moved it). Longer chunks mean fewer, longer workgroups: pick the multiple of 64
+// that minimises rounds x (start-up + steps) under the measured ~3 us + ~1.1 us per 64-pixel step.
+int conv_dw_pick_chunk(const dsact_handle* h, int j, int n_st) {
+  const ConvGeom& g = h->cg[j];
+  const long long M = (long long)h->B * g.OH * g.OW;
+  const int c0 = (int)conv_dw_chunk((size_t)M);
+  if (h->env_conv_dw_fixed_chunk || h->env_conv_dw_nkt != 1) return c0;
+  const int per_prob = j == 0 ? n_st : 1, n_prob = n_st / per_prob;
+  const long long per_chunk = (long long)tiles_of(per_prob * g.Cout, TM) * tiles_of(g.K + 4, TN) * n_prob;
+  const long long slots = 4LL * h->n_cu;
+  int best = c0;
+  double best_cost = 1e30;
+  for (int c = c0; c <= 16 * c0 && c <= 8192; c += 64) {
+    const long long blocks = ((M + c - 1) / c) * per_chunk;
+    const long long rounds = (blocks + slots - 1) / slots;
+    const double cost = (double)rounds * (3.0 + 1.1 * (c / 64));
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
 int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) {
   const int B = h->B;
   const int last = h->n_conv - 1;
@@ -1068,7 +1095,7 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
     const ConvGeom& g = h->cg[j];
     const int M = B * g.OH * g.OW;
     const std::string sfx = "_l" + std::to_string(j);
-    const int chunk = (int)conv_dw_chunk(M), n_chunks = (M + chunk - 1) / chunk, K1p = g.K + 4;
+    const int chunk = conv_dw_pick_chunk(h, j, n_st), n_chunks = (M + chunk - 1) / chunk, K1p = g.K + 4;
     {
       ConvDwArgs a;
       memset(&a, 0, sizeof(a));
@@ -1167,7 +1194,7 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
     for (int j = 0; j <= last; ++j) {
       const ConvGeom& g = h->cg[j];
       const int M = B * g.OH * g.OW;
-      const int chunk = (int)conv_dw_chunk(M);
+      const int chunk = conv_dw_pick_chunk(h, j, n_st);
       ConvReduceLayer& Ly = r.L[j];
       Ly.Cout = g.Cout; Ly.K = g.K; Ly.K1p = g.K + 4; Ly.n_chunks = (M + chunk - 1) / chunk;
       Ly.quads = g.Cout * Ly.K1p / 4;
@@ -2131,7 +2158,9 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->env_no_hb_ride = getenv("DSACT_NO_HB_RIDE") != nullptr;
   h->env_no_merged_gather = getenv("DSACT_NO_MERGED_GATHER") != nullptr;
   h->env_no_adam_pack = getenv("DSACT_NO_ADAM_PACK") != nullptr;
+  { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && v > 0) h->n_cu = v; (void)hipGetLastError(); }
   if (const char* v = getenv("DSACT_CONV_DW_NKT")) h->env_conv_dw_nkt = atoi(v);
+  h->env_conv_dw_fixed_chunk = getenv("DSACT_CONV_DW_FIXED_CHUNK") != nullptr;
   if (const char* v = getenv("DSACT_RIDE_SLOTS")) h->env_ride_slots = atoi(v);
   if (const char* v = getenv("DSACT_CHAIN_RG_PI")) h->env_chain_rg_pi = atoi(v);
   h->env_no_mixed_rg = getenv("DSACT_NO_MIXED_RG") != nullptr;

@@ -130,10 +130,11 @@ __global__ void __launch_bounds__(kThreads) k_conv_fwd(ConvStageArgs s) {
     const bool kv = k < g.K;           // K % 4 == 0: a quad is entirely inside or outside
     const int kc = kv ? k : 0;
     const int km = conv_kmap(g, kc);
-    P0 = *(const f32x4u*)(c.in + c.ro0 + km);
-    P1 = *(const f32x4u*)(c.in + c.ro1 + km);
-    Q0 = *(const f32x4u*)(c.q0p + kc);
-    Q1 = *(const f32x4u*)(c.q1p + kc);
+    // (quads past K -- 3/4 of the last k-tile at K = 144 -- read ONE fixed address: every distinct line is an L1 request)
+    P0 = *(const f32x4u*)(c.in + (kv ? c.ro0 + km : 0));
+    P1 = *(const f32x4u*)(c.in + (kv ? c.ro1 + km : 0));
+    Q0 = *(const f32x4u*)(kv ? c.q0p + kc : c.in);
+    Q1 = *(const f32x4u*)(kv ? c.q1p + kc : c.in);
     Msk m;
     m.p0 = kv && c.pv0; m.p1 = kv && c.pv1; m.q0 = kv && c.qv0; m.q1 = kv && c.qv1;
     return m;

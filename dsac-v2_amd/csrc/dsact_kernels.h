@@ -604,21 +604,29 @@ __device__ __forceinline__ f32x4 gload4(const float* p) {  // global (not flat) 
 // LDS image of a staged k-tile is ALWAYS [32 rows][KC_LD] with k contiguous, whatever the operand's
 // layout in memory: an MC operand (rows contiguous in memory) is transposed on the way in (4 scalar
 // ds_write_b32 per vector), so that every MFMA fragment is ONE ds_read_b128 instead of four ds_read_b32.
+// The 16-byte quads of a row are stored SWIZZLED: quad q of row r sits at quad q ^ ((r >> 3) & 3). With the plain
+// layout the transposing stores of a wave (rows 4j + e, j = 0..7, four consecutive k) fall into 16 of the 32 banks --
+// a 4-way conflict on every one of the 16 stores per thread and step, and the LDS is ONE unit per CU shared by the four
+// workgroups resident there (k_conv_dw: the staging, not the MFMAs, was the time; round 3). The XOR moves rows 8..15,
+// 16..23, 24..31 to other quads, which spreads those stores over all banks and leaves the ds_read_b128 fragments (8
+// consecutive rows per pass, (r >> 3) constant among them) and the 16-byte stores conflict-free as before.
+__device__ __forceinline__ int lds_quad(int row, int quad) { return (quad ^ ((row >> 3) & 3)) << 2; }
 template <bool MC>
 __device__ __forceinline__ void tile_store_lds(float* lds, int tid, const f32x4& r0, const f32x4& r1) {
   if (!MC) {
-    *(f32x4*)(lds + (tid >> 4) * KC_LD + (tid & 15) * 4) = r0;
-    *(f32x4*)(lds + ((tid >> 4) + 16) * KC_LD + (tid & 15) * 4) = r1;
+    const int ra = tid >> 4, rb = ra + 16, q = tid & 15;
+    *(f32x4*)(lds + ra * KC_LD + lds_quad(ra, q)) = r0;
+    *(f32x4*)(lds + rb * KC_LD + lds_quad(rb, q)) = r1;
   } else {
-    const int k = tid >> 3, row = (tid & 7) * 4;
-    float* p = lds + row * KC_LD + k;
+    const int k = tid >> 3, row = (tid & 7) * 4;     // rows row .. row+3 share (row >> 3); k + 32 is quad + 8: same swizzle
+    float* p = lds + row * KC_LD + lds_quad(row, k >> 2) + (k & 3);
     p[0] = r0.x; p[KC_LD] = r0.y; p[2 * KC_LD] = r0.z; p[3 * KC_LD] = r0.w;
     p[32] = r1.x; p[KC_LD + 32] = r1.y; p[2 * KC_LD + 32] = r1.z; p[3 * KC_LD + 32] = r1.w;
   }
 }
 
 __device__ __forceinline__ f32x4 frag_read(const float* lds, int row, int kk, int g) {
-  return *(const f32x4*)(lds + row * KC_LD + kk * 16 + 4 * g);
+  return *(const f32x4*)(lds + row * KC_LD + lds_quad(row, kk * 4 + g));
 }
 
 template <bool P_MC, bool Q_MC>
@@ -966,11 +974,12 @@ __device__ __forceinline__ void tile64_load(const float* __restrict__ base, int 
 template <bool MC>
 __device__ __forceinline__ void tile64_store_lds(float* lds, int tid, const f32x4& r0, const f32x4& r1) {
   if (!MC) {
-    *(f32x4*)(lds + (tid >> 4) * KC_LD + (tid & 15) * 4) = r0;
-    *(f32x4*)(lds + ((tid >> 4) + 32) * KC_LD + (tid & 15) * 4) = r1;
+    const int ra = tid >> 4, rb = ra + 32, q = tid & 15;
+    *(f32x4*)(lds + ra * KC_LD + lds_quad(ra, q)) = r0;
+    *(f32x4*)(lds + rb * KC_LD + lds_quad(rb, q)) = r1;
   } else {
     const int k = tid >> 4, row = (tid & 15) * 4;
-    float* p = lds + row * KC_LD + k;
+    float* p = lds + row * KC_LD + lds_quad(row, k >> 2) + (k & 3);
     p[0] = r0.x; p[KC_LD] = r0.y; p[2 * KC_LD] = r0.z; p[3 * KC_LD] = r0.w;
     p[32] = r1.x; p[KC_LD + 32] = r1.y; p[2 * KC_LD + 32] = r1.z; p[3 * KC_LD + 32] = r1.w;
   }
