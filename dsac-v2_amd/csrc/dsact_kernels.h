@@ -626,7 +626,8 @@ __device__ __forceinline__ void tile_store_lds(float* lds, int tid, const f32x4&
 }
 
 __device__ __forceinline__ f32x4 frag_read(const float* lds, int row, int kk, int g) {
-  return *(const f32x4*)(lds + row * KC_LD + lds_quad(row, kk * 4 + g));
+  // (kk * 4 + g) ^ s == kk * 4 + (g ^ s) for s < 4: the k-group stays an immediate offset of ONE per-thread base address
+  return *(const f32x4*)(lds + row * KC_LD + ((g ^ ((row >> 3) & 3)) << 2) + kk * 16);
 }
 
 template <bool P_MC, bool Q_MC>
