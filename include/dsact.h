@@ -289,10 +289,13 @@ const char* dsact_debug_names(void);
  * reference's update is one synchronous CPU call, dsac_v2.py:102-105). A consumer workgroup waits a BOUNDED time for
  * its producers; when it gives up, the next entry point of this library fails with DSACT_E_HIP, the merged launches are
  * disabled for the handle and a captured graph is captured again without them.
- *   dsact_debug_set(h, "withhold_flag", 1)      one producer never raises its flag (forces the timeout path)
+ *   dsact_debug_set(h, "withhold_flag", 1|2)    1: one forward producer never raises its ready flag; 2: one slice of the
+ *                                               policy backward never arrives (both force the timeout path)
  *   dsact_debug_set(h, "poison_handover", v)    fills every buffer handed from producers to consumers with v (e.g. NaN)
  *   dsact_debug_set(h, "fwd_merge", 0|1)        merged forward launch off / on (when the shape allows it)
- *   dsact_debug_get(h, "fwd_merge" | "fat" | "handoff_failures" | "graph_steps", &v) */
+ *   dsact_debug_set(h, "pi_merge", 0|1)         policy weight-gradient tiles inside the policy-backward launch off / on
+ *   dsact_debug_get(h, "fwd_merge" | "pi_merge" | "fat" | "handoff_failures" | "graph_steps" | "act_launch_us" |
+ *                      "act_wait_us", &v) */
 int dsact_debug_set(dsact_handle* h, const char* name, double value);
 int dsact_debug_get(const dsact_handle* h, const char* name, double* value);
 /* stand-alone fused-MLP forward of the policy net on a host batch (sampler / evaluator feed):
