@@ -240,6 +240,7 @@ struct dsact_handle {
   bool env_no_fast_act = false;         // DSACT_NO_FAST_ACT: the sampler's forward through the copy + tile-stage path (A/B)
   int env_chain_rg_pi = 0;              // DSACT_CHAIN_RG_PI (experiments)
   bool env_dw_4wave = false;            // DSACT_DW_4WAVE: k_dw2 keeps 4 waves per tile at every batch (A/B)
+  bool env_no_conv_dx_mfma = false;     // DSACT_NO_CONV_DX_MFMA: the 16-channel layer's data gradient with k_conv_dx_block (A/B)
   bool env_no_mixed_rg = false;         // DSACT_NO_MIXED_RG: every unit of the merged forward's group A runs 8-row workgroups (A/B)
   bool fwd_merge = false;               // launches A and B as one (batch <= 256)
   bool pi_merge = false;                // the policy's weight-gradient tiles + the closing block inside the policy-backward launch (batch <= 512; measured equal-to-slower at 1024)
@@ -1144,7 +1145,14 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
         c.x[st] = h->cact[S(st)][j - 1]; c.dx[st] = h->cdy[S(st)][j - 1];
       }
       const int Yq = (g.H + g.stride - 1) / g.stride, Xq = (g.W + g.stride - 1) / g.stride;   // largest parity class
-      if (g.KS == 3 && g.stride == 2) {
+      if (g.KS == 3 && g.stride == 2 && g.Cin == 16 && g.Cout == 32 && !h->env_no_conv_dx_mfma) {
+        // matrix-core variant (dsact_conv.h: k_conv_dx_mfma): two 16-pixel-pair tiles per wave. 16-channel layer: 43.9 ->
+        // 24.3 us; the 8-channel layer (half of every tile's columns idle) 30.9 -> 38.6 us, so it keeps the block kernel
+        const int Xq_ = (g.W + 1) / 2, Yc0 = (g.H + 1) / 2;
+        const int tiles0 = (B * Yc0 * Xq_ + 15) / 16;
+        const dim3 gm((unsigned)((tiles0 + 7) / 8), n_st, 2);
+        TRY(launch(h, ("conv_dx" + sfx).c_str(), (k_conv_dx_mfma<16, 32>), gm, dim3(kThreads), 0, c));
+      } else if (g.KS == 3 && g.stride == 2) {
         // one thread per 2x2 pixel block (all four parity classes); (one thread per pixel on the 16-channel layer, 4x the
         // workgroups: 72.5 us vs 42.6 us, round 3)
         const dim3 gb((unsigned)((B * Yq * Xq + kThreads - 1) / kThreads), n_st);
@@ -2164,6 +2172,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (const char* v = getenv("DSACT_RIDE_SLOTS")) h->env_ride_slots = atoi(v);
   if (const char* v = getenv("DSACT_CHAIN_RG_PI")) h->env_chain_rg_pi = atoi(v);
   h->env_no_mixed_rg = getenv("DSACT_NO_MIXED_RG") != nullptr;
+  h->env_no_conv_dx_mfma = getenv("DSACT_NO_CONV_DX_MFMA") != nullptr;
   h->env_dw_4wave = getenv("DSACT_DW_4WAVE") != nullptr;
   if (const char* v = getenv("DSACT_CHAIN_RG")) h->env_chain_rg = atoi(v) == 1 ? 1 : atoi(v) == 4 ? 4 : 2;
   h->dw_chunks = (h->B > 448 && h->B % 256 == 0 && getenv("DSACT_NO_SPLITK") == nullptr) ? h->B / 256 : 1;   // (chain path: below)

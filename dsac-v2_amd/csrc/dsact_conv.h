@@ -674,6 +674,117 @@ __global__ void __launch_bounds__(kThreads) k_conv_dx_block(ConvDxArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same data gradient on the matrix cores, wave-autonomous like k_conv_fwd_narrow (no LDS, no column buffer), for the
+// 3x3 / stride-2 layer with 16 input channels (round 3: 43.9 -> 24.3 us; with 8 input channels half of every tile's
+// columns are idle and the block kernel above wins, 30.9 vs 38.6 us; DSACT_NO_CONV_DX_MFMA=1 = A/B):
+//   an input pixel (y, x) = (2 yq + py, 2 xq + px) receives from the taps ky = py + 2 ay, kx = px + 2 ax (< 3), i.e. from
+//   the output pixels (yq - ay, xq - ax): per row parity py (grid.z) a tile is 16 consecutive (b, yq, xq) PAIRS of pixels
+//   (px = 0 and 1 of the same xq -- written as one contiguous 2 * Cin floats per lane group, whole lines per wave);
+//   A operand = the dY rows of the <= 4 neighbours (one dwordx4 per lane, neighbour and 16-channel group; rows outside
+//   the output image zeroed after landing), B operand = W[co][tap][ci] fragments held in registers for the whole wave,
+//   D lane (i, g) = dX[pixel i][ci = 4g .. 4g+3]: one 16-byte store per pixel of the pair, ReLU mask applied.
+// ---------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int PY>
+__device__ __forceinline__ void conv_dx_mfma_body(const ConvDxArgs& a, int pi) {
+  constexpr int NKK = COUT / 16, NAY = PY == 0 ? 2 : 1;
+  const ConvGeom& g = a.g;
+  const int lane = threadIdx.x & 63, i = lane & 15, gq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (kThreads / 64) + ((int)threadIdx.x >> 6));
+  const int n_waves = (int)gridDim.x * (kThreads / 64);
+  const int Yc = (g.H - PY + 1) >> 1, Xq = (g.W + 1) >> 1;
+  const int M = a.B * Yc * Xq, n_tiles = (M + 15) >> 4;
+  if (wave >= n_tiles) return;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const float inv_xq = 1.0f / (float)Xq, inv_yc = 1.0f / (float)Yc;
+  // weight fragments: wq[ay][kx][kk][e] = W[co = 16kk + 4gq + e][ky = PY + 2ay][kx][ci = i] (0 for i >= CIN)
+  f32x4 wq[NAY][3][NKK];
+  const float* __restrict__ wb = a.w[pi];
+#pragma unroll
+  for (int ay = 0; ay < NAY; ++ay)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        f32x4 v = zero;
+        if (i < CIN) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = wb[(size_t)(16 * kk + 4 * gq + e) * g.K + ((PY + 2 * ay) * 3 + kx) * CIN + i];
+        }
+        wq[ay][kx][kk] = v;
+      }
+  const float* __restrict__ dyb = a.dy[pi];
+  struct Tile { f32x4 A[NAY][2][NKK]; bool v[NAY][2]; int b, yq, xq; bool ok; };
+  auto load_tile = [&](int tile, Tile& T) {
+    const int m = tile * 16 + i;
+    T.ok = m < M;
+    const int mc = T.ok ? m : M - 1;
+    const int t1 = fast_div(mc, Xq, inv_xq);
+    T.xq = mc - t1 * Xq;
+    T.b = fast_div(t1, Yc, inv_yc);
+    T.yq = t1 - T.b * Yc;
+#pragma unroll
+    for (int ay = 0; ay < NAY; ++ay)
+#pragma unroll
+      for (int ax = 0; ax < 2; ++ax) {
+        const int oy = T.yq - ay, ox = T.xq - ax;
+        T.v[ay][ax] = T.ok && oy >= 0 && oy < g.OH && ox >= 0 && ox < g.OW;
+        const float* row = dyb + (((size_t)T.b * g.OH + (T.v[ay][ax] ? oy : 0)) * g.OW + (T.v[ay][ax] ? ox : 0)) * COUT + 4 * gq;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) T.A[ay][ax][kk] = *(const f32x4u*)(row + 16 * kk);   // raw: masked at use
+      }
+  };
+  auto compute = [&](const Tile& T) {
+    f32x4 acc0 = zero, acc1 = zero;      // px = 0, px = 1
+#pragma unroll
+    for (int ay = 0; ay < NAY; ++ay)
+#pragma unroll
+      for (int ax = 0; ax < 2; ++ax)
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+          const f32x4 av = T.v[ay][ax] ? T.A[ay][ax][kk] : zero;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[ay][2 * ax][kk][e], av[e], acc0, 0, 0, 0);          // kx = 0 / 2
+            if (ax == 0) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[ay][1][kk][e], av[e], acc1, 0, 0, 0);  // kx = 1
+          }
+        }
+    if (T.ok && 4 * gq < CIN) {
+      const int y = 2 * T.yq + PY, x0 = 2 * T.xq;
+      const size_t o = (((size_t)T.b * g.H + y) * g.W + x0) * CIN + 4 * gq;
+      const f32x4 xv0 = *(const f32x4u*)(a.x[pi] + o);
+      f32x4 r0 = acc0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r0[e] = xv0[e] > 0.f ? r0[e] : 0.f;
+      *(f32x4u*)(a.dx[pi] + o) = r0;
+      if (x0 + 1 < g.W) {
+        const f32x4 xv1 = *(const f32x4u*)(a.x[pi] + o + CIN);
+        f32x4 r1 = acc1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r1[e] = xv1[e] > 0.f ? r1[e] : 0.f;
+        *(f32x4u*)(a.dx[pi] + o + CIN) = r1;
+      }
+    }
+  };
+  Tile Ta, Tb;
+  const int last = n_tiles - 1;
+  load_tile(wave, Ta);
+  for (int tile = wave; tile < n_tiles; tile += 2 * n_waves) {
+    const int nx = tile + n_waves;
+    load_tile(nx < last ? nx : last, Tb);     // unconditional (clamped): no branch between the loads and the MFMAs
+    compute(Ta);
+    if (nx >= n_tiles) break;
+    const int n2 = nx + n_waves;
+    load_tile(n2 < last ? n2 : last, Ta);
+    compute(Tb);
+  }
+}
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(kThreads) k_conv_dx_mfma(ConvDxArgs a) {
+  if (blockIdx.z == 0) conv_dx_mfma_body<CIN, COUT, 0>(a, (int)blockIdx.y);
+  else conv_dx_mfma_body<CIN, COUT, 1>(a, (int)blockIdx.y);
+}
+
 // sums the partials in a fixed order, writes the gradient and (single-GPU path) applies Adam / Polyak.
 // ONE launch for all layers of all differentiated stacks (it runs after the whole conv backward, so every use of the
 // pre-update weights is behind it): six tiny reduces as separate launches cost 65 us of launch latency per update.
