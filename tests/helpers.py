@@ -87,3 +87,27 @@ def humanoid_digest():
         np.testing.assert_allclose(sums, z["s%d/in_sums" % it], rtol=1e-12, atol=1e-12)
         steps.append(({k: torch.as_tensor(v) for k, v in b.items()}, noise))
     return z, cfg, init, steps
+
+
+def policy_saturation_budget(orc, data, noise, B):
+    """What fp32 itself does to the POLICY gradient when an action sits on its limit (the gradient-side twin of the
+    log-prob budget in compare_intermediates): d logp / dx = 2 t (1 - t^2) / (1 + 1e-6 - t^2) with t = tanh(x) rounded to
+    6e-8 and t^2 once more -- numerator and denominator each carry ~1.2e-7 of absolute noise (which of the two products
+    is fused differs between ATen's kernels and any other evaluation order), i.e. a RELATIVE noise of 2.4e-7 / (1 + 1e-6 -
+    t^2) on a factor of magnitude <= 2 that enters d loss / d mean as alpha / B and d loss / d std as alpha / B * |eps|.
+    For every (row, dimension) where that exceeds 1e-5 the noise is pushed through the oracle's own policy net
+    (|d logit / d theta| by autograd) -- an element-wise bound, zero for batches without saturated actions."""
+    from oracle.dsact_oracle import policy_forward
+
+    params = orc.p["policy"]
+    logits = policy_forward(data["obs"], params, orc.cfg, None, (orc.act_sides or {}).get("pi"))
+    A = logits.shape[1] // 2
+    x = (logits[:, :A] + noise["eps_new"] * logits[:, A:]).detach().double()
+    rel = 2.4e-7 / (1.0 + 1e-6 - torch.tanh(x) ** 2)
+    d_mean = orc._alpha() / B * 2.0 * rel
+    budget = [torch.zeros_like(p, dtype=torch.float64) for p in params]
+    for b, k in (rel > 1e-5).nonzero().tolist():
+        for col, w in ((k, float(d_mean[b, k])), (A + k, float(d_mean[b, k]) * abs(float(noise["eps_new"][b, k])))):
+            for acc, g in zip(budget, torch.autograd.grad(logits[b, col], params, retain_graph=True)):
+                acc += w * g.abs().double()
+    return torch.cat([t.reshape(-1) for t in budget]).numpy()
