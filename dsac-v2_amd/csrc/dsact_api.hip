@@ -250,6 +250,29 @@ struct dsact_handle {
   float* X0t = nullptr;                 // transposed pack of the staged minibatch [roundup32(F+A) x B]
   int dw2_off[4] = {0, 0, 0, 0};        // tile ranges of q1, q2, policy in the dw2 problem list
   int n_heads_parts = 0;                // partial (tanh, sigma) sums the last forward wrote
+  // pipelined graph (delayed-update-aware software pipelining, k_chain_fwdp): per-minibatch buffers in kPipeSets copies
+  // (set 0 = the workspace's own), one captured graph per phase first_iteration % delay_update
+  struct PipeSet {
+    float *X0 = nullptr, *XP = nullptr, *X2 = nullptr, *rew = nullptr, *done = nullptr;
+    float *eps_new = nullptr, *eps_2 = nullptr, *z5 = nullptr, *z6 = nullptr;
+    float *logits_pi = nullptr, *logits_pit = nullptr, *logp_new = nullptr, *logp2 = nullptr;
+    float* Hpi[DSACT_MAX_HIDDEN_LAYERS]; float* Gpi[DSACT_MAX_HIDDEN_LAYERS];
+    float* qout_t[2] = {nullptr, nullptr};
+    float* part_heads = nullptr;
+  };
+  static constexpr int kPipeSets = 4;
+  static constexpr int kPipePhases = 4;
+  PipeSet pset[kPipeSets];
+  char* pipe_ws = nullptr;
+  bool pipe_graph = false;              // the captured graphs are the pipelined ones (pgraph / pexec, one per phase)
+  hipGraph_t pgraph[kPipePhases] = {nullptr, nullptr, nullptr, nullptr};
+  hipGraphExec_t pexec[kPipePhases] = {nullptr, nullptr, nullptr, nullptr};
+  PipeFwd* pargs[kPipePhases] = {nullptr, nullptr, nullptr, nullptr};   // device: one PipeFwd per captured forward launch
+  bool env_no_pipe = false;             // DSACT_NO_PIPE: graph replays without the pipelining (A/B)
+  int env_pipe_qt = 0;                  // DSACT_PIPE_QT=1: q_target(obs2', act2') of the next minibatch is precomputed too
+  int env_pipe_rg_next = 2;             // DSACT_PIPE_RG_NEXT=1|2: rows / 4 per workgroup of the next minibatch's policy units
+  int env_pipe_rg_side = 2;             // DSACT_PIPE_RG_SIDE=1|2: rows / 4 per workgroup of the units off the critical path (pit, q_c, q_t)
+  std::string env_pipe_map;             // DSACT_PIPE_MAP: XCD lists per unit (experiments), see pipe_xcds
   // native collective (RCCL): communicator of this rank, see dsact_comm_init
   void* comm = nullptr;
   int comm_rank = 0, comm_world = 1;
@@ -1476,7 +1499,7 @@ FwdUnit fwd_unit(const dsact_handle* h, int ch, int seg, int head) {
 void fill_fwd_common(dsact_handle* h, FwdArgs& a, int rg, const char* name, const XcdMap* map = nullptr) {
   for (int k = 0; k < a.n_units; ++k) {
     if (!a.u[k].rg) a.u[k].rg = rg;
-    a.u[k].n_slices = h->B / (4 * a.u[k].rg);
+    a.u[k].n_slices = (short)(h->B / (4 * a.u[k].rg));
   }
   a.map = map ? *map : xcd_map_uniform(a.n_units);
   a.B = h->B; a.F = h->F; a.A = h->A; a.L = h->L; a.ldx = h->ldx;
@@ -1553,7 +1576,7 @@ int launch_chain_fwd(dsact_handle* h, const char* name, FwdArgs& a) {
   fill_fwd_common(h, a, rg, name);
   const int grid = fwd_grid(a);
   const size_t lds = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 4 * rg).total * sizeof(float);
-  if (a.u[0].part_heads) h->n_heads_parts = a.u[0].n_slices;
+  if (a.u[0].part_heads) h->n_heads_parts = h->B / 4;   // one partial per four rows whatever the rows per workgroup (chain_fwd_body)
 #define CALL_CF(N, G) return launch(h, name, k_chain_fwd<N, G>, dim3(grid), dim3(64 * N), lds, a)
 #define CALL_CFG(N, G) return launch(h, name, k_chain_fwd<N, G, true>, dim3(grid), dim3(64 * N), lds, a)
   if (generic_act(h)) CHAIN_NT(CALL_CFG, rg);
@@ -1594,7 +1617,7 @@ int enqueue_chain_fwd_merged(dsact_handle* h) {
   }
   fill_fwd_common(h, m.A, rga, "chain_fwd", mixed ? &mixed_map : nullptr);
   fill_fwd_common(h, m.B, rgb, "chain_fwd");
-  h->n_heads_parts = m.A.u[0].n_slices;
+  h->n_heads_parts = h->B / 4;   // one partial per four rows whatever the rows per workgroup (chain_fwd_body)
   int* f = h->chain_flags;
   for (int k = 0; k < 6; ++k) m.A.u[k].done = f + k * kChainFlagSlices;   // pi, pit, q1c, q2c, q1t(obs), q2t(obs)
   for (int i = 0; i < 2; ++i) {
@@ -1622,6 +1645,219 @@ int enqueue_chain_fwd_merged(dsact_handle* h) {
   if (h->cNT == 1) return launch(h, "chain_fwd", k_chain_fwd2<1>, dim3(grid), dim3(64), lds, m);
   if (h->cNT == 2) return launch(h, "chain_fwd", k_chain_fwd2<2>, dim3(grid), dim3(128), lds, m);
   return launch(h, "chain_fwd", k_chain_fwd2<4>, dim3(grid), dim3(256), lds, m);
+}
+
+// ---- pipelined graph (k_chain_fwdp, dsact_chain.h) ---------------------------------------------------------------
+// Per-minibatch buffers exist kPipeSets times: update s of a captured graph of n updates works on set (s - (n-1)) & 3 (the
+// LAST update on set 0 = the workspace's own buffers, so whatever reads the handle after a replay -- statistics, debug
+// reads, dsact_read_batch -- sees the last update as after eager updates), update s's forward launch may also fill set
+// s + 1 (policy units of the next minibatch), and the gather riding in update s's critic-backward launch fills set s + 2.
+int alloc_pipe_sets(dsact_handle* h) {
+  if (h->pipe_ws) return DSACT_OK;
+  const size_t B = h->B;
+  const int A = h->A, L = h->L;
+  for (int pass = 0; pass < 2; ++pass) {
+    Carver c;
+    c.base = pass ? h->pipe_ws : nullptr;
+    for (int k = 1; k < dsact_handle::kPipeSets; ++k) {
+      dsact_handle::PipeSet& p = h->pset[k];
+      p.X0 = c.take<float>(B * h->ldx); p.XP = c.take<float>(B * h->ldx); p.X2 = c.take<float>(B * h->ldx);
+      p.rew = c.take<float>(B); p.done = c.take<float>(B);
+      p.eps_new = c.take<float>(B * A); p.eps_2 = c.take<float>(B * A); p.z5 = c.take<float>(B); p.z6 = c.take<float>(B);
+      p.logits_pi = c.take<float>(B * 2 * A); p.logits_pit = c.take<float>(B * 2 * A);
+      p.logp_new = c.take<float>(B); p.logp2 = c.take<float>(B);
+      for (int l = 0; l < L; ++l) { p.Hpi[l] = c.take<float>(B * h->w[l]); p.Gpi[l] = c.take<float>(B * h->w[l]); }
+      for (int i = 0; i < 2; ++i) p.qout_t[i] = c.take<float>(B * 2);
+      p.part_heads = c.take<float>((size_t)h->n_heads_wg * 2);
+    }
+    if (!pass) {
+      HIPCHK(h, hipMalloc((void**)&h->pipe_ws, c.off + 256));
+      HIPCHK(h, hipMemset(h->pipe_ws, 0, c.off + 256));
+    }
+  }
+  dsact_handle::PipeSet& p0 = h->pset[0];
+  p0.X0 = h->X0; p0.XP = h->XP; p0.X2 = h->X2; p0.rew = h->rew; p0.done = h->done;
+  p0.eps_new = h->eps_new; p0.eps_2 = h->eps_2; p0.z5 = h->z5; p0.z6 = h->z6;
+  p0.logits_pi = h->logits_pi; p0.logits_pit = h->logits_pit; p0.logp_new = h->logp_new; p0.logp2 = h->logp2;
+  for (int l = 0; l < L; ++l) { p0.Hpi[l] = h->Hb[C_PI][l]; p0.Gpi[l] = h->Gb[C_PI][l]; }
+  for (int i = 0; i < 2; ++i) p0.qout_t[i] = h->qout_t[i];
+  p0.part_heads = h->part_heads;
+  return DSACT_OK;
+}
+
+// the handle's per-minibatch pointers := set k (every args builder reads the handle); k = 0 restores the workspace's own
+void apply_pipe_set(dsact_handle* h, int k) {
+  const dsact_handle::PipeSet& p = h->pset[k];
+  h->X0 = p.X0; h->XP = p.XP; h->X2 = p.X2; h->rew = p.rew; h->done = p.done;
+  h->eps_new = p.eps_new; h->eps_2 = p.eps_2; h->z5 = p.z5; h->z6 = p.z6;
+  h->logits_pi = p.logits_pi; h->logits_pit = p.logits_pit; h->logp_new = p.logp_new; h->logp2 = p.logp2;
+  for (int l = 0; l < h->L; ++l) { h->Hb[C_PI][l] = p.Hpi[l]; h->Gb[C_PI][l] = p.Gpi[l]; }
+  for (int i = 0; i < 2; ++i) h->qout_t[i] = p.qout_t[i];
+  h->part_heads = p.part_heads;
+  h->Xc[C_PI] = h->Xc[C_Q1C] = h->Xc[C_Q2C] = h->X0;
+  h->Xc[C_PIT] = h->Xc[C_Q1T] = h->Xc[C_Q2T] = h->X2;
+  h->Xc[C_Q1P] = h->Xc[C_Q2P] = h->XP;
+}
+
+// roles of a pipelined forward launch, in dispatch-priority order: units that never wait, own minibatch then next; then
+// their consumers. A unit waits only for units EARLIER in this order, and every XCD's queue is filled in this order.
+enum PipeRole { PR_PI = 0, PR_PIT, PR_Q1C, PR_Q2C, PR_PIN, PR_PITN, PR_Q1P, PR_Q2P, PR_Q1T, PR_Q2T, PR_Q1TN, PR_Q2TN, PR_N };
+static const char* kPipeRoleName[PR_N] = {"pi", "pit", "q1c", "q2c", "pin", "pitn", "q1p", "q2p", "q1t", "q2t", "q1tn", "q2tn"};
+static_assert(PR_N <= kPipeUnits, "unit table too small");
+
+// XCDs of a role in a launch shape (pre = the policy units of this minibatch were computed by the previous launch, do_pre =
+// this launch computes the next minibatch's): a digit string, slices dealt round-robin over it. Placement is speed only.
+// DSACT_PIPE_MAP="FT.pi=017:1;TF.q1t=45:2;..." overrides a role's XCDs (and, after ':', its rows per workgroup / 4).
+static const char* pipe_xcds_default(bool pre, bool do_pre, int role) {
+  if (!pre) {   // FF / FT: pi -> q_p is the critical path; pi alone on its CUs, everything else beside a non-critical unit
+    static const char* t[PR_N] = {"017", "2", "3", "4", "5", "6", "30", "41", "57", "62", "57", "62"};
+    return t[role];
+  }
+  if (!do_pre) {   // TF: only the fresh-critic chains; q_c and q_p one workgroup per CU, q_t in the second slots beside q_p
+    static const char* t[PR_N] = {"", "", "01", "23", "", "", "45", "67", "45", "67", "", ""};
+    return t[role];
+  }
+  static const char* t[PR_N] = {"", "", "01", "23", "4", "5", "60", "72", "46", "57", "46", "57"};   // TT (delay_update >= 3)
+  return t[role];
+}
+
+struct PipePlace { std::string xcds; int rg; };
+static PipePlace pipe_place(const dsact_handle* h, bool pre, bool do_pre, int role, int rg_default) {
+  PipePlace pl;
+  pl.xcds = pipe_xcds_default(pre, do_pre, role);
+  pl.rg = rg_default;
+  if (!h->env_pipe_map.empty()) {
+    const std::string key = std::string(pre ? "T" : "F") + (do_pre ? "T" : "F") + "." + kPipeRoleName[role] + "=";
+    size_t at = 0;
+    while ((at = h->env_pipe_map.find(key, at)) != std::string::npos) {
+      if (at == 0 || h->env_pipe_map[at - 1] == ';') {
+        size_t e = h->env_pipe_map.find(';', at);
+        std::string v = h->env_pipe_map.substr(at + key.size(), e == std::string::npos ? std::string::npos : e - at - key.size());
+        const size_t c = v.find(':');
+        if (c != std::string::npos) { pl.rg = atoi(v.c_str() + c + 1) == 1 ? 1 : 2; v = v.substr(0, c); }
+        std::string x;
+        for (char ch : v) if (ch >= '0' && ch <= '7') x += ch;
+        if (!x.empty()) pl.xcds = x;
+        break;
+      }
+      at += key.size();
+    }
+  }
+  if (pl.xcds.empty()) pl.xcds = "01234567";
+  return pl;
+}
+
+// fills P for the forward launch of a pipelined update: own minibatch = set_own (pre: its policy units ran in the previous
+// launch), next minibatch = set_next (do_pre: its policy units run here). Leaves the handle on set_own.
+int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do_pre, PipeFwd& P) {
+  memset(&P, 0, sizeof(P));
+  const bool qt_pre = h->env_pipe_qt != 0;
+  int* f = h->chain_flags;
+  const int B = h->B;
+  int idx[PR_N];
+  for (int r = 0; r < PR_N; ++r) idx[r] = -1;
+  int rgs[PR_N];
+  std::string xc[PR_N];
+  // rows per workgroup: the critical units (pi -> q_p) run 4-row workgroups; the others 8-row ones (39 % less CU time per
+  // row) unless the launch leaves CUs idle anyway; a consumer never has more rows than its producer (it waits for ONE flag)
+  const int side = (B % 8 == 0) ? h->env_pipe_rg_side : 1, nxt = (B % 8 == 0) ? h->env_pipe_rg_next : 1;
+  const int dflt[PR_N] = {1, side, pre ? 1 : side, pre ? 1 : side, nxt, nxt, 1, 1, side, side, side, side};
+  for (int r = 0; r < PR_N; ++r) {
+    const PipePlace pl = pipe_place(h, pre, do_pre, r, dflt[r]);
+    rgs[r] = (B % 8 == 0) ? pl.rg : 1; xc[r] = pl.xcds;
+  }
+  auto cap = [&](int consumer, int producer) { if (rgs[consumer] > rgs[producer]) rgs[consumer] = rgs[producer]; };
+  cap(PR_Q1P, PR_Q1C); cap(PR_Q2P, PR_Q2C);
+  if (!pre) { cap(PR_Q1P, PR_PI); cap(PR_Q2P, PR_PI); cap(PR_Q1T, PR_PIT); cap(PR_Q2T, PR_PIT); }
+  cap(PR_Q1TN, PR_PITN); cap(PR_Q2TN, PR_PITN);
+  auto put = [&](int role, const FwdUnit& u) {
+    idx[role] = role;
+    P.u[role] = u;
+    P.u[role].rg = (short)rgs[role];
+    P.u[role].n_slices = (short)(B / (4 * rgs[role]));
+  };
+  auto policy_units = [&](int r_pi, int r_pit, bool flag_pi, bool flag_pit) {
+    FwdUnit pi = fwd_unit(h, C_PI, SEG_FULL, HEAD_POLICY);
+    pi.logits = h->logits_pi; pi.logp = h->logp_new; pi.eps = h->eps_new; pi.xact = h->Xc[C_Q1P]; pi.part_heads = h->part_heads;
+    if (flag_pi) pi.done = f + 0 * kChainFlagSlices;
+    put(r_pi, pi);
+    FwdUnit pt = fwd_unit(h, C_PIT, SEG_FULL, HEAD_POLICY);
+    pt.logits = h->logits_pit; pt.logp = h->logp2; pt.eps = h->eps_2; pt.xact = h->Xc[C_Q1T];
+    for (int l = 0; l < h->L; ++l) pt.G[l] = nullptr;   // never differentiated
+    if (flag_pit) pt.done = f + (r_pit == PR_PIT ? 1 : 4) * kChainFlagSlices;
+    put(r_pit, pt);
+  };
+  auto target_units = [&](int r_q1t, int r_pit, bool wait) {
+    for (int i = 0; i < 2; ++i) {
+      FwdUnit qt = fwd_unit(h, C_Q1T + i, SEG_FULL_SPLIT, HEAD_Q);
+      qt.qout = h->qout_t[i];
+      for (int l = 0; l < h->L; ++l) qt.G[l] = nullptr;   // never differentiated
+      if (wait) { qt.wait0 = P.u[r_pit].done; qt.wait_rows0 = 4 * rgs[r_pit]; qt.late_wait = 1; }
+      put(r_q1t + i, qt);
+    }
+  };
+  apply_pipe_set(h, set_own);
+  if (!pre) policy_units(PR_PI, PR_PIT, true, true);
+  for (int i = 0; i < 2; ++i) {
+    FwdUnit qc = fwd_unit(h, C_Q1C + i, SEG_FULL_SAVE, HEAD_Q);
+    qc.zsave = h->zobs[i]; qc.qout = h->qout_c[i]; qc.qstd = h->qstd_c[i];
+    if (i == 0) qc.x0t = h->X0t;
+    qc.zdone = f + (2 + i) * kChainFlagSlices;
+    put(PR_Q1C + i, qc);
+    FwdUnit qp = fwd_unit(h, C_Q1P + i, SEG_ACT_FROM_SAVED, HEAD_Q);
+    qp.zinit = h->zobs[i]; qp.qout = h->qout_p[i];
+    if (!pre) { qp.wait0 = P.u[PR_PI].done; qp.wait_rows0 = 4 * rgs[PR_PI]; }
+    qp.wait1 = qc.zdone; qp.wait_rows1 = 4 * rgs[PR_Q1C + i];
+    put(PR_Q1P + i, qp);
+  }
+  if (!pre || !qt_pre) target_units(PR_Q1T, PR_PIT, !pre);
+  if (do_pre) {
+    apply_pipe_set(h, set_next);
+    policy_units(PR_PIN, PR_PITN, false, qt_pre);
+    if (qt_pre) target_units(PR_Q1TN, PR_PITN, true);
+    apply_pipe_set(h, set_own);
+  }
+  // common fields
+  FwdArgs& a = P.c;
+  a.n_units = PR_N;
+  a.B = h->B; a.F = h->F; a.A = h->A; a.L = h->L; a.ldx = h->ldx;
+  a.s_obs = h->s_obs; a.s_act = h->s_act; a.v1_stats = 0; a.Cb = h->B / 16;
+  a.act_scale = h->act_scale; a.act_center = h->act_center; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
+  a.timeline = tl_for(h, "chain_fwd");
+  a.spin_timeout = h->handoff_dev;
+  a.debug_withhold = h->debug_withhold == 1;
+  // block table: every XCD's queue is filled role by role (the enum is the priority order), a role's slices are dealt
+  // round-robin over its XCDs; block 8 r + x = entry r of XCD x's queue (the dispatcher places block b on XCD b % 8)
+  std::vector<int> q[8];
+  for (int r = 0; r < PR_N; ++r) {
+    if (idx[r] < 0) continue;
+    const int ns = P.u[r].n_slices;
+    for (int sl = 0; sl < ns; ++sl) q[xc[r][sl % xc[r].size()] - '0'].push_back((r << 16) | sl);
+  }
+  size_t rounds = 0;
+  for (int x = 0; x < 8; ++x) rounds = q[x].size() > rounds ? q[x].size() : rounds;
+  if (8 * rounds > (size_t)kPipeMaxBlocks) return fail(h, DSACT_E_INVALID, "pipelined forward: block table too small");
+  P.n_blocks = (int)(8 * rounds);
+  for (size_t r = 0; r < rounds; ++r)
+    for (int x = 0; x < 8; ++x) P.blk[8 * r + x] = r < q[x].size() ? q[x][r] : -1;
+  h->n_heads_parts = h->B / 4;
+  return DSACT_OK;
+}
+
+int launch_chain_fwd_pipe(dsact_handle* h, const PipeFwd& host, const PipeFwd* dev) {
+  // (forwards of a complete update: the critics' backward clears the ready flags)
+  if (h->flags_dirty) HIPCHK(h, hipMemsetAsync(h->chain_flags, 0, kChainFlags * sizeof(int), h->stream));
+  h->flags_dirty = true;
+  const size_t lds = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 8).total * sizeof(float);
+  const int grid = host.n_blocks;
+  if (generic_act(h)) {
+    if (h->cNT == 1) return launch(h, "chain_fwd", k_chain_fwdp<1, true>, dim3(grid), dim3(64), lds, dev);
+    if (h->cNT == 2) return launch(h, "chain_fwd", k_chain_fwdp<2, true>, dim3(grid), dim3(128), lds, dev);
+    return launch(h, "chain_fwd", k_chain_fwdp<4, true>, dim3(grid), dim3(256), lds, dev);
+  }
+  if (h->cNT == 1) return launch(h, "chain_fwd", k_chain_fwdp<1>, dim3(grid), dim3(64), lds, dev);
+  if (h->cNT == 2) return launch(h, "chain_fwd", k_chain_fwdp<2>, dim3(grid), dim3(128), lds, dev);
+  return launch(h, "chain_fwd", k_chain_fwdp<4>, dim3(grid), dim3(256), lds, dev);
 }
 
 // loss + dZ chains of the critics (n_units 2: q1c, q2c only -- off iterations of the delayed update) and of
@@ -2035,8 +2271,15 @@ int enqueue_adam(dsact_handle* h, bool from_parts) {
 void drop_graphs(dsact_handle* h) {
   if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
   if (h->graph) { hipGraphDestroy(h->graph); h->graph = nullptr; }
+  for (int p = 0; p < dsact_handle::kPipePhases; ++p) {
+    if (h->pexec[p]) { hipGraphExecDestroy(h->pexec[p]); h->pexec[p] = nullptr; }
+    if (h->pgraph[p]) { hipGraphDestroy(h->pgraph[p]); h->pgraph[p] = nullptr; }
+    if (h->pargs[p]) { hipFree(h->pargs[p]); h->pargs[p] = nullptr; }
+  }
+  h->pipe_graph = false;
   h->graph_steps = 0;
 }
+bool have_graph(const dsact_handle* h) { return h->graph_exec != nullptr || h->pipe_graph; }
 
 // In-launch hand-overs (merged forward / backward launches) use BOUNDED spins: a consumer that waited ~0.1 s for its
 // producers' flags gives up, computes on whatever it finds and writes the hand-off word in mapped host memory. Every
@@ -2049,7 +2292,7 @@ int check_handoff(dsact_handle* h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   *(volatile int*)h->handoff_host = 0;
-  const bool had_graph = h->graph_exec != nullptr;
+  const bool had_graph = have_graph(h);
   const int steps = h->graph_steps;
   const uint32_t gflags = h->graph_flags;
   h->fwd_merge = false;
@@ -2172,6 +2415,11 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (const char* v = getenv("DSACT_RIDE_SLOTS")) h->env_ride_slots = atoi(v);
   if (const char* v = getenv("DSACT_CHAIN_RG_PI")) h->env_chain_rg_pi = atoi(v);
   h->env_no_mixed_rg = getenv("DSACT_NO_MIXED_RG") != nullptr;
+  h->env_no_pipe = getenv("DSACT_NO_PIPE") != nullptr;
+  if (const char* v = getenv("DSACT_PIPE_QT")) h->env_pipe_qt = atoi(v) ? 1 : 0;
+  if (const char* v = getenv("DSACT_PIPE_RG_NEXT")) h->env_pipe_rg_next = atoi(v) == 1 ? 1 : 2;
+  if (const char* v = getenv("DSACT_PIPE_RG_SIDE")) h->env_pipe_rg_side = atoi(v) == 1 ? 1 : 2;
+  if (const char* v = getenv("DSACT_PIPE_MAP")) h->env_pipe_map = v;
   h->env_no_conv_dx_mfma = getenv("DSACT_NO_CONV_DX_MFMA") != nullptr;
   h->env_dw_4wave = getenv("DSACT_DW_4WAVE") != nullptr;
   if (const char* v = getenv("DSACT_CHAIN_RG")) h->env_chain_rg = atoi(v) == 1 ? 1 : atoi(v) == 4 ? 4 : 2;
@@ -2292,6 +2540,12 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdp<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdp<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdp<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdp<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdp<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdp<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
@@ -2355,6 +2609,7 @@ int dsact_destroy(dsact_handle* h) {
   if (h->d_tiles) hipFree(h->d_tiles);
   if (h->alt.d_tiles) hipFree(h->alt.d_tiles);
   if (h->alt_ws) hipFree(h->alt_ws);
+  if (h->pipe_ws) hipFree(h->pipe_ws);
   if (h->pk_ws) hipFree(h->pk_ws);
   if (h->d_mir) hipFree(h->d_mir);
   if (h->d_apjobs) hipFree(h->d_apjobs);
@@ -2382,7 +2637,7 @@ int dsact_destroy(dsact_handle* h) {
 int dsact_set_stream(dsact_handle* h, void* s) {
   if (!h) return DSACT_E_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
-  if (h->graph_exec) return fail(h, DSACT_E_STATE, "cannot change stream after dsact_graph_build");
+  if (have_graph(h)) return fail(h, DSACT_E_STATE, "cannot change stream after dsact_graph_build");
   if (h->stream) HIPCHK(h, hipStreamSynchronize(h->stream));
   if (h->own_stream && h->stream) { hipStreamDestroy(h->stream); h->stream = nullptr; }
   if (s) { h->stream = (hipStream_t)s; h->own_stream = false; }
@@ -2408,7 +2663,7 @@ int dsact_bind_arenas(dsact_handle* h, float* online, float* target, float* adam
   if (!h) return DSACT_E_INVALID;
   if (!online || !target || !adam_m || !adam_v || !grads) return fail(h, DSACT_E_INVALID, "null arena pointer");
   HIPCHK(h, hipSetDevice(h->device));
-  if (h->graph_exec) return fail(h, DSACT_E_STATE, "cannot rebind arenas after dsact_graph_build");
+  if (have_graph(h)) return fail(h, DSACT_E_STATE, "cannot rebind arenas after dsact_graph_build");
   h->online = online; h->target = target; h->adam_m = adam_m; h->adam_v = adam_v; h->grads = grads;
   TRY(build_chain(h));
   TRY(build_pack_jobs(h));
@@ -2730,7 +2985,7 @@ int dsact_upload_index_table(dsact_handle* h, const int64_t* idx_host, int32_t r
     if (idx_host[i] < 0 || idx_host[i] >= h->size) return fail(h, DSACT_E_INVALID, "index out of range");
     tmp[i] = (int)idx_host[i];
   }
-  if (h->graph_exec && rows != h->idx_rows) return fail(h, DSACT_E_STATE, "index table shape is baked into the captured graph");
+  if (have_graph(h) && rows != h->idx_rows) return fail(h, DSACT_E_STATE, "index table shape is baked into the captured graph");
   if (!h->idx_table || rows != h->idx_rows) {
     if (h->idx_table) hipFree(h->idx_table);
     HIPCHK(h, hipMalloc(&h->idx_table, n * sizeof(int)));
@@ -2756,7 +3011,7 @@ int dsact_set_noise(dsact_handle* h, const float* eps_new, const float* eps_2, c
 
 int dsact_set_device_rng(dsact_handle* h, uint64_t seed) {
   if (!h) return DSACT_E_INVALID;
-  if (h->graph_exec) return fail(h, DSACT_E_STATE, "rng mode is baked into the captured graph");
+  if (have_graph(h)) return fail(h, DSACT_E_STATE, "rng mode is baked into the captured graph");
   h->rng_seed = seed;
   return DSACT_OK;
 }
@@ -2848,6 +3103,7 @@ static int capture_updates(dsact_handle* h, int n, uint32_t flags, bool merged, 
       memset(&ride, 0, sizeof(ride));
       select_set(h, set ^ 1);   // destination of the riding gather
       ride.g = gather_args(h, h->idx_table, h->idx_rows, 1, 0, 1);
+      ride.g.lookahead = 1;
       ride.n_gather = s + 1 < n ? ride.g.n_gather_blocks : 0;
       ride.bookkeeping = 1;
       select_set(h, set);
@@ -2873,6 +3129,62 @@ static int capture_updates(dsact_handle* h, int n, uint32_t flags, bool merged, 
   return DSACT_OK;
 }
 
+// Captures `n` updates starting at an iteration with it % delay_update == phase as the PIPELINED graph:
+//   [gather minibatch 0 (+ repack)] [gather minibatch 1]
+//   per update s:  k_chain_fwdp (own minibatch; + the policy units of minibatch s + 1 when update s leaves the policy alone)
+//                  k_chain_bwd_q (+ riders: gather of minibatch s + 2, bookkeeping)   k_chain_bwd_pi (+ all dW/Adam tiles)
+// Every precomputed item is produced and consumed inside one replay: the first update of a graph never relies on one, the
+// last never produces one. Same kernels behind the forward, same arithmetic per row: bit-identical to eager updates.
+static int capture_updates_pipe(dsact_handle* h, int n, int phase, hipGraph_t* graph, hipGraphExec_t* exec, PipeFwd** dev_args) {
+  const int D = h->cfg.delay_update;
+  std::vector<PipeFwd> host((size_t)n);
+  HIPCHK(h, hipMalloc((void**)dev_args, (size_t)n * sizeof(PipeFwd)));
+  auto set_of = [&](int s) { return (s - (n - 1)) & (dsact_handle::kPipeSets - 1); };
+  HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  int rc = DSACT_OK;
+  h->mirror_w0 = true;
+  apply_pipe_set(h, set_of(0));
+  rc = enqueue_gather(h, h->idx_table, h->idx_rows, 1, 0, 1, /*bookkeeping=*/0);
+  if (rc == DSACT_OK && n > 1) {
+    apply_pipe_set(h, set_of(1));
+    GatherArgs g = gather_args(h, h->idx_table, h->idx_rows, 1, 0, 1);
+    g.bookkeeping = 0; g.lookahead = 1;
+    g.rp = repack_args(h, 0);
+    rc = launch(h, "gather", k_gather, dim3(g.n_gather_blocks), dim3(kThreads), 0, g);
+  }
+  bool pre = false;
+  for (int s = 0; s < n && rc == DSACT_OK; ++s) {
+    const bool leaves_policy = ((phase + s) % D) != 0;          // this update's close does not touch policy / alpha / targets
+    const bool do_pre = s + 1 < n && leaves_policy;
+    rc = pipe_fwd_build(h, set_of(s), set_of(s + 1), pre, do_pre, host[(size_t)s]);   // leaves the handle on set_of(s)
+    if (rc == DSACT_OK) rc = launch_chain_fwd_pipe(h, host[(size_t)s], *dev_args + s);
+    if (rc != DSACT_OK) break;
+    RideArgs ride;
+    memset(&ride, 0, sizeof(ride));
+    if (s + 2 < n) {
+      apply_pipe_set(h, set_of(s + 2));   // destination of the riding gather
+      ride.g = gather_args(h, h->idx_table, h->idx_rows, 1, 0, 1);
+      ride.g.lookahead = 2;
+      ride.n_gather = ride.g.n_gather_blocks;
+      apply_pipe_set(h, set_of(s));
+    } else {
+      ride.g = gather_args(h, h->idx_table, h->idx_rows, 1, 0, 1);   // (st / hp of the bookkeeping block)
+      ride.n_gather = 0;
+    }
+    ride.bookkeeping = 1;
+    rc = enqueue_grads(h, true, true, 2, &ride);
+    pre = do_pre;
+  }
+  apply_pipe_set(h, 0);
+  h->mirror_w0 = false;
+  hipError_t e = hipStreamEndCapture(h->stream, graph);
+  if (rc != DSACT_OK) return rc;
+  if (e != hipSuccess) return fail(h, DSACT_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  HIPCHK(h, hipGraphInstantiate(exec, *graph, nullptr, nullptr, 0));
+  HIPCHK(h, hipMemcpy(*dev_args, host.data(), (size_t)n * sizeof(PipeFwd), hipMemcpyHostToDevice));
+  return DSACT_OK;
+}
+
 int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) {
   TRY(check_ready(h, false));
   if (steps_per_graph < 1) return fail(h, DSACT_E_INVALID, "steps_per_graph must be >= 1");
@@ -2895,9 +3207,22 @@ int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) 
   const bool merged = !h->cnn && h->use_w1p && h->dw_chunks == 1 && !h->use_fork && !h->use_std_sums && h->alt_ws != nullptr &&
                       !h->env_no_merged_gather && (!(flags & DSACT_F_DATA_PARALLEL) || h->chain_ok);
   h->merged_graph = merged;
+  // Pipelined graph (fused single-GPU update on the row-slice chains with both in-launch hand-overs available, device RNG,
+  // 2 <= delay_update <= 4, at least 2 updates per graph): one graph per phase first_iteration % delay_update
+  const int D = h->cfg.delay_update;
+  const bool pipe = merged && h->chain_ok && !h->fat && h->fwd_merge && h->B % 4 == 0 && h->rng_seed != 0 && h->cfg.algo == 0 &&
+                    !(flags & (DSACT_F_DATA_PARALLEL | DSACT_F_SKIP_ACTOR_ON_OFF_ITERS)) && D >= 2 &&
+                    D <= dsact_handle::kPipePhases && steps_per_graph >= 2 && !h->env_no_pipe;
   const bool was_prof = h->profiling;
   h->profiling = false;
-  int rc = capture_updates(h, steps_per_graph, flags, merged, &h->graph, &h->graph_exec);
+  int rc = DSACT_OK;
+  if (pipe) {
+    rc = alloc_pipe_sets(h);
+    for (int ph = 0; ph < D && rc == DSACT_OK; ++ph) rc = capture_updates_pipe(h, steps_per_graph, ph, &h->pgraph[ph], &h->pexec[ph], &h->pargs[ph]);
+    h->pipe_graph = rc == DSACT_OK;
+  } else {
+    rc = capture_updates(h, steps_per_graph, flags, merged, &h->graph, &h->graph_exec);
+  }
   h->profiling = was_prof;
   if (rc != DSACT_OK) { drop_graphs(h); return rc; }
   h->graph_steps = steps_per_graph;
@@ -2907,9 +3232,18 @@ int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) 
 }
 
 // n_groups back-to-back replays of the captured updates
-static int launch_groups(dsact_handle* h, int64_t n_groups) {
+static int launch_groups(dsact_handle* h, int64_t first_iteration, int64_t n_groups) {
   h->uev_valid = false;
   int64_t i = 0;
+  if (h->pipe_graph) {
+    // the pipelined graphs are captured per phase of the delayed update: replay i starts at first_iteration + i * graph_steps
+    const int D = h->cfg.delay_update;
+    for (; i < n_groups; ++i) {
+      const int ph = (int)(((first_iteration + i * h->graph_steps) % D + D) % D);
+      HIPCHK(h, hipGraphLaunch(h->pexec[ph], h->stream));
+    }
+    return DSACT_OK;
+  }
   for (; i < n_groups; ++i) HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
   return DSACT_OK;
 }
@@ -2926,13 +3260,13 @@ static int set_device_iteration(dsact_handle* h, long long it) {
 int dsact_graph_run(dsact_handle* h, int64_t first_iteration, int64_t n_steps) {
   if (!h) return DSACT_E_INVALID;
   TRY(check_handoff(h));
-  if (!h->graph_exec) return fail(h, DSACT_E_STATE, "dsact_graph_build first");
+  if (!have_graph(h)) return fail(h, DSACT_E_STATE, "dsact_graph_build first");
   if (n_steps % h->graph_steps) return fail(h, DSACT_E_INVALID, "n_steps must be a multiple of steps_per_graph");
   if ((h->graph_flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) && first_iteration % h->cfg.delay_update)
     return fail(h, DSACT_E_INVALID, "first_iteration must be a multiple of delay_update for a graph captured with DSACT_F_SKIP_ACTOR_ON_OFF_ITERS");
   HIPCHK(h, hipSetDevice(h->device));
   TRY(set_device_iteration(h, first_iteration));
-  TRY(launch_groups(h, n_steps / h->graph_steps));
+  TRY(launch_groups(h, first_iteration, n_steps / h->graph_steps));
   h->dev_it_next = first_iteration + n_steps;
   return DSACT_OK;
 }
@@ -2975,7 +3309,7 @@ int dsact_dp_set_strict(dsact_handle* h, float* std_sums_dev) {
   if (!h) return DSACT_E_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (h->graph_exec) return fail(h, DSACT_E_STATE, "data-parallel mode is baked into the captured graph");
+  if (have_graph(h)) return fail(h, DSACT_E_STATE, "data-parallel mode is baked into the captured graph");
   if (!h->std_sums_own) h->std_sums_own = h->std_sums;
   h->use_std_sums = std_sums_dev != nullptr;
   h->std_sums = std_sums_dev ? std_sums_dev : h->std_sums_own;
@@ -3021,7 +3355,7 @@ int dsact_comm_unique_id(const char* rccl_path, uint8_t id[128]) {
 int dsact_comm_init(dsact_handle* h, int32_t rank, int32_t world, const uint8_t id[128], const char* rccl_path) {
   if (!h || !id || world < 1 || rank < 0 || rank >= world) return DSACT_E_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
-  if (h->graph_exec) return fail(h, DSACT_E_STATE, "the communicator is baked into the captured graph");
+  if (have_graph(h)) return fail(h, DSACT_E_STATE, "the communicator is baked into the captured graph");
   if (const char* e = rccl_load(rccl_path)) return fail(h, DSACT_E_STATE, "%s", e);
   if (h->comm) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   NcclUid u;
@@ -3111,11 +3445,11 @@ int dsact_time_steps(dsact_handle* h, int64_t first_iteration, int64_t n_steps, 
   TRY(set_device_iteration(h, first_iteration));
   HIPCHK(h, hipEventRecord(h->tev0, h->stream));
   if (use_graph) {
-    if (!h->graph_exec) return fail(h, DSACT_E_STATE, "dsact_graph_build first");
+    if (!have_graph(h)) return fail(h, DSACT_E_STATE, "dsact_graph_build first");
     if (n_steps % h->graph_steps) return fail(h, DSACT_E_INVALID, "n_steps must be a multiple of steps_per_graph");
     if ((h->graph_flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) && first_iteration % h->cfg.delay_update)
       return fail(h, DSACT_E_INVALID, "first_iteration must be a multiple of delay_update");
-    TRY(launch_groups(h, n_steps / h->graph_steps));
+    TRY(launch_groups(h, first_iteration, n_steps / h->graph_steps));
     h->dev_it_next = first_iteration + n_steps;
   } else {
     h->dev_it_next = -1;
@@ -3328,6 +3662,7 @@ int dsact_debug_get(const dsact_handle* h, const char* name, double* value) {
   else if (!strcmp(name, "fat")) *value = (h->fat ? 1.0 : 0.0) + (h->fat_bwd ? 2.0 : 0.0);
   else if (!strcmp(name, "handoff_failures")) *value = (double)h->handoff_failures;
   else if (!strcmp(name, "graph_steps")) *value = (double)h->graph_steps;
+  else if (!strcmp(name, "pipe_graph")) *value = h->pipe_graph ? 1.0 : 0.0;   // the captured graphs are the pipelined ones
   else return DSACT_E_INVALID;
   return DSACT_OK;
 }

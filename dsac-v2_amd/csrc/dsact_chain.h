@@ -533,7 +533,10 @@ __global__ void __launch_bounds__(256) k_adam_pack(AdamPackArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 // k_chain_fwd
 // ---------------------------------------------------------------------------------------------------------------
-enum : int { SEG_FULL = 0, SEG_OBS_ONLY = 1, SEG_ACT_FROM_SAVED = 2, SEG_FULL_SAVE = 3 };
+// SEG_FULL_SPLIT: observation segment, then the two accumulators are merged exactly as SEG_OBS_ONLY's zsave /
+// SEG_ACT_FROM_SAVED's zinit would have carried them through memory, then the action segment -- ONE workgroup, the same
+// bits as the two-unit form (the pipelined graph's q_target units: no obs-only producer, no saved accumulators)
+enum : int { SEG_FULL = 0, SEG_OBS_ONLY = 1, SEG_ACT_FROM_SAVED = 2, SEG_FULL_SAVE = 3, SEG_FULL_SPLIT = 4 };
 enum : int { HEAD_NONE = 0, HEAD_POLICY = 1, HEAD_Q = 2 };
 
 struct FwdUnit {
@@ -557,7 +560,9 @@ struct FwdUnit {
                                     // observation part do not wait for the rest of this unit's chain)
   short rg, act;                    // rows per workgroup / 4 of THIS unit (units of one launch may differ); hidden activation
                                     // of its net (ACT_*, dsact_math.h). (shorts: two FwdArgs must fit the 4 KB of kernel arguments)
-  int n_slices;                     // slices of this unit
+  short n_slices;                   // slices of this unit
+  short late_wait;                  // 1: wait for the producers AFTER the observation segment (only the action columns are
+                                    // handed over): the wait hides under this unit's own first 3/4 of a layer
 };
 constexpr int kMaxFwdUnits = 6;
 struct FwdArgs {
@@ -663,9 +668,11 @@ inline int fwd_grid(const FwdArgs& a) {
 
 // GA ("generic activation"): false compiles the GELU-only epilogue every shipped example uses -- the other activations'
 // expm1f / tanhf / expf bodies cost the hot kernel registers and ~1 us per launch even when not taken
-template <int NW, int RG, bool GA = false>
-__device__ __forceinline__ void chain_fwd_body(const FwdArgs& a, int unit, int slice, float* lds) {
-  const FwdUnit& u = a.u[unit];
+// `a`: the launch's common fields (its unit table is not read here); `u`: the unit -- an element of a.u (k_chain_fwd /
+// k_chain_fwd2, kernel arguments) or of the pipelined graph's unit table in device memory (k_chain_fwdp)
+// (AT / UT: FwdArgs / FwdUnit, or their constant-address-space qualified forms -- every field stays a scalar load)
+template <int NW, int RG, bool GA = false, typename AT = FwdArgs, typename UT = FwdUnit>
+__device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int unit, int slice, float* lds) {
   constexpr int W = 64 * NW, SH = W / 4, R = 4 * RG, NTHR = 64 * NW, TPR = NTHR / R;
   int* const done_flag = (u.done && !(a.debug_withhold && unit == 0 && slice == 0)) ? u.done + slice : nullptr;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -709,7 +716,10 @@ __device__ __forceinline__ void chain_fwd_body(const FwdArgs& a, int unit, int s
     pre_bmu[0] = u.bias[L][0]; pre_braw[0] = u.bias[L][1];
   }
   // merged launch: the weight stream and the loads above are already in flight while this waits for its producers
-  if (u.wait0 || u.wait1)
+  // (late_wait: only the action columns come from a producer -- the wait follows the observation segment)
+  const bool waits = u.wait0 || u.wait1;
+  const bool late = waits && u.late_wait && u.seg != SEG_ACT_FROM_SAVED && u.s_act > 0;
+  if (waits && !late)
     chain_wait(u.wait0 ? u.wait0 + row0 / u.wait_rows0 : nullptr, u.wait1 ? u.wait1 + row0 / u.wait_rows1 : nullptr, a.spin_timeout);
   f32x4 zi[RG];
   if (u.seg == SEG_ACT_FROM_SAVED) {
@@ -720,6 +730,17 @@ __device__ __forceinline__ void chain_fwd_body(const FwdArgs& a, int unit, int s
   }
   // ---- stage the input rows: xin[r][k'] (observation part, zero padding to 4*s_obs, action part, zero padding).
   //      Four independent loads per thread and trip, stores after (a load -> wait -> store loop is one round trip per trip)
+  auto stage_act = [&]() {
+    const int Fp = 4 * a.s_obs;
+    const int aq = u.s_act, total = R * aq;   // float4 groups of the action segment
+    for (int e = tid; e < total; e += NTHR) {
+      const int r = e / aq, k = (e % aq) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const float* s = u.x + (size_t)(row0 + r) * a.ldx + F + k;
+      for (int c = 0; c < 4; ++c) if (k + c < A) v[c] = ld_agent(s + c);
+      *(f32x4*)(lds + xin + r * S.ld_in + Fp + k) = v;
+    }
+  };
   {
     const int Fp = 4 * a.s_obs;
     if (do_obs) {
@@ -748,16 +769,7 @@ __device__ __forceinline__ void chain_fwd_body(const FwdArgs& a, int unit, int s
         }
       }
     }
-    if (do_act) {
-      const int aq = u.s_act, total = R * aq;   // float4 groups of the action segment
-      for (int e = tid; e < total; e += NTHR) {
-        const int r = e / aq, k = (e % aq) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const float* s = u.x + (size_t)(row0 + r) * a.ldx + F + k;
-        for (int c = 0; c < 4; ++c) if (k + c < A) v[c] = ld_agent(s + c);
-        *(f32x4*)(lds + xin + r * S.ld_in + Fp + k) = v;
-      }
-    }
+    if (do_act && !late) stage_act();
   }
   f32x4 acc[RG][2];
 #pragma unroll
@@ -798,6 +810,15 @@ __device__ __forceinline__ void chain_fwd_body(const FwdArgs& a, int unit, int s
     }
     CTL(a.timeline, 2);
     if (u.seg == SEG_OBS_ONLY) { CTLR(a.timeline, 15); chain_publish(done_flag); return; }
+    if (u.seg == SEG_FULL_SPLIT) {   // what zsave -> zinit carries from an obs-only unit to its SEG_ACT_FROM_SAVED consumer
+#pragma unroll
+      for (int g = 0; g < RG; ++g) { acc[g][0] = acc[g][0] + acc[g][1]; acc[g][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+  }
+  if (late) {
+    chain_wait(u.wait0 ? u.wait0 + row0 / u.wait_rows0 : nullptr, u.wait1 ? u.wait1 + row0 / u.wait_rows1 : nullptr, a.spin_timeout);
+    stage_act();
+    lds_barrier();
   }
   if (do_act) gemm44_seg<RG>(ws, w0, a.s_obs, S0, w1, 0, more, lds, xs_in, S.ld_in, lane4, acc);
   CTL(a.timeline, 3);
@@ -873,15 +894,17 @@ __device__ __forceinline__ void chain_fwd_body(const FwdArgs& a, int unit, int s
   if (j == 0) u.logp[r] = lp;
   CTL(a.timeline, 13);
   if (u.part_heads) {
-    s_tanh = wave_sum(s_tanh); s_sig = wave_sum(s_sig);
-    float* sc = lds + S.off_sc;
-    if (lane == 0) { sc[wave] = s_tanh; sc[4 + wave] = s_sig; }
+    // one partial per FOUR rows: row sums over the TPR lanes of a row, then the group's rows in order -- the B/4 partial
+    // sums (and the statistic k_stats forms from them) do not depend on the rows per workgroup of whoever ran this unit
+    s_tanh = rowN_sum<TPR>(s_tanh); s_sig = rowN_sum<TPR>(s_sig);
+    float* sc = lds + S.off_sc;     // 64 floats >= 2 * R
+    if (j == 0) { sc[2 * m] = s_tanh; sc[2 * m + 1] = s_sig; }
     lds_barrier();
-    if (tid == 0) {
+    if (tid < RG) {
       float t0 = 0.f, t1 = 0.f;
-      for (int w = 0; w < NW; ++w) { t0 += sc[w]; t1 += sc[4 + w]; }
-      u.part_heads[2 * slice] = t0;
-      u.part_heads[2 * slice + 1] = t1;
+      for (int rr = 0; rr < 4; ++rr) { t0 += sc[2 * (4 * tid + rr)]; t1 += sc[2 * (4 * tid + rr) + 1]; }
+      u.part_heads[2 * (RG * slice + tid)] = t0;
+      u.part_heads[2 * (RG * slice + tid) + 1] = t1;
     }
   }
   CTLR(a.timeline, 15);
@@ -893,7 +916,7 @@ __global__ void __launch_bounds__(64 * NW, RG >= 4 ? 1 : 2) k_chain_fwd(FwdArgs 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int unit, slice;
   if (!fwd_decode(a, (int)blockIdx.x, unit, slice)) return;
-  chain_fwd_body<NW, RG, GA>(a, unit, slice, lds);
+  chain_fwd_body<NW, RG, GA>(a, a.u[unit], unit, slice, lds);
 }
 
 // Launches A and B in one: blocks [0, n_a) run group A with RGA row groups, blocks [n_a, ..) group B with RGB. Every
@@ -911,8 +934,42 @@ __global__ void __launch_bounds__(64 * NW, 2) k_chain_fwd2(Fwd2Args a) {
   const FwdArgs& f = in_a ? a.A : a.B;
   int unit, slice;
   if (!fwd_decode(f, in_a ? (int)blockIdx.x : (int)blockIdx.x - a.n_a, unit, slice)) return;
-  if (f.u[unit].rg == 1) chain_fwd_body<NW, 1, GA>(f, unit, slice, lds);
-  else chain_fwd_body<NW, 2, GA>(f, unit, slice, lds);
+  if (f.u[unit].rg == 1) chain_fwd_body<NW, 1, GA>(f, f.u[unit], unit, slice, lds);
+  else chain_fwd_body<NW, 2, GA>(f, f.u[unit], unit, slice, lds);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_chain_fwdp: the forward launch of the PIPELINED graph (delayed-update-aware software pipelining).
+// policy, log_alpha and the three target nets change only at the end of an update with it % delay_update == 0
+// (dsac_v2.py:320-347), so update it + 1 of such a window sees the policy / targets update `it` saw: the launch of
+// update `it` also runs pi(obs') + rsample and pi_target(obs2') + act2 / logp2 for the NEXT minibatch (resident two
+// updates ahead: the riding gather looks two updates ahead in this graph), and the launch of update it + 1 then holds
+// only the chains that need the fresh critics -- q1/q2(obs,act), q1/q2(obs,new_act), q1_t/q2_t(obs2,act2) -- with no
+// in-launch pi -> q dependency. Units and the block -> (unit, slice) table live in DEVICE memory (one PipeFwd per
+// captured launch): up to kPipeUnits units of either minibatch, each with its own rows per workgroup, XCDs and
+// position in the dispatch order. A unit waits only for units that come EARLIER in every XCD's queue (the table is
+// built group by group), so the bounded spins cannot deadlock. Same body, same arithmetic per row as k_chain_fwd2.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kPipeUnits = 12;
+constexpr int kPipeMaxBlocks = 1536;
+struct PipeFwd {
+  FwdArgs c;                        // common fields (c.u / c.map unused)
+  FwdUnit u[kPipeUnits];
+  int n_blocks;
+  int blk[kPipeMaxBlocks];          // (unit << 16) | slice, or -1: padding block
+};
+template <int NW, bool GA = false>
+__global__ void __launch_bounds__(64 * NW, 2) k_chain_fwdp(const PipeFwd* __restrict__ pd) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  // read-only for the whole launch: a constant-address-space view keeps every field a scalar load that no asm / atomic
+  // "memory" clobber forces to be repeated (the table is written by a hipMemcpy before the graph's first launch)
+  typedef __attribute__((address_space(4))) const PipeFwd KP;
+  KP* p = (KP*)(unsigned long long)pd;
+  const int code = p->blk[blockIdx.x];
+  if (code < 0) return;
+  const int unit = code >> 16, slice = code & 0xffff;
+  if (p->u[unit].rg == 1) chain_fwd_body<NW, 1, GA>(p->c, p->u[unit], unit, slice, lds);
+  else chain_fwd_body<NW, 2, GA>(p->c, p->u[unit], unit, slice, lds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -409,6 +409,7 @@ struct GatherArgs {
   NoiseArgs nz;
   RepackArgs rp;
   int n_gather_blocks;
+  int lookahead;          // use_dev: stage the minibatch of iteration it_next + lookahead (table row seq_next + lookahead)
 };
 
 // rows [4*blk, 4*blk+4) of the minibatch of iteration `it` (index-table row `trow`) + their noise
@@ -480,15 +481,16 @@ __global__ void __launch_bounds__(kThreads) k_gather(GatherArgs a) {
     repack_rows(a.rp, (int)blockIdx.x - a.n_gather_blocks, tid);
     return;
   }
-  const long long it = a.use_dev ? a.st->it_next : a.host_it;
-  const int trow = a.use_dev ? (int)(a.st->seq_next % a.idx_rows) : a.host_row;
+  const long long it = a.use_dev ? a.st->it_next + a.lookahead : a.host_it;
+  const int trow = a.use_dev ? (int)((a.st->seq_next + a.lookahead) % a.idx_rows) : a.host_row;
   gather_block(a, (int)blockIdx.x, it, trow, tid);
   if (a.bookkeeping && blockIdx.x == 0 && tid == 0) prologue_duties(a.st, it, a.advance_counters, a.hp);
 }
 
 // Riders of the loss launch in graph replays (k_loss has B/4 blocks: three quarters of the chip idle). Blocks
 // [n_loss_blocks, +n_gather) stage the NEXT update's minibatch into the other batch set (iteration it_next + 1,
-// table row seq_next + 1: the counters advance when this update closes); one more block does THIS update's
+// table row seq_next + 1: the counters advance when this update closes; the pipelined graph stages the update
+// AFTER the next, g.lookahead = 2); one more block does THIS update's
 // bookkeeping (nothing before the first weight-gradient tile reads what prologue_duties writes).
 struct RideArgs {
   GatherArgs g;          // destination pointers = the other set; g.st / g.hp also serve the bookkeeping
@@ -501,7 +503,7 @@ __device__ __forceinline__ bool loss_rider(const RideArgs& r) {
   if (b < 0) return false;
   if (b < r.n_gather) {
     const DevState* st = r.g.st;
-    gather_block(r.g, b, st->it_next + 1, (int)((st->seq_next + 1) % r.g.idx_rows), threadIdx.x);
+    gather_block(r.g, b, st->it_next + r.g.lookahead, (int)((st->seq_next + r.g.lookahead) % r.g.idx_rows), threadIdx.x);
   } else if (r.bookkeeping && threadIdx.x == 0) {
     prologue_duties(r.g.st, r.g.st->it_next, 1, r.g.hp);
   }

@@ -197,7 +197,14 @@ int dsact_step(dsact_handle* h, int64_t iteration, uint32_t flags); /* compute_g
  * updates starting at `first_iteration` (n_steps % steps_per_graph == 0). The replay ring must not
  * be written while a graph runs: inside a graph the minibatch of update s+1 is gathered while
  * update s is still in flight (it rides in that update's loss launch); results are bit-identical
- * to the same updates issued one by one. The last update's minibatch stays staged. */
+ * to the same updates issued one by one. The last update's minibatch stays staged.
+ * Pipelined graph (row-slice chains, batch <= 256, device RNG, 2 <= delay_update <= 4, steps_per_graph >= 2, no flags):
+ * policy, log_alpha and the three target nets change only when iteration % delay_update == 0 (dsac_v2.py:320-347), so
+ * update it + 1 of such a window sees the policy update `it` saw -- the forward launch of update `it` also evaluates
+ * policy(obs) + rsample and policy_target(obs2) for the NEXT minibatch (gathered two updates ahead) and update it + 1's
+ * forward launch holds only the chains that need the fresh critics. One graph per phase first_iteration % delay_update is
+ * captured; dsact_graph_run picks per replay. Same bits as eager updates. DSACT_NO_PIPE=1 captures the plain graph;
+ * dsact_debug_get(h, "pipe_graph") tells which one was captured. */
 int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags);
 int dsact_graph_run(dsact_handle* h, int64_t first_iteration, int64_t n_steps);
 
@@ -294,8 +301,8 @@ const char* dsact_debug_names(void);
  *   dsact_debug_set(h, "poison_handover", v)    fills every buffer handed from producers to consumers with v (e.g. NaN)
  *   dsact_debug_set(h, "fwd_merge", 0|1)        merged forward launch off / on (when the shape allows it)
  *   dsact_debug_set(h, "pi_merge", 0|1)         policy weight-gradient tiles inside the policy-backward launch off / on
- *   dsact_debug_get(h, "fwd_merge" | "pi_merge" | "fat" | "handoff_failures" | "graph_steps" | "act_launch_us" |
- *                      "act_wait_us", &v) */
+ *   dsact_debug_get(h, "fwd_merge" | "pi_merge" | "fat" | "handoff_failures" | "graph_steps" | "pipe_graph" |
+ *                      "act_launch_us" | "act_wait_us", &v) */
 int dsact_debug_set(dsact_handle* h, const char* name, double value);
 int dsact_debug_get(const dsact_handle* h, const char* name, double* value);
 /* stand-alone fused-MLP forward of the policy net on a host batch (sampler / evaluator feed):

@@ -692,6 +692,73 @@ def test_graph_replay_equals_eager_steps(O, A, hid, B, per_graph, total):
         assert np.array_equal(b0[k], b1[k]), k
 
 
+PIPE_BUFFERS = ("logits_pi", "logp_new", "logp2", "qout_t0", "qout_t1", "qout_p0", "qout_c1", "XP", "X2", "eps_new", "z5",
+                "part_heads", "part_loss", "H.pi.0", "G.pi.1", "dZ.pi.0", "d_new_act")
+
+
+@pytest.mark.parametrize("O,A,hid,B,D,per_graph,first,total,env", [
+    (16, 4, (64, 64), 64, 2, 4, 1, 8, {}),             # starts on an odd iteration: every update is half of a pair
+    (16, 4, (64, 64), 64, 2, 4, 0, 8, {}),             # starts on an even one: single, pairs, single
+    (16, 4, (64, 64), 64, 2, 3, 1, 9, {}),             # odd graph length: replays alternate between the two phase graphs
+    (16, 4, (64, 64), 64, 2, 5, 2, 10, {"DSACT_PIPE_QT": "1"}),           # q_target of the next minibatch precomputed too
+    (24, 6, (128, 128, 128), 32, 3, 6, 1, 12, {}),     # delay_update 3: a (has, makes) launch in the middle of every window
+    (24, 6, (128, 128, 128), 32, 3, 4, 0, 12, {"DSACT_PIPE_QT": "1", "DSACT_PIPE_RG_SIDE": "1"}),
+    (16, 4, (64, 64), 64, 1, 4, 0, 8, {}),             # delay_update 1: nothing to share, the plain graph
+    (16, 4, (64, 64), 16, 2, 2, 1, 6, {"DSACT_PIPE_RG_NEXT": "1"}),       # 4 slices per unit
+    (376, 17, (256, 256, 256), 256, 2, 8, 1, 16, {}),  # the BASELINE.json shape
+    (376, 17, (256, 256, 256), 256, 2, 6, 4, 12, {"DSACT_PIPE_MAP": "FT.pit=23:1;FT.q1t=01;TF.q1c=0123:2"}),
+])
+def test_pipelined_graph_equals_eager_steps(O, A, hid, B, D, per_graph, first, total, env, monkeypatch):
+    """Delayed-update-aware pipelined graph (k_chain_fwdp: the forward launch of an update that leaves the policy alone
+    also runs the policy units of the NEXT minibatch; the gather rides two updates ahead) == eager updates, bit for bit:
+    parameters, targets, optimiser state, step state, statistics, the staged minibatch and the intermediates of the last
+    update -- for graphs that start on either parity, odd graph lengths, delay_update 1 / 2 / 3, and placement variants."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    N = 2048
+    algs, stats, bufs = [], [], []
+    for mode in ("eager", "graph"):
+        alg, _ = make_pair(O, A, hid, B, seed=4, delay_update=D)
+        e = alg.engine
+        assert e.chain_active
+        e.set_device_rng(777)
+        e.buffer_create(N)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        e.buffer_fill_device(0, torch.randn(N, O, device="cuda", generator=g), torch.rand(N, A, device="cuda", generator=g) - .5,
+                             torch.randn(N, device="cuda", generator=g), torch.randn(N, O, device="cuda", generator=g),
+                             (torch.rand(N, device="cuda", generator=g) < .05).float())
+        np.random.seed(1)
+        e.upload_index_table(np.random.randint(0, N, size=(7, B)))
+        if mode == "graph":
+            e.graph_build(per_graph)
+            assert e.debug_get("pipe_graph") == (1.0 if D >= 2 else 0.0)
+            e.graph_run(first, total)
+        else:
+            assert e.time_steps(first, total, use_graph=False) > 0
+        e.sync()
+        algs.append(alg)
+        st = e.read_stats()
+        stats.append({k: v for k, v in st.items() if not k.startswith("_device")})
+        bufs.append({n: e.debug_read(n) for n in PIPE_BUFFERS})
+    for name in ("online", "target", "adam_m", "adam_v"):
+        assert torch.equal(getattr(algs[0].engine, name), getattr(algs[1].engine, name)), name
+    assert algs[0].engine.get_state() == algs[1].engine.get_state()
+    assert torch.isfinite(algs[1].engine.online).all()
+    for k in stats[0]:
+        assert stats[0][k] == stats[1][k] or (np.isnan(stats[0][k]) and np.isnan(stats[1][k])), (k, stats[0][k], stats[1][k])
+    for n in PIPE_BUFFERS:
+        assert np.array_equal(bufs[0][n], bufs[1][n]), n
+    b0, b1 = algs[0].engine.read_batch(with_logp=False), algs[1].engine.read_batch(with_logp=False)
+    for k in ("obs", "act", "rew", "obs2", "done"):
+        assert np.array_equal(b0[k], b1[k]), k
+    # a second run on the same handle continues identically (the phase graphs are cached; the other phase is picked)
+    algs[0].engine.time_steps(first + total, per_graph, use_graph=False)
+    algs[1].engine.graph_run(first + total, per_graph)
+    algs[0].engine.sync(); algs[1].engine.sync()
+    assert torch.equal(algs[0].engine.online, algs[1].engine.online)
+    assert torch.equal(algs[0].engine.target, algs[1].engine.target)
+
+
 def test_device_rng_is_standard_normal():
     alg, _ = make_pair(8, 8, (32,), 1024)
     e = alg.engine
