@@ -661,6 +661,11 @@ def chain_flops(lay, batch):
         "dW": dw_pi,
     }
     per_row["chain_fwd"] = per_row["chain_fwd_a"] + per_row["chain_fwd_b"]   # merged A+B launch (batch <= 256)
+    # pipelined graph (k_chain_fwdp): "+next" also runs pi(obs') and pi_target(obs2') of the next minibatch; "_q" holds only
+    # the chains that need the fresh critics (its own policy units ran in the previous launch)
+    per_row["chain_fwd+next"] = per_row["chain_fwd"] + 2 * pi
+    per_row["chain_fwd_q"] = per_row["chain_fwd"] - 2 * pi
+    per_row["chain_fwd_q+next"] = per_row["chain_fwd"]
     per_row["chain_bwd"] = per_row["chain_bwd_q"] + per_row["chain_bwd_pi"] + per_row["dW"]   # merged backward + optimiser launch
     return {k: 2.0 * v * batch for k, v in per_row.items()}
 
@@ -707,6 +712,25 @@ def profile_kernels(e, first_it, n_steps=12, skip=2):
             acc[name] += ms
             cnt[name] += 1
     return [(n, acc[n] / cnt[n], blocks[n]) for n in order]
+
+
+def profile_kernels_pipe(e, first_it, n_steps, reps=10, skip=2):
+    """the same for the PIPELINED launch sequence: `reps` eager runs of the sequence graph_build(n_steps) captures (its
+    forward launches come in shapes, named by what they hold); average per launch name + launches per update"""
+    acc, cnt, blocks, order = {}, {}, {}, []
+    for i in range(reps):
+        prof = e.profile_steps(first_it + i * n_steps, n_steps)
+        e.sync()
+        if i < skip:
+            continue
+        for name, ms, b in prof:
+            if name not in acc:
+                acc[name], cnt[name], blocks[name] = 0.0, 0, b
+                order.append(name)
+            acc[name] += ms
+            cnt[name] += 1
+    per_update = {n: cnt[n] / float((reps - skip) * n_steps) for n in order}
+    return [(n, acc[n] / cnt[n], blocks[n]) for n in order], per_update
 
 
 def self_spawn(args):
@@ -854,7 +878,7 @@ def main():
             "global_batch": args.batch * world, "parallelism": "dp%d" % world, "hidden": hidden,
             "noise": "device Philox4x32-10", "mode": "fast (discarded actor backward skipped)" if args.fast else "strict (every gradient the reference computes)",
             "launch": dp_mode if use_dp else "hipGraph (%d steps/graph; the next update's gather rides in the loss launch)" % gs,
-            "kernels": ("row-slice fused chains + transposed-operand weight-gradient tiles (%d launches/update)%s" % (4 if Bb <= 256 else 5 if Bb <= 1024 else 6, "; throughput-regime kernels (dsact_fat.h) for the forward launches" + (" and the backward launches" if Bb >= 4096 else "") if Bb >= 1024 else "")) if chain else "per-layer tile stages",
+            "kernels": ("row-slice fused chains + transposed-operand weight-gradient tiles (%d launches/update)%s" % (3 if Bb <= 256 else 4 if Bb <= 512 else 5 if Bb <= 1024 else 6, "; throughput-regime kernels (dsact_fat.h) for the forward launches" + (" and the backward launches" if Bb >= 4096 else "") if Bb >= 1024 else "")) if chain else "per-layer tile stages",
             "timing": "median of %d timed regions of exactly %d steps (each bracketed by barrier + device sync; max over ranks)" % (len(regions), steps),
             "replay_fill": "torch device generator, the distributions of SURVEY.md 8(d) (a host np.random.default_rng(0) fill would push "
                            "3 GB through PCIe); indices: np.random.seed(1 + rank) + np.random.randint, a %d-row table cycled" % IDX_ROWS,
@@ -878,8 +902,19 @@ def main():
         if ev_ms is not None:
             out["hip_event_ms_per_step"] = ev_ms / steps
         try:
-            prof = profile_kernels(e, warmup + steps * len(regions))
-            out["kernels"] = [{"name": n, "us": round(ms * 1000, 2), "blocks": b} for n, ms, b in prof]
+            pipe = (not use_dp) and e.debug_get("pipe_graph") == 1.0
+            if pipe:
+                # the timed graph is the pipelined one: profile ITS launch sequence (same first-iteration parity, same length)
+                prof, per_update = profile_kernels_pipe(e, warmup + steps * len(regions), gs)
+                out["kernels"] = [{"name": n, "us": round(ms * 1000, 2), "blocks": b, "launches_per_update": round(per_update[n], 4)}
+                                  for n, ms, b in prof]
+                out["kernels_per_update_us"] = round(sum(ms * 1000.0 * per_update[n] for n, ms, _ in prof if n not in ("gather", "pack")), 2)
+                out["config"]["launch"] = ("hipGraph (%d steps/graph), delayed-update-aware pipelining: the forward launch of an update that "
+                                           "leaves the policy alone also runs pi / pi_target of the next minibatch (chain_fwd+next), the next "
+                                           "update's forward holds only the fresh-critic chains (chain_fwd_q); gather rides two updates ahead" % gs)
+            else:
+                prof = profile_kernels(e, warmup + steps * len(regions))
+                out["kernels"] = [{"name": n, "us": round(ms * 1000, 2), "blocks": b} for n, ms, b in prof]
             out["kernels_note"] = ("average in-chain duration per launch over 10 eager updates: start/stop events attached to each "
                                    "dispatch (hipExtLaunchKernelGGL), i.e. the kernel's own begin/end timestamps as rocprofv3 reports "
                                    "them (profiles/r02_final_bench_kernel_stats.csv); the eager update has its own gather launch, the timed "
@@ -910,7 +945,9 @@ def main():
             out["dominant_kernel"] = {"name": dom[0], "us": round(dom[1] * 1000, 2)}
             if chain and Bb % 256 == 0 or chain and Bb <= 256:
                 fl = chain_flops(lay, Bb)
-                kname = {"chain_bwd": "dsact::k_chain_bwd2 (critics' + policy backward + all dW/Adam tiles in one launch)",
+                kname = {"chain_fwd+next": "dsact::k_chain_fwdp (own minibatch: all 8 chains; + policy / policy_target of the next minibatch)",
+                         "chain_fwd_q": "dsact::k_chain_fwdp (fresh-critic chains only)", "chain_fwd_q+next": "dsact::k_chain_fwdp",
+                         "chain_bwd": "dsact::k_chain_bwd2 (critics' + policy backward + all dW/Adam tiles in one launch)",
                          "chain_fwd": "dsact::k_chain_fwd2 (groups A + B in one launch)", "chain_fwd_a": "dsact::k_chain_fwd (group A)", "chain_fwd_b": "dsact::k_chain_fwd (group B)",
                          "chain_bwd_q": "dsact::k_chain_bwd_q", "chain_bwd_pi": "dsact::k_chain_bwd_pi (+ riding k_dw2 tiles)",
                          "dW": "dsact::k_dw2"}.get(dom[0], dom[0])
@@ -919,7 +956,7 @@ def main():
                     ach = fl[dom[0]] / (dur_us * 1e-6) / 1e12
                     out["roofline"] = {
                         "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
-                        "traffic": pmc_traffic({"chain_bwd": "k_chain_bwd2", "chain_fwd": "k_chain_fwd2", "chain_fwd_a": "k_chain_fwd", "chain_fwd_b": "k_chain_fwd", "chain_bwd_q": "k_chain_bwd_q",
+                        "traffic": pmc_traffic({"chain_bwd": "k_chain_bwd2", "chain_fwd": "k_chain_fwdp" if pipe else "k_chain_fwd2", "chain_fwd+next": "k_chain_fwdp", "chain_fwd_q": "k_chain_fwdp", "chain_fwd_q+next": "k_chain_fwdp", "chain_fwd_a": "k_chain_fwd", "chain_fwd_b": "k_chain_fwd", "chain_bwd_q": "k_chain_bwd_q",
                                                 "chain_bwd_pi": "k_chain_bwd_pi", "dW": "k_dw2"}.get(dom[0], dom[0]),
                                                "min" if dom[0] == "chain_fwd_b" else "max"),
                         "traffic_source": "%s (a committed rocprofv3 --pmc pass of this bench; NOT measured in this run)" % getattr(pmc_traffic, "source", None),

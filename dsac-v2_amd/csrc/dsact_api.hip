@@ -1844,20 +1844,20 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
   return DSACT_OK;
 }
 
-int launch_chain_fwd_pipe(dsact_handle* h, const PipeFwd& host, const PipeFwd* dev) {
+int launch_chain_fwd_pipe(dsact_handle* h, const char* name, const PipeFwd& host, const PipeFwd* dev) {
   // (forwards of a complete update: the critics' backward clears the ready flags)
   if (h->flags_dirty) HIPCHK(h, hipMemsetAsync(h->chain_flags, 0, kChainFlags * sizeof(int), h->stream));
   h->flags_dirty = true;
   const size_t lds = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 8).total * sizeof(float);
   const int grid = host.n_blocks;
   if (generic_act(h)) {
-    if (h->cNT == 1) return launch(h, "chain_fwd", k_chain_fwdp<1, true>, dim3(grid), dim3(64), lds, dev);
-    if (h->cNT == 2) return launch(h, "chain_fwd", k_chain_fwdp<2, true>, dim3(grid), dim3(128), lds, dev);
-    return launch(h, "chain_fwd", k_chain_fwdp<4, true>, dim3(grid), dim3(256), lds, dev);
+    if (h->cNT == 1) return launch(h, name, k_chain_fwdp<1, true>, dim3(grid), dim3(64), lds, dev);
+    if (h->cNT == 2) return launch(h, name, k_chain_fwdp<2, true>, dim3(grid), dim3(128), lds, dev);
+    return launch(h, name, k_chain_fwdp<4, true>, dim3(grid), dim3(256), lds, dev);
   }
-  if (h->cNT == 1) return launch(h, "chain_fwd", k_chain_fwdp<1>, dim3(grid), dim3(64), lds, dev);
-  if (h->cNT == 2) return launch(h, "chain_fwd", k_chain_fwdp<2>, dim3(grid), dim3(128), lds, dev);
-  return launch(h, "chain_fwd", k_chain_fwdp<4>, dim3(grid), dim3(256), lds, dev);
+  if (h->cNT == 1) return launch(h, name, k_chain_fwdp<1>, dim3(grid), dim3(64), lds, dev);
+  if (h->cNT == 2) return launch(h, name, k_chain_fwdp<2>, dim3(grid), dim3(128), lds, dev);
+  return launch(h, name, k_chain_fwdp<4>, dim3(grid), dim3(256), lds, dev);
 }
 
 // loss + dZ chains of the critics (n_units 2: q1c, q2c only -- off iterations of the delayed update) and of
@@ -3129,18 +3129,40 @@ static int capture_updates(dsact_handle* h, int n, uint32_t flags, bool merged, 
   return DSACT_OK;
 }
 
-// Captures `n` updates starting at an iteration with it % delay_update == phase as the PIPELINED graph:
+// `n` updates starting at an iteration with it % delay_update == phase as the PIPELINED launch sequence:
 //   [gather minibatch 0 (+ repack)] [gather minibatch 1]
 //   per update s:  k_chain_fwdp (own minibatch; + the policy units of minibatch s + 1 when update s leaves the policy alone)
 //                  k_chain_bwd_q (+ riders: gather of minibatch s + 2, bookkeeping)   k_chain_bwd_pi (+ all dW/Adam tiles)
-// Every precomputed item is produced and consumed inside one replay: the first update of a graph never relies on one, the
-// last never produces one. Same kernels behind the forward, same arithmetic per row: bit-identical to eager updates.
-static int capture_updates_pipe(dsact_handle* h, int n, int phase, hipGraph_t* graph, hipGraphExec_t* exec, PipeFwd** dev_args) {
+// Every precomputed item is produced and consumed inside one sequence: its first update never relies on one, its last
+// never produces one. Same kernels behind the forward, same arithmetic per row: bit-identical to eager updates.
+// The forward launches read their unit tables from `dev_args` (n PipeFwd, filled here BEFORE anything is enqueued).
+static const char* pipe_fwd_name(bool pre, bool do_pre) {
+  return pre ? (do_pre ? "chain_fwd_q+next" : "chain_fwd_q") : (do_pre ? "chain_fwd+next" : "chain_fwd");
+}
+struct PipePlan { std::vector<PipeFwd> host; std::vector<char> pre, dop; };
+// unit tables of the n forward launches -> plan.host and (synchronous copy: call it BEFORE a stream capture begins) dev_args
+static int plan_updates_pipe(dsact_handle* h, int n, int phase, PipePlan& plan, PipeFwd* dev_args) {
   const int D = h->cfg.delay_update;
-  std::vector<PipeFwd> host((size_t)n);
-  HIPCHK(h, hipMalloc((void**)dev_args, (size_t)n * sizeof(PipeFwd)));
   auto set_of = [&](int s) { return (s - (n - 1)) & (dsact_handle::kPipeSets - 1); };
-  HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  plan.host.resize((size_t)n); plan.pre.resize((size_t)n); plan.dop.resize((size_t)n);
+  bool pre = false;
+  int rc = DSACT_OK;
+  for (int s = 0; s < n && rc == DSACT_OK; ++s) {
+    const bool leaves_policy = ((phase + s) % D) != 0;        // this update's close does not touch policy / alpha / targets
+    const bool do_pre = s + 1 < n && leaves_policy;
+    rc = pipe_fwd_build(h, set_of(s), set_of(s + 1), pre, do_pre, plan.host[(size_t)s]);
+    plan.pre[(size_t)s] = pre; plan.dop[(size_t)s] = do_pre;
+    pre = do_pre;
+  }
+  apply_pipe_set(h, 0);
+  TRY(rc);
+  HIPCHK(h, hipMemcpy(dev_args, plan.host.data(), (size_t)n * sizeof(PipeFwd), hipMemcpyHostToDevice));
+  return DSACT_OK;
+}
+static int enqueue_updates_pipe(dsact_handle* h, int n, const PipePlan& plan, PipeFwd* dev_args) {
+  auto set_of = [&](int s) { return (s - (n - 1)) & (dsact_handle::kPipeSets - 1); };
+  const std::vector<PipeFwd>& host = plan.host;
+  const std::vector<char>&pre_v = plan.pre, &do_v = plan.dop;
   int rc = DSACT_OK;
   h->mirror_w0 = true;
   apply_pipe_set(h, set_of(0));
@@ -3152,12 +3174,9 @@ static int capture_updates_pipe(dsact_handle* h, int n, int phase, hipGraph_t* g
     g.rp = repack_args(h, 0);
     rc = launch(h, "gather", k_gather, dim3(g.n_gather_blocks), dim3(kThreads), 0, g);
   }
-  bool pre = false;
   for (int s = 0; s < n && rc == DSACT_OK; ++s) {
-    const bool leaves_policy = ((phase + s) % D) != 0;          // this update's close does not touch policy / alpha / targets
-    const bool do_pre = s + 1 < n && leaves_policy;
-    rc = pipe_fwd_build(h, set_of(s), set_of(s + 1), pre, do_pre, host[(size_t)s]);   // leaves the handle on set_of(s)
-    if (rc == DSACT_OK) rc = launch_chain_fwd_pipe(h, host[(size_t)s], *dev_args + s);
+    apply_pipe_set(h, set_of(s));
+    rc = launch_chain_fwd_pipe(h, pipe_fwd_name(pre_v[(size_t)s], do_v[(size_t)s]), host[(size_t)s], dev_args + s);
     if (rc != DSACT_OK) break;
     RideArgs ride;
     memset(&ride, 0, sizeof(ride));
@@ -3173,16 +3192,34 @@ static int capture_updates_pipe(dsact_handle* h, int n, int phase, hipGraph_t* g
     }
     ride.bookkeeping = 1;
     rc = enqueue_grads(h, true, true, 2, &ride);
-    pre = do_pre;
   }
   apply_pipe_set(h, 0);
   h->mirror_w0 = false;
+  h->n_heads_parts = h->B / 4;
+  return rc;
+}
+
+static int capture_updates_pipe(dsact_handle* h, int n, int phase, hipGraph_t* graph, hipGraphExec_t* exec, PipeFwd** dev_args) {
+  HIPCHK(h, hipMalloc((void**)dev_args, (size_t)n * sizeof(PipeFwd)));
+  PipePlan plan;
+  TRY(plan_updates_pipe(h, n, phase, plan, *dev_args));
+  HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  const int rc = enqueue_updates_pipe(h, n, plan, *dev_args);
   hipError_t e = hipStreamEndCapture(h->stream, graph);
   if (rc != DSACT_OK) return rc;
   if (e != hipSuccess) return fail(h, DSACT_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
   HIPCHK(h, hipGraphInstantiate(exec, *graph, nullptr, nullptr, 0));
-  HIPCHK(h, hipMemcpy(*dev_args, host.data(), (size_t)n * sizeof(PipeFwd), hipMemcpyHostToDevice));
   return DSACT_OK;
+}
+
+// would dsact_graph_build(steps_per_graph, flags) capture the pipelined graph?
+static bool pipe_eligible(const dsact_handle* h, int steps_per_graph, uint32_t flags) {
+  const int D = h->cfg.delay_update;
+  const bool merged = !h->cnn && h->use_w1p && h->dw_chunks == 1 && !h->use_fork && !h->use_std_sums && h->alt_ws != nullptr &&
+                      !h->env_no_merged_gather;
+  return merged && h->chain_ok && !h->fat && h->fwd_merge && h->B % 4 == 0 && h->rng_seed != 0 && h->cfg.algo == 0 &&
+         !(flags & (DSACT_F_DATA_PARALLEL | DSACT_F_SKIP_ACTOR_ON_OFF_ITERS)) && D >= 2 && D <= dsact_handle::kPipePhases &&
+         steps_per_graph >= 2 && !h->env_no_pipe;
 }
 
 int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) {
@@ -3210,9 +3247,7 @@ int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) 
   // Pipelined graph (fused single-GPU update on the row-slice chains with both in-launch hand-overs available, device RNG,
   // 2 <= delay_update <= 4, at least 2 updates per graph): one graph per phase first_iteration % delay_update
   const int D = h->cfg.delay_update;
-  const bool pipe = merged && h->chain_ok && !h->fat && h->fwd_merge && h->B % 4 == 0 && h->rng_seed != 0 && h->cfg.algo == 0 &&
-                    !(flags & (DSACT_F_DATA_PARALLEL | DSACT_F_SKIP_ACTOR_ON_OFF_ITERS)) && D >= 2 &&
-                    D <= dsact_handle::kPipePhases && steps_per_graph >= 2 && !h->env_no_pipe;
+  const bool pipe = pipe_eligible(h, steps_per_graph, flags);
   const bool was_prof = h->profiling;
   h->profiling = false;
   int rc = DSACT_OK;
@@ -3526,6 +3561,55 @@ int dsact_profile_step(dsact_handle* h, int64_t iteration, uint32_t flags, dsact
   }
   *n = cnt;
   return DSACT_OK;
+}
+
+// n consecutive updates issued eagerly as the launch sequence dsact_graph_build(n_steps, flags) would capture -- the
+// pipelined sequence when that is what it would capture -- with start/stop events on every dispatch
+int dsact_profile_steps(dsact_handle* h, int64_t first_iteration, int32_t n_steps, uint32_t flags, dsact_kernel_time* out, int32_t cap, int32_t* n) {
+  if (!h || !out || !n || n_steps < 1) return DSACT_E_INVALID;
+  TRY(check_ready(h, false));
+  if (!h->idx_table) return fail(h, DSACT_E_STATE, "upload an index table first");
+  HIPCHK(h, hipSetDevice(h->device));
+  TRY(set_device_iteration(h, first_iteration));
+  h->dev_it_next = -1;
+  for (auto& r : h->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  h->prof.clear();
+  int rc = DSACT_OK;
+  if (pipe_eligible(h, n_steps, flags)) {
+    const int D = h->cfg.delay_update;
+    PipeFwd* dev = nullptr;
+    TRY(alloc_pipe_sets(h));
+    HIPCHK(h, hipMalloc((void**)&dev, (size_t)n_steps * sizeof(PipeFwd)));
+    PipePlan plan;
+    rc = plan_updates_pipe(h, n_steps, (int)((first_iteration % D + D) % D), plan, dev);
+    if (rc == DSACT_OK) {
+      h->profiling = true;
+      rc = enqueue_updates_pipe(h, n_steps, plan, dev);
+      h->profiling = false;
+    }
+    hipStreamSynchronize(h->stream);
+    hipFree(dev);
+  } else {
+    h->profiling = true;
+    for (int i = 0; i < n_steps && rc == DSACT_OK; ++i) rc = enqueue_graph_step(h, first_iteration + i, flags);
+    h->profiling = false;
+  }
+  TRY(rc);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->have_batch = true;
+  int cnt = 0;
+  for (auto& r : h->prof) {
+    if (cnt >= cap) break;
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, r.e0, r.e1));
+    memset(&out[cnt], 0, sizeof(out[cnt]));
+    strncpy(out[cnt].name, r.name.c_str(), sizeof(out[cnt].name) - 1);
+    out[cnt].ms = ms;
+    out[cnt].blocks = r.blocks;
+    ++cnt;
+  }
+  *n = cnt;
+  return check_handoff(h);
 }
 
 int dsact_chain_active(const dsact_handle* h) { return h && h->chain_ok ? 1 : 0; }

@@ -100,6 +100,8 @@ SYMBOLS = [
     ("dsact_chain_active", C.c_int, [_P]),
     ("dsact_profile_step", C.c_int, [_P, C.c_int64, C.c_uint32, C.POINTER(KernelTime), C.c_int32,
                                      C.POINTER(C.c_int32)]),
+    ("dsact_profile_steps", C.c_int, [_P, C.c_int64, C.c_int32, C.c_uint32, C.POINTER(KernelTime), C.c_int32,
+                                      C.POINTER(C.c_int32)]),
     ("dsact_debug_read", C.c_int, [_P, C.c_char_p, _FP, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("dsact_debug_names", C.c_char_p, []),
     ("dsact_debug_set", C.c_int, [_P, C.c_char_p, C.c_double]),

@@ -397,6 +397,15 @@ class DsactEngine:
         self._chk(self._lib.dsact_profile_step(self._h, int(iteration), int(flags), arr, 128, C.byref(n)))
         return [(arr[i].name.decode(), float(arr[i].ms), int(arr[i].blocks)) for i in range(n.value)]
 
+    def profile_steps(self, first_iteration: int, n_steps: int, flags: int = 0):
+        """per-dispatch (name, ms, blocks) of n_steps updates issued eagerly as the sequence graph_build(n_steps) would
+        capture (the pipelined one where eligible)"""
+        arr = (_ffi.KernelTime * 512)()
+        n = C.c_int32()
+        self.stage_serial += 1
+        self._chk(self._lib.dsact_profile_steps(self._h, int(first_iteration), int(n_steps), int(flags), arr, 512, C.byref(n)))
+        return [(arr[i].name.decode(), float(arr[i].ms), int(arr[i].blocks)) for i in range(n.value)]
+
     def debug_read(self, name: str, cap: int = 1 << 24) -> np.ndarray:
         buf = np.empty(cap, np.float32)
         n = C.c_size_t()

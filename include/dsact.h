@@ -288,6 +288,11 @@ typedef struct dsact_kernel_time {
 } dsact_kernel_time;
 int dsact_profile_step(dsact_handle* h, int64_t iteration, uint32_t flags, dsact_kernel_time* out,
                        int32_t cap, int32_t* n);
+/* the same for n_steps consecutive updates issued eagerly as the launch sequence dsact_graph_build(n_steps, flags) would
+ * capture (the pipelined sequence when that is what it would capture: its forward launches are named "chain_fwd",
+ * "chain_fwd+next", "chain_fwd_q", "chain_fwd_q+next" by what they hold) */
+int dsact_profile_steps(dsact_handle* h, int64_t first_iteration, int32_t n_steps, uint32_t flags, dsact_kernel_time* out,
+                        int32_t cap, int32_t* n);
 /* copy an internal device buffer to host by name (parity tests); returns element count in *n.
  * names: see dsact_debug_names(). */
 int dsact_debug_read(dsact_handle* h, const char* name, float* out, size_t cap, size_t* n);

@@ -717,7 +717,7 @@ def test_pipelined_graph_equals_eager_steps(O, A, hid, B, D, per_graph, first, t
         monkeypatch.setenv(k, v)
     N = 2048
     algs, stats, bufs = [], [], []
-    for mode in ("eager", "graph"):
+    for mode in ("eager", "graph", "sequence"):
         alg, _ = make_pair(O, A, hid, B, seed=4, delay_update=D)
         e = alg.engine
         assert e.chain_active
@@ -733,6 +733,11 @@ def test_pipelined_graph_equals_eager_steps(O, A, hid, B, D, per_graph, first, t
             e.graph_build(per_graph)
             assert e.debug_get("pipe_graph") == (1.0 if D >= 2 else 0.0)
             e.graph_run(first, total)
+        elif mode == "sequence":
+            # the same launch sequence issued eagerly with an event pair per dispatch (what bench.py profiles)
+            names = [n for n, _, _ in e.profile_steps(first, total)]
+            if D >= 2:
+                assert "chain_fwd+next" in names and "chain_fwd_q" in names, names
         else:
             assert e.time_steps(first, total, use_graph=False) > 0
         e.sync()
@@ -740,17 +745,18 @@ def test_pipelined_graph_equals_eager_steps(O, A, hid, B, D, per_graph, first, t
         st = e.read_stats()
         stats.append({k: v for k, v in st.items() if not k.startswith("_device")})
         bufs.append({n: e.debug_read(n) for n in PIPE_BUFFERS})
-    for name in ("online", "target", "adam_m", "adam_v"):
-        assert torch.equal(getattr(algs[0].engine, name), getattr(algs[1].engine, name)), name
-    assert algs[0].engine.get_state() == algs[1].engine.get_state()
-    assert torch.isfinite(algs[1].engine.online).all()
-    for k in stats[0]:
-        assert stats[0][k] == stats[1][k] or (np.isnan(stats[0][k]) and np.isnan(stats[1][k])), (k, stats[0][k], stats[1][k])
-    for n in PIPE_BUFFERS:
-        assert np.array_equal(bufs[0][n], bufs[1][n]), n
-    b0, b1 = algs[0].engine.read_batch(with_logp=False), algs[1].engine.read_batch(with_logp=False)
-    for k in ("obs", "act", "rew", "obs2", "done"):
-        assert np.array_equal(b0[k], b1[k]), k
+    for other in (1, 2):
+        for name in ("online", "target", "adam_m", "adam_v"):
+            assert torch.equal(getattr(algs[0].engine, name), getattr(algs[other].engine, name)), (other, name)
+        assert algs[0].engine.get_state() == algs[other].engine.get_state()
+        assert torch.isfinite(algs[other].engine.online).all()
+        for k in stats[0]:
+            assert stats[0][k] == stats[other][k] or (np.isnan(stats[0][k]) and np.isnan(stats[other][k])), (other, k, stats[0][k], stats[other][k])
+        for n in PIPE_BUFFERS:
+            assert np.array_equal(bufs[0][n], bufs[other][n]), (other, n)
+        b0, b1 = algs[0].engine.read_batch(with_logp=False), algs[other].engine.read_batch(with_logp=False)
+        for k in ("obs", "act", "rew", "obs2", "done"):
+            assert np.array_equal(b0[k], b1[k]), (other, k)
     # a second run on the same handle continues identically (the phase graphs are cached; the other phase is picked)
     algs[0].engine.time_steps(first + total, per_graph, use_graph=False)
     algs[1].engine.graph_run(first + total, per_graph)
