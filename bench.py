@@ -666,6 +666,10 @@ def chain_flops(lay, batch):
     per_row["chain_fwd+next"] = per_row["chain_fwd"] + 2 * pi
     per_row["chain_fwd_q"] = per_row["chain_fwd"] - 2 * pi
     per_row["chain_fwd_q+next"] = per_row["chain_fwd"]
+    # the last launch of an update whose (discarded) policy backward is deferred: the critics' weight-gradient tiles only;
+    # `deferred_bwd_pi` is what the next forward launch then carries on top of its own chains
+    per_row["chain_dw_q"] = 2 * dw_q
+    per_row["deferred_bwd_pi"] = 2 * A_ * W + hid + dw_pi
     per_row["chain_bwd"] = per_row["chain_bwd_q"] + per_row["chain_bwd_pi"] + per_row["dW"]   # merged backward + optimiser launch
     return {k: 2.0 * v * batch for k, v in per_row.items()}
 
@@ -945,6 +949,9 @@ def main():
             out["dominant_kernel"] = {"name": dom[0], "us": round(dom[1] * 1000, 2)}
             if chain and Bb % 256 == 0 or chain and Bb <= 256:
                 fl = chain_flops(lay, Bb)
+                if any(r[0] == "chain_dw_q" for r in prof):   # the policy backward of the previous update rides in these launches
+                    fl["chain_fwd_q"] += fl["deferred_bwd_pi"]
+                    fl["chain_fwd_q+next"] += fl["deferred_bwd_pi"]
                 kname = {"chain_fwd+next": "dsact::k_chain_fwdp (own minibatch: all 8 chains; + policy / policy_target of the next minibatch)",
                          "chain_fwd_q": "dsact::k_chain_fwdp (fresh-critic chains only)", "chain_fwd_q+next": "dsact::k_chain_fwdp",
                          "chain_bwd": "dsact::k_chain_bwd2 (critics' + policy backward + all dW/Adam tiles in one launch)",

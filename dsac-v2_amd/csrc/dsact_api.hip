@@ -259,17 +259,21 @@ struct dsact_handle {
     float* Hpi[DSACT_MAX_HIDDEN_LAYERS]; float* Gpi[DSACT_MAX_HIDDEN_LAYERS];
     float* qout_t[2] = {nullptr, nullptr};
     float* part_heads = nullptr;
+    float* X0t = nullptr;
   };
   static constexpr int kPipeSets = 4;
   static constexpr int kPipePhases = 4;
   PipeSet pset[kPipeSets];
   char* pipe_ws = nullptr;
+  bool pipe_defer_now = false;          // set while the update being enqueued defers its (discarded) policy backward
   bool pipe_graph = false;              // the captured graphs are the pipelined ones (pgraph / pexec, one per phase)
   hipGraph_t pgraph[kPipePhases] = {nullptr, nullptr, nullptr, nullptr};
   hipGraphExec_t pexec[kPipePhases] = {nullptr, nullptr, nullptr, nullptr};
   PipeFwd* pargs[kPipePhases] = {nullptr, nullptr, nullptr, nullptr};   // device: one PipeFwd per captured forward launch
   bool env_no_pipe = false;             // DSACT_NO_PIPE: graph replays without the pipelining (A/B)
   int env_pipe_qt = 0;                  // DSACT_PIPE_QT=1: q_target(obs2', act2') of the next minibatch is precomputed too
+  bool env_no_pipe_defer = false;       // DSACT_NO_PIPE_DEFER: the discarded policy backward stays in its own update's last launch (A/B)
+  bool env_pipe_qp_split = false;       // DSACT_PIPE_QP_SPLIT: q(obs,new_act) computes its own observation part in every pipelined launch
   int env_pipe_rg_next = 2;             // DSACT_PIPE_RG_NEXT=1|2: rows / 4 per workgroup of the next minibatch's policy units
   int env_pipe_rg_side = 2;             // DSACT_PIPE_RG_SIDE=1|2: rows / 4 per workgroup of the units off the critical path (pit, q_c, q_t)
   std::string env_pipe_map;             // DSACT_PIPE_MAP: XCD lists per unit (experiments), see pipe_xcds
@@ -1669,6 +1673,7 @@ int alloc_pipe_sets(dsact_handle* h) {
       for (int l = 0; l < L; ++l) { p.Hpi[l] = c.take<float>(B * h->w[l]); p.Gpi[l] = c.take<float>(B * h->w[l]); }
       for (int i = 0; i < 2; ++i) p.qout_t[i] = c.take<float>(B * 2);
       p.part_heads = c.take<float>((size_t)h->n_heads_wg * 2);
+      p.X0t = c.take<float>(B * (size_t)((h->F + A + 31) / 32 * 32));
     }
     if (!pass) {
       HIPCHK(h, hipMalloc((void**)&h->pipe_ws, c.off + 256));
@@ -1682,6 +1687,7 @@ int alloc_pipe_sets(dsact_handle* h) {
   for (int l = 0; l < L; ++l) { p0.Hpi[l] = h->Hb[C_PI][l]; p0.Gpi[l] = h->Gb[C_PI][l]; }
   for (int i = 0; i < 2; ++i) p0.qout_t[i] = h->qout_t[i];
   p0.part_heads = h->part_heads;
+  p0.X0t = h->X0t;
   return DSACT_OK;
 }
 
@@ -1694,9 +1700,14 @@ void apply_pipe_set(dsact_handle* h, int k) {
   for (int l = 0; l < h->L; ++l) { h->Hb[C_PI][l] = p.Hpi[l]; h->Gb[C_PI][l] = p.Gpi[l]; }
   for (int i = 0; i < 2; ++i) h->qout_t[i] = p.qout_t[i];
   h->part_heads = p.part_heads;
+  h->X0t = p.X0t;
   h->Xc[C_PI] = h->Xc[C_Q1C] = h->Xc[C_Q2C] = h->X0;
   h->Xc[C_PIT] = h->Xc[C_Q1T] = h->Xc[C_Q2T] = h->X2;
   h->Xc[C_Q1P] = h->Xc[C_Q2P] = h->XP;
+}
+
+const char* pipe_fwd_name(bool pre, bool do_pre) {
+  return pre ? (do_pre ? "chain_fwd_q+next" : "chain_fwd_q") : (do_pre ? "chain_fwd+next" : "chain_fwd");
 }
 
 // roles of a pipelined forward launch, in dispatch-priority order: units that never wait, own minibatch then next; then
@@ -1714,7 +1725,7 @@ static const char* pipe_xcds_default(bool pre, bool do_pre, int role) {
     return t[role];
   }
   if (!do_pre) {   // TF: only the fresh-critic chains; q_c and q_p one workgroup per CU, q_t in the second slots beside q_p
-    static const char* t[PR_N] = {"", "", "01", "23", "", "", "45", "67", "45", "67", "", ""};
+    static const char* t[PR_N] = {"", "", "01", "23", "", "", "45", "67", "0246", "1357", "", ""};
     return t[role];
   }
   static const char* t[PR_N] = {"", "", "01", "23", "4", "5", "60", "72", "46", "57", "46", "57"};   // TT (delay_update >= 3)
@@ -1749,7 +1760,8 @@ static PipePlace pipe_place(const dsact_handle* h, bool pre, bool do_pre, int ro
 
 // fills P for the forward launch of a pipelined update: own minibatch = set_own (pre: its policy units ran in the previous
 // launch), next minibatch = set_next (do_pre: its policy units run here). Leaves the handle on set_own.
-int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do_pre, PipeFwd& P) {
+// bp: nullptr, or the deferred policy backward of the previous update this launch carries (its chain slices and tiles)
+int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do_pre, PipeFwd& P, const BwdPiArgs* bp = nullptr) {
   memset(&P, 0, sizeof(P));
   const bool qt_pre = h->env_pipe_qt != 0;
   int* f = h->chain_flags;
@@ -1767,7 +1779,7 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
     rgs[r] = (B % 8 == 0) ? pl.rg : 1; xc[r] = pl.xcds;
   }
   auto cap = [&](int consumer, int producer) { if (rgs[consumer] > rgs[producer]) rgs[consumer] = rgs[producer]; };
-  cap(PR_Q1P, PR_Q1C); cap(PR_Q2P, PR_Q2C);
+  if (!(pre || h->env_pipe_qp_split)) { cap(PR_Q1P, PR_Q1C); cap(PR_Q2P, PR_Q2C); }
   if (!pre) { cap(PR_Q1P, PR_PI); cap(PR_Q2P, PR_PI); cap(PR_Q1T, PR_PIT); cap(PR_Q2T, PR_PIT); }
   cap(PR_Q1TN, PR_PITN); cap(PR_Q2TN, PR_PITN);
   auto put = [&](int role, const FwdUnit& u) {
@@ -1798,16 +1810,21 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
   };
   apply_pipe_set(h, set_own);
   if (!pre) policy_units(PR_PI, PR_PIT, true, true);
+  // q(obs, new_act): eager updates run it as "saved observation part of q(obs, act)'s first layer + action part". A unit
+  // that computes the observation part itself and merges the accumulators where the hand-over would have (SEG_FULL_SPLIT)
+  // produces the same bits with no producer: that is how the launches whose policy units ran earlier hold it (no in-launch
+  // dependency at all), and -- DSACT_PIPE_QP_SPLIT=1 -- optionally the others (observation part under the wait for pi)
+  const bool qp_split = pre || h->env_pipe_qp_split;
   for (int i = 0; i < 2; ++i) {
-    FwdUnit qc = fwd_unit(h, C_Q1C + i, SEG_FULL_SAVE, HEAD_Q);
-    qc.zsave = h->zobs[i]; qc.qout = h->qout_c[i]; qc.qstd = h->qstd_c[i];
+    FwdUnit qc = fwd_unit(h, C_Q1C + i, qp_split ? SEG_FULL : SEG_FULL_SAVE, HEAD_Q);
+    qc.qout = h->qout_c[i]; qc.qstd = h->qstd_c[i];
     if (i == 0) qc.x0t = h->X0t;
-    qc.zdone = f + (2 + i) * kChainFlagSlices;
+    if (!qp_split) { qc.zsave = h->zobs[i]; qc.zdone = f + (2 + i) * kChainFlagSlices; }
     put(PR_Q1C + i, qc);
-    FwdUnit qp = fwd_unit(h, C_Q1P + i, SEG_ACT_FROM_SAVED, HEAD_Q);
-    qp.zinit = h->zobs[i]; qp.qout = h->qout_p[i];
-    if (!pre) { qp.wait0 = P.u[PR_PI].done; qp.wait_rows0 = 4 * rgs[PR_PI]; }
-    qp.wait1 = qc.zdone; qp.wait_rows1 = 4 * rgs[PR_Q1C + i];
+    FwdUnit qp = fwd_unit(h, C_Q1P + i, qp_split ? SEG_FULL_SPLIT : SEG_ACT_FROM_SAVED, HEAD_Q);
+    qp.qout = h->qout_p[i];
+    if (!pre) { qp.wait0 = P.u[PR_PI].done; qp.wait_rows0 = 4 * rgs[PR_PI]; qp.late_wait = 1; }
+    if (!qp_split) { qp.zinit = h->zobs[i]; qp.wait1 = qc.zdone; qp.wait_rows1 = 4 * rgs[PR_Q1C + i]; }
     put(PR_Q1P + i, qp);
   }
   if (!pre || !qt_pre) target_units(PR_Q1T, PR_PIT, !pre);
@@ -1823,7 +1840,7 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
   a.B = h->B; a.F = h->F; a.A = h->A; a.L = h->L; a.ldx = h->ldx;
   a.s_obs = h->s_obs; a.s_act = h->s_act; a.v1_stats = 0; a.Cb = h->B / 16;
   a.act_scale = h->act_scale; a.act_center = h->act_center; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
-  a.timeline = tl_for(h, "chain_fwd");
+  a.timeline = tl_for(h, pipe_fwd_name(pre, do_pre));
   a.spin_timeout = h->handoff_dev;
   a.debug_withhold = h->debug_withhold == 1;
   // block table: every XCD's queue is filled role by role (the enum is the priority order), a role's slices are dealt
@@ -1831,8 +1848,14 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
   std::vector<int> q[8];
   for (int r = 0; r < PR_N; ++r) {
     if (idx[r] < 0) continue;
+    if (bp && r == PR_Q1P)   // the deferred chain's slices: producers of the tiles at the end of every queue; they never wait
+      for (int sl = 0; sl < bp->n_slices; ++sl) q[sl & 7].push_back((kPipeRoleBwdPi << 16) | sl);
     const int ns = P.u[r].n_slices;
     for (int sl = 0; sl < ns; ++sl) q[xc[r][sl % xc[r].size()] - '0'].push_back((r << 16) | sl);
+  }
+  if (bp) {   // the deferred policy tiles: XCD x takes the x-th contiguous eighth of the tile list (xcd_chunk's locality)
+    const int per = (bp->n_pi_tiles + 7) >> 3;
+    for (int t = 0; t < bp->n_pi_tiles; ++t) q[t / per].push_back((kPipeRoleTile << 16) | t);
   }
   size_t rounds = 0;
   for (int x = 0; x < 8; ++x) rounds = q[x].size() > rounds ? q[x].size() : rounds;
@@ -1844,12 +1867,25 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
   return DSACT_OK;
 }
 
-int launch_chain_fwd_pipe(dsact_handle* h, const char* name, const PipeFwd& host, const PipeFwd* dev) {
+int launch_chain_fwd_pipe(dsact_handle* h, const char* name, const PipeFwd& host, const PipeFwd* dev, const BwdPiArgs* bp = nullptr, int bp_rg = 2) {
   // (forwards of a complete update: the critics' backward clears the ready flags)
   if (h->flags_dirty) HIPCHK(h, hipMemsetAsync(h->chain_flags, 0, kChainFlags * sizeof(int), h->stream));
   h->flags_dirty = true;
-  const size_t lds = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 8).total * sizeof(float);
+  size_t lds = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 8).total * sizeof(float);
   const int grid = host.n_blocks;
+  if (bp) {   // + the previous update's deferred policy backward (k_chain_fwdpb, 256 threads for its tiles)
+    const size_t lb = (size_t)chain_lds(4 * h->SoT, h->cW, 4 * bp_rg).total * sizeof(float);
+    if (lb > lds) lds = lb;
+    if (lds < kDw2LdsFloats * sizeof(float)) lds = kDw2LdsFloats * sizeof(float);
+    if (generic_act(h)) {
+      if (h->cNT == 1) return launch(h, name, k_chain_fwdpb<1, true>, dim3(grid), dim3(256), lds, dev, *bp, bp_rg);
+      if (h->cNT == 2) return launch(h, name, k_chain_fwdpb<2, true>, dim3(grid), dim3(256), lds, dev, *bp, bp_rg);
+      return launch(h, name, k_chain_fwdpb<4, true>, dim3(grid), dim3(256), lds, dev, *bp, bp_rg);
+    }
+    if (h->cNT == 1) return launch(h, name, k_chain_fwdpb<1>, dim3(grid), dim3(256), lds, dev, *bp, bp_rg);
+    if (h->cNT == 2) return launch(h, name, k_chain_fwdpb<2>, dim3(grid), dim3(256), lds, dev, *bp, bp_rg);
+    return launch(h, name, k_chain_fwdpb<4>, dim3(grid), dim3(256), lds, dev, *bp, bp_rg);
+  }
   if (generic_act(h)) {
     if (h->cNT == 1) return launch(h, name, k_chain_fwdp<1, true>, dim3(grid), dim3(64), lds, dev);
     if (h->cNT == 2) return launch(h, name, k_chain_fwdp<2, true>, dim3(grid), dim3(128), lds, dev);
@@ -1969,6 +2005,20 @@ int enqueue_chain_bwd_pi(dsact_handle* h, int x0, int x1, bool fused, bool merge
 #undef CALL_CP
 }
 
+// pipelined graph, update whose policy backward is deferred into the next forward launch (k_chain_fwdpb): the last launch
+// of the update holds the critics' weight-gradient / Adam tiles and the block that closes the update, nothing else
+int enqueue_chain_bwd_pi_close(dsact_handle* h, bool fused) {
+  BwdPiArgs a;
+  int rg;
+  bwd_pi_args(h, h->dw2_off[0], h->dw2_off[2], fused, a, rg, true);
+  a.n_slices = 0; a.n_chain_blocks = 0; a.n_pi_tiles = 0;   // no chain slice arrives, nobody but the closing block waits (for 0 arrivals)
+  const size_t lds = kDw2LdsFloats * sizeof(float);
+  const int grid = xcd_chunk_grid(a.n_extra) + 1;
+#define CALL_CPC(N, G) return launch(h, "chain_dw_q", k_chain_bwd_pi<N, G>, dim3(grid), dim3(kThreads), lds, a)
+  CHAIN_NT(CALL_CPC, 2);
+#undef CALL_CPC
+}
+
 // same contract as enqueue_grads (phases, fused optimiser, riders of the loss launch)
 int enqueue_grads_chain(dsact_handle* h, bool actor_backward, bool fused, int phase, const RideArgs* ride) {
   const int* off = h->dw2_off;
@@ -2010,7 +2060,10 @@ actor_part:
     if (h->env_ride_slots > 0 && ride_end - h->dw2_off[0] > h->env_ride_slots) ride_end = h->dw2_off[0] + h->env_ride_slots;
     // batch <= 256: the policy's own tiles and the closing block ride in the same launch behind the riders and wait for
     // the chain's arrival counter (k_chain_bwd_pi, merge_dw) -- one launch and one kernel boundary less per update
-    if (h->pi_merge && h->dw_chunks == 1 && ride_end == h->dw2_off[2]) return enqueue_chain_bwd_pi(h, h->dw2_off[0], ride_end, fused, true);
+    if (h->pi_merge && h->dw_chunks == 1 && ride_end == h->dw2_off[2]) {
+      if (h->pipe_defer_now) return enqueue_chain_bwd_pi_close(h, fused);   // the policy backward rides in the next forward launch
+      return enqueue_chain_bwd_pi(h, h->dw2_off[0], ride_end, fused, true);
+    }
     TRY(enqueue_chain_bwd_pi(h, h->dw2_off[0], ride_end, fused));
     if (h->dw_chunks == 1) return run_dw2(h, ride_end, h->dw2_off[3], fused, fused);
     TRY(run_dw2(h, ride_end, h->dw2_off[3], false, false));
@@ -2417,6 +2470,8 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->env_no_mixed_rg = getenv("DSACT_NO_MIXED_RG") != nullptr;
   h->env_no_pipe = getenv("DSACT_NO_PIPE") != nullptr;
   if (const char* v = getenv("DSACT_PIPE_QT")) h->env_pipe_qt = atoi(v) ? 1 : 0;
+  h->env_pipe_qp_split = getenv("DSACT_PIPE_QP_SPLIT") != nullptr;
+  h->env_no_pipe_defer = getenv("DSACT_NO_PIPE_DEFER") != nullptr;
   if (const char* v = getenv("DSACT_PIPE_RG_NEXT")) h->env_pipe_rg_next = atoi(v) == 1 ? 1 : 2;
   if (const char* v = getenv("DSACT_PIPE_RG_SIDE")) h->env_pipe_rg_side = atoi(v) == 1 ? 1 : 2;
   if (const char* v = getenv("DSACT_PIPE_MAP")) h->env_pipe_map = v;
@@ -2540,6 +2595,12 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwd2<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdpb<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdpb<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdpb<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdpb<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdpb<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdpb<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdp<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdp<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdp<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
@@ -3136,24 +3197,41 @@ static int capture_updates(dsact_handle* h, int n, uint32_t flags, bool merged, 
 // Every precomputed item is produced and consumed inside one sequence: its first update never relies on one, its last
 // never produces one. Same kernels behind the forward, same arithmetic per row: bit-identical to eager updates.
 // The forward launches read their unit tables from `dev_args` (n PipeFwd, filled here BEFORE anything is enqueued).
-static const char* pipe_fwd_name(bool pre, bool do_pre) {
-  return pre ? (do_pre ? "chain_fwd_q+next" : "chain_fwd_q") : (do_pre ? "chain_fwd+next" : "chain_fwd");
-}
-struct PipePlan { std::vector<PipeFwd> host; std::vector<char> pre, dop; };
+struct PipePlan {
+  std::vector<PipeFwd> host; std::vector<char> pre, dop;
+  std::vector<char> defer;        // update s leaves the policy alone and has a successor: its policy backward rides in launch s + 1
+  std::vector<BwdPiArgs> bp;      // [s]: the deferred policy backward of update s - 1 (valid when defer[s - 1])
+  std::vector<int> bp_rg;
+};
 // unit tables of the n forward launches -> plan.host and (synchronous copy: call it BEFORE a stream capture begins) dev_args
 static int plan_updates_pipe(dsact_handle* h, int n, int phase, PipePlan& plan, PipeFwd* dev_args) {
   const int D = h->cfg.delay_update;
   auto set_of = [&](int s) { return (s - (n - 1)) & (dsact_handle::kPipeSets - 1); };
   plan.host.resize((size_t)n); plan.pre.resize((size_t)n); plan.dop.resize((size_t)n);
+  plan.defer.assign((size_t)n, 0); plan.bp.resize((size_t)n); plan.bp_rg.assign((size_t)n, 2);
+  // the discarded policy backward can move when it is the merged launch's (chain + its own tiles behind the arrival counter)
+  const int rg_pi = h->env_chain_rg_pi ? h->env_chain_rg_pi : h->env_chain_rg ? h->env_chain_rg : (h->B >= 8 ? h->cRG : 1);
+  const bool can_defer = h->pi_merge && h->dw_chunks == 1 && !h->fat_bwd && h->env_ride_slots == 0 && rg_pi <= 2 && !h->env_no_pipe_defer;
   bool pre = false;
   int rc = DSACT_OK;
+  h->mirror_w0 = true;   // (what the enqueue pass sets: the tiles' argument blocks are built here)
   for (int s = 0; s < n && rc == DSACT_OK; ++s) {
     const bool leaves_policy = ((phase + s) % D) != 0;        // this update's close does not touch policy / alpha / targets
     const bool do_pre = s + 1 < n && leaves_policy;
-    rc = pipe_fwd_build(h, set_of(s), set_of(s + 1), pre, do_pre, plan.host[(size_t)s]);
+    const BwdPiArgs* bp = nullptr;
+    if (s > 0 && plan.defer[(size_t)s - 1]) {
+      apply_pipe_set(h, set_of(s - 1));   // the deferred backward works on the PREVIOUS update's minibatch
+      BwdPiArgs& a = plan.bp[(size_t)s];
+      bwd_pi_args(h, h->dw2_off[2], h->dw2_off[2], true, a, plan.bp_rg[(size_t)s], true);
+      a.finalize = 0;                     // that update was closed by its own last launch
+      bp = &a;
+    }
+    rc = pipe_fwd_build(h, set_of(s), set_of(s + 1), pre, do_pre, plan.host[(size_t)s], bp);
     plan.pre[(size_t)s] = pre; plan.dop[(size_t)s] = do_pre;
+    plan.defer[(size_t)s] = do_pre && can_defer;
     pre = do_pre;
   }
+  h->mirror_w0 = false;
   apply_pipe_set(h, 0);
   TRY(rc);
   HIPCHK(h, hipMemcpy(dev_args, plan.host.data(), (size_t)n * sizeof(PipeFwd), hipMemcpyHostToDevice));
@@ -3176,7 +3254,9 @@ static int enqueue_updates_pipe(dsact_handle* h, int n, const PipePlan& plan, Pi
   }
   for (int s = 0; s < n && rc == DSACT_OK; ++s) {
     apply_pipe_set(h, set_of(s));
-    rc = launch_chain_fwd_pipe(h, pipe_fwd_name(pre_v[(size_t)s], do_v[(size_t)s]), host[(size_t)s], dev_args + s);
+    const bool carries = s > 0 && plan.defer[(size_t)s - 1];
+    rc = launch_chain_fwd_pipe(h, pipe_fwd_name(pre_v[(size_t)s], do_v[(size_t)s]), host[(size_t)s], dev_args + s,
+                               carries ? &plan.bp[(size_t)s] : nullptr, plan.bp_rg[(size_t)s]);
     if (rc != DSACT_OK) break;
     RideArgs ride;
     memset(&ride, 0, sizeof(ride));
@@ -3191,7 +3271,9 @@ static int enqueue_updates_pipe(dsact_handle* h, int n, const PipePlan& plan, Pi
       ride.n_gather = 0;
     }
     ride.bookkeeping = 1;
+    h->pipe_defer_now = plan.defer[(size_t)s] != 0;
     rc = enqueue_grads(h, true, true, 2, &ride);
+    h->pipe_defer_now = false;
   }
   apply_pipe_set(h, 0);
   h->mirror_w0 = false;

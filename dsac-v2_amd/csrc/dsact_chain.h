@@ -968,6 +968,9 @@ __global__ void __launch_bounds__(64 * NW, 2) k_chain_fwdp(const PipeFwd* __rest
   const int code = p->blk[blockIdx.x];
   if (code < 0) return;
   const int unit = code >> 16, slice = code & 0xffff;
+#ifdef DSACT_TIMELINE
+  if (p->c.timeline && threadIdx.x == 0 && blockIdx.x < 512) p->c.timeline[blockIdx.x * 16 + 11] = unit + 1;   // who ran here
+#endif
   if (p->u[unit].rg == 1) chain_fwd_body<NW, 1, GA>(p->c, p->u[unit], unit, slice, lds);
   else chain_fwd_body<NW, 2, GA>(p->c, p->u[unit], unit, slice, lds);
 }
@@ -1326,6 +1329,43 @@ __global__ void __launch_bounds__(256) k_chain_bwd_pi(BwdPiArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if ((int)blockIdx.x >= a.n_chain_blocks) { bwd_pi_tail_blocks(a, (int)blockIdx.x - a.n_chain_blocks, lds); return; }
   bwd_pi_body<NW, RG>(a, (int)blockIdx.x, lds);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_chain_fwdpb: k_chain_fwdp + the DEFERRED policy backward of the previous update. An update that leaves the policy
+// alone (iteration % delay_update != 0) still computes the policy gradient -- the reference does (dsac_v2.py:174-186)
+// and discards it (:324) -- but nothing reads it: its rsample backward, policy dZ chain and the policy's 240 weight-gradient
+// tiles were the critical path of that update's last launch (chain 12 us, then the tiles: 20 us) for no consumer. In the
+// pipelined graph they ride in the NEXT update's forward launch, which holds only the fresh-critic chains and leaves a
+// slot per CU free: same arithmetic, same buffers (written before that update's own policy backward needs them), and the
+// previous update's last launch is the critics' weight-gradient / Adam tiles + the block that closes the update.
+// Block table codes: unit kPipeRoleBwdPi = a slice of the policy backward chain, kPipeRoleTile = policy tile `slice`
+// (waits for the chain's arrival counter like the merged policy-backward launch). 256 threads wide for the tiles.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kPipeRoleBwdPi = 14, kPipeRoleTile = 15;
+template <int NW, bool GA = false>
+__global__ void __launch_bounds__(256, 2) k_chain_fwdpb(const PipeFwd* __restrict__ pd, BwdPiArgs bp, int bp_rg) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  typedef __attribute__((address_space(4))) const PipeFwd KP;
+  KP* p = (KP*)(unsigned long long)pd;
+  const int code = p->blk[blockIdx.x];
+  if (code < 0) return;
+  const int unit = code >> 16, slice = code & 0xffff;
+#ifdef DSACT_TIMELINE
+  if (p->c.timeline && threadIdx.x == 0 && blockIdx.x < 512) p->c.timeline[blockIdx.x * 16 + 11] = unit + 1;
+#endif
+  if (unit == kPipeRoleBwdPi) {
+    if (bp_rg == 1) bwd_pi_body<NW, 1>(bp, slice, lds); else bwd_pi_body<NW, 2>(bp, slice, lds);
+    return;
+  }
+  if (unit == kPipeRoleTile) {
+    dw2_tile<2, ArriveWait>(bp.dw, bp.pi_tile0 + slice, lds, ArriveWait{bp.cnt_pi, bp.n_slices, bp.spin_timeout});
+    return;
+  }
+  if ((int)threadIdx.x >= 64 * NW) return;      // narrow nets: the launch is 256 wide for the tiles
+  if (p->u[unit].rg == 1) chain_fwd_body<NW, 1, GA>(p->c, p->u[unit], unit, slice, lds);
+  else chain_fwd_body<NW, 2, GA>(p->c, p->u[unit], unit, slice, lds);
 }
 
 }  // namespace dsact

@@ -705,6 +705,8 @@ PIPE_BUFFERS = ("logits_pi", "logp_new", "logp2", "qout_t0", "qout_t1", "qout_p0
     (24, 6, (128, 128, 128), 32, 3, 4, 0, 12, {"DSACT_PIPE_QT": "1", "DSACT_PIPE_RG_SIDE": "1"}),
     (16, 4, (64, 64), 64, 1, 4, 0, 8, {}),             # delay_update 1: nothing to share, the plain graph
     (16, 4, (64, 64), 16, 2, 2, 1, 6, {"DSACT_PIPE_RG_NEXT": "1"}),       # 4 slices per unit
+    (16, 4, (64, 64), 64, 2, 4, 1, 8, {"DSACT_NO_PIPE_DEFER": "1"}),      # the discarded policy backward stays in its own update
+    (32, 8, (256, 256), 48, 2, 5, 1, 10, {"DSACT_PIPE_QT": "1", "DSACT_PIPE_QP_SPLIT": "1"}),
     (376, 17, (256, 256, 256), 256, 2, 8, 1, 16, {}),  # the BASELINE.json shape
     (376, 17, (256, 256, 256), 256, 2, 6, 4, 12, {"DSACT_PIPE_MAP": "FT.pit=23:1;FT.q1t=01;TF.q1c=0123:2"}),
 ])
