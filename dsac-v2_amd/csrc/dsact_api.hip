@@ -272,6 +272,8 @@ struct dsact_handle {
   PipeFwd* pargs[kPipePhases] = {nullptr, nullptr, nullptr, nullptr};   // device: one PipeFwd per captured forward launch
   bool env_no_pipe = false;             // DSACT_NO_PIPE: graph replays without the pipelining (A/B)
   int env_pipe_qt = 0;                  // DSACT_PIPE_QT=1: q_target(obs2', act2') of the next minibatch is precomputed too
+  int env_pipe_bp_rg = 0;               // DSACT_PIPE_BP_RG=1|2: rows / 4 per workgroup of the deferred policy backward chain (0: as in its own launch)
+  bool env_no_pipe_warm = false;        // DSACT_NO_PIPE_WARM: no L2 warm-up touches in the pipelined forward launches (A/B)
   bool env_no_pipe_defer = false;       // DSACT_NO_PIPE_DEFER: the discarded policy backward stays in its own update's last launch (A/B)
   bool env_pipe_qp_split = false;       // DSACT_PIPE_QP_SPLIT: q(obs,new_act) computes its own observation part in every pipelined launch
   int env_pipe_rg_next = 2;             // DSACT_PIPE_RG_NEXT=1|2: rows / 4 per workgroup of the next minibatch's policy units
@@ -1863,6 +1865,17 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
   P.n_blocks = (int)(8 * rounds);
   for (size_t r = 0; r < rounds; ++r)
     for (int x = 0; x < 8; ++x) P.blk[8 * r + x] = r < q[x].size() ? q[x][r] : -1;
+  if (!h->env_no_pipe_warm) {   // L2 warm-up shares: (index, count) among the workgroups of the same unit on the same XCD
+    for (int x = 0; x < 8; ++x) {
+      int cnt[PR_N], seen[PR_N];
+      for (int r = 0; r < PR_N; ++r) cnt[r] = seen[r] = 0;
+      for (int code : q[x]) if ((code >> 16) < PR_N) cnt[code >> 16]++;
+      for (size_t r = 0; r < q[x].size(); ++r) {
+        const int role = q[x][r] >> 16;
+        if (role < PR_N) P.warm[8 * r + x] = (seen[role]++ << 16) | cnt[role];
+      }
+    }
+  }
   h->n_heads_parts = h->B / 4;
   return DSACT_OK;
 }
@@ -1954,7 +1967,7 @@ int enqueue_chain_bwd_q(dsact_handle* h, int n_units, const RideArgs* ride) {
 
 // rsample backward + policy dZ chain; weight-gradient tiles [x0, x1) ride along on the other CUs
 // merge: the policy's tiles [x1, dw2_off[3]) and (fused) the closing block ride behind the riders [x0, x1)
-void bwd_pi_args(dsact_handle* h, int x0, int x1, bool fused, BwdPiArgs& a, int& rg_out, bool merge = false) {
+void bwd_pi_args(dsact_handle* h, int x0, int x1, bool fused, BwdPiArgs& a, int& rg_out, bool merge = false, int rg_force = 0) {
   memset(&a, 0, sizeof(a));
   const int L = h->L;
   a.dA[0] = h->dAq[0]; a.dA[1] = h->dAq[1];
@@ -1966,7 +1979,7 @@ void bwd_pi_args(dsact_handle* h, int x0, int x1, bool fused, BwdPiArgs& a, int&
   // the policy chain shares its launch with ~2 rounds of weight-gradient tiles, which bound it: 8-row workgroups leave
   // them 32 more CUs (measured: 15.7 us vs 16.3 us with 4-row workgroups at batch 256)
   const int rg_pi = h->env_chain_rg_pi;   // experiments (4-row slices with the merged tiles waiting for the chain: 20.99 vs 20.04 us, round 3)
-  const int rg = h->fat_bwd ? 4 * fat_rt(h, 1) : rg_pi ? rg_pi : h->env_chain_rg ? h->env_chain_rg : (h->B >= 8 ? h->cRG : 1);
+  const int rg = rg_force ? rg_force : h->fat_bwd ? 4 * fat_rt(h, 1) : rg_pi ? rg_pi : h->env_chain_rg ? h->env_chain_rg : (h->B >= 8 ? h->cRG : 1);
   a.n_slices = h->B / (4 * rg); a.B = h->B; a.A = h->A; a.L = L; a.Cb = h->B / 16;
   a.inv_B = 1.0f / (float)h->B; a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed;
   a.act_scale = h->act_scale; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
@@ -2472,6 +2485,8 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (const char* v = getenv("DSACT_PIPE_QT")) h->env_pipe_qt = atoi(v) ? 1 : 0;
   h->env_pipe_qp_split = getenv("DSACT_PIPE_QP_SPLIT") != nullptr;
   h->env_no_pipe_defer = getenv("DSACT_NO_PIPE_DEFER") != nullptr;
+  h->env_no_pipe_warm = getenv("DSACT_NO_PIPE_WARM") != nullptr;
+  if (const char* v = getenv("DSACT_PIPE_BP_RG")) h->env_pipe_bp_rg = atoi(v) == 1 ? 1 : atoi(v) == 2 ? 2 : 0;
   if (const char* v = getenv("DSACT_PIPE_RG_NEXT")) h->env_pipe_rg_next = atoi(v) == 1 ? 1 : 2;
   if (const char* v = getenv("DSACT_PIPE_RG_SIDE")) h->env_pipe_rg_side = atoi(v) == 1 ? 1 : 2;
   if (const char* v = getenv("DSACT_PIPE_MAP")) h->env_pipe_map = v;
@@ -3222,7 +3237,8 @@ static int plan_updates_pipe(dsact_handle* h, int n, int phase, PipePlan& plan, 
     if (s > 0 && plan.defer[(size_t)s - 1]) {
       apply_pipe_set(h, set_of(s - 1));   // the deferred backward works on the PREVIOUS update's minibatch
       BwdPiArgs& a = plan.bp[(size_t)s];
-      bwd_pi_args(h, h->dw2_off[2], h->dw2_off[2], true, a, plan.bp_rg[(size_t)s], true);
+      // (the deferred chain shares its launch with forward chains, not with ~500 riding tiles: 4-row slices by default)
+      bwd_pi_args(h, h->dw2_off[2], h->dw2_off[2], true, a, plan.bp_rg[(size_t)s], true, h->env_pipe_bp_rg);
       a.finalize = 0;                     // that update was closed by its own last launch
       bp = &a;
     }

@@ -671,8 +671,13 @@ inline int fwd_grid(const FwdArgs& a) {
 // `a`: the launch's common fields (its unit table is not read here); `u`: the unit -- an element of a.u (k_chain_fwd /
 // k_chain_fwd2, kernel arguments) or of the pipelined graph's unit table in device memory (k_chain_fwdp)
 // (AT / UT: FwdArgs / FwdUnit, or their constant-address-space qualified forms -- every field stays a scalar load)
-template <int NW, int RG, bool GA = false, typename AT = FwdArgs, typename UT = FwdUnit>
-__device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int unit, int slice, float* lds) {
+// warm_cnt > 0 (pipelined launches): this workgroup is number warm_idx of the warm_cnt workgroups that run this unit on
+// this XCD, and touches its share of the unit's packed weights (one dword per 128-byte line) right after its own stream
+// has started: every launch begins with cold L2s (the weights were rewritten by the previous update's Adam tiles on other
+// XCDs), the workgroups of a unit stream in lockstep, and 16 steps of look-ahead (~0.6 us) do not cover a miss to the
+// memory side -- the first layer ran at 112 cycles per step against 81 for the later ones (profiles/r04_pipe_timeline.txt).
+template <int NW, int RG, bool GA = false, typename AT = FwdArgs, typename UT = FwdUnit, bool WARM = false>
+__device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int unit, int slice, float* lds, int warm_idx = 0, int warm_cnt = 0) {
   constexpr int W = 64 * NW, SH = W / 4, R = 4 * RG, NTHR = 64 * NW, TPR = NTHR / R;
   int* const done_flag = (u.done && !(a.debug_withhold && unit == 0 && slice == 0)) ? u.done + slice : nullptr;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -692,6 +697,35 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
   WStr ws;
   const float* w0 = u.wf[0] + (size_t)wave * S0 * 256;
   stream_prologue(ws, w0, do_obs ? 0 : a.s_obs, lane4);
+  constexpr int NWARM = 4;
+  float wt[NWARM] = {0.f, 0.f, 0.f, 0.f};
+  if (WARM) {   // (no branch on warm_cnt: with 0 every lane re-reads line 0 -- a branch here would cost the stream a vmcnt(0))
+    const int n0 = NW * S0 * 8, nh = NW * SH * 8;                     // 128-byte lines of the first layer / of a hidden layer
+    const int nhead = u.head == HEAD_NONE ? 0 : (u.head == HEAD_POLICY ? (2 * A + 15) >> 4 : 1) * (W / 16) * 8;
+    const int total = warm_cnt > 0 ? n0 + (L - 1) * nh + nhead : 0;
+    const int share = (total + warm_cnt - 1) / (warm_cnt > 0 ? warm_cnt : 1);
+    const int lo = warm_idx * share, hi = lo + share < total ? lo + share : total;
+    // (branch-free: a scalar branch between the stream prologue's loads and their use makes the compiler wait vmcnt(0))
+    const float* wb[kChMaxL + 1];
+#pragma unroll
+    for (int l = 0; l <= kChMaxL; ++l) wb[l] = u.wf[l <= L ? l : L];
+#pragma unroll
+    for (int q = 0; q < NWARM; ++q) {
+      int i = lo + tid + q * NTHR;
+      i = i < hi ? i : lo;
+      const float* base = wb[0];
+      int off = i;
+#pragma unroll
+      for (int l = 1; l <= kChMaxL; ++l) {
+        const int start = n0 + (l - 1) * nh;              // first line of layer l (the head follows the last hidden layer)
+        const bool in = l <= L && i >= start;
+        base = in ? wb[l] : base;
+        off = in ? i - start : off;
+      }
+      wt[q] = *(const __attribute__((address_space(1))) float*)(base + (size_t)off * 32);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
   float bq[kChMaxL];
 #pragma unroll
   for (int l = 0; l < kChMaxL; ++l) bq[l] = u.bias[l < L ? l : 0][n];
@@ -809,6 +843,10 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
       if (u.zdone) chain_publish(u.zdone + slice);   // drains this wave's prefetch queue once (~1 us) -- off the critical path
     }
     CTL(a.timeline, 2);
+    if (WARM) {   // the touched values are dead; naming them here keeps the loads where they were issued
+      const float wsum = (wt[0] + wt[1]) + (wt[2] + wt[3]);
+      asm volatile("" : : "v"(wsum));
+    }
     if (u.seg == SEG_OBS_ONLY) { CTLR(a.timeline, 15); chain_publish(done_flag); return; }
     if (u.seg == SEG_FULL_SPLIT) {   // what zsave -> zinit carries from an obs-only unit to its SEG_ACT_FROM_SAVED consumer
 #pragma unroll
@@ -957,6 +995,7 @@ struct PipeFwd {
   FwdUnit u[kPipeUnits];
   int n_blocks;
   int blk[kPipeMaxBlocks];          // (unit << 16) | slice, or -1: padding block
+  int warm[kPipeMaxBlocks];         // (index << 16) | count among the workgroups of the same unit on the same XCD; 0: no warm-up
 };
 template <int NW, bool GA = false>
 __global__ void __launch_bounds__(64 * NW, 2) k_chain_fwdp(const PipeFwd* __restrict__ pd) {
@@ -971,8 +1010,11 @@ __global__ void __launch_bounds__(64 * NW, 2) k_chain_fwdp(const PipeFwd* __rest
 #ifdef DSACT_TIMELINE
   if (p->c.timeline && threadIdx.x == 0 && blockIdx.x < 512) p->c.timeline[blockIdx.x * 16 + 11] = unit + 1;   // who ran here
 #endif
-  if (p->u[unit].rg == 1) chain_fwd_body<NW, 1, GA>(p->c, p->u[unit], unit, slice, lds);
-  else chain_fwd_body<NW, 2, GA>(p->c, p->u[unit], unit, slice, lds);
+  const int wm = p->warm[blockIdx.x];
+  typedef __attribute__((address_space(4))) const FwdArgs KA;
+  typedef __attribute__((address_space(4))) const FwdUnit KU;
+  if (p->u[unit].rg == 1) chain_fwd_body<NW, 1, GA, KA, KU, true>(p->c, p->u[unit], unit, slice, lds, wm >> 16, wm & 0xffff);
+  else chain_fwd_body<NW, 2, GA, KA, KU, true>(p->c, p->u[unit], unit, slice, lds, wm >> 16, wm & 0xffff);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1364,8 +1406,11 @@ __global__ void __launch_bounds__(256, 2) k_chain_fwdpb(const PipeFwd* __restric
     return;
   }
   if ((int)threadIdx.x >= 64 * NW) return;      // narrow nets: the launch is 256 wide for the tiles
-  if (p->u[unit].rg == 1) chain_fwd_body<NW, 1, GA>(p->c, p->u[unit], unit, slice, lds);
-  else chain_fwd_body<NW, 2, GA>(p->c, p->u[unit], unit, slice, lds);
+  const int wm = p->warm[blockIdx.x];
+  typedef __attribute__((address_space(4))) const FwdArgs KA;
+  typedef __attribute__((address_space(4))) const FwdUnit KU;
+  if (p->u[unit].rg == 1) chain_fwd_body<NW, 1, GA, KA, KU, true>(p->c, p->u[unit], unit, slice, lds, wm >> 16, wm & 0xffff);
+  else chain_fwd_body<NW, 2, GA, KA, KU, true>(p->c, p->u[unit], unit, slice, lds, wm >> 16, wm & 0xffff);
 }
 
 }  // namespace dsact
