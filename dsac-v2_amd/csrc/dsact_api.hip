@@ -273,7 +273,7 @@ struct dsact_handle {
   bool env_no_pipe = false;             // DSACT_NO_PIPE: graph replays without the pipelining (A/B)
   int env_pipe_qt = 0;                  // DSACT_PIPE_QT=1: q_target(obs2', act2') of the next minibatch is precomputed too
   int env_pipe_bp_rg = 0;               // DSACT_PIPE_BP_RG=1|2: rows / 4 per workgroup of the deferred policy backward chain (0: as in its own launch)
-  bool env_no_pipe_warm = false;        // DSACT_NO_PIPE_WARM: no L2 warm-up touches in the pipelined forward launches (A/B)
+  bool env_no_pipe_warm = true;         // DSACT_PIPE_WARM=1: L2 warm-up touches in the pipelined forward launches (measured: slower, 60.4 vs 59.6 us)
   bool env_no_pipe_defer = false;       // DSACT_NO_PIPE_DEFER: the discarded policy backward stays in its own update's last launch (A/B)
   bool env_pipe_qp_split = false;       // DSACT_PIPE_QP_SPLIT: q(obs,new_act) computes its own observation part in every pipelined launch
   int env_pipe_rg_next = 2;             // DSACT_PIPE_RG_NEXT=1|2: rows / 4 per workgroup of the next minibatch's policy units
@@ -1722,15 +1722,18 @@ static_assert(PR_N <= kPipeUnits, "unit table too small");
 // this launch computes the next minibatch's): a digit string, slices dealt round-robin over it. Placement is speed only.
 // DSACT_PIPE_MAP="FT.pi=017:1;TF.q1t=45:2;..." overrides a role's XCDs (and, after ':', its rows per workgroup / 4).
 static const char* pipe_xcds_default(bool pre, bool do_pre, int role) {
-  if (!pre) {   // FF / FT: pi -> q_p is the critical path; pi alone on its CUs, everything else beside a non-critical unit
-    static const char* t[PR_N] = {"017", "2", "3", "4", "5", "6", "30", "41", "57", "62", "57", "62"};
+  if (!pre) {   // FF / FT: pi -> q_p is the critical path; pi alone on its CUs (its XCDs' second slots hold waiting q_p workgroups),
+    // every other unit one XCD, q_t beside the next minibatch's policy units; no XCD beyond its 64 slots. Random placements
+    // cost 7 - 16 us, single-unit moves around this one +-1 us (scripts/pipe_map_search.py, profiles/r04_pipe_map_search.txt)
+    static const char* t[PR_N] = {"017", "2", "3", "4", "5", "6", "30", "41", "5", "6", "57", "62"};
     return t[role];
   }
-  if (!do_pre) {   // TF: only the fresh-critic chains; q_c and q_p one workgroup per CU, q_t in the second slots beside q_p
-    static const char* t[PR_N] = {"", "", "01", "23", "", "", "45", "67", "0246", "1357", "", ""};
+  if (!do_pre) {   // TF: only the fresh-critic chains, all independent: 8-row workgroups (half the L2 traffic of 4-row ones:
+    // 22.2 vs 26.6 us, profiles/r04_pipe_map_search.txt), every unit on two or more XCDs (placement among those: equal)
+    static const char* t[PR_N] = {"", "", "04", "15", "", "", "26", "37", "0246", "1357", "", ""};
     return t[role];
   }
-  static const char* t[PR_N] = {"", "", "01", "23", "4", "5", "60", "72", "46", "57", "46", "57"};   // TT (delay_update >= 3)
+  static const char* t[PR_N] = {"", "", "04", "15", "26", "37", "26", "37", "0246", "1357", "0246", "1357"};   // TT (delay_update >= 3)
   return t[role];
 }
 
@@ -1775,7 +1778,7 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
   // rows per workgroup: the critical units (pi -> q_p) run 4-row workgroups; the others 8-row ones (39 % less CU time per
   // row) unless the launch leaves CUs idle anyway; a consumer never has more rows than its producer (it waits for ONE flag)
   const int side = (B % 8 == 0) ? h->env_pipe_rg_side : 1, nxt = (B % 8 == 0) ? h->env_pipe_rg_next : 1;
-  const int dflt[PR_N] = {1, side, pre ? 1 : side, pre ? 1 : side, nxt, nxt, 1, 1, side, side, side, side};
+  const int dflt[PR_N] = {1, side, side, side, nxt, nxt, pre ? side : 1, pre ? side : 1, side, side, side, side};
   for (int r = 0; r < PR_N; ++r) {
     const PipePlace pl = pipe_place(h, pre, do_pre, r, dflt[r]);
     rgs[r] = (B % 8 == 0) ? pl.rg : 1; xc[r] = pl.xcds;
@@ -2485,7 +2488,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (const char* v = getenv("DSACT_PIPE_QT")) h->env_pipe_qt = atoi(v) ? 1 : 0;
   h->env_pipe_qp_split = getenv("DSACT_PIPE_QP_SPLIT") != nullptr;
   h->env_no_pipe_defer = getenv("DSACT_NO_PIPE_DEFER") != nullptr;
-  h->env_no_pipe_warm = getenv("DSACT_NO_PIPE_WARM") != nullptr;
+  h->env_no_pipe_warm = getenv("DSACT_PIPE_WARM") == nullptr;
   if (const char* v = getenv("DSACT_PIPE_BP_RG")) h->env_pipe_bp_rg = atoi(v) == 1 ? 1 : atoi(v) == 2 ? 2 : 0;
   if (const char* v = getenv("DSACT_PIPE_RG_NEXT")) h->env_pipe_rg_next = atoi(v) == 1 ? 1 : 2;
   if (const char* v = getenv("DSACT_PIPE_RG_SIDE")) h->env_pipe_rg_side = atoi(v) == 1 ? 1 : 2;
@@ -3259,14 +3262,22 @@ static int enqueue_updates_pipe(dsact_handle* h, int n, const PipePlan& plan, Pi
   const std::vector<char>&pre_v = plan.pre, &do_v = plan.dop;
   int rc = DSACT_OK;
   h->mirror_w0 = true;
-  apply_pipe_set(h, set_of(0));
-  rc = enqueue_gather(h, h->idx_table, h->idx_rows, 1, 0, 1, /*bookkeeping=*/0);
-  if (rc == DSACT_OK && n > 1) {
-    apply_pipe_set(h, set_of(1));
-    GatherArgs g = gather_args(h, h->idx_table, h->idx_rows, 1, 0, 1);
-    g.bookkeeping = 0; g.lookahead = 1;
-    g.rp = repack_args(h, 0);
-    rc = launch(h, "gather", k_gather, dim3(g.n_gather_blocks), dim3(kThreads), 0, g);
+  {
+    // the first two minibatches (+ the packed-copy refresh: anything may have written the arenas since the last replay)
+    Gather2Args g;
+    apply_pipe_set(h, set_of(0));
+    g.a = gather_args(h, h->idx_table, h->idx_rows, 1, 0, 1);
+    g.a.bookkeeping = 0;
+    g.a.rp = repack_args(h, repack_blocks(h));
+    g.b = g.a;
+    g.b.n_gather_blocks = 0;
+    if (n > 1) {
+      apply_pipe_set(h, set_of(1));
+      g.b = gather_args(h, h->idx_table, h->idx_rows, 1, 0, 1);
+      g.b.bookkeeping = 0; g.b.lookahead = 1;
+      g.b.rp = repack_args(h, 0);
+    }
+    rc = launch(h, "gather", k_gather2, dim3(g.a.n_gather_blocks + g.b.n_gather_blocks + g.a.rp.n_blocks), dim3(kThreads), 0, g);
   }
   for (int s = 0; s < n && rc == DSACT_OK; ++s) {
     apply_pipe_set(h, set_of(s));

@@ -475,16 +475,28 @@ __device__ __forceinline__ void gather_block(const GatherArgs& a, int blk, long 
   }
 }
 
+__device__ __forceinline__ void gather_main(const GatherArgs& a, int blk, int tid) {
+  const long long it = a.use_dev ? a.st->it_next + a.lookahead : a.host_it;
+  const int trow = a.use_dev ? (int)((a.st->seq_next + a.lookahead) % a.idx_rows) : a.host_row;
+  gather_block(a, blk, it, trow, tid);
+  if (a.bookkeeping && blk == 0 && tid == 0) prologue_duties(a.st, it, a.advance_counters, a.hp);
+}
 __global__ void __launch_bounds__(kThreads) k_gather(GatherArgs a) {
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= a.n_gather_blocks) {  // spare blocks: weight repack (independent of the gather)
     repack_rows(a.rp, (int)blockIdx.x - a.n_gather_blocks, tid);
     return;
   }
-  const long long it = a.use_dev ? a.st->it_next + a.lookahead : a.host_it;
-  const int trow = a.use_dev ? (int)((a.st->seq_next + a.lookahead) % a.idx_rows) : a.host_row;
-  gather_block(a, (int)blockIdx.x, it, trow, tid);
-  if (a.bookkeeping && blockIdx.x == 0 && tid == 0) prologue_duties(a.st, it, a.advance_counters, a.hp);
+  gather_main(a, (int)blockIdx.x, tid);
+}
+// the pipelined graph opens with the minibatches of its first TWO updates (the riding gathers look two updates ahead):
+// one launch, blocks [0, na) -> a, [na, na + nb) -> b, the rest -> a's repack blocks
+struct Gather2Args { GatherArgs a, b; };
+__global__ void __launch_bounds__(kThreads) k_gather2(Gather2Args g) {
+  const int tid = threadIdx.x, blk = (int)blockIdx.x, na = g.a.n_gather_blocks, nb = g.b.n_gather_blocks;
+  if (blk < na) gather_main(g.a, blk, tid);
+  else if (blk < na + nb) gather_main(g.b, blk - na, tid);
+  else repack_rows(g.a.rp, blk - na - nb, tid);
 }
 
 // Riders of the loss launch in graph replays (k_loss has B/4 blocks: three quarters of the chip idle). Blocks
