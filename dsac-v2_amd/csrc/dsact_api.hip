@@ -265,6 +265,8 @@ struct dsact_handle {
   static constexpr int kPipePhases = 4;
   PipeSet pset[kPipeSets];
   char* pipe_ws = nullptr;
+  unsigned long long* pipe_hand[3] = {nullptr, nullptr, nullptr};   // tagged hand-over buffers [B][32] (value, tag): new_act, act2, act2 of the next minibatch
+  bool env_no_pipe_tagged = false;      // DSACT_NO_PIPE_TAGGED: ready flags + separate data instead of (value, tag) pairs (A/B)
   bool pipe_defer_now = false;          // set while the update being enqueued defers its (discarded) policy backward
   bool pipe_graph = false;              // the captured graphs are the pipelined ones (pgraph / pexec, one per phase)
   hipGraph_t pgraph[kPipePhases] = {nullptr, nullptr, nullptr, nullptr};
@@ -1677,6 +1679,7 @@ int alloc_pipe_sets(dsact_handle* h) {
       p.part_heads = c.take<float>((size_t)h->n_heads_wg * 2);
       p.X0t = c.take<float>(B * (size_t)((h->F + A + 31) / 32 * 32));
     }
+    for (int i = 0; i < 3; ++i) h->pipe_hand[i] = c.take<unsigned long long>(B * 32);
     if (!pass) {
       HIPCHK(h, hipMalloc((void**)&h->pipe_ws, c.off + 256));
       HIPCHK(h, hipMemset(h->pipe_ws, 0, c.off + 256));
@@ -1785,23 +1788,27 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
   }
   auto cap = [&](int consumer, int producer) { if (rgs[consumer] > rgs[producer]) rgs[consumer] = rgs[producer]; };
   if (!(pre || h->env_pipe_qp_split)) { cap(PR_Q1P, PR_Q1C); cap(PR_Q2P, PR_Q2C); }
-  if (!pre) { cap(PR_Q1P, PR_PI); cap(PR_Q2P, PR_PI); cap(PR_Q1T, PR_PIT); cap(PR_Q2T, PR_PIT); }
-  cap(PR_Q1TN, PR_PITN); cap(PR_Q2TN, PR_PITN);
+  if (!pre && h->env_no_pipe_tagged) { cap(PR_Q1P, PR_PI); cap(PR_Q2P, PR_PI); cap(PR_Q1T, PR_PIT); cap(PR_Q2T, PR_PIT); }
+  if (h->env_no_pipe_tagged) { cap(PR_Q1TN, PR_PITN); cap(PR_Q2TN, PR_PITN); }   // (tagged pairs are polled per element: any rows)
   auto put = [&](int role, const FwdUnit& u) {
     idx[role] = role;
     P.u[role] = u;
     P.u[role].rg = (short)rgs[role];
     P.u[role].n_slices = (short)(B / (4 * rgs[role]));
   };
+  // in-launch hand-over of the sampled actions: (value, tag) pairs (the data is the flag) or, DSACT_NO_PIPE_TAGGED, ready flags
+  const bool tagged = !h->env_no_pipe_tagged;
   auto policy_units = [&](int r_pi, int r_pit, bool flag_pi, bool flag_pit) {
     FwdUnit pi = fwd_unit(h, C_PI, SEG_FULL, HEAD_POLICY);
     pi.logits = h->logits_pi; pi.logp = h->logp_new; pi.eps = h->eps_new; pi.xact = h->Xc[C_Q1P]; pi.part_heads = h->part_heads;
-    if (flag_pi) pi.done = f + 0 * kChainFlagSlices;
+    if (flag_pi && tagged) { pi.xact2 = (float*)h->pipe_hand[0]; pi.late_wait |= HW_PAIRS_OUT; }
+    else if (flag_pi) pi.done = f + 0 * kChainFlagSlices;
     put(r_pi, pi);
     FwdUnit pt = fwd_unit(h, C_PIT, SEG_FULL, HEAD_POLICY);
     pt.logits = h->logits_pit; pt.logp = h->logp2; pt.eps = h->eps_2; pt.xact = h->Xc[C_Q1T];
     for (int l = 0; l < h->L; ++l) pt.G[l] = nullptr;   // never differentiated
-    if (flag_pit) pt.done = f + (r_pit == PR_PIT ? 1 : 4) * kChainFlagSlices;
+    if (flag_pit && tagged) { pt.xact2 = (float*)h->pipe_hand[r_pit == PR_PIT ? 1 : 2]; pt.late_wait |= HW_PAIRS_OUT; }
+    else if (flag_pit) pt.done = f + (r_pit == PR_PIT ? 1 : 4) * kChainFlagSlices;
     put(r_pit, pt);
   };
   auto target_units = [&](int r_q1t, int r_pit, bool wait) {
@@ -1809,7 +1816,8 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
       FwdUnit qt = fwd_unit(h, C_Q1T + i, SEG_FULL_SPLIT, HEAD_Q);
       qt.qout = h->qout_t[i];
       for (int l = 0; l < h->L; ++l) qt.G[l] = nullptr;   // never differentiated
-      if (wait) { qt.wait0 = P.u[r_pit].done; qt.wait_rows0 = 4 * rgs[r_pit]; qt.late_wait = 1; }
+      if (wait && tagged) { qt.wait0 = (const int*)h->pipe_hand[r_pit == PR_PIT ? 1 : 2]; qt.wait_rows0 = 4; qt.late_wait = HW_LATE | HW_PAIRS_IN; }
+      else if (wait) { qt.wait0 = P.u[r_pit].done; qt.wait_rows0 = 4 * rgs[r_pit]; qt.late_wait = HW_LATE; }
       put(r_q1t + i, qt);
     }
   };
@@ -1828,7 +1836,8 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
     put(PR_Q1C + i, qc);
     FwdUnit qp = fwd_unit(h, C_Q1P + i, qp_split ? SEG_FULL_SPLIT : SEG_ACT_FROM_SAVED, HEAD_Q);
     qp.qout = h->qout_p[i];
-    if (!pre) { qp.wait0 = P.u[PR_PI].done; qp.wait_rows0 = 4 * rgs[PR_PI]; qp.late_wait = 1; }
+    if (!pre && tagged) { qp.wait0 = (const int*)h->pipe_hand[0]; qp.wait_rows0 = 4; qp.late_wait = HW_LATE | HW_PAIRS_IN; }
+    else if (!pre) { qp.wait0 = P.u[PR_PI].done; qp.wait_rows0 = 4 * rgs[PR_PI]; qp.late_wait = HW_LATE; }
     if (!qp_split) { qp.zinit = h->zobs[i]; qp.wait1 = qc.zdone; qp.wait_rows1 = 4 * rgs[PR_Q1C + i]; }
     put(PR_Q1P + i, qp);
   }
@@ -1848,6 +1857,7 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
   a.timeline = tl_for(h, pipe_fwd_name(pre, do_pre));
   a.spin_timeout = h->handoff_dev;
   a.debug_withhold = h->debug_withhold == 1;
+  a.tagp = &h->st->seq_next;
   // block table: every XCD's queue is filled role by role (the enum is the priority order), a role's slices are dealt
   // round-robin over its XCDs; block 8 r + x = entry r of XCD x's queue (the dispatcher places block b on XCD b % 8)
   std::vector<int> q[8];
@@ -2489,6 +2499,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->env_pipe_qp_split = getenv("DSACT_PIPE_QP_SPLIT") != nullptr;
   h->env_no_pipe_defer = getenv("DSACT_NO_PIPE_DEFER") != nullptr;
   h->env_no_pipe_warm = getenv("DSACT_PIPE_WARM") == nullptr;
+  h->env_no_pipe_tagged = getenv("DSACT_NO_PIPE_TAGGED") != nullptr;
   if (const char* v = getenv("DSACT_PIPE_BP_RG")) h->env_pipe_bp_rg = atoi(v) == 1 ? 1 : atoi(v) == 2 ? 2 : 0;
   if (const char* v = getenv("DSACT_PIPE_RG_NEXT")) h->env_pipe_rg_next = atoi(v) == 1 ? 1 : 2;
   if (const char* v = getenv("DSACT_PIPE_RG_SIDE")) h->env_pipe_rg_side = atoi(v) == 1 ? 1 : 2;

@@ -538,6 +538,7 @@ __global__ void __launch_bounds__(256) k_adam_pack(AdamPackArgs a) {
 // bits as the two-unit form (the pipelined graph's q_target units: no obs-only producer, no saved accumulators)
 enum : int { SEG_FULL = 0, SEG_OBS_ONLY = 1, SEG_ACT_FROM_SAVED = 2, SEG_FULL_SAVE = 3, SEG_FULL_SPLIT = 4 };
 enum : int { HEAD_NONE = 0, HEAD_POLICY = 1, HEAD_Q = 2 };
+enum : int { HW_LATE = 1, HW_PAIRS_OUT = 2, HW_PAIRS_IN = 4 };
 
 struct FwdUnit {
   const float* wf[kChMaxL + 1];     // packed weights per layer: style 44 for l < L, style 16 for the output layer (index L)
@@ -561,8 +562,12 @@ struct FwdUnit {
   short rg, act;                    // rows per workgroup / 4 of THIS unit (units of one launch may differ); hidden activation
                                     // of its net (ACT_*, dsact_math.h). (shorts: two FwdArgs must fit the 4 KB of kernel arguments)
   short n_slices;                   // slices of this unit
-  short late_wait;                  // 1: wait for the producers AFTER the observation segment (only the action columns are
-                                    // handed over): the wait hides under this unit's own first 3/4 of a layer
+  short late_wait;                  // bit 0 (HW_LATE): wait for the producers AFTER the observation segment (only the action columns
+                                    // are handed over): the wait hides under this unit's own first 3/4 of a layer.
+                                    // Tagged hand-over (pipelined launches): the sampled actions travel as (value, tag) pairs, one
+                                    // 8-byte agent-scope store / load each -- the data IS the flag (no store-acknowledge barrier
+                                    // + flag on the producer side, no second round trip on the consumer side). bit 1 (HW_PAIRS_OUT,
+                                    // policy heads): xact2 is the pair buffer [B][32]; bit 2 (HW_PAIRS_IN): wait0 is that buffer
 };
 constexpr int kMaxFwdUnits = 6;
 struct FwdArgs {
@@ -578,6 +583,7 @@ struct FwdArgs {
   int* spin_timeout;                // merged launch: set to 1 by a consumer that gave up waiting. The word lives in mapped
                                     // HOST memory: every entry point of the library checks it and fails the call
   int debug_withhold;               // tests only (dsact_debug_set "withhold_flag"): unit 0 / slice 0 never raises its flag
+  const long long* tagp;            // tagged hand-over: DevState::seq_next (advances with every closed update): tag = low word + 1
 };
 
 // Data handed from a producer to a consumer INSIDE the merged launch (sampled actions, saved first-layer accumulators)
@@ -751,10 +757,13 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
   }
   // merged launch: the weight stream and the loads above are already in flight while this waits for its producers
   // (late_wait: only the action columns come from a producer -- the wait follows the observation segment)
-  const bool waits = u.wait0 || u.wait1;
-  const bool late = waits && u.late_wait && u.seg != SEG_ACT_FROM_SAVED && u.s_act > 0;
-  if (waits && !late)
-    chain_wait(u.wait0 ? u.wait0 + row0 / u.wait_rows0 : nullptr, u.wait1 ? u.wait1 + row0 / u.wait_rows1 : nullptr, a.spin_timeout);
+  const bool pairs_in = (u.late_wait & HW_PAIRS_IN) != 0, pairs_out = (u.late_wait & HW_PAIRS_OUT) != 0;
+  const unsigned tag = (pairs_in || pairs_out) ? (unsigned)(*a.tagp) + 1u : 0u;
+  const int* const flag0 = pairs_in ? nullptr : u.wait0;      // (tagged hand-over: wait0 is the pair buffer, not a flag array)
+  const bool waits = flag0 || u.wait1 || pairs_in;
+  const bool late = waits && (u.late_wait & HW_LATE) && u.seg != SEG_ACT_FROM_SAVED && u.s_act > 0;
+  if ((flag0 || u.wait1) && !late)
+    chain_wait(flag0 ? flag0 + row0 / u.wait_rows0 : nullptr, u.wait1 ? u.wait1 + row0 / u.wait_rows1 : nullptr, a.spin_timeout);
   f32x4 zi[RG];
   if (u.seg == SEG_ACT_FROM_SAVED) {
 #pragma unroll
@@ -766,6 +775,28 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
   //      Four independent loads per thread and trip, stores after (a load -> wait -> store loop is one round trip per trip)
   auto stage_act = [&]() {
     const int Fp = 4 * a.s_obs;
+    if (pairs_in) {
+      // every lane polls ITS element until the pair carries this update's tag (bounded: a lost producer must not hang the GPU)
+      const unsigned long long* hp = (const unsigned long long*)u.wait0;
+      const int per_row = 4 * u.s_act;
+      for (int e = tid; e < R * per_row; e += NTHR) {
+        const int r = e / per_row, k = e % per_row;
+        float v = 0.0f;
+        if (k < A) {
+          const unsigned long long* src = hp + (size_t)(row0 + r) * 32 + k;
+          unsigned long long pv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          int spins = 0;
+          while ((unsigned)(pv >> 32) != tag) {
+            if (++spins > (1 << 17)) { if (a.spin_timeout) *a.spin_timeout = 1; break; }   // ~0.1 s, then the hand-off word
+            __builtin_amdgcn_s_sleep(8);
+            pv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          v = __builtin_bit_cast(float, (unsigned)pv);
+        }
+        lds[xin + r * S.ld_in + Fp + k] = v;
+      }
+      return;
+    }
     const int aq = u.s_act, total = R * aq;   // float4 groups of the action segment
     for (int e = tid; e < total; e += NTHR) {
       const int r = e / aq, k = (e % aq) * 4;
@@ -854,7 +885,8 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
     }
   }
   if (late) {
-    chain_wait(u.wait0 ? u.wait0 + row0 / u.wait_rows0 : nullptr, u.wait1 ? u.wait1 + row0 / u.wait_rows1 : nullptr, a.spin_timeout);
+    if (flag0 || u.wait1)
+      chain_wait(flag0 ? flag0 + row0 / u.wait_rows0 : nullptr, u.wait1 ? u.wait1 + row0 / u.wait_rows1 : nullptr, a.spin_timeout);
     stage_act();
     lds_barrier();
   }
@@ -919,7 +951,11 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
     const TanhGaussFwd f = tanh_gauss_fwd(mu, raw, pre_eps[q], pre_s[q], pre_c[q], a.lo_ls, a.hi_ls);
     lp += f.lp;
     st_agent(u.xact + (size_t)r * a.ldx + F + d, f.a);
-    if (u.xact2) st_agent(u.xact2 + (size_t)r * a.ldx + F + d, f.a);
+    if (pairs_out) {
+      if (!(a.debug_withhold && unit == 0 && slice == 0))
+        __hip_atomic_store((unsigned long long*)u.xact2 + (size_t)r * 32 + d,
+                           ((unsigned long long)tag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, f.a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (u.xact2) st_agent(u.xact2 + (size_t)r * a.ldx + F + d, f.a);
     u.logits[(size_t)r * 2 * A + d] = mu;
     u.logits[(size_t)r * 2 * A + A + d] = raw;
     if (!a.v1_stats) { s_tanh += tanhf(mu); s_sig += f.sigma; }
