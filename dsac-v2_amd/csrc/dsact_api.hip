@@ -1728,7 +1728,9 @@ static const char* pipe_xcds_default(bool pre, bool do_pre, int role) {
   if (!pre) {   // FF / FT: pi -> q_p is the critical path; pi alone on its CUs (its XCDs' second slots hold waiting q_p workgroups),
     // every other unit one XCD, q_t beside the next minibatch's policy units; no XCD beyond its 64 slots. Random placements
     // cost 7 - 16 us, single-unit moves around this one +-1 us (scripts/pipe_map_search.py, profiles/r04_pipe_map_search.txt)
-    static const char* t[PR_N] = {"017", "2", "3", "4", "5", "6", "30", "41", "5", "6", "57", "62"};
+    // pi and pi_target (their consumers q_p / q_t are the two critical paths) 4-row workgroups on two XCDs each, one per CU;
+    // q_t's 4-row workgroups half beside pi_target (they resume when it exits), half beside the next minibatch's policy units
+    static const char* t[PR_N] = {"01", "27", "3", "4", "5", "6", "30", "41", "52", "67", "52", "67"};
     return t[role];
   }
   if (!do_pre) {   // TF: only the fresh-critic chains, all independent: 8-row workgroups (half the L2 traffic of 4-row ones:
@@ -1781,7 +1783,7 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
   // rows per workgroup: the critical units (pi -> q_p) run 4-row workgroups; the others 8-row ones (39 % less CU time per
   // row) unless the launch leaves CUs idle anyway; a consumer never has more rows than its producer (it waits for ONE flag)
   const int side = (B % 8 == 0) ? h->env_pipe_rg_side : 1, nxt = (B % 8 == 0) ? h->env_pipe_rg_next : 1;
-  const int dflt[PR_N] = {1, side, side, side, nxt, nxt, pre ? side : 1, pre ? side : 1, side, side, side, side};
+  const int dflt[PR_N] = {1, pre ? side : 1, side, side, nxt, nxt, pre ? side : 1, pre ? side : 1, pre ? side : 1, pre ? side : 1, side, side};
   for (int r = 0; r < PR_N; ++r) {
     const PipePlace pl = pipe_place(h, pre, do_pre, r, dflt[r]);
     rgs[r] = (B % 8 == 0) ? pl.rg : 1; xc[r] = pl.xcds;
