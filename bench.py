@@ -290,14 +290,21 @@ def cpu_baseline_child(hidden, n_rows=CPU_ROWS, warm=50, timed=300, budget_s=12.
             step(it)
             it += 1
             nw += 1
-        t0 = time.perf_counter()
-        n = 0
-        while n < timed and time.perf_counter() - t0 < budget_s:
-            step(it)
-            it += 1
-            n += 1
-        dt = time.perf_counter() - t0
-        legs[threads] = {"value": n / dt, "updates": n, "seconds": dt, "warmup": nw}
+        # three timed repeats (the hosts are shared: the spread is part of the answer), each a third of the budget
+        reps, n_all, dt_all = [], 0, 0.0
+        for _ in range(3):
+            t0 = time.perf_counter()
+            n = 0
+            while n < max(timed // 3, 1) and time.perf_counter() - t0 < budget_s / 3.0:
+                step(it)
+                it += 1
+                n += 1
+            dt = time.perf_counter() - t0
+            reps.append(n / dt)
+            n_all += n
+            dt_all += dt
+        legs[threads] = {"value": sorted(reps)[1], "updates": n_all, "seconds": dt_all, "warmup": nw,
+                         "repeats": [round(v, 2) for v in reps], "min": min(reps), "max": max(reps)}
     v4 = legs[4]
     who = ("unmodified reference (create_alg -> DSAC_V2, create_buffer -> ReplayBuffer)" if use_ref else
            "oracle port of the reference arithmetic (the reference is not mounted on this box)")
@@ -306,9 +313,10 @@ def cpu_baseline_child(hidden, n_rows=CPU_ROWS, warm=50, timed=300, budget_s=12.
     except Exception as ex:   # informational leg
         e2e = {"error": repr(ex)}
     return {"value": v4.get("value"), "unit": "steps/s", "cores": 4, "kind": "reference" if use_ref else "port",
+            "repeats": v4.get("repeats"), "min": v4.get("min"), "max": v4.get("max"),
             "all_cores": dict(legs[ncpu], cores=ncpu), "e2e": e2e,
             "sample": "%s: sample_batch(256) + local_update, hidden %s, %d-row host buffer (SURVEY 8d recipe; 1M rows = minutes of first-touch page faults in this sandbox), %s warm-up + "
-                      "%s timed updates in %.1f s at 4 torch threads, torch %s / numpy %s CPU, %d host cores"
+                      "%s timed updates in %.1f s (value = median of 3 repeats, min / max beside it) at 4 torch threads, torch %s / numpy %s CPU, %d host cores"
                       % (who, "x".join(map(str, hidden)), n_rows, v4.get("warmup"), v4.get("updates"), v4.get("seconds", 0.0),
                          torch.__version__, np.__version__, ncpu)}
 

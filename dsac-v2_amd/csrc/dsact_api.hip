@@ -231,6 +231,10 @@ struct dsact_handle {
   int* handoff_host = nullptr; int* handoff_dev = nullptr;
   bool in_handoff = false;
   int handoff_failures = 0;
+  bool state_invalid = false;           // sticky after a hand-over timeout: the fused Adam / Polyak epilogues ran on whatever the
+                                        // consumers found, so parameters / moments / targets are suspect. Every update entry point
+                                        // fails (DSACT_E_STATE) until the caller acknowledges with dsact_set_state or
+                                        // dsact_bind_arenas -- which it calls after restoring a checkpoint
   int debug_withhold = 0;               // dsact_debug_set("withhold_flag"): tests force the timeout path
   // single-launch acting forward (dsact_act.h): mapped host block = [hand-off word | done counter | logits], device scratch
   unsigned long long* act_out_host = nullptr; unsigned long long* act_out_dev = nullptr;   // 64 (value, call) pairs
@@ -2370,8 +2374,9 @@ bool have_graph(const dsact_handle* h) { return h->graph_exec != nullptr || h->p
 int check_handoff(dsact_handle* h) {
   if (!h->handoff_host || h->in_handoff || !*(volatile int*)h->handoff_host) return DSACT_OK;
   h->in_handoff = true;
-  hipSetDevice(h->device);
-  hipStreamSynchronize(h->stream);
+  h->state_invalid = true;
+  const hipError_t e_dev = hipSetDevice(h->device);
+  const hipError_t e_sync = hipStreamSynchronize(h->stream);
   *(volatile int*)h->handoff_host = 0;
   const bool had_graph = have_graph(h);
   const int steps = h->graph_steps;
@@ -2380,21 +2385,29 @@ int check_handoff(dsact_handle* h) {
   h->pi_merge = false;
   h->handoff_failures += 1;
   drop_graphs(h);
-  if (h->chain_flags) hipMemset(h->chain_flags, 0, kChainFlagInts * sizeof(int));
+  hipError_t e_set = hipSuccess;
+  if (h->chain_flags) e_set = hipMemset(h->chain_flags, 0, kChainFlagInts * sizeof(int));
   h->flags_dirty = false;
   int rebuilt = DSACT_E_STATE;
   if (had_graph) rebuilt = dsact_graph_build(h, steps, gflags);
   h->in_handoff = false;
+  const hipError_t e_hip = e_dev != hipSuccess ? e_dev : e_sync != hipSuccess ? e_sync : e_set;
   return fail(h, DSACT_E_HIP,
               "an in-launch hand-over timed out: a workgroup waited > 0.1 s for its producers' ready flags, so every result "
-              "since the last successful call is invalid. Merged launches are now disabled for this handle%s",
+              "since the last successful call is invalid -- parameters, optimiser moments and targets included: restore them, "
+              "then acknowledge with dsact_set_state or dsact_bind_arenas (update entry points fail until then). Merged "
+              "launches are now disabled for this handle%s%s%s",
               had_graph ? (rebuilt == DSACT_OK ? "; the graph was captured again without them" : "; re-capturing the graph failed")
-                        : "");
+                        : "",
+              e_hip != hipSuccess ? "; HIP also reported: " : "", e_hip != hipSuccess ? hipGetErrorString(e_hip) : "");
 }
 
 int check_ready(dsact_handle* h, bool need_batch) {
   if (!h) return DSACT_E_INVALID;
   TRY(check_handoff(h));
+  if (h->state_invalid)
+    return fail(h, DSACT_E_STATE, "device state is invalid after a hand-over timeout: restore parameters / optimiser state, then "
+                                  "call dsact_set_state or dsact_bind_arenas");
   if (!h->online || !h->grads) return fail(h, DSACT_E_STATE, "arenas not bound (dsact_bind_arenas)");
   if (!h->limits_set) return fail(h, DSACT_E_STATE, "action limits not set (dsact_set_action_limits)");
   if (need_batch && !h->have_batch) return fail(h, DSACT_E_STATE, "no minibatch staged (dsact_gather / dsact_load_batch)");
@@ -2769,6 +2782,7 @@ int dsact_bind_arenas(dsact_handle* h, float* online, float* target, float* adam
     select_set(h, 0);
     TRY(rc);
   }
+  h->state_invalid = false;
   return DSACT_OK;
 }
 
@@ -2818,6 +2832,7 @@ int dsact_set_state(dsact_handle* h, const int32_t adam_steps[3], const float me
     st.ms1 = mean_std[0]; st.ms2 = mean_std[1];
   }
   HIPCHK(h, hipMemcpy(h->st, &st, sizeof(st), hipMemcpyHostToDevice));
+  h->state_invalid = false;   // the caller restored (or accepts) the device state after a hand-over timeout
   return DSACT_OK;
 }
 
@@ -3417,6 +3432,9 @@ static int set_device_iteration(dsact_handle* h, long long it) {
 int dsact_graph_run(dsact_handle* h, int64_t first_iteration, int64_t n_steps) {
   if (!h) return DSACT_E_INVALID;
   TRY(check_handoff(h));
+  if (h->state_invalid)
+    return fail(h, DSACT_E_STATE, "device state is invalid after a hand-over timeout: restore parameters / optimiser state, then "
+                                  "call dsact_set_state or dsact_bind_arenas");
   if (!have_graph(h)) return fail(h, DSACT_E_STATE, "dsact_graph_build first");
   if (n_steps % h->graph_steps) return fail(h, DSACT_E_INVALID, "n_steps must be a multiple of steps_per_graph");
   if ((h->graph_flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) && first_iteration % h->cfg.delay_update)
@@ -3869,6 +3887,7 @@ int dsact_debug_get(const dsact_handle* h, const char* name, double* value) {
   else if (!strcmp(name, "handoff_failures")) *value = (double)h->handoff_failures;
   else if (!strcmp(name, "graph_steps")) *value = (double)h->graph_steps;
   else if (!strcmp(name, "pipe_graph")) *value = h->pipe_graph ? 1.0 : 0.0;   // the captured graphs are the pipelined ones
+  else if (!strcmp(name, "state_invalid")) *value = h->state_invalid ? 1.0 : 0.0;
   else return DSACT_E_INVALID;
   return DSACT_OK;
 }

@@ -439,9 +439,14 @@ class HipBatch(dict):
         # ring write position when the rows were sampled: the reference's batch is a COPY taken at sample time
         # (replay_buffer.py:85-90), so a late re-gather must not silently train on rows add_batch has replaced
         self._ptr0, self._added0 = engine.buffer_ptr, engine.rows_added
+        self._fill_epoch0 = engine.fill_epoch
 
     def _overwritten(self):
         cap, written = self.engine.buffer_capacity, self.engine.rows_added - self._added0
+        if self.engine.fill_epoch != self._fill_epoch0:
+            # buffer_fill_device wrote rows at an arbitrary position (not the ring's append order): which of the sampled
+            # rows it replaced is not known here -- the token counts as overwritten entirely
+            return int(self.idxs.size)
         if written <= 0 or cap <= 0:
             return 0
         if written >= cap:

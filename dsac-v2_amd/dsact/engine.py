@@ -111,6 +111,7 @@ class DsactEngine:
         self.stage_serial = 0
         self.buffer_capacity = 0
         self.rows_added = 0      # rows ever written to the ring (HipBatch tokens detect overwritten rows with it)
+        self.fill_epoch = 0      # bumped by buffer_fill_device (writes at an arbitrary row: outstanding tokens become invalid)
 
     # ---- plumbing -----------------------------------------------------------------------------
     def _chk(self, rc):
@@ -201,6 +202,7 @@ class DsactEngine:
         self._chk(self._lib.dsact_buffer_fill_device(self._h, int(row0), n, obs.data_ptr(), act.data_ptr(),
                                                      rew.data_ptr(), obs2.data_ptr(), done.data_ptr()))
         self.rows_added += n
+        self.fill_epoch += 1
 
     @property
     def buffer_size(self):

@@ -128,7 +128,11 @@ int dsact_bind_arenas(dsact_handle* h, float* online, float* target, float* adam
 /* act_high_lim / act_low_lim buffers of StochaPolicy (networks/mlp.py:75-76); host pointers */
 int dsact_set_action_limits(dsact_handle* h, const float* high, const float* low);
 /* Adam step counters (q, policy, alpha) and the mean_std EMA state (dsac_v2.py:88-89,233-241);
- * mean_std < 0 encodes the reference's -1.0 "not yet initialised" sentinel. Synchronous. */
+ * mean_std < 0 encodes the reference's -1.0 "not yet initialised" sentinel. Synchronous.
+ * dsact_set_state (and a successful dsact_bind_arenas) also ACKNOWLEDGES a hand-over timeout: after one (DSACT_E_HIP from
+ * any entry point, see dsact_debug_set below) parameters / moments / targets are suspect and every update entry point
+ * fails with DSACT_E_STATE until the caller has restored them and called one of the two
+ * (dsact_debug_get(h, "state_invalid") reads the flag). */
 int dsact_get_state(dsact_handle* h, int32_t adam_steps[3], float mean_std[2]);
 int dsact_set_state(dsact_handle* h, const int32_t adam_steps[3], const float mean_std[2]);
 /* The reference re-reads its `adjustable_parameters` (dsac_v2.py:92-99: gamma, tau, auto_alpha, alpha, delay_update;

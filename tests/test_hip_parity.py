@@ -13,6 +13,7 @@ Gates (BASELINE.json north_star: "losses / stats within 1e-4 of the reference CP
     2*lr-per-update worst case of a sign flip. Polyak targets: 1e-7 + tau x the parameter bound.
   * replay index draws and gathered rows: bit-exact
 """
+import copy
 import os
 
 import numpy as np
@@ -234,28 +235,36 @@ def run_case(title, O, A, hid, B, steps, act_limit=0.4, init=None, golden=None, 
         e.sync()  # the engine runs on its own stream; torch reads below are on torch's
         if cfg["value_act"] in KINKED or cfg["policy_act"] in KINKED:
             orc.act_sides = hip_act_sides(e, cfg, L, B)
+        orc_chk = orc
         if (cfg["value_act"], cfg["policy_act"]) != ("gelu", "gelu") and it == steps - 1 and it > 0:
-            # The intermediates of the last step are a per-kernel check at tight tolerances, so the reference is evaluated
-            # AT the parameters the engine holds: after two updates the two trajectories differ by the (enumerated, bounded)
-            # Adam noise of the steps before, which the tanh / sigmoid nets' O(1) activations turn into 3e-5 of H -- above
-            # gates sized for a summation-order difference. The trajectory itself was compared on every earlier step.
-            orc.load_state_dict({k_: v_.cpu() for k_, v_ in alg.networks.state_dict().items()})
-        tb_ref = orc.compute_gradient(data, noise, keep=keep)
-        for ch, j, cnt, zmax in (orc.act_kinks or []):
+            # The intermediates and gradients of the last step are a per-kernel check at tight tolerances, so THEY are taken
+            # from a copy of the oracle evaluated AT the parameters the engine holds: after two updates the two trajectories
+            # differ by the (enumerated, bounded) Adam noise of the steps before, which the tanh / sigmoid nets' O(1)
+            # activations turn into 3e-5 of H -- above gates sized for a summation-order difference. The trajectory oracle
+            # itself is NEVER re-synchronised: it takes this step on its own parameters (with its own activation sides) and
+            # the params / targets / mean_std rows below compare the accumulated multi-step trajectories.
+            orc_chk = copy.deepcopy(orc)
+            orc_chk.load_state_dict({k_: v_.cpu() for k_, v_ in alg.networks.state_dict().items()})
+            orc.act_sides = None
+            orc.compute_gradient(data, noise, keep=False)
+        tb_ref = orc_chk.compute_gradient(data, noise, keep=keep)
+        for ch, j, cnt, zmax in (orc_chk.act_kinks or []):
             assert zmax < 1e-5, "activation sides differ at a pre-activation of %g (%s layer %d): not a kink" % (zmax, ch, j)
         if keep:
-            compare_intermediates(rep, alg, orc, L, B, A)
+            compare_intermediates(rep, alg, orc_chk, L, B, A)
         g = e.grads.cpu().numpy()
-        g_ref = orc.flat_grads().numpy()
+        g_ref = orc_chk.flat_grads().numpy()
         off = 0
         for net, n in (("q1", lay.n_q), ("q2", lay.n_q), ("policy", lay.n_pi), ("log_alpha", 1)):
             if net == "policy":   # 3e-5 of the tensor's scale + the enumerated fp32 budget of saturated actions
                 want = g_ref[off:off + n]
                 base = 1e-9 + 3e-5 * float(np.abs(want).max())
-                rep.cmp_each("it%d grad.policy" % it, g[off:off + n], want, base + policy_saturation_budget(orc, data, noise, B))
+                rep.cmp_each("it%d grad.policy" % it, g[off:off + n], want, base + policy_saturation_budget(orc_chk, data, noise, B))
             else:
                 rep.cmp("it%d grad.%s" % (it, net), g[off:off + n], g_ref[off:off + n], 1e-9, 3e-5)
             off += n
+        if orc_chk is not orc:
+            g_ref = orc.flat_grads().numpy()   # the Adam-noise bound follows the TRAJECTORY oracle's gradients
         delayed = it % cfg["delay_update"] == 0
         noise_b.step(g_ref, g, ("q1", "q2") + (("policy",) + (("log_alpha",) if cfg["auto_alpha"] else ()) if delayed else ()))
         e.apply_update(it)
@@ -1492,14 +1501,17 @@ def test_forced_handover_timeout_fails_the_call_and_falls_back(which):
         e.sync()
     assert e.debug_get("handoff_failures") == 1.0 and e.debug_get("fwd_merge") == 0.0 and e.debug_get("pi_merge") == 0.0
     assert e.debug_get("graph_steps") == 2.0     # captured again, without the merged launches
-    names = [k for k, _, _ in e.profile_step(0)]
-    assert "chain_fwd_a" in names and "dW" in names
     e.sync()                                      # the word was consumed: no second error
+    # the fused Adam / Polyak epilogues ran on whatever the consumers found -- the handle refuses to train on
+    # until the caller has restored the state and acknowledged
+    assert e.debug_get("state_invalid") == 1.0
+    for call in (lambda: e.step(0), lambda: e.graph_run(0, 2), lambda: e.profile_step(0)):
+        with pytest.raises(DsactError, match="invalid after a hand-over timeout"):
+            call()
     # --- restore the state the failed call invalidated, then both engines run the same updates (the reference engine
-    #     replays the same three updates first so that both index-table cursors agree, and is restored the same way)
+    #     replays the same updates first so that both index-table cursors agree, and is restored the same way)
     r.graph_build(2)
     r.graph_run(0, 2)
-    r.profile_step(0)
     r.sync()
     for a_, x in ((alg, e), (ref, r)):
         a_.networks.load_state_dict(snap)
@@ -1507,6 +1519,10 @@ def test_forced_handover_timeout_fails_the_call_and_falls_back(which):
             getattr(x, n).copy_(t)
         torch.cuda.synchronize()
         x.set_state(adam_steps=state["adam_steps"], mean_std=state["mean_std"])
+    assert e.debug_get("state_invalid") == 0.0
+    names = [k for k, _, _ in e.profile_step(0)]
+    assert "chain_fwd_a" in names and "dW" in names
+    r.profile_step(0)
     for x in (e, r):
         x.graph_run(0, 4)
         x.sync()

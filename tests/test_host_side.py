@@ -231,6 +231,7 @@ def test_hip_batch_detects_rows_overwritten_after_sampling():
     class FakeEngine:
         def __init__(self, cap, ptr):
             self.buffer_capacity, self.buffer_ptr, self.rows_added, self.stage_serial, self.gathers = cap, ptr, 0, 0, 0
+            self.fill_epoch = 0
 
         def gather(self, idx):
             self.gathers += 1
@@ -256,3 +257,9 @@ def test_hip_batch_detects_rows_overwritten_after_sampling():
         tok.restage()
     e.add(200)
     assert tok._overwritten() == 4
+    # buffer_fill_device writes at an arbitrary row (not in append order): every outstanding token is invalid
+    e2 = FakeEngine(100, 10)
+    tok2 = HipBatch(e2, np.array([50, 60]))
+    assert tok2._overwritten() == 0
+    e2.fill_epoch += 1
+    assert tok2._overwritten() == 2
