@@ -199,7 +199,7 @@ def upload_indices(engine, n_rows, rows, seed):
     engine.upload_index_table(np.random.randint(0, n_rows, size=(rows, engine.batch)))
 
 
-CPU_ROWS = 100_000   # host buffer of the CPU leg: first touch of fresh pages costs ~20 MB/s in this sandbox (a 1M-row,
+CPU_ROWS = int(os.environ.get("DSACT_CPU_ROWS", 100_000))   # host buffer of the CPU leg: first touch of fresh pages costs ~20 MB/s in this sandbox (a 1M-row,
                       # 3.1 GB buffer = minutes); sample_batch is 2 % of the CPU step even at 1M rows
 
 

@@ -35,6 +35,12 @@ struct ActArgs {
   int act;                          // the policy's hidden activation (ACT_*)
   unsigned long long* out;          // MAPPED HOST memory: 2A pairs (call << 32 | float bits) of (mean | std)
   int* timeout;                     // the hand-off word (mapped host memory, see check_handoff)
+  // sample mode (dsact_act_sample: TanhGaussDistribution.sample() of utils/act_distribution_cls.py:32-42 in the output layer's
+  // epilogue): ONE wave per action dimension d computes both of its logits (rows d and A + d), draws
+  // a = scale * tanh(mean + std * eps[d]) + center and this dimension's log-prob term; out = A (action | log-prob term) pairs
+  int sample;
+  const float* act_scale; const float* act_center;
+  float eps[32];                    // the host's torch.randn(1, A) draw (consumes the generator as Normal.sample() does)
   float x[kActMaxObs];              // the observation
 };
 static_assert(sizeof(ActArgs) <= 4096, "kernel arguments are limited to 4 KB");
@@ -50,7 +56,8 @@ __global__ void __launch_bounds__(256) k_act_mlp(ActArgs a) {
   for (int q = 1; q < kActMaxLayers; ++q) if (q < a.n_layers && b >= a.wg_begin[q]) l = q;
   const ActLayer& Ly = a.ly[l];
   const int n = (b - a.wg_begin[l]) * 4 + wave;
-  if (n >= Ly.N) return;                      // whole wave
+  const bool smp = a.sample && l + 1 == a.n_layers;      // output layer in sample mode: waves 0 .. A-1, two rows each
+  if (n >= (smp ? a.A : Ly.N)) return;        // whole wave
   // this wave's weight row, fetched before anything waits: lane k, k + 64, ...
   constexpr int NJ = (kMaxWidth > kActMaxObs ? kMaxWidth : kActMaxObs) / 64;
   float w[NJ];
@@ -58,7 +65,21 @@ __global__ void __launch_bounds__(256) k_act_mlp(ActArgs a) {
 #pragma unroll
   for (int j = 0; j < NJ; ++j) w[j] = 64 * j + lane < Ly.K ? wr[64 * j + lane] : 0.f;
   const float bias = Ly.b[n];
-  float acc = 0.f;
+  // (sample mode: the raw log-std row of the same action dimension; the output layer never reads the kernel arguments' x)
+  constexpr int NJ2 = kMaxWidth / 64;
+  float w2[NJ2];
+  float bias2 = 0.f, s_eps = 0.f, s_scale = 1.f, s_center = 0.f;
+  if (smp) {
+    const float* wr2 = Ly.W + (size_t)(a.A + n) * Ly.K;
+#pragma unroll
+    for (int j = 0; j < NJ2; ++j) w2[j] = 64 * j + lane < Ly.K ? wr2[64 * j + lane] : 0.f;
+    bias2 = Ly.b[a.A + n];
+    typedef __attribute__((address_space(4))) const char KChar2;
+    typedef __attribute__((address_space(4))) const float KFloat2;
+    s_eps = ((KFloat2*)((KChar2*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(ActArgs, eps)))[n];
+    s_scale = a.act_scale[n]; s_center = a.act_center[n];
+  }
+  float acc = 0.f, acc2 = 0.f;
   if (l == 0) {
     // the observation sits in the kernel-argument segment: read it as memory (indexing the by-value struct with a
     // lane-dependent index would make the compiler spill the whole 4 KB argument to scratch)
@@ -86,15 +107,24 @@ __global__ void __launch_bounds__(256) k_act_mlp(ActArgs a) {
           v = __builtin_bit_cast(float, (unsigned)p);
         }
         acc = fmaf(w[j], v, acc);
+        if (smp && j < NJ2) acc2 = fmaf(w2[j], v, acc2);
       }
     }
   }
   acc = wave_sum(acc) + bias;
+  if (smp) acc2 = wave_sum(acc2) + bias2;
   if (lane != 0) return;
   if (l + 1 < a.n_layers) {
     float hv, gd;
     act_fwd_grad(a.act, acc, hv, gd);
     __hip_atomic_store(a.h + (size_t)l * kMaxWidth + n, act_pair(hv, a.call), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (smp) {
+    // TanhGaussDistribution.sample(): the closed form the training kernels use for rsample (dsact_math.h), term for term
+    const TanhGaussFwd f = tanh_gauss_fwd(acc, acc2, s_eps, s_scale, s_center, a.lo_ls, a.hi_ls);
+    __hip_atomic_store(a.out + n, act_pair(f.a, a.call), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(a.out + a.A + n, act_pair(f.lp, a.call), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
   // output layer: (mean | exp(clamp(log_std))) as StochaPolicy.forward returns them (networks/mlp.py:85-100)

@@ -3892,60 +3892,88 @@ int dsact_debug_get(const dsact_handle* h, const char* name, double* value) {
   return DSACT_OK;
 }
 
+// the single-launch acting forward (dsact_act.h). eps == nullptr: out = the 2A logits (mean | std); else out = A actions
+// followed by A per-dimension log-prob terms of TanhGaussDistribution.sample() with the caller's N(0,1) draw
+static int act_forward_fast(dsact_handle* h, const float* obs_host, const float* eps, float* out_host) {
+  TRY(check_handoff(h));
+  ActArgs a;
+  a.n_layers = h->L + 1;
+  const float* base = net_params(h, N_POL);
+  int wg = 0;
+  for (int l = 0; l <= h->L; ++l) {
+    a.ly[l].W = base + h->pd.w_off[l]; a.ly[l].b = base + h->pd.b_off[l];
+    a.ly[l].K = h->pd.in[l]; a.ly[l].N = h->pd.out[l];
+    a.wg_begin[l] = wg;
+    wg += ((l == h->L && eps ? h->A : h->pd.out[l]) + 3) / 4;
+  }
+  a.wg_begin[h->L + 1] = wg;
+  if (h->act_call >= 0x7ffffff0) {   // the tags only have to differ from call to call: restart far from the sign bit
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemset(h->act_h, 0, (size_t)kActMaxLayers * kMaxWidth * sizeof(unsigned long long)));
+    memset(h->act_out_host, 0, 64 * sizeof(unsigned long long));
+    h->act_call = 0;
+  }
+  a.h = h->act_h; a.call = ++h->act_call;
+  a.A = h->A; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std; a.act = h->cfg.policy_act;
+  a.out = h->act_out_dev; a.timeout = h->handoff_dev;
+  a.sample = eps ? 1 : 0; a.act_scale = h->act_scale; a.act_center = h->act_center;
+  if (eps) memcpy(a.eps, eps, (size_t)h->A * sizeof(float));
+  memcpy(a.x, obs_host, (size_t)h->O * sizeof(float));
+  const auto tl = std::chrono::steady_clock::now();
+  TRY(launch(h, "act_mlp", k_act_mlp, dim3(wg), dim3(256), 0, a));
+  const auto t0 = std::chrono::steady_clock::now();
+  h->act_launch_us = std::chrono::duration<double, std::micro>(t0 - tl).count();
+  const int n_out = 2 * h->A;
+  const unsigned want = (unsigned)a.call;
+  unsigned polls = 0;
+  for (int k = 0; k < n_out;) {   // the data is the flag: every result arrives as a (value, call) pair
+    const unsigned long long pr = ((volatile unsigned long long*)h->act_out_host)[k];
+    if ((unsigned)(pr >> 32) == want) {
+      const unsigned bits = (unsigned)pr;
+      memcpy(out_host + k, &bits, sizeof(float));
+      ++k;
+      continue;
+    }
+    if ((++polls & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
+      HIPCHK(h, hipStreamSynchronize(h->stream));   // surfaces a device fault, if that is what happened
+      TRY(check_handoff(h));
+      return fail(h, DSACT_E_HIP, "acting forward did not complete");
+    }
+  }
+  h->act_wait_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  return check_handoff(h);
+}
+static bool act_fast_ok(const dsact_handle* h) {
+  return !h->cnn && h->O <= kActMaxObs && h->L + 1 <= kActMaxLayers && !h->env_no_fast_act && h->A <= 32;
+}
+
+// OffSampler.sample()'s per-step device work in ONE call (training/off_sampler.py:46-54): policy(obs) on the live weights +
+// TanhGaussDistribution.sample() (utils/act_distribution_cls.py:32-42) with the caller's standard-normal draw eps[A]
+// (torch.randn(1, A) consumes the torch generator exactly as Normal.sample() does and mean + std * eps IS its result):
+// action[A] (inside the action limits by construction of the tanh squashing; the caller clips like the reference) and
+// its log-probability. MLP policies only (DSACT_E_INVALID otherwise: the caller takes dsact_policy_forward).
+int dsact_act_sample(dsact_handle* h, const float* obs_host, const float* eps_host, float* action_host, float* logp_host) {
+  if (!h || !obs_host || !eps_host || !action_host || !logp_host) return DSACT_E_INVALID;
+  if (!h->online) return fail(h, DSACT_E_STATE, "arenas not bound");
+  if (!h->limits_set) return fail(h, DSACT_E_STATE, "action limits not set (dsact_set_action_limits)");
+  if (!act_fast_ok(h)) return fail(h, DSACT_E_INVALID, "dsact_act_sample serves MLP policies with obs <= %d floats", kActMaxObs);
+  HIPCHK(h, hipSetDevice(h->device));
+  float out[64];
+  TRY(act_forward_fast(h, obs_host, eps_host, out));
+  const int A = h->A;
+  float lp = 0.0f;
+  for (int d = 0; d < A; ++d) { action_host[d] = out[d]; lp += out[A + d]; }   // Independent(..., 1): sum over the action dimensions
+  *logp_host = lp;
+  return DSACT_OK;
+}
+
 int dsact_policy_forward(dsact_handle* h, const float* obs_host, int32_t n, float* logits_host) {
   if (!h || !obs_host || !logits_host) return DSACT_E_INVALID;
   if (n < 1 || n > kActRows) return fail(h, DSACT_E_INVALID, "n must be 1..%d", kActRows);
   if (!h->online) return fail(h, DSACT_E_STATE, "arenas not bound");
   HIPCHK(h, hipSetDevice(h->device));
   const size_t O = h->O, ld = h->ldx;
-  if (!h->cnn && n == 1 && h->O <= kActMaxObs && h->L + 1 <= kActMaxLayers && !h->env_no_fast_act) {
-    // one launch: observation in the kernel arguments, logits back through mapped host memory (dsact_act.h)
-    TRY(check_handoff(h));
-    ActArgs a;
-    a.n_layers = h->L + 1;
-    const float* base = net_params(h, N_POL);
-    int wg = 0;
-    for (int l = 0; l <= h->L; ++l) {
-      a.ly[l].W = base + h->pd.w_off[l]; a.ly[l].b = base + h->pd.b_off[l];
-      a.ly[l].K = h->pd.in[l]; a.ly[l].N = h->pd.out[l];
-      a.wg_begin[l] = wg;
-      wg += (h->pd.out[l] + 3) / 4;
-    }
-    a.wg_begin[h->L + 1] = wg;
-    if (h->act_call >= 0x7ffffff0) {   // the tags only have to differ from call to call: restart far from the sign bit
-      HIPCHK(h, hipStreamSynchronize(h->stream));
-      HIPCHK(h, hipMemset(h->act_h, 0, (size_t)kActMaxLayers * kMaxWidth * sizeof(unsigned long long)));
-      memset(h->act_out_host, 0, 64 * sizeof(unsigned long long));
-      h->act_call = 0;
-    }
-    a.h = h->act_h; a.call = ++h->act_call;
-    a.A = h->A; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std; a.act = h->cfg.policy_act;
-    a.out = h->act_out_dev; a.timeout = h->handoff_dev;
-    memcpy(a.x, obs_host, O * sizeof(float));
-    const auto tl = std::chrono::steady_clock::now();
-    TRY(launch(h, "act_mlp", k_act_mlp, dim3(wg), dim3(256), 0, a));
-    const auto t0 = std::chrono::steady_clock::now();
-    h->act_launch_us = std::chrono::duration<double, std::micro>(t0 - tl).count();
-    const int n_out = 2 * h->A;
-    const unsigned want = (unsigned)a.call;
-    unsigned polls = 0;
-    for (int k = 0; k < n_out;) {   // the data is the flag: every logit arrives as a (value, call) pair
-      const unsigned long long pr = ((volatile unsigned long long*)h->act_out_host)[k];
-      if ((unsigned)(pr >> 32) == want) {
-        const unsigned bits = (unsigned)pr;
-        memcpy(logits_host + k, &bits, sizeof(float));
-        ++k;
-        continue;
-      }
-      if ((++polls & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
-        HIPCHK(h, hipStreamSynchronize(h->stream));   // surfaces a device fault, if that is what happened
-        TRY(check_handoff(h));
-        return fail(h, DSACT_E_HIP, "acting forward did not complete");
-      }
-    }
-    h->act_wait_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    return check_handoff(h);
-  }
+  if (n == 1 && act_fast_ok(h)) return act_forward_fast(h, obs_host, nullptr, logits_host);   // one launch (dsact_act.h)
   if (h->cnn) {
     // conv stack of the online policy on n images: (C,H,W) rows -> pixel-major -> conv layers -> feature rows
     if (!h->stage_img) HIPCHK(h, hipMalloc(&h->stage_img, 2 * (size_t)h->Brows * O * sizeof(float)));

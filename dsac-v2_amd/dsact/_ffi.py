@@ -107,6 +107,7 @@ SYMBOLS = [
     ("dsact_debug_set", C.c_int, [_P, C.c_char_p, C.c_double]),
     ("dsact_debug_get", C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double)]),
     ("dsact_policy_forward", C.c_int, [_P, _FP, C.c_int32, _FP]),
+    ("dsact_act_sample", C.c_int, [_P, _FP, _FP, _FP, _FP]),
 ]
 
 _lib = None

@@ -424,6 +424,19 @@ class DsactEngine:
         self._chk(self._lib.dsact_debug_get(self._h, name.encode(), C.byref(v)))
         return float(v.value)
 
+    def act_sample(self, obs, eps):
+        """dsact_act_sample: (action float32[A], logp float) of TanhGaussDistribution.sample() for ONE observation with the
+        caller's N(0,1) draw eps[A]; obs / eps are contiguous float32 arrays (no copies are made here)"""
+        if getattr(self, "_act_out", None) is None:
+            self._act_out = np.empty(self.act_dim, np.float32)
+            self._act_lp = np.empty(1, np.float32)
+            self._act_out_p, self._act_lp_p = _ffi.fptr(self._act_out), _ffi.fptr(self._act_lp)
+        rc = self._lib.dsact_act_sample(self._h, obs.ctypes.data_as(_ffi._FP), eps.ctypes.data_as(_ffi._FP),
+                                        self._act_out_p, self._act_lp_p)
+        if rc != 0:
+            self._chk(rc)
+        return self._act_out, self._act_lp
+
     def policy_forward(self, obs) -> np.ndarray:
         obs = _f32(obs).reshape(-1, self.obs_dim)
         n = obs.shape[0]

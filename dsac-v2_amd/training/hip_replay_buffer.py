@@ -62,6 +62,12 @@ class HipReplayBuffer:
         n = len(samples)
         if n == 0:
             return
+        packed = getattr(samples, "packed", None)
+        if packed is not None and packed[0].shape == (n, self._obs_flat):
+            # HipOffSampler's fast path already holds the transitions as packed float32 arrays (training/hip_sampler.py)
+            obs, act, rew, obs2, done, logp = packed
+            self.engine.buffer_add(obs, act, rew, obs2, done, logp)
+            return
         O, A = self._obs_flat, self.act_dim
         obs = np.empty((n, O), np.float32)
         obs2 = np.empty((n, O), np.float32)

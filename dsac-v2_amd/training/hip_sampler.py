@@ -35,6 +35,14 @@ def _reset(env):
     return out, {}
 
 
+class SampleBatch(list):
+    """The reference's list of (obs, info, act, rew, next_obs, done, logp, next_info) tuples (off_sampler.py:74-84) that
+    ALSO carries the same transitions as packed float32 arrays: HipReplayBuffer.add_batch hands `packed` to the HBM ring
+    without walking the tuples; any other consumer sees an ordinary list."""
+
+    packed = None   # (obs[n,O], act[n,A], rew[n], obs2[n,O], done[n], logp[n])
+
+
 class HipOffSampler:
     def __init__(self, index=0, **kwargs):
         from plugin import create_env
@@ -61,9 +69,61 @@ class HipOffSampler:
     def load_state_dict(self, state_dict):
         self.networks.load_state_dict(state_dict)
 
+    def _fast_engine(self):
+        """the engine behind an ATTACHED MLP policy whose action distribution is the tanh-Gaussian (what every shipped
+        DSAC example uses): one dsact_act_sample call per environment step replaces tensor round trips, Normal objects and
+        .cpu().numpy() (145 -> ~50 us per step, bench.py `e2e`). None: the general path below."""
+        pol = getattr(self.networks, "policy", None)
+        eng = getattr(pol, "_engine", None)
+        if eng is None or self.action_type != "continu" or getattr(eng, "conv_type", None):
+            return None
+        if type(pol).__name__ != "HipStochaPolicy" or getattr(eng, "obs_dim", 1 << 30) > 768:
+            return None
+        return eng
+
+    def _sample_fast(self, eng):
+        """same step order, same generator consumption (ONE torch.randn(1, A) per step: Normal.sample() is
+        mean + std * that draw, bit for bit) and the same stored transitions as the loop in sample()"""
+        n, env = self.sample_batch_size, self.env
+        O, A = eng.obs_dim, eng.act_dim
+        obs_b, obs2_b = np.empty((n, O), np.float32), np.empty((n, O), np.float32)
+        act_b = np.empty((n, A), np.float32)
+        rew_b, done_b, logp_b = np.empty(n, np.float32), np.empty(n, np.float32), np.empty(n, np.float32)
+        low, high = env.action_space.low, env.action_space.high
+        batch = SampleBatch()
+        randn, act_sample, scale = torch.randn, eng.act_sample, self.reward_scale
+        obs, info = self.obs, self.info
+        for i in range(n):
+            ob = obs_b[i]
+            ob[:] = np.reshape(obs, -1)
+            eps = randn(1, A).numpy()
+            action, logp = act_sample(ob, eps)
+            act_b[i] = action
+            logp_b[i] = logp[0]
+            next_obs, reward, done, next_info = env.step(np.clip(act_b[i], low, high))
+            truncated = bool(next_info.get("TimeLimit.truncated", False))
+            next_info["TimeLimit.truncated"] = truncated
+            if truncated:
+                done = False  # time-outs are stored as non-terminal (off_sampler.py:70-73)
+            obs2_b[i] = np.reshape(next_obs, -1)
+            rew_b[i] = scale * reward
+            done_b[i] = done
+            batch.append((ob.reshape(np.shape(obs)), info, act_b[i], scale * reward, obs2_b[i].reshape(np.shape(next_obs)), done,
+                          logp_b[i], next_info))
+            obs, info = next_obs, next_info
+            if done or truncated:
+                obs, info = _reset(env)
+        self.obs, self.info = obs, info
+        batch.packed = (obs_b, act_b, rew_b, obs2_b, done_b, logp_b)
+        return batch
+
     def sample(self):
         self.total_sample_number += self.sample_batch_size
         t0 = time.perf_counter()
+        eng = self._fast_engine()
+        if eng is not None:
+            batch = self._sample_fast(eng)
+            return batch, {SAMPLER_TIME_KEY: (time.perf_counter() - t0) * 1000}
         batch = []
         for _ in range(self.sample_batch_size):
             obs_t = torch.from_numpy(np.expand_dims(self.obs, axis=0).astype("float32"))

@@ -317,6 +317,12 @@ int dsact_debug_get(const dsact_handle* h, const char* name, double* value);
 /* stand-alone fused-MLP forward of the policy net on a host batch (sampler / evaluator feed):
  * logits[n*2A] = (mean | std) exactly as StochaPolicy.forward returns (networks/mlp.py:79-100) */
 int dsact_policy_forward(dsact_handle* h, const float* obs_host, int32_t n, float* logits_host);
+/* OffSampler.sample()'s device work of one environment step in ONE call (training/off_sampler.py:46-54): policy(obs) on the
+ * live weights + TanhGaussDistribution.sample() (utils/act_distribution_cls.py:32-42) in the output layer's epilogue, with
+ * the caller's standard-normal draw eps[A] (torch.randn(1, A): it consumes the torch generator exactly as Normal.sample()
+ * does, and mean + std * eps is bit for bit what Normal.sample() returns). action[A], logp[1] on the host; MLP policies
+ * (DSACT_E_INVALID otherwise -- the caller then takes dsact_policy_forward and samples itself). Synchronous. */
+int dsact_act_sample(dsact_handle* h, const float* obs_host, const float* eps_host, float* action_host, float* logp_host);
 
 #ifdef __cplusplus
 }

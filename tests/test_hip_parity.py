@@ -867,6 +867,76 @@ def test_single_launch_acting_forward(monkeypatch):
     np.testing.assert_allclose(f2, w2, atol=2e-5, rtol=1e-5)
 
 
+def test_act_sample_is_the_reference_sampling_step():
+    """dsact_act_sample (acting forward + TanhGaussDistribution.sample() in the output layer's epilogue, dsact_act.h) against
+    the reference's own sequence on the same logits and the same N(0,1) draw (training/off_sampler.py:46-54,
+    utils/act_distribution_cls.py:32-42), and the sampler's fast path (one call per environment step, one torch.randn per
+    step, packed transitions) against its general path from the same seeds: same generator consumption, same transitions."""
+    from dsac_v2_hip import TanhGaussDistribution
+    from training.hip_sampler import HipOffSampler
+
+    for O, A, hid, B, lim in ((376, 17, (256, 256, 256), 256, 0.4), (5, 1, (33,), 7, 2.0), (24, 6, (128, 128), 64, 1.0)):
+        alg, _ = make_pair(O, A, hid, B, act_limit=lim, seed=61)
+        e = alg.engine
+        rng = np.random.default_rng(2)
+        for i in range(20):
+            obs = (3.0 * rng.standard_normal(O)).astype(np.float32)      # large inputs: some actions near their limits
+            torch.manual_seed(i)
+            eps = torch.randn(1, A)
+            action, logp = e.act_sample(obs, eps.numpy())
+            logits = torch.from_numpy(e.policy_forward(obs[None]))
+            dist = TanhGaussDistribution(logits)
+            dist.act_high_lim, dist.act_low_lim = alg.networks.policy.act_high_lim.cpu(), alg.networks.policy.act_low_lim.cpu()
+            torch.manual_seed(i)
+            a_ref, lp_ref = dist.sample()                                  # draws the same eps from the same generator state
+            np.testing.assert_allclose(action, a_ref[0].numpy(), atol=2e-6 * lim, rtol=0)
+            t2 = (np.asarray(a_ref[0], np.float64) / lim) ** 2             # saturation budget as in compare_intermediates
+            tol = 2e-4 + float((2.4e-7 / (1.0 + 1e-6 - np.minimum(t2, 1.0))).sum())
+            assert abs(float(logp[0]) - float(lp_ref[0])) <= tol, (i, float(logp[0]), float(lp_ref[0]), tol)
+
+    class Env:     # deterministic toy dynamics with a time limit
+        class _S:
+            low, high = np.full(4, -0.3, np.float32), np.full(4, 0.3, np.float32)
+        action_space = _S()
+
+        def __init__(self):
+            self.t, self.s = 0, np.zeros(16, np.float32)
+
+        def reset(self):
+            self.t, self.s = 0, np.linspace(-1, 1, 16).astype(np.float32)
+            return self.s.copy(), {}
+
+        def step(self, a):
+            self.t += 1
+            self.s = (0.9 * self.s + 0.1 * np.resize(a, 16)).astype(np.float32)
+            trunc = self.t >= 7
+            return self.s.copy(), float(self.s.sum()), bool(abs(self.s[0]) > 5), {"TimeLimit.truncated": trunc}
+
+    alg, _ = make_pair(16, 4, (64, 64), 32, act_limit=0.4, seed=62)
+    outs = []
+    for fast in (True, False):
+        smp = HipOffSampler(env=Env(), networks=alg.networks, sample_batch_size=25, action_type="continu")
+        if not fast:
+            smp._fast_engine = lambda: None
+        torch.manual_seed(9)
+        batch, _ = smp.sample()
+        outs.append((batch, torch.randn(2)))
+        assert (getattr(batch, "packed", None) is not None) == fast
+    (b0, r0), (b1, r1) = outs
+    assert torch.equal(r0, r1)                                             # the generator was consumed identically
+    assert len(b0) == len(b1) == 25
+    for s0, s1 in zip(b0, b1):
+        np.testing.assert_allclose(s0[0], s1[0], atol=1e-5)
+        np.testing.assert_allclose(s0[2], s1[2], atol=2e-6)
+        assert abs(s0[3] - s1[3]) < 1e-4 and bool(s0[5]) == bool(s1[5]) and abs(float(s0[6]) - float(s1[6])) < 5e-4
+        np.testing.assert_allclose(s0[4], s1[4], atol=1e-5)
+        assert s0[7]["TimeLimit.truncated"] == s1[7]["TimeLimit.truncated"]
+    obs_p, act_p, rew_p, obs2_p, done_p, logp_p = b0.packed
+    assert obs_p.shape == (25, 16) and act_p.dtype == np.float32
+    np.testing.assert_array_equal(obs_p[3], np.asarray(b0[3][0]).reshape(-1))
+    np.testing.assert_array_equal(act_p[3], b0[3][2])
+
+
 def _replay_pair(O, A, hid, B, N, seed):
     alg, _ = make_pair(O, A, hid, B, seed=seed)
     e = alg.engine
