@@ -2374,7 +2374,6 @@ bool have_graph(const dsact_handle* h) { return h->graph_exec != nullptr || h->p
 int check_handoff(dsact_handle* h) {
   if (!h->handoff_host || h->in_handoff || !*(volatile int*)h->handoff_host) return DSACT_OK;
   h->in_handoff = true;
-  h->state_invalid = true;
   const hipError_t e_dev = hipSetDevice(h->device);
   const hipError_t e_sync = hipStreamSynchronize(h->stream);
   *(volatile int*)h->handoff_host = 0;
@@ -2391,6 +2390,7 @@ int check_handoff(dsact_handle* h) {
   int rebuilt = DSACT_E_STATE;
   if (had_graph) rebuilt = dsact_graph_build(h, steps, gflags);
   h->in_handoff = false;
+  h->state_invalid = true;   // (after the re-capture: dsact_graph_build itself is an entry point that refuses an invalid state)
   const hipError_t e_hip = e_dev != hipSuccess ? e_dev : e_sync != hipSuccess ? e_sync : e_set;
   return fail(h, DSACT_E_HIP,
               "an in-launch hand-over timed out: a workgroup waited > 0.1 s for its producers' ready flags, so every result "
