@@ -1408,6 +1408,23 @@ __global__ void __launch_bounds__(256) k_chain_bwd_pi(BwdPiArgs a) {
   if ((int)blockIdx.x >= a.n_chain_blocks) { bwd_pi_tail_blocks(a, (int)blockIdx.x - a.n_chain_blocks, lds); return; }
   bwd_pi_body<NW, RG>(a, (int)blockIdx.x, lds);
 }
+// The same launch 512 threads wide (unmerged form, long contractions: batch >= 1024): a riding weight-gradient tile runs
+// EIGHT waves, two per SIMD, that hide each other's operand waits (what k_dw2<2, 8> does for the policy's own tiles:
+// 13.8 -> 11.8 us, profiles/r03_ab_dw_8wave.txt) -- the riders' 4 rounds of 16 chunks each were latency chains of one
+// wave per SIMD and bounded this launch at 27 us. The chain's slices use the first 64 NW threads.
+template <int NW, int RG>
+__global__ void __launch_bounds__(512) k_chain_bwd_pi8(BwdPiArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if ((int)blockIdx.x >= a.n_chain_blocks) {
+    const int idx = (int)blockIdx.x - a.n_chain_blocks;
+    const int per_range = xcd_chunk_grid(a.n_extra);
+    int t;
+    if (!xcd_chunk(idx % per_range, a.n_extra, t)) return;
+    dw2_tile<2, NoWait, 8>(a.dw, (idx / per_range) * a.dw.n_base + a.tile0 + t, lds);
+    return;
+  }
+  bwd_pi_body<NW, RG>(a, (int)blockIdx.x, lds);
+}
 
 
 // ---------------------------------------------------------------------------------------------------------------
