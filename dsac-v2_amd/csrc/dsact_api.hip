@@ -243,7 +243,8 @@ struct dsact_handle {
   double act_launch_us = 0.0, act_wait_us = 0.0;   // host time of the last fast acting forward: launch call, completion spin
   bool env_no_fast_act = false;         // DSACT_NO_FAST_ACT: the sampler's forward through the copy + tile-stage path (A/B)
   int env_chain_rg_pi = 0;              // DSACT_CHAIN_RG_PI (experiments)
-  bool env_no_ride8 = false;            // DSACT_NO_RIDE8: the critics' riding tiles keep 4 waves at every batch (A/B)
+  bool env_no_ride8 = true;             // DSACT_RIDE8=1: the critics' riding tiles run 8 waves (512-thread launch) at batch >= 1024 (measured
+                                        // equal: 27.4 vs 27.1 us, 8,784 vs 8,767 steps/s -- that launch is not bound by the riders' wave count)
   bool env_dw_4wave = false;            // DSACT_DW_4WAVE: k_dw2 keeps 4 waves per tile at every batch (A/B)
   bool env_no_conv_dx_mfma = false;     // DSACT_NO_CONV_DX_MFMA: the 16-channel layer's data gradient with k_conv_dx_block (A/B)
   bool env_no_mixed_rg = false;         // DSACT_NO_MIXED_RG: every unit of the merged forward's group A runs 8-row workgroups (A/B)
@@ -2529,7 +2530,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (const char* v = getenv("DSACT_PIPE_MAP")) h->env_pipe_map = v;
   h->env_no_conv_dx_mfma = getenv("DSACT_NO_CONV_DX_MFMA") != nullptr;
   h->env_dw_4wave = getenv("DSACT_DW_4WAVE") != nullptr;
-  h->env_no_ride8 = getenv("DSACT_NO_RIDE8") != nullptr;
+  h->env_no_ride8 = getenv("DSACT_RIDE8") == nullptr;
   if (const char* v = getenv("DSACT_CHAIN_RG")) h->env_chain_rg = atoi(v) == 1 ? 1 : atoi(v) == 4 ? 4 : 2;
   h->dw_chunks = (h->B > 448 && h->B % 256 == 0 && getenv("DSACT_NO_SPLITK") == nullptr) ? h->B / 256 : 1;   // (chain path: below)
   h->dw_part_stride = (h->n_online + 2 + 63) & ~(size_t)63;
@@ -3266,16 +3267,20 @@ struct PipePlan {
   std::vector<char> defer;        // update s leaves the policy alone and has a successor: its policy backward rides in launch s + 1
   std::vector<BwdPiArgs> bp;      // [s]: the deferred policy backward of update s - 1 (valid when defer[s - 1])
   std::vector<int> bp_rg;
+  bool dp = false;                // local gradients -> all-reduce -> k_adam_pack instead of the fused optimiser
 };
 // unit tables of the n forward launches -> plan.host and (synchronous copy: call it BEFORE a stream capture begins) dev_args
-static int plan_updates_pipe(dsact_handle* h, int n, int phase, PipePlan& plan, PipeFwd* dev_args) {
+static int plan_updates_pipe(dsact_handle* h, int n, int phase, PipePlan& plan, PipeFwd* dev_args, uint32_t flags = 0) {
   const int D = h->cfg.delay_update;
   auto set_of = [&](int s) { return (s - (n - 1)) & (dsact_handle::kPipeSets - 1); };
   plan.host.resize((size_t)n); plan.pre.resize((size_t)n); plan.dop.resize((size_t)n);
   plan.defer.assign((size_t)n, 0); plan.bp.resize((size_t)n); plan.bp_rg.assign((size_t)n, 2);
   // the discarded policy backward can move when it is the merged launch's (chain + its own tiles behind the arrival counter)
   const int rg_pi = h->env_chain_rg_pi ? h->env_chain_rg_pi : h->env_chain_rg ? h->env_chain_rg : (h->B >= 8 ? h->cRG : 1);
-  const bool can_defer = h->pi_merge && h->dw_chunks == 1 && !h->fat_bwd && h->env_ride_slots == 0 && rg_pi <= 2 && !h->env_no_pipe_defer;
+  // (data parallel: every rank's policy gradient is part of the all-reduced arena -- nothing is deferred)
+  const bool can_defer = h->pi_merge && h->dw_chunks == 1 && !h->fat_bwd && h->env_ride_slots == 0 && rg_pi <= 2 && !h->env_no_pipe_defer &&
+                         !(flags & DSACT_F_DATA_PARALLEL);
+  plan.dp = (flags & DSACT_F_DATA_PARALLEL) != 0;
   bool pre = false;
   int rc = DSACT_OK;
   h->mirror_w0 = true;   // (what the enqueue pass sets: the tiles' argument blocks are built here)
@@ -3344,6 +3349,13 @@ static int enqueue_updates_pipe(dsact_handle* h, int n, const PipePlan& plan, Pi
       ride.n_gather = 0;
     }
     ride.bookkeeping = 1;
+    if (plan.dp) {
+      rc = enqueue_grads(h, true, false, 2, &ride);
+      if (rc == DSACT_OK) rc = enqueue_allreduce(h, h->grads, h->n_online + 2, kNcclAvg);
+      if (rc == DSACT_OK) rc = h->env_no_adam_pack ? enqueue_adam(h) : enqueue_adam_pack(h);
+      if (rc == DSACT_OK && h->env_no_adam_pack) rc = enqueue_pack(h, true);
+      continue;
+    }
     h->pipe_defer_now = plan.defer[(size_t)s] != 0;
     rc = enqueue_grads(h, true, true, 2, &ride);
     h->pipe_defer_now = false;
@@ -3354,10 +3366,10 @@ static int enqueue_updates_pipe(dsact_handle* h, int n, const PipePlan& plan, Pi
   return rc;
 }
 
-static int capture_updates_pipe(dsact_handle* h, int n, int phase, hipGraph_t* graph, hipGraphExec_t* exec, PipeFwd** dev_args) {
+static int capture_updates_pipe(dsact_handle* h, int n, int phase, hipGraph_t* graph, hipGraphExec_t* exec, PipeFwd** dev_args, uint32_t flags) {
   HIPCHK(h, hipMalloc((void**)dev_args, (size_t)n * sizeof(PipeFwd)));
   PipePlan plan;
-  TRY(plan_updates_pipe(h, n, phase, plan, *dev_args));
+  TRY(plan_updates_pipe(h, n, phase, plan, *dev_args, flags));
   HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
   const int rc = enqueue_updates_pipe(h, n, plan, *dev_args);
   hipError_t e = hipStreamEndCapture(h->stream, graph);
@@ -3372,9 +3384,10 @@ static bool pipe_eligible(const dsact_handle* h, int steps_per_graph, uint32_t f
   const int D = h->cfg.delay_update;
   const bool merged = !h->cnn && h->use_w1p && h->dw_chunks == 1 && !h->use_fork && !h->use_std_sums && h->alt_ws != nullptr &&
                       !h->env_no_merged_gather;
+  // (data parallel: the forward pipelining only -- replicas hold identical policies, which change on the same iterations)
   return merged && h->chain_ok && !h->fat && h->fwd_merge && h->B % 4 == 0 && h->rng_seed != 0 && h->cfg.algo == 0 &&
-         !(flags & (DSACT_F_DATA_PARALLEL | DSACT_F_SKIP_ACTOR_ON_OFF_ITERS)) && D >= 2 && D <= dsact_handle::kPipePhases &&
-         steps_per_graph >= 2 && !h->env_no_pipe;
+         !(flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) && (!(flags & DSACT_F_DATA_PARALLEL) || h->comm != nullptr) && D >= 2 &&
+         D <= dsact_handle::kPipePhases && steps_per_graph >= 2 && !h->env_no_pipe;
 }
 
 int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) {
@@ -3408,7 +3421,7 @@ int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) 
   int rc = DSACT_OK;
   if (pipe) {
     rc = alloc_pipe_sets(h);
-    for (int ph = 0; ph < D && rc == DSACT_OK; ++ph) rc = capture_updates_pipe(h, steps_per_graph, ph, &h->pgraph[ph], &h->pexec[ph], &h->pargs[ph]);
+    for (int ph = 0; ph < D && rc == DSACT_OK; ++ph) rc = capture_updates_pipe(h, steps_per_graph, ph, &h->pgraph[ph], &h->pexec[ph], &h->pargs[ph], flags);
     h->pipe_graph = rc == DSACT_OK;
   } else {
     rc = capture_updates(h, steps_per_graph, flags, merged, &h->graph, &h->graph_exec);
@@ -3739,7 +3752,7 @@ int dsact_profile_steps(dsact_handle* h, int64_t first_iteration, int32_t n_step
     TRY(alloc_pipe_sets(h));
     HIPCHK(h, hipMalloc((void**)&dev, (size_t)n_steps * sizeof(PipeFwd)));
     PipePlan plan;
-    rc = plan_updates_pipe(h, n_steps, (int)((first_iteration % D + D) % D), plan, dev);
+    rc = plan_updates_pipe(h, n_steps, (int)((first_iteration % D + D) % D), plan, dev, flags);
     if (rc == DSACT_OK) {
       h->profiling = true;
       rc = enqueue_updates_pipe(h, n_steps, plan, dev);
