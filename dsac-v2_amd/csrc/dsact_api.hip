@@ -687,6 +687,7 @@ int build_pack_jobs(dsact_handle* h) {
   std::vector<PackJob> jobs;
   int blocks = 0;
   for (int net = 0; net < N_NET; ++net) {
+    if (h->nq == 1 && (net == N_Q2 || net == N_Q2T)) continue;   // one critic (DSAC_V1)
     const NetDesc& d = net_desc(h, net);
     const bool target = net >= N_Q1T;
     const int n3 = net % 3;
@@ -727,6 +728,7 @@ int build_adam_pack_jobs(dsact_handle* h) {
   std::vector<AdamPackJob> jobs;
   int blocks = 0;
   for (int n3 = 0; n3 < 3; ++n3) {
+    if (n3 == 1 && h->nq == 1) continue;   // one critic (DSAC_V1)
     const int net = kChainNet[chs[n3]];
     const NetDesc& d = net_desc(h, net);
     const long long base = (long long)(net_grads(h, net) - h->grads);
@@ -1418,6 +1420,7 @@ Dw2Args dw2_args(dsact_handle* h, bool fused) {
   int tiles = 0;
   for (int n3 = 0; n3 < 3; ++n3) {
     h->dw2_off[n3] = tiles;
+    if (n3 == 1 && h->nq == 1) continue;   // one critic (DSAC_V1): q2's tile range is empty
     const int ch = chs[n3], net = kChainNet[ch], slot = kDzSlot[ch];
     const NetDesc& d = net_desc(h, net);
     const long long base = (long long)(net_grads(h, net) - h->grads);
@@ -1517,7 +1520,7 @@ void fill_fwd_common(dsact_handle* h, FwdArgs& a, int rg, const char* name, cons
   }
   a.map = map ? *map : xcd_map_uniform(a.n_units);
   a.B = h->B; a.F = h->F; a.A = h->A; a.L = h->L; a.ldx = h->ldx;
-  a.s_obs = h->fat ? h->c_obs : h->s_obs; a.s_act = h->fat ? h->c_act : h->s_act; a.v1_stats = 0; a.Cb = h->B / 16;
+  a.s_obs = h->fat ? h->c_obs : h->s_obs; a.s_act = h->fat ? h->c_act : h->s_act; a.v1_stats = h->nq == 1; a.Cb = h->B / 16;
   a.act_scale = h->act_scale; a.act_center = h->act_center; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
   a.timeline = tl_for(h, name);
   a.spin_timeout = h->handoff_dev;
@@ -1532,27 +1535,29 @@ void fwd_args_a(dsact_handle* h, FwdArgs& a) {
   FwdUnit& pt = a.u[1] = fwd_unit(h, C_PIT, SEG_FULL, HEAD_POLICY);
   pt.logits = h->logits_pit; pt.logp = h->logp2; pt.eps = h->eps_2; pt.xact = h->Xc[C_Q1T];
   for (int l = 0; l < h->L; ++l) pt.G[l] = nullptr;   // never differentiated
-  for (int i = 0; i < 2; ++i) {
+  const int nq = h->nq;      // 2 critics (DSAC_V2) or 1 (DSAC_V1): units [pi, pit, q_c x nq, q_t(obs) x nq]
+  for (int i = 0; i < nq; ++i) {
     FwdUnit& qc = a.u[2 + i] = fwd_unit(h, C_Q1C + i, SEG_FULL_SAVE, HEAD_Q);
     qc.zsave = h->zobs[i]; qc.qout = h->qout_c[i]; qc.qstd = h->qstd_c[i];
     if (i == 0) qc.x0t = h->X0t;
-    FwdUnit& qt = a.u[4 + i] = fwd_unit(h, C_Q1T + i, SEG_OBS_ONLY, HEAD_NONE);
+    FwdUnit& qt = a.u[2 + nq + i] = fwd_unit(h, C_Q1T + i, SEG_OBS_ONLY, HEAD_NONE);
     qt.zsave = h->zobs[2 + i];
   }
-  a.n_units = 6;
+  a.n_units = 2 + 2 * nq;
 }
 
 // group B: q1_t/q2_t(obs2,act2), q1/q2(obs,new_act): saved observation part + action part, hidden layers, heads
 void fwd_args_b(dsact_handle* h, FwdArgs& a) {
   memset(&a, 0, sizeof(a));
-  for (int i = 0; i < 2; ++i) {
+  const int nq = h->nq;      // units [q_t x nq, q_p x nq]
+  for (int i = 0; i < nq; ++i) {
     FwdUnit& qt = a.u[i] = fwd_unit(h, C_Q1T + i, SEG_ACT_FROM_SAVED, HEAD_Q);
     qt.zinit = h->zobs[2 + i]; qt.qout = h->qout_t[i];
     for (int l = 0; l < h->L; ++l) qt.G[l] = nullptr;   // never differentiated
-    FwdUnit& qp = a.u[2 + i] = fwd_unit(h, C_Q1P + i, SEG_ACT_FROM_SAVED, HEAD_Q);
+    FwdUnit& qp = a.u[nq + i] = fwd_unit(h, C_Q1P + i, SEG_ACT_FROM_SAVED, HEAD_Q);
     qp.zinit = h->zobs[i]; qp.qout = h->qout_p[i];
   }
-  a.n_units = 4;
+  a.n_units = 2 * nq;
 }
 
 // fat mode: 32-row workgroups when even those fill the chip twice over, else 16-row ones
@@ -1623,23 +1628,24 @@ int enqueue_chain_fwd_merged(dsact_handle* h) {
   // workgroups (0.75x the layer time) on two XCDs each, the four critic units 8-row ones on one XCD each: 256
   // workgroups, one per CU, 8 XCDs busy; with group B's 256 that is exactly two per CU.
   XcdMap mixed_map;
-  const bool mixed = rga == 2 && h->B % 8 == 0 && 2 * (h->B / 4) + 4 * (h->B / 8) <= 256 && !h->env_no_mixed_rg;
+  const int nq = h->nq;
+  const bool mixed = rga == 2 && h->B % 8 == 0 && 2 * (h->B / 4) + 2 * nq * (h->B / 8) <= 256 && !h->env_no_mixed_rg;
   if (mixed) {
     m.A.u[0].rg = m.A.u[1].rg = 1;
-    const int share[6] = {2, 2, 1, 1, 1, 1};
-    mixed_map = xcd_map_shares(6, share);
+    const int share6[6] = {2, 2, 1, 1, 1, 1}, share4[4] = {2, 2, 2, 2};
+    mixed_map = nq == 2 ? xcd_map_shares(6, share6) : xcd_map_shares(4, share4);
   }
   fill_fwd_common(h, m.A, rga, "chain_fwd", mixed ? &mixed_map : nullptr);
   fill_fwd_common(h, m.B, rgb, "chain_fwd");
   h->n_heads_parts = h->B / 4;   // one partial per four rows whatever the rows per workgroup (chain_fwd_body)
   int* f = h->chain_flags;
-  for (int k = 0; k < 6; ++k) m.A.u[k].done = f + k * kChainFlagSlices;   // pi, pit, q1c, q2c, q1t(obs), q2t(obs)
-  for (int i = 0; i < 2; ++i) {
+  for (int k = 0; k < m.A.n_units; ++k) m.A.u[k].done = f + k * kChainFlagSlices;   // pi, pit, q_c x nq, q_t(obs) x nq
+  for (int i = 0; i < nq; ++i) {
     m.A.u[2 + i].zdone = f + (6 + i) * kChainFlagSlices;   // q_c: the saved observation part is ready
     FwdUnit& qt = m.B.u[i];       // q_t(obs2, act2): action from pit, observation part from the obs-only unit
     qt.wait0 = m.A.u[1].done; qt.wait_rows0 = 4 * m.A.u[1].rg;
-    qt.wait1 = m.A.u[4 + i].done; qt.wait_rows1 = 4 * m.A.u[4 + i].rg;
-    FwdUnit& qp = m.B.u[2 + i];   // q(obs, new_act): action from pi, observation part from q_c (its early flag)
+    qt.wait1 = m.A.u[2 + nq + i].done; qt.wait_rows1 = 4 * m.A.u[2 + nq + i].rg;
+    FwdUnit& qp = m.B.u[nq + i];  // q(obs, new_act): action from pi, observation part from q_c (its early flag)
     qp.wait0 = m.A.u[0].done; qp.wait_rows0 = 4 * m.A.u[0].rg;
     qp.wait1 = m.A.u[2 + i].zdone; qp.wait_rows1 = 4 * m.A.u[2 + i].rg;
   }
@@ -1936,27 +1942,35 @@ int launch_chain_fwd_pipe(dsact_handle* h, const char* name, const PipeFwd& host
 void bwd_q_args(dsact_handle* h, int n_units, const RideArgs* ride, BwdQArgs& a, int& rg_out, int& n_riders_out) {
   memset(&a, 0, sizeof(a));
   const int L = h->L;
+  // units: the critic chains q_c x nq, then (actor backward) the chains q(obs, new_act) x nq; `which` keeps DSAC_V2's
+  // numbering (0 q1c, 1 q2c, 2 q1p, 3 q2p) so that the row phase and the buffers are the same for one critic (DSAC_V1)
   const int chs[4] = {C_Q1C, C_Q2C, C_Q1P, C_Q2P};
   for (int w = 0; w < n_units; ++w) {
     BwdQUnit& u = a.u[w];
-    const int net = kChainNet[chs[w]], n3 = net == N_Q1 ? 0 : 1;
+    const int which = h->nq == 2 ? w : 2 * w;
+    const int ch = chs[which];
+    const int net = kChainNet[ch], n3 = net == N_Q1 ? 0 : 1;
     for (int l = 1; l < L; ++l) u.wb[l] = h->pk_bwd[n3][l];
     u.wout = net_params(h, net) + h->qd.w_off[L];
-    for (int l = 0; l < L; ++l) { u.G[l] = h->Gb[chs[w]][l]; u.dZ[l] = h->dZ[kDzSlot[chs[w]]][l]; }
-    u.dout = h->dout[w];
-    if (w < 2) u.doutT = h->doutT[w];
-    if (w >= 2) { u.w1at = h->pk_w1at[n3]; u.dA = h->dAq[n3]; }
-    u.which = w;
+    for (int l = 0; l < L; ++l) { u.G[l] = h->Gb[ch][l]; u.dZ[l] = h->dZ[kDzSlot[ch]][l]; }
+    u.dout = h->dout[which];
+    if (which < 2) u.doutT = h->doutT[which];
+    if (which >= 2) { u.w1at = h->pk_w1at[n3]; u.dA = h->dAq[n3]; }
+    u.which = which;
   }
+  a.v1 = h->nq == 1; a.td_bound = h->cfg.td_bound; a.v1_bound = h->cfg.v1_unbounded ? 0 : 1;
   const int rg = h->fat_bwd ? 4 * fat_rt(h, n_units) : chain_rg(h, n_units, true);
   a.n_units = n_units; a.n_slices = h->B / (4 * rg); a.B = h->B; a.A = h->A; a.L = L; a.Cb = h->B / 16;
-  for (int i = 0; i < 2; ++i) { a.qout_c[i] = h->qout_c[i]; a.qstd_c[i] = h->qstd_c[i]; a.qout_t[i] = h->qout_t[i]; a.qout_p[i] = h->qout_p[i]; }
+  for (int i = 0; i < 2; ++i) {   // (one critic: the second slots repeat the first -- the DSAC_V1 row phase never reads them)
+    const int k = i < h->nq ? i : 0;
+    a.qout_c[i] = h->qout_c[k]; a.qstd_c[i] = h->qstd_c[k]; a.qout_t[i] = h->qout_t[k]; a.qout_p[i] = h->qout_p[k];
+  }
   a.rew = h->rew; a.done = h->done; a.logp2 = h->logp2; a.logp_new = h->logp_new; a.z5 = h->z5; a.z6 = h->z6;
   a.log_alpha = h->online + h->n_online - 1;
   a.part_loss = h->part_loss; a.grads_tail = h->grads + h->n_online; a.st = h->st;
   a.inv_B = 1.0f / (float)h->B;
   a.inv_Bg = h->use_std_sums ? 1.0f / (float)h->cfg.global_batch : 1.0f / (float)h->B;
-  a.std_sums = h->use_std_sums ? h->std_sums : nullptr;
+  a.std_sums = (h->use_std_sums && h->nq == 2) ? h->std_sums : nullptr;
   a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.gamma = h->cfg.gamma; a.tau_b = h->cfg.tau_b;
   a.one_minus_tau_b = (float)(1.0 - h->cfg.tau_b);
   a.n_chain_blocks = h->fat_bwd ? n_units * a.n_slices : chain_grid(n_units, a.n_slices);
@@ -2071,14 +2085,14 @@ int enqueue_grads_chain(dsact_handle* h, bool actor_backward, bool fused, int ph
       TRY(enqueue_chain_fwd_a(h));
       TRY(enqueue_chain_fwd_b(h));
     }
-    if (h->use_std_sums) {
+    if (h->use_std_sums && h->nq == 2) {
       StdSumArgs s;
       s.qstd_c[0] = h->qstd_c[0]; s.qstd_c[1] = h->qstd_c[1]; s.B = h->B; s.out = h->std_sums;
       TRY(launch(h, "std_sums", k_std_sums, dim3(1), dim3(kThreads), 0, s));
     }
   }
   if (phase == 1) return DSACT_OK;
-  TRY(enqueue_chain_bwd_q(h, actor_backward ? 4 : 2, ride));
+  TRY(enqueue_chain_bwd_q(h, (actor_backward ? 2 : 1) * h->nq, ride));
   if (!actor_backward) {
     if (h->dw_chunks == 1) return run_dw2(h, off[0], off[2], fused, fused);
     TRY(run_dw2(h, off[0], off[2], false, false));
@@ -2537,8 +2551,8 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   {
     // row-slice fused chains: MLP nets of DSAC_V2 with equal hidden widths of 64 / 128 / 256, batch a multiple of 16
     const int R = 4 * h->cRG;
-    bool ok = !h->cnn && h->nq == 2 && h->B % R == 0 && h->B % 16 == 0 && (h->B <= 256 || h->B % 256 == 0) && h->F % 4 == 0 &&
-              getenv("DSACT_NO_CHAIN") == nullptr;
+    bool ok = !h->cnn && h->B % R == 0 && h->B % 16 == 0 && (h->B <= 256 || h->B % 256 == 0) && h->F % 4 == 0 &&
+              getenv("DSACT_NO_CHAIN") == nullptr && !(h->nq == 1 && getenv("DSACT_NO_CHAIN_V1") != nullptr);
     ok = ok && h->L <= kChMaxL;
     for (int l = 0; l < h->L; ++l) ok = ok && cfg->hidden[l] == cfg->hidden[0];
     const int W0 = cfg->hidden[0];
@@ -2566,7 +2580,8 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
       const int fat_min = fm ? atoi(fm) : 1024;
       const char* fb = getenv("DSACT_FAT_BWD_MIN");
       const int fat_bwd_min = fb ? atoi(fb) : 4096;
-      h->fat = ok && h->B >= fat_min && h->B % 32 == 0 && (W0 == 128 || W0 == 256) && getenv("DSACT_NO_FAT") == nullptr;
+      // (the throughput-regime kernels hold DSAC_V2's two-critic row phase: one critic keeps the 8-row chains at every batch)
+      h->fat = ok && h->nq == 2 && h->B >= fat_min && h->B % 32 == 0 && (W0 == 128 || W0 == 256) && getenv("DSACT_NO_FAT") == nullptr;
       h->fat_bwd = h->fat && h->B >= fat_bwd_min;
       if (const char* v = getenv("DSACT_FAT_RT")) h->env_fat_rt = atoi(v) == 2 ? 2 : 1;
     }

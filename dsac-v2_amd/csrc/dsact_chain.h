@@ -1081,6 +1081,9 @@ struct BwdQArgs {
   long long* timeline;
   RideArgs ride;
   int* flags_reset; int n_flags;   // the merged forward launch's ready flags: cleared here, after it and before the next one
+  // DSAC_V1 (dsac_v1.py:194-253): ONE critic -- units `which` 0 (q(obs,act)) and 2 (q(obs,new_act)), no mean_std EMA, the
+  // fixed TD_bound clip, and the variance-weighted pseudo-loss (v1_bound) or the Gaussian NLL; same row layout otherwise
+  int v1; float td_bound; int v1_bound;
 };
 
 template <int NW, int RG>
@@ -1108,7 +1111,7 @@ __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* 
   if (L > 1) stream_prologue(ws, u.wb[L - 1] + (size_t)wave * SH * 256, 0, lane4);
   // ---- batch sums of std1 / std2 -> mean_std EMA (dsac_v2.py:233-241); identical in every workgroup
   float s1 = 0.f, s2 = 0.f;
-  if (a.std_sums == nullptr) {
+  if (a.std_sums == nullptr && !a.v1) {
     for (int r = tid; r < a.B; r += NTHR) { s1 += a.qstd_c[0][2 * r]; s2 += a.qstd_c[1][2 * r]; }
     s1 = wave_sum(s1); s2 = wave_sum(s2);
     if (lane == 0) { sc[wave] = s1; sc[4 + wave] = s2; }
@@ -1159,11 +1162,39 @@ __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* 
   else if (u.which == 1) { d0 = c2.dq * a.inv_B; d1 = c2.dstd * a.inv_B * sg2; }
   else if (u.which == 2) { d0 = -wq1 * a.inv_B; d1 = 0.0f; }
   else { d0 = -(1.0f - wq1) * a.inv_B; d1 = 0.0f; }
+  float v1_loss = 0.f;
+  if (a.v1) {
+    // dsac_v1.py:184-253, term for term as k_loss_v1 (dsact_kernels.h): one critic, z5 is q_target's sample noise
+    const float qs1 = q1n + z5 * std1n;                                   // q_next_sample
+    const float tq1 = rew + nd * a.gamma * (qs1 - alpha * lp2);
+    const float tqb = q1 + clampf(tq1 - q1, -a.td_bound, a.td_bound);
+    const float sd = fmaxf(std1, 0.0f);
+    float dq = -(tq1 - q1) / (sd * sd + 0.1f);
+    const float e = q1 - tqb;
+    float dstd = -((e * e - sd * sd) / (sd * sd * sd + 0.1f));
+    v1_loss = dq * q1 + dstd * std1;
+    if (!a.v1_bound) {   // -Normal(q, std).log_prob(target_q)
+      const float d = tq1 - q1, var = std1 * std1;
+      dq = -d / var;
+      dstd = 1.0f / std1 - (d * d) / (var * std1);
+      v1_loss = (d * d) / (2.0f * var) + logf(std1) + kLogSqrt2Pi;
+    }
+    if (u.which == 0) { d0 = dq * a.inv_B; d1 = dstd * a.inv_B * sg1; }
+    else { d0 = -a.inv_B; d1 = 0.0f; }
+  }
   if (j == 0) {
     u.dout[2 * r] = d0; u.dout[2 * r + 1] = d1;
     sc[16 + 2 * m] = d0; sc[16 + 2 * m + 1] = d1;
     if (u.doutT) { u.doutT[pk_index(0, r, a.Cb)] = d0; u.doutT[pk_index(1, r, a.Cb)] = d1; }
-    if (u.which == 0) {
+    if (u.which == 0 && a.v1) {
+      float* pl = a.part_loss + (size_t)r * kLossPart;
+      pl[0] = v1_loss; pl[1] = 0.f; pl[2] = q1; pl[3] = 0.f; pl[4] = std1; pl[5] = 0.f;
+      pl[6] = alpha * lpn - q1p;
+      pl[7] = lpn;
+      pl[8] = r == 0 ? alpha : 0.0f;
+      pl[9] = 0.0f; pl[10] = std1; pl[11] = std1;
+      if (r == 0) { a.grads_tail[0] = 0.f; a.grads_tail[1] = 0.f; }
+    } else if (u.which == 0) {
       float* pl = a.part_loss + (size_t)r * kLossPart;
       pl[0] = c1.loss; pl[1] = c2.loss; pl[2] = q1; pl[3] = q2; pl[4] = std1; pl[5] = std2;
       pl[6] = alpha * lpn - fminf(q1p, q2p);

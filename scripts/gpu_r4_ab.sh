@@ -13,7 +13,7 @@ if [ -n "$K" ]; then
   grep -n "^FAILED\|^ERROR\|passed\|failed\|^E  " $OUT/pytest_gpu.log | tail -30
 fi
 STEPS=${BENCH_STEPS:-2000}; WARM=${BENCH_WARMUP:-200}
-summ() { tail -1 $1 | python -c "
+summ() { grep "^{\"metric\"" $1 | tail -1 | python -c "
 import sys, json
 try:
     d = json.loads(sys.stdin.read())
