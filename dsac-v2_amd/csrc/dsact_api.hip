@@ -1826,7 +1826,7 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
     put(r_pit, pt);
   };
   auto target_units = [&](int r_q1t, int r_pit, bool wait) {
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < h->nq; ++i) {   // (one critic: DSAC_V1)
       FwdUnit qt = fwd_unit(h, C_Q1T + i, SEG_FULL_SPLIT, HEAD_Q);
       qt.qout = h->qout_t[i];
       for (int l = 0; l < h->L; ++l) qt.G[l] = nullptr;   // never differentiated
@@ -1842,7 +1842,7 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
   // produces the same bits with no producer: that is how the launches whose policy units ran earlier hold it (no in-launch
   // dependency at all), and -- DSACT_PIPE_QP_SPLIT=1 -- optionally the others (observation part under the wait for pi)
   const bool qp_split = pre || h->env_pipe_qp_split;
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < h->nq; ++i) {   // (one critic: DSAC_V1)
     FwdUnit qc = fwd_unit(h, C_Q1C + i, qp_split ? SEG_FULL : SEG_FULL_SAVE, HEAD_Q);
     qc.qout = h->qout_c[i]; qc.qstd = h->qstd_c[i];
     if (i == 0) qc.x0t = h->X0t;
@@ -1866,7 +1866,7 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
   FwdArgs& a = P.c;
   a.n_units = PR_N;
   a.B = h->B; a.F = h->F; a.A = h->A; a.L = h->L; a.ldx = h->ldx;
-  a.s_obs = h->s_obs; a.s_act = h->s_act; a.v1_stats = 0; a.Cb = h->B / 16;
+  a.s_obs = h->s_obs; a.s_act = h->s_act; a.v1_stats = h->nq == 1; a.Cb = h->B / 16;
   a.act_scale = h->act_scale; a.act_center = h->act_center; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
   a.timeline = tl_for(h, pipe_fwd_name(pre, do_pre));
   a.spin_timeout = h->handoff_dev;
@@ -3400,7 +3400,7 @@ static bool pipe_eligible(const dsact_handle* h, int steps_per_graph, uint32_t f
   const bool merged = !h->cnn && h->use_w1p && h->dw_chunks == 1 && !h->use_fork && !h->use_std_sums && h->alt_ws != nullptr &&
                       !h->env_no_merged_gather;
   // (data parallel: the forward pipelining only -- replicas hold identical policies, which change on the same iterations)
-  return merged && h->chain_ok && !h->fat && h->fwd_merge && h->B % 4 == 0 && h->rng_seed != 0 && h->cfg.algo == 0 &&
+  return merged && h->chain_ok && !h->fat && h->fwd_merge && h->B % 4 == 0 && h->rng_seed != 0 &&
          !(flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) && (!(flags & DSACT_F_DATA_PARALLEL) || h->comm != nullptr) && D >= 2 &&
          D <= dsact_handle::kPipePhases && steps_per_graph >= 2 && !h->env_no_pipe;
 }

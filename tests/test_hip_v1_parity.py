@@ -97,6 +97,29 @@ def test_v1_humanoid_shapes():
     run_case("v1 humanoid 3x256 B=256", 376, 17, (256, 256, 256), 256, steps=3)
 
 
+def test_v1_runs_on_the_row_slice_chains(monkeypatch):
+    """round 4: DSAC_V1 with MLP nets of equal width takes the row-slice chain kernels (one critic = fewer units in the same
+    launches, the V1 row phase in the critics' backward chain): chain path == tile path within fp32 summation order on
+    every intermediate the debug buffers expose, and both against the oracle (the cases above)."""
+    a1, _ = make_pair(376, 17, (256, 256, 256), 256, seed=3)
+    assert a1.engine.chain_active
+    monkeypatch.setenv("DSACT_NO_CHAIN_V1", "1")
+    a2, _ = make_pair(376, 17, (256, 256, 256), 256, seed=3)
+    assert not a2.engine.chain_active
+    rng = np.random.default_rng(4)
+    for it in range(3):
+        data = synth_batch(rng, 256, 376, 17)
+        for a in (a1, a2):
+            torch.manual_seed(90 + it)
+            a.local_update(data, it)
+    a1.engine.sync(); a2.engine.sync()
+    for n in ("qout_c0", "qout_t0", "qout_p0", "logp_new", "d_new_act", "dZ.q1c.0", "dZ.pi.0", "H.q1p.2"):
+        x, y = a1.engine.debug_read(n), a2.engine.debug_read(n)
+        assert np.abs(x - y).max() <= 2e-5 * max(1.0, np.abs(y).max()), n
+    d = (a1.engine.online - a2.engine.online).abs().max().item()
+    assert d < 5e-6, d
+
+
 def test_v1_unbounded_critic_loss():
     """`bound=False` (dsac_v1.py:227-228): the critic loss is -Normal(q, std).log_prob(target_q); also switchable on a live
     algorithm through `adjustable_parameters`."""
@@ -149,11 +172,13 @@ def test_v1_local_update_surface_and_fused_equals_split():
         assert torch.equal(s1[k].cpu(), s2[k].cpu()), k
 
 
-@pytest.mark.parametrize("per_graph,total", [(2, 8), (3, 6)])
-def test_v1_graph_replay_equals_eager_steps(per_graph, total):
+@pytest.mark.parametrize("per_graph,total,O", [(2, 8, 17), (3, 6, 17), (4, 8, 16), (3, 9, 16)])
+def test_v1_graph_replay_equals_eager_steps(per_graph, total, O):
     """DSAC_V1 through the graph flow (gather of the next update and the bookkeeping ride in k_loss_v1's launch, the
-    single critic's first-layer tiles keep the padded copies fresh) == eager updates, bit for bit."""
-    O, A, hid, B, N = 17, 4, (64, 64), 64, 2048
+    single critic's first-layer tiles keep the padded copies fresh) == eager updates, bit for bit. obs 16: the row-slice
+    chains, whose graph is the pipelined one (policy units of the next minibatch precomputed, discarded policy backward
+    deferred, tagged hand-over)."""
+    A, hid, B, N = 4, (64, 64), 64, 2048
     engines = []
     for mode in ("eager", "graph"):
         alg, _ = make_pair(O, A, hid, B, seed=4)
@@ -166,8 +191,10 @@ def test_v1_graph_replay_equals_eager_steps(per_graph, total):
                              (torch.rand(N, device="cuda", generator=g) < .05).float())
         np.random.seed(1)
         e.upload_index_table(np.random.randint(0, N, size=(8, B)))
+        assert e.chain_active == (O % 4 == 0)
         if mode == "graph":
             e.graph_build(per_graph)
+            assert e.debug_get("pipe_graph") == (1.0 if O % 4 == 0 else 0.0)
             e.graph_run(0, total)
         else:
             assert e.time_steps(0, total, use_graph=False) > 0
