@@ -280,6 +280,7 @@ struct dsact_handle {
   PipeFwd* pargs[kPipePhases] = {nullptr, nullptr, nullptr, nullptr};   // device: one PipeFwd per captured forward launch
   bool env_no_pipe = false;             // DSACT_NO_PIPE: graph replays without the pipelining (A/B)
   int env_pipe_qt = 0;                  // DSACT_PIPE_QT=1: q_target(obs2', act2') of the next minibatch is precomputed too
+  int env_pk_pad = 0;                   // DSACT_PK_PAD: see build_chain
   int env_pipe_bp_rg = 0;               // DSACT_PIPE_BP_RG=1|2: rows / 4 per workgroup of the deferred policy backward chain (0: as in its own launch)
   bool env_no_pipe_warm = true;         // DSACT_PIPE_WARM=1: L2 warm-up touches in the pipelined forward launches (measured: slower, 60.4 vs 59.6 us)
   bool env_no_pipe_defer = false;       // DSACT_NO_PIPE_DEFER: the discarded policy backward stays in its own update's last launch (A/B)
@@ -632,9 +633,10 @@ int build_chain(dsact_handle* h) {
   // fat mode (dsact_fat.h): EVERY pack is style 16 (16-row tiles x chunks of 16 k; a tile-chunk block is 256 floats like
   // a style-44 step, so the sizes below count blocks either way)
   const bool fat = h->fat, fatb = h->fat_bwd;
-  const int tiles_f = fat ? W / 16 : tiles, S_hid = fat ? CH : SH;
+  const int tiles_f = fat ? W / 16 : tiles, S_hid = fat ? CH : SH + (h->fat ? 0 : h->env_pk_pad);
   const int tiles_b = fatb ? W / 16 : tiles, S_hidb = fatb ? CH : SH, S_out = fatb ? h->c_out : h->SoT;
-  const int C0q = fat ? h->c_obs + h->c_act : h->s_obs + h->s_act, C0p = fat ? h->c_obs : h->s_obs;
+  const int tpad = fat ? 0 : h->env_pk_pad;   // style-44 forward packs: padding steps behind every tile (DSACT_PK_PAD)
+  const int C0q = fat ? h->c_obs + h->c_act : h->s_obs + h->s_act + tpad, C0p = fat ? h->c_obs : h->s_obs + tpad;
   const int nth_q = 1, nth_p = (2 * A + 15) / 16, nta = (A + 15) / 16;
   // carve the packed copies
   for (int pass = 0; pass < 2; ++pass) {
@@ -1525,6 +1527,7 @@ void fill_fwd_common(dsact_handle* h, FwdArgs& a, int rg, const char* name, cons
   a.timeline = tl_for(h, name);
   a.spin_timeout = h->handoff_dev;
   a.debug_withhold = h->debug_withhold == 1;
+  a.tpad = h->fat ? 0 : h->env_pk_pad;
 }
 
 // group A: policy(obs), policy_target(obs2), q1/q2(obs,act) + observation part of q1_t/q2_t(obs2, .)
@@ -1872,6 +1875,7 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
   a.spin_timeout = h->handoff_dev;
   a.debug_withhold = h->debug_withhold == 1;
   a.tagp = &h->st->seq_next;
+  a.tpad = h->env_pk_pad;
   // block table: every XCD's queue is filled role by role (the enum is the priority order), a role's slices are dealt
   // round-robin over its XCDs; block 8 r + x = entry r of XCD x's queue (the dispatcher places block b on XCD b % 8)
   std::vector<int> q[8];
@@ -2538,6 +2542,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->env_no_pipe_defer = getenv("DSACT_NO_PIPE_DEFER") != nullptr;
   h->env_no_pipe_warm = getenv("DSACT_PIPE_WARM") == nullptr;
   h->env_no_pipe_tagged = getenv("DSACT_NO_PIPE_TAGGED") != nullptr;
+  if (const char* v = getenv("DSACT_PK_PAD")) h->env_pk_pad = atoi(v) > 0 && atoi(v) <= 64 ? atoi(v) : 0;
   if (const char* v = getenv("DSACT_PIPE_BP_RG")) h->env_pipe_bp_rg = atoi(v) == 1 ? 1 : atoi(v) == 2 ? 2 : 0;
   if (const char* v = getenv("DSACT_PIPE_RG_NEXT")) h->env_pipe_rg_next = atoi(v) == 1 ? 1 : 2;
   if (const char* v = getenv("DSACT_PIPE_RG_SIDE")) h->env_pipe_rg_side = atoi(v) == 1 ? 1 : 2;

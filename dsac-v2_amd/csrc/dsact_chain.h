@@ -584,6 +584,7 @@ struct FwdArgs {
                                     // HOST memory: every entry point of the library checks it and fails the call
   int debug_withhold;               // tests only (dsact_debug_set "withhold_flag"): unit 0 / slice 0 never raises its flag
   const long long* tagp;            // tagged hand-over: DevState::seq_next (advances with every closed update): tag = low word + 1
+  int tpad;                         // steps of padding behind every 64-row tile of the forward packs (experiments: DSACT_PK_PAD)
 };
 
 // Data handed from a producer to a consumer INSIDE the merged launch (sampled actions, saved first-layer accumulators)
@@ -701,7 +702,7 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
   const bool do_obs = u.seg != SEG_ACT_FROM_SAVED;
   const bool do_act = u.seg != SEG_OBS_ONLY && u.s_act > 0;
   WStr ws;
-  const float* w0 = u.wf[0] + (size_t)wave * S0 * 256;
+  const float* w0 = u.wf[0] + (size_t)wave * (S0 + a.tpad) * 256;
   stream_prologue(ws, w0, do_obs ? 0 : a.s_obs, lane4);
   constexpr int NWARM = 4;
   float wt[NWARM] = {0.f, 0.f, 0.f, 0.f};
@@ -859,7 +860,7 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
   const int xs_in = xin + (lane & 3) * S.ld_in;
   // ---- first layer
   const bool more = L > 1;
-  const float* w1 = u.wf[more ? 1 : 0] + (size_t)wave * SH * 256;
+  const float* w1 = u.wf[more ? 1 : 0] + (size_t)wave * (more ? SH + a.tpad : S0 + a.tpad) * 256;
   if (do_obs) {
     const bool into_act = do_act;   // continues into the action segment (same tensor, next steps) or the second layer
     gemm44_seg<RG>(ws, w0, 0, a.s_obs, into_act ? w0 : w1, into_act ? a.s_obs : 0, into_act || (more && u.seg != SEG_OBS_ONLY),
@@ -913,9 +914,9 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
     lds_barrier();
     CTL(a.timeline, 4 + 2 * l);
     if (l + 1 < L) {
-      const float* wc = u.wf[l + 1] + (size_t)wave * SH * 256;
+      const float* wc = u.wf[l + 1] + (size_t)wave * (SH + a.tpad) * 256;
       const bool has_nxt = l + 2 < L;
-      const float* wn = u.wf[has_nxt ? l + 2 : l + 1] + (size_t)wave * SH * 256;
+      const float* wn = u.wf[has_nxt ? l + 2 : l + 1] + (size_t)wave * (SH + a.tpad) * 256;
       gemm44_seg<RG>(ws, wc, 0, SH, wn, 0, has_nxt, lds, hn + (lane & 3) * S.ld_h, S.ld_h, lane4, acc);
       CTL(a.timeline, 5 + 2 * l);
     }
