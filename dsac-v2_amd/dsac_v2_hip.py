@@ -552,6 +552,35 @@ class DSAC_V2_HIP:
     def adjustable_parameters(self):
         return ("gamma", "tau", "auto_alpha", "alpha", "delay_update")
 
+    # ---- optimiser sidecar (additive: the reference's checkpoints hold `networks.state_dict()` only, trainer.py:148-152, so
+    #      a resumed reference run restarts Adam and the mean_std EMA from scratch) --------------------------------------
+    SIDECAR_FORMAT = "dsact-optimizer-sidecar/1"
+
+    def optimizer_state_dict(self) -> dict:
+        """Everything `networks.state_dict()` does not hold and a bit-exact resume needs: both Adam moment arenas (flat, in
+        the engine's arena order), the three Adam step counters, the mean_std EMA; plus the arena signature they belong to."""
+        e = self.engine
+        e.sync()
+        st = e.get_state()
+        return {"format": self.SIDECAR_FORMAT, "algorithm": type(self).__name__,
+                "signature": [(k, tuple(v.shape)) for k, v in self.networks.state_dict().items()],
+                "adam_m": e.adam_m.detach().cpu().clone(), "adam_v": e.adam_v.detach().cpu().clone(),
+                "adam_steps": list(st["adam_steps"]), "mean_std": list(st["mean_std"])}
+
+    def load_optimizer_state_dict(self, sd: dict):
+        """restores what optimizer_state_dict() saved (after `networks.load_state_dict`); refuses another layout"""
+        if sd.get("format") != self.SIDECAR_FORMAT:
+            raise ValueError("not a %s file" % self.SIDECAR_FORMAT)
+        sig = [(k, tuple(v.shape)) for k, v in self.networks.state_dict().items()]
+        if [(k, tuple(shape)) for k, shape in sd["signature"]] != sig:
+            raise ValueError("optimizer sidecar belongs to another network layout")
+        e = self.engine
+        e.sync()
+        e.adam_m.copy_(sd["adam_m"].to(e.adam_m.device))
+        e.adam_v.copy_(sd["adam_v"].to(e.adam_v.device))
+        torch.cuda.synchronize(e.device)
+        e.set_state(adam_steps=[int(v) for v in sd["adam_steps"]], mean_std=[float(v) for v in sd["mean_std"]])
+
     @property
     def mean_std1(self):
         return self.engine.get_state()["mean_std"][0]

@@ -151,6 +151,12 @@ class HipOffSerialTrainer:
             evaluator.networks = self.networks
         if kwargs.get("ini_network_dir") is not None:
             self.networks.load_state_dict(torch.load(kwargs["ini_network_dir"]))
+        # additive (absent in the reference, whose checkpoints hold the networks only): optimiser sidecar next to every
+        # apprfunc_{it}.pkl when `save_optimizer_state` is set, `ini_optimizer_dir` to resume from one
+        self.save_optimizer_state = bool(kwargs.get("save_optimizer_state", False))
+        if kwargs.get("ini_optimizer_dir") is not None:
+            side = torch.load(kwargs["ini_optimizer_dir"])
+            alg.load_optimizer_state_dict(side)
         self.replay_batch_size = kwargs["replay_batch_size"]
         self.max_iteration = kwargs["max_iteration"]
         self.sample_interval = kwargs.get("sample_interval", 1)
@@ -214,6 +220,9 @@ class HipOffSerialTrainer:
     def save_apprfunc(self):
         torch.save(self.networks.state_dict(),
                    os.path.join(self.save_folder, "apprfunc", "apprfunc_{}.pkl".format(self.iteration)))
+        if self.save_optimizer_state and hasattr(self.alg, "optimizer_state_dict"):
+            side = dict(self.alg.optimizer_state_dict(), iteration=int(self.iteration))
+            torch.save(side, os.path.join(self.save_folder, "apprfunc", "apprfunc_{}.optstate.pkl".format(self.iteration)))
 
 
 def create_trainer(alg, sampler, buffer, evaluator, **kwargs):

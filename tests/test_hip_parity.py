@@ -1243,6 +1243,55 @@ def test_state_save_restore_continues_identically():
     assert a1.engine.get_state() == a2.engine.get_state()
 
 
+def test_optimizer_sidecar_roundtrip_resumes_bitwise(tmp_path):
+    """f2 (optional in SURVEY 8f; absent in the reference, whose checkpoints hold the networks only): `optimizer_state_dict()`
+    / `load_optimizer_state_dict()` through torch.save / torch.load + the reference-format network checkpoint resume a run bit
+    for bit; a sidecar of another layout is refused; the trainer writes one next to every apprfunc file when asked to."""
+    O, A, hid, B = 16, 4, (64, 64), 32
+    a1, _ = make_pair(O, A, hid, B, seed=5)
+    rng = np.random.default_rng(11)
+    batches = [synth_batch(rng, B, O, A) for _ in range(6)]
+
+    def run(alg, its):
+        for it in its:
+            torch.manual_seed(300 + it)
+            alg.local_update(batches[it], it)
+        alg.engine.sync()
+
+    run(a1, range(3))
+    torch.save(a1.networks.state_dict(), tmp_path / "apprfunc_3.pkl")
+    torch.save(a1.optimizer_state_dict(), tmp_path / "apprfunc_3.optstate.pkl")
+    run(a1, range(3, 6))
+    a2, _ = make_pair(O, A, hid, B, seed=99)          # different init, then restored from the two files
+    a2.networks.load_state_dict(torch.load(tmp_path / "apprfunc_3.pkl"))
+    a2.load_optimizer_state_dict(torch.load(tmp_path / "apprfunc_3.optstate.pkl"))
+    run(a2, range(3, 6))
+    for n in ("online", "target", "adam_m", "adam_v"):
+        assert torch.equal(getattr(a1.engine, n), getattr(a2.engine, n)), n
+    assert a1.engine.get_state() == a2.engine.get_state()
+    a3, _ = make_pair(O, A, (64, 64, 64), B, seed=1)
+    with pytest.raises(ValueError, match="another network layout"):
+        a3.load_optimizer_state_dict(torch.load(tmp_path / "apprfunc_3.optstate.pkl"))
+    from training.hip_trainer import HipOffSerialTrainer
+
+    class Buf:
+        size = 10 ** 6
+
+        def sample_batch(self, n):
+            return batches[0]
+
+        def __get_RAM__(self):
+            return 0.0
+
+    tr = HipOffSerialTrainer(a2, None, Buf(), None, replay_batch_size=B, max_iteration=2, log_save_interval=10, apprfunc_save_interval=1,
+                             eval_interval=10 ** 9, save_folder=str(tmp_path / "run"), buffer_warm_size=0, save_optimizer_state=True)
+    tr.train()
+    files = sorted(os.listdir(tmp_path / "run" / "apprfunc"))
+    assert "apprfunc_1.pkl" in files and "apprfunc_1.optstate.pkl" in files and "apprfunc_2.optstate.pkl" in files
+    side = torch.load(tmp_path / "run" / "apprfunc" / "apprfunc_2.optstate.pkl")
+    assert side["iteration"] == 2 and side["format"] == a2.SIDECAR_FORMAT and side["adam_m"].numel() == a2.engine.adam_m.numel()
+
+
 def test_full_size_replay_gather_and_determinism():
     """BASELINE.json configs[1] sizes: 1M-row ring in HBM, batch 256 -- gathered rows equal torch's
     index_select on the same device arrays (bit-exact), and two replays of the same 8 updates agree bit-for-bit."""
