@@ -836,6 +836,7 @@ int build_tasks(dsact_handle* h) {
   h->dfeat_pi = fresh("dfeat_pi", 2);
   if (h->cnn) {
     for (int ch : {C_Q1C, C_Q2C, C_PI}) {
+      if (ch == C_Q2C && h->nq == 1) continue;   // one critic (DSAC_V1)
       const int net = kChainNet[ch];
       const NetDesc& d = net_desc(h, net);
       GemmProb t;
@@ -844,7 +845,7 @@ int build_tasks(dsact_handle* h) {
       if (ch == C_PI) { t.Q = net_params(h, net) + d.w_off[0]; t.ldq = d.in[0]; }
       else if (h->use_w1p) { t.Q = h->W1p[ch == C_Q1C ? 0 : 1]; t.ldq = h->ldx; }  // this step's pre-update copy
       else { t.Q = net_params(h, net) + d.w_off[0]; t.ldq = d.in[0]; }              // (dfeat_q runs before the critics' update)
-      t.C0 = h->dfeat[ch == C_Q1C ? S_Q1 : ch == C_Q2C ? S_Q2 : S_PI]; t.ldc = h->F;
+      t.C0 = h->dfeat[ch == C_PI ? h->nq : ch - C_Q1C]; t.ldc = h->F;   // (stack numbering: q x nq, then the policy)
       t.M = B; t.N = h->F; t.K = d.out[0];
       stage_add(ch == C_PI ? h->dfeat_pi : h->dfeat_q, t);
     }
@@ -1018,7 +1019,24 @@ int run_dw(dsact_handle* h, int x0, int x1, bool fused, bool finalize, hipStream
 
 
 // ---- CNN encoders -----------------------------------------------------------------------------------
-static const int kStackNet[N_STACK] = {N_Q1, N_Q2, N_POL, N_Q1T, N_Q2T, N_POLT};
+// Conv stacks are numbered [q x nq, policy | q_target x nq, policy_target]: nd = nq + 1 differentiated stacks on `obs`, then the
+// nd target stacks on `obs2` (DSAC_V2: q1 q2 pi q1t q2t pit = the ConvStack enum; DSAC_V1 with one critic: q pi qt pit)
+int n_diff_stacks(const dsact_handle* h) { return h->nq + 1; }
+int n_conv_stacks(const dsact_handle* h) { return 2 * (h->nq + 1); }
+int stack_net(const dsact_handle* h, int st) {
+  const int nq = h->nq, nd = nq + 1;
+  if (st < nq) return N_Q1 + st;
+  if (st == nq) return N_POL;
+  if (st < nd + nq) return N_Q1T + (st - nd);
+  return N_POLT;
+}
+int stack_chain(const dsact_handle* h, int st) {   // the chain whose MLP rows a stack's features feed first
+  const int nq = h->nq, nd = nq + 1;
+  if (st < nq) return C_Q1C + st;
+  if (st == nq) return C_PI;
+  if (st < nd + nq) return C_Q1T + (st - nd);
+  return C_PIT;
+}
 
 // conv stacks forward: one launch per layer carrying all six stacks, then the feature scatter into the
 // MLP input rows of the chains each stack feeds
@@ -1045,13 +1063,14 @@ int enqueue_conv_forward(dsact_handle* h) {
     int items = 0;
     // layer 0: the three nets on `obs` (resp. `obs2`) read the same image -> one group each, weights
     // concatenated along the channel dimension; deeper layers: one group per stack
-    const int per_group = j == 0 ? 3 : 1;
-    for (int st0 = 0; st0 < N_STACK; st0 += per_group) {
+    const int nd = n_diff_stacks(h), n_stacks = n_conv_stacks(h);
+    const int per_group = j == 0 ? nd : 1;
+    for (int st0 = 0; st0 < n_stacks; st0 += per_group) {
       ConvGroup& p = a.p[a.n_prob++];
-      p.in = j == 0 ? h->img[st0 < 3 ? 0 : 1] : h->cact[st0][j - 1];
+      p.in = j == 0 ? h->img[st0 < nd ? 0 : 1] : h->cact[st0][j - 1];
       p.n_sub = per_group;
       for (int u = 0; u < per_group; ++u) {
-        const int st = st0 + u, net = kStackNet[st];
+        const int st = st0 + u, net = stack_net(h, st);
         const NetDesc& d = net_desc(h, net);
         p.w[u] = net_params(h, net) + d.cw_off[j];
         p.bias[u] = net_params(h, net) + d.cb_off[j];
@@ -1083,12 +1102,12 @@ int enqueue_conv_forward(dsact_handle* h) {
   FeatArgs f;
   memset(&f, 0, sizeof(f));
   const int last = h->n_conv - 1;
-  const int d0[N_STACK] = {C_Q1C, C_Q2C, C_PI, C_Q1T, C_Q2T, C_PIT};
-  for (int st = 0; st < N_STACK; ++st) { f.act[st] = h->cact[st][last]; f.dst0[st] = h->Xc[d0[st]]; f.dst1[st] = nullptr; }
-  f.dst1[S_Q1] = h->Xc[C_Q1P]; f.dst1[S_Q2] = h->Xc[C_Q2P];
-  f.n_stack = N_STACK; f.B = B; f.P = h->cP; f.C = h->cg[last].Cout; f.ldx = h->ldx;
+  const int n_stacks = n_conv_stacks(h);
+  for (int st = 0; st < n_stacks; ++st) { f.act[st] = h->cact[st][last]; f.dst0[st] = h->Xc[stack_chain(h, st)]; f.dst1[st] = nullptr; }
+  for (int i = 0; i < h->nq; ++i) f.dst1[i] = h->Xc[C_Q1P + i];   // q(obs, new_act) shares q(obs, act)'s features
+  f.n_stack = n_stacks; f.B = B; f.P = h->cP; f.C = h->cg[last].Cout; f.ldx = h->ldx;
   const long long n = (long long)B * h->F;
-  return launch(h, "feat_scatter", k_feat_scatter, dim3((unsigned)((n + kThreads - 1) / kThreads), N_STACK), dim3(kThreads), 0, f);
+  return launch(h, "feat_scatter", k_feat_scatter, dim3((unsigned)((n + kThreads - 1) / kThreads), n_stacks), dim3(kThreads), 0, f);
 }
 
 // conv stacks backward for the first n_st differentiated stacks (q1, q2[, policy]); dfeat[] must hold
@@ -1181,7 +1200,7 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
       memset(&c, 0, sizeof(c));
       c.g = g; c.n_prob = n_st; c.B = B;
       for (int st = 0; st < n_st; ++st) {
-        const int net = kStackNet[S(st)];
+        const int net = stack_net(h, S(st));
         c.dy[st] = h->cdy[S(st)][j]; c.w[st] = net_params(h, net) + net_desc(h, net).cw_off[j];
         c.x[st] = h->cact[S(st)][j - 1]; c.dx[st] = h->cdy[S(st)][j - 1];
       }
@@ -1210,7 +1229,7 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
       s.name = "conv_dcol" + sfx; s.kind = 2; s.n_blocks = 0;
       memset(&s.args, 0, sizeof(s.args));
       for (int st = 0; st < n_st; ++st) {
-        const int net = kStackNet[S(st)];
+        const int net = stack_net(h, S(st));
         const NetDesc& d = net_desc(h, net);
         GemmProb t;
         memset(&t, 0, sizeof(t));
@@ -1251,7 +1270,7 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
       Ly.block_begin = blocks;
       blocks += Ly.wide ? (Ly.quads + 15) / 16 : (Ly.quads + kThreads - 1) / kThreads;
       for (int st = 0; st < n_st; ++st) {
-        const int net = kStackNet[S(st)];
+        const int net = stack_net(h, S(st));
         const NetDesc& d = net_desc(h, net);
         r.p[j][st].part = h->dwpart[S(st)][j];
         r.p[j][st].w_idx = (long long)((net_grads(h, net) + d.cw_off[j]) - h->grads);
@@ -2249,10 +2268,10 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
     if (h->cnn) TRY(run_stage(h, h->dfeat_q));
     if (h->dw_chunks == 1) {
       TRY(run_dw(h, h->dw_off[0], h->dw_off[2], fused, fused));
-      if (h->cnn) TRY(enqueue_conv_backward(h, 2, fused));
+      if (h->cnn) TRY(enqueue_conv_backward(h, h->nq, fused));
     } else {
       TRY(run_dw(h, h->dw_off[0], h->dw_off[2], false, false));
-      if (h->cnn) TRY(enqueue_conv_backward(h, 2, false));
+      if (h->cnn) TRY(enqueue_conv_backward(h, h->nq, false));
       if (fused) TRY(enqueue_adam(h, true));   // policy segment: not updated on off iterations, partials ignored
       else TRY(sum_parts(h, 0, (size_t)h->nq * h->n_q));
     }
@@ -2262,7 +2281,7 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
   if (h->cnn) TRY(run_stage(h, h->dfeat_q));   // reads the step's padded copy of W0: safe against the fused Adam below
   if (phase == 3) {
     TRY(run_dw(h, h->dw_off[0], h->dw_off[2], false, false));
-    if (h->cnn) TRY(enqueue_conv_backward(h, 2, false));
+    if (h->cnn) TRY(enqueue_conv_backward(h, h->nq, false));
     TRY(sum_parts(h, 0, (size_t)h->nq * h->n_q));
     return DSACT_OK;
   }
@@ -2322,7 +2341,7 @@ actor_part:
     for (size_t i = 0; i < np; ++i) TRY(run_stage(h, h->bwdpi[i]));
     if (h->cnn) TRY(run_stage(h, h->dfeat_pi));
     TRY(run_dw(h, h->dw_off[2], h->dw_off[3], false, false));
-    if (h->cnn) TRY(enqueue_conv_backward(h, 1, false, 2));
+    if (h->cnn) TRY(enqueue_conv_backward(h, 1, false, h->nq));
     TRY(sum_parts(h, (size_t)h->nq * h->n_q, h->n_online - 1));
     return DSACT_OK;
   }
@@ -2341,10 +2360,10 @@ actor_part:
   // policy weight gradients (+ the critics' when there was no launch to ride in) + close of the update
   if (h->dw_chunks == 1) {
     TRY(run_dw(h, np ? ride_end : h->dw_off[0] + ride_hb, h->dw_off[3], fused, fused));
-    if (h->cnn) TRY(enqueue_conv_backward(h, 3, fused));
+    if (h->cnn) TRY(enqueue_conv_backward(h, h->nq + 1, fused));
   } else {
     TRY(run_dw(h, np ? ride_end : h->dw_off[0] + ride_hb, h->dw_off[3], false, false));
-    if (h->cnn) TRY(enqueue_conv_backward(h, 3, false));
+    if (h->cnn) TRY(enqueue_conv_backward(h, h->nq + 1, false));
     if (fused) TRY(enqueue_adam(h, true));
     else TRY(sum_parts(h, 0, h->n_online - 1));
   }
@@ -2518,7 +2537,6 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->n_q = h->qd.count; h->n_pi = h->pd.count;
   if (cfg->algo != DSACT_ALGO_DSAC_V2 && cfg->algo != DSACT_ALGO_DSAC_V1) return fail(h, DSACT_E_INVALID, "algo must be 0 (DSAC_V2) or 1 (DSAC_V1)");
   h->nq = cfg->algo == DSACT_ALGO_DSAC_V1 ? 1 : 2;
-  if (h->nq == 1 && h->cnn) return fail(h, DSACT_E_INVALID, "DSAC_V1 is built for the MLP nets only");
   h->n_online = h->nq * h->n_q + h->n_pi + 1;
   h->n_target = h->nq * h->n_q + h->n_pi;
   h->n_heads_wg = (h->B + 3) / 4;

@@ -12,7 +12,9 @@ Discovered like every reference algorithm: `create_alg(algorithm="DSAC_V1_HIP", 
 
 libdsact.so runs the update with `dsact_config.algo = DSACT_ALGO_DSAC_V1`: the tile stages carry one critic chain
 per group instead of two, `k_loss_v1` replaces the DSAC-T loss kernel, everything else (replay, gather, heads,
-policy backward, fused Adam/Polyak, graphs, data-parallel halves) is shared. MLP approximators only.
+policy backward, fused Adam/Polyak, graphs, data-parallel halves) is shared. Round 4: equal-width MLP nets run the row-slice
+chains and the pipelined graph (one critic = fewer units in the same launches); the CNN approximators
+(example_train/dsacv1_cnn_carracing_offasync.py) run the conv kernels + tile stages with four conv stacks instead of six.
 """
 __all__ = ["ApproxContainer", "DSAC_V1_HIP"]
 
@@ -47,9 +49,7 @@ ALG_TIME_KEY = _v2.ALG_TIME_KEY
 
 
 def _check_supported(kwargs):
-    if kwargs.get("value_func_type", "MLP") != "MLP" or kwargs.get("policy_func_type", "MLP") != "MLP":
-        raise NotImplementedError("DSAC_V1_HIP is built for the MLP approximators")
-    _v2._check_supported(kwargs)
+    _v2._check_supported(kwargs)   # MLP nets, or the CNN nets of example_train/dsacv1_cnn_carracing_offasync.py (round 4)
 
 
 class ApproxContainer(_v2.ApproxContainer):
@@ -59,20 +59,31 @@ class ApproxContainer(_v2.ApproxContainer):
         nn.Module.__init__(self)
         _check_supported(kwargs)
         hidden = _v2._hidden_sizes(kwargs)
-        O, A = int(kwargs["obsv_dim"]), int(kwargs["action_dim"])
+        A = int(kwargs["action_dim"])
         hi = np.asarray(kwargs["action_high_limit"], dtype=np.float32)
         lo = np.asarray(kwargs["action_low_limit"], dtype=np.float32)
-        self.q = _v2.HipActionValueDistri(O, A, hidden, kwargs.get("value_hidden_activation", "gelu"))
-        self.q_target = copy.deepcopy(self.q)
-        self.policy = _v2.HipStochaPolicy(O, A, hidden, hi, lo, kwargs.get("policy_min_log_std", -20.0),
-                                          kwargs.get("policy_max_log_std", 2.0), kwargs.get("policy_hidden_activation", "gelu"))
+        va, pa = kwargs.get("value_hidden_activation", "gelu"), kwargs.get("policy_hidden_activation", "gelu")
+        mn, mx = kwargs.get("policy_min_log_std", -20.0), kwargs.get("policy_max_log_std", 2.0)
+        ct = _v2._conv_type(kwargs)
+        if ct:   # networks/cnn.py:151-240,383-461: conv stack -> separate `mean` / `log_std` MLPs per net
+            O = tuple(int(v) for v in kwargs["obsv_dim"])
+            self.q = _v2.HipCnnActionValueDistri(O, A, ct, va)
+            self.q_target = copy.deepcopy(self.q)
+            self.policy = _v2.HipCnnStochaPolicy(O, A, ct, hi, lo, mn, mx, pa)
+            layout = _v2.CnnArenaLayout(O, A, ct, n_critics=1)
+        else:
+            O = int(kwargs["obsv_dim"])
+            self.q = _v2.HipActionValueDistri(O, A, hidden, va)
+            self.q_target = copy.deepcopy(self.q)
+            self.policy = _v2.HipStochaPolicy(O, A, hidden, hi, lo, mn, mx, pa)
+            layout = ArenaLayout(O, A, hidden, n_critics=1)
         self.policy_target = copy.deepcopy(self.policy)
         for net in (self.policy_target, self.q_target):
             for p in net.parameters():
                 p.requires_grad = False
         self.log_alpha = nn.Parameter(torch.tensor(1, dtype=torch.float32))
         object.__setattr__(self, "_engine", None)
-        object.__setattr__(self, "_layout", ArenaLayout(O, A, hidden, n_critics=1))
+        object.__setattr__(self, "_layout", layout)
 
 
 class LazyTbInfoV1(_v2.LazyTbInfo):
@@ -120,8 +131,10 @@ class DSAC_V1_HIP(_v2.DSAC_V2_HIP):
         self.strict_rng = bool(kwargs.get("strict_rng", False))
         self.flags = int(kwargs.get("hip_flags", 0))
         B = int(kwargs["replay_batch_size"])
+        ct = _v2._conv_type(kwargs)
         self.engine = DsactEngine(
-            int(kwargs["obsv_dim"]), int(kwargs["action_dim"]), _v2._hidden_sizes(kwargs), B,
+            tuple(kwargs["obsv_dim"]) if ct else int(kwargs["obsv_dim"]), int(kwargs["action_dim"]), _v2._hidden_sizes(kwargs), B,
+            conv_type=ct,
             gamma=self.gamma, tau=self.tau, auto_alpha=bool(self.auto_alpha), alpha=float(self.alpha),
             delay_update=int(self.delay_update), lr_q=kwargs["value_learning_rate"],
             lr_pi=kwargs["policy_learning_rate"], lr_alpha=kwargs["alpha_learning_rate"],

@@ -47,10 +47,8 @@ class DsactEngine:
         self.algo = algo
         if algo not in ("DSAC_V2", "DSAC_V1"):
             raise DsactError("algo must be DSAC_V2 or DSAC_V1")
-        if conv_type and algo != "DSAC_V2":
-            raise DsactError("the CNN approximators are built for DSAC_V2 only")
         if conv_type:
-            self.layout = CnnArenaLayout(obs_dim, act_dim, conv_type)
+            self.layout = CnnArenaLayout(obs_dim, act_dim, conv_type, n_critics=2 if algo == "DSAC_V2" else 1)
             if list(hidden) != self.layout.hidden:
                 raise DsactError("conv_type %s fixes the MLP widths to %s" % (conv_type, self.layout.hidden))
             self.obs_shape = self.layout.obs_shape

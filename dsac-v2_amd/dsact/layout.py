@@ -152,7 +152,9 @@ class CnnArenaLayout:
       output layer   (n_out x 2H) = [[w_mean, 0], [0, w_ls]] | [b_mean ; b_ls]      (zero blocks structural)
     """
 
-    def __init__(self, obs_shape, act_dim: int, conv_type: str):
+    def __init__(self, obs_shape, act_dim: int, conv_type: str, n_critics: int = 2):
+        """n_critics = 2: DSAC_V2 (q1, q2); 1: DSAC_V1 (a single `q`; online = q | policy | log_alpha)."""
+        self.n_critics = int(n_critics)
         self.obs_shape = tuple(int(v) for v in obs_shape)
         self.obs_dim = int(self.obs_shape[0] * self.obs_shape[1] * self.obs_shape[2])
         self.act_dim = int(act_dim)
@@ -165,18 +167,23 @@ class CnnArenaLayout:
         self._views = {}
         self.n_q = self._build("q", self.feat_dim + self.act_dim, 1)
         self.n_pi = self._build("policy", self.feat_dim, self.act_dim)
-        self.n_online = 2 * self.n_q + self.n_pi + 1
-        self.n_target = 2 * self.n_q + self.n_pi
-        self.net_offset = {
-            "q1": ("online", 0), "q2": ("online", self.n_q), "policy": ("online", 2 * self.n_q),
-            "q1_target": ("target", 0), "q2_target": ("target", self.n_q),
-            "policy_target": ("target", 2 * self.n_q),
-        }
+        nq = self.n_critics
+        self.n_online = nq * self.n_q + self.n_pi + 1
+        self.n_target = nq * self.n_q + self.n_pi
+        if nq == 2:
+            self.net_offset = {
+                "q1": ("online", 0), "q2": ("online", self.n_q), "policy": ("online", 2 * self.n_q),
+                "q1_target": ("target", 0), "q2_target": ("target", self.n_q),
+                "policy_target": ("target", 2 * self.n_q),
+            }
+            self.online_nets = ("q1", "q2", "policy")
+            self.all_nets = ("q1", "q2", "q1_target", "q2_target", "policy", "policy_target")
+        else:   # registration order of dsac_v1.py:26-33
+            self.net_offset = {"q": ("online", 0), "policy": ("online", self.n_q),
+                               "q_target": ("target", 0), "policy_target": ("target", self.n_q)}
+            self.online_nets = ("q", "policy")
+            self.all_nets = ("q", "q_target", "policy", "policy_target")
         self.log_alpha_offset = self.n_online - 1
-
-    n_critics = 2
-    online_nets = ("q1", "q2", "policy")
-    all_nets = ("q1", "q2", "q1_target", "q2_target", "policy", "policy_target")
 
     def _build(self, kind, in0, nb):
         """nb = outputs per trunk (1 for Q: mean / std; A for the policy). Returns the float count."""
@@ -231,7 +238,7 @@ class CnnArenaLayout:
     def state_dict_keys(self):
         sd = OrderedDict()
         sd["log_alpha"] = ()
-        for net in ("q1", "q2", "q1_target", "q2_target", "policy", "policy_target"):
+        for net in self.all_nets:
             if net.startswith("policy"):
                 sd[net + ".act_high_lim"] = (self.act_dim,)
                 sd[net + ".act_low_lim"] = (self.act_dim,)

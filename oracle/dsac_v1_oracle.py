@@ -52,11 +52,11 @@ class DsacV1Oracle:
 
     def __init__(self, cfg: Dict, state_dict=None):
         self.cfg = cfg
-        O, A, hid = cfg["obs_dim"], cfg["act_dim"], list(cfg["hidden"])
+        A = cfg["act_dim"]
         self.act_high = torch.as_tensor(np.asarray(cfg["act_high"], dtype=np.float32))
         self.act_low = torch.as_tensor(np.asarray(cfg["act_low"], dtype=np.float32))
-        q = _new_mlp_params([O + A] + hid + [2])          # dsac_v1.py:26-28
-        pi = _new_mlp_params([O] + hid + [2 * A])         # dsac_v1.py:31-33
+        q = self._new_q_params()                           # dsac_v1.py:26-28
+        pi = self._new_pi_params()                         # dsac_v1.py:31-33
         self.p = {"q": q, "q_target": [t.clone() for t in q], "policy": pi, "policy_target": [t.clone() for t in pi]}
         self.log_alpha = torch.tensor(1.0, dtype=torch.float32)
         if state_dict is not None:
@@ -72,30 +72,45 @@ class DsacV1Oracle:
         self.TD_bound = cfg.get("TD_bound", 20)            # dsac_v1.py:78
         self.bound = bool(cfg.get("bound", True))          # dsac_v1.py:81
 
+    # ---- the approximators (overridden by the CNN variant, oracle/dsac_v1_oracle_cnn.py) ---------------------------
+    def _new_q_params(self):
+        cfg = self.cfg
+        return _new_mlp_params([cfg["obs_dim"] + cfg["act_dim"]] + list(cfg["hidden"]) + [2])
+
+    def _new_pi_params(self):
+        cfg = self.cfg
+        return _new_mlp_params([cfg["obs_dim"]] + list(cfg["hidden"]) + [2 * cfg["act_dim"]])
+
+    def _pi(self, obs, params):
+        return policy_forward(obs, params, self.cfg)
+
+    def _q(self, obs, act, params):
+        return q_forward(obs, act, params, None, self.cfg.get("value_act", "gelu"))
+
+    def _names(self, n):
+        sub = "policy" if n.startswith("policy") else "q"
+        names = []
+        for j in range(len(self.p[n]) // 2):
+            names += ["%s.%s.%d.weight" % (n, sub, 2 * j), "%s.%s.%d.bias" % (n, sub, 2 * j)]
+        return names
+
     def state_dict(self):
         sd = OrderedDict()
         sd["log_alpha"] = self.log_alpha.detach().clone()         # direct parameters precede sub-modules
         for n in ("q", "q_target", "policy", "policy_target"):    # registration order, dsac_v1.py:26-33
-            is_pi = n.startswith("policy")
-            if is_pi:
+            if n.startswith("policy"):
                 sd[n + ".act_high_lim"] = self.act_high.clone()
                 sd[n + ".act_low_lim"] = self.act_low.clone()
-            sub = "policy" if is_pi else "q"
-            ps = self.p[n]
-            for j in range(len(ps) // 2):
-                sd["%s.%s.%d.weight" % (n, sub, 2 * j)] = ps[2 * j].detach().clone()
-                sd["%s.%s.%d.bias" % (n, sub, 2 * j)] = ps[2 * j + 1].detach().clone()
+            for name, t in zip(self._names(n), self.p[n]):
+                sd[name] = t.detach().clone()
         return sd
 
     def load_state_dict(self, sd):
         with torch.no_grad():
             self.log_alpha.copy_(sd["log_alpha"])
             for n in self.NETS:
-                sub = "policy" if n.startswith("policy") else "q"
-                ps = self.p[n]
-                for j in range(len(ps) // 2):
-                    ps[2 * j].copy_(sd["%s.%s.%d.weight" % (n, sub, 2 * j)])
-                    ps[2 * j + 1].copy_(sd["%s.%s.%d.bias" % (n, sub, 2 * j)])
+                for name, t in zip(self._names(n), self.p[n]):
+                    t.copy_(sd[name])
 
     def _alpha(self):
         return self.log_alpha.exp().item() if self.cfg["auto_alpha"] else self.cfg["alpha"]
@@ -103,16 +118,16 @@ class DsacV1Oracle:
     def compute_gradient(self, data, noise):
         cfg = self.cfg
         obs, act, rew, obs2, done = data["obs"], data["act"], data["rew"], data["obs2"], data["done"]
-        logits = policy_forward(obs, self.p["policy"], cfg)
+        logits = self._pi(obs, self.p["policy"])
         policy_mean = torch.tanh(logits[..., 0]).mean().item()     # dsac_v1.py:145
         policy_std = logits[..., 1].mean().item()                   # dsac_v1.py:146
         new_act, new_log_prob = tanh_gauss_rsample(logits, noise["eps_new"], self.act_high, self.act_low)
         self.opt["q"].zero_grad()
         # ---- __compute_loss_q ----
-        logits_2 = policy_forward(obs2, self.p["policy_target"], cfg)
+        logits_2 = self._pi(obs2, self.p["policy_target"])
         act2, log_prob_act2 = tanh_gauss_rsample(logits_2, noise["eps_2"], self.act_high, self.act_low)
-        q, q_std = q_forward(obs, act, self.p["q"], None, cfg.get("value_act", "gelu"))
-        qn_mean, qn_std = q_forward(obs2, act2, self.p["q_target"], None, cfg.get("value_act", "gelu"))
+        q, q_std = self._q(obs, act, self.p["q"])
+        qn_mean, qn_std = self._q(obs2, act2, self.p["q_target"])
         q_next_sample = qn_mean + torch.mul(torch.clamp(noise["z_t"], -3, 3), qn_std)
         alpha = self._alpha()
         target_q = rew + (1 - done) * cfg["gamma"] * (q_next_sample.detach() - alpha * log_prob_act2.detach())
@@ -131,7 +146,7 @@ class DsacV1Oracle:
         for t in self.p["q"]:
             t.requires_grad_(False)
         self.opt["policy"].zero_grad()
-        q_pi, _ = q_forward(obs, new_act, self.p["q"], None, cfg.get("value_act", "gelu"))
+        q_pi, _ = self._q(obs, new_act, self.p["q"])
         loss_policy = (alpha * new_log_prob - q_pi).mean()
         entropy = -new_log_prob.detach().mean()
         loss_policy.backward()
