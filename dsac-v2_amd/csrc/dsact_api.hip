@@ -3315,9 +3315,9 @@ static int plan_updates_pipe(dsact_handle* h, int n, int phase, PipePlan& plan, 
   plan.defer.assign((size_t)n, 0); plan.bp.resize((size_t)n); plan.bp_rg.assign((size_t)n, 2);
   // the discarded policy backward can move when it is the merged launch's (chain + its own tiles behind the arrival counter)
   const int rg_pi = h->env_chain_rg_pi ? h->env_chain_rg_pi : h->env_chain_rg ? h->env_chain_rg : (h->B >= 8 ? h->cRG : 1);
-  // (data parallel: every rank's policy gradient is part of the all-reduced arena -- nothing is deferred)
-  const bool can_defer = h->pi_merge && h->dw_chunks == 1 && !h->fat_bwd && h->env_ride_slots == 0 && rg_pi <= 2 && !h->env_no_pipe_defer &&
-                         !(flags & DSACT_F_DATA_PARALLEL);
+  // (data parallel: the same -- on those updates k_adam_pack leaves the policy alone, so the policy segment of the all-reduced
+  //  arena is read by nobody; the deferred tiles store nothing and that segment simply keeps its previous content)
+  const bool can_defer = h->pi_merge && h->dw_chunks == 1 && !h->fat_bwd && h->env_ride_slots == 0 && rg_pi <= 2 && !h->env_no_pipe_defer;
   plan.dp = (flags & DSACT_F_DATA_PARALLEL) != 0;
   bool pre = false;
   int rc = DSACT_OK;
@@ -3330,8 +3330,9 @@ static int plan_updates_pipe(dsact_handle* h, int n, int phase, PipePlan& plan, 
       apply_pipe_set(h, set_of(s - 1));   // the deferred backward works on the PREVIOUS update's minibatch
       BwdPiArgs& a = plan.bp[(size_t)s];
       // (the deferred chain shares its launch with forward chains, not with ~500 riding tiles: 4-row slices by default)
-      bwd_pi_args(h, h->dw2_off[2], h->dw2_off[2], true, a, plan.bp_rg[(size_t)s], true, h->env_pipe_bp_rg);
+      bwd_pi_args(h, h->dw2_off[2], h->dw2_off[2], !plan.dp, a, plan.bp_rg[(size_t)s], true, h->env_pipe_bp_rg);
       a.finalize = 0;                     // that update was closed by its own last launch
+      a.dw.store_g = 0;                   // nothing reads this gradient (fused: no optimiser step on that update either)
       bp = &a;
     }
     rc = pipe_fwd_build(h, set_of(s), set_of(s + 1), pre, do_pre, plan.host[(size_t)s], bp);
@@ -3388,7 +3389,9 @@ static int enqueue_updates_pipe(dsact_handle* h, int n, const PipePlan& plan, Pi
     }
     ride.bookkeeping = 1;
     if (plan.dp) {
+      h->pipe_defer_now = plan.defer[(size_t)s] != 0;
       rc = enqueue_grads(h, true, false, 2, &ride);
+      h->pipe_defer_now = false;
       if (rc == DSACT_OK) rc = enqueue_allreduce(h, h->grads, h->n_online + 2, kNcclAvg);
       if (rc == DSACT_OK) rc = h->env_no_adam_pack ? enqueue_adam(h) : enqueue_adam_pack(h);
       if (rc == DSACT_OK && h->env_no_adam_pack) rc = enqueue_pack(h, true);
@@ -3422,7 +3425,7 @@ static bool pipe_eligible(const dsact_handle* h, int steps_per_graph, uint32_t f
   const int D = h->cfg.delay_update;
   const bool merged = !h->cnn && h->use_w1p && h->dw_chunks == 1 && !h->use_fork && !h->use_std_sums && h->alt_ws != nullptr &&
                       !h->env_no_merged_gather;
-  // (data parallel: the forward pipelining only -- replicas hold identical policies, which change on the same iterations)
+  // (data parallel too: replicas hold identical policies, which change on the same iterations)
   return merged && h->chain_ok && !h->fat && h->fwd_merge && h->B % 4 == 0 && h->rng_seed != 0 &&
          !(flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) && (!(flags & DSACT_F_DATA_PARALLEL) || h->comm != nullptr) && D >= 2 &&
          D <= dsact_handle::kPipePhases && steps_per_graph >= 2 && !h->env_no_pipe;
