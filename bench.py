@@ -682,7 +682,7 @@ def chain_flops(lay, batch):
     return {k: 2.0 * v * batch for k, v in per_row.items()}
 
 
-PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json")
+PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
 
 
 def pmc_traffic(kernel_substr, pick="max"):
