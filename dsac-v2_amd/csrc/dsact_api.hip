@@ -3464,7 +3464,14 @@ int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) 
     rc = alloc_pipe_sets(h);
     for (int ph = 0; ph < D && rc == DSACT_OK; ++ph) rc = capture_updates_pipe(h, steps_per_graph, ph, &h->pgraph[ph], &h->pexec[ph], &h->pargs[ph], flags);
     h->pipe_graph = rc == DSACT_OK;
-  } else {
+    if (rc != DSACT_OK) {   // (e.g. out of memory for the extra minibatch sets): the plain graph serves the same contract
+      drop_graphs(h);
+      (void)hipGetLastError();
+      if (h->pipe_ws) apply_pipe_set(h, 0);   // (set 0 = the workspace's own buffers, recorded once the extra sets exist)
+      rc = DSACT_OK;
+    }
+  }
+  if (!h->pipe_graph) {
     rc = capture_updates(h, steps_per_graph, flags, merged, &h->graph, &h->graph_exec);
   }
   h->profiling = was_prof;
