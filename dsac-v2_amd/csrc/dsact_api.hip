@@ -251,7 +251,15 @@ struct dsact_handle {
   bool fwd_merge = false;               // launches A and B as one (batch <= 256)
   bool pi_merge = false;                // the policy's weight-gradient tiles + the closing block inside the policy-backward launch (batch <= 512; measured equal-to-slower at 1024)
   float* zobs[4];                       // first-layer accumulators after the observation part: q1, q2 (obs), q1_t, q2_t (obs2)
-  float* dAq[2];                        // dL/d new_act through q1 / q2  [B][32]
+  float* dAq[4];                        // dL/d new_act through q1 / q2  [B][32] (twin trunks: [2 + i] = the log_std trunks' share)
+  // twin-trunk nets on the chains (CNN approximators: mean / log_std MLPs over one conv feature row, networks/cnn.py:214-240,
+  // 437-461): each trunk is a chain unit of its own over its half of the twin-width buffers (activation packs: features
+  // [t*H, (t+1)*H) = floats t*H*B onward; weight packs: tiles / chunks of the trunk's rows / columns)
+  bool twin = false;
+  float* X0t_net[3] = {nullptr, nullptr, nullptr};   // every net has its own input rows (features): transposed packs for q1, q2, policy
+  float* dz0row[3] = {nullptr, nullptr, nullptr};    // row-major dZ[0] of q1c, q2c, pi [B][w[0]]: operand of the dL/d features product
+  PipeFwd* d_fwdt[2] = {nullptr, nullptr};           // k_chain_fwdt tables (group A, group B), built by dsact_bind_arenas
+  PipeFwd* fwdt_host[2] = {nullptr, nullptr};
   float* doutT[3];                      // transposed packs of dL/d(out): q1, q2 [32 x B], policy [roundup32(2A) x B]
   float* X0t = nullptr;                 // transposed pack of the staged minibatch [roundup32(F+A) x B]
   int dw2_off[4] = {0, 0, 0, 0};        // tile ranges of q1, q2, policy in the dw2 problem list
@@ -517,10 +525,15 @@ void carve(dsact_handle* h, Carver& c) {
   h->dw_parts = c.take<float>(h->dw_chunks > 1 ? (size_t)h->dw_chunks * h->dw_part_stride : 4);
   for (int i = 0; i < 4; ++i) h->zobs[i] = c.take<float>(B * h->w[0]);
   h->chain_flags = c.take<int>(kChainFlagInts);   // [unit 0..5][slice] ready flags of the merged forward launch, then the spin-timeout word
-  for (int i = 0; i < 2; ++i) h->dAq[i] = c.take<float>(B * 32);
+  for (int i = 0; i < 4; ++i) h->dAq[i] = c.take<float>(B * 32);
   for (int i = 0; i < 2; ++i) h->doutT[i] = c.take<float>(B * 32);
   h->doutT[2] = c.take<float>(B * (size_t)((2 * A + 31) / 32 * 32));
   h->X0t = c.take<float>(B * (size_t)((h->F + A + 31) / 32 * 32));
+  if (h->twin) {
+    h->X0t_net[0] = h->X0t;
+    for (int i = 1; i < 3; ++i) h->X0t_net[i] = c.take<float>(B * (size_t)((h->F + A + 31) / 32 * 32));
+    for (int i = 0; i < 3; ++i) h->dz0row[i] = c.take<float>(B * h->w[0]);
+  }
   h->act_scale = c.take<float>(A);
   h->act_center = c.take<float>(A);
   h->idx_eager = c.take<int>(B);
@@ -638,27 +651,35 @@ int build_chain(dsact_handle* h) {
   const int tpad = fat ? 0 : h->env_pk_pad;   // style-44 forward packs: padding steps behind every tile (DSACT_PK_PAD)
   const int C0q = fat ? h->c_obs + h->c_act : h->s_obs + h->s_act + tpad, C0p = fat ? h->c_obs : h->s_obs + tpad;
   const int nth_q = 1, nth_p = (2 * A + 15) / 16, nta = (A + 15) / 16;
+  // twin trunks (nb = 2): a net's first layer is the dense [2W x in] matrix = 2 x tiles row tiles (trunk t: the second half);
+  // hidden layers are two [W x W] blocks with a pack each (trunk t: t * tiles * steps * 256 floats further); the output layer
+  // is the dense [n_out x 2W] matrix: 2 x CH chunks per 16-row tile (trunk t: chunks [t*CH, (t+1)*CH)); its transpose (policy)
+  // has 2 x tiles row tiles; (W0[:, F:])^T is [A x 2W]: 2 x CH chunks per tile
+  const int nb = h->twin ? 2 : 1;
   // carve the packed copies
   for (int pass = 0; pass < 2; ++pass) {
     Carver c;
     c.base = pass ? h->pk_ws : nullptr;
     for (int net = 0; net < N_NET; ++net) {
       const bool pol = net == N_POL || net == N_POLT;
-      h->pk_fwd[net][0] = c.take<float>((size_t)tiles_f * (pol ? C0p : C0q) * 256);
-      for (int l = 1; l < L; ++l) h->pk_fwd[net][l] = c.take<float>((size_t)tiles_f * S_hid * 256);
-      h->pk_fwd[net][L] = c.take<float>((size_t)(pol ? nth_p : nth_q) * CH * 256);
+      h->pk_fwd[net][0] = c.take<float>((size_t)nb * tiles_f * (pol ? C0p : C0q) * 256);
+      for (int l = 1; l < L; ++l) h->pk_fwd[net][l] = c.take<float>((size_t)nb * tiles_f * S_hid * 256);
+      h->pk_fwd[net][L] = c.take<float>((size_t)(pol ? nth_p : nth_q) * nb * CH * 256);
     }
     for (int n3 = 0; n3 < 3; ++n3) {
       for (int l = 0; l <= L; ++l) h->pk_bwd[n3][l] = nullptr;
-      for (int l = 1; l < L; ++l) h->pk_bwd[n3][l] = c.take<float>((size_t)tiles_b * S_hidb * 256);
+      for (int l = 1; l < L; ++l) h->pk_bwd[n3][l] = c.take<float>((size_t)nb * tiles_b * S_hidb * 256);
     }
-    h->pk_bwd[2][L] = c.take<float>((size_t)tiles_b * S_out * 256);
-    for (int i = 0; i < 2; ++i) h->pk_w1at[i] = c.take<float>((size_t)nta * CH * 256);
+    h->pk_bwd[2][L] = c.take<float>((size_t)nb * tiles_b * S_out * 256);
+    for (int i = 0; i < 2; ++i) h->pk_w1at[i] = c.take<float>((size_t)nta * nb * CH * 256);
     if (!pass) {
       HIPCHK(h, hipMalloc((void**)&h->pk_ws, c.off + 256));
       HIPCHK(h, hipMemset(h->pk_ws, 0, c.off + 256));   // the zero padding of every copy is written here, once
     }
   }
+  // twin trunks: the packed copies are rebuilt from the arenas at the start of every update (the pack blocks ride in the
+  // image gather; there is no replayed graph without that launch), so the weight-gradient tiles carry no mirror descriptors
+  if (h->twin) return DSACT_OK;
   // what the Adam tiles of (q1, q2, policy) x layer refresh
   const int on3[3] = {N_Q1, N_Q2, N_POL}, tg3[3] = {N_Q1T, N_Q2T, N_POLT};
   std::vector<MirrorDesc> mir((size_t)3 * (L + 1));
@@ -684,11 +705,46 @@ int build_chain(dsact_handle* h) {
 int build_pack_jobs(dsact_handle* h) {
   if (!h->chain_ok) return DSACT_OK;
   const int L = h->L;
-  std::vector<MirrorDesc> mir((size_t)3 * (L + 1));
-  HIPCHK(h, hipMemcpy(mir.data(), h->d_mir, mir.size() * sizeof(MirrorDesc), hipMemcpyDeviceToHost));
   std::vector<PackJob> jobs;
   int blocks = 0;
-  for (int net = 0; net < N_NET; ++net) {
+  if (h->twin) {
+    // one job per contiguous row-major matrix of the arena: first layer (dense), hidden layer x trunk, output layer (dense)
+    const int W = h->cW, tiles = W / 64, SH = W / 4, CH = W / 16;
+    for (int net = 0; net < N_NET; ++net) {
+      if (h->nq == 1 && (net == N_Q2 || net == N_Q2T)) continue;   // one critic (DSAC_V1)
+      const NetDesc& d = net_desc(h, net);
+      const bool target = net >= N_Q1T, pol = net == N_POL || net == N_POLT;
+      const int n3 = net % 3;
+      for (int l = 0; l <= L; ++l)
+        for (int t = 0; t < ((l >= 1 && l < L) ? 2 : 1); ++t) {
+          PackJob j;
+          memset(&j, 0, sizeof(j));
+          MirrorDesc& m = j.m;
+          m.F = 1 << 30; m.Fp = 4 * h->s_obs;
+          if (l == 0) {
+            j.src = net_params(h, net) + d.w_off[0]; j.N = d.out[0]; j.K = d.in[0];
+            m.fwd = h->pk_fwd[net][0]; m.fwd_44 = 1; m.fwd_C = pol ? h->s_obs : h->s_obs + h->s_act;
+            if (!pol) m.F = h->F;
+            if (!pol && !target) { m.bwd = h->pk_w1at[n3]; m.bwd_44 = 0; m.bwd_C = 2 * CH; m.bwd_k0 = h->F; }
+          } else if (l < L) {
+            j.src = net_params(h, net) + d.w_off[l] + (size_t)t * W * W; j.N = W; j.K = W;
+            m.fwd = h->pk_fwd[net][l] + (size_t)t * tiles * SH * 256; m.fwd_44 = 1; m.fwd_C = SH;
+            if (!target) { m.bwd = h->pk_bwd[n3][l] + (size_t)t * tiles * SH * 256; m.bwd_44 = 1; m.bwd_C = SH; m.bwd_k0 = 0; }
+          } else {
+            j.src = net_params(h, net) + d.w_off[L]; j.N = d.out[L]; j.K = d.in[L];
+            m.fwd = h->pk_fwd[net][L]; m.fwd_44 = 0; m.fwd_C = 2 * CH;
+            if (pol && !target) { m.bwd = h->pk_bwd[2][L]; m.bwd_44 = 1; m.bwd_C = h->SoT; m.bwd_k0 = 0; }
+          }
+          j.is_target = target ? 1 : 0;
+          blocks += (j.N + 15) / 16;
+          j.block_end = blocks;
+          jobs.push_back(j);
+        }
+    }
+  }
+  std::vector<MirrorDesc> mir((size_t)3 * (L + 1));
+  if (!h->twin) HIPCHK(h, hipMemcpy(mir.data(), h->d_mir, mir.size() * sizeof(MirrorDesc), hipMemcpyDeviceToHost));
+  for (int net = 0; net < N_NET && !h->twin; ++net) {
     if (h->nq == 1 && (net == N_Q2 || net == N_Q2T)) continue;   // one critic (DSAC_V1)
     const NetDesc& d = net_desc(h, net);
     const bool target = net >= N_Q1T;
@@ -842,7 +898,10 @@ int build_tasks(dsact_handle* h) {
       GemmProb t;
       memset(&t, 0, sizeof(t));
       t.P = h->dZ[kDzSlot[ch]][0]; t.ldp = d.out[0];
-      if (ch == C_PI) { t.Q = net_params(h, net) + d.w_off[0]; t.ldq = d.in[0]; }
+      // chain mode: dZ[0] is a transposed pack; the backward chains also leave it row-major (dz0row), and the product reads
+      // the arena's W0 -- it runs before the launch whose tiles update that net
+      if (h->twin) { t.P = h->dz0row[ch == C_PI ? 2 : ch - C_Q1C]; t.Q = net_params(h, net) + d.w_off[0]; t.ldq = d.in[0]; }
+      else if (ch == C_PI) { t.Q = net_params(h, net) + d.w_off[0]; t.ldq = d.in[0]; }
       else if (h->use_w1p) { t.Q = h->W1p[ch == C_Q1C ? 0 : 1]; t.ldq = h->ldx; }  // this step's pre-update copy
       else { t.Q = net_params(h, net) + d.w_off[0]; t.ldq = d.in[0]; }              // (dfeat_q runs before the critics' update)
       t.C0 = h->dfeat[ch == C_PI ? h->nq : ch - C_Q1C]; t.ldc = h->F;   // (stack numbering: q x nq, then the policy)
@@ -1445,6 +1504,28 @@ Dw2Args dw2_args(dsact_handle* h, bool fused) {
     const int ch = chs[n3], net = kChainNet[ch], slot = kDzSlot[ch];
     const NetDesc& d = net_desc(h, net);
     const long long base = (long long)(net_grads(h, net) - h->grads);
+    if (h->twin) {
+      // first layer: dense [2W x in] (both trunks' dZ[0] are one pack of 2W features); hidden layers: one [W x W] problem per
+      // trunk; output layer: the dense [n_out x 2W] matrix with its two structurally-zero blocks masked (DwProb::nsplit)
+      const int W = h->cW;
+      const size_t tB = (size_t)W * h->B;   // floats between the trunks' halves of an activation pack
+      for (int l = 0; l <= L; ++l)
+        for (int t = 0; t < ((l >= 1 && l < L) ? 2 : 1); ++t) {
+          DwProb& P = a.p[a.n_prob++];
+          const bool hid = l >= 1 && l < L;
+          P.At = l < L ? h->dZ[slot][l] + (hid ? t * tB : 0) : h->doutT[n3];
+          P.Xt = l == 0 ? h->X0t_net[n3] : h->Hb[ch][l - 1] + (hid ? t * tB : 0);
+          P.M = hid ? W : d.out[l]; P.N = hid ? W : d.in[l];
+          P.w_idx = base + (long long)d.w_off[l] + (hid ? (long long)t * W * W : 0);
+          P.b_idx = base + (long long)d.b_off[l] + (hid ? (long long)t * W : 0);
+          if (l == L) { P.msplit = d.out[L] / 2; P.nsplit = W; }
+          P.tiles_n = (P.N + 31) / 32;
+          tiles += ((P.M + 31) / 32) * P.tiles_n;
+          P.tile_end = tiles;
+          P.mir = nullptr;
+        }
+      continue;
+    }
     for (int l = 0; l <= L; ++l) {
       DwProb& P = a.p[a.n_prob++];
       P.At = l < L ? h->dZ[slot][l] : h->doutT[n3];
@@ -1580,6 +1661,122 @@ void fwd_args_b(dsact_handle* h, FwdArgs& a) {
     qp.zinit = h->zobs[i]; qp.qout = h->qout_p[i];
   }
   a.n_units = 2 * nq;
+}
+
+// ---- twin-trunk nets (CNN approximators): forward launches from device-memory tables (k_chain_fwdt) -----------------
+// unit of trunk t of chain ch: the trunk's half of every twin-width buffer (see dsact_handle::twin)
+FwdUnit fwd_unit_twin(const dsact_handle* h, int ch, int t, int head_kind) {
+  FwdUnit u;
+  memset(&u, 0, sizeof(u));
+  const int net = kChainNet[ch], L = h->L, W = h->cW, tiles = W / 64, SH = W / 4, CH = W / 16;
+  const bool pol = net == N_POL || net == N_POLT;
+  const NetDesc& d = net_desc(h, net);
+  const float* base = net_params(h, net);
+  const int S0 = h->s_obs + (pol ? 0 : h->s_act);
+  u.wf[0] = h->pk_fwd[net][0] + (size_t)t * tiles * S0 * 256;
+  for (int l = 1; l < L; ++l) u.wf[l] = h->pk_fwd[net][l] + (size_t)t * tiles * SH * 256;
+  u.wf[L] = h->pk_fwd[net][L] + (size_t)t * CH * 256;
+  for (int l = 0; l < L; ++l) u.bias[l] = base + d.b_off[l] + (size_t)t * W;
+  u.bias[L] = base + d.b_off[L];
+  u.x = h->Xc[ch];
+  u.seg = SEG_FULL;
+  u.s_act = pol ? 0 : h->s_act;
+  for (int l = 0; l < L; ++l) { u.H[l] = h->Hb[ch][l] + (size_t)t * W * h->B; u.G[l] = h->Gb[ch][l] + (size_t)t * W * h->B; }
+  u.head = head_code(head_kind, t == 0 ? HEAD_TWIN_FIRST : HEAD_TWIN_SECOND, 2 * CH);
+  u.act = (short)net_act(h, net);
+  return u;
+}
+
+// group 0: policy(obs), policy_target(obs2), q_c(obs, act) x nq; group 1: q_t(obs2, act2) x nq, q(obs, new_act) x nq
+int build_twin_fwd(dsact_handle* h) {
+  const int nq = h->nq, L = h->L;
+  for (int grp = 0; grp < 2; ++grp) {
+    if (!h->fwdt_host[grp]) h->fwdt_host[grp] = new PipeFwd;
+    if (!h->d_fwdt[grp]) HIPCHK(h, hipMalloc((void**)&h->d_fwdt[grp], sizeof(PipeFwd)));
+    PipeFwd& P = *h->fwdt_host[grp];
+    memset(&P, 0, sizeof(P));
+    int n_nets = 0;
+    auto add = [&](int ch, int kind) {
+      for (int t = 0; t < 2; ++t) P.u[2 * n_nets + t] = fwd_unit_twin(h, ch, t, kind);
+      return &P.u[2 * n_nets++];
+    };
+    if (grp == 0) {
+      FwdUnit* pi = add(C_PI, HEAD_POLICY);
+      for (int t = 0; t < 2; ++t) {
+        pi[t].logits = h->logits_pi; pi[t].logp = h->logp_new; pi[t].eps = h->eps_new;
+        pi[t].xact = h->Xc[C_Q1P]; pi[t].xact2 = nq == 2 ? h->Xc[C_Q2P] : nullptr;
+      }
+      pi[1].part_heads = h->part_heads;
+      pi[0].x0t = h->X0t_net[2];
+      FwdUnit* pt = add(C_PIT, HEAD_POLICY);
+      for (int t = 0; t < 2; ++t) {
+        pt[t].logits = h->logits_pit; pt[t].logp = h->logp2; pt[t].eps = h->eps_2;
+        pt[t].xact = h->Xc[C_Q1T]; pt[t].xact2 = nq == 2 ? h->Xc[C_Q2T] : nullptr;
+        for (int l = 0; l < L; ++l) pt[t].G[l] = nullptr;   // never differentiated
+      }
+      for (int i = 0; i < nq; ++i) {
+        FwdUnit* qc = add(C_Q1C + i, HEAD_Q);
+        for (int t = 0; t < 2; ++t) { qc[t].qout = h->qout_c[i]; qc[t].qstd = h->qstd_c[i]; }
+        qc[0].x0t = h->X0t_net[i];
+      }
+    } else {
+      for (int i = 0; i < nq; ++i) {
+        FwdUnit* qt = add(C_Q1T + i, HEAD_Q);
+        for (int t = 0; t < 2; ++t) {
+          qt[t].qout = h->qout_t[i];
+          for (int l = 0; l < L; ++l) qt[t].G[l] = nullptr;   // never differentiated
+        }
+      }
+      for (int i = 0; i < nq; ++i) {
+        FwdUnit* qp = add(C_Q1P + i, HEAD_Q);
+        for (int t = 0; t < 2; ++t) qp[t].qout = h->qout_p[i];
+      }
+    }
+    const char* name = grp == 0 ? "chain_fwd_a" : "chain_fwd_b";
+    const int rg = chain_rg(h, n_nets);
+    FwdArgs& c = P.c;
+    c.n_units = 2 * n_nets;
+    for (int k = 0; k < c.n_units; ++k) { P.u[k].rg = (short)rg; P.u[k].n_slices = (short)(h->B / (4 * rg)); }
+    c.B = h->B; c.F = h->F; c.A = h->A; c.L = L; c.ldx = h->ldx;
+    c.s_obs = h->s_obs; c.s_act = h->s_act; c.v1_stats = nq == 1; c.Cb = h->B / 16;
+    c.act_scale = h->act_scale; c.act_center = h->act_center; c.lo_ls = h->cfg.min_log_std; c.hi_ls = h->cfg.max_log_std;
+    c.timeline = tl_for(h, name);
+    c.spin_timeout = h->handoff_dev;
+    // block -> (net, slice): the slices of a net on the same XCD(s) like xcd_map_uniform
+    const XcdMap map = xcd_map_uniform(n_nets);
+    const int n_slices = h->B / (4 * rg);
+    int rounds = 0;
+    for (int x = 0; x < 8; ++x) {
+      if (map.unit[x] < 0) continue;
+      const int n = n_slices - map.base[x];
+      const int r = n > 0 ? (n + map.stride[x] - 1) / map.stride[x] : 0;
+      rounds = r > rounds ? r : rounds;
+    }
+    P.n_blocks = 8 * rounds;
+    if (P.n_blocks > kPipeMaxBlocks) return fail(h, DSACT_E_INVALID, "twin forward table: %d blocks exceed %d", P.n_blocks, kPipeMaxBlocks);
+    for (int b = 0; b < P.n_blocks; ++b) {
+      const int x = b & 7, unit = map.unit[x];
+      const int slice = unit < 0 ? -1 : map.base[x] + map.stride[x] * (b >> 3);
+      P.blk[b] = (unit >= 0 && slice < n_slices) ? (((2 * unit) << 16) | slice) : -1;
+    }
+    HIPCHK(h, hipMemcpy(h->d_fwdt[grp], &P, sizeof(PipeFwd), hipMemcpyHostToDevice));
+  }
+  return DSACT_OK;
+}
+
+int enqueue_chain_fwd_twin(dsact_handle* h, int grp) {
+  const PipeFwd& P = *h->fwdt_host[grp];
+  const int rg = P.u[0].rg;
+  const size_t lds = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 4 * rg).total * sizeof(float);
+  if (grp == 0) h->n_heads_parts = h->B / 4;   // one partial per four rows whatever the rows per workgroup (chain_fwd_body)
+  const char* name = grp == 0 ? "chain_fwd_a" : "chain_fwd_b";
+  const PipeFwd* dev = h->d_fwdt[grp];
+#define CALL_FT(N) return generic_act(h) ? launch(h, name, k_chain_fwdt<N, true>, dim3(P.n_blocks), dim3(64 * N), lds, dev) \
+                                         : launch(h, name, k_chain_fwdt<N>, dim3(P.n_blocks), dim3(64 * N), lds, dev)
+  if (h->cNT == 1) CALL_FT(1);
+  if (h->cNT == 2) CALL_FT(2);
+  CALL_FT(4);
+#undef CALL_FT
 }
 
 // fat mode: 32-row workgroups when even those fill the chip twice over, else 16-row ones
@@ -1981,6 +2178,27 @@ void bwd_q_args(dsact_handle* h, int n_units, const RideArgs* ride, BwdQArgs& a,
     if (which >= 2) { u.w1at = h->pk_w1at[n3]; u.dA = h->dAq[n3]; }
     u.which = which;
   }
+  if (h->twin) {
+    // every chain becomes two trunk units (mean, log_std) over their halves of the twin-width buffers
+    const int W = h->cW, tiles = W / 64, SH = W / 4, CH = W / 16;
+    const size_t tB = (size_t)W * h->B;
+    for (int w = n_units - 1; w >= 0; --w) {
+      const BwdQUnit src = a.u[w];
+      const int which = src.which, n3 = (which & 1);
+      for (int t = 1; t >= 0; --t) {
+        BwdQUnit& u = a.u[2 * w + t];
+        u = src;
+        for (int l = 1; l < L; ++l) u.wb[l] = src.wb[l] + (size_t)t * tiles * SH * 256;
+        u.wout = src.wout + (size_t)t * W;
+        for (int l = 0; l < L; ++l) { u.G[l] = src.G[l] + t * tB; u.dZ[l] = src.dZ[l] + t * tB; }
+        if (which >= 2) { u.w1at = src.w1at + (size_t)t * CH * 256; u.dA = h->dAq[n3 + 2 * t]; }
+        else u.dz0row = h->dz0row[n3] + (size_t)t * W;
+        u.trunk = t;
+      }
+    }
+    n_units *= 2;
+    a.ldo = 2 * W; a.c1at = 2 * CH; a.ldz0 = h->w[0];
+  }
   a.v1 = h->nq == 1; a.td_bound = h->cfg.td_bound; a.v1_bound = h->cfg.v1_unbounded ? 0 : 1;
   const int rg = h->fat_bwd ? 4 * fat_rt(h, n_units) : chain_rg(h, n_units, true);
   a.n_units = n_units; a.n_slices = h->B / (4 * rg); a.B = h->B; a.A = h->A; a.L = L; a.Cb = h->B / 16;
@@ -2044,6 +2262,18 @@ void bwd_pi_args(dsact_handle* h, int x0, int x1, bool fused, BwdPiArgs& a, int&
   a.part_loss = h->part_loss; a.n_part = h->B; a.target_entropy = -(float)h->A;
   a.grad_log_alpha = h->grads + h->n_online - 1;
   a.n_chain_blocks = roundup(a.n_slices, 8);   // the riders' first block lands on XCD 0 (xcd_chunk)
+  a.n_trunks = 1;
+  if (h->twin) {
+    const int W = h->cW, tiles = W / 64, SH = W / 4;
+    const size_t tB = (size_t)W * h->B;
+    a.n_trunks = 2;
+    a.woutT1 = a.woutT + (size_t)tiles * a.SoT * 256;
+    for (int l = 1; l < L; ++l) a.wb1[l] = a.wb[l] + (size_t)tiles * SH * 256;
+    for (int l = 0; l < L; ++l) { a.G1[l] = a.G[l] + tB; a.dZ1[l] = a.dZ[l] + tB; }
+    a.dA2[0] = h->dAq[2]; a.dA2[1] = h->dAq[3];
+    a.dz0row = h->dz0row[2]; a.ldz0 = h->w[0];
+    a.n_chain_blocks *= 2;
+  }
   a.timeline = tl_for(h, "chain_bwd_pi");
   a.dw = dw2_args(h, fused);
   a.tile0 = x0; a.n_extra = x1 > x0 ? x1 - x0 : 0;
@@ -2102,7 +2332,11 @@ int enqueue_grads_chain(dsact_handle* h, bool actor_backward, bool fused, int ph
   const int* off = h->dw2_off;
   if (phase == 4) goto actor_part;
   if (phase != 2) {
-    if (h->fwd_merge) {
+    if (h->cnn) TRY(enqueue_conv_forward(h));
+    if (h->twin) {
+      TRY(enqueue_chain_fwd_twin(h, 0));
+      TRY(enqueue_chain_fwd_twin(h, 1));
+    } else if (h->fwd_merge) {
       TRY(enqueue_chain_fwd_merged(h));
     } else {
       TRY(enqueue_chain_fwd_a(h));
@@ -2116,20 +2350,30 @@ int enqueue_grads_chain(dsact_handle* h, bool actor_backward, bool fused, int ph
   }
   if (phase == 1) return DSACT_OK;
   TRY(enqueue_chain_bwd_q(h, (actor_backward ? 2 : 1) * h->nq, ride));
+  // CNN nets (batch <= 1024: one gradient arena): dL/d features = dZ0 . W0[:, :F] right behind the chains that produce dZ0 and
+  // before the launch whose tiles update W0; the conv stacks' backward follows the MLP part (enqueue_grads' order)
+  if (h->cnn) TRY(run_stage(h, h->dfeat_q));
   if (!actor_backward) {
-    if (h->dw_chunks == 1) return run_dw2(h, off[0], off[2], fused, fused);
+    if (h->dw_chunks == 1) {
+      TRY(run_dw2(h, off[0], off[2], fused, fused));
+      if (h->cnn) TRY(enqueue_conv_backward(h, h->nq, fused));
+      return DSACT_OK;
+    }
     TRY(run_dw2(h, off[0], off[2], false, false));
     if (fused) return enqueue_adam(h, true);
     return sum_parts(h, 0, (size_t)h->nq * h->n_q);
   }
   if (phase == 3) {
     TRY(run_dw2(h, off[0], off[2], false, false));
+    if (h->cnn) TRY(enqueue_conv_backward(h, h->nq, false));
     return sum_parts(h, 0, (size_t)h->nq * h->n_q);
   }
 actor_part:
   if (phase == 4) {
     TRY(enqueue_chain_bwd_pi(h, 0, 0, false));
+    if (h->cnn) TRY(run_stage(h, h->dfeat_pi));
     TRY(run_dw2(h, h->dw2_off[2], h->dw2_off[3], false, false));
+    if (h->cnn) TRY(enqueue_conv_backward(h, 1, false, h->nq));
     return sum_parts(h, (size_t)h->nq * h->n_q, h->n_online - 1);
   }
   // the critics' dW (+ Adam) tiles ride in the policy-backward launch on the CUs its 32 chain workgroups leave idle
@@ -2143,7 +2387,12 @@ actor_part:
       return enqueue_chain_bwd_pi(h, h->dw2_off[0], ride_end, fused, true);
     }
     TRY(enqueue_chain_bwd_pi(h, h->dw2_off[0], ride_end, fused));
-    if (h->dw_chunks == 1) return run_dw2(h, ride_end, h->dw2_off[3], fused, fused);
+    if (h->cnn) TRY(run_stage(h, h->dfeat_pi));   // needs the policy's W0 BEFORE the fused Adam of the next launch
+    if (h->dw_chunks == 1) {
+      TRY(run_dw2(h, ride_end, h->dw2_off[3], fused, fused));
+      if (h->cnn) TRY(enqueue_conv_backward(h, h->nq + 1, fused));
+      return DSACT_OK;
+    }
     TRY(run_dw2(h, ride_end, h->dw2_off[3], false, false));
   }
   if (fused) return enqueue_adam(h, true);
@@ -2574,8 +2823,10 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   {
     // row-slice fused chains: MLP nets of DSAC_V2 with equal hidden widths of 64 / 128 / 256, batch a multiple of 16
     const int R = 4 * h->cRG;
-    bool ok = !h->cnn && h->B % R == 0 && h->B % 16 == 0 && (h->B <= 256 || h->B % 256 == 0) && h->F % 4 == 0 &&
-              getenv("DSACT_NO_CHAIN") == nullptr && !(h->nq == 1 && getenv("DSACT_NO_CHAIN_V1") != nullptr);
+    // (CNN nets: the twin MLP trunks over the conv features run as chain units -- DSACT_NO_CHAIN_CNN keeps them on the tile path)
+    bool ok = h->B % R == 0 && h->B % 16 == 0 && (h->B <= 256 || h->B % 256 == 0) && h->F % 4 == 0 &&
+              getenv("DSACT_NO_CHAIN") == nullptr && !(h->nq == 1 && getenv("DSACT_NO_CHAIN_V1") != nullptr) &&
+              !(h->cnn && (getenv("DSACT_NO_CHAIN_CNN") != nullptr || h->B > 1024));
     ok = ok && h->L <= kChMaxL;
     for (int l = 0; l < h->L; ++l) ok = ok && cfg->hidden[l] == cfg->hidden[0];
     const int W0 = cfg->hidden[0];
@@ -2586,6 +2837,8 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     // LDS: input slice + two hidden slices + partial tiles must fit beside nothing else (one workgroup per CU)
     ok = ok && (size_t)chain_lds(4 * (h->s_obs + h->s_act), W0, R).total * sizeof(float) <= 150 * 1024;
     h->chain_ok = ok;
+    h->twin = ok && h->cnn;
+    if (h->cnn) h->env_pk_pad = 0;
     if (ok) {
       // chain path: a weight-gradient tile contracts up to 1024 batch rows itself (rounds of 256, dw2_tile), so up to
       // batch 1024 there is ONE gradient arena and the optimiser stays fused into the tiles (no split-K partials, no
@@ -2604,12 +2857,12 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
       const char* fb = getenv("DSACT_FAT_BWD_MIN");
       const int fat_bwd_min = fb ? atoi(fb) : 4096;
       // (the throughput-regime kernels hold DSAC_V2's two-critic row phase: one critic keeps the 8-row chains at every batch)
-      h->fat = ok && h->nq == 2 && h->B >= fat_min && h->B % 32 == 0 && (W0 == 128 || W0 == 256) && getenv("DSACT_NO_FAT") == nullptr;
+      h->fat = ok && !h->cnn && h->nq == 2 && h->B >= fat_min && h->B % 32 == 0 && (W0 == 128 || W0 == 256) && getenv("DSACT_NO_FAT") == nullptr;
       h->fat_bwd = h->fat && h->B >= fat_bwd_min;
       if (const char* v = getenv("DSACT_FAT_RT")) h->env_fat_rt = atoi(v) == 2 ? 2 : 1;
     }
-    h->fwd_merge = ok && h->B <= 256 && h->B / 4 <= kChainFlagSlices && chain_rg(h, 4) == 1 && getenv("DSACT_NO_FWD_MERGE") == nullptr;
-    h->pi_merge = ok && h->B <= 512 && !h->fat_bwd && getenv("DSACT_NO_PI_MERGE") == nullptr;
+    h->fwd_merge = ok && !h->cnn && h->B <= 256 && h->B / 4 <= kChainFlagSlices && chain_rg(h, 4) == 1 && getenv("DSACT_NO_FWD_MERGE") == nullptr;
+    h->pi_merge = ok && !h->cnn && h->B <= 512 && !h->fat_bwd && getenv("DSACT_NO_PI_MERGE") == nullptr;
   }
   Carver c0;
   carve(h, c0);
@@ -2693,6 +2946,12 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdpb<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdpb<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdpb<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdt<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdt<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdt<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdt<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdt<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdt<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdp<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdp<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_fwdp<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
@@ -2773,6 +3032,7 @@ int dsact_destroy(dsact_handle* h) {
   if (h->alt_ws) hipFree(h->alt_ws);
   if (h->pipe_ws) hipFree(h->pipe_ws);
   if (h->pk_ws) hipFree(h->pk_ws);
+  for (int i = 0; i < 2; ++i) { if (h->d_fwdt[i]) hipFree(h->d_fwdt[i]); delete h->fwdt_host[i]; }
   if (h->d_mir) hipFree(h->d_mir);
   if (h->d_apjobs) hipFree(h->d_apjobs);
   if (h->d_pack) hipFree(h->d_pack);
@@ -2829,8 +3089,9 @@ int dsact_bind_arenas(dsact_handle* h, float* online, float* target, float* adam
   h->online = online; h->target = target; h->adam_m = adam_m; h->adam_v = adam_v; h->grads = grads;
   TRY(build_chain(h));
   TRY(build_pack_jobs(h));
-  if (h->chain_ok) TRY(build_adam_pack_jobs(h));
+  if (h->chain_ok && !h->twin) TRY(build_adam_pack_jobs(h));
   TRY(build_tasks(h));
+  if (h->twin) TRY(build_twin_fwd(h));
   if (h->chain_ok) (void)dw2_args(h, false);   // tile ranges of the dw2 problem list
   if (!h->cnn) {   // the same task lists over the second batch set
     TRY(alloc_alt_set(h));
@@ -3942,13 +4203,13 @@ int dsact_debug_set(dsact_handle* h, const char* name, double value) {
   if (!strcmp(name, "fwd_merge")) {   // A/B switch of the merged forward launch on a live handle (tests)
     HIPCHK(h, hipStreamSynchronize(h->stream));
     drop_graphs(h);
-    h->fwd_merge = value != 0.0 && h->chain_ok && h->B <= 256 && h->B / 4 <= kChainFlagSlices && chain_rg(h, 4) == 1;
+    h->fwd_merge = value != 0.0 && h->chain_ok && !h->cnn && h->B <= 256 && h->B / 4 <= kChainFlagSlices && chain_rg(h, 4) == 1;
     return DSACT_OK;
   }
   if (!strcmp(name, "pi_merge")) {    // same for the merged policy-backward / policy weight-gradient launch
     HIPCHK(h, hipStreamSynchronize(h->stream));
     drop_graphs(h);
-    h->pi_merge = value != 0.0 && h->chain_ok && h->B <= 512 && !h->fat_bwd;
+    h->pi_merge = value != 0.0 && h->chain_ok && !h->cnn && h->B <= 512 && !h->fat_bwd;
     if (h->chain_flags) HIPCHK(h, hipMemset(h->chain_flags, 0, kChainFlagInts * sizeof(int)));
     h->flags_dirty = false;
     return DSACT_OK;

@@ -195,7 +195,7 @@ inline XcdMap xcd_map_shares(int n_units, const int* share) {
 
 // LDS carve-up shared by the chain kernels (floats)
 struct ChainLds {
-  int ld_in, ld_h, off_in, off_h0, off_h1, off_red, off_sc, total;
+  int ld_in, ld_h, off_in, off_h0, off_h1, off_red, off_sc, off_carry, total;
 };
 __host__ __device__ inline ChainLds chain_lds(int k_in /*floats of the widest staged operand row*/, int W, int R) {
   ChainLds s;
@@ -205,7 +205,8 @@ __host__ __device__ inline ChainLds chain_lds(int k_in /*floats of the widest st
   s.off_h1 = s.off_h0 + R * s.ld_h + 16;
   s.off_red = s.off_h1 + R * s.ld_h + 16;
   s.off_sc = s.off_red + (W / 64) * 4 * 64 * 4;   // red: [NW waves][<= 4 tiles][64][4]
-  s.total = s.off_sc + 64;
+  s.off_carry = s.off_sc + 64;              // twin trunks: [R][64] output-layer partial sums of the first trunk
+  s.total = s.off_carry + R * 64;
   return s;
 }
 
@@ -229,8 +230,10 @@ struct DwProb {
   int M, N;
   int tiles_n, tile_end;              // 32-wide column tiles; exclusive end of this problem's tile range
   const MirrorDesc* mir;
+  int msplit, nsplit;                 // nsplit > 0: the block-diagonal output layer [[w_mean, 0], [0, w_log_std]] of a twin-trunk net
+                                      // (networks/cnn.py:224-229): element (m, n) is structurally zero when (m < msplit) != (n < nsplit)
 };
-constexpr int kMaxDwProb = 3 * (kChMaxL + 1);
+constexpr int kMaxDwProb = 3 * 2 * kChMaxL;   // twin trunks: first layer + 2 x hidden layers + output layer per net
 struct Dw2Args {
   DwProb p[kMaxDwProb]; int n_prob;
   int C, ct;              // chunks (16 batch rows) per operand row tile; chunks per tile (<= 16 per round, rounds as needed)
@@ -374,6 +377,7 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds, Wa
   f32x4 v = *(const f32x4*)(lds + ((0 * 4 + wave) * 64 + lane) * 4);
 #pragma unroll
   for (int w = 1; w < NWV; ++w) v += *(const f32x4*)(lds + ((w * 4 + wave) * 64 + lane) * 4);
+  if (P.nsplit > 0 && ((m < P.msplit) != (n < P.nsplit))) v = f32x4{0.f, 0.f, 0.f, 0.f};   // (n, nsplit: multiples of 4)
   float* C = a.gout + range * a.part_stride;
   if (in_range) {
     float* c0 = C + oi;
@@ -538,6 +542,14 @@ __global__ void __launch_bounds__(256) k_adam_pack(AdamPackArgs a) {
 // bits as the two-unit form (the pipelined graph's q_target units: no obs-only producer, no saved accumulators)
 enum : int { SEG_FULL = 0, SEG_OBS_ONLY = 1, SEG_ACT_FROM_SAVED = 2, SEG_FULL_SAVE = 3, SEG_FULL_SPLIT = 4 };
 enum : int { HEAD_NONE = 0, HEAD_POLICY = 1, HEAD_Q = 2 };
+// FwdUnit::head = HEAD_* | twin role | (chunks of 16 k per 16-row tile of the output-layer pack << 8; 0: W / 16).
+// Twin trunks (the CNN nets' `mean` / `log_std` MLPs over one feature row, networks/cnn.py:214-240,437-461): the output layer is
+// the dense [n_out x 2H] matrix [[w_mean, 0], [0, w_log_std]], each trunk multiplies ITS 2H-columns half of it (the structural
+// zeros contribute exact +0), and the two partial products add up to the net's outputs. One workgroup runs the two trunk
+// units of its slice back to back (k_chain_fwdt): HEAD_TWIN_FIRST leaves its partial outputs in LDS and returns,
+// HEAD_TWIN_SECOND adds them to its own before the head's row phase.
+enum : int { HEAD_KIND = 15, HEAD_TWIN_FIRST = 16, HEAD_TWIN_SECOND = 32 };
+__host__ __device__ inline int head_code(int kind, int twin_role, int c_out) { return kind | twin_role | (c_out << 8); }
 enum : int { HW_LATE = 1, HW_PAIRS_OUT = 2, HW_PAIRS_IN = 4 };
 
 struct FwdUnit {
@@ -694,6 +706,8 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
   const int row0 = slice * R;
   const int L = a.L, F = a.F, A = a.A;
   const int S0 = a.s_obs + u.s_act;               // steps of this unit's first layer
+  const int head = u.head & HEAD_KIND, twin = u.head & (HEAD_TWIN_FIRST | HEAD_TWIN_SECOND);
+  const int c_out = (u.head >> 8) ? (u.head >> 8) : W / 16;
   const ChainLds S = chain_lds(4 * (a.s_obs + a.s_act), W, R);
   const int xin = S.off_in, red = S.off_red;
   CTL(a.timeline, 0);
@@ -708,7 +722,7 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
   float wt[NWARM] = {0.f, 0.f, 0.f, 0.f};
   if (WARM) {   // (no branch on warm_cnt: with 0 every lane re-reads line 0 -- a branch here would cost the stream a vmcnt(0))
     const int n0 = NW * S0 * 8, nh = NW * SH * 8;                     // 128-byte lines of the first layer / of a hidden layer
-    const int nhead = u.head == HEAD_NONE ? 0 : (u.head == HEAD_POLICY ? (2 * A + 15) >> 4 : 1) * (W / 16) * 8;
+    const int nhead = head == HEAD_NONE ? 0 : (head == HEAD_POLICY ? (2 * A + 15) >> 4 : 1) * (W / 16) * 8;
     const int total = warm_cnt > 0 ? n0 + (L - 1) * nh + nhead : 0;
     const int share = (total + warm_cnt - 1) / (warm_cnt > 0 ? warm_cnt : 1);
     const int lo = warm_idx * share, hi = lo + share < total ? lo + share : total;
@@ -743,7 +757,7 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
   float pre_eps[NQ], pre_bmu[NQ], pre_braw[NQ], pre_s[NQ], pre_c[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) { pre_eps[q] = 0.f; pre_bmu[q] = 0.f; pre_braw[q] = 0.f; pre_s[q] = 1.f; pre_c[q] = 0.f; }
-  if (u.head == HEAD_POLICY) {
+  if (head == HEAD_POLICY) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int d = jr + q * TPR;
@@ -753,7 +767,7 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
         pre_s[q] = a.act_scale[d]; pre_c[q] = a.act_center[d];
       }
     }
-  } else if (u.head == HEAD_Q && jr == 0) {
+  } else if (head == HEAD_Q && jr == 0) {
     pre_bmu[0] = u.bias[L][0]; pre_braw[0] = u.bias[L][1];
   }
   // merged launch: the weight stream and the loads above are already in flight while this waits for its producers
@@ -895,9 +909,9 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
   CTL(a.timeline, 3);
   // ---- epilogues + hidden layers
   NarrowFrags<4> hf;
-  const int nto = u.head == HEAD_POLICY ? (2 * A + 15) >> 4 : 1;
+  const int nto = head == HEAD_POLICY ? (2 * A + 15) >> 4 : 1;
   for (int l = 0; l < L; ++l) {
-    if (l == L - 1 && u.head != HEAD_NONE) narrow_load<4>(hf, u.wf[L], W / 16, nto, wave, lane4);   // under the last epilogue
+    if (l == L - 1 && head != HEAD_NONE) narrow_load<4>(hf, u.wf[L], c_out, nto, wave, lane4);   // under the last epilogue
     const int hn = (l & 1) ? S.off_h1 : S.off_h0;
     const float bl = l == 0 ? bq[0] : l == 1 ? bq[1] : l == 2 ? bq[2] : bq[3];
 #pragma unroll
@@ -921,18 +935,29 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
       CTL(a.timeline, 5 + 2 * l);
     }
   }
-  if (u.head == HEAD_NONE) { CTLR(a.timeline, 15); chain_publish(done_flag); return; }
+  if (head == HEAD_NONE) { CTLR(a.timeline, 15); chain_publish(done_flag); return; }
   // ---- output layer: 16x16x4 tiles, contraction split over the waves, partials through LDS
   const int hl = ((L - 1) & 1) ? S.off_h1 : S.off_h0;
   narrow_mma<4>(hf, nto, wave, lds, hl + ((lane & 15) & (R - 1)) * S.ld_h + 4 * (lane >> 4), red, lane);
   lds_barrier();
   CTL(a.timeline, 12);
+  float* const carry = lds + S.off_carry;
+  if (twin == HEAD_TWIN_FIRST) {   // first trunk of a twin net: the partial outputs wait in LDS for the second trunk's
+    for (int e = tid; e < R * 16 * nto; e += NTHR) {
+      const int mm = e / (16 * nto), o = e % (16 * nto);
+      carry[mm * 64 + o] = narrow_get<4, NW>(lds, red, mm, o);
+    }
+    CTLR(a.timeline, 15);
+    return;
+  }
+  const bool add_carry = twin == HEAD_TWIN_SECOND;
   const int m = mr, j = jr;                    // row phase: TPR consecutive lanes per batch row
   const int r = row0 + m;
-  if (u.head == HEAD_Q) {
+  if (head == HEAD_Q) {
     if (j == 0) {
-      const float mean = narrow_get<4, NW>(lds, red, m, 0) + pre_bmu[0];
-      const float raw = narrow_get<4, NW>(lds, red, m, 1) + pre_braw[0];
+      float mean = narrow_get<4, NW>(lds, red, m, 0), raw = narrow_get<4, NW>(lds, red, m, 1);
+      if (add_carry) { mean += carry[m * 64]; raw += carry[m * 64 + 1]; }
+      mean += pre_bmu[0]; raw += pre_braw[0];
       u.qout[2 * r] = mean; u.qout[2 * r + 1] = raw;
       if (u.qstd) { u.qstd[2 * r] = softplus(raw); u.qstd[2 * r + 1] = softplus_grad(raw); }
     }
@@ -947,8 +972,9 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
   for (int q = 0; q < NQ; ++q) {
     const int d = j + q * TPR;
     if (d >= A) break;
-    const float mu = narrow_get<4, NW>(lds, red, m, d) + pre_bmu[q];
-    const float raw = narrow_get<4, NW>(lds, red, m, A + d) + pre_braw[q];
+    float mu = narrow_get<4, NW>(lds, red, m, d), raw = narrow_get<4, NW>(lds, red, m, A + d);
+    if (add_carry) { mu += carry[m * 64 + d]; raw += carry[m * 64 + A + d]; }
+    mu += pre_bmu[q]; raw += pre_braw[q];
     const TanhGaussFwd f = tanh_gauss_fwd(mu, raw, pre_eps[q], pre_s[q], pre_c[q], a.lo_ls, a.hi_ls);
     lp += f.lp;
     st_agent(u.xact + (size_t)r * a.ldx + F + d, f.a);
@@ -1054,6 +1080,29 @@ __global__ void __launch_bounds__(64 * NW, 2) k_chain_fwdp(const PipeFwd* __rest
   else chain_fwd_body<NW, 2, GA, KA, KU, true>(p->c, p->u[unit], unit, slice, lds, wm >> 16, wm & 0xffff);
 }
 
+// k_chain_fwdt: a forward launch of TWIN-trunk nets (the CNN approximators' mean / log_std MLPs over the conv features).
+// Same device-memory unit / block table as k_chain_fwdp; a block code names the FIRST trunk's unit, the workgroup runs
+// that unit and then unit + 1 on the same slice (see HEAD_TWIN_*). No in-launch hand-overs: group A (policy, policy
+// target, critics) and group B (q targets, q(obs, new_act)) are two launches.
+template <int NW, bool GA = false>
+__global__ void __launch_bounds__(64 * NW, 2) k_chain_fwdt(const PipeFwd* __restrict__ pd) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  typedef __attribute__((address_space(4))) const PipeFwd KP;
+  KP* p = (KP*)(unsigned long long)pd;
+  const int code = p->blk[blockIdx.x];
+  if (code < 0) return;
+  const int unit = code >> 16, slice = code & 0xffff;
+  typedef __attribute__((address_space(4))) const FwdArgs KA;
+  typedef __attribute__((address_space(4))) const FwdUnit KU;
+  const int nt = (p->u[unit].head & HEAD_TWIN_FIRST) ? 2 : 1;
+#pragma nounroll
+  for (int t = 0; t < nt; ++t) {
+    if (t) lds_barrier();
+    if (p->u[unit + t].rg == 1) chain_fwd_body<NW, 1, GA, KA, KU, false>(p->c, p->u[unit + t], unit + t, slice, lds);
+    else chain_fwd_body<NW, 2, GA, KA, KU, false>(p->c, p->u[unit + t], unit + t, slice, lds);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // k_chain_bwd_q: loss + dZ chains of q1(obs,act), q2(obs,act), q1(obs,new_act), q2(obs,new_act)
 // ---------------------------------------------------------------------------------------------------------------
@@ -1066,9 +1115,11 @@ struct BwdQUnit {
   float* doutT;                    // transposed pack of dout [2 (16-row tile)][batch] (critic chains: operand of the output layer's dW)
   const float* w1at; float* dA;    // actor chains: style-16 packed (W0[:, F:])^T [16*nta x W], dL/d new_act partial [B][32]
   int which;                       // 0 q1c, 1 q2c, 2 q1p, 3 q2p
+  int trunk;                       // twin-trunk nets: 0 = mean trunk (writes the shared row-phase results), 1 = log_std trunk
+  float* dz0row;                   // row-major copy of dZ[0] [B][ldz0] at this trunk's columns (CNN nets: operand of dL/d features), or nullptr
 };
 struct BwdQArgs {
-  BwdQUnit u[4];
+  BwdQUnit u[8];                   // twin-trunk nets: (chain, trunk) pairs -- wout / wb / G / dZ / w1at / dA point at the trunk's part
   int n_units, n_slices;
   int B, A, L, Cb;
   // loss inputs (dsac_v2.py:218-318), as k_loss
@@ -1085,6 +1136,9 @@ struct BwdQArgs {
   // DSAC_V1 (dsac_v1.py:194-253): ONE critic -- units `which` 0 (q(obs,act)) and 2 (q(obs,new_act)), no mean_std EMA, the
   // fixed TD_bound clip, and the variance-weighted pseudo-loss (v1_bound) or the Gaussian NLL; same row layout otherwise
   int v1; float td_bound; int v1_bound;
+  int ldo;                         // floats between the two rows of wout (0: W; twin trunks: 2W -- the dense block-diagonal matrix)
+  int c1at;                        // chunks of 16 k per 16-row tile of w1at (0: W / 16; twin trunks: 2W / 16)
+  int ldz0;                        // row stride of dz0row
 };
 
 template <int NW, int RG>
@@ -1121,7 +1175,9 @@ __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* 
   const int m = tid / TPR, j = tid % TPR;
   const int r = row0 + m;
   // lane = hidden unit n for the output-layer backward: Wout[:, n], gelu'(z_last)[rows][n]
-  const float wo0 = u.wout[n], wo1 = u.wout[W + n];
+  const float wo0 = u.wout[n], wo1 = u.wout[(a.ldo ? a.ldo : W) + n];
+  const int c1at = a.c1at ? a.c1at : W / 16;
+  const bool lead = u.trunk == 0;  // the trunk units of a chain compute the same row phase; one of them publishes it
   f32x4 gl[RG];
 #pragma unroll
   for (int g = 0; g < RG; ++g) gl[g] = gload4(u.G[L - 1] + pk_index(n, row0 + 4 * g, a.Cb));
@@ -1184,10 +1240,11 @@ __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* 
     else { d0 = -a.inv_B; d1 = 0.0f; }
   }
   if (j == 0) {
-    u.dout[2 * r] = d0; u.dout[2 * r + 1] = d1;
     sc[16 + 2 * m] = d0; sc[16 + 2 * m + 1] = d1;
-    if (u.doutT) { u.doutT[pk_index(0, r, a.Cb)] = d0; u.doutT[pk_index(1, r, a.Cb)] = d1; }
-    if (u.which == 0 && a.v1) {
+    if (lead) { u.dout[2 * r] = d0; u.dout[2 * r + 1] = d1; }
+    if (lead && u.doutT) { u.doutT[pk_index(0, r, a.Cb)] = d0; u.doutT[pk_index(1, r, a.Cb)] = d1; }
+    if (!lead) {
+    } else if (u.which == 0 && a.v1) {
       float* pl = a.part_loss + (size_t)r * kLossPart;
       pl[0] = v1_loss; pl[1] = 0.f; pl[2] = q1; pl[3] = 0.f; pl[4] = std1; pl[5] = 0.f;
       pl[6] = alpha * lpn - q1p;
@@ -1215,10 +1272,14 @@ __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* 
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) lds[S.off_h0 + (4 * g + rr) * S.ld_h + n] = ov[rr];
     nt_store4(u.dZ[L - 1] + pk_index(n, row0 + 4 * g, a.Cb), ov);
+    if (u.dz0row && L == 1) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) u.dz0row[(size_t)(row0 + 4 * g + rr) * a.ldz0 + n] = ov[rr];
+    }
   }
   NarrowFrags<2> af;
   const int nta = (a.A + 15) >> 4;
-  if (u.w1at && L == 1) narrow_load<2>(af, u.w1at, W / 16, nta, wave, lane4);
+  if (u.w1at && L == 1) narrow_load<2>(af, u.w1at, c1at, nta, wave, lane4);
   lds_barrier();
   CTL(a.timeline, 2);
   // ---- hidden layers: dZ[l-1] = (dZ[l] W_l) * gelu'(z[l-1])
@@ -1234,7 +1295,7 @@ __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* 
     gemm44_seg<RG>(ws, u.wb[l] + (size_t)wave * SH * 256, 0, SH, u.wb[has_nxt ? l - 1 : l] + (size_t)wave * SH * 256, 0, has_nxt,
                    lds, (cur ? S.off_h1 : S.off_h0) + (lane & 3) * S.ld_h, S.ld_h, lane4, acc);
     CTL(a.timeline, 3 + 2 * (L - 1 - l));
-    if (l == 1 && u.w1at) narrow_load<2>(af, u.w1at, W / 16, nta, wave, lane4);
+    if (l == 1 && u.w1at) narrow_load<2>(af, u.w1at, c1at, nta, wave, lane4);
     const int hn = cur ? S.off_h0 : S.off_h1;
 #pragma unroll
     for (int g = 0; g < RG; ++g) {
@@ -1242,6 +1303,10 @@ __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* 
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) lds[hn + (4 * g + rr) * S.ld_h + n] = dz[rr];
       nt_store4(u.dZ[l - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz);
+      if (u.dz0row && l == 1) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) u.dz0row[(size_t)(row0 + 4 * g + rr) * a.ldz0 + n] = dz[rr];
+      }
     }
     cur ^= 1;
     lds_barrier();
@@ -1267,6 +1332,13 @@ __global__ void __launch_bounds__(256) k_chain_bwd_q(BwdQArgs a) {
 // blocks >= n_chain_blocks: ride-along weight-gradient tiles (the critics' dW + Adam), 256 threads each
 // ---------------------------------------------------------------------------------------------------------------
 struct BwdPiArgs {
+  // twin-trunk policy (CNN nets): n_trunks = 2 -- chain blocks [0, n_chain_blocks / 2) run the mean trunk (woutT, wb, G, dZ),
+  // the rest the log_std trunk (woutT1, wb1, G1, dZ1); both compute the row phase, the first publishes it. dA2: the
+  // log_std trunks' share of dL/d new_act (nullptr: none)
+  int n_trunks;
+  const float* woutT1; const float* wb1[kChMaxL]; const float* G1[kChMaxL]; float* dZ1[kChMaxL];
+  const float* dA2[2];
+  float* dz0row; int ldz0;         // row-major copy of the policy's dZ[0] [B][ldz0] (CNN nets: operand of dL/d features), or nullptr
   const float* dA[2];              // [B][32] from k_chain_bwd_q (q1p, q2p)
   const float* logits_pi; const float* eps_new; const float* log_alpha;
   const float* woutT; int SoT;     // style-44 packed Wout_pi^T [W x 4*SoT]
@@ -1301,10 +1373,15 @@ __device__ __forceinline__ void bwd_pi_alpha_grad(const BwdPiArgs& a, int lane) 
 }
 
 template <int NW, int RG>
-__device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float* lds) {
+__device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float* lds, int trunk = 0) {
   constexpr int W = 64 * NW, SH = W / 4, R = 4 * RG, NTHR = 64 * NW, TPR = NTHR / R;
   const int tid = threadIdx.x;
   if (slice >= a.n_slices || tid >= NTHR) return;
+  const bool lead = trunk == 0;
+  const float* const* const t_wb = trunk ? a.wb1 : a.wb;
+  const float* const* const t_G = trunk ? a.G1 : a.G;
+  float* const* const t_dZ = trunk ? a.dZ1 : a.dZ;
+  float* const dz0row = a.dz0row ? a.dz0row + trunk * W : nullptr;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane4 = lane * 4;
@@ -1316,7 +1393,7 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
   CTL(a.timeline, 0);
   CTLR(a.timeline, 14);
   WStr ws;
-  const float* wo = a.woutT + (size_t)wave * a.SoT * 256;
+  const float* wo = (trunk ? a.woutT1 : a.woutT) + (size_t)wave * a.SoT * 256;
   stream_prologue(ws, wo, 0, lane4);
   const int m = tid / TPR, j = tid % TPR;
   const int r = row0 + m;
@@ -1328,13 +1405,14 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
     const int d = j + q * TPR;
     const bool ok = d < A;
     pdA[q] = ok ? a.dA[0][(size_t)r * 32 + d] + a.dA[1][(size_t)r * 32 + d] : 0.f;
+    if (a.dA2[0] && ok) pdA[q] += a.dA2[0][(size_t)r * 32 + d] + a.dA2[1][(size_t)r * 32 + d];
     pmu[q] = ok ? a.logits_pi[(size_t)r * 2 * A + d] : 0.f;
     praw[q] = ok ? a.logits_pi[(size_t)r * 2 * A + A + d] : 0.f;
     peps[q] = ok ? a.eps_new[(size_t)r * A + d] : 0.f;
     psc[q] = ok ? a.act_scale[d] : 1.f;
   }
   // alpha gradient (dsac_v2.py:312-318): -mean(logp_new + target_entropy)
-  if (slice == 0 && wave == 0 && !a.merge_dw) bwd_pi_alpha_grad(a, lane);   // merged launch: the closing block does it
+  if (slice == 0 && wave == 0 && !a.merge_dw && lead) bwd_pi_alpha_grad(a, lane);   // merged launch: the closing block does it
   const int agent = a.merge_dw;
   const float alpha = a.auto_alpha ? expf(a.log_alpha[0]) : a.alpha_fixed;
   // zero the operand rows (padding included), then fill (dmu | draw)
@@ -1347,11 +1425,13 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
     const float dA = pdA[q];
     float dmu, draw;
     tanh_gauss_bwd(pmu[q], praw[q], peps[q], psc[q], a.lo_ls, a.hi_ls, dA, alpha * a.inv_B, dmu, draw);
-    a.dout_pi[(size_t)r * 2 * A + d] = dmu;
-    a.dout_pi[(size_t)r * 2 * A + A + d] = draw;
-    hand_store(a.dout_piT + pk_index(d, r, a.Cb), dmu, agent);
-    hand_store(a.dout_piT + pk_index(A + d, r, a.Cb), draw, agent);
-    a.d_new_act[(size_t)r * A + d] = dA;
+    if (lead) {
+      a.dout_pi[(size_t)r * 2 * A + d] = dmu;
+      a.dout_pi[(size_t)r * 2 * A + A + d] = draw;
+      hand_store(a.dout_piT + pk_index(d, r, a.Cb), dmu, agent);
+      hand_store(a.dout_piT + pk_index(A + d, r, a.Cb), draw, agent);
+      a.d_new_act[(size_t)r * A + d] = dA;
+    }
     xdo[m * S.ld_in + d] = dmu;
     xdo[m * S.ld_in + A + d] = draw;
   }
@@ -1364,16 +1444,20 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
     for (int g = 0; g < RG; ++g) { acc[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = acc[g][0]; }
     f32x4 gq[RG];
 #pragma unroll
-    for (int g = 0; g < RG; ++g) gq[g] = gload4(a.G[L - 1] + pk_index(n, row0 + 4 * g, a.Cb));
+    for (int g = 0; g < RG; ++g) gq[g] = gload4(t_G[L - 1] + pk_index(n, row0 + 4 * g, a.Cb));
     const bool has_nxt = L > 1;
-    gemm44_seg<RG>(ws, wo, 0, a.SoT, has_nxt ? a.wb[L - 1] + (size_t)wave * SH * 256 : wo, 0, has_nxt,
+    gemm44_seg<RG>(ws, wo, 0, a.SoT, has_nxt ? t_wb[L - 1] + (size_t)wave * SH * 256 : wo, 0, has_nxt,
                    lds, S.off_in + (lane & 3) * S.ld_in, S.ld_in, lane4, acc);
 #pragma unroll
     for (int g = 0; g < RG; ++g) {
       const f32x4 dz = (acc[g][0] + acc[g][1]) * gq[g];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) lds[S.off_h0 + (4 * g + rr) * S.ld_h + n] = dz[rr];
-      pack_store4(a.dZ[L - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz, agent);
+      pack_store4(t_dZ[L - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz, agent);
+      if (dz0row && L == 1) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) dz0row[(size_t)(row0 + 4 * g + rr) * a.ldz0 + n] = dz[rr];
+      }
     }
     lds_barrier();
     CTL(a.timeline, 2);
@@ -1384,9 +1468,9 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
     for (int g = 0; g < RG; ++g) { acc[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = acc[g][0]; }
     f32x4 gq[RG];
 #pragma unroll
-    for (int g = 0; g < RG; ++g) gq[g] = gload4(a.G[l - 1] + pk_index(n, row0 + 4 * g, a.Cb));
+    for (int g = 0; g < RG; ++g) gq[g] = gload4(t_G[l - 1] + pk_index(n, row0 + 4 * g, a.Cb));
     const bool has_nxt = l > 1;
-    gemm44_seg<RG>(ws, a.wb[l] + (size_t)wave * SH * 256, 0, SH, a.wb[has_nxt ? l - 1 : l] + (size_t)wave * SH * 256, 0, has_nxt,
+    gemm44_seg<RG>(ws, t_wb[l] + (size_t)wave * SH * 256, 0, SH, t_wb[has_nxt ? l - 1 : l] + (size_t)wave * SH * 256, 0, has_nxt,
                    lds, (cur ? S.off_h1 : S.off_h0) + (lane & 3) * S.ld_h, S.ld_h, lane4, acc);
     const int hn = cur ? S.off_h0 : S.off_h1;
 #pragma unroll
@@ -1394,7 +1478,11 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
       const f32x4 dz = (acc[g][0] + acc[g][1]) * gq[g];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) lds[hn + (4 * g + rr) * S.ld_h + n] = dz[rr];
-      pack_store4(a.dZ[l - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz, agent);
+      pack_store4(t_dZ[l - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz, agent);
+      if (dz0row && l == 1) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) dz0row[(size_t)(row0 + 4 * g + rr) * a.ldz0 + n] = dz[rr];
+      }
     }
     cur ^= 1;
     if (l > 1) lds_barrier();
@@ -1438,6 +1526,11 @@ template <int NW, int RG>
 __global__ void __launch_bounds__(256) k_chain_bwd_pi(BwdPiArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if ((int)blockIdx.x >= a.n_chain_blocks) { bwd_pi_tail_blocks(a, (int)blockIdx.x - a.n_chain_blocks, lds); return; }
+  if (a.n_trunks == 2) {
+    const int per = a.n_chain_blocks >> 1, b = (int)blockIdx.x;
+    bwd_pi_body<NW, RG>(a, b >= per ? b - per : b, lds, b >= per ? 1 : 0);
+    return;
+  }
   bwd_pi_body<NW, RG>(a, (int)blockIdx.x, lds);
 }
 // The same launch 512 threads wide (unmerged form, long contractions: batch >= 1024): a riding weight-gradient tile runs
@@ -1453,6 +1546,11 @@ __global__ void __launch_bounds__(512) k_chain_bwd_pi8(BwdPiArgs a) {
     int t;
     if (!xcd_chunk(idx % per_range, a.n_extra, t)) return;
     dw2_tile<2, NoWait, 8>(a.dw, (idx / per_range) * a.dw.n_base + a.tile0 + t, lds);
+    return;
+  }
+  if (a.n_trunks == 2) {
+    const int per = a.n_chain_blocks >> 1, b = (int)blockIdx.x;
+    bwd_pi_body<NW, RG>(a, b >= per ? b - per : b, lds, b >= per ? 1 : 0);
     return;
   }
   bwd_pi_body<NW, RG>(a, (int)blockIdx.x, lds);

@@ -44,10 +44,12 @@ def np_of(t):
     return t.detach().cpu().contiguous().numpy()
 
 
-def run_case(title, obs_shape, A, conv_type, B, steps, golden=None):
+def run_case(title, obs_shape, A, conv_type, B, steps, golden=None, chains=None):
     rep = Report(title)
     alg, orc, cfg = make_pair(obs_shape, A, conv_type, B)
     e = alg.engine
+    if chains is not None:   # the twin MLP trunks over the conv features as row-slice chain units (batch % 16 == 0, equal widths)
+        assert e.chain_active == chains
     names = {n: orc._names(n) for n in ("q1", "q2", "policy")}
     orc.keep_conv = True
     lrs = {"q1": orc.cfg["lr_q"], "q2": orc.cfg["lr_q"], "policy": orc.cfg["lr_pi"]}
@@ -185,20 +187,32 @@ def test_cnn_type1():
 
 
 def test_cnn_type2_b256():
-    """BASELINE.json configs[3] at its full batch."""
-    run_case("cnn type_2 (3,96,96) B=256", (3, 96, 96), 3, "type_2", 256, steps=2)
+    """BASELINE.json configs[3] at its full batch: conv stacks + the twin trunks on the row-slice chains."""
+    run_case("cnn type_2 (3,96,96) B=256", (3, 96, 96), 3, "type_2", 256, steps=2, chains=True)
+
+
+def test_cnn_type2_b16_twin_trunk_chains():
+    """smallest batch the chain kernels take: several updates, so the fused Adam / Polyak of the twin-trunk weight-gradient
+    tiles (dense first layer, per-trunk hidden blocks, block-diagonal output layer) feeds the next forward passes."""
+    run_case("cnn type_2 (3,96,96) B=16 (twin trunks on the chains)", (3, 96, 96), 3, "type_2", 16, steps=4, chains=True)
+
+
+def test_cnn_type2_b16_tile_path_switch(monkeypatch):
+    """DSACT_NO_CHAIN_CNN keeps the twin trunks on the stage tiles (the round-1 path, the fallback)."""
+    monkeypatch.setenv("DSACT_NO_CHAIN_CNN", "1")
+    run_case("cnn type_2 (3,96,96) B=16 (tile path)", (3, 96, 96), 3, "type_2", 16, steps=2, chains=False)
 
 
 def test_cnn_type2_b512_large_batch_paths():
-    """batch 512: the twin-trunk MLP part runs on the 64x64 stage tiles and split-K weight gradients while the conv
-    stacks keep their own chunked weight gradient; the optimiser is the streaming kernel for both."""
-    run_case("cnn type_2 (3,96,96) B=512", (3, 96, 96), 3, "type_2", 512, steps=1)
+    """batch 512: the twin trunks run 8-row chain slices (one gradient arena up to batch 1024) while the conv stacks keep
+    their own chunked weight gradient."""
+    run_case("cnn type_2 (3,96,96) B=512", (3, 96, 96), 3, "type_2", 512, steps=1, chains=True)
 
 
 @pytest.mark.parametrize("B,steps", [(16, 4), (512, 2)])
 def test_cnn_fused_step_equals_split_path(B, steps):
-    """fused step == gradient halves + streaming Adam, bit for bit; at batch 512 the fused step's Adam kernel sums
-    the MLP part's split-K partials itself while the conv gradients come from the gradient arena."""
+    """fused step (Adam / Polyak inside the weight-gradient tiles and the conv reduce) == gradient halves + streaming Adam,
+    bit for bit, on the chain path of the twin trunks."""
     a1, _, cfg = make_pair((3, 96, 96), 3, "type_2", B, seed=3)
     a2, _, _ = make_pair((3, 96, 96), 3, "type_2", B, seed=3)
     for it in range(steps):

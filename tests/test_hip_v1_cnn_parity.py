@@ -31,13 +31,15 @@ def make_pair(obs_shape, A, conv_type, B, seed=0, bound=True):
 
 
 @pytest.mark.parametrize("conv_type,obs_shape,B,bound", [("type_2", (3, 96, 96), 4, True), ("type_2", (3, 96, 96), 8, False),
-                                                         ("type_1", (4, 84, 84), 4, True)])
+                                                         ("type_1", (4, 84, 84), 4, True), ("type_2", (3, 96, 96), 16, True),
+                                                         ("type_2", (3, 96, 96), 32, False)])
 def test_v1_cnn_against_oracle(conv_type, obs_shape, B, bound):
     A = 3
     alg, orc, cfg = make_pair(obs_shape, A, conv_type, B, bound=bound)
     sd0 = alg.networks.state_dict()
     assert list(sd0.keys())[:2] == ["log_alpha", "q.conv.0.weight"] and "q_target.mean.0.weight" in sd0
-    assert alg.engine.layout.n_critics == 1 and not alg.engine.chain_active
+    # batch % 16 == 0 with equal trunk widths (type_2): the twin trunks run as row-slice chain units, else on the stage tiles
+    assert alg.engine.layout.n_critics == 1 and alg.engine.chain_active == (B % 16 == 0 and conv_type == "type_2")
     for it in range(3):
         data = synth_image_batch(cfg, B, seed=it)
         torch.manual_seed(500 + it)
