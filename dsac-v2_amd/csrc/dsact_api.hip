@@ -258,6 +258,9 @@ struct dsact_handle {
   bool twin = false;
   float* X0t_net[3] = {nullptr, nullptr, nullptr};   // every net has its own input rows (features): transposed packs for q1, q2, policy
   float* dz0row[3] = {nullptr, nullptr, nullptr};    // row-major dZ[0] of q1c, q2c, pi [B][w[0]]: operand of the dL/d features product
+  float* twin_part[8];                               // [B][64] output-layer partials of the first trunks (group x net), parallel trunks
+  bool twin_par = false;                             // the two trunks of a net as workgroups of their own (flags: chain_flags)
+  bool env_twin_seq = false;                         // DSACT_TWIN_SEQ: one workgroup runs both trunks back to back
   PipeFwd* d_fwdt[2] = {nullptr, nullptr};           // k_chain_fwdt tables (group A, group B), built by dsact_bind_arenas
   PipeFwd* fwdt_host[2] = {nullptr, nullptr};
   float* doutT[3];                      // transposed packs of dL/d(out): q1, q2 [32 x B], policy [roundup32(2A) x B]
@@ -533,6 +536,7 @@ void carve(dsact_handle* h, Carver& c) {
     h->X0t_net[0] = h->X0t;
     for (int i = 1; i < 3; ++i) h->X0t_net[i] = c.take<float>(B * (size_t)((h->F + A + 31) / 32 * 32));
     for (int i = 0; i < 3; ++i) h->dz0row[i] = c.take<float>(B * h->w[0]);
+    for (int i = 0; i < 8; ++i) h->twin_part[i] = c.take<float>(B * 64);
   }
   h->act_scale = c.take<float>(A);
   h->act_center = c.take<float>(A);
@@ -1733,7 +1737,21 @@ int build_twin_fwd(dsact_handle* h) {
       }
     }
     const char* name = grp == 0 ? "chain_fwd_a" : "chain_fwd_b";
-    const int rg = chain_rg(h, n_nets);
+    // the two trunks of a net as workgroups of their own when every (net, slice) has a ready flag: twice the workgroups
+    // at half the chain length (measured at batch 256: 45 / 41 us per launch with one workgroup per net and slice)
+    int rg = chain_rg(h, 2 * n_nets);
+    const bool par = !h->env_twin_seq && h->B / (4 * rg) <= kChainFlagSlices;
+    if (!par) rg = chain_rg(h, n_nets);
+    if (grp == 0) h->twin_par = par;
+    for (int i = 0; i < n_nets; ++i) { P.u[2 * i].qout = nullptr; P.u[2 * i].qstd = nullptr; }   // first trunks: no head of their own
+    if (par)
+      for (int i = 0; i < n_nets; ++i) {
+        FwdUnit& f = P.u[2 * i];
+        FwdUnit& g = P.u[2 * i + 1];
+        int* flags = h->chain_flags + (4 * grp + i) * kChainFlagSlices;
+        f.qout = h->twin_part[4 * grp + i]; f.qstd = nullptr; f.done = flags;
+        g.zinit = h->twin_part[4 * grp + i]; g.wait0 = flags; g.wait_rows0 = 4 * rg; g.late_wait = HW_HEAD;
+      }
     FwdArgs& c = P.c;
     c.n_units = 2 * n_nets;
     for (int k = 0; k < c.n_units; ++k) { P.u[k].rg = (short)rg; P.u[k].n_slices = (short)(h->B / (4 * rg)); }
@@ -1742,9 +1760,23 @@ int build_twin_fwd(dsact_handle* h) {
     c.act_scale = h->act_scale; c.act_center = h->act_center; c.lo_ls = h->cfg.min_log_std; c.hi_ls = h->cfg.max_log_std;
     c.timeline = tl_for(h, name);
     c.spin_timeout = h->handoff_dev;
+    const int n_slices = h->B / (4 * rg);
+    if (par) {
+      // XCDs 0-3 run the first trunks, 4-7 the second ones; the nets share each half (rep XCDs per net, slices dealt
+      // round-robin over them). A second-trunk block sits 4 ids behind its partner: dispatched later, never before it
+      const int rep = n_nets >= 3 ? 1 : 4 / n_nets, rounds = (n_slices + rep - 1) / rep;
+      P.n_blocks = 8 * rounds;
+      if (P.n_blocks > kPipeMaxBlocks) return fail(h, DSACT_E_INVALID, "twin forward table: %d blocks exceed %d", P.n_blocks, kPipeMaxBlocks);
+      for (int b = 0; b < P.n_blocks; ++b) {
+        const int x = b & 3, t = (b >> 2) & 1, round = b >> 3;
+        const int net = x % n_nets, k = x / n_nets, slice = k + rep * round;
+        P.blk[b] = (x < n_nets * rep && slice < n_slices) ? (((2 * net + t) << 16) | slice) : -1;
+      }
+      HIPCHK(h, hipMemcpy(h->d_fwdt[grp], &P, sizeof(PipeFwd), hipMemcpyHostToDevice));
+      continue;
+    }
     // block -> (net, slice): the slices of a net on the same XCD(s) like xcd_map_uniform
     const XcdMap map = xcd_map_uniform(n_nets);
-    const int n_slices = h->B / (4 * rg);
     int rounds = 0;
     for (int x = 0; x < 8; ++x) {
       if (map.unit[x] < 0) continue;
@@ -1769,6 +1801,10 @@ int enqueue_chain_fwd_twin(dsact_handle* h, int grp) {
   const int rg = P.u[0].rg;
   const size_t lds = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 4 * rg).total * sizeof(float);
   if (grp == 0) h->n_heads_parts = h->B / 4;   // one partial per four rows whatever the rows per workgroup (chain_fwd_body)
+  if (grp == 0 && h->twin_par) {
+    if (h->flags_dirty) HIPCHK(h, hipMemsetAsync(h->chain_flags, 0, kChainFlags * sizeof(int), h->stream));
+    h->flags_dirty = true;
+  }
   const char* name = grp == 0 ? "chain_fwd_a" : "chain_fwd_b";
   const PipeFwd* dev = h->d_fwdt[grp];
 #define CALL_FT(N) return generic_act(h) ? launch(h, name, k_chain_fwdt<N, true>, dim3(P.n_blocks), dim3(64 * N), lds, dev) \
@@ -2216,7 +2252,7 @@ void bwd_q_args(dsact_handle* h, int n_units, const RideArgs* ride, BwdQArgs& a,
   a.one_minus_tau_b = (float)(1.0 - h->cfg.tau_b);
   a.n_chain_blocks = h->fat_bwd ? n_units * a.n_slices : chain_grid(n_units, a.n_slices);
   a.timeline = tl_for(h, "chain_bwd_q");
-  if (h->fwd_merge) { a.flags_reset = h->chain_flags; a.n_flags = kChainFlags; h->flags_dirty = false; }
+  if (h->fwd_merge || h->twin_par) { a.flags_reset = h->chain_flags; a.n_flags = kChainFlags; h->flags_dirty = false; }
   if (h->pi_merge) { a.flags_reset = h->chain_flags; a.n_flags = kChainFlagInts; h->flags_dirty = false; }   // + the arrival counters
   if (ride) a.ride = *ride;
   a.ride.n_loss_blocks = a.n_chain_blocks;
@@ -2839,6 +2875,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     h->chain_ok = ok;
     h->twin = ok && h->cnn;
     if (h->cnn) h->env_pk_pad = 0;
+    h->env_twin_seq = getenv("DSACT_TWIN_SEQ") != nullptr;
     if (ok) {
       // chain path: a weight-gradient tile contracts up to 1024 batch rows itself (rounds of 256, dw2_tile), so up to
       // batch 1024 there is ONE gradient arena and the optimiser stays fused into the tiles (no split-K partials, no

@@ -547,10 +547,14 @@ enum : int { HEAD_NONE = 0, HEAD_POLICY = 1, HEAD_Q = 2 };
 // the dense [n_out x 2H] matrix [[w_mean, 0], [0, w_log_std]], each trunk multiplies ITS 2H-columns half of it (the structural
 // zeros contribute exact +0), and the two partial products add up to the net's outputs. One workgroup runs the two trunk
 // units of its slice back to back (k_chain_fwdt): HEAD_TWIN_FIRST leaves its partial outputs in LDS and returns,
-// HEAD_TWIN_SECOND adds them to its own before the head's row phase.
+// HEAD_TWIN_SECOND adds them to its own before the head's row phase. Or -- the two trunks as workgroups of their own,
+// twice the workgroups at half the chain length each: the first trunk hands its partial outputs over through memory
+// (FwdUnit::qout = [B][64] partials, agent-scope stores, done[slice]); the second one (late_wait & HW_HEAD: wait0 / zinit
+// name the partner's flags / partials) waits for them just before its row phase. The first trunk's blocks come earlier in
+// the dispatch order than their partners, so the bounded spin cannot deadlock.
 enum : int { HEAD_KIND = 15, HEAD_TWIN_FIRST = 16, HEAD_TWIN_SECOND = 32 };
 __host__ __device__ inline int head_code(int kind, int twin_role, int c_out) { return kind | twin_role | (c_out << 8); }
-enum : int { HW_LATE = 1, HW_PAIRS_OUT = 2, HW_PAIRS_IN = 4 };
+enum : int { HW_LATE = 1, HW_PAIRS_OUT = 2, HW_PAIRS_IN = 4, HW_HEAD = 8 };
 
 struct FwdUnit {
   const float* wf[kChMaxL + 1];     // packed weights per layer: style 44 for l < L, style 16 for the output layer (index L)
@@ -776,8 +780,9 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
   const unsigned tag = (pairs_in || pairs_out) ? (unsigned)(*a.tagp) + 1u : 0u;
   const int* const flag0 = pairs_in ? nullptr : u.wait0;      // (tagged hand-over: wait0 is the pair buffer, not a flag array)
   const bool waits = flag0 || u.wait1 || pairs_in;
-  const bool late = waits && (u.late_wait & HW_LATE) && u.seg != SEG_ACT_FROM_SAVED && u.s_act > 0;
-  if ((flag0 || u.wait1) && !late)
+  const bool head_wait = (u.late_wait & HW_HEAD) != 0;   // twin trunks as separate workgroups: the wait precedes the row phase
+  const bool late = waits && !head_wait && (u.late_wait & HW_LATE) && u.seg != SEG_ACT_FROM_SAVED && u.s_act > 0;
+  if ((flag0 || u.wait1) && !late && !head_wait)
     chain_wait(flag0 ? flag0 + row0 / u.wait_rows0 : nullptr, u.wait1 ? u.wait1 + row0 / u.wait_rows1 : nullptr, a.spin_timeout);
   f32x4 zi[RG];
   if (u.seg == SEG_ACT_FROM_SAVED) {
@@ -942,15 +947,26 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
   lds_barrier();
   CTL(a.timeline, 12);
   float* const carry = lds + S.off_carry;
-  if (twin == HEAD_TWIN_FIRST) {   // first trunk of a twin net: the partial outputs wait in LDS for the second trunk's
+  if (twin == HEAD_TWIN_FIRST) {   // first trunk of a twin net: the partial outputs wait for the second trunk's
     for (int e = tid; e < R * 16 * nto; e += NTHR) {
       const int mm = e / (16 * nto), o = e % (16 * nto);
-      carry[mm * 64 + o] = narrow_get<4, NW>(lds, red, mm, o);
+      const float v = narrow_get<4, NW>(lds, red, mm, o);
+      if (u.qout) st_agent(u.qout + (size_t)(row0 + mm) * 64 + o, v);   // the partner is another workgroup
+      else carry[mm * 64 + o] = v;                                       // the partner is this workgroup's next pass
     }
     CTLR(a.timeline, 15);
+    if (u.qout) chain_publish(done_flag);
     return;
   }
   const bool add_carry = twin == HEAD_TWIN_SECOND;
+  if (head_wait) {
+    chain_wait(u.wait0 + row0 / u.wait_rows0, nullptr, a.spin_timeout);
+    for (int e = tid; e < R * 16 * nto; e += NTHR) {
+      const int mm = e / (16 * nto), o = e % (16 * nto);
+      carry[mm * 64 + o] = ld_agent(u.zinit + (size_t)(row0 + mm) * 64 + o);
+    }
+    lds_barrier();
+  }
   const int m = mr, j = jr;                    // row phase: TPR consecutive lanes per batch row
   const int r = row0 + m;
   if (head == HEAD_Q) {
@@ -1094,7 +1110,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_chain_fwdt(const PipeFwd* __rest
   const int unit = code >> 16, slice = code & 0xffff;
   typedef __attribute__((address_space(4))) const FwdArgs KA;
   typedef __attribute__((address_space(4))) const FwdUnit KU;
-  const int nt = (p->u[unit].head & HEAD_TWIN_FIRST) ? 2 : 1;
+  const int nt = ((p->u[unit].head & HEAD_TWIN_FIRST) && !p->u[unit].qout) ? 2 : 1;   // (qout: the partner is another workgroup)
 #pragma nounroll
   for (int t = 0; t < nt; ++t) {
     if (t) lds_barrier();
