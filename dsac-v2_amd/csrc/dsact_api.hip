@@ -70,7 +70,7 @@ struct ProfRec {
 }  // namespace
 
 constexpr int kChainFlagSlices = 64;                 // slices per unit of a merged forward launch (batch <= 256, >= 4 rows each)
-constexpr int kChainFlags = 8 * kChainFlagSlices;   // done[6 units] + zdone[q1c, q2c]
+constexpr int kChainFlags = 10 * kChainFlagSlices;  // done[6 units] + zdone[q1c, q2c]; twin trunks: 8 x (group, net) partial-output flags + done[pi, pit]
 constexpr int kChainCounters = 8 * kArriveStride;   // behind the flags (+128 ints of padding): arrival counter replicas of the merged policy backward
 constexpr int kChainFlagInts = kChainFlags + 128 + kChainCounters;
 
@@ -148,7 +148,7 @@ struct dsact_handle {
   float* dw_parts = nullptr;     // [dw_chunks][dw_part_stride]
   size_t dw_part_stride = 0;
   std::vector<Stage> fwd1, fwd2, bwdq, bwdq_critic, bwdpi, actf;
-  Stage dfeat_q, dfeat_pi;
+  Stage dfeat_q, dfeat_pi, dfeat_all;
   // Second batch set (MLP nets): graph replays stage update s+1's minibatch while update s still reads its own
   // (the gather rides in the loss launch, see RideArgs). `alt` holds the set that is NOT selected; select_set()
   // swaps the two, so every enqueue function keeps reading h->X0, h->fwd1, h->d_tiles ... of the selected set.
@@ -261,11 +261,13 @@ struct dsact_handle {
   float* twin_part[8];                               // [B][64] output-layer partials of the first trunks (group x net), parallel trunks
   bool twin_par = false;                             // the two trunks of a net as workgroups of their own (flags: chain_flags)
   bool env_twin_seq = false;                         // DSACT_TWIN_SEQ: one workgroup runs both trunks back to back
+  bool twin_merged = false;                          // groups A and B in one launch (table 0), DSACT_TWIN_NO_MERGE: two
   PipeFwd* d_fwdt[2] = {nullptr, nullptr};           // k_chain_fwdt tables (group A, group B), built by dsact_bind_arenas
   PipeFwd* fwdt_host[2] = {nullptr, nullptr};
   float* doutT[3];                      // transposed packs of dL/d(out): q1, q2 [32 x B], policy [roundup32(2A) x B]
   float* X0t = nullptr;                 // transposed pack of the staged minibatch [roundup32(F+A) x B]
   int dw2_off[4] = {0, 0, 0, 0};        // tile ranges of q1, q2, policy in the dw2 problem list
+  int dw2_mid = 0;                      // twin trunks: the critics' FIRST-layer tiles are [dw2_mid, dw2_off[2]) (behind their other tiles)
   int n_heads_parts = 0;                // partial (tanh, sigma) sums the last forward wrote
   // pipelined graph (delayed-update-aware software pipelining, k_chain_fwdp): per-minibatch buffers in kPipeSets copies
   // (set 0 = the workspace's own), one captured graph per phase first_iteration % delay_update
@@ -894,6 +896,7 @@ int build_tasks(dsact_handle* h) {
   // CNN nets: gradient w.r.t. the conv features, dFeat = dZ0 . W0[:, :F]  (plain store)
   h->dfeat_q = fresh("dfeat_q", 2);
   h->dfeat_pi = fresh("dfeat_pi", 2);
+  h->dfeat_all = fresh("dfeat", 2);
   if (h->cnn) {
     for (int ch : {C_Q1C, C_Q2C, C_PI}) {
       if (ch == C_Q2C && h->nq == 1) continue;   // one critic (DSAC_V1)
@@ -911,6 +914,7 @@ int build_tasks(dsact_handle* h) {
       t.C0 = h->dfeat[ch == C_PI ? h->nq : ch - C_Q1C]; t.ldc = h->F;   // (stack numbering: q x nq, then the policy)
       t.M = B; t.N = h->F; t.K = d.out[0];
       stage_add(ch == C_PI ? h->dfeat_pi : h->dfeat_q, t);
+      stage_add(h->dfeat_all, t);
     }
   }
   // weight / bias gradients of q1, q2, policy: one table entry per 32x32 tile
@@ -1508,28 +1512,7 @@ Dw2Args dw2_args(dsact_handle* h, bool fused) {
     const int ch = chs[n3], net = kChainNet[ch], slot = kDzSlot[ch];
     const NetDesc& d = net_desc(h, net);
     const long long base = (long long)(net_grads(h, net) - h->grads);
-    if (h->twin) {
-      // first layer: dense [2W x in] (both trunks' dZ[0] are one pack of 2W features); hidden layers: one [W x W] problem per
-      // trunk; output layer: the dense [n_out x 2W] matrix with its two structurally-zero blocks masked (DwProb::nsplit)
-      const int W = h->cW;
-      const size_t tB = (size_t)W * h->B;   // floats between the trunks' halves of an activation pack
-      for (int l = 0; l <= L; ++l)
-        for (int t = 0; t < ((l >= 1 && l < L) ? 2 : 1); ++t) {
-          DwProb& P = a.p[a.n_prob++];
-          const bool hid = l >= 1 && l < L;
-          P.At = l < L ? h->dZ[slot][l] + (hid ? t * tB : 0) : h->doutT[n3];
-          P.Xt = l == 0 ? h->X0t_net[n3] : h->Hb[ch][l - 1] + (hid ? t * tB : 0);
-          P.M = hid ? W : d.out[l]; P.N = hid ? W : d.in[l];
-          P.w_idx = base + (long long)d.w_off[l] + (hid ? (long long)t * W * W : 0);
-          P.b_idx = base + (long long)d.b_off[l] + (hid ? (long long)t * W : 0);
-          if (l == L) { P.msplit = d.out[L] / 2; P.nsplit = W; }
-          P.tiles_n = (P.N + 31) / 32;
-          tiles += ((P.M + 31) / 32) * P.tiles_n;
-          P.tile_end = tiles;
-          P.mir = nullptr;
-        }
-      continue;
-    }
+    if (h->twin) continue;   // (below)
     for (int l = 0; l <= L; ++l) {
       DwProb& P = a.p[a.n_prob++];
       P.At = l < L ? h->dZ[slot][l] : h->doutT[n3];
@@ -1541,6 +1524,43 @@ Dw2Args dw2_args(dsact_handle* h, bool fused) {
       P.tile_end = tiles;
       P.mir = h->d_mir ? h->d_mir + (size_t)n3 * (L + 1) + l : nullptr;
     }
+  }
+  if (h->twin) {
+    // first layer: dense [2W x in] (both trunks' dZ[0] are one pack of 2W features); hidden layers: one [W x W] problem per
+    // trunk; output layer: the dense [n_out x 2W] matrix with its two structurally-zero blocks masked (DwProb::nsplit).
+    // Order: critics' hidden + output layers, critics' FIRST layers, policy -- the first-layer tiles (which rewrite W0)
+    // can then run behind the ONE launch that forms dL/d features = dZ0 . W0 for all three nets (enqueue_grads_chain)
+    const int W = h->cW;
+    const size_t tB = (size_t)W * h->B;   // floats between the trunks' halves of an activation pack
+    a.n_prob = 0; tiles = 0;
+    auto add = [&](int n3, int l, int t) {
+      const int ch = chs[n3], net = kChainNet[ch], slot = kDzSlot[ch];
+      const NetDesc& d = net_desc(h, net);
+      const long long base = (long long)(net_grads(h, net) - h->grads);
+      DwProb& P = a.p[a.n_prob++];
+      const bool hid = l >= 1 && l < L;
+      P.At = l < L ? h->dZ[slot][l] + (hid ? t * tB : 0) : h->doutT[n3];
+      P.Xt = l == 0 ? h->X0t_net[n3] : h->Hb[ch][l - 1] + (hid ? t * tB : 0);
+      P.M = hid ? W : d.out[l]; P.N = hid ? W : d.in[l];
+      P.w_idx = base + (long long)d.w_off[l] + (hid ? (long long)t * W * W : 0);
+      P.b_idx = base + (long long)d.b_off[l] + (hid ? (long long)t * W : 0);
+      if (l == L) { P.msplit = d.out[L] / 2; P.nsplit = W; }
+      P.tiles_n = (P.N + 31) / 32;
+      tiles += ((P.M + 31) / 32) * P.tiles_n;
+      P.tile_end = tiles;
+      P.mir = nullptr;
+    };
+    for (int n3 = 0; n3 < h->nq; ++n3) {
+      h->dw2_off[n3] = tiles;
+      for (int l = 1; l <= L; ++l)
+        for (int t = 0; t < (l < L ? 2 : 1); ++t) add(n3, l, t);
+    }
+    if (h->nq == 1) h->dw2_off[1] = tiles;
+    h->dw2_mid = tiles;
+    for (int n3 = 0; n3 < h->nq; ++n3) add(n3, 0, 0);
+    h->dw2_off[2] = tiles;
+    for (int l = 0; l <= L; ++l)
+      for (int t = 0; t < ((l >= 1 && l < L) ? 2 : 1); ++t) add(2, l, t);
   }
   h->dw2_off[3] = tiles;
   a.C = h->B / 16;
@@ -1793,10 +1813,37 @@ int build_twin_fwd(dsact_handle* h) {
     }
     HIPCHK(h, hipMemcpy(h->d_fwdt[grp], &P, sizeof(PipeFwd), hipMemcpyHostToDevice));
   }
+  // Groups A and B in ONE launch (parallel trunks, every workgroup resident: 2 per CU): group B's units compute their
+  // observation segment while the policies run, then wait (HW_LATE) for the done flags of policy / policy_target's second
+  // trunk -- whose head wrote the sampled action into their input rows -- before the action segment. Every wait targets
+  // blocks with lower ids (A before B, first trunks before their partners): the bounded spins cannot deadlock.
+  h->twin_merged = false;
+  PipeFwd& A = *h->fwdt_host[0];
+  const PipeFwd& Bt = *h->fwdt_host[1];
+  if (h->twin_par && getenv("DSACT_TWIN_NO_MERGE") == nullptr && A.c.n_units + Bt.c.n_units <= kPipeUnits &&
+      A.n_blocks + Bt.n_blocks <= kPipeMaxBlocks && A.u[0].rg == Bt.u[0].rg) {
+    const int uoff = A.c.n_units, rg = A.u[0].rg;
+    int* done_pi = h->chain_flags + 8 * kChainFlagSlices;
+    int* done_pit = h->chain_flags + 9 * kChainFlagSlices;
+    A.u[1].done = done_pi; A.u[3].done = done_pit;     // second trunks of policy / policy_target (units 0..3: pi, pit)
+    for (int k = 0; k < Bt.c.n_units; ++k) {
+      FwdUnit u = Bt.u[k];
+      const bool target_chain = k < 2 * nq;             // group B: q_t x nq (read act2: policy_target), then q(obs, new_act) x nq
+      u.wait1 = target_chain ? done_pit : done_pi; u.wait_rows1 = 4 * rg; u.late_wait |= HW_LATE;
+      A.u[uoff + k] = u;
+    }
+    for (int b = 0; b < Bt.n_blocks; ++b) A.blk[A.n_blocks + b] = Bt.blk[b] < 0 ? -1 : Bt.blk[b] + (uoff << 16);
+    A.n_blocks += Bt.n_blocks;
+    A.c.n_units += Bt.c.n_units;
+    A.c.timeline = tl_for(h, "chain_fwd");
+    HIPCHK(h, hipMemcpy(h->d_fwdt[0], &A, sizeof(PipeFwd), hipMemcpyHostToDevice));
+    h->twin_merged = true;
+  }
   return DSACT_OK;
 }
 
 int enqueue_chain_fwd_twin(dsact_handle* h, int grp) {
+  if (grp == 1 && h->twin_merged) return DSACT_OK;
   const PipeFwd& P = *h->fwdt_host[grp];
   const int rg = P.u[0].rg;
   const size_t lds = (size_t)chain_lds(4 * (h->s_obs + h->s_act), h->cW, 4 * rg).total * sizeof(float);
@@ -1805,7 +1852,7 @@ int enqueue_chain_fwd_twin(dsact_handle* h, int grp) {
     if (h->flags_dirty) HIPCHK(h, hipMemsetAsync(h->chain_flags, 0, kChainFlags * sizeof(int), h->stream));
     h->flags_dirty = true;
   }
-  const char* name = grp == 0 ? "chain_fwd_a" : "chain_fwd_b";
+  const char* name = h->twin_merged ? "chain_fwd" : grp == 0 ? "chain_fwd_a" : "chain_fwd_b";
   const PipeFwd* dev = h->d_fwdt[grp];
 #define CALL_FT(N) return generic_act(h) ? launch(h, name, k_chain_fwdt<N, true>, dim3(P.n_blocks), dim3(64 * N), lds, dev) \
                                          : launch(h, name, k_chain_fwdt<N>, dim3(P.n_blocks), dim3(64 * N), lds, dev)
@@ -2366,6 +2413,7 @@ int enqueue_chain_bwd_pi_close(dsact_handle* h, bool fused) {
 // same contract as enqueue_grads (phases, fused optimiser, riders of the loss launch)
 int enqueue_grads_chain(dsact_handle* h, bool actor_backward, bool fused, int phase, const RideArgs* ride) {
   const int* off = h->dw2_off;
+  const bool one_dfeat = h->twin && actor_backward && (phase == 0 || phase == 2) && h->dw_chunks == 1 && h->env_ride_slots == 0;
   if (phase == 4) goto actor_part;
   if (phase != 2) {
     if (h->cnn) TRY(enqueue_conv_forward(h));
@@ -2388,7 +2436,8 @@ int enqueue_grads_chain(dsact_handle* h, bool actor_backward, bool fused, int ph
   TRY(enqueue_chain_bwd_q(h, (actor_backward ? 2 : 1) * h->nq, ride));
   // CNN nets (batch <= 1024: one gradient arena): dL/d features = dZ0 . W0[:, :F] right behind the chains that produce dZ0 and
   // before the launch whose tiles update W0; the conv stacks' backward follows the MLP part (enqueue_grads' order)
-  if (h->cnn) TRY(run_stage(h, h->dfeat_q));
+  // (full update on one gradient arena: ONE dfeat launch for the three nets behind the policy chain, see below)
+  if (h->cnn && !one_dfeat) TRY(run_stage(h, h->dfeat_q));
   if (!actor_backward) {
     if (h->dw_chunks == 1) {
       TRY(run_dw2(h, off[0], off[2], fused, fused));
@@ -2421,6 +2470,13 @@ actor_part:
     if (h->pi_merge && h->dw_chunks == 1 && ride_end == h->dw2_off[2]) {
       if (h->pipe_defer_now) return enqueue_chain_bwd_pi_close(h, fused);   // the policy backward rides in the next forward launch
       return enqueue_chain_bwd_pi(h, h->dw2_off[0], ride_end, fused, true);
+    }
+    if (one_dfeat) {
+      // riders: the critics' hidden / output layer tiles; their first-layer tiles (Adam on W0) follow the dfeat launch
+      TRY(enqueue_chain_bwd_pi(h, h->dw2_off[0], h->dw2_mid, fused));
+      TRY(run_stage(h, h->dfeat_all));
+      TRY(run_dw2(h, h->dw2_mid, h->dw2_off[3], fused, fused));
+      return enqueue_conv_backward(h, h->nq + 1, fused);
     }
     TRY(enqueue_chain_bwd_pi(h, h->dw2_off[0], ride_end, fused));
     if (h->cnn) TRY(run_stage(h, h->dfeat_pi));   // needs the policy's W0 BEFORE the fused Adam of the next launch

@@ -778,11 +778,12 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
   // (late_wait: only the action columns come from a producer -- the wait follows the observation segment)
   const bool pairs_in = (u.late_wait & HW_PAIRS_IN) != 0, pairs_out = (u.late_wait & HW_PAIRS_OUT) != 0;
   const unsigned tag = (pairs_in || pairs_out) ? (unsigned)(*a.tagp) + 1u : 0u;
-  const int* const flag0 = pairs_in ? nullptr : u.wait0;      // (tagged hand-over: wait0 is the pair buffer, not a flag array)
+  const bool head_wait = (u.late_wait & HW_HEAD) != 0;   // twin trunks as separate workgroups: wait0 = the partner trunk's flags,
+                                                         // waited for just before the row phase
+  const int* const flag0 = (pairs_in || head_wait) ? nullptr : u.wait0;      // (tagged hand-over: wait0 is the pair buffer, not a flag array)
   const bool waits = flag0 || u.wait1 || pairs_in;
-  const bool head_wait = (u.late_wait & HW_HEAD) != 0;   // twin trunks as separate workgroups: the wait precedes the row phase
-  const bool late = waits && !head_wait && (u.late_wait & HW_LATE) && u.seg != SEG_ACT_FROM_SAVED && u.s_act > 0;
-  if ((flag0 || u.wait1) && !late && !head_wait)
+  const bool late = waits && (u.late_wait & HW_LATE) && u.seg != SEG_ACT_FROM_SAVED && u.s_act > 0;
+  if ((flag0 || u.wait1) && !late)
     chain_wait(flag0 ? flag0 + row0 / u.wait_rows0 : nullptr, u.wait1 ? u.wait1 + row0 / u.wait_rows1 : nullptr, a.spin_timeout);
   f32x4 zi[RG];
   if (u.seg == SEG_ACT_FROM_SAVED) {
@@ -1067,7 +1068,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_chain_fwd2(Fwd2Args a) {
 // position in the dispatch order. A unit waits only for units that come EARLIER in every XCD's queue (the table is
 // built group by group), so the bounded spins cannot deadlock. Same body, same arithmetic per row as k_chain_fwd2.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kPipeUnits = 12;
+constexpr int kPipeUnits = 16;     // (12 roles of the pipelined graph; 16 trunk units of a merged twin-trunk forward)
 constexpr int kPipeMaxBlocks = 1536;
 struct PipeFwd {
   FwdArgs c;                        // common fields (c.u / c.map unused)
