@@ -168,6 +168,7 @@ struct dsact_handle {
   bool env_no_tile64 = false, env_no_hb_ride = false, env_no_merged_gather = false, env_no_adam_pack = false;
   int n_cu = 256;                       // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   int env_conv_dw_nkt = 1;
+  bool env_no_conv_narrow9 = false;     // DSACT_NO_CONV_NARROW9: type_2's third conv layer stays on the LDS-tile forward kernel
   bool env_conv_dw_fixed_chunk = false; // DSACT_CONV_DW_FIXED_CHUNK: every layer uses conv_dw_chunk(M) (A/B of conv_dw_pick_chunk)
   int env_ride_slots = 0;           // DSACT_RIDE_SLOTS: weight-gradient tiles riding in the policy-backward launch (default: one round)
   bool mirror_w0 = false;      // set while the merged-gather graph is being captured (see FusedOpt::mir_*)
@@ -1150,15 +1151,19 @@ int enqueue_conv_forward(dsact_handle* h) {
     }
     a.n_items = items;
     const std::string name = "conv_fwd_l" + std::to_string(j);
-    if (g.K <= 80 && per_group * g.Cout <= 32) {
+    // (K <= 144 with 32 channels -- type_2's third layer: 9 k-groups, 256 VGPRs, ONE wave per SIMD that prefetches the next
+    //  tile's 18 patch quads under its 144 MFMAs; round 4: 40.0 us on the LDS-tile kernel)
+    const bool narrow9 = g.K > 80 && g.K <= 144 && per_group * g.Cout <= 32 && !h->env_no_conv_narrow9;
+    if ((g.K <= 80 || narrow9) && per_group * g.Cout <= 32) {
       // narrow layer: wave-autonomous register tiles (k_conv_fwd_narrow); every wave works on one group
-      const int waves_total = 5120;                       // ~20 waves per CU
+      const int waves_total = narrow9 ? 4 * h->n_cu : 5120;   // ~20 waves per CU; the 9-group form: every SIMD one wave, one round
       int wpg = waves_total / a.n_prob;
       if (wpg > tiles_of(M, 32)) wpg = tiles_of(M, 32);
       a.n_items = wpg;                                    // waves per group
       const int grid = (a.n_prob * wpg + 3) / 4;
       const bool one_block = per_group * g.Cout <= 16;
-      if (g.K <= 48 && one_block) TRY(launch(h, name.c_str(), (k_conv_fwd_narrow<3, 1>), dim3(grid), dim3(kThreads), 0, a));
+      if (narrow9) TRY(launch(h, name.c_str(), (k_conv_fwd_narrow<9, 2>), dim3(grid), dim3(kThreads), 0, a));
+      else if (g.K <= 48 && one_block) TRY(launch(h, name.c_str(), (k_conv_fwd_narrow<3, 1>), dim3(grid), dim3(kThreads), 0, a));
       else if (g.K <= 48) TRY(launch(h, name.c_str(), (k_conv_fwd_narrow<3, 2>), dim3(grid), dim3(kThreads), 0, a));
       else if (one_block) TRY(launch(h, name.c_str(), (k_conv_fwd_narrow<5, 1>), dim3(grid), dim3(kThreads), 0, a));
       else TRY(launch(h, name.c_str(), (k_conv_fwd_narrow<5, 2>), dim3(grid), dim3(kThreads), 0, a));
@@ -2907,6 +2912,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (const char* v = getenv("DSACT_PIPE_RG_SIDE")) h->env_pipe_rg_side = atoi(v) == 1 ? 1 : 2;
   if (const char* v = getenv("DSACT_PIPE_MAP")) h->env_pipe_map = v;
   h->env_no_conv_dx_mfma = getenv("DSACT_NO_CONV_DX_MFMA") != nullptr;
+  h->env_no_conv_narrow9 = getenv("DSACT_NO_CONV_NARROW9") != nullptr;
   h->env_dw_4wave = getenv("DSACT_DW_4WAVE") != nullptr;
   h->env_no_ride8 = getenv("DSACT_RIDE8") == nullptr;
   if (const char* v = getenv("DSACT_CHAIN_RG")) h->env_chain_rg = atoi(v) == 1 ? 1 : atoi(v) == 4 ? 4 : 2;

@@ -818,16 +818,18 @@ __global__ void __launch_bounds__(kThreads) k_conv_dw_reduce(ConvReduceArgs a) {
   const bool qv = q < Ly.quads;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (qv) {
-    // chunk lane cl sums chunks cl, cl+CL, ...: 4 independent loads per trip
-    for (int c0 = cl; c0 < Ly.n_chunks; c0 += 4 * CL) {
-      f32x4 v[4];
+    // chunk lane cl sums chunks cl, cl+CL, ...: NU independent loads per trip (8: the ~500 chunks of the first layers were
+    // 8 dependent round trips per lane at 4; same summation order)
+    constexpr int NU = 8;
+    for (int c0 = cl; c0 < Ly.n_chunks; c0 += NU * CL) {
+      f32x4 v[NU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NU; ++u) {
         const int c = c0 + CL * u;
         v[u] = *(const f32x4u*)(t.part + ((size_t)(c < Ly.n_chunks ? c : 0) * Ly.quads + q) * 4);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) if (c0 + CL * u < Ly.n_chunks) s += v[u];
+      for (int u = 0; u < NU; ++u) if (c0 + CL * u < Ly.n_chunks) s += v[u];
     }
   }
   if (Ly.wide) {               // uniform per block
@@ -843,12 +845,28 @@ __global__ void __launch_bounds__(kThreads) k_conv_dw_reduce(ConvReduceArgs a) {
   const bool is_bias = kk == Ly.K;
   const long long oi = is_bias ? t.b_idx + co : t.w_idx + (long long)co * Ly.K + kk;
   const int nel = is_bias ? 1 : 4;
-  for (int e = 0; e < nel; ++e) fo.grads[oi + e] = s[e];
+  if (is_bias) fo.grads[oi] = s[0];
+  else *(f32x4u*)(fo.grads + oi) = s;
   if (fo.st == nullptr) return;
   const bool is_q = oi < fo.n_q2;
   const bool delayed = fo.st->do_delayed != 0;
   if (!(is_q || delayed)) return;
   const float ss = is_q ? fo.st->ss_q : fo.st->ss_pi, bc2 = is_q ? fo.st->bc2_q : fo.st->bc2_pi;
+  if (!is_bias) {   // one 16-byte access per stream instead of four 4-byte ones (same per-element arithmetic)
+    f32x4 op = *(const f32x4u*)(fo.online + oi), om = *(const f32x4u*)(fo.adam_m + oi), ov = *(const f32x4u*)(fo.adam_v + oi);
+    f32x4 ot = {0.f, 0.f, 0.f, 0.f};
+    if (delayed) ot = *(const f32x4u*)(fo.target + oi);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float pe = op[e], me = om[e], ve = ov[e];
+      adam_update(pe, me, ve, s[e], fo.b1w, fo.beta2, fo.b2w, ss, bc2, fo.eps);
+      op[e] = pe; om[e] = me; ov[e] = ve;
+      if (delayed) ot[e] = polyak_update(ot[e], pe, fo.polyak, fo.one_minus_polyak);
+    }
+    *(f32x4u*)(fo.online + oi) = op; *(f32x4u*)(fo.adam_m + oi) = om; *(f32x4u*)(fo.adam_v + oi) = ov;
+    if (delayed) *(f32x4u*)(fo.target + oi) = ot;
+    return;
+  }
   for (int e = 0; e < nel; ++e) {
     float pe = fo.online[oi + e], me = fo.adam_m[oi + e], ve = fo.adam_v[oi + e];
     adam_update(pe, me, ve, s[e], fo.b1w, fo.beta2, fo.b2w, ss, bc2, fo.eps);
