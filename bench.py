@@ -1016,7 +1016,7 @@ def main():
                       "frac_fp32": l2.flop_per_step(B) * steps / w2 / 1e12 / FP32_PEAK_TFLOPS,
                       "frac_hbm": l2.bytes_per_step(B, 2) * steps / w2 / 1e9 / HBM_PEAK_GBS}
     if rank == 0 and not use_dp and not args.no_alt and args.batch == B:
-        # the reference's DSAC_V1 (one critic) on the tile-stage kernels, same shapes
+        # the reference's DSAC_V1 (one critic) on the chain kernels + pipelined graph, same shapes
         try:
             alg1 = make_alg(hidden, local, seed=0, v1=True)
             fill_replay(alg1.engine, min(args.replay_rows, 200_000), seed=100)
