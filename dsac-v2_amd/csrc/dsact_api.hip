@@ -1568,6 +1568,7 @@ Dw2Args dw2_args(dsact_handle* h, bool fused) {
       for (int t = 0; t < ((l >= 1 && l < L) ? 2 : 1); ++t) add(2, l, t);
   }
   h->dw2_off[3] = tiles;
+  for (int q = 0; q < kMaxDwProb; ++q) a.tile_ends[q] = q < a.n_prob ? a.p[q].tile_end : tiles;
   a.C = h->B / 16;
   a.ct = a.C / h->dw_chunks;   // chunks per batch range (batch <= 256: one round of <= 16; else rounds of 16 inside the tile)
   a.n_base = tiles;

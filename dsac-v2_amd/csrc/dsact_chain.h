@@ -236,6 +236,8 @@ struct DwProb {
 constexpr int kMaxDwProb = 3 * 2 * kChMaxL;   // twin trunks: first layer + 2 x hidden layers + output layer per net
 struct Dw2Args {
   DwProb p[kMaxDwProb]; int n_prob;
+  int tile_ends[kMaxDwProb];   // p[q].tile_end again, contiguous: a tile finds its problem from two wide scalar loads instead
+                               // of one strided load per problem
   int C, ct;              // chunks (16 batch rows) per operand row tile; chunks per tile (<= 16 per round, rounds as needed)
   int n_base;             // tiles of one batch range (split-K: tile index = range * n_base + base tile)
   float* gout;            // gradient destination arena (grads; split-K: partial arena 0)
@@ -262,7 +264,7 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds, Wa
   int pi = 0;
 #pragma unroll
   for (int q = 0; q + 1 < kMaxDwProb; ++q)
-    if (q + 1 < a.n_prob && bt >= a.p[q].tile_end) pi = q + 1;
+    if (q + 1 < a.n_prob && bt >= a.tile_ends[q]) pi = q + 1;
   const DwProb& P = a.p[pi];
   const int local = bt - (pi ? a.p[pi - 1].tile_end : 0);
   const int mt = local / P.tiles_n, nt = local - mt * P.tiles_n;
@@ -1158,6 +1160,18 @@ struct BwdQArgs {
   int ldz0;                        // row stride of dz0row
 };
 
+// row-major copy of a slice's dZ[0] from its LDS image [R][ld_h] (CNN nets: the dL/d features product reads it as a plain
+// matrix). A loop of its own behind a uniform branch: the same stores inside the chains' unrolled epilogues kept 32
+// address registers alive through the whole kernel (k_chain_bwd_q<4,4>: 176 -> 208 VGPRs, one wave per SIMD instead of two)
+template <int W, int R, int NTHR>
+__device__ __forceinline__ void store_dz0_rows(float* dst, int ldz0, int row0, const float* lds_rows, int ld_h) {
+  const int tid = threadIdx.x;
+  for (int e = tid; e < R * W; e += NTHR) {
+    const int r = e / W, c = e - r * W;
+    dst[(size_t)(row0 + r) * ldz0 + c] = lds_rows[r * ld_h + c];
+  }
+}
+
 template <int NW, int RG>
 __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* lds) {
   if (a.flags_reset && threadIdx.x == 0)
@@ -1289,15 +1303,12 @@ __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* 
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) lds[S.off_h0 + (4 * g + rr) * S.ld_h + n] = ov[rr];
     nt_store4(u.dZ[L - 1] + pk_index(n, row0 + 4 * g, a.Cb), ov);
-    if (u.dz0row && L == 1) {
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) u.dz0row[(size_t)(row0 + 4 * g + rr) * a.ldz0 + n] = ov[rr];
-    }
   }
   NarrowFrags<2> af;
   const int nta = (a.A + 15) >> 4;
   if (u.w1at && L == 1) narrow_load<2>(af, u.w1at, c1at, nta, wave, lane4);
   lds_barrier();
+  if (u.dz0row && L == 1) store_dz0_rows<W, R, NTHR>(u.dz0row, a.ldz0, row0, lds + S.off_h0, S.ld_h);
   CTL(a.timeline, 2);
   // ---- hidden layers: dZ[l-1] = (dZ[l] W_l) * gelu'(z[l-1])
   f32x4 acc[RG][2];
@@ -1320,13 +1331,10 @@ __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* 
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) lds[hn + (4 * g + rr) * S.ld_h + n] = dz[rr];
       nt_store4(u.dZ[l - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz);
-      if (u.dz0row && l == 1) {
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) u.dz0row[(size_t)(row0 + 4 * g + rr) * a.ldz0 + n] = dz[rr];
-      }
     }
     cur ^= 1;
     lds_barrier();
+    if (u.dz0row && l == 1) store_dz0_rows<W, R, NTHR>(u.dz0row, a.ldz0, row0, lds + hn, S.ld_h);
     CTL(a.timeline, 4 + 2 * (L - 1 - l));
   }
   if (!u.w1at) return;
@@ -1471,12 +1479,9 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) lds[S.off_h0 + (4 * g + rr) * S.ld_h + n] = dz[rr];
       pack_store4(t_dZ[L - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz, agent);
-      if (dz0row && L == 1) {
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) dz0row[(size_t)(row0 + 4 * g + rr) * a.ldz0 + n] = dz[rr];
-      }
     }
     lds_barrier();
+    if (dz0row && L == 1) store_dz0_rows<W, R, NTHR>(dz0row, a.ldz0, row0, lds + S.off_h0, S.ld_h);
     CTL(a.timeline, 2);
   }
   int cur = 0;
@@ -1496,13 +1501,10 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) lds[hn + (4 * g + rr) * S.ld_h + n] = dz[rr];
       pack_store4(t_dZ[l - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz, agent);
-      if (dz0row && l == 1) {
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) dz0row[(size_t)(row0 + 4 * g + rr) * a.ldz0 + n] = dz[rr];
-      }
     }
     cur ^= 1;
-    if (l > 1) lds_barrier();
+    if (l > 1 || dz0row) lds_barrier();
+    if (dz0row && l == 1) store_dz0_rows<W, R, NTHR>(dz0row, a.ldz0, row0, lds + hn, S.ld_h);
     CTL(a.timeline, 3 + (L - 1 - l));
   }
   CTLR(a.timeline, 15);
@@ -1543,12 +1545,9 @@ template <int NW, int RG>
 __global__ void __launch_bounds__(256) k_chain_bwd_pi(BwdPiArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if ((int)blockIdx.x >= a.n_chain_blocks) { bwd_pi_tail_blocks(a, (int)blockIdx.x - a.n_chain_blocks, lds); return; }
-  if (a.n_trunks == 2) {
-    const int per = a.n_chain_blocks >> 1, b = (int)blockIdx.x;
-    bwd_pi_body<NW, RG>(a, b >= per ? b - per : b, lds, b >= per ? 1 : 0);
-    return;
-  }
-  bwd_pi_body<NW, RG>(a, (int)blockIdx.x, lds);
+  const int per = a.n_chain_blocks >> 1, b = (int)blockIdx.x;
+  const int trunk = (a.n_trunks == 2 && b >= per) ? 1 : 0;   // (one inlined body: the trunk's pointers are scalar selects)
+  bwd_pi_body<NW, RG>(a, trunk ? b - per : b, lds, trunk);
 }
 // The same launch 512 threads wide (unmerged form, long contractions: batch >= 1024): a riding weight-gradient tile runs
 // EIGHT waves, two per SIMD, that hide each other's operand waits (what k_dw2<2, 8> does for the policy's own tiles:
@@ -1565,12 +1564,9 @@ __global__ void __launch_bounds__(512) k_chain_bwd_pi8(BwdPiArgs a) {
     dw2_tile<2, NoWait, 8>(a.dw, (idx / per_range) * a.dw.n_base + a.tile0 + t, lds);
     return;
   }
-  if (a.n_trunks == 2) {
-    const int per = a.n_chain_blocks >> 1, b = (int)blockIdx.x;
-    bwd_pi_body<NW, RG>(a, b >= per ? b - per : b, lds, b >= per ? 1 : 0);
-    return;
-  }
-  bwd_pi_body<NW, RG>(a, (int)blockIdx.x, lds);
+  const int per = a.n_chain_blocks >> 1, b = (int)blockIdx.x;
+  const int trunk = (a.n_trunks == 2 && b >= per) ? 1 : 0;   // (one inlined body: the trunk's pointers are scalar selects)
+  bwd_pi_body<NW, RG>(a, trunk ? b - per : b, lds, trunk);
 }
 
 

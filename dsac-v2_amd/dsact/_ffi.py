@@ -10,6 +10,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libdsact.so")
+if os.environ.get("DSACT_LIB_PATH"):   # A/B runs against another build of the same ABI (scripts/): never a fallback
+    LIB_PATH = os.environ["DSACT_LIB_PATH"]
 
 MAX_HIDDEN = 6
 F_SKIP_ACTOR_ON_OFF_ITERS = 1
