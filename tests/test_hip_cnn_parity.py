@@ -284,3 +284,96 @@ def test_cnn_load_batch_from_cuda_tensors_equals_host_staging():
     for k in ("obs", "act", "rew", "obs2", "done"):
         assert np.array_equal(outs[0][k], outs[1][k]), k
         assert np.array_equal(outs[0][k].reshape(-1), data[k].numpy().reshape(-1)), k
+
+
+def _cnn_ring_alg(B, seed, rows=96):
+    """DSAC_V2 with CNN nets, a filled image replay ring, an index table and the device RNG: ready for graph replays."""
+    alg, _, cfg = make_pair((3, 96, 96), 3, "type_2", B, seed=seed)
+    e = alg.engine
+    e.set_device_rng(4242)
+    e.buffer_create(rows)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    O = 3 * 96 * 96
+    e.buffer_fill_device(0, torch.rand(rows, O, device="cuda", generator=g), torch.rand(rows, 3, device="cuda", generator=g) * 2 - 1,
+                         torch.randn(rows, device="cuda", generator=g), torch.rand(rows, O, device="cuda", generator=g),
+                         (torch.rand(rows, device="cuda", generator=g) < .1).float())
+    np.random.seed(2)
+    e.upload_index_table(np.random.randint(0, rows, size=(6, B)))
+    return alg
+
+
+@pytest.mark.parametrize("B", [16, 64])
+def test_cnn_twin_trunk_launch_forms_agree(B, monkeypatch):
+    """The twin trunks as chain units in their three launch forms -- both trunks of a net in one workgroup (DSACT_TWIN_SEQ),
+    the trunks as workgroups of their own with groups A and B as two launches (DSACT_TWIN_NO_MERGE), and everything in one
+    forward launch (default) -- are the same arithmetic: parameters, targets and optimiser state bit for bit."""
+    states = []
+    for env in ({"DSACT_TWIN_SEQ": "1"}, {"DSACT_TWIN_NO_MERGE": "1"}, {}):
+        for k in ("DSACT_TWIN_SEQ", "DSACT_TWIN_NO_MERGE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        alg = _cnn_ring_alg(B, seed=5)
+        e = alg.engine
+        assert e.chain_active
+        ms = e.time_steps(0, 5, use_graph=False)
+        assert ms > 0
+        e.sync()
+        states.append({n: getattr(e, n).clone() for n in ("online", "target", "adam_m", "adam_v")})
+        assert torch.isfinite(states[-1]["online"]).all()
+    for s in states[1:]:
+        for n in s:
+            assert torch.equal(states[0][n], s[n]), n
+
+
+def test_cnn_graph_replay_equals_eager_steps():
+    """hipGraph replays of the CNN update (image gather + conv stacks + twin-trunk chains + conv backward per update) == eager
+    updates, bit for bit."""
+    algs = []
+    for mode in ("eager", "graph"):
+        alg = _cnn_ring_alg(32, seed=6)
+        e = alg.engine
+        if mode == "graph":
+            e.graph_build(3)
+            e.graph_run(0, 6)
+        else:
+            assert e.time_steps(0, 6, use_graph=False) > 0
+        e.sync()
+        algs.append(alg)
+    for name in ("online", "target", "adam_m", "adam_v"):
+        assert torch.equal(getattr(algs[0].engine, name), getattr(algs[1].engine, name)), name
+    assert algs[0].engine.get_state() == algs[1].engine.get_state()
+
+
+def test_cnn_data_parallel_halves_equal_fused_steps():
+    """The data-parallel seams on the CNN chain path (critic half -> all-reduce -> actor half -> all-reduce -> streaming Adam; world
+    size 1) == the fused eager updates, bit for bit: the split flow forms dL/d features per half (dfeat_q, dfeat_pi) where the
+    fused flow has one launch for the three nets."""
+    import torch.distributed as dist
+    from dsact.dp import DataParallelUpdater
+
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29537")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        created = True
+    try:
+        a1 = _cnn_ring_alg(16, seed=7)
+        assert a1.engine.time_steps(0, 4, use_graph=False) > 0
+        a1.engine.sync()
+        for overlap in (False, True):
+            a2 = _cnn_ring_alg(16, seed=7)
+            e = a2.engine
+            dp = DataParallelUpdater(e, broadcast_tensors=(e.online, e.target, e.adam_m, e.adam_v), overlap=overlap)
+            dp.force_collective = True
+            e.dp_begin(0)
+            for _ in range(4):
+                dp.step()
+            torch.cuda.synchronize()
+            for name in ("online", "target", "adam_m", "adam_v"):
+                assert torch.equal(getattr(a1.engine, name), getattr(e, name)), (name, overlap)
+            assert a1.engine.get_state() == e.get_state()
+    finally:
+        if created:
+            dist.destroy_process_group()
