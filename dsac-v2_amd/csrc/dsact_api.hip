@@ -167,7 +167,8 @@ struct dsact_handle {
   std::string env_timeline_stage;   // DSACT_TIMELINE_STAGE
   bool env_no_tile64 = false, env_no_hb_ride = false, env_no_merged_gather = false, env_no_adam_pack = false;
   int n_cu = 256;                       // compute units of the device (hipDeviceAttributeMultiprocessorCount)
-  int env_conv_dw_nkt = 1;
+  int env_conv_dw_nkt = 0;
+  int conv_dw_nkt_l[kMaxConv] = {1, 1, 1, 1, 1, 1};   // k-tiles per k_conv_dw workgroup, per layer (DSACT_CONV_DW_NKT_L=a,b,..; DSACT_CONV_DW_NKT: all)
   bool env_no_conv_narrow9 = false;     // DSACT_NO_CONV_NARROW9: type_2's third conv layer stays on the LDS-tile forward kernel
   bool env_conv_dw_fixed_chunk = false; // DSACT_CONV_DW_FIXED_CHUNK: every layer uses conv_dw_chunk(M) (A/B of conv_dw_pick_chunk)
   int env_ride_slots = 0;           // DSACT_RIDE_SLOTS: weight-gradient tiles riding in the policy-backward launch (default: one round)
@@ -1195,16 +1196,17 @@ int conv_dw_pick_chunk(const dsact_handle* h, int j, int n_st) {
   const ConvGeom& g = h->cg[j];
   const long long M = (long long)h->B * g.OH * g.OW;
   const int c0 = (int)conv_dw_chunk((size_t)M);
-  if (h->env_conv_dw_fixed_chunk || h->env_conv_dw_nkt != 1) return c0;
+  if (h->env_conv_dw_fixed_chunk) return c0;
+  const int nkt = h->conv_dw_nkt_l[j];
   const int per_prob = j == 0 ? n_st : 1, n_prob = n_st / per_prob;
-  const long long per_chunk = (long long)tiles_of(per_prob * g.Cout, TM) * tiles_of(g.K + 4, TN) * n_prob;
-  const long long slots = 4LL * h->n_cu;
+  const long long per_chunk = (long long)tiles_of(per_prob * g.Cout, TM) * tiles_of(tiles_of(g.K + 4, TN), nkt) * n_prob;
+  const long long slots = (nkt == 1 ? 4LL : 2LL) * h->n_cu;   // 2 x (1 + nkt) LDS tiles of 9 KB per workgroup
   int best = c0;
   double best_cost = 1e30;
   for (int c = c0; c <= 16 * c0 && c <= 8192; c += 64) {
     const long long blocks = ((M + c - 1) / c) * per_chunk;
     const long long rounds = (blocks + slots - 1) / slots;
-    const double cost = (double)rounds * (3.0 + 1.1 * (c / 64));
+    const double cost = (double)rounds * (3.0 + 1.1 * (c / 64) * (nkt == 1 ? 1.0 : 0.6 + 0.4 * nkt));
     if (cost < best_cost - 1e-9) { best_cost = cost; best = c; }
   }
   return best;
@@ -1237,7 +1239,7 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
       const int kt_all = tiles_of(a.K1p, TN);
       // k-tiles per workgroup (the dY tile would be staged once for all of them): measured slower than one
       // k-tile per workgroup on every layer (fewer, longer dependent chains) -> 1
-      const int nkt = h->env_conv_dw_nkt;
+      const int nkt = h->conv_dw_nkt_l[j];
       a.tiles_k = tiles_of(kt_all, nkt);             // k-groups
       int blocks = 0;
       // layer 0: every differentiated stack reads the staged `obs` image -> one problem, dY rows concatenated
@@ -2897,6 +2899,22 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->env_no_adam_pack = getenv("DSACT_NO_ADAM_PACK") != nullptr;
   { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && v > 0) h->n_cu = v; (void)hipGetLastError(); }
   if (const char* v = getenv("DSACT_CONV_DW_NKT")) h->env_conv_dw_nkt = atoi(v);
+  for (int j = 0; j < kMaxConv; ++j) h->conv_dw_nkt_l[j] = h->env_conv_dw_nkt;   // (0: the per-layer default, set below once the geometry is known)
+  if (const char* v = getenv("DSACT_CONV_DW_NKT_L")) {
+    int j = 0;
+    for (const char* p = v; *p && j < kMaxConv; ++j) {
+      const int n = atoi(p);
+      if (n >= 1 && n <= 3) h->conv_dw_nkt_l[j] = n;
+      while (*p && *p != ',') ++p;
+      if (*p == ',') ++p;
+    }
+  }
+  // default: two k-tiles per workgroup (the dY tile of a step is staged once for both) unless the layer has three -- a 2 + 1
+  // split leaves the odd workgroups half as long (measured at type_2, batch 256, profiles/r04_convdw_nkt.txt: layers
+  // 0 / 2 / 3 / 4 / 5 35.5 / 24.0 / 16.6 / 19.6 / 12.7 -> 33.3 / 20.4 / 15.5 / 19.0 / 12.3 us, layer 1 36.6 -> 44.2)
+  for (int j = 0; j < h->n_conv; ++j)
+    if (h->conv_dw_nkt_l[j] < 1 || h->conv_dw_nkt_l[j] > 3) h->conv_dw_nkt_l[j] = tiles_of(h->cg[j].K + 4, TN) == 3 ? 1 : 2;
+  for (int j = h->n_conv; j < kMaxConv; ++j) h->conv_dw_nkt_l[j] = 1;
   h->env_conv_dw_fixed_chunk = getenv("DSACT_CONV_DW_FIXED_CHUNK") != nullptr;
   if (const char* v = getenv("DSACT_RIDE_SLOTS")) h->env_ride_slots = atoi(v);
   if (const char* v = getenv("DSACT_CHAIN_RG_PI")) h->env_chain_rg_pi = atoi(v);
@@ -3000,6 +3018,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   for (int j = 0; j <= kMaxConv; ++j) HIPCHK(h, hipEventCreateWithFlags(&h->ev_conv[j], hipEventDisableTiming));
   h->conv_fork = h->cnn && getenv("DSACT_CONV_FORK") != nullptr;
+  if (h->conv_fork) for (int j = 0; j < kMaxConv; ++j) h->conv_dw_nkt_l[j] = 1;   // (the second-queue launches are the one-k-tile form)
   h->use_fork = getenv("DSACT_FORK") != nullptr && !h->cnn && h->dw_chunks == 1;  // measured: a forked graph branch costs +20 us/update (cross-queue signals) -> opt-in only
   {
     const int max_lds = (int)tile_lds_bytes(BK * kMaxPrefetchTiles);  // 129 KB of the CU's 160 KB
