@@ -280,8 +280,9 @@ int dsact_time_steps(dsact_handle* h, int64_t first_iteration, int64_t n_steps, 
  * returns the stage's algorithmic multiply-accumulate count. Leaves the activations of that stage
  * overwritten (measurement only). */
 int dsact_time_stage(dsact_handle* h, int32_t stage, int32_t reps, float* ms_total, double* macs);
-/* 1 when this handle runs the update as row-slice fused chains (csrc/dsact_chain.h: MLP nets of DSAC_V2 with equal
- * hidden widths of 64 / 128 / 256 and batch % 16 == 0; DSACT_NO_CHAIN=1 forces the per-layer tile stages), else 0.
+/* 1 when this handle runs the update's MLP layers as row-slice fused chains (csrc/dsact_chain.h: DSAC_V2 / DSAC_V1 with equal
+ * hidden widths of 64 / 128 / 256 and batch % 16 == 0 -- MLP nets, or the twin mean / log_std trunks of the CNN nets behind
+ * their conv stacks at batch <= 1024; DSACT_NO_CHAIN=1 / DSACT_NO_CHAIN_CNN=1 force the per-layer tile stages), else 0.
  * Both paths replace the same reference functions (dsac_v2.py:150-347) and fill the same debug buffers. */
 int dsact_chain_active(const dsact_handle* h);
 /* per-kernel hipEvent timing of ONE eager step: fills up to `cap` entries; returns count in *n */
