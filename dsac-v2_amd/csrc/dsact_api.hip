@@ -1788,6 +1788,7 @@ int build_twin_fwd(dsact_handle* h) {
     c.act_scale = h->act_scale; c.act_center = h->act_center; c.lo_ls = h->cfg.min_log_std; c.hi_ls = h->cfg.max_log_std;
     c.timeline = tl_for(h, name);
     c.spin_timeout = h->handoff_dev;
+    c.debug_withhold = h->debug_withhold == 1;   // tests: the first trunk of the policy never raises slice 0's flag
     const int n_slices = h->B / (4 * rg);
     if (par) {
       // XCDs 0-3 run the first trunks, 4-7 the second ones; the nets share each half (rep XCDs per net, slices dealt
@@ -2779,11 +2780,17 @@ int check_handoff(dsact_handle* h) {
   h->pi_merge = false;
   h->handoff_failures += 1;
   drop_graphs(h);
+  int twin_rc = DSACT_OK;
+  if (h->twin_par) {   // CNN nets: both trunks of a net in one workgroup, groups A and B as two launches -- no in-launch waits left
+    h->env_twin_seq = true;
+    h->debug_withhold = 0;
+    twin_rc = build_twin_fwd(h);
+  }
   hipError_t e_set = hipSuccess;
   if (h->chain_flags) e_set = hipMemset(h->chain_flags, 0, kChainFlagInts * sizeof(int));
   h->flags_dirty = false;
   int rebuilt = DSACT_E_STATE;
-  if (had_graph) rebuilt = dsact_graph_build(h, steps, gflags);
+  if (had_graph && twin_rc == DSACT_OK) rebuilt = dsact_graph_build(h, steps, gflags);
   h->in_handoff = false;
   h->state_invalid = true;   // (after the re-capture: dsact_graph_build itself is an entry point that refuses an invalid state)
   const hipError_t e_hip = e_dev != hipSuccess ? e_dev : e_sync != hipSuccess ? e_sync : e_set;
@@ -4304,6 +4311,7 @@ int dsact_debug_set(dsact_handle* h, const char* name, double value) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     drop_graphs(h);   // the switch travels in the kernel arguments
     h->debug_withhold = (int)value;   // 1: a forward producer's ready flag; 2: a policy-backward slice's arrival
+    if (h->twin && h->online) TRY(build_twin_fwd(h));   // (the twin-trunk forward reads the switch from its device-memory table)
     return DSACT_OK;
   }
   if (!strcmp(name, "poison_handover")) {
@@ -4347,6 +4355,7 @@ int dsact_debug_get(const dsact_handle* h, const char* name, double* value) {
   else if (!strcmp(name, "graph_steps")) *value = (double)h->graph_steps;
   else if (!strcmp(name, "pipe_graph")) *value = h->pipe_graph ? 1.0 : 0.0;   // the captured graphs are the pipelined ones
   else if (!strcmp(name, "state_invalid")) *value = h->state_invalid ? 1.0 : 0.0;
+  else if (!strcmp(name, "twin_par")) *value = (h->twin_par ? 1.0 : 0.0) + (h->twin_merged ? 2.0 : 0.0);   // CNN nets: trunks as own workgroups (+2: one launch)
   else return DSACT_E_INVALID;
   return DSACT_OK;
 }

@@ -377,3 +377,42 @@ def test_cnn_data_parallel_halves_equal_fused_steps():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_cnn_twin_trunk_handover_timeout_fails_the_call_and_falls_back():
+    """A first trunk that never raises its flag (debug switch): its partner gives up after the bounded spin, the next
+    synchronising entry point FAILS the call, the handle refuses to train on until the state is restored, and falls back to
+    the form without in-launch waits (both trunks of a net in one workgroup, groups A and B as two launches) -- from restored
+    state bit-identical to an engine that never failed."""
+    from dsact._ffi import DsactError
+
+    alg, ref = _cnn_ring_alg(16, seed=8), _cnn_ring_alg(16, seed=8)
+    e, r = alg.engine, ref.engine
+    assert e.debug_get("twin_par") == 3.0
+    snap = {k: v.clone() for k, v in alg.networks.state_dict().items()}
+    arenas = {n: getattr(e, n).clone() for n in ("adam_m", "adam_v")}
+    state = e.get_state()
+    e.debug_set("withhold_flag", 1)
+    with pytest.raises(DsactError, match="hand-over timed out"):
+        e.time_steps(0, 1, use_graph=False)   # (raised here or by the next synchronising entry point)
+        e.sync()
+    assert e.debug_get("handoff_failures") == 1.0 and e.debug_get("twin_par") == 0.0 and e.debug_get("state_invalid") == 1.0
+    with pytest.raises(DsactError, match="invalid after a hand-over timeout"):
+        e.time_steps(0, 1, use_graph=False)
+    r.time_steps(0, 1, use_graph=False)   # the same index-table cursor as the failed engine
+    r.sync()
+    for a_, x in ((alg, e), (ref, r)):
+        a_.networks.load_state_dict(snap)
+        for n, t in arenas.items():
+            getattr(x, n).copy_(t)
+        torch.cuda.synchronize()
+        x.set_state(adam_steps=state["adam_steps"], mean_std=state["mean_std"])
+    assert e.debug_get("state_invalid") == 0.0
+    names = [k for k, _, _ in e.profile_step(0)]
+    assert "chain_fwd_a" in names and "chain_fwd_b" in names
+    r.profile_step(0)
+    for x in (e, r):
+        x.time_steps(0, 3, use_graph=False)
+        x.sync()
+    for name in ("online", "target", "adam_m", "adam_v"):
+        assert torch.equal(getattr(e, name), getattr(r, name)), name
