@@ -1030,7 +1030,8 @@ int run_stage(dsact_handle* h, const Stage& s0, int x0 = 0, int x1 = 0, bool fus
   s.args.n_extra = x1 > x0 ? x1 - x0 : 0;
   s.args.fo = fused_opt(h, fused);
   // large batches: 64x64 tiles (k_stage64) when every problem of the stage allows it and nothing rides along
-  if (s.args.n_extra == 0 && (s.kind == 0 || s.kind == 1) && !h->env_no_tile64) {
+  // (kind 2, plain store: the conv data gradient's dCol products -- many 32 x 32 tiles with a contraction of only 64-256)
+  if (s.args.n_extra == 0 && (s.kind == 0 || s.kind == 1 || (s.kind == 2 && s.name.compare(0, 9, "conv_dcol") == 0)) && !h->env_no_tile64) {
     bool ok = true;
     int blocks = 0;
     StageArgs a64 = s.args;
@@ -1049,6 +1050,7 @@ int run_stage(dsact_handle* h, const Stage& s0, int x0 = 0, int x1 = 0, bool fus
     }
     if (ok) {
       if (s.kind == 0) return launch(h, s.name.c_str(), k_stage64<false, EPI_GELU>, dim3(blocks), dim3(kThreads64), tile64_lds_bytes(), a64);
+      if (s.kind == 2) return launch(h, s.name.c_str(), k_stage64<true, EPI_STORE>, dim3(blocks), dim3(kThreads64), tile64_lds_bytes(), a64);
       return launch(h, s.name.c_str(), k_stage64<true, EPI_MULG>, dim3(blocks), dim3(kThreads64), tile64_lds_bytes(), a64);
     }
   }
@@ -3113,6 +3115,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<false, EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<true, EPI_MULG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<true, EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
   }
   HIPCHK(h, hipHostMalloc((void**)&h->handoff_host, 1024, hipHostMallocMapped));
   memset(h->handoff_host, 0, 1024);

@@ -1021,7 +1021,8 @@ __device__ __forceinline__ void run_tile64(const GemmProb& t, int m0, int n0, fl
   for (int mb = 0; mb < 2; ++mb) {
     const int m = m0 + wr * 32 + mb * 16 + i;
     if (EPI == EPI_GELU) epv[mb] = gload4(t.aux + n);
-    else epv[mb] = gload4(t.aux + (size_t)m * t.ldaux + n);
+    else if (EPI == EPI_MULG) epv[mb] = gload4(t.aux + (size_t)m * t.ldaux + n);
+    else epv[mb] = zero;   // EPI_STORE: plain store (round 4: the conv data gradient's dCol = dY . W on 64 x 64 tiles)
   }
   f32x4 acc[2] = {zero, zero};
   f32x4 p0, p1, q0, q1;
@@ -1056,8 +1057,10 @@ __device__ __forceinline__ void run_tile64(const GemmProb& t, int m0, int n0, fl
       act4(t.act, acc[mb] + epv[mb], hv, gd);
       *(f32x4u*)c0 = hv;
       *(f32x4u*)(t.C1 + (size_t)m * t.ldc + n) = gd;
-    } else {
+    } else if (EPI == EPI_MULG) {
       *(f32x4u*)c0 = acc[mb] * epv[mb];
+    } else {
+      *(f32x4u*)c0 = acc[mb];
     }
   }
 }
