@@ -169,6 +169,7 @@ struct dsact_handle {
   int n_cu = 256;                       // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   int env_conv_dw_nkt = 0;
   int conv_dw_nkt_l[kMaxConv] = {1, 1, 1, 1, 1, 1};   // k-tiles per k_conv_dw workgroup, per layer (DSACT_CONV_DW_NKT_L=a,b,..; DSACT_CONV_DW_NKT: all)
+  bool env_no_conv_fwd64 = false;       // DSACT_NO_CONV_FWD64: wide conv layers' forward on the 32 x 32 tile kernel
   bool env_no_conv_narrow9 = false;     // DSACT_NO_CONV_NARROW9: type_2's third conv layer stays on the LDS-tile forward kernel
   bool env_conv_dw_fixed_chunk = false; // DSACT_CONV_DW_FIXED_CHUNK: every layer uses conv_dw_chunk(M) (A/B of conv_dw_pick_chunk)
   int env_ride_slots = 0;           // DSACT_RIDE_SLOTS: weight-gradient tiles riding in the policy-backward launch (default: one round)
@@ -1170,6 +1171,15 @@ int enqueue_conv_forward(dsact_handle* h) {
       else if (g.K <= 48) TRY(launch(h, name.c_str(), (k_conv_fwd_narrow<3, 2>), dim3(grid), dim3(kThreads), 0, a));
       else if (one_block) TRY(launch(h, name.c_str(), (k_conv_fwd_narrow<5, 1>), dim3(grid), dim3(kThreads), 0, a));
       else TRY(launch(h, name.c_str(), (k_conv_fwd_narrow<5, 2>), dim3(grid), dim3(kThreads), 0, a));
+      continue;
+    }
+    // wide layers: 64 x 64 tiles when they divide the problem and still give every CU a workgroup (type_2 layers 3, 4)
+    if (per_group == 1 && M % 64 == 0 && g.Cout % 64 == 0 && g.K % 4 == 0 && !h->env_no_conv_fwd64 &&
+        (long long)a.n_prob * (M / 64) * (g.Cout / 64) >= 256) {
+      int it64 = 0;
+      for (int q = 0; q < a.n_prob; ++q) { it64 += (M / 64) * (g.Cout / 64); a.p[q].item_end = it64; a.p[q].tiles_n = g.Cout / 64; }
+      a.n_items = it64;
+      TRY(launch(h, name.c_str(), k_conv_fwd64, dim3(it64), dim3(kThreads64), tile64_lds_bytes(), a));
       continue;
     }
     TRY(launch(h, name.c_str(), k_conv_fwd, dim3(conv_fwd_grid(items)), dim3(kThreads), 0, a));
@@ -2941,6 +2951,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (const char* v = getenv("DSACT_PIPE_MAP")) h->env_pipe_map = v;
   h->env_no_conv_dx_mfma = getenv("DSACT_NO_CONV_DX_MFMA") != nullptr;
   h->env_no_conv_narrow9 = getenv("DSACT_NO_CONV_NARROW9") != nullptr;
+  h->env_no_conv_fwd64 = getenv("DSACT_NO_CONV_FWD64") != nullptr;
   h->env_dw_4wave = getenv("DSACT_DW_4WAVE") != nullptr;
   h->env_no_ride8 = getenv("DSACT_RIDE8") == nullptr;
   if (const char* v = getenv("DSACT_CHAIN_RG")) h->env_chain_rg = atoi(v) == 1 ? 1 : atoi(v) == 4 ? 4 : 2;
@@ -3116,6 +3127,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<false, EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<true, EPI_MULG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<true, EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_conv_fwd64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
   }
   HIPCHK(h, hipHostMalloc((void**)&h->handoff_host, 1024, hipHostMallocMapped));
   memset(h->handoff_host, 0, 1024);

@@ -186,6 +186,77 @@ __global__ void __launch_bounds__(kThreads) k_conv_fwd(ConvStageArgs s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward, wide layers (round 4): 64 (pixels) x 64 (channels) tiles, 512 threads -- run_tile64's structure (dsact_kernels.h:
+// 8 waves, wave (wr, wc) owns rows wr*32..+31 x columns wc*16..+15, k-tiles of 64 double-buffered through LDS with the next
+// tile's loads in flight) with the patch operand gathered through conv_rowoff / conv_kmap. Half the operand bytes per FLOP
+// of the 32 x 32 tiles above; layers with M % 64 == 0, Cout % 64 == 0 and one net per group (type_2 layers 3, 4).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads64) k_conv_fwd64(ConvStageArgs s) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const ConvGeom& g = s.g;
+  const int b = (int)blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int q = 0; q + 1 < kMaxConvProb; ++q)
+    if (q + 1 < s.n_prob && b >= s.p[q].item_end) pi = q + 1;
+  const ConvGroup& t = s.p[pi];
+  const int local = b - (pi ? s.p[pi - 1].item_end : 0);
+  const int tn = g.Cout >> 6;
+  const int mt = local / tn, nt = local - mt * tn;
+  const int m0 = mt * 64, n0 = nt * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int i = lane & 15, gq = lane >> 4;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const int T = (g.K + BK - 1) / BK;
+  // this thread's two patch rows (pixels) and two weight rows (channels) of every k-tile; k quad (tid & 15)
+  const float* pa = t.in + conv_rowoff(g, s.ix, m0 + (tid >> 4));
+  const float* pb = t.in + conv_rowoff(g, s.ix, m0 + (tid >> 4) + 32);
+  const float* qa = t.w[0] + (size_t)(n0 + (tid >> 4)) * g.K;
+  const float* qb = qa + (size_t)32 * g.K;
+  auto load = [&](int kt, f32x4& p0, f32x4& p1, f32x4& q0, f32x4& q1) {
+    const int k = kt * BK + (tid & 15) * 4;
+    const int kc = k < g.K ? k : 0;             // (K % 4 == 0: a quad is inside or outside; outside: masked at store time)
+    const int km = conv_kmap(g, kc);
+    p0 = *(const f32x4u*)(pa + km); p1 = *(const f32x4u*)(pb + km);
+    q0 = *(const f32x4u*)(qa + kc); q1 = *(const f32x4u*)(qb + kc);
+  };
+  const int n = n0 + wc * 16 + 4 * gq;
+  const f32x4 bv = *(const f32x4u*)(t.bias[0] + n);
+  f32x4 acc[2] = {zero, zero};
+  f32x4 p0, p1, q0, q1;
+  load(0, p0, p1, q0, q1);
+  for (int kt = 0; kt < T; ++kt) {
+    float* Ps = lds + (kt & 1) * 2 * TILE64_LDS;
+    float* Qs = Ps + TILE64_LDS;
+    if (!(kt * BK + (tid & 15) * 4 < g.K)) { p0 = zero; p1 = zero; q0 = zero; q1 = zero; }
+    tile64_store_lds<false>(Ps, tid, p0, p1);
+    tile64_store_lds<false>(Qs, tid, q0, q1);
+    __syncthreads();
+    if (kt + 1 < T) load(kt + 1, p0, p1, q0, q1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const f32x4 q = frag_read(Qs, wc * 16 + i, kk, gq);
+      const f32x4 xa = frag_read(Ps, wr * 32 + i, kk, gq);
+      const f32x4 xb = frag_read(Ps, wr * 32 + 16 + i, kk, gq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[e], xa[e], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[e], xb[e], acc[1], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const int m = m0 + wr * 32 + mb * 16 + i;
+    f32x4 o = acc[mb] + bv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
+    *(f32x4u*)(t.out[0] + (size_t)m * g.Cout + n) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward, narrow layers (K <= 16*NKK <= 80, n_sub*Cout <= 32: the first two layers of conv type_2, which
 // hold 2/3 of the stack's pixels): WAVE-autonomous tiles, no LDS, no barriers. A lane (i = lane&15,
 // g = lane>>4) feeds the matrix core with row i of both operands and the four k = 16*kk + 4*g + e of MFMA
