@@ -571,6 +571,8 @@ struct FwdUnit {
   float* logits; float* logp; const float* eps;   // policy head: [B][2A], [B], [B][A]
   float* xact; float* xact2;        // policy head: rows whose action columns (at F) receive the sampled action
   float* qout; float* qstd;         // q head: raw (mean, pre-softplus std) [B][2]; (std, d std/d raw) [B][2] or nullptr
+                                    // (a HEAD_TWIN_FIRST unit has no head of its own: qout != nullptr = the [B][64] buffer its partial
+                                    //  outputs go to when the partner trunk is another workgroup -- whose zinit reads it, late_wait & HW_HEAD)
   float* part_heads;                // policy head: [slices][2] sums of tanh(mu), sigma; nullptr: none
   // merged A+B launch (k_chain_fwd2): a producer raises done[slice] when everything it wrote is visible chip-wide; a
   // consumer waits for wait0/wait1[its first row / wait_rows] before it reads what the producers wrote. nullptr: no flags
