@@ -169,6 +169,8 @@ struct dsact_handle {
   int n_cu = 256;                       // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   int env_conv_dw_nkt = 0;
   int conv_dw_nkt_l[kMaxConv] = {1, 1, 1, 1, 1, 1};   // k-tiles per k_conv_dw workgroup, per layer (DSACT_CONV_DW_NKT_L=a,b,..; DSACT_CONV_DW_NKT: all)
+  int env_conv_fwd64_min = 256;         // DSACT_CONV_FWD64_MIN: fewest 64 x 64 tiles a conv forward launch must have to use them
+  int env_dcol64_min_m = 256;           // DSACT_DCOL64_MIN_M: fewest rows of a dCol product for the 64 x 64 stage tiles (layer 5 at batch 256: 11.4 -> 8.9 us)
   bool env_no_conv_fwd64 = false;       // DSACT_NO_CONV_FWD64: wide conv layers' forward on the 32 x 32 tile kernel
   bool env_no_conv_narrow9 = false;     // DSACT_NO_CONV_NARROW9: type_2's third conv layer stays on the LDS-tile forward kernel
   bool env_conv_dw_fixed_chunk = false; // DSACT_CONV_DW_FIXED_CHUNK: every layer uses conv_dw_chunk(M) (A/B of conv_dw_pick_chunk)
@@ -1043,7 +1045,7 @@ int run_stage(dsact_handle* h, const Stage& s0, int x0 = 0, int x1 = 0, bool fus
         const int K4 = (K + 3) & ~3;
         if (s.kind == 0 && g.ldp >= K4 && g.ldq >= K4) K = K4; else ok = false;
       }
-      ok = ok && g.M >= 512 && g.M % 64 == 0 && g.N % 64 == 0;
+      ok = ok && g.M >= (s.kind == 2 ? h->env_dcol64_min_m : 512) && g.M % 64 == 0 && g.N % 64 == 0;
       g.K = K;
       g.tiles_n = g.N / 64;
       blocks += (g.M / 64) * g.tiles_n;
@@ -1175,7 +1177,7 @@ int enqueue_conv_forward(dsact_handle* h) {
     }
     // wide layers: 64 x 64 tiles when they divide the problem and still give every CU a workgroup (type_2 layers 3, 4)
     if (per_group == 1 && M % 64 == 0 && g.Cout % 64 == 0 && g.K % 4 == 0 && !h->env_no_conv_fwd64 &&
-        (long long)a.n_prob * (M / 64) * (g.Cout / 64) >= 256) {
+        (long long)a.n_prob * (M / 64) * (g.Cout / 64) >= h->env_conv_fwd64_min) {
       int it64 = 0;
       for (int q = 0; q < a.n_prob; ++q) { it64 += (M / 64) * (g.Cout / 64); a.p[q].item_end = it64; a.p[q].tiles_n = g.Cout / 64; }
       a.n_items = it64;
@@ -2952,6 +2954,8 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->env_no_conv_dx_mfma = getenv("DSACT_NO_CONV_DX_MFMA") != nullptr;
   h->env_no_conv_narrow9 = getenv("DSACT_NO_CONV_NARROW9") != nullptr;
   h->env_no_conv_fwd64 = getenv("DSACT_NO_CONV_FWD64") != nullptr;
+  if (const char* v = getenv("DSACT_CONV_FWD64_MIN")) h->env_conv_fwd64_min = atoi(v);
+  if (const char* v = getenv("DSACT_DCOL64_MIN_M")) h->env_dcol64_min_m = atoi(v);
   h->env_dw_4wave = getenv("DSACT_DW_4WAVE") != nullptr;
   h->env_no_ride8 = getenv("DSACT_RIDE8") == nullptr;
   if (const char* v = getenv("DSACT_CHAIN_RG")) h->env_chain_rg = atoi(v) == 1 ? 1 : atoi(v) == 4 ? 4 : 2;
