@@ -171,6 +171,8 @@ struct dsact_handle {
   int conv_dw_nkt_l[kMaxConv] = {1, 1, 1, 1, 1, 1};   // k-tiles per k_conv_dw workgroup, per layer (DSACT_CONV_DW_NKT_L=a,b,..; DSACT_CONV_DW_NKT: all)
   int env_conv_fwd64_min = 256;         // DSACT_CONV_FWD64_MIN: fewest 64 x 64 tiles a conv forward launch must have to use them
   int env_dcol64_min_m = 256;           // DSACT_DCOL64_MIN_M: fewest rows of a dCol product for the 64 x 64 stage tiles (layer 5 at batch 256: 11.4 -> 8.9 us)
+  bool env_no_conv_fwd32x64 = false;    // DSACT_NO_CONV_FWD32X64
+  bool env_dfeat64 = false;             // DSACT_DFEAT64: dL/d features on 64 x 64 stage tiles (experiment)
   bool env_no_conv_fwd64 = false;       // DSACT_NO_CONV_FWD64: wide conv layers' forward on the 32 x 32 tile kernel
   bool env_no_conv_narrow9 = false;     // DSACT_NO_CONV_NARROW9: type_2's third conv layer stays on the LDS-tile forward kernel
   bool env_conv_dw_fixed_chunk = false; // DSACT_CONV_DW_FIXED_CHUNK: every layer uses conv_dw_chunk(M) (A/B of conv_dw_pick_chunk)
@@ -1034,7 +1036,7 @@ int run_stage(dsact_handle* h, const Stage& s0, int x0 = 0, int x1 = 0, bool fus
   s.args.fo = fused_opt(h, fused);
   // large batches: 64x64 tiles (k_stage64) when every problem of the stage allows it and nothing rides along
   // (kind 2, plain store: the conv data gradient's dCol products -- many 32 x 32 tiles with a contraction of only 64-256)
-  if (s.args.n_extra == 0 && (s.kind == 0 || s.kind == 1 || (s.kind == 2 && s.name.compare(0, 9, "conv_dcol") == 0)) && !h->env_no_tile64) {
+  if (s.args.n_extra == 0 && (s.kind == 0 || s.kind == 1 || (s.kind == 2 && (s.name.compare(0, 9, "conv_dcol") == 0 || (s.name.compare(0, 5, "dfeat") == 0 && h->env_dfeat64)))) && !h->env_no_tile64) {
     bool ok = true;
     int blocks = 0;
     StageArgs a64 = s.args;
@@ -1181,7 +1183,15 @@ int enqueue_conv_forward(dsact_handle* h) {
       int it64 = 0;
       for (int q = 0; q < a.n_prob; ++q) { it64 += (M / 64) * (g.Cout / 64); a.p[q].item_end = it64; a.p[q].tiles_n = g.Cout / 64; }
       a.n_items = it64;
-      TRY(launch(h, name.c_str(), k_conv_fwd64, dim3(it64), dim3(kThreads64), tile64_lds_bytes(), a));
+      TRY(launch(h, name.c_str(), k_conv_fwd64<2>, dim3(it64), dim3(kThreads64), tile64_lds_bytes(), a));
+      continue;
+    }
+    // ... 32 x 64 tiles where those would leave CUs idle but the contraction is long (type_2 layer 5: K = 1152, M = batch)
+    if (per_group == 1 && M % 32 == 0 && g.Cout % 64 == 0 && g.K % 4 == 0 && g.K >= 512 && !h->env_no_conv_fwd64 && !h->env_no_conv_fwd32x64) {
+      int it = 0;
+      for (int q = 0; q < a.n_prob; ++q) { it += (M / 32) * (g.Cout / 64); a.p[q].item_end = it; a.p[q].tiles_n = g.Cout / 64; }
+      a.n_items = it;
+      TRY(launch(h, name.c_str(), k_conv_fwd64<1>, dim3(it), dim3(kThreads64), tile64_lds_bytes(), a));
       continue;
     }
     TRY(launch(h, name.c_str(), k_conv_fwd, dim3(conv_fwd_grid(items)), dim3(kThreads), 0, a));
@@ -2954,6 +2964,8 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->env_no_conv_dx_mfma = getenv("DSACT_NO_CONV_DX_MFMA") != nullptr;
   h->env_no_conv_narrow9 = getenv("DSACT_NO_CONV_NARROW9") != nullptr;
   h->env_no_conv_fwd64 = getenv("DSACT_NO_CONV_FWD64") != nullptr;
+  h->env_no_conv_fwd32x64 = getenv("DSACT_NO_CONV_FWD32X64") != nullptr;
+  h->env_dfeat64 = getenv("DSACT_DFEAT64") != nullptr;
   if (const char* v = getenv("DSACT_CONV_FWD64_MIN")) h->env_conv_fwd64_min = atoi(v);
   if (const char* v = getenv("DSACT_DCOL64_MIN_M")) h->env_dcol64_min_m = atoi(v);
   h->env_dw_4wave = getenv("DSACT_DW_4WAVE") != nullptr;
@@ -3131,7 +3143,8 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<false, EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<true, EPI_MULG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_stage64<true, EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_conv_fwd64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_conv_fwd64<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
+    HIPCHK(h, hipFuncSetAttribute((const void*)k_conv_fwd64<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile64_lds_bytes()));
   }
   HIPCHK(h, hipHostMalloc((void**)&h->handoff_host, 1024, hipHostMallocMapped));
   memset(h->handoff_host, 0, 1024);

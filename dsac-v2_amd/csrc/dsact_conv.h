@@ -191,6 +191,9 @@ __global__ void __launch_bounds__(kThreads) k_conv_fwd(ConvStageArgs s) {
 // tile's loads in flight) with the patch operand gathered through conv_rowoff / conv_kmap. Half the operand bytes per FLOP
 // of the 32 x 32 tiles above; layers with M % 64 == 0, Cout % 64 == 0 and one net per group (type_2 layers 3, 4).
 // ---------------------------------------------------------------------------------------------
+// MB = 16-row blocks per wave: 2 = 64-pixel tiles; 1 = 32 (pixels) x 64 (channels) tiles, k-tiles of 64 -- half the dependent
+// k-tile steps of the 32 x 32 kernel for a layer whose 64 x 64 tiles would not fill the chip (type_2 layer 5: M = batch)
+template <int MB>
 __global__ void __launch_bounds__(kThreads64) k_conv_fwd64(ConvStageArgs s) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const ConvGeom& g = s.g;
@@ -203,7 +206,7 @@ __global__ void __launch_bounds__(kThreads64) k_conv_fwd64(ConvStageArgs s) {
   const int local = b - (pi ? s.p[pi - 1].item_end : 0);
   const int tn = g.Cout >> 6;
   const int mt = local / tn, nt = local - mt * tn;
-  const int m0 = mt * 64, n0 = nt * 64;
+  const int m0 = mt * 32 * MB, n0 = nt * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
   const int i = lane & 15, gq = lane >> 4;
@@ -211,7 +214,7 @@ __global__ void __launch_bounds__(kThreads64) k_conv_fwd64(ConvStageArgs s) {
   const int T = (g.K + BK - 1) / BK;
   // this thread's two patch rows (pixels) and two weight rows (channels) of every k-tile; k quad (tid & 15)
   const float* pa = t.in + conv_rowoff(g, s.ix, m0 + (tid >> 4));
-  const float* pb = t.in + conv_rowoff(g, s.ix, m0 + (tid >> 4) + 32);
+  const float* pb = MB == 2 ? t.in + conv_rowoff(g, s.ix, m0 + (tid >> 4) + 32) : pa;   // (MB == 1: the second row slot is unused)
   const float* qa = t.w[0] + (size_t)(n0 + (tid >> 4)) * g.K;
   const float* qb = qa + (size_t)32 * g.K;
   auto load = [&](int kt, f32x4& p0, f32x4& p1, f32x4& q0, f32x4& q1) {
@@ -237,18 +240,18 @@ __global__ void __launch_bounds__(kThreads64) k_conv_fwd64(ConvStageArgs s) {
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
       const f32x4 q = frag_read(Qs, wc * 16 + i, kk, gq);
-      const f32x4 xa = frag_read(Ps, wr * 32 + i, kk, gq);
-      const f32x4 xb = frag_read(Ps, wr * 32 + 16 + i, kk, gq);
+      const f32x4 xa = frag_read(Ps, wr * 16 * MB + i, kk, gq);
+      const f32x4 xb = MB == 2 ? frag_read(Ps, wr * 32 + 16 + i, kk, gq) : xa;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[e], xa[e], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[e], xb[e], acc[1], 0, 0, 0);
+        if (MB == 2) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[e], xb[e], acc[1], 0, 0, 0);
       }
     }
   }
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {
-    const int m = m0 + wr * 32 + mb * 16 + i;
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = m0 + wr * 16 * MB + mb * 16 + i;
     f32x4 o = acc[mb] + bv;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
