@@ -172,7 +172,6 @@ struct dsact_handle {
   int env_conv_fwd64_min = 256;         // DSACT_CONV_FWD64_MIN: fewest 64 x 64 tiles a conv forward launch must have to use them
   int env_dcol64_min_m = 256;           // DSACT_DCOL64_MIN_M: fewest rows of a dCol product for the 64 x 64 stage tiles (layer 5 at batch 256: 11.4 -> 8.9 us)
   bool env_no_conv_fwd32x64 = false;    // DSACT_NO_CONV_FWD32X64
-  bool env_dfeat64 = false;             // DSACT_DFEAT64: dL/d features on 64 x 64 stage tiles (experiment)
   bool env_no_conv_fwd64 = false;       // DSACT_NO_CONV_FWD64: wide conv layers' forward on the 32 x 32 tile kernel
   bool env_no_conv_narrow9 = false;     // DSACT_NO_CONV_NARROW9: type_2's third conv layer stays on the LDS-tile forward kernel
   bool env_conv_dw_fixed_chunk = false; // DSACT_CONV_DW_FIXED_CHUNK: every layer uses conv_dw_chunk(M) (A/B of conv_dw_pick_chunk)
@@ -1036,7 +1035,7 @@ int run_stage(dsact_handle* h, const Stage& s0, int x0 = 0, int x1 = 0, bool fus
   s.args.fo = fused_opt(h, fused);
   // large batches: 64x64 tiles (k_stage64) when every problem of the stage allows it and nothing rides along
   // (kind 2, plain store: the conv data gradient's dCol products -- many 32 x 32 tiles with a contraction of only 64-256)
-  if (s.args.n_extra == 0 && (s.kind == 0 || s.kind == 1 || (s.kind == 2 && (s.name.compare(0, 9, "conv_dcol") == 0 || (s.name.compare(0, 5, "dfeat") == 0 && h->env_dfeat64)))) && !h->env_no_tile64) {
+  if (s.args.n_extra == 0 && (s.kind == 0 || s.kind == 1 || (s.kind == 2 && s.name.compare(0, 9, "conv_dcol") == 0)) && !h->env_no_tile64) {   // (dfeat on 48 such tiles: 14.3 vs 12.3 us)
     bool ok = true;
     int blocks = 0;
     StageArgs a64 = s.args;
@@ -2965,7 +2964,6 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->env_no_conv_narrow9 = getenv("DSACT_NO_CONV_NARROW9") != nullptr;
   h->env_no_conv_fwd64 = getenv("DSACT_NO_CONV_FWD64") != nullptr;
   h->env_no_conv_fwd32x64 = getenv("DSACT_NO_CONV_FWD32X64") != nullptr;
-  h->env_dfeat64 = getenv("DSACT_DFEAT64") != nullptr;
   if (const char* v = getenv("DSACT_CONV_FWD64_MIN")) h->env_conv_fwd64_min = atoi(v);
   if (const char* v = getenv("DSACT_DCOL64_MIN_M")) h->env_dcol64_min_m = atoi(v);
   h->env_dw_4wave = getenv("DSACT_DW_4WAVE") != nullptr;

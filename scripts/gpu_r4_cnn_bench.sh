@@ -7,8 +7,8 @@ export TMPDIR=/tmp
 if [ "$1" = test ]; then
   timeout 900 python -m pytest tests/test_hip_cnn_parity.py tests/test_hip_v1_cnn_parity.py -m gpu -x -q 2>&1 | tail -15 | tee gpurun_out/cnn_chain_tests.txt
 fi
-for v in ${VARIANTS:-par no32x64}; do
-  unset DSACT_NO_CHAIN_CNN DSACT_TWIN_SEQ DSACT_CHAIN_RG DSACT_TWIN_NO_MERGE DSACT_NO_CONV_NARROW9 DSACT_NO_CONV_FWD64 DSACT_NO_CONV_FWD32X64
+for v in ${VARIANTS:-par}; do
+  unset DSACT_NO_CHAIN_CNN DSACT_TWIN_SEQ DSACT_CHAIN_RG DSACT_TWIN_NO_MERGE DSACT_NO_CONV_NARROW9 DSACT_NO_CONV_FWD64 DSACT_NO_CONV_FWD32X64 DSACT_DFEAT64
   case $v in
     tile) export DSACT_NO_CHAIN_CNN=1;;
     seq) export DSACT_TWIN_SEQ=1;;
@@ -17,6 +17,7 @@ for v in ${VARIANTS:-par no32x64}; do
     nonarrow9) export DSACT_NO_CONV_NARROW9=1;;
     nofwd64) export DSACT_NO_CONV_FWD64=1;;
     no32x64) export DSACT_NO_CONV_FWD32X64=1;;
+    dfeat64) export DSACT_DFEAT64=1;;
   esac
   timeout 300 python bench.py --cnn-only --cnn-steps 400 --no-cpu-baseline 2>/dev/null | grep '^{"cnn"' > gpurun_out/r04_cnn_$v.json
   python - <<PY
