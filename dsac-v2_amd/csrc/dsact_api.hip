@@ -172,6 +172,7 @@ struct dsact_handle {
   int env_conv_fwd64_min = 256;         // DSACT_CONV_FWD64_MIN: fewest 64 x 64 tiles a conv forward launch must have to use them
   int env_dcol64_min_m = 256;           // DSACT_DCOL64_MIN_M: fewest rows of a dCol product for the 64 x 64 stage tiles (layer 5 at batch 256: 11.4 -> 8.9 us)
   bool env_no_conv_fwd32x64 = false;    // DSACT_NO_CONV_FWD32X64
+  bool env_conv_dw_sb3 = false;         // DSACT_CONV_DW_SB3: layers with three k-tiles per workgroup run the single-buffered form
   bool env_no_conv_fwd64 = false;       // DSACT_NO_CONV_FWD64: wide conv layers' forward on the 32 x 32 tile kernel
   bool env_no_conv_narrow9 = false;     // DSACT_NO_CONV_NARROW9: type_2's third conv layer stays on the LDS-tile forward kernel
   bool env_conv_dw_fixed_chunk = false; // DSACT_CONV_DW_FIXED_CHUNK: every layer uses conv_dw_chunk(M) (A/B of conv_dw_pick_chunk)
@@ -1223,7 +1224,7 @@ int conv_dw_pick_chunk(const dsact_handle* h, int j, int n_st) {
   const int nkt = h->conv_dw_nkt_l[j];
   const int per_prob = j == 0 ? n_st : 1, n_prob = n_st / per_prob;
   const long long per_chunk = (long long)tiles_of(per_prob * g.Cout, TM) * tiles_of(tiles_of(g.K + 4, TN), nkt) * n_prob;
-  const long long slots = (nkt == 1 ? 4LL : 2LL) * h->n_cu;   // 2 x (1 + nkt) LDS tiles of 9 KB per workgroup
+  const long long slots = ((nkt == 1 || (nkt == 3 && h->env_conv_dw_sb3)) ? 4LL : 2LL) * h->n_cu;   // (1 or 2) x (1 + nkt) LDS tiles of 9 KB per workgroup
   int best = c0;
   double best_cost = 1e30;
   for (int c = c0; c <= 16 * c0 && c <= 8192; c += 64) {
@@ -1277,7 +1278,8 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
         blocks += a.n_chunks * p.tiles_co * a.tiles_k;
         p.block_end = blocks;
       }
-      const size_t lds = (size_t)2 * (1 + nkt) * TILE_LDS * sizeof(float);
+      const bool sb3 = nkt == 3 && h->env_conv_dw_sb3;   // single-buffered three-k-tile form
+      const size_t lds = (size_t)(sb3 ? 1 : 2) * (1 + nkt) * TILE_LDS * sizeof(float);
       if (fork) {
         HIPCHK(h, hipStreamWaitEvent(h->aux_stream, h->ev_conv[j], 0));
         if (nkt != 1) return fail(h, DSACT_E_INVALID, "DSACT_CONV_FORK needs DSACT_CONV_DW_NKT=1");
@@ -1286,6 +1288,7 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
       // (three / four steps of loads in flight, k_conv_dw<1, 3|4>: 46.4-48.3 us vs 45 us on layers 0 / 1 -- not latency-bound)
       if (nkt == 1) TRY(launch(h, ("conv_dw" + sfx).c_str(), k_conv_dw<1>, dim3(blocks), dim3(kThreads), lds, a));
       else if (nkt == 2) TRY(launch(h, ("conv_dw" + sfx).c_str(), k_conv_dw<2>, dim3(blocks), dim3(kThreads), lds, a));
+      else if (sb3) TRY(launch(h, ("conv_dw" + sfx).c_str(), (k_conv_dw<3, 2, false>), dim3(blocks), dim3(kThreads), lds, a));
       else if (nkt == 3) TRY(launch(h, ("conv_dw" + sfx).c_str(), k_conv_dw<3>, dim3(blocks), dim3(kThreads), lds, a));
       else return fail(h, DSACT_E_INVALID, "DSACT_CONV_DW_NKT must be 1..3");
     }
@@ -2964,6 +2967,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->env_no_conv_narrow9 = getenv("DSACT_NO_CONV_NARROW9") != nullptr;
   h->env_no_conv_fwd64 = getenv("DSACT_NO_CONV_FWD64") != nullptr;
   h->env_no_conv_fwd32x64 = getenv("DSACT_NO_CONV_FWD32X64") != nullptr;
+  h->env_conv_dw_sb3 = getenv("DSACT_CONV_DW_SB3") != nullptr;
   if (const char* v = getenv("DSACT_CONV_FWD64_MIN")) h->env_conv_fwd64_min = atoi(v);
   if (const char* v = getenv("DSACT_DCOL64_MIN_M")) h->env_dcol64_min_m = atoi(v);
   h->env_dw_4wave = getenv("DSACT_DW_4WAVE") != nullptr;

@@ -436,9 +436,11 @@ struct ConvDwArgs {
 // with NKT patch tiles, so dY is not re-read per k-tile (PMC: the weight gradient was the largest consumer
 // of memory-side traffic, 2-3x its algorithmic bytes, when every k-tile had its own workgroup).
 // NS = steps of global loads in flight (register sets).
-template <int NKT, int NS = 2>
+// DB = LDS double buffering (one barrier per step, 2 x (1 + NKT) tiles); false: ONE set of 1 + NKT tiles and a second barrier per
+// step -- NKT = 3 then costs the LDS of the double-buffered NKT = 1 form (four workgroups per CU) while dY is read once.
+template <int NKT, int NS = 2, bool DB = true>
 __global__ void __launch_bounds__(kThreads) k_conv_dw(ConvDwArgs s) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x (1 + NKT) tiles
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // (DB ? 2 : 1) x (1 + NKT) tiles
   const int b = blockIdx.x;
   int pi = 0;
   if (s.n_prob > 1 && b >= s.p[0].block_end) pi = 1;
@@ -540,7 +542,7 @@ __global__ void __launch_bounds__(kThreads) k_conv_dw(ConvDwArgs s) {
 #pragma unroll
   for (int st = 0; st < NS; ++st) load_next(ps0[st], ps1[st], qs0[st], qs1[st]);   // steps 0 .. NS-1 (past T: masked, clamped)
   auto step = [&](int it, f32x4& P0, f32x4& P1, f32x4 (&Q0)[NKT], f32x4 (&Q1)[NKT]) {
-    float* Ps = lds + (it & 1) * (1 + NKT) * TILE_LDS;
+    float* Ps = lds + (DB ? (it & 1) : 0) * (1 + NKT) * TILE_LDS;
     mask(it, P0, P1, Q0, Q1);
     tile_store_lds<true>(Ps, tid, P0, P1);
 #pragma unroll
@@ -550,6 +552,7 @@ __global__ void __launch_bounds__(kThreads) k_conv_dw(ConvDwArgs s) {
 #pragma unroll
     for (int u = 0; u < NKT; ++u)
       tile_mma<true, true>(Ps, Ps + (1 + u) * TILE_LDS, wr * 16 + i, wc * 16 + i, gq, acc0[u], acc1[u]);
+    if (!DB) lds_barrier();                    // the next step's stores overwrite these tiles
   };
   int it = 0;
   for (; it + NS <= T; it += NS) {
