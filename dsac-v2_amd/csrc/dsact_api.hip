@@ -172,6 +172,8 @@ struct dsact_handle {
   int env_conv_fwd64_min = 256;         // DSACT_CONV_FWD64_MIN: fewest 64 x 64 tiles a conv forward launch must have to use them
   int env_dcol64_min_m = 256;           // DSACT_DCOL64_MIN_M: fewest rows of a dCol product for the 64 x 64 stage tiles (layer 5 at batch 256: 11.4 -> 8.9 us)
   bool env_no_conv_fwd32x64 = false;    // DSACT_NO_CONV_FWD32X64
+  int env_conv_dw_reg = 0;              // DSACT_CONV_DW_REG: bit mask of the (narrow) layers whose weight gradient runs on register tiles (k_conv_dw_reg)
+  int env_conv_dw_reg_wgs = 512;        // DSACT_CONV_DW_REG_WGS: workgroups (4 waves each) such a launch aims for
   bool env_conv_dw_sb3 = false;         // DSACT_CONV_DW_SB3: layers with three k-tiles per workgroup run the single-buffered form
   bool env_no_conv_fwd64 = false;       // DSACT_NO_CONV_FWD64: wide conv layers' forward on the 32 x 32 tile kernel
   bool env_no_conv_narrow9 = false;     // DSACT_NO_CONV_NARROW9: type_2's third conv layer stays on the LDS-tile forward kernel
@@ -447,7 +449,7 @@ int launch(dsact_handle* h, const char* name, void (*kernel)(KArgs...), dim3 gri
 
 // pixels per split of a conv weight-gradient contraction (multiple of 64): the SMALLEST the launch may use -- the partial
 // buffers are sized for it
-size_t conv_dw_chunk(size_t M) { return M >= 65536 ? 1024 : 256; }
+size_t conv_dw_chunk(size_t M) { (void)M; return 256; }   // (round 3: 1024 from 64 Ki pixels on; the register-tile launches want finer chunks)
 
 // ---- workspace carving ------------------------------------------------------------------------
 struct Carver {
@@ -1216,10 +1218,25 @@ int enqueue_conv_forward(dsact_handle* h) {
 // second one for 82 workgroups (found round 3: 44 us where ~25 are due; neither deeper prefetch nor half the address
 // arithmetic nor fewer L1 requests had moved it). Longer chunks mean fewer, longer workgroups: pick the multiple of 64
 // that minimises rounds x (start-up + steps) under the measured ~3 us + ~1.1 us per 64-pixel step.
+// narrow layers (all channels of a problem in <= 32 rows, K + 4 <= 160 columns): the register-tile weight gradient (k_conv_dw_reg)
+bool conv_dw_reg_ok(const dsact_handle* h, int j, int n_st) {
+  const ConvGeom& g = h->cg[j];
+  const int per_prob = j == 0 ? n_st : 1;
+  return ((h->env_conv_dw_reg >> j) & 1) && per_prob * g.Cout <= 32 && g.K + 4 <= 160 && g.OW >= 4 && !h->conv_fork;
+}
+
 int conv_dw_pick_chunk(const dsact_handle* h, int j, int n_st) {
   const ConvGeom& g = h->cg[j];
   const long long M = (long long)h->B * g.OH * g.OW;
   const int c0 = (int)conv_dw_chunk((size_t)M);
+  if (conv_dw_reg_ok(h, j, n_st)) {
+    // one workgroup (4 waves) per chunk and problem: about two workgroups per CU, never more chunks than the partial buffers hold
+    const int n_prob = j == 0 ? 1 : n_st;
+    const long long want = ((long long)h->env_conv_dw_reg_wgs + n_prob - 1) / n_prob;
+    long long c = (M + want - 1) / want;
+    c = (c + 63) / 64 * 64;
+    return (int)(c < c0 ? c0 : c);
+  }
   if (h->env_conv_dw_fixed_chunk) return c0;
   const int nkt = h->conv_dw_nkt_l[j];
   const int per_prob = j == 0 ? n_st : 1, n_prob = n_st / per_prob;
@@ -1280,6 +1297,19 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
       }
       const bool sb3 = nkt == 3 && h->env_conv_dw_sb3;   // single-buffered three-k-tile form
       const size_t lds = (size_t)(sb3 ? 1 : 2) * (1 + nkt) * TILE_LDS * sizeof(float);
+      if (conv_dw_reg_ok(h, j, n_st)) {
+        // register tiles: one workgroup per (problem, chunk)
+        int rb = 0;
+        for (int q = 0; q < a.n_prob; ++q) { rb += a.n_chunks; a.p[q].block_end = rb; }
+        const int ncb = (per_prob * g.Cout + 15) / 16, nkb = (a.K1p + 15) / 16;
+        const std::string nm = "conv_dw" + sfx;
+        if (ncb == 1 && nkb <= 4) TRY(launch(h, nm.c_str(), (k_conv_dw_reg<1, 4>), dim3(rb), dim3(kThreads), 0, a));
+        else if (ncb == 2 && nkb <= 4) TRY(launch(h, nm.c_str(), (k_conv_dw_reg<2, 4>), dim3(rb), dim3(kThreads), 0, a));
+        else if (ncb == 1 && nkb <= 5) TRY(launch(h, nm.c_str(), (k_conv_dw_reg<1, 5>), dim3(rb), dim3(kThreads), 0, a));
+        else if (ncb == 2 && nkb <= 5) TRY(launch(h, nm.c_str(), (k_conv_dw_reg<2, 5>), dim3(rb), dim3(kThreads), 0, a));
+        else if (ncb == 1) TRY(launch(h, nm.c_str(), (k_conv_dw_reg<1, 10>), dim3(rb), dim3(kThreads), 0, a));
+        else TRY(launch(h, nm.c_str(), (k_conv_dw_reg<2, 10>), dim3(rb), dim3(kThreads), 0, a));
+      } else
       if (fork) {
         HIPCHK(h, hipStreamWaitEvent(h->aux_stream, h->ev_conv[j], 0));
         if (nkt != 1) return fail(h, DSACT_E_INVALID, "DSACT_CONV_FORK needs DSACT_CONV_DW_NKT=1");
@@ -2968,6 +2998,11 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->env_no_conv_fwd64 = getenv("DSACT_NO_CONV_FWD64") != nullptr;
   h->env_no_conv_fwd32x64 = getenv("DSACT_NO_CONV_FWD32X64") != nullptr;
   h->env_conv_dw_sb3 = getenv("DSACT_CONV_DW_SB3") != nullptr;
+  // default: the 16-channel layers whose K + 4 columns make three LDS k-tiles (type_2 layer 1: 37.0 -> 30.3 us)
+  for (int j = 1; j < h->n_conv; ++j)
+    if (h->cg[j].Cout == 16 && tiles_of(h->cg[j].K + 4, TN) == 3) h->env_conv_dw_reg |= 1 << j;
+  if (const char* v = getenv("DSACT_CONV_DW_REG")) h->env_conv_dw_reg = atoi(v);
+  if (const char* v = getenv("DSACT_CONV_DW_REG_WGS")) h->env_conv_dw_reg_wgs = atoi(v) > 0 ? atoi(v) : 512;
   if (const char* v = getenv("DSACT_CONV_FWD64_MIN")) h->env_conv_fwd64_min = atoi(v);
   if (const char* v = getenv("DSACT_DCOL64_MIN_M")) h->env_dcol64_min_m = atoi(v);
   h->env_dw_4wave = getenv("DSACT_DW_4WAVE") != nullptr;

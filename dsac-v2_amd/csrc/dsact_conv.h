@@ -575,6 +575,153 @@ __global__ void __launch_bounds__(kThreads) k_conv_dw(ConvDwArgs s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// weight gradient of the narrow layers (n_sub * Cout <= 16 * NCB, K + 4 <= 16 * NKB) on REGISTER tiles: no LDS staging, no
+// transposition, no barrier inside the contraction (round 4; the LDS-tile kernel above spends a step on its transposing
+// stores and 16-byte gathers, not on bytes or MFMAs -- DESIGN.md 4b). With the contraction over pixels,
+// v_mfma_f32_16x16x4_f32 wants from lane (i = lane & 15, g = lane >> 4)  A[i][g] = dY[px0 + g][co0 + i]  and
+// B[g][i] = P[px0 + g][k0 + i]: both are coalesced 4-byte loads from the row-major operands as they lie in memory.
+// D[co0 + 4g + r][k0 + i] accumulates in NCB x NKB register tiles per wave. A workgroup = one pixel chunk of one problem,
+// its four waves split the chunk's pixels; 16 pixels (4 MFMA steps) of loads are in flight while the previous 16 are
+// multiplied; the four partial tiles meet in LDS once, at the end (fixed order). Same partial layout as k_conv_dw.
+// Measured at type_2, batch 256 (two groups in flight, ~512 workgroups): layer 1 37.0 -> 30.3 us, layer 0 33.4 -> 41.0, layer 2
+// (228 VGPRs, one wave per SIMD) 20.2 -> 37.0; more, shorter workgroups are slower (layer 1: 39 us at 1024-2048): chosen per
+// layer (DSACT_CONV_DW_REG = bit mask of layers; default: the layers with 16 channels and three k-tiles, i.e. layer 1).
+// ---------------------------------------------------------------------------------------------
+template <int NCB, int NKB>
+__global__ void __launch_bounds__(kThreads) k_conv_dw_reg(ConvDwArgs s) {
+  __shared__ f32x4 red[NCB * NKB][64];
+  const ConvGeom& g = s.g;
+  const int b = blockIdx.x;
+  int pi = 0;
+  if (s.n_prob > 1 && b >= s.p[0].block_end) pi = 1;
+  if (s.n_prob > 2 && b >= s.p[1].block_end) pi = 2;
+  const ConvDwProb& t = s.p[pi];
+  const int ch = b - (pi ? s.p[pi - 1].block_end : 0);
+  const int mb = ch * s.chunk;
+  const int me = mb + s.chunk < t.M ? mb + s.chunk : t.M;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, gq = lane >> 4;
+  const int ntot = t.n_sub * g.Cout;
+  // this wave's pixels: a quarter of the chunk, rounded up to whole groups of 16
+  const int per = (((me - mb + 3) >> 2) + 15) & ~15;
+  const int w0 = mb + wave * per;
+  const int w1 = w0 + per < me ? w0 + per : me;
+  // operand addressing of this lane
+  const float* dyp[NCB]; bool cov[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int co = cb * 16 + i;
+    cov[cb] = co < ntot;
+    const int sub = cov[cb] ? co / g.Cout : 0;
+    dyp[cb] = t.dy[sub] + (cov[cb] ? co - sub * g.Cout : 0);
+  }
+  int km[NKB], kmode[NKB];
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    const int k = kb * 16 + i;
+    kmode[kb] = k < g.K ? 0 : (k == g.K ? 1 : 2);   // gathered / bias column (constant 1) / padding
+    km[kb] = conv_kmap(g, kmode[kb] == 0 ? k : 0);
+  }
+  // pixel walk of this lane: pixel w0 + gq, then 4 pixels per MFMA step (ox, oy, patch origin advanced incrementally)
+  const int SX = g.stride * g.Cin, SY = g.stride * g.W * g.Cin, SB = g.H * g.W * g.Cin;
+  const int d4y = 4 / g.OW, d4x = 4 - d4y * g.OW;           // OW >= 2: at most ... (host: OW >= 4, so d4y = 0 or 1)
+  const int doff4 = d4y * SY + d4x * SX, wrapx = SY - g.OW * SX, wrapy = SB - g.OH * SY;
+  const int off_last = conv_rowoff(g, s.ix, t.M - 1);
+  int pm = w0 + gq, pox, poy, poff;
+  {
+    const int mc_ = pm < t.M ? pm : t.M - 1;
+    const int b_ = fast_div(mc_, s.ix.OHW, s.ix.inv_ohw);
+    const int p_ = mc_ - b_ * s.ix.OHW;
+    poy = fast_div(p_, g.OW, s.ix.inv_ow);
+    pox = p_ - poy * g.OW;
+    poff = b_ * SB + poy * SY + pox * SX;
+  }
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  struct Grp { float a[NCB][4]; float bq[NKB][4]; };
+  auto load_grp = [&](Grp& G) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool ok = pm < w1;
+      const size_t ao = ok ? (size_t)pm * g.Cout : (size_t)(t.M - 1) * g.Cout;
+      const int ro = ok ? poff : off_last;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) G.a[cb][e] = dyp[cb][cov[cb] ? ao : 0];
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) G.bq[kb][e] = t.in[kmode[kb] == 0 ? ro + km[kb] : 0];
+      pm += 4;
+      pox += d4x; poy += d4y; poff += doff4;
+      if (pox >= g.OW) { pox -= g.OW; poy += 1; poff += wrapx; }
+      if (poy >= g.OH) { poy -= g.OH; poff += wrapy; }
+    }
+  };
+  f32x4 acc[NCB][NKB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) acc[cb][kb] = zero;
+  auto compute = [&](int p0, const Grp& G) {    // p0: first pixel of the group (lane's pixels: p0 + gq + 4e)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool ok = p0 + gq + 4 * e < w1;
+      float av[NCB], bv[NKB];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) av[cb] = (ok && cov[cb]) ? G.a[cb][e] : 0.0f;    // masking dY is enough: the other operand is finite
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) bv[kb] = kmode[kb] == 0 ? G.bq[kb][e] : (kmode[kb] == 1 ? 1.0f : 0.0f);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) acc[cb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cb], bv[kb], acc[cb][kb], 0, 0, 0);
+    }
+  };
+  // NG groups of 16 pixels in flight: a group's 4 x NCB x NKB MFMAs are 0.3-0.4 us, a memory round trip is several times that.
+  // Everything is unconditional (loads clamped, masked groups multiply zeros): no branch between the loads and the MFMAs.
+  constexpr int NG = 2;   // (4: layer 1 33.0 instead of 30.3 us -- the registers cost more occupancy than the depth hides)
+  Grp G[NG];
+#pragma unroll
+  for (int u = 0; u < NG; ++u) load_grp(G[u]);
+  for (int p0 = w0; p0 < w1; p0 += 16 * NG) {
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      compute(p0 + 16 * u, G[u]);
+      load_grp(G[u]);                    // the group NG further on
+    }
+  }
+  // the four waves' partial tiles, added in wave order
+  for (int w = 1; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) red[cb * NKB + kb][lane] = acc[cb][kb];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) acc[cb][kb] += red[cb * NKB + kb][lane];
+    }
+    __syncthreads();
+  }
+  if (wave != 0) return;
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cot = cb * 16 + 4 * gq + r;
+      if (cot >= ntot) continue;
+      const int sub = cot / g.Cout, co = cot - sub * g.Cout;
+      float* dst = t.part[sub] + ((size_t)ch * g.Cout + co) * s.K1p;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const int kk = kb * 16 + i;
+        if (kk < s.K1p) dst[kk] = acc[cb][kb][r];
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // data gradient of the narrow layers (Cin <= 16) without a column buffer:
 //   dX[b,y,x,:] = relu'(x) * sum_{ky,kx valid} sum_co dY[b,(y-ky)/s,(x-kx)/s,co] * W[co][ky][kx][:]
 // one thread per input pixel, all Cin channels in registers. A workgroup handles pixels of ONE parity
