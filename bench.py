@@ -694,13 +694,22 @@ def chain_flops(lay, batch):
     return {k: 2.0 * v * batch for k, v in per_row.items()}
 
 
-PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
+PMC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
 
 
-def pmc_traffic(kernel_substr, pick="max"):
-    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r02_pmc_traffic.json, produced
-    by scripts/gpu_pmc2.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this bench with --kernel-trace only,
-    FETCH_SIZE doubled per the MI355X guide's gfx950 note). Not measurable live (needs rocprofv3); None if absent."""
+def _kernel_base_name(full):
+    """'void dsact::k_chain_fwdp<4, false>(dsact::PipeFwd const*)' -> 'k_chain_fwdp'"""
+    import re
+
+    m = re.search(r"dsact::(k_\w+)", full)
+    return m.group(1) if m else full
+
+
+def pmc_traffic(kernel_name, pick="max"):
+    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/rNN_pmc_traffic.json, produced
+    by scripts/gpu_r*_prof.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this bench with --kernel-trace only,
+    FETCH_SIZE doubled per the MI355X guide's gfx950 note). Not measurable live (needs rocprofv3); None if absent.
+    `kernel_name` is matched EXACTLY against the kernel's base name (k_chain_fwdp does not pick up k_chain_fwdpb)."""
     d = None
     for name in PMC_FILES:
         try:
@@ -714,7 +723,7 @@ def pmc_traffic(kernel_substr, pick="max"):
     # several instantiations may match (k_chain_fwd<4, 2> = group A, <4, 1> = group B at batch 256): `pick` chooses
     best = None
     for k, v in d.items():
-        if kernel_substr in k:
+        if _kernel_base_name(k) == kernel_name:
             per = (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0
             if best is None or (per > best if pick == "max" else per < best):
                 best = per
@@ -983,7 +992,7 @@ def main():
                     ach = fl[dom[0]] / (dur_us * 1e-6) / 1e12
                     out["roofline"] = {
                         "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
-                        "traffic": pmc_traffic({"chain_bwd": "k_chain_bwd2", "chain_fwd": "k_chain_fwdp" if pipe else "k_chain_fwd2", "chain_fwd+next": "k_chain_fwdp", "chain_fwd_q": "k_chain_fwdp", "chain_fwd_q+next": "k_chain_fwdp", "chain_fwd_a": "k_chain_fwd", "chain_fwd_b": "k_chain_fwd", "chain_bwd_q": "k_chain_bwd_q",
+                        "traffic": pmc_traffic({"chain_bwd": "k_chain_bwd2", "chain_fwd": "k_chain_fwdp" if pipe else "k_chain_fwd2", "chain_fwd+next": "k_chain_fwdp", "chain_fwd_q": "k_chain_fwdpb" if any(r[0] == "chain_dw_q" for r in prof) else "k_chain_fwdp", "chain_fwd_q+next": "k_chain_fwdp", "chain_fwd_a": "k_chain_fwd", "chain_fwd_b": "k_chain_fwd", "chain_bwd_q": "k_chain_bwd_q",
                                                 "chain_bwd_pi": "k_chain_bwd_pi", "dW": "k_dw2"}.get(dom[0], dom[0]),
                                                "min" if dom[0] == "chain_fwd_b" else "max"),
                         "traffic_source": "%s (a committed rocprofv3 --pmc pass of this bench; NOT measured in this run)" % getattr(pmc_traffic, "source", None),

@@ -208,6 +208,26 @@ struct dsact_handle {
   hipGraphExec_t graph_exec = nullptr;
   int graph_steps = 0;
   uint32_t graph_flags = 0;
+  // dsact_run_group: captured graphs of OTHER lengths / noise modes than the active one stay instantiated (a trainer's
+  // groups between two sampler calls come in a few lengths: sample_interval, and what log / eval / save iterations cut off)
+  struct GraphSet {
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    hipGraph_t pgraph[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipGraphExec_t pexec[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* pargs[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool pipe = false, merged = false, noise_table = false;
+    int steps = 0; uint32_t flags = 0;
+  };
+  std::vector<GraphSet> graph_cache;
+  bool graph_noise_table = false;       // the ACTIVE graph's gathers read the noise table (strict RNG) instead of drawing Philox noise
+  bool noise_table_on = false;          // set while such a graph is being captured (noise_args)
+  bool build_keeps_cache = false;       // set by dsact_run_group around dsact_graph_build: the previous graphs are stashed, not destroyed
+  float* noise_table = nullptr;         // [idx_rows][2*B*A + 2*B]: eps_new | eps_2 | z5 | z6 per replayed update
+  char* grp_pin[4] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging of dsact_run_group (index rows + noise rows), 4 slots
+  size_t grp_pin_bytes = 0;
+  hipEvent_t grp_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned grp_k = 0;
+  int want_graph_steps = 0; uint32_t want_graph_flags = 0;   // a hand-over failure could not re-capture the graph: built again lazily
   // profiling
   bool profiling = false;
   std::vector<ProfRec> prof;
@@ -1463,8 +1483,9 @@ StepHyper step_hyper(const dsact_handle* h) {
 }
 NoiseArgs noise_args(const dsact_handle* h) {
   NoiseArgs nz;
-  nz.seed = h->rng_seed;
+  nz.seed = h->noise_table_on ? 1 : h->rng_seed;
   nz.eps_new = h->eps_new; nz.eps_2 = h->eps_2; nz.z5 = h->z5; nz.z6 = h->z6;
+  nz.table = h->noise_table_on ? h->noise_table : nullptr; nz.B = h->B;
   return nz;
 }
 
@@ -1522,7 +1543,7 @@ GatherArgs gather_args(const dsact_handle* h, const int* table, int rows, int us
 int enqueue_prologue(dsact_handle* h, int use_dev, long long it, int advance, int fill_noise) {
   PrologueArgs a;
   a.st = h->st; a.use_dev = use_dev; a.host_it = it; a.advance_counters = advance; a.fill_noise = fill_noise;
-  a.hp = step_hyper(h); a.nz = noise_args(h); a.B = h->B; a.A = h->A;
+  a.hp = step_hyper(h); a.nz = noise_args(h); a.B = h->B; a.A = h->A; a.table_rows = h->idx_rows > 0 ? h->idx_rows : 1;
   TRY(launch(h, "prologue", k_prologue, dim3(1), dim3(kThreads), 0, a));
   if ((fill_noise || !advance) && h->chain_ok) return enqueue_pack(h);   // a forward pass follows: refresh the packed copies
   if (fill_noise || !advance) {  // a forward pass follows: refresh the padded first-layer weights
@@ -2805,6 +2826,44 @@ int enqueue_adam(dsact_handle* h, bool from_parts) {
   return launch(h, "adam_polyak", k_adam, dim3(blocks), dim3(kThreads), 0, a);
 }
 
+static void destroy_graph_set(dsact_handle::GraphSet& g) {
+  if (g.exec) hipGraphExecDestroy(g.exec);
+  if (g.graph) hipGraphDestroy(g.graph);
+  for (int p = 0; p < dsact_handle::kPipePhases; ++p) {
+    if (g.pexec[p]) hipGraphExecDestroy(g.pexec[p]);
+    if (g.pgraph[p]) hipGraphDestroy(g.pgraph[p]);
+    if (g.pargs[p]) hipFree(g.pargs[p]);
+  }
+  g = dsact_handle::GraphSet();
+}
+// the active graph (if any) moves into the cache; nothing is destroyed
+static void stash_graph(dsact_handle* h) {
+  if (!(h->graph_exec != nullptr || h->pipe_graph)) return;
+  dsact_handle::GraphSet g;
+  g.graph = h->graph; g.exec = h->graph_exec;
+  for (int p = 0; p < dsact_handle::kPipePhases; ++p) { g.pgraph[p] = h->pgraph[p]; g.pexec[p] = h->pexec[p]; g.pargs[p] = h->pargs[p]; }
+  g.pipe = h->pipe_graph; g.merged = h->merged_graph; g.noise_table = h->graph_noise_table;
+  g.steps = h->graph_steps; g.flags = h->graph_flags;
+  h->graph_cache.push_back(g);
+  h->graph = nullptr; h->graph_exec = nullptr;
+  for (int p = 0; p < dsact_handle::kPipePhases; ++p) { h->pgraph[p] = nullptr; h->pexec[p] = nullptr; h->pargs[p] = nullptr; }
+  h->pipe_graph = false; h->graph_steps = 0; h->graph_noise_table = false;
+}
+// a cached graph of that shape becomes the active one (the caller stashed the previous one); false: none cached
+static bool activate_graph(dsact_handle* h, int steps, uint32_t flags, bool noise_table) {
+  for (size_t i = 0; i < h->graph_cache.size(); ++i) {
+    dsact_handle::GraphSet& g = h->graph_cache[i];
+    if (g.steps != steps || g.flags != flags || g.noise_table != noise_table) continue;
+    h->graph = g.graph; h->graph_exec = g.exec;
+    for (int p = 0; p < dsact_handle::kPipePhases; ++p) { h->pgraph[p] = g.pgraph[p]; h->pexec[p] = g.pexec[p]; h->pargs[p] = (PipeFwd*)g.pargs[p]; }
+    h->pipe_graph = g.pipe; h->merged_graph = g.merged; h->graph_noise_table = g.noise_table;
+    h->graph_steps = g.steps; h->graph_flags = g.flags;
+    h->graph_cache.erase(h->graph_cache.begin() + (long)i);
+    return true;
+  }
+  return false;
+}
+// every captured graph goes: the active one and the cached ones (they bake in pointers, hyper-parameters, launch forms)
 void drop_graphs(dsact_handle* h) {
   if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
   if (h->graph) { hipGraphDestroy(h->graph); h->graph = nullptr; }
@@ -2813,8 +2872,11 @@ void drop_graphs(dsact_handle* h) {
     if (h->pgraph[p]) { hipGraphDestroy(h->pgraph[p]); h->pgraph[p] = nullptr; }
     if (h->pargs[p]) { hipFree(h->pargs[p]); h->pargs[p] = nullptr; }
   }
+  for (auto& g : h->graph_cache) destroy_graph_set(g);
+  h->graph_cache.clear();
   h->pipe_graph = false;
   h->graph_steps = 0;
+  h->graph_noise_table = false;
 }
 bool have_graph(const dsact_handle* h) { return h->graph_exec != nullptr || h->pipe_graph; }
 
@@ -2826,12 +2888,24 @@ bool have_graph(const dsact_handle* h) { return h->graph_exec != nullptr || h->p
 int check_handoff(dsact_handle* h) {
   if (!h->handoff_host || h->in_handoff || !*(volatile int*)h->handoff_host) return DSACT_OK;
   h->in_handoff = true;
+  const int word = *(volatile int*)h->handoff_host;
   const hipError_t e_dev = hipSetDevice(h->device);
   const hipError_t e_sync = hipStreamSynchronize(h->stream);
+  const int word2 = *(volatile int*)h->handoff_host;   // (an update kernel may have given up too while the stream drained)
   *(volatile int*)h->handoff_host = 0;
+  if (word == 2 && word2 == 2) {
+    // raised by the acting forward (k_act_mlp) only: it reads the parameters and writes nothing the update path reads, so
+    // the training state is intact -- the call fails, nothing is switched off, nothing has to be restored
+    h->in_handoff = false;
+    h->handoff_failures += 1;
+    return fail(h, DSACT_E_HIP, "the acting forward's layer hand-over timed out (a wave waited > 0.1 s for its input): this "
+                                "call's action is invalid; parameters and optimiser state are untouched%s%s",
+                e_sync != hipSuccess ? "; HIP also reported: " : "", e_sync != hipSuccess ? hipGetErrorString(e_sync) : "");
+  }
   const bool had_graph = have_graph(h);
-  const int steps = h->graph_steps;
-  const uint32_t gflags = h->graph_flags;
+  const int steps = had_graph ? h->graph_steps : h->want_graph_steps;
+  const uint32_t gflags = had_graph ? h->graph_flags : h->want_graph_flags;
+  const bool noise_tab = h->graph_noise_table;
   h->fwd_merge = false;
   h->pi_merge = false;
   h->handoff_failures += 1;
@@ -2846,18 +2920,37 @@ int check_handoff(dsact_handle* h) {
   if (h->chain_flags) e_set = hipMemset(h->chain_flags, 0, kChainFlagInts * sizeof(int));
   h->flags_dirty = false;
   int rebuilt = DSACT_E_STATE;
-  if (had_graph && twin_rc == DSACT_OK) rebuilt = dsact_graph_build(h, steps, gflags);
+  const bool wanted = had_graph || steps > 0;
+  if (wanted && twin_rc == DSACT_OK) {
+    // (the re-capture must not trip over an earlier, still unacknowledged timeout: capturing launches nothing)
+    h->state_invalid = false;
+    h->noise_table_on = noise_tab;
+    rebuilt = dsact_graph_build(h, steps, gflags);
+    h->noise_table_on = false;
+    if (rebuilt == DSACT_OK) h->graph_noise_table = noise_tab;
+  }
+  // not re-captured: remembered, and built by the first replay after the caller's acknowledgement
+  h->want_graph_steps = (wanted && rebuilt != DSACT_OK) ? steps : 0;
+  h->want_graph_flags = gflags;
   h->in_handoff = false;
   h->state_invalid = true;   // (after the re-capture: dsact_graph_build itself is an entry point that refuses an invalid state)
   const hipError_t e_hip = e_dev != hipSuccess ? e_dev : e_sync != hipSuccess ? e_sync : e_set;
   return fail(h, DSACT_E_HIP,
               "an in-launch hand-over timed out: a workgroup waited > 0.1 s for its producers' ready flags, so every result "
               "since the last successful call is invalid -- parameters, optimiser moments and targets included: restore them, "
-              "then acknowledge with dsact_set_state or dsact_bind_arenas (update entry points fail until then). Merged "
-              "launches are now disabled for this handle%s%s%s",
-              had_graph ? (rebuilt == DSACT_OK ? "; the graph was captured again without them" : "; re-capturing the graph failed")
-                        : "",
+              "then acknowledge with dsact_set_state(adam_steps, mean_std), dsact_debug_set(\"ack_state\") or dsact_bind_arenas "
+              "(update entry points fail until then). Merged launches are now disabled for this handle%s%s%s",
+              wanted ? (rebuilt == DSACT_OK ? "; the graph was captured again without them" : "; re-capturing the graph failed (it is built again by the next replay)")
+                     : "",
               e_hip != hipSuccess ? "; HIP also reported: " : "", e_hip != hipSuccess ? hipGetErrorString(e_hip) : "");
+}
+
+// a graph a hand-over failure could not re-capture is captured by the first replay after the acknowledgement
+static int ensure_wanted_graph(dsact_handle* h) {
+  if (have_graph(h) || h->want_graph_steps <= 0) return DSACT_OK;
+  const int steps = h->want_graph_steps;
+  h->want_graph_steps = 0;
+  return dsact_graph_build(h, steps, h->want_graph_flags);
 }
 
 int check_ready(dsact_handle* h, bool need_batch) {
@@ -3232,6 +3325,11 @@ int dsact_destroy(dsact_handle* h) {
   if (h->d_apjobs) hipFree(h->d_apjobs);
   if (h->d_pack) hipFree(h->d_pack);
   if (h->idx_table) hipFree(h->idx_table);
+  if (h->noise_table) hipFree(h->noise_table);
+  for (int i = 0; i < 4; ++i) {
+    if (h->grp_pin[i]) hipHostFree(h->grp_pin[i]);
+    if (h->grp_ev[i]) hipEventDestroy(h->grp_ev[i]);
+  }
   if (h->stage_dev) hipFree(h->stage_dev);
   for (int i = 0; i < 2; ++i) {
     if (h->stage_pin[i]) hipHostFree(h->stage_pin[i]);
@@ -3345,7 +3443,9 @@ int dsact_set_state(dsact_handle* h, const int32_t adam_steps[3], const float me
     st.ms1 = mean_std[0]; st.ms2 = mean_std[1];
   }
   HIPCHK(h, hipMemcpy(h->st, &st, sizeof(st), hipMemcpyHostToDevice));
-  h->state_invalid = false;   // the caller restored (or accepts) the device state after a hand-over timeout
+  // a FULL restore (step counters and the EMA, after the arenas were rewritten) acknowledges a hand-over timeout; a partial
+  // call (e.g. only mean_std tweaked) does not: dsact_debug_set("ack_state", 1) is the explicit acknowledgement
+  if (adam_steps && mean_std) h->state_invalid = false;
   return DSACT_OK;
 }
 
@@ -3607,7 +3707,9 @@ int dsact_upload_index_table(dsact_handle* h, const int64_t* idx_host, int32_t r
   }
   if (have_graph(h) && rows != h->idx_rows) return fail(h, DSACT_E_STATE, "index table shape is baked into the captured graph");
   if (!h->idx_table || rows != h->idx_rows) {
+    drop_graphs(h);   // (cached ones included: the table's address and row count are baked into them)
     if (h->idx_table) hipFree(h->idx_table);
+    if (h->noise_table) { hipFree(h->noise_table); h->noise_table = nullptr; }   // sized by the row count
     HIPCHK(h, hipMalloc(&h->idx_table, n * sizeof(int)));
     h->idx_rows = rows;
   }
@@ -3762,6 +3864,8 @@ struct PipePlan {
   std::vector<BwdPiArgs> bp;      // [s]: the deferred policy backward of update s - 1 (valid when defer[s - 1])
   std::vector<int> bp_rg;
   bool dp = false;                // local gradients -> all-reduce -> k_adam_pack instead of the fused optimiser
+  bool skip = false;              // DSACT_F_SKIP_ACTOR_ON_OFF_ITERS: the discarded policy backward is not computed at all
+  std::vector<char> leaves;       // update s leaves policy / alpha / targets alone
 };
 // unit tables of the n forward launches -> plan.host and (synchronous copy: call it BEFORE a stream capture begins) dev_args
 static int plan_updates_pipe(dsact_handle* h, int n, int phase, PipePlan& plan, PipeFwd* dev_args, uint32_t flags = 0) {
@@ -3775,12 +3879,15 @@ static int plan_updates_pipe(dsact_handle* h, int n, int phase, PipePlan& plan, 
   //  arena is read by nobody; the deferred tiles store nothing and that segment simply keeps its previous content)
   const bool can_defer = h->pi_merge && h->dw_chunks == 1 && !h->fat_bwd && h->env_ride_slots == 0 && rg_pi <= 2 && !h->env_no_pipe_defer;
   plan.dp = (flags & DSACT_F_DATA_PARALLEL) != 0;
+  plan.skip = (flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) != 0 && !plan.dp;
+  plan.leaves.assign((size_t)n, 0);
   bool pre = false;
   int rc = DSACT_OK;
   h->mirror_w0 = true;   // (what the enqueue pass sets: the tiles' argument blocks are built here)
   for (int s = 0; s < n && rc == DSACT_OK; ++s) {
     const bool leaves_policy = ((phase + s) % D) != 0;        // this update's close does not touch policy / alpha / targets
     const bool do_pre = s + 1 < n && leaves_policy;
+    plan.leaves[(size_t)s] = leaves_policy;
     const BwdPiArgs* bp = nullptr;
     if (s > 0 && plan.defer[(size_t)s - 1]) {
       apply_pipe_set(h, set_of(s - 1));   // the deferred backward works on the PREVIOUS update's minibatch
@@ -3793,7 +3900,7 @@ static int plan_updates_pipe(dsact_handle* h, int n, int phase, PipePlan& plan, 
     }
     rc = pipe_fwd_build(h, set_of(s), set_of(s + 1), pre, do_pre, plan.host[(size_t)s], bp);
     plan.pre[(size_t)s] = pre; plan.dop[(size_t)s] = do_pre;
-    plan.defer[(size_t)s] = do_pre && can_defer;
+    plan.defer[(size_t)s] = do_pre && can_defer && !plan.skip;   // (skip: there is no policy backward to move)
     pre = do_pre;
   }
   h->mirror_w0 = false;
@@ -3854,7 +3961,7 @@ static int enqueue_updates_pipe(dsact_handle* h, int n, const PipePlan& plan, Pi
       continue;
     }
     h->pipe_defer_now = plan.defer[(size_t)s] != 0;
-    rc = enqueue_grads(h, true, true, 2, &ride);
+    rc = enqueue_grads(h, !(plan.skip && plan.leaves[(size_t)s]), true, 2, &ride);
     h->pipe_defer_now = false;
   }
   apply_pipe_set(h, 0);
@@ -3882,8 +3989,9 @@ static bool pipe_eligible(const dsact_handle* h, int steps_per_graph, uint32_t f
   const bool merged = !h->cnn && h->use_w1p && h->dw_chunks == 1 && !h->use_fork && !h->use_std_sums && h->alt_ws != nullptr &&
                       !h->env_no_merged_gather;
   // (data parallel too: replicas hold identical policies, which change on the same iterations)
-  return merged && h->chain_ok && !h->fat && h->fwd_merge && h->B % 4 == 0 && h->rng_seed != 0 &&
-         !(flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) && (!(flags & DSACT_F_DATA_PARALLEL) || h->comm != nullptr) && D >= 2 &&
+  // (noise comes from the device either way: Philox keyed by iteration, or the uploaded noise table of dsact_run_group)
+  return merged && h->chain_ok && !h->fat && h->fwd_merge && h->B % 4 == 0 && (h->rng_seed != 0 || h->noise_table_on) &&
+         (!(flags & DSACT_F_DATA_PARALLEL) || h->comm != nullptr) && D >= 2 &&
          D <= dsact_handle::kPipePhases && steps_per_graph >= 2 && !h->env_no_pipe;
 }
 
@@ -3892,7 +4000,8 @@ int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) 
   if (steps_per_graph < 1) return fail(h, DSACT_E_INVALID, "steps_per_graph must be >= 1");
   if (!h->idx_table) return fail(h, DSACT_E_STATE, "upload an index table first (dsact_upload_index_table)");
   HIPCHK(h, hipSetDevice(h->device));
-  drop_graphs(h);
+  if (h->build_keeps_cache) stash_graph(h); else drop_graphs(h);
+  h->want_graph_steps = 0;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (h->flags_dirty && h->chain_flags) {   // not inside the graph: the captured updates clear the flags themselves
     HIPCHK(h, hipMemset(h->chain_flags, 0, kChainFlags * sizeof(int)));
@@ -3970,6 +4079,7 @@ int dsact_graph_run(dsact_handle* h, int64_t first_iteration, int64_t n_steps) {
   if (h->state_invalid)
     return fail(h, DSACT_E_STATE, "device state is invalid after a hand-over timeout: restore parameters / optimiser state, then "
                                   "call dsact_set_state or dsact_bind_arenas");
+  TRY(ensure_wanted_graph(h));
   if (!have_graph(h)) return fail(h, DSACT_E_STATE, "dsact_graph_build first");
   if (n_steps % h->graph_steps) return fail(h, DSACT_E_INVALID, "n_steps must be a multiple of steps_per_graph");
   if ((h->graph_flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) && first_iteration % h->cfg.delay_update)
@@ -3978,6 +4088,90 @@ int dsact_graph_run(dsact_handle* h, int64_t first_iteration, int64_t n_steps) {
   TRY(set_device_iteration(h, first_iteration));
   TRY(launch_groups(h, first_iteration, n_steps / h->graph_steps));
   h->dev_it_next = first_iteration + n_steps;
+  return DSACT_OK;
+}
+
+// The reference's loop between two sampler calls (training/trainer.py:63-82 with sample_interval = n_steps: the CNN examples run 8,
+// example_train/dsacv2_cnn_carracing_offasync.py:133): n_steps x { ReplayBuffer.sample_batch (replay_buffer.py:85-90) ->
+// DSAC_V2.local_update (dsac_v2.py:102-105) } as ONE graph replay. While no add_batch intervenes the ring size is constant and
+// only np.random.randint consumes the NumPy stream, so the caller draws the n_steps index rows up front -- the very calls,
+// in the very order, the reference makes -- and hands them over here: idx [n_steps][batch]. noise (nullable): the
+// reference's torch.randn draws of those updates, [n_steps][2*B*A + 2*B] = eps_new | eps_2 | z5 | z6 per update (strict RNG
+// through the graph; nullptr: device Philox keyed by iteration, which needs dsact_set_device_rng). Nothing here waits for
+// the device: the rows travel through pinned staging slots, the replay counters are reset by a stream-ordered kernel, and
+// captured graphs are kept per (n_steps, flags, noise mode) -- the first group of a new shape pays its capture.
+int dsact_run_group(dsact_handle* h, int64_t first_iteration, int32_t n_steps, const int64_t* idx, const float* noise, uint32_t flags) {
+  if (!h || !idx || n_steps < 1) return DSACT_E_INVALID;
+  TRY(check_ready(h, false));
+  if (!h->rb_obs) return fail(h, DSACT_E_STATE, "buffer not created");
+  if (h->size == 0) return fail(h, DSACT_E_STATE, "buffer empty");
+  if (!noise && h->rng_seed == 0) return fail(h, DSACT_E_STATE, "no noise source: pass the noise rows or call dsact_set_device_rng");
+  if ((flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) && (n_steps % h->cfg.delay_update || first_iteration % h->cfg.delay_update))
+    return fail(h, DSACT_E_INVALID, "with DSACT_F_SKIP_ACTOR_ON_OFF_ITERS a group must cover whole delay_update periods");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t B = (size_t)h->B, A = (size_t)h->A;
+  const size_t n_idx = (size_t)n_steps * B, nz_row = 2 * B * A + 2 * B;
+  for (size_t i = 0; i < n_idx; ++i)
+    if (idx[i] < 0 || idx[i] >= h->size) return fail(h, DSACT_E_INVALID, "index %lld out of range [0,%lld)", (long long)idx[i], h->size);
+  // ---- tables (their addresses and row counts are baked into every captured graph)
+  if (!h->idx_table || h->idx_rows < n_steps) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    drop_graphs(h);
+    if (h->idx_table) hipFree(h->idx_table);
+    if (h->noise_table) { hipFree(h->noise_table); h->noise_table = nullptr; }
+    h->idx_table = nullptr;
+    const int rows = n_steps > 16 ? n_steps : 16;
+    HIPCHK(h, hipMalloc(&h->idx_table, (size_t)rows * B * sizeof(int)));
+    HIPCHK(h, hipMemset(h->idx_table, 0, (size_t)rows * B * sizeof(int)));
+    h->idx_rows = rows;
+  }
+  if (noise && !h->noise_table) {
+    HIPCHK(h, hipMalloc(&h->noise_table, (size_t)h->idx_rows * nz_row * sizeof(float)));
+    HIPCHK(h, hipMemset(h->noise_table, 0, (size_t)h->idx_rows * nz_row * sizeof(float)));
+  }
+  // ---- the graph of this shape: active, cached, or captured now
+  const bool want_table = noise != nullptr;
+  if (!(have_graph(h) && h->graph_steps == n_steps && h->graph_flags == flags && h->graph_noise_table == want_table)) {
+    stash_graph(h);
+    if (!activate_graph(h, n_steps, flags, want_table)) {
+      h->build_keeps_cache = true;
+      h->noise_table_on = want_table;
+      const int rc = dsact_graph_build(h, n_steps, flags);
+      h->noise_table_on = false;
+      h->build_keeps_cache = false;
+      TRY(rc);
+      h->graph_noise_table = want_table;
+    }
+  }
+  // ---- rows -> pinned slot -> tables (stream-ordered; the slot is reused four groups later)
+  const size_t need = n_idx * sizeof(int) + (noise ? (size_t)n_steps * nz_row * sizeof(float) : 0);
+  if (need > h->grp_pin_bytes) {
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    size_t cap = need < (1u << 16) ? (1u << 16) : need;
+    for (int i = 0; i < 4; ++i) {
+      if (h->grp_pin[i]) { hipHostFree(h->grp_pin[i]); h->grp_pin[i] = nullptr; }
+      HIPCHK(h, hipHostMalloc((void**)&h->grp_pin[i], cap, hipHostMallocDefault));
+      if (!h->grp_ev[i]) HIPCHK(h, hipEventCreateWithFlags(&h->grp_ev[i], hipEventDisableTiming));
+    }
+    h->grp_pin_bytes = cap;
+  }
+  const int slot = (int)(h->grp_k++ & 3);
+  HIPCHK(h, hipEventSynchronize(h->grp_ev[slot]));
+  int* pin_idx = (int*)h->grp_pin[slot];
+  for (size_t i = 0; i < n_idx; ++i) pin_idx[i] = (int)idx[i];
+  HIPCHK(h, hipMemcpyAsync(h->idx_table, pin_idx, n_idx * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if (noise) {
+    float* pin_nz = (float*)(h->grp_pin[slot] + n_idx * sizeof(int));
+    memcpy(pin_nz, noise, (size_t)n_steps * nz_row * sizeof(float));
+    HIPCHK(h, hipMemcpyAsync(h->noise_table, pin_nz, (size_t)n_steps * nz_row * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  }
+  HIPCHK(h, hipEventRecord(h->grp_ev[slot], h->stream));
+  // ---- iteration of the first update, table row 0; then the replay
+  hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(64), 0, h->stream, h->st, (long long)first_iteration, 0LL);
+  if (hipGetLastError() != hipSuccess) return fail(h, DSACT_E_HIP, "launch k_set_counters failed");
+  TRY(launch_groups(h, first_iteration, 1));
+  h->dev_it_next = first_iteration + n_steps;
+  h->have_batch = true;
   return DSACT_OK;
 }
 
@@ -4155,6 +4349,7 @@ int dsact_time_steps(dsact_handle* h, int64_t first_iteration, int64_t n_steps, 
   TRY(set_device_iteration(h, first_iteration));
   HIPCHK(h, hipEventRecord(h->tev0, h->stream));
   if (use_graph) {
+    TRY(ensure_wanted_graph(h));
     if (!have_graph(h)) return fail(h, DSACT_E_STATE, "dsact_graph_build first");
     if (n_steps % h->graph_steps) return fail(h, DSACT_E_INVALID, "n_steps must be a multiple of steps_per_graph");
     if ((h->graph_flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) && first_iteration % h->cfg.delay_update)
@@ -4383,6 +4578,10 @@ int dsact_debug_set(dsact_handle* h, const char* name, double value) {
     if (h->twin && h->online) TRY(build_twin_fwd(h));   // (the twin-trunk forward reads the switch from its device-memory table)
     return DSACT_OK;
   }
+  if (!strcmp(name, "ack_state")) {     // the caller restored (or accepts) the device state after a hand-over timeout
+    h->state_invalid = false;
+    return DSACT_OK;
+  }
   if (!strcmp(name, "poison_handover")) {
     // everything a merged launch hands from producers to consumers: the saved observation parts of the critics' first
     // layers and the action columns the policy heads fill (both batch sets). A consumer that does not wait for -- or
@@ -4413,6 +4612,7 @@ int dsact_debug_set(dsact_handle* h, const char* name, double value) {
   return fail(h, DSACT_E_INVALID, "dsact_debug_set: unknown name '%s'", name);
 }
 
+static bool act_fast_ok(const dsact_handle* h);
 int dsact_debug_get(const dsact_handle* h, const char* name, double* value) {
   if (!h || !name || !value) return DSACT_E_INVALID;
   if (!strcmp(name, "fwd_merge")) *value = h->fwd_merge ? 1.0 : 0.0;
@@ -4424,6 +4624,9 @@ int dsact_debug_get(const dsact_handle* h, const char* name, double* value) {
   else if (!strcmp(name, "graph_steps")) *value = (double)h->graph_steps;
   else if (!strcmp(name, "pipe_graph")) *value = h->pipe_graph ? 1.0 : 0.0;   // the captured graphs are the pipelined ones
   else if (!strcmp(name, "state_invalid")) *value = h->state_invalid ? 1.0 : 0.0;
+  else if (!strcmp(name, "act_fast")) *value = act_fast_ok(h) ? 1.0 : 0.0;     // dsact_act_sample / the one-launch acting forward serve this handle
+  else if (!strcmp(name, "graph_cache")) *value = (double)h->graph_cache.size();   // inactive captured graphs kept by dsact_run_group
+  else if (!strcmp(name, "graph_noise_table")) *value = h->graph_noise_table ? 1.0 : 0.0;
   else if (!strcmp(name, "twin_par")) *value = (h->twin_par ? 1.0 : 0.0) + (h->twin_merged ? 2.0 : 0.0);   // CNN nets: trunks as own workgroups (+2: one launch)
   else return DSACT_E_INVALID;
   return DSACT_OK;

@@ -1268,7 +1268,7 @@ __global__ void __launch_bounds__(kThreads) k_gather_img(ImgGatherArgs a) {
     if (a.rb_act && t == 0) { a.rew[r] = a.rb_rew[src]; a.done[r] = a.rb_done[src]; }
     if (a.bookkeeping) {
       const long long it = a.use_dev ? a.st->it_next : a.host_it;
-      if (a.nz.seed != 0) fill_noise_rows(a.nz, it, r, r + 1, a.A, t, kThreads);
+      if (a.nz.seed != 0) fill_noise_rows(a.nz, it, trow, r, r + 1, a.A, t, kThreads);
       if (blockIdx.x == 0 && t == 0) prologue_duties(a.stw, it, a.advance_counters, a.hp);
     }
   }

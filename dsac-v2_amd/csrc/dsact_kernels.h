@@ -341,10 +341,21 @@ __device__ void prologue_duties(DevState* st, long long it, int advance_counters
 struct NoiseArgs {
   uint64_t seed;  // 0: noise buffers were filled by the host (parity mode)
   float* eps_new; float* eps_2; float* z5; float* z6;
+  // noise TABLE (strict RNG through graph replays): row `trow` of [rows][2*B*A + 2*B] floats = eps_new | eps_2 | z5 | z6 of the
+  // update that reads index-table row `trow` -- the reference's own torch.randn draws, uploaded with
+  // the index rows by dsact_run_group. nullptr: device Philox keyed by (seed, iteration)
+  const float* table; int B;
 };
 
-// fills the noise of rows [r0, r1)
-__device__ void fill_noise_rows(const NoiseArgs& nz, long long it, int r0, int r1, int A, int tid, int nthreads) {
+// fills the noise of rows [r0, r1) of the minibatch of iteration `it` (index / noise table row `trow`)
+__device__ void fill_noise_rows(const NoiseArgs& nz, long long it, int trow, int r0, int r1, int A, int tid, int nthreads) {
+  if (nz.table) {
+    const size_t BA = (size_t)nz.B * A;
+    const float* row = nz.table + (size_t)trow * (2 * BA + 2 * (size_t)nz.B);
+    for (int q = r0 * A + tid; q < r1 * A; q += nthreads) { nz.eps_new[q] = row[q]; nz.eps_2[q] = row[BA + q]; }
+    for (int r = r0 + tid; r < r1; r += nthreads) { nz.z5[r] = row[2 * BA + r]; nz.z6[r] = row[2 * BA + nz.B + r]; }
+    return;
+  }
   const int per_row4 = (A + 3) >> 2;
   const int n4 = (r1 - r0) * per_row4;
   for (int q = tid; q < n4; q += nthreads) {
@@ -458,7 +469,7 @@ __device__ __forceinline__ void gather_block(const GatherArgs& a, int blk, long 
   }
   if (a.nz.seed != 0) {
     const int r1 = r0 + 4 < a.B ? r0 + 4 : a.B;
-    if (r0 < a.B) fill_noise_rows(a.nz, it, r0, r1, a.A, tid, kThreads);
+    if (r0 < a.B) fill_noise_rows(a.nz, it, trow, r0, r1, a.A, tid, kThreads);
   }
   if (row) {
     if (one_trip) {
@@ -525,12 +536,18 @@ __device__ __forceinline__ bool loss_rider(const RideArgs& r) {
 // stand-alone bookkeeping for the flows that do not gather (host-staged minibatch, apply-only)
 struct PrologueArgs {
   DevState* st; int use_dev; long long host_it; int advance_counters; int fill_noise; StepHyper hp;
-  NoiseArgs nz; int B, A;
+  NoiseArgs nz; int B, A; int table_rows;
 };
 __global__ void __launch_bounds__(kThreads) k_prologue(PrologueArgs a) {
   const long long it = a.use_dev ? a.st->it_next : a.host_it;
-  if (a.nz.seed != 0 && a.fill_noise) fill_noise_rows(a.nz, it, 0, a.B, a.A, threadIdx.x, kThreads);
+  if (a.nz.seed != 0 && a.fill_noise) fill_noise_rows(a.nz, it, a.use_dev && a.nz.table ? (int)(a.st->seq_next % a.table_rows) : 0, 0, a.B, a.A, threadIdx.x, kThreads);
   if (threadIdx.x == 0) prologue_duties(a.st, it, a.advance_counters, a.hp);
+}
+
+// device-side (stream-ordered, no host sync) reset of the replay counters before a group of graph-replayed updates:
+// iteration of the group's first update, index / noise table row 0
+__global__ void k_set_counters(DevState* st, long long it_next, long long seq_next) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { st->it_next = it_next; st->seq_next = seq_next; }
 }
 
 // replay ring scatter (training/replay_buffer.py:58-83): n staged rows -> ring rows (ptr+i) % cap

@@ -155,14 +155,12 @@ class DSAC_V1_HIP(_v2.DSAC_V2_HIP):
     def adjustable_parameters(self):
         return ("gamma", "tau", "auto_alpha", "alpha", "TD_bound", "bound", "delay_update")
 
-    def _noise(self):
-        if not self.strict_rng:
-            return
+    def _draw_noise(self):
         B, A = self.engine.batch, self.engine.act_dim
         # the reference's 5 draws in order (dsac_v1.py:148-149,201-206,240): the q_target sample is the only z used
         eps_new, eps_2 = torch.randn(B, A), torch.randn(B, A)
         z = [torch.randn(B) for _ in range(3)]
-        self.engine.set_noise(eps_new.numpy(), eps_2.numpy(), z[1].numpy(), z[1].numpy())
+        return eps_new.numpy(), eps_2.numpy(), z[1].numpy(), z[1].numpy()
 
     def local_update(self, data: Dict, iteration: int) -> dict:
         t0 = time.time()

@@ -488,6 +488,36 @@ class HipBatch(dict):
         return dict.__iter__(self)
 
 
+class HipBatchGroup:
+    """Token returned by HipReplayBuffer.sample_batches(batch_size, n): the index rows of the next n minibatches, drawn with
+    the reference's own n `np.random.randint` calls (replay_buffer.py:86) while the ring cannot change between them. The
+    rows are gathered on the device by the graph replay DSAC_V2_HIP.local_update_group issues; like a HipBatch it refuses
+    to be trained on once add_batch has replaced sampled rows."""
+
+    def __init__(self, engine, idxs):
+        self.engine, self.idxs = engine, np.array(idxs, dtype=np.int64, copy=True)
+        assert self.idxs.ndim == 2
+        self._ptr0, self._added0, self._fill_epoch0 = engine.buffer_ptr, engine.rows_added, engine.fill_epoch
+
+    def __len__(self):
+        return int(self.idxs.shape[0])
+
+    def batch(self, j):
+        """minibatch j as an ordinary HipBatch token (re-gathers its rows when used)"""
+        b = HipBatch(self.engine, self.idxs[j])
+        b.serial = -1
+        b._ptr0, b._added0, b._fill_epoch0 = self._ptr0, self._added0, self._fill_epoch0
+        return b
+
+    def check_fresh(self):
+        probe = self.batch(0)
+        probe.idxs = self.idxs.reshape(-1)
+        n = probe._overwritten()
+        if n:
+            raise RuntimeError("HipBatchGroup: %d of the %d sampled ring rows were overwritten by add_batch after "
+                               "sample_batches; sample again" % (n, self.idxs.size))
+
+
 class _Hyper:
     """An `adjustable_parameters` entry (dsac_v2.py:92-99): the reference re-reads the attribute on every update,
     so assignment after construction must reach the engine (dsact_set_hyper; drops a captured graph)."""
@@ -557,8 +587,12 @@ class DSAC_V2_HIP:
     SIDECAR_FORMAT = "dsact-optimizer-sidecar/1"
 
     def optimizer_state_dict(self) -> dict:
-        """Everything `networks.state_dict()` does not hold and a bit-exact resume needs: both Adam moment arenas (flat, in
-        the engine's arena order), the three Adam step counters, the mean_std EMA; plus the arena signature they belong to."""
+        """The optimiser-side state `networks.state_dict()` does not hold: both Adam moment arenas (flat, in the engine's
+        arena order), the three Adam step counters, the mean_std EMA; plus the arena signature and the algorithm class they
+        belong to. Restoring it (after `networks.load_state_dict`) makes the UPDATES continue bit for bit from the same
+        minibatches and noise (tests/test_hip_parity.py::test_optimizer_sidecar_roundtrip_resumes_bitwise). It is not a
+        whole-run snapshot: the trainer's iteration counter (hence the delay_update phase and the iteration-keyed device
+        noise), the replay ring and the NumPy / torch generator states are the caller's to restore."""
         e = self.engine
         e.sync()
         st = e.get_state()
@@ -571,6 +605,8 @@ class DSAC_V2_HIP:
         """restores what optimizer_state_dict() saved (after `networks.load_state_dict`); refuses another layout"""
         if sd.get("format") != self.SIDECAR_FORMAT:
             raise ValueError("not a %s file" % self.SIDECAR_FORMAT)
+        if sd.get("algorithm", type(self).__name__) != type(self).__name__:
+            raise ValueError("optimizer sidecar was written by %s, this is %s" % (sd.get("algorithm"), type(self).__name__))
         sig = [(k, tuple(v.shape)) for k, v in self.networks.state_dict().items()]
         if [(k, tuple(shape)) for k, shape in sd["signature"]] != sig:
             raise ValueError("optimizer sidecar belongs to another network layout")
@@ -598,14 +634,18 @@ class DSAC_V2_HIP:
         # (training/trainer.py:72-74); CUDA ones are copied device-to-device
         self.engine.load_batch(data["obs"], data["act"], data["rew"], data["obs2"], data["done"])
 
-    def _noise(self):
-        if not self.strict_rng:
-            return
+    def _draw_noise(self):
+        """ONE update's draws from the torch global generator in the reference's order -> (eps_new, eps_2, z5, z6)"""
         B, A = self.engine.batch, self.engine.act_dim
         # the reference's 8 draws, in order (SURVEY.md App. A.1); 4 of them are discarded there too
         eps_new, eps_2 = torch.randn(B, A), torch.randn(B, A)
         z = [torch.randn(B) for _ in range(6)]
-        self.engine.set_noise(eps_new.numpy(), eps_2.numpy(), z[2].numpy(), z[3].numpy())
+        return eps_new.numpy(), eps_2.numpy(), z[2].numpy(), z[3].numpy()
+
+    def _noise(self):
+        if not self.strict_rng:
+            return
+        self.engine.set_noise(*self._draw_noise())
 
     # ---- reference surface ------------------------------------------------------------------------
     def _keep_previous_stats(self):
@@ -616,11 +656,11 @@ class DSAC_V2_HIP:
         if self._serial and prev is not None and not prev._done:
             self.engine.stats_snapshot(self._serial)   # asynchronous; see LazyTbInfo._stats
 
-    def _new_tb(self, t0):
+    def _new_tb(self, t0, n_updates=1):
         import weakref
 
         self._serial += 1
-        tb = self._tb_cls(self, self._serial, (time.time() - t0) * 1000)
+        tb = self._tb_cls(self, self._serial, (time.time() - t0) * 1000 / n_updates)
         self._last_tb = weakref.ref(tb)
         return tb
 
@@ -631,6 +671,25 @@ class DSAC_V2_HIP:
         self._noise()
         self.engine.step(int(iteration), self.flags)
         return self._new_tb(t0)
+
+    def local_update_group(self, group: "HipBatchGroup", iteration: int) -> dict:
+        """len(group) consecutive { sample_batch -> local_update } of the reference's loop (training/trainer.py:68-82), for
+        iterations `iteration` .. `iteration + len(group) - 1`, as ONE graph replay (dsact_run_group: the pipelined graph
+        where the shape allows it). `group` comes from HipReplayBuffer.sample_batches, which drew the index rows with the
+        reference's own calls; with `strict_rng` the reference's torch.randn draws of those updates are made here, in its
+        order, and travel as the graph's noise table. Returns the tb_info of the LAST update (the one a trainer can log:
+        HipOffSerialTrainer ends a group at every iteration it has to log, evaluate or save at)."""
+        if not (isinstance(group, HipBatchGroup) and group.engine is self.engine):
+            raise TypeError("local_update_group takes the HipBatchGroup this engine's HipReplayBuffer.sample_batches returned")
+        t0 = time.time()
+        group.check_fresh()
+        self._keep_previous_stats()
+        n = len(group)
+        noise = None
+        if self.strict_rng:
+            noise = np.stack([np.concatenate([a.reshape(-1) for a in self._draw_noise()]) for _ in range(n)]).astype(np.float32)
+        self.engine.run_group(int(iteration), group.idxs, noise, self.flags)
+        return self._new_tb(t0, n)
 
     def _grad_views(self):
         lay, g = self.engine.layout, self.engine.grads

@@ -82,6 +82,7 @@ SYMBOLS = [
     ("dsact_step", C.c_int, [_P, C.c_int64, C.c_uint32]),
     ("dsact_graph_build", C.c_int, [_P, C.c_int32, C.c_uint32]),
     ("dsact_graph_run", C.c_int, [_P, C.c_int64, C.c_int64]),
+    ("dsact_run_group", C.c_int, [_P, C.c_int64, C.c_int32, C.POINTER(C.c_int64), _FP, C.c_uint32]),
     ("dsact_dp_begin", C.c_int, [_P, C.c_int64]),
     ("dsact_dp_enqueue_grads", C.c_int, [_P, C.c_uint32]),
     ("dsact_dp_enqueue_grads_critic", C.c_int, [_P, C.c_uint32]),

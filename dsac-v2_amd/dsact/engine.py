@@ -286,6 +286,23 @@ class DsactEngine:
         self.stage_serial += 1   # the index table's device-side gather replaces the staged minibatch
         self._chk(self._lib.dsact_graph_run(self._h, int(first_iteration), int(n_steps)))
 
+    def run_group(self, first_iteration: int, idx_rows, noise_rows=None, flags: int = 0):
+        """dsact_run_group: len(idx_rows) x { sample_batch -> local_update } of the reference's loop between two sampler calls
+        as one graph replay. idx_rows int64 [n][batch] (drawn by the caller with the reference's np.random.randint calls);
+        noise_rows float32 [n][2*B*A + 2*B] (eps_new | eps_2 | z5 | z6 per update) or None for device Philox noise.
+        Asynchronous."""
+        idx = np.ascontiguousarray(np.asarray(idx_rows, dtype=np.int64))
+        assert idx.ndim == 2 and idx.shape[1] == self.batch, idx.shape
+        n = int(idx.shape[0])
+        nz = None
+        if noise_rows is not None:
+            nz = _f32(noise_rows)
+            assert nz.shape == (n, 2 * self.batch * self.act_dim + 2 * self.batch), nz.shape
+        self.stage_serial += 1   # the group's last minibatch replaces the staged one
+        self._chk(self._lib.dsact_run_group(self._h, int(first_iteration), n, idx.ctypes.data_as(C.POINTER(C.c_int64)),
+                                            _ffi.fptr(nz), int(flags)))
+        self._graph_steps = n
+
     # data-parallel halves (iteration and index-table row come from device state)
     def dp_begin(self, first_iteration: int):
         self._chk(self._lib.dsact_dp_begin(self._h, int(first_iteration)))

@@ -63,7 +63,7 @@ class HipReplayBuffer:
         if n == 0:
             return
         packed = getattr(samples, "packed", None)
-        if packed is not None and packed[0].shape == (n, self._obs_flat):
+        if packed is not None and packed[0].shape == (n, self._obs_flat) and self._packed_matches(samples, packed):
             # HipOffSampler's fast path already holds the transitions as packed float32 arrays (training/hip_sampler.py)
             obs, act, rew, obs2, done, logp = packed
             self.engine.buffer_add(obs, act, rew, obs2, done, logp)
@@ -79,6 +79,37 @@ class HipReplayBuffer:
             obs[i], act[i], rew[i], done[i], logp[i] = np.asarray(s[0]).reshape(-1), s[2], s[3], s[5], s[6]
             obs2[i] = np.asarray(s[4]).reshape(-1)
         self.engine.buffer_add(obs, act, rew, obs2, done, logp)
+
+    @staticmethod
+    def _packed_matches(samples, packed):
+        """the packed arrays are only trusted while the list still is what the sampler built: a consumer that filtered,
+        reordered or replaced tuples (reward shaping, n-step post-processing) gets the tuple walk. Checked on the first,
+        middle and last tuple: their action must still BE the packed row (same memory) and their reward the packed value."""
+        n = len(samples)
+        try:
+            for i in {0, n // 2, n - 1}:
+                t = samples[i]
+                a = t[2]
+                if not (isinstance(a, np.ndarray) and a.ctypes.data == packed[1][i].ctypes.data):
+                    return False
+                if np.float32(t[3]) != packed[2][i] or bool(t[5]) != bool(packed[4][i]):
+                    return False
+        except Exception:
+            return False
+        return True
+
+    def sample_batches(self, batch_size: int, n: int):
+        """the index rows of the next `n` minibatches: n x `np.random.randint(0, size, batch_size)` -- the calls, and the
+        order, of n reference `sample_batch` calls with no add_batch between them (replay_buffer.py:86; the ring size is
+        constant, nothing else consumes the NumPy stream). The rows are gathered on the device by
+        DSAC_V2_HIP.local_update_group (one graph replay for the n updates)."""
+        from dsac_v2_hip import HipBatchGroup
+
+        if batch_size != self.engine.batch:
+            raise ValueError("batch_size %d != the engine's minibatch rows %d" % (batch_size, self.engine.batch))
+        size = self.size
+        idxs = np.stack([np.random.randint(0, size, size=batch_size) for _ in range(int(n))])
+        return HipBatchGroup(self.engine, idxs)
 
     def sample_batch(self, batch_size: int):
         from dsac_v2_hip import HipBatch

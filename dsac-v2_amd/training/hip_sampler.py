@@ -65,6 +65,10 @@ class HipOffSampler:
         self.action_type = kwargs.get("action_type", "continu")
         self.reward_scale = kwargs.get("reward_scale", 1)
         self.total_sample_number = 0
+        # additive: `hip_sampler_general_path=True` forces the general loop below (reproducibility comparisons against the
+        # reference sampler: the fast path's logits differ from the module forward's in the last bits)
+        self.general_path = bool(kwargs.get("hip_sampler_general_path", False))
+        self._fast_ok, self._fast_started = {}, False
 
     def load_state_dict(self, state_dict):
         self.networks.load_state_dict(state_dict)
@@ -73,17 +77,31 @@ class HipOffSampler:
         """the engine behind an ATTACHED MLP policy whose action distribution is the tanh-Gaussian (what every shipped
         DSAC example uses): one dsact_act_sample call per environment step replaces tensor round trips, Normal objects and
         .cpu().numpy() (145 -> ~50 us per step, bench.py `e2e`). None: the general path below."""
+        if self.general_path:
+            return None
         pol = getattr(self.networks, "policy", None)
         eng = getattr(pol, "_engine", None)
         if eng is None or self.action_type != "continu" or getattr(eng, "conv_type", None):
             return None
-        if type(pol).__name__ != "HipStochaPolicy" or getattr(eng, "obs_dim", 1 << 30) > 768:
+        if type(pol).__name__ != "HipStochaPolicy":
             return None
-        return eng
+        # the library's own gate (act_fast_ok, csrc/dsact_api.hip): MLP policy, observation <= 768 floats, at most 4 hidden
+        # layers, act_dim <= 32, DSACT_NO_FAST_ACT unset -- asked once per engine, never restated here
+        ok = self._fast_ok.get(id(eng))
+        if ok is None:
+            try:
+                ok = eng.debug_get("act_fast") == 1.0
+            except Exception:
+                ok = False
+            self._fast_ok[id(eng)] = ok
+        return eng if ok else None
 
     def _sample_fast(self, eng):
-        """same step order, same generator consumption (ONE torch.randn(1, A) per step: Normal.sample() is
-        mean + std * that draw, bit for bit) and the same stored transitions as the loop in sample()"""
+        """same step order and the same generator consumption as the loop in sample() (ONE torch.randn(1, A) per step:
+        Normal.sample() is mean + std * that draw); actions / log-probs equal the general path's within fp32 rounding
+        (k_act_mlp sums a layer in another order than the module forward: 2e-6 of the action limit, 5e-4 on logp), so a
+        long run from the same seed may leave the general path's trajectory. `hip_sampler_general_path=True` forces the
+        general loop."""
         n, env = self.sample_batch_size, self.env
         O, A = eng.obs_dim, eng.act_dim
         obs_b, obs2_b = np.empty((n, O), np.float32), np.empty((n, O), np.float32)
@@ -93,11 +111,13 @@ class HipOffSampler:
         batch = SampleBatch()
         randn, act_sample, scale = torch.randn, eng.act_sample, self.reward_scale
         obs, info = self.obs, self.info
+        self._fast_started = False
         for i in range(n):
             ob = obs_b[i]
             ob[:] = np.reshape(obs, -1)
             eps = randn(1, A).numpy()
             action, logp = act_sample(ob, eps)
+            self._fast_started = True     # (an environment step follows: no silent fallback from here on)
             act_b[i] = action
             logp_b[i] = logp[0]
             next_obs, reward, done, next_info = env.step(np.clip(act_b[i], low, high))
@@ -122,8 +142,17 @@ class HipOffSampler:
         t0 = time.perf_counter()
         eng = self._fast_engine()
         if eng is not None:
-            batch = self._sample_fast(eng)
-            return batch, {SAMPLER_TIME_KEY: (time.perf_counter() - t0) * 1000}
+            from dsact._ffi import DsactError
+            try:
+                batch = self._sample_fast(eng)
+                return batch, {SAMPLER_TIME_KEY: (time.perf_counter() - t0) * 1000}
+            except DsactError as ex:
+                # dsact_act_sample refused this handle (DSACT_E_INVALID) before anything was stepped: the general loop
+                # serves every policy (a safety net behind the "act_fast" gate: one torch.randn draw has been spent by then).
+                # Anything else (a failed launch, a hand-over timeout) is the caller's to see.
+                if "E_INVALID" not in str(ex) or self._fast_started:
+                    raise
+                self._fast_ok[id(eng)] = False
         batch = []
         for _ in range(self.sample_batch_size):
             obs_t = torch.from_numpy(np.expand_dims(self.obs, axis=0).astype("float32"))

@@ -3,6 +3,10 @@ the per-iteration device ping-pong and without per-step host syncs.
 
     step():  sampler.sample() -> buffer.add_batch()           every sample_interval iterations
              buffer.sample_batch(B) -> alg.local_update()     minibatch stays in HBM (HipBatch token)
+               train(): the updates between two sampler calls (sample_interval = K: the reference's CNN examples run 8) are
+               issued as GROUPS -- buffer.sample_batches(B, n) -> alg.local_update_group(): one (pipelined) hipGraph replay
+               for n updates -- whenever algorithm and buffer offer those two methods. A group ends at every iteration the
+               loop has to log, evaluate or save at, so everything the host reads sees exactly the reference's state.
              log (reads the lazily materialised tb_info)      every log_save_interval
              evaluator.run_evaluation()                       every eval_interval
              torch.save(networks.state_dict())                every apprfunc_save_interval
@@ -167,6 +171,10 @@ class HipOffSerialTrainer:
         self.best_tar = -float("inf")
         self.iteration = 0
         self.last_tar = None
+        # additive: `hip_group_updates` (default True) -- see train(); False keeps one local_update call per iteration
+        self.group_updates = bool(kwargs.get("hip_group_updates", True))
+        self._grouping = False        # only while train() drives the loop (a caller of step() sees one update per call)
+        self._seg_end, self._seg_tb = -1, None
         if self.save_folder:
             os.makedirs(os.path.join(self.save_folder, "apprfunc"), exist_ok=True)
         self.writer = _Scalars(self.save_folder)
@@ -178,13 +186,44 @@ class HipOffSerialTrainer:
             self.buffer.add_batch(samples)
         self.start_time = time.time()
 
+    def _has_event(self, it):
+        """the host reads device state at the end of iteration `it`: tb_info (log), the policy (evaluation), the networks (save)"""
+        return (it % self.log_save_interval == 0 or (self.evaluator is not None and it % self.eval_interval == 0)
+                or (self.save_folder and it % self.apprfunc_save_interval == 0))
+
+    def _segment_end(self, it):
+        """last iteration of the run of updates that may be issued at once from iteration `it` on: nothing but
+        sample_batch + local_update happens between them in the reference loop (training/trainer.py:60-146) -- it stops before
+        the next sampler call and at the first iteration with a host-side event; the last iteration of train() bounds it"""
+        end = (it // self.sample_interval + 1) * self.sample_interval - 1 if self.sampler is not None else it + 63
+        end = min(end, self.max_iteration - 1, it + 63)
+        j = it
+        while j < end and not self._has_event(j):
+            j += 1
+        return max(j, it)
+
+    def _update(self, it):
+        """the replay + learn part of iteration `it` (trainer.py:68-82); returns its tb_info, or None inside a group (whose
+        updates were issued by the group's first iteration; only its LAST iteration has host-side events)"""
+        if it <= self._seg_end:
+            return self._seg_tb if it == self._seg_end else None
+        n = 1
+        if self._grouping and self.group_updates and hasattr(self.alg, "local_update_group") and hasattr(self.buffer, "sample_batches"):
+            n = self._segment_end(it) - it + 1
+        if n >= 2:
+            group = self.buffer.sample_batches(self.replay_batch_size, n)
+            self._seg_tb = self.alg.local_update_group(group, it)
+            self._seg_end = it + n - 1
+            return None
+        batch = self.buffer.sample_batch(self.replay_batch_size)
+        return self.alg.local_update(batch, it)
+
     def step(self):
         sampler_tb = {}
         if self.sampler is not None and self.iteration % self.sample_interval == 0:
             samples, sampler_tb = self.sampler.sample()
             self.buffer.add_batch(samples)
-        batch = self.buffer.sample_batch(self.replay_batch_size)
-        alg_tb = self.alg.local_update(batch, self.iteration)
+        alg_tb = self._update(self.iteration)
         if self.iteration % self.log_save_interval == 0:
             self.writer.add_dict(dict(alg_tb.items()), self.iteration)  # the only host sync of the update
             self.writer.add_dict(sampler_tb, self.iteration)
@@ -208,9 +247,13 @@ class HipOffSerialTrainer:
             self.save_apprfunc()
 
     def train(self):
-        while self.iteration < self.max_iteration:
-            self.step()
-            self.iteration += 1
+        self._grouping = True
+        try:
+            while self.iteration < self.max_iteration:
+                self.step()
+                self.iteration += 1
+        finally:
+            self._grouping = False
         if self.save_folder:
             self.save_apprfunc()
         self.writer.flush()

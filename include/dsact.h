@@ -202,7 +202,8 @@ int dsact_step(dsact_handle* h, int64_t iteration, uint32_t flags); /* compute_g
  * be written while a graph runs: inside a graph the minibatch of update s+1 is gathered while
  * update s is still in flight (it rides in that update's loss launch); results are bit-identical
  * to the same updates issued one by one. The last update's minibatch stays staged.
- * Pipelined graph (row-slice chains, batch <= 256, device RNG, 2 <= delay_update <= 4, steps_per_graph >= 2, no flags):
+ * Pipelined graph (row-slice chains, batch <= 256, device RNG or dsact_run_group's noise table, 2 <= delay_update <= 4,
+ * steps_per_graph >= 2; DSACT_F_SKIP_ACTOR_ON_OFF_ITERS: the same graph without the discarded policy backward):
  * policy, log_alpha and the three target nets change only when iteration % delay_update == 0 (dsac_v2.py:320-347), so
  * update it + 1 of such a window sees the policy update `it` saw -- the forward launch of update `it` also evaluates
  * policy(obs) + rsample and policy_target(obs2) for the NEXT minibatch (gathered two updates ahead) and update it + 1's
@@ -211,6 +212,18 @@ int dsact_step(dsact_handle* h, int64_t iteration, uint32_t flags); /* compute_g
  * dsact_debug_get(h, "pipe_graph") tells which one was captured. */
 int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags);
 int dsact_graph_run(dsact_handle* h, int64_t first_iteration, int64_t n_steps);
+/* OffSerialTrainer.step between two sampler calls (training/trainer.py:63-82 with sample_interval = n_steps; the reference's
+ * CNN examples run 8, example_train/dsacv2_cnn_carracing_offasync.py:133): n_steps x { ReplayBuffer.sample_batch
+ * (replay_buffer.py:85-90) -> DSAC_V2.local_update (dsac_v2.py:102-105) } as ONE graph replay. While no add_batch intervenes
+ * the ring size is constant and only np.random.randint consumes the NumPy stream (replay_buffer.py:86), so the caller
+ * draws the n_steps index rows up front with the reference's own calls: idx[n_steps][batch]. noise (nullable): the
+ * reference's torch.randn draws of those updates, [n_steps][2*batch*act_dim + 2*batch] floats =
+ * eps_new | eps_2 | z5 | z6 per update -- strict RNG through the (pipelined) graph; NULL: device Philox keyed by the
+ * iteration (dsact_set_device_rng). Asynchronous: pinned staging, a stream-ordered reset of the replay counters, no host
+ * wait. Captured graphs are kept per (n_steps, flags, noise mode); the first group of a new shape pays its capture.
+ * Same bits as n_steps x { dsact_gather; dsact_step }. The ring must not be written while the group runs (dsact_sync or
+ * any synchronising call first) -- dsact_buffer_add is stream-ordered behind it and therefore safe. */
+int dsact_run_group(dsact_handle* h, int64_t first_iteration, int32_t n_steps, const int64_t* idx, const float* noise, uint32_t flags);
 
 /* data-parallel replay (one process per GPU): the same two halves with iteration / index-table row
  * taken from device state, so the host never touches the step. Between them the caller all-reduces

@@ -55,6 +55,24 @@ TRAINER_CASE = dict(
 )
 
 
+# sample_interval > 1 (training/trainer.py:63-66; the reference's CNN examples run 8, example_train/dsacv2_cnn_carracing_offasync.py:133):
+# the sampler is called every K-th iteration and K updates follow each call. `si2` / `si8` keep the dense log / eval / save
+# cadence above (every group of updates is cut by host-side events), `si8_sparse` has whole groups of 8 between events.
+VARIANTS = {
+    "si2": dict(sample_interval=2),
+    "si8": dict(sample_interval=8),
+    "si8_sparse": dict(sample_interval=8, max_iteration=48, log_save_interval=16, eval_interval=24, apprfunc_save_interval=40),
+}
+
+
+def variant_case(name):
+    return dict(TRAINER_CASE, **VARIANTS[name])
+
+
+def variant_golden(name):
+    return os.path.join(ROOT, "tests", "golden", "trainer_trajectory_%s.json" % name)
+
+
 class Hooks:
     """records the loop from outside; usable around the reference trainer and around HipOffSerialTrainer alike"""
 
@@ -161,12 +179,14 @@ def run_reference(save_folder, case=None):
 def main():
     import tempfile
 
-    with tempfile.TemporaryDirectory() as d:
-        traj = run_reference(d)
-    with open(GOLDEN, "w") as f:
-        json.dump(traj, f)
-    print("wrote %s: %d updates, %d scalars, %d checkpoints, evals %s" % (
-        GOLDEN, len(traj["tb_info"]), len(traj["scalars"]), len(traj["saved"]), traj["evals"]))
+    for name in [None] + sorted(VARIANTS):
+        path = GOLDEN if name is None else variant_golden(name)
+        with tempfile.TemporaryDirectory() as d:
+            traj = run_reference(d, None if name is None else variant_case(name))
+        with open(path, "w") as f:
+            json.dump(traj, f)
+        print("wrote %s: %d updates, %d scalars, %d checkpoints, evals %s" % (
+            path, len(traj["tb_info"]), len(traj["scalars"]), len(traj["saved"]), traj["evals"]))
 
 
 if __name__ == "__main__":

@@ -19,7 +19,8 @@ import pytest
 import torch
 
 from oracle import ref_loader
-from oracle.trainer_trajectory import ENVS, GOLDEN, TIME_TAGS, TRAINER_CASE, Hooks, run_reference, tb_floats
+from oracle.trainer_trajectory import (ENVS, GOLDEN, TIME_TAGS, TRAINER_CASE, VARIANTS, Hooks, run_reference, tb_floats, variant_case,
+                                       variant_golden)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(os.path.dirname(HERE), "dsac-v2_amd")
@@ -56,7 +57,7 @@ def run_hip_loop(kw, alg, buffer):
 
     sampler = plugin.create_sampler(**kw)
     evaluator = plugin.create_evaluator(**kw)
-    updates, evals, buf_state = [], [], []
+    updates, evals, buf_state, groups = [], [], [], []
     with Hooks() as hk:
         trainer = plugin.create_trainer(alg, sampler, buffer, evaluator, **kw)
         inner_update, inner_eval, inner_sample = alg.local_update, evaluator.run_evaluation, buffer.sample_batch
@@ -67,13 +68,26 @@ def run_hip_loop(kw, alg, buffer):
             return tb
 
         alg.local_update = local_update
+        if hasattr(alg, "local_update_group"):
+            inner_group = alg.local_update_group
+
+            def local_update_group(group, it):
+                tb = inner_group(group, it)
+                # a group's intermediate updates have no readable statistics (nobody logs them): recorded as None
+                updates.extend([None] * (len(group) - 1) + [tb_floats(tb)])
+                groups.append([int(it), len(group)])
+                for _ in range(len(group)):
+                    buf_state.append([int(buffer.size), int(buffer.ptr)])
+                return tb
+
+            alg.local_update_group = local_update_group
         evaluator.run_evaluation = lambda it: (lambda r: (evals.append([int(it), float(r)]), r)[1])(inner_eval(it))
         buffer.sample_batch = lambda n: (buf_state.append([int(buffer.size), int(buffer.ptr)]), inner_sample(n))[1]
         trainer.train()
     scalars = [[r["tag"], r["step"], r["value"]] for r in map(json.loads, open(os.path.join(kw["save_folder"], "scalars.jsonl")))]
     return {"indices": hk.indices, "buffer": buf_state, "scalars": scalars, "saved": hk.saved,
             "apprfunc_dir": sorted(os.listdir(os.path.join(kw["save_folder"], "apprfunc"))), "evals": evals,
-            "tb_info": updates, "samples": int(sampler.get_total_sample_number())}
+            "tb_info": updates, "samples": int(sampler.get_total_sample_number()), "groups": groups}
 
 
 def check_cadence(got, want):
@@ -119,24 +133,109 @@ def test_trainer_loop_equals_the_reference_loop_exactly(tmp_path):
     assert len(os.listdir(tmp_path / "hip" / "data")) == len(tags)
 
 
-def test_committed_trajectory_is_what_the_reference_produces_here(tmp_path):
-    """the fixture the GPU test compares against is regenerated where the reference is mounted"""
-    if not ref_loader.reference_available():
-        pytest.skip("reference not mounted")
-    want = json.load(open(GOLDEN))
-    got = run_reference(str(tmp_path))
-    check_cadence(got, want)
-    assert got["tb_info"] == want["tb_info"] and got["evals"] == want["evals"]
+class _GroupedRefAlg:
+    """the reference's algorithm behind the GROUP surface of DSAC_V2_HIP (local_update_group): K updates issued by one
+    call. With identical arithmetic on both sides, HipOffSerialTrainer's grouping (which iterations it batches, when it
+    draws their indices, where host-side events cut a group) must reproduce the reference loop exactly."""
+
+    def __init__(self, alg):
+        self._alg = alg
+        self.networks = alg.networks
+
+    def __getattr__(self, k):
+        return getattr(self._alg, k)
+
+    def local_update(self, data, it):
+        return self._alg.local_update(data, it)
+
+    def local_update_group(self, group, it):
+        tb = None
+        for j, batch in enumerate(group):
+            tb = self._alg.local_update(batch, it + j)
+        return tb
 
 
-@pytest.mark.gpu
-def test_hip_stack_follows_the_reference_trajectory(tmp_path):
+class _GroupedRefBuffer:
+    def __init__(self, buf):
+        self._buf = buf
+
+    def __getattr__(self, k):
+        return getattr(self._buf, k)
+
+    def sample_batch(self, n):
+        return self._buf.sample_batch(n)
+
+    def sample_batches(self, batch_size, n):
+        return [self._buf.sample_batch(batch_size) for _ in range(n)]
+
+
+@pytest.mark.skipif(not ref_loader.reference_available(), reason="reference not mounted")
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_grouped_updates_follow_the_reference_loop_exactly(tmp_path, variant):
+    """sample_interval = K (training/trainer.py:63-66): HipOffSerialTrainer.train() issues the updates between two sampler
+    calls as groups (sample_batches + local_update_group) cut at every iteration with a log / evaluation / checkpoint. Around
+    the reference's own arithmetic that must be the reference loop to the last bit: index draws, ring state, every scalar,
+    checkpoint names, evaluation returns, and the tb_info of every update a group can report (its last)."""
+    ref_loader.import_reference()
     for p in (PKG, ENVS):
         if p not in sys.path:
             sys.path.append(p)
     import plugin
 
-    want = json.load(open(GOLDEN))
+    plugin.install()
+    case = variant_case(variant)
+    want = run_reference(str(tmp_path / "ref"), case)
+    from utils.initialization import create_alg, create_buffer
+
+    kw = derived_kwargs(case, str(tmp_path / "hip"))
+    alg = _GroupedRefAlg(create_alg(**kw))
+    buffer = _GroupedRefBuffer(create_buffer(**kw))
+    got = run_hip_loop(kw, alg, buffer)
+    assert got["groups"], "no group was issued"
+    K = case["sample_interval"]
+    sizes = sorted({n for _, n in got["groups"]})
+    assert sizes[-1] <= K and sizes[0] >= 2
+    if variant == "si2":
+        assert sizes == [2]
+    if variant == "si8":
+        assert len(sizes) >= 3          # the dense log / eval / save cadence cuts the groups of 8 into several lengths
+    if variant == "si8_sparse":
+        assert 8 in sizes               # whole groups of 8 between events
+    # indices: the reference trainer draws per iteration, ours per group -- the same calls in the same order
+    check_cadence(got, want)
+    for g, w in zip(got["tb_info"], want["tb_info"]):
+        assert g is None or g == w
+    assert sum(g is not None for g in got["tb_info"]) >= len(want["tb_info"]) // K
+    assert got["evals"] == want["evals"]
+    for g, w in zip(got["scalars"], want["scalars"]):
+        if g[0] in TIME_TAGS:
+            continue
+        assert g[2] == w[2] or (g[0] == RAM_TAG), (g, w)
+
+
+def test_committed_trajectory_is_what_the_reference_produces_here(tmp_path):
+    """the fixtures the GPU tests compare against are regenerated where the reference is mounted"""
+    if not ref_loader.reference_available():
+        pytest.skip("reference not mounted")
+    for path, case in [(GOLDEN, None)] + [(variant_golden(v), variant_case(v)) for v in sorted(VARIANTS)]:
+        want = json.load(open(path))
+        got = run_reference(str(tmp_path / os.path.basename(path)), case)
+        check_cadence(got, want)
+        assert got["tb_info"] == want["tb_info"] and got["evals"] == want["evals"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [None] + sorted(VARIANTS))
+def test_hip_stack_follows_the_reference_trajectory(tmp_path, variant):
+    """variant None: sample_interval 1 (one eager update per iteration). si2 / si8 / si8_sparse: the updates between two sampler
+    calls run as graph replays (dsact_run_group: the pipelined graph, the reference's torch.randn draws through the noise
+    table) -- against the trajectory the UNMODIFIED reference loop produced with that sample_interval."""
+    for p in (PKG, ENVS):
+        if p not in sys.path:
+            sys.path.append(p)
+    import plugin
+
+    want = json.load(open(GOLDEN if variant is None else variant_golden(variant)))
     case = dict(want["case"], algorithm="DSAC_V2_HIP", buffer_name="hip_replay_buffer")
     kw = derived_kwargs(case, str(tmp_path), strict_rng=True)
     alg = plugin.create_alg(**kw)
@@ -144,8 +243,14 @@ def test_hip_stack_follows_the_reference_trajectory(tmp_path):
     assert buffer.engine is alg.engine
     got = run_hip_loop(kw, alg, buffer)
     check_cadence(got, want)
+    if variant is not None:
+        assert got["groups"] and alg.engine.debug_get("graph_noise_table") == 1.0
+        if variant == "si8_sparse":
+            assert any(n == 8 for _, n in got["groups"]) and alg.engine.debug_get("pipe_graph") == 1.0
     crit = 7   # Loss/Critic loss: a sum of squared TD terms -> relative gate
     for it, (g, w) in enumerate(zip(got["tb_info"], want["tb_info"])):
+        if g is None:      # inside a group: not reported (the next reported update carries its effect)
+            continue
         for k, (a, b) in enumerate(zip(g, w)):
             tol = 1e-6 + 1e-5 * abs(b) if k == crit else 1e-4
             assert abs(a - b) <= tol, (it, k, a, b)
@@ -162,5 +267,5 @@ def test_hip_stack_follows_the_reference_trajectory(tmp_path):
         vals[g[0]] = g[2]
     assert len(vals) >= 15
     # checkpoints load back into a reference-shaped container (state_dict keys of dsac_v2.py:19-62)
-    sd = torch.load(os.path.join(str(tmp_path), "apprfunc", "apprfunc_40.pkl"))
+    sd = torch.load(os.path.join(str(tmp_path), "apprfunc", "apprfunc_%d.pkl" % case["max_iteration"]))
     assert list(sd.keys())[0] == "log_alpha" and len(sd) == 41
