@@ -436,6 +436,41 @@ def e2e_gpu(hidden, device, iters=400, warm=60):
                     "forward call (observation in the kernel arguments, logits through mapped host memory)"}
 
 
+def e2e_gpu_grouped(hidden, device, interval=8, iters=1600, warm=160):
+    """the same loop with the reference's CNN-example cadence sample_interval = 8 (example_train/dsacv2_cnn_carracing_offasync.py:133;
+    loop training/trainer.py:63-82): one sampler call, then 8 updates -- which HipOffSerialTrainer.train() issues as ONE graph
+    replay (HipReplayBuffer.sample_batches + DSAC_V2_HIP.local_update_group = dsact_run_group: the pipelined graph). Reported:
+    iterations/s and the cost of an update THROUGH THE PLUGIN SURFACE = (iteration time - sampler time); the same loop with
+    hip_group_updates=False (one local_update call per iteration) beside it."""
+    import plugin
+
+    out = {}
+    for grouped in (True, False):
+        kw = e2e_kwargs(hidden, B, hip_device=device, sample_interval=interval, hip_group_updates=grouped)
+        alg = plugin.create_alg(**kw)
+        sampler = plugin.create_sampler(**kw)
+        buf = plugin.create_buffer(**kw)
+        trainer = plugin.create_trainer(alg, sampler, buf, None, **kw)
+        trainer._grouping = True          # what train() sets: step() alone keeps one update per call
+        w, ws = _timed_loop(trainer, sampler, warm, iters, alg.engine.sync)
+        r = {"value": iters / w, "unit": "iterations/s", "ms_per_iteration": 1000.0 * w / iters,
+             "sampler_ms_per_iteration": 1000.0 * ws / iters, "update_us_through_local_update": 1e6 * (w - ws) / iters}
+        if grouped:
+            try:
+                r["pipelined_graph"] = alg.engine.debug_get("pipe_graph") == 1.0
+            except Exception:
+                pass
+            out.update(r)
+        else:
+            out["ungrouped"] = r
+        del trainer, buf, sampler, alg
+    out.update({"sample_interval": interval, "iterations": iters,
+                "note": "HipOffSerialTrainer with sample_interval = %d: per %d iterations one sampler call (20 env steps) and ONE graph "
+                        "replay of %d updates; update_us_through_local_update = (iteration time - sampler time): what an update costs "
+                        "through sample_batches + local_update_group, host work included" % (interval, interval, interval)})
+    return out
+
+
 def e2e_cpu(hidden, budget_s=10.0):
     """the same loop on the host cores: the UNMODIFIED reference trainer (its own factories, CPU nets) where
     /root/reference is mounted -- kind "reference"; elsewhere our loop around the oracle port of the update and a CPU
@@ -1025,6 +1060,10 @@ def main():
             out["e2e"] = e2e_gpu(hidden, local)
         except Exception as ex:  # informational leg
             out["e2e_error"] = repr(ex)
+        try:
+            out["e2e_si8"] = e2e_gpu_grouped(hidden, local)
+        except Exception as ex:  # informational leg
+            out["e2e_si8_error"] = repr(ex)
     if not use_dp and not args.no_alt and args.batch == B:
         alt_hidden = [256, 256] if hidden != [256, 256] else [256, 256, 256]
         del alg

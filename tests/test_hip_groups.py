@@ -1,0 +1,303 @@
+"""dsact_run_group -- the updates between two sampler calls of the reference loop (training/trainer.py:63-82 with
+sample_interval = K) as ONE graph replay -- against the same updates issued one by one, bit for bit, and (strict RNG through
+the noise table) against the oracle directly.
+
+  * device Philox noise: group replays of several lengths (graphs are cached per length; the pipelined graph where the shape
+    allows it) == { dsact_gather; dsact_step } per update: parameters, targets, both Adam moments, step state, statistics,
+    the staged minibatch;
+  * reference noise (`strict_rng`): the reference's torch.randn draws travel as the graph's noise table -- == eager strict
+    updates bitwise, and the pipelined graph's results against the ORACLE fed the same minibatches and noise (no
+    test fed reference noise through the pipelined graph itself);
+  * the plugin surface: HipReplayBuffer.sample_batches + DSAC_V2_HIP.local_update_group == sample_batch + local_update.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import hip_kwargs
+from oracle.dsact_oracle import TB_KEYS, draw_noise
+from test_hip_parity import Report, make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def host_ring(N, O, A, seed):
+    rng = np.random.default_rng(seed)
+    return {"obs": rng.standard_normal((N, O), dtype=np.float32), "act": rng.uniform(-0.4, 0.4, (N, A)).astype(np.float32),
+            "rew": rng.standard_normal(N, dtype=np.float32), "obs2": rng.standard_normal((N, O), dtype=np.float32),
+            "done": (rng.random(N) < 0.05).astype(np.float32)}
+
+
+def fill(e, ring):
+    e.buffer_create(ring["rew"].shape[0])
+    e.buffer_add(ring["obs"], ring["act"], ring["rew"], ring["obs2"], ring["done"])
+    e.sync()
+
+
+def same_engine_state(a, b, tag):
+    for name in ("online", "target", "adam_m", "adam_v"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), (tag, name)
+    assert a.get_state() == b.get_state(), tag
+    sa, sb = a.read_stats(), b.read_stats()
+    for k in sa:
+        if k.startswith("_device"):
+            continue
+        assert sa[k] == sb[k] or (np.isnan(sa[k]) and np.isnan(sb[k])), (tag, k, sa[k], sb[k])
+    ba, bb = a.read_batch(with_logp=False), b.read_batch(with_logp=False)
+    for k in ("obs", "act", "rew", "obs2", "done"):
+        assert np.array_equal(ba[k], bb[k]), (tag, k)
+
+
+@pytest.mark.parametrize("O,A,hid,B,D,first,lengths", [
+    (16, 4, (64, 64), 64, 2, 0, [8, 8, 3, 1, 2, 8, 3]),          # lengths recur: cached graphs are re-activated
+    (16, 4, (64, 64), 64, 2, 5, [7, 2, 7]),                       # starts on an odd iteration, odd lengths: both phase graphs
+    (24, 6, (128, 128, 128), 32, 3, 1, [6, 4, 6]),                # delay_update 3
+    (11, 3, (96, 40), 50, 2, 0, [4, 5]),                          # tile path (ragged widths): the plain merged graph
+    (376, 17, (256, 256, 256), 256, 2, 3, [8, 8, 5]),             # the BASELINE.json shape
+])
+def test_run_group_equals_eager_steps(O, A, hid, B, D, first, lengths):
+    N = 3000
+    ring = host_ring(N, O, A, 3)
+    engines = []
+    for mode in ("eager", "group"):
+        alg, _ = make_pair(O, A, hid, B, seed=4, delay_update=D)
+        e = alg.engine
+        e.set_device_rng(4242)
+        fill(e, ring)
+        np.random.seed(7)
+        it = first
+        for n in lengths:
+            rows = np.stack([np.random.randint(0, N, size=B) for _ in range(n)])
+            if mode == "group":
+                e.run_group(it, rows)
+            else:
+                for j in range(n):
+                    e.gather(rows[j])
+                    e.step(it + j)
+            it += n
+        e.sync()
+        engines.append(e)
+    same_engine_state(engines[0], engines[1], "group vs eager")
+    g = engines[1]
+    assert g.debug_get("graph_cache") == len(set(lengths)) - 1       # one active graph, the other lengths cached
+    if g.chain_active:
+        assert g.debug_get("pipe_graph") == (1.0 if lengths[-1] >= 2 else 0.0)
+    assert torch.isfinite(g.online).all()
+
+
+def noise_row(nz):
+    return np.concatenate([nz["eps_new"].numpy().reshape(-1), nz["eps_2"].numpy().reshape(-1), nz["z5"].numpy(), nz["z6"].numpy()])
+
+
+@pytest.mark.parametrize("O,A,hid,B,first,lengths", [
+    (16, 4, (64, 64), 64, 1, [4, 3, 4]),
+    (376, 17, (256, 256, 256), 256, 0, [8]),                      # the BASELINE.json shape, one pipelined graph of 8 updates
+])
+def test_reference_noise_through_the_pipelined_graph(O, A, hid, B, first, lengths):
+    """strict RNG: the reference's eight torch.randn draws per update are drawn up front, in its order,
+    and replayed from the graph's noise table. (1) == the same updates issued eagerly with dsact_set_noise, bit for bit;
+    (2) the graph's results against the ORACLE on the same minibatches and noise at the parity gates."""
+    N = 2000
+    ring = host_ring(N, O, A, 5)
+    total = sum(lengths)
+    np.random.seed(11)
+    rows = np.stack([np.random.randint(0, N, size=B) for _ in range(total)])
+    torch.manual_seed(99)
+    noises = [draw_noise(B, A) for _ in range(total)]
+    engines, orc = [], None
+    for mode in ("eager", "group"):
+        alg, o = make_pair(O, A, hid, B, seed=4)
+        e = alg.engine
+        fill(e, ring)
+        k = 0
+        for n in lengths:
+            if mode == "group":
+                e.run_group(first + k, rows[k:k + n], np.stack([noise_row(z) for z in noises[k:k + n]]))
+            else:
+                for j in range(k, k + n):
+                    z = noises[j]
+                    e.set_noise(z["eps_new"].numpy(), z["eps_2"].numpy(), z["z5"].numpy(), z["z6"].numpy())
+                    e.gather(rows[j])
+                    e.step(first + j)
+            k += n
+        e.sync()
+        engines.append(e)
+        orc = o
+    same_engine_state(engines[0], engines[1], "noise table vs eager strict")
+    g = engines[1]
+    assert g.debug_get("graph_noise_table") == 1.0 and g.debug_get("pipe_graph") == 1.0
+    # ---- the oracle on the same minibatches and noise
+    tb = None
+    for j in range(total):
+        r = rows[j]
+        data = {k: torch.as_tensor(ring[k][r]) for k in ("obs", "act", "rew", "obs2", "done")}
+        data["logp"] = torch.zeros(B)
+        tb = orc.local_update(data, noises[j], first + j)
+    rep = Report("reference noise through the pipelined graph: O=%d A=%d hid=%s B=%d, %d updates vs oracle" % (O, A, hid, B, total))
+    st = g.read_stats()
+    for k in TB_KEYS[:-1]:
+        if k == "Loss/Critic loss-RL iter":
+            rep.cmp("tb." + k, st[k], float(tb[k]), 1e-6, 1e-5)
+        else:
+            rep.cmp("tb." + k, st[k], float(tb[k]), 1e-4)
+    got, want = g.online.cpu().numpy().astype(np.float64), orc.flat_params().numpy().astype(np.float64)
+    err = np.abs(got - want)
+    # (the element-wise Adam-noise budget is enforced on the eager path by test_hip_parity.run_case; the graph equals that
+    #  path bitwise -- here: every element within the sign-flip worst case, all but a few per mille within 1e-6)
+    frac = float((err > 1e-6).mean())
+    rep.rows.append(("params: fraction over 1e-6", frac, 0.0, 2e-3, frac <= 2e-3))
+    worst_ok = float(err.max()) <= 2.0 * 1e-4 * total
+    rep.rows.append(("params: worst element", float(err.max()), float(np.abs(want).max()), 2e-4 * total, worst_ok))
+    if frac > 2e-3 or not worst_ok:
+        rep.bad.append("params")
+    rep.cmp("targets", g.target.cpu().numpy(), orc.flat_targets(), 1e-6)
+    rep.finish()
+
+
+def test_group_surface_equals_per_iteration_surface():
+    """HipReplayBuffer.sample_batches + DSAC_V2_HIP.local_update_group (what HipOffSerialTrainer.train() issues between two
+    sampler calls) == sample_batch + local_update per iteration: same NumPy stream consumption, same parameters, and the
+    group's tb_info is the last update's."""
+    from dsac_v2_hip import DSAC_V2_HIP
+    from training.hip_replay_buffer import HipReplayBuffer
+
+    O, A, hid, B, N, K = 16, 4, (64, 64), 64, 500, 6
+    ring = host_ring(N, O, A, 9)
+    out = []
+    for mode in ("single", "group"):
+        torch.manual_seed(2)
+        kw = hip_kwargs(O, A, hid, B, buffer_max_size=N, seed=5)
+        alg = DSAC_V2_HIP(**kw)
+        buf = HipReplayBuffer(**kw)
+        assert buf.engine is alg.engine
+        samples = [(ring["obs"][i], {}, ring["act"][i], float(ring["rew"][i]), ring["obs2"][i], bool(ring["done"][i]), 0.0, {})
+                   for i in range(N)]
+        buf.add_batch(samples)
+        np.random.seed(3)
+        if mode == "group":
+            g1 = buf.sample_batches(B, K)
+            tb = alg.local_update_group(g1, 10)
+            g2 = buf.sample_batches(B, 2)
+            tb = alg.local_update_group(g2, 10 + K)
+        else:
+            for it in range(10, 10 + K + 2):
+                tb = alg.local_update(buf.sample_batch(B), it)
+        vals = [float(tb[k]) for k in TB_KEYS[:-1]]
+        out.append((alg, vals, np.random.randint(0, 1 << 30)))
+    assert out[0][2] == out[1][2]                       # the NumPy stream stands where the reference loop would leave it
+    assert out[0][1] == out[1][1]
+    for name in ("online", "target", "adam_m", "adam_v"):
+        assert torch.equal(getattr(out[0][0].engine, name), getattr(out[1][0].engine, name)), name
+    # a token whose rows were overwritten after sampling refuses to train (the reference's batch is a copy taken at sample time)
+    alg, buf = out[1][0], None
+    from dsac_v2_hip import HipBatchGroup
+    grp = HipBatchGroup(alg.engine, np.zeros((2, B), np.int64))
+    alg.engine.buffer_add(ring["obs"][:N], ring["act"][:N], ring["rew"][:N], ring["obs2"][:N], ring["done"][:N])
+    with pytest.raises(RuntimeError, match="overwritten"):
+        alg.local_update_group(grp, 0)
+
+
+@pytest.mark.parametrize("O,A,hid,B,first,total", [(16, 4, (64, 64), 64, 0, 8), (376, 17, (256, 256, 256), 256, 2, 8)])
+def test_fast_mode_takes_the_pipelined_graph(O, A, hid, B, first, total):
+    """DSACT_F_SKIP_ACTOR_ON_OFF_ITERS ("fast": the discarded policy backward of the policy-preserving updates is not computed,
+    dsac_v2.py:174-186 vs :324) now captures the pipelined graph too (fast was slower than strict because it fell
+    back to the plain graph): == eager fast updates == the strict trajectory's parameters, bit for bit."""
+    N = 2048
+    engines = []
+    for mode in ("eager_fast", "graph_fast", "graph_strict"):
+        alg, _ = make_pair(O, A, hid, B, seed=4)
+        e = alg.engine
+        e.set_device_rng(31)
+        e.buffer_create(N)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        e.buffer_fill_device(0, torch.randn(N, O, device="cuda", generator=g), torch.rand(N, A, device="cuda", generator=g) - .5,
+                             torch.randn(N, device="cuda", generator=g), torch.randn(N, O, device="cuda", generator=g),
+                             (torch.rand(N, device="cuda", generator=g) < .05).float())
+        np.random.seed(1)
+        e.upload_index_table(np.random.randint(0, N, size=(8, B)))
+        if mode == "eager_fast":
+            e.time_steps(first, total, use_graph=False, flags=1)
+        else:
+            fl = 1 if mode == "graph_fast" else 0
+            e.graph_build(4, fl)
+            assert e.debug_get("pipe_graph") == 1.0
+            e.graph_run(first, total)
+        e.sync()
+        engines.append(e)
+    for name in ("online", "target", "adam_m", "adam_v"):
+        assert torch.equal(getattr(engines[0], name), getattr(engines[1], name)), ("fast graph vs fast eager", name)
+    for name in ("online", "target"):
+        assert torch.equal(getattr(engines[1], name), getattr(engines[2], name)), ("fast vs strict", name)
+
+
+def test_state_acknowledgement_is_explicit():
+    """dsact_set_state acknowledges a hand-over timeout only as a FULL restore (step counters AND the EMA); a
+    partial call leaves the handle refusing updates; dsact_debug_set("ack_state") is the explicit acknowledgement."""
+    from dsact._ffi import DsactError
+
+    O, A, hid, B = 16, 4, (64, 64), 64
+    alg, _ = make_pair(O, A, hid, B, seed=4)
+    e = alg.engine
+    e.set_device_rng(5)
+    ring = host_ring(512, O, A, 1)
+    fill(e, ring)
+    e.upload_index_table(np.random.default_rng(0).integers(0, 512, size=(4, B)))
+    state = e.get_state()
+    e.debug_set("withhold_flag", 1)
+    e.graph_build(4)
+    e.graph_run(0, 4)
+    with pytest.raises(DsactError):
+        e.sync()
+    assert e.debug_get("state_invalid") == 1.0
+    e.debug_set("withhold_flag", 0)
+    e.set_state(mean_std=state["mean_std"])                 # partial: not an acknowledgement
+    assert e.debug_get("state_invalid") == 1.0
+    with pytest.raises(DsactError):
+        e.step(0)
+    e.debug_set("ack_state", 1)
+    assert e.debug_get("state_invalid") == 0.0
+    e.gather(np.arange(B))
+    e.step(0)
+    e.sync()
+
+
+class _ToyEnv:     # deterministic toy dynamics with a time limit (gym 0.23 protocol)
+    class _S:
+        low, high = np.full(4, -0.3, np.float32), np.full(4, 0.3, np.float32)
+    action_space = _S()
+
+    def __init__(self):
+        self.t, self.s = 0, np.zeros(16, np.float32)
+
+    def reset(self):
+        self.t, self.s = 0, np.linspace(-1, 1, 16).astype(np.float32)
+        return self.s.copy(), {}
+
+    def step(self, a):
+        self.t += 1
+        self.s = (0.9 * self.s + 0.1 * np.resize(a, 16)).astype(np.float32)
+        return self.s.copy(), float(self.s.sum()), False, {"TimeLimit.truncated": self.t >= 7}
+
+
+@pytest.mark.parametrize("hid,env,kw,fast", [
+    ((64, 64), {}, {}, True),
+    ((64, 64, 64, 64, 64), {}, {}, False),                      # 5 hidden layers: beyond the one-launch acting forward (kActMaxLayers)
+    ((64, 64), {"DSACT_NO_FAST_ACT": "1"}, {}, False),          # the documented A/B switch
+    ((64, 64), {}, {"hip_sampler_general_path": True}, False),  # forced by the caller
+])
+def test_sampler_fast_path_gate_is_the_librarys(hid, env, kw, fast, monkeypatch):
+    """HipOffSampler took dsact_act_sample for every attached MLP policy with obs_dim <= 768, but the
+    library also wants <= 4 hidden layers and DSACT_NO_FAST_ACT unset -- sample() aborted training on those. The gate is now
+    the library's own answer (dsact_debug_get "act_fast"); every configuration samples."""
+    from training.hip_sampler import HipOffSampler
+
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    alg, _ = make_pair(16, 4, hid, 32, act_limit=0.4, seed=62)
+    assert alg.engine.debug_get("act_fast") == (1.0 if fast or kw else 0.0)
+    smp = HipOffSampler(env=_ToyEnv(), networks=alg.networks, sample_batch_size=12, action_type="continu", **kw)
+    torch.manual_seed(9)
+    batch, tb = smp.sample()
+    assert len(batch) == 12 and (getattr(batch, "packed", None) is not None) == fast
+    for s in batch:
+        assert np.isfinite(np.asarray(s[2])).all() and np.all(np.abs(np.asarray(s[2])) <= 0.4 + 1e-6)
