@@ -71,7 +71,7 @@ struct ProfRec {
 
 constexpr int kChainFlagSlices = 64;                 // slices per unit of a merged forward launch (batch <= 256, >= 4 rows each)
 constexpr int kChainFlags = 10 * kChainFlagSlices;  // done[6 units] + zdone[q1c, q2c]; twin trunks: 8 x (group, net) partial-output flags + done[pi, pit]
-constexpr int kChainCounters = 8 * kArriveStride;   // behind the flags (+128 ints of padding): arrival counter replicas of the merged policy backward
+constexpr int kChainCounters = kChMaxL * 8 * kArriveStride;   // behind the flags (+128 ints of padding): per-layer arrival counters (8 replicas each) of the merged policy backward
 constexpr int kChainFlagInts = kChainFlags + 128 + kChainCounters;
 
 struct dsact_handle {
@@ -316,6 +316,13 @@ struct dsact_handle {
   unsigned long long* pipe_hand[3] = {nullptr, nullptr, nullptr};   // tagged hand-over buffers [B][32] (value, tag): new_act, act2, act2 of the next minibatch
   bool env_no_pipe_tagged = false;      // DSACT_NO_PIPE_TAGGED: ready flags + separate data instead of (value, tag) pairs (A/B)
   bool pipe_defer_now = false;          // set while the update being enqueued defers its (discarded) policy backward
+  // merged critic backward + critic tiles + close (k_chain_bwd_qt) on the updates that defer their policy backward
+  int* bqt_cnt = nullptr;               // arrival counters [2 critics][8 x kArriveStride], zeroed by the forward launch's bookkeeping block
+  int* bqt_tab = nullptr; int bqt_tab_blocks = 0;   // block -> tile table (classes of layers in arrival order, dealt to the XCDs)
+  bool env_pi_layers = false;           // DSACT_PI_LAYERS=1 (experiments): per-layer arrival counters for the policy's tiles (measured slower:
+                                        // chain_bwd_pi 22.5-22.8 -> 23.4-23.6 us -- the early tiles' traffic slows the chain whose end the first layer's tiles wait for)
+  bool env_no_bqt = false;              // DSACT_NO_BQT_MERGE: critics' backward and their tiles stay two launches (A/B)
+  bool bqt_now = false;                 // set while such an update is being enqueued
   bool pipe_graph = false;              // the captured graphs are the pipelined ones (pgraph / pexec, one per phase)
   hipGraph_t pgraph[kPipePhases] = {nullptr, nullptr, nullptr, nullptr};
   hipGraphExec_t pexec[kPipePhases] = {nullptr, nullptr, nullptr, nullptr};
@@ -555,7 +562,7 @@ void carve(dsact_handle* h, Carver& c) {
   h->stats = c.take<float>(16 * (1 + DSACT_STATS_SLOTS));   // [0]: dsact_read_stats; [1 + slot]: the snapshot ring
   h->ones = c.take<float>(B);
   h->std_sums = c.take<float>(2);
-  h->timeline = c.take<long long>(512 * 16);
+  h->timeline = c.take<long long>(1024 * 16);
   h->dw_parts = c.take<float>(h->dw_chunks > 1 ? (size_t)h->dw_chunks * h->dw_part_stride : 4);
   for (int i = 0; i < 4; ++i) h->zobs[i] = c.take<float>(B * h->w[0]);
   h->chain_flags = c.take<int>(kChainFlagInts);   // [unit 0..5][slice] ready flags of the merged forward launch, then the spin-timeout word
@@ -2171,7 +2178,7 @@ static PipePlace pipe_place(const dsact_handle* h, bool pre, bool do_pre, int ro
 // fills P for the forward launch of a pipelined update: own minibatch = set_own (pre: its policy units ran in the previous
 // launch), next minibatch = set_next (do_pre: its policy units run here). Leaves the handle on set_own.
 // bp: nullptr, or the deferred policy backward of the previous update this launch carries (its chain slices and tiles)
-int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do_pre, PipeFwd& P, const BwdPiArgs* bp = nullptr) {
+int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do_pre, PipeFwd& P, const BwdPiArgs* bp = nullptr, bool book = false) {
   memset(&P, 0, sizeof(P));
   const bool qt_pre = h->env_pipe_qt != 0;
   int* f = h->chain_flags;
@@ -2274,6 +2281,12 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
   if (bp) {   // the deferred policy tiles: XCD x takes the x-th contiguous eighth of the tile list (xcd_chunk's locality)
     const int per = (bp->n_pi_tiles + 7) >> 3;
     for (int t = 0; t < bp->n_pi_tiles; ++t) q[t / per].push_back((kPipeRoleTile << 16) | t);
+  }
+  if (book) {   // this update's bookkeeping + the reset of k_chain_bwd_qt's arrival counters: one thread, at the end of the shortest queue
+    int xs = 0;
+    for (int x = 1; x < 8; ++x) if (q[x].size() < q[xs].size()) xs = x;
+    q[xs].push_back(kPipeRoleBook << 16);
+    P.book_st = h->st; P.book_hp = step_hyper(h); P.book_cnt = h->bqt_cnt; P.book_ncnt = 2 * 8;
   }
   size_t rounds = 0;
   for (int x = 0; x < 8; ++x) rounds = q[x].size() > rounds ? q[x].size() : rounds;
@@ -2449,6 +2462,8 @@ void bwd_pi_args(dsact_handle* h, int x0, int x1, bool fused, BwdPiArgs& a, int&
   if (merge) {
     a.merge_dw = 1; a.pi_tile0 = x1; a.n_pi_tiles = h->dw2_off[3] - x1; a.finalize = fused ? 1 : 0;
     a.cnt_pi = h->chain_flags + kChainFlags + 128;
+    a.per_layer = (!h->twin && h->env_pi_layers) ? 1 : 0;
+    a.pi_prob0 = h->nq * (L + 1);
     a.spin_timeout = (int*)h->handoff_dev;
     a.debug_withhold = h->debug_withhold == 2;
   }
@@ -2496,6 +2511,68 @@ int enqueue_chain_bwd_pi_close(dsact_handle* h, bool fused) {
 #undef CALL_CPC
 }
 
+// k_chain_bwd_qt (dsact_chain.h): may the critics' backward, their weight-gradient tiles and the closing block of an update
+// that defers its policy backward be ONE launch?
+bool bqt_ok(const dsact_handle* h) {
+  return h->chain_ok && h->pi_merge && h->dw_chunks == 1 && !h->fat_bwd && !h->twin && !h->cnn && h->env_ride_slots == 0 && !h->env_no_bqt;
+}
+// counters + the block -> tile table: tiles class by class in the order their operands arrive (output + last hidden layer,
+// ..., first layer), every class dealt to the XCDs in contiguous eighths (xcd_chunk's locality), block 8 r + x = entry r of XCD x
+int build_bqt(dsact_handle* h) {
+  if (h->bqt_tab) return DSACT_OK;
+  HIPCHK(h, hipMalloc((void**)&h->bqt_cnt, kBqtCntInts * sizeof(int)));
+  HIPCHK(h, hipMemset(h->bqt_cnt, 0, kBqtCntInts * sizeof(int)));
+  const Dw2Args d = dw2_args(h, true);
+  const int L = h->L;
+  std::vector<int> q[8];
+  for (int c = L - 1; c >= 0; --c) {
+    std::vector<int> cls;
+    for (int net = 0; net < h->nq; ++net)
+      for (int l = 0; l <= L; ++l) {
+        if ((l < L ? l : L - 1) != c) continue;
+        const int pi = net * (L + 1) + l;
+        for (int t = pi ? d.p[pi - 1].tile_end : 0; t < d.p[pi].tile_end; ++t) cls.push_back(t);
+      }
+    const int per = ((int)cls.size() + 7) >> 3;
+    size_t depth = 0;
+    for (int x = 0; x < 8; ++x) depth = q[x].size() > depth ? q[x].size() : depth;
+    for (int x = 0; x < 8; ++x) q[x].resize(depth, -1);      // a class starts at the same depth on every XCD
+    for (size_t i = 0; i < cls.size(); ++i) q[i / (size_t)per].push_back(cls[i]);
+  }
+  size_t rounds = 0;
+  for (int x = 0; x < 8; ++x) rounds = q[x].size() > rounds ? q[x].size() : rounds;
+  std::vector<int> tab(8 * rounds, -1);
+  for (size_t r = 0; r < rounds; ++r)
+    for (int x = 0; x < 8; ++x) if (r < q[x].size()) tab[8 * r + x] = q[x][r];
+  HIPCHK(h, hipMalloc((void**)&h->bqt_tab, tab.size() * sizeof(int)));
+  HIPCHK(h, hipMemcpy(h->bqt_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+  h->bqt_tab_blocks = (int)tab.size();
+  return DSACT_OK;
+}
+int enqueue_chain_bwd_qt(dsact_handle* h, bool fused, const RideArgs* ride) {
+  BwdQtArgs a;
+  memset(&a, 0, sizeof(a));
+  int rg, n_riders;
+  bwd_q_args(h, 2 * h->nq, ride, a.q, rg, n_riders);
+  a.q.arrive = h->bqt_cnt;
+  a.q.debug_withhold = h->debug_withhold == 3;
+  a.q.timeline = tl_for(h, "chain_bwd_qt");
+  a.dw = dw2_args(h, fused);
+  a.tile_tab = h->bqt_tab; a.n_tile_blocks = h->bqt_tab_blocks;
+  a.n_riders = n_riders;
+  a.need = a.q.n_slices;
+  a.spin_timeout = h->handoff_dev;
+  a.logp_new = h->logp_new; a.n_part = h->B; a.target_entropy = -(float)h->A;
+  a.grad_log_alpha = h->grads + h->n_online - 1;
+  a.finalize = fused ? 1 : 0;
+  size_t lds = (size_t)chain_lds(h->cW, h->cW, 4 * rg).total * sizeof(float);
+  if (lds < kDw2LdsFloats * sizeof(float)) lds = kDw2LdsFloats * sizeof(float);
+  const int grid = a.q.n_chain_blocks + n_riders + a.n_tile_blocks + 1;
+#define CALL_CQT(N, G) return launch(h, "chain_bwd_qt", k_chain_bwd_qt<N, G>, dim3(grid), dim3(kThreads), lds, a)
+  CHAIN_NT(CALL_CQT, rg);
+#undef CALL_CQT
+}
+
 // same contract as enqueue_grads (phases, fused optimiser, riders of the loss launch)
 int enqueue_grads_chain(dsact_handle* h, bool actor_backward, bool fused, int phase, const RideArgs* ride) {
   const int* off = h->dw2_off;
@@ -2519,6 +2596,8 @@ int enqueue_grads_chain(dsact_handle* h, bool actor_backward, bool fused, int ph
     }
   }
   if (phase == 1) return DSACT_OK;
+  // pipelined graph, update whose policy backward rides in the next forward launch: critics' backward + their tiles + close
+  if (h->bqt_now && h->pipe_defer_now && actor_backward && fused && phase == 2) return enqueue_chain_bwd_qt(h, fused, ride);
   TRY(enqueue_chain_bwd_q(h, (actor_backward ? 2 : 1) * h->nq, ride));
   // CNN nets (batch <= 1024: one gradient arena): dL/d features = dZ0 . W0[:, :F] right behind the chains that produce dZ0 and
   // before the launch whose tiles update W0; the conv stacks' backward follows the MLP part (enqueue_grads' order)
@@ -3079,6 +3158,8 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (const char* v = getenv("DSACT_PIPE_QT")) h->env_pipe_qt = atoi(v) ? 1 : 0;
   h->env_pipe_qp_split = getenv("DSACT_PIPE_QP_SPLIT") != nullptr;
   h->env_no_pipe_defer = getenv("DSACT_NO_PIPE_DEFER") != nullptr;
+  h->env_no_bqt = getenv("DSACT_NO_BQT_MERGE") != nullptr;
+  h->env_pi_layers = getenv("DSACT_PI_LAYERS") != nullptr;
   h->env_no_pipe_warm = getenv("DSACT_PIPE_WARM") == nullptr;
   h->env_no_pipe_tagged = getenv("DSACT_NO_PIPE_TAGGED") != nullptr;
   if (const char* v = getenv("DSACT_PK_PAD")) h->env_pk_pad = atoi(v) > 0 && atoi(v) <= 64 ? atoi(v) : 0;
@@ -3319,6 +3400,8 @@ int dsact_destroy(dsact_handle* h) {
   if (h->alt.d_tiles) hipFree(h->alt.d_tiles);
   if (h->alt_ws) hipFree(h->alt_ws);
   if (h->pipe_ws) hipFree(h->pipe_ws);
+  if (h->bqt_cnt) hipFree(h->bqt_cnt);
+  if (h->bqt_tab) hipFree(h->bqt_tab);
   if (h->pk_ws) hipFree(h->pk_ws);
   for (int i = 0; i < 2; ++i) { if (h->d_fwdt[i]) hipFree(h->d_fwdt[i]); delete h->fwdt_host[i]; }
   if (h->d_mir) hipFree(h->d_mir);
@@ -3864,6 +3947,7 @@ struct PipePlan {
   std::vector<BwdPiArgs> bp;      // [s]: the deferred policy backward of update s - 1 (valid when defer[s - 1])
   std::vector<int> bp_rg;
   bool dp = false;                // local gradients -> all-reduce -> k_adam_pack instead of the fused optimiser
+  std::vector<char> bqt;          // update s: critics' backward + their tiles + close as one launch (its bookkeeping rides in its forward)
   bool skip = false;              // DSACT_F_SKIP_ACTOR_ON_OFF_ITERS: the discarded policy backward is not computed at all
   std::vector<char> leaves;       // update s leaves policy / alpha / targets alone
 };
@@ -3881,6 +3965,9 @@ static int plan_updates_pipe(dsact_handle* h, int n, int phase, PipePlan& plan, 
   plan.dp = (flags & DSACT_F_DATA_PARALLEL) != 0;
   plan.skip = (flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) != 0 && !plan.dp;
   plan.leaves.assign((size_t)n, 0);
+  plan.bqt.assign((size_t)n, 0);
+  const bool bqt = bqt_ok(h) && !plan.dp;
+  if (bqt) TRY(build_bqt(h));
   bool pre = false;
   int rc = DSACT_OK;
   h->mirror_w0 = true;   // (what the enqueue pass sets: the tiles' argument blocks are built here)
@@ -3898,9 +3985,10 @@ static int plan_updates_pipe(dsact_handle* h, int n, int phase, PipePlan& plan, 
       a.dw.store_g = 0;                   // nothing reads this gradient (fused: no optimiser step on that update either)
       bp = &a;
     }
-    rc = pipe_fwd_build(h, set_of(s), set_of(s + 1), pre, do_pre, plan.host[(size_t)s], bp);
-    plan.pre[(size_t)s] = pre; plan.dop[(size_t)s] = do_pre;
     plan.defer[(size_t)s] = do_pre && can_defer && !plan.skip;   // (skip: there is no policy backward to move)
+    plan.bqt[(size_t)s] = plan.defer[(size_t)s] && bqt;
+    rc = pipe_fwd_build(h, set_of(s), set_of(s + 1), pre, do_pre, plan.host[(size_t)s], bp, plan.bqt[(size_t)s] != 0);
+    plan.pre[(size_t)s] = pre; plan.dop[(size_t)s] = do_pre;
     pre = do_pre;
   }
   h->mirror_w0 = false;
@@ -3950,7 +4038,7 @@ static int enqueue_updates_pipe(dsact_handle* h, int n, const PipePlan& plan, Pi
       ride.g = gather_args(h, h->idx_table, h->idx_rows, 1, 0, 1);   // (st / hp of the bookkeeping block)
       ride.n_gather = 0;
     }
-    ride.bookkeeping = 1;
+    ride.bookkeeping = plan.bqt[(size_t)s] ? 0 : 1;   // (merged critic backward: the forward launch did the bookkeeping)
     if (plan.dp) {
       h->pipe_defer_now = plan.defer[(size_t)s] != 0;
       rc = enqueue_grads(h, true, false, 2, &ride);
@@ -3961,8 +4049,10 @@ static int enqueue_updates_pipe(dsact_handle* h, int n, const PipePlan& plan, Pi
       continue;
     }
     h->pipe_defer_now = plan.defer[(size_t)s] != 0;
+    h->bqt_now = plan.bqt[(size_t)s] != 0;
     rc = enqueue_grads(h, !(plan.skip && plan.leaves[(size_t)s]), true, 2, &ride);
     h->pipe_defer_now = false;
+    h->bqt_now = false;
   }
   apply_pipe_set(h, 0);
   h->mirror_w0 = false;
@@ -4508,7 +4598,7 @@ int dsact_debug_read(dsact_handle* h, const char* name, float* out, size_t cap, 
       {"dout0", h->dout[0], 2 * B}, {"dout1", h->dout[1], 2 * B}, {"dout2", h->dout[2], 2 * B}, {"dout3", h->dout[3], 2 * B},
       {"dout_pi", h->dout_pi, B * 2 * A}, {"d_new_act", h->d_new_act, B * A},
       {"part_loss", h->part_loss, (size_t)h->B * kLossPart}, {"part_heads", h->part_heads, (size_t)h->n_heads_wg * 2},
-      {"timeline", (const float*)h->timeline, (size_t)512 * 16 * 2},
+      {"timeline", (const float*)h->timeline, (size_t)1024 * 16 * 2},
   };
   for (const E& e : tab) if (s == e.k) { src = e.p; cnt = e.c; }
   if (!src && s.size() > 4 && (s[0] == 'H' || s[0] == 'G' || s.compare(0, 2, "dZ") == 0)) {
@@ -4593,6 +4683,12 @@ int dsact_debug_set(dsact_handle* h, const char* name, double value) {
     for (int i = 0; i < 2; ++i) TRY(debug_fill(h, h->dAq[i], 1, 0, 0, h->B * 32, v));
     // merged policy backward: the policy's dZ packs its weight-gradient tiles wait for
     if (h->chain_ok) for (int l = 0; l < h->L; ++l) TRY(debug_fill(h, h->dZ[kDzSlot[C_PI]][l], 1, 0, 0, h->B * h->w[l], v));
+    // merged critic backward (k_chain_bwd_qt): the critics' dZ packs and dL/dout their weight-gradient tiles wait for
+    if (h->chain_ok && !h->twin)
+      for (int i = 0; i < h->nq; ++i) {
+        for (int l = 0; l < h->L; ++l) TRY(debug_fill(h, h->dZ[kDzSlot[i == 0 ? C_Q1C : C_Q2C]][l], 1, 0, 0, h->B * h->w[l], v));
+        TRY(debug_fill(h, h->doutT[i], 1, 0, 0, 32 * h->B, v));
+      }
     return DSACT_OK;
   }
   if (!strcmp(name, "fwd_merge")) {   // A/B switch of the merged forward launch on a live handle (tests)

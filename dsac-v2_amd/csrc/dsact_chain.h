@@ -44,12 +44,14 @@ constexpr int kPD = DSACT_KPD;        // weight steps (4 k of a 64-output tile =
 
 // phase stamps of the chain kernels (instrumented builds, -DDSACT_TIMELINE): [block][16] shader-clock values
 #ifdef DSACT_TIMELINE
-#define CTL(buf, k) do { if ((buf) && threadIdx.x == 0 && blockIdx.x < 512) (buf)[blockIdx.x * 16 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define CTL(buf, k) do { if ((buf) && threadIdx.x == 0 && blockIdx.x < 1024) (buf)[blockIdx.x * 16 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
 // slots 14 / 15: workgroup begin / end on the chip-wide 100 MHz counter (the cycle counter is per XCD: no skew across them)
-#define CTLR(buf, k) do { if ((buf) && threadIdx.x == 0 && blockIdx.x < 512) (buf)[blockIdx.x * 16 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define CTLR(buf, k) do { if ((buf) && threadIdx.x == 0 && blockIdx.x < 1024) (buf)[blockIdx.x * 16 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define CTLV(buf, k, v) do { if ((buf) && threadIdx.x == 0 && blockIdx.x < 1024) (buf)[blockIdx.x * 16 + (k)] = (long long)(v); } while (0)
 #else
 #define CTL(buf, k) do {} while (0)
 #define CTLR(buf, k) do {} while (0)
+#define CTLV(buf, k, v) do {} while (0)
 #endif
 
 
@@ -661,16 +663,19 @@ __device__ __forceinline__ void chain_arrive(int* cnt) {
 }
 struct ArriveWait {
   const int* cnt; int need; int* timeout;
+  long long* tl = nullptr;                       // instrumented builds: chip-wide stamp when the wait ended (slot 13)
+  int quick = 0;                                 // 1: short naps between polls (k_chain_bwd_qt: the waiters sit on the critical path)
   __device__ __forceinline__ void operator()() const {
     if (threadIdx.x == 0) {
       const int* c = cnt + ((int)blockIdx.x & 7) * kArriveStride;
       int spins = 0;
       while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
         if (++spins > (1 << 17)) { if (timeout) *timeout = 1; break; }   // ~0.1 s, then the hand-off word
-        __builtin_amdgcn_s_sleep(24);
+        if (quick) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(24);
       }
     }
     asm volatile("s_barrier" ::: "memory");   // the waves keep their operand loads in flight (no vmcnt wait here)
+    CTLR(tl, 13);
   }
 };
 
@@ -1078,9 +1083,25 @@ struct PipeFwd {
   FwdArgs c;                        // common fields (c.u / c.map unused)
   FwdUnit u[kPipeUnits];
   int n_blocks;
+  // role kPipeRoleBook (one block, one thread): this update's bookkeeping (prologue_duties: Adam step sizes, do_delayed) and
+  // the reset of the merged critic-backward launch's arrival counters -- ahead of k_chain_bwd_qt, whose tiles read the step
+  // state before they wait
+  DevState* book_st; StepHyper book_hp; int* book_cnt; int book_ncnt;
   int blk[kPipeMaxBlocks];          // (unit << 16) | slice, or -1: padding block
   int warm[kPipeMaxBlocks];         // (index << 16) | count among the workgroups of the same unit on the same XCD; 0: no warm-up
 };
+constexpr int kPipeRoleBook = 13;
+// the bookkeeping block of a forward launch (see PipeFwd::book_*): one thread
+__device__ __forceinline__ void pipe_book(const __attribute__((address_space(4))) PipeFwd* p) {
+  if (threadIdx.x != 0) return;
+  DevState* st = (DevState*)p->book_st;
+  StepHyper hp;
+  hp.delay_update = p->book_hp.delay_update; hp.lr_q = p->book_hp.lr_q; hp.lr_pi = p->book_hp.lr_pi; hp.lr_alpha = p->book_hp.lr_alpha;
+  hp.beta1 = p->book_hp.beta1; hp.beta2 = p->book_hp.beta2;
+  prologue_duties(st, st->it_next, 1, hp);
+  int* c = (int*)p->book_cnt;
+  for (int i = 0; i < p->book_ncnt; ++i) c[i * kArriveStride] = 0;
+}
 template <int NW, bool GA = false>
 __global__ void __launch_bounds__(64 * NW, 2) k_chain_fwdp(const PipeFwd* __restrict__ pd) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1091,6 +1112,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_chain_fwdp(const PipeFwd* __rest
   const int code = p->blk[blockIdx.x];
   if (code < 0) return;
   const int unit = code >> 16, slice = code & 0xffff;
+  if (unit == kPipeRoleBook) { pipe_book(p); return; }
 #ifdef DSACT_TIMELINE
   if (p->c.timeline && threadIdx.x == 0 && blockIdx.x < 512) p->c.timeline[blockIdx.x * 16 + 11] = unit + 1;   // who ran here
 #endif
@@ -1160,7 +1182,14 @@ struct BwdQArgs {
   int ldo;                         // floats between the two rows of wout (0: W; twin trunks: 2W -- the dense block-diagonal matrix)
   int c1at;                        // chunks of 16 k per 16-row tile of w1at (0: W / 16; twin trunks: 2W / 16)
   int ldz0;                        // row stride of dz0row
+  // merged launch (k_chain_bwd_qt): the critics' own chains (which 0 / 1) hand their dZ packs / dL/dout to the critics'
+  // weight-gradient tiles of the SAME launch: counter [which] (8 replicas, kArriveStride ints apart) counts the slices of
+  // that chain whose stores (write-through) have all been acknowledged
+  // nullptr: not merged
+  int* arrive;
+  int debug_withhold;              // tests only (dsact_debug_set "withhold_flag" 3): slice 0 of q1's chain never arrives
 };
+constexpr int kBqtCntInts = 2 * 8 * 64;   // [2 critics][8 replicas x kArriveStride]
 
 // row-major copy of a slice's dZ[0] from its LDS image [R][ld_h] (CNN nets: the dL/d features product reads it as a plain
 // matrix). A loop of its own behind a uniform branch: the same stores inside the chains' unrolled epilogues kept 32
@@ -1174,7 +1203,9 @@ __device__ __forceinline__ void store_dz0_rows(float* dst, int ldz0, int row0, c
   }
 }
 
-template <int NW, int RG>
+// MRG: compiled for the merged launch k_chain_bwd_qt (write-through stores + arrival counters on the critics' own chains);
+// false: every hand-over branch folds away (k_chain_bwd_q is the code it was)
+template <int NW, int RG, bool MRG = false>
 __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* lds) {
   if (a.flags_reset && threadIdx.x == 0)
     for (int i = block; i < a.n_flags; i += a.n_chain_blocks) a.flags_reset[i] = 0;
@@ -1194,6 +1225,8 @@ __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* 
   const int red = S.off_red;
   float* sc = lds + S.off_sc;
   CTL(a.timeline, 0);
+  CTLR(a.timeline, 14);
+  CTLV(a.timeline, 11, 1 + u.which);
   // ---- weight stream: layers L-1 .. 1 (nothing to stream for a one-hidden-layer net)
   WStr ws;
   if (L > 1) stream_prologue(ws, u.wb[L - 1] + (size_t)wave * SH * 256, 0, lane4);
@@ -1211,6 +1244,16 @@ __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* 
   const float wo0 = u.wout[n], wo1 = u.wout[(a.ldo ? a.ldo : W) + n];
   const int c1at = a.c1at ? a.c1at : W / 16;
   const bool lead = u.trunk == 0;  // the trunk units of a chain compute the same row phase; one of them publishes it
+  // merged launch: this unit's dZ packs feed weight-gradient tiles of the same launch (the critics' own chains only)
+  // merged launch: the critics' own chains store dZ / dL/dout write-through and, at their END (dZ[0] stored, every store
+  // acknowledged), add 1 to their critic's arrival counter; every weight-gradient tile of that critic waits for it.
+  // (Measured and rejected, profiles/r05_bqt_variants.txt: per-layer counters that let the later layers' tiles start while
+  //  the chains still run -- with a drain of the weight stream per layer, or raised one product late behind
+  //  `s_waitcnt vmcnt(kPD)`, or after the next product's first trip: the early tiles take MFMA / L2 time from the chains,
+  //  whose end the first layer's 208 tiles wait for: launch 22.1 -> 22.4-24.6 us.)
+  const bool merged = MRG && a.arrive != nullptr;
+  const int agent = merged && u.which < 2 ? 1 : 0;
+  int* const arr = agent && !(a.debug_withhold && u.which == 0 && slice == 0) ? a.arrive + u.which * (8 * kArriveStride) : nullptr;
   f32x4 gl[RG];
 #pragma unroll
   for (int g = 0; g < RG; ++g) gl[g] = gload4(u.G[L - 1] + pk_index(n, row0 + 4 * g, a.Cb));
@@ -1275,7 +1318,7 @@ __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* 
   if (j == 0) {
     sc[16 + 2 * m] = d0; sc[16 + 2 * m + 1] = d1;
     if (lead) { u.dout[2 * r] = d0; u.dout[2 * r + 1] = d1; }
-    if (lead && u.doutT) { u.doutT[pk_index(0, r, a.Cb)] = d0; u.doutT[pk_index(1, r, a.Cb)] = d1; }
+    if (lead && u.doutT) { hand_store(u.doutT + pk_index(0, r, a.Cb), d0, agent); hand_store(u.doutT + pk_index(1, r, a.Cb), d1, agent); }
     if (!lead) {
     } else if (u.which == 0 && a.v1) {
       float* pl = a.part_loss + (size_t)r * kLossPart;
@@ -1284,7 +1327,7 @@ __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* 
       pl[7] = lpn;
       pl[8] = r == 0 ? alpha : 0.0f;
       pl[9] = 0.0f; pl[10] = std1; pl[11] = std1;
-      if (r == 0) { a.grads_tail[0] = 0.f; a.grads_tail[1] = 0.f; }
+      if (r == 0) { hand_store(a.grads_tail, 0.f, merged); hand_store(a.grads_tail + 1, 0.f, merged); }
     } else if (u.which == 0) {
       float* pl = a.part_loss + (size_t)r * kLossPart;
       pl[0] = c1.loss; pl[1] = c2.loss; pl[2] = q1; pl[3] = q2; pl[4] = std1; pl[5] = std2;
@@ -1292,7 +1335,7 @@ __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* 
       pl[7] = lpn;
       pl[8] = r == 0 ? alpha : 0.0f;
       pl[9] = 0.0f; pl[10] = std1; pl[11] = std2;
-      if (r == 0) { a.grads_tail[0] = ms1; a.grads_tail[1] = ms2; }
+      if (r == 0) { hand_store(a.grads_tail, ms1, merged); hand_store(a.grads_tail + 1, ms2, merged); }   // (the closing block of a merged launch reads them)
     }
   }
   lds_barrier();
@@ -1304,12 +1347,13 @@ __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* 
     for (int rr = 0; rr < 4; ++rr) ov[rr] = (sc[16 + 2 * (4 * g + rr)] * wo0 + sc[16 + 2 * (4 * g + rr) + 1] * wo1) * gl[g][rr];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) lds[S.off_h0 + (4 * g + rr) * S.ld_h + n] = ov[rr];
-    nt_store4(u.dZ[L - 1] + pk_index(n, row0 + 4 * g, a.Cb), ov);
+    pack_store4(u.dZ[L - 1] + pk_index(n, row0 + 4 * g, a.Cb), ov, agent);
   }
   NarrowFrags<2> af;
   const int nta = (a.A + 15) >> 4;
-  if (u.w1at && L == 1) narrow_load<2>(af, u.w1at, c1at, nta, wave, lane4);
-  lds_barrier();
+  if (u.w1at && L == 1 && !MRG) narrow_load<2>(af, u.w1at, c1at, nta, wave, lane4);
+  if (arr && L == 1) chain_arrive(arr);   // one hidden layer: dZ[0] is the last thing this chain delivers
+  else lds_barrier();
   if (u.dz0row && L == 1) store_dz0_rows<W, R, NTHR>(u.dz0row, a.ldz0, row0, lds + S.off_h0, S.ld_h);
   CTL(a.timeline, 2);
   // ---- hidden layers: dZ[l-1] = (dZ[l] W_l) * gelu'(z[l-1])
@@ -1322,29 +1366,37 @@ __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* 
 #pragma unroll
     for (int g = 0; g < RG; ++g) gq[g] = gload4(u.G[l - 1] + pk_index(n, row0 + 4 * g, a.Cb));
     const bool has_nxt = l > 1;
-    gemm44_seg<RG>(ws, u.wb[l] + (size_t)wave * SH * 256, 0, SH, u.wb[has_nxt ? l - 1 : l] + (size_t)wave * SH * 256, 0, has_nxt,
-                   lds, (cur ? S.off_h1 : S.off_h0) + (lane & 3) * S.ld_h, S.ld_h, lane4, acc);
+    const float* wl = u.wb[l] + (size_t)wave * SH * 256;
+    const float* wn = u.wb[has_nxt ? l - 1 : l] + (size_t)wave * SH * 256;
+    const int xop = (cur ? S.off_h1 : S.off_h0) + (lane & 3) * S.ld_h;
+    gemm44_seg<RG>(ws, wl, 0, SH, wn, 0, has_nxt, lds, xop, S.ld_h, lane4, acc);
     CTL(a.timeline, 3 + 2 * (L - 1 - l));
-    if (l == 1 && u.w1at) narrow_load<2>(af, u.w1at, c1at, nta, wave, lane4);
+    // (merged launch: the 32 fragment registers of dL/da are loaded AFTER the last epilogue -- one L2 round trip on a chain
+    //  whose end nobody in this launch waits for -- so that the kernel fits 168 registers: three workgroups per CU, the
+    //  chain's and two waiting tiles)
+    if (l == 1 && u.w1at && !MRG) narrow_load<2>(af, u.w1at, c1at, nta, wave, lane4);
     const int hn = cur ? S.off_h0 : S.off_h1;
 #pragma unroll
     for (int g = 0; g < RG; ++g) {
       const f32x4 dz = (acc[g][0] + acc[g][1]) * gq[g];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) lds[hn + (4 * g + rr) * S.ld_h + n] = dz[rr];
-      nt_store4(u.dZ[l - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz);
+      pack_store4(u.dZ[l - 1] + pk_index(n, row0 + 4 * g, a.Cb), dz, agent);
     }
     cur ^= 1;
-    lds_barrier();
+    if (arr && l == 1) chain_arrive(arr);                // dZ[0]: explicit acknowledgement wait (the chain ends here)
+    else lds_barrier();
     if (u.dz0row && l == 1) store_dz0_rows<W, R, NTHR>(u.dz0row, a.ldz0, row0, lds + hn, S.ld_h);
     CTL(a.timeline, 4 + 2 * (L - 1 - l));
   }
-  if (!u.w1at) return;
+  if (!u.w1at) { CTLR(a.timeline, 15); return; }
+  if (MRG) narrow_load<2>(af, u.w1at, c1at, nta, wave, lane4);
   // ---- dL/d new_act through this critic: dZ0 . W0[:, F:F+A]   (contraction over the hidden units, split over waves)
   narrow_mma<2>(af, nta, wave, lds, (cur ? S.off_h1 : S.off_h0) + ((lane & 15) & (R - 1)) * S.ld_h + 4 * (lane >> 4), red, lane);
   lds_barrier();
   for (int d = j; d < 16 * nta; d += TPR) u.dA[(size_t)r * 32 + d] = d < a.A ? narrow_get<2, NW>(lds, red, m, d) : 0.0f;
   CTL(a.timeline, 12);
+  CTLR(a.timeline, 15);
 }
 
 template <int NW, int RG>
@@ -1384,6 +1436,12 @@ struct BwdPiArgs {
   // the arrival counter of the chain's slices; one more block closes the update (alpha gradient, finalize_update)
   int merge_dw, pi_tile0, n_pi_tiles, finalize;
   int* cnt_pi; int* spin_timeout;
+  // per-layer arrival (round 5 experiment, DSACT_PI_LAYERS=1; OFF by default -- measured slower, 22.5-22.8 -> 23.4-23.6 us:
+  // what the early tiles move through L2 / the fabric slows the chain whose END the first layer's 96 tiles wait for):
+  // counter [l] (8 replicas each, l * 8 * kArriveStride ints on) counts the slices whose dZ[l] (l == L - 1: and dL/dout) is
+  // visible chip-wide; a policy tile waits for ITS layer's counter only. pi_prob0: index of the policy's first problem in
+  // dw.p. per_layer == 0: one counter, raised at the end of the chain
+  int per_layer, pi_prob0;
   int debug_withhold;              // tests only (dsact_debug_set "withhold_flag" 2): slice 0 never arrives
   long long* timeline;
   Dw2Args dw;
@@ -1441,6 +1499,7 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
   // alpha gradient (dsac_v2.py:312-318): -mean(logp_new + target_entropy)
   if (slice == 0 && wave == 0 && !a.merge_dw && lead) bwd_pi_alpha_grad(a, lane);   // merged launch: the closing block does it
   const int agent = a.merge_dw;
+  const bool arr_layers = a.merge_dw && a.per_layer && !(a.debug_withhold && slice == 0);
   const float alpha = a.auto_alpha ? expf(a.log_alpha[0]) : a.alpha_fixed;
   // zero the operand rows (padding included), then fill (dmu | draw)
   for (int e = tid; e < R * 4 * a.SoT; e += NTHR) xdo[(e / (4 * a.SoT)) * S.ld_in + e % (4 * a.SoT)] = 0.0f;
@@ -1496,6 +1555,16 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
     const bool has_nxt = l > 1;
     gemm44_seg<RG>(ws, t_wb[l] + (size_t)wave * SH * 256, 0, SH, t_wb[has_nxt ? l - 1 : l] + (size_t)wave * SH * 256, 0, has_nxt,
                    lds, (cur ? S.off_h1 : S.off_h0) + (lane & 3) * S.ld_h, S.ld_h, lane4, acc);
+    if (arr_layers) {
+      // Per-layer arrival WITHOUT draining the weight stream: a wave's vector-memory operations retire in issue order (gfx9
+      // has ONE vmcnt counter for loads and stores: every s_waitcnt vmcnt(N > 0) the compiler emits for a load with younger
+      // stores in flight relies on it). Behind dZ[l]'s stores (l == L - 1: and dL/dout's) this wave has issued the whole
+      // product that just ended -- at least kPD refill loads -- so vmcnt(kPD) (the last trip's refills stay in flight)
+      // proves those stores acknowledged (write-through: visible chip-wide). Layer l's counter is raised one product late
+      // for the price of a barrier and 8 atomic adds; dZ[0] (nothing follows) waits for vmcnt(0) in chain_arrive below.
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"(kPD) : "memory");
+      if (tid < 8) __hip_atomic_fetch_add(a.cnt_pi + l * 8 * kArriveStride + tid * kArriveStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const int hn = cur ? S.off_h0 : S.off_h1;
 #pragma unroll
     for (int g = 0; g < RG; ++g) {
@@ -1511,6 +1580,17 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
   }
   CTLR(a.timeline, 15);
   if (a.merge_dw && !(a.debug_withhold && slice == 0)) chain_arrive(a.cnt_pi);
+}
+
+// the arrival counter policy tile `t` (an index into dw's tile list) waits for
+__device__ __forceinline__ const int* pi_tile_counter(const BwdPiArgs& a, int t) {
+  if (!a.per_layer) return a.cnt_pi;
+  int pi = 0;
+#pragma unroll
+  for (int q = 0; q + 1 < kMaxDwProb; ++q)
+    if (q + 1 < a.dw.n_prob && t >= a.dw.tile_ends[q]) pi = q + 1;
+  const int l = pi - a.pi_prob0;
+  return a.cnt_pi + (l < a.L ? l : a.L - 1) * 8 * kArriveStride;
 }
 
 // blocks past the chain's: riders (xcd_chunk_grid(n_extra) per batch range), then -- merged launch -- the policy's
@@ -1529,7 +1609,7 @@ __device__ __forceinline__ void bwd_pi_tail_blocks(const BwdPiArgs& a, int idx, 
   idx -= n_rider_blocks;
   if (idx < xcd_chunk_grid(a.n_pi_tiles)) {
     if (!xcd_chunk(idx, a.n_pi_tiles, t)) return;
-    dw2_tile<2, ArriveWait>(a.dw, a.pi_tile0 + t, lds, ArriveWait{a.cnt_pi, a.n_slices, a.spin_timeout});
+    dw2_tile<2, ArriveWait>(a.dw, a.pi_tile0 + t, lds, ArriveWait{pi_tile_counter(a, a.pi_tile0 + t), a.n_slices, a.spin_timeout});
     return;
   }
   // closing block: waits for the chain as well -- its slices read log_alpha (alpha = exp(log_alpha)) when they start, and
@@ -1573,6 +1653,79 @@ __global__ void __launch_bounds__(512) k_chain_bwd_pi8(BwdPiArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_chain_bwd_qt (round 5): the critics' backward AND their weight-gradient / Adam tiles AND the block that closes the update
+// in ONE launch -- the last two launches of an update that leaves the policy alone in the pipelined graph (chain_bwd_q 12.3 us
+// + chain_dw_q 11.7 us: the tiles' kernel boundary, dispatch ramp and first-touch latency sat on the critics' dependent chain
+// forward -> backward -> dW + Adam -> next forward). The critics' own chains (q1c, q2c) store their dZ packs and dL/dout
+// write-through and raise their critic's arrival counter when they end (BwdQArgs::arrive); every tile of that critic waits
+// for it with its X-side fragments and Adam operands already in flight (dw2_tile's `wait`): all 480 tiles are resident beside
+// the chains from the start (144 registers: three workgroups per CU) and run the moment the chains end. Blocks: [chain
+// slices] [riders: the gather of minibatch s + 2] [tiles, dealt to the XCDs layer class by layer class] [closing block]. This update's bookkeeping (Adam step sizes: the tiles read them BEFORE they wait) moved into the
+// forward launch of the same update (k_chain_fwdp, role kPipeRoleBook), which also zeroes the arrival counters. Every wait
+// targets blocks with lower ids (resident first), bounded like the other in-launch hand-overs. Same arithmetic per tile and
+// per row as the two launches: bit-identical (tests/test_hip_parity.py::test_pipelined_graph_equals_eager_steps).
+// ---------------------------------------------------------------------------------------------------------------
+struct BwdQtArgs {
+  BwdQArgs q;
+  Dw2Args dw;
+  const int* tile_tab; int n_tile_blocks;      // block behind the chain slices and riders -> base tile of dw, or -1 (padding)
+  int n_riders;
+  int need;                                    // slices of one critic chain
+  int* spin_timeout;
+  const float* logp_new; int n_part; float target_entropy; float* grad_log_alpha; int finalize;
+};
+static_assert(sizeof(BwdQtArgs) <= 4096, "kernel arguments are limited to 4 KB");
+
+#ifndef DSACT_BQT_OCC
+#define DSACT_BQT_OCC 3
+#endif
+template <int NW, int RG>
+__global__ void __launch_bounds__(256, DSACT_BQT_OCC) k_chain_bwd_qt(BwdQtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int b = (int)blockIdx.x;
+  if (b < a.q.n_chain_blocks) { bwd_q_body<NW, RG, true>(a.q, b, lds); return; }
+  int idx = b - a.q.n_chain_blocks;
+  if (idx < a.n_riders) { loss_rider(a.q.ride); return; }
+  idx -= a.n_riders;
+  const int L = a.q.L;
+  if (idx < a.n_tile_blocks) {
+    const int t = ((const __attribute__((address_space(4))) int*)(unsigned long long)a.tile_tab)[idx];
+    if (t < 0) return;
+    // problem of the tile -> (critic, layer): problems are [critic][layer 0 .. L-1, output layer]
+    int pi = 0;
+#pragma unroll
+    for (int q = 0; q + 1 < kMaxDwProb; ++q)
+      if (q + 1 < a.dw.n_prob && t >= a.dw.tile_ends[q]) pi = q + 1;
+    const int net = pi / (L + 1), l = pi - net * (L + 1);
+    const int* cnt = a.q.arrive + net * 8 * kArriveStride;
+    CTLR(a.q.timeline, 14);
+    CTLV(a.q.timeline, 11, 10 + (l < L ? l : L - 1));   // tile class
+    dw2_tile<2, ArriveWait>(a.dw, t, lds, ArriveWait{cnt, a.need, a.spin_timeout, a.q.timeline, 0});
+    CTLR(a.q.timeline, 15);
+    return;
+  }
+  // closing block: the chains have passed their row phase (mean_std tail) and nothing reads the step state any more once
+  // every slice of both critics has delivered its last layer
+  ArriveWait{a.q.arrive, a.need, a.spin_timeout}();
+  if (a.q.n_units > 1 && !a.q.v1) ArriveWait{a.q.arrive + 8 * kArriveStride, a.need, a.spin_timeout}();
+  if (threadIdx.x < 64) {
+    // alpha gradient (dsac_v2.py:312-318): -mean(logp_new + target_entropy). part_loss[.][7] IS logp_new (bwd_q_body's row
+    // phase copies it): read from the forward launch's buffer, in bwd_pi_alpha_grad's order
+    const int lane = (int)threadIdx.x;
+    float s = 0.f;
+    for (int r0 = 0; r0 < a.n_part; r0 += 64) {
+      const int rr = r0 + lane;
+      s += rr < a.n_part ? a.logp_new[rr] : 0.f;
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+      a.grad_log_alpha[0] = a.q.auto_alpha ? -(s * a.q.inv_B + a.target_entropy) : 0.0f;
+      if (a.finalize) finalize_update(a.dw.fo);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k_chain_fwdpb: k_chain_fwdp + the DEFERRED policy backward of the previous update. An update that leaves the policy
 // alone (iteration % delay_update != 0) still computes the policy gradient -- the reference does (dsac_v2.py:174-186)
 // and discards it (:324) -- but nothing reads it: its rsample backward, policy dZ chain and the policy's 240 weight-gradient
@@ -1600,9 +1753,10 @@ __global__ void __launch_bounds__(256, 2) k_chain_fwdpb(const PipeFwd* __restric
     return;
   }
   if (unit == kPipeRoleTile) {
-    dw2_tile<2, ArriveWait>(bp.dw, bp.pi_tile0 + slice, lds, ArriveWait{bp.cnt_pi, bp.n_slices, bp.spin_timeout});
+    dw2_tile<2, ArriveWait>(bp.dw, bp.pi_tile0 + slice, lds, ArriveWait{pi_tile_counter(bp, bp.pi_tile0 + slice), bp.n_slices, bp.spin_timeout});
     return;
   }
+  if (unit == kPipeRoleBook) { pipe_book(p); return; }
   if ((int)threadIdx.x >= 64 * NW) return;      // narrow nets: the launch is 256 wide for the tiles
   const int wm = p->warm[blockIdx.x];
   typedef __attribute__((address_space(4))) const FwdArgs KA;

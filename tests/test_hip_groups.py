@@ -301,3 +301,43 @@ def test_sampler_fast_path_gate_is_the_librarys(hid, env, kw, fast, monkeypatch)
     assert len(batch) == 12 and (getattr(batch, "packed", None) is not None) == fast
     for s in batch:
         assert np.isfinite(np.asarray(s[2])).all() and np.all(np.abs(np.asarray(s[2])) <= 0.4 + 1e-6)
+
+
+def test_merged_critic_backward_handover_poisoned_between_replays(monkeypatch):
+    """k_chain_bwd_qt (round 5): the critics' chains hand their dZ packs / dL/dout to the critics' weight-gradient tiles of the
+    SAME launch, layer by layer, with the arrival counter of layer l raised one layer late and no drain of the weight stream
+    (dsact_chain.h: the `s_waitcnt vmcnt(kPD)` argument). Every handed-over buffer is filled with NaN before EVERY replay of a
+    two-update graph whose first update runs the merged launch: a tile that passed its counter before the producers' stores
+    had landed would compute on NaN. 80 replays at the BASELINE shape and 80 at a 64-wide one (one stream trip per layer):
+    merged == two launches (DSACT_NO_BQT_MERGE=1) bit for bit, all finite, no hand-over failure."""
+    for O, A, hid, B in ((376, 17, (256, 256, 256), 256), (16, 4, (64, 64), 64)):
+        engines = []
+        for merged in (True, False):
+            if not merged:
+                monkeypatch.setenv("DSACT_NO_BQT_MERGE", "1")
+            alg, _ = make_pair(O, A, hid, B, seed=31)
+            monkeypatch.delenv("DSACT_NO_BQT_MERGE", raising=False)
+            e = alg.engine
+            e.set_device_rng(77)
+            N = 4096
+            e.buffer_create(N)
+            g = torch.Generator(device="cuda").manual_seed(3)
+            e.buffer_fill_device(0, torch.randn(N, O, device="cuda", generator=g), torch.rand(N, A, device="cuda", generator=g) - .5,
+                                 torch.randn(N, device="cuda", generator=g), torch.randn(N, O, device="cuda", generator=g),
+                                 (torch.rand(N, device="cuda", generator=g) < .05).float())
+            np.random.seed(2)
+            e.upload_index_table(np.random.randint(0, N, size=(8, B)))
+            e.graph_build(2)
+            names = [n for n, _, _ in e.profile_steps(1, 2)]
+            assert ("chain_bwd_qt" in names) == merged, names
+            for rep in range(80):
+                e.debug_set("poison_handover", float("nan"))
+                e.graph_run(3 + 2 * rep, 2)
+            e.sync()
+            engines.append(e)
+        for name in ("online", "target", "adam_m", "adam_v"):
+            t0, t1 = getattr(engines[0], name), getattr(engines[1], name)
+            assert bool(torch.isfinite(t0).all()), (hid, name)
+            assert torch.equal(t0, t1), (hid, name)
+        assert engines[0].debug_get("handoff_failures") == 0.0
+        assert all(np.isfinite(v) for v in engines[0].read_stats().values())

@@ -715,6 +715,8 @@ PIPE_BUFFERS = ("logits_pi", "logp_new", "logp2", "qout_t0", "qout_t1", "qout_p0
     (16, 4, (64, 64), 64, 1, 4, 0, 8, {}),             # delay_update 1: nothing to share, the plain graph
     (16, 4, (64, 64), 16, 2, 2, 1, 6, {"DSACT_PIPE_RG_NEXT": "1"}),       # 4 slices per unit
     (16, 4, (64, 64), 64, 2, 4, 1, 8, {"DSACT_NO_PIPE_DEFER": "1"}),      # the discarded policy backward stays in its own update
+    (16, 4, (64, 64), 64, 2, 4, 1, 8, {"DSACT_NO_BQT_MERGE": "1"}),       # critics' backward and their tiles as two launches (round 4's form)
+    (376, 17, (256, 256, 256), 256, 2, 8, 1, 16, {"DSACT_NO_BQT_MERGE": "1"}),
     (32, 8, (256, 256), 48, 2, 5, 1, 10, {"DSACT_PIPE_QT": "1", "DSACT_PIPE_QP_SPLIT": "1"}),
     (376, 17, (256, 256, 256), 256, 2, 8, 1, 16, {}),  # the BASELINE.json shape
     (376, 17, (256, 256, 256), 256, 2, 6, 4, 12, {"DSACT_PIPE_MAP": "FT.pit=23:1;FT.q1t=01;TF.q1c=0123:2"}),
@@ -749,6 +751,7 @@ def test_pipelined_graph_equals_eager_steps(O, A, hid, B, D, per_graph, first, t
             names = [n for n, _, _ in e.profile_steps(first, total)]
             if D >= 2:
                 assert "chain_fwd+next" in names and "chain_fwd_q" in names, names
+                assert ("chain_bwd_qt" in names) == ("DSACT_NO_BQT_MERGE" not in env and "DSACT_NO_PIPE_DEFER" not in env), names
         else:
             assert e.time_steps(first, total, use_graph=False) > 0
         e.sync()
@@ -1589,10 +1592,11 @@ def test_handover_buffers_poisoned_between_updates():
     assert algs[0].engine.debug_get("handoff_failures") == 0.0
 
 
-@pytest.mark.parametrize("which", [1, 2])
+@pytest.mark.parametrize("which", [1, 2, 3])
 def test_forced_handover_timeout_fails_the_call_and_falls_back(which):
     """a consumer that gives up waiting must FAIL the call, not poison the statistics. One producer
-    withholds its ready flag ("withhold_flag" 1: a forward unit's; 2: a policy-backward slice never arrives): the next
+    withholds its ready flag ("withhold_flag" 1: a forward unit's; 2: a policy-backward slice never arrives; 3: a slice of
+    q1's backward chain never arrives in the merged critic-backward launch k_chain_bwd_qt, round 5): the next
     synchronising entry point returns DSACT_E_HIP, the handle drops to the unmerged launches (and re-captures its graph
     without the merged ones), and from restored state it trains on, bit-identical to an engine that never merged."""
     from dsact._ffi import DsactError
@@ -1613,9 +1617,10 @@ def test_forced_handover_timeout_fails_the_call_and_falls_back(which):
     arenas = {n: getattr(e, n).clone() for n in ("adam_m", "adam_v")}
     state = e.get_state()
     # --- a graph replay with a withheld flag: the launch succeeds, the first synchronising call fails
+    first = 1 if which == 3 else 0    # (the merged critic backward belongs to an update that leaves the policy alone and has a successor)
     e.debug_set("withhold_flag", which)
     e.graph_build(2)
-    e.graph_run(0, 2)                 # asynchronous: returns before the consumers give up
+    e.graph_run(first, 2)             # asynchronous: returns before the consumers give up
     with pytest.raises(DsactError, match="hand-over timed out"):
         e.sync()
     assert e.debug_get("handoff_failures") == 1.0 and e.debug_get("fwd_merge") == 0.0 and e.debug_get("pi_merge") == 0.0
@@ -1624,13 +1629,13 @@ def test_forced_handover_timeout_fails_the_call_and_falls_back(which):
     # the fused Adam / Polyak epilogues ran on whatever the consumers found -- the handle refuses to train on
     # until the caller has restored the state and acknowledged
     assert e.debug_get("state_invalid") == 1.0
-    for call in (lambda: e.step(0), lambda: e.graph_run(0, 2), lambda: e.profile_step(0)):
+    for call in (lambda: e.step(0), lambda: e.graph_run(first, 2), lambda: e.profile_step(0)):
         with pytest.raises(DsactError, match="invalid after a hand-over timeout"):
             call()
     # --- restore the state the failed call invalidated, then both engines run the same updates (the reference engine
     #     replays the same updates first so that both index-table cursors agree, and is restored the same way)
     r.graph_build(2)
-    r.graph_run(0, 2)
+    r.graph_run(first, 2)
     r.sync()
     for a_, x in ((alg, e), (ref, r)):
         a_.networks.load_state_dict(snap)
