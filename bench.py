@@ -662,11 +662,12 @@ def measure(alg, steps, warmup, world=1, dp=None, flags=0):
                 e.dp_begin(0)
                 for _ in range(warmup):
                     dp.step()
-                dp.build_graph(gs)
+                native = dp.build_graph(gs)      # False: capture failed somewhere -> every rank steps eagerly (loud message)
             else:
-                dp.build_graph(gs)
+                native = dp.build_graph(gs)
                 if warmup:
-                    dp.run_graph(0, warmup)
+                    dp.run(0, warmup)
+            measure.dp_graph = native
         else:
             e.dp_begin(0)
             for _ in range(warmup):
@@ -925,6 +926,8 @@ def main():
         dp_mode = "hipGraph (gather -> gradients -> ncclAllReduce -> Adam/Polyak, library-owned RCCL communicator)" if dp.native \
             else "eager launches + torch.distributed all-reduce (%s)" % ("critics' segment overlapped" if dp.overlap else "single")
     wall, regions, ev_ms = measure(alg, steps, warmup, world, dp, flags=1 if args.fast else 0)
+    if use_dp and getattr(dp, "native", False) and not getattr(measure, "dp_graph", True):
+        dp_mode = "EAGER launches + ncclAllReduce on the library-owned RCCL communicator (the hipGraph capture of the data-parallel update FAILED on this runtime: see stderr)"
     stats = e.read_stats()
     finite = all(v == v and abs(v) < 1e30 for v in stats.values())
     updates_per_s = steps / wall

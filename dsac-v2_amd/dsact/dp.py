@@ -67,11 +67,53 @@ class DataParallelUpdater:
         ts = getattr(self.engine, "torch_stream", None)   # CPU stand-ins (gloo tests) have no stream
         return torch.cuda.stream(ts) if ts is not None else contextlib.nullcontext()
 
-    def build_graph(self, steps_per_graph: int):
-        """capture gather -> gradients -> RCCL all-reduce -> Adam/Polyak, `steps_per_graph` updates per hipGraph"""
+    def build_graph(self, steps_per_graph: int, fallback: bool = True) -> bool:
+        """capture gather -> gradients -> RCCL all-reduce -> Adam/Polyak, `steps_per_graph` updates per hipGraph.
+
+        The communicator is warmed up with ONE eager all-reduce first (RCCL sets its channels, proxies and buffers up on the
+        first collective: that work does not belong inside a stream capture). With `fallback` a capture that fails on ANY
+        rank (a runtime that cannot capture ncclAllReduce with real peers -- gpurun boxes have one GPU, so the first multi-GPU
+        launch is also the first such capture) makes EVERY rank fall back to the eager coordinator (`step()`: the same
+        library-owned communicator, one launch sequence per update) with a loud message instead of an exception on some
+        ranks and a hang on the others. Returns True when the graph was captured; `graph_mode` tells which path `run()` takes."""
         if not self.native:
             raise RuntimeError("the graph-captured data-parallel update needs native=True (dsact_comm_init)")
-        self.engine.graph_build(steps_per_graph, F_DATA_PARALLEL)
+        import sys
+
+        ok, err = 1, None
+        try:
+            if self.world > 1 or self.force_collective:
+                self.engine.dp_allreduce()          # warm-up on whatever the gradient arena holds (recomputed by every update)
+                self.engine.sync()
+            self.engine.graph_build(steps_per_graph, F_DATA_PARALLEL)
+        except Exception as ex:   # DsactError (capture / instantiate / RCCL), or anything the runtime raises
+            if not fallback:
+                raise
+            ok, err = 0, ex
+        if self.world > 1:
+            t = torch.tensor([ok], dtype=torch.int32, device=getattr(self.engine, "device", "cpu"))
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            all_ok = int(t.item())
+        else:
+            all_ok = ok
+        self.graph_mode = bool(all_ok)
+        if not all_ok:
+            sys.stderr.write("dsact.dp: rank %d: the data-parallel hipGraph could NOT be captured (%s) -- falling back to the "
+                             "EAGER coordinator on every rank (same RCCL communicator, one launch sequence per update)\n"
+                             % (self.rank, repr(err) if err is not None else "another rank failed"))
+            try:
+                self.engine.sync()
+            except Exception:
+                pass
+        return self.graph_mode
+
+    def run(self, first_iteration: int, n_steps: int):
+        """n_steps updates: graph replays when build_graph captured one, else the eager coordinator"""
+        if getattr(self, "graph_mode", False):
+            return self.run_graph(first_iteration, n_steps)
+        self.engine.dp_begin(first_iteration)
+        for _ in range(n_steps):
+            self.step()
 
     def run_graph(self, first_iteration: int, n_steps: int):
         self.engine.graph_run(first_iteration, n_steps)

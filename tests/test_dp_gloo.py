@@ -237,3 +237,84 @@ def test_two_rank_overlapped_step_equals_plain_step():
             np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
     np.testing.assert_array_equal(runs[True][0][1], runs[True][1][1])
 
+
+
+def _fallback_worker(rank, world, port, out_q):
+    for p in (ROOT, os.path.join(ROOT, "dsac-v2_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from dsact.dp import DataParallelUpdater
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Eng:     # the native surface the coordinator touches; the graph capture fails on rank 1 only
+        def __init__(self):
+            self.grads = torch.full((6,), float(rank + 1))
+            self.calls = []
+
+        def comm_unique_id(self):
+            return b"\0" * 128
+
+        def comm_init(self, r, w, uid):
+            self.calls.append("comm_init")
+
+        def dp_allreduce(self):       # stands in for the library's RCCL all-reduce (AVG)
+            self.calls.append("allreduce")
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)
+            self.grads /= world
+
+        def sync(self):
+            pass
+
+        def graph_build(self, n, flags):
+            self.calls.append("graph_build")
+            if rank == 1:
+                raise RuntimeError("hipStreamEndCapture: operation not permitted when stream is capturing")
+
+        def graph_run(self, it, n):
+            self.calls.append("graph_run")
+
+        def dp_begin(self, it):
+            self.calls.append("dp_begin %d" % it)
+
+        def dp_grads(self):
+            self.calls.append("grads")
+
+        def dp_apply(self):
+            self.calls.append("apply")
+
+    eng = Eng()
+    dp = DataParallelUpdater(eng, native=True)
+    ok = dp.build_graph(4)
+    dp.run(8, 2)
+    out_q.put((rank, ok, list(eng.calls), eng.grads.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_failed_graph_capture_falls_back_to_the_eager_coordinator_on_every_rank():
+    """the first multi-GPU launch is also the first time ncclAllReduce with real peers is captured into a
+    hipGraph. If the capture fails on ANY rank, EVERY rank must take the eager coordinator (same communicator) -- loudly --
+    instead of one rank raising while the others hang in their first replayed collective."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=120)
+        got[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        ok, calls, grads = got[r]
+        assert ok is False
+        assert calls[:3] == ["comm_init", "allreduce", "graph_build"]           # the communicator is warmed up before the capture
+        assert "graph_run" not in calls
+        assert calls[3:] == ["dp_begin 8", "grads", "allreduce", "apply", "grads", "allreduce", "apply"]
+        assert grads == [1.5] * 6                                                # the eager collectives still average over both ranks

@@ -55,6 +55,7 @@ def run_case(title, obs_shape, A, conv_type, B, steps, golden=None, chains=None)
     lrs = {"q1": orc.cfg["lr_q"], "q2": orc.cfg["lr_q"], "policy": orc.cfg["lr_pi"]}
     adam_noise = {name: AdamNoise([(net, p.numel(), lrs[net])]) for net in names for name, p in zip(names[net], orc.p[net])}
     n_kinks = 0
+    n_digest_rows = 0
     for it in range(steps):
         data = synth_image_batch(cfg, B, seed=it)
         torch.manual_seed(1000 + it)
@@ -158,6 +159,7 @@ def run_case(title, obs_shape, A, conv_type, B, steps, golden=None, chains=None)
             tol = np.array([1e-6 * abs(w_) + 3e-6 * np.sqrt(sd[k].numel()) + (float(adam_noise[k].bound.sum()) if k in adam_noise else 0.0)
                             for k, w_ in zip(keys, want)])
             rep.cmp_each("it%d param sums vs reference" % it, sums, want, tol)
+            n_digest_rows += 1
         elif golden is not None:
             # (visible in the report: the digest row was NOT checked on this iteration and why)
             rep.rows.append(("it%d param sums vs reference: SKIPPED after %d verified ReLU kink(s)" % (it, n_kinks), 0.0, 0.0, 0.0, True))
@@ -173,6 +175,14 @@ def run_case(title, obs_shape, A, conv_type, B, steps, golden=None, chains=None)
     assert float(e.online.cpu()[mask].abs().max()) == 0.0
     assert float(e.adam_m.cpu()[mask].abs().max()) == 0.0
     assert e.get_state()["adam_steps"][0] == steps
+    if golden is not None:
+        # on the COMMITTED seed no pre-activation sits within rounding noise of a ReLU kink (profiles/
+        # r04_final_parity_report.txt: 0 kinks, every digest row checked), so every iteration's parameter sums must have
+        # been compared with the unmodified reference's digest. A kernel change that moves a pre-activation across 0 on this
+        # seed shows up HERE instead of silently dropping the only rows that tie the CNN path to the reference itself
+        # (regenerate the fixture on another seed with oracle/make_golden.py if that ever happens legitimately).
+        assert n_kinks == 0 and n_digest_rows == steps, (
+            "reference-digest rows checked on %d of %d iterations (%d ReLU kink(s)) on the committed seed" % (n_digest_rows, steps, n_kinks))
     rep.finish()
 
 
