@@ -3078,6 +3078,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (cfg->delay_update < 1) return fail(h, DSACT_E_INVALID, "delay_update must be >= 1");
   if (cfg->value_act < 0 || cfg->value_act > ACT_TANH || cfg->policy_act < 0 || cfg->policy_act > ACT_TANH)
     return fail(h, DSACT_E_INVALID, "hidden activation must be 0..5 (gelu, relu, elu, selu, sigmoid, tanh)");
+  if (cfg->act_dist != 0 && cfg->act_dist != 1) return fail(h, DSACT_E_INVALID, "act_dist must be 0 (TanhGaussDistribution) or 1 (GaussDistribution)");
   if (h->cfg.global_batch < h->cfg.batch) h->cfg.global_batch = h->cfg.batch;
   HIPCHK(h, hipSetDevice(device));
   h->O = cfg->obs_dim; h->A = cfg->act_dim; h->L = cfg->n_hidden; h->B = cfg->batch;
@@ -3488,6 +3489,7 @@ int dsact_set_action_limits(dsact_handle* h, const float* high, const float* low
     if (!(high[j] > low[j])) return fail(h, DSACT_E_INVALID, "action_high_limit must exceed action_low_limit");
     s[j] = (high[j] - low[j]) / 2;  // fp32 like the reference's tensor arithmetic
     c[j] = (high[j] + low[j]) / 2;
+    if (h->cfg.act_dist == 1) { s[j] = 0.0f; c[j] = 0.0f; }   // GaussDistribution: the closed forms' "no squashing" selector (dsact_math.h)
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(h->act_scale, s.data(), h->A * sizeof(float), hipMemcpyHostToDevice));

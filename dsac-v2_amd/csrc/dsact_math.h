@@ -107,6 +107,9 @@ DSACT_HD float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), 
 struct TanhGaussFwd {
   float a, lp, sigma, t;
 };
+// s == 0 selects the reference's plain GaussDistribution (utils/act_distribution_cls.py:82-115; policy_act_distribution =
+// "GaussDistribution"): no squashing -- a = x, logp = Normal(mu, sigma).log_prob(x). (A tanh-Gaussian's half range is > 0:
+// dsact_set_action_limits rejects high <= low, and stores 0 in every dimension when the handle was created for the Gaussian.)
 DSACT_HD TanhGaussFwd tanh_gauss_fwd(float mu, float raw, float eps, float s, float c, float lo_ls,
                                      float hi_ls) {
   // Every product below is rounded on its own, as the reference's separate tensor ops are (the library is built with
@@ -117,12 +120,13 @@ DSACT_HD TanhGaussFwd tanh_gauss_fwd(float mu, float raw, float eps, float s, fl
   TanhGaussFwd o;
   o.sigma = expf(clampf(raw, lo_ls, hi_ls));
   const float x = mu + eps * o.sigma;  // Normal.rsample: loc + eps*scale
-  o.t = tanhf(x);
-  o.a = s * o.t + c;
   const float d = x - mu;
   const float var = o.sigma * o.sigma;
   // Normal.log_prob: -((v-loc)^2)/(2 var) - log(scale) - log(sqrt(2 pi))
   float lp = -(d * d) / (2.0f * var) - logf(o.sigma) - kLogSqrt2Pi;
+  if (s == 0.0f) { o.t = x; o.a = x; o.lp = lp; return o; }   // GaussDistribution.rsample (:99-102)
+  o.t = tanhf(x);
+  o.a = s * o.t + c;
   const float t2 = o.t * o.t;          // torch.pow(tanh(action), 2)
   lp -= logf((1.0f + kTanhEps) - t2);
   lp -= logf(s);
@@ -136,6 +140,12 @@ DSACT_HD void tanh_gauss_bwd(float mu, float raw, float eps, float s, float lo_l
 #pragma clang fp contract(off)
   const float sigma = expf(clampf(raw, lo_ls, hi_ls));
   const float x = mu + eps * sigma;
+  if (s == 0.0f) {   // GaussDistribution: a = x, logp = -eps^2/2 - log(sigma) - const through x = mu + eps sigma
+    dmu = gA;
+    const float dsg = gA * eps + gLp * (-1.0f / sigma);
+    draw = ((raw >= lo_ls) && (raw <= hi_ls)) ? dsg * sigma : 0.0f;
+    return;
+  }
   const float t = tanhf(x);
   const float omt2 = fmaf(-t, t, 1.0f);   // tanh backward: 1 - y*y in ONE rounding, which is what ATen's vectorised kernel does
                                           // (until round 3 this was 1.0f - t*t, two roundings: 6e-5 relative on saturated rows)

@@ -16,7 +16,7 @@ All arithmetic of the update runs in libdsact.so (hand-written gfx950 kernels, C
 include/dsact.h). torch owns the parameter/optimizer arenas and the checkpoint I/O only. There is no
 CPU fallback for the update: constructing DSAC_V2_HIP without the library or without a GPU raises.
 """
-__all__ = ["ApproxContainer", "DSAC_V2_HIP", "TanhGaussDistribution"]
+__all__ = ["ApproxContainer", "DSAC_V2_HIP", "TanhGaussDistribution", "GaussDistribution"]
 
 import copy
 import math
@@ -92,6 +92,30 @@ class TanhGaussDistribution:
         return self._half_range() * torch.tanh(self.mean) + self._center()
 
 
+class GaussDistribution(TanhGaussDistribution):
+    """plain diagonal Gaussian (reference utils/act_distribution_cls.py:82-115; policy_act_distribution =
+    "GaussDistribution"): no squashing; the action limits only bound mode()."""
+
+    def sample(self):
+        with torch.no_grad():
+            x = torch.normal(self.mean, self.std)  # same generator consumption as Normal.sample
+        return x, self._base_log_prob(x)
+
+    def rsample(self):
+        eps = torch.randn(self.mean.shape, dtype=self.mean.dtype, device=self.mean.device)
+        x = self.mean + eps * self.std
+        return x, self._base_log_prob(x)
+
+    def log_prob(self, action):
+        return self._base_log_prob(action)
+
+    def mode(self):
+        return torch.clamp(self.mean, self.act_low_lim, self.act_high_lim)
+
+
+ACT_DISTRIBUTIONS = {"TanhGaussDistribution": (0, TanhGaussDistribution), "GaussDistribution": (1, GaussDistribution)}
+
+
 # --------------------------------------------------------------------------------------------------
 # networks: torch modules whose parameters become views of the HIP arenas once attached
 # --------------------------------------------------------------------------------------------------
@@ -140,8 +164,10 @@ class HipStochaPolicy(nn.Module):
         mean, log_std = torch.chunk(out, chunks=2, dim=-1)
         return torch.cat((mean, torch.clamp(log_std, self.min_log_std, self.max_log_std).exp()), dim=-1)
 
+    action_distribution_cls = TanhGaussDistribution   # reference networks/mlp.py:77; ApproxContainer sets the configured class
+
     def get_act_dist(self, logits):
-        dist = TanhGaussDistribution(logits)
+        dist = self.action_distribution_cls(logits)
         dist.act_high_lim = self.act_high_lim.to(logits.device)
         dist.act_low_lim = self.act_low_lim.to(logits.device)
         return dist
@@ -236,11 +262,13 @@ def _check_supported(kwargs):
     for key in ("value_hidden_activation", "policy_hidden_activation"):
         if kwargs.get(key, "gelu") not in ACTIVATIONS:
             raise NotImplementedError("DSAC_V2_HIP supports %s in %s (got %r)" % (key, sorted(ACTIVATIONS), kwargs.get(key)))
-    for key, want in (("value_output_activation", "linear"), ("policy_output_activation", "linear"),
-                      ("policy_act_distribution", "TanhGaussDistribution")):
+    for key, want in (("value_output_activation", "linear"), ("policy_output_activation", "linear")):
         got = kwargs.get(key, want)
         if got != want:
             raise NotImplementedError("DSAC_V2_HIP supports %s=%r only (got %r)" % (key, want, got))
+    if kwargs.get("policy_act_distribution", "TanhGaussDistribution") not in ACT_DISTRIBUTIONS:
+        raise NotImplementedError("DSAC_V2_HIP supports policy_act_distribution in %s (got %r)"
+                                  % (sorted(ACT_DISTRIBUTIONS), kwargs.get("policy_act_distribution")))
     if kwargs.get("cnn_shared", False):
         raise NotImplementedError("cnn_shared is not supported by the HIP path")
     if kwargs.get("policy_std_type", "mlp_shared") != "mlp_shared":
@@ -281,6 +309,7 @@ class ApproxContainer(nn.Module):
             self.policy = HipCnnStochaPolicy(O, A, ct, hi, lo, mn, mx, pa)
         else:
             self.policy = HipStochaPolicy(O, A, hidden, hi, lo, mn, mx, pa)
+        self.policy.action_distribution_cls = ACT_DISTRIBUTIONS[kwargs.get("policy_act_distribution", "TanhGaussDistribution")][1]
         self.policy_target = copy.deepcopy(self.policy)
         for net in (self.policy_target, self.q1_target, self.q2_target):
             for p in net.parameters():
@@ -569,7 +598,8 @@ class DSAC_V2_HIP:
             min_log_std=kwargs.get("policy_min_log_std", -20.0), max_log_std=kwargs.get("policy_max_log_std", 2.0),
             global_batch=kwargs.get("global_batch"), device=int(kwargs.get("hip_device", 0)),
             value_act=ACTIVATIONS[kwargs.get("value_hidden_activation", "gelu")][0],
-            policy_act=ACTIVATIONS[kwargs.get("policy_hidden_activation", "gelu")][0])
+            policy_act=ACTIVATIONS[kwargs.get("policy_hidden_activation", "gelu")][0],
+            act_dist=ACT_DISTRIBUTIONS[kwargs.get("policy_act_distribution", "TanhGaussDistribution")][0])
         self.networks.attach(self.engine)
         register_engine(self.engine)
         if not self.strict_rng:

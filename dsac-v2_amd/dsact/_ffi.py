@@ -36,7 +36,7 @@ class Config(C.Structure):
         ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
         ("conv_type", C.c_int32), ("img_c", C.c_int32), ("img_h", C.c_int32), ("img_w", C.c_int32),
         ("algo", C.c_int32), ("td_bound", C.c_double),
-        ("v1_unbounded", C.c_int32), ("value_act", C.c_int32), ("policy_act", C.c_int32), ("reserved0", C.c_int32),
+        ("v1_unbounded", C.c_int32), ("value_act", C.c_int32), ("policy_act", C.c_int32), ("act_dist", C.c_int32),
     ]
 
 

@@ -101,7 +101,10 @@ typedef struct dsact_config {
   /* value_hidden_activation / policy_hidden_activation (utils/common_utils.py:16-45): 0 gelu (every shipped example),
    * 1 relu, 2 elu, 3 selu, 4 sigmoid, 5 tanh -- torch's default arguments. Output activations are linear. */
   int32_t value_act, policy_act;
-  int32_t reserved0;
+  /* policy_act_distribution (utils/act_distribution_cls.py): 0 = "TanhGaussDistribution" (:21-79, every shipped example),
+   * 1 = "GaussDistribution" (:82-115: no squashing -- action = mean + std * eps, log-prob of the plain diagonal Gaussian;
+   * the action limits are only used by the caller's clipping and by mode()). */
+  int32_t act_dist;
 } dsact_config;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

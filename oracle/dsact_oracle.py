@@ -157,6 +157,19 @@ def tanh_gauss_rsample(logits, eps, act_high, act_low):
     return action_limited, log_prob
 
 
+def gauss_rsample(logits, eps, act_high=None, act_low=None):
+    """GaussDistribution.rsample (utils/act_distribution_cls.py:99-102; policy_act_distribution = "GaussDistribution") with
+    the standard normal draw `eps` injected: no squashing, the action limits are not applied here."""
+    mean, std = torch.chunk(logits, chunks=2, dim=-1)
+    action = mean + eps * std
+    var = std ** 2
+    lp = -((action - mean) ** 2) / (2 * var) - std.log() - math.log(math.sqrt(2 * math.pi))
+    return action, lp.sum(-1)
+
+
+RSAMPLE = {"TanhGaussDistribution": tanh_gauss_rsample, "GaussDistribution": gauss_rsample}
+
+
 def seeded_state_dict(template, seed):
     """Initial values that regenerate WITHOUT the reference (the GPU box): every Linear weight / bias of the online
     nets drawn by numpy's default_rng(seed) from torch.nn.Linear's own default range U(-1/sqrt(fan_in), 1/sqrt(fan_in))
@@ -320,13 +333,14 @@ class DsactOracle:
         logits_mean, logits_std = torch.chunk(logits, chunks=2, dim=-1)
         policy_mean = torch.tanh(logits_mean).mean().item()
         policy_std = logits_std.mean().item()
-        new_act, new_log_prob = tanh_gauss_rsample(logits, noise["eps_new"], self.act_high, self.act_low)
+        rsample = RSAMPLE[cfg.get("act_dist", "TanhGaussDistribution")]
+        new_act, new_log_prob = rsample(logits, noise["eps_new"], self.act_high, self.act_low)
 
         for n in ("q1", "q2"):
             self.opt[n].zero_grad()
         # ---- __compute_loss_q (dsac_v2.py:218-290) ----
         logits_2 = self._pi(obs2, self.p["policy_target"])
-        act2, log_prob_act2 = tanh_gauss_rsample(logits_2, noise["eps_2"], self.act_high, self.act_low)
+        act2, log_prob_act2 = rsample(logits_2, noise["eps_2"], self.act_high, self.act_low)
         c_q1, c_q2 = col(), col()
         q1, q1_std = self._q(obs, act, self.p["q1"], c_q1)
         q2, q2_std = self._q(obs, act, self.p["q2"], c_q2)

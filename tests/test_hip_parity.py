@@ -135,6 +135,7 @@ def make_pair(O, A, hid, B, act_limit=0.4, seed=0, init=None, **over):
         alg.networks.load_state_dict(init)
     cfg = default_config(O, A, hid, act_limit=act_limit, value_act=over.get("value_hidden_activation", "gelu"),
                          policy_act=over.get("policy_hidden_activation", "gelu"),
+                         act_dist=over.get("policy_act_distribution", "TanhGaussDistribution"),
                          **{k: over[k] for k in ("auto_alpha", "alpha", "delay_update") if k in over})
     orc = DsactOracle(cfg, state_dict={k: v.cpu() for k, v in alg.networks.state_dict().items()})
     return alg, orc
@@ -204,7 +205,11 @@ def compare_intermediates(rep, alg, orc, L, B, A):
     for ch, key in (("pi", "z_pi"), ("q1c", "z_q1"), ("q2c", "z_q2"), ("q1p", "z_q1p"), ("q2p", "z_q2p")):
         for l in range(L):
             rep.cmp("H.%s.%d" % (ch, l), d("H.%s.%d" % (ch, l)), act_np(I[key][l], orc.cfg["policy_act" if ch == "pi" else "value_act"]), 2e-6, 2e-5)
-    rep.cmp("d_new_act", d("d_new_act"), I["d_new_act"], 1e-9, 2e-4)
+    if orc.cfg.get("act_dist", "TanhGaussDistribution") == "TanhGaussDistribution":
+        rep.cmp("d_new_act", d("d_new_act"), I["d_new_act"], 1e-9, 2e-4)
+    # (GaussDistribution: the oracle's new_act IS the pre-limit sample x, so its .grad also carries d logp / d x through
+    #  log_prob(action); the kernels keep dL/d new_act through the critics only and add the log-prob path in the rsample
+    #  backward -- the policy's dZ and gradient rows below compare the sum)
     for ch, key in (("q1c", "dz_q1"), ("q2c", "dz_q2"), ("q1p", "dz_q1p"), ("q2p", "dz_q2p"), ("pi", "dz_pi")):
         for l in range(L):
             rep.cmp("dZ.%s.%d" % (ch, l), d("dZ.%s.%d" % (ch, l)), I[key][l], 1e-10, 2e-4)
@@ -777,6 +782,39 @@ def test_pipelined_graph_equals_eager_steps(O, A, hid, B, D, per_graph, first, t
     algs[0].engine.sync(); algs[1].engine.sync()
     assert torch.equal(algs[0].engine.online, algs[1].engine.online)
     assert torch.equal(algs[0].engine.target, algs[1].engine.target)
+
+
+@pytest.mark.parametrize("O,A,hid,B", [(24, 6, (64, 64), 64), (376, 17, (256, 256, 256), 256), (11, 3, (96, 40), 50)])
+def test_gauss_distribution(O, A, hid, B):
+    """policy_act_distribution = "GaussDistribution" (utils/act_distribution_cls.py:82-115, a kwarg of rows a10 / a11 the HIP
+    path refused until round 5): action = mean + std * eps without squashing, log-prob of the plain diagonal Gaussian -- every
+    intermediate, gradient, statistic and parameter against the oracle (pinned bit-exact to the live reference with this
+    kwarg, tests/test_oracle_vs_reference.py) on the chain path, the BASELINE shape and the tile path."""
+    run_case("GaussDistribution O=%d A=%d hid=%s B=%d" % (O, A, hid, B), O, A, hid, B, steps=3, policy_act_distribution="GaussDistribution")
+
+
+def test_gauss_distribution_sampling_step():
+    """dsact_act_sample with the plain Gaussian == GaussDistribution.sample() on the same logits and generator state, and the
+    container hands the sampler / evaluator that class (mode() = clamp(mean, limits))."""
+    from dsac_v2_hip import GaussDistribution
+
+    O, A, hid, B, lim = 24, 6, (64, 64), 64, 0.4
+    alg, _ = make_pair(O, A, hid, B, act_limit=lim, seed=3, policy_act_distribution="GaussDistribution")
+    e = alg.engine
+    rng = np.random.default_rng(2)
+    for i in range(10):
+        obs = rng.standard_normal(O).astype(np.float32)
+        torch.manual_seed(i)
+        eps = torch.randn(1, A)
+        action, logp = e.act_sample(obs, eps.numpy())
+        logits = torch.from_numpy(e.policy_forward(obs[None]))
+        dist = alg.networks.create_action_distributions(logits)
+        assert isinstance(dist, GaussDistribution)
+        torch.manual_seed(i)
+        a_ref, lp_ref = dist.sample()
+        np.testing.assert_allclose(action, a_ref[0].numpy(), atol=2e-6, rtol=0)
+        assert abs(float(logp[0]) - float(lp_ref[0])) <= 2e-4
+        assert torch.equal(dist.mode(), torch.clamp(dist.mean, -lim, lim))
 
 
 def test_device_rng_is_standard_normal():

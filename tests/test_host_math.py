@@ -120,3 +120,34 @@ def test_adam_and_polyak_track_torch(hm):
     st = opt.state[prm]
     np.testing.assert_allclose(m, f32(st["exp_avg"]), rtol=1e-6, atol=1e-7 * float(np.abs(m).max()))
     np.testing.assert_allclose(v, f32(st["exp_avg_sq"]), rtol=1e-6, atol=1e-7 * float(np.abs(v).max()))
+
+
+def test_gauss_distribution_branch(hm):
+    """s == 0 selects the reference's plain GaussDistribution (utils/act_distribution_cls.py:82-115) in the closed forms:
+    action = mu + sigma * eps, log-prob of the diagonal Gaussian, and its gradients against torch autograd."""
+    n = 3000
+    torch.manual_seed(1)
+    mu = (torch.randn(n) * 1.5).requires_grad_(True)
+    raw = torch.cat([torch.randn(n - 4) * 2 - 1, torch.tensor([0.5, 0.6, -20.0, -21.0])]).requires_grad_(True)
+    eps = torch.randn(n)
+    std = torch.clamp(raw, -20.0, 0.5).exp()
+    base = torch.distributions.Normal(mu, std)
+    act = mu + eps * std                      # Normal.rsample
+    lp = base.log_prob(act)
+    gA = torch.randn(n)
+    gLp = 0.37
+    (act * gA).sum().backward(retain_graph=True)
+    (lp * gLp).sum().backward()
+    mun, rawn, epsn, gAn = f32(mu), f32(raw), f32(eps), f32(gA)
+    a_o, lp_o = np.empty_like(mun), np.empty_like(mun)
+    hm.hm_tanh_gauss_fwd.argtypes = [FP, FP, FP, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, FP, FP]
+    hm.hm_tanh_gauss_fwd(p(mun), p(rawn), p(epsn), n, 0.0, 0.0, -20.0, 0.5, p(a_o), p(lp_o))
+    np.testing.assert_allclose(a_o, f32(act), atol=1e-6, rtol=1e-6)
+    np.testing.assert_allclose(lp_o, f32(lp), atol=2e-5, rtol=1e-5)
+    dmu, draw = np.empty_like(mun), np.empty_like(mun)
+    hm.hm_tanh_gauss_bwd.argtypes = [FP, FP, FP, FP, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, FP, FP]
+    hm.hm_tanh_gauss_bwd(p(mun), p(rawn), p(epsn), p(gAn), n, 0.0, -20.0, 0.5, gLp, p(dmu), p(draw))
+    # (autograd's d logp / d mu is the difference of two equal terms: zero up to their rounding)
+    np.testing.assert_allclose(dmu, f32(mu.grad), atol=2e-5 * float(np.abs(f32(mu.grad)).max()) + 1e-5, rtol=0)
+    np.testing.assert_allclose(draw, f32(raw.grad), atol=2e-5 * float(np.abs(f32(raw.grad)).max()) + 1e-5, rtol=1e-5)
+

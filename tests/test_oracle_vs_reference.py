@@ -11,17 +11,21 @@ from helpers import synth_batch
 pytestmark = pytest.mark.skipif(not ref_loader.reference_available(), reason="reference not mounted")
 
 
-@pytest.mark.parametrize("O,A,hid,B,va,pa", [
-    (376, 17, (256, 256, 256), 256, "gelu", "gelu"), (376, 17, (256, 256), 128, "gelu", "gelu"), (3, 1, (64, 64, 64), 64, "gelu", "gelu"),
+@pytest.mark.parametrize("O,A,hid,B,va,pa,dist", [
+    (376, 17, (256, 256, 256), 256, "gelu", "gelu", "TanhGaussDistribution"), (376, 17, (256, 256), 128, "gelu", "gelu", "TanhGaussDistribution"),
+    (3, 1, (64, 64, 64), 64, "gelu", "gelu", "TanhGaussDistribution"),
     # value_hidden_activation / policy_hidden_activation other than the examples' gelu (utils/common_utils.py:16-45)
-    (24, 6, (64, 64), 64, "relu", "tanh"), (24, 6, (64, 64), 64, "elu", "selu"), (24, 6, (64, 64), 64, "sigmoid", "relu")])
-def test_bit_exact_vs_live_reference(O, A, hid, B, va, pa):
+    (24, 6, (64, 64), 64, "relu", "tanh", "TanhGaussDistribution"), (24, 6, (64, 64), 64, "elu", "selu", "TanhGaussDistribution"),
+    (24, 6, (64, 64), 64, "sigmoid", "relu", "TanhGaussDistribution"),
+    # policy_act_distribution = GaussDistribution (utils/act_distribution_cls.py:82-115): no tanh squashing (round 5)
+    (24, 6, (64, 64), 64, "gelu", "gelu", "GaussDistribution"), (376, 17, (256, 256, 256), 64, "gelu", "gelu", "GaussDistribution")])
+def test_bit_exact_vs_live_reference(O, A, hid, B, va, pa, dist):
     torch.set_num_threads(2)
     ref = ref_loader.import_reference()
-    kw = ref_loader.reference_kwargs(O, A, hid, value_hidden_activation=va, policy_hidden_activation=pa)
+    kw = ref_loader.reference_kwargs(O, A, hid, value_hidden_activation=va, policy_hidden_activation=pa, policy_act_distribution=dist)
     torch.manual_seed(0)
     alg = ref.DSAC_V2(**kw)
-    cfg = default_config(O, A, hid, value_act=va, policy_act=pa)
+    cfg = default_config(O, A, hid, value_act=va, policy_act=pa, act_dist=dist)
     torch.manual_seed(0)
     same_seed = DsactOracle(cfg)  # same construction order => same init from the same seed
     sd = alg.networks.state_dict()
