@@ -726,6 +726,7 @@ def chain_flops(lay, batch):
     # `deferred_bwd_pi` is what the next forward launch then carries on top of its own chains
     per_row["chain_dw_q"] = 2 * dw_q
     per_row["chain_bwd_qt"] = per_row["chain_bwd_q"] + 2 * dw_q    # round 5: critics' backward + their tiles + close in one launch
+    per_row["chain_bwd_qpt"] = per_row["chain_bwd_q"] + per_row["chain_bwd_pi"] + dw_pi   # ... and of a policy-moving update: the whole backward
     per_row["deferred_bwd_pi"] = 2 * A_ * W + hid + dw_pi
     per_row["chain_bwd"] = per_row["chain_bwd_q"] + per_row["chain_bwd_pi"] + per_row["dW"]   # merged backward + optimiser launch
     return {k: 2.0 * v * batch for k, v in per_row.items()}
@@ -1024,14 +1025,15 @@ def main():
                          "chain_fwd_q": "dsact::k_chain_fwdp (fresh-critic chains only)", "chain_fwd_q+next": "dsact::k_chain_fwdp",
                          "chain_bwd": "dsact::k_chain_bwd2 (critics' + policy backward + all dW/Adam tiles in one launch)",
                          "chain_fwd": "dsact::k_chain_fwd2 (groups A + B in one launch)", "chain_fwd_a": "dsact::k_chain_fwd (group A)", "chain_fwd_b": "dsact::k_chain_fwd (group B)",
-                         "chain_bwd_q": "dsact::k_chain_bwd_q", "chain_bwd_qt": "dsact::k_chain_bwd_qt (critics' backward + their dW/Adam tiles + close)", "chain_bwd_pi": "dsact::k_chain_bwd_pi (+ riding k_dw2 tiles)",
+                         "chain_bwd_q": "dsact::k_chain_bwd_q", "chain_bwd_qt": "dsact::k_chain_bwd_qt (critics' backward + their dW/Adam tiles + close)",
+                         "chain_bwd_qpt": "dsact::k_chain_bwd_qpt (critics' backward -> policy backward -> all dW/Adam/Polyak tiles -> close)", "chain_bwd_pi": "dsact::k_chain_bwd_pi (+ riding k_dw2 tiles)",
                          "dW": "dsact::k_dw2"}.get(dom[0], dom[0])
                 if dom[0] in fl:
                     dur_us = dom[1] * 1000.0
                     ach = fl[dom[0]] / (dur_us * 1e-6) / 1e12
                     out["roofline"] = {
                         "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
-                        "traffic": pmc_traffic({"chain_bwd": "k_chain_bwd2", "chain_fwd": "k_chain_fwdp" if pipe else "k_chain_fwd2", "chain_fwd+next": "k_chain_fwdp", "chain_fwd_q": "k_chain_fwdpb" if any(r[0] == "chain_dw_q" for r in prof) else "k_chain_fwdp", "chain_fwd_q+next": "k_chain_fwdp", "chain_fwd_a": "k_chain_fwd", "chain_fwd_b": "k_chain_fwd", "chain_bwd_q": "k_chain_bwd_q", "chain_bwd_qt": "k_chain_bwd_qt",
+                        "traffic": pmc_traffic({"chain_bwd": "k_chain_bwd2", "chain_fwd": "k_chain_fwdp" if pipe else "k_chain_fwd2", "chain_fwd+next": "k_chain_fwdp", "chain_fwd_q": "k_chain_fwdpb" if any(r[0] == "chain_dw_q" for r in prof) else "k_chain_fwdp", "chain_fwd_q+next": "k_chain_fwdp", "chain_fwd_a": "k_chain_fwd", "chain_fwd_b": "k_chain_fwd", "chain_bwd_q": "k_chain_bwd_q", "chain_bwd_qt": "k_chain_bwd_qt", "chain_bwd_qpt": "k_chain_bwd_qpt",
                                                 "chain_bwd_pi": "k_chain_bwd_pi", "dW": "k_dw2"}.get(dom[0], dom[0]),
                                                "min" if dom[0] == "chain_fwd_b" else "max"),
                         "traffic_source": "%s (a committed rocprofv3 --pmc pass of this bench; NOT measured in this run)" % getattr(pmc_traffic, "source", None),

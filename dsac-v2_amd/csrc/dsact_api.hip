@@ -323,6 +323,10 @@ struct dsact_handle {
                                         // chain_bwd_pi 22.5-22.8 -> 23.4-23.6 us -- the early tiles' traffic slows the chain whose end the first layer's tiles wait for)
   bool env_no_bqt = false;              // DSACT_NO_BQT_MERGE: critics' backward and their tiles stay two launches (A/B)
   bool bqt_now = false;                 // set while such an update is being enqueued
+  // k_chain_bwd_qpt: the whole backward of a policy-moving update of the pipelined graph as one launch
+  unsigned long long* bqp_pairs[2] = {nullptr, nullptr};   // dL/d new_act through q1 / q2 as (value, tag) pairs [B][32]
+  bool env_no_bqp = false;              // DSACT_NO_BQP_MERGE: critics' backward and policy backward stay two launches on those updates (A/B)
+  bool bqp_now = false;
   bool pipe_graph = false;              // the captured graphs are the pipelined ones (pgraph / pexec, one per phase)
   hipGraph_t pgraph[kPipePhases] = {nullptr, nullptr, nullptr, nullptr};
   hipGraphExec_t pexec[kPipePhases] = {nullptr, nullptr, nullptr, nullptr};
@@ -2266,7 +2270,7 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
   a.timeline = tl_for(h, pipe_fwd_name(pre, do_pre));
   a.spin_timeout = h->handoff_dev;
   a.debug_withhold = h->debug_withhold == 1;
-  a.tagp = &h->st->seq_next;
+  a.tagp = &h->st->tag_seq;
   a.tpad = h->env_pk_pad;
   // block table: every XCD's queue is filled role by role (the enum is the priority order), a role's slices are dealt
   // round-robin over its XCDs; block 8 r + x = entry r of XCD x's queue (the dispatcher places block b on XCD b % 8)
@@ -2286,7 +2290,7 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
     int xs = 0;
     for (int x = 1; x < 8; ++x) if (q[x].size() < q[xs].size()) xs = x;
     q[xs].push_back(kPipeRoleBook << 16);
-    P.book_st = h->st; P.book_hp = step_hyper(h); P.book_cnt = h->bqt_cnt; P.book_ncnt = 2 * 8;
+    P.book_st = h->st; P.book_hp = step_hyper(h); P.book_cnt = h->bqt_cnt; P.book_ncnt = 3 * 8;
   }
   size_t rounds = 0;
   for (int x = 0; x < 8; ++x) rounds = q[x].size() > rounds ? q[x].size() : rounds;
@@ -2522,6 +2526,10 @@ int build_bqt(dsact_handle* h) {
   if (h->bqt_tab) return DSACT_OK;
   HIPCHK(h, hipMalloc((void**)&h->bqt_cnt, kBqtCntInts * sizeof(int)));
   HIPCHK(h, hipMemset(h->bqt_cnt, 0, kBqtCntInts * sizeof(int)));
+  for (int i = 0; i < 2; ++i) {
+    HIPCHK(h, hipMalloc((void**)&h->bqp_pairs[i], (size_t)h->B * 32 * sizeof(unsigned long long)));
+    HIPCHK(h, hipMemset(h->bqp_pairs[i], 0, (size_t)h->B * 32 * sizeof(unsigned long long)));
+  }
   const Dw2Args d = dw2_args(h, true);
   const int L = h->L;
   std::vector<int> q[8];
@@ -2549,11 +2557,18 @@ int build_bqt(dsact_handle* h) {
   h->bqt_tab_blocks = (int)tab.size();
   return DSACT_OK;
 }
+// the 4-unit form of the critics' backward arguments (the merged launches' kernel-argument budget)
+static void shrink_bwd_q(const BwdQArgs& s8, BwdQArgsN<4>& d) {
+  (BwdQTail&)d = (const BwdQTail&)s8;
+  for (int i = 0; i < 4; ++i) d.u[i] = s8.u[i];
+}
 int enqueue_chain_bwd_qt(dsact_handle* h, bool fused, const RideArgs* ride) {
   BwdQtArgs a;
   memset(&a, 0, sizeof(a));
   int rg, n_riders;
-  bwd_q_args(h, 2 * h->nq, ride, a.q, rg, n_riders);
+  BwdQArgs q8;
+  bwd_q_args(h, 2 * h->nq, ride, q8, rg, n_riders);
+  shrink_bwd_q(q8, a.q);
   a.q.arrive = h->bqt_cnt;
   a.q.debug_withhold = h->debug_withhold == 3;
   a.q.timeline = tl_for(h, "chain_bwd_qt");
@@ -2571,6 +2586,44 @@ int enqueue_chain_bwd_qt(dsact_handle* h, bool fused, const RideArgs* ride) {
 #define CALL_CQT(N, G) return launch(h, "chain_bwd_qt", k_chain_bwd_qt<N, G>, dim3(grid), dim3(kThreads), lds, a)
   CHAIN_NT(CALL_CQT, rg);
 #undef CALL_CQT
+}
+
+// k_chain_bwd_qpt: critics' backward -> policy backward -> every weight-gradient tile -> close, one launch
+int enqueue_chain_bwd_qpt(dsact_handle* h, bool fused, const RideArgs* ride) {
+  BwdQpArgs a;
+  memset(&a, 0, sizeof(a));
+  int rg_q, n_riders, rg_pi;
+  BwdQArgs q8;
+  bwd_q_args(h, 2 * h->nq, ride, q8, rg_q, n_riders);
+  shrink_bwd_q(q8, a.q);
+  a.q.arrive = h->bqt_cnt;
+  a.q.debug_withhold = h->debug_withhold == 3;
+  a.q.tagp = &h->st->tag_seq;
+  for (int w = 0; w < 4; ++w)
+    if (a.q.u[w].which >= 2) a.q.u[w].dA_pairs = h->bqp_pairs[a.q.u[w].which - 2];
+  bwd_pi_args(h, h->dw2_off[0], h->dw2_off[2], fused, a.pi, rg_pi, true);
+  a.pi.cnt_pi = h->bqt_cnt + 2 * 8 * kArriveStride;    // (its own counter: the forward launch's deferred chain uses the flags' one)
+  a.pi.per_layer = 0;
+  a.pi.dA_pairs[0] = h->bqp_pairs[0]; a.pi.dA_pairs[1] = h->bqp_pairs[1];
+  a.pi.tagp = &h->st->tag_seq;
+  a.pi.timeline = nullptr;
+  a.q.ride.n_loss_blocks = a.q.n_chain_blocks + a.pi.n_chain_blocks;   // loss_rider numbers its blocks from the first rider
+  a.tile_tab = h->bqt_tab; a.n_tile_blocks = h->bqt_tab_blocks;
+  a.n_riders = n_riders;
+  a.need_c = a.q.n_slices;
+  a.spin_timeout = h->handoff_dev;
+  a.logp_new = h->logp_new; a.n_part = h->B; a.target_entropy = -(float)h->A;
+  a.grad_log_alpha = h->grads + h->n_online - 1;
+  a.finalize = fused ? 1 : 0;
+  size_t lds = (size_t)chain_lds(h->cW, h->cW, 4 * rg_q).total * sizeof(float);
+  const size_t lp = (size_t)chain_lds(4 * h->SoT, h->cW, 4 * rg_pi).total * sizeof(float);
+  if (lp > lds) lds = lp;
+  if (lds < kDw2LdsFloats * sizeof(float)) lds = kDw2LdsFloats * sizeof(float);
+  const int grid = a.q.n_chain_blocks + a.pi.n_chain_blocks + n_riders + a.n_tile_blocks + xcd_chunk_grid(a.pi.n_pi_tiles) + 1;
+  if (rg_q != 1 || rg_pi != 2) return fail(h, DSACT_E_STATE, "k_chain_bwd_qpt expects 4-row critic slices and 8-row policy slices");
+  if (h->cNT == 1) return launch(h, "chain_bwd_qpt", k_chain_bwd_qpt<1, 1, 2>, dim3(grid), dim3(kThreads), lds, a);
+  if (h->cNT == 2) return launch(h, "chain_bwd_qpt", k_chain_bwd_qpt<2, 1, 2>, dim3(grid), dim3(kThreads), lds, a);
+  return launch(h, "chain_bwd_qpt", k_chain_bwd_qpt<4, 1, 2>, dim3(grid), dim3(kThreads), lds, a);
 }
 
 // same contract as enqueue_grads (phases, fused optimiser, riders of the loss launch)
@@ -2598,6 +2651,8 @@ int enqueue_grads_chain(dsact_handle* h, bool actor_backward, bool fused, int ph
   if (phase == 1) return DSACT_OK;
   // pipelined graph, update whose policy backward rides in the next forward launch: critics' backward + their tiles + close
   if (h->bqt_now && h->pipe_defer_now && actor_backward && fused && phase == 2) return enqueue_chain_bwd_qt(h, fused, ride);
+  // ... update that moves the policy: the whole backward as one launch
+  if (h->bqp_now && !h->pipe_defer_now && actor_backward && fused && phase == 2) return enqueue_chain_bwd_qpt(h, fused, ride);
   TRY(enqueue_chain_bwd_q(h, (actor_backward ? 2 : 1) * h->nq, ride));
   // CNN nets (batch <= 1024: one gradient arena): dL/d features = dZ0 . W0[:, :F] right behind the chains that produce dZ0 and
   // before the launch whose tiles update W0; the conv stacks' backward follows the MLP part (enqueue_grads' order)
@@ -3160,6 +3215,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->env_pipe_qp_split = getenv("DSACT_PIPE_QP_SPLIT") != nullptr;
   h->env_no_pipe_defer = getenv("DSACT_NO_PIPE_DEFER") != nullptr;
   h->env_no_bqt = getenv("DSACT_NO_BQT_MERGE") != nullptr;
+  h->env_no_bqp = getenv("DSACT_NO_BQP_MERGE") != nullptr;
   h->env_pi_layers = getenv("DSACT_PI_LAYERS") != nullptr;
   h->env_no_pipe_warm = getenv("DSACT_PIPE_WARM") == nullptr;
   h->env_no_pipe_tagged = getenv("DSACT_NO_PIPE_TAGGED") != nullptr;
@@ -3403,6 +3459,7 @@ int dsact_destroy(dsact_handle* h) {
   if (h->pipe_ws) hipFree(h->pipe_ws);
   if (h->bqt_cnt) hipFree(h->bqt_cnt);
   if (h->bqt_tab) hipFree(h->bqt_tab);
+  for (int i = 0; i < 2; ++i) if (h->bqp_pairs[i]) hipFree(h->bqp_pairs[i]);
   if (h->pk_ws) hipFree(h->pk_ws);
   for (int i = 0; i < 2; ++i) { if (h->d_fwdt[i]) hipFree(h->d_fwdt[i]); delete h->fwdt_host[i]; }
   if (h->d_mir) hipFree(h->d_mir);
@@ -3950,6 +4007,7 @@ struct PipePlan {
   std::vector<int> bp_rg;
   bool dp = false;                // local gradients -> all-reduce -> k_adam_pack instead of the fused optimiser
   std::vector<char> bqt;          // update s: critics' backward + their tiles + close as one launch (its bookkeeping rides in its forward)
+  std::vector<char> bqp;          // update s (moves the policy): critics' + policy backward + all tiles + close as one launch
   bool skip = false;              // DSACT_F_SKIP_ACTOR_ON_OFF_ITERS: the discarded policy backward is not computed at all
   std::vector<char> leaves;       // update s leaves policy / alpha / targets alone
 };
@@ -3968,7 +4026,10 @@ static int plan_updates_pipe(dsact_handle* h, int n, int phase, PipePlan& plan, 
   plan.skip = (flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) != 0 && !plan.dp;
   plan.leaves.assign((size_t)n, 0);
   plan.bqt.assign((size_t)n, 0);
+  plan.bqp.assign((size_t)n, 0);
   const bool bqt = bqt_ok(h) && !plan.dp;
+  // (4-row critic slices, 8-row policy slices: the instantiation k_chain_bwd_qpt is built for)
+  const bool bqp = bqt && h->nq == 2 && !h->env_no_bqp && chain_rg(h, 4, true) == 1 && rg_pi == 2;
   if (bqt) TRY(build_bqt(h));
   bool pre = false;
   int rc = DSACT_OK;
@@ -3982,14 +4043,17 @@ static int plan_updates_pipe(dsact_handle* h, int n, int phase, PipePlan& plan, 
       apply_pipe_set(h, set_of(s - 1));   // the deferred backward works on the PREVIOUS update's minibatch
       BwdPiArgs& a = plan.bp[(size_t)s];
       // (the deferred chain shares its launch with forward chains, not with ~500 riding tiles: 4-row slices by default)
-      bwd_pi_args(h, h->dw2_off[2], h->dw2_off[2], !plan.dp, a, plan.bp_rg[(size_t)s], true, h->env_pipe_bp_rg);
+      // (fused = false: the tiles compute, apply nothing and store nothing -- and never read the step state, which the
+      //  bookkeeping block of THIS forward launch may be rewriting for the update the launch belongs to)
+      bwd_pi_args(h, h->dw2_off[2], h->dw2_off[2], false, a, plan.bp_rg[(size_t)s], true, h->env_pipe_bp_rg);
       a.finalize = 0;                     // that update was closed by its own last launch
       a.dw.store_g = 0;                   // nothing reads this gradient (fused: no optimiser step on that update either)
       bp = &a;
     }
     plan.defer[(size_t)s] = do_pre && can_defer && !plan.skip;   // (skip: there is no policy backward to move)
     plan.bqt[(size_t)s] = plan.defer[(size_t)s] && bqt;
-    rc = pipe_fwd_build(h, set_of(s), set_of(s + 1), pre, do_pre, plan.host[(size_t)s], bp, plan.bqt[(size_t)s] != 0);
+    plan.bqp[(size_t)s] = !leaves_policy && bqp;
+    rc = pipe_fwd_build(h, set_of(s), set_of(s + 1), pre, do_pre, plan.host[(size_t)s], bp, plan.bqt[(size_t)s] != 0 || plan.bqp[(size_t)s] != 0);
     plan.pre[(size_t)s] = pre; plan.dop[(size_t)s] = do_pre;
     pre = do_pre;
   }
@@ -4040,7 +4104,7 @@ static int enqueue_updates_pipe(dsact_handle* h, int n, const PipePlan& plan, Pi
       ride.g = gather_args(h, h->idx_table, h->idx_rows, 1, 0, 1);   // (st / hp of the bookkeeping block)
       ride.n_gather = 0;
     }
-    ride.bookkeeping = plan.bqt[(size_t)s] ? 0 : 1;   // (merged critic backward: the forward launch did the bookkeeping)
+    ride.bookkeeping = (plan.bqt[(size_t)s] || plan.bqp[(size_t)s]) ? 0 : 1;   // (merged backward launches: the forward launch did the bookkeeping)
     if (plan.dp) {
       h->pipe_defer_now = plan.defer[(size_t)s] != 0;
       rc = enqueue_grads(h, true, false, 2, &ride);
@@ -4052,9 +4116,11 @@ static int enqueue_updates_pipe(dsact_handle* h, int n, const PipePlan& plan, Pi
     }
     h->pipe_defer_now = plan.defer[(size_t)s] != 0;
     h->bqt_now = plan.bqt[(size_t)s] != 0;
+    h->bqp_now = plan.bqp[(size_t)s] != 0;
     rc = enqueue_grads(h, !(plan.skip && plan.leaves[(size_t)s]), true, 2, &ride);
     h->pipe_defer_now = false;
     h->bqt_now = false;
+    h->bqp_now = false;
   }
   apply_pipe_set(h, 0);
   h->mirror_w0 = false;

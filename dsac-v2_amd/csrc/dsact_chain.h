@@ -605,7 +605,7 @@ struct FwdArgs {
   int* spin_timeout;                // merged launch: set to 1 by a consumer that gave up waiting. The word lives in mapped
                                     // HOST memory: every entry point of the library checks it and fails the call
   int debug_withhold;               // tests only (dsact_debug_set "withhold_flag"): unit 0 / slice 0 never raises its flag
-  const long long* tagp;            // tagged hand-over: DevState::seq_next (advances with every closed update): tag = low word + 1
+  const long long* tagp;            // tagged hand-over: DevState::tag_seq (advances with every closed update, never reset): tag = low word + 1
   int tpad;                         // steps of padding behind every 64-row tile of the forward packs (experiments: DSACT_PK_PAD)
 };
 
@@ -1160,9 +1160,12 @@ struct BwdQUnit {
   int which;                       // 0 q1c, 1 q2c, 2 q1p, 3 q2p
   int trunk;                       // twin-trunk nets: 0 = mean trunk (writes the shared row-phase results), 1 = log_std trunk
   float* dz0row;                   // row-major copy of dZ[0] [B][ldz0] at this trunk's columns (CNN nets: operand of dL/d features), or nullptr
+  unsigned long long* dA_pairs;    // actor chains of k_chain_bwd_qpt: dL/d new_act ALSO as (value, tag) pairs [B][32] for the policy
+                                   // backward slices of the same launch (nullptr: none)
 };
-struct BwdQArgs {
-  BwdQUnit u[8];                   // twin-trunk nets: (chain, trunk) pairs -- wout / wb / G / dZ / w1at / dA point at the trunk's part
+// (the unit array comes LAST and is sized by the kernel: the merged launches carry 4 units, so that critic backward +
+//  policy backward + the weight-gradient tiles' descriptors fit the 4 KB of kernel arguments)
+struct BwdQTail {
   int n_units, n_slices;
   int B, A, L, Cb;
   // loss inputs (dsac_v2.py:218-318), as k_loss
@@ -1188,8 +1191,14 @@ struct BwdQArgs {
   // nullptr: not merged
   int* arrive;
   int debug_withhold;              // tests only (dsact_debug_set "withhold_flag" 3): slice 0 of q1's chain never arrives
+  const long long* tagp;           // dA_pairs: DevState::tag_seq (tag = low word + 1, as in the pipelined forward launches)
 };
-constexpr int kBqtCntInts = 2 * 8 * 64;   // [2 critics][8 replicas x kArriveStride]
+template <int NU>
+struct BwdQArgsN : BwdQTail {
+  BwdQUnit u[NU];                  // twin-trunk nets: (chain, trunk) pairs -- wout / wb / G / dZ / w1at / dA point at the trunk's part
+};
+typedef BwdQArgsN<8> BwdQArgs;
+constexpr int kBqtCntInts = 3 * 8 * 64;   // [q1, q2 chains | policy chain of k_chain_bwd_qpt][8 replicas x kArriveStride]
 
 // row-major copy of a slice's dZ[0] from its LDS image [R][ld_h] (CNN nets: the dL/d features product reads it as a plain
 // matrix). A loop of its own behind a uniform branch: the same stores inside the chains' unrolled epilogues kept 32
@@ -1205,8 +1214,8 @@ __device__ __forceinline__ void store_dz0_rows(float* dst, int ldz0, int row0, c
 
 // MRG: compiled for the merged launch k_chain_bwd_qt (write-through stores + arrival counters on the critics' own chains);
 // false: every hand-over branch folds away (k_chain_bwd_q is the code it was)
-template <int NW, int RG, bool MRG = false>
-__device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* lds) {
+template <int NW, int RG, bool MRG = false, typename QA = BwdQArgs>
+__device__ __forceinline__ void bwd_q_body(const QA& a, int block, float* lds) {
   if (a.flags_reset && threadIdx.x == 0)
     for (int i = block; i < a.n_flags; i += a.n_chain_blocks) a.flags_reset[i] = 0;
   int unit, slice;
@@ -1394,7 +1403,14 @@ __device__ __forceinline__ void bwd_q_body(const BwdQArgs& a, int block, float* 
   // ---- dL/d new_act through this critic: dZ0 . W0[:, F:F+A]   (contraction over the hidden units, split over waves)
   narrow_mma<2>(af, nta, wave, lds, (cur ? S.off_h1 : S.off_h0) + ((lane & 15) & (R - 1)) * S.ld_h + 4 * (lane >> 4), red, lane);
   lds_barrier();
-  for (int d = j; d < 16 * nta; d += TPR) u.dA[(size_t)r * 32 + d] = d < a.A ? narrow_get<2, NW>(lds, red, m, d) : 0.0f;
+  const unsigned ptag = (MRG && u.dA_pairs) ? (unsigned)(*a.tagp) + 1u : 0u;
+  for (int d = j; d < 16 * nta; d += TPR) {
+    const float v = d < a.A ? narrow_get<2, NW>(lds, red, m, d) : 0.0f;
+    u.dA[(size_t)r * 32 + d] = v;
+    if (MRG && u.dA_pairs)   // the data is the flag: one 8-byte agent-scope store per element (k_chain_bwd_qpt's policy slices poll them)
+      __hip_atomic_store(u.dA_pairs + (size_t)r * 32 + d, ((unsigned long long)ptag << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   CTL(a.timeline, 12);
   CTLR(a.timeline, 15);
 }
@@ -1442,6 +1458,9 @@ struct BwdPiArgs {
   // visible chip-wide; a policy tile waits for ITS layer's counter only. pi_prob0: index of the policy's first problem in
   // dw.p. per_layer == 0: one counter, raised at the end of the chain
   int per_layer, pi_prob0;
+  // k_chain_bwd_qpt: dL/d new_act arrives from the critics' chains of the SAME launch as (value, tag) pairs [B][32] per critic
+  // (every lane polls ITS elements until they carry this update's tag; bounded). nullptr: plain loads of dA (an earlier launch)
+  const unsigned long long* dA_pairs[2]; const long long* tagp;
   int debug_withhold;              // tests only (dsact_debug_set "withhold_flag" 2): slice 0 never arrives
   long long* timeline;
   Dw2Args dw;
@@ -1485,16 +1504,42 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
   // the row phase's inputs, fetched before anything waits (each would otherwise be a round trip on the critical path)
   constexpr int NQ = (32 + TPR - 1) / TPR;      // act_dim <= 32
   float pdA[NQ], pmu[NQ], praw[NQ], peps[NQ], psc[NQ];
+  const bool pairs = a.dA_pairs[0] != nullptr;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int d = j + q * TPR;
     const bool ok = d < A;
-    pdA[q] = ok ? a.dA[0][(size_t)r * 32 + d] + a.dA[1][(size_t)r * 32 + d] : 0.f;
+    pdA[q] = (ok && !pairs) ? a.dA[0][(size_t)r * 32 + d] + a.dA[1][(size_t)r * 32 + d] : 0.f;
     if (a.dA2[0] && ok) pdA[q] += a.dA2[0][(size_t)r * 32 + d] + a.dA2[1][(size_t)r * 32 + d];
     pmu[q] = ok ? a.logits_pi[(size_t)r * 2 * A + d] : 0.f;
     praw[q] = ok ? a.logits_pi[(size_t)r * 2 * A + A + d] : 0.f;
     peps[q] = ok ? a.eps_new[(size_t)r * A + d] : 0.f;
     psc[q] = ok ? a.act_scale[d] : 1.f;
+  }
+  if (pairs) {
+    // the critics' chains of this launch deliver dL/d new_act as (value, tag) pairs: this slice's weight stream and every other
+    // input are already in flight while its lanes poll their own elements (same sum, same order as the plain loads)
+    const unsigned tag = (unsigned)(*a.tagp) + 1u;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int d = j + q * TPR;
+      if (d < A) {
+        float v[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const unsigned long long* src = a.dA_pairs[c] + (size_t)r * 32 + d;
+          unsigned long long pv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          int spins = 0;
+          while ((unsigned)(pv >> 32) != tag) {
+            if (++spins > (1 << 17)) { if (a.spin_timeout) *a.spin_timeout = 1; break; }   // ~0.1 s, then the hand-off word
+            __builtin_amdgcn_s_sleep(8);
+            pv = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          v[c] = __builtin_bit_cast(float, (unsigned)pv);
+        }
+        pdA[q] = v[0] + v[1];
+      }
+    }
   }
   // alpha gradient (dsac_v2.py:312-318): -mean(logp_new + target_entropy)
   if (slice == 0 && wave == 0 && !a.merge_dw && lead) bwd_pi_alpha_grad(a, lane);   // merged launch: the closing block does it
@@ -1666,7 +1711,7 @@ __global__ void __launch_bounds__(512) k_chain_bwd_pi8(BwdPiArgs a) {
 // per row as the two launches: bit-identical (tests/test_hip_parity.py::test_pipelined_graph_equals_eager_steps).
 // ---------------------------------------------------------------------------------------------------------------
 struct BwdQtArgs {
-  BwdQArgs q;
+  BwdQArgsN<4> q;
   Dw2Args dw;
   const int* tile_tab; int n_tile_blocks;      // block behind the chain slices and riders -> base tile of dw, or -1 (padding)
   int n_riders;
@@ -1683,7 +1728,7 @@ template <int NW, int RG>
 __global__ void __launch_bounds__(256, DSACT_BQT_OCC) k_chain_bwd_qt(BwdQtArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b = (int)blockIdx.x;
-  if (b < a.q.n_chain_blocks) { bwd_q_body<NW, RG, true>(a.q, b, lds); return; }
+  if (b < a.q.n_chain_blocks) { bwd_q_body<NW, RG, true, BwdQArgsN<4> >(a.q, b, lds); return; }
   int idx = b - a.q.n_chain_blocks;
   if (idx < a.n_riders) { loss_rider(a.q.ride); return; }
   idx -= a.n_riders;
@@ -1721,6 +1766,85 @@ __global__ void __launch_bounds__(256, DSACT_BQT_OCC) k_chain_bwd_qt(BwdQtArgs a
     if (lane == 0) {
       a.grad_log_alpha[0] = a.q.auto_alpha ? -(s * a.q.inv_B + a.target_entropy) : 0.0f;
       if (a.finalize) finalize_update(a.dw.fo);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_chain_bwd_qpt (round 5): the WHOLE backward of an update that moves the policy (iteration % delay_update == 0) in the
+// pipelined graph as ONE launch -- critics' backward chains -> (dL/d new_act as tagged pairs) -> policy backward chain ->
+// the policy's weight-gradient / Adam / Polyak tiles; the critics' tiles wait for the critics' own chains (as in
+// k_chain_bwd_qt) and run while the policy chain works; one block closes the update. Replaces chain_bwd_q (12.6 us) +
+// chain_bwd_pi (22.5 us): the policy chain's slices are resident from the start with their weight stream, gelu' packs and
+// row-phase inputs in flight, so the kernel boundary, the dispatch ramp and their ~3.4 us of start-up leave the dependent
+// chain forward -> dL/da -> policy backward -> policy Adam -> next forward. Blocks: [critic chain slices] [policy chain
+// slices] [riders: gather of minibatch s + 2] [critics' tiles (table)] [policy tiles] [closing block]; every wait targets
+// blocks with lower ids. Bookkeeping and the reset of the three arrival counters ride in this update's forward launch.
+// ---------------------------------------------------------------------------------------------------------------
+struct BwdQpArgs {
+  BwdQArgsN<4> q;
+  BwdPiArgs pi;                                // pi.dw: the problem list of ALL weight-gradient tiles of the launch
+  const int* tile_tab; int n_tile_blocks;      // the critics' tiles (k_chain_bwd_qt's table)
+  int n_riders;
+  int need_c;                                  // slices of one critic chain
+  int* spin_timeout;
+  const float* logp_new; int n_part; float target_entropy; float* grad_log_alpha; int finalize;
+};
+static_assert(sizeof(BwdQpArgs) <= 4096, "kernel arguments are limited to 4 KB");
+
+template <int NW, int RGQ, int RGP>
+__global__ void __launch_bounds__(256, DSACT_BQT_OCC) k_chain_bwd_qpt(BwdQpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int idx = (int)blockIdx.x;
+  if (idx < a.q.n_chain_blocks) { bwd_q_body<NW, RGQ, true, BwdQArgsN<4> >(a.q, idx, lds); return; }
+  idx -= a.q.n_chain_blocks;
+  if (idx < a.pi.n_chain_blocks) { bwd_pi_body<NW, RGP>(a.pi, idx, lds); return; }
+  idx -= a.pi.n_chain_blocks;
+  if (idx < a.n_riders) { loss_rider(a.q.ride); return; }
+  idx -= a.n_riders;
+  const int L = a.q.L;
+  const int n_pol_blocks = xcd_chunk_grid(a.pi.n_pi_tiles);
+  if (idx < a.n_tile_blocks + n_pol_blocks) {
+    // ONE call site of dw2_tile for both tile kinds (two inlined copies made hipcc keep the whole kernel-argument struct in
+    // scratch: 3.7 KB per lane): the critics' tiles come through the table and wait for their critic's chain, the policy's
+    // through xcd_chunk and wait for the policy chain
+    int t;
+    const int* cnt;
+    int need;
+    if (idx < a.n_tile_blocks) {
+      t = ((const __attribute__((address_space(4))) int*)(unsigned long long)a.tile_tab)[idx];
+      if (t < 0) return;
+      int pi = 0;
+#pragma unroll
+      for (int q = 0; q + 1 < kMaxDwProb; ++q)
+        if (q + 1 < a.pi.dw.n_prob && t >= a.pi.dw.tile_ends[q]) pi = q + 1;
+      cnt = a.q.arrive + (pi / (L + 1)) * 8 * kArriveStride;
+      need = a.need_c;
+    } else {
+      if (!xcd_chunk(idx - a.n_tile_blocks, a.pi.n_pi_tiles, t)) return;
+      t += a.pi.pi_tile0;
+      cnt = a.pi.cnt_pi;
+      need = a.pi.n_slices;
+    }
+    dw2_tile<2, ArriveWait>(a.pi.dw, t, lds, ArriveWait{cnt, need, a.spin_timeout});
+    return;
+  }
+  // closing block: the policy chain's slices read log_alpha when they start (this block's Adam step on it must not overtake
+  // them) and the critics' chains wrote the mean_std tail
+  ArriveWait{a.pi.cnt_pi, a.pi.n_slices, a.spin_timeout}();
+  ArriveWait{a.q.arrive, a.need_c, a.spin_timeout}();
+  ArriveWait{a.q.arrive + 8 * kArriveStride, a.need_c, a.spin_timeout}();
+  if (threadIdx.x < 64) {
+    const int lane = (int)threadIdx.x;
+    float s = 0.f;
+    for (int r0 = 0; r0 < a.n_part; r0 += 64) {
+      const int rr = r0 + lane;
+      s += rr < a.n_part ? a.logp_new[rr] : 0.f;
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+      a.grad_log_alpha[0] = a.q.auto_alpha ? -(s * a.q.inv_B + a.target_entropy) : 0.0f;
+      if (a.finalize) finalize_update(a.pi.dw.fo);
     }
   }
 }

@@ -211,6 +211,9 @@ struct DevState {
   int pad;
   // beta1^t, beta2^t per optimiser as running products (double): device pow() is ~1 us per call
   double b1p_q, b2p_q, b1p_pi, b2p_pi, b1p_alpha, b2p_alpha;
+  long long tag_seq;   // closed updates since the handle was created, NEVER reset: the (value, tag) hand-overs tag with its low
+                       // word + 1 (seq_next restarts at 0 with every dsact_run_group: a tag derived from it would match the
+                       // pairs a previous group left in the buffers)
 };
 
 // opt-in phase timeline (build with -DDSACT_TIMELINE): shader-clock stamps of selected blocks
@@ -1122,6 +1125,7 @@ __device__ __forceinline__ void finalize_update_s(DevState* stp, float* online, 
   stp->ms1 = grads[n_total]; stp->ms2 = grads[n_total + 1]; stp->ms_init = 1;
   stp->it_next = it_cur + 1;
   stp->seq_next = seq + 1;
+  stp->tag_seq += 1;
 }
 __device__ __forceinline__ void finalize_update(const FusedOpt& fo) {
   finalize_update_s(fo.st, fo.online, fo.adam_m, fo.adam_v, fo.grads, fo.n_total, fo.auto_alpha, fo.b1w, fo.beta2, fo.b2w, fo.eps);
@@ -1882,6 +1886,7 @@ __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
     if (a.commit_ms) { a.st->ms1 = a.g[a.n_total]; a.st->ms2 = a.g[a.n_total + 1]; a.st->ms_init = 1; }
     a.st->it_next = st.it_cur + 1;
     a.st->seq_next = st.seq_next + 1;
+    a.st->tag_seq = st.tag_seq + 1;
   }
 }
 

@@ -722,6 +722,8 @@ PIPE_BUFFERS = ("logits_pi", "logp_new", "logp2", "qout_t0", "qout_t1", "qout_p0
     (16, 4, (64, 64), 64, 2, 4, 1, 8, {"DSACT_NO_PIPE_DEFER": "1"}),      # the discarded policy backward stays in its own update
     (16, 4, (64, 64), 64, 2, 4, 1, 8, {"DSACT_NO_BQT_MERGE": "1"}),       # critics' backward and their tiles as two launches (round 4's form)
     (376, 17, (256, 256, 256), 256, 2, 8, 1, 16, {"DSACT_NO_BQT_MERGE": "1"}),
+    (16, 4, (64, 64), 64, 2, 4, 0, 8, {"DSACT_NO_BQP_MERGE": "1"}),       # policy-moving updates: critics' and policy backward as two launches
+    (24, 6, (128, 128, 128), 32, 3, 6, 2, 12, {"DSACT_NO_BQP_MERGE": "1"}),
     (32, 8, (256, 256), 48, 2, 5, 1, 10, {"DSACT_PIPE_QT": "1", "DSACT_PIPE_QP_SPLIT": "1"}),
     (376, 17, (256, 256, 256), 256, 2, 8, 1, 16, {}),  # the BASELINE.json shape
     (376, 17, (256, 256, 256), 256, 2, 6, 4, 12, {"DSACT_PIPE_MAP": "FT.pit=23:1;FT.q1t=01;TF.q1c=0123:2"}),
@@ -757,6 +759,7 @@ def test_pipelined_graph_equals_eager_steps(O, A, hid, B, D, per_graph, first, t
             if D >= 2:
                 assert "chain_fwd+next" in names and "chain_fwd_q" in names, names
                 assert ("chain_bwd_qt" in names) == ("DSACT_NO_BQT_MERGE" not in env and "DSACT_NO_PIPE_DEFER" not in env), names
+                assert ("chain_bwd_qpt" in names) == ("DSACT_NO_BQT_MERGE" not in env and "DSACT_NO_BQP_MERGE" not in env), names
         else:
             assert e.time_steps(first, total, use_graph=False) > 0
         e.sync()
