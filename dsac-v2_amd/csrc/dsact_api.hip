@@ -325,6 +325,7 @@ struct dsact_handle {
   bool bqt_now = false;                 // set while such an update is being enqueued
   // k_chain_bwd_qpt: the whole backward of a policy-moving update of the pipelined graph as one launch
   unsigned long long* bqp_pairs[2] = {nullptr, nullptr};   // dL/d new_act through q1 / q2 as (value, tag) pairs [B][32]
+  int env_bqp_rg_pi = 0;                // DSACT_BQP_RG_PI=1|2: rows / 4 per policy-chain workgroup inside k_chain_bwd_qpt (0: the policy backward's own choice)
   bool env_no_bqp = false;              // DSACT_NO_BQP_MERGE: critics' backward and policy backward stay two launches on those updates (A/B)
   bool bqp_now = false;
   bool pipe_graph = false;              // the captured graphs are the pipelined ones (pgraph / pexec, one per phase)
@@ -2601,12 +2602,13 @@ int enqueue_chain_bwd_qpt(dsact_handle* h, bool fused, const RideArgs* ride) {
   a.q.tagp = &h->st->tag_seq;
   for (int w = 0; w < 4; ++w)
     if (a.q.u[w].which >= 2) a.q.u[w].dA_pairs = h->bqp_pairs[a.q.u[w].which - 2];
-  bwd_pi_args(h, h->dw2_off[0], h->dw2_off[2], fused, a.pi, rg_pi, true);
+  bwd_pi_args(h, h->dw2_off[0], h->dw2_off[2], fused, a.pi, rg_pi, true, h->env_bqp_rg_pi);
   a.pi.cnt_pi = h->bqt_cnt + 2 * 8 * kArriveStride;    // (its own counter: the forward launch's deferred chain uses the flags' one)
   a.pi.per_layer = 0;
   a.pi.dA_pairs[0] = h->bqp_pairs[0]; a.pi.dA_pairs[1] = h->bqp_pairs[1];
   a.pi.tagp = &h->st->tag_seq;
-  a.pi.timeline = nullptr;
+  a.q.timeline = tl_for(h, "chain_bwd_qpt");
+  a.pi.timeline = a.q.timeline;
   a.q.ride.n_loss_blocks = a.q.n_chain_blocks + a.pi.n_chain_blocks;   // loss_rider numbers its blocks from the first rider
   a.tile_tab = h->bqt_tab; a.n_tile_blocks = h->bqt_tab_blocks;
   a.n_riders = n_riders;
@@ -2620,7 +2622,12 @@ int enqueue_chain_bwd_qpt(dsact_handle* h, bool fused, const RideArgs* ride) {
   if (lp > lds) lds = lp;
   if (lds < kDw2LdsFloats * sizeof(float)) lds = kDw2LdsFloats * sizeof(float);
   const int grid = a.q.n_chain_blocks + a.pi.n_chain_blocks + n_riders + a.n_tile_blocks + xcd_chunk_grid(a.pi.n_pi_tiles) + 1;
-  if (rg_q != 1 || rg_pi != 2) return fail(h, DSACT_E_STATE, "k_chain_bwd_qpt expects 4-row critic slices and 8-row policy slices");
+  if (rg_q != 1 || (rg_pi != 2 && rg_pi != 1)) return fail(h, DSACT_E_STATE, "k_chain_bwd_qpt expects 4-row critic slices and 4- or 8-row policy slices");
+  if (rg_pi == 1) {
+    if (h->cNT == 1) return launch(h, "chain_bwd_qpt", k_chain_bwd_qpt<1, 1, 1>, dim3(grid), dim3(kThreads), lds, a);
+    if (h->cNT == 2) return launch(h, "chain_bwd_qpt", k_chain_bwd_qpt<2, 1, 1>, dim3(grid), dim3(kThreads), lds, a);
+    return launch(h, "chain_bwd_qpt", k_chain_bwd_qpt<4, 1, 1>, dim3(grid), dim3(kThreads), lds, a);
+  }
   if (h->cNT == 1) return launch(h, "chain_bwd_qpt", k_chain_bwd_qpt<1, 1, 2>, dim3(grid), dim3(kThreads), lds, a);
   if (h->cNT == 2) return launch(h, "chain_bwd_qpt", k_chain_bwd_qpt<2, 1, 2>, dim3(grid), dim3(kThreads), lds, a);
   return launch(h, "chain_bwd_qpt", k_chain_bwd_qpt<4, 1, 2>, dim3(grid), dim3(kThreads), lds, a);
@@ -2650,9 +2657,9 @@ int enqueue_grads_chain(dsact_handle* h, bool actor_backward, bool fused, int ph
   }
   if (phase == 1) return DSACT_OK;
   // pipelined graph, update whose policy backward rides in the next forward launch: critics' backward + their tiles + close
-  if (h->bqt_now && h->pipe_defer_now && actor_backward && fused && phase == 2) return enqueue_chain_bwd_qt(h, fused, ride);
+  if (h->bqt_now && h->pipe_defer_now && actor_backward && phase == 2) return enqueue_chain_bwd_qt(h, fused, ride);
   // ... update that moves the policy: the whole backward as one launch
-  if (h->bqp_now && !h->pipe_defer_now && actor_backward && fused && phase == 2) return enqueue_chain_bwd_qpt(h, fused, ride);
+  if (h->bqp_now && !h->pipe_defer_now && actor_backward && phase == 2) return enqueue_chain_bwd_qpt(h, fused, ride);
   TRY(enqueue_chain_bwd_q(h, (actor_backward ? 2 : 1) * h->nq, ride));
   // CNN nets (batch <= 1024: one gradient arena): dL/d features = dZ0 . W0[:, :F] right behind the chains that produce dZ0 and
   // before the launch whose tiles update W0; the conv stacks' backward follows the MLP part (enqueue_grads' order)
@@ -3216,6 +3223,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->env_no_pipe_defer = getenv("DSACT_NO_PIPE_DEFER") != nullptr;
   h->env_no_bqt = getenv("DSACT_NO_BQT_MERGE") != nullptr;
   h->env_no_bqp = getenv("DSACT_NO_BQP_MERGE") != nullptr;
+  if (const char* v = getenv("DSACT_BQP_RG_PI")) h->env_bqp_rg_pi = atoi(v) == 1 ? 1 : atoi(v) == 2 ? 2 : 0;
   h->env_pi_layers = getenv("DSACT_PI_LAYERS") != nullptr;
   h->env_no_pipe_warm = getenv("DSACT_PIPE_WARM") == nullptr;
   h->env_no_pipe_tagged = getenv("DSACT_NO_PIPE_TAGGED") != nullptr;
@@ -4027,7 +4035,7 @@ static int plan_updates_pipe(dsact_handle* h, int n, int phase, PipePlan& plan, 
   plan.leaves.assign((size_t)n, 0);
   plan.bqt.assign((size_t)n, 0);
   plan.bqp.assign((size_t)n, 0);
-  const bool bqt = bqt_ok(h) && !plan.dp;
+  const bool bqt = bqt_ok(h);   // (data-parallel graphs too: the tiles then store gradients and the closing block closes nothing)
   // (4-row critic slices, 8-row policy slices: the instantiation k_chain_bwd_qpt is built for)
   const bool bqp = bqt && h->nq == 2 && !h->env_no_bqp && chain_rg(h, 4, true) == 1 && rg_pi == 2;
   if (bqt) TRY(build_bqt(h));
@@ -4107,8 +4115,12 @@ static int enqueue_updates_pipe(dsact_handle* h, int n, const PipePlan& plan, Pi
     ride.bookkeeping = (plan.bqt[(size_t)s] || plan.bqp[(size_t)s]) ? 0 : 1;   // (merged backward launches: the forward launch did the bookkeeping)
     if (plan.dp) {
       h->pipe_defer_now = plan.defer[(size_t)s] != 0;
+      h->bqt_now = plan.bqt[(size_t)s] != 0;
+      h->bqp_now = plan.bqp[(size_t)s] != 0;
       rc = enqueue_grads(h, true, false, 2, &ride);
       h->pipe_defer_now = false;
+      h->bqt_now = false;
+      h->bqp_now = false;
       if (rc == DSACT_OK) rc = enqueue_allreduce(h, h->grads, h->n_online + 2, kNcclAvg);
       if (rc == DSACT_OK) rc = h->env_no_adam_pack ? enqueue_adam(h) : enqueue_adam_pack(h);
       if (rc == DSACT_OK && h->env_no_adam_pack) rc = enqueue_pack(h, true);

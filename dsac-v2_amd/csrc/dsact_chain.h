@@ -1798,7 +1798,7 @@ __global__ void __launch_bounds__(256, DSACT_BQT_OCC) k_chain_bwd_qpt(BwdQpArgs 
   int idx = (int)blockIdx.x;
   if (idx < a.q.n_chain_blocks) { bwd_q_body<NW, RGQ, true, BwdQArgsN<4> >(a.q, idx, lds); return; }
   idx -= a.q.n_chain_blocks;
-  if (idx < a.pi.n_chain_blocks) { bwd_pi_body<NW, RGP>(a.pi, idx, lds); return; }
+  if (idx < a.pi.n_chain_blocks) { CTLV(a.pi.timeline, 11, 5); bwd_pi_body<NW, RGP>(a.pi, idx, lds); return; }
   idx -= a.pi.n_chain_blocks;
   if (idx < a.n_riders) { loss_rider(a.q.ride); return; }
   idx -= a.n_riders;
@@ -1820,13 +1820,17 @@ __global__ void __launch_bounds__(256, DSACT_BQT_OCC) k_chain_bwd_qpt(BwdQpArgs 
         if (q + 1 < a.pi.dw.n_prob && t >= a.pi.dw.tile_ends[q]) pi = q + 1;
       cnt = a.q.arrive + (pi / (L + 1)) * 8 * kArriveStride;
       need = a.need_c;
+      CTLV(a.q.timeline, 11, 10);      // critics' tile
     } else {
       if (!xcd_chunk(idx - a.n_tile_blocks, a.pi.n_pi_tiles, t)) return;
       t += a.pi.pi_tile0;
       cnt = a.pi.cnt_pi;
       need = a.pi.n_slices;
+      CTLV(a.q.timeline, 11, 11);      // policy tile
     }
-    dw2_tile<2, ArriveWait>(a.pi.dw, t, lds, ArriveWait{cnt, need, a.spin_timeout});
+    CTLR(a.q.timeline, 14);
+    dw2_tile<2, ArriveWait>(a.pi.dw, t, lds, ArriveWait{cnt, need, a.spin_timeout, a.q.timeline});
+    CTLR(a.q.timeline, 15);
     return;
   }
   // closing block: the policy chain's slices read log_alpha when they start (this block's Adam step on it must not overtake

@@ -1,15 +1,15 @@
 #!/bin/bash
-# instrumented build (-DDSACT_TIMELINE): chip-wide stamps of the merged critic-backward launch k_chain_bwd_qt, grouped by role
-# usage: gpurun -- 'bash scripts/gpu_r5_timeline_bqt.sh'   (env switches pass through)
+# instrumented build (-DDSACT_TIMELINE): chip-wide stamps of the merged critic-backward launch k_chain_bwd_qpt, grouped by role
+# usage: gpurun -- 'bash scripts/gpu_r5_timeline_bqpt.sh'   (env switches pass through)
 set -u
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
-OUTF=$PWD/gpurun_out/r5_timeline_bqt.txt
+OUTF=$PWD/gpurun_out/r5_timeline_bqpt.txt
 mkdir -p gpurun_out /tmp/tl
 cp -r dsac-v2_amd include oracle tests __graft_entry__.py /tmp/tl/
 cd /tmp/tl
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value -DDSACT_TIMELINE -shared -fPIC -o dsac-v2_amd/lib/libdsact.so dsac-v2_amd/csrc/dsact_api.hip || exit 1
-DSACT_TIMELINE_STAGE=chain_bwd_qt python - <<'PY' 2>&1 | grep -v amdgpu.ids | tee $OUTF
+DSACT_TIMELINE_STAGE=chain_bwd_qpt python - <<'PY' 2>&1 | grep -v amdgpu.ids | tee $OUTF
 import sys, os
 sys.path[:0] = ['/tmp/tl', '/tmp/tl/dsac-v2_amd', '/tmp/tl/tests']
 import numpy as np, torch
@@ -33,9 +33,9 @@ e.sync()
 full = e.debug_read("timeline").view(np.int64).reshape(1024, 16)
 ok = (full[:,14] != 0) & (full[:,15] != 0)
 rt = full[ok]
-print("chain_bwd_qt: %d workgroups stamped" % len(rt))
+print("chain_bwd_qpt: %d workgroups stamped" % len(rt))
 t00 = rt[(rt[:,11] >= 1) & (rt[:,11] <= 4)][:,14].min()   # launch start = first critic chain slice
-names = {1: "q1c", 2: "q2c", 3: "q1p", 4: "q2p", 10: "tiles L0", 11: "tiles L1", 12: "tiles L2+out"}
+names = {1: "q1c", 2: "q2c", 3: "q1p", 4: "q2p", 5: "pi chain", 10: "critic tiles", 11: "policy tiles"}
 for u in sorted(set(int(v) for v in rt[:,11])):
     gq = rt[rt[:,11] == u]
     b, en = (gq[:,14]-t00)/100.0, (gq[:,15]-t00)/100.0
