@@ -191,12 +191,12 @@ def bench_cnn(device, steps, warmup, batch=B, cpu=True):
     # memory-side bytes per update from the committed PMC passes of this workload (2 * FETCH_SIZE + WRITE_SIZE per launch x launches
     # per update, summed over kernels; scripts/gpu_final.sh) -- NOT measured in this run
     try:
-        path = os.path.join(ROOT, "profiles", "r04_pmc_traffic_cnn.json")
+        path = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_traffic_cnn.json", "r04_pmc_traffic_cnn.json")) if os.path.exists(q)), "")
         per = json.load(open(path))["cnn"]
         n_upd = max(v["launches"] for k, v in per.items() if "k_gather_img" in k)
         tot = sum((2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024 * v["launches"] / n_upd for v in per.values())
         out["roofline_hbm"]["traffic"] = tot
-        out["roofline_hbm"]["traffic_source"] = "profiles/r04_pmc_traffic_cnn.json (committed rocprofv3 --pmc passes at batch 256; not measured in this run)"
+        out["roofline_hbm"]["traffic_source"] = "profiles/%s (committed rocprofv3 --pmc passes at batch 256; not measured in this run)" % os.path.basename(path)
     except Exception:
         out["roofline_hbm"]["traffic"] = None
     if cpu:

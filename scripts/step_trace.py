@@ -32,8 +32,8 @@ def main():
         cur.append(r)
         nxt = rows[i + 1][2] if i + 1 < len(rows) else ""
         closes = "k_stage_table(" in r[2] or "k_adam(" in r[2] or \
-            (("k_dw2<" in r[2] or "k_chain_bwd_pi<" in r[2]) and "k_adam(" not in nxt and "k_sum_parts(" not in nxt
-             and "k_dw2<" not in nxt and "AllReduce" not in nxt)
+            (("k_dw2<" in r[2] or "k_chain_bwd_pi<" in r[2] or "k_chain_bwd_qt<" in r[2] or "k_chain_bwd_qpt<" in r[2])
+             and "k_adam(" not in nxt and "k_sum_parts(" not in nxt and "k_dw2<" not in nxt and "AllReduce" not in nxt)
         if close_on:
             closes = any(c in r[2] for c in close_on)
         if closes:
