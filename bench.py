@@ -453,8 +453,17 @@ def e2e_gpu_grouped(hidden, device, interval=8, iters=1600, warm=160):
         trainer = plugin.create_trainer(alg, sampler, buf, None, **kw)
         trainer._grouping = True          # what train() sets: step() alone keeps one update per call
         w, ws = _timed_loop(trainer, sampler, warm, iters, alg.engine.sync)
+        # the sampler ALONE (device idle when it starts): inside the loop its first acting forward queues behind the updates
+        # in flight, so the loop's sampler time contains their device time
+        alg.engine.sync()
+        t0 = time.perf_counter()
+        for _ in range(40):
+            sampler.sample()
+        s_only = (time.perf_counter() - t0) / 40
         r = {"value": iters / w, "unit": "iterations/s", "ms_per_iteration": 1000.0 * w / iters,
-             "sampler_ms_per_iteration": 1000.0 * ws / iters, "update_us_through_local_update": 1e6 * (w - ws) / iters}
+             "sampler_ms_per_iteration": 1000.0 * ws / iters, "sampler_alone_ms_per_call": 1000.0 * s_only,
+             "update_us_through_the_surface": 1e6 * (w / iters - s_only / interval),
+             "host_us_per_update": 1e6 * (w - ws) / iters}
         if grouped:
             try:
                 r["pipelined_graph"] = alg.engine.debug_get("pipe_graph") == 1.0
@@ -466,8 +475,11 @@ def e2e_gpu_grouped(hidden, device, interval=8, iters=1600, warm=160):
         del trainer, buf, sampler, alg
     out.update({"sample_interval": interval, "iterations": iters,
                 "note": "HipOffSerialTrainer with sample_interval = %d: per %d iterations one sampler call (20 env steps) and ONE graph "
-                        "replay of %d updates; update_us_through_local_update = (iteration time - sampler time): what an update costs "
-                        "through sample_batches + local_update_group, host work included" % (interval, interval, interval)})
+                        "replay of %d updates; update_us_through_the_surface = iteration time - (sampler call alone) / %d: what an update "
+                        "costs through sample_batches + local_update_group with everything the loop adds (host enqueue, the acting "
+                        "forward waiting for the updates in flight); host_us_per_update = iteration time - sampler time inside the loop "
+                        "(host work only: the device time of the updates shows up in the sampler's first acting forward)"
+                        % (interval, interval, interval, interval)})
     return out
 
 

@@ -18,7 +18,7 @@ try:
     d = json.loads(sys.stdin.read())
     print('   value %.0f  us %.2f  kernels %s' % (d['value'], 1000 * d['ms_per_step'], ' '.join('%s=%.2f' % (k['name'], k['us']) for k in d.get('kernels', []))))
     for k in ('fast', 'e2e'):
-        if k in d: print('   %s %s' % (k, json.dumps({a: b for a, b in d[k].items() if a in ('value', 'ms_per_step', 'ms_per_iteration', 'sampler_ms_per_iteration', 'update_us_through_local_update', 'groups')})))
+        if k in d: print('   %s %s' % (k, json.dumps({a: b for a, b in d[k].items() if a in ('value', 'ms_per_step', 'ms_per_iteration', 'sampler_ms_per_iteration', 'update_us_through_the_surface', 'groups')})))
 except Exception as e:
     print('   parse error', e)
 "; }
