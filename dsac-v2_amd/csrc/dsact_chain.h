@@ -361,13 +361,48 @@ __device__ __forceinline__ void dw2_tile(const Dw2Args& a, int t, float* lds, Wa
       }
     }
   };
-  for (int hr = 0; hr < n_half; hr += NSET) {
+  // Long contractions (batch >= 512 per range): every half round but the last NSET belongs to a FULL round (each wave has
+  // its chunks), so the streaming part runs without a branch -- MFMAs of a set, then its refill, in a fixed order, the
+  // first trip peeled: hipcc derives its s_waitcnt counts from the request order it can see on a loop's entry and back
+  // edges, and the round-4 form (refill under `if`, per-chunk `if` around the MFMAs) got `vmcnt(0)` before every half --
+  // each half waited for the refill requested just before it (one L2 round trip per 32 MFMAs). The last NSET halves (all
+  // of a batch <= 256 contraction) keep the wave-uniform checks of a ragged round. Same accumulation order.
+  auto mma_half_full = [&](int set) {
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int bm = 0; bm < 2; ++bm)
+#pragma unroll
+          for (int bn = 0; bn < 2; ++bn)
+            acc[bm][bn] = __builtin_amdgcn_mfma_f32_16x16x4f32(fx[set][q2][bn][e], fa[set][q2][bm][e], acc[bm][bn], 0, 0, 0);
+#pragma unroll
+      for (int bm = 0; bm < 2; ++bm)
+        sb[bm] += (fa[set][q2][bm][0] + fa[set][q2][bm][1]) + (fa[set][q2][bm][2] + fa[set][q2][bm][3]);
+    }
+  };
+  auto stream_trip = [&](int hr) {
+#pragma unroll
+    for (int st = 0; st < NSET; ++st) {
+      mma_half_full(st);
+      const int nx = hr + st + NSET;
+      load_half(st, nx < n_half ? nx : n_half - 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto last_halves = [&](int hr) {
 #pragma unroll
     for (int st = 0; st < NSET; ++st)
-      if (hr + st < n_half) {
-        mma_half(st, hr + st);
-        if (hr + st + NSET < n_half) load_half(st, hr + st + NSET);
-      }
+      if (hr + st < n_half) mma_half(st, hr + st);
+  };
+  if (NSET < n_half) {
+    stream_trip(0);
+    int hr = NSET;
+    for (; hr + NSET < n_half; hr += NSET) stream_trip(hr);
+    last_halves(hr);
+  } else {
+    last_halves(0);
   }
   // ---- partial blocks -> LDS -> block `wave`
   const bool bias = nt == 0 && P.b_idx >= 0;

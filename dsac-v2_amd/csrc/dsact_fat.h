@@ -198,6 +198,9 @@ __device__ __forceinline__ void fat_fwd_body(const FwdArgs& a, int unit, int sli
   const int c_obs = a.s_obs, c_act = u.s_act, C0 = c_obs + c_act;
   const bool do_obs = u.seg != SEG_ACT_FROM_SAVED;
   const bool do_act = u.seg != SEG_OBS_ONLY && c_act > 0;
+  CTL(a.timeline, 0);   // (instrumented builds: scripts/gpu_r5_timeline_fat.sh)
+  CTLR(a.timeline, 14);
+  CTLV(a.timeline, 11, 1 + unit);
   int nf[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) nf[nt] = 64 * wave + 16 * nt + i;   // this lane's output features
@@ -245,6 +248,7 @@ __device__ __forceinline__ void fat_fwd_body(const FwdArgs& a, int unit, int sli
       nt_store4(u.x0t + pk_index(k, row0 + 4 * q4, a.Cb), v);
     }
   }
+  CTL(a.timeline, 1);
   // ---- first layer
   FatX X;
   X.p = u.x + (size_t)(row0 + i) * a.ldx + 4 * g; X.rt_stride = (size_t)16 * a.ldx;
@@ -260,9 +264,11 @@ __device__ __forceinline__ void fat_fwd_body(const FwdArgs& a, int unit, int sli
 #pragma unroll
           for (int r = 0; r < 4; ++r) u.zsave[(size_t)(row0 + 16 * rt + 4 * g + r) * W + nf[nt]] = acc[rt][nt][r];
     }
-    if (u.seg == SEG_OBS_ONLY) return;
+    CTL(a.timeline, 2);
+    if (u.seg == SEG_OBS_ONLY) { CTLR(a.timeline, 15); return; }
   }
   if (do_act) fat_gemm_x<RT>(acc, w0, C0, c_obs, C0, X, lane4);
+  CTL(a.timeline, 3);
   // ---- epilogues + hidden layers (the slice's activations live in ONE LDS buffer, overwritten in place)
   NarrowFrags<4> hf;
   const int nto = u.head == HEAD_POLICY ? (2 * A + 15) >> 4 : 1;
@@ -288,6 +294,7 @@ __device__ __forceinline__ void fat_fwd_body(const FwdArgs& a, int unit, int sli
 #pragma unroll
         for (int r = 0; r < 4; ++r) lds[S.off_h + (16 * rt + 4 * g + r) * S.ldh + nf[nt]] = acc[rt][nt][r];
     lds_barrier();
+    CTL(a.timeline, 4 + 2 * l);
     if (l + 1 < L) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) bl[nt] = u.bias[l + 1][nf[nt]];
@@ -296,6 +303,7 @@ __device__ __forceinline__ void fat_fwd_body(const FwdArgs& a, int unit, int sli
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[rt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
       fat_gemm_lds<RT>(acc, u.wf[l + 1] + (size_t)(4 * wave) * CW * 256, CW, 0, CW, lds, xs_h, S.ldh, lane4);
+      CTL(a.timeline, 5 + 2 * l);
     }
   }
   if (u.head == HEAD_NONE) return;
@@ -307,6 +315,7 @@ __device__ __forceinline__ void fat_fwd_body(const FwdArgs& a, int unit, int sli
     fat_narrow_store<4, RT, NW>(part, nto, wave, lds, S.off_h, lane);
     lds_barrier();
   }
+  CTL(a.timeline, 12);
   const int red = S.off_h;
   const int m = mr, j = jr;                    // row phase: TPR consecutive lanes per batch row
   const int r = row0 + m;
@@ -317,6 +326,8 @@ __device__ __forceinline__ void fat_fwd_body(const FwdArgs& a, int unit, int sli
       u.qout[2 * r] = mean; u.qout[2 * r + 1] = raw;
       if (u.qstd) { u.qstd[2 * r] = softplus(raw); u.qstd[2 * r + 1] = softplus_grad(raw); }
     }
+    CTL(a.timeline, 13);
+    CTLR(a.timeline, 15);
     return;
   }
   // policy: (mu, raw log-std) -> tanh-Gaussian rsample (act_distribution_cls.py:44-54)
@@ -353,6 +364,8 @@ __device__ __forceinline__ void fat_fwd_body(const FwdArgs& a, int unit, int sli
       u.part_heads[2 * slice + 1] = t1;
     }
   }
+  CTL(a.timeline, 13);
+  CTLR(a.timeline, 15);
 }
 
 // blocks are unit-major (block = unit * n_slices + slice): the chip works on one or two units at a time, whose weights
