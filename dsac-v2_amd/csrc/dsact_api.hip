@@ -1008,6 +1008,7 @@ int build_tasks(dsact_handle* h) {
         if (l < L || nb == 1) { t.C0 = g + d.w_off[l] + (size_t)b * hb * kb; t.ldc = kb; }
         else { t.C0 = g + d.w_off[l] + (size_t)b * hb * d.in[l] + (size_t)b * kb; t.ldc = d.in[l]; }  // [[w_mean,0],[0,w_ls]]
         if (h->d_mir) t.mir = h->d_mir + (size_t)(which - 1) * (L + 1) + l;   // chain mode: packed copies of this tensor
+        if (ch == C_PI && l == L && h->cfg.policy_std_param) t.mzero = h->A;   // (see DwProb::msplit for the chain path's tiles)
         add_tiles(t);
       }
       // bias: Q = ones
@@ -1619,6 +1620,9 @@ Dw2Args dw2_args(dsact_handle* h, bool fused) {
       tiles += ((P.M + 31) / 32) * P.tiles_n;
       P.tile_end = tiles;
       P.mir = h->d_mir ? h->d_mir + (size_t)n3 * (L + 1) + l : nullptr;
+      // policy_std_type "parameter": rows [A, 2A) of the policy's output layer are structurally zero -- their gradient is
+      // masked (every column: nsplit = N), so Adam / Polyak leave them at 0; the bias rows [A, 2A) are log_std (not masked)
+      if (n3 == 2 && l == L && h->cfg.policy_std_param) { P.msplit = h->A; P.nsplit = P.N; }
     }
   }
   if (h->twin) {
@@ -3141,6 +3145,9 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (cfg->value_act < 0 || cfg->value_act > ACT_TANH || cfg->policy_act < 0 || cfg->policy_act > ACT_TANH)
     return fail(h, DSACT_E_INVALID, "hidden activation must be 0..5 (gelu, relu, elu, selu, sigmoid, tanh)");
   if (cfg->act_dist != 0 && cfg->act_dist != 1) return fail(h, DSACT_E_INVALID, "act_dist must be 0 (TanhGaussDistribution) or 1 (GaussDistribution)");
+  if (cfg->policy_std_param != 0 && cfg->policy_std_param != 1) return fail(h, DSACT_E_INVALID, "policy_std_param must be 0 (mlp_shared) or 1 (parameter)");
+  if (cfg->policy_std_param && (cfg->conv_type != DSACT_CONV_NONE || cfg->algo != 0))
+    return fail(h, DSACT_E_INVALID, "policy_std_type 'parameter' is built for DSAC_V2 with MLP nets");
   if (h->cfg.global_batch < h->cfg.batch) h->cfg.global_batch = h->cfg.batch;
   HIPCHK(h, hipSetDevice(device));
   h->O = cfg->obs_dim; h->A = cfg->act_dim; h->L = cfg->n_hidden; h->B = cfg->batch;

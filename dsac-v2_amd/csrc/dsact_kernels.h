@@ -690,6 +690,8 @@ struct GemmProb {
   int tile_end;         // exclusive end of this problem's block range inside its stage
   const MirrorDesc* mir;  // weight-gradient tiles with the fused optimiser: packed copies of the tensor to refresh (or nullptr)
   int act;                // EPI_GELU stages: hidden activation of this problem's net (ACT_*, dsact_math.h)
+  int mzero;              // EPI_STORE: rows m >= mzero > 0 are structurally zero (policy_std_type "parameter": the log-std half of
+                          // the policy's output-layer weight) -- their gradient is stored as 0, so the optimiser leaves them at 0
 };
 
 // Optimiser fused into the weight-gradient tiles (single-GPU path): every parameter element is the
@@ -872,7 +874,7 @@ __device__ __forceinline__ void run_tile(const GemmProb& t, int m0, int n0, floa
     }
   }
 #undef DSACT_LOAD_TILE
-  const f32x4 acc = acc0 + acc1;
+  f32x4 acc = acc0 + acc1;
   TL_STAMP();  // 3: MFMA loop done
   if (!in_range) { TL_FLUSH(tl_buf, tl_slot); return; }
   if (EPI == EPI_GELU) {
@@ -893,6 +895,7 @@ __device__ __forceinline__ void run_tile(const GemmProb& t, int m0, int n0, floa
     }
   } else {
     float* c0 = t.C0 + (size_t)m * t.ldc + n;
+    if (t.mzero > 0 && m >= t.mzero) acc = f32x4{0.f, 0.f, 0.f, 0.f};
     if (full) *(f32x4u*)c0 = acc;
     else for (int e = 0; e < 4 && n + e < t.N; ++e) c0[e] = acc[e];
     if (fused && o_upd) {

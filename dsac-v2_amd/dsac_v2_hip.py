@@ -124,6 +124,10 @@ ACTIVATIONS = {"gelu": (0, nn.GELU), "relu": (1, nn.ReLU), "elu": (2, nn.ELU), "
                "sigmoid": (4, nn.Sigmoid), "tanh": (5, nn.Tanh)}
 
 
+# policy_std_type (reference networks/mlp.py:43-73): "mlp_shared" (every example) and "parameter"; "mlp_separated" is refused
+STD_TYPES = ("mlp_shared", "parameter")
+
+
 def _mlp(sizes, activation="gelu"):
     layers = []
     for j in range(len(sizes) - 1):
@@ -147,9 +151,15 @@ class HipActionValueDistri(nn.Module):
 class HipStochaPolicy(nn.Module):
     """Stochastic policy obs -> (mean | std); parameter names as reference networks/mlp.py:28-100."""
 
-    def __init__(self, obs_dim, act_dim, hidden, act_high, act_low, min_log_std, max_log_std, activation="gelu"):
+    def __init__(self, obs_dim, act_dim, hidden, act_high, act_low, min_log_std, max_log_std, activation="gelu",
+                 std_type="mlp_shared"):
         super().__init__()
-        self.policy = _mlp([obs_dim] + list(hidden) + [2 * act_dim], activation)
+        self.std_type = std_type
+        if std_type == "parameter":   # networks/mlp.py:63-73: the MLP gives the mean, log_std is a learnable parameter
+            self.mean = _mlp([obs_dim] + list(hidden) + [act_dim], activation)
+            self.log_std = nn.Parameter(-0.5 * torch.ones(1, act_dim))
+        else:
+            self.policy = _mlp([obs_dim] + list(hidden) + [2 * act_dim], activation)
         self.min_log_std, self.max_log_std = float(min_log_std), float(max_log_std)
         self.register_buffer("act_high_lim", torch.from_numpy(np.asarray(act_high, dtype=np.float32).copy()))
         self.register_buffer("act_low_lim", torch.from_numpy(np.asarray(act_low, dtype=np.float32).copy()))
@@ -160,8 +170,12 @@ class HipStochaPolicy(nn.Module):
             # parameters live in the HIP arena: the fused-MLP kernels serve the forward
             lg = self._engine.policy_forward(obs.detach().cpu().numpy())
             return torch.from_numpy(lg).reshape(*obs.shape[:-1], lg.shape[-1]).to(obs.device)
-        out = self.policy(obs)
-        mean, log_std = torch.chunk(out, chunks=2, dim=-1)
+        if self.std_type == "parameter":
+            mean = self.mean(obs)
+            log_std = self.log_std + torch.zeros_like(mean)
+        else:
+            out = self.policy(obs)
+            mean, log_std = torch.chunk(out, chunks=2, dim=-1)
         return torch.cat((mean, torch.clamp(log_std, self.min_log_std, self.max_log_std).exp()), dim=-1)
 
     action_distribution_cls = TanhGaussDistribution   # reference networks/mlp.py:77; ApproxContainer sets the configured class
@@ -271,8 +285,11 @@ def _check_supported(kwargs):
                                   % (sorted(ACT_DISTRIBUTIONS), kwargs.get("policy_act_distribution")))
     if kwargs.get("cnn_shared", False):
         raise NotImplementedError("cnn_shared is not supported by the HIP path")
-    if kwargs.get("policy_std_type", "mlp_shared") != "mlp_shared":
-        raise NotImplementedError("policy_std_type must be mlp_shared")
+    st = kwargs.get("policy_std_type", "mlp_shared")
+    if st not in STD_TYPES:
+        raise NotImplementedError("DSAC_V2_HIP supports policy_std_type in %s (got %r: two separate MLPs are not built)" % (sorted(STD_TYPES), st))
+    if st == "parameter" and _conv_type(kwargs):
+        raise NotImplementedError("policy_std_type='parameter' is built for the MLP approximators only")
 
 
 class ApproxContainer(nn.Module):
@@ -308,7 +325,7 @@ class ApproxContainer(nn.Module):
         if ct:
             self.policy = HipCnnStochaPolicy(O, A, ct, hi, lo, mn, mx, pa)
         else:
-            self.policy = HipStochaPolicy(O, A, hidden, hi, lo, mn, mx, pa)
+            self.policy = HipStochaPolicy(O, A, hidden, hi, lo, mn, mx, pa, kwargs.get("policy_std_type", "mlp_shared"))
         self.policy.action_distribution_cls = ACT_DISTRIBUTIONS[kwargs.get("policy_act_distribution", "TanhGaussDistribution")][1]
         self.policy_target = copy.deepcopy(self.policy)
         for net in (self.policy_target, self.q1_target, self.q2_target):
@@ -317,7 +334,8 @@ class ApproxContainer(nn.Module):
         self.log_alpha = nn.Parameter(torch.tensor(1, dtype=torch.float32))
         # nn.Module.__setattr__ would register these as sub-state; keep them out of state_dict
         object.__setattr__(self, "_engine", None)
-        object.__setattr__(self, "_layout", CnnArenaLayout(O, A, ct) if ct else ArenaLayout(O, A, hidden))
+        object.__setattr__(self, "_layout", CnnArenaLayout(O, A, ct) if ct else
+                           ArenaLayout(O, A, hidden, policy_std_type=kwargs.get("policy_std_type", "mlp_shared")))
 
     # reference dsac_v2.py:61-62
     def create_action_distributions(self, logits):
@@ -346,6 +364,10 @@ class ApproxContainer(nn.Module):
                 assert tuple(view.shape) == tuple(p.shape), (tuple(view.shape), tuple(p.shape))
                 view.copy_(p.data.to(view.device))
                 p.data = view
+            for net in ("policy", "policy_target"):   # policy_std_type "parameter": the hidden half of the output layer
+                zr = getattr(self._layout, "zero_rows", lambda _n: None)(net)
+                if zr is not None:
+                    arenas[zr[0]][zr[1]:zr[1] + zr[2]].zero_()
             for pol in (self.policy, self.policy_target):
                 pol.act_high_lim = pol.act_high_lim.to(engine.device)
                 pol.act_low_lim = pol.act_low_lim.to(engine.device)
@@ -599,7 +621,8 @@ class DSAC_V2_HIP:
             global_batch=kwargs.get("global_batch"), device=int(kwargs.get("hip_device", 0)),
             value_act=ACTIVATIONS[kwargs.get("value_hidden_activation", "gelu")][0],
             policy_act=ACTIVATIONS[kwargs.get("policy_hidden_activation", "gelu")][0],
-            act_dist=ACT_DISTRIBUTIONS[kwargs.get("policy_act_distribution", "TanhGaussDistribution")][0])
+            act_dist=ACT_DISTRIBUTIONS[kwargs.get("policy_act_distribution", "TanhGaussDistribution")][0],
+            policy_std_type=kwargs.get("policy_std_type", "mlp_shared"))
         self.networks.attach(self.engine)
         register_engine(self.engine)
         if not self.strict_rng:

@@ -33,7 +33,8 @@ class DsactEngine:
                  gamma=0.99, tau=0.005, tau_b=None, auto_alpha=True, alpha=0.2, delay_update=2,
                  lr_q=1e-4, lr_pi=1e-4, lr_alpha=3e-4, min_log_std=-20.0, max_log_std=0.5,
                  global_batch: Optional[int] = None, device: int = 0, conv_type: Optional[str] = None,
-                 algo: str = "DSAC_V2", td_bound: float = 20.0, v1_bound: bool = True, value_act: int = 0, policy_act: int = 0, act_dist: int = 0):
+                 algo: str = "DSAC_V2", td_bound: float = 20.0, v1_bound: bool = True, value_act: int = 0, policy_act: int = 0, act_dist: int = 0,
+                 policy_std_type: str = "mlp_shared"):
         """obs_dim: int for the MLP nets; with `conv_type` ("type_1" / "type_2", reference
         networks/cnn.py:173-228) the (C, H, W) image shape, and `hidden` must be that type's MLP widths."""
         import torch
@@ -47,6 +48,8 @@ class DsactEngine:
         self.algo = algo
         if algo not in ("DSAC_V2", "DSAC_V1"):
             raise DsactError("algo must be DSAC_V2 or DSAC_V1")
+        if conv_type and policy_std_type != "mlp_shared":
+            raise DsactError("policy_std_type %r is built for the MLP nets only" % policy_std_type)
         if conv_type:
             self.layout = CnnArenaLayout(obs_dim, act_dim, conv_type, n_critics=2 if algo == "DSAC_V2" else 1)
             if list(hidden) != self.layout.hidden:
@@ -54,7 +57,8 @@ class DsactEngine:
             self.obs_shape = self.layout.obs_shape
             obs_dim = self.layout.obs_dim
         else:
-            self.layout = ArenaLayout(obs_dim, act_dim, list(hidden), n_critics=2 if algo == "DSAC_V2" else 1)
+            self.layout = ArenaLayout(obs_dim, act_dim, list(hidden), n_critics=2 if algo == "DSAC_V2" else 1,
+                                      policy_std_type=policy_std_type)
             self.obs_shape = (int(obs_dim),)
         self.obs_dim, self.act_dim, self.batch = int(obs_dim), int(act_dim), int(batch)
         self.device_index = int(device)
@@ -82,6 +86,7 @@ class DsactEngine:
         cfg.td_bound = float(td_bound)
         cfg.v1_unbounded = 0 if v1_bound else 1
         cfg.value_act, cfg.policy_act = int(value_act), int(policy_act)   # hidden activations: 0 gelu .. 5 tanh (include/dsact.h)
+        cfg.policy_std_param = 1 if policy_std_type == "parameter" else 0   # networks/mlp.py:63-73 (include/dsact.h)
         cfg.act_dist = int(act_dist)                                       # 0 TanhGaussDistribution, 1 GaussDistribution
         self.cfg = cfg
         self._h = C.c_void_p()

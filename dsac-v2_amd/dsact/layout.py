@@ -17,10 +17,17 @@ def mlp_sizes(in_dim: int, hidden: List[int], out_dim: int) -> List[Tuple[int, i
 
 
 class ArenaLayout:
-    def __init__(self, obs_dim: int, act_dim: int, hidden: List[int], n_critics: int = 2):
-        """n_critics = 2: DSAC_V2 (q1, q2); 1: DSAC_V1 (a single `q`; online = q | policy | log_alpha)."""
+    def __init__(self, obs_dim: int, act_dim: int, hidden: List[int], n_critics: int = 2, policy_std_type: str = "mlp_shared"):
+        """n_critics = 2: DSAC_V2 (q1, q2); 1: DSAC_V1 (a single `q`; online = q | policy | log_alpha).
+
+        policy_std_type "parameter" (reference networks/mlp.py:63-73): the arena keeps the policy's output layer in the
+        (2 act_dim x H) shape of "mlp_shared" -- the kernels are the same -- with rows [act_dim, 2 act_dim) of the weight
+        STRUCTURALLY ZERO (never exposed, their gradient masked: csrc DwProb::msplit) and the second half of the bias being
+        the reference's `log_std` parameter: raw log-std = 0 . h + log_std, d log_std = sum over the batch of d raw."""
         self.obs_dim, self.act_dim, self.hidden = int(obs_dim), int(act_dim), [int(h) for h in hidden]
         self.n_critics = int(n_critics)
+        self.policy_std_type = policy_std_type
+        assert policy_std_type in ("mlp_shared", "parameter")
         self.q_shapes = mlp_sizes(obs_dim + act_dim, self.hidden, 2)
         self.pi_shapes = mlp_sizes(obs_dim, self.hidden, 2 * act_dim)
         self.n_q = sum(o * i + o for o, i in self.q_shapes)
@@ -57,13 +64,35 @@ class ArenaLayout:
         """[(suffix, arena, offset, shape)] e.g. ('q.0.weight', 'online', 0, (256, 393))"""
         arena, off = self.net_offset[net]
         sub = "policy" if net.startswith("policy") else "q"
+        std_param = net.startswith("policy") and self.policy_std_type == "parameter"
         out = []
-        for j, (o, i) in enumerate(self.net_shapes(net)):
-            out.append(("%s.%d.weight" % (sub, 2 * j), arena, off, (o, i)))
+        shapes = self.net_shapes(net)
+        for j, (o, i) in enumerate(shapes):
+            if std_param and j == len(shapes) - 1:
+                # module order of the reference (own parameters before sub-modules): log_std first, then mean.*
+                A = self.act_dim
+                out.insert(0, ("log_std", arena, off + o * i + A, (1, A)))
+                out.append(("mean.%d.weight" % (2 * j), arena, off, (A, i)))
+                out.append(("mean.%d.bias" % (2 * j), arena, off + o * i, (A,)))
+                off += o * i + o
+                continue
+            name = "mean" if std_param else sub
+            out.append(("%s.%d.weight" % (name, 2 * j), arena, off, (o, i)))
             off += o * i
-            out.append(("%s.%d.bias" % (sub, 2 * j), arena, off, (o,)))
+            out.append(("%s.%d.bias" % (name, 2 * j), arena, off, (o,)))
             off += o
         return out
+
+    def zero_rows(self, net: str):
+        """(arena, offset, count) of the structurally-zero weight rows of a policy net (policy_std_type "parameter"), or None"""
+        if not (net.startswith("policy") and self.policy_std_type == "parameter"):
+            return None
+        arena, off = self.net_offset[net]
+        shapes = self.net_shapes(net)
+        for o, i in shapes[:-1]:
+            off += o * i + o
+        o, i = shapes[-1]
+        return arena, off + self.act_dim * i, self.act_dim * i
 
     def param_views(self, net: str):
         """[(suffix, arena, storage_offset, shape, strides)] -- contiguous views for the MLP nets."""
@@ -78,10 +107,14 @@ class ArenaLayout:
         sd = OrderedDict()
         sd["log_alpha"] = ()
         for net in self.all_nets:
+            slices = self.param_slices(net)
             if net.startswith("policy"):
+                if self.policy_std_type == "parameter":   # a module's own parameters precede its buffers
+                    sd[net + ".log_std"] = slices[0][3]
+                    slices = slices[1:]
                 sd[net + ".act_high_lim"] = (self.act_dim,)
                 sd[net + ".act_low_lim"] = (self.act_dim,)
-            for suffix, _, _, shape in self.param_slices(net):
+            for suffix, _, _, shape in slices:
                 sd[net + "." + suffix] = shape
         return sd
 

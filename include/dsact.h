@@ -105,6 +105,12 @@ typedef struct dsact_config {
    * 1 = "GaussDistribution" (:82-115: no squashing -- action = mean + std * eps, log-prob of the plain diagonal Gaussian;
    * the action limits are only used by the caller's clipping and by mode()). */
   int32_t act_dist;
+  /* policy_std_type (networks/mlp.py:43-73): 0 = "mlp_shared" (one MLP -> mean | log_std; every shipped example),
+   * 1 = "parameter" (:63-73,92-97: the MLP gives the mean, log_std is a learnable (1, act_dim) parameter). With 1 the arenas
+   * keep the (2 act_dim x H) output layer: rows [act_dim, 2 act_dim) of its weight are structurally zero (the caller zeroes
+   * them once; their gradient is masked, so Adam / Polyak leave them at 0) and the second half of its bias IS log_std.
+   * DSAC_V2 with MLP nets on the row-slice chain path only (equal hidden widths 64 / 128 / 256, batch a multiple of 16). */
+  int32_t policy_std_param;
 } dsact_config;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

@@ -123,9 +123,15 @@ def mlp_forward(x, params, collect=None, act="gelu", sides=None, kink_log=None):
 
 
 def policy_forward(obs, params, cfg, collect=None, sides=None, kink_log=None):
-    """StochaPolicy.forward, std_type == mlp_shared (networks/mlp.py:85-100)."""
-    logits = mlp_forward(obs, params, collect, cfg.get("policy_act", "gelu"), sides, kink_log)
-    mean, log_std = torch.chunk(logits, chunks=2, dim=-1)
+    """StochaPolicy.forward (networks/mlp.py:79-100): std_type "mlp_shared" (one MLP -> mean | log_std, the default of every
+    example) or "parameter" (cfg["policy_std_type"]: the MLP gives the mean, log_std is a learnable (1, act_dim) parameter --
+    here the LAST element of `params`; networks/mlp.py:63-73,92-97)."""
+    if cfg.get("policy_std_type", "mlp_shared") == "parameter":
+        mean = mlp_forward(obs, params[:-1], collect, cfg.get("policy_act", "gelu"), sides, kink_log)
+        log_std = params[-1] + torch.zeros_like(mean)
+    else:
+        logits = mlp_forward(obs, params, collect, cfg.get("policy_act", "gelu"), sides, kink_log)
+        mean, log_std = torch.chunk(logits, chunks=2, dim=-1)
     std = torch.clamp(log_std, cfg["min_log_std"], cfg["max_log_std"]).exp()
     return torch.cat((mean, std), dim=-1)
 
@@ -250,7 +256,14 @@ class DsactOracle:
 
     def _new_pi_params(self):
         cfg = self.cfg
+        if self._std_param:   # networks/mlp.py:63-73: the mean MLP, then log_std = -0.5 (no RNG consumed)
+            return (_new_mlp_params([cfg["obs_dim"]] + list(cfg["hidden"]) + [cfg["act_dim"]])
+                    + [torch.full((1, cfg["act_dim"]), -0.5, dtype=torch.float32)])
         return _new_mlp_params([cfg["obs_dim"]] + list(cfg["hidden"]) + [2 * cfg["act_dim"]])
+
+    @property
+    def _std_param(self):
+        return self.cfg.get("policy_std_type", "mlp_shared") == "parameter"
 
     # Parity tests with relu / selu hidden activations: act_sides[chain] = per hidden layer the bool tensor `z > 0` as the
     # implementation under test decided it, for the differentiated chains "pi", "q1c", "q2c" (first evaluation of the
@@ -292,10 +305,29 @@ class DsactOracle:
                 sd[n + ".act_low_lim"] = self.act_low.clone()
             sub = "policy" if is_pi else "q"
             ps = self.p[n]
+            if is_pi and self._std_param:   # module parameters precede buffers and sub-modules in a state_dict
+                sd.pop(n + ".act_high_lim"); sd.pop(n + ".act_low_lim")
+                sd[n + ".log_std"] = ps[-1].detach().clone()
+                sd[n + ".act_high_lim"] = self.act_high.clone()
+                sd[n + ".act_low_lim"] = self.act_low.clone()
+                sub = "mean"
             for j in range(len(ps) // 2):
                 sd["%s.%s.%d.weight" % (n, sub, 2 * j)] = ps[2 * j].detach().clone()
                 sd["%s.%s.%d.bias" % (n, sub, 2 * j)] = ps[2 * j + 1].detach().clone()
         return sd
+
+    def grad_dict(self):
+        """gradients of the online nets under the reference's parameter names (the flat views below are in ARENA order)"""
+        out = {"log_alpha": self.log_alpha.grad}
+        for n in ("q1", "q2", "policy"):
+            ps, sub = self.p[n], ("policy" if n == "policy" else "q")
+            if n == "policy" and self._std_param:
+                out[n + ".log_std"] = ps[-1].grad
+                sub = "mean"
+            for j in range(len(ps) // 2):
+                out["%s.%s.%d.weight" % (n, sub, 2 * j)] = ps[2 * j].grad
+                out["%s.%s.%d.bias" % (n, sub, 2 * j)] = ps[2 * j + 1].grad
+        return out
 
     def load_state_dict(self, sd):
         with torch.no_grad():
@@ -303,6 +335,9 @@ class DsactOracle:
             for n in self.NETS:
                 sub = "policy" if n.startswith("policy") else "q"
                 ps = self.p[n]
+                if n.startswith("policy") and self._std_param:
+                    ps[-1].copy_(sd[n + ".log_std"])
+                    sub = "mean"
                 for j in range(len(ps) // 2):
                     ps[2 * j].copy_(sd["%s.%s.%d.weight" % (n, sub, 2 * j)])
                     ps[2 * j + 1].copy_(sd["%s.%s.%d.bias" % (n, sub, 2 * j)])
@@ -467,16 +502,26 @@ class DsactOracle:
         return tb
 
     # ---- flat views in the arena order used by the HIP path: q1 | q2 | policy | log_alpha ---
+    # policy_std_type "parameter": the HIP arena keeps the policy's output layer in the (2 act_dim x H) shape of mlp_shared --
+    # rows [act_dim, 2 act_dim) of the weight are structurally zero, the second half of the bias IS log_std
+    # (dsac-v2_amd/dsact/layout.py); the flat views pad the same way.
+    def _arena_tensors(self, n, pick):
+        ps = [pick(t) for t in self.p[n]]
+        if not (n.startswith("policy") and self._std_param):
+            return [t.reshape(-1) for t in ps]
+        w, b, ls = ps[-3], ps[-2], ps[-1]
+        return [t.reshape(-1) for t in ps[:-3]] + [w.reshape(-1), torch.zeros(w.numel()), b.reshape(-1), ls.reshape(-1)]
+
     def flat_params(self):
-        ts = [t.detach().reshape(-1) for n in ("q1", "q2", "policy") for t in self.p[n]]
+        ts = [t for n in ("q1", "q2", "policy") for t in self._arena_tensors(n, lambda t: t.detach())]
         return torch.cat(ts + [self.log_alpha.detach().reshape(1)])
 
     def flat_targets(self):
-        ts = [t.detach().reshape(-1) for n in ("q1_target", "q2_target", "policy_target") for t in self.p[n]]
+        ts = [t for n in ("q1_target", "q2_target", "policy_target") for t in self._arena_tensors(n, lambda t: t.detach())]
         return torch.cat(ts)
 
     def flat_grads(self):
-        ts = [t.grad.detach().reshape(-1) for n in ("q1", "q2", "policy") for t in self.p[n]]
+        ts = [t for n in ("q1", "q2", "policy") for t in self._arena_tensors(n, lambda t: t.grad.detach())]
         g_a = self.log_alpha.grad if self.log_alpha.grad is not None else torch.zeros(())
         return torch.cat(ts + [g_a.detach().reshape(1)])
 

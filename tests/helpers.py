@@ -108,6 +108,10 @@ def policy_saturation_budget(orc, data, noise, B):
     budget = [torch.zeros_like(p, dtype=torch.float64) for p in params]
     for b, k in (rel > 1e-5).nonzero().tolist():
         for col, w in ((k, float(d_mean[b, k])), (A + k, float(d_mean[b, k]) * abs(float(noise["eps_new"][b, k])))):
-            for acc, g in zip(budget, torch.autograd.grad(logits[b, col], params, retain_graph=True)):
-                acc += w * g.abs().double()
+            for acc, g in zip(budget, torch.autograd.grad(logits[b, col], params, retain_graph=True, allow_unused=True)):
+                if g is not None:   # (policy_std_type "parameter": the std column does not depend on the mean net)
+                    acc += w * g.abs().double()
+    if getattr(orc, "_std_param", False):   # arena order: zero rows behind the mean rows of the output layer, log_std in the bias tail
+        w, b, ls = budget[-3], budget[-2], budget[-1]
+        budget = budget[:-3] + [w, torch.zeros_like(w), b, ls]
     return torch.cat([t.reshape(-1) for t in budget]).numpy()

@@ -136,6 +136,7 @@ def make_pair(O, A, hid, B, act_limit=0.4, seed=0, init=None, **over):
     cfg = default_config(O, A, hid, act_limit=act_limit, value_act=over.get("value_hidden_activation", "gelu"),
                          policy_act=over.get("policy_hidden_activation", "gelu"),
                          act_dist=over.get("policy_act_distribution", "TanhGaussDistribution"),
+                         policy_std_type=over.get("policy_std_type", "mlp_shared"),
                          **{k: over[k] for k in ("auto_alpha", "alpha", "delay_update") if k in over})
     orc = DsactOracle(cfg, state_dict={k: v.cpu() for k, v in alg.networks.state_dict().items()})
     return alg, orc

@@ -50,6 +50,47 @@ def test_bit_exact_vs_live_reference(O, A, hid, B, va, pa, dist):
         assert all(torch.equal(sd[k], osd[k]) for k in sd)
 
 
+@pytest.mark.parametrize("O,A,hid,B,dist", [(24, 6, (64, 64), 64, "TanhGaussDistribution"), (376, 17, (256, 256, 256), 64, "TanhGaussDistribution"),
+                                            (11, 3, (64, 64), 32, "GaussDistribution")])
+def test_std_type_parameter_bit_exact_vs_live_reference(O, A, hid, B, dist):
+    """policy_std_type = "parameter" (networks/mlp.py:63-73,92-97: the MLP gives the mean, log_std is a learnable (1, act_dim)
+    parameter): same seed -> same initial state, then four updates with every gradient and parameter equal under the
+    reference's own parameter names (the oracle's flat views are in the HIP arena's padded order)."""
+    torch.set_num_threads(2)
+    ref = ref_loader.import_reference()
+    kw = ref_loader.reference_kwargs(O, A, hid, policy_act_distribution=dist, policy_std_type="parameter")
+    torch.manual_seed(0)
+    alg = ref.DSAC_V2(**kw)
+    cfg = default_config(O, A, hid, act_dist=dist, policy_std_type="parameter")
+    torch.manual_seed(0)
+    same_seed = DsactOracle(cfg)
+    sd, osd = alg.networks.state_dict(), same_seed.state_dict()
+    assert list(sd.keys()) == list(osd.keys())
+    assert all(torch.equal(sd[k], osd[k]) for k in sd)
+    orc = DsactOracle(cfg, state_dict=sd)
+    rng = np.random.default_rng(0)
+    for it in range(4):
+        d = synth_batch(rng, B, O, A)
+        torch.manual_seed(1000 + it)
+        tb_ref = alg.local_update({k: v.clone() for k, v in d.items()}, it)
+        torch.manual_seed(1000 + it)
+        tb = orc.local_update(d, draw_noise(B, A), it)
+        for k in TB_KEYS[:-1]:
+            assert float(tb_ref[k]) == float(tb[k]), k
+        nets, og = alg.networks, orc.grad_dict()
+        for n in ("q1", "q2", "policy"):
+            for name, p_ in getattr(nets, n).named_parameters():
+                assert torch.equal(p_.grad, og[n + "." + name]), (n, name)
+        assert torch.equal(nets.log_alpha.grad, og["log_alpha"])
+        # the padded flat view: the structurally-zero rows carry zeros, log_std's gradient sits in the bias tail
+        fg, nq = orc.flat_grads(), sum(p_.numel() for p_ in nets.q1.parameters())
+        H = hid[-1]
+        tail = fg[2 * nq:-1][-(2 * A * H + 2 * A):]
+        assert torch.equal(tail[A * H:2 * A * H], torch.zeros(A * H)) and torch.equal(tail[-A:], nets.policy.log_std.grad.reshape(-1))
+        sd, osd = nets.state_dict(), orc.state_dict()
+        assert all(torch.equal(sd[k], osd[k]) for k in sd)
+
+
 def _cnn_kwargs(obs_shape, A, conv_type):
     kw = ref_loader.reference_kwargs(obs_shape, A, (256, 256, 256), act_limit=1.0)
     for key in ("value", "policy"):
