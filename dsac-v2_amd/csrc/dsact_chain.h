@@ -35,6 +35,9 @@
 
 namespace dsact {
 
+#ifndef DSACT_TILE_NAP
+#define DSACT_TILE_NAP 24   // s_sleep units (64 cycles) between two polls of an arrival counter (ArriveWait)
+#endif
 constexpr int kChMaxL = 4;     // == DSACT_MAX_HIDDEN_LAYERS
 #ifndef DSACT_KPD
 #define DSACT_KPD 16
@@ -706,7 +709,7 @@ struct ArriveWait {
       int spins = 0;
       while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
         if (++spins > (1 << 17)) { if (timeout) *timeout = 1; break; }   // ~0.1 s, then the hand-off word
-        if (quick) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(24);
+        if (quick) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(DSACT_TILE_NAP);
       }
     }
     asm volatile("s_barrier" ::: "memory");   // the waves keep their operand loads in flight (no vmcnt wait here)
