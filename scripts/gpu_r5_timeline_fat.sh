@@ -1,7 +1,10 @@
 #!/bin/bash
 # instrumented library built in the container (build/libdsact_tl.so, -DDSACT_TIMELINE): chip-wide stamps of the throughput-regime
 # forward launches (k_fat_fwd) at batch 1024, per unit.   usage: gpurun -- 'STAGE=chain_fwd_b bash scripts/gpu_r5_timeline_fat.sh'
+# build it first, in the container:  mkdir -p build && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value \
+#     -DDSACT_TIMELINE -shared -fPIC -Iinclude -o build/libdsact_tl.so dsac-v2_amd/csrc/dsact_api.hip      (build/ is git-ignored and travels with gpurun)
 set -u
+[ -f build/libdsact_tl.so ] || { echo 'build/libdsact_tl.so is missing (see the header of this script)'; exit 1; }
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp DSACT_LIB_PATH=$PWD/build/libdsact_tl.so
 mkdir -p gpurun_out

@@ -2,7 +2,10 @@
 # instrumented library built in the container (build/libdsact_tl.so): per-workgroup phase stamps of the pipelined forward launches,
 # grouped by unit, for several observation widths (first-layer study).
 # usage: gpurun -- 'OBS="376 120 760" STAGES="chain_fwd+next" bash scripts/gpu_r5_timeline_fwd.sh'   (env switches pass through)
+# build it first, in the container:  mkdir -p build && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value \
+#     -DDSACT_TIMELINE -shared -fPIC -Iinclude -o build/libdsact_tl.so dsac-v2_amd/csrc/dsact_api.hip      (build/ is git-ignored and travels with gpurun)
 set -u
+[ -f build/libdsact_tl.so ] || { echo 'build/libdsact_tl.so is missing (see the header of this script)'; exit 1; }
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp DSACT_LIB_PATH=$PWD/build/libdsact_tl.so
 mkdir -p gpurun_out
