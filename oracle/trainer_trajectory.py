@@ -62,6 +62,9 @@ VARIANTS = {
     "si2": dict(sample_interval=2),
     "si8": dict(sample_interval=8),
     "si8_sparse": dict(sample_interval=8, max_iteration=48, log_save_interval=16, eval_interval=24, apprfunc_save_interval=40),
+    # policy_std_type = "parameter" (networks/mlp.py:63-73; utils/common_utils.py:55 reads the kwarg): the whole loop -- sampler,
+    # evaluator, checkpoints with `policy.log_std` / `policy.mean.*` -- with the learnable-parameter log-std, groups of two updates
+    "std_param_si2": dict(sample_interval=2, policy_std_type="parameter"),
 }
 
 

@@ -270,4 +270,7 @@ def test_hip_stack_follows_the_reference_trajectory(tmp_path, variant):
     assert len(vals) >= 15
     # checkpoints load back into a reference-shaped container (state_dict keys of dsac_v2.py:19-62)
     sd = torch.load(os.path.join(str(tmp_path), "apprfunc", "apprfunc_%d.pkl" % case["max_iteration"]))
-    assert list(sd.keys())[0] == "log_alpha" and len(sd) == 41
+    std_param = case.get("policy_std_type", "mlp_shared") == "parameter"
+    assert list(sd.keys())[0] == "log_alpha" and len(sd) == (43 if std_param else 41)
+    if std_param:   # the reference's own names for this policy_std_type (networks/mlp.py:63-73)
+        assert tuple(sd["policy.log_std"].shape) == (1, kw["action_dim"]) and "policy.mean.0.weight" in sd and "policy.policy.0.weight" not in sd
