@@ -65,6 +65,9 @@ VARIANTS = {
     # policy_std_type = "parameter" (networks/mlp.py:63-73; utils/common_utils.py:55 reads the kwarg): the whole loop -- sampler,
     # evaluator, checkpoints with `policy.log_std` / `policy.mean.*` -- with the learnable-parameter log-std, groups of two updates
     "std_param_si2": dict(sample_interval=2, policy_std_type="parameter"),
+    # policy_act_distribution = "GaussDistribution" (utils/act_distribution_cls.py:82-115): sampler, evaluator (mode() clamps the
+    # mean) and the update without tanh squashing
+    "gauss_si2": dict(sample_interval=2, policy_act_distribution="GaussDistribution"),
 }
 
 
@@ -182,7 +185,10 @@ def run_reference(save_folder, case=None):
 def main():
     import tempfile
 
+    only = sys.argv[1:]   # python -m oracle.trainer_trajectory [variant ...]: regenerate just those (wall-clock scalars differ per run)
     for name in [None] + sorted(VARIANTS):
+        if only and name not in only:
+            continue
         path = GOLDEN if name is None else variant_golden(name)
         with tempfile.TemporaryDirectory() as d:
             traj = run_reference(d, None if name is None else variant_case(name))
