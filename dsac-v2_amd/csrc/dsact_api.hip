@@ -2760,6 +2760,7 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
     a.qstd[0] = h->qstd_c[0]; a.qstd[1] = h->qstd_c[1];
     a.part_heads = h->part_heads; a.act_scale = h->act_scale; a.act_center = h->act_center;
     a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
+    a.q_out_act = h->cfg.value_out_act; a.pi_out_act = h->cfg.policy_out_act; a.pi_out_n = h->cfg.policy_std_param ? A : 2 * A;
     a.timeline = tl_for(h, "heads");
 #define CALL_HEADS(N) TRY(launch(h, "heads", k_heads<N>, dim3(h->n_heads_wg, n_heads), dim3(kThreads), 0, a))
     NCH_DISPATCH(a.W, CALL_HEADS);
@@ -2826,6 +2827,7 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
     a.inv_Bg = h->use_std_sums ? 1.0f / (float)h->cfg.global_batch : 1.0f / (float)B;
     a.std_sums = (h->use_std_sums || h->auto_std_sums) ? h->std_sums : nullptr;
     a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.gamma = h->cfg.gamma; a.tau_b = h->cfg.tau_b; a.one_minus_tau_b = (float)(1.0 - h->cfg.tau_b);
+    a.q_out_act = h->cfg.value_out_act;
     a.timeline = tl_for(h, "loss");
     if (ride) a.ride = *ride;
     a.ride.n_loss_blocks = h->n_loss_wg;
@@ -2889,6 +2891,7 @@ actor_part:
     a.act_scale = h->act_scale; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
     a.part_loss = h->part_loss; a.n_part = B; a.target_entropy = -(float)A;
     a.grad_log_alpha = h->grads + h->n_online - 1;
+    a.pi_out_act = h->cfg.policy_out_act; a.pi_out_n = h->cfg.policy_std_param ? A : 2 * A;
     a.timeline = tl_for(h, "heads_bwd");
     a.n_row_blocks = (B + 3) / 4;
     a.extra = h->d_tiles; a.n_extra = 0;
@@ -3148,6 +3151,10 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (cfg->policy_std_param != 0 && cfg->policy_std_param != 1) return fail(h, DSACT_E_INVALID, "policy_std_param must be 0 (mlp_shared) or 1 (parameter)");
   if (cfg->policy_std_param && (cfg->conv_type != DSACT_CONV_NONE || cfg->algo != 0))
     return fail(h, DSACT_E_INVALID, "policy_std_type 'parameter' is built for DSAC_V2 with MLP nets");
+  for (int oa : {cfg->value_out_act, cfg->policy_out_act})
+    if (oa != 0 && (oa < ACT_RELU || oa > ACT_TANH)) return fail(h, DSACT_E_INVALID, "output activation must be 0 (linear) or 1..5 (relu, elu, selu, sigmoid, tanh)");
+  if ((cfg->value_out_act || cfg->policy_out_act) && (cfg->conv_type != DSACT_CONV_NONE || cfg->algo != 0))
+    return fail(h, DSACT_E_INVALID, "output activations other than linear are built for DSAC_V2 with MLP nets (tile-stage kernels)");
   if (h->cfg.global_batch < h->cfg.batch) h->cfg.global_batch = h->cfg.batch;
   HIPCHK(h, hipSetDevice(device));
   h->O = cfg->obs_dim; h->A = cfg->act_dim; h->L = cfg->n_hidden; h->B = cfg->batch;
@@ -3264,6 +3271,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
               getenv("DSACT_NO_CHAIN") == nullptr && !(h->nq == 1 && getenv("DSACT_NO_CHAIN_V1") != nullptr) &&
               !(h->cnn && (getenv("DSACT_NO_CHAIN_CNN") != nullptr || h->B > 1024));
     ok = ok && h->L <= kChMaxL;
+    ok = ok && cfg->value_out_act == 0 && cfg->policy_out_act == 0;   // output activations live in the tile-stage row kernels only
     for (int l = 0; l < h->L; ++l) ok = ok && cfg->hidden[l] == cfg->hidden[0];
     const int W0 = cfg->hidden[0];
     ok = ok && (W0 == 64 || W0 == 128 || W0 == 256);
@@ -4867,7 +4875,8 @@ static int act_forward_fast(dsact_handle* h, const float* obs_host, const float*
   return check_handoff(h);
 }
 static bool act_fast_ok(const dsact_handle* h) {
-  return !h->cnn && h->O <= kActMaxObs && h->L + 1 <= kActMaxLayers && !h->env_no_fast_act && h->A <= 32;
+  // (an output activation other than linear is served by the general path: k_policy_out applies it)
+  return !h->cnn && h->O <= kActMaxObs && h->L + 1 <= kActMaxLayers && !h->env_no_fast_act && h->A <= 32 && h->cfg.policy_out_act == 0;
 }
 
 // OffSampler.sample()'s per-step device work in ONE call (training/off_sampler.py:46-54): policy(obs) on the live weights +
@@ -4931,6 +4940,7 @@ int dsact_policy_forward(dsact_handle* h, const float* obs_host, int32_t n, floa
   a.Wout = net_params(h, N_POL) + h->pd.w_off[h->L];
   a.bout = net_params(h, N_POL) + h->pd.b_off[h->L];
   a.W = h->w[h->L - 1]; a.n = n; a.A = h->A; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std; a.out = h->act_out;
+  a.out_act = h->cfg.policy_out_act; a.out_n = h->cfg.policy_std_param ? h->A : 2 * h->A;
 #define CALL_POUT(N) TRY(launch(h, "policy_out", k_policy_out<N>, dim3((n + 3) / 4), dim3(kThreads), 0, a))
   NCH_DISPATCH(a.W, CALL_POUT);
   HIPCHK(h, hipMemcpyAsync(logits_host, h->act_out, (size_t)n * 2 * h->A * sizeof(float), hipMemcpyDeviceToHost, h->stream));

@@ -1235,6 +1235,9 @@ struct HeadsArgs {
   float lo_ls, hi_ls;
   long long* timeline;
   int v1_stats;   // DSAC_V1 reports tanh(logits[...,0]) and logits[...,1] only (dsac_v1.py:145-146)
+  int q_out_act, pi_out_act;   // output activations (dsact_math.h out_act_fwd): the stored outputs are POST-activation
+  int pi_out_n;                // policy outputs the activation applies to: 2A, or A with policy_std_type "parameter" (log_std is a
+                               // plain parameter there, networks/mlp.py:92-97)
 };
 
 template <int NCH>
@@ -1255,11 +1258,11 @@ __global__ void __launch_bounds__(kThreads) k_heads(HeadsArgs a) {
       float o[2];
       row_dots<NCH, 2>(h, a.Wout[chain], a.W, 0, 2, lane, o);
       if (lane == 0) {
-        const float mean = o[0] + a.bout[chain][0], raw = o[1] + a.bout[chain][1];
+        const float mean = out_act_fwd(a.q_out_act, o[0] + a.bout[chain][0]), raw = out_act_fwd(a.q_out_act, o[1] + a.bout[chain][1]);
         a.qout[chain - 2][2 * r] = mean;
         a.qout[chain - 2][2 * r + 1] = raw;
         a.qstd[chain - 2][2 * r] = softplus(raw);
-        a.qstd[chain - 2][2 * r + 1] = softplus_grad(raw);
+        a.qstd[chain - 2][2 * r + 1] = softplus_grad(raw) * out_act_grad_y(a.q_out_act, raw);   // d std / d (pre-activation output)
       }
     } else {
       const int A = a.A;
@@ -1272,6 +1275,7 @@ __global__ void __launch_bounds__(kThreads) k_heads(HeadsArgs a) {
           if (lane == n0 + q) mine = o[q];
       }
       if (lane < 2 * A) mine += a.bout[chain][lane];
+      if (lane < a.pi_out_n) mine = out_act_fwd(a.pi_out_act, mine);
       const float raw = __shfl(mine, lane + A, 64);  // lane j < A: raw log-std of dim j
       float lp = 0.f;
       if (lane < A) {
@@ -1346,6 +1350,7 @@ struct LossArgs {
   float inv_Bg;            // 1 / global batch   (mean of std for the EMA; == inv_B on one GPU)
   const float* std_sums;   // {sum std1, sum std2} computed elsewhere (large B / strict data-parallel); else NULL
   int auto_alpha; float alpha_fixed, gamma, tau_b, one_minus_tau_b;
+  int q_out_act;           // output activation of the critics (dsact_math.h out_act_fwd); qout_c / qstd_c hold post-activation values
   long long* timeline;
   RideArgs ride;
 };
@@ -1417,7 +1422,7 @@ __global__ void __launch_bounds__(kThreads) k_loss(LossArgs a) {
         s += h[c][q].x * wv[c][j][q].x; s += h[c][q].y * wv[c][j][q].y;
         s += h[c][q].z * wv[c][j][q].z; s += h[c][q].w * wv[c][j][q].w;
       }
-      o[c][j] = wave_sum(s) + bo[c][j];
+      o[c][j] = out_act_fwd(a.q_out_act, wave_sum(s) + bo[c][j]);
     }
   // ---------------- 1: mean_std EMA ----------------
   s1 = wave_sum(s1); s2 = wave_sum(s2);
@@ -1442,15 +1447,16 @@ __global__ void __launch_bounds__(kThreads) k_loss(LossArgs a) {
   const CriticTerm c1 = critic_term(q1, std1, ms1, tq, tqs);
   const CriticTerm c2 = critic_term(q2, std2, ms2, tq, tqs);
   float dv[8];
-  dv[0] = c1.dq * a.inv_B;
+  // (d / d pre-activation output: the std column's factor is folded into sg by k_heads, the mean column's is formed here)
+  dv[0] = c1.dq * a.inv_B * out_act_grad_y(a.q_out_act, q1);
   dv[1] = c1.dstd * a.inv_B * sg1;
-  dv[2] = c2.dq * a.inv_B;
+  dv[2] = c2.dq * a.inv_B * out_act_grad_y(a.q_out_act, q2);
   dv[3] = c2.dstd * a.inv_B * sg2;
   // actor: mean(alpha*logp_new - min(q1p, q2p)); torch.min ties split the gradient evenly
   const float q1p = o[2][0], q2p = o[3][0];
   const float w1 = q1p < q2p ? 1.0f : (q1p > q2p ? 0.0f : 0.5f);
-  dv[4] = -w1 * a.inv_B; dv[5] = 0.0f;
-  dv[6] = -(1.0f - w1) * a.inv_B; dv[7] = 0.0f;
+  dv[4] = -w1 * a.inv_B * out_act_grad_y(a.q_out_act, q1p); dv[5] = 0.0f;
+  dv[6] = -(1.0f - w1) * a.inv_B * out_act_grad_y(a.q_out_act, q2p); dv[7] = 0.0f;
   if (lane == 0) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -1641,6 +1647,7 @@ struct HeadsBwdArgs {
   float inv_B; int auto_alpha; float alpha_fixed;
   const float* act_scale; float lo_ls, hi_ls;
   const float* part_loss; int n_part; float target_entropy; float* grad_log_alpha;
+  int pi_out_act, pi_out_n;   // policy output activation and the outputs it applies to (HeadsArgs); logits_pi holds post-activation values
   long long* timeline;
   // ride-along weight-gradient tiles of the critics (blocks >= n_row_blocks): this launch has only B/4 row blocks, and
   // the critics' dW is complete (and their weights free) as soon as the critic backward is
@@ -1742,6 +1749,8 @@ __global__ void __launch_bounds__(kThreads) k_heads_bwd(HeadsBwdArgs a) {
   float dmu = 0.f, draw = 0.f;
   if (lane < A) {
     tanh_gauss_bwd(mu, raw, eps, scale, a.lo_ls, a.hi_ls, dA, alpha * a.inv_B, dmu, draw);
+    dmu *= out_act_grad_y(a.pi_out_act, mu);
+    if (A + lane < a.pi_out_n) draw *= out_act_grad_y(a.pi_out_act, raw);
     a.dout_pi[(size_t)r * 2 * A + lane] = dmu;
     a.dout_pi[(size_t)r * 2 * A + A + lane] = draw;
     a.d_new_act[(size_t)r * A + lane] = dA;
@@ -1977,7 +1986,7 @@ __global__ void __launch_bounds__(kThreads) k_std_sums(StdSumArgs a) {
 }
 
 // policy head only (sampler / evaluator feed): logits (mean | std) as StochaPolicy.forward returns
-struct PolicyOutArgs { const float* H; const float* Wout; const float* bout; int W, n, A; float lo_ls, hi_ls; float* out; };
+struct PolicyOutArgs { const float* H; const float* Wout; const float* bout; int W, n, A; float lo_ls, hi_ls; float* out; int out_act, out_n; };
 template <int NCH>
 __global__ void __launch_bounds__(kThreads) k_policy_out(PolicyOutArgs a) {
   constexpr int G = NCH == 1 ? 12 : (NCH == 2 ? 8 : 4);
@@ -1994,6 +2003,7 @@ __global__ void __launch_bounds__(kThreads) k_policy_out(PolicyOutArgs a) {
       const int n = n0 + q;
       if (lane == 0 && n < 2 * a.A) {
         float v = o[q] + a.bout[n];
+        if (n < a.out_n) v = out_act_fwd(a.out_act, v);
         if (n >= a.A) v = expf(clampf(v, a.lo_ls, a.hi_ls));
         a.out[(size_t)r * 2 * a.A + n] = v;
       }

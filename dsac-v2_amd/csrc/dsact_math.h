@@ -91,6 +91,27 @@ DSACT_HD void act_fwd_grad(int act, float z, float& h, float& g) {
   }
 }
 
+// ---- OUTPUT activations (value_output_activation / policy_output_activation, networks/mlp.py:15-20: the last Linear is
+// followed by `output_activation()`; every shipped example uses "linear"). Code: 0 = linear, else an ACT_* id (relu, elu,
+// selu, sigmoid, tanh; a GELU output layer is refused at create time). The heads keep the POST-activation outputs y, and the
+// derivative is expressed through y so that nothing else has to be stored.
+DSACT_HD float out_act_fwd(int act, float z) {
+  if (act == 0) return z;
+  float h, g;
+  act_fwd_grad(act, z, h, g);
+  return h;
+}
+DSACT_HD float out_act_grad_y(int act, float y) {
+  switch (act) {
+    case ACT_RELU: return y > 0.0f ? 1.0f : 0.0f;
+    case ACT_ELU: return y > 0.0f ? 1.0f : y + 1.0f;
+    case ACT_SELU: return y > 0.0f ? kSeluScale : y + kSeluScale * kSeluAlpha;
+    case ACT_SIGMOID: return y * (1.0f - y);
+    case ACT_TANH: return 1.0f - y * y;
+    default: return 1.0f;
+  }
+}
+
 DSACT_HD float softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 // d softplus / dx (torch: grad * (x*beta > threshold ? 1 : z/(z+1)), z = exp(x))
 DSACT_HD float softplus_grad(float x) {

@@ -50,6 +50,9 @@ ALG_TIME_KEY = _v2.ALG_TIME_KEY
 
 def _check_supported(kwargs):
     _v2._check_supported(kwargs)   # MLP nets, or the CNN nets of example_train/dsacv1_cnn_carracing_offasync.py (round 4)
+    for key in ("value_output_activation", "policy_output_activation"):
+        if kwargs.get(key, "linear") != "linear":
+            raise NotImplementedError("DSAC_V1_HIP supports %s='linear' only (output activations are built for DSAC_V2_HIP)" % key)
     if kwargs.get("policy_std_type", "mlp_shared") != "mlp_shared":
         raise NotImplementedError("DSAC_V1_HIP supports policy_std_type='mlp_shared' only (the learnable-parameter log_std is built "
                                   "for DSAC_V2_HIP)")

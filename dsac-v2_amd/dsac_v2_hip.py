@@ -128,20 +128,26 @@ ACTIVATIONS = {"gelu": (0, nn.GELU), "relu": (1, nn.ReLU), "elu": (2, nn.ELU), "
 STD_TYPES = ("mlp_shared", "parameter")
 
 
-def _mlp(sizes, activation="gelu"):
+# value_output_activation / policy_output_activation (utils/common_utils.py:16-45; the module behind the last Linear,
+# networks/mlp.py:15-20): id = dsact_config value (0 linear, else the hidden-activation id); "gelu" as an OUTPUT activation is refused
+OUT_ACTIVATIONS = {"linear": (0, nn.Identity), "relu": (1, nn.ReLU), "elu": (2, nn.ELU), "selu": (3, nn.SELU),
+                   "sigmoid": (4, nn.Sigmoid), "tanh": (5, nn.Tanh)}
+
+
+def _mlp(sizes, activation="gelu", out_activation="linear"):
     layers = []
     for j in range(len(sizes) - 1):
         layers.append(nn.Linear(sizes[j], sizes[j + 1]))
-        layers.append(ACTIVATIONS[activation][1]() if j < len(sizes) - 2 else nn.Identity())
+        layers.append(ACTIVATIONS[activation][1]() if j < len(sizes) - 2 else OUT_ACTIVATIONS[out_activation][1]())
     return nn.Sequential(*layers)
 
 
 class HipActionValueDistri(nn.Module):
     """Distributional Q(s,a) -> (mean, std); parameter names as reference networks/mlp.py:109-127."""
 
-    def __init__(self, obs_dim, act_dim, hidden, activation="gelu"):
+    def __init__(self, obs_dim, act_dim, hidden, activation="gelu", out_activation="linear"):
         super().__init__()
-        self.q = _mlp([obs_dim + act_dim] + list(hidden) + [2], activation)
+        self.q = _mlp([obs_dim + act_dim] + list(hidden) + [2], activation, out_activation)
 
     def forward(self, obs, act):
         out = self.q(torch.cat([obs, act], dim=-1))
@@ -152,14 +158,14 @@ class HipStochaPolicy(nn.Module):
     """Stochastic policy obs -> (mean | std); parameter names as reference networks/mlp.py:28-100."""
 
     def __init__(self, obs_dim, act_dim, hidden, act_high, act_low, min_log_std, max_log_std, activation="gelu",
-                 std_type="mlp_shared"):
+                 std_type="mlp_shared", out_activation="linear"):
         super().__init__()
         self.std_type = std_type
         if std_type == "parameter":   # networks/mlp.py:63-73: the MLP gives the mean, log_std is a learnable parameter
-            self.mean = _mlp([obs_dim] + list(hidden) + [act_dim], activation)
+            self.mean = _mlp([obs_dim] + list(hidden) + [act_dim], activation, out_activation)
             self.log_std = nn.Parameter(-0.5 * torch.ones(1, act_dim))
         else:
-            self.policy = _mlp([obs_dim] + list(hidden) + [2 * act_dim], activation)
+            self.policy = _mlp([obs_dim] + list(hidden) + [2 * act_dim], activation, out_activation)
         self.min_log_std, self.max_log_std = float(min_log_std), float(max_log_std)
         self.register_buffer("act_high_lim", torch.from_numpy(np.asarray(act_high, dtype=np.float32).copy()))
         self.register_buffer("act_low_lim", torch.from_numpy(np.asarray(act_low, dtype=np.float32).copy()))
@@ -276,10 +282,12 @@ def _check_supported(kwargs):
     for key in ("value_hidden_activation", "policy_hidden_activation"):
         if kwargs.get(key, "gelu") not in ACTIVATIONS:
             raise NotImplementedError("DSAC_V2_HIP supports %s in %s (got %r)" % (key, sorted(ACTIVATIONS), kwargs.get(key)))
-    for key, want in (("value_output_activation", "linear"), ("policy_output_activation", "linear")):
-        got = kwargs.get(key, want)
-        if got != want:
-            raise NotImplementedError("DSAC_V2_HIP supports %s=%r only (got %r)" % (key, want, got))
+    for key in ("value_output_activation", "policy_output_activation"):
+        got = kwargs.get(key, "linear")
+        if got not in OUT_ACTIVATIONS:
+            raise NotImplementedError("DSAC_V2_HIP supports %s in %s (got %r)" % (key, sorted(OUT_ACTIVATIONS), got))
+        if got != "linear" and _conv_type(kwargs):
+            raise NotImplementedError("DSAC_V2_HIP supports %s=%r for the MLP approximators only" % (key, got))
     if kwargs.get("policy_act_distribution", "TanhGaussDistribution") not in ACT_DISTRIBUTIONS:
         raise NotImplementedError("DSAC_V2_HIP supports policy_act_distribution in %s (got %r)"
                                   % (sorted(ACT_DISTRIBUTIONS), kwargs.get("policy_act_distribution")))
@@ -318,14 +326,16 @@ class ApproxContainer(nn.Module):
             self.q1 = HipCnnActionValueDistri(O, A, ct, va)
             self.q2 = HipCnnActionValueDistri(O, A, ct, va)
         else:
-            self.q1 = HipActionValueDistri(O, A, hidden, va)
-            self.q2 = HipActionValueDistri(O, A, hidden, va)
+            vo = kwargs.get("value_output_activation", "linear")
+            self.q1 = HipActionValueDistri(O, A, hidden, va, vo)
+            self.q2 = HipActionValueDistri(O, A, hidden, va, vo)
         self.q1_target = copy.deepcopy(self.q1)  # no RNG consumed, like the reference's deepcopy
         self.q2_target = copy.deepcopy(self.q2)
         if ct:
             self.policy = HipCnnStochaPolicy(O, A, ct, hi, lo, mn, mx, pa)
         else:
-            self.policy = HipStochaPolicy(O, A, hidden, hi, lo, mn, mx, pa, kwargs.get("policy_std_type", "mlp_shared"))
+            self.policy = HipStochaPolicy(O, A, hidden, hi, lo, mn, mx, pa, kwargs.get("policy_std_type", "mlp_shared"),
+                                          kwargs.get("policy_output_activation", "linear"))
         self.policy.action_distribution_cls = ACT_DISTRIBUTIONS[kwargs.get("policy_act_distribution", "TanhGaussDistribution")][1]
         self.policy_target = copy.deepcopy(self.policy)
         for net in (self.policy_target, self.q1_target, self.q2_target):
@@ -622,7 +632,9 @@ class DSAC_V2_HIP:
             value_act=ACTIVATIONS[kwargs.get("value_hidden_activation", "gelu")][0],
             policy_act=ACTIVATIONS[kwargs.get("policy_hidden_activation", "gelu")][0],
             act_dist=ACT_DISTRIBUTIONS[kwargs.get("policy_act_distribution", "TanhGaussDistribution")][0],
-            policy_std_type=kwargs.get("policy_std_type", "mlp_shared"))
+            policy_std_type=kwargs.get("policy_std_type", "mlp_shared"),
+            value_out_act=0 if ct else OUT_ACTIVATIONS[kwargs.get("value_output_activation", "linear")][0],
+            policy_out_act=0 if ct else OUT_ACTIVATIONS[kwargs.get("policy_output_activation", "linear")][0])
         self.networks.attach(self.engine)
         register_engine(self.engine)
         if not self.strict_rng:

@@ -34,7 +34,7 @@ class DsactEngine:
                  lr_q=1e-4, lr_pi=1e-4, lr_alpha=3e-4, min_log_std=-20.0, max_log_std=0.5,
                  global_batch: Optional[int] = None, device: int = 0, conv_type: Optional[str] = None,
                  algo: str = "DSAC_V2", td_bound: float = 20.0, v1_bound: bool = True, value_act: int = 0, policy_act: int = 0, act_dist: int = 0,
-                 policy_std_type: str = "mlp_shared"):
+                 policy_std_type: str = "mlp_shared", value_out_act: int = 0, policy_out_act: int = 0):
         """obs_dim: int for the MLP nets; with `conv_type` ("type_1" / "type_2", reference
         networks/cnn.py:173-228) the (C, H, W) image shape, and `hidden` must be that type's MLP widths."""
         import torch
@@ -87,6 +87,7 @@ class DsactEngine:
         cfg.v1_unbounded = 0 if v1_bound else 1
         cfg.value_act, cfg.policy_act = int(value_act), int(policy_act)   # hidden activations: 0 gelu .. 5 tanh (include/dsact.h)
         cfg.policy_std_param = 1 if policy_std_type == "parameter" else 0   # networks/mlp.py:63-73 (include/dsact.h)
+        cfg.value_out_act, cfg.policy_out_act = int(value_out_act), int(policy_out_act)   # 0 linear, 1..5 relu .. tanh (include/dsact.h)
         cfg.act_dist = int(act_dist)                                       # 0 TanhGaussDistribution, 1 GaussDistribution
         self.cfg = cfg
         self._h = C.c_void_p()

@@ -111,6 +111,12 @@ typedef struct dsact_config {
    * them once; their gradient is masked, so Adam / Polyak leave them at 0) and the second half of its bias IS log_std.
    * DSAC_V2 with MLP nets on the row-slice chain path only (equal hidden widths 64 / 128 / 256, batch a multiple of 16). */
   int32_t policy_std_param;
+  /* value_output_activation / policy_output_activation (utils/common_utils.py:16-45 -> networks/mlp.py:15-20: the module that
+   * follows the LAST Linear): 0 = "linear" (every shipped example), 1 relu, 2 elu, 3 selu, 4 sigmoid, 5 tanh ("gelu" as an
+   * output activation is refused). Anything but 0 selects the tile-stage kernels (round 1's launch structure) -- the row-slice
+   * chains and the one-launch acting forward are built for linear outputs; DSAC_V2 with MLP nets only. With policy_std_param
+   * the policy's activation applies to the mean half only (log_std is a plain parameter, networks/mlp.py:92-97). */
+  int32_t value_out_act, policy_out_act;
 } dsact_config;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

@@ -101,7 +101,7 @@ def _act_with_side(z, act, pos):
     return SELU_SCALE * torch.where(pos, z, SELU_ALPHA * torch.expm1(z))
 
 
-def mlp_forward(x, params, collect=None, act="gelu", sides=None, kink_log=None):
+def mlp_forward(x, params, collect=None, act="gelu", sides=None, kink_log=None, out_act="linear"):
     """Linear-act ... Linear (identity output), networks/mlp.py:15-20. sides (parity tests, relu / selu only): per hidden
     layer the bool tensor `z > 0` as another implementation decided it; disagreements are logged as max |z|."""
     n_lin = len(params) // 2
@@ -110,8 +110,8 @@ def mlp_forward(x, params, collect=None, act="gelu", sides=None, kink_log=None):
         z = F.linear(h, params[2 * j], params[2 * j + 1])
         if collect is not None:
             collect.append(z)
-        if j == n_lin - 1:
-            h = z
+        if j == n_lin - 1:   # output_activation (networks/mlp.py:18: the module behind the last Linear; "linear" = Identity)
+            h = z if out_act == "linear" else ACTIVATIONS[out_act](z)
         elif sides is not None and act in ("relu", "selu"):
             flip = sides[j] != (z > 0)
             if kink_log is not None and bool(flip.any()):
@@ -127,18 +127,18 @@ def policy_forward(obs, params, cfg, collect=None, sides=None, kink_log=None):
     example) or "parameter" (cfg["policy_std_type"]: the MLP gives the mean, log_std is a learnable (1, act_dim) parameter --
     here the LAST element of `params`; networks/mlp.py:63-73,92-97)."""
     if cfg.get("policy_std_type", "mlp_shared") == "parameter":
-        mean = mlp_forward(obs, params[:-1], collect, cfg.get("policy_act", "gelu"), sides, kink_log)
+        mean = mlp_forward(obs, params[:-1], collect, cfg.get("policy_act", "gelu"), sides, kink_log, cfg.get("policy_out_act", "linear"))
         log_std = params[-1] + torch.zeros_like(mean)
     else:
-        logits = mlp_forward(obs, params, collect, cfg.get("policy_act", "gelu"), sides, kink_log)
+        logits = mlp_forward(obs, params, collect, cfg.get("policy_act", "gelu"), sides, kink_log, cfg.get("policy_out_act", "linear"))
         mean, log_std = torch.chunk(logits, chunks=2, dim=-1)
     std = torch.clamp(log_std, cfg["min_log_std"], cfg["max_log_std"]).exp()
     return torch.cat((mean, std), dim=-1)
 
 
-def q_forward(obs, act, params, collect=None, hidden_act="gelu", sides=None, kink_log=None):
+def q_forward(obs, act, params, collect=None, hidden_act="gelu", sides=None, kink_log=None, out_act="linear"):
     """ActionValueDistri.forward (networks/mlp.py:122-127) -> (mean, std)."""
-    logits = mlp_forward(torch.cat([obs, act], dim=-1), params, collect, hidden_act, sides, kink_log)
+    logits = mlp_forward(torch.cat([obs, act], dim=-1), params, collect, hidden_act, sides, kink_log, out_act)
     value_mean, value_std = torch.chunk(logits, chunks=2, dim=-1)
     value_std = F.softplus(value_std)
     out = torch.cat((value_mean, value_std), dim=-1)
@@ -289,7 +289,8 @@ class DsactOracle:
     def _q(self, obs, act, params, collect=None):
         ch = self._chain_of(params) if self.act_sides else None
         log = [] if ch in (self.act_sides or {}) else None
-        out = q_forward(obs, act, params, collect, self.cfg.get("value_act", "gelu"), (self.act_sides or {}).get(ch), log)
+        out = q_forward(obs, act, params, collect, self.cfg.get("value_act", "gelu"), (self.act_sides or {}).get(ch), log,
+                        self.cfg.get("value_out_act", "linear"))
         if log:
             self.act_kinks += [(ch,) + e for e in log]
         return out

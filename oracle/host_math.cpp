@@ -35,4 +35,8 @@ void hm_adam(float* p, float* m, float* v, const float* g, int n, float b1w, flo
 void hm_polyak(float* pt, const float* p, int n, float polyak, float one_minus) {
   for (int i = 0; i < n; ++i) pt[i] = dsact::polyak_update(pt[i], p[i], polyak, one_minus);
 }
+void hm_out_act(int act, float z, float* y, float* dy) {   // output activations: y = act(z), dy = d act / dz expressed through y
+  *y = dsact::out_act_fwd(act, z);
+  *dy = dsact::out_act_grad_y(act, *y);
+}
 }

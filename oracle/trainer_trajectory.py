@@ -68,6 +68,8 @@ VARIANTS = {
     # policy_act_distribution = "GaussDistribution" (utils/act_distribution_cls.py:82-115): sampler, evaluator (mode() clamps the
     # mean) and the update without tanh squashing
     "gauss_si2": dict(sample_interval=2, policy_act_distribution="GaussDistribution"),
+    # value_output_activation / policy_output_activation = "tanh" (utils/common_utils.py:16-45 -> networks/mlp.py:15-20)
+    "out_tanh_si2": dict(sample_interval=2, value_output_activation="tanh", policy_output_activation="tanh"),
 }
 
 

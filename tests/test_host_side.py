@@ -97,10 +97,17 @@ def test_unsupported_configs_raise():
     with pytest.raises(NotImplementedError):
         ApproxContainer(**hip_kwargs(4, 2, (32,), 8, policy_hidden_activation="swish"))   # not one of the reference's six
     with pytest.raises(NotImplementedError):
-        ApproxContainer(**hip_kwargs(4, 2, (32,), 8, value_output_activation="tanh"))
-    # the reference's hidden activations (utils/common_utils.py:16-45) build the matching torch modules
+        ApproxContainer(**hip_kwargs(4, 2, (32,), 8, value_output_activation="gelu"))     # (as an OUTPUT activation; the others are built)
+    # output activations (networks/mlp.py:15-20: the module behind the last Linear) build the matching torch modules
     import torch
     from oracle.dsact_oracle import DsactOracle, default_config, policy_forward
+    for oa in ("relu", "elu", "selu", "sigmoid", "tanh", "linear"):
+        torch.manual_seed(3)
+        c = ApproxContainer(**hip_kwargs(6, 2, (16, 16), 8, policy_output_activation=oa, value_output_activation=oa))
+        orc = DsactOracle(default_config(6, 2, (16, 16), policy_out_act=oa, value_out_act=oa), state_dict=c.state_dict())
+        x = torch.randn(5, 6)
+        assert torch.equal(c.policy(x), policy_forward(x, orc.p["policy"], orc.cfg).detach()), oa
+    # the reference's hidden activations (utils/common_utils.py:16-45) build the matching torch modules
     for act in ("relu", "elu", "selu", "sigmoid", "tanh", "gelu"):
         torch.manual_seed(3)
         c = ApproxContainer(**hip_kwargs(6, 2, (16, 16), 8, policy_hidden_activation=act, value_hidden_activation=act))

@@ -91,6 +91,41 @@ def test_std_type_parameter_bit_exact_vs_live_reference(O, A, hid, B, dist):
         assert all(torch.equal(sd[k], osd[k]) for k in sd)
 
 
+@pytest.mark.parametrize("O,A,hid,B,vo,po,st", [(24, 6, (64, 64), 64, "tanh", "tanh", "mlp_shared"), (376, 17, (256, 256, 256), 64, "tanh", "linear", "mlp_shared"),
+                                                (11, 3, (64, 64), 32, "sigmoid", "elu", "mlp_shared"), (24, 6, (64, 64), 64, "relu", "selu", "mlp_shared"),
+                                                (24, 6, (64, 64), 64, "linear", "tanh", "parameter")])
+def test_output_activations_bit_exact_vs_live_reference(O, A, hid, B, vo, po, st):
+    """value_output_activation / policy_output_activation other than "linear" (utils/common_utils.py:16-45 -> the module behind
+    the last Linear, networks/mlp.py:15-20), alone and with policy_std_type "parameter" (whose log_std is NOT activated)."""
+    torch.set_num_threads(2)
+    ref = ref_loader.import_reference()
+    kw = ref_loader.reference_kwargs(O, A, hid, value_output_activation=vo, policy_output_activation=po, policy_std_type=st)
+    torch.manual_seed(0)
+    alg = ref.DSAC_V2(**kw)
+    cfg = default_config(O, A, hid, value_out_act=vo, policy_out_act=po, policy_std_type=st)
+    torch.manual_seed(0)
+    same_seed = DsactOracle(cfg)
+    sd, osd = alg.networks.state_dict(), same_seed.state_dict()
+    assert list(sd.keys()) == list(osd.keys())
+    assert all(torch.equal(sd[k], osd[k]) for k in sd)
+    orc = DsactOracle(cfg, state_dict=sd)
+    rng = np.random.default_rng(0)
+    for it in range(4):
+        d = synth_batch(rng, B, O, A)
+        torch.manual_seed(1000 + it)
+        tb_ref = alg.local_update({k: v.clone() for k, v in d.items()}, it)
+        torch.manual_seed(1000 + it)
+        tb = orc.local_update(d, draw_noise(B, A), it)
+        for k in TB_KEYS[:-1]:
+            assert float(tb_ref[k]) == float(tb[k]), k
+        nets, og = alg.networks, orc.grad_dict()
+        for n in ("q1", "q2", "policy"):
+            for name, p_ in getattr(nets, n).named_parameters():
+                assert torch.equal(p_.grad, og[n + "." + name]), (n, name)
+        sd, osd = nets.state_dict(), orc.state_dict()
+        assert all(torch.equal(sd[k], osd[k]) for k in sd)
+
+
 def _cnn_kwargs(obs_shape, A, conv_type):
     kw = ref_loader.reference_kwargs(obs_shape, A, (256, 256, 256), act_limit=1.0)
     for key in ("value", "policy"):
