@@ -111,7 +111,8 @@ struct dsact_handle {
   float* stage_img = nullptr;           // device staging of a host minibatch's images (dsact_load_batch)
   int* idx_iota = nullptr;
   float* Xc[8];                         // MLP input rows per chain
-  int w[DSACT_MAX_HIDDEN_LAYERS];
+  int w[DSACT_MAX_HIDDEN_LAYERS];     // activation row widths: the wider of the two families per layer (buffer sizes)
+  int wq[DSACT_MAX_HIDDEN_LAYERS], wp[DSACT_MAX_HIDDEN_LAYERS];   // ... of the critics / of the policy nets (equal unless policy_hidden is set)
   // workspace
   char* ws = nullptr;
   size_t ws_bytes = 0;
@@ -232,6 +233,7 @@ struct dsact_handle {
   bool profiling = false;
   std::vector<ProfRec> prof;
   // row-slice fused chains (dsact_chain.h): MLP nets, equal hidden widths of 64 / 128 / 256, batch % 16 == 0
+  bool unequal_widths = false;          // policy_hidden differs from hidden: tile-stage kernels only
   bool chain_ok = false;
   int cW = 0, cNT = 0;                  // hidden width, W / 64
   int s_obs = 0, s_act = 0, SoT = 0;    // stream steps (4 k each): observation / action segment of a first layer, policy outputs (2A)
@@ -1050,7 +1052,7 @@ FusedOpt fused_opt(const dsact_handle* h, bool enable) {
     // merged-gather graph replays: no per-step repack -- the first-layer tiles of the Q nets keep the copies fresh
     const int on[2] = {N_Q1, N_Q2};
     f.mir_n = h->nq;
-    f.mir_ldp = h->ldx; f.mir_O = h->F; f.mir_A = h->A; f.mir_rows = h->w[0];
+    f.mir_ldp = h->ldx; f.mir_O = h->F; f.mir_A = h->A; f.mir_rows = h->wq[0];
     for (int i = 0; i < h->nq; ++i) {
       f.mir_lo[i] = (long long)(net_grads(h, on[i]) - h->grads) + (long long)h->qd.w_off[0];
       f.mir_w[i] = h->W1p[i]; f.mir_wt[i] = h->W1p[2 + i];
@@ -1506,7 +1508,7 @@ RepackArgs repack_args(const dsact_handle* h, int n_blocks) {
   RepackArgs rp;
   const int nets[4] = {N_Q1, N_Q2, N_Q1T, N_Q2T};
   for (int i = 0; i < 4; ++i) { rp.src[i] = net_params(h, nets[i]) + h->qd.w_off[0]; rp.dst[i] = h->W1p[i]; }
-  rp.rows = h->w[0]; rp.K = h->F + h->A; rp.ldp = h->ldx;
+  rp.rows = h->wq[0]; rp.K = h->F + h->A; rp.ldp = h->ldx;
   rp.n_blocks = n_blocks;
   rp.w1at[0] = h->W1aT[0]; rp.w1at[1] = h->W1aT[1]; rp.O = h->F; rp.A = h->A;
   rp.skip_pad = h->use_w1p ? 0 : 1;
@@ -1516,7 +1518,7 @@ RepackArgs repack_args(const dsact_handle* h, int n_blocks) {
 }
 int repack_blocks(const dsact_handle* h) {
   if (h->chain_ok) return h->pack_blocks;   // one block per 16 source rows of every weight tensor
-  const int total4 = h->use_w1p ? 4 * h->w[0] * h->ldx : 2 * 32 * h->w[0];
+  const int total4 = h->use_w1p ? 4 * h->wq[0] * h->ldx : 2 * 32 * h->wq[0];
   int nb = (total4 + kThreads * 8 - 1) / (kThreads * 8);
   // the repack blocks share the gather launch: keep the launch within one round of workgroups (256 CUs)
   const int gather_blocks = h->cnn ? 0 : (h->B + 3) / 4;
@@ -2751,7 +2753,8 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
       a.Wout[i] = net_params(h, net) + d.w_off[L];
       a.bout[i] = net_params(h, net) + d.b_off[L];
     }
-    a.W = h->w[L - 1]; a.B = B; a.O = h->F; a.A = A; a.ldx = h->ldx;
+    a.W = h->w[L - 1]; a.Wch[0] = a.Wch[1] = h->wp[L - 1]; a.Wch[2] = a.Wch[3] = h->wq[L - 1];
+    a.B = B; a.O = h->F; a.A = A; a.ldx = h->ldx;
     a.eps_new = h->eps_new; a.eps_2 = h->eps_2;
     a.XP = h->Xc[C_Q1P]; a.XPb = h->Xc[C_Q2P] != h->Xc[C_Q1P] ? h->Xc[C_Q2P] : nullptr;
     a.X2 = h->Xc[C_Q1T]; a.X2b = h->Xc[C_Q2T] != h->Xc[C_Q1T] ? h->Xc[C_Q2T] : nullptr;
@@ -2822,7 +2825,7 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
     a.rew = h->rew; a.done = h->done; a.logp2 = h->logp2; a.logp_new = h->logp_new; a.z5 = h->z5; a.z6 = h->z6;
     a.log_alpha = h->online + h->n_online - 1;
     a.part_loss = h->part_loss; a.grads_tail = h->grads + h->n_online; a.st = h->st;
-    a.W = h->w[L - 1]; a.B = B;
+    a.W = h->wq[L - 1]; a.B = B;
     a.inv_B = 1.0f / (float)B;
     a.inv_Bg = h->use_std_sums ? 1.0f / (float)h->cfg.global_batch : 1.0f / (float)B;
     a.std_sums = (h->use_std_sums || h->auto_std_sums) ? h->std_sums : nullptr;
@@ -2881,12 +2884,12 @@ actor_part:
   {
     HeadsBwdArgs a;
     a.dZ1[0] = h->dZ[kDzSlot[C_Q1P]][0]; a.dZ1[1] = h->dZ[kDzSlot[C_Q2P]][0];
-    a.W1aT[0] = h->W1aT[0]; a.W1aT[1] = h->W1aT[1]; a.W0 = h->w[0];
+    a.W1aT[0] = h->W1aT[0]; a.W1aT[1] = h->W1aT[1]; a.W0 = h->wq[0];
     a.logits_pi = h->logits_pi; a.eps_new = h->eps_new; a.log_alpha = h->online + h->n_online - 1;
     a.Wout_pi = net_params(h, N_POL) + h->pd.w_off[L];
     a.G_pi = h->Gb[C_PI][L - 1]; a.dZ_pi = h->dZ[kDzSlot[C_PI]][L - 1];
     a.dout_pi = h->dout_pi; a.d_new_act = h->d_new_act;
-    a.WL = h->w[L - 1]; a.B = B; a.O = h->F; a.A = A;
+    a.WL = h->wp[L - 1]; a.B = B; a.O = h->F; a.A = A;
     a.inv_B = 1.0f / (float)B; a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed;
     a.act_scale = h->act_scale; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
     a.part_loss = h->part_loss; a.n_part = B; a.target_entropy = -(float)A;
@@ -3188,13 +3191,27 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     h->F = C * H * W;
     nblk = 2;
   }
-  for (int l = 0; l < h->L; ++l) h->w[l] = nblk * cfg->hidden[l];   // activation row widths
+  // value_hidden_sizes != policy_hidden_sizes (same depth): cfg->hidden sizes the critics, cfg->policy_hidden the policy nets
+  int pol_hidden[DSACT_MAX_HIDDEN_LAYERS];
+  bool unequal = false;
+  for (int l = 0; l < h->L; ++l) {
+    pol_hidden[l] = cfg->policy_hidden[l] > 0 ? cfg->policy_hidden[l] : cfg->hidden[l];
+    if (pol_hidden[l] > kMaxWidth) return fail(h, DSACT_E_INVALID, "hidden width must be 1..%d", kMaxWidth);
+    unequal = unequal || pol_hidden[l] != cfg->hidden[l];
+  }
+  if (unequal && (cfg->conv_type != DSACT_CONV_NONE || cfg->algo != 0))
+    return fail(h, DSACT_E_INVALID, "value_hidden_sizes != policy_hidden_sizes is built for DSAC_V2 with MLP nets (tile-stage kernels)");
+  h->unequal_widths = unequal;
+  for (int l = 0; l < h->L; ++l) {
+    h->wq[l] = nblk * cfg->hidden[l]; h->wp[l] = nblk * pol_hidden[l];
+    h->w[l] = h->wq[l] > h->wp[l] ? h->wq[l] : h->wp[l];
+  }
   for (int l = 0; l < h->L; ++l)
     if (h->w[l] > kMaxWidth) return fail(h, DSACT_E_INVALID, "activation row width %d exceeds %d", h->w[l], kMaxWidth);
   h->ldx = (h->F + h->A + 3) & ~3;
   h->use_w1p = (size_t)4 * nblk * cfg->hidden[0] * h->ldx <= ((size_t)4 << 20);
   build_net(h->qd, h->F + h->A, cfg->hidden, h->L, 2, nblk, h->n_conv, h->cg);
-  build_net(h->pd, h->F, cfg->hidden, h->L, 2 * h->A, nblk, h->n_conv, h->cg);
+  build_net(h->pd, h->F, pol_hidden, h->L, 2 * h->A, nblk, h->n_conv, h->cg);
   h->n_q = h->qd.count; h->n_pi = h->pd.count;
   if (cfg->algo != DSACT_ALGO_DSAC_V2 && cfg->algo != DSACT_ALGO_DSAC_V1) return fail(h, DSACT_E_INVALID, "algo must be 0 (DSAC_V2) or 1 (DSAC_V1)");
   h->nq = cfg->algo == DSACT_ALGO_DSAC_V1 ? 1 : 2;
@@ -3272,6 +3289,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
               !(h->cnn && (getenv("DSACT_NO_CHAIN_CNN") != nullptr || h->B > 1024));
     ok = ok && h->L <= kChMaxL;
     ok = ok && cfg->value_out_act == 0 && cfg->policy_out_act == 0;   // output activations live in the tile-stage row kernels only
+    ok = ok && !h->unequal_widths;                                     // one width per layer for every chain unit
     for (int l = 0; l < h->L; ++l) ok = ok && cfg->hidden[l] == cfg->hidden[0];
     const int W0 = cfg->hidden[0];
     ok = ok && (W0 == 64 || W0 == 128 || W0 == 256);
@@ -4704,11 +4722,12 @@ int dsact_debug_read(dsact_handle* h, const char* name, float* out, size_t cap, 
       int ch = -1;
       for (int c = 0; c < N_CHAIN; ++c) if (chn == kChainName[c]) ch = c;
       if (ch >= 0 && l >= 0 && l < h->L) {
-        cnt = B * h->w[l];
+        const int wch = (kChainNet[ch] == N_POL || kChainNet[ch] == N_POLT) ? h->wp[l] : h->wq[l];
+        cnt = B * wch;
         if (kind == "H") src = h->Hb[ch][l];
         else if (kind == "G") src = h->Gb[ch][l];
         else if (kind == "dZ" && kDzSlot[ch] >= 0) src = h->dZ[kDzSlot[ch]][l];
-        unpack_w = h->chain_ok ? h->w[l] : 0;   // chain mode keeps these as transposed packs [feature][batch]
+        unpack_w = h->chain_ok ? wch : 0;   // chain mode keeps these as transposed packs [feature][batch]
       }
     }
   }
@@ -4939,7 +4958,7 @@ int dsact_policy_forward(dsact_handle* h, const float* obs_host, int32_t n, floa
   a.H = h->Hact[h->L - 1];
   a.Wout = net_params(h, N_POL) + h->pd.w_off[h->L];
   a.bout = net_params(h, N_POL) + h->pd.b_off[h->L];
-  a.W = h->w[h->L - 1]; a.n = n; a.A = h->A; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std; a.out = h->act_out;
+  a.W = h->wp[h->L - 1]; a.n = n; a.A = h->A; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std; a.out = h->act_out;
   a.out_act = h->cfg.policy_out_act; a.out_n = h->cfg.policy_std_param ? h->A : 2 * h->A;
 #define CALL_POUT(N) TRY(launch(h, "policy_out", k_policy_out<N>, dim3((n + 3) / 4), dim3(kThreads), 0, a))
   NCH_DISPATCH(a.W, CALL_POUT);

@@ -1221,7 +1221,8 @@ struct HeadsArgs {
   const float* H[4];      // last hidden activations [B x W]
   const float* Wout[4];   // [n_out x W]
   const float* bout[4];
-  int W, B, O, A, ldx;
+  int W, B, O, A, ldx;     // W: the widest last hidden layer (template dispatch); Wch: per chain
+  int Wch[4];
   const float* eps_new; const float* eps_2;
   float* XP; float* X2;
   float* XPb; float* X2b;   // second destination of new_act / act2 (CNN nets: one input-row buffer per chain), or NULL
@@ -1253,10 +1254,11 @@ __global__ void __launch_bounds__(kThreads) k_heads(HeadsArgs a) {
   float s_tanh = 0.f, s_sig = 0.f;
   if (active) {
     f32x4 h[NCH];
-    row_load<NCH>(a.H[chain] + (size_t)r * a.W, a.W, lane, h);
+    const int W = a.Wch[chain];
+    row_load<NCH>(a.H[chain] + (size_t)r * W, W, lane, h);
     if (chain >= 2) {
       float o[2];
-      row_dots<NCH, 2>(h, a.Wout[chain], a.W, 0, 2, lane, o);
+      row_dots<NCH, 2>(h, a.Wout[chain], W, 0, 2, lane, o);
       if (lane == 0) {
         const float mean = out_act_fwd(a.q_out_act, o[0] + a.bout[chain][0]), raw = out_act_fwd(a.q_out_act, o[1] + a.bout[chain][1]);
         a.qout[chain - 2][2 * r] = mean;
@@ -1269,7 +1271,7 @@ __global__ void __launch_bounds__(kThreads) k_heads(HeadsArgs a) {
       float mine = 0.f;  // lane n keeps logits[n]
       for (int n0 = 0; n0 < 2 * A; n0 += G) {
         float o[G];
-        row_dots<NCH, G>(h, a.Wout[chain], a.W, n0, 2 * A, lane, o);
+        row_dots<NCH, G>(h, a.Wout[chain], W, n0, 2 * A, lane, o);
 #pragma unroll
         for (int q = 0; q < G; ++q)
           if (lane == n0 + q) mine = o[q];

@@ -50,6 +50,8 @@ ALG_TIME_KEY = _v2.ALG_TIME_KEY
 
 def _check_supported(kwargs):
     _v2._check_supported(kwargs)   # MLP nets, or the CNN nets of example_train/dsacv1_cnn_carracing_offasync.py (round 4)
+    if not _v2._conv_type(kwargs) and list(kwargs["value_hidden_sizes"]) != list(kwargs["policy_hidden_sizes"]):
+        raise NotImplementedError("DSAC_V1_HIP needs value_hidden_sizes == policy_hidden_sizes (unequal widths are built for DSAC_V2_HIP)")
     for key in ("value_output_activation", "policy_output_activation"):
         if kwargs.get(key, "linear") != "linear":
             raise NotImplementedError("DSAC_V1_HIP supports %s='linear' only (output activations are built for DSAC_V2_HIP)" % key)

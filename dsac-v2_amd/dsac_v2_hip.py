@@ -272,9 +272,17 @@ def _hidden_sizes(kwargs):
     if ct:
         return list(CONV_TYPES[ct][4])
     hv, hp = list(kwargs["value_hidden_sizes"]), list(kwargs["policy_hidden_sizes"])
-    if hv != hp:
-        raise NotImplementedError("DSAC_V2_HIP needs value_hidden_sizes == policy_hidden_sizes (got %s / %s)" % (hv, hp))
+    if len(hv) != len(hp):
+        raise NotImplementedError("DSAC_V2_HIP needs value_hidden_sizes and policy_hidden_sizes of the same DEPTH (got %s / %s)" % (hv, hp))
     return hv
+
+
+def _policy_hidden_sizes(kwargs):
+    """policy_hidden_sizes when they differ from value_hidden_sizes (same depth: served by the tile-stage kernels), else None"""
+    if _conv_type(kwargs):
+        return None
+    hv, hp = list(kwargs["value_hidden_sizes"]), list(kwargs["policy_hidden_sizes"])
+    return hp if hp != hv else None
 
 
 def _check_supported(kwargs):
@@ -334,8 +342,8 @@ class ApproxContainer(nn.Module):
         if ct:
             self.policy = HipCnnStochaPolicy(O, A, ct, hi, lo, mn, mx, pa)
         else:
-            self.policy = HipStochaPolicy(O, A, hidden, hi, lo, mn, mx, pa, kwargs.get("policy_std_type", "mlp_shared"),
-                                          kwargs.get("policy_output_activation", "linear"))
+            self.policy = HipStochaPolicy(O, A, _policy_hidden_sizes(kwargs) or hidden, hi, lo, mn, mx, pa,
+                                          kwargs.get("policy_std_type", "mlp_shared"), kwargs.get("policy_output_activation", "linear"))
         self.policy.action_distribution_cls = ACT_DISTRIBUTIONS[kwargs.get("policy_act_distribution", "TanhGaussDistribution")][1]
         self.policy_target = copy.deepcopy(self.policy)
         for net in (self.policy_target, self.q1_target, self.q2_target):
@@ -345,7 +353,8 @@ class ApproxContainer(nn.Module):
         # nn.Module.__setattr__ would register these as sub-state; keep them out of state_dict
         object.__setattr__(self, "_engine", None)
         object.__setattr__(self, "_layout", CnnArenaLayout(O, A, ct) if ct else
-                           ArenaLayout(O, A, hidden, policy_std_type=kwargs.get("policy_std_type", "mlp_shared")))
+                           ArenaLayout(O, A, hidden, policy_std_type=kwargs.get("policy_std_type", "mlp_shared"),
+                                       policy_hidden=_policy_hidden_sizes(kwargs)))
 
     # reference dsac_v2.py:61-62
     def create_action_distributions(self, logits):
@@ -634,7 +643,8 @@ class DSAC_V2_HIP:
             act_dist=ACT_DISTRIBUTIONS[kwargs.get("policy_act_distribution", "TanhGaussDistribution")][0],
             policy_std_type=kwargs.get("policy_std_type", "mlp_shared"),
             value_out_act=0 if ct else OUT_ACTIVATIONS[kwargs.get("value_output_activation", "linear")][0],
-            policy_out_act=0 if ct else OUT_ACTIVATIONS[kwargs.get("policy_output_activation", "linear")][0])
+            policy_out_act=0 if ct else OUT_ACTIVATIONS[kwargs.get("policy_output_activation", "linear")][0],
+            policy_hidden=_policy_hidden_sizes(kwargs))
         self.networks.attach(self.engine)
         register_engine(self.engine)
         if not self.strict_rng:

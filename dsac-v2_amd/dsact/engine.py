@@ -34,7 +34,8 @@ class DsactEngine:
                  lr_q=1e-4, lr_pi=1e-4, lr_alpha=3e-4, min_log_std=-20.0, max_log_std=0.5,
                  global_batch: Optional[int] = None, device: int = 0, conv_type: Optional[str] = None,
                  algo: str = "DSAC_V2", td_bound: float = 20.0, v1_bound: bool = True, value_act: int = 0, policy_act: int = 0, act_dist: int = 0,
-                 policy_std_type: str = "mlp_shared", value_out_act: int = 0, policy_out_act: int = 0):
+                 policy_std_type: str = "mlp_shared", value_out_act: int = 0, policy_out_act: int = 0,
+                 policy_hidden: Optional[Sequence[int]] = None):
         """obs_dim: int for the MLP nets; with `conv_type` ("type_1" / "type_2", reference
         networks/cnn.py:173-228) the (C, H, W) image shape, and `hidden` must be that type's MLP widths."""
         import torch
@@ -58,7 +59,7 @@ class DsactEngine:
             obs_dim = self.layout.obs_dim
         else:
             self.layout = ArenaLayout(obs_dim, act_dim, list(hidden), n_critics=2 if algo == "DSAC_V2" else 1,
-                                      policy_std_type=policy_std_type)
+                                      policy_std_type=policy_std_type, policy_hidden=policy_hidden)
             self.obs_shape = (int(obs_dim),)
         self.obs_dim, self.act_dim, self.batch = int(obs_dim), int(act_dim), int(batch)
         self.device_index = int(device)
@@ -87,6 +88,11 @@ class DsactEngine:
         cfg.v1_unbounded = 0 if v1_bound else 1
         cfg.value_act, cfg.policy_act = int(value_act), int(policy_act)   # hidden activations: 0 gelu .. 5 tanh (include/dsact.h)
         cfg.policy_std_param = 1 if policy_std_type == "parameter" else 0   # networks/mlp.py:63-73 (include/dsact.h)
+        if policy_hidden is not None and list(policy_hidden) != list(hidden):   # value_hidden_sizes != policy_hidden_sizes (include/dsact.h)
+            if conv_type or len(policy_hidden) != len(hidden):
+                raise DsactError("policy_hidden needs the MLP nets and as many layers as `hidden`")
+            for i, w in enumerate(policy_hidden):
+                cfg.policy_hidden[i] = int(w)
         cfg.value_out_act, cfg.policy_out_act = int(value_out_act), int(policy_out_act)   # 0 linear, 1..5 relu .. tanh (include/dsact.h)
         cfg.act_dist = int(act_dist)                                       # 0 TanhGaussDistribution, 1 GaussDistribution
         self.cfg = cfg

@@ -8,7 +8,7 @@ Key names and order follow the reference checkpoints (SURVEY.md App. C;
 training/trainer.py:148-152 saves `networks.state_dict()`).
 """
 from collections import OrderedDict
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 
 def mlp_sizes(in_dim: int, hidden: List[int], out_dim: int) -> List[Tuple[int, int]]:
@@ -17,7 +17,8 @@ def mlp_sizes(in_dim: int, hidden: List[int], out_dim: int) -> List[Tuple[int, i
 
 
 class ArenaLayout:
-    def __init__(self, obs_dim: int, act_dim: int, hidden: List[int], n_critics: int = 2, policy_std_type: str = "mlp_shared"):
+    def __init__(self, obs_dim: int, act_dim: int, hidden: List[int], n_critics: int = 2, policy_std_type: str = "mlp_shared",
+                 policy_hidden: Optional[List[int]] = None):
         """n_critics = 2: DSAC_V2 (q1, q2); 1: DSAC_V1 (a single `q`; online = q | policy | log_alpha).
 
         policy_std_type "parameter" (reference networks/mlp.py:63-73): the arena keeps the policy's output layer in the
@@ -28,8 +29,10 @@ class ArenaLayout:
         self.n_critics = int(n_critics)
         self.policy_std_type = policy_std_type
         assert policy_std_type in ("mlp_shared", "parameter")
+        # value_hidden_sizes != policy_hidden_sizes (utils/common_utils.py:59-62): `hidden` sizes the critics, `policy_hidden` the policy nets
+        self.policy_hidden = [int(h) for h in policy_hidden] if policy_hidden is not None else list(self.hidden)
         self.q_shapes = mlp_sizes(obs_dim + act_dim, self.hidden, 2)
-        self.pi_shapes = mlp_sizes(obs_dim, self.hidden, 2 * act_dim)
+        self.pi_shapes = mlp_sizes(obs_dim, self.policy_hidden, 2 * act_dim)
         self.n_q = sum(o * i + o for o, i in self.q_shapes)
         self.n_pi = sum(o * i + o for o, i in self.pi_shapes)
         nq = self.n_critics

@@ -117,6 +117,10 @@ typedef struct dsact_config {
    * chains and the one-launch acting forward are built for linear outputs; DSAC_V2 with MLP nets only. With policy_std_param
    * the policy's activation applies to the mean half only (log_std is a plain parameter, networks/mlp.py:92-97). */
   int32_t value_out_act, policy_out_act;
+  /* value_hidden_sizes != policy_hidden_sizes (utils/common_utils.py:59-62 reads them per key): `hidden` sizes the critics,
+   * `policy_hidden[l]` > 0 the policy nets (all zeros: the same widths). Same number of layers; DSAC_V2 with MLP nets on the
+   * tile-stage kernels (the row-slice chains run one width per layer across every unit). */
+  int32_t policy_hidden[DSACT_MAX_HIDDEN_LAYERS];
 } dsact_config;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

@@ -256,10 +256,11 @@ class DsactOracle:
 
     def _new_pi_params(self):
         cfg = self.cfg
+        hid = list(cfg.get("policy_hidden") or cfg["hidden"])   # policy_hidden_sizes when they differ from value_hidden_sizes
         if self._std_param:   # networks/mlp.py:63-73: the mean MLP, then log_std = -0.5 (no RNG consumed)
-            return (_new_mlp_params([cfg["obs_dim"]] + list(cfg["hidden"]) + [cfg["act_dim"]])
+            return (_new_mlp_params([cfg["obs_dim"]] + hid + [cfg["act_dim"]])
                     + [torch.full((1, cfg["act_dim"]), -0.5, dtype=torch.float32)])
-        return _new_mlp_params([cfg["obs_dim"]] + list(cfg["hidden"]) + [2 * cfg["act_dim"]])
+        return _new_mlp_params([cfg["obs_dim"]] + hid + [2 * cfg["act_dim"]])
 
     @property
     def _std_param(self):

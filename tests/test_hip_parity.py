@@ -138,6 +138,7 @@ def make_pair(O, A, hid, B, act_limit=0.4, seed=0, init=None, **over):
                          act_dist=over.get("policy_act_distribution", "TanhGaussDistribution"),
                          policy_std_type=over.get("policy_std_type", "mlp_shared"),
                          value_out_act=over.get("value_output_activation", "linear"), policy_out_act=over.get("policy_output_activation", "linear"),
+                         policy_hidden=over.get("policy_hidden_sizes"),
                          **{k: over[k] for k in ("auto_alpha", "alpha", "delay_update") if k in over})
     orc = DsactOracle(cfg, state_dict={k: v.cpu() for k, v in alg.networks.state_dict().items()})
     return alg, orc

@@ -115,7 +115,11 @@ def test_unsupported_configs_raise():
         x = torch.randn(5, 6)
         assert torch.equal(c.policy(x), policy_forward(x, orc.p["policy"], orc.cfg).detach()), act
     with pytest.raises(NotImplementedError):
-        ApproxContainer(**hip_kwargs(4, 2, (32,), 8, value_hidden_sizes=[16]))
+        ApproxContainer(**hip_kwargs(4, 2, (32,), 8, value_hidden_sizes=[16, 16]))     # another DEPTH than the policy's
+    # value_hidden_sizes != policy_hidden_sizes of the same depth: the policy nets get their own widths
+    c = ApproxContainer(**hip_kwargs(4, 2, (32, 32), 8, policy_hidden_sizes=[16, 24]))
+    assert tuple(c.policy.policy[0].weight.shape) == (16, 4) and tuple(c.policy.policy[2].weight.shape) == (24, 16)
+    assert tuple(c.q1.q[0].weight.shape) == (32, 6) and c._layout.n_pi == 16 * 4 + 16 + 24 * 16 + 24 + 4 * 24 + 4
 
 
 def test_plugin_discovery_rules():

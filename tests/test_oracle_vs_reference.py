@@ -126,6 +126,38 @@ def test_output_activations_bit_exact_vs_live_reference(O, A, hid, B, vo, po, st
         assert all(torch.equal(sd[k], osd[k]) for k in sd)
 
 
+@pytest.mark.parametrize("O,A,hv,hp,B", [(24, 6, (64, 64), (32, 48), 64), (376, 17, (256, 256, 256), (128, 128, 128), 64), (11, 3, (96, 40), (40, 96), 32)])
+def test_unequal_hidden_sizes_bit_exact_vs_live_reference(O, A, hv, hp, B):
+    """value_hidden_sizes != policy_hidden_sizes (utils/common_utils.py:59-62 reads them per key), same depth"""
+    torch.set_num_threads(2)
+    ref = ref_loader.import_reference()
+    kw = ref_loader.reference_kwargs(O, A, hv, policy_hidden_sizes=list(hp))
+    torch.manual_seed(0)
+    alg = ref.DSAC_V2(**kw)
+    cfg = default_config(O, A, hv, policy_hidden=list(hp))
+    torch.manual_seed(0)
+    same_seed = DsactOracle(cfg)
+    sd, osd = alg.networks.state_dict(), same_seed.state_dict()
+    assert list(sd.keys()) == list(osd.keys())
+    assert all(torch.equal(sd[k], osd[k]) for k in sd)
+    orc = DsactOracle(cfg, state_dict=sd)
+    rng = np.random.default_rng(0)
+    for it in range(4):
+        d = synth_batch(rng, B, O, A)
+        torch.manual_seed(1000 + it)
+        tb_ref = alg.local_update({k: v.clone() for k, v in d.items()}, it)
+        torch.manual_seed(1000 + it)
+        tb = orc.local_update(d, draw_noise(B, A), it)
+        for k in TB_KEYS[:-1]:
+            assert float(tb_ref[k]) == float(tb[k]), k
+        nets = alg.networks
+        gref = torch.cat([p.grad.reshape(-1) for n in ("q1", "q2", "policy") for p in getattr(nets, n).parameters()]
+                         + [nets.log_alpha.grad.reshape(1)])
+        assert torch.equal(gref, orc.flat_grads())
+        sd, osd = nets.state_dict(), orc.state_dict()
+        assert all(torch.equal(sd[k], osd[k]) for k in sd)
+
+
 def _cnn_kwargs(obs_shape, A, conv_type):
     kw = ref_loader.reference_kwargs(obs_shape, A, (256, 256, 256), act_limit=1.0)
     for key in ("value", "policy"):
