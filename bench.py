@@ -744,7 +744,7 @@ def chain_flops(lay, batch):
     return {k: 2.0 * v * batch for k, v in per_row.items()}
 
 
-PMC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
+PMC_FILES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")
 
 
 def _kernel_base_name(full):
@@ -844,7 +844,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true")
     ap.add_argument("--fast", action="store_true", help="primary number with DSACT_F_SKIP_ACTOR_ON_OFF_ITERS (default: strict; fast is reported in `fast`)")
-    ap.add_argument("--replay-rows", type=int, default=N_REPLAY)
+    ap.add_argument("--replay-rows", "--rows", dest="replay_rows", type=int, default=N_REPLAY,
+                    help="rows of the replay ring in HBM per GPU (configs[1]: 1M; configs[4]: 10M = 30.9 GB)")
     ap.add_argument("--batch", type=int, default=B, help="minibatch rows per GPU (BASELINE metric: 256)")
     ap.add_argument("--cnn-only", action="store_true", help="measure only the CNN workload (configs[3]); prints its object")
     ap.add_argument("--cnn-steps", type=int, default=400)
@@ -994,16 +995,19 @@ def main():
                 out["kernels"] = [{"name": n, "us": round(ms * 1000, 2), "blocks": b, "launches_per_update": round(per_update[n], 4)}
                                   for n, ms, b in prof]
                 out["kernels_per_update_us"] = round(sum(ms * 1000.0 * per_update[n] for n, ms, _ in prof if n not in ("gather", "pack")), 2)
+                lpu = sum(per_update[n] for n, _, _ in prof if n not in ("gather", "pack"))
+                out["config"]["kernels"] = ("row-slice fused chains + transposed-operand weight-gradient tiles with fused Adam / Polyak: "
+                                            "%.3g launches/update in the timed (pipelined) graph -- one forward launch + one merged backward launch" % lpu)
                 out["config"]["launch"] = ("hipGraph (%d steps/graph), delayed-update-aware pipelining: the forward launch of an update that "
                                            "leaves the policy alone also runs pi / pi_target of the next minibatch (chain_fwd+next), the next "
                                            "update's forward holds only the fresh-critic chains (chain_fwd_q); gather rides two updates ahead" % gs)
             else:
                 prof = profile_kernels(e, warmup + steps * len(regions))
                 out["kernels"] = [{"name": n, "us": round(ms * 1000, 2), "blocks": b} for n, ms, b in prof]
-            out["kernels_note"] = ("average in-chain duration per launch over 10 eager updates: start/stop events attached to each "
-                                   "dispatch (hipExtLaunchKernelGGL), i.e. the kernel's own begin/end timestamps as rocprofv3 reports "
-                                   "them (profiles/r02_final_bench_kernel_stats.csv); the eager update has its own gather launch, the timed "
-                                   "graph replay does not (the gather rides in the loss launch)")
+            out["kernels_note"] = ("average in-chain duration per launch: start/stop events attached to each dispatch (hipExtLaunchKernelGGL) "
+                                   "-- the kernel's own begin / end timestamps, what rocprofv3 --kernel-trace reports -- over eager runs of the "
+                                   "launch sequence the timed graph captures; rocprofv3 summary of this configuration ALONE: "
+                                   "profiles/r06_bench_kernel_stats.csv, two consecutive updates launch by launch: profiles/r06_step_trace.txt")
             # the two streaming parts of the update, reported separately
             kus = {n: ms * 1000.0 for n, ms, _ in prof}
             if "gather" in kus:

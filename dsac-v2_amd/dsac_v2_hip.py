@@ -758,12 +758,33 @@ class DSAC_V2_HIP:
             raise TypeError("local_update_group takes the HipBatchGroup this engine's HipReplayBuffer.sample_batches returned")
         t0 = time.time()
         group.check_fresh()
-        self._keep_previous_stats()
         n = len(group)
+        # DSACT_F_SKIP_ACTOR_ON_OFF_ITERS: a graph that skips the discarded policy backward is captured per whole delay_update
+        # period (dsact_run_group refuses anything else), but a trainer cuts its groups at log / evaluation / checkpoint
+        # iterations, wherever those fall. The misaligned head and tail of such a group are issued one update at a time --
+        # what local_update accepts at any iteration -- and the aligned middle as the group replay.
+        D = int(self.delay_update)
+        if (self.flags & 1) and D > 1 and (iteration % D or n % D):
+            head = min(n, (-int(iteration)) % D)
+            body = ((n - head) // D) * D
+            tb, j = None, 0
+            while j < n:
+                if j == head and body >= 2:
+                    tb = self._run_group_rows(group.idxs[j:j + body], int(iteration) + j, time.time())
+                    j += body
+                else:
+                    tb = self.local_update(group.batch(j), int(iteration) + j)
+                    j += 1
+            return tb
+        return self._run_group_rows(group.idxs, int(iteration), t0)
+
+    def _run_group_rows(self, idxs, iteration, t0):
+        self._keep_previous_stats()
+        n = int(idxs.shape[0])
         noise = None
         if self.strict_rng:
             noise = np.stack([np.concatenate([a.reshape(-1) for a in self._draw_noise()]) for _ in range(n)]).astype(np.float32)
-        self.engine.run_group(int(iteration), group.idxs, noise, self.flags)
+        self.engine.run_group(iteration, idxs, noise, self.flags)
         return self._new_tb(t0, n)
 
     def _grad_views(self):

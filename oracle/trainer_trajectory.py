@@ -70,6 +70,13 @@ VARIANTS = {
     "gauss_si2": dict(sample_interval=2, policy_act_distribution="GaussDistribution"),
     # value_output_activation / policy_output_activation = "tanh" (utils/common_utils.py:16-45 -> networks/mlp.py:15-20)
     "out_tanh_si2": dict(sample_interval=2, value_output_activation="tanh", policy_output_activation="tanh"),
+    # the configuration the reference itself runs sample_interval = 8 with: the CNN examples (example_train/
+    # dsacv2_cnn_carracing_offasync.py:133, sample_batch_size 8 at :140) -- conv type_2 over a (3,96,96) image env (tests/envs/
+    # synth_blob_data.py), whole groups of 8 between host-side events, batch 16 (the smallest the twin-trunk chain units take)
+    "cnn_si8": dict(env_id="synth_blob", value_func_type="CNN", policy_func_type="CNN", value_conv_type="type_2", policy_conv_type="type_2",
+                    value_hidden_sizes=[256, 256, 256], policy_hidden_sizes=[256, 256, 256], sample_interval=8, sample_batch_size=8,
+                    replay_batch_size=16, buffer_warm_size=24, buffer_max_size=48, max_iteration=24, log_save_interval=8,
+                    eval_interval=16, apprfunc_save_interval=24, num_eval_episode=1, max_episode_steps=20),
 }
 
 

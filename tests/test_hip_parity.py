@@ -1381,6 +1381,64 @@ def test_full_size_replay_gather_and_determinism():
     assert outs[0][1] == outs[1][1]
 
 
+def test_ten_million_row_ring_addressing():
+    """BASELINE.json configs[4]'s single-GPU leg (training/replay_buffer.py:20-50 semantics at buffer_max_size = 10M): a
+    10,000,000-row Humanoid ring is 30.9 GB, and row x obs_dim crosses 2^31 floats at row 5,711,393 -- every ring offset is
+    size_t (csrc/dsact_kernels.h k_gather / k_ring_write), the indices travel as int32. Rows written at 0, around the 2^31
+    crossing (device fill AND the ring-write kernel of dsact_buffer_add) and at 9,999,999 come back from the gather bit for bit;
+    a graph of updates that samples them runs finite."""
+    O, A, B, N = 376, 17, 1024, 10_000_000
+    cross = (1 << 31) // O                      # 5,711,393: the first row whose LAST float sits past 2^31
+    alg, _ = make_pair(O, A, (256, 256, 256), B, seed=1)
+    e = alg.engine
+    e.set_device_rng(7)
+    e.buffer_create(N)
+    g = torch.Generator(device="cuda").manual_seed(3)
+
+    def rows(n):
+        return dict(obs=torch.randn(n, O, device="cuda", generator=g), act=torch.rand(n, A, device="cuda", generator=g) - .5,
+                    rew=torch.randn(n, device="cuda", generator=g), obs2=torch.randn(n, O, device="cuda", generator=g),
+                    done=(torch.rand(n, device="cuda", generator=g) < .5).float())
+
+    want = {}
+    def put(r0, d):
+        for i in range(d["rew"].shape[0]):
+            want[r0 + i] = {k: v[i].cpu().numpy() for k, v in d.items()}
+
+    # the last row first: the ring counts as full from here on (size = 10M, ptr = 0)
+    d = rows(1); e.buffer_fill_device(N - 1, d["obs"], d["act"], d["rew"], d["obs2"], d["done"]); put(N - 1, d)
+    assert e.buffer_size == N and e.buffer_ptr == 0
+    d = rows(2); e.buffer_fill_device(0, d["obs"], d["act"], d["rew"], d["obs2"], d["done"]); put(0, d)
+    d = rows(3); e.buffer_fill_device(cross - 2, d["obs"], d["act"], d["rew"], d["obs2"], d["done"]); put(cross - 2, d)
+    assert e.buffer_ptr == cross + 1
+    # the ring-write kernel (dsact_buffer_add -> k_ring_write) continues at ptr = cross + 1, on the far side of 2^31 floats
+    d = {k: v.cpu() for k, v in rows(4).items()}
+    e.buffer_add(d["obs"].numpy(), d["act"].numpy(), d["rew"].numpy(), d["obs2"].numpy(), d["done"].numpy())
+    put(cross + 1, d)
+    assert e.buffer_ptr == cross + 5 and e.buffer_size == N
+    keys = sorted(want)
+    idx = np.array([keys[i % len(keys)] for i in range(B)], dtype=np.int64)
+    e.gather(idx)
+    got = e.read_batch(with_logp=False)
+    for b, r in enumerate(idx):
+        for k in ("obs", "obs2", "act", "rew", "done"):
+            assert np.array_equal(got[k][b], want[int(r)][k]), (int(r), k)
+    # index rows past int32-sized offsets through the graph's device-side gather too
+    tab = np.stack([np.roll(idx, s) for s in range(4)])
+    e.upload_index_table(tab)
+    e.graph_build(2)
+    e.graph_run(0, 4)
+    e.sync()
+    assert torch.isfinite(e.online).all() and all(np.isfinite(v) for v in e.read_stats().values())
+    got = e.read_batch(with_logp=False)          # the staged minibatch = the last table row
+    for b, r in enumerate(tab[3]):
+        assert np.array_equal(got["obs2"][b], want[int(r)]["obs2"]), int(r)
+    with pytest.raises(Exception):
+        e.gather(np.full(B, N, dtype=np.int64))   # one past the end is refused, not wrapped
+    del alg, e
+    torch.cuda.empty_cache()
+
+
 def test_local_update_takes_cuda_tensors_like_the_reference_trainer():
     """The reference trainer hands `local_update` per-key `.cuda()` tensors (training/trainer.py:72-74).
     dsact_load_batch takes them by device address: the staged rows are bit-identical to staging the CPU batch,

@@ -37,7 +37,8 @@ def derived_kwargs(case, save_folder, **over):
     env = plugin.create_env(**kw)
     kw["use_gpu"] = bool(kw.get("enable_cuda", False))
     kw["batch_size_per_sampler"] = kw["sample_batch_size"]
-    kw["obsv_dim"] = env.observation_space.shape[0]
+    shape = tuple(env.observation_space.shape)
+    kw["obsv_dim"] = shape[0] if len(shape) == 1 else shape      # utils/init_args.py:29-33
     kw["action_dim"] = env.action_space.shape[0]
     kw["action_high_limit"] = env.action_space.high.astype("float32")
     kw["action_low_limit"] = env.action_space.low.astype("float32")
@@ -271,6 +272,10 @@ def test_hip_stack_follows_the_reference_trajectory(tmp_path, variant):
     # checkpoints load back into a reference-shaped container (state_dict keys of dsac_v2.py:19-62)
     sd = torch.load(os.path.join(str(tmp_path), "apprfunc", "apprfunc_%d.pkl" % case["max_iteration"]))
     std_param = case.get("policy_std_type", "mlp_shared") == "parameter"
+    if case.get("value_func_type") == "CNN":   # 173 keys, <net>.conv.* then the twin <net>.mean.* / <net>.log_std.* MLPs
+        assert list(sd.keys())[0] == "log_alpha" and len(sd) == 173 and "policy.conv.0.weight" in sd and "q1_target.log_std.6.bias" in sd
+        assert any(n == 8 for _, n in got["groups"])          # whole groups of 8 updates: the CNN examples' own sample_interval
+        return
     assert list(sd.keys())[0] == "log_alpha" and len(sd) == (43 if std_param else 41)
     if std_param:   # the reference's own names for this policy_std_type (networks/mlp.py:63-73)
         assert tuple(sd["policy.log_std"].shape) == (1, kw["action_dim"]) and "policy.mean.0.weight" in sd and "policy.policy.0.weight" not in sd
