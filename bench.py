@@ -425,7 +425,12 @@ def e2e_gpu(hidden, device, iters=400, warm=60):
         e.policy_forward(obs1)
     fwd_us = (time.perf_counter() - t0) / 500 * 1e6
     try:
-        fwd_split = {"launch_call_us": e.debug_get("act_launch_us"), "completion_spin_us": e.debug_get("act_wait_us")}
+        if e.debug_get("act_host") == 1.0:   # the acting forward runs on the calling thread (csrc/dsact_host_act.h)
+            fwd_split = {"where": "host", "forward_us": e.debug_get("act_host_us"), "threads": e.debug_get("act_host_threads"),
+                         "isa": {0.0: "x86-64", 1.0: "avx2+fma", 2.0: "avx512f"}.get(e.debug_get("act_host_isa")), "snapshot_copies": e.debug_get("act_copies"),
+                         "calls": e.debug_get("act_host_calls"), "last_copy_wait_us": e.debug_get("act_copy_wait_us")}
+        else:
+            fwd_split = {"where": "gpu", "launch_call_us": e.debug_get("act_launch_us"), "completion_spin_us": e.debug_get("act_wait_us")}
     except Exception:
         fwd_split = None
     return {"policy_forward_split": fwd_split, "value": iters / w, "unit": "iterations/s", "ms_per_iteration": 1000.0 * w / iters,
@@ -433,7 +438,8 @@ def e2e_gpu(hidden, device, iters=400, warm=60):
             "policy_forward_us": fwd_us, "iterations": iters,
             "note": "HipOffSerialTrainer.step(): 20 env steps (Humanoid-shaped table-lookup env, ~2 us/step: the figure is the "
                     "framework's cost, not MuJoCo's) + add_batch + sample_batch(256) + local_update; policy_forward_us = one acting "
-                    "forward call (observation in the kernel arguments, logits through mapped host memory)"}
+                    "forward call: on the host from the pinned policy snapshot refreshed behind every policy-moving update "
+                    "(csrc/dsact_host_act.h; `hip_host_act=False`: one GPU launch per call, csrc/dsact_act.h)"}
 
 
 def e2e_gpu_grouped(hidden, device, interval=8, iters=1600, warm=160):

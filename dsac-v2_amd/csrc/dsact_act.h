@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256) k_act_mlp(ActArgs a) {
           for (;;) {
             p = __hip_atomic_load(hin + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((int)(p >> 32) == a.call) break;
-            if (++spins > (1 << 20)) { if (a.timeout) *a.timeout = 2; break; }   // 2: raised by the acting forward (check_handoff)
+            if (++spins > (1 << 20)) { if (a.timeout) *a.timeout = 1; break; }   // the acting forward's OWN word (check_handoff)
           }
           v = __builtin_bit_cast(float, (unsigned)p);
         }

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <string>
 #include <vector>
@@ -19,6 +20,7 @@
 #include "dsact_chain.h"
 #include "dsact_fat.h"
 #include "dsact_act.h"
+#include "dsact_host_act.h"
 #include "dsact_conv.h"
 
 using namespace dsact;
@@ -273,6 +275,20 @@ struct dsact_handle {
   int act_call = 0;
   double act_launch_us = 0.0, act_wait_us = 0.0;   // host time of the last fast acting forward: launch call, completion spin
   bool env_no_fast_act = false;         // DSACT_NO_FAST_ACT: the sampler's forward through the copy + tile-stage path (A/B)
+  // host-side acting (dsact_host_act.h): pinned snapshot of the policy net, refreshed on the handle's stream behind every
+  // enqueued update that moves the policy; dsact_act_sample / dsact_policy_forward(n = 1) run on the calling thread
+  bool host_act = true;                 // DSACT_NO_HOST_ACT / dsact_debug_set("host_act", 0): the one-launch GPU forward instead
+  float* pol_host = nullptr;            // pinned: the policy net's n_pi floats in arena order
+  hipEvent_t pol_ev = nullptr;
+  bool pol_pending = false;             // a copy has been enqueued and its event not yet seen complete
+  unsigned long long pol_epoch = 1;     // bumped by every enqueued operation that may change the policy's parameters
+  unsigned long long pol_copied = 0;    // epoch the snapshot (or the copy in flight) belongs to
+  float* act_buf = nullptr;             // host scratch: two activation buffers + the output layer's products
+  hostact::Pool* act_pool = nullptr;    // fork-join helpers for the wide layers (nullptr: the calling thread alone)
+  int act_threads = 0;                  // 0: not calibrated yet; DSACT_HOST_ACT_THREADS forces a count
+  float act_scale_h[32] = {0}, act_center_h[32] = {0};   // host copies of act_scale / act_center (act_dim <= 32 on this path)
+  double act_host_us = 0.0, act_copy_wait_us = 0.0;
+  unsigned long long act_host_calls = 0, act_copies = 0;
   int env_chain_rg_pi = 0;              // DSACT_CHAIN_RG_PI (experiments)
   bool env_no_ride8 = true;             // DSACT_RIDE8=1: the critics' riding tiles run 8 waves (512-thread launch) at batch >= 1024 (measured
                                         // equal: 27.4 vs 27.1 us, 8,784 vs 8,767 steps/s -- that launch is not bound by the riders' wave count)
@@ -3015,6 +3031,19 @@ static bool activate_graph(dsact_handle* h, int steps, uint32_t flags, bool nois
   return false;
 }
 // every captured graph goes: the active one and the cached ones (they bake in pointers, hyper-parameters, launch forms)
+// the ACTIVE graph only (a failed or abandoned capture): cached graphs of other shapes stay valid
+static void drop_active_graph(dsact_handle* h) {
+  if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+  if (h->graph) { hipGraphDestroy(h->graph); h->graph = nullptr; }
+  for (int p = 0; p < dsact_handle::kPipePhases; ++p) {
+    if (h->pexec[p]) { hipGraphExecDestroy(h->pexec[p]); h->pexec[p] = nullptr; }
+    if (h->pgraph[p]) { hipGraphDestroy(h->pgraph[p]); h->pgraph[p] = nullptr; }
+    if (h->pargs[p]) { hipFree(h->pargs[p]); h->pargs[p] = nullptr; }
+  }
+  h->pipe_graph = false;
+  h->graph_steps = 0;
+  h->graph_noise_table = false;
+}
 void drop_graphs(dsact_handle* h) {
   if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
   if (h->graph) { hipGraphDestroy(h->graph); h->graph = nullptr; }
@@ -3030,6 +3059,9 @@ void drop_graphs(dsact_handle* h) {
   h->graph_noise_table = false;
 }
 bool have_graph(const dsact_handle* h) { return h->graph_exec != nullptr || h->pipe_graph; }
+// active OR cached: what the "baked into the captured graph" refusals have to look at (dsact_run_group keeps graphs of other
+// group lengths in the cache, and a failed build may leave no active graph beside them)
+bool any_graph(const dsact_handle* h) { return have_graph(h) || !h->graph_cache.empty(); }
 
 // In-launch hand-overs (merged forward / backward launches) use BOUNDED spins: a consumer that waited ~0.1 s for its
 // producers' flags gives up, computes on whatever it finds and writes the hand-off word in mapped host memory. Every
@@ -3037,16 +3069,19 @@ bool have_graph(const dsact_handle* h) { return h->graph_exec != nullptr || h->p
 // (the plain multi-launch chain has no in-launch dependencies) and a captured graph is captured again without them, so
 // the NEXT call runs -- on device state the caller must treat as invalid (restore a checkpoint / re-bind the arenas).
 int check_handoff(dsact_handle* h) {
-  if (!h->handoff_host || h->in_handoff || !*(volatile int*)h->handoff_host) return DSACT_OK;
+  // two words in mapped host memory (one overwritten word let an acting-forward timeout hide an update kernel's):
+  // [0] is raised by the update kernels, [1] by the acting forward (k_act_mlp) -- neither store can erase the other
+  volatile int* const w_upd = (volatile int*)h->handoff_host;
+  volatile int* const w_act = w_upd ? w_upd + 1 : nullptr;
+  if (!h->handoff_host || h->in_handoff || !(*w_upd | *w_act)) return DSACT_OK;
   h->in_handoff = true;
-  const int word = *(volatile int*)h->handoff_host;
   const hipError_t e_dev = hipSetDevice(h->device);
   const hipError_t e_sync = hipStreamSynchronize(h->stream);
-  const int word2 = *(volatile int*)h->handoff_host;   // (an update kernel may have given up too while the stream drained)
-  *(volatile int*)h->handoff_host = 0;
-  if (word == 2 && word2 == 2) {
-    // raised by the acting forward (k_act_mlp) only: it reads the parameters and writes nothing the update path reads, so
-    // the training state is intact -- the call fails, nothing is switched off, nothing has to be restored
+  const int upd = *w_upd;   // (read after the drain: an update kernel may have given up too while the stream emptied)
+  *w_upd = 0; *w_act = 0;
+  if (!upd) {
+    // raised by the acting forward only: it reads the parameters and writes nothing the update path reads, so the training
+    // state is intact -- the call fails, nothing is switched off, nothing has to be restored
     h->in_handoff = false;
     h->handoff_failures += 1;
     return fail(h, DSACT_E_HIP, "the acting forward's layer hand-over timed out (a wave waited > 0.1 s for its input): this "
@@ -3462,6 +3497,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   HIPCHK(h, hipMalloc((void**)&h->act_h, (size_t)kActMaxLayers * kMaxWidth * sizeof(unsigned long long)));
   HIPCHK(h, hipMemset(h->act_h, 0, (size_t)kActMaxLayers * kMaxWidth * sizeof(unsigned long long)));
   h->env_no_fast_act = getenv("DSACT_NO_FAST_ACT") != nullptr;
+  h->host_act = getenv("DSACT_NO_HOST_ACT") == nullptr;
 
   if (h->fwd_merge) {
     // the merged forward is sized for both groups' workgroups being resident at once: two per CU (speed, not
@@ -3494,6 +3530,10 @@ int dsact_destroy(dsact_handle* h) {
   }
   if (h->handoff_host) hipHostFree(h->handoff_host);
   if (h->act_h) hipFree(h->act_h);
+  if (h->pol_host) hipHostFree(h->pol_host);
+  if (h->pol_ev) hipEventDestroy(h->pol_ev);
+  free(h->act_buf);
+  delete h->act_pool;
   if (h->d_tiles) hipFree(h->d_tiles);
   if (h->alt.d_tiles) hipFree(h->alt.d_tiles);
   if (h->alt_ws) hipFree(h->alt_ws);
@@ -3534,7 +3574,7 @@ int dsact_destroy(dsact_handle* h) {
 int dsact_set_stream(dsact_handle* h, void* s) {
   if (!h) return DSACT_E_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
-  if (have_graph(h)) return fail(h, DSACT_E_STATE, "cannot change stream after dsact_graph_build");
+  if (any_graph(h)) return fail(h, DSACT_E_STATE, "cannot change stream after dsact_graph_build");
   if (h->stream) HIPCHK(h, hipStreamSynchronize(h->stream));
   if (h->own_stream && h->stream) { hipStreamDestroy(h->stream); h->stream = nullptr; }
   if (s) { h->stream = (hipStream_t)s; h->own_stream = false; }
@@ -3560,7 +3600,7 @@ int dsact_bind_arenas(dsact_handle* h, float* online, float* target, float* adam
   if (!h) return DSACT_E_INVALID;
   if (!online || !target || !adam_m || !adam_v || !grads) return fail(h, DSACT_E_INVALID, "null arena pointer");
   HIPCHK(h, hipSetDevice(h->device));
-  if (have_graph(h)) return fail(h, DSACT_E_STATE, "cannot rebind arenas after dsact_graph_build");
+  if (any_graph(h)) return fail(h, DSACT_E_STATE, "cannot rebind arenas after dsact_graph_build");
   h->online = online; h->target = target; h->adam_m = adam_m; h->adam_v = adam_v; h->grads = grads;
   TRY(build_chain(h));
   TRY(build_pack_jobs(h));
@@ -3576,6 +3616,7 @@ int dsact_bind_arenas(dsact_handle* h, float* online, float* target, float* adam
     TRY(rc);
   }
   h->state_invalid = false;
+  h->pol_epoch++;   // (new arenas: the host-side acting snapshot is stale; the next acting call copies again)
   return DSACT_OK;
 }
 
@@ -3592,6 +3633,7 @@ int dsact_set_action_limits(dsact_handle* h, const float* high, const float* low
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(h->act_scale, s.data(), h->A * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->act_center, c.data(), h->A * sizeof(float), hipMemcpyHostToDevice));
+  for (int j = 0; j < h->A && j < 32; ++j) { h->act_scale_h[j] = s[j]; h->act_center_h[j] = c[j]; }
   h->limits_set = true;
   return DSACT_OK;
 }
@@ -3888,7 +3930,7 @@ int dsact_upload_index_table(dsact_handle* h, const int64_t* idx_host, int32_t r
     if (idx_host[i] < 0 || idx_host[i] >= h->size) return fail(h, DSACT_E_INVALID, "index out of range");
     tmp[i] = (int)idx_host[i];
   }
-  if (have_graph(h) && rows != h->idx_rows) return fail(h, DSACT_E_STATE, "index table shape is baked into the captured graph");
+  if (any_graph(h) && rows != h->idx_rows) return fail(h, DSACT_E_STATE, "index table shape is baked into the captured graph");
   if (!h->idx_table || rows != h->idx_rows) {
     drop_graphs(h);   // (cached ones included: the table's address and row count are baked into them)
     if (h->idx_table) hipFree(h->idx_table);
@@ -3916,7 +3958,7 @@ int dsact_set_noise(dsact_handle* h, const float* eps_new, const float* eps_2, c
 
 int dsact_set_device_rng(dsact_handle* h, uint64_t seed) {
   if (!h) return DSACT_E_INVALID;
-  if (have_graph(h)) return fail(h, DSACT_E_STATE, "rng mode is baked into the captured graph");
+  if (any_graph(h)) return fail(h, DSACT_E_STATE, "rng mode is baked into the captured graph");
   h->rng_seed = seed;
   return DSACT_OK;
 }
@@ -3924,6 +3966,75 @@ int dsact_set_device_rng(dsact_handle* h, uint64_t seed) {
 // ---- update --------------------------------------------------------------------------------------
 // device time of the last eager update (the reference's "Time/Algorithm time" is the wall time of a synchronous CPU
 // update; here the call returns after the enqueue, so the honest figure is the stream time between these two events)
+// ---- host-side acting (dsact_host_act.h) ------------------------------------------------------------------------------
+// the policy net's parameters -> the pinned snapshot, stream-ordered behind everything enqueued so far
+static int enqueue_policy_copy(dsact_handle* h) {
+  HIPCHK(h, hipMemcpyAsync(h->pol_host, net_params(h, N_POL), (size_t)h->n_pi * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipEventRecord(h->pol_ev, h->stream));
+  h->pol_pending = true;
+  h->pol_copied = h->pol_epoch;
+  h->act_copies++;
+  return DSACT_OK;
+}
+// called by every entry point that enqueued work which may change the policy's parameters (an update with
+// iteration % delay_update == 0, graph replays, the data-parallel apply): the snapshot of a handle that acts on the host is
+// refreshed right behind it, so the copy is already in flight when the sampler asks
+static int policy_moved(dsact_handle* h) {
+  h->pol_epoch++;
+  if (h->pol_host && h->host_act) return enqueue_policy_copy(h);
+  return DSACT_OK;
+}
+static bool act_fast_ok(const dsact_handle* h);
+static bool act_host_ok(const dsact_handle* h) { return h->host_act && act_fast_ok(h); }
+// policy(obs) [+ TanhGaussDistribution.sample()] on the calling thread with the weights of the last completed update
+// (training/off_sampler.py:46-56). eps == nullptr: out = the 2A logits; else out = A actions and *logp
+static int act_forward_host(dsact_handle* h, const float* obs_host, const float* eps, float* out, float* logp) {
+  TRY(check_handoff(h));
+  const auto t0 = std::chrono::steady_clock::now();
+  if (!h->pol_host) {
+    HIPCHK(h, hipHostMalloc((void**)&h->pol_host, ((size_t)h->n_pi + 64) * sizeof(float), hipHostMallocDefault));
+    HIPCHK(h, hipEventCreateWithFlags(&h->pol_ev, hipEventDisableTiming));
+    h->act_buf = (float*)malloc((size_t)(2 * (kMaxWidth + 64) + 128) * sizeof(float));
+    if (!h->act_buf) return fail(h, DSACT_E_HIP, "out of host memory");
+  }
+  if (h->pol_copied != h->pol_epoch) TRY(enqueue_policy_copy(h));
+  if (h->pol_pending) {
+    // poll first: a blocking wait sleeps the thread and its wake-up (tens of us) would sit in front of every burst of
+    // environment steps; after ~5 ms fall back to the blocking wait
+    hipError_t q = hipErrorNotReady;
+    while ((q = hipEventQuery(h->pol_ev)) == hipErrorNotReady) {
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+    }
+    if (q != hipSuccess) HIPCHK(h, hipEventSynchronize(h->pol_ev));
+    h->pol_pending = false;
+    TRY(check_handoff(h));     // (an update kernel that gave up while the stream drained: this snapshot is not to be acted on)
+    h->act_copy_wait_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  }
+  hostact::Layer ly[kActMaxLayers];
+  for (int l = 0; l <= h->L; ++l) {
+    ly[l].W = h->pol_host + h->pd.w_off[l]; ly[l].b = h->pol_host + h->pd.b_off[l];
+    ly[l].K = h->pd.in[l]; ly[l].N = h->pd.out[l];
+  }
+  float* b0 = h->act_buf; float* b1 = b0 + kMaxWidth + 64; float* raw = b1 + kMaxWidth + 64;
+  if (h->act_threads == 0) {
+    // One thread by default. DSACT_HOST_ACT_THREADS=n lets n - 1 helpers share the wide layers (dsact_host_act.h, Pool; the
+    // result is bit-identical): measured on the 2-socket EPYC 9575F of the MI355X boxes with unpinned helpers, 4 threads ran a
+    // forward in 9.6 us against 8.9 us alone -- the weights (0.95 MB) stream from the L3 at ~20 B/clk either way and every
+    // layer's fork-join crosses CCDs; in the 8-vCPU build container 2 threads were 4x slower than 1.
+    const char* ev = getenv("DSACT_HOST_ACT_THREADS");
+    int t = ev ? atoi(ev) : 1;
+    t = t < 1 ? 1 : (t > 16 ? 16 : t);
+    h->act_threads = t;
+    if (t > 1) h->act_pool = new hostact::Pool(t);
+  }
+  const auto t1 = std::chrono::steady_clock::now();
+  hostact::forward(ly, h->L + 1, h->cfg.policy_act, obs_host, b0, b1, raw, h->act_pool);
+  hostact::head(raw, h->A, h->cfg.min_log_std, h->cfg.max_log_std, eps, h->act_scale_h, h->act_center_h, out, logp);
+  h->act_host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
+  h->act_host_calls++;
+  return DSACT_OK;
+}
+
 static int mark_update(dsact_handle* h, bool end) {
   if (!h->uev0) {
     HIPCHK(h, hipEventCreate(&h->uev0));
@@ -3947,7 +4058,8 @@ int dsact_apply_update(dsact_handle* h, int64_t iteration) {
   TRY(check_ready(h, false));
   HIPCHK(h, hipSetDevice(h->device));
   TRY(enqueue_prologue(h, 0, iteration, 1, 0));
-  return enqueue_adam(h);
+  TRY(enqueue_adam(h));
+  return (iteration % h->cfg.delay_update) == 0 ? policy_moved(h) : DSACT_OK;
 }
 
 int dsact_step(dsact_handle* h, int64_t iteration, uint32_t flags) {
@@ -3957,7 +4069,8 @@ int dsact_step(dsact_handle* h, int64_t iteration, uint32_t flags) {
   TRY(enqueue_prologue(h, 0, iteration, 1, 1));
   // single-GPU update: Adam / Polyak are applied by the weight-gradient tiles themselves (no k_adam)
   TRY(enqueue_grads(h, !(flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) || (iteration % h->cfg.delay_update) == 0, true));
-  return mark_update(h, true);
+  TRY(mark_update(h, true));
+  return (iteration % h->cfg.delay_update) == 0 ? policy_moved(h) : DSACT_OK;   // dsac_v2.py:320-347: the policy moves on these iterations only
 }
 
 // one replayed update (iteration and index-table row from device state). `iteration` is only used to
@@ -3982,7 +4095,8 @@ static int enqueue_graph_step_dp(dsact_handle* h) {
   }
   TRY(enqueue_allreduce(h, h->grads, h->n_online + 2, kNcclAvg));
   TRY(enqueue_prologue(h, 1, 0, 1, 0));
-  return enqueue_adam(h);
+  TRY(enqueue_adam(h));
+  return policy_moved(h);
 }
 
 static int enqueue_graph_step(dsact_handle* h, long long iteration, uint32_t flags) {
@@ -4203,20 +4317,21 @@ int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) 
   if (steps_per_graph < 1) return fail(h, DSACT_E_INVALID, "steps_per_graph must be >= 1");
   if (!h->idx_table) return fail(h, DSACT_E_STATE, "upload an index table first (dsact_upload_index_table)");
   HIPCHK(h, hipSetDevice(h->device));
+  // (argument checks first: a refused build leaves the active graph and the cache as they were -- ADVICE r5)
+  if ((flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) && steps_per_graph % h->cfg.delay_update)
+    return fail(h, DSACT_E_INVALID, "with DSACT_F_SKIP_ACTOR_ON_OFF_ITERS steps_per_graph must be a multiple of delay_update");
+  if ((flags & DSACT_F_DATA_PARALLEL) && !h->comm) return fail(h, DSACT_E_STATE, "DSACT_F_DATA_PARALLEL needs dsact_comm_init");
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   if (h->build_keeps_cache) stash_graph(h); else drop_graphs(h);
   h->want_graph_steps = 0;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
   if (h->flags_dirty && h->chain_flags) {   // not inside the graph: the captured updates clear the flags themselves
     HIPCHK(h, hipMemset(h->chain_flags, 0, kChainFlags * sizeof(int)));
     h->flags_dirty = false;
   }
-  if ((flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) && steps_per_graph % h->cfg.delay_update)
-    return fail(h, DSACT_E_INVALID, "with DSACT_F_SKIP_ACTOR_ON_OFF_ITERS steps_per_graph must be a multiple of delay_update");
   // Merged gather (MLP nets, fused single-launch-chain update): one gather launch opens the graph; every update's
   // loss launch carries the bookkeeping and the NEXT update's gather into the other batch set; the per-step repack
   // of the padded first-layer copies is done by the weight-gradient tiles themselves (FusedOpt::mir_*).
   // Update s of n uses set (n-1-s)&1, so the last staged minibatch sits in set 0 like after eager updates.
-  if ((flags & DSACT_F_DATA_PARALLEL) && !h->comm) return fail(h, DSACT_E_STATE, "DSACT_F_DATA_PARALLEL needs dsact_comm_init");
   // (data parallel: only on the chain path, whose packed copies k_pack can rebuild after the streaming optimiser)
   const bool merged = !h->cnn && h->use_w1p && h->dw_chunks == 1 && !h->use_fork && !h->use_std_sums && h->alt_ws != nullptr &&
                       !h->env_no_merged_gather && (!(flags & DSACT_F_DATA_PARALLEL) || h->chain_ok);
@@ -4233,7 +4348,7 @@ int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) 
     for (int ph = 0; ph < D && rc == DSACT_OK; ++ph) rc = capture_updates_pipe(h, steps_per_graph, ph, &h->pgraph[ph], &h->pexec[ph], &h->pargs[ph], flags);
     h->pipe_graph = rc == DSACT_OK;
     if (rc != DSACT_OK) {   // (e.g. out of memory for the extra minibatch sets): the plain graph serves the same contract
-      drop_graphs(h);
+      drop_active_graph(h);   // the partially built pipelined graph only: cached graphs of other shapes stay
       (void)hipGetLastError();
       if (h->pipe_ws) apply_pipe_set(h, 0);   // (set 0 = the workspace's own buffers, recorded once the extra sets exist)
       rc = DSACT_OK;
@@ -4243,7 +4358,7 @@ int dsact_graph_build(dsact_handle* h, int32_t steps_per_graph, uint32_t flags) 
     rc = capture_updates(h, steps_per_graph, flags, merged, &h->graph, &h->graph_exec);
   }
   h->profiling = was_prof;
-  if (rc != DSACT_OK) { drop_graphs(h); return rc; }
+  if (rc != DSACT_OK) { if (h->build_keeps_cache) drop_active_graph(h); else drop_graphs(h); return rc; }
   h->graph_steps = steps_per_graph;
   h->graph_flags = flags;
   h->have_batch = true;
@@ -4291,7 +4406,7 @@ int dsact_graph_run(dsact_handle* h, int64_t first_iteration, int64_t n_steps) {
   TRY(set_device_iteration(h, first_iteration));
   TRY(launch_groups(h, first_iteration, n_steps / h->graph_steps));
   h->dev_it_next = first_iteration + n_steps;
-  return DSACT_OK;
+  return policy_moved(h);
 }
 
 // The reference's loop between two sampler calls (training/trainer.py:63-82 with sample_interval = n_steps: the CNN examples run 8,
@@ -4375,7 +4490,7 @@ int dsact_run_group(dsact_handle* h, int64_t first_iteration, int32_t n_steps, c
   TRY(launch_groups(h, first_iteration, 1));
   h->dev_it_next = first_iteration + n_steps;
   h->have_batch = true;
-  return DSACT_OK;
+  return policy_moved(h);
 }
 
 int dsact_dp_begin(dsact_handle* h, int64_t first_iteration) {
@@ -4416,7 +4531,7 @@ int dsact_dp_set_strict(dsact_handle* h, float* std_sums_dev) {
   if (!h) return DSACT_E_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (have_graph(h)) return fail(h, DSACT_E_STATE, "data-parallel mode is baked into the captured graph");
+  if (any_graph(h)) return fail(h, DSACT_E_STATE, "data-parallel mode is baked into the captured graph");
   if (!h->std_sums_own) h->std_sums_own = h->std_sums;
   h->use_std_sums = std_sums_dev != nullptr;
   h->std_sums = std_sums_dev ? std_sums_dev : h->std_sums_own;
@@ -4462,7 +4577,7 @@ int dsact_comm_unique_id(const char* rccl_path, uint8_t id[128]) {
 int dsact_comm_init(dsact_handle* h, int32_t rank, int32_t world, const uint8_t id[128], const char* rccl_path) {
   if (!h || !id || world < 1 || rank < 0 || rank >= world) return DSACT_E_INVALID;
   HIPCHK(h, hipSetDevice(h->device));
-  if (have_graph(h)) return fail(h, DSACT_E_STATE, "the communicator is baked into the captured graph");
+  if (any_graph(h)) return fail(h, DSACT_E_STATE, "the communicator is baked into the captured graph");
   if (const char* e = rccl_load(rccl_path)) return fail(h, DSACT_E_STATE, "%s", e);
   if (h->comm) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
   NcclUid u;
@@ -4576,6 +4691,7 @@ int dsact_time_steps(dsact_handle* h, int64_t first_iteration, int64_t n_steps, 
   }
   HIPCHK(h, hipEventElapsedTime(ms_total, h->tev0, h->tev1));
   h->have_batch = true;   // the last update's minibatch stays staged
+  h->pol_epoch++;         // (measurement entry point: the acting snapshot is refreshed lazily by the next acting call)
   return check_handoff(h);
 }
 
@@ -4610,6 +4726,7 @@ int dsact_time_stage(dsact_handle* h, int32_t stage, int32_t reps, float* ms_tot
 
 int dsact_profile_step(dsact_handle* h, int64_t iteration, uint32_t flags, dsact_kernel_time* out, int32_t cap, int32_t* n) {
   if (!h || !out || !n) return DSACT_E_INVALID;
+  h->pol_epoch++;
   TRY(check_ready(h, false));
   if (!h->idx_table) return fail(h, DSACT_E_STATE, "upload an index table first");
   HIPCHK(h, hipSetDevice(h->device));
@@ -4640,6 +4757,7 @@ int dsact_profile_step(dsact_handle* h, int64_t iteration, uint32_t flags, dsact
 // pipelined sequence when that is what it would capture -- with start/stop events on every dispatch
 int dsact_profile_steps(dsact_handle* h, int64_t first_iteration, int32_t n_steps, uint32_t flags, dsact_kernel_time* out, int32_t cap, int32_t* n) {
   if (!h || !out || !n || n_steps < 1) return DSACT_E_INVALID;
+  h->pol_epoch++;
   TRY(check_ready(h, false));
   if (!h->idx_table) return fail(h, DSACT_E_STATE, "upload an index table first");
   HIPCHK(h, hipSetDevice(h->device));
@@ -4782,6 +4900,22 @@ int dsact_debug_set(dsact_handle* h, const char* name, double value) {
     if (h->twin && h->online) TRY(build_twin_fwd(h));   // (the twin-trunk forward reads the switch from its device-memory table)
     return DSACT_OK;
   }
+  if (!strcmp(name, "raise_handoff_word")) {   // tests: what a timed-out waiter writes -- bit 0: an update kernel's word, bit 1: the acting forward's
+    if (!h->handoff_host) return fail(h, DSACT_E_STATE, "no hand-off words");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if ((int)value & 1) ((volatile int*)h->handoff_host)[0] = 1;
+    if ((int)value & 2) ((volatile int*)h->handoff_host)[1] = 1;
+    return DSACT_OK;
+  }
+  if (!strcmp(name, "host_act")) {      // 1: acting forward on the host (default), 0: the one-launch GPU forward (A/B, tests)
+    h->host_act = value != 0.0;
+    h->pol_epoch++;
+    return DSACT_OK;
+  }
+  if (!strcmp(name, "policy_dirty")) {  // the caller wrote policy parameters itself (torch ops on the arena: load_state_dict, ...)
+    h->pol_epoch++;
+    return DSACT_OK;
+  }
   if (!strcmp(name, "ack_state")) {     // the caller restored (or accepts) the device state after a hand-over timeout
     h->state_invalid = false;
     return DSACT_OK;
@@ -4822,12 +4956,18 @@ int dsact_debug_set(dsact_handle* h, const char* name, double value) {
   return fail(h, DSACT_E_INVALID, "dsact_debug_set: unknown name '%s'", name);
 }
 
-static bool act_fast_ok(const dsact_handle* h);
 int dsact_debug_get(const dsact_handle* h, const char* name, double* value) {
   if (!h || !name || !value) return DSACT_E_INVALID;
   if (!strcmp(name, "fwd_merge")) *value = h->fwd_merge ? 1.0 : 0.0;
   else if (!strcmp(name, "pi_merge")) *value = h->pi_merge ? 1.0 : 0.0;
   else if (!strcmp(name, "act_launch_us")) *value = h->act_launch_us;
+  else if (!strcmp(name, "act_host")) *value = act_host_ok(h) ? 1.0 : 0.0;
+  else if (!strcmp(name, "act_host_us")) *value = h->act_host_us;
+  else if (!strcmp(name, "act_host_threads")) *value = (double)h->act_threads;
+  else if (!strcmp(name, "act_host_isa")) *value = (double)hostact::cpu_isa();
+  else if (!strcmp(name, "act_copy_wait_us")) *value = h->act_copy_wait_us;
+  else if (!strcmp(name, "act_host_calls")) *value = (double)h->act_host_calls;
+  else if (!strcmp(name, "act_copies")) *value = (double)h->act_copies;
   else if (!strcmp(name, "act_wait_us")) *value = h->act_wait_us;
   else if (!strcmp(name, "fat")) *value = (h->fat ? 1.0 : 0.0) + (h->fat_bwd ? 2.0 : 0.0);
   else if (!strcmp(name, "handoff_failures")) *value = (double)h->handoff_failures;
@@ -4865,7 +5005,7 @@ static int act_forward_fast(dsact_handle* h, const float* obs_host, const float*
   }
   a.h = h->act_h; a.call = ++h->act_call;
   a.A = h->A; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std; a.act = h->cfg.policy_act;
-  a.out = h->act_out_dev; a.timeout = h->handoff_dev;
+  a.out = h->act_out_dev; a.timeout = h->handoff_dev + 1;   // the acting forward's own hand-off word (check_handoff)
   a.sample = eps ? 1 : 0; a.act_scale = h->act_scale; a.act_center = h->act_center;
   if (eps) memcpy(a.eps, eps, (size_t)h->A * sizeof(float));
   memcpy(a.x, obs_host, (size_t)h->O * sizeof(float));
@@ -4909,6 +5049,7 @@ int dsact_act_sample(dsact_handle* h, const float* obs_host, const float* eps_ho
   if (!h->limits_set) return fail(h, DSACT_E_STATE, "action limits not set (dsact_set_action_limits)");
   if (!act_fast_ok(h)) return fail(h, DSACT_E_INVALID, "dsact_act_sample serves MLP policies with obs <= %d floats", kActMaxObs);
   HIPCHK(h, hipSetDevice(h->device));
+  if (act_host_ok(h)) return act_forward_host(h, obs_host, eps_host, action_host, logp_host);   // dsact_host_act.h
   float out[64];
   TRY(act_forward_fast(h, obs_host, eps_host, out));
   const int A = h->A;
@@ -4924,6 +5065,7 @@ int dsact_policy_forward(dsact_handle* h, const float* obs_host, int32_t n, floa
   if (!h->online) return fail(h, DSACT_E_STATE, "arenas not bound");
   HIPCHK(h, hipSetDevice(h->device));
   const size_t O = h->O, ld = h->ldx;
+  if (n == 1 && act_host_ok(h)) return act_forward_host(h, obs_host, nullptr, logits_host, nullptr);   // on the calling thread (dsact_host_act.h)
   if (n == 1 && act_fast_ok(h)) return act_forward_fast(h, obs_host, nullptr, logits_host);   // one launch (dsact_act.h)
   if (h->cnn) {
     // conv stack of the online policy on n images: (C,H,W) rows -> pixel-major -> conv layers -> feature rows

@@ -1,0 +1,272 @@
+// dsact_host_act.h -- the sampler's batch-1 acting forward ON THE HOST (SURVEY.md section 8 f1's other branch: "policy-weights
+// snapshot for acting"; reference training/off_sampler.py:46-56, networks/mlp.py:79-100, utils/act_distribution_cls.py:32-42).
+//
+// The reference acts with a CPU copy of the whole module (ModuleOnDevice, utils/common_utils.py:164-177). The one-launch GPU
+// forward of dsact_act.h costs a launch + a completion spin per ENVIRONMENT STEP (3.5 + 21 us measured, twenty times per
+// iteration: 89 % of an iteration at sample_interval 1). Here the policy net (0.95 MB at Humanoid 3x256) is copied
+// into pinned host memory on the handle's stream right behind every enqueued update that moves it, and dsact_act_sample /
+// dsact_policy_forward(n = 1) run the forward on the host once that copy's event has fired: same semantics as the reference
+// (acts with the weights of the last completed update), no launch, no spin, and environment steps that follow an update which
+// leaves the policy alone overlap with it.
+//
+// Arithmetic: fp32, the closed forms of dsact_math.h (erf_2fit's two-interval GELU, tanh_gauss_fwd term for term); a dense
+// layer is a row-major [N][K] matrix-vector product, two vector accumulators per row, rows in groups of four; the summation
+// order differs from k_act_mlp's (64 lanes + a wave reduction) and from the reference's sgemv -- within the gates of
+// tests/test_reference_differential.py like the GPU forward. Three instantiations of one source: 512-bit (avx512f), 256-bit
+// (avx2 + fma), baseline x86-64; an output row is computed by ONE thread in ONE fixed order, so the result does not depend on
+// how many threads share a layer (Pool below) -- only on the vector width the CPU offers.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "dsact_math.h"
+
+namespace dsact {
+namespace hostact {
+
+struct Layer { const float* W; const float* b; int K, N; };
+
+#if defined(__clang__)
+#define DSACT_HOSTACT_CONTRACT _Pragma("clang fp contract(fast)")
+#else
+#define DSACT_HOSTACT_CONTRACT
+#endif
+
+// ---- one instantiation: VB = bytes of a vector, ATTR = the function attribute that selects the instruction set.
+//   exp2_neg: 2^x for x <= 0 (the only range erf_2fit's exponential sees): x = n + r, r in (-1, 0], degree-6 fit of 2^r
+//             (Chebyshev-node fit in double, rounded to fp32: 1.9e-7 relative), 2^n through the exponent field; x < -126 -> 2^-126
+//   erfv:     erf_2fit (dsact_math.h) on a vector, same coefficients, same interval split
+//   dense:    y[n] = b[n] + sum_k W[n][k] x[k] for rows [n0, n1) (n0 a multiple of 4)
+//   gelu_inplace over [i0, i1) (multiples of the lane count; the buffers are padded)
+#define DSACT_HOSTACT_BODY(ATTR, VB)                                                                                              \
+  typedef float vf __attribute__((vector_size(VB)));                                                                              \
+  typedef int vi __attribute__((vector_size(VB)));                                                                                \
+  constexpr int VL = VB / 4;                                                                                                      \
+  ATTR static inline vf exp2_neg(vf x) {                                                                                          \
+    const vf lo = vf{} - 126.f;                                                                                                   \
+    x = x < lo ? lo : x;                                                                                                          \
+    const vi n = __builtin_convertvector(x, vi);                    /* truncation: ceil for x <= 0 */                              \
+    const vf r = x - __builtin_convertvector(n, vf);                                                                              \
+    vf p = r * 1.0938752530e-04f + 1.2757162331e-03f;                                                                             \
+    p = p * r + 9.5800580457e-03f;                                                                                                \
+    p = p * r + 5.5491033942e-02f;                                                                                                \
+    p = p * r + 2.4022436142e-01f;                                                                                                \
+    p = p * r + 6.9314706326e-01f;                                                                                                \
+    p = p * r + 1.0f;                                                                                                             \
+    vi bits;                                                                                                                      \
+    memcpy(&bits, &p, sizeof(bits));                                                                                              \
+    bits += n << 23;                                                                                                              \
+    memcpy(&p, &bits, sizeof(p));                                                                                                 \
+    return p;                                                                                                                     \
+  }                                                                                                                               \
+  ATTR static inline vf erfv(vf x) {                                                                                              \
+    const vf ax = x < 0.f ? -x : x;                                                                                               \
+    const vf hi = vf{} + kErfHi;                                                                                                  \
+    const vf t = ax > hi ? hi : ax;                                                                                               \
+    const vf s = x * x;                                                                                                           \
+    vf rs = s * kErfS[5] + kErfS[4];                                                                                              \
+    rs = rs * s + kErfS[3]; rs = rs * s + kErfS[2]; rs = rs * s + kErfS[1]; rs = rs * s + kErfS[0];                                \
+    const vf small = rs * x + x;                                                                                                  \
+    vf rl = t * kErfL[8] + kErfL[7];                                                                                              \
+    rl = rl * t + kErfL[6]; rl = rl * t + kErfL[5]; rl = rl * t + kErfL[4]; rl = rl * t + kErfL[3];                                \
+    rl = rl * t + kErfL[2]; rl = rl * t + kErfL[1]; rl = rl * t + kErfL[0];                                                        \
+    const vf e = exp2_neg((rl * t - t) * kLog2e);                                                                                 \
+    vf large = 1.0f - e;                                                                                                          \
+    large = x < 0.f ? -large : large;                                                                                             \
+    return t > kErfT0 ? large : small;                                                                                            \
+  }                                                                                                                               \
+  ATTR static inline float hsum(vf a) {                                                                                           \
+    float s[VL];                                                                                                                  \
+    memcpy(s, &a, sizeof(s));                                                                                                     \
+    for (int w = VL / 2; w >= 1; w /= 2)                                                                                          \
+      for (int i = 0; i < w; ++i) s[i] += s[i + w];                                                                               \
+    return s[0];                                                                                                                  \
+  }                                                                                                                               \
+  ATTR static void dense(const Layer& L, const float* x, float* y, int n0, int n1) {                                              \
+    DSACT_HOSTACT_CONTRACT                                                                                                        \
+    const int K = L.K, KV = K - K % (2 * VL);                                                                                     \
+    int n = n0;                                                                                                                   \
+    for (; n + 4 <= n1; n += 4) {                                                                                                 \
+      const float* w0 = L.W + (size_t)n * K;                                                                                      \
+      const float *w1 = w0 + K, *w2 = w1 + K, *w3 = w2 + K;                                                                       \
+      vf a0 = vf{}, a1 = a0, a2 = a0, a3 = a0, c0 = a0, c1 = a0, c2 = a0, c3 = a0;                                                \
+      for (int k = 0; k < KV; k += 2 * VL) {                                                                                      \
+        vf xa, xb, t;                                                                                                             \
+        memcpy(&xa, x + k, VB); memcpy(&xb, x + k + VL, VB);                                                                      \
+        memcpy(&t, w0 + k, VB); a0 += t * xa; memcpy(&t, w0 + k + VL, VB); c0 += t * xb;                                           \
+        memcpy(&t, w1 + k, VB); a1 += t * xa; memcpy(&t, w1 + k + VL, VB); c1 += t * xb;                                           \
+        memcpy(&t, w2 + k, VB); a2 += t * xa; memcpy(&t, w2 + k + VL, VB); c2 += t * xb;                                           \
+        memcpy(&t, w3 + k, VB); a3 += t * xa; memcpy(&t, w3 + k + VL, VB); c3 += t * xb;                                           \
+      }                                                                                                                           \
+      float s0 = hsum(a0 + c0), s1 = hsum(a1 + c1), s2 = hsum(a2 + c2), s3 = hsum(a3 + c3);                                       \
+      for (int k = KV; k < K; ++k) { const float xv = x[k]; s0 += w0[k] * xv; s1 += w1[k] * xv; s2 += w2[k] * xv; s3 += w3[k] * xv; } \
+      y[n] = s0 + L.b[n]; y[n + 1] = s1 + L.b[n + 1]; y[n + 2] = s2 + L.b[n + 2]; y[n + 3] = s3 + L.b[n + 3];                     \
+    }                                                                                                                             \
+    for (; n < n1; ++n) {                                                                                                         \
+      const float* w0 = L.W + (size_t)n * K;                                                                                      \
+      vf a0 = vf{}, c0 = a0;                                                                                                      \
+      for (int k = 0; k < KV; k += 2 * VL) {                                                                                      \
+        vf xa, xb, t;                                                                                                             \
+        memcpy(&xa, x + k, VB); memcpy(&xb, x + k + VL, VB);                                                                      \
+        memcpy(&t, w0 + k, VB); a0 += t * xa; memcpy(&t, w0 + k + VL, VB); c0 += t * xb;                                           \
+      }                                                                                                                           \
+      float s0 = hsum(a0 + c0);                                                                                                   \
+      for (int k = KV; k < K; ++k) s0 += w0[k] * x[k];                                                                            \
+      y[n] = s0 + L.b[n];                                                                                                         \
+    }                                                                                                                             \
+  }                                                                                                                               \
+  ATTR static void gelu_inplace(float* y, int i0, int i1) {                                                                       \
+    DSACT_HOSTACT_CONTRACT                                                                                                        \
+    for (int i = i0; i < i1; i += VL) {                                                                                           \
+      vf z;                                                                                                                       \
+      memcpy(&z, y + i, VB);                                                                                                      \
+      const vf cdf = erfv(z * kInvSqrt2) * 0.5f + 0.5f;                                                                           \
+      z = z * cdf;                                                                                                                \
+      memcpy(y + i, &z, VB);                                                                                                      \
+    }                                                                                                                             \
+  }                                                                                                                               \
+  /* rows [n0, n1) of a layer (n0, n1 multiples of 16 or the layer's end) + its hidden activation */                             \
+  ATTR static void layer_rows(const Layer& L, int act, bool hidden, const float* x, float* y, int n0, int n1) {                   \
+    dense(L, x, y, n0, n1);                                                                                                       \
+    if (!hidden) return;                                                                                                          \
+    const int np = (n1 + 15) & ~15;                     /* (the last chunk also owns the padding behind the layer's end) */       \
+    for (int i = n1; i < np; ++i) y[i] = 0.f;                                                                                     \
+    if (act == ACT_GELU) gelu_inplace(y, n0, np);                                                                                 \
+    else for (int i = n0; i < n1; ++i) { float hv, gd; act_fwd_grad(act, y[i], hv, gd); y[i] = hv; }                              \
+    for (int i = n1; i < np; ++i) y[i] = 0.f;                                                                                     \
+  }
+
+namespace avx512 {
+DSACT_HOSTACT_BODY(__attribute__((target("avx512f,fma"))), 64)
+}  // namespace avx512
+namespace avx2 {
+DSACT_HOSTACT_BODY(__attribute__((target("avx2,fma"))), 32)
+}  // namespace avx2
+namespace base {
+DSACT_HOSTACT_BODY(, 32)
+}  // namespace base
+#undef DSACT_HOSTACT_BODY
+
+enum : int { ISA_BASE = 0, ISA_AVX2 = 1, ISA_AVX512 = 2 };
+inline int cpu_isa() {
+  static const int isa = (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("fma")) ? ISA_AVX512
+                         : (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) ? ISA_AVX2 : ISA_BASE;
+  return isa;
+}
+inline bool cpu_has_avx2_fma() { return cpu_isa() >= ISA_AVX2; }
+inline void layer_rows(int isa, const Layer& L, int act, bool hidden, const float* x, float* y, int n0, int n1) {
+  if (isa == ISA_AVX512) avx512::layer_rows(L, act, hidden, x, y, n0, n1);
+  else if (isa == ISA_AVX2) avx2::layer_rows(L, act, hidden, x, y, n0, n1);
+  else base::layer_rows(L, act, hidden, x, y, n0, n1);
+}
+
+// ---- a small fork-join pool for the wide layers: the caller is worker 0, T - 1 helpers spin for the next layer while a burst
+// of acting calls lasts (an environment step between two calls is microseconds) and go to sleep on a condition variable when
+// none has come for ~200 us. A layer's rows are dealt in contiguous chunks of multiples of 16; chunk boundaries do not change
+// any row's arithmetic. Not created at all for T == 1 (DSACT_HOST_ACT_THREADS=1).
+class Pool {
+ public:
+  explicit Pool(int threads) : T_(threads < 1 ? 1 : threads) {
+    for (int i = 1; i < T_; ++i) th_.emplace_back([this, i] { run(i); });
+  }
+  ~Pool() {
+    stop_.store(true);
+    gen_.fetch_add(1);
+    { std::lock_guard<std::mutex> g(m_); }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  int threads() const { return T_; }
+  // rows [0, N) of layer L on all workers; returns when every row is written
+  void layer(int isa, const Layer& L, int act, bool hidden, const float* x, float* y) {
+    const int per = (((L.N + T_ - 1) / T_) + 15) & ~15;
+    if (T_ == 1 || L.N < 64 || per >= L.N) { layer_rows(isa, L, act, hidden, x, y, 0, L.N); return; }
+    job_ = Job{isa, &L, act, hidden, x, y, per};
+    done_.store(0, std::memory_order_relaxed);
+    gen_.fetch_add(1);                                   // (seq_cst: publishes job_, orders against sleepers_ below)
+    if (sleepers_.load() > 0) { { std::lock_guard<std::mutex> g(m_); } cv_.notify_all(); }
+    slice(0);
+    while (done_.load(std::memory_order_acquire) < T_ - 1) __builtin_ia32_pause();
+  }
+
+ private:
+  struct Job { int isa; const Layer* L; int act; bool hidden; const float* x; float* y; int per; };
+  void slice(int id) {
+    const Job j = job_;
+    const int n0 = id * j.per, n1 = n0 + j.per < j.L->N ? n0 + j.per : j.L->N;
+    if (n0 < n1) layer_rows(j.isa, *j.L, j.act, j.hidden, j.x, j.y, n0, n1);
+  }
+  void run(int id) {
+    unsigned seen = 0;
+    for (;;) {
+      int spins = 0;
+      while (gen_.load(std::memory_order_acquire) == seen) {
+        __builtin_ia32_pause();
+        if (++spins > 20000) {                           // ~200 us without work: sleep until the next burst
+          std::unique_lock<std::mutex> lk(m_);
+          sleepers_.fetch_add(1);
+          cv_.wait(lk, [&] { return gen_.load() != seen || stop_.load(); });
+          sleepers_.fetch_sub(1);
+          spins = 0;
+        }
+      }
+      seen = gen_.load(std::memory_order_acquire);
+      if (stop_.load()) return;
+      slice(id);
+      done_.fetch_add(1, std::memory_order_release);
+    }
+  }
+  const int T_;
+  std::vector<std::thread> th_;
+  std::atomic<unsigned> gen_{0};
+  std::atomic<int> done_{0}, sleepers_{0};
+  std::atomic<bool> stop_{false};
+  std::mutex m_;
+  std::condition_variable cv_;
+  Job job_{};
+};
+
+// hidden layers + the output layer's raw products: out[0 .. N_last). buf0 / buf1: activation buffers of >= widest layer + 64
+// floats. pool == nullptr: everything on the calling thread.
+inline void forward(const Layer* ly, int n_layers, int act, const float* obs, float* buf0, float* buf1, float* out, Pool* pool = nullptr,
+                    int isa = -1) {
+  if (isa < 0) isa = cpu_isa();
+  const float* x = obs;
+  float* nxt = buf0;
+  for (int l = 0; l < n_layers; ++l) {
+    const bool hidden = l + 1 < n_layers;
+    float* y = hidden ? nxt : out;
+    if (pool) pool->layer(isa, ly[l], act, hidden, x, y);
+    else layer_rows(isa, ly[l], act, hidden, x, y, 0, ly[l].N);
+    x = y;
+    nxt = nxt == buf0 ? buf1 : buf0;
+  }
+}
+
+// dsact_act_sample on the host: policy(obs) + TanhGaussDistribution.sample() (utils/act_distribution_cls.py:32-42) with the
+// caller's N(0,1) draw -- tanh_gauss_fwd of dsact_math.h term for term, as k_act_mlp's sample mode. raw: the output layer's
+// 2A products (mean | raw log-std). eps == nullptr: out = the 2A logits (mean | exp(clamp(raw))) of StochaPolicy.forward
+// (networks/mlp.py:85-100); else action[A] and the summed log-probability.
+inline void head(const float* raw, int A, float lo_ls, float hi_ls, const float* eps, const float* scale, const float* center,
+                 float* action_or_logits, float* logp) {
+  if (!eps) {
+    for (int d = 0; d < A; ++d) { action_or_logits[d] = raw[d]; action_or_logits[A + d] = expf(clampf(raw[A + d], lo_ls, hi_ls)); }
+    return;
+  }
+  float lp = 0.0f;
+  for (int d = 0; d < A; ++d) {
+    const TanhGaussFwd f = tanh_gauss_fwd(raw[d], raw[A + d], eps[d], scale[d], center[d], lo_ls, hi_ls);
+    action_or_logits[d] = f.a;
+    lp += f.lp;            // Independent(..., 1): sum over the action dimensions, in order
+  }
+  *logp = lp;
+}
+
+}  // namespace hostact
+}  // namespace dsact

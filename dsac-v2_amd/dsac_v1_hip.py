@@ -156,6 +156,8 @@ class DSAC_V1_HIP(_v2.DSAC_V2_HIP):
             policy_act=_v2.ACTIVATIONS[kwargs.get("policy_hidden_activation", "gelu")][0])
         self.networks.attach(self.engine)
         register_engine(self.engine)
+        if not kwargs.get("hip_host_act", True):   # (see DSAC_V2_HIP: host-side acting forward on / off)
+            self.engine.debug_set("host_act", 0)
         if not self.strict_rng:
             seed = kwargs.get("seed") or 0
             self.engine.set_device_rng((int(seed) * 0x9E3779B97F4A7C15 + 0x1234567) % (1 << 63) or 1)

@@ -174,6 +174,7 @@ class HipStochaPolicy(nn.Module):
     def forward(self, obs):
         if self._engine is not None:
             # parameters live in the HIP arena: the fused-MLP kernels serve the forward
+            self._engine.note_torch_writes(self.parameters())
             lg = self._engine.policy_forward(obs.detach().cpu().numpy())
             return torch.from_numpy(lg).reshape(*obs.shape[:-1], lg.shape[-1]).to(obs.device)
         if self.std_type == "parameter":
@@ -419,6 +420,7 @@ class ApproxContainer(nn.Module):
             torch.cuda.current_stream(self._engine.device).synchronize()   # torch's copies land before the next update
             self._engine.set_action_limits(self.policy.act_high_lim.cpu().numpy(),
                                            self.policy.act_low_lim.cpu().numpy())
+            self._engine.policy_dirty()   # the host-side acting snapshot follows the loaded weights
         return out
 
     def state_dict(self, *a, **k):
@@ -647,6 +649,11 @@ class DSAC_V2_HIP:
             policy_hidden=_policy_hidden_sizes(kwargs))
         self.networks.attach(self.engine)
         register_engine(self.engine)
+        # additive: `hip_host_act` (default True) -- the sampler's / evaluator's batch-1 policy forward runs on the host from a
+        # pinned snapshot of the policy net refreshed behind every update that moves it (csrc/dsact_host_act.h); False keeps the
+        # one-launch GPU forward (csrc/dsact_act.h)
+        if not kwargs.get("hip_host_act", True):
+            self.engine.debug_set("host_act", 0)
         if not self.strict_rng:
             seed = kwargs.get("seed") or 0
             self.engine.set_device_rng((int(seed) * 0x9E3779B97F4A7C15 + 0x1234567) % (1 << 63) or 1)

@@ -452,6 +452,19 @@ class DsactEngine:
         self._chk(self._lib.dsact_debug_get(self._h, name.encode(), C.byref(v)))
         return float(v.value)
 
+    def policy_dirty(self):
+        """the caller wrote policy parameters with torch ops on the arena (load_state_dict, a manual copy_): the host-side
+        acting snapshot (csrc/dsact_host_act.h) is refreshed before the next acting call"""
+        self._chk(self._lib.dsact_debug_set(self._h, b"policy_dirty", 1.0))
+
+    def note_torch_writes(self, params):
+        """torch bumps a tensor's version counter on every in-place write: a changed sum over the policy's parameters
+        since the last look means somebody wrote them outside the library"""
+        v = sum(p._version for p in params)
+        if v != getattr(self, "_param_versions", None):
+            self._param_versions = v
+            self.policy_dirty()
+
     def act_sample(self, obs, eps):
         """dsact_act_sample: (action float32[A], logp float) of TanhGaussDistribution.sample() for ONE observation with the
         caller's N(0,1) draw eps[A]; obs / eps are contiguous float32 arrays (no copies are made here)"""
@@ -464,6 +477,18 @@ class DsactEngine:
         if rc != 0:
             self._chk(rc)
         return self._act_out, self._act_lp
+
+    def act_sample_addr(self, obs_addr: int, eps_addr: int, act_addr: int, logp_addr: int):
+        """dsact_act_sample on plain integer addresses (the sampler's per-step call: no array or pointer objects are made;
+        results land in the caller's rows). A second binding of the same symbol whose arguments are void*."""
+        f = getattr(self, "_act_addr_fn", None)
+        if f is None:
+            f = self._lib["dsact_act_sample"]          # a fresh function object: its argtypes are its own
+            f.restype, f.argtypes = C.c_int, [C.c_void_p] * 5
+            self._act_addr_fn = f
+        rc = f(self._h, obs_addr, eps_addr, act_addr, logp_addr)
+        if rc != 0:
+            self._chk(rc)
 
     def policy_forward(self, obs) -> np.ndarray:
         obs = _f32(obs).reshape(-1, self.obs_dim)

@@ -106,30 +106,46 @@ class HipOffSampler:
         O, A = eng.obs_dim, eng.act_dim
         obs_b, obs2_b = np.empty((n, O), np.float32), np.empty((n, O), np.float32)
         act_b = np.empty((n, A), np.float32)
+        clip_b = np.empty((n, A), np.float32)
         rew_b, done_b, logp_b = np.empty(n, np.float32), np.empty(n, np.float32), np.empty(n, np.float32)
         low, high = env.action_space.low, env.action_space.high
         batch = SampleBatch()
-        randn, act_sample, scale = torch.randn, eng.act_sample, self.reward_scale
+        append, step, scale = batch.append, env.step, self.reward_scale
         obs, info = self.obs, self.info
         self._fast_started = False
+        eng.note_torch_writes(self.networks.policy.parameters())   # (host-side acting: weights written with torch ops since the last call)
+        # per-step host work is what this loop costs once the acting forward runs on the host (csrc/dsact_host_act.h: ~2-9 us per
+        # call): row views and their addresses are made once per call, the N(0,1) draw lands in ONE reused tensor
+        # (torch.randn(1, A, out=...) consumes the generator exactly as torch.randn(1, A) does), the action is clipped with two
+        # ufunc calls into a preallocated row (np.clip's wrapper costs more than the clip)
+        eps_t = torch.empty(1, A)
+        randn = torch.randn
+        # plain integer addresses: the binding used here takes void* arguments, so no ctypes pointer object is made per step
+        eps_a, obs_a, act_a, logp_a = eps_t.data_ptr(), obs_b.ctypes.data, act_b.ctypes.data, logp_b.ctypes.data
+        obs_s, act_s = 4 * O, 4 * A
+        act_into = eng.act_sample_addr
+        flat = np.ndim(obs) == 1
+        maximum, minimum = np.maximum, np.minimum
         for i in range(n):
             ob = obs_b[i]
-            ob[:] = np.reshape(obs, -1)
-            eps = randn(1, A).numpy()
-            action, logp = act_sample(ob, eps)
+            ob[:] = obs if flat else np.reshape(obs, -1)
+            randn(1, A, out=eps_t)
+            act_into(obs_a + i * obs_s, eps_a, act_a + i * act_s, logp_a + 4 * i)
             self._fast_started = True     # (an environment step follows: no silent fallback from here on)
-            act_b[i] = action
-            logp_b[i] = logp[0]
-            next_obs, reward, done, next_info = env.step(np.clip(act_b[i], low, high))
+            a_i, c_i = act_b[i], clip_b[i]
+            minimum(maximum(a_i, low, out=c_i), high, out=c_i)
+            next_obs, reward, done, next_info = step(c_i)
             truncated = bool(next_info.get("TimeLimit.truncated", False))
             next_info["TimeLimit.truncated"] = truncated
             if truncated:
                 done = False  # time-outs are stored as non-terminal (off_sampler.py:70-73)
-            obs2_b[i] = np.reshape(next_obs, -1)
-            rew_b[i] = scale * reward
+            ob2 = obs2_b[i]
+            ob2[:] = next_obs if flat else np.reshape(next_obs, -1)
+            r = scale * reward
+            rew_b[i] = r
             done_b[i] = done
-            batch.append((ob.reshape(np.shape(obs)), info, act_b[i], scale * reward, obs2_b[i].reshape(np.shape(next_obs)), done,
-                          logp_b[i], next_info))
+            append((ob if flat else ob.reshape(np.shape(obs)), info, a_i, r, ob2 if flat else ob2.reshape(np.shape(next_obs)), done,
+                    logp_b[i], next_info))
             obs, info = next_obs, next_info
             if done or truncated:
                 obs, info = _reset(env)

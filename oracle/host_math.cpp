@@ -40,3 +40,31 @@ void hm_out_act(int act, float z, float* y, float* dy) {   // output activations
   *dy = dsact::out_act_grad_y(act, *y);
 }
 }
+
+// the host-side acting forward of the product (dsac-v2_amd/csrc/dsact_host_act.h: the sampler's batch-1 policy forward on the
+// calling thread) over a flat parameter vector in arena order, for tests/test_host_math.py
+#include "dsact_host_act.h"
+extern "C" {
+int hm_policy_act(const float* params, int n_layers, const int* k_in, const int* n_out, const long long* w_off,
+                  const long long* b_off, int act, const float* obs, int A, float lo_ls, float hi_ls, const float* eps,
+                  const float* scale, const float* center, float* out, float* logp, int isa, int threads) {
+  // isa: -1 = what the CPU offers, 0 baseline x86-64, 1 avx2 + fma, 2 avx512f (refused with -2 when the CPU lacks it)
+  dsact::hostact::Layer ly[8];
+  if (n_layers > 8) return -1;
+  if (isa > dsact::hostact::cpu_isa()) return -2;
+  int widest = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    ly[l].W = params + w_off[l]; ly[l].b = params + b_off[l]; ly[l].K = k_in[l]; ly[l].N = n_out[l];
+    if (n_out[l] > widest) widest = n_out[l];
+  }
+  float* buf = new float[3 * (widest + 64)];
+  float* raw = buf + 2 * (widest + 64);
+  {
+    dsact::hostact::Pool pool(threads);
+    dsact::hostact::forward(ly, n_layers, act, obs, buf, buf + widest + 64, raw, threads > 1 ? &pool : nullptr, isa);
+  }
+  dsact::hostact::head(raw, A, lo_ls, hi_ls, eps, scale, center, out, logp);
+  delete[] buf;
+  return dsact::hostact::cpu_isa();
+}
+}

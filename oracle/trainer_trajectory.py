@@ -75,7 +75,7 @@ VARIANTS = {
     # synth_blob_data.py), whole groups of 8 between host-side events, batch 16 (the smallest the twin-trunk chain units take)
     "cnn_si8": dict(env_id="synth_blob", value_func_type="CNN", policy_func_type="CNN", value_conv_type="type_2", policy_conv_type="type_2",
                     value_hidden_sizes=[256, 256, 256], policy_hidden_sizes=[256, 256, 256], sample_interval=8, sample_batch_size=8,
-                    replay_batch_size=16, buffer_warm_size=24, buffer_max_size=48, max_iteration=24, log_save_interval=8,
+                    replay_batch_size=16, buffer_warm_size=24, buffer_max_size=48, max_iteration=32, log_save_interval=16,
                     eval_interval=16, apprfunc_save_interval=24, num_eval_episode=1, max_episode_steps=20),
 }
 

@@ -151,3 +151,75 @@ def test_gauss_distribution_branch(hm):
     np.testing.assert_allclose(dmu, f32(mu.grad), atol=2e-5 * float(np.abs(f32(mu.grad)).max()) + 1e-5, rtol=0)
     np.testing.assert_allclose(draw, f32(raw.grad), atol=2e-5 * float(np.abs(f32(raw.grad)).max()) + 1e-5, rtol=1e-5)
 
+
+
+@pytest.mark.parametrize("O,A,hid,act", [(376, 17, (256, 256, 256), "gelu"), (3, 1, (64, 64), "gelu"), (23, 5, (96, 40), "gelu"),
+                                         (11, 3, (33,), "tanh"), (16, 4, (64, 64, 64, 64), "relu")])
+def test_host_acting_forward_and_sampling_step(hm, O, A, hid, act):
+    """csrc/dsact_host_act.h -- the sampler's batch-1 policy forward + TanhGaussDistribution.sample() on the host (SURVEY 8 f1;
+    reference training/off_sampler.py:46-56, networks/mlp.py:79-100, utils/act_distribution_cls.py:32-42) -- against the torch
+    CPU module the reference acts with: logits within fp32 summation-order noise, the action and log-prob of the same N(0,1)
+    draw at the gates of the GPU acting forward's test. Every instantiation the CPU offers (512-bit, 256-bit FMA, baseline x86-64) and
+    the fork-join pool (3 / 4 threads: bitwise the single-thread result)."""
+    import torch.nn as nn
+
+    acts = {"gelu": (0, nn.GELU), "relu": (1, nn.ReLU), "tanh": (5, nn.Tanh)}
+    torch.manual_seed(5)
+    sizes = [O] + list(hid) + [2 * A]
+    layers = []
+    for j in range(len(sizes) - 1):
+        layers += [nn.Linear(sizes[j], sizes[j + 1]), acts[act][1]() if j < len(sizes) - 2 else nn.Identity()]
+    net = nn.Sequential(*layers)
+    flat, w_off, b_off, k_in, n_out = [], [], [], [], []
+    off = 0
+    for m in net:
+        if isinstance(m, nn.Linear):
+            w_off.append(off); flat.append(f32(m.weight).reshape(-1)); off += m.weight.numel()
+            b_off.append(off); flat.append(f32(m.bias)); off += m.bias.numel()
+            k_in.append(m.in_features); n_out.append(m.out_features)
+    params = np.concatenate(flat)
+    L = len(k_in)
+    lim, lo_ls, hi_ls = 0.4, -20.0, 0.5
+    scale, center = np.full(A, lim, np.float32), np.zeros(A, np.float32)
+    rng = np.random.default_rng(1)
+    IA, LA = (C.c_int * L), (C.c_longlong * L)
+    for i in range(12):
+        obs = (2.0 * rng.standard_normal(O)).astype(np.float32)
+        with torch.no_grad():
+            raw = net(torch.from_numpy(obs)[None].double().float())
+            raw64 = net.double()(torch.from_numpy(obs)[None].double()); net.float()
+        mean, std = raw[0, :A], torch.clamp(raw[0, A:], lo_ls, hi_ls).exp()
+        torch.manual_seed(100 + i)
+        eps = torch.randn(1, A)
+        hm.hm_policy_act.argtypes = [FP, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
+                                     C.c_int, FP, C.c_int, C.c_float, C.c_float, FP, FP, FP, FP, FP, C.c_int, C.c_int]
+        per_isa = {}
+        for isa, threads in ((0, 1), (1, 1), (2, 1), (-1, 3), (0, 4)):
+            logits = np.empty(2 * A, np.float32)
+            rc = hm.hm_policy_act(p(params), L, IA(*k_in), IA(*n_out), LA(*w_off), LA(*b_off), acts[act][0], p(obs), A, lo_ls, hi_ls,
+                                  None, p(scale), p(center), p(logits), None, isa, threads)
+            if rc == -2:
+                continue                     # this CPU lacks the instruction set
+            assert rc >= 0
+            # against the fp64 forward: both fp32 evaluations (torch's and this one) sit within summation-order noise of it
+            scale64 = float(raw64.abs().max()) + 1.0
+            assert np.abs(logits[:A] - raw64[0, :A].numpy()).max() <= 2e-6 * scale64
+            np.testing.assert_allclose(logits[:A], f32(mean), atol=4e-6 * scale64, rtol=0)
+            np.testing.assert_allclose(logits[A:], f32(std), rtol=2e-5, atol=1e-7)
+            # the thread count never changes a bit (an output row is one thread's, in one order); the vector width may
+            key = rc if isa < 0 else isa
+            if key in per_isa:
+                assert np.array_equal(per_isa[key], logits), (isa, threads)
+            per_isa[key] = logits.copy()
+            action, logp = np.empty(A, np.float32), np.empty(1, np.float32)
+            hm.hm_policy_act(p(params), L, IA(*k_in), IA(*n_out), LA(*w_off), LA(*b_off), acts[act][0], p(obs), A, lo_ls, hi_ls,
+                             p(f32(eps[0])), p(scale), p(center), p(action), p(logp), isa, threads)
+            # the reference's sampling step on ITS logits and the same draw (act_distribution_cls.py:32-42)
+            x = mean + std * eps[0]
+            a_ref = lim * torch.tanh(x)
+            lp_ref = (torch.distributions.Normal(mean, std).log_prob(x) - torch.log(1 + 1e-6 - torch.tanh(x) ** 2) - np.log(lim)).sum()
+            np.testing.assert_allclose(action, f32(a_ref), atol=4e-6 * lim * scale64, rtol=0)
+            t2 = (np.asarray(a_ref, np.float64) / lim) ** 2
+            tol = 5e-4 + float((2.4e-7 / (1.0 + 1e-6 - np.minimum(t2, 1.0))).sum())
+            assert abs(float(logp[0]) - float(lp_ref)) <= tol, (i, float(logp[0]), float(lp_ref), tol)
+        assert len(per_isa) >= 2
