@@ -290,8 +290,6 @@ struct dsact_handle {
   double act_host_us = 0.0, act_copy_wait_us = 0.0;
   unsigned long long act_host_calls = 0, act_copies = 0;
   int env_chain_rg_pi = 0;              // DSACT_CHAIN_RG_PI (experiments)
-  bool env_no_ride8 = true;             // DSACT_RIDE8=1: the critics' riding tiles run 8 waves (512-thread launch) at batch >= 1024 (measured
-                                        // equal: 27.4 vs 27.1 us, 8,784 vs 8,767 steps/s -- that launch is not bound by the riders' wave count)
   bool env_dw_4wave = false;            // DSACT_DW_4WAVE: k_dw2 keeps 4 waves per tile at every batch (A/B)
   bool env_no_conv_dx_mfma = false;     // DSACT_NO_CONV_DX_MFMA: the 16-channel layer's data gradient with k_conv_dx_block (A/B)
   bool env_no_mixed_rg = false;         // DSACT_NO_MIXED_RG: every unit of the merged forward's group A runs 8-row workgroups (A/B)
@@ -337,8 +335,6 @@ struct dsact_handle {
   // merged critic backward + critic tiles + close (k_chain_bwd_qt) on the updates that defer their policy backward
   int* bqt_cnt = nullptr;               // arrival counters [2 critics][8 x kArriveStride], zeroed by the forward launch's bookkeeping block
   int* bqt_tab = nullptr; int bqt_tab_blocks = 0;   // block -> tile table (classes of layers in arrival order, dealt to the XCDs)
-  bool env_pi_layers = false;           // DSACT_PI_LAYERS=1 (experiments): per-layer arrival counters for the policy's tiles (measured slower:
-                                        // chain_bwd_pi 22.5-22.8 -> 23.4-23.6 us -- the early tiles' traffic slows the chain whose end the first layer's tiles wait for)
   bool env_no_bqt = false;              // DSACT_NO_BQT_MERGE: critics' backward and their tiles stay two launches (A/B)
   bool bqt_now = false;                 // set while such an update is being enqueued
   // k_chain_bwd_qpt: the whole backward of a policy-moving update of the pipelined graph as one launch
@@ -2489,8 +2485,6 @@ void bwd_pi_args(dsact_handle* h, int x0, int x1, bool fused, BwdPiArgs& a, int&
   if (merge) {
     a.merge_dw = 1; a.pi_tile0 = x1; a.n_pi_tiles = h->dw2_off[3] - x1; a.finalize = fused ? 1 : 0;
     a.cnt_pi = h->chain_flags + kChainFlags + 128;
-    a.per_layer = (!h->twin && h->env_pi_layers) ? 1 : 0;
-    a.pi_prob0 = h->nq * (L + 1);
     a.spin_timeout = (int*)h->handoff_dev;
     a.debug_withhold = h->debug_withhold == 2;
   }
@@ -2512,13 +2506,6 @@ int enqueue_chain_bwd_pi(dsact_handle* h, int x0, int x1, bool fused, bool merge
   size_t lds = (size_t)chain_lds(4 * h->SoT, h->cW, 4 * rg).total * sizeof(float);
   if (lds < kDw2LdsFloats * sizeof(float)) lds = kDw2LdsFloats * sizeof(float);
   const int tail = merge ? xcd_chunk_grid(a.n_extra) + xcd_chunk_grid(a.n_pi_tiles) + 1 : xcd_chunk_grid(a.n_extra) * h->dw_chunks;
-  if (!merge && a.dw.ct >= 32 && a.n_extra > 0 && !h->env_dw_4wave && !h->env_no_ride8) {
-    // long contractions (batch >= 1024 per range): the riders run 8 waves per tile -- the launch is 512 threads wide
-    if (lds < (size_t)dw2_lds_floats(8) * sizeof(float)) lds = (size_t)dw2_lds_floats(8) * sizeof(float);
-#define CALL_CP8(N, G) return launch(h, "chain_bwd_pi", k_chain_bwd_pi8<N, G>, dim3(a.n_chain_blocks + tail), dim3(512), lds, a)
-    CHAIN_NT(CALL_CP8, rg);
-#undef CALL_CP8
-  }
 #define CALL_CP(N, G) return launch(h, "chain_bwd_pi", k_chain_bwd_pi<N, G>, dim3(a.n_chain_blocks + tail), dim3(kThreads), lds, a)
   CHAIN_NT(CALL_CP, rg);
 #undef CALL_CP
@@ -2606,8 +2593,13 @@ int enqueue_chain_bwd_qt(dsact_handle* h, bool fused, const RideArgs* ride) {
   size_t lds = (size_t)chain_lds(h->cW, h->cW, 4 * rg).total * sizeof(float);
   if (lds < kDw2LdsFloats * sizeof(float)) lds = kDw2LdsFloats * sizeof(float);
   const int grid = a.q.n_chain_blocks + n_riders + a.n_tile_blocks + 1;
+  // (4- and 8-row slices only: the 16-row instantiations spilled 20-92 B under this kernel's three-workgroups-per-CU register
+  //  bound and were reachable only where bqt_ok() is false -- batch >= 1024, pi_merge off)
+  if (rg != 1 && rg != 2) return fail(h, DSACT_E_STATE, "k_chain_bwd_qt expects 4- or 8-row critic slices");
 #define CALL_CQT(N, G) return launch(h, "chain_bwd_qt", k_chain_bwd_qt<N, G>, dim3(grid), dim3(kThreads), lds, a)
-  CHAIN_NT(CALL_CQT, rg);
+  if (rg == 1) { if (h->cNT == 1) { CALL_CQT(1, 1); } else if (h->cNT == 2) { CALL_CQT(2, 1); } else { CALL_CQT(4, 1); } }
+  if (h->cNT == 1) { CALL_CQT(1, 2); } else if (h->cNT == 2) { CALL_CQT(2, 2); }
+  CALL_CQT(4, 2);
 #undef CALL_CQT
 }
 
@@ -2626,7 +2618,6 @@ int enqueue_chain_bwd_qpt(dsact_handle* h, bool fused, const RideArgs* ride) {
     if (a.q.u[w].which >= 2) a.q.u[w].dA_pairs = h->bqp_pairs[a.q.u[w].which - 2];
   bwd_pi_args(h, h->dw2_off[0], h->dw2_off[2], fused, a.pi, rg_pi, true, h->env_bqp_rg_pi);
   a.pi.cnt_pi = h->bqt_cnt + 2 * 8 * kArriveStride;    // (its own counter: the forward launch's deferred chain uses the flags' one)
-  a.pi.per_layer = 0;
   a.pi.dA_pairs[0] = h->bqp_pairs[0]; a.pi.dA_pairs[1] = h->bqp_pairs[1];
   a.pi.tagp = &h->st->tag_seq;
   a.q.timeline = tl_for(h, "chain_bwd_qpt");
@@ -3290,7 +3281,6 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->env_no_bqt = getenv("DSACT_NO_BQT_MERGE") != nullptr;
   h->env_no_bqp = getenv("DSACT_NO_BQP_MERGE") != nullptr;
   if (const char* v = getenv("DSACT_BQP_RG_PI")) h->env_bqp_rg_pi = atoi(v) == 1 ? 1 : atoi(v) == 2 ? 2 : 0;
-  h->env_pi_layers = getenv("DSACT_PI_LAYERS") != nullptr;
   h->env_no_pipe_warm = getenv("DSACT_PIPE_WARM") == nullptr;
   h->env_no_pipe_tagged = getenv("DSACT_NO_PIPE_TAGGED") != nullptr;
   if (const char* v = getenv("DSACT_PK_PAD")) h->env_pk_pad = atoi(v) > 0 && atoi(v) <= 64 ? atoi(v) : 0;
@@ -3311,7 +3301,6 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (const char* v = getenv("DSACT_CONV_FWD64_MIN")) h->env_conv_fwd64_min = atoi(v);
   if (const char* v = getenv("DSACT_DCOL64_MIN_M")) h->env_dcol64_min_m = atoi(v);
   h->env_dw_4wave = getenv("DSACT_DW_4WAVE") != nullptr;
-  h->env_no_ride8 = getenv("DSACT_RIDE8") == nullptr;
   if (const char* v = getenv("DSACT_CHAIN_RG")) h->env_chain_rg = atoi(v) == 1 ? 1 : atoi(v) == 4 ? 4 : 2;
   h->dw_chunks = (h->B > 448 && h->B % 256 == 0 && getenv("DSACT_NO_SPLITK") == nullptr) ? h->B / 256 : 1;   // (chain path: below)
   h->dw_part_stride = (h->n_online + 2 + 63) & ~(size_t)63;
@@ -3466,15 +3455,6 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_q<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi8<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi8<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi8<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi8<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi8<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi8<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi8<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi8<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-    HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi8<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
     HIPCHK(h, hipFuncSetAttribute((const void*)k_chain_bwd_pi<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
@@ -4017,15 +3997,28 @@ static int act_forward_host(dsact_handle* h, const float* obs_host, const float*
   }
   float* b0 = h->act_buf; float* b1 = b0 + kMaxWidth + 64; float* raw = b1 + kMaxWidth + 64;
   if (h->act_threads == 0) {
-    // One thread by default. DSACT_HOST_ACT_THREADS=n lets n - 1 helpers share the wide layers (dsact_host_act.h, Pool; the
-    // result is bit-identical): measured on the 2-socket EPYC 9575F of the MI355X boxes with unpinned helpers, 4 threads ran a
-    // forward in 9.6 us against 8.9 us alone -- the weights (0.95 MB) stream from the L3 at ~20 B/clk either way and every
-    // layer's fork-join crosses CCDs; in the 8-vCPU build container 2 threads were 4x slower than 1.
+    // How many threads share a wide layer (dsact_host_act.h, Pool; the result is bit-identical for every count). The weights
+    // (0.95 MB at Humanoid 3x256) do not stay in one core's L2 between two environment steps, so one thread streams them from
+    // the L3 (8.9 us per forward on the boxes' EPYC 9575F); four cores of ONE core complex hold a quarter each in their own L2.
+    // Unpinned helpers measured no gain there (9.6 us: every fork-join crossed CCDs / sockets) and 2 threads were 4x SLOWER
+    // than 1 in the 8-vCPU build container -- so helpers are used only where they can be pinned beside the calling thread's
+    // core (same last-level cache, Linux sysfs), on hosts with >= 16 CPUs, for policies at least 128 wide.
+    // DSACT_HOST_ACT_THREADS=n forces a count (1: never any helper).
     const char* ev = getenv("DSACT_HOST_ACT_THREADS");
-    int t = ev ? atoi(ev) : 1;
+    int t = 1;
+    std::vector<int> pin;
+#if defined(__linux__)
+    const int cpu = sched_getcpu();
+    if (cpu >= 0) pin = hostact::llc_sibling_cores(cpu);
+#endif
+    if (ev) t = atoi(ev);
+    else if ((int)std::thread::hardware_concurrency() >= 16 && h->pd.out[0] >= 128 && pin.size() >= 3) t = 4;
     t = t < 1 ? 1 : (t > 16 ? 16 : t);
+    if (t > 1) {
+      h->act_pool = new hostact::Pool(t, pin);
+      if (!ev && h->act_pool->pinned() < t - 1) { delete h->act_pool; h->act_pool = nullptr; t = 1; }   // (a cpuset refused the pinning)
+    }
     h->act_threads = t;
-    if (t > 1) h->act_pool = new hostact::Pool(t);
   }
   const auto t1 = std::chrono::steady_clock::now();
   hostact::forward(ly, h->L + 1, h->cfg.policy_act, obs_host, b0, b1, raw, h->act_pool);
@@ -4964,6 +4957,7 @@ int dsact_debug_get(const dsact_handle* h, const char* name, double* value) {
   else if (!strcmp(name, "act_host")) *value = act_host_ok(h) ? 1.0 : 0.0;
   else if (!strcmp(name, "act_host_us")) *value = h->act_host_us;
   else if (!strcmp(name, "act_host_threads")) *value = (double)h->act_threads;
+  else if (!strcmp(name, "act_host_pinned")) *value = h->act_pool ? (double)h->act_pool->pinned() : 0.0;
   else if (!strcmp(name, "act_host_isa")) *value = (double)hostact::cpu_isa();
   else if (!strcmp(name, "act_copy_wait_us")) *value = h->act_copy_wait_us;
   else if (!strcmp(name, "act_host_calls")) *value = (double)h->act_host_calls;

@@ -1490,12 +1490,6 @@ struct BwdPiArgs {
   // the arrival counter of the chain's slices; one more block closes the update (alpha gradient, finalize_update)
   int merge_dw, pi_tile0, n_pi_tiles, finalize;
   int* cnt_pi; int* spin_timeout;
-  // per-layer arrival (round 5 experiment, DSACT_PI_LAYERS=1; OFF by default -- measured slower, 22.5-22.8 -> 23.4-23.6 us:
-  // what the early tiles move through L2 / the fabric slows the chain whose END the first layer's 96 tiles wait for):
-  // counter [l] (8 replicas each, l * 8 * kArriveStride ints on) counts the slices whose dZ[l] (l == L - 1: and dL/dout) is
-  // visible chip-wide; a policy tile waits for ITS layer's counter only. pi_prob0: index of the policy's first problem in
-  // dw.p. per_layer == 0: one counter, raised at the end of the chain
-  int per_layer, pi_prob0;
   // k_chain_bwd_qpt: dL/d new_act arrives from the critics' chains of the SAME launch as (value, tag) pairs [B][32] per critic
   // (every lane polls ITS elements until they carry this update's tag; bounded). nullptr: plain loads of dA (an earlier launch)
   const unsigned long long* dA_pairs[2]; const long long* tagp;
@@ -1582,7 +1576,6 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
   // alpha gradient (dsac_v2.py:312-318): -mean(logp_new + target_entropy)
   if (slice == 0 && wave == 0 && !a.merge_dw && lead) bwd_pi_alpha_grad(a, lane);   // merged launch: the closing block does it
   const int agent = a.merge_dw;
-  const bool arr_layers = a.merge_dw && a.per_layer && !(a.debug_withhold && slice == 0);
   const float alpha = a.auto_alpha ? expf(a.log_alpha[0]) : a.alpha_fixed;
   // zero the operand rows (padding included), then fill (dmu | draw)
   for (int e = tid; e < R * 4 * a.SoT; e += NTHR) xdo[(e / (4 * a.SoT)) * S.ld_in + e % (4 * a.SoT)] = 0.0f;
@@ -1638,16 +1631,6 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
     const bool has_nxt = l > 1;
     gemm44_seg<RG>(ws, t_wb[l] + (size_t)wave * SH * 256, 0, SH, t_wb[has_nxt ? l - 1 : l] + (size_t)wave * SH * 256, 0, has_nxt,
                    lds, (cur ? S.off_h1 : S.off_h0) + (lane & 3) * S.ld_h, S.ld_h, lane4, acc);
-    if (arr_layers) {
-      // Per-layer arrival WITHOUT draining the weight stream: a wave's vector-memory operations retire in issue order (gfx9
-      // has ONE vmcnt counter for loads and stores: every s_waitcnt vmcnt(N > 0) the compiler emits for a load with younger
-      // stores in flight relies on it). Behind dZ[l]'s stores (l == L - 1: and dL/dout's) this wave has issued the whole
-      // product that just ended -- at least kPD refill loads -- so vmcnt(kPD) (the last trip's refills stay in flight)
-      // proves those stores acknowledged (write-through: visible chip-wide). Layer l's counter is raised one product late
-      // for the price of a barrier and 8 atomic adds; dZ[0] (nothing follows) waits for vmcnt(0) in chain_arrive below.
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" : : "n"(kPD) : "memory");
-      if (tid < 8) __hip_atomic_fetch_add(a.cnt_pi + l * 8 * kArriveStride + tid * kArriveStride, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     const int hn = cur ? S.off_h0 : S.off_h1;
 #pragma unroll
     for (int g = 0; g < RG; ++g) {
@@ -1665,16 +1648,10 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
   if (a.merge_dw && !(a.debug_withhold && slice == 0)) chain_arrive(a.cnt_pi);
 }
 
-// the arrival counter policy tile `t` (an index into dw's tile list) waits for
-__device__ __forceinline__ const int* pi_tile_counter(const BwdPiArgs& a, int t) {
-  if (!a.per_layer) return a.cnt_pi;
-  int pi = 0;
-#pragma unroll
-  for (int q = 0; q + 1 < kMaxDwProb; ++q)
-    if (q + 1 < a.dw.n_prob && t >= a.dw.tile_ends[q]) pi = q + 1;
-  const int l = pi - a.pi_prob0;
-  return a.cnt_pi + (l < a.L ? l : a.L - 1) * 8 * kArriveStride;
-}
+// the arrival counter the policy's tiles wait for: ONE, raised at the end of the chain (per-layer counters -- tiles of later
+// layers starting while the chain still runs -- were measured slower in round 5, 22.5-22.8 -> 23.4-23.6 us: what the early
+// tiles move through L2 / the fabric slows the chain whose END the first layer's 96 tiles wait for; profiles/r05_bqt_variants.txt)
+__device__ __forceinline__ const int* pi_tile_counter(const BwdPiArgs& a, int) { return a.cnt_pi; }
 
 // blocks past the chain's: riders (xcd_chunk_grid(n_extra) per batch range), then -- merged launch -- the policy's
 // tiles and the closing block
@@ -1714,26 +1691,8 @@ __global__ void __launch_bounds__(256) k_chain_bwd_pi(BwdPiArgs a) {
   const int trunk = (a.n_trunks == 2 && b >= per) ? 1 : 0;   // (one inlined body: the trunk's pointers are scalar selects)
   bwd_pi_body<NW, RG>(a, trunk ? b - per : b, lds, trunk);
 }
-// The same launch 512 threads wide (unmerged form, long contractions: batch >= 1024): a riding weight-gradient tile runs
-// EIGHT waves, two per SIMD, that hide each other's operand waits (what k_dw2<2, 8> does for the policy's own tiles:
-// 13.8 -> 11.8 us, profiles/r03_ab_dw_8wave.txt) -- the riders' 4 rounds of 16 chunks each were latency chains of one
-// wave per SIMD and bounded this launch at 27 us. The chain's slices use the first 64 NW threads.
-template <int NW, int RG>
-__global__ void __launch_bounds__(512) k_chain_bwd_pi8(BwdPiArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  if ((int)blockIdx.x >= a.n_chain_blocks) {
-    const int idx = (int)blockIdx.x - a.n_chain_blocks;
-    const int per_range = xcd_chunk_grid(a.n_extra);
-    int t;
-    if (!xcd_chunk(idx % per_range, a.n_extra, t)) return;
-    dw2_tile<2, NoWait, 8>(a.dw, (idx / per_range) * a.dw.n_base + a.tile0 + t, lds);
-    return;
-  }
-  const int per = a.n_chain_blocks >> 1, b = (int)blockIdx.x;
-  const int trunk = (a.n_trunks == 2 && b >= per) ? 1 : 0;   // (one inlined body: the trunk's pointers are scalar selects)
-  bwd_pi_body<NW, RG>(a, trunk ? b - per : b, lds, trunk);
-}
-
+// (Round 3-5 kept a 512-thread form of this launch whose riding tiles ran eight waves, DSACT_RIDE8: measured equal at batch
+//  >= 1024 -- 27.4 vs 27.1 us, 8,784 vs 8,767 steps/s: that launch is not bound by the riders' wave count -- and removed in round 6.)
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_chain_bwd_qt (round 5): the critics' backward AND their weight-gradient / Adam tiles AND the block that closes the update

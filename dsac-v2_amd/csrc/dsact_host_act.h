@@ -17,7 +17,13 @@
 // how many threads share a layer (Pool below) -- only on the vector width the CPU offers.
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#if defined(__linux__)
+#include <pthread.h>
+#include <sched.h>
+#endif
 
 #include <atomic>
 #include <condition_variable>
@@ -170,11 +176,68 @@ inline void layer_rows(int isa, const Layer& L, int act, bool hidden, const floa
 // of acting calls lasts (an environment step between two calls is microseconds) and go to sleep on a condition variable when
 // none has come for ~200 us. A layer's rows are dealt in contiguous chunks of multiples of 16; chunk boundaries do not change
 // any row's arithmetic. Not created at all for T == 1 (DSACT_HOST_ACT_THREADS=1).
+// CPUs that share the last-level cache with `cpu` (Linux sysfs), one per physical core, `cpu`'s own core excluded: where the
+// helpers of a Pool want to run -- a layer's fork-join is two cache-line hand-overs, which cost tens of nanoseconds inside a
+// core complex and a microsecond across sockets. Empty: unknown topology (the helpers then run wherever the scheduler puts them).
+inline std::vector<int> llc_sibling_cores(int cpu) {
+  std::vector<int> out;
+#if defined(__linux__)
+  auto read_list = [](const char* path, std::vector<int>& v) {
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    char buf[4096];
+    const bool ok = fgets(buf, sizeof(buf), f) != nullptr;
+    fclose(f);
+    if (!ok) return false;
+    for (char* p = buf; *p && *p != '\n';) {        // "0-7,128-135"
+      char* e;
+      const long a = strtol(p, &e, 10);
+      if (e == p) break;
+      long b = a;
+      if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); }
+      for (long c = a; c <= b && c - a < 4096; ++c) v.push_back((int)c);
+      p = *e == ',' ? e + 1 : e;
+    }
+    return !v.empty();
+  };
+  char path[160];
+  std::vector<int> llc, mine;
+  snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+  if (!read_list(path, llc)) return out;
+  snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu);
+  read_list(path, mine);
+  std::vector<int> taken = mine;                     // hardware threads of cores already used
+  for (int c : llc) {
+    bool used = false;
+    for (int t : taken) used = used || t == c;
+    if (used || c == cpu) continue;
+    std::vector<int> sib;
+    snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+    if (!read_list(path, sib)) sib.push_back(c);
+    for (int t : sib) taken.push_back(t);
+    out.push_back(c);
+  }
+#endif
+  return out;
+}
+
 class Pool {
  public:
-  explicit Pool(int threads) : T_(threads < 1 ? 1 : threads) {
-    for (int i = 1; i < T_; ++i) th_.emplace_back([this, i] { run(i); });
+  // pin_to: CPU of helper i (i = 1 .. threads-1) at pin_to[i - 1], or fewer entries / empty: unpinned helpers
+  explicit Pool(int threads, const std::vector<int>& pin_to = std::vector<int>()) : T_(threads < 1 ? 1 : threads) {
+    for (int i = 1; i < T_; ++i) {
+      th_.emplace_back([this, i] { run(i); });
+#if defined(__linux__)
+      if ((size_t)(i - 1) < pin_to.size()) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(pin_to[(size_t)i - 1], &set);
+        if (pthread_setaffinity_np(th_.back().native_handle(), sizeof(set), &set) == 0) ++pinned_;
+      }
+#endif
+    }
   }
+  int pinned() const { return pinned_; }
   ~Pool() {
     stop_.store(true);
     gen_.fetch_add(1);
@@ -223,6 +286,7 @@ class Pool {
     }
   }
   const int T_;
+  int pinned_ = 0;
   std::vector<std::thread> th_;
   std::atomic<unsigned> gen_{0};
   std::atomic<int> done_{0}, sleepers_{0};
