@@ -849,6 +849,9 @@ def main():
                     help="reference default (example_train/*.py); BASELINE.json words it as 256,256 -> reported in `alt`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="the timed regions of the headline configuration and nothing else (no fast / alt / V1 / e2e / CNN legs, no eager "
+                         "per-kernel profile): what a rocprofv3 pass should see so that its kernel statistics are this configuration's alone")
     ap.add_argument("--fast", action="store_true", help="primary number with DSACT_F_SKIP_ACTOR_ON_OFF_ITERS (default: strict; fast is reported in `fast`)")
     ap.add_argument("--replay-rows", "--rows", dest="replay_rows", type=int, default=N_REPLAY,
                     help="rows of the replay ring in HBM per GPU (configs[1]: 1M; configs[4]: 10M = 30.9 GB)")
@@ -861,6 +864,8 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: print the cpu_baseline object and exit")
     ap.add_argument("--dp-eager", action="store_true", help="data-parallel leg through torch.distributed eagerly instead of the graph-captured native RCCL path")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_alt = args.no_cpu_baseline = True
     steps, warmup = int(args.steps), int(args.warmup)
     if args.fast:   # whole delay_update periods per graph
         steps += steps & 1
@@ -994,6 +999,8 @@ def main():
         if ev_ms is not None:
             out["hip_event_ms_per_step"] = ev_ms / steps
         try:
+            if args.headline_only:
+                raise RuntimeError("--headline-only: no eager per-kernel profile")
             pipe = (not use_dp) and e.debug_get("pipe_graph") == 1.0
             if pipe:
                 # the timed graph is the pipelined one: profile ITS launch sequence (same first-iteration parity, same length)
@@ -1070,7 +1077,7 @@ def main():
             out["kernels_error"] = str(ex)
         if "roofline" not in out:
             out["roofline"] = dict(out["roofline_step"], note="whole update (no per-kernel profile available on this path)")
-    if rank == 0 and not use_dp and not args.fast:
+    if rank == 0 and not use_dp and not args.fast and not args.headline_only:
         # same workload with the actor/alpha backward skipped on the off iterations of the delayed update: the
         # reference computes and discards those gradients (dsac_v2.py:174-186 vs :324); bitwise-identical parameter
         # trajectory (tests/test_hip_parity.py::test_skip_discarded_actor_backward_keeps_trajectory)

@@ -49,6 +49,7 @@ __device__ __forceinline__ unsigned long long act_pair(float v, int call) {
   return ((unsigned long long)(unsigned)call << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v);
 }
 
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void __launch_bounds__(256) k_act_mlp(ActArgs a) {
   const int b = (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int l = 0;
@@ -131,5 +132,6 @@ __global__ void __launch_bounds__(256) k_act_mlp(ActArgs a) {
   const float v = n < a.A ? acc : expf(clampf(acc, a.lo_ls, a.hi_ls));
   __hip_atomic_store(a.out + n, act_pair(v, a.call), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+#endif
 
 }  // namespace dsact

@@ -23,6 +23,11 @@
 #include "dsact_host_act.h"
 #include "dsact_conv.h"
 
+// every listed template-kernel instantiation is compiled in its family's translation unit (csrc/dsact_tu_<group>.hip, dsact_tu.h)
+#define DSACT_KERNEL(group, ...) extern template __global__ void __VA_ARGS__;
+#include "dsact_instances.inc"
+#undef DSACT_KERNEL
+
 using namespace dsact;
 
 namespace {

@@ -517,6 +517,7 @@ struct AdamPackJob {
   int block_end;            // exclusive end of this job's block range (row blocks x col_chunks)
 };
 struct AdamPackArgs { const AdamPackJob* jobs; int n_jobs, n_blocks; FusedOpt fo; };
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void __launch_bounds__(256) k_adam_pack(AdamPackArgs a) {
   const int b = (int)blockIdx.x, tid = threadIdx.x;
   if (b >= a.n_blocks) {
@@ -575,6 +576,7 @@ __global__ void __launch_bounds__(256) k_adam_pack(AdamPackArgs a) {
     if (o_delayed) fo.target[bi] = polyak_update(fo.target[bi], pe, fo.polyak, fo.one_minus_polyak);
   }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_chain_fwd

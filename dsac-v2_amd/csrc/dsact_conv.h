@@ -82,6 +82,7 @@ struct ConvStageArgs {
 // NEXT k-tile (possibly of the next item) are in flight while the current one is multiplied, so the
 // L2 round trip is paid once per workgroup, not once per tile.
 // ---------------------------------------------------------------------------------------------
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void __launch_bounds__(kThreads) k_conv_fwd(ConvStageArgs s) {
   __shared__ __attribute__((aligned(16))) float lds[4 * TILE_LDS];
   const ConvGeom& g = s.g;
@@ -184,6 +185,7 @@ __global__ void __launch_bounds__(kThreads) k_conv_fwd(ConvStageArgs s) {
     item = next_item;
   }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // forward, wide layers (round 4): 64 (pixels) x 64 (channels) tiles, 512 threads -- run_tile64's structure (dsact_kernels.h:
@@ -1028,6 +1030,7 @@ struct ConvReduceArgs {
   FusedOpt fo;
 };
 
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void __launch_bounds__(kThreads) k_conv_dw_reduce(ConvReduceArgs a) {
   __shared__ f32x4 red[kThreads];
   int j = 0;
@@ -1098,6 +1101,7 @@ __global__ void __launch_bounds__(kThreads) k_conv_dw_reduce(ConvReduceArgs a) {
     if (delayed) fo.target[oi + e] = polyak_update(fo.target[oi + e], pe, fo.polyak, fo.one_minus_polyak);
   }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // col2im: dX[b,y,x,ci] = relu'(x[b,y,x,ci]) * sum over the (ky,kx) whose window covers (y,x) of
@@ -1112,6 +1116,7 @@ struct Col2imArgs {
   int n_prob;
   int B;
 };
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void __launch_bounds__(kThreads) k_col2im(Col2imArgs a) {
   const ConvGeom& g = a.g;
   const int pi = blockIdx.y;
@@ -1146,6 +1151,7 @@ __global__ void __launch_bounds__(kThreads) k_col2im(Col2imArgs a) {
   for (int q = 0; q < 4; ++q) s[q] = xv[q] > 0.f ? s[q] : 0.f;
   *(f32x4u*)(a.dx[pi] + o) = s;
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // features: last conv activation [B*P][C] (pixel-major) <-> flattened NCHW feature columns of the MLP
@@ -1156,6 +1162,7 @@ struct FeatArgs {
   float* dst0[6]; float* dst1[6];   // MLP input rows fed by the stack (dst1 may be null)
   int n_stack, B, P, C, ldx;
 };
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void __launch_bounds__(kThreads) k_feat_scatter(FeatArgs a) {
   const int st = blockIdx.y;
   const int F = a.P * a.C;
@@ -1167,12 +1174,14 @@ __global__ void __launch_bounds__(kThreads) k_feat_scatter(FeatArgs a) {
   a.dst0[st][(size_t)b * a.ldx + f] = v;
   if (a.dst1[st]) a.dst1[st][(size_t)b * a.ldx + f] = v;
 }
+#endif
 struct FeatBwdArgs {
   const float* dfeat[3];  // [B x F]
   const float* act[3];    // last-layer activations (ReLU mask)
   float* dy[3];           // [B*P][C]
   int n_stack, B, P, C;
 };
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void __launch_bounds__(kThreads) k_feat_bwd(FeatBwdArgs a) {
   const int st = blockIdx.y;
   const int F = a.P * a.C;
@@ -1184,6 +1193,7 @@ __global__ void __launch_bounds__(kThreads) k_feat_bwd(FeatBwdArgs a) {
   const float g = a.dfeat[st][(size_t)b * F + c * a.P + p];
   a.dy[st][e] = a.act[st][e] > 0.f ? g : 0.f;
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // image minibatch gather (training/replay_buffer.py:85-90 for obsv_dim = (C,H,W)): replay rows hold the
@@ -1205,6 +1215,7 @@ struct ImgGatherArgs {
   DevState* stw;
   StepHyper hp; NoiseArgs nz; RepackArgs rp;
 };
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void __launch_bounds__(kThreads) k_gather_img(ImgGatherArgs a) {
   if ((int)blockIdx.x >= a.B * a.chunks) {
     repack_rows(a.rp, (int)blockIdx.x - a.B * a.chunks, threadIdx.x);
@@ -1273,12 +1284,14 @@ __global__ void __launch_bounds__(kThreads) k_gather_img(ImgGatherArgs a) {
     }
   }
 }
+#endif
 
 // replay ring write for image rows (wide rows: a block per row)
 struct ImgScatterArgs {
   const float* s_obs; const float* s_obs2; float* rb_obs; float* rb_obs2;
   long long ptr, cap; int n; long long O;
 };
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void __launch_bounds__(kThreads) k_ring_write_img(ImgScatterArgs a) {
   const int i = blockIdx.y;
   const long long dst = (a.ptr + i) % a.cap;
@@ -1288,5 +1301,6 @@ __global__ void __launch_bounds__(kThreads) k_ring_write_img(ImgScatterArgs a) {
     *(f32x4*)(a.rb_obs2 + dst * a.O + q * 4) = *(const f32x4*)(a.s_obs2 + (long long)i * a.O + q * 4);
   }
 }
+#endif
 
 }  // namespace dsact

@@ -188,7 +188,9 @@ __device__ __forceinline__ void pack_block(const PackJob* jobs, int n_jobs, int 
   }
 }
 struct PackArgs { const PackJob* jobs; int n_jobs; const int* targets_if; };
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void __launch_bounds__(256) k_pack(PackArgs a) { pack_block(a.jobs, a.n_jobs, (int)blockIdx.x, threadIdx.x, a.targets_if); }
+#endif
 
 constexpr int kWave = 64;
 constexpr int kThreads = 256;  // 4 waves, one per SIMD
@@ -406,7 +408,9 @@ __device__ void repack_rows(const RepackArgs& rp, int blk, int tid) {
     rp.w1at[net][rem] = j < rp.A ? rp.src[net][(size_t)row * rp.K + rp.O + j] : 0.0f;
   }
 }
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void __launch_bounds__(kThreads) k_repack(RepackArgs rp) { repack_rows(rp, blockIdx.x, threadIdx.x); }
+#endif
 
 struct GatherArgs {
   const float* rb_obs; const float* rb_obs2; const float* rb_act; const float* rb_rew; const float* rb_done;
@@ -495,6 +499,7 @@ __device__ __forceinline__ void gather_main(const GatherArgs& a, int blk, int ti
   gather_block(a, blk, it, trow, tid);
   if (a.bookkeeping && blk == 0 && tid == 0) prologue_duties(a.st, it, a.advance_counters, a.hp);
 }
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void __launch_bounds__(kThreads) k_gather(GatherArgs a) {
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= a.n_gather_blocks) {  // spare blocks: weight repack (independent of the gather)
@@ -503,15 +508,18 @@ __global__ void __launch_bounds__(kThreads) k_gather(GatherArgs a) {
   }
   gather_main(a, (int)blockIdx.x, tid);
 }
+#endif
 // the pipelined graph opens with the minibatches of its first TWO updates (the riding gathers look two updates ahead):
 // one launch, blocks [0, na) -> a, [na, na + nb) -> b, the rest -> a's repack blocks
 struct Gather2Args { GatherArgs a, b; };
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void __launch_bounds__(kThreads) k_gather2(Gather2Args g) {
   const int tid = threadIdx.x, blk = (int)blockIdx.x, na = g.a.n_gather_blocks, nb = g.b.n_gather_blocks;
   if (blk < na) gather_main(g.a, blk, tid);
   else if (blk < na + nb) gather_main(g.b, blk - na, tid);
   else repack_rows(g.a.rp, blk - na - nb, tid);
 }
+#endif
 
 // Riders of the loss launch in graph replays (k_loss has B/4 blocks: three quarters of the chip idle). Blocks
 // [n_loss_blocks, +n_gather) stage the NEXT update's minibatch into the other batch set (iteration it_next + 1,
@@ -541,17 +549,21 @@ struct PrologueArgs {
   DevState* st; int use_dev; long long host_it; int advance_counters; int fill_noise; StepHyper hp;
   NoiseArgs nz; int B, A; int table_rows;
 };
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void __launch_bounds__(kThreads) k_prologue(PrologueArgs a) {
   const long long it = a.use_dev ? a.st->it_next : a.host_it;
   if (a.nz.seed != 0 && a.fill_noise) fill_noise_rows(a.nz, it, a.use_dev && a.nz.table ? (int)(a.st->seq_next % a.table_rows) : 0, 0, a.B, a.A, threadIdx.x, kThreads);
   if (threadIdx.x == 0) prologue_duties(a.st, it, a.advance_counters, a.hp);
 }
+#endif
 
 // device-side (stream-ordered, no host sync) reset of the replay counters before a group of graph-replayed updates:
 // iteration of the group's first update, index / noise table row 0
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void k_set_counters(DevState* st, long long it_next, long long seq_next) {
   if (threadIdx.x == 0 && blockIdx.x == 0) { st->it_next = it_next; st->seq_next = seq_next; }
 }
+#endif
 
 // replay ring scatter (training/replay_buffer.py:58-83): n staged rows -> ring rows (ptr+i) % cap
 struct ScatterArgs {
@@ -559,6 +571,7 @@ struct ScatterArgs {
   float* rb_obs; float* rb_obs2; float* rb_act; float* rb_rew; float* rb_done; float* rb_logp;
   long long ptr, cap; int n, O, A;
 };
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void __launch_bounds__(kThreads) k_ring_write(ScatterArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 4 + wave;
@@ -575,6 +588,7 @@ __global__ void __launch_bounds__(kThreads) k_ring_write(ScatterArgs a) {
     a.rb_logp[dst] = a.s_logp ? a.s_logp[i] : 0.0f;
   }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // k_tiles: C[m][n] (+epilogue) = sum_k P(m,k) * Q(n,k) on 32x32 tiles, BK = 64
@@ -1140,6 +1154,7 @@ __device__ __forceinline__ void finalize_update(const FusedOpt& fo) {
 // stores_acked_barrier() of dsact_chain.h.)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void __launch_bounds__(kThreads) k_stage_table(TableArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if ((int)blockIdx.x >= a.n_tiles) {
@@ -1149,6 +1164,7 @@ __global__ void __launch_bounds__(kThreads) k_stage_table(TableArgs a) {
   const GemmProb g = a.tiles[xcd_logical_block(blockIdx.x, a.n_tiles)];
   run_tile<true, true, EPI_STORE>(g, g.tiles_n, g.tile_end, lds, a.timeline, (int)blockIdx.x, &a.fo);
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // row-vector helpers for the narrow layers (N_out = 2 or 2A, K = 2A): one wave per row, the row lives
@@ -1841,6 +1857,7 @@ __device__ __forceinline__ void adam_classify(const AdamArgs& a, const DevState&
   }
 }
 
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
   const DevState st = *a.st;
   const long long n4 = (a.n_total + 3) >> 2;
@@ -1903,11 +1920,13 @@ __global__ void __launch_bounds__(kThreads) k_adam(AdamArgs a) {
     a.st->tag_seq = st.tag_seq + 1;
   }
 }
+#endif
 
 // split-K weight gradients (batch > 448): every 256-sample chunk of the batch writes its own partial gradient arena;
 // this pass adds them in chunk order into the gradient arena [0, n) (log_alpha's gradient and the mean_std tail are
 // produced elsewhere and left alone)
 struct SumPartsArgs { const float* part; long long stride; int n_part; float* g; long long n; };
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void __launch_bounds__(kThreads) k_sum_parts(SumPartsArgs a) {
   const long long i4 = ((long long)blockIdx.x * kThreads + threadIdx.x) * 4;
   if (i4 >= a.n) return;
@@ -1923,6 +1942,7 @@ __global__ void __launch_bounds__(kThreads) k_sum_parts(SumPartsArgs a) {
     }
   }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // k_stats: the 14 numeric tb_info entries (dsac_v2.py:188-202) from the partial sums; launched
@@ -1930,10 +1950,12 @@ __global__ void __launch_bounds__(kThreads) k_sum_parts(SumPartsArgs a) {
 // ---------------------------------------------------------------------------------------------
 // dst[i] = src[idx[i]]  (dsact_read_batch: the sampled rows' logp column, one launch + one copy)
 struct TakeArgs { const float* src; const int* idx; float* dst; int n; };
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void k_take(TakeArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < a.n) a.dst[i] = a.src[a.idx[i]];
 }
+#endif
 
 struct StatsArgs {
   const float* part_loss; int n_loss; const float* part_heads; int n_heads;
@@ -1942,6 +1964,7 @@ struct StatsArgs {
   const float* ms_tail;   // nullptr, or mean_std1/2 of the gradient that is pending (not yet committed to DevState)
   const int* spin_timeout;   // merged forward launch: a consumer gave up waiting for its producers -> every statistic reads NaN
 };
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void k_stats(StatsArgs a) {
   const int lane = threadIdx.x;
   float s[kLossPart];
@@ -1970,9 +1993,11 @@ __global__ void k_stats(StatsArgs a) {
       for (int k = 0; k < 14; ++k) o[k] = NAN;
   }
 }
+#endif
 
 // strict data-parallel mode: local {sum std1, sum std2} for the pre-loss all-reduce
 struct StdSumArgs { const float* qstd_c[2]; int B; float* out; };
+#ifndef DSACT_FAMILY_UNIT   // plain kernel: compiled in dsact_api.hip only (dsact_tu.h)
 __global__ void __launch_bounds__(kThreads) k_std_sums(StdSumArgs a) {
   __shared__ float red[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1986,6 +2011,7 @@ __global__ void __launch_bounds__(kThreads) k_std_sums(StdSumArgs a) {
   __syncthreads();
   if (tid == 0) { a.out[0] = red[0] + red[1] + red[2] + red[3]; a.out[1] = red[4] + red[5] + red[6] + red[7]; }
 }
+#endif
 
 // policy head only (sampler / evaluator feed): logits (mean | std) as StochaPolicy.forward returns
 struct PolicyOutArgs { const float* H; const float* Wout; const float* bout; int W, n, A; float lo_ls, hi_ls; float* out; int out_act, out_n; };

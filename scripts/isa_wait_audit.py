@@ -7,8 +7,8 @@ refills / multiplies under a (wave-uniform) `if`, gets `vmcnt(0)` at the top of 
 every trip pays one L2 round trip (round 5: dw2_tile's streaming loop at batch >= 512 -- fixed: branch-free body, peeled
 first trip; the throughput-regime first layer fat_gemm_x has the same shape and measured no gain from the fix).
 
-usage: python scripts/isa_wait_audit.py [substring of a demangled kernel name ...]      (compiles csrc/dsact_api.hip to
-assembly, ~2.5 min, cached in /tmp/dsact_isa/all.s while the sources are unchanged)
+usage: python scripts/isa_wait_audit.py [substring of a demangled kernel name ...]      (compiles the units of csrc/ to
+assembly, ~40 s, cached in /tmp/dsact_isa/all.s while the sources are unchanged)
 Prints, per innermost loop that contains vector-memory loads: its length, loads, MFMAs and its events in order
 (M = MFMA, L = load, wN = s_waitcnt vmcnt(N), B = barrier, d / r = LDS write / read; a count follows a repeated event) -- a `w0`
 in front of the MFMAs of a loop that issues its loads AFTER them is the pattern to look for."""
@@ -31,9 +31,23 @@ def build():
     tag, asm = os.path.join(OUT, "tag"), os.path.join(OUT, "all.s")
     if os.path.exists(asm) and os.path.exists(tag) and open(tag).read() == h.hexdigest():
         return asm
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value",
-                    "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", asm, os.path.join(CSRC, "dsact_api.hip")],
-                   check=True, stderr=subprocess.DEVNULL)
+    # every translation unit of the library (the host side + one unit per kernel family, csrc/dsact_tu.h), side by side
+    from concurrent.futures import ThreadPoolExecutor
+
+    units = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+    def one(u):
+        out = os.path.join(OUT, u + ".s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value",
+                        "-Wno-cuda-compat", "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out, os.path.join(CSRC, u)],
+                       check=True, stderr=subprocess.DEVNULL)
+        return out
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        parts = list(ex.map(one, units))
+    with open(asm, "w") as f:
+        for part in parts:
+            f.write(open(part).read())
     open(tag, "w").write(h.hexdigest())
     return asm
 
