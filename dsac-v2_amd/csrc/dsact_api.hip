@@ -173,7 +173,7 @@ struct dsact_handle {
   // environment switches, read once at dsact_create (getenv walks the whole environment: ~20 calls per eager update
   // were host time on the launch path)
   std::string env_timeline_stage;   // DSACT_TIMELINE_STAGE
-  bool env_no_tile64 = false, env_no_hb_ride = false, env_no_merged_gather = false, env_no_adam_pack = false;
+  bool env_no_merged_gather = false, env_no_adam_pack = false;
   int n_cu = 256;                       // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   int env_conv_dw_nkt = 0;
   int conv_dw_nkt_l[kMaxConv] = {1, 1, 1, 1, 1, 1};   // k-tiles per k_conv_dw workgroup, per layer (DSACT_CONV_DW_NKT_L=a,b,..; DSACT_CONV_DW_NKT: all)
@@ -185,8 +185,6 @@ struct dsact_handle {
   bool env_conv_dw_sb3 = false;         // DSACT_CONV_DW_SB3: layers with three k-tiles per workgroup run the single-buffered form
   bool env_no_conv_fwd64 = false;       // DSACT_NO_CONV_FWD64: wide conv layers' forward on the 32 x 32 tile kernel
   bool env_no_conv_narrow9 = false;     // DSACT_NO_CONV_NARROW9: type_2's third conv layer stays on the LDS-tile forward kernel
-  bool env_conv_dw_fixed_chunk = false; // DSACT_CONV_DW_FIXED_CHUNK: every layer uses conv_dw_chunk(M) (A/B of conv_dw_pick_chunk)
-  int env_ride_slots = 0;           // DSACT_RIDE_SLOTS: weight-gradient tiles riding in the policy-backward launch (default: one round)
   bool mirror_w0 = false;      // set while the merged-gather graph is being captured (see FusedOpt::mir_*)
   bool merged_graph = false;   // the captured graph uses the merged-gather flow
   bool have_local_tail = false;   // the gradient arena's tail holds mean_std of a gradient computed HERE and not yet committed
@@ -294,10 +292,7 @@ struct dsact_handle {
   float act_scale_h[32] = {0}, act_center_h[32] = {0};   // host copies of act_scale / act_center (act_dim <= 32 on this path)
   double act_host_us = 0.0, act_copy_wait_us = 0.0;
   unsigned long long act_host_calls = 0, act_copies = 0;
-  int env_chain_rg_pi = 0;              // DSACT_CHAIN_RG_PI (experiments)
-  bool env_dw_4wave = false;            // DSACT_DW_4WAVE: k_dw2 keeps 4 waves per tile at every batch (A/B)
   bool env_no_conv_dx_mfma = false;     // DSACT_NO_CONV_DX_MFMA: the 16-channel layer's data gradient with k_conv_dx_block (A/B)
-  bool env_no_mixed_rg = false;         // DSACT_NO_MIXED_RG: every unit of the merged forward's group A runs 8-row workgroups (A/B)
   bool fwd_merge = false;               // launches A and B as one (batch <= 256)
   bool pi_merge = false;                // the policy's weight-gradient tiles + the closing block inside the policy-backward launch (batch <= 512; measured equal-to-slower at 1024)
   float* zobs[4];                       // first-layer accumulators after the observation part: q1, q2 (obs), q1_t, q2_t (obs2)
@@ -344,7 +339,6 @@ struct dsact_handle {
   bool bqt_now = false;                 // set while such an update is being enqueued
   // k_chain_bwd_qpt: the whole backward of a policy-moving update of the pipelined graph as one launch
   unsigned long long* bqp_pairs[2] = {nullptr, nullptr};   // dL/d new_act through q1 / q2 as (value, tag) pairs [B][32]
-  int env_bqp_rg_pi = 0;                // DSACT_BQP_RG_PI=1|2: rows / 4 per policy-chain workgroup inside k_chain_bwd_qpt (0: the policy backward's own choice)
   bool env_no_bqp = false;              // DSACT_NO_BQP_MERGE: critics' backward and policy backward stay two launches on those updates (A/B)
   bool bqp_now = false;
   bool pipe_graph = false;              // the captured graphs are the pipelined ones (pgraph / pexec, one per phase)
@@ -352,14 +346,9 @@ struct dsact_handle {
   hipGraphExec_t pexec[kPipePhases] = {nullptr, nullptr, nullptr, nullptr};
   PipeFwd* pargs[kPipePhases] = {nullptr, nullptr, nullptr, nullptr};   // device: one PipeFwd per captured forward launch
   bool env_no_pipe = false;             // DSACT_NO_PIPE: graph replays without the pipelining (A/B)
-  int env_pipe_qt = 0;                  // DSACT_PIPE_QT=1: q_target(obs2', act2') of the next minibatch is precomputed too
   int env_pk_pad = 0;                   // DSACT_PK_PAD: see build_chain
-  int env_pipe_bp_rg = 0;               // DSACT_PIPE_BP_RG=1|2: rows / 4 per workgroup of the deferred policy backward chain (0: as in its own launch)
   bool env_no_pipe_warm = true;         // DSACT_PIPE_WARM=1: L2 warm-up touches in the pipelined forward launches (measured: slower, 60.4 vs 59.6 us)
   bool env_no_pipe_defer = false;       // DSACT_NO_PIPE_DEFER: the discarded policy backward stays in its own update's last launch (A/B)
-  bool env_pipe_qp_split = false;       // DSACT_PIPE_QP_SPLIT: q(obs,new_act) computes its own observation part in every pipelined launch
-  int env_pipe_rg_next = 2;             // DSACT_PIPE_RG_NEXT=1|2: rows / 4 per workgroup of the next minibatch's policy units
-  int env_pipe_rg_side = 2;             // DSACT_PIPE_RG_SIDE=1|2: rows / 4 per workgroup of the units off the critical path (pit, q_c, q_t)
   std::string env_pipe_map;             // DSACT_PIPE_MAP: XCD lists per unit (experiments), see pipe_xcds
   // native collective (RCCL): communicator of this rank, see dsact_comm_init
   void* comm = nullptr;
@@ -1090,7 +1079,7 @@ int run_stage(dsact_handle* h, const Stage& s0, int x0 = 0, int x1 = 0, bool fus
   s.args.fo = fused_opt(h, fused);
   // large batches: 64x64 tiles (k_stage64) when every problem of the stage allows it and nothing rides along
   // (kind 2, plain store: the conv data gradient's dCol products -- many 32 x 32 tiles with a contraction of only 64-256)
-  if (s.args.n_extra == 0 && (s.kind == 0 || s.kind == 1 || (s.kind == 2 && s.name.compare(0, 9, "conv_dcol") == 0)) && !h->env_no_tile64) {   // (dfeat on 48 such tiles: 14.3 vs 12.3 us)
+  if (s.args.n_extra == 0 && (s.kind == 0 || s.kind == 1 || (s.kind == 2 && s.name.compare(0, 9, "conv_dcol") == 0))) {   // (dfeat on 48 such tiles: 14.3 vs 12.3 us)
     bool ok = true;
     int blocks = 0;
     StageArgs a64 = s.args;
@@ -1289,7 +1278,6 @@ int conv_dw_pick_chunk(const dsact_handle* h, int j, int n_st) {
     c = (c + 63) / 64 * 64;
     return (int)(c < c0 ? c0 : c);
   }
-  if (h->env_conv_dw_fixed_chunk) return c0;
   const int nkt = h->conv_dw_nkt_l[j];
   const int per_prob = j == 0 ? n_st : 1, n_prob = n_st / per_prob;
   const long long per_chunk = (long long)tiles_of(per_prob * g.Cout, TM) * tiles_of(tiles_of(g.K + 4, TN), nkt) * n_prob;
@@ -1704,7 +1692,7 @@ int run_dw2(dsact_handle* h, int x0, int x1, bool fused, bool finalize) {
   // long contractions (batch >= 512 per range) with one tile per CU: 8 waves per tile, two per SIMD (dsact_chain.h: dw2_tile NWV)
   // (batch 1024: 13.8 -> 11.8 us, 8,611 -> 8,787 steps/s; batch 4096 with its 960 split-K tiles -- several per CU anyway --
   //  is 0.5 % slower with it, hence the tile-count condition; profiles/r03_ab_dw_8wave.txt)
-  if (L.a.ct >= 32 && (long long)L.n_tiles * h->dw_chunks <= 512 && !h->env_dw_4wave)
+  if (L.a.ct >= 32 && (long long)L.n_tiles * h->dw_chunks <= 512)
     return launch(h, "dW", (k_dw2<2, 8>), dim3(xcd_chunk_grid(L.n_tiles) + (finalize ? 1 : 0), h->dw_chunks), dim3(512), 0, L);
   return launch(h, "dW", k_dw2<2>, dim3(xcd_chunk_grid(L.n_tiles) + (finalize ? 1 : 0), h->dw_chunks), dim3(kThreads), 0, L);
 }
@@ -2052,7 +2040,7 @@ int enqueue_chain_fwd_merged(dsact_handle* h) {
   // workgroups, one per CU, 8 XCDs busy; with group B's 256 that is exactly two per CU.
   XcdMap mixed_map;
   const int nq = h->nq;
-  const bool mixed = rga == 2 && h->B % 8 == 0 && 2 * (h->B / 4) + 2 * nq * (h->B / 8) <= 256 && !h->env_no_mixed_rg;
+  const bool mixed = rga == 2 && h->B % 8 == 0 && 2 * (h->B / 4) + 2 * nq * (h->B / 8) <= 256;
   if (mixed) {
     m.A.u[0].rg = m.A.u[1].rg = 1;
     const int share6[6] = {2, 2, 1, 1, 1, 1}, share4[4] = {2, 2, 2, 2};
@@ -2208,7 +2196,7 @@ static PipePlace pipe_place(const dsact_handle* h, bool pre, bool do_pre, int ro
 // bp: nullptr, or the deferred policy backward of the previous update this launch carries (its chain slices and tiles)
 int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do_pre, PipeFwd& P, const BwdPiArgs* bp = nullptr, bool book = false) {
   memset(&P, 0, sizeof(P));
-  const bool qt_pre = h->env_pipe_qt != 0;
+  const bool qt_pre = false;   // (precomputing the NEXT minibatch's target units too -- DSACT_PIPE_QT, rounds 4-5 -- measured slower and removed)
   int* f = h->chain_flags;
   const int B = h->B;
   int idx[PR_N];
@@ -2217,14 +2205,14 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
   std::string xc[PR_N];
   // rows per workgroup: the critical units (pi -> q_p) run 4-row workgroups; the others 8-row ones (39 % less CU time per
   // row) unless the launch leaves CUs idle anyway; a consumer never has more rows than its producer (it waits for ONE flag)
-  const int side = (B % 8 == 0) ? h->env_pipe_rg_side : 1, nxt = (B % 8 == 0) ? h->env_pipe_rg_next : 1;
+  const int side = (B % 8 == 0) ? 2 : 1, nxt = side;   // 8-row workgroups off the critical path (4-row ones: measured slower, rounds 4-5)
   const int dflt[PR_N] = {1, pre ? side : 1, side, side, nxt, nxt, pre ? side : 1, pre ? side : 1, pre ? side : 1, pre ? side : 1, side, side};
   for (int r = 0; r < PR_N; ++r) {
     const PipePlace pl = pipe_place(h, pre, do_pre, r, dflt[r]);
     rgs[r] = (B % 8 == 0) ? pl.rg : 1; xc[r] = pl.xcds;
   }
   auto cap = [&](int consumer, int producer) { if (rgs[consumer] > rgs[producer]) rgs[consumer] = rgs[producer]; };
-  if (!(pre || h->env_pipe_qp_split)) { cap(PR_Q1P, PR_Q1C); cap(PR_Q2P, PR_Q2C); }
+  if (!pre) { cap(PR_Q1P, PR_Q1C); cap(PR_Q2P, PR_Q2C); }
   if (!pre && h->env_no_pipe_tagged) { cap(PR_Q1P, PR_PI); cap(PR_Q2P, PR_PI); cap(PR_Q1T, PR_PIT); cap(PR_Q2T, PR_PIT); }
   if (h->env_no_pipe_tagged) { cap(PR_Q1TN, PR_PITN); cap(PR_Q2TN, PR_PITN); }   // (tagged pairs are polled per element: any rows)
   auto put = [&](int role, const FwdUnit& u) {
@@ -2264,7 +2252,7 @@ int pipe_fwd_build(dsact_handle* h, int set_own, int set_next, bool pre, bool do
   // that computes the observation part itself and merges the accumulators where the hand-over would have (SEG_FULL_SPLIT)
   // produces the same bits with no producer: that is how the launches whose policy units ran earlier hold it (no in-launch
   // dependency at all), and -- DSACT_PIPE_QP_SPLIT=1 -- optionally the others (observation part under the wait for pi)
-  const bool qp_split = pre || h->env_pipe_qp_split;
+  const bool qp_split = pre;
   for (int i = 0; i < h->nq; ++i) {   // (one critic: DSAC_V1)
     FwdUnit qc = fwd_unit(h, C_Q1C + i, qp_split ? SEG_FULL : SEG_FULL_SAVE, HEAD_Q);
     qc.qout = h->qout_c[i]; qc.qstd = h->qstd_c[i];
@@ -2464,7 +2452,7 @@ void bwd_pi_args(dsact_handle* h, int x0, int x1, bool fused, BwdPiArgs& a, int&
   a.dout_pi = h->dout_pi; a.d_new_act = h->d_new_act; a.dout_piT = h->doutT[2];
   // the policy chain shares its launch with ~2 rounds of weight-gradient tiles, which bound it: 8-row workgroups leave
   // them 32 more CUs (measured: 15.7 us vs 16.3 us with 4-row workgroups at batch 256)
-  const int rg_pi = h->env_chain_rg_pi;   // experiments (4-row slices with the merged tiles waiting for the chain: 20.99 vs 20.04 us, round 3)
+  const int rg_pi = 0;   // (4-row slices with the merged tiles waiting for the chain measured 20.99 vs 20.04 us, round 3: the chain's own choice)
   const int rg = rg_force ? rg_force : h->fat_bwd ? 4 * fat_rt(h, 1) : rg_pi ? rg_pi : h->env_chain_rg ? h->env_chain_rg : (h->B >= 8 ? h->cRG : 1);
   a.n_slices = h->B / (4 * rg); a.B = h->B; a.A = h->A; a.L = L; a.Cb = h->B / 16;
   a.inv_B = 1.0f / (float)h->B; a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed;
@@ -2533,7 +2521,7 @@ int enqueue_chain_bwd_pi_close(dsact_handle* h, bool fused) {
 // k_chain_bwd_qt (dsact_chain.h): may the critics' backward, their weight-gradient tiles and the closing block of an update
 // that defers its policy backward be ONE launch?
 bool bqt_ok(const dsact_handle* h) {
-  return h->chain_ok && h->pi_merge && h->dw_chunks == 1 && !h->fat_bwd && !h->twin && !h->cnn && h->env_ride_slots == 0 && !h->env_no_bqt;
+  return h->chain_ok && h->pi_merge && h->dw_chunks == 1 && !h->fat_bwd && !h->twin && !h->cnn && !h->env_no_bqt;
 }
 // counters + the block -> tile table: tiles class by class in the order their operands arrive (output + last hidden layer,
 // ..., first layer), every class dealt to the XCDs in contiguous eighths (xcd_chunk's locality), block 8 r + x = entry r of XCD x
@@ -2621,7 +2609,7 @@ int enqueue_chain_bwd_qpt(dsact_handle* h, bool fused, const RideArgs* ride) {
   a.q.tagp = &h->st->tag_seq;
   for (int w = 0; w < 4; ++w)
     if (a.q.u[w].which >= 2) a.q.u[w].dA_pairs = h->bqp_pairs[a.q.u[w].which - 2];
-  bwd_pi_args(h, h->dw2_off[0], h->dw2_off[2], fused, a.pi, rg_pi, true, h->env_bqp_rg_pi);
+  bwd_pi_args(h, h->dw2_off[0], h->dw2_off[2], fused, a.pi, rg_pi, true);
   a.pi.cnt_pi = h->bqt_cnt + 2 * 8 * kArriveStride;    // (its own counter: the forward launch's deferred chain uses the flags' one)
   a.pi.dA_pairs[0] = h->bqp_pairs[0]; a.pi.dA_pairs[1] = h->bqp_pairs[1];
   a.pi.tagp = &h->st->tag_seq;
@@ -2654,7 +2642,7 @@ int enqueue_chain_bwd_qpt(dsact_handle* h, bool fused, const RideArgs* ride) {
 // same contract as enqueue_grads (phases, fused optimiser, riders of the loss launch)
 int enqueue_grads_chain(dsact_handle* h, bool actor_backward, bool fused, int phase, const RideArgs* ride) {
   const int* off = h->dw2_off;
-  const bool one_dfeat = h->twin && actor_backward && (phase == 0 || phase == 2) && h->dw_chunks == 1 && h->env_ride_slots == 0;
+  const bool one_dfeat = h->twin && actor_backward && (phase == 0 || phase == 2) && h->dw_chunks == 1;
   if (phase == 4) goto actor_part;
   if (phase != 2) {
     if (h->cnn) TRY(enqueue_conv_forward(h));
@@ -2709,7 +2697,6 @@ actor_part:
   // the critics' dW (+ Adam) tiles ride in the policy-backward launch on the CUs its 32 chain workgroups leave idle
   {
     int ride_end = h->dw2_off[2];
-    if (h->env_ride_slots > 0 && ride_end - h->dw2_off[0] > h->env_ride_slots) ride_end = h->dw2_off[0] + h->env_ride_slots;
     // batch <= 256: the policy's own tiles and the closing block ride in the same launch behind the riders and wait for
     // the chain's arrival counter (k_chain_bwd_pi, merge_dw) -- one launch and one kernel boundary less per update
     if (h->pi_merge && h->dw_chunks == 1 && ride_end == h->dw2_off[2]) {
@@ -2883,7 +2870,7 @@ actor_part:
   // tiles that may ride: the critics' + (behind heads_bwd only) the policy's output layer
   const int ride_end = h->bwdpi.empty() ? h->dw_off[2] : h->dw_pol_rest;
   int ride_hb = 0;
-  if (phase == 0 && !(h->use_fork && !h->profiling) && !h->env_no_hb_ride) {
+  if (phase == 0 && !(h->use_fork && !h->profiling)) {
     ride_hb = (ride_end - h->dw_off[0]) / n_carriers;
     if (ride_hb > crit_tiles) ride_hb = crit_tiles;
   }
@@ -3253,8 +3240,6 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->loss_rows = 4;
   h->auto_std_sums = h->B > 1024;   // large batches: the std column is summed once, not by every wave
   if (const char* v = getenv("DSACT_TIMELINE_STAGE")) h->env_timeline_stage = v;
-  h->env_no_tile64 = getenv("DSACT_NO_TILE64") != nullptr;
-  h->env_no_hb_ride = getenv("DSACT_NO_HB_RIDE") != nullptr;
   h->env_no_merged_gather = getenv("DSACT_NO_MERGED_GATHER") != nullptr;
   h->env_no_adam_pack = getenv("DSACT_NO_ADAM_PACK") != nullptr;
   { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && v > 0) h->n_cu = v; (void)hipGetLastError(); }
@@ -3275,23 +3260,13 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   for (int j = 0; j < h->n_conv; ++j)
     if (h->conv_dw_nkt_l[j] < 1 || h->conv_dw_nkt_l[j] > 3) h->conv_dw_nkt_l[j] = tiles_of(h->cg[j].K + 4, TN) == 3 ? 1 : 2;
   for (int j = h->n_conv; j < kMaxConv; ++j) h->conv_dw_nkt_l[j] = 1;
-  h->env_conv_dw_fixed_chunk = getenv("DSACT_CONV_DW_FIXED_CHUNK") != nullptr;
-  if (const char* v = getenv("DSACT_RIDE_SLOTS")) h->env_ride_slots = atoi(v);
-  if (const char* v = getenv("DSACT_CHAIN_RG_PI")) h->env_chain_rg_pi = atoi(v);
-  h->env_no_mixed_rg = getenv("DSACT_NO_MIXED_RG") != nullptr;
   h->env_no_pipe = getenv("DSACT_NO_PIPE") != nullptr;
-  if (const char* v = getenv("DSACT_PIPE_QT")) h->env_pipe_qt = atoi(v) ? 1 : 0;
-  h->env_pipe_qp_split = getenv("DSACT_PIPE_QP_SPLIT") != nullptr;
   h->env_no_pipe_defer = getenv("DSACT_NO_PIPE_DEFER") != nullptr;
   h->env_no_bqt = getenv("DSACT_NO_BQT_MERGE") != nullptr;
   h->env_no_bqp = getenv("DSACT_NO_BQP_MERGE") != nullptr;
-  if (const char* v = getenv("DSACT_BQP_RG_PI")) h->env_bqp_rg_pi = atoi(v) == 1 ? 1 : atoi(v) == 2 ? 2 : 0;
   h->env_no_pipe_warm = getenv("DSACT_PIPE_WARM") == nullptr;
   h->env_no_pipe_tagged = getenv("DSACT_NO_PIPE_TAGGED") != nullptr;
   if (const char* v = getenv("DSACT_PK_PAD")) h->env_pk_pad = atoi(v) > 0 && atoi(v) <= 64 ? atoi(v) : 0;
-  if (const char* v = getenv("DSACT_PIPE_BP_RG")) h->env_pipe_bp_rg = atoi(v) == 1 ? 1 : atoi(v) == 2 ? 2 : 0;
-  if (const char* v = getenv("DSACT_PIPE_RG_NEXT")) h->env_pipe_rg_next = atoi(v) == 1 ? 1 : 2;
-  if (const char* v = getenv("DSACT_PIPE_RG_SIDE")) h->env_pipe_rg_side = atoi(v) == 1 ? 1 : 2;
   if (const char* v = getenv("DSACT_PIPE_MAP")) h->env_pipe_map = v;
   h->env_no_conv_dx_mfma = getenv("DSACT_NO_CONV_DX_MFMA") != nullptr;
   h->env_no_conv_narrow9 = getenv("DSACT_NO_CONV_NARROW9") != nullptr;
@@ -3305,7 +3280,6 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (const char* v = getenv("DSACT_CONV_DW_REG_WGS")) h->env_conv_dw_reg_wgs = atoi(v) > 0 ? atoi(v) : 512;
   if (const char* v = getenv("DSACT_CONV_FWD64_MIN")) h->env_conv_fwd64_min = atoi(v);
   if (const char* v = getenv("DSACT_DCOL64_MIN_M")) h->env_dcol64_min_m = atoi(v);
-  h->env_dw_4wave = getenv("DSACT_DW_4WAVE") != nullptr;
   if (const char* v = getenv("DSACT_CHAIN_RG")) h->env_chain_rg = atoi(v) == 1 ? 1 : atoi(v) == 4 ? 4 : 2;
   h->dw_chunks = (h->B > 448 && h->B % 256 == 0 && getenv("DSACT_NO_SPLITK") == nullptr) ? h->B / 256 : 1;   // (chain path: below)
   h->dw_part_stride = (h->n_online + 2 + 63) & ~(size_t)63;
@@ -4171,10 +4145,10 @@ static int plan_updates_pipe(dsact_handle* h, int n, int phase, PipePlan& plan, 
   plan.host.resize((size_t)n); plan.pre.resize((size_t)n); plan.dop.resize((size_t)n);
   plan.defer.assign((size_t)n, 0); plan.bp.resize((size_t)n); plan.bp_rg.assign((size_t)n, 2);
   // the discarded policy backward can move when it is the merged launch's (chain + its own tiles behind the arrival counter)
-  const int rg_pi = h->env_chain_rg_pi ? h->env_chain_rg_pi : h->env_chain_rg ? h->env_chain_rg : (h->B >= 8 ? h->cRG : 1);
+  const int rg_pi = h->env_chain_rg ? h->env_chain_rg : (h->B >= 8 ? h->cRG : 1);
   // (data parallel: the same -- on those updates k_adam_pack leaves the policy alone, so the policy segment of the all-reduced
   //  arena is read by nobody; the deferred tiles store nothing and that segment simply keeps its previous content)
-  const bool can_defer = h->pi_merge && h->dw_chunks == 1 && !h->fat_bwd && h->env_ride_slots == 0 && rg_pi <= 2 && !h->env_no_pipe_defer;
+  const bool can_defer = h->pi_merge && h->dw_chunks == 1 && !h->fat_bwd && rg_pi <= 2 && !h->env_no_pipe_defer;
   plan.dp = (flags & DSACT_F_DATA_PARALLEL) != 0;
   plan.skip = (flags & DSACT_F_SKIP_ACTOR_ON_OFF_ITERS) != 0 && !plan.dp;
   plan.leaves.assign((size_t)n, 0);
@@ -4198,7 +4172,7 @@ static int plan_updates_pipe(dsact_handle* h, int n, int phase, PipePlan& plan, 
       // (the deferred chain shares its launch with forward chains, not with ~500 riding tiles: 4-row slices by default)
       // (fused = false: the tiles compute, apply nothing and store nothing -- and never read the step state, which the
       //  bookkeeping block of THIS forward launch may be rewriting for the update the launch belongs to)
-      bwd_pi_args(h, h->dw2_off[2], h->dw2_off[2], false, a, plan.bp_rg[(size_t)s], true, h->env_pipe_bp_rg);
+      bwd_pi_args(h, h->dw2_off[2], h->dw2_off[2], false, a, plan.bp_rg[(size_t)s], true);
       a.finalize = 0;                     // that update was closed by its own last launch
       a.dw.store_g = 0;                   // nothing reads this gradient (fused: no optimiser step on that update either)
       bp = &a;
