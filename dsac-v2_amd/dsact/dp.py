@@ -58,6 +58,7 @@ class DataParallelUpdater:
             engine.comm_init(self.rank, self.world, ids[0])
         # overlap: all-reduce the critics' segment (2/3 of the arena) while the actor's backward still runs
         self.overlap = bool(overlap) and not self.strict and hasattr(engine, "dp_grads_critic")
+        self.graph_mode = False   # set by build_graph; run() without one takes the eager coordinator
         # replicas must start identical: rank 0's parameters / optimiser state win
         with self._on_engine_stream():
             for t in broadcast_tensors:
@@ -91,7 +92,13 @@ class DataParallelUpdater:
                 raise
             ok, err = 0, ex
         if self.world > 1:
-            t = torch.tensor([ok], dtype=torch.int32, device=getattr(self.engine, "device", "cpu"))
+            # (the flag lives where the GROUP's backend can reduce it: gloo groups are legitimate here -- the gradient traffic
+            #  goes over the library's own RCCL communicator -- and cannot take a CUDA tensor)
+            try:
+                cpu_group = "gloo" in str(dist.get_backend(self.group)).lower()
+            except Exception:
+                cpu_group = True
+            t = torch.tensor([ok], dtype=torch.int32, device="cpu" if cpu_group else getattr(self.engine, "device", "cpu"))
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
             all_ok = int(t.item())
         else:

@@ -109,7 +109,9 @@ typedef struct dsact_config {
    * 1 = "parameter" (:63-73,92-97: the MLP gives the mean, log_std is a learnable (1, act_dim) parameter). With 1 the arenas
    * keep the (2 act_dim x H) output layer: rows [act_dim, 2 act_dim) of its weight are structurally zero (the caller zeroes
    * them once; their gradient is masked, so Adam / Polyak leave them at 0) and the second half of its bias IS log_std.
-   * DSAC_V2 with MLP nets on the row-slice chain path only (equal hidden widths 64 / 128 / 256, batch a multiple of 16). */
+   * DSAC_V2 with MLP nets, on BOTH kernel families: the row-slice chains (equal hidden widths 64 / 128 / 256, batch a multiple
+   * of 16; DwProb::msplit masks the gradient) and the tile stages (every other shape, incl. split-K at batch > 448, unequal
+   * widths and non-linear output activations; GemmProb::mzero) -- tests/test_std_parameter.py covers a shape of each. */
   int32_t policy_std_param;
   /* value_output_activation / policy_output_activation (utils/common_utils.py:16-45 -> networks/mlp.py:15-20: the module that
    * follows the LAST Linear): 0 = "linear" (every shipped example), 1 relu, 2 elu, 3 selu, 4 sigmoid, 5 tanh ("gelu" as an

@@ -81,6 +81,7 @@ def test_unsupported_combinations_are_refused():
     (376, 17, (256, 256, 256), 256, {}),                           # the BASELINE shape
     (11, 3, (96, 40), 50, {}),                                     # tile path (ragged widths, odd observation width)
     (376, 17, (256, 256, 256), 1024, {}),                          # throughput-regime kernels
+    (23, 5, (96, 40), 512, {}),                                    # tile path with split-K weight gradients (batch > 448): ADVICE r5
     (24, 6, (64, 64), 64, {"policy_act_distribution": "GaussDistribution"}),
 ])
 def test_parameter_std_against_the_oracle(O, A, hid, B, over):
