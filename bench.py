@@ -427,7 +427,7 @@ def e2e_gpu(hidden, device, iters=400, warm=60):
     try:
         if e.debug_get("act_host") == 1.0:   # the acting forward runs on the calling thread (csrc/dsact_host_act.h)
             fwd_split = {"where": "host", "forward_us": e.debug_get("act_host_us"), "threads": e.debug_get("act_host_threads"),
-                         "isa": {0.0: "x86-64", 1.0: "avx2+fma", 2.0: "avx512f"}.get(e.debug_get("act_host_isa")), "snapshot_copies": e.debug_get("act_copies"),
+                         "isa": {0.0: "x86-64", 1.0: "avx2+fma", 2.0: "avx512f"}.get(e.debug_get("act_host_isa")), "helpers_pinned": e.debug_get("act_host_pinned"), "helpers_moved": e.debug_get("act_host_repins"), "snapshot_copies": e.debug_get("act_copies"),
                          "calls": e.debug_get("act_host_calls"), "last_copy_wait_us": e.debug_get("act_copy_wait_us")}
         else:
             fwd_split = {"where": "gpu", "launch_call_us": e.debug_get("act_launch_us"), "completion_spin_us": e.debug_get("act_wait_us")}

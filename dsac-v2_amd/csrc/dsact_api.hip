@@ -288,6 +288,9 @@ struct dsact_handle {
   unsigned long long pol_copied = 0;    // epoch the snapshot (or the copy in flight) belongs to
   float* act_buf = nullptr;             // host scratch: two activation buffers + the output layer's products
   hostact::Pool* act_pool = nullptr;    // fork-join helpers for the wide layers (nullptr: the calling thread alone)
+  std::vector<int> act_pin;             // CPUs the helpers are pinned to (cores sharing the last-level cache with the caller)
+  int act_cpu = -1;                     // CPU of the calling thread when the helpers were (re)pinned
+  unsigned act_repins = 0;
   int act_threads = 0;                  // 0: not calibrated yet; DSACT_HOST_ACT_THREADS forces a count
   float act_scale_h[32] = {0}, act_center_h[32] = {0};   // host copies of act_scale / act_center (act_dim <= 32 on this path)
   double act_host_us = 0.0, act_copy_wait_us = 0.0;
@@ -3998,7 +4001,27 @@ static int act_forward_host(dsact_handle* h, const float* obs_host, const float*
       if (!ev && h->act_pool->pinned() < t - 1) { delete h->act_pool; h->act_pool = nullptr; t = 1; }   // (a cpuset refused the pinning)
     }
     h->act_threads = t;
+#if defined(__linux__)
+    h->act_pin = pin; h->act_cpu = cpu;
+#endif
   }
+#if defined(__linux__)
+  // The scheduler may move the calling thread to another core complex (a long-running trainer, other legs of a benchmark in
+  // the same process): helpers pinned beside the OLD core then make every layer's fork-join cross complexes (measured: 2.7 ->
+  // 5.7 us per forward). Every 256th call: if the caller's CPU is neither where it was nor among the helpers' cache siblings,
+  // the helpers follow it.
+  if (h->act_pool && h->act_pool->pinned() > 0 && (h->act_host_calls & 255) == 255) {
+    const int cpu = sched_getcpu();
+    if (cpu >= 0 && cpu != h->act_cpu) {
+      h->act_cpu = cpu;
+      const std::vector<int> pin = hostact::llc_sibling_cores(cpu);   // (sysfs reads: only when the caller actually moved)
+      const size_t need = (size_t)h->act_threads - 1;
+      bool same = pin.size() >= need && h->act_pin.size() >= need;
+      for (size_t i = 0; same && i < need; ++i) same = pin[i] == h->act_pin[i];
+      if (!same && pin.size() >= need) { h->act_pool->repin(pin); h->act_pin = pin; h->act_repins++; }
+    }
+  }
+#endif
   const auto t1 = std::chrono::steady_clock::now();
   hostact::forward(ly, h->L + 1, h->cfg.policy_act, obs_host, b0, b1, raw, h->act_pool);
   hostact::head(raw, h->A, h->cfg.min_log_std, h->cfg.max_log_std, eps, h->act_scale_h, h->act_center_h, out, logp);
@@ -4937,6 +4960,7 @@ int dsact_debug_get(const dsact_handle* h, const char* name, double* value) {
   else if (!strcmp(name, "act_host_us")) *value = h->act_host_us;
   else if (!strcmp(name, "act_host_threads")) *value = (double)h->act_threads;
   else if (!strcmp(name, "act_host_pinned")) *value = h->act_pool ? (double)h->act_pool->pinned() : 0.0;
+  else if (!strcmp(name, "act_host_repins")) *value = (double)h->act_repins;
   else if (!strcmp(name, "act_host_isa")) *value = (double)hostact::cpu_isa();
   else if (!strcmp(name, "act_copy_wait_us")) *value = h->act_copy_wait_us;
   else if (!strcmp(name, "act_host_calls")) *value = (double)h->act_host_calls;

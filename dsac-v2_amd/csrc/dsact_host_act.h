@@ -238,6 +238,19 @@ class Pool {
     }
   }
   int pinned() const { return pinned_; }
+  // move the helpers (the calling thread migrated to another core complex: see llc_sibling_cores); returns the number pinned
+  int repin(const std::vector<int>& pin_to) {
+    pinned_ = 0;
+#if defined(__linux__)
+    for (size_t i = 0; i < th_.size() && i < pin_to.size(); ++i) {
+      cpu_set_t set;
+      CPU_ZERO(&set);
+      CPU_SET(pin_to[i], &set);
+      if (pthread_setaffinity_np(th_[i].native_handle(), sizeof(set), &set) == 0) ++pinned_;
+    }
+#endif
+    return pinned_;
+  }
   ~Pool() {
     stop_.store(true);
     gen_.fetch_add(1);
