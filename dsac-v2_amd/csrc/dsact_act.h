@@ -39,6 +39,7 @@ struct ActArgs {
   // epilogue): ONE wave per action dimension d computes both of its logits (rows d and A + d), draws
   // a = scale * tanh(mean + std * eps[d]) + center and this dimension's log-prob term; out = A (action | log-prob term) pairs
   int sample;
+  int out_act, out_n;               // policy_output_activation (ACT_* id, 0: linear) and the outputs it applies to (2A, or A: mean half only)
   const float* act_scale; const float* act_center;
   float eps[32];                    // the host's torch.randn(1, A) draw (consumes the generator as Normal.sample() does)
   float x[kActMaxObs];              // the observation
@@ -120,6 +121,10 @@ __global__ void __launch_bounds__(256) k_act_mlp(ActArgs a) {
     act_fwd_grad(a.act, acc, hv, gd);
     __hip_atomic_store(a.h + (size_t)l * kMaxWidth + n, act_pair(hv, a.call), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
+  }
+  if (a.out_act) {   // (wave-uniform) the module that follows the last Linear (networks/mlp.py:15-20)
+    if (smp) { acc = out_act_fwd(a.out_act, acc); if (a.A + n < a.out_n) acc2 = out_act_fwd(a.out_act, acc2); }
+    else if (n < a.out_n) acc = out_act_fwd(a.out_act, acc);
   }
   if (smp) {
     // TanhGaussDistribution.sample(): the closed form the training kernels use for rsample (dsact_math.h), term for term

@@ -437,7 +437,10 @@ int net_act(const dsact_handle* h, int net);
 const NetDesc& net_desc(const dsact_handle* h, int net) { return (net == N_POL || net == N_POLT) ? h->pd : h->qd; }
 
 // any net with a hidden activation other than GELU: the forward chains run their generic-activation instantiations
-bool generic_act(const dsact_handle* h) { return h->cfg.value_act != ACT_GELU || h->cfg.policy_act != ACT_GELU; }
+// (the generic-activation instantiations also carry the heads' OUTPUT activations, round 6)
+bool generic_act(const dsact_handle* h) {
+  return h->cfg.value_act != ACT_GELU || h->cfg.policy_act != ACT_GELU || h->cfg.value_out_act != 0 || h->cfg.policy_out_act != 0;
+}
 // hidden activation of a net's MLP layers (value_hidden_activation / policy_hidden_activation, common_utils.py:16-45)
 int net_act(const dsact_handle* h, int net) { return (net == N_POL || net == N_POLT) ? h->cfg.policy_act : h->cfg.value_act; }
 
@@ -1745,6 +1748,9 @@ FwdUnit fwd_unit(const dsact_handle* h, int ch, int seg, int head) {
   if (seg != SEG_OBS_ONLY)
     for (int l = 0; l < h->L; ++l) { u.H[l] = h->Hb[ch][l]; u.G[l] = h->Gb[ch][l]; }
   u.head = head;
+  if (head == HEAD_Q && h->cfg.value_out_act) u.head |= h->cfg.value_out_act << HEAD_OUT_ACT_SHIFT;
+  if (head == HEAD_POLICY && h->cfg.policy_out_act)
+    u.head |= (h->cfg.policy_out_act << HEAD_OUT_ACT_SHIFT) | (h->cfg.policy_std_param ? HEAD_STD_PLAIN : 0);
   u.act = net_act(h, net);
   return u;
 }
@@ -2401,6 +2407,7 @@ void bwd_q_args(dsact_handle* h, int n_units, const RideArgs* ride, BwdQArgs& a,
     a.ldo = 2 * W; a.c1at = 2 * CH; a.ldz0 = h->w[0];
   }
   a.v1 = h->nq == 1; a.td_bound = h->cfg.td_bound; a.v1_bound = h->cfg.v1_unbounded ? 0 : 1;
+  a.q_out_act = h->cfg.value_out_act;
   const int rg = h->fat_bwd ? 4 * fat_rt(h, n_units) : chain_rg(h, n_units, true);
   a.n_units = n_units; a.n_slices = h->B / (4 * rg); a.B = h->B; a.A = h->A; a.L = L; a.Cb = h->B / 16;
   for (int i = 0; i < 2; ++i) {   // (one critic: the second slots repeat the first -- the DSAC_V1 row phase never reads them)
@@ -2460,6 +2467,7 @@ void bwd_pi_args(dsact_handle* h, int x0, int x1, bool fused, BwdPiArgs& a, int&
   a.n_slices = h->B / (4 * rg); a.B = h->B; a.A = h->A; a.L = L; a.Cb = h->B / 16;
   a.inv_B = 1.0f / (float)h->B; a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed;
   a.act_scale = h->act_scale; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
+  a.pi_out_act = h->cfg.policy_out_act; a.pi_out_n = h->cfg.policy_std_param ? h->A : 2 * h->A;
   a.part_loss = h->part_loss; a.n_part = h->B; a.target_entropy = -(float)h->A;
   a.grad_log_alpha = h->grads + h->n_online - 1;
   a.n_chain_blocks = roundup(a.n_slices, 8);   // the riders' first block lands on XCD 0 (xcd_chunk)
@@ -3294,7 +3302,9 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
               getenv("DSACT_NO_CHAIN") == nullptr && !(h->nq == 1 && getenv("DSACT_NO_CHAIN_V1") != nullptr) &&
               !(h->cnn && (getenv("DSACT_NO_CHAIN_CNN") != nullptr || h->B > 1024));
     ok = ok && h->L <= kChMaxL;
-    ok = ok && cfg->value_out_act == 0 && cfg->policy_out_act == 0;   // output activations live in the tile-stage row kernels only
+    // (round 6: non-linear OUTPUT activations run on the chains too -- the generic-activation instantiations of the forward
+    //  kernels carry them, the backward row phases multiply by their derivative; the throughput-regime kernels of batch >= 1024
+    //  do not: `fat` below)
     ok = ok && !h->unequal_widths;                                     // one width per layer for every chain unit
     for (int l = 0; l < h->L; ++l) ok = ok && cfg->hidden[l] == cfg->hidden[0];
     const int W0 = cfg->hidden[0];
@@ -3326,7 +3336,8 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
       const char* fb = getenv("DSACT_FAT_BWD_MIN");
       const int fat_bwd_min = fb ? atoi(fb) : 4096;
       // (the throughput-regime kernels hold DSAC_V2's two-critic row phase: one critic keeps the 8-row chains at every batch)
-      h->fat = ok && !h->cnn && h->nq == 2 && h->B >= fat_min && h->B % 32 == 0 && (W0 == 128 || W0 == 256) && getenv("DSACT_NO_FAT") == nullptr;
+      h->fat = ok && !h->cnn && h->nq == 2 && h->B >= fat_min && h->B % 32 == 0 && (W0 == 128 || W0 == 256) && getenv("DSACT_NO_FAT") == nullptr &&
+               cfg->value_out_act == 0 && cfg->policy_out_act == 0;   // (their heads are linear-only)
       h->fat_bwd = h->fat && h->B >= fat_bwd_min;
       if (const char* v = getenv("DSACT_FAT_RT")) h->env_fat_rt = atoi(v) == 2 ? 2 : 1;
     }
@@ -4024,7 +4035,8 @@ static int act_forward_host(dsact_handle* h, const float* obs_host, const float*
 #endif
   const auto t1 = std::chrono::steady_clock::now();
   hostact::forward(ly, h->L + 1, h->cfg.policy_act, obs_host, b0, b1, raw, h->act_pool);
-  hostact::head(raw, h->A, h->cfg.min_log_std, h->cfg.max_log_std, eps, h->act_scale_h, h->act_center_h, out, logp);
+  hostact::head(raw, h->A, h->cfg.min_log_std, h->cfg.max_log_std, eps, h->act_scale_h, h->act_center_h, out, logp,
+                h->cfg.policy_out_act, h->cfg.policy_std_param ? h->A : 2 * h->A);
   h->act_host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
   h->act_host_calls++;
   return DSACT_OK;
@@ -5004,6 +5016,7 @@ static int act_forward_fast(dsact_handle* h, const float* obs_host, const float*
   a.A = h->A; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std; a.act = h->cfg.policy_act;
   a.out = h->act_out_dev; a.timeout = h->handoff_dev + 1;   // the acting forward's own hand-off word (check_handoff)
   a.sample = eps ? 1 : 0; a.act_scale = h->act_scale; a.act_center = h->act_center;
+  a.out_act = h->cfg.policy_out_act; a.out_n = h->cfg.policy_std_param ? h->A : 2 * h->A;
   if (eps) memcpy(a.eps, eps, (size_t)h->A * sizeof(float));
   memcpy(a.x, obs_host, (size_t)h->O * sizeof(float));
   const auto tl = std::chrono::steady_clock::now();
@@ -5031,8 +5044,7 @@ static int act_forward_fast(dsact_handle* h, const float* obs_host, const float*
   return check_handoff(h);
 }
 static bool act_fast_ok(const dsact_handle* h) {
-  // (an output activation other than linear is served by the general path: k_policy_out applies it)
-  return !h->cnn && h->O <= kActMaxObs && h->L + 1 <= kActMaxLayers && !h->env_no_fast_act && h->A <= 32 && h->cfg.policy_out_act == 0;
+  return !h->cnn && h->O <= kActMaxObs && h->L + 1 <= kActMaxLayers && !h->env_no_fast_act && h->A <= 32;
 }
 
 // OffSampler.sample()'s per-step device work in ONE call (training/off_sampler.py:46-54): policy(obs) on the live weights +

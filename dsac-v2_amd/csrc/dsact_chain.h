@@ -598,6 +598,14 @@ enum : int { HEAD_NONE = 0, HEAD_POLICY = 1, HEAD_Q = 2 };
 // the dispatch order than their partners, so the bounded spin cannot deadlock.
 enum : int { HEAD_KIND = 15, HEAD_TWIN_FIRST = 16, HEAD_TWIN_SECOND = 32 };
 __host__ __device__ inline int head_code(int kind, int twin_role, int c_out) { return kind | twin_role | (c_out << 8); }
+// Round 6 -- OUTPUT activations on the chains (value_output_activation / policy_output_activation, networks/mlp.py:15-20; until now
+// the tile-stage kernels only): bits 16-18 of FwdUnit::head = the ACT_* id applied to the head's outputs (0: linear), bit 19 =
+// the policy's log-std outputs are NOT activated (policy_std_type "parameter": log_std is a plain parameter, networks/mlp.py:92-97).
+// The heads store POST-activation outputs, as the tile path's do (k_heads); the derivative is expressed through them
+// (out_act_grad_y) in the backward row phases. Compiled only into the generic-activation instantiations (GA): every shipped
+// example is linear, and the default kernels stay exactly as they were.
+enum : int { HEAD_OUT_ACT_SHIFT = 16, HEAD_STD_PLAIN = 1 << 19 };
+__host__ __device__ inline int head_out_act(int head) { return (head >> HEAD_OUT_ACT_SHIFT) & 7; }
 enum : int { HW_LATE = 1, HW_PAIRS_OUT = 2, HW_PAIRS_IN = 4, HW_HEAD = 8 };
 
 struct FwdUnit {
@@ -760,7 +768,8 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
   const int L = a.L, F = a.F, A = a.A;
   const int S0 = a.s_obs + u.s_act;               // steps of this unit's first layer
   const int head = u.head & HEAD_KIND, twin = u.head & (HEAD_TWIN_FIRST | HEAD_TWIN_SECOND);
-  const int c_out = (u.head >> 8) ? (u.head >> 8) : W / 16;
+  const int c_out = ((u.head >> 8) & 0xff) ? ((u.head >> 8) & 0xff) : W / 16;
+  const int oact = GA ? head_out_act(u.head) : 0;
   const ChainLds S = chain_lds(4 * (a.s_obs + a.s_act), W, R);
   const int xin = S.off_in, red = S.off_red;
   CTL(a.timeline, 0);
@@ -1024,8 +1033,10 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
       float mean = narrow_get<4, NW>(lds, red, m, 0), raw = narrow_get<4, NW>(lds, red, m, 1);
       if (add_carry) { mean += carry[m * 64]; raw += carry[m * 64 + 1]; }
       mean += pre_bmu[0]; raw += pre_braw[0];
+      float sgm = 1.0f;
+      if (GA && oact) { mean = out_act_fwd(oact, mean); raw = out_act_fwd(oact, raw); sgm = out_act_grad_y(oact, raw); }
       u.qout[2 * r] = mean; u.qout[2 * r + 1] = raw;
-      if (u.qstd) { u.qstd[2 * r] = softplus(raw); u.qstd[2 * r + 1] = softplus_grad(raw); }
+      if (u.qstd) { u.qstd[2 * r] = softplus(raw); u.qstd[2 * r + 1] = softplus_grad(raw) * sgm; }   // d std / d (pre-activation output)
     }
     CTL(a.timeline, 13);
     CTLR(a.timeline, 15);
@@ -1041,6 +1052,7 @@ __device__ __forceinline__ void chain_fwd_body(const AT& a, const UT& u, int uni
     float mu = narrow_get<4, NW>(lds, red, m, d), raw = narrow_get<4, NW>(lds, red, m, A + d);
     if (add_carry) { mu += carry[m * 64 + d]; raw += carry[m * 64 + A + d]; }
     mu += pre_bmu[q]; raw += pre_braw[q];
+    if (GA && oact) { mu = out_act_fwd(oact, mu); if (!(u.head & HEAD_STD_PLAIN)) raw = out_act_fwd(oact, raw); }
     const TanhGaussFwd f = tanh_gauss_fwd(mu, raw, pre_eps[q], pre_s[q], pre_c[q], a.lo_ls, a.hi_ls);
     lp += f.lp;
     st_agent(u.xact + (size_t)r * a.ldx + F + d, f.a);
@@ -1225,6 +1237,7 @@ struct BwdQTail {
   int ldo;                         // floats between the two rows of wout (0: W; twin trunks: 2W -- the dense block-diagonal matrix)
   int c1at;                        // chunks of 16 k per 16-row tile of w1at (0: W / 16; twin trunks: 2W / 16)
   int ldz0;                        // row stride of dz0row
+  int q_out_act;                   // the critics' output activation (0: linear): qout_* / qstd_* hold POST-activation values
   // merged launch (k_chain_bwd_qt): the critics' own chains (which 0 / 1) hand their dZ packs / dL/dout to the critics'
   // weight-gradient tiles of the SAME launch: counter [which] (8 replicas, kArriveStride ints apart) counts the slices of
   // that chain whose stores (write-through) have all been acknowledged
@@ -1344,6 +1357,8 @@ __device__ __forceinline__ void bwd_q_body(const QA& a, int block, float* lds) {
   else if (u.which == 1) { d0 = c2.dq * a.inv_B; d1 = c2.dstd * a.inv_B * sg2; }
   else if (u.which == 2) { d0 = -wq1 * a.inv_B; d1 = 0.0f; }
   else { d0 = -(1.0f - wq1) * a.inv_B; d1 = 0.0f; }
+  if (a.q_out_act)   // (wave-uniform; sg1 / sg2 already carry the activation's derivative of the std output)
+    d0 *= out_act_grad_y(a.q_out_act, u.which == 0 ? q1 : u.which == 1 ? q2 : u.which == 2 ? q1p : q2p);
   float v1_loss = 0.f;
   if (a.v1) {
     // dsac_v1.py:184-253, term for term as k_loss_v1 (dsact_kernels.h): one critic, z5 is q_target's sample noise
@@ -1484,6 +1499,7 @@ struct BwdPiArgs {
   float* dout_piT;                 // transposed pack of dout_pi [2A (16-row tiles)][batch]
   int n_slices, B, A, L, Cb;
   float inv_B; int auto_alpha; float alpha_fixed;
+  int pi_out_act, pi_out_n;        // the policy's output activation (0: linear) and the outputs it applies to (A: mean half only); logits_pi is POST-activation
   const float* act_scale; float lo_ls, hi_ls;
   const float* part_loss; int n_part; float target_entropy; float* grad_log_alpha;
   int n_chain_blocks;
@@ -1589,6 +1605,10 @@ __device__ __forceinline__ void bwd_pi_body(const BwdPiArgs& a, int slice, float
     const float dA = pdA[q];
     float dmu, draw;
     tanh_gauss_bwd(pmu[q], praw[q], peps[q], psc[q], a.lo_ls, a.hi_ls, dA, alpha * a.inv_B, dmu, draw);
+    if (a.pi_out_act) {   // (wave-uniform)
+      dmu *= out_act_grad_y(a.pi_out_act, pmu[q]);
+      if (A + d < a.pi_out_n) draw *= out_act_grad_y(a.pi_out_act, praw[q]);
+    }
     if (lead) {
       a.dout_pi[(size_t)r * 2 * A + d] = dmu;
       a.dout_pi[(size_t)r * 2 * A + A + d] = draw;

@@ -330,8 +330,14 @@ inline void forward(const Layer* ly, int n_layers, int act, const float* obs, fl
 // caller's N(0,1) draw -- tanh_gauss_fwd of dsact_math.h term for term, as k_act_mlp's sample mode. raw: the output layer's
 // 2A products (mean | raw log-std). eps == nullptr: out = the 2A logits (mean | exp(clamp(raw))) of StochaPolicy.forward
 // (networks/mlp.py:85-100); else action[A] and the summed log-probability.
-inline void head(const float* raw, int A, float lo_ls, float hi_ls, const float* eps, const float* scale, const float* center,
-                 float* action_or_logits, float* logp) {
+inline void head(const float* raw_in, int A, float lo_ls, float hi_ls, const float* eps, const float* scale, const float* center,
+                 float* action_or_logits, float* logp, int out_act = 0, int out_n = 0) {
+  float act_buf[64];
+  const float* raw = raw_in;
+  if (out_act) {   // policy_output_activation: the module that follows the last Linear, on the outputs it applies to
+    for (int i = 0; i < 2 * A; ++i) act_buf[i] = i < out_n ? out_act_fwd(out_act, raw_in[i]) : raw_in[i];
+    raw = act_buf;
+  }
   if (!eps) {
     for (int d = 0; d < A; ++d) { action_or_logits[d] = raw[d]; action_or_logits[A + d] = expf(clampf(raw[A + d], lo_ls, hi_ls)); }
     return;

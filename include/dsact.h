@@ -115,9 +115,12 @@ typedef struct dsact_config {
   int32_t policy_std_param;
   /* value_output_activation / policy_output_activation (utils/common_utils.py:16-45 -> networks/mlp.py:15-20: the module that
    * follows the LAST Linear): 0 = "linear" (every shipped example), 1 relu, 2 elu, 3 selu, 4 sigmoid, 5 tanh ("gelu" as an
-   * output activation is refused). Anything but 0 selects the tile-stage kernels (round 1's launch structure) -- the row-slice
-   * chains and the one-launch acting forward are built for linear outputs; DSAC_V2 with MLP nets only. With policy_std_param
-   * the policy's activation applies to the mean half only (log_std is a plain parameter, networks/mlp.py:92-97). */
+   * output activation is refused). DSAC_V2 with MLP nets only. Round 6: served by the row-slice chains wherever a linear head would
+   * be (the generic-activation instantiations of the forward kernels apply it in the heads, the backward row phases multiply by
+   * its derivative expressed through the stored POST-activation outputs) and by both acting forwards; shapes the chains do not
+   * take, and batch >= 1024's throughput-regime kernels, fall to the chains' generic forms / the tile-stage kernels as for linear
+   * heads. With policy_std_param the policy's activation applies to the mean half only (log_std is a plain parameter,
+   * networks/mlp.py:92-97). */
   int32_t value_out_act, policy_out_act;
   /* value_hidden_sizes != policy_hidden_sizes (utils/common_utils.py:59-62 reads them per key): `hidden` sizes the critics,
    * `policy_hidden[l]` > 0 the policy nets (all zeros: the same widths). Same number of layers; DSAC_V2 with MLP nets on the

@@ -48,6 +48,8 @@ def close(h, g, lim, tag):
     (24, 6, (64, 64), 64, 0.4, {"policy_act_distribution": "GaussDistribution"}),
     (16, 4, (64, 64), 64, 0.4, {"policy_hidden_sizes": [96, 40]}),
     (16, 4, (64, 64), 64, 0.4, {"policy_hidden_activation": "tanh"}),
+    (24, 6, (64, 64), 64, 0.4, {"policy_output_activation": "tanh", "value_output_activation": "tanh"}),
+    (24, 6, (64, 64), 64, 0.4, {"policy_output_activation": "sigmoid", "policy_std_type": "parameter"}),
 ])
 def test_host_forward_equals_gpu_forward(O, A, hid, B, lim, over):
     alg, _ = make_pair(O, A, hid, B, act_limit=lim, seed=61, **over)

@@ -1,7 +1,8 @@
 """value_output_activation / policy_output_activation other than "linear" (reference utils/common_utils.py:16-45 -> the module
-behind the last Linear of networks/mlp.py:15-20; kwargs of SURVEY.md section 8 rows a10 / a12). The HIP path serves them with the
+behind the last Linear of networks/mlp.py:15-20; kwargs of SURVEY.md section 8 rows a10 / a12). Round 5 served them with the
 tile-stage kernels (k_heads / k_loss / k_heads_bwd / k_policy_out apply the activation and its derivative, expressed through the
-stored post-activation outputs); the row-slice chains and the one-launch acting forward stay linear-only."""
+stored post-activation outputs); round 6 also on the row-slice chains (the generic-activation instantiations of the forward kernels
+apply it in the heads, the backward row phases multiply by out_act_grad_y) and in both acting forwards (host / one launch)."""
 import numpy as np
 import pytest
 import torch
@@ -49,7 +50,9 @@ def test_host_closed_forms_of_the_output_activations():
 @pytest.mark.gpu
 @pytest.mark.parametrize("O,A,hid,B,over", [
     (24, 6, (64, 64), 64, {"value_output_activation": "tanh", "policy_output_activation": "tanh"}),
-    (376, 17, (256, 256, 256), 256, {"value_output_activation": "tanh"}),                 # the BASELINE shape on the tile stages
+    (376, 17, (256, 256, 256), 256, {"value_output_activation": "tanh"}),                 # the BASELINE shape (row-slice chains since round 6)
+    (376, 17, (256, 256, 256), 256, {"value_output_activation": "relu", "policy_output_activation": "elu"}),
+    (376, 17, (256, 256, 256), 1024, {"value_output_activation": "tanh", "policy_output_activation": "tanh"}),   # batch 1024: chains, not the (linear-only) throughput-regime kernels
     (11, 3, (96, 40), 50, {"value_output_activation": "sigmoid", "policy_output_activation": "elu"}),
     (24, 6, (64, 64), 64, {"value_output_activation": "selu", "policy_output_activation": "sigmoid"}),
     (24, 6, (64, 64), 64, {"policy_output_activation": "tanh", "policy_std_type": "parameter"}),   # log_std is not activated
@@ -64,24 +67,40 @@ def test_output_activations_against_the_oracle(O, A, hid, B, over):
 
 
 @pytest.mark.gpu
-def test_output_activation_selects_the_tile_stages_and_the_general_acting_path():
+def test_output_activation_runs_on_the_chains_and_in_both_acting_forwards(monkeypatch):
     from oracle.dsact_oracle import policy_forward
     from test_hip_parity import make_pair
 
     O, A, hid, B = 24, 6, (64, 64), 64
     alg, orc = make_pair(O, A, hid, B, seed=2, value_output_activation="tanh", policy_output_activation="tanh")
     e = alg.engine
-    assert not e.chain_active and e.debug_get("act_fast") == 0.0
-    plain, _ = make_pair(O, A, hid, B, seed=2)
-    assert plain.engine.chain_active and plain.engine.debug_get("act_fast") == 1.0
+    assert e.chain_active and e.debug_get("act_fast") == 1.0        # round 5: tile stages + the general acting path
+    monkeypatch.setenv("DSACT_NO_CHAIN", "1")
+    tiles, _ = make_pair(O, A, hid, B, seed=2, value_output_activation="tanh", policy_output_activation="tanh")
+    monkeypatch.delenv("DSACT_NO_CHAIN")
+    assert not tiles.engine.chain_active
     obs = np.random.default_rng(0).standard_normal((3, O)).astype(np.float32)
     want = policy_forward(torch.as_tensor(obs), [p.detach() for p in orc.p["policy"]], orc.cfg).numpy()
-    np.testing.assert_allclose(e.policy_forward(obs), want, atol=2e-5, rtol=1e-5)
-    np.testing.assert_allclose(np.concatenate([e.policy_forward(obs[i:i + 1]) for i in range(3)]), want, atol=2e-5, rtol=1e-5)
     assert np.all(np.abs(want[:, :A]) <= 1.0)        # tanh-activated means
+    for eng in (e, tiles.engine):
+        for host in (1, 0):                          # acting forward on the host / as one launch; 3 rows at once: the tile-stage forward
+            eng.debug_set("host_act", host)
+            np.testing.assert_allclose(np.concatenate([eng.policy_forward(obs[i:i + 1]) for i in range(3)]), want, atol=2e-5, rtol=1e-5)
+        np.testing.assert_allclose(eng.policy_forward(obs), want, atol=2e-5, rtol=1e-5)
+    e.debug_set("host_act", 1)
     # the attached module's forward (what samplers / evaluators call) goes through the same kernels
     got = alg.networks.policy(torch.as_tensor(obs)).cpu().numpy()
     np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-5)
+    # the sampling step with the activation in front of the tanh-Gaussian: host == one launch
+    eps = np.full((1, A), 0.25, np.float32)
+    outs = []
+    for host in (1, 0):
+        e.debug_set("host_act", host)
+        a, lp = e.act_sample(obs[0], eps)
+        outs.append((a.copy(), float(lp[0])))
+    e.debug_set("host_act", 1)
+    np.testing.assert_allclose(outs[0][0], outs[1][0], atol=2e-6, rtol=0)
+    assert abs(outs[0][1] - outs[1][1]) <= 5e-4
 
 
 @pytest.mark.gpu
