@@ -24,7 +24,9 @@ namespace dsact {
 constexpr int kActMaxObs = 768;
 constexpr int kActMaxLayers = kChMaxL + 1;
 
-struct ActLayer { const float* W; const float* b; int K, N; };   // row-major [N][K] in the parameter arena
+struct ActLayer { const float* W; const float* b; int K, N; int half; };   // row-major [N][K] in the parameter arena; half > 0: a
+                                                                         // twin-trunk hidden layer (policy_std_type "mlp_separated"): two [half][K]
+                                                                         // blocks one after the other, rows >= half read inputs [K, 2K)
 struct ActArgs {
   ActLayer ly[kActMaxLayers];
   int n_layers;                     // hidden layers + the output layer
@@ -92,7 +94,7 @@ __global__ void __launch_bounds__(256) k_act_mlp(ActArgs a) {
     for (int j = 0; j < NJ; ++j)
       if (64 * j + lane < Ly.K) acc = fmaf(w[j], xk[64 * j + lane], acc);
   } else {
-    const unsigned long long* hin = a.h + (size_t)(l - 1) * kMaxWidth;
+    const unsigned long long* hin = a.h + (size_t)(l - 1) * kMaxWidth + ((Ly.half > 0 && n >= Ly.half) ? Ly.K : 0);   // (wave-uniform)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       if (64 * j < Ly.K) {                    // wave-uniform

@@ -3183,6 +3183,9 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (cfg->policy_std_param != 0 && cfg->policy_std_param != 1) return fail(h, DSACT_E_INVALID, "policy_std_param must be 0 (mlp_shared) or 1 (parameter)");
   if (cfg->policy_std_param && (cfg->conv_type != DSACT_CONV_NONE || cfg->algo != 0))
     return fail(h, DSACT_E_INVALID, "policy_std_type 'parameter' is built for DSAC_V2 with MLP nets");
+  if (cfg->policy_twin != 0 && cfg->policy_twin != 1) return fail(h, DSACT_E_INVALID, "policy_twin must be 0 or 1 (policy_std_type mlp_separated)");
+  if (cfg->policy_twin && (cfg->conv_type != DSACT_CONV_NONE || cfg->algo != 0 || cfg->policy_std_param))
+    return fail(h, DSACT_E_INVALID, "policy_std_type 'mlp_separated' is built for DSAC_V2 with MLP nets (and excludes 'parameter')");
   for (int oa : {cfg->value_out_act, cfg->policy_out_act})
     if (oa != 0 && (oa < ACT_RELU || oa > ACT_TANH)) return fail(h, DSACT_E_INVALID, "output activation must be 0 (linear) or 1..5 (relu, elu, selu, sigmoid, tanh)");
   if ((cfg->value_out_act || cfg->policy_out_act) && (cfg->conv_type != DSACT_CONV_NONE || cfg->algo != 0))
@@ -3230,9 +3233,12 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   }
   if (unequal && (cfg->conv_type != DSACT_CONV_NONE || cfg->algo != 0))
     return fail(h, DSACT_E_INVALID, "value_hidden_sizes != policy_hidden_sizes is built for DSAC_V2 with MLP nets (tile-stage kernels)");
-  h->unequal_widths = unequal;
+  // policy_std_type "mlp_separated": the policy nets are twin trunks (NetDesc::nblk == 2) beside single-trunk critics -- their
+  // activation rows are twice as wide as their hidden sizes, so this is an unequal-widths configuration too (tile-stage kernels)
+  const int nblk_pol = cfg->policy_twin ? 2 : nblk;
+  h->unequal_widths = unequal || nblk_pol != nblk;
   for (int l = 0; l < h->L; ++l) {
-    h->wq[l] = nblk * cfg->hidden[l]; h->wp[l] = nblk * pol_hidden[l];
+    h->wq[l] = nblk * cfg->hidden[l]; h->wp[l] = nblk_pol * pol_hidden[l];
     h->w[l] = h->wq[l] > h->wp[l] ? h->wq[l] : h->wp[l];
   }
   for (int l = 0; l < h->L; ++l)
@@ -3240,7 +3246,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   h->ldx = (h->F + h->A + 3) & ~3;
   h->use_w1p = (size_t)4 * nblk * cfg->hidden[0] * h->ldx <= ((size_t)4 << 20);
   build_net(h->qd, h->F + h->A, cfg->hidden, h->L, 2, nblk, h->n_conv, h->cg);
-  build_net(h->pd, h->F, pol_hidden, h->L, 2 * h->A, nblk, h->n_conv, h->cg);
+  build_net(h->pd, h->F, pol_hidden, h->L, 2 * h->A, nblk_pol, h->n_conv, h->cg);
   h->n_q = h->qd.count; h->n_pi = h->pd.count;
   if (cfg->algo != DSACT_ALGO_DSAC_V2 && cfg->algo != DSACT_ALGO_DSAC_V1) return fail(h, DSACT_E_INVALID, "algo must be 0 (DSAC_V2) or 1 (DSAC_V1)");
   h->nq = cfg->algo == DSACT_ALGO_DSAC_V1 ? 1 : 2;
@@ -3986,7 +3992,8 @@ static int act_forward_host(dsact_handle* h, const float* obs_host, const float*
   hostact::Layer ly[kActMaxLayers];
   for (int l = 0; l <= h->L; ++l) {
     ly[l].W = h->pol_host + h->pd.w_off[l]; ly[l].b = h->pol_host + h->pd.b_off[l];
-    ly[l].K = h->pd.in[l]; ly[l].N = h->pd.out[l];
+    ly[l].K = h->pd.in[l]; ly[l].N = h->pd.out[l]; ly[l].half = 0;
+    if (h->pd.nblk == 2 && l > 0 && l < h->L) { ly[l].K = h->pd.in[l] / 2; ly[l].half = h->pd.out[l] / 2; }   // two (H x Hprev) blocks
   }
   float* b0 = h->act_buf; float* b1 = b0 + kMaxWidth + 64; float* raw = b1 + kMaxWidth + 64;
   if (h->act_threads == 0) {
@@ -5001,7 +5008,8 @@ static int act_forward_fast(dsact_handle* h, const float* obs_host, const float*
   int wg = 0;
   for (int l = 0; l <= h->L; ++l) {
     a.ly[l].W = base + h->pd.w_off[l]; a.ly[l].b = base + h->pd.b_off[l];
-    a.ly[l].K = h->pd.in[l]; a.ly[l].N = h->pd.out[l];
+    a.ly[l].K = h->pd.in[l]; a.ly[l].N = h->pd.out[l]; a.ly[l].half = 0;
+    if (h->pd.nblk == 2 && l > 0 && l < h->L) { a.ly[l].K = h->pd.in[l] / 2; a.ly[l].half = h->pd.out[l] / 2; }   // two (H x Hprev) blocks
     a.wg_begin[l] = wg;
     wg += ((l == h->L && eps ? h->A : h->pd.out[l]) + 3) / 4;
   }

@@ -36,7 +36,8 @@
 namespace dsact {
 namespace hostact {
 
-struct Layer { const float* W; const float* b; int K, N; };
+struct Layer { const float* W; const float* b; int K, N; int half; };   // half > 0: a twin-trunk hidden layer -- two [half][K] blocks one
+                                                                    // after the other, rows >= half read inputs [K, 2K) (dsact_act.h, ActLayer)
 
 #if defined(__clang__)
 #define DSACT_HOSTACT_CONTRACT _Pragma("clang fp contract(fast)")
@@ -139,7 +140,11 @@ struct Layer { const float* W; const float* b; int K, N; };
   }                                                                                                                               \
   /* rows [n0, n1) of a layer (n0, n1 multiples of 16 or the layer's end) + its hidden activation */                             \
   ATTR static void layer_rows(const Layer& L, int act, bool hidden, const float* x, float* y, int n0, int n1) {                   \
-    dense(L, x, y, n0, n1);                                                                                                       \
+    if (L.half > 0) {                                                                                                             \
+      const int m = n1 < L.half ? n1 : L.half, q = n0 > L.half ? n0 : L.half;                                                     \
+      if (n0 < m) dense(L, x, y, n0, m);                                                                                          \
+      if (q < n1) dense(L, x + L.K, y, q, n1);                                                                                    \
+    } else dense(L, x, y, n0, n1);                                                                                                \
     if (!hidden) return;                                                                                                          \
     const int np = (n1 + 15) & ~15;                     /* (the last chunk also owns the padding behind the layer's end) */       \
     for (int i = n1; i < np; ++i) y[i] = 0.f;                                                                                     \

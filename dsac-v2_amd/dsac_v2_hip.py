@@ -124,8 +124,9 @@ ACTIVATIONS = {"gelu": (0, nn.GELU), "relu": (1, nn.ReLU), "elu": (2, nn.ELU), "
                "sigmoid": (4, nn.Sigmoid), "tanh": (5, nn.Tanh)}
 
 
-# policy_std_type (reference networks/mlp.py:43-73): "mlp_shared" (every example) and "parameter"; "mlp_separated" is refused
-STD_TYPES = ("mlp_shared", "parameter")
+# policy_std_type (reference networks/mlp.py:43-73): "mlp_shared" (every example), "parameter", and "mlp_separated" (two MLPs `mean` /
+# `log_std` side by side in the arena like the CNN nets' twin trunks: dsact_config.policy_twin)
+STD_TYPES = ("mlp_shared", "parameter", "mlp_separated")
 
 
 # value_output_activation / policy_output_activation (utils/common_utils.py:16-45; the module behind the last Linear,
@@ -164,6 +165,9 @@ class HipStochaPolicy(nn.Module):
         if std_type == "parameter":   # networks/mlp.py:63-73: the MLP gives the mean, log_std is a learnable parameter
             self.mean = _mlp([obs_dim] + list(hidden) + [act_dim], activation, out_activation)
             self.log_std = nn.Parameter(-0.5 * torch.ones(1, act_dim))
+        elif std_type == "mlp_separated":   # networks/mlp.py:46-57: mean and log_std from two MLPs, constructed in this order
+            self.mean = _mlp([obs_dim] + list(hidden) + [act_dim], activation, out_activation)
+            self.log_std = _mlp([obs_dim] + list(hidden) + [act_dim], activation, out_activation)
         else:
             self.policy = _mlp([obs_dim] + list(hidden) + [2 * act_dim], activation, out_activation)
         self.min_log_std, self.max_log_std = float(min_log_std), float(max_log_std)
@@ -180,6 +184,8 @@ class HipStochaPolicy(nn.Module):
         if self.std_type == "parameter":
             mean = self.mean(obs)
             log_std = self.log_std + torch.zeros_like(mean)
+        elif self.std_type == "mlp_separated":
+            mean, log_std = self.mean(obs), self.log_std(obs)
         else:
             out = self.policy(obs)
             mean, log_std = torch.chunk(out, chunks=2, dim=-1)
@@ -304,9 +310,9 @@ def _check_supported(kwargs):
         raise NotImplementedError("cnn_shared is not supported by the HIP path")
     st = kwargs.get("policy_std_type", "mlp_shared")
     if st not in STD_TYPES:
-        raise NotImplementedError("DSAC_V2_HIP supports policy_std_type in %s (got %r: two separate MLPs are not built)" % (sorted(STD_TYPES), st))
-    if st == "parameter" and _conv_type(kwargs):
-        raise NotImplementedError("policy_std_type='parameter' is built for the MLP approximators only")
+        raise NotImplementedError("DSAC_V2_HIP supports policy_std_type in %s (got %r)" % (sorted(STD_TYPES), st))
+    if st != "mlp_shared" and _conv_type(kwargs):
+        raise NotImplementedError("policy_std_type=%r is built for the MLP approximators only" % st)
 
 
 class ApproxContainer(nn.Module):
@@ -388,6 +394,8 @@ class ApproxContainer(nn.Module):
                 zr = getattr(self._layout, "zero_rows", lambda _n: None)(net)
                 if zr is not None:
                     arenas[zr[0]][zr[1]:zr[1] + zr[2]].zero_()
+                for arena, off, shape, strides in getattr(self._layout, "zero_blocks", lambda _n: [])(net):   # "mlp_separated"
+                    torch.as_strided(arenas[arena], shape, strides, off).zero_()
             for pol in (self.policy, self.policy_target):
                 pol.act_high_lim = pol.act_high_lim.to(engine.device)
                 pol.act_low_lim = pol.act_low_lim.to(engine.device)

@@ -88,6 +88,7 @@ class DsactEngine:
         cfg.v1_unbounded = 0 if v1_bound else 1
         cfg.value_act, cfg.policy_act = int(value_act), int(policy_act)   # hidden activations: 0 gelu .. 5 tanh (include/dsact.h)
         cfg.policy_std_param = 1 if policy_std_type == "parameter" else 0   # networks/mlp.py:63-73 (include/dsact.h)
+        cfg.policy_twin = 1 if policy_std_type == "mlp_separated" else 0    # networks/mlp.py:46-57: two MLPs side by side
         if policy_hidden is not None and list(policy_hidden) != list(hidden):   # value_hidden_sizes != policy_hidden_sizes (include/dsact.h)
             if conv_type or len(policy_hidden) != len(hidden):
                 raise DsactError("policy_hidden needs the MLP nets and as many layers as `hidden`")

@@ -16,6 +16,48 @@ def mlp_sizes(in_dim: int, hidden: List[int], out_dim: int) -> List[Tuple[int, i
     return [(dims[i + 1], dims[i]) for i in range(len(dims) - 1)]  # (out, in) per Linear
 
 
+def twin_mlp_views(off: int, in0: int, hid: List[int], nb: int):
+    """Two MLPs (`mean`, `log_std`: in0 -> hid -> nb each) laid side by side from float `off` on (include/dsact.h, NetDesc::nblk == 2):
+      layer 0        [mean.0.weight ; log_std.0.weight]  (2*H0 x in0) | [mean.0.bias ; log_std.0.bias]
+      hidden layer l mean.W (H x Hprev) | log_std.W (H x Hprev) | [b_mean ; b_ls]
+      output layer   (2 nb x 2H) = [[w_mean, 0], [0, w_ls]] | [b_mean ; b_ls]      (zero blocks structural)
+    -> (views of `mean`, views of `log_std`, [(offset, shape, strides)] of the structural zero blocks, end offset);
+    a view is (suffix, offset, shape, strides)."""
+    L = len(hid)
+    mean, lstd, zeros = [], [], []
+    width_in = in0
+    for l in range(L + 1):
+        if l == 0:
+            h0 = hid[0]
+            mean.append(("mean.0.weight", off, (h0, in0), (in0, 1)))
+            lstd.append(("log_std.0.weight", off + h0 * in0, (h0, in0), (in0, 1)))
+            off += 2 * h0 * in0
+            mean.append(("mean.0.bias", off, (h0,), (1,)))
+            lstd.append(("log_std.0.bias", off + h0, (h0,), (1,)))
+            off += 2 * h0
+            width_in = h0
+        elif l < L:
+            h, hp = hid[l], width_in
+            mean.append(("mean.%d.weight" % (2 * l), off, (h, hp), (hp, 1)))
+            lstd.append(("log_std.%d.weight" % (2 * l), off + h * hp, (h, hp), (hp, 1)))
+            off += 2 * h * hp
+            mean.append(("mean.%d.bias" % (2 * l), off, (h,), (1,)))
+            lstd.append(("log_std.%d.bias" % (2 * l), off + h, (h,), (1,)))
+            off += 2 * h
+            width_in = h
+        else:
+            hp = width_in
+            mean.append(("mean.%d.weight" % (2 * l), off, (nb, hp), (2 * hp, 1)))
+            lstd.append(("log_std.%d.weight" % (2 * l), off + nb * 2 * hp + hp, (nb, hp), (2 * hp, 1)))
+            zeros.append((off + hp, (nb, hp), (2 * hp, 1)))
+            zeros.append((off + nb * 2 * hp, (nb, hp), (2 * hp, 1)))
+            off += 2 * nb * 2 * hp
+            mean.append(("mean.%d.bias" % (2 * l), off, (nb,), (1,)))
+            lstd.append(("log_std.%d.bias" % (2 * l), off + nb, (nb,), (1,)))
+            off += 2 * nb
+    return mean, lstd, zeros, off
+
+
 class ArenaLayout:
     def __init__(self, obs_dim: int, act_dim: int, hidden: List[int], n_critics: int = 2, policy_std_type: str = "mlp_shared",
                  policy_hidden: Optional[List[int]] = None):
@@ -24,17 +66,24 @@ class ArenaLayout:
         policy_std_type "parameter" (reference networks/mlp.py:63-73): the arena keeps the policy's output layer in the
         (2 act_dim x H) shape of "mlp_shared" -- the kernels are the same -- with rows [act_dim, 2 act_dim) of the weight
         STRUCTURALLY ZERO (never exposed, their gradient masked: csrc DwProb::msplit) and the second half of the bias being
-        the reference's `log_std` parameter: raw log-std = 0 . h + log_std, d log_std = sum over the batch of d raw."""
+        the reference's `log_std` parameter: raw log-std = 0 . h + log_std, d log_std = sum over the batch of d raw.
+
+        policy_std_type "mlp_separated" (networks/mlp.py:46-57): the policy is two MLPs `mean` / `log_std` (obs -> hidden -> act_dim
+        each), kept side by side like the CNN nets' twin trunks (`twin_mlp_views`; dsact_config.policy_twin)."""
         self.obs_dim, self.act_dim, self.hidden = int(obs_dim), int(act_dim), [int(h) for h in hidden]
         self.n_critics = int(n_critics)
         self.policy_std_type = policy_std_type
-        assert policy_std_type in ("mlp_shared", "parameter")
+        assert policy_std_type in ("mlp_shared", "parameter", "mlp_separated")
+        self.policy_twin = policy_std_type == "mlp_separated"
         # value_hidden_sizes != policy_hidden_sizes (utils/common_utils.py:59-62): `hidden` sizes the critics, `policy_hidden` the policy nets
         self.policy_hidden = [int(h) for h in policy_hidden] if policy_hidden is not None else list(self.hidden)
         self.q_shapes = mlp_sizes(obs_dim + act_dim, self.hidden, 2)
         self.pi_shapes = mlp_sizes(obs_dim, self.policy_hidden, 2 * act_dim)
         self.n_q = sum(o * i + o for o, i in self.q_shapes)
         self.n_pi = sum(o * i + o for o, i in self.pi_shapes)
+        if self.policy_twin:
+            self.pi_shapes = mlp_sizes(obs_dim, self.policy_hidden, act_dim)      # one trunk
+            self._pi_mean, self._pi_lstd, self._pi_zeros, self.n_pi = twin_mlp_views(0, self.obs_dim, self.policy_hidden, self.act_dim)
         nq = self.n_critics
         self.n_online = nq * self.n_q + self.n_pi + 1
         self.n_target = nq * self.n_q + self.n_pi
@@ -97,8 +146,19 @@ class ArenaLayout:
         o, i = shapes[-1]
         return arena, off + self.act_dim * i, self.act_dim * i
 
+    def zero_blocks(self, net: str):
+        """[(arena, storage_offset, shape, strides)] of the structural zero blocks of a twin-trunk policy net's output layer"""
+        if not (net.startswith("policy") and self.policy_twin):
+            return []
+        arena, base = self.net_offset[net]
+        return [(arena, base + off, shape, strides) for off, shape, strides in self._pi_zeros]
+
     def param_views(self, net: str):
-        """[(suffix, arena, storage_offset, shape, strides)] -- contiguous views for the MLP nets."""
+        """[(suffix, arena, storage_offset, shape, strides)] -- contiguous views for the MLP nets (the output layers of a
+        twin-trunk policy: windows of one (2 act_dim x 2H) matrix), in the reference's state_dict order."""
+        if net.startswith("policy") and self.policy_twin:
+            arena, base = self.net_offset[net]
+            return [(sfx, arena, base + off, shape, strides) for sfx, off, shape, strides in self._pi_mean + self._pi_lstd]
         out = []
         for suffix, arena, off, shape in self.param_slices(net):
             strides = (shape[1], 1) if len(shape) == 2 else (1,)
@@ -110,6 +170,12 @@ class ArenaLayout:
         sd = OrderedDict()
         sd["log_alpha"] = ()
         for net in self.all_nets:
+            if net.startswith("policy") and self.policy_twin:
+                sd[net + ".act_high_lim"] = (self.act_dim,)
+                sd[net + ".act_low_lim"] = (self.act_dim,)
+                for suffix, _, _, shape, _ in self.param_views(net):
+                    sd[net + "." + suffix] = shape
+                continue
             slices = self.param_slices(net)
             if net.startswith("policy"):
                 if self.policy_std_type == "parameter":   # a module's own parameters precede its buffers
@@ -128,8 +194,9 @@ class ArenaLayout:
         p_layers = [(o, i) for o, i in self.pi_shapes]
         q_fwd = sum(o * i for o, i in q_layers)
         p_fwd = sum(o * i for o, i in p_layers)
+        ntr = 2 if self.policy_twin else 1         # "mlp_separated": two trunks of pi_shapes each
         nq = self.n_critics
-        fwd = 2 * p_fwd + 3 * nq * q_fwd
+        fwd = 2 * ntr * p_fwd + 3 * nq * q_fwd
         # critic: dW all layers + dX of layers >= 1 (per critic)
         q_dw = q_fwd
         q_dx = sum(o * i for o, i in q_layers[1:])
@@ -138,7 +205,7 @@ class ArenaLayout:
         w0 = q_layers[0][0]
         act = nq * (q_dx + w0 * self.act_dim)
         # policy: dW all + dX of layers >= 1
-        pol = p_fwd + sum(o * i for o, i in p_layers[1:])
+        pol = ntr * (p_fwd + sum(o * i for o, i in p_layers[1:]))
         return fwd, crit + act + pol
 
     def flop_per_step(self, batch: int) -> float:
@@ -231,37 +298,7 @@ class CnnArenaLayout:
             off += co * K
             views.append(("conv.%d.bias" % (2 * j), off, (co,), (1,)))
             off += co
-        hid = self.hidden
-        L = len(hid)
-        mean, lstd = [], []
-        width_in = in0
-        for l in range(L + 1):
-            if l == 0:
-                h0 = hid[0]
-                mean.append(("mean.0.weight", off, (h0, in0), (in0, 1)))
-                lstd.append(("log_std.0.weight", off + h0 * in0, (h0, in0), (in0, 1)))
-                off += 2 * h0 * in0
-                mean.append(("mean.0.bias", off, (h0,), (1,)))
-                lstd.append(("log_std.0.bias", off + h0, (h0,), (1,)))
-                off += 2 * h0
-                width_in = h0
-            elif l < L:
-                h, hp = hid[l], width_in
-                mean.append(("mean.%d.weight" % (2 * l), off, (h, hp), (hp, 1)))
-                lstd.append(("log_std.%d.weight" % (2 * l), off + h * hp, (h, hp), (hp, 1)))
-                off += 2 * h * hp
-                mean.append(("mean.%d.bias" % (2 * l), off, (h,), (1,)))
-                lstd.append(("log_std.%d.bias" % (2 * l), off + h, (h,), (1,)))
-                off += 2 * h
-                width_in = h
-            else:
-                hp = width_in
-                mean.append(("mean.%d.weight" % (2 * l), off, (nb, hp), (2 * hp, 1)))
-                lstd.append(("log_std.%d.weight" % (2 * l), off + nb * 2 * hp + hp, (nb, hp), (2 * hp, 1)))
-                off += 2 * nb * 2 * hp
-                mean.append(("mean.%d.bias" % (2 * l), off, (nb,), (1,)))
-                lstd.append(("log_std.%d.bias" % (2 * l), off + nb, (nb,), (1,)))
-                off += 2 * nb
+        mean, lstd, _, off = twin_mlp_views(off, in0, self.hidden, nb)
         self._views[kind] = views + mean + lstd
         return off
 

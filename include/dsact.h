@@ -126,6 +126,14 @@ typedef struct dsact_config {
    * `policy_hidden[l]` > 0 the policy nets (all zeros: the same widths). Same number of layers; DSAC_V2 with MLP nets on the
    * tile-stage kernels (the row-slice chains run one width per layer across every unit). */
   int32_t policy_hidden[DSACT_MAX_HIDDEN_LAYERS];
+  /* policy_std_type "mlp_separated" (networks/mlp.py:46-57,80-85): 1 = the policy is TWO MLPs over the observation, `mean` and
+   * `log_std`, each obs -> hidden -> act_dim (0: one of the two forms policy_std_param selects). The arenas keep them side by
+   * side, exactly as the CNN nets' twin trunks: layer 0 one dense (2 H0 x obs) matrix [mean.0 ; log_std.0], hidden layer l two
+   * (H x Hprev) blocks mean | log_std, output layer the dense (2 act_dim x 2 H) matrix [[w_mean, 0], [0, w_log_std]] whose two
+   * zero blocks are structural (the caller zeroes them once; no gradient is ever written there), biases [b_mean ; b_log_std].
+   * DSAC_V2 with MLP nets, tile-stage kernels (the critics stay single MLPs: the row-slice chains run one trunk count per
+   * launch); policy_std_param must be 0. Both acting forwards serve it (a block layer is a row range with an input offset). */
+  int32_t policy_twin;
 } dsact_config;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

@@ -126,7 +126,36 @@ def policy_forward(obs, params, cfg, collect=None, sides=None, kink_log=None):
     """StochaPolicy.forward (networks/mlp.py:79-100): std_type "mlp_shared" (one MLP -> mean | log_std, the default of every
     example) or "parameter" (cfg["policy_std_type"]: the MLP gives the mean, log_std is a learnable (1, act_dim) parameter --
     here the LAST element of `params`; networks/mlp.py:63-73,92-97)."""
-    if cfg.get("policy_std_type", "mlp_shared") == "parameter":
+    if cfg.get("policy_std_type", "mlp_shared") == "mlp_separated":
+        # networks/mlp.py:46-57,80-85: two MLPs over the observation; params = the `mean` MLP's tensors, then `log_std`'s. The two
+        # trunks are walked layer by layer so that `collect` receives ONE row [z_mean | z_log_std] per layer (the layout the HIP
+        # arenas keep); the concatenation and the split back are exact, the values are those of two separate nn.Sequential passes
+        # (tests/test_oracle_vs_reference.py pins it bit for bit to the live reference).
+        n = len(params) // 2
+        act, out_act = cfg.get("policy_act", "gelu"), cfg.get("policy_out_act", "linear")
+        hm = hl = obs
+        for j in range(n // 2):
+            zm = F.linear(hm, params[2 * j], params[2 * j + 1])
+            zl = F.linear(hl, params[n + 2 * j], params[n + 2 * j + 1])
+            last = j == n // 2 - 1
+            if collect is not None:
+                zc = torch.cat([zm, zl], dim=-1)
+                collect.append(zc)
+                zm, zl = (t.contiguous() for t in torch.chunk(zc, chunks=2, dim=-1))   # (the next Linear sees the layout it has in the reference)
+            if last:
+                hm = zm if out_act == "linear" else ACTIVATIONS[out_act](zm)
+                hl = zl if out_act == "linear" else ACTIVATIONS[out_act](zl)
+            elif sides is not None and act in ("relu", "selu"):
+                sm, sl = torch.chunk(sides[j], chunks=2, dim=-1)
+                for z, sd in ((zm, sm), (zl, sl)):
+                    flip = sd != (z > 0)
+                    if kink_log is not None and bool(flip.any()):
+                        kink_log.append((j, int(flip.sum()), float(z.detach()[flip].abs().max())))
+                hm, hl = _act_with_side(zm, act, sm), _act_with_side(zl, act, sl)
+            else:
+                hm, hl = ACTIVATIONS[act](zm), ACTIVATIONS[act](zl)
+        mean, log_std = hm, hl
+    elif cfg.get("policy_std_type", "mlp_shared") == "parameter":
         mean = mlp_forward(obs, params[:-1], collect, cfg.get("policy_act", "gelu"), sides, kink_log, cfg.get("policy_out_act", "linear"))
         log_std = params[-1] + torch.zeros_like(mean)
     else:
@@ -257,6 +286,8 @@ class DsactOracle:
     def _new_pi_params(self):
         cfg = self.cfg
         hid = list(cfg.get("policy_hidden") or cfg["hidden"])   # policy_hidden_sizes when they differ from value_hidden_sizes
+        if self._std_twin:    # networks/mlp.py:46-57: the `mean` MLP, then the `log_std` MLP (construction order = RNG order)
+            return (_new_mlp_params([cfg["obs_dim"]] + hid + [cfg["act_dim"]]) + _new_mlp_params([cfg["obs_dim"]] + hid + [cfg["act_dim"]]))
         if self._std_param:   # networks/mlp.py:63-73: the mean MLP, then log_std = -0.5 (no RNG consumed)
             return (_new_mlp_params([cfg["obs_dim"]] + hid + [cfg["act_dim"]])
                     + [torch.full((1, cfg["act_dim"]), -0.5, dtype=torch.float32)])
@@ -265,6 +296,22 @@ class DsactOracle:
     @property
     def _std_param(self):
         return self.cfg.get("policy_std_type", "mlp_shared") == "parameter"
+
+    @property
+    def _std_twin(self):
+        return self.cfg.get("policy_std_type", "mlp_shared") == "mlp_separated"
+
+    def _named(self, n):
+        """[(reference parameter name under net n, tensor)] in the reference's state_dict order"""
+        ps = self.p[n]
+        if n.startswith("policy") and self._std_twin:
+            h = len(ps) // 2
+            out = []
+            for sub, part in (("mean", ps[:h]), ("log_std", ps[h:])):
+                for j in range(len(part) // 2):
+                    out += [("%s.%d.weight" % (sub, 2 * j), part[2 * j]), ("%s.%d.bias" % (sub, 2 * j), part[2 * j + 1])]
+            return out
+        return None
 
     # Parity tests with relu / selu hidden activations: act_sides[chain] = per hidden layer the bool tensor `z > 0` as the
     # implementation under test decided it, for the differentiated chains "pi", "q1c", "q2c" (first evaluation of the
@@ -307,6 +354,10 @@ class DsactOracle:
                 sd[n + ".act_low_lim"] = self.act_low.clone()
             sub = "policy" if is_pi else "q"
             ps = self.p[n]
+            if is_pi and self._std_twin:
+                for name, t in self._named(n):
+                    sd[n + "." + name] = t.detach().clone()
+                continue
             if is_pi and self._std_param:   # module parameters precede buffers and sub-modules in a state_dict
                 sd.pop(n + ".act_high_lim"); sd.pop(n + ".act_low_lim")
                 sd[n + ".log_std"] = ps[-1].detach().clone()
@@ -323,6 +374,10 @@ class DsactOracle:
         out = {"log_alpha": self.log_alpha.grad}
         for n in ("q1", "q2", "policy"):
             ps, sub = self.p[n], ("policy" if n == "policy" else "q")
+            if n == "policy" and self._std_twin:
+                for name, t in self._named(n):
+                    out[n + "." + name] = t.grad
+                continue
             if n == "policy" and self._std_param:
                 out[n + ".log_std"] = ps[-1].grad
                 sub = "mean"
@@ -337,6 +392,10 @@ class DsactOracle:
             for n in self.NETS:
                 sub = "policy" if n.startswith("policy") else "q"
                 ps = self.p[n]
+                if n.startswith("policy") and self._std_twin:
+                    for name, t in self._named(n):
+                        t.copy_(sd[n + "." + name])
+                    continue
                 if n.startswith("policy") and self._std_param:
                     ps[-1].copy_(sd[n + ".log_std"])
                     sub = "mean"
@@ -508,7 +567,25 @@ class DsactOracle:
     # rows [act_dim, 2 act_dim) of the weight are structurally zero, the second half of the bias IS log_std
     # (dsac-v2_amd/dsact/layout.py); the flat views pad the same way.
     def _arena_tensors(self, n, pick):
-        ps = [pick(t) for t in self.p[n]]
+        return self.arena_order(n, [pick(t) for t in self.p[n]])
+
+    def arena_order(self, n, ps):
+        """per-parameter tensors of net n (in the order of self.p[n]) -> flat pieces in the HIP arena's order"""
+        if n.startswith("policy") and self._std_twin:
+            # "mlp_separated": the arena's twin-trunk layout (dsac-v2_amd/dsact/layout.py, twin_mlp_views): layer 0 [W_mean ; W_ls],
+            # hidden layers W_mean | W_ls, output layer the dense [[w_mean, 0], [0, w_ls]]; biases [b_mean ; b_ls]
+            h = len(ps) // 2
+            m, l = ps[:h], ps[h:]
+            out = []
+            for j in range(h // 2):
+                wm, wl = m[2 * j], l[2 * j]
+                if j == h // 2 - 1:
+                    z = torch.zeros_like(wm)
+                    out.append(torch.cat([torch.cat([wm, z], 1), torch.cat([z, wl], 1)], 0).reshape(-1))
+                else:
+                    out += [wm.reshape(-1), wl.reshape(-1)]
+                out += [m[2 * j + 1].reshape(-1), l[2 * j + 1].reshape(-1)]
+            return out
         if not (n.startswith("policy") and self._std_param):
             return [t.reshape(-1) for t in ps]
         w, b, ls = ps[-3], ps[-2], ps[-1]

@@ -47,7 +47,8 @@ void hm_out_act(int act, float z, float* y, float* dy) {   // output activations
 extern "C" {
 int hm_policy_act(const float* params, int n_layers, const int* k_in, const int* n_out, const long long* w_off,
                   const long long* b_off, int act, const float* obs, int A, float lo_ls, float hi_ls, const float* eps,
-                  const float* scale, const float* center, float* out, float* logp, int isa, int threads) {
+                  const float* scale, const float* center, float* out, float* logp, int isa, int threads, const int* half) {
+  // half (may be NULL): per layer, > 0 = a twin-trunk hidden layer of two [half][k_in] blocks (policy_std_type "mlp_separated")
   // isa: -1 = what the CPU offers, 0 baseline x86-64, 1 avx2 + fma, 2 avx512f (refused with -2 when the CPU lacks it)
   dsact::hostact::Layer ly[8];
   if (n_layers > 8) return -1;
@@ -55,6 +56,7 @@ int hm_policy_act(const float* params, int n_layers, const int* k_in, const int*
   int widest = 0;
   for (int l = 0; l < n_layers; ++l) {
     ly[l].W = params + w_off[l]; ly[l].b = params + b_off[l]; ly[l].K = k_in[l]; ly[l].N = n_out[l];
+    ly[l].half = half ? half[l] : 0;
     if (n_out[l] > widest) widest = n_out[l];
   }
   float* buf = new float[3 * (widest + 64)];

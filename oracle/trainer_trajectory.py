@@ -65,6 +65,9 @@ VARIANTS = {
     # policy_std_type = "parameter" (networks/mlp.py:63-73; utils/common_utils.py:55 reads the kwarg): the whole loop -- sampler,
     # evaluator, checkpoints with `policy.log_std` / `policy.mean.*` -- with the learnable-parameter log-std, groups of two updates
     "std_param_si2": dict(sample_interval=2, policy_std_type="parameter"),
+    # policy_std_type = "mlp_separated" (networks/mlp.py:46-57): `mean` and `log_std` from two MLPs -- checkpoints with
+    # `policy.mean.*` / `policy.log_std.*`, sampler and evaluator acting through the twin-trunk arena layout (round 6)
+    "std_sep_si2": dict(sample_interval=2, policy_std_type="mlp_separated"),
     # policy_act_distribution = "GaussDistribution" (utils/act_distribution_cls.py:82-115): sampler, evaluator (mode() clamps the
     # mean) and the update without tanh squashing
     "gauss_si2": dict(sample_interval=2, policy_act_distribution="GaussDistribution"),

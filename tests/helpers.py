@@ -111,7 +111,6 @@ def policy_saturation_budget(orc, data, noise, B):
             for acc, g in zip(budget, torch.autograd.grad(logits[b, col], params, retain_graph=True, allow_unused=True)):
                 if g is not None:   # (policy_std_type "parameter": the std column does not depend on the mean net)
                     acc += w * g.abs().double()
-    if getattr(orc, "_std_param", False):   # arena order: zero rows behind the mean rows of the output layer, log_std in the bias tail
-        w, b, ls = budget[-3], budget[-2], budget[-1]
-        budget = budget[:-3] + [w, torch.zeros_like(w), b, ls]
-    return torch.cat([t.reshape(-1) for t in budget]).numpy()
+    if hasattr(orc, "arena_order"):   # arena order ("parameter": zero rows behind the mean rows of the output layer, log_std in the
+        budget = orc.arena_order("policy", budget)   # bias tail; "mlp_separated": the twin-trunk layout)
+    return torch.cat([t.reshape(-1).double() for t in budget]).numpy()

@@ -192,12 +192,12 @@ def test_host_acting_forward_and_sampling_step(hm, O, A, hid, act):
         torch.manual_seed(100 + i)
         eps = torch.randn(1, A)
         hm.hm_policy_act.argtypes = [FP, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
-                                     C.c_int, FP, C.c_int, C.c_float, C.c_float, FP, FP, FP, FP, FP, C.c_int, C.c_int]
+                                     C.c_int, FP, C.c_int, C.c_float, C.c_float, FP, FP, FP, FP, FP, C.c_int, C.c_int, C.POINTER(C.c_int)]
         per_isa = {}
         for isa, threads in ((0, 1), (1, 1), (2, 1), (-1, 3), (0, 4)):
             logits = np.empty(2 * A, np.float32)
             rc = hm.hm_policy_act(p(params), L, IA(*k_in), IA(*n_out), LA(*w_off), LA(*b_off), acts[act][0], p(obs), A, lo_ls, hi_ls,
-                                  None, p(scale), p(center), p(logits), None, isa, threads)
+                                  None, p(scale), p(center), p(logits), None, isa, threads, None)
             if rc == -2:
                 continue                     # this CPU lacks the instruction set
             assert rc >= 0
@@ -213,7 +213,7 @@ def test_host_acting_forward_and_sampling_step(hm, O, A, hid, act):
             per_isa[key] = logits.copy()
             action, logp = np.empty(A, np.float32), np.empty(1, np.float32)
             hm.hm_policy_act(p(params), L, IA(*k_in), IA(*n_out), LA(*w_off), LA(*b_off), acts[act][0], p(obs), A, lo_ls, hi_ls,
-                             p(f32(eps[0])), p(scale), p(center), p(action), p(logp), isa, threads)
+                             p(f32(eps[0])), p(scale), p(center), p(action), p(logp), isa, threads, None)
             # the reference's sampling step on ITS logits and the same draw (act_distribution_cls.py:32-42)
             x = mean + std * eps[0]
             a_ref = lim * torch.tanh(x)
@@ -223,3 +223,69 @@ def test_host_acting_forward_and_sampling_step(hm, O, A, hid, act):
             tol = 5e-4 + float((2.4e-7 / (1.0 + 1e-6 - np.minimum(t2, 1.0))).sum())
             assert abs(float(logp[0]) - float(lp_ref)) <= tol, (i, float(logp[0]), float(lp_ref), tol)
         assert len(per_isa) >= 2
+
+
+def test_host_acting_forward_of_a_twin_trunk_policy(hm):
+    """csrc/dsact_host_act.h on the arena's twin-trunk layout (a hidden layer = two row ranges with their own input halves) against
+    the two torch MLPs, every instruction set the CPU offers and the fork-join pool"""
+    import torch.nn as nn
+    from dsact.layout import ArenaLayout
+
+    O, A, hid = 23, 5, (96, 40, 64)
+    torch.manual_seed(7)
+
+    def mlp():
+        sizes = [O] + list(hid) + [A]
+        layers = []
+        for j in range(len(sizes) - 1):
+            layers += [nn.Linear(sizes[j], sizes[j + 1]), nn.GELU() if j < len(sizes) - 2 else nn.Identity()]
+        return nn.Sequential(*layers)
+
+    mean, lstd = mlp(), mlp()
+    lay = ArenaLayout(O, A, list(hid), policy_std_type="mlp_separated")
+    base = lay.net_offset["policy"][1]
+    arena = torch.zeros(lay.n_online)
+    named = {("mean.%s" % n): t for n, t in mean.named_parameters()}
+    named.update({("log_std.%s" % n): t for n, t in lstd.named_parameters()})
+    for name, _, off, shape, strides in lay.param_views("policy"):
+        torch.as_strided(arena, shape, strides, off).copy_(named[name].detach())
+    params = arena[base:base + lay.n_pi].numpy().copy()
+    L = len(hid) + 1
+    widths = [O] + [2 * h for h in hid]
+    k_in, n_out, half, w_off, b_off = [], [], [], [], []
+    off = 0
+    for l in range(L):
+        blk = 0 < l < L - 1
+        n = 2 * hid[l] if l < L - 1 else 2 * A
+        k = widths[l] // 2 if blk else widths[l]
+        k_in.append(k); n_out.append(n); half.append(hid[l] if blk else 0)
+        w_off.append(off); off += n * k if (blk or l == 0) else n * widths[l]
+        b_off.append(off); off += n
+    assert off == lay.n_pi
+    lo_ls, hi_ls = -20.0, 0.5
+    scale, center = np.full(A, 0.4, np.float32), np.zeros(A, np.float32)
+    IA, LA = (C.c_int * L), (C.c_longlong * L)
+    hm.hm_policy_act.argtypes = [FP, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
+                                 C.c_int, FP, C.c_int, C.c_float, C.c_float, FP, FP, FP, FP, FP, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    rng = np.random.default_rng(2)
+    for _ in range(6):
+        obs = (2.0 * rng.standard_normal(O)).astype(np.float32)
+        with torch.no_grad():
+            m = mean(torch.from_numpy(obs)[None])[0]
+            s = torch.clamp(lstd(torch.from_numpy(obs)[None])[0], lo_ls, hi_ls).exp()
+        seen = {}
+        for isa, threads in ((0, 1), (1, 1), (2, 1), (-1, 3), (0, 4)):
+            logits = np.empty(2 * A, np.float32)
+            rc = hm.hm_policy_act(p(params), L, IA(*k_in), IA(*n_out), LA(*w_off), LA(*b_off), 0, p(obs), A, lo_ls, hi_ls,
+                                  None, p(scale), p(center), p(logits), None, isa, threads, IA(*half))
+            if rc == -2:
+                continue
+            assert rc >= 0
+            sc = float(m.abs().max()) + 1.0
+            np.testing.assert_allclose(logits[:A], f32(m), atol=4e-6 * sc, rtol=0)
+            np.testing.assert_allclose(logits[A:], f32(s), rtol=2e-5, atol=1e-7)
+            key = rc if isa < 0 else isa
+            if key in seen:
+                assert np.array_equal(seen[key], logits)
+            seen[key] = logits.copy()
+        assert len(seen) >= 2

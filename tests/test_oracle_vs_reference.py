@@ -126,6 +126,54 @@ def test_output_activations_bit_exact_vs_live_reference(O, A, hid, B, vo, po, st
         assert all(torch.equal(sd[k], osd[k]) for k in sd)
 
 
+@pytest.mark.parametrize("O,A,hid,hp,B,pa,po,dist", [
+    (24, 6, (64, 64), None, 64, "gelu", "linear", "TanhGaussDistribution"), (376, 17, (256, 256, 256), None, 64, "gelu", "linear", "TanhGaussDistribution"),
+    (11, 3, (96, 40), (40, 24), 32, "relu", "linear", "TanhGaussDistribution"), (24, 6, (64, 64), None, 64, "tanh", "tanh", "GaussDistribution")])
+def test_std_type_mlp_separated_bit_exact_vs_live_reference(O, A, hid, hp, B, pa, po, dist):
+    """policy_std_type = "mlp_separated" (networks/mlp.py:46-57,80-85: `mean` and `log_std` from two MLPs over the observation):
+    same seed -> same initial state under the reference's names and order, then four updates with every gradient and parameter
+    equal; the oracle's flat views are in the HIP arena's twin-trunk order (its structural zero blocks carry zeros)."""
+    torch.set_num_threads(2)
+    ref = ref_loader.import_reference()
+    over = dict(policy_std_type="mlp_separated", policy_hidden_activation=pa, policy_output_activation=po, policy_act_distribution=dist)
+    if hp is not None:
+        over["policy_hidden_sizes"] = list(hp)
+    kw = ref_loader.reference_kwargs(O, A, hid, **over)
+    torch.manual_seed(0)
+    alg = ref.DSAC_V2(**kw)
+    cfg = default_config(O, A, hid, policy_std_type="mlp_separated", policy_act=pa, policy_out_act=po, act_dist=dist,
+                         policy_hidden=list(hp) if hp is not None else None)
+    torch.manual_seed(0)
+    same_seed = DsactOracle(cfg)
+    sd, osd = alg.networks.state_dict(), same_seed.state_dict()
+    assert list(sd.keys()) == list(osd.keys())
+    assert all(torch.equal(sd[k], osd[k]) for k in sd)
+    orc = DsactOracle(cfg, state_dict=sd)
+    rng = np.random.default_rng(0)
+    for it in range(4):
+        d = synth_batch(rng, B, O, A)
+        torch.manual_seed(1000 + it)
+        tb_ref = alg.local_update({k: v.clone() for k, v in d.items()}, it)
+        torch.manual_seed(1000 + it)
+        tb = orc.local_update(d, draw_noise(B, A), it, keep=(it == 1))     # (keep: the [z_mean | z_log_std] collection changes nothing)
+        for k in TB_KEYS[:-1]:
+            assert float(tb_ref[k]) == float(tb[k]), k
+        nets, og = alg.networks, orc.grad_dict()
+        for n in ("q1", "q2", "policy"):
+            for name, p_ in getattr(nets, n).named_parameters():
+                assert torch.equal(p_.grad, og[n + "." + name]), (n, name)
+        assert torch.equal(nets.log_alpha.grad, og["log_alpha"])
+        # the arena-order flat view: the output layer is the dense (2A x 2H) matrix [[w_mean, 0], [0, w_log_std]]
+        fg, nq = orc.flat_grads(), sum(p_.numel() for p_ in nets.q1.parameters())
+        H = (hp or hid)[-1]
+        wout = fg[2 * nq:-1][-(4 * A * H + 2 * A):-(2 * A)].reshape(2 * A, 2 * H)
+        assert torch.equal(wout[:A, :H], nets.policy.mean[-2].weight.grad) and torch.equal(wout[A:, H:], nets.policy.log_std[-2].weight.grad)
+        assert not wout[:A, H:].any() and not wout[A:, :H].any()
+        assert fg.numel() == 2 * nq + 2 * sum(p_.numel() for p_ in nets.policy.mean.parameters()) + 2 * A * H + 1
+        sd, osd = nets.state_dict(), orc.state_dict()
+        assert all(torch.equal(sd[k], osd[k]) for k in sd)
+
+
 @pytest.mark.parametrize("O,A,hv,hp,B", [(24, 6, (64, 64), (32, 48), 64), (376, 17, (256, 256, 256), (128, 128, 128), 64), (11, 3, (96, 40), (40, 96), 32)])
 def test_unequal_hidden_sizes_bit_exact_vs_live_reference(O, A, hv, hp, B):
     """value_hidden_sizes != policy_hidden_sizes (utils/common_utils.py:59-62 reads them per key), same depth"""

@@ -62,7 +62,7 @@ def test_unsupported_combinations_are_refused():
     from dsac_v2_hip import _check_supported
     import dsac_v1_hip
 
-    kw = dict(obsv_dim=8, action_dim=2, value_hidden_sizes=[64, 64], policy_hidden_sizes=[64, 64], policy_std_type="mlp_separated")
+    kw = dict(obsv_dim=8, action_dim=2, value_hidden_sizes=[64, 64], policy_hidden_sizes=[64, 64], policy_std_type="no_such_type")
     with pytest.raises(NotImplementedError):
         _check_supported(kw)
     kw["policy_std_type"] = "parameter"

@@ -276,6 +276,10 @@ def test_hip_stack_follows_the_reference_trajectory(tmp_path, variant):
         assert list(sd.keys())[0] == "log_alpha" and len(sd) == 173 and "policy.conv.0.weight" in sd and "q1_target.log_std.6.bias" in sd
         assert any(n == 8 for _, n in got["groups"])          # whole groups of 8 updates: the CNN examples' own sample_interval
         return
+    if case.get("policy_std_type", "mlp_shared") == "mlp_separated":   # networks/mlp.py:46-57: two MLPs per policy net, 12 more tensors each
+        assert list(sd.keys())[0] == "log_alpha" and len(sd) == 41 + 2 * 6 and "policy.policy.0.weight" not in sd
+        assert tuple(sd["policy.log_std.4.weight"].shape) == (kw["action_dim"], kw["policy_hidden_sizes"][-1]) and "policy_target.mean.0.bias" in sd
+        return
     assert list(sd.keys())[0] == "log_alpha" and len(sd) == (43 if std_param else 41)
     if std_param:   # the reference's own names for this policy_std_type (networks/mlp.py:63-73)
         assert tuple(sd["policy.log_std"].shape) == (1, kw["action_dim"]) and "policy.mean.0.weight" in sd and "policy.policy.0.weight" not in sd
