@@ -119,6 +119,7 @@ struct dsact_handle {
   int* idx_iota = nullptr;
   float* Xc[8];                         // MLP input rows per chain
   int w[DSACT_MAX_HIDDEN_LAYERS];     // activation row widths: the wider of the two families per layer (buffer sizes)
+  int Lq = 0, Lp = 0;   // hidden layers of the critics / of the policy nets (L = the larger; they differ only with policy_n_hidden)
   int wq[DSACT_MAX_HIDDEN_LAYERS], wp[DSACT_MAX_HIDDEN_LAYERS];   // ... of the critics / of the policy nets (equal unless policy_hidden is set)
   // workspace
   char* ws = nullptr;
@@ -435,6 +436,8 @@ void build_net(NetDesc& d, int in0, const int* hidden, int L, int n_out, int nbl
 
 int net_act(const dsact_handle* h, int net);
 const NetDesc& net_desc(const dsact_handle* h, int net) { return (net == N_POL || net == N_POLT) ? h->pd : h->qd; }
+// hidden layers of the net chain `ch` evaluates (value_hidden_sizes and policy_hidden_sizes may differ in length)
+int chain_L(const dsact_handle* h, int ch) { return (ch == C_PI || ch == C_PIT) ? h->Lp : h->Lq; }
 
 // any net with a hidden activation other than GELU: the forward chains run their generic-activation instantiations
 // (the generic-activation instantiations also carry the heads' OUTPUT activations, round 6)
@@ -896,11 +899,12 @@ int build_tasks(dsact_handle* h) {
   const std::vector<int> g2 = twin ? std::vector<int>{C_Q1T, C_Q2T, C_Q1P, C_Q2P} : std::vector<int>{C_Q1T, C_Q1P};
   h->fwd1.clear(); h->fwd2.clear();
   for (int grp = 0; grp < 2; ++grp)
-    for (int l = 0; l < L; ++l) {
+    for (int l = 0; l < (grp == 0 ? L : h->Lq); ++l) {   // (group B holds critics only)
       Stage s = fresh(std::string(grp == 0 ? "fwdA_l" : "fwdB_l") + std::to_string(l), 0);
       pv.clear();
       for (size_t i = 0; i < (grp == 0 ? g1 : g2).size(); ++i) {
         const int ch = grp == 0 ? g1[i] : g2[i];
+        if (l >= chain_L(h, ch)) continue;   // the shallower family has no layer l
         fwd_probs(h, ch, l, chain_input(h, ch), h->ldx, B, h->Hb[ch], h->Gb[ch][l], pv);
       }
       for (const GemmProb& g : pv) stage_add(s, g);
@@ -926,7 +930,7 @@ int build_tasks(dsact_handle* h) {
     }
   };
   h->bwdq.clear(); h->bwdq_critic.clear(); h->bwdpi.clear();
-  for (int l = L - 1; l >= 1; --l) {
+  for (int l = h->Lq - 1; l >= 1; --l) {
     Stage s = fresh("bwdQ_l" + std::to_string(l), 1);
     for (int ch : twin ? std::vector<int>{C_Q1C, C_Q2C, C_Q1P, C_Q2P} : std::vector<int>{C_Q1C, C_Q1P}) bwd_probs(s, ch, l);
     h->bwdq.push_back(s);
@@ -934,14 +938,14 @@ int build_tasks(dsact_handle* h) {
     for (int ch : twin ? std::vector<int>{C_Q1C, C_Q2C} : std::vector<int>{C_Q1C}) bwd_probs(c, ch, l);
     h->bwdq_critic.push_back(c);
   }
-  for (int l = L - 1; l >= 1; --l) {
+  for (int l = h->Lp - 1; l >= 1; --l) {
     Stage s = fresh("bwdPi_l" + std::to_string(l), 1);
     bwd_probs(s, C_PI, l);
     h->bwdpi.push_back(s);
   }
   // stand-alone policy forward (kActRows rows)
   h->actf.clear();
-  for (int l = 0; l < L; ++l) {
+  for (int l = 0; l < h->Lp; ++l) {
     Stage s = fresh("act_l" + std::to_string(l), 0);
     pv.clear();
     fwd_probs(h, C_PI, l, h->Xact, h->ldx, kActRows, h->Hact, h->Gact, pv);
@@ -1001,6 +1005,7 @@ int build_tasks(dsact_handle* h) {
     const NetDesc& d = net_desc(h, net);
     float* g = net_grads(h, net);
     const int slot = kDzSlot[ch];
+    const int L = chain_L(h, ch);   // (shadows build_tasks' L: this net's own depth)
     for (int li = 0; li <= L; ++li) {
       // policy: output layer first (see dw_pol_rest); critics: layer order
       const int l = ch == C_PI ? (li == 0 ? L : li - 1) : li;
@@ -2745,11 +2750,12 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
   h->have_local_tail = true;
   h->uev_valid = false;   // dsact_step / dsact_compute_grads set it again once their closing event is recorded
   if (h->chain_ok) return enqueue_grads_chain(h, actor_backward, fused, phase, ride);
-  const int L = h->L, B = h->B, A = h->A;
+  const int B = h->B, A = h->A;
+  const int Lq = h->Lq, Lp = h->Lp;   // hidden layers of the critics / the policy nets (equal unless policy_n_hidden is set)
   if (phase == 4) goto actor_part;
   if (phase != 2) {
   if (h->cnn) TRY(enqueue_conv_forward(h));
-  for (int l = 0; l < L; ++l) TRY(run_stage(h, h->fwd1[l]));
+  for (size_t l = 0; l < h->fwd1.size(); ++l) TRY(run_stage(h, h->fwd1[l]));
   {
     HeadsArgs a;
     memset(&a, 0, sizeof(a));
@@ -2759,11 +2765,13 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
     for (int i = 0; i < 4; ++i) {
       const int net = kChainNet[chs[i]];
       const NetDesc& d = net_desc(h, net);
+      const int L = chain_L(h, chs[i]);
       a.H[i] = h->Hb[chs[i]][L - 1];
       a.Wout[i] = net_params(h, net) + d.w_off[L];
       a.bout[i] = net_params(h, net) + d.b_off[L];
     }
-    a.W = h->w[L - 1]; a.Wch[0] = a.Wch[1] = h->wp[L - 1]; a.Wch[2] = a.Wch[3] = h->wq[L - 1];
+    a.Wch[0] = a.Wch[1] = h->wp[Lp - 1]; a.Wch[2] = a.Wch[3] = h->wq[Lq - 1];
+    a.W = a.Wch[0] > a.Wch[2] ? a.Wch[0] : a.Wch[2];
     a.B = B; a.O = h->F; a.A = A; a.ldx = h->ldx;
     a.eps_new = h->eps_new; a.eps_2 = h->eps_2;
     a.XP = h->Xc[C_Q1P]; a.XPb = h->Xc[C_Q2P] != h->Xc[C_Q1P] ? h->Xc[C_Q2P] : nullptr;
@@ -2778,7 +2786,7 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
 #define CALL_HEADS(N) TRY(launch(h, "heads", k_heads<N>, dim3(h->n_heads_wg, n_heads), dim3(kThreads), 0, a))
     NCH_DISPATCH(a.W, CALL_HEADS);
   }
-  for (int l = 0; l < L; ++l) TRY(run_stage(h, h->fwd2[l]));
+  for (size_t l = 0; l < h->fwd2.size(); ++l) TRY(run_stage(h, h->fwd2[l]));
   if (h->use_std_sums || h->auto_std_sums) {
     // large batches (and the strict data-parallel mode, where the caller all-reduces std_sums
     // between the phases): the std column is summed by one workgroup instead of by every wave
@@ -2788,6 +2796,8 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
   }
   }  // phase != 2
   if (phase == 1) return DSACT_OK;
+  {
+  const int L = Lq;   // the loss kernels read the critics' last hidden layer
   if (h->nq == 1) {
     LossV1Args a;
     memset(&a, 0, sizeof(a));
@@ -2808,7 +2818,7 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
     a.rew = h->rew; a.done = h->done; a.logp2 = h->logp2; a.logp_new = h->logp_new; a.z_t = h->z5;
     a.log_alpha = h->online + h->n_online - 1;
     a.part_loss = h->part_loss; a.grads_tail = h->grads + h->n_online;
-    a.W = h->w[L - 1]; a.B = B; a.inv_B = 1.0f / (float)B;
+    a.W = h->wq[L - 1]; a.B = B; a.inv_B = 1.0f / (float)B;
     a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.gamma = h->cfg.gamma; a.td_bound = h->cfg.td_bound; a.bound = h->cfg.v1_unbounded ? 0 : 1;
     if (ride) a.ride = *ride;
     a.ride.n_loss_blocks = h->n_loss_wg;
@@ -2847,6 +2857,7 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
     const int n_riders = ride ? ride->n_gather + (ride->bookkeeping ? 1 : 0) : 0;
 #define CALL_LOSS(N) TRY(launch(h, "loss", k_loss<N>, dim3(h->n_loss_wg + n_riders), dim3(kThreads), 0, a))
     NCH_DISPATCH(a.W, CALL_LOSS);
+  }
   }
   if (!actor_backward) {
     // off iteration of the delayed update: the reference computes the actor / alpha gradients and
@@ -2896,10 +2907,10 @@ actor_part:
     a.dZ1[0] = h->dZ[kDzSlot[C_Q1P]][0]; a.dZ1[1] = h->dZ[kDzSlot[C_Q2P]][0];
     a.W1aT[0] = h->W1aT[0]; a.W1aT[1] = h->W1aT[1]; a.W0 = h->wq[0];
     a.logits_pi = h->logits_pi; a.eps_new = h->eps_new; a.log_alpha = h->online + h->n_online - 1;
-    a.Wout_pi = net_params(h, N_POL) + h->pd.w_off[L];
-    a.G_pi = h->Gb[C_PI][L - 1]; a.dZ_pi = h->dZ[kDzSlot[C_PI]][L - 1];
+    a.Wout_pi = net_params(h, N_POL) + h->pd.w_off[Lp];
+    a.G_pi = h->Gb[C_PI][Lp - 1]; a.dZ_pi = h->dZ[kDzSlot[C_PI]][Lp - 1];
     a.dout_pi = h->dout_pi; a.d_new_act = h->d_new_act;
-    a.WL = h->wp[L - 1]; a.B = B; a.O = h->F; a.A = A;
+    a.WL = h->wp[Lp - 1]; a.B = B; a.O = h->F; a.A = A;
     a.inv_B = 1.0f / (float)B; a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed;
     a.act_scale = h->act_scale; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
     a.part_loss = h->part_loss; a.n_part = B; a.target_entropy = -(float)A;
@@ -3192,7 +3203,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     return fail(h, DSACT_E_INVALID, "output activations other than linear are built for DSAC_V2 with MLP nets (tile-stage kernels)");
   if (h->cfg.global_batch < h->cfg.batch) h->cfg.global_batch = h->cfg.batch;
   HIPCHK(h, hipSetDevice(device));
-  h->O = cfg->obs_dim; h->A = cfg->act_dim; h->L = cfg->n_hidden; h->B = cfg->batch;
+  h->O = cfg->obs_dim; h->A = cfg->act_dim; h->L = cfg->n_hidden; h->B = cfg->batch;   // (L: the deeper family once policy_n_hidden is read)
   h->F = h->O;
   h->Brows = h->B > kActRows ? h->B : kActRows;
   int nblk = 1;
@@ -3224,12 +3235,20 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     nblk = 2;
   }
   // value_hidden_sizes != policy_hidden_sizes (same depth): cfg->hidden sizes the critics, cfg->policy_hidden the policy nets
-  int pol_hidden[DSACT_MAX_HIDDEN_LAYERS];
+  // ... and lists of different LENGTH (policy_n_hidden > 0): every layer-indexed table below is sized by the deeper family
+  // (h->L), the stage lists / heads / tiles take each net's own depth (chain_L)
+  int pol_hidden[DSACT_MAX_HIDDEN_LAYERS] = {0};
   bool unequal = false;
-  for (int l = 0; l < h->L; ++l) {
-    pol_hidden[l] = cfg->policy_hidden[l] > 0 ? cfg->policy_hidden[l] : cfg->hidden[l];
-    if (pol_hidden[l] > kMaxWidth) return fail(h, DSACT_E_INVALID, "hidden width must be 1..%d", kMaxWidth);
-    unequal = unequal || pol_hidden[l] != cfg->hidden[l];
+  h->Lq = cfg->n_hidden;
+  h->Lp = cfg->policy_n_hidden > 0 ? cfg->policy_n_hidden : cfg->n_hidden;
+  if (h->Lp > DSACT_MAX_HIDDEN_LAYERS) return fail(h, DSACT_E_INVALID, "policy_n_hidden must be 0 (= n_hidden) or 1..%d", DSACT_MAX_HIDDEN_LAYERS);
+  if (h->Lp != h->Lq && cfg->conv_type != DSACT_CONV_NONE) return fail(h, DSACT_E_INVALID, "policy_n_hidden: the CNN nets' MLP widths are fixed by conv_type");
+  unequal = h->Lp != h->Lq;
+  h->L = h->Lp > h->Lq ? h->Lp : h->Lq;
+  for (int l = 0; l < h->Lp; ++l) {
+    pol_hidden[l] = cfg->policy_hidden[l] > 0 ? cfg->policy_hidden[l] : (l < h->Lq ? cfg->hidden[l] : 0);
+    if (pol_hidden[l] < 1 || pol_hidden[l] > kMaxWidth) return fail(h, DSACT_E_INVALID, "policy hidden width of layer %d must be 1..%d", l, kMaxWidth);
+    unequal = unequal || l >= h->Lq || pol_hidden[l] != cfg->hidden[l];
   }
   if (unequal && (cfg->conv_type != DSACT_CONV_NONE || cfg->algo != 0))
     return fail(h, DSACT_E_INVALID, "value_hidden_sizes != policy_hidden_sizes is built for DSAC_V2 with MLP nets (tile-stage kernels)");
@@ -3238,15 +3257,15 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   const int nblk_pol = cfg->policy_twin ? 2 : nblk;
   h->unequal_widths = unequal || nblk_pol != nblk;
   for (int l = 0; l < h->L; ++l) {
-    h->wq[l] = nblk * cfg->hidden[l]; h->wp[l] = nblk_pol * pol_hidden[l];
+    h->wq[l] = l < h->Lq ? nblk * cfg->hidden[l] : 0; h->wp[l] = l < h->Lp ? nblk_pol * pol_hidden[l] : 0;
     h->w[l] = h->wq[l] > h->wp[l] ? h->wq[l] : h->wp[l];
   }
   for (int l = 0; l < h->L; ++l)
     if (h->w[l] > kMaxWidth) return fail(h, DSACT_E_INVALID, "activation row width %d exceeds %d", h->w[l], kMaxWidth);
   h->ldx = (h->F + h->A + 3) & ~3;
   h->use_w1p = (size_t)4 * nblk * cfg->hidden[0] * h->ldx <= ((size_t)4 << 20);
-  build_net(h->qd, h->F + h->A, cfg->hidden, h->L, 2, nblk, h->n_conv, h->cg);
-  build_net(h->pd, h->F, pol_hidden, h->L, 2 * h->A, nblk_pol, h->n_conv, h->cg);
+  build_net(h->qd, h->F + h->A, cfg->hidden, h->Lq, 2, nblk, h->n_conv, h->cg);
+  build_net(h->pd, h->F, pol_hidden, h->Lp, 2 * h->A, nblk_pol, h->n_conv, h->cg);
   h->n_q = h->qd.count; h->n_pi = h->pd.count;
   if (cfg->algo != DSACT_ALGO_DSAC_V2 && cfg->algo != DSACT_ALGO_DSAC_V1) return fail(h, DSACT_E_INVALID, "algo must be 0 (DSAC_V2) or 1 (DSAC_V1)");
   h->nq = cfg->algo == DSACT_ALGO_DSAC_V1 ? 1 : 2;
@@ -3990,10 +4009,10 @@ static int act_forward_host(dsact_handle* h, const float* obs_host, const float*
     h->act_copy_wait_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
   }
   hostact::Layer ly[kActMaxLayers];
-  for (int l = 0; l <= h->L; ++l) {
+  for (int l = 0; l <= h->Lp; ++l) {
     ly[l].W = h->pol_host + h->pd.w_off[l]; ly[l].b = h->pol_host + h->pd.b_off[l];
     ly[l].K = h->pd.in[l]; ly[l].N = h->pd.out[l]; ly[l].half = 0;
-    if (h->pd.nblk == 2 && l > 0 && l < h->L) { ly[l].K = h->pd.in[l] / 2; ly[l].half = h->pd.out[l] / 2; }   // two (H x Hprev) blocks
+    if (h->pd.nblk == 2 && l > 0 && l < h->Lp) { ly[l].K = h->pd.in[l] / 2; ly[l].half = h->pd.out[l] / 2; }   // two (H x Hprev) blocks
   }
   float* b0 = h->act_buf; float* b1 = b0 + kMaxWidth + 64; float* raw = b1 + kMaxWidth + 64;
   if (h->act_threads == 0) {
@@ -4041,7 +4060,7 @@ static int act_forward_host(dsact_handle* h, const float* obs_host, const float*
   }
 #endif
   const auto t1 = std::chrono::steady_clock::now();
-  hostact::forward(ly, h->L + 1, h->cfg.policy_act, obs_host, b0, b1, raw, h->act_pool);
+  hostact::forward(ly, h->Lp + 1, h->cfg.policy_act, obs_host, b0, b1, raw, h->act_pool);
   hostact::head(raw, h->A, h->cfg.min_log_std, h->cfg.max_log_std, eps, h->act_scale_h, h->act_center_h, out, logp,
                 h->cfg.policy_out_act, h->cfg.policy_std_param ? h->A : 2 * h->A);
   h->act_host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
@@ -4713,7 +4732,8 @@ int dsact_time_stage(dsact_handle* h, int32_t stage, int32_t reps, float* ms_tot
   if (!h || !ms_total || reps < 1) return DSACT_E_INVALID;
   TRY(check_ready(h, false));
   const int L = h->L;
-  if (stage < 0 || stage >= 2 * L) return fail(h, DSACT_E_INVALID, "stage must be in 0..%d", 2 * L - 1);
+  if (stage < 0 || stage >= 2 * L || (stage >= L && stage - L >= (int)h->fwd2.size()))
+    return fail(h, DSACT_E_INVALID, "stage must be in 0..%d (group B has %d layers)", 2 * L - 1, (int)h->fwd2.size());
   HIPCHK(h, hipSetDevice(h->device));
   const Stage& s = stage < L ? h->fwd1[stage] : h->fwd2[stage - L];
   if (macs) {
@@ -4853,7 +4873,7 @@ int dsact_debug_read(dsact_handle* h, const char* name, float* out, size_t cap, 
       const int l = atoi(s.c_str() + d2 + 1);
       int ch = -1;
       for (int c = 0; c < N_CHAIN; ++c) if (chn == kChainName[c]) ch = c;
-      if (ch >= 0 && l >= 0 && l < h->L) {
+      if (ch >= 0 && l >= 0 && l < chain_L(h, ch)) {
         const int wch = (kChainNet[ch] == N_POL || kChainNet[ch] == N_POLT) ? h->wp[l] : h->wq[l];
         cnt = B * wch;
         if (kind == "H") src = h->Hb[ch][l];
@@ -5003,17 +5023,17 @@ int dsact_debug_get(const dsact_handle* h, const char* name, double* value) {
 static int act_forward_fast(dsact_handle* h, const float* obs_host, const float* eps, float* out_host) {
   TRY(check_handoff(h));
   ActArgs a;
-  a.n_layers = h->L + 1;
+  a.n_layers = h->Lp + 1;
   const float* base = net_params(h, N_POL);
   int wg = 0;
-  for (int l = 0; l <= h->L; ++l) {
+  for (int l = 0; l <= h->Lp; ++l) {
     a.ly[l].W = base + h->pd.w_off[l]; a.ly[l].b = base + h->pd.b_off[l];
     a.ly[l].K = h->pd.in[l]; a.ly[l].N = h->pd.out[l]; a.ly[l].half = 0;
-    if (h->pd.nblk == 2 && l > 0 && l < h->L) { a.ly[l].K = h->pd.in[l] / 2; a.ly[l].half = h->pd.out[l] / 2; }   // two (H x Hprev) blocks
+    if (h->pd.nblk == 2 && l > 0 && l < h->Lp) { a.ly[l].K = h->pd.in[l] / 2; a.ly[l].half = h->pd.out[l] / 2; }   // two (H x Hprev) blocks
     a.wg_begin[l] = wg;
-    wg += ((l == h->L && eps ? h->A : h->pd.out[l]) + 3) / 4;
+    wg += ((l == h->Lp && eps ? h->A : h->pd.out[l]) + 3) / 4;
   }
-  a.wg_begin[h->L + 1] = wg;
+  a.wg_begin[h->Lp + 1] = wg;
   if (h->act_call >= 0x7ffffff0) {   // the tags only have to differ from call to call: restart far from the sign bit
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemset(h->act_h, 0, (size_t)kActMaxLayers * kMaxWidth * sizeof(unsigned long long)));
@@ -5052,7 +5072,7 @@ static int act_forward_fast(dsact_handle* h, const float* obs_host, const float*
   return check_handoff(h);
 }
 static bool act_fast_ok(const dsact_handle* h) {
-  return !h->cnn && h->O <= kActMaxObs && h->L + 1 <= kActMaxLayers && !h->env_no_fast_act && h->A <= 32;
+  return !h->cnn && h->O <= kActMaxObs && h->Lp + 1 <= kActMaxLayers && !h->env_no_fast_act && h->A <= 32;
 }
 
 // OffSampler.sample()'s per-step device work in ONE call (training/off_sampler.py:46-54): policy(obs) on the live weights +
@@ -5112,12 +5132,12 @@ int dsact_policy_forward(dsact_handle* h, const float* obs_host, int32_t n, floa
   } else {
     HIPCHK(h, hipMemcpy2DAsync(h->Xact, ld * 4, obs_host, O * 4, O * 4, n, hipMemcpyHostToDevice, h->stream));
   }
-  for (int l = 0; l < h->L; ++l) TRY(run_stage(h, h->actf[l]));
+  for (int l = 0; l < h->Lp; ++l) TRY(run_stage(h, h->actf[l]));
   PolicyOutArgs a;
-  a.H = h->Hact[h->L - 1];
-  a.Wout = net_params(h, N_POL) + h->pd.w_off[h->L];
-  a.bout = net_params(h, N_POL) + h->pd.b_off[h->L];
-  a.W = h->wp[h->L - 1]; a.n = n; a.A = h->A; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std; a.out = h->act_out;
+  a.H = h->Hact[h->Lp - 1];
+  a.Wout = net_params(h, N_POL) + h->pd.w_off[h->Lp];
+  a.bout = net_params(h, N_POL) + h->pd.b_off[h->Lp];
+  a.W = h->wp[h->Lp - 1]; a.n = n; a.A = h->A; a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std; a.out = h->act_out;
   a.out_act = h->cfg.policy_out_act; a.out_n = h->cfg.policy_std_param ? h->A : 2 * h->A;
 #define CALL_POUT(N) TRY(launch(h, "policy_out", k_policy_out<N>, dim3((n + 3) / 4), dim3(kThreads), 0, a))
   NCH_DISPATCH(a.W, CALL_POUT);

@@ -278,14 +278,11 @@ def _hidden_sizes(kwargs):
     ct = _conv_type(kwargs)
     if ct:
         return list(CONV_TYPES[ct][4])
-    hv, hp = list(kwargs["value_hidden_sizes"]), list(kwargs["policy_hidden_sizes"])
-    if len(hv) != len(hp):
-        raise NotImplementedError("DSAC_V2_HIP needs value_hidden_sizes and policy_hidden_sizes of the same DEPTH (got %s / %s)" % (hv, hp))
-    return hv
+    return list(kwargs["value_hidden_sizes"])   # (policy_hidden_sizes may differ in widths AND depth: _policy_hidden_sizes)
 
 
 def _policy_hidden_sizes(kwargs):
-    """policy_hidden_sizes when they differ from value_hidden_sizes (same depth: served by the tile-stage kernels), else None"""
+    """policy_hidden_sizes when they differ from value_hidden_sizes (widths and / or depth: served by the tile-stage kernels), else None"""
     if _conv_type(kwargs):
         return None
     hv, hp = list(kwargs["value_hidden_sizes"]), list(kwargs["policy_hidden_sizes"])

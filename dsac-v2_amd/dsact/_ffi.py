@@ -38,7 +38,7 @@ class Config(C.Structure):
         ("algo", C.c_int32), ("td_bound", C.c_double),
         ("v1_unbounded", C.c_int32), ("value_act", C.c_int32), ("policy_act", C.c_int32), ("act_dist", C.c_int32),
         ("policy_std_param", C.c_int32), ("value_out_act", C.c_int32), ("policy_out_act", C.c_int32),
-        ("policy_hidden", C.c_int32 * MAX_HIDDEN), ("policy_twin", C.c_int32),
+        ("policy_hidden", C.c_int32 * MAX_HIDDEN), ("policy_twin", C.c_int32), ("policy_n_hidden", C.c_int32),
     ]
 
 

@@ -90,10 +90,12 @@ class DsactEngine:
         cfg.policy_std_param = 1 if policy_std_type == "parameter" else 0   # networks/mlp.py:63-73 (include/dsact.h)
         cfg.policy_twin = 1 if policy_std_type == "mlp_separated" else 0    # networks/mlp.py:46-57: two MLPs side by side
         if policy_hidden is not None and list(policy_hidden) != list(hidden):   # value_hidden_sizes != policy_hidden_sizes (include/dsact.h)
-            if conv_type or len(policy_hidden) != len(hidden):
-                raise DsactError("policy_hidden needs the MLP nets and as many layers as `hidden`")
+            if conv_type or not 1 <= len(policy_hidden) <= _ffi.MAX_HIDDEN:
+                raise DsactError("policy_hidden needs the MLP nets and 1..%d layers" % _ffi.MAX_HIDDEN)
             for i, w in enumerate(policy_hidden):
                 cfg.policy_hidden[i] = int(w)
+            if len(policy_hidden) != len(hidden):    # lists of different depth (include/dsact.h policy_n_hidden)
+                cfg.policy_n_hidden = len(policy_hidden)
         cfg.value_out_act, cfg.policy_out_act = int(value_out_act), int(policy_out_act)   # 0 linear, 1..5 relu .. tanh (include/dsact.h)
         cfg.act_dist = int(act_dist)                                       # 0 TanhGaussDistribution, 1 GaussDistribution
         self.cfg = cfg

@@ -134,6 +134,10 @@ typedef struct dsact_config {
    * DSAC_V2 with MLP nets, tile-stage kernels (the critics stay single MLPs: the row-slice chains run one trunk count per
    * launch); policy_std_param must be 0. Both acting forwards serve it (a block layer is a row range with an input offset). */
   int32_t policy_twin;
+  /* len(policy_hidden_sizes) when it differs from len(value_hidden_sizes) (0: the same number of layers). The policy nets then
+   * take `policy_hidden[0 .. policy_n_hidden)` (every entry > 0) and their own depth everywhere; the critics keep `n_hidden` /
+   * `hidden`. DSAC_V2 with MLP nets, tile-stage kernels (stage lists, heads and weight-gradient tiles are built per net). */
+  int32_t policy_n_hidden;
 } dsact_config;
 
 /* ---- lifecycle ------------------------------------------------------------------------------ */

@@ -68,6 +68,8 @@ VARIANTS = {
     # policy_std_type = "mlp_separated" (networks/mlp.py:46-57): `mean` and `log_std` from two MLPs -- checkpoints with
     # `policy.mean.*` / `policy.log_std.*`, sampler and evaluator acting through the twin-trunk arena layout (round 6)
     "std_sep_si2": dict(sample_interval=2, policy_std_type="mlp_separated"),
+    # value_hidden_sizes / policy_hidden_sizes of different widths AND depth (utils/common_utils.py:59-62 reads the lists per key)
+    "depth_si2": dict(sample_interval=2, policy_hidden_sizes=[48, 32, 40]),
     # policy_act_distribution = "GaussDistribution" (utils/act_distribution_cls.py:82-115): sampler, evaluator (mode() clamps the
     # mean) and the update without tanh squashing
     "gauss_si2": dict(sample_interval=2, policy_act_distribution="GaussDistribution"),

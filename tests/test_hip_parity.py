@@ -156,7 +156,7 @@ def act_np(z, act):
     return ACTIVATIONS[act](z).numpy()
 
 
-def hip_act_sides(e, cfg, L, B):
+def hip_act_sides(e, cfg, L, B, Lp=None):
     """the side of 0 the HIP kernels put every hidden pre-activation of the differentiated chains on (read back from the
     stored act'(z) for relu, from the sign of the stored activation for selu), for the oracle's `act_sides` (oracle/dsact_oracle.py:
     at a pre-activation within rounding noise of 0 either subgradient is valid; the reference is evaluated with the
@@ -167,7 +167,7 @@ def hip_act_sides(e, cfg, L, B):
         if act not in KINKED:
             continue
         per = []
-        for l in range(L):
+        for l in range((Lp or L) if ch == "pi" else L):     # (policy_hidden_sizes may be a list of another length)
             if act == "relu":     # act'(z) is 0 / 1
                 per.append(torch.as_tensor(e.debug_read("G.%s.%d" % (ch, l)).reshape(B, -1)) > 0.5)
             else:                 # selu: sign(h) == sign(z) (its derivative below 0 passes through the value it has above 0)
@@ -176,7 +176,7 @@ def hip_act_sides(e, cfg, L, B):
     return sides
 
 
-def compare_intermediates(rep, alg, orc, L, B, A):
+def compare_intermediates(rep, alg, orc, L, B, A, Lp=None):
     e, I = alg.engine, orc.inter
     d = lambda n: e.debug_read(n)
     ld = e.debug_read("X0").size // B
@@ -206,7 +206,7 @@ def compare_intermediates(rep, alg, orc, L, B, A):
     for i, q in enumerate(("q1_pi", "q2_pi")):
         rep.cmp(q, d("qout_p%d" % i).reshape(B, 2)[:, 0], I[q], 2e-5)
     for ch, key in (("pi", "z_pi"), ("q1c", "z_q1"), ("q2c", "z_q2"), ("q1p", "z_q1p"), ("q2p", "z_q2p")):
-        for l in range(L):
+        for l in range((Lp or L) if ch == "pi" else L):
             rep.cmp("H.%s.%d" % (ch, l), d("H.%s.%d" % (ch, l)), act_np(I[key][l], orc.cfg["policy_act" if ch == "pi" else "value_act"]), 2e-6, 2e-5)
     if orc.cfg.get("act_dist", "TanhGaussDistribution") == "TanhGaussDistribution":
         rep.cmp("d_new_act", d("d_new_act"), I["d_new_act"], 1e-9, 2e-4)
@@ -214,7 +214,7 @@ def compare_intermediates(rep, alg, orc, L, B, A):
     #  log_prob(action); the kernels keep dL/d new_act through the critics only and add the log-prob path in the rsample
     #  backward -- the policy's dZ and gradient rows below compare the sum)
     for ch, key in (("q1c", "dz_q1"), ("q2c", "dz_q2"), ("q1p", "dz_q1p"), ("q2p", "dz_q2p"), ("pi", "dz_pi")):
-        for l in range(L):
+        for l in range((Lp or L) if ch == "pi" else L):
             rep.cmp("dZ.%s.%d" % (ch, l), d("dZ.%s.%d" % (ch, l)), I[key][l], 1e-10, 2e-4)
 
 
@@ -223,6 +223,7 @@ def run_case(title, O, A, hid, B, steps, act_limit=0.4, init=None, golden=None, 
     alg, orc = make_pair(O, A, hid, B, act_limit=act_limit, init=init, **over)
     e = alg.engine
     L = len(hid)
+    Lp = len(over.get("policy_hidden_sizes") or hid)
     rng = np.random.default_rng(5)
     lay = e.layout
     cfg = orc.cfg
@@ -242,7 +243,7 @@ def run_case(title, O, A, hid, B, steps, act_limit=0.4, init=None, golden=None, 
         e.compute_grads(it)
         e.sync()  # the engine runs on its own stream; torch reads below are on torch's
         if cfg["value_act"] in KINKED or cfg["policy_act"] in KINKED:
-            orc.act_sides = hip_act_sides(e, cfg, L, B)
+            orc.act_sides = hip_act_sides(e, cfg, L, B, Lp)
         orc_chk = orc
         if (cfg["value_act"], cfg["policy_act"]) != ("gelu", "gelu") and it == steps - 1 and it > 0:
             # The intermediates and gradients of the last step are a per-kernel check at tight tolerances, so THEY are taken
@@ -259,7 +260,7 @@ def run_case(title, O, A, hid, B, steps, act_limit=0.4, init=None, golden=None, 
         for ch, j, cnt, zmax in (orc_chk.act_kinks or []):
             assert zmax < 1e-5, "activation sides differ at a pre-activation of %g (%s layer %d): not a kink" % (zmax, ch, j)
         if keep:
-            compare_intermediates(rep, alg, orc_chk, L, B, A)
+            compare_intermediates(rep, alg, orc_chk, L, B, A, Lp)
         g = e.grads.cpu().numpy()
         g_ref = orc_chk.flat_grads().numpy()
         off = 0

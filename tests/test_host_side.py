@@ -114,8 +114,10 @@ def test_unsupported_configs_raise():
         orc = DsactOracle(default_config(6, 2, (16, 16), policy_act=act, value_act=act), state_dict=c.state_dict())
         x = torch.randn(5, 6)
         assert torch.equal(c.policy(x), policy_forward(x, orc.p["policy"], orc.cfg).detach()), act
-    with pytest.raises(NotImplementedError):
-        ApproxContainer(**hip_kwargs(4, 2, (32,), 8, value_hidden_sizes=[16, 16]))     # another DEPTH than the policy's
+    # another DEPTH than the policy's (round 6: each family keeps its own layer count)
+    c = ApproxContainer(**hip_kwargs(4, 2, (32,), 8, value_hidden_sizes=[16, 16]))
+    assert len(c.q1.q) == 6 and len(c.policy.policy) == 4 and c._layout.n_q == 16 * 6 + 16 + 16 * 16 + 16 + 2 * 16 + 2
+    assert c._layout.n_pi == 32 * 4 + 32 + 4 * 32 + 4
     # value_hidden_sizes != policy_hidden_sizes of the same depth: the policy nets get their own widths
     c = ApproxContainer(**hip_kwargs(4, 2, (32, 32), 8, policy_hidden_sizes=[16, 24]))
     assert tuple(c.policy.policy[0].weight.shape) == (16, 4) and tuple(c.policy.policy[2].weight.shape) == (24, 16)

@@ -174,9 +174,12 @@ def test_std_type_mlp_separated_bit_exact_vs_live_reference(O, A, hid, hp, B, pa
         assert all(torch.equal(sd[k], osd[k]) for k in sd)
 
 
-@pytest.mark.parametrize("O,A,hv,hp,B", [(24, 6, (64, 64), (32, 48), 64), (376, 17, (256, 256, 256), (128, 128, 128), 64), (11, 3, (96, 40), (40, 96), 32)])
+@pytest.mark.parametrize("O,A,hv,hp,B", [(24, 6, (64, 64), (32, 48), 64), (376, 17, (256, 256, 256), (128, 128, 128), 64), (11, 3, (96, 40), (40, 96), 32),
+                                         # lists of different length (round 6)
+                                         (24, 6, (64, 64, 64), (64, 64), 64), (24, 6, (64, 64), (48, 96, 32), 64), (376, 17, (256, 256, 256), (256, 256), 64),
+                                         (11, 3, (40,), (96, 40, 24, 56), 32)])
 def test_unequal_hidden_sizes_bit_exact_vs_live_reference(O, A, hv, hp, B):
-    """value_hidden_sizes != policy_hidden_sizes (utils/common_utils.py:59-62 reads them per key), same depth"""
+    """value_hidden_sizes != policy_hidden_sizes (utils/common_utils.py:59-62 reads them per key): other widths, other depth"""
     torch.set_num_threads(2)
     ref = ref_loader.import_reference()
     kw = ref_loader.reference_kwargs(O, A, hv, policy_hidden_sizes=list(hp))

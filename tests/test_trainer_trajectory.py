@@ -280,6 +280,11 @@ def test_hip_stack_follows_the_reference_trajectory(tmp_path, variant):
         assert list(sd.keys())[0] == "log_alpha" and len(sd) == 41 + 2 * 6 and "policy.policy.0.weight" not in sd
         assert tuple(sd["policy.log_std.4.weight"].shape) == (kw["action_dim"], kw["policy_hidden_sizes"][-1]) and "policy_target.mean.0.bias" in sd
         return
+    if len(kw["policy_hidden_sizes"]) != len(kw["value_hidden_sizes"]):   # each family with its own layer count
+        n_lin = 4 * (len(kw["value_hidden_sizes"]) + 1) + 2 * (len(kw["policy_hidden_sizes"]) + 1)
+        assert list(sd.keys())[0] == "log_alpha" and len(sd) == 1 + 4 + 2 * n_lin
+        assert tuple(sd["policy.policy.%d.weight" % (2 * len(kw["policy_hidden_sizes"]))].shape) == (2 * kw["action_dim"], kw["policy_hidden_sizes"][-1])
+        return
     assert list(sd.keys())[0] == "log_alpha" and len(sd) == (43 if std_param else 41)
     if std_param:   # the reference's own names for this policy_std_type (networks/mlp.py:63-73)
         assert tuple(sd["policy.log_std"].shape) == (1, kw["action_dim"]) and "policy.mean.0.weight" in sd and "policy.policy.0.weight" not in sd
