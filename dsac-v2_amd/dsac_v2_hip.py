@@ -379,6 +379,8 @@ class ApproxContainer(nn.Module):
     def attach(self, engine: DsactEngine):
         """Move the current parameter values into the engine's arenas and alias them."""
         arenas = {"online": engine.online, "target": engine.target}
+        if isinstance(engine.layout, type(self._layout)):
+            object.__setattr__(self, "_layout", engine.layout)   # (the engine decides the stored widths: ArenaLayout pad_to)
         with torch.no_grad():
             for p, arena, off, shape, strides in self._named_param_slots():
                 # a (possibly strided) window of the flat arena: conv weights are stored [Cout][KH][KW][Cin],
@@ -651,7 +653,10 @@ class DSAC_V2_HIP:
             policy_std_type=kwargs.get("policy_std_type", "mlp_shared"),
             value_out_act=0 if ct else OUT_ACTIVATIONS[kwargs.get("value_output_activation", "linear")][0],
             policy_out_act=0 if ct else OUT_ACTIVATIONS[kwargs.get("policy_output_activation", "linear")][0],
-            policy_hidden=_policy_hidden_sizes(kwargs))
+            policy_hidden=_policy_hidden_sizes(kwargs),
+            # additive: `hip_pad_widths` (default True) -- ragged / unequal hidden widths of the same depth are stored zero-padded to
+            # 64 / 128 / 256 when that puts the update on the row-slice chain kernels (dsact/engine.py, dsact/layout.py pad_to)
+            pad_widths=bool(kwargs.get("hip_pad_widths", True)))
         self.networks.attach(self.engine)
         register_engine(self.engine)
         # additive: `hip_host_act` (default True) -- the sampler's / evaluator's batch-1 policy forward runs on the host from a

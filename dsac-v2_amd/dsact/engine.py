@@ -35,9 +35,48 @@ class DsactEngine:
                  global_batch: Optional[int] = None, device: int = 0, conv_type: Optional[str] = None,
                  algo: str = "DSAC_V2", td_bound: float = 20.0, v1_bound: bool = True, value_act: int = 0, policy_act: int = 0, act_dist: int = 0,
                  policy_std_type: str = "mlp_shared", value_out_act: int = 0, policy_out_act: int = 0,
-                 policy_hidden: Optional[Sequence[int]] = None):
+                 policy_hidden: Optional[Sequence[int]] = None, pad_widths: bool = False):
         """obs_dim: int for the MLP nets; with `conv_type` ("type_1" / "type_2", reference
-        networks/cnn.py:173-228) the (C, H, W) image shape, and `hidden` must be that type's MLP widths."""
+        networks/cnn.py:173-228) the (C, H, W) image shape, and `hidden` must be that type's MLP widths.
+
+        pad_widths (round 6): hidden widths the row-slice chain kernels do not take as they are -- ragged ones (96, 40), unequal
+        value / policy lists of the same depth -- are STORED zero-padded to one common width of 64 / 128 / 256 when that puts
+        the update on the chains (ArenaLayout pad_to: the reference's tensors are windows of the stored ones, the padding stays an
+        exact zero). Falls back to the exact layout (tile-stage kernels) when the chains refuse the padded shape anyway."""
+        kw = dict(gamma=gamma, tau=tau, tau_b=tau_b, auto_alpha=auto_alpha, alpha=alpha, delay_update=delay_update, lr_q=lr_q, lr_pi=lr_pi,
+                  lr_alpha=lr_alpha, min_log_std=min_log_std, max_log_std=max_log_std, global_batch=global_batch, device=device,
+                  conv_type=conv_type, algo=algo, td_bound=td_bound, v1_bound=v1_bound, value_act=value_act, policy_act=policy_act,
+                  act_dist=act_dist, policy_std_type=policy_std_type, value_out_act=value_out_act, policy_out_act=policy_out_act,
+                  policy_hidden=policy_hidden)
+        pad = self._pad_width(hidden, policy_hidden, batch, obs_dim, **{k: v for k, v in kw.items() if k != "policy_hidden"}) if pad_widths else None
+        self._init(obs_dim, act_dim, hidden, batch, pad_to=pad, **kw)
+        if pad and not self.chain_active:     # the chains refused it (LDS, an environment switch, ...): no reason to carry the padding
+            self.close()
+            self._init(obs_dim, act_dim, hidden, batch, pad_to=None, **kw)
+
+    @staticmethod
+    def _pad_width(hidden, policy_hidden, batch, obs_dim, *, conv_type=None, algo="DSAC_V2", policy_std_type="mlp_shared", value_act=0,
+                   policy_act=0, **_):
+        """the common stored width that puts this configuration on the row-slice chains, or None (no padding needed / possible):
+        the shape conditions of dsact_create's chain_ok (csrc/dsact_api.hip) + act(0) == 0 for both hidden activations"""
+        ph = list(policy_hidden) if policy_hidden is not None else list(hidden)
+        widths = list(hidden) + ph
+        if conv_type or algo != "DSAC_V2" or policy_std_type == "mlp_separated" or len(ph) != len(hidden) or len(hidden) > 4:
+            return None
+        if len(set(widths)) == 1 and widths[0] in (64, 128, 256):
+            return None                                   # the chains take it as it is
+        if max(widths) > 256 or 4 in (int(value_act), int(policy_act)):   # 4 = sigmoid: act(0) = 0.5 would make the padding live
+            return None
+        if batch % 16 or (batch > 256 and batch % 256) or int(obs_dim) % 4:
+            return None
+        return 64 if max(widths) <= 64 else (128 if max(widths) <= 128 else 256)
+
+    def _init(self, obs_dim, act_dim, hidden, batch, *, pad_to=None,
+              gamma=0.99, tau=0.005, tau_b=None, auto_alpha=True, alpha=0.2, delay_update=2,
+              lr_q=1e-4, lr_pi=1e-4, lr_alpha=3e-4, min_log_std=-20.0, max_log_std=0.5,
+              global_batch=None, device=0, conv_type=None,
+              algo="DSAC_V2", td_bound=20.0, v1_bound=True, value_act=0, policy_act=0, act_dist=0,
+              policy_std_type="mlp_shared", value_out_act=0, policy_out_act=0, policy_hidden=None):
         import torch
 
         self._lib = _ffi.load()
@@ -59,7 +98,7 @@ class DsactEngine:
             obs_dim = self.layout.obs_dim
         else:
             self.layout = ArenaLayout(obs_dim, act_dim, list(hidden), n_critics=2 if algo == "DSAC_V2" else 1,
-                                      policy_std_type=policy_std_type, policy_hidden=policy_hidden)
+                                      policy_std_type=policy_std_type, policy_hidden=policy_hidden, pad_to=pad_to)
             self.obs_shape = (int(obs_dim),)
         self.obs_dim, self.act_dim, self.batch = int(obs_dim), int(act_dim), int(batch)
         self.device_index = int(device)
@@ -69,7 +108,7 @@ class DsactEngine:
         if len(hidden) > _ffi.MAX_HIDDEN:
             raise DsactError("at most %d hidden layers" % _ffi.MAX_HIDDEN)
         for i, w in enumerate(hidden):
-            cfg.hidden[i] = int(w)
+            cfg.hidden[i] = int(pad_to or w)      # (pad_to: the library sees the STORED widths -- an equal-width configuration)
         cfg.batch = batch
         cfg.global_batch = int(global_batch or batch)
         cfg.auto_alpha = 1 if auto_alpha else 0
@@ -89,7 +128,7 @@ class DsactEngine:
         cfg.value_act, cfg.policy_act = int(value_act), int(policy_act)   # hidden activations: 0 gelu .. 5 tanh (include/dsact.h)
         cfg.policy_std_param = 1 if policy_std_type == "parameter" else 0   # networks/mlp.py:63-73 (include/dsact.h)
         cfg.policy_twin = 1 if policy_std_type == "mlp_separated" else 0    # networks/mlp.py:46-57: two MLPs side by side
-        if policy_hidden is not None and list(policy_hidden) != list(hidden):   # value_hidden_sizes != policy_hidden_sizes (include/dsact.h)
+        if policy_hidden is not None and list(policy_hidden) != list(hidden) and not pad_to:   # value_hidden_sizes != policy_hidden_sizes (include/dsact.h)
             if conv_type or not 1 <= len(policy_hidden) <= _ffi.MAX_HIDDEN:
                 raise DsactError("policy_hidden needs the MLP nets and 1..%d layers" % _ffi.MAX_HIDDEN)
             for i, w in enumerate(policy_hidden):

@@ -60,7 +60,7 @@ def twin_mlp_views(off: int, in0: int, hid: List[int], nb: int):
 
 class ArenaLayout:
     def __init__(self, obs_dim: int, act_dim: int, hidden: List[int], n_critics: int = 2, policy_std_type: str = "mlp_shared",
-                 policy_hidden: Optional[List[int]] = None):
+                 policy_hidden: Optional[List[int]] = None, pad_to: Optional[int] = None):
         """n_critics = 2: DSAC_V2 (q1, q2); 1: DSAC_V1 (a single `q`; online = q | policy | log_alpha).
 
         policy_std_type "parameter" (reference networks/mlp.py:63-73): the arena keeps the policy's output layer in the
@@ -69,7 +69,14 @@ class ArenaLayout:
         the reference's `log_std` parameter: raw log-std = 0 . h + log_std, d log_std = sum over the batch of d raw.
 
         policy_std_type "mlp_separated" (networks/mlp.py:46-57): the policy is two MLPs `mean` / `log_std` (obs -> hidden -> act_dim
-        each), kept side by side like the CNN nets' twin trunks (`twin_mlp_views`; dsact_config.policy_twin)."""
+        each), kept side by side like the CNN nets' twin trunks (`twin_mlp_views`; dsact_config.policy_twin).
+
+        pad_to = W (64 / 128 / 256; round 6): every hidden layer of every net is STORED W wide -- the row-slice chain kernels run one
+        width per layer across all their units -- and the reference's tensors are the top-left windows of the stored matrices
+        (`param_views` strides). The padding is structurally zero and stays zero: a padded feature has zero weights and bias, so its
+        pre-activation is 0 and (for every hidden activation with act(0) = 0, i.e. all but sigmoid) its activation is 0; its outgoing
+        weights are 0, so its dZ is 0; hence every gradient element that touches the padding is an exact 0 and Adam / Polyak leave
+        the zeros in place. n_q / n_pi / n_online count STORED floats; q_shapes / pi_shapes (the cost model) stay the reference's."""
         self.obs_dim, self.act_dim, self.hidden = int(obs_dim), int(act_dim), [int(h) for h in hidden]
         self.n_critics = int(n_critics)
         self.policy_std_type = policy_std_type
@@ -79,8 +86,18 @@ class ArenaLayout:
         self.policy_hidden = [int(h) for h in policy_hidden] if policy_hidden is not None else list(self.hidden)
         self.q_shapes = mlp_sizes(obs_dim + act_dim, self.hidden, 2)
         self.pi_shapes = mlp_sizes(obs_dim, self.policy_hidden, 2 * act_dim)
-        self.n_q = sum(o * i + o for o, i in self.q_shapes)
-        self.n_pi = sum(o * i + o for o, i in self.pi_shapes)
+        self.pad_to = int(pad_to) if pad_to else None
+        if self.pad_to:
+            assert len(self.policy_hidden) == len(self.hidden) and not self.policy_twin
+            assert max(self.hidden + self.policy_hidden) <= self.pad_to
+            self.stored_hidden = [self.pad_to] * len(self.hidden)
+            self.q_stored = mlp_sizes(obs_dim + act_dim, self.stored_hidden, 2)
+            self.pi_stored = mlp_sizes(obs_dim, self.stored_hidden, 2 * act_dim)
+        else:
+            self.stored_hidden = list(self.hidden)
+            self.q_stored, self.pi_stored = self.q_shapes, self.pi_shapes
+        self.n_q = sum(o * i + o for o, i in self.q_stored)
+        self.n_pi = sum(o * i + o for o, i in self.pi_stored)
         if self.policy_twin:
             self.pi_shapes = mlp_sizes(obs_dim, self.policy_hidden, act_dim)      # one trunk
             self._pi_mean, self._pi_lstd, self._pi_zeros, self.n_pi = twin_mlp_views(0, self.obs_dim, self.policy_hidden, self.act_dim)
@@ -110,29 +127,35 @@ class ArenaLayout:
         return ("q", "q_target", "policy", "policy_target")
 
     def net_shapes(self, net: str):
+        """the reference's (out, in) per Linear"""
         return self.pi_shapes if net.startswith("policy") else self.q_shapes
 
+    def stored_shapes(self, net: str):
+        """(out, in) per Linear as the arena stores it (== net_shapes unless pad_to)"""
+        return self.pi_stored if net.startswith("policy") else self.q_stored
+
     def param_slices(self, net: str):
-        """[(suffix, arena, offset, shape)] e.g. ('q.0.weight', 'online', 0, (256, 393))"""
+        """[(suffix, arena, offset, shape)] e.g. ('q.0.weight', 'online', 0, (256, 393)); shape = the reference's, offset = where the
+        tensor starts in the arena (pad_to: the row stride is the STORED input width, see param_views)"""
         arena, off = self.net_offset[net]
         sub = "policy" if net.startswith("policy") else "q"
         std_param = net.startswith("policy") and self.policy_std_type == "parameter"
         out = []
-        shapes = self.net_shapes(net)
-        for j, (o, i) in enumerate(shapes):
+        shapes, stored = self.net_shapes(net), self.stored_shapes(net)
+        for j, ((o, i), (so, si)) in enumerate(zip(shapes, stored)):
             if std_param and j == len(shapes) - 1:
                 # module order of the reference (own parameters before sub-modules): log_std first, then mean.*
                 A = self.act_dim
-                out.insert(0, ("log_std", arena, off + o * i + A, (1, A)))
+                out.insert(0, ("log_std", arena, off + so * si + A, (1, A)))
                 out.append(("mean.%d.weight" % (2 * j), arena, off, (A, i)))
-                out.append(("mean.%d.bias" % (2 * j), arena, off + o * i, (A,)))
-                off += o * i + o
+                out.append(("mean.%d.bias" % (2 * j), arena, off + so * si, (A,)))
+                off += so * si + so
                 continue
             name = "mean" if std_param else sub
             out.append(("%s.%d.weight" % (name, 2 * j), arena, off, (o, i)))
-            off += o * i
+            off += so * si
             out.append(("%s.%d.bias" % (name, 2 * j), arena, off, (o,)))
-            off += o
+            off += so
         return out
 
     def zero_rows(self, net: str):
@@ -140,7 +163,7 @@ class ArenaLayout:
         if not (net.startswith("policy") and self.policy_std_type == "parameter"):
             return None
         arena, off = self.net_offset[net]
-        shapes = self.net_shapes(net)
+        shapes = self.stored_shapes(net)
         for o, i in shapes[:-1]:
             off += o * i + o
         o, i = shapes[-1]
@@ -160,8 +183,14 @@ class ArenaLayout:
             arena, base = self.net_offset[net]
             return [(sfx, arena, base + off, shape, strides) for sfx, off, shape, strides in self._pi_mean + self._pi_lstd]
         out = []
+        ld = {}   # row stride of layer j's weight = its STORED input width
+        for j, (_, si) in enumerate(self.stored_shapes(net)):
+            ld[2 * j] = si
         for suffix, arena, off, shape in self.param_slices(net):
-            strides = (shape[1], 1) if len(shape) == 2 else (1,)
+            if len(shape) == 2 and suffix != "log_std":
+                strides = (ld[int(suffix.split(".")[-2])], 1)
+            else:
+                strides = (shape[1], 1) if len(shape) == 2 else (1,)
             out.append((suffix, arena, off, shape, strides))
         return out
 

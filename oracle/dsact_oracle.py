@@ -571,6 +571,17 @@ class DsactOracle:
 
     def arena_order(self, n, ps):
         """per-parameter tensors of net n (in the order of self.p[n]) -> flat pieces in the HIP arena's order"""
+        W = self.cfg.get("pad_to")
+        if W:   # the arena stores every hidden layer W wide, zero padded (dsac-v2_amd/dsact/layout.py, ArenaLayout pad_to)
+            ps = list(ps)
+            n_lin = (len(ps) - (1 if (n.startswith("policy") and self._std_param) else 0)) // 2
+            for j in range(n_lin):
+                w, b = ps[2 * j], ps[2 * j + 1]
+                rows = W if j < n_lin - 1 else w.shape[0]
+                cols = w.shape[1] if j == 0 else W
+                wp = torch.zeros(rows, cols, dtype=w.dtype); wp[:w.shape[0], :w.shape[1]] = w
+                bp = torch.zeros(rows, dtype=b.dtype); bp[:b.shape[0]] = b
+                ps[2 * j], ps[2 * j + 1] = wp, bp
         if n.startswith("policy") and self._std_twin:
             # "mlp_separated": the arena's twin-trunk layout (dsac-v2_amd/dsact/layout.py, twin_mlp_views): layer 0 [W_mean ; W_ls],
             # hidden layers W_mean | W_ls, output layer the dense [[w_mean, 0], [0, w_ls]]; biases [b_mean ; b_ls]

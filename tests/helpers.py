@@ -60,6 +60,9 @@ def hip_kwargs(O, A, hidden, B, act_limit=0.4, **over):
         action_high_limit=np.full((A,), act_limit, dtype=np.float32),
         action_low_limit=np.full((A,), -act_limit, dtype=np.float32),
         additional_info={}, cnn_shared=False, trainer="off_serial_trainer", use_gpu=True,
+        # the parity cases pick ragged / unequal widths to reach the tile-stage kernels: they keep the exact arena layout;
+        # tests/test_padded_widths.py turns the zero-padded storage (the plugin's default) on
+        hip_pad_widths=False,
     )
     kw.update(over)
     return kw

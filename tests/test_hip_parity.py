@@ -140,6 +140,7 @@ def make_pair(O, A, hid, B, act_limit=0.4, seed=0, init=None, **over):
                          value_out_act=over.get("value_output_activation", "linear"), policy_out_act=over.get("policy_output_activation", "linear"),
                          policy_hidden=over.get("policy_hidden_sizes"),
                          **{k: over[k] for k in ("auto_alpha", "alpha", "delay_update") if k in over})
+    cfg["pad_to"] = getattr(alg.engine.layout, "pad_to", None)   # stored widths of the HIP arenas: the oracle's FLAT views follow them
     orc = DsactOracle(cfg, state_dict={k: v.cpu() for k, v in alg.networks.state_dict().items()})
     return alg, orc
 
@@ -167,11 +168,12 @@ def hip_act_sides(e, cfg, L, B, Lp=None):
         if act not in KINKED:
             continue
         per = []
+        wid = list((cfg.get("policy_hidden") or cfg["hidden"]) if ch == "pi" else cfg["hidden"])   # (the arena may store them padded)
         for l in range((Lp or L) if ch == "pi" else L):     # (policy_hidden_sizes may be a list of another length)
             if act == "relu":     # act'(z) is 0 / 1
-                per.append(torch.as_tensor(e.debug_read("G.%s.%d" % (ch, l)).reshape(B, -1)) > 0.5)
+                per.append(torch.as_tensor(e.debug_read("G.%s.%d" % (ch, l)).reshape(B, -1)[:, :wid[l]].copy()) > 0.5)
             else:                 # selu: sign(h) == sign(z) (its derivative below 0 passes through the value it has above 0)
-                per.append(torch.as_tensor(e.debug_read("H.%s.%d" % (ch, l)).reshape(B, -1)) > 0)
+                per.append(torch.as_tensor(e.debug_read("H.%s.%d" % (ch, l)).reshape(B, -1)[:, :wid[l]].copy()) > 0)
         sides[ch] = per
     return sides
 
@@ -179,6 +181,14 @@ def hip_act_sides(e, cfg, L, B, Lp=None):
 def compare_intermediates(rep, alg, orc, L, B, A, Lp=None):
     e, I = alg.engine, orc.inter
     d = lambda n: e.debug_read(n)
+
+    def dl(name, want):
+        """a hidden-layer buffer [B x stored width] cut to the reference's width; the padding (ArenaLayout pad_to) must be exact zeros"""
+        got = np.asarray(d(name)).reshape(B, -1)
+        w = int(np.asarray(want).reshape(B, -1).shape[1])
+        assert not got[:, w:].any(), "%s: the padded features are not zero" % name
+        return got[:, :w]
+
     ld = e.debug_read("X0").size // B
     O = e.obs_dim
     rep.cmp("new_act", d("XP").reshape(B, ld)[:, O:O + A], I["new_act"], 2e-6)
@@ -207,7 +217,7 @@ def compare_intermediates(rep, alg, orc, L, B, A, Lp=None):
         rep.cmp(q, d("qout_p%d" % i).reshape(B, 2)[:, 0], I[q], 2e-5)
     for ch, key in (("pi", "z_pi"), ("q1c", "z_q1"), ("q2c", "z_q2"), ("q1p", "z_q1p"), ("q2p", "z_q2p")):
         for l in range((Lp or L) if ch == "pi" else L):
-            rep.cmp("H.%s.%d" % (ch, l), d("H.%s.%d" % (ch, l)), act_np(I[key][l], orc.cfg["policy_act" if ch == "pi" else "value_act"]), 2e-6, 2e-5)
+            rep.cmp("H.%s.%d" % (ch, l), dl("H.%s.%d" % (ch, l), I[key][l]), act_np(I[key][l], orc.cfg["policy_act" if ch == "pi" else "value_act"]), 2e-6, 2e-5)
     if orc.cfg.get("act_dist", "TanhGaussDistribution") == "TanhGaussDistribution":
         rep.cmp("d_new_act", d("d_new_act"), I["d_new_act"], 1e-9, 2e-4)
     # (GaussDistribution: the oracle's new_act IS the pre-limit sample x, so its .grad also carries d logp / d x through
@@ -215,7 +225,7 @@ def compare_intermediates(rep, alg, orc, L, B, A, Lp=None):
     #  backward -- the policy's dZ and gradient rows below compare the sum)
     for ch, key in (("q1c", "dz_q1"), ("q2c", "dz_q2"), ("q1p", "dz_q1p"), ("q2p", "dz_q2p"), ("pi", "dz_pi")):
         for l in range((Lp or L) if ch == "pi" else L):
-            rep.cmp("dZ.%s.%d" % (ch, l), d("dZ.%s.%d" % (ch, l)), I[key][l], 1e-10, 2e-4)
+            rep.cmp("dZ.%s.%d" % (ch, l), dl("dZ.%s.%d" % (ch, l), I[key][l]), I[key][l], 1e-10, 2e-4)
 
 
 def run_case(title, O, A, hid, B, steps, act_limit=0.4, init=None, golden=None, **over):
