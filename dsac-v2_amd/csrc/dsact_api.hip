@@ -3323,7 +3323,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     // row-slice fused chains: MLP nets of DSAC_V2 with equal hidden widths of 64 / 128 / 256, batch a multiple of 16
     const int R = 4 * h->cRG;
     // (CNN nets: the twin MLP trunks over the conv features run as chain units -- DSACT_NO_CHAIN_CNN keeps them on the tile path)
-    bool ok = h->B % R == 0 && h->B % 16 == 0 && (h->B <= 256 || h->B % 256 == 0) && h->F % 4 == 0 &&
+    bool ok = h->B % R == 0 && h->B % 16 == 0 && (h->B <= 256 || h->B % 256 == 0) &&   // (round 6: any observation width -- the packed copies place a Q net's action columns element-wise when F % 4 != 0)
               getenv("DSACT_NO_CHAIN") == nullptr && !(h->nq == 1 && getenv("DSACT_NO_CHAIN_V1") != nullptr) &&
               !(h->cnn && (getenv("DSACT_NO_CHAIN_CNN") != nullptr || h->B > 1024));
     ok = ok && h->L <= kChMaxL;

@@ -96,11 +96,23 @@ struct MirrorDesc {
 };
 
 // one lane's 4 consecutive-k values of row n (k % 4 == 0, all inside one segment) -> the copies
+// A Q net's first layer whose observation width F is no multiple of 4: the source quad (k .. k+3) straddles the observation /
+// action boundary or lies behind it, where the packed position Fp + (k - F) is no multiple of 4 either -- element by element
+// (the action columns: at most 32 + 3 per row; every other quad keeps its 16-byte store).
+__device__ __forceinline__ void mirror_fwd_each(const MirrorDesc& m, int n, int k, int K, const f32x4& v, bool target, const f32x4& vt) {
+  for (int e = 0; e < 4 && k + e < K; ++e) {
+    const int ke = k + e, kk = ke < m.F ? ke : m.Fp + (ke - m.F);
+    const size_t o = m.fwd_44 ? pk44_index(n, kk, m.fwd_C) : pk_index(n, kk, m.fwd_C);
+    m.fwd[o] = v[e];
+    if (target && m.fwd_t) m.fwd_t[o] = vt[e];
+  }
+}
 __device__ __forceinline__ void mirror_store4(const MirrorDesc& m, int n, int k, int K, const f32x4& v, bool target, const f32x4& vt) {
   if (m.fwd) {
     const int kk = k < m.F ? k : m.Fp + (k - m.F);
     const size_t o = m.fwd_44 ? pk44_index(n, kk, m.fwd_C) : pk_index(n, kk, m.fwd_C);
-    if (k + 3 < K) {
+    if ((m.F & 3) && k + 3 >= m.F && m.F < (1 << 30)) mirror_fwd_each(m, n, k, K, v, target, vt);   // (observation width no multiple of 4)
+    else if (k + 3 < K) {
       *(f32x4*)(m.fwd + o) = v;
       if (target && m.fwd_t) *(f32x4*)(m.fwd_t + o) = vt;
     } else {
@@ -143,7 +155,8 @@ __device__ __forceinline__ void mirror_store4_quad(const MirrorDesc& m, int n, i
   if (m.fwd && valid) {
     const int kk = k < m.F ? k : m.Fp + (k - m.F);
     const size_t o = m.fwd_44 ? pk44_index(n, kk, m.fwd_C) : pk_index(n, kk, m.fwd_C);
-    if (k + 3 < K) {
+    if ((m.F & 3) && k + 3 >= m.F && m.F < (1 << 30)) mirror_fwd_each(m, n, k, K, v, target, vt);   // (observation width no multiple of 4)
+    else if (k + 3 < K) {
       *(f32x4*)(m.fwd + o) = v;
       if (target && m.fwd_t) *(f32x4*)(m.fwd_t + o) = vt;
     } else {

@@ -67,7 +67,7 @@ class DsactEngine:
             return None                                   # the chains take it as it is
         if max(widths) > 256 or 4 in (int(value_act), int(policy_act)):   # 4 = sigmoid: act(0) = 0.5 would make the padding live
             return None
-        if batch % 16 or (batch > 256 and batch % 256) or int(obs_dim) % 4:
+        if batch % 16 or (batch > 256 and batch % 256):
             return None
         return 64 if max(widths) <= 64 else (128 if max(widths) <= 128 else 256)
 

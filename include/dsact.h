@@ -123,8 +123,10 @@ typedef struct dsact_config {
    * networks/mlp.py:92-97). */
   int32_t value_out_act, policy_out_act;
   /* value_hidden_sizes != policy_hidden_sizes (utils/common_utils.py:59-62 reads them per key): `hidden` sizes the critics,
-   * `policy_hidden[l]` > 0 the policy nets (all zeros: the same widths). Same number of layers; DSAC_V2 with MLP nets on the
-   * tile-stage kernels (the row-slice chains run one width per layer across every unit). */
+   * `policy_hidden[l]` > 0 the policy nets (all zeros: the same widths); policy_n_hidden below for another number of layers.
+   * DSAC_V2 with MLP nets on the tile-stage kernels (the row-slice chains run one width per layer across every unit -- a caller
+   * who wants such nets on the chains stores them zero-padded to a common width and passes THAT as `hidden`: the Python host
+   * side does, dsac-v2_amd/dsact/layout.py ArenaLayout pad_to). */
   int32_t policy_hidden[DSACT_MAX_HIDDEN_LAYERS];
   /* policy_std_type "mlp_separated" (networks/mlp.py:46-57,80-85): 1 = the policy is TWO MLPs over the observation, `mean` and
    * `log_std`, each obs -> hidden -> act_dim (0: one of the two forms policy_std_param selects). The arenas keep them side by

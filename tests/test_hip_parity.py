@@ -169,6 +169,8 @@ def hip_act_sides(e, cfg, L, B, Lp=None):
             continue
         per = []
         wid = list((cfg.get("policy_hidden") or cfg["hidden"]) if ch == "pi" else cfg["hidden"])   # (the arena may store them padded)
+        if ch == "pi" and cfg.get("policy_std_type") == "mlp_separated":
+            wid = [2 * w for w in wid]                       # rows [z_mean | z_log_std]
         for l in range((Lp or L) if ch == "pi" else L):     # (policy_hidden_sizes may be a list of another length)
             if act == "relu":     # act'(z) is 0 / 1
                 per.append(torch.as_tensor(e.debug_read("G.%s.%d" % (ch, l)).reshape(B, -1)[:, :wid[l]].copy()) > 0.5)

@@ -172,13 +172,17 @@ def test_v1_local_update_surface_and_fused_equals_split():
         assert torch.equal(s1[k].cpu(), s2[k].cpu()), k
 
 
-@pytest.mark.parametrize("per_graph,total,O", [(2, 8, 17), (3, 6, 17), (4, 8, 16), (3, 9, 16)])
-def test_v1_graph_replay_equals_eager_steps(per_graph, total, O):
-    """DSAC_V1 through the graph flow (gather of the next update and the bookkeeping ride in k_loss_v1's launch, the
-    single critic's first-layer tiles keep the padded copies fresh) == eager updates, bit for bit. obs 16: the row-slice
-    chains, whose graph is the pipelined one (policy units of the next minibatch precomputed, discarded policy backward
-    deferred, tagged hand-over)."""
+@pytest.mark.parametrize("per_graph,total,O,tiles", [(2, 8, 17, True), (3, 6, 17, True), (4, 8, 16, False), (3, 9, 16, False),
+                                                      (2, 8, 17, False), (3, 9, 11, False)])
+def test_v1_graph_replay_equals_eager_steps(per_graph, total, O, tiles, monkeypatch):
+    """DSAC_V1 through the graph flow == eager updates, bit for bit. tiles: the tile-stage kernels (DSACT_NO_CHAIN_V1; gather of
+    the next update and the bookkeeping ride in k_loss_v1's launch, the single critic's first-layer tiles keep the padded copies
+    fresh); else the row-slice chains, whose graph is the pipelined one (policy units of the next minibatch precomputed,
+    discarded policy backward deferred, tagged hand-over) -- round 6: at any observation width (17, 11: the action columns of
+    the critic's packed first layer are placed element-wise)."""
     A, hid, B, N = 4, (64, 64), 64, 2048
+    if tiles:
+        monkeypatch.setenv("DSACT_NO_CHAIN_V1", "1")
     engines = []
     for mode in ("eager", "graph"):
         alg, _ = make_pair(O, A, hid, B, seed=4)
@@ -191,10 +195,10 @@ def test_v1_graph_replay_equals_eager_steps(per_graph, total, O):
                              (torch.rand(N, device="cuda", generator=g) < .05).float())
         np.random.seed(1)
         e.upload_index_table(np.random.randint(0, N, size=(8, B)))
-        assert e.chain_active == (O % 4 == 0)
+        assert e.chain_active == (not tiles)
         if mode == "graph":
             e.graph_build(per_graph)
-            assert e.debug_get("pipe_graph") == (1.0 if O % 4 == 0 else 0.0)
+            assert e.debug_get("pipe_graph") == (0.0 if tiles else 1.0)
             e.graph_run(0, total)
         else:
             assert e.time_steps(0, total, use_graph=False) > 0

@@ -35,7 +35,7 @@ def test_padded_layout_windows_and_the_padding_rule():
     assert P([200] * 3, None, 1024, 376) == 256
     assert P([256] * 3, None, 256, 376) is None and P([64, 64], None, 64, 24) is None            # the chains take these as they are
     assert P([300, 64], None, 64, 24) is None                                                   # wider than the chains go
-    assert P([96, 40], None, 50, 24) is None and P([96, 40], None, 64, 11) is None              # batch / observation the chains refuse
+    assert P([96, 40], None, 50, 24) is None and P([96, 40], None, 64, 11) == 128               # a batch the chains refuse; any observation width
     assert P([96, 40], None, 64, 24, value_act=4) is None and P([96, 40], None, 64, 24, policy_act=4) is None   # sigmoid(0) != 0
     assert P([96, 40], [40], 64, 24) is None and P([96, 40], None, 64, 24, policy_std_type="mlp_separated") is None
     assert P([96, 40], None, 64, 24, algo="DSAC_V1") is None
@@ -75,7 +75,7 @@ def test_sigmoid_nets_and_refused_shapes_keep_the_exact_layout():
 
     alg, _ = make_pair(24, 6, (96, 40), 64, hip_pad_widths=True, value_hidden_activation="sigmoid")
     assert alg.engine.layout.pad_to is None and not alg.engine.chain_active
-    alg, _ = make_pair(11, 3, (96, 40), 50, hip_pad_widths=True)
+    alg, _ = make_pair(11, 3, (96, 40), 50, hip_pad_widths=True)     # batch 50: no multiple of 16
     assert alg.engine.layout.pad_to is None and not alg.engine.chain_active
     alg, _ = make_pair(24, 6, (64, 64), 64, hip_pad_widths=True)
     assert alg.engine.layout.pad_to is None and alg.engine.chain_active

@@ -248,8 +248,8 @@ def test_hip_stack_follows_the_reference_trajectory(tmp_path, variant):
         assert got["groups"] and alg.engine.debug_get("graph_noise_table") == 1.0
         if variant == "si8_sparse":
             assert any(n == 8 for _, n in got["groups"])
-        # (obs_dim 3 is no multiple of 4: this Pendulum case runs the tile path's merged graph; the pipelined graph with the
-        #  noise table is pinned by tests/test_hip_groups.py::test_reference_noise_through_the_pipelined_graph)
+        # (round 6: observation widths that are no multiple of 4 -- Pendulum's 3 -- run the row-slice chains, so these groups are
+        #  replays of the pipelined graph with the noise table; the depth / mlp_separated variants take the tile path's merged graph)
     crit = 7   # Loss/Critic loss: a sum of squared TD terms -> relative gate
     for it, (g, w) in enumerate(zip(got["tb_info"], want["tb_info"])):
         if g is None:      # inside a group: not reported (the next reported update carries its effect)
