@@ -47,3 +47,31 @@ for title, O, A, hv, hp, B in CASES:
         e.sync()
         e.close()
     print("%-40s" % title + "".join("  | pad_widths=%-5s stored %-4s chains %-5s %8.0f steps/s %7.2f us" % r for r in row))
+
+# ---- observation widths that are no multiple of 4: the row-slice chains (round 6) against the tile stages (rounds 2-5: DSACT_NO_CHAIN) ----
+print()
+for title, O, A, hv, B in (("HalfCheetah / Walker2d obs 17 act 6, 3x256", 17, 6, (256, 256, 256), 256), ("Hopper obs 11 act 3, 3x256", 11, 3, (256, 256, 256), 256),
+                           ("Ant obs 105 act 8, 3x256", 105, 8, (256, 256, 256), 256), ("Pendulum obs 3 act 1, 2x64", 3, 1, (64, 64), 256)):
+    row = []
+    for tiles in (False, True):
+        if tiles:
+            os.environ["DSACT_NO_CHAIN"] = "1"
+        torch.manual_seed(0)
+        alg = DSAC_V2_HIP(**hip_kwargs(O, A, hv, B))
+        os.environ.pop("DSACT_NO_CHAIN", None)
+        e = alg.engine
+        e.set_device_rng(1)
+        e.buffer_create(N)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        e.buffer_fill_device(0, torch.randn(N, O, device="cuda", generator=g), torch.rand(N, A, device="cuda", generator=g) - .5,
+                             torch.randn(N, device="cuda", generator=g), torch.randn(N, O, device="cuda", generator=g),
+                             (torch.rand(N, device="cuda", generator=g) < .05).float())
+        np.random.seed(1)
+        e.upload_index_table(np.random.randint(0, N, size=(64, B)))
+        e.graph_build(8)
+        e.time_steps(1, 400, use_graph=True)
+        ms = min(e.time_steps(1 + 400 * (k + 1), 2000, use_graph=True) for k in range(3))
+        row.append((e.chain_active, 2000.0 / ms * 1000.0, ms / 2000.0 * 1000.0))
+        e.sync()
+        e.close()
+    print("%-46s" % title + "".join("  | chains %-5s %8.0f steps/s %7.2f us" % r for r in row))
