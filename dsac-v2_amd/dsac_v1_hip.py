@@ -51,7 +51,15 @@ ALG_TIME_KEY = _v2.ALG_TIME_KEY
 def _check_supported(kwargs):
     _v2._check_supported(kwargs)   # MLP nets, or the CNN nets of example_train/dsacv1_cnn_carracing_offasync.py (round 4)
     if not _v2._conv_type(kwargs) and list(kwargs["value_hidden_sizes"]) != list(kwargs["policy_hidden_sizes"]):
-        raise NotImplementedError("DSAC_V1_HIP needs value_hidden_sizes == policy_hidden_sizes (unequal widths are built for DSAC_V2_HIP)")
+        # unequal lists run through the zero-padded storage of the row-slice chains only (dsact/layout.py ArenaLayout pad_to): same
+        # depth, widths <= 256, no sigmoid, a batch the chains take -- the tile-stage form of unequal widths is DSAC_V2_HIP's
+        hv, hp = list(kwargs["value_hidden_sizes"]), list(kwargs["policy_hidden_sizes"])
+        pad = DsactEngine._pad_width(hv, hp, int(kwargs["replay_batch_size"]), kwargs["obsv_dim"], algo="DSAC_V1",
+                                     value_act=_v2.ACTIVATIONS[kwargs.get("value_hidden_activation", "gelu")][0],
+                                     policy_act=_v2.ACTIVATIONS[kwargs.get("policy_hidden_activation", "gelu")][0])
+        if not (kwargs.get("hip_pad_widths", True) and pad and "replay_batch_size" in kwargs):
+            raise NotImplementedError("DSAC_V1_HIP takes value_hidden_sizes != policy_hidden_sizes only where the row-slice chains can "
+                                      "store them zero-padded (same depth, widths <= 256, batch a multiple of 16); got %s / %s" % (hv, hp))
     for key in ("value_output_activation", "policy_output_activation"):
         if kwargs.get(key, "linear") != "linear":
             raise NotImplementedError("DSAC_V1_HIP supports %s='linear' only (output activations are built for DSAC_V2_HIP)" % key)
@@ -86,8 +94,8 @@ class ApproxContainer(_v2.ApproxContainer):
             O = int(kwargs["obsv_dim"])
             self.q = _v2.HipActionValueDistri(O, A, hidden, va)
             self.q_target = copy.deepcopy(self.q)
-            self.policy = _v2.HipStochaPolicy(O, A, hidden, hi, lo, mn, mx, pa)
-            layout = ArenaLayout(O, A, hidden, n_critics=1)
+            self.policy = _v2.HipStochaPolicy(O, A, _v2._policy_hidden_sizes(kwargs) or hidden, hi, lo, mn, mx, pa)
+            layout = ArenaLayout(O, A, hidden, n_critics=1, policy_hidden=_v2._policy_hidden_sizes(kwargs))   # (attach: the engine's, maybe padded)
         self.policy_target = copy.deepcopy(self.policy)
         for net in (self.policy_target, self.q_target):
             for p in net.parameters():
@@ -153,7 +161,11 @@ class DSAC_V1_HIP(_v2.DSAC_V2_HIP):
             global_batch=kwargs.get("global_batch"), device=int(kwargs.get("hip_device", 0)),
             algo="DSAC_V1", td_bound=float(self.TD_bound), v1_bound=bool(self.bound),
             value_act=_v2.ACTIVATIONS[kwargs.get("value_hidden_activation", "gelu")][0],
-            policy_act=_v2.ACTIVATIONS[kwargs.get("policy_hidden_activation", "gelu")][0])
+            policy_act=_v2.ACTIVATIONS[kwargs.get("policy_hidden_activation", "gelu")][0],
+            policy_hidden=None if ct else _v2._policy_hidden_sizes(kwargs),
+            pad_widths=bool(kwargs.get("hip_pad_widths", True)))   # ragged / unequal widths on the chains (see DSAC_V2_HIP)
+        if not ct and _v2._policy_hidden_sizes(kwargs) and not self.engine.layout.pad_to:
+            raise NotImplementedError("DSAC_V1_HIP: the row-slice chains refused the padded shape of unequal value / policy widths")
         self.networks.attach(self.engine)
         register_engine(self.engine)
         if not kwargs.get("hip_host_act", True):   # (see DSAC_V2_HIP: host-side acting forward on / off)

@@ -61,7 +61,7 @@ class DsactEngine:
         the shape conditions of dsact_create's chain_ok (csrc/dsact_api.hip) + act(0) == 0 for both hidden activations"""
         ph = list(policy_hidden) if policy_hidden is not None else list(hidden)
         widths = list(hidden) + ph
-        if conv_type or algo != "DSAC_V2" or policy_std_type == "mlp_separated" or len(ph) != len(hidden) or len(hidden) > 4:
+        if conv_type or policy_std_type == "mlp_separated" or len(ph) != len(hidden) or len(hidden) > 4:
             return None
         if len(set(widths)) == 1 and widths[0] in (64, 128, 256):
             return None                                   # the chains take it as it is

@@ -23,7 +23,7 @@ from typing import Dict
 import numpy as np
 import torch
 
-from .dsact_oracle import _new_mlp_params, policy_forward, q_forward, tanh_gauss_rsample
+from .dsact_oracle import _new_mlp_params, pad_stored, policy_forward, q_forward, tanh_gauss_rsample
 
 V1_TB_KEYS = [  # dsac_v1.py:171-180, order preserved
     "DSAC/critic_avg_q-RL iter",
@@ -79,7 +79,12 @@ class DsacV1Oracle:
 
     def _new_pi_params(self):
         cfg = self.cfg
-        return _new_mlp_params([cfg["obs_dim"]] + list(cfg["hidden"]) + [2 * cfg["act_dim"]])
+        hid = list(cfg.get("policy_hidden") or cfg["hidden"])   # policy_hidden_sizes when they differ from value_hidden_sizes
+        return _new_mlp_params([cfg["obs_dim"]] + hid + [2 * cfg["act_dim"]])
+
+    def _arena(self, ts):
+        """a net's tensors as the HIP arena stores them (zero-padded hidden widths: oracle/dsact_oracle.py pad_stored)"""
+        return pad_stored(ts, self.cfg["pad_to"]) if self.cfg.get("pad_to") else ts
 
     def _pi(self, obs, params):
         return policy_forward(obs, params, self.cfg)
@@ -179,13 +184,13 @@ class DsacV1Oracle:
         return tb
 
     def flat_params(self):
-        ts = [t.detach().reshape(-1) for n in ("q", "policy") for t in self.p[n]]
+        ts = [t.reshape(-1) for n in ("q", "policy") for t in self._arena([t.detach() for t in self.p[n]])]
         return torch.cat(ts + [self.log_alpha.detach().reshape(1)])
 
     def flat_targets(self):
-        return torch.cat([t.detach().reshape(-1) for n in ("q_target", "policy_target") for t in self.p[n]])
+        return torch.cat([t.reshape(-1) for n in ("q_target", "policy_target") for t in self._arena([t.detach() for t in self.p[n]])])
 
     def flat_grads(self):
-        ts = [t.grad.detach().reshape(-1) for n in ("q", "policy") for t in self.p[n]]
+        ts = [t.reshape(-1) for n in ("q", "policy") for t in self._arena([t.grad.detach() for t in self.p[n]])]
         g_a = self.log_alpha.grad if self.log_alpha.grad is not None else torch.zeros(())
         return torch.cat(ts + [g_a.detach().reshape(1)])

@@ -241,6 +241,22 @@ def draw_noise(batch, act_dim, generator=None):
             "z_discarded": [z[0], z[1], z[4], z[5]]}
 
 
+def pad_stored(ps, W, n_tail=0):
+    """[W0, b0, W1, b1, ... (+ n_tail trailing tensors)] of an MLP -> the same list with every hidden layer W wide, zero padded:
+    the form the HIP arenas STORE when ragged / unequal widths ride the row-slice chains (dsac-v2_amd/dsact/layout.py, ArenaLayout
+    pad_to). Test infrastructure only: the flat views the parity tests compare arena against."""
+    ps = list(ps)
+    n_lin = (len(ps) - n_tail) // 2
+    for j in range(n_lin):
+        w, b = ps[2 * j], ps[2 * j + 1]
+        rows = W if j < n_lin - 1 else w.shape[0]
+        cols = w.shape[1] if j == 0 else W
+        wp = torch.zeros(rows, cols, dtype=w.dtype); wp[:w.shape[0], :w.shape[1]] = w
+        bp = torch.zeros(rows, dtype=b.dtype); bp[:b.shape[0]] = b
+        ps[2 * j], ps[2 * j + 1] = wp, bp
+    return ps
+
+
 class DsactOracle:
     """State + one-step semantics of DSAC_V2 (dsac_v2.py:65-347) on CPU fp32."""
 
@@ -571,17 +587,8 @@ class DsactOracle:
 
     def arena_order(self, n, ps):
         """per-parameter tensors of net n (in the order of self.p[n]) -> flat pieces in the HIP arena's order"""
-        W = self.cfg.get("pad_to")
-        if W:   # the arena stores every hidden layer W wide, zero padded (dsac-v2_amd/dsact/layout.py, ArenaLayout pad_to)
-            ps = list(ps)
-            n_lin = (len(ps) - (1 if (n.startswith("policy") and self._std_param) else 0)) // 2
-            for j in range(n_lin):
-                w, b = ps[2 * j], ps[2 * j + 1]
-                rows = W if j < n_lin - 1 else w.shape[0]
-                cols = w.shape[1] if j == 0 else W
-                wp = torch.zeros(rows, cols, dtype=w.dtype); wp[:w.shape[0], :w.shape[1]] = w
-                bp = torch.zeros(rows, dtype=b.dtype); bp[:b.shape[0]] = b
-                ps[2 * j], ps[2 * j + 1] = wp, bp
+        if self.cfg.get("pad_to"):
+            ps = pad_stored(ps, self.cfg["pad_to"], 1 if (n.startswith("policy") and self._std_param) else 0)
         if n.startswith("policy") and self._std_twin:
             # "mlp_separated": the arena's twin-trunk layout (dsac-v2_amd/dsact/layout.py, twin_mlp_views): layer 0 [W_mean ; W_ls],
             # hidden layers W_mean | W_ls, output layer the dense [[w_mean, 0], [0, w_ls]]; biases [b_mean ; b_ls]

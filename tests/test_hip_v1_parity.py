@@ -22,7 +22,9 @@ def make_pair(O, A, hid, B, act_limit=0.4, seed=0, init=None, td_bound=10.0, **o
                                    TD_bound=td_bound, **over))
     if init is not None:
         alg.networks.load_state_dict(init)
-    cfg = default_config(O, A, hid, act_limit=act_limit, TD_bound=td_bound, bound=over.get("bound", True))
+    cfg = default_config(O, A, hid, act_limit=act_limit, TD_bound=td_bound, bound=over.get("bound", True),
+                         policy_hidden=over.get("policy_hidden_sizes"))
+    cfg["pad_to"] = getattr(alg.engine.layout, "pad_to", None)   # stored widths of the HIP arenas: the oracle's FLAT views follow them
     orc = DsacV1Oracle(cfg, state_dict={k: v.cpu() for k, v in alg.networks.state_dict().items()})
     return alg, orc
 
@@ -146,6 +148,22 @@ def test_v1_large_batch_tiles_and_split_k():
 def test_v1_ragged_and_one_dim_action():
     run_case("v1 ragged O=11 A=3 (96,40) B=50", 11, 3, (96, 40), 50, steps=3)
     run_case("v1 O=3 A=1 (64,64) B=64", 3, 1, (64, 64), 64, steps=3, act_limit=2.0)
+
+
+def test_v1_ragged_and_unequal_widths_on_the_padded_chains():
+    """round 6: ragged widths, and value_hidden_sizes != policy_hidden_sizes of the same depth, stored zero-padded (dsact/layout.py
+    ArenaLayout pad_to) -- DSAC_V1 on the row-slice chains at shapes it ran on the tile stages (or refused) before"""
+    for O, A, hid, B, over in ((24, 6, (96, 40), 64, {}), (17, 6, (200, 200, 200), 256, {}), (24, 6, (64, 64), 64, {"policy_hidden_sizes": [32, 48]}),
+                               (11, 3, (128, 128), 128, {"policy_hidden_sizes": [256, 200]})):
+        alg, _ = make_pair(O, A, hid, B, hip_pad_widths=True, **over)
+        assert alg.engine.chain_active and alg.engine.layout.pad_to in (64, 128, 256)
+        alg.engine.close()
+        run_case("v1 padded O=%d A=%d %s B=%d %s" % (O, A, hid, B, over), O, A, hid, B, steps=3, hip_pad_widths=True, **over)
+    from dsac_v1_hip import DSAC_V1_HIP
+    with pytest.raises(NotImplementedError):     # another depth: no padded form; the tile-stage form of unequal lists is DSAC_V2_HIP's
+        DSAC_V1_HIP(**hip_kwargs(24, 6, (64, 64), 64, algorithm="DSAC_V1_HIP", TD_bound=10.0, hip_pad_widths=True, policy_hidden_sizes=[64]))
+    with pytest.raises(NotImplementedError):     # the exact layout was asked for
+        DSAC_V1_HIP(**hip_kwargs(24, 6, (64, 64), 64, algorithm="DSAC_V1_HIP", TD_bound=10.0, hip_pad_widths=False, policy_hidden_sizes=[32, 48]))
 
 
 def test_v1_local_update_surface_and_fused_equals_split():

@@ -252,9 +252,11 @@ def test_cnn_bit_exact_vs_live_reference(obs_shape, A, conv_type, B):
         assert all(torch.equal(sd[k], osd[k]) for k in sd)
 
 
-@pytest.mark.parametrize("O,A,hid,B,bound", [(11, 3, (64, 64), 32, True), (376, 17, (256, 256, 256), 64, True), (3, 1, (32, 32), 16, True),
-                                             (11, 3, (64, 64), 32, False)])
-def test_v1_bit_exact_vs_live_reference(O, A, hid, B, bound):
+@pytest.mark.parametrize("O,A,hid,B,bound,hp", [(11, 3, (64, 64), 32, True, None), (376, 17, (256, 256, 256), 64, True, None), (3, 1, (32, 32), 16, True, None),
+                                                (11, 3, (64, 64), 32, False, None),
+                                                # value_hidden_sizes != policy_hidden_sizes (round 6: DSAC_V1_HIP stores them zero-padded)
+                                                (24, 6, (64, 64), 64, True, (32, 48)), (11, 3, (128, 128), 32, True, (256, 200))])
+def test_v1_bit_exact_vs_live_reference(O, A, hid, B, bound, hp):
     """DSAC_V1 (reference dsac_v1.py) restated in oracle/dsac_v1_oracle.py -- both critic
     losses (`bound` True: dsac_v1.py:217-226, False: :227-228)."""
     import importlib
@@ -264,10 +266,10 @@ def test_v1_bit_exact_vs_live_reference(O, A, hid, B, bound):
     torch.set_num_threads(2)
     ref_loader.import_reference()
     v1 = importlib.import_module("dsac_v1")
-    kw = ref_loader.reference_kwargs(O, A, hid, algorithm="DSAC_V1", TD_bound=10, bound=bound)
+    kw = ref_loader.reference_kwargs(O, A, hid, algorithm="DSAC_V1", TD_bound=10, bound=bound, **({"policy_hidden_sizes": list(hp)} if hp else {}))
     torch.manual_seed(0)
     alg = v1.DSAC_V1(**kw)
-    cfg = default_config(O, A, hid, TD_bound=10, bound=bound)
+    cfg = default_config(O, A, hid, TD_bound=10, bound=bound, policy_hidden=list(hp) if hp else None)
     torch.manual_seed(0)
     same_seed = DsacV1Oracle(cfg)
     sd, osd = alg.networks.state_dict(), same_seed.state_dict()

@@ -38,7 +38,7 @@ def test_padded_layout_windows_and_the_padding_rule():
     assert P([96, 40], None, 50, 24) is None and P([96, 40], None, 64, 11) == 128               # a batch the chains refuse; any observation width
     assert P([96, 40], None, 64, 24, value_act=4) is None and P([96, 40], None, 64, 24, policy_act=4) is None   # sigmoid(0) != 0
     assert P([96, 40], [40], 64, 24) is None and P([96, 40], None, 64, 24, policy_std_type="mlp_separated") is None
-    assert P([96, 40], None, 64, 24, algo="DSAC_V1") is None
+    assert P([96, 40], None, 64, 24, algo="DSAC_V1") == 128                                      # DSAC_V1 too
 
 
 # ---- GPU ------------------------------------------------------------------------------------------------------------------
