@@ -75,6 +75,60 @@ def make_alg(hidden, device, seed=0, batch=B, v1=False):
     return DSAC_V2_HIP(**kw)
 
 
+def bench_shapes(device, steps=4000):
+    """Other shapes of the same update on the row-slice chains since round 6 (informational; NOT the headline workload): MuJoCo
+    observation widths that are no multiple of 4, ragged / unequal hidden widths stored zero-padded, each beside
+    the form rounds 1-5 ran it in (tile-stage kernels). Graph replays on a 100k-row synthetic ring, batch 256."""
+    import numpy as np
+    import torch
+    from dsac_v2_hip import DSAC_V2_HIP
+
+    cases = [("halfcheetah_walker2d obs17 act6 3x256", 17, 6, [256] * 3, None),
+             ("hopper obs11 act3 3x256", 11, 3, [256] * 3, None),
+             ("humanoid critics 3x256 policy 3x128", O, A, [256] * 3, [128] * 3),
+             ("humanoid 3x200", O, A, [200] * 3, None)]
+    out = []
+    N = 100_000
+    for name, o, a, hv, hp in cases:
+        row = {"shape": name}
+        for form in ("chains", "tile_stages"):
+            if form == "tile_stages":
+                os.environ["DSACT_NO_CHAIN"] = "1"
+            try:
+                torch.manual_seed(0)
+                alg = DSAC_V2_HIP(
+                    algorithm="DSAC_V2_HIP", obsv_dim=o, action_dim=a, action_type="continu", value_func_type="MLP", policy_func_type="MLP",
+                    value_hidden_sizes=list(hv), policy_hidden_sizes=list(hp or hv), value_hidden_activation="gelu",
+                    policy_hidden_activation="gelu", value_output_activation="linear", policy_output_activation="linear",
+                    policy_act_distribution="TanhGaussDistribution", policy_min_log_std=-20, policy_max_log_std=0.5,
+                    value_learning_rate=1e-4, policy_learning_rate=1e-4, alpha_learning_rate=3e-4, gamma=0.99, tau=0.005, auto_alpha=True,
+                    alpha=0.2, delay_update=2, cnn_shared=False, replay_batch_size=B, seed=1, hip_device=device,
+                    hip_pad_widths=form == "chains",
+                    action_high_limit=np.full((a,), 0.4, np.float32), action_low_limit=np.full((a,), -0.4, np.float32))
+            finally:
+                os.environ.pop("DSACT_NO_CHAIN", None)
+            e = alg.engine
+            e.set_device_rng(1)
+            e.buffer_create(N)
+            g = torch.Generator(device=e.device).manual_seed(1)
+            e.buffer_fill_device(0, torch.randn(N, o, device=e.device, generator=g), torch.rand(N, a, device=e.device, generator=g) * 0.8 - 0.4,
+                                 torch.randn(N, device=e.device, generator=g), torch.randn(N, o, device=e.device, generator=g),
+                                 (torch.rand(N, device=e.device, generator=g) < 0.01).float())
+            np.random.seed(1)
+            e.upload_index_table(np.random.randint(0, N, size=(64, B)))
+            e.graph_build(8)
+            e.time_steps(0, 400, use_graph=True)
+            ms = min(e.time_steps(400 + steps * k, steps, use_graph=True) for k in range(2))
+            assert e.chain_active == (form == "chains")
+            row[form] = {"value": 1000.0 * steps / ms, "unit": "steps/s", "us_per_step": 1000.0 * ms / steps}
+            if form == "chains":
+                row["stored_width"] = e.layout.pad_to or hv[0]
+            e.sync()
+            e.close()
+        out.append(row)
+    return out
+
+
 def fill_replay(engine, n_rows, seed):
     """synthetic ring per SURVEY.md 8(d): obs,obs2 ~ N(0,1); act ~ U(-.4,.4); rew ~ N(0,1); done ~ Bern(.01);
     generated on the device in chunks (3.09 GB at 1M rows never crosses PCIe)."""
@@ -1123,6 +1177,11 @@ def main():
             del alg1
         except Exception as ex:
             out["dsac_v1_error"] = repr(ex)
+    if rank == 0 and not use_dp and not args.no_alt and args.batch == B:
+        try:
+            out["shapes"] = bench_shapes(local)
+        except Exception as ex:  # informational leg
+            out["shapes_error"] = repr(ex)
     if rank == 0 and not args.no_cpu_baseline and args.batch == B:
         try:
             out["cpu_baseline"] = cpu_baseline(hidden)

@@ -107,8 +107,10 @@ class HipReplayBuffer:
 
         if batch_size != self.engine.batch:
             raise ValueError("batch_size %d != the engine's minibatch rows %d" % (batch_size, self.engine.batch))
-        size = self.size
-        idxs = np.stack([np.random.randint(0, size, size=batch_size) for _ in range(int(n))])
+        # ONE call of shape (n, batch): the legacy RandomState fills int64 draws element by element with no buffering between
+        # calls, so this is the stream of n calls of `batch` draws (values AND final generator state; tests/test_host_side.py
+        # pins it, the trainer-trajectory fixtures compare every index with the reference loop's) at a quarter of the host time
+        idxs = np.random.randint(0, self.size, size=(int(n), batch_size))
         return HipBatchGroup(self.engine, idxs)
 
     def sample_batch(self, batch_size: int):

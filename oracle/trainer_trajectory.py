@@ -103,7 +103,10 @@ class Hooks:
     def __enter__(self):
         def randint(*a, **k):
             out = self._randint(*a, **k)
-            self.indices.append(np.asarray(out).astype(np.int64).tolist())
+            arr = np.asarray(out).astype(np.int64)
+            # (HipReplayBuffer.sample_batches draws the rows of a whole group with ONE call of shape (n, batch): the same stream, in
+            #  the same order, as the reference's n calls -- recorded per minibatch like them)
+            self.indices.extend(arr.tolist() if arr.ndim == 2 else [arr.tolist()])
             return out
 
         def save(obj, f, *a, **k):

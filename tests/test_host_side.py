@@ -276,3 +276,21 @@ def test_hip_batch_detects_rows_overwritten_after_sampling():
     assert tok2._overwritten() == 0
     e2.fill_epoch += 1
     assert tok2._overwritten() == 2
+
+
+def test_one_vectorised_index_draw_is_the_stream_of_n_reference_draws():
+    """HipReplayBuffer.sample_batches draws a group's rows with one np.random.randint(0, size, (n, batch)): values and the
+    generator state afterwards must be those of n reference-style calls (training/replay_buffer.py:86), for ring sizes on both
+    sides of 2**31 (the masked-rejection path changes width there)"""
+    import numpy as np
+
+    for size in (7, 1000, 10 ** 6, 10 ** 7, 2 ** 31 - 1, 2 ** 31 + 5, 2 ** 33):
+        for n, b in ((8, 256), (3, 50), (1, 16)):
+            np.random.seed(11)
+            ref = np.stack([np.random.randint(0, size, size=b) for _ in range(n)])
+            st_ref = np.random.get_state()
+            np.random.seed(11)
+            one = np.random.randint(0, size, size=(n, b))
+            st_one = np.random.get_state()
+            assert np.array_equal(ref, one) and ref.dtype == one.dtype
+            assert np.array_equal(st_ref[1], st_one[1]) and st_ref[2:] == st_one[2:]
