@@ -703,6 +703,10 @@ class DSAC_V2_HIP:
         if [(k, tuple(shape)) for k, shape in sd["signature"]] != sig:
             raise ValueError("optimizer sidecar belongs to another network layout")
         e = self.engine
+        if sd["adam_m"].numel() != e.adam_m.numel():
+            raise ValueError("optimizer sidecar holds %d floats per moment arena, this engine stores %d: the arenas were laid out "
+                             "differently (zero-padded hidden widths on one side only? see the `hip_pad_widths` kwarg)"
+                             % (sd["adam_m"].numel(), e.adam_m.numel()))
         e.sync()
         e.adam_m.copy_(sd["adam_m"].to(e.adam_m.device))
         e.adam_v.copy_(sd["adam_v"].to(e.adam_v.device))

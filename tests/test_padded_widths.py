@@ -145,6 +145,10 @@ def test_padding_stays_zero_through_graph_replays_checkpoints_and_acting(tmp_pat
         got = np.concatenate([e1.policy_forward(obs[i:i + 1]) for i in range(3)])
         assert e1.debug_get("act_host") == float(mode)
         np.testing.assert_allclose(got, want, atol=2e-5, rtol=1e-5)
+    # the optimiser sidecar holds the moment ARENAS: one written by the other layout is refused by name, its own round-trips
+    with pytest.raises(ValueError, match="hip_pad_widths"):
+        algs["graph"].load_optimizer_state_dict(algs["exact"].optimizer_state_dict())
+    algs["graph"].load_optimizer_state_dict(algs["graph"].optimizer_state_dict())
     # a checkpoint written by the exact layout loads into the padded one (and back): windows only, the padding is untouched
     algs["graph"].networks.load_state_dict({k: v.cpu() for k, v in sx.items()})
     e1.sync()
