@@ -179,6 +179,7 @@ struct dsact_handle {
   int env_conv_dw_nkt = 0;
   int conv_dw_nkt_l[kMaxConv] = {1, 1, 1, 1, 1, 1};   // k-tiles per k_conv_dw workgroup, per layer (DSACT_CONV_DW_NKT_L=a,b,..; DSACT_CONV_DW_NKT: all)
   int env_conv_fwd64_min = 256;         // DSACT_CONV_FWD64_MIN: fewest 64 x 64 tiles a conv forward launch must have to use them
+  bool env_no_dcol_ident = false;       // DSACT_NO_DCOL_IDENT: keep dCol + col2im on the layer whose col2im is the identity (round 6 fuses the mask into the product)
   int env_dcol64_min_m = 256;           // DSACT_DCOL64_MIN_M: fewest rows of a dCol product for the 64 x 64 stage tiles (layer 5 at batch 256: 11.4 -> 8.9 us)
   bool env_no_conv_fwd32x64 = false;    // DSACT_NO_CONV_FWD32X64
   int env_conv_dw_reg = 0;              // DSACT_CONV_DW_REG: bit mask of the (narrow) layers whose weight gradient runs on register tiles (k_conv_dw_reg)
@@ -953,9 +954,12 @@ int build_tasks(dsact_handle* h) {
     h->actf.push_back(s);
   }
   // CNN nets: gradient w.r.t. the conv features, dFeat = dZ0 . W0[:, :F]  (plain store)
-  h->dfeat_q = fresh("dfeat_q", 2);
-  h->dfeat_pi = fresh("dfeat_pi", 2);
-  h->dfeat_all = fresh("dfeat", 2);
+  // (round 6: a conv stack that ends in ONE pixel -- type_2 -- has features == last-layer activations in the same order, so the
+  //  ReLU mask of k_feat_bwd is applied in this product's epilogue and the result lands in the last layer's dY: kind 3, one launch less)
+  const bool feat_ident = h->cnn && h->cP == 1 && !h->env_no_dcol_ident;
+  h->dfeat_q = fresh("dfeat_q", feat_ident ? 3 : 2);
+  h->dfeat_pi = fresh("dfeat_pi", feat_ident ? 3 : 2);
+  h->dfeat_all = fresh("dfeat", feat_ident ? 3 : 2);
   if (h->cnn) {
     for (int ch : {C_Q1C, C_Q2C, C_PI}) {
       if (ch == C_Q2C && h->nq == 1) continue;   // one critic (DSAC_V1)
@@ -970,8 +974,10 @@ int build_tasks(dsact_handle* h) {
       else if (ch == C_PI) { t.Q = net_params(h, net) + d.w_off[0]; t.ldq = d.in[0]; }
       else if (h->use_w1p) { t.Q = h->W1p[ch == C_Q1C ? 0 : 1]; t.ldq = h->ldx; }  // this step's pre-update copy
       else { t.Q = net_params(h, net) + d.w_off[0]; t.ldq = d.in[0]; }              // (dfeat_q runs before the critics' update)
-      t.C0 = h->dfeat[ch == C_PI ? h->nq : ch - C_Q1C]; t.ldc = h->F;   // (stack numbering: q x nq, then the policy)
+      const int stack = ch == C_PI ? h->nq : ch - C_Q1C;               // (stack numbering: q x nq, then the policy)
+      t.C0 = h->dfeat[stack]; t.ldc = h->F;
       t.M = B; t.N = h->F; t.K = d.out[0];
+      if (feat_ident) { t.C0 = h->cdy[stack][h->n_conv - 1]; t.aux = h->cact[stack][h->n_conv - 1]; t.ldaux = h->F; t.act = MULG_RELU_MASK; }
       stage_add(ch == C_PI ? h->dfeat_pi : h->dfeat_q, t);
       stage_add(h->dfeat_all, t);
     }
@@ -1090,7 +1096,7 @@ int run_stage(dsact_handle* h, const Stage& s0, int x0 = 0, int x1 = 0, bool fus
   s.args.fo = fused_opt(h, fused);
   // large batches: 64x64 tiles (k_stage64) when every problem of the stage allows it and nothing rides along
   // (kind 2, plain store: the conv data gradient's dCol products -- many 32 x 32 tiles with a contraction of only 64-256)
-  if (s.args.n_extra == 0 && (s.kind == 0 || s.kind == 1 || (s.kind == 2 && s.name.compare(0, 9, "conv_dcol") == 0))) {   // (dfeat on 48 such tiles: 14.3 vs 12.3 us)
+  if (s.args.n_extra == 0 && (s.kind == 0 || s.kind == 1 || (s.kind >= 2 && s.name.compare(0, 9, "conv_dcol") == 0))) {   // (dfeat on 48 such tiles: 14.3 vs 12.3 us)
     bool ok = true;
     int blocks = 0;
     StageArgs a64 = s.args;
@@ -1101,7 +1107,7 @@ int run_stage(dsact_handle* h, const Stage& s0, int x0 = 0, int x1 = 0, bool fus
         const int K4 = (K + 3) & ~3;
         if (s.kind == 0 && g.ldp >= K4 && g.ldq >= K4) K = K4; else ok = false;
       }
-      ok = ok && g.M >= (s.kind == 2 ? h->env_dcol64_min_m : 512) && g.M % 64 == 0 && g.N % 64 == 0;
+      ok = ok && g.M >= (s.kind >= 2 ? h->env_dcol64_min_m : 512) && g.M % 64 == 0 && g.N % 64 == 0;
       g.K = K;
       g.tiles_n = g.N / 64;
       blocks += (g.M / 64) * g.tiles_n;
@@ -1130,7 +1136,7 @@ int run_stage(dsact_handle* h, const Stage& s0, int x0 = 0, int x1 = 0, bool fus
     return launch(h, s.name.c_str(), k_stage<false, false, EPI_GELU>, dim3(grid), dim3(kThreads), lds, s.args);
   if (s.kind == 2)
     return launch(h, s.name.c_str(), k_stage<false, true, EPI_STORE>, dim3(grid), dim3(kThreads), lds, s.args);
-  return launch(h, s.name.c_str(), k_stage<false, true, EPI_MULG>, dim3(grid), dim3(kThreads), lds, s.args);
+  return launch(h, s.name.c_str(), k_stage<false, true, EPI_MULG>, dim3(grid), dim3(kThreads), lds, s.args);   // kinds 1 and 3
 }
 
 // weight-gradient tiles [x0, x1) as their own launch; `fused`: Adam/Polyak in the tile epilogue;
@@ -1308,7 +1314,7 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
   const int B = h->B;
   const int last = h->n_conv - 1;
   auto S = [st_lo](int st) { return st_lo + st; };
-  {
+  if (!(h->cP == 1 && !h->env_no_dcol_ident)) {   // (one-pixel stacks: the dfeat product wrote the masked dY itself, build_tasks)
     FeatBwdArgs f;
     memset(&f, 0, sizeof(f));
     for (int st = 0; st < n_st; ++st) { f.dfeat[st] = h->dfeat[S(st)]; f.act[st] = h->cact[S(st)][last]; f.dy[st] = h->cdy[S(st)][last]; }
@@ -1406,8 +1412,13 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
       }
     } else if (j > 0) {
       // dCol[m][k] = sum_co dY[m][co] W[co][k]: dense KC x MC product, plain store
+      // A layer with ONE output pixel whose kernel covers its whole input (type_2's last layer: 3 x 3 x 128 -> 1 x 1 x 256): every
+      // input pixel receives exactly one column of dCol, in dCol's own order -- col2im is the identity, and the ReLU mask of the
+      // layer's input is applied in the product's epilogue (MULG_RELU_MASK) straight into the previous layer's dY: one launch
+      // less, bit-identical values (round 6)
+      const bool ident = g.OH == 1 && g.OW == 1 && g.H == g.KS && g.W == g.KS && !h->env_no_dcol_ident;
       Stage s;
-      s.name = "conv_dcol" + sfx; s.kind = 2; s.n_blocks = 0;
+      s.name = "conv_dcol" + sfx; s.kind = ident ? 3 : 2; s.n_blocks = 0;
       memset(&s.args, 0, sizeof(s.args));
       for (int st = 0; st < n_st; ++st) {
         const int net = stack_net(h, S(st));
@@ -1418,9 +1429,11 @@ int enqueue_conv_backward(dsact_handle* h, int n_st, bool fused, int st_lo = 0) 
         t.Q = net_params(h, net) + d.cw_off[j]; t.ldq = g.K;
         t.C0 = h->dcol[S(st)]; t.ldc = g.K;
         t.M = M; t.N = g.K; t.K = g.Cout;
+        if (ident) { t.C0 = h->cdy[S(st)][j - 1]; t.aux = h->cact[S(st)][j - 1]; t.ldaux = g.K; t.act = MULG_RELU_MASK; }
         stage_add(s, t);
       }
       TRY(run_stage(h, s));
+      if (ident) { if (fork && j > 0) HIPCHK(h, hipEventRecord(h->ev_conv[j - 1], h->stream)); continue; }
       Col2imArgs c;
       memset(&c, 0, sizeof(c));
       c.g = g; c.n_prob = n_st; c.B = B;
@@ -3316,6 +3329,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (const char* v = getenv("DSACT_CONV_DW_REG_WGS")) h->env_conv_dw_reg_wgs = atoi(v) > 0 ? atoi(v) : 512;
   if (const char* v = getenv("DSACT_CONV_FWD64_MIN")) h->env_conv_fwd64_min = atoi(v);
   if (const char* v = getenv("DSACT_DCOL64_MIN_M")) h->env_dcol64_min_m = atoi(v);
+  h->env_no_dcol_ident = getenv("DSACT_NO_DCOL_IDENT") != nullptr;
   if (const char* v = getenv("DSACT_CHAIN_RG")) h->env_chain_rg = atoi(v) == 1 ? 1 : atoi(v) == 4 ? 4 : 2;
   h->dw_chunks = (h->B > 448 && h->B % 256 == 0 && getenv("DSACT_NO_SPLITK") == nullptr) ? h->B / 256 : 1;   // (chain path: below)
   h->dw_part_stride = (h->n_online + 2 + 63) & ~(size_t)63;
@@ -4994,6 +5008,14 @@ int dsact_debug_get(const dsact_handle* h, const char* name, double* value) {
   if (!h || !name || !value) return DSACT_E_INVALID;
   if (!strcmp(name, "fwd_merge")) *value = h->fwd_merge ? 1.0 : 0.0;
   else if (!strcmp(name, "pi_merge")) *value = h->pi_merge ? 1.0 : 0.0;
+  else if (!strcmp(name, "dcol_ident")) {   // conv layers whose data gradient is one masked product (identity col2im, enqueue_conv_backward)
+    int n = 0;
+    for (int j = 1; j < h->n_conv; ++j) {
+      const ConvGeom& g = h->cg[j];
+      if (g.OH == 1 && g.OW == 1 && g.H == g.KS && g.W == g.KS && !h->env_no_dcol_ident && g.Cin > 16) ++n;
+    }
+    *value = (double)n;
+  }
   else if (!strcmp(name, "act_launch_us")) *value = h->act_launch_us;
   else if (!strcmp(name, "act_host")) *value = act_host_ok(h) ? 1.0 : 0.0;
   else if (!strcmp(name, "act_host_us")) *value = h->act_host_us;

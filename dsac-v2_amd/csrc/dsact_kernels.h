@@ -620,6 +620,9 @@ constexpr int MC_LD = TM + 4;   // 36 floats
 constexpr int TILE_LDS = BK * MC_LD;  // 2304 floats >= 32*KC_LD (2176)
 
 enum : int { EPI_GELU = 0, EPI_MULG = 1, EPI_STORE = 2 };
+// GemmProb::act of an EPI_MULG problem: aux holds post-ReLU activations a, the product is multiplied by (a > 0) -- the conv data
+// gradient of a layer whose col2im is the identity (round 6: one output pixel, kernel = the whole input: type_2's last layer)
+enum : int { MULG_RELU_MASK = 1 };
 
 
 // Operand fetch: ONE unconditional dwordx4 per lane and slot (addresses clamped into the matrix,
@@ -710,7 +713,7 @@ __device__ __forceinline__ void tile_mma(const float* ps, const float* qs, int p
 struct GemmProb {
   const float* P; const float* Q;
   float* C0; float* C1;
-  const float* aux;     // EPI_GELU: bias[N]; EPI_MULG: G[M x ldaux]
+  const float* aux;     // EPI_GELU: bias[N]; EPI_MULG: G[M x ldaux] (act == MULG_RELU_MASK: post-ReLU activations whose SIGN is the factor)
   int ldp, ldq, ldc, ldaux;
   int M, N, K;
   int tiles_n;          // n-tiles per m-tile row
@@ -915,10 +918,14 @@ __device__ __forceinline__ void run_tile(const GemmProb& t, int m0, int n0, floa
     else for (int e = 0; e < 4 && n + e < t.N; ++e) { c0[e] = h[e]; c1[e] = gd[e]; }
   } else if (EPI == EPI_MULG) {
     float* c0 = t.C0 + (size_t)m * t.ldc + n;
-    if (full) *(f32x4u*)c0 = acc * epv;
-    else {
+    const bool mask = t.act == MULG_RELU_MASK;   // (a select, not a product: a masked element is +0 like col2im's / k_feat_bwd's)
+    if (full) {
+      f32x4 o = acc * epv;
+      if (mask) for (int e = 0; e < 4; ++e) o[e] = epv[e] > 0.f ? acc[e] : 0.f;
+      *(f32x4u*)c0 = o;
+    } else {
       const float* gp = t.aux + (size_t)m * t.ldaux + n;
-      for (int e = 0; e < 4 && n + e < t.N; ++e) c0[e] = acc[e] * gp[e];
+      for (int e = 0; e < 4 && n + e < t.N; ++e) c0[e] = mask ? (gp[e] > 0.f ? acc[e] : 0.f) : acc[e] * gp[e];
     }
   } else {
     float* c0 = t.C0 + (size_t)m * t.ldc + n;
@@ -1108,7 +1115,9 @@ __device__ __forceinline__ void run_tile64(const GemmProb& t, int m0, int n0, fl
       *(f32x4u*)c0 = hv;
       *(f32x4u*)(t.C1 + (size_t)m * t.ldc + n) = gd;
     } else if (EPI == EPI_MULG) {
-      *(f32x4u*)c0 = acc[mb] * epv[mb];
+      f32x4 o = acc[mb] * epv[mb];
+      if (t.act == MULG_RELU_MASK) for (int e = 0; e < 4; ++e) o[e] = epv[mb][e] > 0.f ? acc[mb][e] : 0.f;   // (a select: +0 where masked)
+      *(f32x4u*)c0 = o;
     } else {
       *(f32x4u*)c0 = acc[mb];
     }

@@ -237,6 +237,27 @@ def test_cnn_fused_step_equals_split_path(B, steps):
         assert torch.equal(s1[k].cpu(), s2[k].cpu()), k
 
 
+@pytest.mark.parametrize("B", [16, 256])
+def test_cnn_identity_col2im_layer_fused_equals_dcol_plus_col2im(B, monkeypatch):
+    """type_2's last conv layer has one output pixel and a kernel as large as its input: col2im is the identity there, and round 6
+    applies the ReLU mask in the dCol product's epilogue, straight into the previous layer's dY (csrc/dsact_kernels.h
+    MULG_RELU_MASK). Against the two-launch form (DSACT_NO_DCOL_IDENT) every parameter must agree bit for bit."""
+    nets = []
+    for two_launch in (False, True):
+        if two_launch:
+            monkeypatch.setenv("DSACT_NO_DCOL_IDENT", "1")
+        a, _, cfg = make_pair((3, 96, 96), 3, "type_2", B, seed=3)
+        monkeypatch.delenv("DSACT_NO_DCOL_IDENT", raising=False)
+        for it in range(3):
+            d = synth_image_batch(cfg, B, seed=10 + it)
+            torch.manual_seed(50 + it)
+            a.local_update(d, it)
+        assert a.engine.debug_get("dcol_ident") == (0.0 if two_launch else 1.0)
+        nets.append(a.networks.state_dict())
+    for k in nets[0]:
+        assert torch.equal(nets[0][k].cpu(), nets[1][k].cpu()), k
+
+
 def test_cnn_replay_rows_bit_exact_and_policy_forward():
     from training.hip_replay_buffer import HipReplayBuffer
 
