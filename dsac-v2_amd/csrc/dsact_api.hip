@@ -1189,6 +1189,17 @@ int conv_fwd_grid(int n_items) { return n_items < 1024 ? n_items : 1024; }
 
 int enqueue_conv_forward(dsact_handle* h) {
   const int B = h->B;
+  bool feat_direct = false;   // the last layer's kernel wrote the trunks' feature rows itself (one-pixel stacks on k_conv_fwd64)
+  // (round 6) a stack that ends in ONE pixel: features == last-layer activations, in the same order
+  auto feat_rows = [&](ConvStageArgs& a, int j) {
+    if (j != h->n_conv - 1 || h->cP != 1 || h->env_no_dcol_ident) return;
+    for (int q = 0; q < a.n_prob; ++q) {     // (one group per stack at every layer but the first)
+      a.p[q].feat[0] = h->Xc[stack_chain(h, q)];
+      a.p[q].feat[1] = q < h->nq ? h->Xc[C_Q1P + q] : nullptr;   // q(obs, new_act) shares q(obs, act)'s features
+      a.p[q].ldf = h->ldx;
+    }
+    feat_direct = true;
+  };
   for (int j = 0; j < h->n_conv; ++j) {
     const ConvGeom& g = h->cg[j];
     ConvStageArgs a;
@@ -1243,6 +1254,7 @@ int enqueue_conv_forward(dsact_handle* h) {
       int it64 = 0;
       for (int q = 0; q < a.n_prob; ++q) { it64 += (M / 64) * (g.Cout / 64); a.p[q].item_end = it64; a.p[q].tiles_n = g.Cout / 64; }
       a.n_items = it64;
+      feat_rows(a, j);
       TRY(launch(h, name.c_str(), k_conv_fwd64<2>, dim3(it64), dim3(kThreads64), tile64_lds_bytes(), a));
       continue;
     }
@@ -1251,11 +1263,13 @@ int enqueue_conv_forward(dsact_handle* h) {
       int it = 0;
       for (int q = 0; q < a.n_prob; ++q) { it += (M / 32) * (g.Cout / 64); a.p[q].item_end = it; a.p[q].tiles_n = g.Cout / 64; }
       a.n_items = it;
+      feat_rows(a, j);
       TRY(launch(h, name.c_str(), k_conv_fwd64<1>, dim3(it), dim3(kThreads64), tile64_lds_bytes(), a));
       continue;
     }
     TRY(launch(h, name.c_str(), k_conv_fwd, dim3(conv_fwd_grid(items)), dim3(kThreads), 0, a));
   }
+  if (feat_direct) return DSACT_OK;
   FeatArgs f;
   memset(&f, 0, sizeof(f));
   const int last = h->n_conv - 1;

@@ -60,6 +60,8 @@ struct ConvGroup {
   const float* w[3];     // [Cout][K] each
   const float* bias[3];
   float* out[3];         // [M][Cout] each
+  float* feat[2];        // k_conv_fwd64, last layer of a stack that ends in ONE pixel (round 6): the rows are the feature rows of the
+  int ldf;               // MLP trunks too -- also stored at feat[i] + m * ldf (i = 1: the second chain on the same features), or nullptr
   int n_sub;
   int M;
   int tiles_n;           // ceil(n_sub*Cout / 32)
@@ -258,6 +260,8 @@ __global__ void __launch_bounds__(kThreads64) k_conv_fwd64(ConvStageArgs s) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
     *(f32x4u*)(t.out[0] + (size_t)m * g.Cout + n) = o;
+    if (t.feat[0]) *(f32x4u*)(t.feat[0] + (size_t)m * t.ldf + n) = o;   // (uniform per group: what k_feat_scatter did for P == 1)
+    if (t.feat[1]) *(f32x4u*)(t.feat[1] + (size_t)m * t.ldf + n) = o;
   }
 }
 
