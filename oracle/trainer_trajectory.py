@@ -70,6 +70,9 @@ VARIANTS = {
     "std_sep_si2": dict(sample_interval=2, policy_std_type="mlp_separated"),
     # value_hidden_sizes / policy_hidden_sizes of different widths AND depth (utils/common_utils.py:59-62 reads the lists per key)
     "depth_si2": dict(sample_interval=2, policy_hidden_sizes=[48, 32, 40]),
+    # ragged AND unequal widths of the same depth: DSAC_V2_HIP stores them zero-padded to 128 and runs the row-slice chains + the
+    # pipelined graph (round 6) -- sampler, evaluator and checkpoints see the reference's shapes through windows of the arenas
+    "ragged_si2": dict(sample_interval=2, value_hidden_sizes=[96, 40], policy_hidden_sizes=[40, 72]),
     # policy_act_distribution = "GaussDistribution" (utils/act_distribution_cls.py:82-115): sampler, evaluator (mode() clamps the
     # mean) and the update without tanh squashing
     "gauss_si2": dict(sample_interval=2, policy_act_distribution="GaussDistribution"),

@@ -280,6 +280,10 @@ def test_hip_stack_follows_the_reference_trajectory(tmp_path, variant):
         assert list(sd.keys())[0] == "log_alpha" and len(sd) == 41 + 2 * 6 and "policy.policy.0.weight" not in sd
         assert tuple(sd["policy.log_std.4.weight"].shape) == (kw["action_dim"], kw["policy_hidden_sizes"][-1]) and "policy_target.mean.0.bias" in sd
         return
+    if variant == "ragged_si2":      # (96, 40) / (40, 72): stored 128 wide, on the chains; the checkpoint holds the reference's shapes
+        assert alg.engine.layout.pad_to == 128 and alg.engine.chain_active and alg.engine.debug_get("pipe_graph") == 1.0
+        assert tuple(sd["q1.q.2.weight"].shape) == (40, 96) and tuple(sd["policy.policy.2.weight"].shape) == (72, 40) and len(sd) == 41
+        return
     if len(kw["policy_hidden_sizes"]) != len(kw["value_hidden_sizes"]):   # each family with its own layer count
         n_lin = 4 * (len(kw["value_hidden_sizes"]) + 1) + 2 * (len(kw["policy_hidden_sizes"]) + 1)
         assert list(sd.keys())[0] == "log_alpha" and len(sd) == 1 + 4 + 2 * n_lin
