@@ -135,6 +135,7 @@ struct dsact_handle {
   bool use_w1p = true;   // false for very wide first layers: copying them every step costs more than unaligned rows
   float* dout[4];
   float *dout_pi, *d_new_act;
+  float* qdmean[2] = {nullptr, nullptr}; float* pi_dact = nullptr;   // GELU output layers: the heads' stored d y / d z (carve)
   float* W1aT[2];  // transposed zero-padded action columns of q1 / q2's first layer  [32][w0]
   float *part_loss, *part_heads, *stats, *ones, *std_sums;
   long long* timeline;  // [512][8] stamps of the stage named by DSACT_TIMELINE_STAGE (instrumented builds)
@@ -252,6 +253,7 @@ struct dsact_handle {
   int env_fat_rt = 0;                   // DSACT_FAT_RT=1|2: force the rows per fat workgroup (16 / 32)
   int cRG = 2;                          // row groups of 4 per chain workgroup (8 rows) when 4-row workgroups would oversubscribe the CUs
   int env_chain_rg = 0;                 // DSACT_CHAIN_RG=1|2|4: force
+  bool env_no_fat_stage = false;        // DSACT_NO_FAT_STAGE: the throughput-regime forward reads its first layer's rows from global memory
   bool rg4_ok = false;                  // 16-row chain workgroups fit (LDS) and divide the batch
   int n_slices = 0;
   char* pk_ws = nullptr;                // the fragment-major copies
@@ -577,6 +579,9 @@ void carve(dsact_handle* h, Carver& c) {
   for (int i = 0; i < 4; ++i) h->dout[i] = c.take<float>(B * 2);
   h->dout_pi = c.take<float>(B * 2 * A);
   h->d_new_act = c.take<float>(B * A);
+  // GELU output layers (tile-stage kernels only): d y / d z of the heads that are differentiated later
+  for (int i = 0; i < 2; ++i) h->qdmean[i] = h->cfg.value_out_act == OUT_ACT_GELU ? c.take<float>(B) : nullptr;
+  h->pi_dact = h->cfg.policy_out_act == OUT_ACT_GELU ? c.take<float>(B * 2 * A) : nullptr;
   h->W1aT[0] = c.take<float>((size_t)32 * h->w[0]);
   h->W1aT[1] = c.take<float>((size_t)32 * h->w[0]);
   h->part_loss = c.take<float>(B * kLossPart);
@@ -2033,8 +2038,12 @@ int launch_chain_fwd(dsact_handle* h, const char* name, FwdArgs& a) {
   if (h->fat) {
     const int rt = fat_rt(h, a.n_units);
     fill_fwd_common(h, a, 4 * rt, name);
+    // the slice's input rows staged in LDS (round 6) where they fit the default 64 KB of dynamic LDS; else (very wide
+    // observations) the first layer reads them from global memory as in rounds 3-5. DSACT_NO_FAT_STAGE: the A/B switch
+    size_t lds = (size_t)fat_lds(h->cW, 16 * rt, 0, 16 * (a.s_obs + a.s_act)).total * sizeof(float);
+    a.x0_lds = !h->env_no_fat_stage && lds <= 64 * 1024;
+    if (!a.x0_lds) lds = (size_t)fat_lds(h->cW, 16 * rt, 0).total * sizeof(float);
     const int grid = a.n_units * a.u[0].n_slices;
-    const size_t lds = (size_t)fat_lds(h->cW, 16 * rt, 0).total * sizeof(float);
     if (a.u[0].part_heads) h->n_heads_parts = a.u[0].n_slices;
 #define CALL_FF(N, T) return launch(h, name, k_fat_fwd<N, T>, dim3(grid), dim3(64 * N), lds, a)
 #define CALL_FFG(N, T) return launch(h, name, k_fat_fwd<N, T, true>, dim3(grid), dim3(64 * N), lds, a)
@@ -2809,6 +2818,7 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
     a.part_heads = h->part_heads; a.act_scale = h->act_scale; a.act_center = h->act_center;
     a.lo_ls = h->cfg.min_log_std; a.hi_ls = h->cfg.max_log_std;
     a.q_out_act = h->cfg.value_out_act; a.pi_out_act = h->cfg.policy_out_act; a.pi_out_n = h->cfg.policy_std_param ? A : 2 * A;
+    a.qdmean[0] = h->qdmean[0]; a.qdmean[1] = h->qdmean[1]; a.pi_dact = h->pi_dact;
     a.timeline = tl_for(h, "heads");
 #define CALL_HEADS(N) TRY(launch(h, "heads", k_heads<N>, dim3(h->n_heads_wg, n_heads), dim3(kThreads), 0, a))
     NCH_DISPATCH(a.W, CALL_HEADS);
@@ -2878,6 +2888,7 @@ int enqueue_grads(dsact_handle* h, bool actor_backward, bool fused, int phase = 
     a.std_sums = (h->use_std_sums || h->auto_std_sums) ? h->std_sums : nullptr;
     a.auto_alpha = h->cfg.auto_alpha; a.alpha_fixed = h->cfg.alpha_fixed; a.gamma = h->cfg.gamma; a.tau_b = h->cfg.tau_b; a.one_minus_tau_b = (float)(1.0 - h->cfg.tau_b);
     a.q_out_act = h->cfg.value_out_act;
+    a.qdmean[0] = h->qdmean[0]; a.qdmean[1] = h->qdmean[1];
     a.timeline = tl_for(h, "loss");
     if (ride) a.ride = *ride;
     a.ride.n_loss_blocks = h->n_loss_wg;
@@ -2943,6 +2954,7 @@ actor_part:
     a.part_loss = h->part_loss; a.n_part = B; a.target_entropy = -(float)A;
     a.grad_log_alpha = h->grads + h->n_online - 1;
     a.pi_out_act = h->cfg.policy_out_act; a.pi_out_n = h->cfg.policy_std_param ? A : 2 * A;
+    a.pi_dact = h->pi_dact;
     a.timeline = tl_for(h, "heads_bwd");
     a.n_row_blocks = (B + 3) / 4;
     a.extra = h->d_tiles; a.n_extra = 0;
@@ -3225,7 +3237,8 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (cfg->policy_twin && (cfg->conv_type != DSACT_CONV_NONE || cfg->algo != 0 || cfg->policy_std_param))
     return fail(h, DSACT_E_INVALID, "policy_std_type 'mlp_separated' is built for DSAC_V2 with MLP nets (and excludes 'parameter')");
   for (int oa : {cfg->value_out_act, cfg->policy_out_act})
-    if (oa != 0 && (oa < ACT_RELU || oa > ACT_TANH)) return fail(h, DSACT_E_INVALID, "output activation must be 0 (linear) or 1..5 (relu, elu, selu, sigmoid, tanh)");
+    if (oa != 0 && (oa < ACT_RELU || oa > ACT_TANH) && oa != OUT_ACT_GELU)
+      return fail(h, DSACT_E_INVALID, "output activation must be 0 (linear), 1..5 (relu, elu, selu, sigmoid, tanh) or 6 (gelu)");
   if ((cfg->value_out_act || cfg->policy_out_act) && (cfg->conv_type != DSACT_CONV_NONE || cfg->algo != 0))
     return fail(h, DSACT_E_INVALID, "output activations other than linear are built for DSAC_V2 with MLP nets (tile-stage kernels)");
   if (h->cfg.global_batch < h->cfg.batch) h->cfg.global_batch = h->cfg.batch;
@@ -3344,6 +3357,7 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
   if (const char* v = getenv("DSACT_CONV_FWD64_MIN")) h->env_conv_fwd64_min = atoi(v);
   if (const char* v = getenv("DSACT_DCOL64_MIN_M")) h->env_dcol64_min_m = atoi(v);
   h->env_no_dcol_ident = getenv("DSACT_NO_DCOL_IDENT") != nullptr;
+  h->env_no_fat_stage = getenv("DSACT_NO_FAT_STAGE") != nullptr;
   if (const char* v = getenv("DSACT_CHAIN_RG")) h->env_chain_rg = atoi(v) == 1 ? 1 : atoi(v) == 4 ? 4 : 2;
   h->dw_chunks = (h->B > 448 && h->B % 256 == 0 && getenv("DSACT_NO_SPLITK") == nullptr) ? h->B / 256 : 1;   // (chain path: below)
   h->dw_part_stride = (h->n_online + 2 + 63) & ~(size_t)63;
@@ -3359,6 +3373,8 @@ int dsact_create(const dsact_config* cfg, int device, dsact_handle** out) {
     //  kernels carry them, the backward row phases multiply by their derivative; the throughput-regime kernels of batch >= 1024
     //  do not: `fat` below)
     ok = ok && !h->unequal_widths;                                     // one width per layer for every chain unit
+    // a GELU OUTPUT layer: its derivative needs the pre-activation, which only the tile-stage heads keep (HeadsArgs::qdmean / pi_dact)
+    ok = ok && cfg->value_out_act != OUT_ACT_GELU && cfg->policy_out_act != OUT_ACT_GELU;
     for (int l = 0; l < h->L; ++l) ok = ok && cfg->hidden[l] == cfg->hidden[0];
     const int W0 = cfg->hidden[0];
     ok = ok && (W0 == 64 || W0 == 128 || W0 == 256);

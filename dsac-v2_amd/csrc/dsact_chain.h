@@ -655,6 +655,7 @@ struct FwdArgs {
   int debug_withhold;               // tests only (dsact_debug_set "withhold_flag"): unit 0 / slice 0 never raises its flag
   const long long* tagp;            // tagged hand-over: DevState::tag_seq (advances with every closed update, never reset): tag = low word + 1
   int tpad;                         // steps of padding behind every 64-row tile of the forward packs (experiments: DSACT_PK_PAD)
+  int x0_lds;                       // throughput-regime forward (dsact_fat.h): the slice's input rows are staged in LDS (round 6)
 };
 
 // Data handed from a producer to a consumer INSIDE the merged launch (sampled actions, saved first-layer accumulators)

@@ -403,9 +403,16 @@ __global__ void __launch_bounds__(kThreads) k_conv_fwd_narrow(ConvStageArgs s) {
   for (int tile = wv; tile < n_tiles; tile += 2 * wpg) {
     const int nx = tile + wpg;
     load_next(Pb);                            // unconditional (clamped inside): no branch between the loads and the MFMAs
+    // (round 6: hipcc sinks these requests behind all but the tile's last 4-14 MFMAs -- the next tile's patches are in flight
+    //  under the stores, not under the MFMAs. The one-wave-per-SIMD form pins them where they are written: layer 2 27.7 ->
+    //  25.9 us. The narrower forms, 3-4 waves per SIMD on HBM-bound layers, LOSE with the pin -- layer 0 49.3 -> 59.8 us, layer
+    //  1 33.5 -> 41.0: the other waves cover the latency, and 4 waves' requests at once queue behind each other;
+    //  profiles/r06_isa_schedule_fixes.txt)
+    if (NKK >= 9) __builtin_amdgcn_sched_barrier(0);
     compute(tile, Pa);
     if (nx >= n_tiles) break;
     load_next(Pa);
+    if (NKK >= 9) __builtin_amdgcn_sched_barrier(0);
     compute(nx, Pb);
   }
 }
@@ -944,7 +951,10 @@ __device__ __forceinline__ void conv_dx_mfma_body(const ConvDxArgs& a, int pi) {
         wq[ay][kx][kk] = v;
       }
   const float* __restrict__ dyb = a.dy[pi];
-  struct Tile { f32x4 A[NAY][2][NKK]; bool v[NAY][2]; int b, yq, xq; bool ok; };
+  // (X0 / X1: the forward activations behind the ReLU mask of the tile's two pixels -- requested WITH the tile's operands, one
+  //  tile ahead: loaded in the epilogue they cost `s_waitcnt vmcnt(0)` in front of every store, which also drained the next
+  //  tile's operand requests -- nothing was in flight under the MFMAs; round 6, scripts/isa_wait_audit.py)
+  struct Tile { f32x4 A[NAY][2][NKK]; f32x4 X0, X1; bool v[NAY][2]; int b, yq, xq; bool ok; };
   auto load_tile = [&](int tile, Tile& T) {
     const int m = tile * 16 + i;
     T.ok = m < M;
@@ -963,6 +973,9 @@ __device__ __forceinline__ void conv_dx_mfma_body(const ConvDxArgs& a, int pi) {
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) T.A[ay][ax][kk] = *(const f32x4u*)(row + 16 * kk);   // raw: masked at use
       }
+    const size_t o = (((size_t)T.b * g.H + 2 * T.yq + PY) * g.W + 2 * T.xq) * CIN + (4 * gq < CIN ? 4 * gq : 0);
+    T.X0 = *(const f32x4u*)(a.x[pi] + o);
+    T.X1 = *(const f32x4u*)(a.x[pi] + o + (2 * T.xq + 1 < g.W ? CIN : 0));   // (clamped: an odd image width has no second pixel in its last pair)
   };
   auto compute = [&](const Tile& T) {
     f32x4 acc0 = zero, acc1 = zero;      // px = 0, px = 1
@@ -982,13 +995,13 @@ __device__ __forceinline__ void conv_dx_mfma_body(const ConvDxArgs& a, int pi) {
     if (T.ok && 4 * gq < CIN) {
       const int y = 2 * T.yq + PY, x0 = 2 * T.xq;
       const size_t o = (((size_t)T.b * g.H + y) * g.W + x0) * CIN + 4 * gq;
-      const f32x4 xv0 = *(const f32x4u*)(a.x[pi] + o);
+      const f32x4 xv0 = T.X0;
       f32x4 r0 = acc0;
 #pragma unroll
       for (int e = 0; e < 4; ++e) r0[e] = xv0[e] > 0.f ? r0[e] : 0.f;
       *(f32x4u*)(a.dx[pi] + o) = r0;
       if (x0 + 1 < g.W) {
-        const f32x4 xv1 = *(const f32x4u*)(a.x[pi] + o + CIN);
+        const f32x4 xv1 = T.X1;
         f32x4 r1 = acc1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) r1[e] = xv1[e] > 0.f ? r1[e] : 0.f;
@@ -1002,10 +1015,12 @@ __device__ __forceinline__ void conv_dx_mfma_body(const ConvDxArgs& a, int pi) {
   for (int tile = wave; tile < n_tiles; tile += 2 * n_waves) {
     const int nx = tile + n_waves;
     load_tile(nx < last ? nx : last, Tb);     // unconditional (clamped): no branch between the loads and the MFMAs
+    __builtin_amdgcn_sched_barrier(0);        // (the requests stay in front of the MFMAs: hipcc sank them behind most of them)
     compute(Ta);
     if (nx >= n_tiles) break;
     const int n2 = nx + n_waves;
     load_tile(n2 < last ? n2 : last, Ta);
+    __builtin_amdgcn_sched_barrier(0);
     compute(Tb);
   }
 }

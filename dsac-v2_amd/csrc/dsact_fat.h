@@ -20,13 +20,16 @@
 
 namespace dsact {
 
-struct FatLds { int ldh, ldx, off_h, off_x, off_sc, total; };
+struct FatLds { int ldh, ldx, ldx0, off_h, off_x, off_sc, total; };
 // kx: floats of the staged narrow operand rows (policy backward: the (dmu | draw) rows), 0: none
-__host__ __device__ inline FatLds fat_lds(int W, int R, int kx) {
+// k0: floats of the forward's staged INPUT rows (16 per first-layer chunk; round 6), 0: the first layer reads its rows from
+//     global memory. The input rows share the activation buffer (the first layer's output sits in the accumulators when
+//     the last read of its input is done, like every later layer's), so the buffer is sized by the wider of the two
+__host__ __device__ inline FatLds fat_lds(int W, int R, int kx, int k0 = 0) {
   FatLds s;
-  s.ldh = W + 4; s.ldx = kx + 4;
+  s.ldh = W + 4; s.ldx = kx + 4; s.ldx0 = k0 ? k0 + 4 : 0;
   s.off_h = 0;
-  s.off_x = s.off_h + R * s.ldh;
+  s.off_x = s.off_h + R * (s.ldx0 > s.ldh ? s.ldx0 : s.ldh);
   s.off_sc = s.off_x + (kx ? R * s.ldx : 0);
   s.total = s.off_sc + 16 + 2 * R;   // [16] wave partial sums, [2R] per-row (d0, d1)
   return s;
@@ -75,6 +78,42 @@ __device__ __forceinline__ void fat_gemm_lds(f32x4 (&acc)[RT][4], const float* w
       fat_load_b(b1, wt, C, c + 3 < c_hi ? c + 3 : last, lane4);
       __builtin_amdgcn_sched_barrier(0);
     }
+  }
+}
+
+// ... with a run-time chunk range and the first two chunks' weights requested by the caller (the first layer of a staged slice:
+// the requests go out before the workgroup waits for its input rows). Same MFMA sequence as fat_gemm_lds; the loop body is
+// branch-free (whole pairs, the odd chunk behind the loop): with the second half under a wave-uniform `if` hipcc's wait-count
+// pass merges the loop's entry and back edges conservatively and drains the queue (vmcnt(0)) in front of every pair -- one
+// exposed L2 round trip per pair, 0.38 us per chunk against the unrolled hidden layers' 0.275 (scripts/isa_wait_audit.py).
+template <int RT>
+__device__ __forceinline__ void fat_gemm_lds_pl(f32x4 (&acc)[RT][4], f32x4 (&b0)[4], f32x4 (&b1)[4], const float* wt, int C, int c_lo, int c_hi,
+                                                const float* lds, int xs, int ld, int lane4) {
+  if (c_hi <= c_lo) return;
+  const int last = c_hi - 1;
+  auto pair = [&](int c) {
+    f32x4 a[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a[rt] = *(const f32x4*)(lds + xs + 16 * rt * ld + 16 * c);
+    fat_mma<RT>(acc, a, b0);
+    fat_load_b(b0, wt, C, c + 2 < c_hi ? c + 2 : last, lane4);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a[rt] = *(const f32x4*)(lds + xs + 16 * rt * ld + 16 * (c + 1));
+    fat_mma<RT>(acc, a, b1);
+    fat_load_b(b1, wt, C, c + 3 < c_hi ? c + 3 : last, lane4);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int c = c_lo;
+  if (c + 1 < c_hi) {   // first trip peeled, the loop INSIDE its branch: the loop is entered only with the queue its back edge has (dw2_tile's form)
+    pair(c);
+    for (c += 2; c + 1 < c_hi; c += 2) pair(c);
+  }
+  if (c < c_hi) {   // odd chunk count: the last one (its weights sit in b0)
+    f32x4 a[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a[rt] = *(const f32x4*)(lds + xs + 16 * rt * ld + 16 * c);
+    fat_mma<RT>(acc, a, b0);
   }
 }
 
@@ -194,13 +233,15 @@ __device__ __forceinline__ void fat_fwd_body(const FwdArgs& a, int unit, int sli
   const int lane4 = lane * 4, i = lane & 15, g = lane >> 4;
   const int row0 = slice * R;
   const int L = a.L, F = a.F, A = a.A;
-  const FatLds S = fat_lds(W, R, 0);
+  const bool stage = a.x0_lds != 0;   // round 6: the slice's input rows go through LDS once (the host decides: they must fit)
+  const FatLds S = fat_lds(W, R, 0, stage ? 16 * (a.s_obs + a.s_act) : 0);
   const int c_obs = a.s_obs, c_act = u.s_act, C0 = c_obs + c_act;
   const bool do_obs = u.seg != SEG_ACT_FROM_SAVED;
   const bool do_act = u.seg != SEG_OBS_ONLY && c_act > 0;
   CTL(a.timeline, 0);   // (instrumented builds: scripts/gpu_r5_timeline_fat.sh)
   CTLR(a.timeline, 14);
   CTLV(a.timeline, 11, 1 + unit);
+  CTLV(a.timeline, 10, ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4));   // (XCC_ID, HW_ID)
   int nf[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) nf[nt] = 64 * wave + 16 * nt + i;   // this lane's output features
@@ -237,14 +278,59 @@ __device__ __forceinline__ void fat_fwd_body(const FwdArgs& a, int unit, int sli
   float bl[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) bl[nt] = u.bias[0][nf[nt]];
+  const float* w0 = u.wf[0] + (size_t)(4 * wave) * C0 * 256;
+  // ---- staged input rows (round 6). Reading them from global memory chunk by chunk made every wave of the workgroup fetch the
+  // same 16 x 64 B row pieces one chunk ahead of its MFMAs (four times the bytes, half-used lines, one L2 round trip of cover
+  // with one wave per SIMD: 68-83 cycles per MFMA against the hidden layers' 41, profiles/r05_timeline_fat_chain_fwd_a.txt).
+  // Now the workgroup copies its rows once, coalesced, in the chunk layout the MFMAs read -- [R][16 C0], quads outside a segment
+  // zero (what fat_gemm_x selects per lane) -- and the first layer runs the hidden layers' loop. Same operands, same MFMA order.
+  f32x4 pb0[4], pb1[4];
+  const int c_first = do_obs ? 0 : c_obs, c_end1 = do_obs ? c_obs : C0;
+  if (stage) {
+    fat_load_b(pb0, w0, C0, c_first, lane4);
+    fat_load_b(pb1, w0, C0, c_first + 1 < c_end1 ? c_first + 1 : c_end1 - 1, lane4);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const int q_lo = do_obs ? 0 : 4 * c_obs, q_hi = do_act ? 4 * C0 : 4 * c_obs;
+    const int nq = q_hi - q_lo, total = R * nq;
+    for (int e0 = tid; e0 < total; e0 += 4 * NTHR) {
+      f32x4 v[4];
+      bool ok[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = e0 + q * NTHR;
+        const bool in = e < total;
+        const int r = in ? e / nq : 0, qq = q_lo + (in ? e % nq : 0);
+        const int c = qq >> 2, g4 = (qq & 3) * 4;
+        const bool obs = c < c_obs;
+        const int col = obs ? 16 * c : F + 16 * (c - c_obs);
+        ok[q] = col + g4 < (obs ? F : F + A);
+        v[q] = gload4(u.x + (size_t)(row0 + r) * a.ldx + (ok[q] ? col + g4 : 0));
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = e0 + q * NTHR;
+        if (e < total) {
+          const int r = e / nq, qq = q_lo + e % nq;
+          *(f32x4*)(lds + S.off_h + r * S.ldx0 + 4 * qq) = ok[q] ? v[q] : zero;
+        }
+      }
+    }
+    lds_barrier();
+  }
   // the dW tiles of every first layer read the minibatch as [input feature][batch]: one unit transposes its rows
   if (u.x0t) {
     const int K0 = F + (do_act ? A : 0);
     for (int e = tid; e < K0 * (R / 4); e += NTHR) {
       const int k = e % K0, q4 = e / K0;
       f32x4 v;
+      if (stage) {
+        const int kk = k < F ? k : 16 * c_obs + (k - F);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = u.x[(size_t)(row0 + 4 * q4 + r) * a.ldx + k];
+        for (int r = 0; r < 4; ++r) v[r] = lds[S.off_h + (4 * q4 + r) * S.ldx0 + kk];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = u.x[(size_t)(row0 + 4 * q4 + r) * a.ldx + k];
+      }
       nt_store4(u.x0t + pk_index(k, row0 + 4 * q4, a.Cb), v);
     }
   }
@@ -253,9 +339,10 @@ __device__ __forceinline__ void fat_fwd_body(const FwdArgs& a, int unit, int sli
   FatX X;
   X.p = u.x + (size_t)(row0 + i) * a.ldx + 4 * g; X.rt_stride = (size_t)16 * a.ldx;
   X.c_obs = c_obs; X.F = F; X.A = A; X.g4 = 4 * g;
-  const float* w0 = u.wf[0] + (size_t)(4 * wave) * C0 * 256;
+  const int xs_x = S.off_h + i * S.ldx0 + 4 * g;
   if (do_obs) {
-    fat_gemm_x<RT>(acc, w0, C0, 0, c_obs, X, lane4);
+    if (stage) fat_gemm_lds_pl<RT>(acc, pb0, pb1, w0, C0, 0, c_obs, lds, xs_x, S.ldx0, lane4);
+    else fat_gemm_x<RT>(acc, w0, C0, 0, c_obs, X, lane4);
     if (u.zsave) {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -267,7 +354,11 @@ __device__ __forceinline__ void fat_fwd_body(const FwdArgs& a, int unit, int sli
     CTL(a.timeline, 2);
     if (u.seg == SEG_OBS_ONLY) { CTLR(a.timeline, 15); return; }
   }
-  if (do_act) fat_gemm_x<RT>(acc, w0, C0, c_obs, C0, X, lane4);
+  if (do_act) {
+    if (stage && !do_obs) fat_gemm_lds_pl<RT>(acc, pb0, pb1, w0, C0, c_obs, C0, lds, xs_x, S.ldx0, lane4);
+    else if (stage) fat_gemm_lds<RT>(acc, w0, C0, c_obs, C0, lds, xs_x, S.ldx0, lane4);
+    else fat_gemm_x<RT>(acc, w0, C0, c_obs, C0, X, lane4);
+  }
   CTL(a.timeline, 3);
   // ---- epilogues + hidden layers (the slice's activations live in ONE LDS buffer, overwritten in place)
   NarrowFrags<4> hf;
@@ -286,7 +377,7 @@ __device__ __forceinline__ void fat_fwd_body(const FwdArgs& a, int unit, int sli
         if (u.G[l]) nt_store4(u.G[l] + pk_index(nf[nt], row0 + 16 * rt + 4 * g, a.Cb), gd);
         acc[rt][nt] = hv;
       }
-    if (l > 0) lds_barrier();      // every wave has read the last of this layer's input
+    if (l > 0 || stage) lds_barrier();      // every wave has read the last of this layer's input (l == 0: the staged rows)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll

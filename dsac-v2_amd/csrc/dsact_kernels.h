@@ -1277,6 +1277,8 @@ struct HeadsArgs {
   int q_out_act, pi_out_act;   // output activations (dsact_math.h out_act_fwd): the stored outputs are POST-activation
   int pi_out_n;                // policy outputs the activation applies to: 2A, or A with policy_std_type "parameter" (log_std is a
                                // plain parameter there, networks/mlp.py:92-97)
+  float* qdmean[2];            // OUT_ACT_GELU: d mean_y / d z of q1 / q2(obs, act) per row [B] (k_loss reads it), else nullptr
+  float* pi_dact;              // OUT_ACT_GELU: d logit_y / d z of policy(obs) [B x 2A] (k_heads_bwd reads it), else nullptr
 };
 
 template <int NCH>
@@ -1298,11 +1300,13 @@ __global__ void __launch_bounds__(kThreads) k_heads(HeadsArgs a) {
       float o[2];
       row_dots<NCH, 2>(h, a.Wout[chain], W, 0, 2, lane, o);
       if (lane == 0) {
-        const float mean = out_act_fwd(a.q_out_act, o[0] + a.bout[chain][0]), raw = out_act_fwd(a.q_out_act, o[1] + a.bout[chain][1]);
+        const float zm = o[0] + a.bout[chain][0], zr = o[1] + a.bout[chain][1];
+        const float mean = out_act_fwd(a.q_out_act, zm), raw = out_act_fwd(a.q_out_act, zr);
         a.qout[chain - 2][2 * r] = mean;
         a.qout[chain - 2][2 * r + 1] = raw;
         a.qstd[chain - 2][2 * r] = softplus(raw);
-        a.qstd[chain - 2][2 * r + 1] = softplus_grad(raw) * out_act_grad_y(a.q_out_act, raw);   // d std / d (pre-activation output)
+        a.qstd[chain - 2][2 * r + 1] = softplus_grad(raw) * out_act_grad(a.q_out_act, raw, zr);   // d std / d (pre-activation output)
+        if (a.qdmean[chain - 2]) a.qdmean[chain - 2][r] = out_act_grad(a.q_out_act, mean, zm);
       }
     } else {
       const int A = a.A;
@@ -1315,7 +1319,10 @@ __global__ void __launch_bounds__(kThreads) k_heads(HeadsArgs a) {
           if (lane == n0 + q) mine = o[q];
       }
       if (lane < 2 * A) mine += a.bout[chain][lane];
+      const float mine_z = mine;
       if (lane < a.pi_out_n) mine = out_act_fwd(a.pi_out_act, mine);
+      if (chain == 0 && a.pi_dact && lane < 2 * A)
+        a.pi_dact[(size_t)r * 2 * A + lane] = lane < a.pi_out_n ? out_act_grad(a.pi_out_act, mine, mine_z) : 1.0f;
       const float raw = __shfl(mine, lane + A, 64);  // lane j < A: raw log-std of dim j
       float lp = 0.f;
       if (lane < A) {
@@ -1391,6 +1398,7 @@ struct LossArgs {
   const float* std_sums;   // {sum std1, sum std2} computed elsewhere (large B / strict data-parallel); else NULL
   int auto_alpha; float alpha_fixed, gamma, tau_b, one_minus_tau_b;
   int q_out_act;           // output activation of the critics (dsact_math.h out_act_fwd); qout_c / qstd_c hold post-activation values
+  const float* qdmean[2];  // OUT_ACT_GELU: d mean_y / d z of q1 / q2(obs, act) as k_heads stored it, else nullptr
   long long* timeline;
   RideArgs ride;
 };
@@ -1451,7 +1459,7 @@ __global__ void __launch_bounds__(kThreads) k_loss(LossArgs a) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) row_mask<NCH>(h[c], a.W, lane);
   // ---------------- 2: output layers ----------------
-  float o[4][2];
+  float o[4][2], zo[4][2];   // (zo: pre-activation, for the one output activation whose derivative needs it)
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -1462,7 +1470,8 @@ __global__ void __launch_bounds__(kThreads) k_loss(LossArgs a) {
         s += h[c][q].x * wv[c][j][q].x; s += h[c][q].y * wv[c][j][q].y;
         s += h[c][q].z * wv[c][j][q].z; s += h[c][q].w * wv[c][j][q].w;
       }
-      o[c][j] = out_act_fwd(a.q_out_act, wave_sum(s) + bo[c][j]);
+      zo[c][j] = wave_sum(s) + bo[c][j];
+      o[c][j] = out_act_fwd(a.q_out_act, zo[c][j]);
     }
   // ---------------- 1: mean_std EMA ----------------
   s1 = wave_sum(s1); s2 = wave_sum(s2);
@@ -1488,15 +1497,15 @@ __global__ void __launch_bounds__(kThreads) k_loss(LossArgs a) {
   const CriticTerm c2 = critic_term(q2, std2, ms2, tq, tqs);
   float dv[8];
   // (d / d pre-activation output: the std column's factor is folded into sg by k_heads, the mean column's is formed here)
-  dv[0] = c1.dq * a.inv_B * out_act_grad_y(a.q_out_act, q1);
+  dv[0] = c1.dq * a.inv_B * (a.qdmean[0] ? a.qdmean[0][r] : out_act_grad_y(a.q_out_act, q1));
   dv[1] = c1.dstd * a.inv_B * sg1;
-  dv[2] = c2.dq * a.inv_B * out_act_grad_y(a.q_out_act, q2);
+  dv[2] = c2.dq * a.inv_B * (a.qdmean[1] ? a.qdmean[1][r] : out_act_grad_y(a.q_out_act, q2));
   dv[3] = c2.dstd * a.inv_B * sg2;
   // actor: mean(alpha*logp_new - min(q1p, q2p)); torch.min ties split the gradient evenly
   const float q1p = o[2][0], q2p = o[3][0];
   const float w1 = q1p < q2p ? 1.0f : (q1p > q2p ? 0.0f : 0.5f);
-  dv[4] = -w1 * a.inv_B * out_act_grad_y(a.q_out_act, q1p); dv[5] = 0.0f;
-  dv[6] = -(1.0f - w1) * a.inv_B * out_act_grad_y(a.q_out_act, q2p); dv[7] = 0.0f;
+  dv[4] = -w1 * a.inv_B * out_act_grad(a.q_out_act, q1p, zo[2][0]); dv[5] = 0.0f;
+  dv[6] = -(1.0f - w1) * a.inv_B * out_act_grad(a.q_out_act, q2p, zo[3][0]); dv[7] = 0.0f;
   if (lane == 0) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -1688,6 +1697,7 @@ struct HeadsBwdArgs {
   const float* act_scale; float lo_ls, hi_ls;
   const float* part_loss; int n_part; float target_entropy; float* grad_log_alpha;
   int pi_out_act, pi_out_n;   // policy output activation and the outputs it applies to (HeadsArgs); logits_pi holds post-activation values
+  const float* pi_dact;       // OUT_ACT_GELU: d logit_y / d z [B x 2A] as k_heads stored it, else nullptr
   long long* timeline;
   // ride-along weight-gradient tiles of the critics (blocks >= n_row_blocks): this launch has only B/4 row blocks, and
   // the critics' dW is complete (and their weights free) as soon as the critic backward is
@@ -1789,8 +1799,11 @@ __global__ void __launch_bounds__(kThreads) k_heads_bwd(HeadsBwdArgs a) {
   float dmu = 0.f, draw = 0.f;
   if (lane < A) {
     tanh_gauss_bwd(mu, raw, eps, scale, a.lo_ls, a.hi_ls, dA, alpha * a.inv_B, dmu, draw);
-    dmu *= out_act_grad_y(a.pi_out_act, mu);
-    if (A + lane < a.pi_out_n) draw *= out_act_grad_y(a.pi_out_act, raw);
+    if (a.pi_dact) { dmu *= a.pi_dact[(size_t)r * 2 * A + lane]; draw *= a.pi_dact[(size_t)r * 2 * A + A + lane]; }
+    else {
+      dmu *= out_act_grad_y(a.pi_out_act, mu);
+      if (A + lane < a.pi_out_n) draw *= out_act_grad_y(a.pi_out_act, raw);
+    }
     a.dout_pi[(size_t)r * 2 * A + lane] = dmu;
     a.dout_pi[(size_t)r * 2 * A + A + lane] = draw;
     a.d_new_act[(size_t)r * A + lane] = dA;

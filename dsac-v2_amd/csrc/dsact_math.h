@@ -93,12 +93,14 @@ DSACT_HD void act_fwd_grad(int act, float z, float& h, float& g) {
 
 // ---- OUTPUT activations (value_output_activation / policy_output_activation, networks/mlp.py:15-20: the last Linear is
 // followed by `output_activation()`; every shipped example uses "linear"). Code: 0 = linear, else an ACT_* id (relu, elu,
-// selu, sigmoid, tanh; a GELU output layer is refused at create time). The heads keep the POST-activation outputs y, and the
-// derivative is expressed through y so that nothing else has to be stored.
+// selu, sigmoid, tanh) or OUT_ACT_GELU. The heads keep the POST-activation outputs y, and the derivative is expressed through y
+// so that nothing else has to be stored -- except for GELU (round 6), whose derivative is no function of its output: the
+// head that evaluates it stores d y / d z beside y (tile-stage kernels: HeadsArgs::qdmean / pi_dact).
+enum : int { OUT_ACT_GELU = 6 };
 DSACT_HD float out_act_fwd(int act, float z) {
   if (act == 0) return z;
   float h, g;
-  act_fwd_grad(act, z, h, g);
+  act_fwd_grad(act == OUT_ACT_GELU ? ACT_GELU : act, z, h, g);
   return h;
 }
 DSACT_HD float out_act_grad_y(int act, float y) {
@@ -110,6 +112,14 @@ DSACT_HD float out_act_grad_y(int act, float y) {
     case ACT_TANH: return 1.0f - y * y;
     default: return 1.0f;
   }
+}
+
+// ... where the pre-activation z is at hand (the kernel that evaluates the head)
+DSACT_HD float out_act_grad(int act, float y, float z) {
+  if (act != OUT_ACT_GELU) return out_act_grad_y(act, y);
+  float h, g;
+  gelu_fwd_grad(z, h, g);
+  return g;
 }
 
 DSACT_HD float softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }

@@ -130,9 +130,10 @@ STD_TYPES = ("mlp_shared", "parameter", "mlp_separated")
 
 
 # value_output_activation / policy_output_activation (utils/common_utils.py:16-45; the module behind the last Linear,
-# networks/mlp.py:15-20): id = dsact_config value (0 linear, else the hidden-activation id); "gelu" as an OUTPUT activation is refused
+# networks/mlp.py:15-20): id = dsact_config value (0 linear, else the hidden-activation id; 6 = "gelu", whose derivative needs the
+# pre-activation: tile-stage kernels only, round 6)
 OUT_ACTIVATIONS = {"linear": (0, nn.Identity), "relu": (1, nn.ReLU), "elu": (2, nn.ELU), "selu": (3, nn.SELU),
-                   "sigmoid": (4, nn.Sigmoid), "tanh": (5, nn.Tanh)}
+                   "sigmoid": (4, nn.Sigmoid), "tanh": (5, nn.Tanh), "gelu": (6, nn.GELU)}
 
 
 def _mlp(sizes, activation="gelu", out_activation="linear"):

@@ -37,7 +37,7 @@ void hm_polyak(float* pt, const float* p, int n, float polyak, float one_minus) 
 }
 void hm_out_act(int act, float z, float* y, float* dy) {   // output activations: y = act(z), dy = d act / dz expressed through y
   *y = dsact::out_act_fwd(act, z);
-  *dy = dsact::out_act_grad_y(act, *y);
+  *dy = dsact::out_act_grad(act, *y, z);   // (== out_act_grad_y(act, y) for every activation but OUT_ACT_GELU)
 }
 }
 

@@ -381,6 +381,7 @@ def test_hidden_activations(va, pa):
     (1024, (256, 256, 256), {"DSACT_FAT_RT": "2"}),           # 32-row workgroups forced
     (512, (128, 128), {"DSACT_FAT_MIN": "512"}),              # two waves per workgroup (hidden width 128), two layers
     (4096, (256, 256, 256), {}),                              # 32-row workgroups by choice, split-K weight gradients x16
+    (1024, (256, 256, 256), {"DSACT_NO_FAT_STAGE": "1"}),     # first layer reading its rows from global memory (rounds 3-5)
 ])
 def test_throughput_regime_kernels(B, hid, env, monkeypatch):
     """dsact_fat.h (batch >= 1024): v_mfma_f32_16x16x4 slices of 16 / 32 rows, style-16 packs of every layer, in-place
@@ -388,6 +389,61 @@ def test_throughput_regime_kernels(B, hid, env, monkeypatch):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     run_case("fat B=%d hidden %s %s" % (B, "x".join(map(str, hid)), env), 376, 17, hid, B, steps=2)
+    for k in env:
+        monkeypatch.delenv(k, raising=False)
+
+
+@pytest.mark.parametrize("O,A,hid,B,env", [(376, 17, (256, 256, 256), 1024, {}), (17, 6, (256, 256, 256), 1024, {"DSACT_FAT_RT": "2"}),
+                                           (11, 3, (128, 128), 512, {"DSACT_FAT_MIN": "512"}), (105, 8, (256, 256, 256), 4096, {})])
+def test_throughput_regime_staged_input_rows_equal_global_reads(O, A, hid, B, env, monkeypatch):
+    """round 6: the throughput-regime forward copies a slice's input rows into LDS once (chunk layout, zero quads outside a
+    segment) and runs its first layer through the hidden layers' loop == the first layer reading the rows from global memory
+    chunk by chunk (DSACT_NO_FAT_STAGE=1), bit for bit: same operands, same MFMA order -- observation widths that are and are
+    not multiples of 4 / 16, one and two action chunks, 16- and 32-row workgroups, eager updates and a graph replay."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    algs = []
+    # default (staged rows), rows from global memory
+    for switch in (None, "DSACT_NO_FAT_STAGE"):
+        if switch:
+            monkeypatch.setenv(switch, "1")
+        alg, _ = make_pair(O, A, hid, B, seed=23)
+        assert alg.engine.chain_active
+        algs.append(alg)
+        if switch:
+            monkeypatch.delenv(switch, raising=False)
+    rng = np.random.default_rng(14)
+    for it in range(3):
+        data = synth_batch(rng, B, O, A, p_done=0.1)
+        torch.manual_seed(500 + it)
+        noise = draw_noise(B, A)
+        for a in algs:
+            a.engine.load_batch(*(data[k].numpy() for k in ("obs", "act", "rew", "obs2", "done")))
+            a.engine.set_noise(noise["eps_new"].numpy(), noise["eps_2"].numpy(), noise["z5"].numpy(), noise["z6"].numpy())
+            a.engine.step(it)
+    N = 8192
+    for a in algs:
+        e = a.engine
+        e.set_device_rng(77)
+        e.buffer_create(N)
+        g = torch.Generator(device="cuda").manual_seed(6)
+        e.buffer_fill_device(0, torch.randn(N, O, device="cuda", generator=g), torch.rand(N, A, device="cuda", generator=g) - .5,
+                             torch.randn(N, device="cuda", generator=g), torch.randn(N, O, device="cuda", generator=g),
+                             (torch.rand(N, device="cuda", generator=g) < .05).float())
+        np.random.seed(3)
+        e.upload_index_table(np.random.randint(0, N, size=(4, B)))
+        e.graph_build(3)
+        e.graph_run(3, 3)
+        e.sync()
+    st0 = algs[0].engine.read_stats()
+    st0.pop("_device_ms")   # a timing, not a statistic
+    assert all(np.isfinite(v) for v in st0.values())
+    for other in algs[1:]:
+        for name in ("online", "target", "adam_m", "adam_v"):
+            assert torch.equal(getattr(algs[0].engine, name), getattr(other.engine, name)), name
+        st1 = other.engine.read_stats()
+        st1.pop("_device_ms")
+        assert st0 == st1
     for k in env:
         monkeypatch.delenv(k, raising=False)
 

@@ -93,7 +93,8 @@ def test_std_type_parameter_bit_exact_vs_live_reference(O, A, hid, B, dist):
 
 @pytest.mark.parametrize("O,A,hid,B,vo,po,st", [(24, 6, (64, 64), 64, "tanh", "tanh", "mlp_shared"), (376, 17, (256, 256, 256), 64, "tanh", "linear", "mlp_shared"),
                                                 (11, 3, (64, 64), 32, "sigmoid", "elu", "mlp_shared"), (24, 6, (64, 64), 64, "relu", "selu", "mlp_shared"),
-                                                (24, 6, (64, 64), 64, "linear", "tanh", "parameter")])
+                                                (24, 6, (64, 64), 64, "linear", "tanh", "parameter"),
+                                                (24, 6, (64, 64), 64, "gelu", "gelu", "mlp_shared"), (11, 3, (96, 40), 50, "gelu", "tanh", "parameter")])
 def test_output_activations_bit_exact_vs_live_reference(O, A, hid, B, vo, po, st):
     """value_output_activation / policy_output_activation other than "linear" (utils/common_utils.py:16-45 -> the module behind
     the last Linear, networks/mlp.py:15-20), alone and with policy_std_type "parameter" (whose log_std is NOT activated)."""

@@ -16,8 +16,9 @@ def test_unsupported_output_activation_combinations_are_refused():
     _check_supported(kw)
     with pytest.raises(NotImplementedError):
         dsac_v1_hip._check_supported(kw)
+    _check_supported(dict(kw, value_output_activation="gelu"))       # round 6: built (tile-stage kernels)
     with pytest.raises(NotImplementedError):
-        _check_supported(dict(kw, value_output_activation="gelu"))
+        _check_supported(dict(kw, value_output_activation="swish"))  # not one of the reference's names
     with pytest.raises(NotImplementedError):
         _check_supported(dict(kw, value_func_type="CNN", policy_func_type="CNN", value_conv_type="type_2", policy_conv_type="type_2",
                               obsv_dim=(3, 96, 96)))
@@ -32,7 +33,8 @@ def test_host_closed_forms_of_the_output_activations():
     g.build()
     lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_build", "libdsact_hostmath.so"))
     lib.hm_out_act.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
-    mods = {1: torch.nn.ReLU(), 2: torch.nn.ELU(), 3: torch.nn.SELU(), 4: torch.nn.Sigmoid(), 5: torch.nn.Tanh(), 0: torch.nn.Identity()}
+    mods = {1: torch.nn.ReLU(), 2: torch.nn.ELU(), 3: torch.nn.SELU(), 4: torch.nn.Sigmoid(), 5: torch.nn.Tanh(), 0: torch.nn.Identity(),
+            6: torch.nn.GELU()}   # (6: the derivative is taken from the pre-activation, out_act_grad)
     zs = np.concatenate([np.linspace(-6, 6, 97), [0.0, 1e-3, -1e-3]]).astype(np.float32)
     for act, mod in mods.items():
         z = torch.tensor(zs, requires_grad=True)
@@ -57,6 +59,12 @@ def test_host_closed_forms_of_the_output_activations():
     (24, 6, (64, 64), 64, {"value_output_activation": "selu", "policy_output_activation": "sigmoid"}),
     (24, 6, (64, 64), 64, {"policy_output_activation": "tanh", "policy_std_type": "parameter"}),   # log_std is not activated
     (24, 6, (64, 64), 64, {"value_output_activation": "tanh", "policy_act_distribution": "GaussDistribution"}),
+    # "gelu" as an OUTPUT activation (round 6: the heads store d y / d z beside y; tile-stage kernels)
+    (24, 6, (64, 64), 64, {"value_output_activation": "gelu", "policy_output_activation": "gelu"}),
+    (376, 17, (256, 256, 256), 256, {"value_output_activation": "gelu"}),
+    (11, 3, (96, 40), 50, {"policy_output_activation": "gelu", "value_output_activation": "tanh"}),
+    (24, 6, (64, 64), 512, {"value_output_activation": "gelu", "policy_output_activation": "gelu", "policy_std_type": "parameter"}),
+    (24, 6, (64, 64), 64, {"policy_output_activation": "gelu", "policy_std_type": "mlp_separated"}),
 ])
 def test_output_activations_against_the_oracle(O, A, hid, B, over):
     """every intermediate, gradient, statistic and parameter against the oracle, which is pinned bit-exact to the live
