@@ -631,13 +631,17 @@ struct FwdUnit {
                                     // observation part do not wait for the rest of this unit's chain)
   short rg, act;                    // rows per workgroup / 4 of THIS unit (units of one launch may differ); hidden activation
                                     // of its net (ACT_*, dsact_math.h). (shorts: two FwdArgs must fit the 4 KB of kernel arguments)
-  short n_slices;                   // slices of this unit
+  // (late_wait sits at a DWORD-ALIGNED offset, in front of n_slices: a 16-bit field at +2 of a dword of a unit table in device
+  //  memory -- k_chain_fwdp / fwdpb / fwdt -- is no scalar load but `global_load_ushort` + `s_waitcnt vmcnt(0)`: the wait drained
+  //  the weight stream's prologue and the warm-up touches BEFORE the input rows were requested, one memory round trip of every
+  //  chain's start-up; an aligned 16-bit field is widened to s_load_dword. Round 6, ISA.)
   short late_wait;                  // bit 0 (HW_LATE): wait for the producers AFTER the observation segment (only the action columns
                                     // are handed over): the wait hides under this unit's own first 3/4 of a layer.
                                     // Tagged hand-over (pipelined launches): the sampled actions travel as (value, tag) pairs, one
                                     // 8-byte agent-scope store / load each -- the data IS the flag (no store-acknowledge barrier
                                     // + flag on the producer side, no second round trip on the consumer side). bit 1 (HW_PAIRS_OUT,
                                     // policy heads): xact2 is the pair buffer [B][32]; bit 2 (HW_PAIRS_IN): wait0 is that buffer
+  short n_slices;                   // slices of this unit
 };
 constexpr int kMaxFwdUnits = 6;
 struct FwdArgs {
@@ -1293,13 +1297,6 @@ __device__ __forceinline__ void bwd_q_body(const QA& a, int block, float* lds) {
   // ---- weight stream: layers L-1 .. 1 (nothing to stream for a one-hidden-layer net)
   WStr ws;
   if (L > 1) stream_prologue(ws, u.wb[L - 1] + (size_t)wave * SH * 256, 0, lane4);
-  // ---- batch sums of std1 / std2 -> mean_std EMA (dsac_v2.py:233-241); identical in every workgroup
-  float s1 = 0.f, s2 = 0.f;
-  if (a.std_sums == nullptr && !a.v1) {
-    for (int r = tid; r < a.B; r += NTHR) { s1 += a.qstd_c[0][2 * r]; s2 += a.qstd_c[1][2 * r]; }
-    s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if (lane == 0) { sc[wave] = s1; sc[4 + wave] = s2; }
-  }
   // row phase: TPR consecutive lanes per batch row
   const int m = tid / TPR, j = tid % TPR;
   const int r = row0 + m;
@@ -1331,6 +1328,15 @@ __device__ __forceinline__ void bwd_q_body(const QA& a, int block, float* lds) {
   const float la = a.log_alpha[0];
   const float ms1_old = a.st->ms1, ms2_old = a.st->ms2;
   const int ms_init = a.st->ms_init;
+  // ---- batch sums of std1 / std2 -> mean_std EMA (dsac_v2.py:233-241); identical in every workgroup.
+  // (BEHIND the row phase's requests, round 6: the loop's reduction waits for its loads with vmcnt(0) -- in front of them it
+  //  made the start-up two memory round trips, the weight stream's prologue + the sums, then the ~20 row operands.)
+  float s1 = 0.f, s2 = 0.f;
+  if (a.std_sums == nullptr && !a.v1) {
+    for (int r = tid; r < a.B; r += NTHR) { s1 += a.qstd_c[0][2 * r]; s2 += a.qstd_c[1][2 * r]; }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) { sc[wave] = s1; sc[4 + wave] = s2; }
+  }
   lds_barrier();
   CTL(a.timeline, 1);
   if (a.std_sums == nullptr) {
