@@ -114,8 +114,9 @@ typedef struct dsact_config {
    * widths and non-linear output activations; GemmProb::mzero) -- tests/test_std_parameter.py covers a shape of each. */
   int32_t policy_std_param;
   /* value_output_activation / policy_output_activation (utils/common_utils.py:16-45 -> networks/mlp.py:15-20: the module that
-   * follows the LAST Linear): 0 = "linear" (every shipped example), 1 relu, 2 elu, 3 selu, 4 sigmoid, 5 tanh ("gelu" as an
-   * output activation is refused). DSAC_V2 with MLP nets only. Round 6: served by the row-slice chains wherever a linear head would
+   * follows the LAST Linear): 0 = "linear" (every shipped example), 1 relu, 2 elu, 3 selu, 4 sigmoid, 5 tanh, 6 gelu (whose
+   * derivative is no function of its output: the tile-stage heads store it beside the output, and a handle with it stays on the
+   * tile-stage kernels). DSAC_V2 with MLP nets only. Round 6: served by the row-slice chains wherever a linear head would
    * be (the generic-activation instantiations of the forward kernels apply it in the heads, the backward row phases multiply by
    * its derivative expressed through the stored POST-activation outputs) and by both acting forwards; shapes the chains do not
    * take, and batch >= 1024's throughput-regime kernels, fall to the chains' generic forms / the tile-stage kernels as for linear
