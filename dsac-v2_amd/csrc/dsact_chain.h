@@ -1206,6 +1206,28 @@ __global__ void __launch_bounds__(64 * NW, 2) k_chain_fwdt(const PipeFwd* __rest
 // ---------------------------------------------------------------------------------------------------------------
 // k_chain_bwd_q: loss + dZ chains of q1(obs,act), q2(obs,act), q1(obs,new_act), q2(obs,new_act)
 // ---------------------------------------------------------------------------------------------------------------
+// Per-thread partial sums of the critics' std column over the batch (rows tid, tid + NTHR, ...), in THAT order -- with the
+// requests of four trips out before the first add (round 6): written as `for (r...) { s1 += p1[2r]; s2 += p2[2r]; }` every trip was
+// load -> s_waitcnt vmcnt(0) -> add, one L2 round trip per trip at the start of every backward unit (batch 1024: 4, batch
+// 4096: 16). Rows past the batch add +0.0f to a sum of positive terms: the same bits.
+template <int NTHR>
+__device__ __forceinline__ void std_column_sums(const float* p1, const float* p2, int B, int tid, float& s1, float& s2) {
+  for (int r0 = tid; r0 < B; r0 += 4 * NTHR) {
+    float v1[4], v2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = r0 + q * NTHR;
+      const int rc = r < B ? r : tid;
+      v1[q] = p1[2 * rc]; v2[q] = p2[2 * rc];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool ok = r0 + q * NTHR < B;
+      s1 += ok ? v1[q] : 0.0f; s2 += ok ? v2[q] : 0.0f;
+    }
+  }
+}
+
 struct BwdQUnit {
   const float* wb[kChMaxL];        // style-44 packed W_l^T, l = 1..L-1
   const float* wout;               // row-major output layer [2][W] of this chain's net
@@ -1333,7 +1355,7 @@ __device__ __forceinline__ void bwd_q_body(const QA& a, int block, float* lds) {
   //  made the start-up two memory round trips, the weight stream's prologue + the sums, then the ~20 row operands.)
   float s1 = 0.f, s2 = 0.f;
   if (a.std_sums == nullptr && !a.v1) {
-    for (int r = tid; r < a.B; r += NTHR) { s1 += a.qstd_c[0][2 * r]; s2 += a.qstd_c[1][2 * r]; }
+    std_column_sums<NTHR>(a.qstd_c[0], a.qstd_c[1], a.B, tid, s1, s2);
     s1 = wave_sum(s1); s2 = wave_sum(s2);
     if (lane == 0) { sc[wave] = s1; sc[4 + wave] = s2; }
   }

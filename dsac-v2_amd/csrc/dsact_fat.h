@@ -492,7 +492,7 @@ __device__ __forceinline__ void fat_bwd_q_body(const BwdQArgs& a, int unit, int 
   // ---- batch sums of std1 / std2 -> mean_std EMA (dsac_v2.py:233-241); identical in every workgroup
   float s1 = 0.f, s2 = 0.f;
   if (a.std_sums == nullptr) {
-    for (int r = tid; r < a.B; r += NTHR) { s1 += a.qstd_c[0][2 * r]; s2 += a.qstd_c[1][2 * r]; }
+    std_column_sums<NTHR>(a.qstd_c[0], a.qstd_c[1], a.B, tid, s1, s2);
     s1 = wave_sum(s1); s2 = wave_sum(s2);
     if (lane == 0) { sc[wave] = s1; sc[4 + wave] = s2; }
   }
