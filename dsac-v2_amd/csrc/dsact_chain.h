@@ -1212,6 +1212,10 @@ __global__ void __launch_bounds__(64 * NW, 2) k_chain_fwdt(const PipeFwd* __rest
 // 4096: 16). Rows past the batch add +0.0f to a sum of positive terms: the same bits.
 template <int NTHR>
 __device__ __forceinline__ void std_column_sums(const float* p1, const float* p2, int B, int tid, float& s1, float& s2) {
+  if (B <= NTHR) {   // one trip (the batch-256 headline): nothing to batch
+    if (tid < B) { s1 += p1[2 * tid]; s2 += p2[2 * tid]; }
+    return;
+  }
   for (int r0 = tid; r0 < B; r0 += 4 * NTHR) {
     float v1[4], v2[4];
 #pragma unroll
