@@ -73,23 +73,12 @@ __device__ __forceinline__ void stream_prologue(WStr& ws, const float* cur, int 
 // lasts, then from `nxt` starting at its step nxt_s0 (has_nxt == false: the stream ends; spare slots re-read a valid
 // address). lds + xs: this lane's LDS operand (row lane&3 of group 0; group g is 4g rows further; step s is 4s floats
 // further), read one step ahead.
-// (round 6) Row groups through the MFMA's A-matrix BROADCAST: v_mfma_f32_4x4x1_16b takes srcA = the 4 batch rows of a block from
-// that block's 4 lanes, and CBSZ = 4 / ABID = g makes all 16 blocks use block g's. So ONE ds_read_b128 per step -- lane l of
-// the first 16 reads row l & (4 RG - 1), lanes 4g .. 4g+3 hold row group g -- feeds every row group, instead of RG reads in which
-// all 16 blocks fetched the same four rows: the LDS pipe carried RG KB per wave and step (8-row workgroups: 64 of a step's
-// 64 MFMA cycles per CU, 16-row ones 128 of 128), now 1 KB whatever RG. Same operands per MFMA, same bits.
-template <int G, int RG>
-__device__ __forceinline__ f32x4 mfma44_rows(float a, float b, const f32x4& c) {
-  if (RG == 1) return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, G, 0);
-}
 template <int RG>
 __device__ __forceinline__ void gemm44_seg(WStr& ws, const float* cur, int s_lo, int s_hi, const float* nxt, int nxt_s0,
                                            bool has_nxt, const float* lds, int xs, int ld, int lane4, f32x4 (&acc)[RG][2]) {
-  // xs: this lane's row lane & 3 of group 0 (the callers' form); + 4 rows per quad of lanes for the groups behind it
-  const int xr = xs + (((lane4 >> 4) & (RG - 1)) * 4) * ld;
-  f32x4 a0, a1;
-  a0 = *(const f32x4*)(lds + xr + 4 * s_lo);
+  f32x4 a0[RG], a1[RG];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) a0[g] = *(const f32x4*)(lds + xs + 4 * g * ld + 4 * s_lo);
   for (int s0 = s_lo; s0 < s_hi; s0 += kPD) {
     // segment lengths are multiples of kPD and a refill looks kPD steps ahead, so the source of a whole trip's refills
     // is uniform: the next kPD steps of `cur`, or (last trip) the first kPD steps of what follows
@@ -99,17 +88,16 @@ __device__ __forceinline__ void gemm44_seg(WStr& ws, const float* cur, int s_lo,
     for (int u = 0; u < kPD; ++u) {
       const int s = s0 + u;
       // operand of the next step (one step past the end at the last step: unused)
-      if (u & 1) a0 = *(const f32x4*)(lds + xr + 4 * (s + 1));
-      else a1 = *(const f32x4*)(lds + xr + 4 * (s + 1));
+#pragma unroll
+      for (int g = 0; g < RG; ++g) {
+        if (u & 1) a0[g] = *(const f32x4*)(lds + xs + 4 * g * ld + 4 * (s + 1));
+        else a1[g] = *(const f32x4*)(lds + xs + 4 * g * ld + 4 * (s + 1));
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float av = (u & 1) ? a1[e] : a0[e];
-        acc[0][e & 1] = mfma44_rows<0, RG>(av, ws.b[u][e], acc[0][e & 1]);
-        if (RG >= 2) acc[1 % RG][e & 1] = mfma44_rows<1, RG>(av, ws.b[u][e], acc[1 % RG][e & 1]);
-        if (RG >= 4) {
-          acc[2 % RG][e & 1] = mfma44_rows<2, RG>(av, ws.b[u][e], acc[2 % RG][e & 1]);
-          acc[3 % RG][e & 1] = mfma44_rows<3, RG>(av, ws.b[u][e], acc[3 % RG][e & 1]);
-        }
+#pragma unroll
+        for (int g = 0; g < RG; ++g)
+          acc[g][e & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32((u & 1) ? a1[g][e] : a0[g][e], ws.b[u][e], acc[g][e & 1], 0, 0, 0);
         if (e == 1) __builtin_amdgcn_sched_barrier(0);   // keeps MFMAs on one accumulator 2*RG instructions apart
       }
       ws.b[u] = gload4(src + (size_t)u * 256 + lane4);
