@@ -39,7 +39,8 @@ def build():
     def one(u):
         out = os.path.join(OUT, u + ".s")
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value",
-                        "-Wno-cuda-compat", "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out, os.path.join(CSRC, u)],
+                        "-Wno-cuda-compat", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out,
+                        os.path.join(CSRC, u)],
                        check=True, stderr=subprocess.DEVNULL)
         return out
 
